@@ -1,0 +1,389 @@
+"""Synthetic configuration, weights and inputs for the AirV2X Where2Comm hot path.
+
+Nothing here comes from the reference at run time: the hypes dictionary below
+restates the *keys and values* the hot path consumes from
+``opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_where2com.yaml``
+(:114-119 voxel/range, :164-248 per-agent lidar blocks, :251-283 backbone /
+shrink / where2comm fusion, :286-297 heads) so that bench.py, the tests and
+smoke() can build the model on a box where ``/root/reference`` does not exist.
+
+The weight generator is deterministic per state_dict key (numpy PCG64 seeded by
+crc32(key)), so golden fixtures only need to store the key->shape manifest and
+the seed, not 29 MB of parameters.
+"""
+from __future__ import annotations
+
+import copy
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+AGENT_TYPES = ("vehicle", "rsu", "drone")
+TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_models"}
+
+# default AirV2X geometry (where2com yaml :114-119, :168-169, :198-199, :228-229)
+DEFAULT_RANGE = [-140.8, -40.0, -3.0, 140.8, 40.0, 1.0]
+DEFAULT_VOXEL = [0.4, 0.4, 4.0]
+
+
+def default_hypes(lidar_range=None, max_cav=(5, 5, 5)):
+    """Return a hypes dict with the same nesting the reference loader produces
+    (yaml_utils.py:224-299 ``load_airv2x_params``): ``model.args`` carries the
+    per-type ``grid_size`` and ``max_cav_num``; ``postprocess.anchor_args``
+    carries W/H/D and vw/vh/vd.
+
+    ``lidar_range`` lets the tests shrink the BEV grid (x/y extents must give a
+    grid divisible by 8); the z extents of every agent type stay the reference's.
+    """
+    r = list(DEFAULT_RANGE if lidar_range is None else lidar_range)
+    xy = lambda z0, z1: [r[0], r[1], z0, r[3], r[4], z1]
+    per_type = {
+        "vehicle": (xy(-3.0, 1.0), [0.4, 0.4, 4.0]),
+        "rsu": (xy(-30.0, 30.0), [0.4, 0.4, 60.0]),
+        "drone": (xy(-150.0, -6.0), [0.4, 0.4, 144.0]),
+    }
+    args = {
+        "ego_type": "vehicle",
+        "collaborators": list(AGENT_TYPES),
+        "active_sensors": ["lidar"],
+        "max_cav": {"vehicle": max_cav[0], "rsu": max_cav[1], "drone": max_cav[2]},
+        "max_cav_num": int(sum(max_cav)),
+        "device": "cuda",
+        "train": True,
+        "proj_first": True,
+        "supervise_single": False,
+        "backbone_fix": False,
+        "modality_fusion": {
+            "base_bev_backbone": {
+                "layer_nums": [3, 5, 8],
+                "layer_strides": [2, 2, 2],
+                "num_filters": [64, 128, 256],
+                "upsample_strides": [1, 2, 4],
+                "num_upsample_filter": [128, 128, 128],
+            },
+            "shrink_header": {
+                "use": True,
+                "input_dim": 384,
+                "dim": [256],
+                "kernal_size": [1],
+                "stride": [1],
+                "padding": [0],
+            },
+            "compression": 0,
+        },
+        "where2com_fusion": {
+            "fully": False,
+            "voxel_size": list(DEFAULT_VOXEL),
+            "downsample_rate": 4,
+            "in_channels": 256,
+            "multi_scale": True,
+            "layer_nums": [3, 5, 8],
+            "num_filters": [64, 128, 256],
+            "communication": {
+                "round": 1,
+                "threshold": 0.01,
+                "gaussian_smooth": {"k_size": 5, "c_sigma": 1.0},
+            },
+        },
+        "task": "det",
+        "head_dim": 256,
+        "outC": 256,
+        "anchor_number": 2,
+        "num_class": 7,
+        "cav_range": list(r),
+        "obj_head": True,
+    }
+    for t, (rng, vs) in per_type.items():
+        grid = np.round((np.array(rng[3:6]) - np.array(rng[0:3])) / np.array(vs)).astype(np.int64)
+        args[t] = {
+            "modalities": ["lidar"],
+            "lidar": {
+                "voxel_size": vs,
+                "lidar_range": rng,
+                "compression": 0,
+                "backbone_fix": False,
+                "pillar_vfe": {
+                    "use_norm": True,
+                    "with_distance": False,
+                    "use_absolute_xyz": True,
+                    "num_filters": [64],
+                },
+                "point_pillar_scatter": {"num_features": 64, "grid_size": grid},
+            },
+        }
+    vw, vh, vd = DEFAULT_VOXEL
+    hypes = {
+        "name": "airv2x_intermediate_where2comm",
+        "preprocess": {
+            "core_method": "SpVoxelPreprocessor",
+            "ego_type": "vehicle",
+            "args": {
+                "voxel_size": list(DEFAULT_VOXEL),
+                "max_points_per_voxel": 32,
+                "max_voxel_train": 32000,
+                "max_voxel_test": 70000,
+            },
+            "cav_lidar_range": list(r),
+        },
+        "postprocess": {
+            "core_method": "VoxelPostprocessor",
+            "ego_type": "vehicle",
+            "anchor_args": {
+                "cav_lidar_range": list(r),
+                "l": 3.9, "w": 1.6, "h": 1.56, "r": [0, 90],
+                "feature_stride": 2, "num": 2,
+                "vw": vw, "vh": vh, "vd": vd,
+                "W": int(np.ceil((r[3] - r[0]) / vw - 1e-9)),
+                "H": int(np.ceil((r[4] - r[1]) / vh - 1e-9)),
+                "D": int(np.ceil((r[5] - r[2]) / vd - 1e-9)),
+            },
+            "target_args": {"pos_threshold": 0.6, "neg_threshold": 0.45,
+                            "score_threshold": 0.2, "obj_threshold": 0.2},
+            "order": "hwl",
+            "max_num": 300,
+            "nms_thresh": 0.15,
+        },
+        "model": {"core_method": "airv2x_where2com", "args": args},
+    }
+    return hypes
+
+
+# --------------------------------------------------------------------------
+# state_dict manifest (SURVEY.md §8b key contract; verified against the
+# reference's own state_dict by tools/gen_golden.py)
+# --------------------------------------------------------------------------
+
+def _bn(prefix, c):
+    return [
+        (prefix + ".weight", (c,), "bn_w"),
+        (prefix + ".bias", (c,), "bn_b"),
+        (prefix + ".running_mean", (c,), "bn_m"),
+        (prefix + ".running_var", (c,), "bn_v"),
+        (prefix + ".num_batches_tracked", (), "count"),
+    ]
+
+
+def where2com_param_spec(args):
+    """Ordered (key, shape, kind) manifest of Airv2xWhere2com's state_dict.
+
+    Key layout follows the reference constructors: airv2x_base_model.py:36-99
+    (encoders), base_bev_backbone.py:38-105 (blocks/deblocks),
+    downsample_conv.py:17-31 (shrink), where2comm_fuse.py:58-62 (gaussian),
+    airv2x_where2com.py:59-69 (heads).
+    """
+    spec = []
+    for t in AGENT_TYPES:
+        if t not in args["collaborators"]:
+            continue
+        p = f"{TYPE_PREFIX[t]}.0.0.pfn_layers.0"
+        spec.append((p + ".linear.weight", (64, 10), "lin"))
+        spec += _bn(p + ".norm", 64)
+    bb = args["modality_fusion"]["base_bev_backbone"]
+    cin = 64
+    for i, (n, c) in enumerate(zip(bb["layer_nums"], bb["num_filters"])):
+        # Sequential: 0 ZeroPad, 1 conv, 2 bn, 3 relu, then (conv,bn,relu)*n
+        idx = 1
+        spec.append((f"backbone.blocks.{i}.{idx}.weight", (c, cin, 3, 3), "conv"))
+        spec += _bn(f"backbone.blocks.{i}.{idx + 1}", c)
+        idx += 3
+        for _ in range(n):
+            spec.append((f"backbone.blocks.{i}.{idx}.weight", (c, c, 3, 3), "conv"))
+            spec += _bn(f"backbone.blocks.{i}.{idx + 1}", c)
+            idx += 3
+        cin = c
+    for i, (s, cu) in enumerate(zip(bb["upsample_strides"], bb["num_upsample_filter"])):
+        c = bb["num_filters"][i]
+        spec.append((f"backbone.deblocks.{i}.0.weight", (c, cu, s, s), "deconv"))
+        spec += _bn(f"backbone.deblocks.{i}.1", cu)
+    sh = args["modality_fusion"]["shrink_header"]
+    cin = sh["input_dim"]
+    for li, (k, d) in enumerate(zip(sh["kernal_size"], sh["dim"])):
+        p = f"shrink_conv.layers.{li}.double_conv"
+        spec.append((p + ".0.weight", (d, cin, k, k), "conv"))
+        spec.append((p + ".0.bias", (d,), "bias"))
+        spec.append((p + ".2.weight", (d, d, 3, 3), "conv"))
+        spec.append((p + ".2.bias", (d,), "bias"))
+        cin = d
+    ks = args["where2com_fusion"]["communication"]["gaussian_smooth"]["k_size"]
+    spec.append(("fusion_net.naive_communication.gaussian_filter.weight", (1, 1, ks, ks), "gauss_w"))
+    spec.append(("fusion_net.naive_communication.gaussian_filter.bias", (1,), "gauss_b"))
+    A, C, outC = args["anchor_number"], args["num_class"], args["outC"]
+    spec.append(("cls_head.weight", (A * C, outC, 1, 1), "head"))
+    spec.append(("cls_head.bias", (A * C,), "cls_bias"))
+    spec.append(("reg_head.weight", (7 * A, outC, 1, 1), "head"))
+    spec.append(("reg_head.bias", (7 * A,), "bias"))
+    if args["obj_head"]:
+        spec.append(("obj_head.weight", (A, outC, 1, 1), "head"))
+        spec.append(("obj_head.bias", (A,), "obj_bias"))
+    return spec
+
+
+def _rng_for(key, seed):
+    return np.random.default_rng((zlib.crc32(key.encode()) + 7919 * int(seed)) & 0xFFFFFFFF)
+
+
+def synthetic_tensor(key, shape, kind, seed=0):
+    """Deterministic fp32 values for one parameter.
+
+    Convolutions use a He-uniform scale (var = 2/fan_in) so the signal keeps
+    O(1) magnitude through the 19-layer trunk in eval mode (PyTorch's default
+    init shrinks it by ~6x per layer, which would make every fp comparison
+    vacuous); BatchNorm statistics are randomised so that BN folding bugs show.
+    The cls/obj head biases are shifted negative so the where2comm threshold
+    (0.01) and the obj>0.2 gate both split the map instead of being all-ones.
+    """
+    g = _rng_for(key, seed)
+    shape = tuple(shape)
+    if kind == "count":
+        return np.zeros(shape, dtype=np.int64)
+    if kind in ("conv", "lin", "head", "deconv"):
+        if kind == "lin":
+            fan_in = shape[1]
+        elif kind == "deconv":  # ConvTranspose2d weight (Cin, Cout, k, k): each output sums Cin terms
+            fan_in = shape[0]
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        gain = 4.0 if kind == "head" else 2.0
+        b = np.sqrt(3.0 * gain / fan_in)
+        w = g.uniform(-b, b, size=shape).astype(np.float32)
+        if kind == "lin":
+            # PFN input columns: abs x,y,z,intensity, cluster xyz, centre xyz.  Absolute x/y reach
+            # +-140 m, so their weights are scaled down to keep pillar features O(1).
+            w *= 4.0 * np.asarray([0.01, 0.02, 0.3, 1.0, 1.0, 1.0, 0.5, 2.0, 2.0, 0.02], dtype=np.float32)
+        return w
+    if kind == "bn_w":
+        return g.uniform(0.7, 1.3, size=shape).astype(np.float32)
+    if kind == "bn_b":
+        return g.uniform(-0.1, 0.1, size=shape).astype(np.float32)
+    if kind == "bn_m":
+        return g.uniform(-0.1, 0.1, size=shape).astype(np.float32)
+    if kind == "bn_v":
+        return g.uniform(0.8, 1.2, size=shape).astype(np.float32)
+    if kind == "bias":
+        return g.uniform(-0.05, 0.05, size=shape).astype(np.float32)
+    if kind == "cls_bias":
+        return (g.uniform(-0.05, 0.05, size=shape) - 5.7).astype(np.float32)
+    if kind == "obj_bias":
+        return (g.uniform(-0.05, 0.05, size=shape) - 2.5).astype(np.float32)
+    if kind == "gauss_w":
+        k = shape[-1]
+        c = k // 2
+        x, y = np.mgrid[0 - c:k - c, 0 - c:k - c]
+        # the value the reference stores in its checkpoints (where2comm_fuse.py:66-81, sigma=1)
+        w = 1.0 / (2.0 * np.pi) * np.exp(-(np.square(x) + np.square(y)) / 2.0)
+        return w.astype(np.float32).reshape(shape)
+    if kind == "gauss_b":
+        return np.zeros(shape, dtype=np.float32)
+    raise KeyError(kind)
+
+
+def synthetic_state_dict(spec, seed=0):
+    sd = OrderedDict()
+    for key, shape, kind in spec:
+        sd[key] = torch.from_numpy(np.ascontiguousarray(synthetic_tensor(key, shape, kind, seed)))
+    return sd
+
+
+# --------------------------------------------------------------------------
+# synthetic point clouds and the model-input dictionary
+# --------------------------------------------------------------------------
+
+def agent_types_for(n_agents):
+    """types cycle vehicle, vehicle, rsu, drone, ... (ego = vehicle 0)."""
+    cyc = ("vehicle", "vehicle", "rsu", "drone")
+    return [cyc[i % 4] for i in range(n_agents)]
+
+
+def synthetic_cloud(agent_id, n_points=8192, lidar_range=None, seed=1234):
+    """Uniform cloud inside the (ego-type) range; BASELINE.md §3 / SURVEY §8(d)."""
+    r = DEFAULT_RANGE if lidar_range is None else lidar_range
+    g = np.random.default_rng(seed + agent_id)
+    pts = np.empty((n_points, 4), dtype=np.float32)
+    pts[:, 0] = g.uniform(r[0], r[3], n_points)
+    pts[:, 1] = g.uniform(r[1], r[4], n_points)
+    pts[:, 2] = g.uniform(r[2], r[5], n_points)
+    pts[:, 3] = g.uniform(0.0, 1.0, n_points)
+    return pts
+
+
+def clustered_cloud(agent_id, n_points=108000, lidar_range=None, seed=4321):
+    """'dense' distribution: most points in compact clusters so
+    that a few percent of the pillars overflow the 32-point cap."""
+    r = DEFAULT_RANGE if lidar_range is None else lidar_range
+    g = np.random.default_rng(seed + agent_id)
+    n_bg = n_points // 3
+    n_cl = n_points - n_bg
+    n_centres = 400
+    cx = g.uniform(r[0], r[3], n_centres)
+    cy = g.uniform(r[1], r[4], n_centres)
+    which = g.integers(0, n_centres, n_cl)
+    pts = np.empty((n_points, 4), dtype=np.float32)
+    pts[:n_cl, 0] = cx[which] + g.normal(0, 0.8, n_cl)
+    pts[:n_cl, 1] = cy[which] + g.normal(0, 0.8, n_cl)
+    pts[n_cl:, 0] = g.uniform(r[0], r[3], n_bg)
+    pts[n_cl:, 1] = g.uniform(r[1], r[4], n_bg)
+    pts[:, 2] = g.uniform(r[2], r[5], n_points)
+    pts[:, 3] = g.uniform(0.0, 1.0, n_points)
+    perm = g.permutation(n_points)
+    return pts[perm]
+
+
+def build_data_dict(voxelized, types, device="cpu", max_cav_num=15):
+    """Assemble the dict ``model.forward`` receives (SURVEY §8b input contract;
+    produced in the reference by intermediate_fusion_dataset.py:763-867).
+
+    ``voxelized``: list (one per agent, in frame order [veh.., rsu.., drone..])
+    of (voxels (M,32,4) f32, coords (M,3) i32 zyx, num_points (M,) i32).
+    B is 1 (one collaborative frame).
+    """
+    order = {t: i for i, t in enumerate(AGENT_TYPES)}
+    assert list(types) == sorted(types, key=lambda t: order[t]), "agents must be ordered veh, rsu, drone"
+    dd = {}
+    n_total = len(types)
+    for t in AGENT_TYPES:
+        idxs = [i for i, tt in enumerate(types) if tt == t]
+        if not idxs:
+            dd[t] = {"batch_merged_lidar_features_torch": None, "batch_merged_cam_inputs": None,
+                     "record_len": torch.zeros(1, dtype=torch.int32), "batch_idxs": []}
+            continue
+        feats, coords, nums = [], [], []
+        for k, i in enumerate(idxs):
+            v, c, n = voxelized[i]
+            feats.append(np.asarray(v, dtype=np.float32))
+            # prepend the agent's index *within its type* (sp_voxel_preprocessor.py:163-170)
+            coords.append(np.concatenate([np.full((c.shape[0], 1), k, dtype=np.int32),
+                                          np.asarray(c, dtype=np.int32)], axis=1))
+            nums.append(np.asarray(n, dtype=np.int32))
+        dd[t] = {
+            "batch_merged_lidar_features_torch": {
+                "voxel_features": torch.from_numpy(np.concatenate(feats, 0)).to(device),
+                "voxel_coords": torch.from_numpy(np.concatenate(coords, 0)).to(device),
+                "voxel_num_points": torch.from_numpy(np.concatenate(nums, 0)).to(device),
+            },
+            "batch_merged_cam_inputs": None,
+            "record_len": torch.tensor([len(idxs)], dtype=torch.int32),
+            "batch_idxs": [0],
+        }
+    L = max_cav_num
+    eye = torch.eye(4, dtype=torch.float32).view(1, 1, 1, 4, 4).repeat(1, L, L, 1, 1)
+    dd["record_len"] = torch.tensor([n_total], dtype=torch.int32)
+    dd["pairwise_t_matrix_collab"] = eye.clone().to(device)
+    dd["img_pairwise_t_matrix_collab"] = eye.to(device)
+    prior = torch.zeros(1, L, 3, dtype=torch.float32)
+    for i, t in enumerate(types):
+        prior[0, i, 2] = 0.0 if t == "vehicle" else 1.0
+    dd["prior_encoding"] = prior.to(device)
+    dd["spatial_correction_matrix"] = torch.eye(4, dtype=torch.float64).view(1, 1, 4, 4).repeat(1, L, 1, 1).to(device)
+    return dd
+
+
+def sort_types(types):
+    order = {t: i for i, t in enumerate(AGENT_TYPES)}
+    idx = sorted(range(len(types)), key=lambda i: (order[types[i]], i))
+    return idx, [types[i] for i in idx]
+
+
+def clone_hypes(h):
+    return copy.deepcopy(h)
