@@ -1,0 +1,74 @@
+"""ctypes binding of the C-ABI in include/airv2x_hip.h.
+
+There is NO CPU fallback: if libairv2x_hip.so is missing and cannot be built the import of
+this module raises, and every entry point raises on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_uint64, c_void_p
+
+from . import build as _build
+
+_LIB = None
+
+
+class ConvDesc(Structure):
+    """struct av2x_conv_desc (include/airv2x_hip.h)."""
+    _fields_ = [(n, c_int32) for n in (
+        "n", "h", "w", "cin", "in_ctot", "in_coff", "ho", "wo", "cout", "coutp", "out_ctot", "out_coff",
+        "ks", "stride", "pad", "relu", "mode", "up", "tile")]
+
+
+AV2X_CONV, AV2X_DECONV, AV2X_CONV_NCHW = 0, 1, 2
+
+# name -> (restype, argtypes); the exported-symbol test walks this table against the header
+SIGNATURES = {
+    "av2x_version": (c_int32, []),
+    "av2x_last_error": (c_char_p, []),
+    "av2x_pillar_vfe_scatter": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_fill_zero": (c_int32, [c_void_p, c_uint64, c_void_p]),
+    "av2x_conv2d": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_comm_mask": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_apply_mask": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_pixel_attn_fuse": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_count_nonzero": (c_int32, [c_void_p, c_uint64, c_void_p, c_void_p]),
+}
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load (building in-tree first if needed and hipcc exists).  Raises if unavailable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if build_if_missing:
+        try:
+            _build.build()
+        except Exception as e:  # a prebuilt .so that is merely older than a touched source is still usable
+            if not os.path.exists(path):
+                raise RuntimeError(f"libairv2x_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: the HIP extension is required (no CPU fallback)")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.av2x_version() != 1:
+        raise RuntimeError(f"ABI version mismatch: library {lib.av2x_version()}, binding 1")
+    _LIB = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().av2x_last_error()
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else 'unknown error'}")

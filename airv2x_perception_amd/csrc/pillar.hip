@@ -1,0 +1,140 @@
+// Pillar feature net (10 -> 64 linear + folded BatchNorm1d + ReLU + max over the pillar's points)
+// fused with the BEV scatter.  HBM-bound: 512 B of points + 16 B coords + 4 B count in, 256 B out
+// per pillar.  One wave64 per pillar: lanes 0..31 each load one point as a
+// single 16-byte load (a pillar = one 512-byte coalesced run), the augmented 10-vector of every
+// point is staged in LDS, then lane c produces output channel c and the wave writes one
+// contiguous 256-byte NHWC pixel of the canvas.
+#include "av2x_common.hpp"
+
+namespace {
+
+constexpr int kPts = 32;   // max_points_per_voxel (where2com yaml:115)
+constexpr int kFeat = 10;  // x y z i | cluster xyz | centre xyz (airv2x_pillar_vfe.py:140-148)
+constexpr int kOut = 64;
+constexpr int kLdF = 12;   // padded feature row (three 16-byte reads)
+
+__global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
+    const float4* __restrict__ vox, const int4* __restrict__ coords, const int* __restrict__ npts, int n_pillars,
+    const float* __restrict__ pfn_w, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+    float vx, float vy, float vz, float xoff, float yoff, float zoff, float* __restrict__ canvas, int agent0,
+    const int* __restrict__ slot_map, int n_agents, int ny, int nx) {
+    __shared__ __attribute__((aligned(16))) float feats[4][kPts][kLdF];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * 4;
+
+    // this lane's output channel: weights stay in registers for the whole grid-stride loop
+    float w[kFeat];
+#pragma unroll
+    for (int j = 0; j < kFeat; ++j) w[j] = pfn_w[lane * kFeat + j];
+    const float sc = bn_scale[lane], sh = bn_shift[lane];
+
+    for (int pil = blockIdx.x * 4 + wave; pil < n_pillars; pil += waves_total) {
+        const int4 c = coords[pil];  // agent, z, y, x
+        int num = npts[pil];
+        num = num < 0 ? 0 : (num > kPts ? kPts : num);
+        float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < kPts) pt = vox[(size_t)pil * kPts + lane];
+        // mean over the stored rows (zero padded rows add 0) / num_points   (:121-123)
+        float sx = pt.x, sy = pt.y, sz = pt.z;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            sx += __shfl_xor(sx, o);
+            sy += __shfl_xor(sy, o);
+            sz += __shfl_xor(sz, o);
+        }
+        const float fn = (float)npts[pil];
+        const float mx = sx / fn, my = sy / fn, mz = sz / fn;
+        if (lane < kPts) {
+            float f[kLdF];
+            const bool valid = lane < num;  // get_paddings_indicator (:95-103, :151-153)
+            // pillar centre: coord * voxel + offset, no FMA contraction (matches the two-op reference)
+            const float cx = __fadd_rn(__fmul_rn((float)c.w, vx), xoff);
+            const float cy = __fadd_rn(__fmul_rn((float)c.z, vy), yoff);
+            const float cz = __fadd_rn(__fmul_rn((float)c.y, vz), zoff);
+            f[0] = pt.x; f[1] = pt.y; f[2] = pt.z; f[3] = pt.w;
+            f[4] = pt.x - mx; f[5] = pt.y - my; f[6] = pt.z - mz;
+            f[7] = pt.x - cx; f[8] = pt.y - cy; f[9] = pt.z - cz;
+            f[10] = 0.f; f[11] = 0.f;
+#pragma unroll
+            for (int j = 0; j < kLdF; ++j) feats[wave][lane][j] = valid ? f[j] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are visible
+        // rows >= num are all-zero: linear(0) = 0 -> BN -> relu(shift); they take part in the max
+        // exactly as in the reference (features *= mask happens BEFORE the PFN, :153-155)
+        float best = (num < kPts) ? fmaxf(sh, 0.f) : 0.f;
+        for (int q = 0; q < num; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(&feats[wave][q][0]);
+            const float4 b = *reinterpret_cast<const float4*>(&feats[wave][q][4]);
+            const float4 d = *reinterpret_cast<const float4*>(&feats[wave][q][8]);
+            float acc = a.x * w[0];
+            acc = fmaf(a.y, w[1], acc); acc = fmaf(a.z, w[2], acc); acc = fmaf(a.w, w[3], acc);
+            acc = fmaf(b.x, w[4], acc); acc = fmaf(b.y, w[5], acc); acc = fmaf(b.z, w[6], acc);
+            acc = fmaf(b.w, w[7], acc); acc = fmaf(d.x, w[8], acc); acc = fmaf(d.y, w[9], acc);
+            best = fmaxf(best, fmaxf(fmaf(acc, sc, sh), 0.f));
+        }
+        if (c.x >= 0 && c.x < n_agents && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx) {
+            const int agent = slot_map ? slot_map[c.x] : agent0 + c.x;
+            // idx = z + y*nx + x with nz == 1 (point_pillar_scatter.py:59-61)
+            const size_t pix = ((size_t)agent * ny + c.z) * nx + c.w + c.y;
+            canvas[pix * kOut + lane] = best;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void count_nonzero_kernel(const float4* __restrict__ x, size_t n4, const float* __restrict__ tail, int ntail,
+                                     unsigned long long* result) {
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        c += (v.x != 0.f) + (v.y != 0.f) + (v.z != 0.f) + (v.w != 0.f);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) c += tail[threadIdx.x] != 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(result, part[0] + part[1] + part[2] + part[3]);
+}
+
+}  // namespace
+
+extern "C" int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_t* voxel_coords,
+                                       const int32_t* voxel_num_points, int32_t n_pillars, const float* pfn_w,
+                                       const float* bn_scale, const float* bn_shift, const float* geom, float* canvas,
+                                       int32_t canvas_agent0, const int32_t* slot_map, int32_t n_agents_type, int32_t ny,
+                                       int32_t nx, av2x_stream_t stream) {
+    if (n_pillars == 0) return 0;
+    if (!voxel_features || !voxel_coords || !voxel_num_points || !pfn_w || !bn_scale || !bn_shift || !geom || !canvas)
+        return av2x::fail("av2x_pillar_vfe_scatter: null argument");
+    if (n_pillars < 0 || ny <= 0 || nx <= 0) return av2x::fail("av2x_pillar_vfe_scatter: bad sizes");
+    int blocks = (n_pillars + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(pillar_vfe_scatter_kernel, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
+                       voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
+                       geom[4], geom[5], canvas, canvas_agent0, slot_map, n_agents_type, ny, nx);
+    return av2x::check_launch("pillar_vfe_scatter_kernel");
+}
+
+extern "C" int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream) {
+    if (bytes == 0) return 0;
+    if (!ptr) return av2x::fail("av2x_fill_zero: null pointer");
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, av2x::as_stream(stream));
+    if (e != hipSuccess) return av2x::fail("av2x_fill_zero: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int av2x_count_nonzero(const float* x, uint64_t n_elems, unsigned long long* result, av2x_stream_t stream) {
+    if (n_elems == 0) return 0;
+    if (!x || !result) return av2x::fail("av2x_count_nonzero: null argument");
+    if (reinterpret_cast<uintptr_t>(x) % 16) return av2x::fail("av2x_count_nonzero: pointer must be 16-byte aligned");
+    const size_t n4 = n_elems / 4;
+    const int ntail = (int)(n_elems - n4 * 4);
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(2048), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(x), n4, x + n4 * 4, ntail, result);
+    return av2x::check_launch("count_nonzero_kernel");
+}

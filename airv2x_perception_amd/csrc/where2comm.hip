@@ -1,0 +1,169 @@
+// Where2Comm fusion kernels (all HBM-bound):
+//   comm_conf_kernel   sigmoid(max_c psm)                       1.97 MB read / agent
+//   comm_mask_kernel   k x k smoothing conv + bias, > threshold, ego override, exact popcount
+//   apply_mask_kernel  x[n,h,w,:] *= mask[n,h,w]
+//   pixel_attn_kernel  per pixel softmax(x0 . xj / sqrt(C)) weighted sum over the agents
+//                      (ego row only), online softmax, 16 lanes per pixel, 16-byte loads
+#include "av2x_common.hpp"
+
+namespace {
+
+constexpr int kMaxAgents = 32;
+
+__global__ void comm_conf_kernel(const float* __restrict__ psm, int npix, int ctot, int c, float* __restrict__ conf) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float* row = psm + (size_t)p * ctot;
+    float m = row[0];
+    for (int j = 1; j < c; ++j) m = fmaxf(m, row[j]);
+    // sigmoid is monotonic: max_c sigmoid(x_c) == sigmoid(max_c x_c) bit for bit
+    conf[p] = 1.0f / (1.0f + expf(-m));
+}
+
+// one thread per output pixel; the conf map (140 KB / agent) is L2 resident
+__global__ void comm_mask_kernel(const float* __restrict__ conf, int n, int h, int w, const float* __restrict__ gw,
+                                 const float* __restrict__ gb, int k, float threshold,
+                                 const int* __restrict__ sample_of_agent, const int* __restrict__ is_ego,
+                                 float* __restrict__ smooth, float* __restrict__ mask, int* __restrict__ count) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int a = blockIdx.z;
+    int one = 0;
+    if (x < w) {
+        const int r = (k - 1) / 2;
+        const float* img = conf + (size_t)a * h * w;
+        float acc = 0.f;
+        for (int dy = 0; dy < k; ++dy) {
+            const int yy = y + dy - r;
+            if ((unsigned)yy >= (unsigned)h) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int xx = x + dx - r;
+                if ((unsigned)xx >= (unsigned)w) continue;
+                acc = fmaf(img[yy * w + xx], gw[dy * k + dx], acc);
+            }
+        }
+        acc += gb[0];
+        const size_t o = ((size_t)a * h + y) * w + x;
+        smooth[o] = acc;
+        one = (threshold > 0.f) ? (acc > threshold) : 1;
+        mask[o] = (one || is_ego[a]) ? 1.f : 0.f;
+    }
+    // exact integer count of transmitted cells BEFORE the ego override (where2comm_fuse.py:137)
+    const unsigned long long bal = __ballot(one);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&count[sample_of_agent[a]], __popcll(bal));
+}
+
+__global__ void apply_mask_kernel(float4* __restrict__ x, const float* __restrict__ mask, size_t n4, int c4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float m = mask[i / c4];
+        float4 v = x[i];
+        v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+        x[i] = v;
+    }
+}
+
+struct AgentPtrs {
+    const float* p[kMaxAgents];
+};
+
+// C = 64 * CK channels; a pixel is owned by 16 lanes, lane t holds channels {64*k + 4*t .. +3}
+template <int CK>
+__global__ __launch_bounds__(256) void pixel_attn_kernel(const AgentPtrs ap, int n_agents, int hw, float sqrt_c,
+                                                         float* __restrict__ out) {
+    const int t = threadIdx.x & 15;
+    const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (pix >= hw) return;  // whole 16-lane groups exit together
+    const size_t base = (size_t)pix * (64 * CK) + 4 * t;
+    float4 q[CK], o[CK];
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        q[k] = *reinterpret_cast<const float4*>(ap.p[0] + base + 64 * k);
+        o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mrun = -INFINITY, lrun = 0.f;
+    for (int j = 0; j < n_agents; ++j) {
+        float4 x[CK];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < CK; ++k) {
+            x[k] = (j == 0) ? q[k] : *reinterpret_cast<const float4*>(ap.p[j] + base + 64 * k);
+            dot = fmaf(q[k].x, x[k].x, dot);
+            dot = fmaf(q[k].y, x[k].y, dot);
+            dot = fmaf(q[k].z, x[k].z, dot);
+            dot = fmaf(q[k].w, x[k].w, dot);
+        }
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1) dot += __shfl_xor(dot, s, 16);
+        const float sc = dot / sqrt_c;  // score / np.sqrt(dim) (where2comm_fuse.py:42)
+        const float mnew = fmaxf(mrun, sc);
+        const float alpha = expf(mrun - mnew);  // exp(-inf) = 0 on the first agent
+        const float pj = expf(sc - mnew);
+        lrun = lrun * alpha + pj;
+#pragma unroll
+        for (int k = 0; k < CK; ++k) {
+            o[k].x = fmaf(pj, x[k].x, o[k].x * alpha);
+            o[k].y = fmaf(pj, x[k].y, o[k].y * alpha);
+            o[k].z = fmaf(pj, x[k].z, o[k].z * alpha);
+            o[k].w = fmaf(pj, x[k].w, o[k].w * alpha);
+        }
+        mrun = mnew;
+    }
+    const float inv = 1.0f / lrun;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        float4 r = o[k];
+        r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
+        *reinterpret_cast<float4*>(out + base + 64 * k) = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int av2x_comm_mask(const float* psm, int32_t n, int32_t h, int32_t w, int32_t ctot, int32_t c,
+                              const float* gauss_w, const float* gauss_b, int32_t k, float threshold,
+                              const int32_t* sample_of_agent, const int32_t* is_ego, float* conf, float* smooth,
+                              float* mask, int32_t* count, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!psm || !gauss_w || !gauss_b || !sample_of_agent || !is_ego || !conf || !smooth || !mask || !count)
+        return av2x::fail("av2x_comm_mask: null argument");
+    if (n < 0 || h <= 0 || w <= 0 || c <= 0 || c > ctot || k <= 0 || (k & 1) == 0)
+        return av2x::fail("av2x_comm_mask: bad sizes (n=%d h=%d w=%d c=%d ctot=%d k=%d)", n, h, w, c, ctot, k);
+    hipStream_t st = av2x::as_stream(stream);
+    const int npix = n * h * w;
+    hipLaunchKernelGGL(comm_conf_kernel, dim3((npix + 255) / 256), dim3(256), 0, st, psm, npix, ctot, c, conf);
+    if (int e = av2x::check_launch("comm_conf_kernel")) return e;
+    hipLaunchKernelGGL(comm_mask_kernel, dim3((w + 63) / 64, h, n), dim3(64), 0, st, conf, n, h, w, gauss_w, gauss_b, k,
+                       threshold, sample_of_agent, is_ego, smooth, mask, count);
+    return av2x::check_launch("comm_mask_kernel");
+}
+
+extern "C" int av2x_apply_mask(float* x, const float* mask, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!x || !mask) return av2x::fail("av2x_apply_mask: null argument");
+    if (c % 4) return av2x::fail("av2x_apply_mask: c=%d must be a multiple of 4", c);
+    const size_t n4 = (size_t)n * hw * (c / 4);
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<float4*>(x), mask, n4, c / 4);
+    return av2x::check_launch("apply_mask_kernel");
+}
+
+extern "C" int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents, int32_t hw, int32_t c, float* out,
+                                    av2x_stream_t stream) {
+    if (!agents || !out) return av2x::fail("av2x_pixel_attn_fuse: null argument");
+    if (n_agents < 1 || n_agents > kMaxAgents) return av2x::fail("av2x_pixel_attn_fuse: n_agents=%d outside [1,%d]", n_agents, kMaxAgents);
+    if (hw <= 0) return 0;
+    AgentPtrs ap;
+    for (int i = 0; i < kMaxAgents; ++i) ap.p[i] = i < n_agents ? agents[i] : nullptr;
+    const float inv = (float)sqrt((double)c);
+    const dim3 grid((hw + 15) / 16), block(256);
+    hipStream_t st = av2x::as_stream(stream);
+    switch (c) {
+        case 64: hipLaunchKernelGGL(pixel_attn_kernel<1>, grid, block, 0, st, ap, n_agents, hw, inv, out); break;
+        case 128: hipLaunchKernelGGL(pixel_attn_kernel<2>, grid, block, 0, st, ap, n_agents, hw, inv, out); break;
+        case 256: hipLaunchKernelGGL(pixel_attn_kernel<4>, grid, block, 0, st, ap, n_agents, hw, inv, out); break;
+        default: return av2x::fail("av2x_pixel_attn_fuse: c=%d unsupported (64/128/256)", c);
+    }
+    return av2x::check_launch("pixel_attn_kernel");
+}

@@ -1,0 +1,7 @@
+"""Host-side mirror of the reference's model interface for the Where2Comm-LiDAR hot path.
+
+Module / class names follow ``opencood.models`` so that the reference's name registry
+(tools/train_utils.py:288-325 ``create_model``) resolves them through the one-line binding
+shown in INTEGRATION.md.
+"""
+from .airv2x_where2com import Airv2xWhere2com  # noqa: F401

@@ -1,0 +1,96 @@
+"""``Airv2xWhere2com`` — drop-in for opencood/models/airv2x_where2com.py:19-227 (det task,
+LiDAR modality) whose forward runs entirely in libairv2x_hip.so.
+
+Same constructor argument (``hypes["model"]["args"]``), same ``forward(data_dict)`` input
+contract, same output keys (``psm``, ``rm``, ``obj``, ``mask``, ``com``,
+``comm_rate``), and the SAME ``state_dict`` keys/shapes as the reference (162 tensors) so
+released raw-state_dict checkpoints load with ``load_state_dict``.
+
+Inference only: parameters are plain tensors registered under the reference's names; the
+packed device copies used by the kernels are rebuilt lazily whenever a parameter changes
+(``load_state_dict``, ``.to()``, in-place edits bump the version counters).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..synth import where2com_param_spec
+from .engine import Where2ComEngine
+
+
+class _Node(nn.Module):
+    """Pure container used to reproduce the reference's module tree (and thus its keys)."""
+
+    def forward(self, *a, **k):  # pragma: no cover - containers are never called
+        raise RuntimeError("parameter container: the compute lives in libairv2x_hip.so")
+
+
+def _install(root, key, tensor, is_buffer):
+    parts = key.split(".")
+    node = root
+    for p in parts[:-1]:
+        nxt = node._modules.get(p)
+        if nxt is None:
+            nxt = _Node()
+            node.add_module(p, nxt)
+        node = nxt
+    if is_buffer:
+        node.register_buffer(parts[-1], tensor)
+    else:
+        node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class Airv2xWhere2com(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if args.get("task", "det") != "det":
+            raise NotImplementedError("only the det task is on the MI355X hot path (seg branch out of scope)")
+        for t in args["collaborators"]:
+            if args[t]["modalities"] != ["lidar"]:
+                raise NotImplementedError("LiDAR-only agents (camera lift is a later row of SURVEY §8f)")
+        self.args = args
+        self.collaborators = args["collaborators"]
+        self.active_sensors = args["active_sensors"]
+        self.multi_scale = args["where2com_fusion"]["multi_scale"]
+        self.outC = args["outC"]
+        for key, shape, kind in where2com_param_spec(args):
+            buf = kind in ("bn_m", "bn_v", "count")
+            if kind == "count":
+                t = torch.zeros(shape, dtype=torch.long)
+            elif kind == "bn_v" or kind == "bn_w":
+                t = torch.ones(shape)
+            else:
+                t = torch.zeros(shape)
+            _install(self, key, t, buf)
+        self._engine = None
+        self._packed_version = None
+        self.sync_comm_rate = True  # the reference returns a python int (airv2x_where2com.py:122)
+
+    # the reference freezes sub-modules with this (airv2x_where2com.py:80-115); all parameters
+    # here are already inference-only
+    def backbone_fix(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def _version(self):
+        return tuple(t._version for t in self.state_dict(keep_vars=True).values()) + (
+            next(iter(self.parameters())).device,)
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("Airv2xWhere2com (MI355X build) has no CPU path: move the module to the GPU (model.to('cuda'))")
+        ver = self._version()
+        if self._engine is None or self._engine.device != dev:
+            self._engine = Where2ComEngine(self.args, dev)
+            self._packed_version = None
+        if self._packed_version != ver:
+            self._engine.load_state_dict(self.state_dict())
+            self._packed_version = ver
+        return self._engine
+
+    def forward(self, data_dict):
+        if self.training:
+            raise NotImplementedError("training (backward + random top-k masks) is not built yet; call .eval()")
+        return self.engine().forward(data_dict, sync_comm_rate=self.sync_comm_rate)

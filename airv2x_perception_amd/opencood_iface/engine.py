@@ -1,0 +1,395 @@
+"""Host-side driver of the Where2Comm-LiDAR hot path on one MI355X.
+
+This is plumbing only: it owns device buffers (torch tensors used as raw HBM allocations),
+packs the weights once, and enqueues the C-ABI kernels of include/airv2x_hip.h on torch's
+current HIP stream.  All arithmetic happens inside libairv2x_hip.so; there is no CPU or
+ATen fallback for any stage.
+
+Schedule (eval mode; results identical to the reference's three backbone passes,
+airv2x_where2com.py:117-179 + where2comm_fuse.py:198-263):
+
+  canvas  <- pillar VFE + scatter                      (per agent type)
+  b0,b1,b2 <- backbone blocks on all agents            (unmasked pass, ONCE)
+  cat     <- deblocks(b0,b1,b2) written into one 384-channel NHWC buffer (no torch.cat)
+  psm_single <- cls_head(shrink(cat))
+  mask    <- communication(psm_single)                 (ego forced to 1)
+  b0     *= mask                                       (in place; ego unchanged)
+  b1m,b2m <- blocks 1,2 on the masked non-ego agents   (ego rows re-use b1,b2: mask == 1)
+  f_i     <- per-pixel attention over agents at scale i (ego row)
+  out     <- heads(shrink(deblocks(f_0,f_1,f_2)))
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_float, c_void_p
+
+import torch
+
+from .. import _lib
+from .packing import fold_bn, pack_conv_weight, pack_deconv_weight
+
+AGENT_TYPES = ("vehicle", "rsu", "drone")
+TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_models"}
+
+
+class ConvLayer:
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up")
+
+    def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.cin, self.cout, self.coutp = cin, cout, coutp
+        self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+class Where2ComEngine:
+    def __init__(self, args, device="cuda"):
+        self.args = args
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Where2ComEngine runs on a HIP device only (no CPU path exists)")
+        self.lib = _lib.load()
+        self.bb = args["modality_fusion"]["base_bev_backbone"]
+        self.sh = args["modality_fusion"]["shrink_header"]
+        self.fcfg = args["where2com_fusion"]
+        if not self.fcfg["multi_scale"]:
+            raise NotImplementedError("only the multi_scale Where2comm variant (the shipped AirV2X config) is built")
+        if args["modality_fusion"].get("compression", 0):
+            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        self.A, self.C = args["anchor_number"], args["num_class"]
+        self.ws = {}
+        self.weights_ready = False
+        self.conv_tile = 0
+        self._desc = _lib.ConvDesc()
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd):
+        dev = self.device
+        up = lambda t: t.to(dev).contiguous() if t is not None else None
+        self.pfn = {}
+        for t in AGENT_TYPES:
+            if t not in self.args["collaborators"] or "lidar" not in self.args[t]["modalities"]:
+                continue
+            p = TYPE_PREFIX[t] + ".0.0.pfn_layers.0"
+            sc, sh = fold_bn(sd, p + ".norm")
+            cfg = self.args[t]["lidar"]
+            vs, rng = cfg["voxel_size"], cfg["lidar_range"]
+            geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
+            self.pfn[t] = (up(sd[p + ".linear.weight"].detach().float()), up(sc), up(sh), geom)
+        self.blocks, self.deblocks = [], []
+        cin = 64
+        for i, (n, c, s) in enumerate(zip(self.bb["layer_nums"], self.bb["num_filters"], self.bb["layer_strides"])):
+            layers = []
+            idx = 1
+            for li in range(n + 1):
+                w, coutp = pack_conv_weight(sd[f"backbone.blocks.{i}.{idx}.weight"])
+                sc, sh = fold_bn(sd, f"backbone.blocks.{i}.{idx + 1}")
+                layers.append(ConvLayer(up(w), up(sc), up(sh), cin if li == 0 else c, c, coutp, 3,
+                                        s if li == 0 else 1, 1, 1))
+                idx += 3
+            self.blocks.append(layers)
+            cin = c
+        for i, (s, cu) in enumerate(zip(self.bb["upsample_strides"], self.bb["num_upsample_filter"])):
+            w, ncol = pack_deconv_weight(sd[f"backbone.deblocks.{i}.0.weight"])
+            sc, sh = fold_bn(sd, f"backbone.deblocks.{i}.1")
+            self.deblocks.append(ConvLayer(up(w), up(sc), up(sh), self.bb["num_filters"][i], cu, ncol, 1, 1, 0, 1,
+                                           _lib.AV2X_DECONV, s))
+        self.cat_c = sum(self.bb["num_upsample_filter"])
+        self.shrink = []
+        cin = self.sh["input_dim"]
+        if self.sh["use"]:
+            for li, (k, d, s, pd) in enumerate(zip(self.sh["kernal_size"], self.sh["dim"], self.sh["stride"], self.sh["padding"])):
+                if s != 1:
+                    raise NotImplementedError("shrink_header stride != 1")
+                p = f"shrink_conv.layers.{li}.double_conv"
+                w0, cp0 = pack_conv_weight(sd[p + ".0.weight"])
+                w1, cp1 = pack_conv_weight(sd[p + ".2.weight"])
+                self.shrink.append(ConvLayer(up(w0), None, up(sd[p + ".0.bias"].detach().float()), cin, d, cp0, k, 1, pd, 1))
+                self.shrink.append(ConvLayer(up(w1), None, up(sd[p + ".2.bias"].detach().float()), d, d, cp1, 3, 1, 1, 1))
+                cin = d
+        self.feat_c = cin
+        # cls head alone (per-agent confidence) and the three heads fused into one 30-column GEMM
+        wc, cpc = pack_conv_weight(sd["cls_head.weight"])
+        self.cls_single = ConvLayer(up(wc), None, up(sd["cls_head.bias"].detach().float()), cin, self.A * self.C, cpc, 1, 1, 0, 0)
+        names = ["cls_head", "reg_head"] + (["obj_head"] if self.args["obj_head"] else [])
+        wcat = torch.cat([sd[n + ".weight"].detach().float().cpu() for n in names], 0)
+        bcat = torch.cat([sd[n + ".bias"].detach().float().cpu() for n in names], 0)
+        wh, cph = pack_conv_weight(wcat)
+        self.head_splits = [sd[n + ".weight"].shape[0] for n in names]
+        self.heads = ConvLayer(up(wh), None, up(bcat), cin, wcat.shape[0], cph, 1, 1, 0, 0, _lib.AV2X_CONV_NCHW)
+        g = "fusion_net.naive_communication.gaussian_filter"
+        comm = self.fcfg["communication"]
+        if "gaussian_smooth" in comm:
+            self.gauss_w = up(sd[g + ".weight"].detach().float().reshape(-1))
+            self.gauss_b = up(sd[g + ".bias"].detach().float().reshape(-1))
+            self.gauss_k = int(sd[g + ".weight"].shape[-1])
+        else:  # identity smoothing
+            self.gauss_w = torch.ones(1, device=dev)
+            self.gauss_b = torch.zeros(1, device=dev)
+            self.gauss_k = 1
+        self.threshold = float(comm["threshold"] or 0.0)
+        self.weights_ready = True
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self.ws.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.ws[key] = t
+        return t
+
+    @staticmethod
+    def stream():
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------ kernels
+    def conv(self, L, x, n, h, w, out, in_ctot=None, in_coff=0, out_ctot=None, out_coff=0):
+        """x: NHWC buffer holding >= n images of (h, w, in_ctot); returns (ho, wo)."""
+        d = self._desc
+        d.n, d.h, d.w, d.cin = n, h, w, L.cin
+        d.in_ctot = in_ctot if in_ctot is not None else L.cin
+        d.in_coff = in_coff
+        if L.mode == _lib.AV2X_DECONV:
+            ho, wo = h * L.up, w * L.up
+            d.ho, d.wo = h, w
+        else:
+            ho = (h + 2 * L.pad - L.ks) // L.stride + 1
+            wo = (w + 2 * L.pad - L.ks) // L.stride + 1
+            d.ho, d.wo = ho, wo
+        d.cout, d.coutp = L.cout, L.coutp
+        d.out_ctot = out_ctot if out_ctot is not None else L.cout
+        d.out_coff = out_coff
+        d.ks, d.stride, d.pad, d.relu, d.mode, d.up = L.ks, L.stride, L.pad, L.relu, L.mode, L.up
+        d.tile = self.conv_tile
+        _lib.check(self.lib.av2x_conv2d(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(out),
+                                        self.stream()), "av2x_conv2d")
+        return ho, wo
+
+    def run_block(self, i, x, n, h, w, tag):
+        """backbone.blocks[i] on n images; returns (buffer, ho, wo)."""
+        layers = self.blocks[i]
+        c = layers[0].cout
+        ho = (h + 2 - 3) // layers[0].stride + 1
+        wo = (w + 2 - 3) // layers[0].stride + 1
+        ping = self.buf(f"blk{i}_ping_{tag}", (n, ho, wo, c))
+        pong = self.buf(f"blk{i}_pong_{tag}", (n, ho, wo, c))
+        out = self.buf(f"blk{i}_out_{tag}", (n, ho, wo, c))
+        cur, ch, cw = x, h, w
+        for li, L in enumerate(layers):
+            dst = out if li == len(layers) - 1 else (ping if li % 2 == 0 else pong)
+            self.conv(L, cur, n, ch, cw, dst)
+            cur, ch, cw = dst, ho, wo
+        return out, ho, wo
+
+    def run_deblocks(self, feats, n, cat):
+        """feats: [(buffer, h, w)] per level; writes the channel-concatenated map into cat (n,H,W,384)."""
+        coff = 0
+        for i, (x, h, w) in enumerate(feats):
+            L = self.deblocks[i]
+            self.conv(L, x, n, h, w, cat, out_ctot=self.cat_c, out_coff=coff)
+            coff += L.cout
+
+    def run_shrink(self, x, n, h, w, tag):
+        cur, cin_tot = x, self.cat_c
+        for li, L in enumerate(self.shrink):
+            dst = self.buf(f"shrink{li}_{tag}", (n, h, w, L.cout))
+            self.conv(L, cur, n, h, w, dst, in_ctot=cin_tot)
+            cur, cin_tot = dst, L.cout
+        return cur
+
+    # ------------------------------------------------------------------ stages
+    def frame_layout(self, data_dict):
+        """Agent order of the reference's repack_batch (airv2x_base_model.py:209-236):
+        sample-major, then vehicle/rsu/drone, then index inside the type.
+        Returns (record_len list, {type: slot list for that type's agents in batch order})."""
+        per_type = {}
+        B = 0
+        for t in AGENT_TYPES:
+            d = data_dict.get(t)
+            if t not in self.args["collaborators"] or d is None or len(d["batch_idxs"]) == 0:
+                continue
+            rl = d["record_len"]
+            rl = [int(v) for v in (rl.tolist() if hasattr(rl, "tolist") else rl)]
+            per_type[t] = rl
+            B = max(B, len(rl))
+        record_len, slots = [0] * B, {t: [] for t in per_type}
+        nxt = 0
+        for b in range(B):
+            for t in AGENT_TYPES:
+                if t in per_type and b < len(per_type[t]) and b in data_dict[t]["batch_idxs"]:
+                    k = per_type[t][b]
+                    slots[t] += list(range(nxt, nxt + k))
+                    nxt += k
+                    record_len[b] += k
+        return record_len, slots
+
+    def encode(self, data_dict, record_len, slots):
+        n_total = sum(record_len)
+        g = [int(v) for v in self.args[next(iter(slots))]["lidar"]["point_pillar_scatter"]["grid_size"]]
+        nx, ny = g[0], g[1]
+        canvas = self.buf("canvas", (n_total, ny, nx, 64))
+        st = self.stream()
+        _lib.check(self.lib.av2x_fill_zero(_ptr(canvas), canvas.numel() * 4, st), "av2x_fill_zero")
+        for t, sl in slots.items():
+            lid = data_dict[t]["batch_merged_lidar_features_torch"]
+            vf, vc, vn = lid["voxel_features"], lid["voxel_coords"], lid["voxel_num_points"]
+            if vf.device != self.device:
+                vf, vc, vn = vf.to(self.device), vc.to(self.device), vn.to(self.device)
+            vf = vf.contiguous().float()
+            vc = vc.contiguous().to(torch.int32)
+            vn = vn.contiguous().to(torch.int32)
+            if vf.shape[1:] != (32, 4):
+                raise ValueError(f"voxel_features must be (M,32,4), got {tuple(vf.shape)}")
+            w, sc, sh, geom = self.pfn[t]
+            contiguous = sl == list(range(sl[0], sl[0] + len(sl)))
+            smap = None
+            if not contiguous:
+                smap = torch.tensor(sl, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.av2x_pillar_vfe_scatter(_ptr(vf), _ptr(vc), _ptr(vn), vf.shape[0], _ptr(w), _ptr(sc),
+                                                        _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), sl[0],
+                                                        _ptr(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter")
+        return canvas, ny, nx
+
+    def trunk(self, canvas, n, ny, nx, tag="all"):
+        """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""
+        feats = []
+        x, h, w = canvas, ny, nx
+        for i in range(len(self.blocks)):
+            x, h, w = self.run_block(i, x, n, h, w, tag)
+            feats.append((x, h, w))
+        H, W = feats[0][1] * self.deblocks[0].up, feats[0][2] * self.deblocks[0].up
+        cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c))
+        self.run_deblocks(feats, n, cat)
+        s = self.run_shrink(cat, n, H, W, tag) if self.shrink else cat
+        return feats, s, H, W
+
+    def comm_mask(self, psm_single, n, H, W, record_len):
+        B = len(record_len)
+        key = ("layout", tuple(record_len))
+        lay = self.ws.get(key)
+        if lay is None:
+            samp, ego = [], []
+            for b, k in enumerate(record_len):
+                samp += [b] * k
+                ego += [1] + [0] * (k - 1) if k > 0 else []
+            lay = (torch.tensor(samp, dtype=torch.int32, device=self.device),
+                   torch.tensor(ego, dtype=torch.int32, device=self.device),
+                   torch.tensor(record_len, dtype=torch.float32, device=self.device))
+            self.ws[key] = lay
+        conf = self.buf("comm_conf", (n, H, W))
+        smooth = self.buf("comm_smooth", (n, H, W))
+        mask = self.buf("comm_mask", (n, H, W))
+        count = self.buf("comm_count", (B,), torch.int32)
+        st = self.stream()
+        _lib.check(self.lib.av2x_fill_zero(_ptr(count), B * 4, st), "av2x_fill_zero")
+        _lib.check(self.lib.av2x_comm_mask(_ptr(psm_single), n, H, W, psm_single.shape[-1], self.A * self.C,
+                                           _ptr(self.gauss_w), _ptr(self.gauss_b), self.gauss_k, self.threshold,
+                                           _ptr(lay[0]), _ptr(lay[1]), _ptr(conf), _ptr(smooth), _ptr(mask),
+                                           _ptr(count), st), "av2x_comm_mask")
+        return mask, count, smooth, lay[2]
+
+    def attn(self, ptrs, hw, c, out):
+        arr = (c_void_p * len(ptrs))(*ptrs)
+        _lib.check(self.lib.av2x_pixel_attn_fuse(arr, len(ptrs), hw, c, _ptr(out), self.stream()),
+                   "av2x_pixel_attn_fuse")
+
+    # ------------------------------------------------------------------ full forward
+    @torch.no_grad()
+    def forward(self, data_dict, trace=None, sync_comm_rate=False):
+        if not self.weights_ready:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        record_len, slots = self.frame_layout(data_dict)
+        B, n = len(record_len), sum(record_len)
+        if n == 0:
+            raise ValueError("empty frame: no agent has lidar input")
+        canvas, ny, nx = self.encode(data_dict, record_len, slots)
+        st = self.stream()
+        nz = self.buf("nonzero", (1,), torch.int64)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+
+        feats, s, H, W = self.trunk(canvas, n, ny, nx)
+        psm_single = self.buf("psm_single", (n, H, W, self.A * self.C))
+        self.conv(self.cls_single, s, n, H, W, psm_single)
+        if trace is not None:
+            trace["spatial_features"] = canvas.permute(0, 3, 1, 2).clone()
+            for i, (x, _, _) in enumerate(feats):
+                trace[f"block{i}"] = x.permute(0, 3, 1, 2).clone()
+            trace["spatial_features_2d"] = self.buf("cat_all", (n, H, W, self.cat_c)).permute(0, 3, 1, 2).clone()
+            trace["shrink"] = s.permute(0, 3, 1, 2).clone()
+            trace["psm_single"] = psm_single.permute(0, 3, 1, 2).clone()
+
+        (b0, h0, w0), (b1, h1, w1), (b2, h2, w2) = feats
+        if self.fcfg["fully"]:
+            com = torch.tensor(1, device=self.device)
+            mask = None
+        else:
+            if (h0, w0) != (H, W):
+                raise NotImplementedError("mask/feature size mismatch (bilinear resize branch, where2comm_fuse.py:230) "
+                                          "is never taken by AirV2X configs")
+            mask, count, smooth, rl = self.comm_mask(psm_single, n, H, W, record_len)
+            com = (count.to(torch.float32) / (rl * (H * W))).sum() / B  # where2comm_fuse.py:137,147
+            _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask")
+            if trace is not None:
+                trace["comm_mask"] = mask.unsqueeze(1).clone()
+                trace["comm_map"] = smooth.unsqueeze(1).clone()
+
+        # masked pass through blocks 1, 2.  B == 1: agent 0 is the ego (mask == 1) and is skipped.
+        skip_ego = (B == 1) and mask is not None
+        first = 1 if skip_ego else 0
+        nm = n - first
+        if mask is None:
+            m1, m2 = b1, b2
+            first, nm = 0, n
+        else:
+            if nm > 0:
+                x0m = b0[first:]
+                m1, _, _ = self.run_block(1, x0m, nm, h0, w0, "masked")
+                m2, _, _ = self.run_block(2, m1, nm, h1, w1, "masked")
+            else:
+                m1 = m2 = None
+
+        levels = [(b0, None, h0, w0), (b1, m1, h1, w1), (b2, m2, h2, w2)]
+        fused = []
+        for i, (unm, msk, h, w) in enumerate(levels):
+            c = unm.shape[-1]
+            f = self.buf(f"fused{i}", (B, h, w, c))
+            a0 = 0
+            for b, k in enumerate(record_len):
+                ptrs = []
+                for j in range(a0, a0 + k):
+                    if i == 0 or mask is None:
+                        ptrs.append(unm[j].data_ptr())
+                    elif skip_ego:
+                        ptrs.append(unm[j].data_ptr() if j == 0 else msk[j - 1].data_ptr())
+                    else:
+                        ptrs.append(msk[j].data_ptr())
+                self.attn(ptrs, h * w, c, f[b])
+                a0 += k
+            fused.append((f, h, w))
+            if trace is not None:
+                trace[f"fused{i}"] = f.permute(0, 3, 1, 2).clone()
+        catf = self.buf("cat_fused", (B, H, W, self.cat_c))
+        self.run_deblocks(fused, B, catf)
+        fs = self.run_shrink(catf, B, H, W, "fused") if self.shrink else catf
+        nh = self.heads.cout
+        heads = torch.empty((B, nh, H, W), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fs, B, H, W, heads)
+        if trace is not None:
+            trace["fused_2d"] = catf.permute(0, 3, 1, 2).clone()
+            trace["fused_shrink"] = fs.permute(0, 3, 1, 2).clone()
+        outs = torch.split(heads, self.head_splits, dim=1)
+        if B > 1:
+            outs = [o.contiguous() for o in outs]
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        comm_rate = nz[0]
+        if sync_comm_rate:
+            comm_rate = int(comm_rate.item())
+        out.update({"mask": 0, "com": com, "comm_rate": comm_rate})
+        return out

@@ -1,0 +1,50 @@
+"""Host-side weight preparation for the C-ABI kernels (done once per state_dict).
+
+* eval-mode BatchNorm (eps 1e-3 everywhere on the path: airv2x_pillar_vfe.py:21,
+  base_bev_backbone.py:52,65,83) is folded into a per-channel (scale, shift) pair computed in
+  float64 and rounded once to fp32;
+* convolution weights are re-laid out for the implicit-GEMM kernel:
+  ``[tap][cin/4][coutp][4]`` (include/airv2x_hip.h, av2x_conv2d).
+"""
+from __future__ import annotations
+
+import torch
+
+BN_EPS = 1e-3
+
+
+def fold_bn(sd, prefix, eps=BN_EPS):
+    w = sd[prefix + ".weight"].detach().double().cpu()
+    b = sd[prefix + ".bias"].detach().double().cpu()
+    m = sd[prefix + ".running_mean"].detach().double().cpu()
+    v = sd[prefix + ".running_var"].detach().double().cpu()
+    scale = w / torch.sqrt(v + eps)
+    shift = b - m * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pack_conv_weight(w):
+    """(Cout, Cin, k, k) -> (k*k, Cin/4, CoutP, 4) fp32 contiguous, CoutP = Cout rounded up to 32."""
+    w = w.detach().float().cpu()
+    cout, cin, kh, kw = w.shape
+    assert cin % 4 == 0
+    coutp = round_up(cout, 32)
+    t = w.permute(2, 3, 1, 0).reshape(kh * kw, cin // 4, 4, cout).permute(0, 1, 3, 2)
+    out = torch.zeros(kh * kw, cin // 4, coutp, 4, dtype=torch.float32)
+    out[:, :, :cout, :] = t
+    return out.contiguous(), coutp
+
+
+def pack_deconv_weight(w):
+    """ConvTranspose2d weight (Cin, Cout, s, s), kernel == stride ->
+    (1, Cin/4, s*s*Cout, 4); GEMM column n = (i*s + j)*Cout + co."""
+    w = w.detach().float().cpu()
+    cin, cout, s, s2 = w.shape
+    assert s == s2 and cin % 4 == 0 and cout % 32 == 0
+    ncol = s * s * cout
+    t = w.permute(0, 2, 3, 1).reshape(cin // 4, 4, ncol).permute(0, 2, 1)
+    return t.reshape(1, cin // 4, ncol, 4).contiguous(), ncol

@@ -1,0 +1,135 @@
+/*
+ * airv2x_hip.h — C-ABI of the MI355X (gfx950) hot-path library `libairv2x_hip.so`.
+ *
+ * The reference (taco-group/AirV2X-Perception, an OpenCOOD fork) has NO C/FFI plugin
+ * boundary: its hot path is Python calling ATen ops.  This header is therefore the
+ * build-side definition of the boundary: each entry point replaces the
+ * ATen call sequence of one reference function, cited as `file:line` relative to
+ * /root/reference/opencood.  The Python host mirror (airv2x_perception_amd/opencood_iface)
+ * binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP) unless the comment says HOST; tensors are dense
+ *     fp32 / int32;
+ *   - BEV activations are NHWC ("channels-last": index ((n*H + h)*W + w)*ctot + c);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on
+ *     it, nothing allocates, nothing synchronises, every function is re-entrant;
+ *   - return value: 0 = ok, non-zero = error (message via av2x_last_error(), thread-local).
+ */
+#ifndef AIRV2X_HIP_H
+#define AIRV2X_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AV2X_ABI_VERSION 1
+
+typedef void* av2x_stream_t;
+
+int av2x_version(void);
+const char* av2x_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Pillar feature net + BEV scatter.
+ * Replaces PillarVFE.forward + PFNLayer.forward
+ *   (models/common_modules/airv2x_pillar_vfe.py:105-160, :27-45) and
+ * PointPillarScatter.forward (models/common_modules/point_pillar_scatter.py:43-80).
+ *   voxel_features (M,32,4) f32 zero padded; voxel_coords (M,4) i32 [agent,z,y,x];
+ *   voxel_num_points (M,) i32; pfn_w (64,10) row-major (linear.weight);
+ *   bn_scale/bn_shift (64,): eval BatchNorm1d folded to y = x*scale + shift;
+ *   geom: HOST array of 6 floats {voxel_x, voxel_y, voxel_z, x_offset, y_offset, z_offset} of the agent TYPE
+ *   (airv2x_pillar_vfe.py:84-89);
+ *   canvas (n_agents, ny, nx, 64) NHWC — MUST be zero-filled by the caller beforehand
+ *   (av2x_fill_zero); agent k of this type (voxel_coords[:,0] == k) is written to canvas slot
+ *   slot_map[k] (device, n_agents_type entries) or, if slot_map is NULL, canvas_agent0 + k.
+ * ------------------------------------------------------------------------------------ */
+int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_t* voxel_coords,
+                            const int32_t* voxel_num_points, int32_t n_pillars,
+                            const float* pfn_w, const float* bn_scale, const float* bn_shift,
+                            const float* geom, float* canvas, int32_t canvas_agent0,
+                            const int32_t* slot_map, int32_t n_agents_type, int32_t ny, int32_t nx,
+                            av2x_stream_t stream);
+
+int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), fused per-channel
+ * affine (+bias / folded BatchNorm2d) and optional ReLU.
+ * Replaces every Conv2d/ConvTranspose2d(+BatchNorm2d)(+ReLU) on the path:
+ *   BaseBEVBackbone blocks/deblocks (models/common_modules/base_bev_backbone.py:41-105),
+ *   DoubleConv (models/common_modules/downsample_conv.py:17-31),
+ *   NaiveCompressor (models/common_modules/naive_compress.py:12-36),
+ *   cls/reg/obj heads (models/airv2x_where2com.py:60-69).
+ *
+ * mode AV2X_CONV      : out[n,ho,wo, out_coff+co] NHWC, ks in {1,3}, any stride/pad.
+ * mode AV2X_DECONV    : ConvTranspose2d with kernel == stride == up (no overlap):
+ *                       out[n, ho*up+i, wo*up+j, out_coff+co]; (h,w) here are the INPUT dims.
+ * mode AV2X_CONV_NCHW : as AV2X_CONV but the result is stored NCHW (out[n,co,ho,wo]); used
+ *                       for the detection heads whose consumers expect NCHW.
+ *
+ * Weight layout `w` (packed once on the host, see opencood_iface/packing.py):
+ *   [tap = kh*ks+kw][cin/4][coutp][4]  where element [t][q][n][j] = W[cout=n][cin=4q+j][kh][kw]
+ *   (for AV2X_DECONV the GEMM column n = (i*up+j)*cout + co and W = weight[cin][co][i][j]);
+ *   coutp = GEMM columns padded with zeros to a multiple of 32; cin % 32 == 0.
+ * scale/shift: (cout,) applied as y = acc*scale + shift (scale may be NULL = 1).
+ * ------------------------------------------------------------------------------------ */
+enum { AV2X_CONV = 0, AV2X_DECONV = 1, AV2X_CONV_NCHW = 2 };
+
+typedef struct av2x_conv_desc {
+    int32_t n, h, w, cin;      /* input tensor (NHWC) and channels consumed             */
+    int32_t in_ctot, in_coff;  /* channel stride of an input pixel, first channel used   */
+    int32_t ho, wo, cout;      /* output spatial dims (DECONV: unused, = h*up, w*up)     */
+    int32_t coutp;             /* padded GEMM column count of `w`                        */
+    int32_t out_ctot, out_coff;/* channel stride / offset of the output (concat support) */
+    int32_t ks, stride, pad;   /* square kernel                                           */
+    int32_t relu;              /* 1 = ReLU after the affine                               */
+    int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
+    int32_t up;                /* DECONV: kernel == stride                                */
+    int32_t tile;              /* 0 = auto; else BM<<16 | BN (tests / tuning)             */
+} av2x_conv_desc;
+
+int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
+                const float* shift, float* out, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Where2Comm communication mask.  Replaces Communication.forward, eval branch
+ * (models/where2comm_modules/where2comm_fuse.py:83-149).
+ *   psm (n,h,w,ctot) NHWC, first `c` channels = anchor*class logits of each agent;
+ *   conf (n,h,w) scratch: sigmoid(max_c psm);  gauss_w (k,k), gauss_b (1,): the
+ *   `gaussian_filter` Conv2d parameters (state_dict, where2comm_fuse.py:58-62);
+ *   sample_of_agent (n,) i32: sample index b of every agent, is_ego (n,) i32: 1 for the
+ *   first agent of each sample (mask forced to 1, :141);
+ *   mask (n,h,w) f32 in {0,1};  count (B,) i32 += number of ones BEFORE the ego override
+ *   (caller zero-fills; rate_b = count_b / (L_b*h*w), :137).
+ *   threshold <= 0 means "no threshold": mask = 1 everywhere (:132-135).
+ * ------------------------------------------------------------------------------------ */
+int av2x_comm_mask(const float* psm, int32_t n, int32_t h, int32_t w, int32_t ctot, int32_t c,
+                   const float* gauss_w, const float* gauss_b, int32_t k, float threshold,
+                   const int32_t* sample_of_agent, const int32_t* is_ego,
+                   float* conf, float* smooth, float* mask, int32_t* count, av2x_stream_t stream);
+
+/* x[n,h,w,c] *= mask[n,h,w]  (where2comm_fuse.py:237) — in place, NHWC. */
+int av2x_apply_mask(float* x, const float* mask, int32_t n, int32_t hw, int32_t c,
+                    av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-pixel scaled-dot-product attention across the agents of one sample, ego row only.
+ * Replaces AttentionFusion.forward + ScaledDotProductAttention.forward
+ * (where2comm_fuse.py:152-164, :41-45):  out[p,:] = sum_j softmax_j(x0.xj/sqrt(C)) xj.
+ *   agents: HOST array of n_agents DEVICE pointers, each to an (hw, c) NHWC map (ego first);
+ *   out (hw, c).  c % 64 == 0, n_agents >= 1.
+ * ------------------------------------------------------------------------------------ */
+int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents, int32_t hw, int32_t c,
+                         float* out, av2x_stream_t stream);
+
+/* count_nonzero over a dense fp32 buffer (airv2x_where2com.py:122); result (1,) u64 += */
+int av2x_count_nonzero(const float* x, uint64_t n_elems, unsigned long long* result,
+                       av2x_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRV2X_HIP_H */

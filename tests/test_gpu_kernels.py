@@ -1,0 +1,238 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle (run with -m gpu on an MI355X).
+
+Tolerances (fp32 everywhere; the kernels and ATen's CPU kernels only differ in summation
+order and in folding BatchNorm into one multiply-add):
+    |hip - oracle| <= 1e-4 * |oracle| + 1e-4 * rms-ish scale of the tensor
+Integer / mask outputs must be bit-exact, except mask cells whose smoothed confidence lies
+within 1e-6 of the 0.01 threshold (a discontinuity: both sides are "right").
+"""
+import ctypes
+from ctypes import byref, c_void_p
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import where2comm_oracle as orc
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from airv2x_perception_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _lib.load()
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _conv_call(lib, x_nhwc, wp, scale, shift, out, *, cin, cout, coutp, ks, stride, pad, relu, mode=0, up=1,
+               in_coff=0, out_ctot=None, out_coff=0, tile=0):
+    from airv2x_perception_amd import _lib
+    n, h, w, ctot = x_nhwc.shape
+    d = _lib.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.in_ctot, d.in_coff = n, h, w, cin, ctot, in_coff
+    if mode == 1:
+        d.ho, d.wo = h, w
+    else:
+        d.ho, d.wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    d.cout, d.coutp, d.out_ctot, d.out_coff = cout, coutp, out_ctot or cout, out_coff
+    d.ks, d.stride, d.pad, d.relu, d.mode, d.up, d.tile = ks, stride, pad, relu, mode, up, tile
+    _lib.check(lib.av2x_conv2d(byref(d), _p(x_nhwc), _p(wp), _p(scale), _p(shift), _p(out), _stream()), "conv")
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, ks, stride, pad, relu, tile
+    (2, 20, 36, 64, 64, 3, 2, 1, 1, 0),
+    (1, 17, 23, 64, 64, 3, 1, 1, 1, (128 << 16) | 64),
+    (3, 16, 40, 64, 128, 3, 2, 1, 1, (128 << 16) | 128),
+    (2, 9, 13, 128, 128, 3, 1, 1, 0, (64 << 16) | 64),
+    (1, 12, 20, 256, 256, 3, 1, 1, 1, (64 << 16) | 128),
+    (2, 10, 30, 384, 256, 1, 1, 0, 1, 0),
+    (1, 25, 88, 256, 256, 3, 1, 1, 1, 0),
+    (2, 7, 9, 256, 30, 1, 1, 0, 0, (128 << 16) | 32),
+    (1, 5, 5, 32, 14, 1, 1, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_torch_cpu(lib, case):
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    n, h, w, cin, cout, ks, stride, pad, relu, tile = case
+    g = torch.Generator().manual_seed(1234 + cin + cout + ks)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    wp, coutp = pack_conv_weight(wt)
+    dev = "cuda"
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    ho, wo = ref.shape[2], ref.shape[3]
+    out = torch.full((n, ho, wo, cout), float("nan"), device=dev)
+    _conv_call(lib, xd, wp.to(dev), scale.to(dev), shift.to(dev), out, cin=cin, cout=cout, coutp=coutp, ks=ks,
+               stride=stride, pad=pad, relu=relu, tile=tile)
+    got = out.permute(0, 3, 1, 2).cpu()
+    assert_close(got, ref, 1e-4, 1e-4, f"conv {case}")
+
+
+def test_conv_channel_slices_and_nchw(lib):
+    """input channel offset inside a wider tensor, output into a slice of a concat buffer, NCHW store."""
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    g = torch.Generator().manual_seed(7)
+    n, h, w = 2, 11, 19
+    x = torch.randn(n, 96, h, w, generator=g)
+    wt = torch.randn(30, 64, 1, 1, generator=g) / 8
+    b = torch.randn(30, generator=g)
+    ref = F.conv2d(x[:, 32:96], wt, b)
+    wp, coutp = pack_conv_weight(wt)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.full((n, 30, h, w), float("nan"), device="cuda")
+    _conv_call(lib, xd, wp.cuda(), None, b.cuda(), out, cin=64, cout=30, coutp=coutp, ks=1, stride=1, pad=0, relu=0,
+               mode=2, in_coff=32)
+    assert_close(out.cpu(), ref, 1e-4, 1e-4, "nchw head")
+    cat = torch.zeros((n, h, w, 50), device="cuda")
+    _conv_call(lib, xd, wp.cuda(), None, b.cuda(), cat, cin=64, cout=30, coutp=coutp, ks=1, stride=1, pad=0, relu=0,
+               in_coff=32, out_ctot=50, out_coff=20)
+    got = cat.permute(0, 3, 1, 2).cpu()
+    assert_close(got[:, 20:50], ref, 1e-4, 1e-4, "slice")
+    assert float(got[:, :20].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("up,cin", [(1, 64), (2, 128), (4, 256)])
+def test_deconv_matches_torch_cpu(lib, up, cin):
+    from airv2x_perception_amd.opencood_iface.packing import pack_deconv_weight
+    g = torch.Generator().manual_seed(up)
+    n, h, w, cout = 2, 7, 11, 128
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, up, up, generator=g) / np.sqrt(cin)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv_transpose2d(x, wt, None, stride=up) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    wp, ncol = pack_deconv_weight(wt)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    cat = torch.full((n, h * up, w * up, 384), float("nan"), device="cuda")
+    _conv_call(lib, xd, wp.cuda(), scale.cuda(), shift.cuda(), cat, cin=cin, cout=cout, coutp=ncol, ks=1, stride=1,
+               pad=0, relu=1, mode=1, up=up, out_ctot=384, out_coff=128)
+    got = cat.permute(0, 3, 1, 2).cpu()[:, 128:256]
+    assert_close(got, ref, 1e-4, 1e-4, f"deconv up={up}")
+
+
+def test_conv_rejects_bad_arguments(lib):
+    from airv2x_perception_amd import _lib
+    d = _lib.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.in_ctot = 1, 4, 4, 30, 30  # cin not a multiple of 32
+    d.ho, d.wo, d.cout, d.coutp, d.out_ctot, d.ks, d.stride, d.pad = 4, 4, 32, 32, 32, 1, 1, 0
+    t = torch.zeros(16, device="cuda")
+    rc = lib.av2x_conv2d(byref(d), _p(t), _p(t), _p(None), _p(t), _p(t), _stream())
+    assert rc != 0 and b"cin" in lib.av2x_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "conv")
+
+
+@pytest.mark.parametrize("agent_type", ["vehicle", "rsu", "drone"])
+def test_pillar_vfe_scatter(lib, agent_type):
+    from airv2x_perception_amd import synth
+    from airv2x_perception_amd.opencood_iface.packing import fold_bn
+    from oracle import voxelize_oracle as vox
+    rng = [-12.8, -6.4, -3.0, 12.8, 6.4, 1.0]
+    hy = synth.default_hypes(rng)
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), 3)
+    cfg = args[agent_type]["lidar"]
+    voxs = [vox.points_to_voxels(synth.clustered_cloud(i, 6000, rng), rng, [0.4, 0.4, 4.0]) for i in range(2)]
+    assert max(int(v[2].max()) for v in voxs) == 32 and min(int(v[2].min()) for v in voxs) == 1
+    vf = torch.from_numpy(np.concatenate([v[0] for v in voxs]))
+    vc = torch.from_numpy(np.concatenate([np.concatenate([np.full((v[1].shape[0], 1), k, np.int32), v[1]], 1)
+                                          for k, v in enumerate(voxs)]))
+    vn = torch.from_numpy(np.concatenate([v[2] for v in voxs]))
+    prefix = synth.TYPE_PREFIX[agent_type] + ".0.0"
+    pf = orc.pillar_vfe(vf, vn, vc, sd, prefix, cfg["voxel_size"], cfg["lidar_range"])
+    nx, ny = 64, 32
+    ref = orc.pillar_scatter(pf, vc, 2, nx, ny)
+    sc, sh = fold_bn(sd, prefix + ".pfn_layers.0.norm")
+    vs, r = cfg["voxel_size"], cfg["lidar_range"]
+    geom = (ctypes.c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + r[0], vs[1] / 2 + r[1], vs[2] / 2 + r[2])
+    canvas = torch.zeros((3, ny, nx, 64), device="cuda")
+    from airv2x_perception_amd import _lib
+    smap = torch.tensor([2, 0], dtype=torch.int32, device="cuda")  # agent 0 -> slot 2, agent 1 -> slot 0
+    _lib.check(lib.av2x_pillar_vfe_scatter(_p(vf.cuda()), _p(vc.cuda()), _p(vn.cuda()), vf.shape[0],
+                                           _p(sd[prefix + ".pfn_layers.0.linear.weight"].cuda()), _p(sc.cuda()),
+                                           _p(sh.cuda()), ctypes.cast(geom, c_void_p), _p(canvas), 0, _p(smap), 2,
+                                           ny, nx, _stream()), "pillar")
+    got = canvas.permute(0, 3, 1, 2).cpu()
+    assert_close(got[2], ref[0], 1e-4, 1e-5, "agent0->slot2")
+    assert_close(got[0], ref[1], 1e-4, 1e-5, "agent1->slot0")
+    assert float(got[1].abs().max()) == 0.0
+    # occupancy pattern (integer-exact scatter indices)
+    assert torch.equal(got[2].abs().sum(0) > 0, ref[0].abs().sum(0) > 0)
+    nz = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.check(lib.av2x_count_nonzero(_p(canvas), canvas.numel(), _p(nz), _stream()), "nz")
+    assert int(nz.item()) == int(ref.count_nonzero().item())
+
+
+def test_comm_mask(lib):
+    from airv2x_perception_amd import _lib, synth
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = 5, 14, 20, 44
+    psm = torch.randn(n, c, h, w, generator=g) * 1.2 - 5.6
+    hy = synth.default_hypes()
+    sd = synth.synthetic_state_dict(synth.where2com_param_spec(hy["model"]["args"]), 0)
+    record_len = torch.tensor([3, 2])
+    comm_cfg = hy["model"]["args"]["where2com_fusion"]["communication"]
+    masks, rate, maps = orc.communication(orc._split(psm, record_len), sd, comm_cfg)
+    assert 0.05 < float(masks.mean()) < 0.98
+    pd = torch.zeros((n, h, w, 16), device="cuda")
+    pd[..., :c] = psm.permute(0, 2, 3, 1).cuda()
+    conf = torch.empty((n, h, w), device="cuda"); smooth = torch.empty_like(conf); mask = torch.empty_like(conf)
+    count = torch.zeros(2, dtype=torch.int32, device="cuda")
+    samp = torch.tensor([0, 0, 0, 1, 1], dtype=torch.int32, device="cuda")
+    ego = torch.tensor([1, 0, 0, 1, 0], dtype=torch.int32, device="cuda")
+    gk = "fusion_net.naive_communication.gaussian_filter"
+    _lib.check(lib.av2x_comm_mask(_p(pd), n, h, w, 16, c, _p(sd[gk + ".weight"].reshape(-1).cuda()),
+                                  _p(sd[gk + ".bias"].cuda()), 5, 0.01, _p(samp), _p(ego), _p(conf), _p(smooth),
+                                  _p(mask), _p(count), _stream()), "comm_mask")
+    assert_close(smooth.cpu(), maps[:, 0], 1e-5, 1e-8, "smoothed map")
+    near = (maps[:, 0] - 0.01).abs() < 1e-6
+    diff = (mask.cpu() != masks[:, 0]) & ~near
+    assert not diff.any()
+    # rate: exact popcount before the ego override
+    ones = (smooth.cpu() > 0.01)
+    assert count.cpu().tolist() == [int(ones[:3].sum()), int(ones[3:].sum())]
+    my_rate = (count.cpu().float() / (record_len.float() * h * w)).sum() / 2
+    assert abs(float(my_rate) - float(rate)) < 1e-6 + float(near.sum()) / (h * w)
+
+
+@pytest.mark.parametrize("c,n", [(64, 1), (64, 4), (128, 3), (256, 8), (64, 15)])
+def test_pixel_attention(lib, c, n):
+    from airv2x_perception_amd import _lib
+    g = torch.Generator().manual_seed(c + n)
+    h, w = 9, 21
+    x = torch.randn(n, c, h, w, generator=g) * 1.5
+    x[1:, :, ::3] = 0  # masked-out cells of collaborators stay in the softmax as zero vectors
+    ref = orc.attention_fusion(x)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.empty((h, w, c), device="cuda")
+    ptrs = (c_void_p * n)(*[xd[j].data_ptr() for j in range(n)])
+    _lib.check(lib.av2x_pixel_attn_fuse(ptrs, n, h * w, c, _p(out), _stream()), "attn")
+    assert_close(out.permute(2, 0, 1).cpu(), ref, 1e-4, 1e-5, f"attn c={c} n={n}")
+
+
+def test_apply_mask(lib):
+    from airv2x_perception_amd import _lib
+    x = torch.randn(3, 10, 12, 64)
+    m = (torch.rand(3, 10, 12) > 0.5).float()
+    xd = x.cuda()
+    _lib.check(lib.av2x_apply_mask(_p(xd), _p(m.cuda()), 3, 120, 64, _stream()), "apply_mask")
+    assert torch.equal(xd.cpu(), x * m.unsqueeze(-1))
