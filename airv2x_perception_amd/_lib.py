@@ -9,6 +9,11 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_uint64, c_void_p
 
+# torch bundles its own libamdhip64; it MUST be the first HIP runtime mapped into the process so
+# that libairv2x_hip.so binds to the same runtime instance (streams and device pointers are
+# shared with torch).  Loading our library first gives two runtimes and "no ROCm-capable device".
+import torch  # noqa: F401  (import order matters)
+
 from . import build as _build
 
 _LIB = None
@@ -36,6 +41,9 @@ SIGNATURES = {
     "av2x_apply_mask": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_pixel_attn_fuse": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_count_nonzero": (c_int32, [c_void_p, c_uint64, c_void_p, c_void_p]),
+    "av2x_voxelize_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
+    "av2x_voxelize": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
 }
 
 

@@ -1,0 +1,178 @@
+// Deterministic GPU pillar voxelizer with the observable semantics of spconv's
+// Point2VoxelCPU3d (the third-party call behind SpVoxelPreprocessor.preprocess,
+// data_utils/pre_processor/sp_voxel_preprocessor.py:93-110):
+//   * c = floor((p - range_min) / voxel_size) in fp32, point dropped when outside the grid;
+//   * voxels are numbered in order of first appearance in the input; only the first
+//     `max_voxels` of them exist;
+//   * a voxel keeps its first `max_points` points in input order; rows beyond are zero.
+// No sort: a counting sort by grid cell (atomics only for counts / unordered slot fill) followed
+// by an in-cell rank count restores input order exactly, so the result is bit-reproducible.
+//
+//   k_cell   per point : cell id, cnt[cell]++, first[cell] = min(index)
+//   k_scan   1 workgroup: exclusive scan (a) over "is first point of its cell" flags in point
+//            order -> voxel rank + M, (b) over cnt in cell order -> list offsets
+//   k_fill   per point : unordered append of the point index to its cell's list
+//   k_emit   per point : pos = #{j in list : j < i}; write voxels / coords / num_points
+#include "av2x_common.hpp"
+
+namespace {
+
+struct VoxGeom {
+    float rmin[3];
+    float vs[3];
+    int grid[3];  // x, y, z
+};
+
+__global__ void k_cell(const float4* __restrict__ pts, int n, VoxGeom g, int* __restrict__ cell,
+                       int* __restrict__ cnt, int* __restrict__ first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    // IEEE fp32 subtract and divide, as the CPU implementation (no reciprocal, no contraction)
+    const float fx = floorf(__fdiv_rn(__fsub_rn(p.x, g.rmin[0]), g.vs[0]));
+    const float fy = floorf(__fdiv_rn(__fsub_rn(p.y, g.rmin[1]), g.vs[1]));
+    const float fz = floorf(__fdiv_rn(__fsub_rn(p.z, g.rmin[2]), g.vs[2]));
+    int c = -1;
+    if (fx >= 0.f && fx < (float)g.grid[0] && fy >= 0.f && fy < (float)g.grid[1] && fz >= 0.f && fz < (float)g.grid[2]) {
+        c = ((int)fz * g.grid[1] + (int)fy) * g.grid[0] + (int)fx;
+        atomicAdd(&cnt[c], 1);
+        atomicMin(&first[c], i);
+    }
+    cell[i] = c;
+}
+
+// exclusive scan of `n` ints produced by functor f(i), single workgroup of 1024 threads
+template <class F, class G>
+__device__ void block_scan(int n, F f, G store, int* total) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? f(i) : 0;
+        int s = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(s, o);
+            if (lane >= o) s += t;
+        }
+        if (lane == 63) wsum[wave] = s;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wsum[k];
+        const int excl = carry + woff + s - v;
+        if (i < n) store(i, excl);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cell, int n, const int* __restrict__ cnt,
+                                               const int* __restrict__ first, int ncell, int* __restrict__ vrank,
+                                               int* __restrict__ offs, int* __restrict__ m_out, int max_voxels) {
+    __shared__ int tot;
+    // (a) voxel rank = number of earlier "first points"
+    block_scan(
+        n, [&](int i) { const int c = cell[i]; return (c >= 0 && first[c] == i) ? 1 : 0; },
+        [&](int i, int ex) { const int c = cell[i]; if (c >= 0 && first[c] == i) vrank[c] = ex; }, &tot);
+    __syncthreads();
+    if (threadIdx.x == 0) m_out[0] = tot < max_voxels ? tot : max_voxels;
+    __syncthreads();
+    // (b) list offsets in cell order
+    block_scan(ncell, [&](int c) { return cnt[c]; }, [&](int c, int ex) { offs[c] = ex; }, &tot);
+}
+
+__global__ void k_fill(const int* __restrict__ cell, int n, const int* __restrict__ offs, int* __restrict__ fill,
+                       int* __restrict__ list) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell[i];
+    if (c < 0) return;
+    list[offs[c] + atomicAdd(&fill[c], 1)] = i;
+}
+
+__global__ void k_emit(const float4* __restrict__ pts, const int* __restrict__ cell, int n, const int* __restrict__ cnt,
+                       const int* __restrict__ first, const int* __restrict__ vrank, const int* __restrict__ offs,
+                       const int* __restrict__ list, VoxGeom g, int max_points, int max_voxels,
+                       float4* __restrict__ voxels, int* __restrict__ coords, int* __restrict__ num) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell[i];
+    if (c < 0) return;
+    const int v = vrank[c];
+    if (v >= max_voxels) return;
+    const int k = cnt[c];
+    int pos = 0;
+    const int* l = list + offs[c];
+    for (int j = 0; j < k; ++j) pos += l[j] < i;
+    if (pos < max_points) voxels[(size_t)v * max_points + pos] = pts[i];
+    if (first[c] == i) {
+        const int x = c % g.grid[0], yz = c / g.grid[0];
+        coords[3 * v + 0] = yz / g.grid[1];
+        coords[3 * v + 1] = yz % g.grid[1];
+        coords[3 * v + 2] = x;
+        num[v] = k < max_points ? k : max_points;
+    }
+}
+
+__global__ void k_init(int* __restrict__ cnt, int* __restrict__ first, int* __restrict__ fill, int ncell) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    cnt[c] = 0;
+    fill[c] = 0;
+    first[c] = 0x7fffffff;
+}
+
+}  // namespace
+
+extern "C" uint64_t av2x_voxelize_workspace_bytes(int32_t n_points, int32_t nx, int32_t ny, int32_t nz) {
+    const uint64_t ncell = (uint64_t)nx * ny * nz;
+    return (5 * ncell + 2 * (uint64_t)n_points + 4) * sizeof(int);
+}
+
+extern "C" int av2x_voxelize(const float* points, int32_t n_points, const float* range6, const float* voxel3,
+                             int32_t max_points, int32_t max_voxels, void* workspace, float* voxels, int32_t* coords,
+                             int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream) {
+    if (!range6 || !voxel3 || !workspace || !voxels || !coords || !num_points || !n_voxels)
+        return av2x::fail("av2x_voxelize: null argument");
+    if (n_points < 0 || max_points <= 0 || max_voxels <= 0) return av2x::fail("av2x_voxelize: bad sizes");
+    VoxGeom g;
+    for (int j = 0; j < 3; ++j) {
+        g.rmin[j] = range6[j];
+        g.vs[j] = voxel3[j];
+        g.grid[j] = (int)llround(((double)range6[3 + j] - (double)range6[j]) / (double)voxel3[j]);
+        if (g.grid[j] <= 0) return av2x::fail("av2x_voxelize: empty grid");
+    }
+    const long long ncell_ll = (long long)g.grid[0] * g.grid[1] * g.grid[2];
+    if (ncell_ll > (1ll << 28)) return av2x::fail("av2x_voxelize: grid too large");
+    const int ncell = (int)ncell_ll;
+    hipStream_t st = av2x::as_stream(stream);
+    int* w = reinterpret_cast<int*>(workspace);
+    int *cnt = w, *first = w + ncell, *fill = w + 2 * (size_t)ncell, *vrank = w + 3 * (size_t)ncell,
+        *offs = w + 4 * (size_t)ncell;
+    int* cell = w + 5 * (size_t)ncell;
+    int* list = cell + n_points;
+    hipLaunchKernelGGL(k_init, dim3((ncell + 255) / 256), dim3(256), 0, st, cnt, first, fill, ncell);
+    // outputs are capacity-sized by the caller: voxels (cap, max_points, 4) must start zeroed
+    const long long cap = n_points < max_voxels ? n_points : max_voxels;
+    hipError_t e = hipMemsetAsync(voxels, 0, (size_t)cap * max_points * 4 * sizeof(float), st);
+    if (e != hipSuccess) return av2x::fail("av2x_voxelize: memset: %s", hipGetErrorString(e));
+    if (n_points == 0) {
+        e = hipMemsetAsync(n_voxels, 0, sizeof(int), st);
+        return e == hipSuccess ? 0 : av2x::fail("av2x_voxelize: memset: %s", hipGetErrorString(e));
+    }
+    if (!points) return av2x::fail("av2x_voxelize: null points");
+    const dim3 gp((n_points + 255) / 256), bp(256);
+    const float4* p4 = reinterpret_cast<const float4*>(points);
+    hipLaunchKernelGGL(k_cell, gp, bp, 0, st, p4, n_points, g, cell, cnt, first);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cell, n_points, cnt, first, ncell, vrank, offs, n_voxels,
+                       max_voxels);
+    hipLaunchKernelGGL(k_fill, gp, bp, 0, st, cell, n_points, offs, fill, list);
+    hipLaunchKernelGGL(k_emit, gp, bp, 0, st, p4, cell, n_points, cnt, first, vrank, offs, list, g, max_points,
+                       max_voxels, reinterpret_cast<float4*>(voxels), coords, num_points);
+    return av2x::check_launch("av2x_voxelize");
+}

@@ -62,8 +62,27 @@ class Where2ComEngine:
         self.A, self.C = args["anchor_number"], args["num_class"]
         self.ws = {}
         self.weights_ready = False
-        self.conv_tile = 0
+        self.conv_tile = 0          # 0 = pick_tile(); else forced BM<<16|BN (tests / tuning)
+        self.use_graph = False      # replay everything after the scatter from a captured hipGraph
+        self.graphs = {}
+        self.profile = None         # list -> (tile, flops, ev0, ev1) per conv launch (bench roofline pass)
         self._desc = _lib.ConvDesc()
+
+    def graph_active(self):
+        return self.use_graph and len(self.graphs) > 0
+
+    @staticmethod
+    def pick_tile(m, coutp):
+        """Largest workgroup tile that still gives >= 2 workgroups per CU (256 CUs): the deep,
+        low-resolution layers would otherwise leave most of the chip idle."""
+        bn = 128 if coutp % 128 == 0 else (64 if coutp % 64 == 0 else 32)
+        bm = 128
+        wgs = lambda a, b: -(-m // a) * (coutp // b)
+        if bn == 128 and wgs(128, 128) < 512:
+            bn = 64
+        if bn == 64 and wgs(128, 64) < 512:
+            bm = 64
+        return bm, bn
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd):
@@ -164,9 +183,21 @@ class Where2ComEngine:
         d.out_ctot = out_ctot if out_ctot is not None else L.cout
         d.out_coff = out_coff
         d.ks, d.stride, d.pad, d.relu, d.mode, d.up = L.ks, L.stride, L.pad, L.relu, L.mode, L.up
-        d.tile = self.conv_tile
+        if self.conv_tile:
+            bm, bn = self.conv_tile >> 16, self.conv_tile & 0xffff
+        else:
+            bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
+        d.tile = (bm << 16) | bn
+        if self.profile is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(self.lib.av2x_conv2d(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(out),
                                         self.stream()), "av2x_conv2d")
+        if self.profile is not None:
+            e1.record()
+            # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
+            ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
+            self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1))
         return ho, wo
 
     def run_block(self, i, x, n, h, w, tag):
@@ -307,6 +338,40 @@ class Where2ComEngine:
         if n == 0:
             raise ValueError("empty frame: no agent has lidar input")
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
+        if self.use_graph and trace is None and self.profile is None:
+            key = (tuple(record_len), ny, nx)
+            ent = self.graphs.get(key)
+            if ent is None:
+                # one eager pass allocates every workspace buffer and layout tensor outside the capture
+                self._post_encode(canvas, ny, nx, record_len, None)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    static = self._post_encode(canvas, ny, nx, record_len, None)
+                ent = (g, static)
+                self.graphs[key] = ent
+            g, static = ent
+            g.replay()
+            heads, com, nz = static
+            heads = heads.clone()  # outputs are fresh tensors, as in the reference
+            com, nz = com.clone(), nz.clone()
+        else:
+            heads, com, nz = self._post_encode(canvas, ny, nx, record_len, trace)
+        outs = torch.split(heads, self.head_splits, dim=1)
+        if B > 1:
+            outs = [o.contiguous() for o in outs]
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        comm_rate = nz[0]
+        if sync_comm_rate:
+            comm_rate = int(comm_rate.item())
+        out.update({"mask": 0, "com": com, "comm_rate": comm_rate})
+        return out
+
+    def _post_encode(self, canvas, ny, nx, record_len, trace):
+        """Everything after the scatter; static shapes for a given record_len -> capturable."""
+        B, n = len(record_len), sum(record_len)
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
@@ -382,14 +447,4 @@ class Where2ComEngine:
         if trace is not None:
             trace["fused_2d"] = catf.permute(0, 3, 1, 2).clone()
             trace["fused_shrink"] = fs.permute(0, 3, 1, 2).clone()
-        outs = torch.split(heads, self.head_splits, dim=1)
-        if B > 1:
-            outs = [o.contiguous() for o in outs]
-        out = {"psm": outs[0], "rm": outs[1]}
-        if self.args["obj_head"]:
-            out["obj"] = outs[2]
-        comm_rate = nz[0]
-        if sync_comm_rate:
-            comm_rate = int(comm_rate.item())
-        out.update({"mask": 0, "com": com, "comm_rate": comm_rate})
-        return out
+        return heads, com, nz

@@ -1,0 +1,56 @@
+"""GPU counterpart of ``SpVoxelPreprocessor.preprocess``
+(data_utils/pre_processor/sp_voxel_preprocessor.py:74-116): points -> (voxel_features,
+voxel_coords z,y,x, voxel_num_points), computed by av2x_voxelize on the device.
+
+``range_filter=True`` first applies the strict range crop the dataset performs before
+voxelising (utils/pcd_utils.py:136-165, called at intermediate_fusion_dataset.py:598-603);
+it is an order-preserving boolean mask (torch indexing = plumbing, no arithmetic).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_void_p
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def voxelize_points(points, lidar_range, voxel_size, max_points=32, max_voxels=70000, range_filter=False):
+    """points: (P,4) fp32 CUDA tensor -> (voxels (M,32,4), coords (M,3) i32 zyx, num (M,) i32) on the device.
+    Reads M back to the host once (the reference contract has exact-shaped tensors)."""
+    lib = _lib.load()
+    if points.device.type != "cuda":
+        raise RuntimeError("voxelize_points runs on a HIP device only")
+    pts = points.contiguous().float()
+    if range_filter:
+        r = lidar_range
+        m = ((pts[:, 0] > r[0]) & (pts[:, 0] < r[3]) & (pts[:, 1] > r[1]) & (pts[:, 1] < r[4])
+             & (pts[:, 2] > r[2]) & (pts[:, 2] < r[5]))
+        pts = pts[m].contiguous()
+    n = pts.shape[0]
+    if n == 0:
+        # dummy points of the reference's empty-cloud branch (sp_voxel_preprocessor.py:80-90)
+        d = np.array([[0, 0, 0, 0], [-0.218277, -11.13425732, -80.05884552, 1.230595649e-38]], dtype=np.float32)
+        pts = torch.from_numpy(d).to(points.device)
+        n = 2
+    grid = np.round((np.asarray(lidar_range[3:6], np.float64) - np.asarray(lidar_range[0:3], np.float64))
+                    / np.asarray(voxel_size, np.float64)).astype(np.int64)
+    cap = min(n, max_voxels)
+    dev = pts.device
+    ws = torch.empty(int(lib.av2x_voxelize_workspace_bytes(n, int(grid[0]), int(grid[1]), int(grid[2]))),
+                     dtype=torch.uint8, device=dev)
+    voxels = torch.empty((cap, max_points, 4), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    m_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    r6 = (c_float * 6)(*[float(v) for v in lidar_range])
+    v3 = (c_float * 3)(*[float(v) for v in voxel_size])
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.av2x_voxelize(c_void_p(pts.data_ptr()), n, ctypes.cast(r6, c_void_p), ctypes.cast(v3, c_void_p),
+                                 max_points, max_voxels, c_void_p(ws.data_ptr()), c_void_p(voxels.data_ptr()),
+                                 c_void_p(coords.data_ptr()), c_void_p(num.data_ptr()), c_void_p(m_dev.data_ptr()), st),
+               "av2x_voxelize")
+    m = int(m_dev.item())
+    return voxels[:m], coords[:m], num[:m]

@@ -387,3 +387,39 @@ def sort_types(types):
 
 def clone_hypes(h):
     return copy.deepcopy(h)
+
+
+def build_data_dict_device(voxelized, types, device, max_cav_num=15):
+    """Same layout as build_data_dict, from voxel tensors that already live on the device."""
+    order = {t: i for i, t in enumerate(AGENT_TYPES)}
+    assert list(types) == sorted(types, key=lambda t: order[t]), "agents must be ordered veh, rsu, drone"
+    host = build_data_dict([(np.zeros((0, 32, 4), np.float32), np.zeros((0, 3), np.int32), np.zeros((0,), np.int32))
+                            for _ in types], types, "cpu", max_cav_num)
+    for t in AGENT_TYPES:
+        idxs = [i for i, tt in enumerate(types) if tt == t]
+        if not idxs:
+            continue
+        feats, coords, nums = [], [], []
+        for k, i in enumerate(idxs):
+            v, c, n = voxelized[i]
+            feats.append(v)
+            coords.append(torch.cat([torch.full((c.shape[0], 1), k, dtype=torch.int32, device=c.device), c.to(torch.int32)], 1))
+            nums.append(n)
+        host[t]["batch_merged_lidar_features_torch"] = {
+            "voxel_features": torch.cat(feats, 0).contiguous(),
+            "voxel_coords": torch.cat(coords, 0).contiguous(),
+            "voxel_num_points": torch.cat(nums, 0).contiguous(),
+        }
+    for k in ("pairwise_t_matrix_collab", "img_pairwise_t_matrix_collab", "prior_encoding", "spatial_correction_matrix"):
+        host[k] = host[k].to(device)
+    return host
+
+
+def data_dict_to(dd, device):
+    """Recursive .to(device) that tolerates None members (train_utils.py:473-494 ``to_device``);
+    per-type record_len stays on the host (it only drives host-side bookkeeping)."""
+    if isinstance(dd, dict):
+        return {k: (v if k in ("record_len", "batch_idxs") else data_dict_to(v, device)) for k, v in dd.items()}
+    if isinstance(dd, torch.Tensor):
+        return dd.to(device)
+    return dd

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: collaborative frames / second of the Where2Comm-LiDAR hot path.
+
+One "step" = one collaborative frame (B = 1): 4 agents (vehicle, vehicle, rsu, drone), 8192
+synthetic points each on the default AirV2X grid (704 x 200 pillars), already voxelised and
+resident in HBM -> psm / rm / obj on the device (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); every
+rank processes its own independent frames (the path shards by frame: no data-path collective),
+the timed region is bracketed by barrier + synchronize on both sides and the MAX over ranks is
+reported, so value = N * K frames / max-time  ("scaling": "weak").
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (one conv_igemm_f32 instantiation): algorithmic FLOPs of its
+                launches / their HIP-event durations, measured in a second pass of K steps with an
+                event pair around every conv launch on the launch stream (the clean timed region
+                carries no events).  peak = 157.3 TFLOP/s (fp32-input MFMA, MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (oracle/where2comm_oracle.py, "port") on the host cores, rank 0,
+                N == 1 only, bounded sample (a few frames).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="replay the frame from a captured HIP graph (1) or eager (0)")
+    return ap.parse_args()
+
+
+def build_inputs(n_agents, n_points, device):
+    from airv2x_perception_amd import synth
+    from airv2x_perception_amd.opencood_iface.voxelizer import voxelize_points
+    hy = synth.default_hypes()
+    args = hy["model"]["args"]
+    pp = hy["preprocess"]
+    types = synth.agent_types_for(n_agents)
+    order, types_sorted = synth.sort_types(types)
+    clouds = [synth.synthetic_cloud(i, n_points) for i in range(n_agents)]
+    voxd = []
+    for i in order:
+        pts = torch.from_numpy(clouds[i]).to(device)
+        voxd.append(voxelize_points(pts, pp["cav_lidar_range"], pp["args"]["voxel_size"],
+                                    pp["args"]["max_points_per_voxel"], pp["args"]["max_voxel_test"],
+                                    range_filter=True))
+    dd = synth.build_data_dict_device(voxd, types_sorted, device, max_cav_num=args["max_cav_num"])
+    return hy, args, dd, [clouds[i] for i in order], types_sorted
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from airv2x_perception_amd import synth
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+
+    hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev)
+    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    model.sync_comm_rate = False  # no host sync inside the frame; comm_rate stays a device scalar
+    eng = model.engine()
+    eng.use_graph = bool(a.graph)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(a.warmup):
+        out = model(dd)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = model(dd)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / a.steps * 1e3
+    fps = world * a.steps / dt
+
+    res = {
+        "metric": "collaborative frames/sec, Where2Comm-LiDAR 4-agent",
+        "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Where2Comm-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
+                               f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
+                               f"psm/rm/obj out; BASELINE.json configs[1]",
+                   "parallelism": "independent frames per GPU (replicas)" if world > 1 else "single GPU",
+                   "launch": "hipGraph replay" if eng.graph_active() else "eager"},
+    }
+
+    # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
+    if not a.no_roofline and rank == 0:
+        eng.use_graph = False
+        eng.profile = []
+        for _ in range(a.steps):
+            model(dd)
+        torch.cuda.synchronize()
+        prof, eng.profile = eng.profile, None
+        per = {}
+        for tile, flops, e0, e1 in prof:
+            d = per.setdefault(tile, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += flops
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        dom = max(per, key=lambda k: per[k][2])
+        cnt, fl, sec = per[dom]
+        ach = fl / sec / 1e12
+        tot_fl = sum(v[1] for v in per.values())
+        tot_s = sum(v[2] for v in per.values())
+        res["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": f"conv_igemm_f32<{dom[0]},{dom[1]}>", "launches_per_frame": cnt / a.steps,
+            "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
+            "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
+                                 "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},
+            "per_tile": {f"{k[0]}x{k[1]}": {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
+                                            "ms_per_frame": round(v[2] / a.steps * 1e3, 3)} for k, v in per.items()},
+            "timing": "second pass of K steps, hipEvent pair around every conv launch on the launch stream",
+        }
+
+    # ---------------- CPU baseline: the oracle port on the host cores (bounded sample) ---------------------
+    if a.cpu_frames > 0 and rank == 0 and world == 1:
+        from oracle import where2comm_oracle as orc
+        dd_cpu = synth.data_dict_to(dd, "cpu")
+        torch.set_num_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            ref = orc.where2com_forward(dd_cpu, sd, args)  # warm-up + parity reference
+            t0 = time.perf_counter()
+            for _ in range(a.cpu_frames):
+                orc.where2com_forward(dd_cpu, sd, args)
+            cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(a.cpu_frames / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"{a.cpu_frames} frames of the same workload after 1 warm-up, torch CPU fp32 "
+                                         f"de-duplicated schedule (1 backbone pass + masked blocks), {cdt / a.cpu_frames:.2f} s/frame"}
+        res["parity_max_abs_err_vs_oracle"] = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("psm", "rm", "obj")}
+
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,23 @@ int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents, int32_t h
 int av2x_count_nonzero(const float* x, uint64_t n_elems, unsigned long long* result,
                        av2x_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Pillar voxelizer (points -> voxels), deterministic.  Replaces the spconv call behind
+ * SpVoxelPreprocessor.preprocess (data_utils/pre_processor/sp_voxel_preprocessor.py:93-110,
+ * third-party `spconv.utils.Point2VoxelCPU3d`): c = floor((p - range_min)/voxel) in fp32, voxels
+ * numbered by first appearance (at most max_voxels), first max_points points per voxel kept in
+ * input order, zero padded.
+ *   points (n_points,4) f32 device; range6 {xmin,ymin,zmin,xmax,ymax,zmax} and voxel3 are HOST
+ *   arrays; workspace: av2x_voxelize_workspace_bytes() bytes of device scratch;
+ *   outputs are CAPACITY sized, cap = min(n_points, max_voxels):
+ *     voxels (cap,max_points,4) f32, coords (cap,3) i32 in z,y,x order, num_points (cap,) i32,
+ *     n_voxels (1,) i32 device scalar = M, the number of valid leading rows.
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_voxelize_workspace_bytes(int32_t n_points, int32_t nx, int32_t ny, int32_t nz);
+int av2x_voxelize(const float* points, int32_t n_points, const float* range6, const float* voxel3,
+                  int32_t max_points, int32_t max_voxels, void* workspace, float* voxels,
+                  int32_t* coords, int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,7 +151,11 @@ def test_pillar_vfe_scatter(lib, agent_type):
     args = hy["model"]["args"]
     sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), 3)
     cfg = args[agent_type]["lidar"]
-    voxs = [vox.points_to_voxels(synth.clustered_cloud(i, 6000, rng), rng, [0.4, 0.4, 4.0]) for i in range(2)]
+    clouds = [synth.clustered_cloud(i, 6000, rng) for i in range(2)]
+    for cl in clouds:  # a hot spot that overflows the 32-point cap
+        cl[:80, 0] = 3.3 + 0.001 * np.arange(80)
+        cl[:80, 1] = -2.1
+    voxs = [vox.points_to_voxels(cl, rng, [0.4, 0.4, 4.0]) for cl in clouds]
     assert max(int(v[2].max()) for v in voxs) == 32 and min(int(v[2].min()) for v in voxs) == 1
     vf = torch.from_numpy(np.concatenate([v[0] for v in voxs]))
     vc = torch.from_numpy(np.concatenate([np.concatenate([np.full((v[1].shape[0], 1), k, np.int32), v[1]], 1)
@@ -167,10 +171,13 @@ def test_pillar_vfe_scatter(lib, agent_type):
     canvas = torch.zeros((3, ny, nx, 64), device="cuda")
     from airv2x_perception_amd import _lib
     smap = torch.tensor([2, 0], dtype=torch.int32, device="cuda")  # agent 0 -> slot 2, agent 1 -> slot 0
-    _lib.check(lib.av2x_pillar_vfe_scatter(_p(vf.cuda()), _p(vc.cuda()), _p(vn.cuda()), vf.shape[0],
-                                           _p(sd[prefix + ".pfn_layers.0.linear.weight"].cuda()), _p(sc.cuda()),
-                                           _p(sh.cuda()), ctypes.cast(geom, c_void_p), _p(canvas), 0, _p(smap), 2,
-                                           ny, nx, _stream()), "pillar")
+    # keep every device tensor alive in a variable: a temporary passed through _p() would be freed
+    # (and its block re-used by the next .cuda()) before the asynchronous kernel reads it
+    d_vf, d_vc, d_vn = vf.cuda(), vc.cuda(), vn.cuda()
+    d_w, d_sc, d_sh = sd[prefix + ".pfn_layers.0.linear.weight"].cuda(), sc.cuda(), sh.cuda()
+    _lib.check(lib.av2x_pillar_vfe_scatter(_p(d_vf), _p(d_vc), _p(d_vn), vf.shape[0], _p(d_w), _p(d_sc), _p(d_sh),
+                                           ctypes.cast(geom, c_void_p), _p(canvas), 0, _p(smap), 2, ny, nx,
+                                           _stream()), "pillar")
     got = canvas.permute(0, 3, 1, 2).cpu()
     assert_close(got[2], ref[0], 1e-4, 1e-5, "agent0->slot2")
     assert_close(got[0], ref[1], 1e-4, 1e-5, "agent1->slot0")
@@ -200,9 +207,9 @@ def test_comm_mask(lib):
     samp = torch.tensor([0, 0, 0, 1, 1], dtype=torch.int32, device="cuda")
     ego = torch.tensor([1, 0, 0, 1, 0], dtype=torch.int32, device="cuda")
     gk = "fusion_net.naive_communication.gaussian_filter"
-    _lib.check(lib.av2x_comm_mask(_p(pd), n, h, w, 16, c, _p(sd[gk + ".weight"].reshape(-1).cuda()),
-                                  _p(sd[gk + ".bias"].cuda()), 5, 0.01, _p(samp), _p(ego), _p(conf), _p(smooth),
-                                  _p(mask), _p(count), _stream()), "comm_mask")
+    d_gw, d_gb = sd[gk + ".weight"].reshape(-1).cuda(), sd[gk + ".bias"].cuda()
+    _lib.check(lib.av2x_comm_mask(_p(pd), n, h, w, 16, c, _p(d_gw), _p(d_gb), 5, 0.01, _p(samp), _p(ego), _p(conf),
+                                  _p(smooth), _p(mask), _p(count), _stream()), "comm_mask")
     assert_close(smooth.cpu(), maps[:, 0], 1e-5, 1e-8, "smoothed map")
     near = (maps[:, 0] - 0.01).abs() < 1e-6
     diff = (mask.cpu() != masks[:, 0]) & ~near
@@ -233,6 +240,6 @@ def test_apply_mask(lib):
     from airv2x_perception_amd import _lib
     x = torch.randn(3, 10, 12, 64)
     m = (torch.rand(3, 10, 12) > 0.5).float()
-    xd = x.cuda()
-    _lib.check(lib.av2x_apply_mask(_p(xd), _p(m.cuda()), 3, 120, 64, _stream()), "apply_mask")
+    xd, md = x.cuda(), m.cuda()
+    _lib.check(lib.av2x_apply_mask(_p(xd), _p(md), 3, 120, 64, _stream()), "apply_mask")
     assert torch.equal(xd.cpu(), x * m.unsqueeze(-1))
