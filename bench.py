@@ -35,6 +35,20 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup v2 cpu.max quota).
+    (The GPU boxes expose 256 logical CPUs but cap the container at a 16-CPU quota; asking
+    torch for 256 threads there just thrashes.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,7 +176,7 @@ def main():
     if a.cpu_frames > 0 and rank == 0 and world == 1:
         from oracle import where2comm_oracle as orc
         dd_cpu = synth.data_dict_to(dd, "cpu")
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(usable_cores())
         with torch.no_grad():
             ref = orc.where2com_forward(dd_cpu, sd, args)  # warm-up + parity reference
             t0 = time.perf_counter()

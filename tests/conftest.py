@@ -10,3 +10,22 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _torch_threads():
+    """Keep the CPU oracle inside the container's CPU quota (256 visible CPUs, 16 usable on the GPU box)."""
+    import torch
+    torch.set_num_threads(_usable_cores())
+    yield

@@ -193,7 +193,7 @@ def test_comm_mask(lib):
     from airv2x_perception_amd import _lib, synth
     g = torch.Generator().manual_seed(11)
     n, c, h, w = 5, 14, 20, 44
-    psm = torch.randn(n, c, h, w, generator=g) * 1.2 - 5.6
+    psm = torch.randn(n, c, h, w, generator=g) * 1.2 - 6.7
     hy = synth.default_hypes()
     sd = synth.synthetic_state_dict(synth.where2com_param_spec(hy["model"]["args"]), 0)
     record_len = torch.tensor([3, 2])
