@@ -25,6 +25,12 @@ class _Node(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover - containers are never called
         raise RuntimeError("parameter container: the compute lives in libairv2x_hip.so")
 
+    def __getitem__(self, i):  # ModuleList / Sequential style access (backbone.blocks[1][4])
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
 
 def _install(root, key, tensor, is_buffer):
     parts = key.split(".")

@@ -45,6 +45,33 @@ def _ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+def frame_layout(collaborators, data_dict):
+    """Agent order of the reference's repack_batch (airv2x_base_model.py:209-236):
+    sample-major, then vehicle/rsu/drone, then index inside the type.
+    Returns (record_len list, {type: canvas slot of each of that type's agents, in the order
+    of that type's own agent index = voxel_coords[:, 0]})."""
+    per_type = {}
+    B = 0
+    for t in AGENT_TYPES:
+        d = data_dict.get(t)
+        if t not in collaborators or d is None or len(d["batch_idxs"]) == 0:
+            continue
+        rl = d["record_len"]
+        rl = [int(v) for v in (rl.tolist() if hasattr(rl, "tolist") else rl)]
+        per_type[t] = rl
+        B = max(B, len(rl))
+    record_len, slots = [0] * B, {t: [] for t in per_type}
+    nxt = 0
+    for b in range(B):
+        for t in AGENT_TYPES:
+            if t in per_type and b < len(per_type[t]) and b in data_dict[t]["batch_idxs"]:
+                k = per_type[t][b]
+                slots[t] += list(range(nxt, nxt + k))
+                nxt += k
+                record_len[b] += k
+    return record_len, slots
+
+
 class Where2ComEngine:
     def __init__(self, args, device="cuda"):
         self.args = args
@@ -234,29 +261,7 @@ class Where2ComEngine:
 
     # ------------------------------------------------------------------ stages
     def frame_layout(self, data_dict):
-        """Agent order of the reference's repack_batch (airv2x_base_model.py:209-236):
-        sample-major, then vehicle/rsu/drone, then index inside the type.
-        Returns (record_len list, {type: slot list for that type's agents in batch order})."""
-        per_type = {}
-        B = 0
-        for t in AGENT_TYPES:
-            d = data_dict.get(t)
-            if t not in self.args["collaborators"] or d is None or len(d["batch_idxs"]) == 0:
-                continue
-            rl = d["record_len"]
-            rl = [int(v) for v in (rl.tolist() if hasattr(rl, "tolist") else rl)]
-            per_type[t] = rl
-            B = max(B, len(rl))
-        record_len, slots = [0] * B, {t: [] for t in per_type}
-        nxt = 0
-        for b in range(B):
-            for t in AGENT_TYPES:
-                if t in per_type and b < len(per_type[t]) and b in data_dict[t]["batch_idxs"]:
-                    k = per_type[t][b]
-                    slots[t] += list(range(nxt, nxt + k))
-                    nxt += k
-                    record_len[b] += k
-        return record_len, slots
+        return frame_layout(self.args["collaborators"], data_dict)
 
     def encode(self, data_dict, record_len, slots):
         n_total = sum(record_len)
