@@ -19,6 +19,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
     const float* in;
@@ -37,11 +38,14 @@ constexpr int BK = 32;
 constexpr int LDA = 36;
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(const ConvParams p) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int A_LD = BM / 32, B_LD = BN / 32;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    constexpr int NTHR = 64 * (BM / WM) * (BN / WN);  // 256 (4 waves) or 512 (8 waves)
+    constexpr int A_ROWS = NTHR / 8;                   // A rows staged per pass (8 threads x 16 B per row)
+    constexpr int A_LD = BM / A_ROWS, B_LD = 8 * BN / NTHR;
+    static_assert(NTHR == 256 || NTHR == 512, "4 or 8 waves per workgroup");
+    static_assert(A_LD >= 1 && B_LD >= 1 && BM % A_ROWS == 0 && (8 * BN) % NTHR == 0, "tile/threads mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BM*LDA]
     float* Bs = smem + 2 * BM * LDA;    // [2][8*BN*4]
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     int hi0[A_LD], wi0[A_LD], pix0[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int m = m0 + (tid >> 3) + 32 * i;
+        const int m = m0 + (tid >> 3) + A_ROWS * i;
         if (m < p.M) {
             const int img = m / p.HoWo, rem = m - img * p.HoWo;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -77,37 +81,46 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         }
     }
 
-    float4 ra[A_LD], rb[B_LD];
-    auto gload = [&](int tap, int cc) {
-        const int kh = tap / p.ks, kw = tap - kh * p.ks;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int hi = hi0[i] + kh, wi = wi0[i] + kw;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const size_t off = (size_t)(pix0[i] + hi * p.W + wi) * p.in_ctot + p.in_coff + cc * BK + qA * 4;
-                v = *reinterpret_cast<const float4*>(p.in + off);
-            }
-            ra[i] = v;
-        }
-        const size_t wrow = (size_t)(tap * (p.Cin >> 2) + cc * 8) * p.CoutP;
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int idx = tid + 256 * i;
-            const int k4 = idx / BN, n = idx - k4 * BN;
-            rb[i] = *reinterpret_cast<const float4*>(p.w + (wrow + (size_t)k4 * p.CoutP + n0 + n) * 4);
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* a = As + buf * (BM * LDA);
-        float* bq = Bs + buf * (8 * BN * 4);
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<float4*>(a + ((tid >> 3) + 32 * i) * LDA + qA * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4*>(bq + (tid + 256 * i) * 4) = rb[i];
-    };
+    // Register staging of the NEXT K-step (branch-free: out-of-image / out-of-range rows read a
+    // valid dummy address and are zeroed by a select, so every load is issued unconditionally and
+    // stays in flight behind the MFMAs of the current step).
+    f32x4 ra[A_LD], rb[B_LD];
+    unsigned okmask = 0;  // bit i: row i of this thread's A loads is inside the image (applied at the LDS store)
+    const float* __restrict__ gin = p.in + p.in_coff + qA * 4;
+    const float* __restrict__ gw = p.w + (size_t)n0 * 4;
+    // B tile: float4 #idx of the [8][BN] k-quad-major tile, idx = tid + 256*i -> row idx/BN, col idx%BN
+    constexpr int ROWS_PER_PASS = NTHR / BN > 0 ? NTHR / BN : 1;
+    const int bk0 = tid / BN, bn0 = (tid % BN) * 4;
+
+#define AV2X_GLOAD(TAP, CC)                                                                             \
+    {                                                                                                   \
+        const int kh_ = (TAP) / p.ks, kw_ = (TAP) - kh_ * p.ks;                                         \
+        okmask = 0;                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                              \
+            const int hi = hi0[i] + kh_, wi = wi0[i] + kw_;                                             \
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;               \
+            const int pix = ok ? (pix0[i] + hi * p.W + wi) : 0;                                         \
+            okmask |= (ok ? 1u : 0u) << i;                                                              \
+            ra[i] = *reinterpret_cast<const f32x4*>(gin + (size_t)pix * p.in_ctot + (CC)*BK);           \
+        }                                                                                               \
+        const size_t wrow_ = (size_t)((TAP) * (p.Cin >> 2) + (CC)*8) * p.CoutP * 4;                     \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) {                                              \
+            rb[i] = *reinterpret_cast<const f32x4*>(gw + wrow_ +                                        \
+                                                    (size_t)(bk0 + i * ROWS_PER_PASS) * p.CoutP * 4 + bn0); \
+        }                                                                                               \
+    }
+#define AV2X_LSTORE(BUF)                                                                                \
+    {                                                                                                   \
+        float* a_ = As + (BUF) * (BM * LDA);                                                            \
+        float* b_ = Bs + (BUF) * (8 * BN * 4);                                                          \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                              \
+            const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                      \
+            *reinterpret_cast<f32x4*>(a_ + ((tid >> 3) + A_ROWS * i) * LDA + qA * 4) =                  \
+                ((okmask >> i) & 1u) ? ra[i] : z_;                                                      \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                \
+            *reinterpret_cast<f32x4*>(b_ + (tid + NTHR * i) * 4) = rb[i];                               \
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -118,27 +131,30 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
     int tap = 0, cc = 0;
-    gload(tap, cc);
-    lstore(0);
+    AV2X_GLOAD(tap, cc);
+    AV2X_LSTORE(0);
     __syncthreads();
 
     const int li = lane & 31, lh = lane >> 5;
     for (int s = 0; s < p.steps; ++s) {
         const int buf = s & 1;
-        const bool more = (s + 1) < p.steps;
-        if (more) {
+        // prefetch step s+1 (the last iteration re-fetches the final tile: harmless, keeps the loop branch-free)
+        if (s + 1 < p.steps) {
             if (++cc == p.cchunks) { cc = 0; ++tap; }
-            gload(tap, cc);
         }
+        AV2X_GLOAD(tap, cc);
+        // pin the loads here: without this fence hipcc sinks them below the MFMAs (next to the
+        // ds_write that consumes them) and the whole L2/HBM latency is exposed every K-step
+        __builtin_amdgcn_sched_barrier(0);
         const float* Ab = As + buf * (BM * LDA) + (wm0 + li) * LDA + lh * 4;
         const float* Bb = Bs + buf * (8 * BN * 4) + (lh * BN + wn0 + li) * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 fa[MT], fb[NT];
+            f32x4 fa[MT], fb[NT];
 #pragma unroll
-            for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const float4*>(Ab + a * 32 * LDA + g * 8);
+            for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDA + g * 8);
 #pragma unroll
-            for (int c = 0; c < NT; ++c) fb[c] = *reinterpret_cast<const float4*>(Bb + (g * 2 * BN + c * 32) * 4);
+            for (int c = 0; c < NT; ++c) fb[c] = *reinterpret_cast<const f32x4*>(Bb + (g * 2 * BN + c * 32) * 4);
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -149,9 +165,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[c].w, acc[a][c], 0, 0, 0);
                 }
         }
-        if (more) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AV2X_LSTORE(buf ^ 1);
         __syncthreads();
     }
+#undef AV2X_GLOAD
+#undef AV2X_LSTORE
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -202,7 +221,8 @@ int launch(const ConvParams& p, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), dim3(tiles_m * q.tiles_n), dim3(256), lds, st, q);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), dim3(tiles_m * q.tiles_n), dim3(64 * (BM / WM) * (BN / WN)), lds,
+                       st, q);
     return av2x::check_launch("conv_igemm_f32");
 }
 
@@ -241,7 +261,8 @@ extern "C" int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float
     p.tiles_n = 0;
     hipStream_t st = av2x::as_stream(stream);
 
-    int bm = d->tile >> 16, bn = d->tile & 0xffff;
+    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x7fff;
+    const bool w8 = (d->tile & 0x8000) != 0;  // 8-wave (512-thread) variant of the same tile
     if (d->tile == 0) {
         // Heuristic: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).
         bn = (p.CoutP % 128 == 0) ? 128 : (p.CoutP % 64 == 0 ? 64 : 32);
@@ -251,6 +272,12 @@ extern "C" int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float
         if (bn == 64 && wgs(128, 64) < 512) { bm = 64; }
     }
     if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
+    if (w8) {
+        if (bm == 128 && bn == 128) return launch<128, 128, 64, 32>(p, st);
+        if (bm == 128 && bn == 64) return launch<128, 64, 32, 32>(p, st);
+        if (bm == 256 && bn == 128) return launch<256, 128, 64, 64>(p, st);
+        return av2x::fail("av2x_conv2d: unsupported 8-wave tile %dx%d", bm, bn);
+    }
     if (bm == 128 && bn == 128) return launch<128, 128, 64, 64>(p, st);
     if (bm == 128 && bn == 64) return launch<128, 64, 64, 32>(p, st);
     if (bm == 64 && bn == 64) return launch<64, 64, 32, 32>(p, st);

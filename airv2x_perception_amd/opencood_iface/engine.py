@@ -89,7 +89,9 @@ class Where2ComEngine:
         self.A, self.C = args["anchor_number"], args["num_class"]
         self.ws = {}
         self.weights_ready = False
-        self.conv_tile = 0          # 0 = pick_tile(); else forced BM<<16|BN (tests / tuning)
+        self.conv_tile = 0          # 0 = autotune / pick_tile(); else forced BM<<16|BN (tests / tuning)
+        self.autotune = True        # time the candidate tiles once per distinct conv shape, keep the fastest
+        self.tile_cache = {}
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1) per conv launch (bench roofline pass)
@@ -211,10 +213,18 @@ class Where2ComEngine:
         d.out_coff = out_coff
         d.ks, d.stride, d.pad, d.relu, d.mode, d.up = L.ks, L.stride, L.pad, L.relu, L.mode, L.up
         if self.conv_tile:
-            bm, bn = self.conv_tile >> 16, self.conv_tile & 0xffff
+            d.tile = self.conv_tile
+        elif self.autotune:
+            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride)
+            t = self.tile_cache.get(key)
+            if t is None:
+                t = self._tune(d, x, L, out)
+                self.tile_cache[key] = t
+            d.tile = t
         else:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
-        d.tile = (bm << 16) | bn
+            d.tile = (bm << 16) | bn
+        bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -226,6 +236,32 @@ class Where2ComEngine:
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
             self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1))
         return ho, wo
+
+    TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000), (128, 32))
+
+    def _tune(self, d, x, L, out):
+        """Pick the fastest workgroup tile for this conv shape (all tiles give bit-identical results:
+        the K order of every output element does not depend on the tile).  Runs outside graph capture."""
+        if torch.cuda.is_current_stream_capturing():
+            bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
+            return (bm << 16) | bn
+        best, best_t = None, float("inf")
+        args = (_ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(out), self.stream())
+        for bm, bn in self.TILE_CANDIDATES:
+            if L.coutp % (bn & 0x7fff) or ((bn & 0x7fff) == 32 and L.coutp != 32):
+                continue
+            d.tile = (bm << 16) | bn
+            _lib.check(self.lib.av2x_conv2d(byref(d), *args), "av2x_conv2d")  # warm-up (module load, L2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                _lib.check(self.lib.av2x_conv2d(byref(d), *args), "av2x_conv2d")
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = d.tile, t
+        return best
 
     def run_block(self, i, x, n, h, w, tag):
         """backbone.blocks[i] on n images; returns (buffer, ho, wo)."""

@@ -163,11 +163,11 @@ def main():
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": f"conv_igemm_f32<{dom[0]},{dom[1]}>", "launches_per_frame": cnt / a.steps,
+            "kernel": f"conv_igemm_f32<{dom[0]},{dom[1] & 0x7fff}>" + (" 8-wave" if dom[1] & 0x8000 else ""), "launches_per_frame": cnt / a.steps,
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},
-            "per_tile": {f"{k[0]}x{k[1]}": {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
+            "per_tile": {f"{k[0]}x{k[1] & 0x7fff}{'w8' if k[1] & 0x8000 else ''}": {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
                                             "ms_per_frame": round(v[2] / a.steps * 1e3, 3)} for k, v in per.items()},
             "timing": "second pass of K steps, hipEvent pair around every conv launch on the launch stream",
         }
