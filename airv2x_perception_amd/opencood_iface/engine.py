@@ -263,15 +263,17 @@ class Where2ComEngine:
                 best, best_t = d.tile, t
         return best
 
-    def run_block(self, i, x, n, h, w, tag):
-        """backbone.blocks[i] on n images; returns (buffer, ho, wo)."""
+    def run_block(self, i, x, n, h, w, tag, out=None):
+        """backbone.blocks[i] on n images; returns (buffer, ho, wo).  ``out``: write the block's
+        result into this (n,ho,wo,c) buffer (e.g. a slice of the all-gather send buffer)."""
         layers = self.blocks[i]
         c = layers[0].cout
         ho = (h + 2 - 3) // layers[0].stride + 1
         wo = (w + 2 - 3) // layers[0].stride + 1
         ping = self.buf(f"blk{i}_ping_{tag}", (n, ho, wo, c))
         pong = self.buf(f"blk{i}_pong_{tag}", (n, ho, wo, c))
-        out = self.buf(f"blk{i}_out_{tag}", (n, ho, wo, c))
+        if out is None:
+            out = self.buf(f"blk{i}_out_{tag}", (n, ho, wo, c))
         cur, ch, cw = x, h, w
         for li, L in enumerate(layers):
             dst = out if li == len(layers) - 1 else (ping if li % 2 == 0 else pong)
@@ -326,12 +328,12 @@ class Where2ComEngine:
                                                         _ptr(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter")
         return canvas, ny, nx
 
-    def trunk(self, canvas, n, ny, nx, tag="all"):
+    def trunk(self, canvas, n, ny, nx, tag="all", block_out=None):
         """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""
         feats = []
         x, h, w = canvas, ny, nx
         for i in range(len(self.blocks)):
-            x, h, w = self.run_block(i, x, n, h, w, tag)
+            x, h, w = self.run_block(i, x, n, h, w, tag, out=(block_out or {}).get(i))
             feats.append((x, h, w))
         H, W = feats[0][1] * self.deblocks[0].up, feats[0][2] * self.deblocks[0].up
         cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c))
@@ -339,15 +341,15 @@ class Where2ComEngine:
         s = self.run_shrink(cat, n, H, W, tag) if self.shrink else cat
         return feats, s, H, W
 
-    def comm_mask(self, psm_single, n, H, W, record_len):
+    def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True):
         B = len(record_len)
-        key = ("layout", tuple(record_len))
+        key = ("layout", tuple(record_len), has_ego)
         lay = self.ws.get(key)
         if lay is None:
             samp, ego = [], []
             for b, k in enumerate(record_len):
                 samp += [b] * k
-                ego += [1] + [0] * (k - 1) if k > 0 else []
+                ego += [1 if has_ego else 0] + [0] * (k - 1) if k > 0 else []
             lay = (torch.tensor(samp, dtype=torch.int32, device=self.device),
                    torch.tensor(ego, dtype=torch.int32, device=self.device),
                    torch.tensor(record_len, dtype=torch.float32, device=self.device))
@@ -489,3 +491,83 @@ class Where2ComEngine:
             trace["fused_2d"] = catf.permute(0, 3, 1, 2).clone()
             trace["fused_shrink"] = fs.permute(0, 3, 1, 2).clone()
         return heads, com, nz
+
+    # ------------------------------------------------------------------ agent-sharded frame (one frame over N GPUs)
+    def level_dims(self, ny, nx):
+        dims, h, w = [], ny, nx
+        for layers in self.blocks:
+            h, w = (h + 2 - 3) // layers[0].stride + 1, (w + 2 - 3) // layers[0].stride + 1
+            dims.append((h, w, layers[0].cout))
+        return dims
+
+    @torch.no_grad()
+    def shard_local_stage(self, data_dict_local, has_ego):
+        """Per-rank half of an agent-sharded frame: encode + trunk + confidence mask +
+        masked blocks for THIS rank's agents, written straight into the all-gather send buffer
+        [level0: n_loc maps | level1 | level2] (15.77 MB per agent at the default grid).
+        Returns (send flat f32, stats int64[2] = [mask ones before ego override, canvas non-zeros], meta)."""
+        if self.fcfg["fully"]:
+            raise NotImplementedError("agent sharding with fully-connected communication")
+        record_len, slots = self.frame_layout(data_dict_local)
+        if len(record_len) != 1:
+            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
+        n = record_len[0]
+        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        st = self.stream()
+        nz = self.buf("nonzero", (1,), torch.int64)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        dims = self.level_dims(ny, nx)
+        sizes = [h * w * c for h, w, c in dims]
+        send = self.buf("shard_send", (n * sum(sizes),))
+        lv, off = [], 0
+        for (h, w, c), f in zip(dims, sizes):
+            lv.append(send[off:off + n * f].view(n, h, w, c))
+            off += n * f
+        feats, s, H, W = self.trunk(canvas, n, ny, nx, block_out={0: lv[0]})
+        psm_single = self.buf("psm_single", (n, H, W, self.A * self.C))
+        self.conv(self.cls_single, s, n, H, W, psm_single)
+        mask, count, _, _ = self.comm_mask(psm_single, n, H, W, record_len, has_ego=has_ego)
+        (b0, h0, w0), (b1, h1, w1), (b2, h2, w2) = feats
+        _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask")
+        first = 1 if has_ego else 0
+        if n - first > 0:
+            m1, _, _ = self.run_block(1, b0[first:], n - first, h0, w0, "masked", out=lv[1][first:])
+            self.run_block(2, m1, n - first, h1, w1, "masked", out=lv[2][first:])
+        if has_ego:  # the ego's mask is all ones: its "masked" features are the unmasked ones
+            lv[1][0].copy_(b1[0])
+            lv[2][0].copy_(b2[0])
+        stats = torch.stack([count.sum().to(torch.int64), nz[0]])
+        return send, stats, {"dims": dims, "n_loc": n, "H": H, "W": W}
+
+    @torch.no_grad()
+    def shard_ego_stage(self, recv, stats, meta, world, sync_comm_rate=False):
+        """Ego half: per-pixel attention over all N = world * n_loc gathered agents (pointer
+        arithmetic into the all-gather buffer, no regroup copy), deblocks, shrink, heads."""
+        dims, n_loc, H, W = meta["dims"], meta["n_loc"], meta["H"], meta["W"]
+        sizes = [h * w * c for h, w, c in dims]
+        per_rank = n_loc * sum(sizes)
+        if recv.numel() != world * per_rank:
+            raise ValueError("gathered buffer has the wrong size")
+        base = recv.data_ptr()
+        fused, off = [], 0
+        for i, ((h, w, c), f) in enumerate(zip(dims, sizes)):
+            out = self.buf(f"fused{i}", (1, h, w, c))
+            ptrs = [base + 4 * (r * per_rank + off + j * f) for r in range(world) for j in range(n_loc)]
+            self.attn(ptrs, h * w, c, out[0])
+            fused.append((out, h, w))
+            off += n_loc * f
+        catf = self.buf("cat_fused", (1, H, W, self.cat_c))
+        self.run_deblocks(fused, 1, catf)
+        fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
+        heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fs, 1, H, W, heads)
+        outs = torch.split(heads, self.head_splits, dim=1)
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        n_total = world * n_loc
+        com = stats[0].to(torch.float32) / float(n_total * H * W)
+        comm_rate = int(stats[1].item()) if sync_comm_rate else stats[1]
+        out.update({"mask": 0, "com": com, "comm_rate": comm_rate})
+        return out

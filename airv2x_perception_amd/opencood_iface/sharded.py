@@ -1,0 +1,63 @@
+"""Agent-sharded collaborative frame: the agents of ONE frame are split over the ranks of a
+``torch.distributed`` group (one process per GPU; backend "nccl" = RCCL over xGMI), and the
+reference's in-process "communication" — ``Airv2xBase.merge_output_dict_list`` / ``regroup``
+(models/common_modules/airv2x_base_model.py:250-283, models/where2comm_modules/where2comm_fuse.py:193-196)
+— becomes ONE all-gather of each rank's masked multi-scale feature maps.
+
+The compute is delegated to a *backend* with two methods (``Where2ComEngine`` implements them on
+the GPU; the gloo/CPU tests plug in an oracle-based backend to exercise exactly this file):
+
+    local_stage(data_dict_local, has_ego) -> (send: flat f32 tensor, stats: int64[2], meta)
+    ego_stage(recv: flat f32 tensor [world * send.numel()], stats, meta, world) -> output dict
+
+Agent order: the global frame order is [vehicles.., rsus.., drones..] with the ego = vehicle 0
+(intermediate_fusion_dataset.py:129-134); rank r owns the contiguous global slice
+``partition_agents(n, world)[r]``, so the ego is always local agent 0 of rank 0 and the gathered
+buffer is already in frame order (rank-major = agent-major).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def partition_agents(n_agents, world):
+    """Contiguous equal slices (all_gather needs equal counts): n_agents % world must be 0."""
+    if n_agents % world != 0 or n_agents < world:
+        raise ValueError(f"{n_agents} agents cannot be sharded evenly over {world} ranks")
+    k = n_agents // world
+    return [range(r * k, (r + 1) * k) for r in range(world)]
+
+
+class ShardedFrame:
+    def __init__(self, backend, group=None):
+        self.backend = backend
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    @torch.no_grad()
+    def forward(self, data_dict_local, **kw):
+        send, stats, meta = self.backend.local_stage(data_dict_local, has_ego=(self.rank == 0))
+        if self.world == 1:
+            recv = send
+        else:
+            recv = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
+            # the feature-sharing step: every rank contributes 15.77 MB per agent (default grid);
+            # xGMI is point-to-point, so the 7 peer transfers into each GPU run on separate links
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+        return self.backend.ego_stage(recv, stats, meta, self.world, **kw)
+
+
+class EngineBackend:
+    """Adapter: Where2ComEngine as the ShardedFrame backend."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def local_stage(self, data_dict_local, has_ego):
+        return self.engine.shard_local_stage(data_dict_local, has_ego)
+
+    def ego_stage(self, recv, stats, meta, world, **kw):
+        return self.engine.shard_ego_stage(recv, stats, meta, world, **kw)

@@ -59,10 +59,13 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the frame from a captured HIP graph (1) or eager (0)")
+    ap.add_argument("--mode", choices=["replica", "shard"], default="replica",
+                    help="replica: every GPU runs its own frames (default, weak scaling); shard: ONE frame's agents are "
+                         "split over the GPUs with an RCCL all-gather of the masked features (SURVEY 8e, strong scaling)")
     return ap.parse_args()
 
 
-def build_inputs(n_agents, n_points, device):
+def build_inputs(n_agents, n_points, device, only=None):
     from airv2x_perception_amd import synth
     from airv2x_perception_amd.opencood_iface.voxelizer import voxelize_points
     hy = synth.default_hypes()
@@ -71,6 +74,9 @@ def build_inputs(n_agents, n_points, device):
     types = synth.agent_types_for(n_agents)
     order, types_sorted = synth.sort_types(types)
     clouds = [synth.synthetic_cloud(i, n_points) for i in range(n_agents)]
+    if only is not None:  # agent-sharded mode: this rank's contiguous slice of the frame order
+        order = [order[j] for j in only]
+        types_sorted = [types_sorted[j] for j in only]
     voxd = []
     for i in order:
         pts = torch.from_numpy(clouds[i]).to(device)
@@ -99,14 +105,24 @@ def main():
     from airv2x_perception_amd import synth
     from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
 
-    hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev)
+    if a.mode == "shard":
+        from airv2x_perception_amd.opencood_iface.sharded import EngineBackend, ShardedFrame, partition_agents
+        mine = list(partition_agents(a.agents, world)[rank])
+    else:
+        mine = None
+    hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev, only=mine)
     sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
     model = Airv2xWhere2com(args)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.sync_comm_rate = False  # no host sync inside the frame; comm_rate stays a device scalar
     eng = model.engine()
-    eng.use_graph = bool(a.graph)
+    eng.use_graph = bool(a.graph) and a.mode == "replica"
+    if a.mode == "shard":
+        frame = ShardedFrame(EngineBackend(eng))
+        step = lambda: frame.forward(dd)
+    else:
+        step = lambda: model(dd)
 
     def barrier():
         if dist is not None:
@@ -115,11 +131,11 @@ def main():
 
     out = None
     for _ in range(a.warmup):
-        out = model(dd)
+        out = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = model(dd)
+        out = step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -127,22 +143,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / a.steps * 1e3
-    fps = world * a.steps / dt
+    fps = (world if a.mode == "replica" else 1) * a.steps / dt
 
     res = {
-        "metric": "collaborative frames/sec, Where2Comm-LiDAR 4-agent",
+        "metric": f"collaborative frames/sec, Where2Comm-LiDAR {a.agents}-agent",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Where2Comm-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
-                               f"psm/rm/obj out; BASELINE.json configs[1]",
-                   "parallelism": "independent frames per GPU (replicas)" if world > 1 else "single GPU",
+                               f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
+                   "parallelism": ("single GPU" if world == 1 else "independent frames per GPU (replicas)") if a.mode == "replica"
+                   else f"one frame, {a.agents // world} agent(s) per GPU, RCCL all-gather of masked multi-scale features",
                    "launch": "hipGraph replay" if eng.graph_active() else "eager"},
     }
 
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline and rank == 0 and a.mode == "replica":
         eng.use_graph = False
         eng.profile = []
         for _ in range(a.steps):
@@ -173,7 +191,7 @@ def main():
         }
 
     # ---------------- CPU baseline: the oracle port on the host cores (bounded sample) ---------------------
-    if a.cpu_frames > 0 and rank == 0 and world == 1:
+    if a.cpu_frames > 0 and rank == 0 and world == 1 and a.mode == "replica":
         from oracle import where2comm_oracle as orc
         dd_cpu = synth.data_dict_to(dd, "cpu")
         torch.set_num_threads(usable_cores())

@@ -1,0 +1,134 @@
+"""CPU, world_size 2, gloo: the agent-sharded frame protocol (opencood_iface/sharded.py) —
+partitioning, ego placement, the all-gather that replaces the reference's in-process concat and
+the stats all-reduce — driven with an oracle-based backend (the HIP engine implements the same
+two-method backend interface on the GPU; see test_gpu_sharded.py for that side)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from airv2x_perception_amd import synth
+from airv2x_perception_amd.opencood_iface.sharded import ShardedFrame, partition_agents
+from oracle import voxelize_oracle as vox
+from oracle import where2comm_oracle as orc
+
+RNG = [-12.8, -6.4, -3.0, 12.8, 6.4, 1.0]
+TYPES = ["vehicle", "vehicle", "rsu", "drone"]
+
+
+class OracleBackend:
+    """The two-stage backend interface of ShardedFrame on CPU tensors (NCHW, oracle functions)."""
+
+    def __init__(self, sd, args):
+        self.sd, self.args = sd, args
+
+    def local_stage(self, dd_local, has_ego):
+        sd, args = self.sd, self.args
+        mf = args["modality_fusion"]
+        feats, record_len = orc.extract_features(dd_local, sd, args)
+        sf2d, blocks = orc.backbone_forward(feats, sd, mf["base_bev_backbone"])
+        s = orc.shrink_conv(sf2d, sd, mf["shrink_header"])
+        psm_single = orc.head(s, sd, "cls_head")
+        masks, _, maps = orc.communication([psm_single], sd, args["where2com_fusion"]["communication"])
+        thr = args["where2com_fusion"]["communication"]["threshold"]
+        ones = (maps > thr)
+        if not has_ego:
+            masks = ones.float()  # no ego on this rank: nothing is forced to 1
+        x0 = blocks[0] * masks
+        x1 = orc.backbone_block(x0, sd, 1, mf["base_bev_backbone"]["layer_nums"][1])
+        x2 = orc.backbone_block(x1, sd, 2, mf["base_bev_backbone"]["layer_nums"][2])
+        send = torch.cat([x0.reshape(-1), x1.reshape(-1), x2.reshape(-1)])
+        stats = torch.tensor([int(ones.sum()), int(feats.count_nonzero())], dtype=torch.int64)
+        return send, stats, {"shapes": [tuple(x0.shape), tuple(x1.shape), tuple(x2.shape)]}
+
+    def ego_stage(self, recv, stats, meta, world):
+        sd, args = self.sd, self.args
+        mf = args["modality_fusion"]
+        per_rank = recv.numel() // world
+        levels = [[], [], []]
+        for r in range(world):
+            chunk, off = recv[r * per_rank:(r + 1) * per_rank], 0
+            for i, shp in enumerate(meta["shapes"]):
+                n = int(np.prod(shp))
+                levels[i].append(chunk[off:off + n].view(shp))
+                off += n
+        ups = []
+        for i in range(3):
+            x = torch.cat(levels[i], 0)
+            f = orc.attention_fusion(x).unsqueeze(0)
+            ups.append(orc.backbone_deblock(f, sd, i, mf["base_bev_backbone"]["upsample_strides"][i]))
+        fs = orc.shrink_conv(torch.cat(ups, 1), sd, mf["shrink_header"])
+        n_total = sum(t.shape[0] for t in levels[0])
+        H, W = levels[0][0].shape[-2:]
+        return {"psm": orc.head(fs, sd, "cls_head"), "rm": orc.head(fs, sd, "reg_head"), "obj": orc.head(fs, sd, "obj_head"),
+                "com": stats[0].float() / (n_total * H * W), "comm_rate": int(stats[1])}
+
+
+def _frame():
+    hy = synth.default_hypes(RNG)
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, 400, RNG), RNG), RNG, [0.4, 0.4, 4.0])
+            for i in range(len(TYPES))]
+    return args, sd, voxd
+
+
+def _worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    args, sd, voxd = _frame()
+    mine = partition_agents(len(TYPES), world)[rank]
+    dd_local = synth.build_data_dict([voxd[i] for i in mine], [TYPES[i] for i in mine])
+    with torch.no_grad():
+        out = ShardedFrame(OracleBackend(sd, args)).forward(dd_local)
+    # every rank ends with the same fused result (SPMD)
+    gathered = [torch.empty_like(out["psm"]) for _ in range(world)]
+    dist.all_gather(gathered, out["psm"])
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+    if rank == 0:
+        torch.save({k: out[k] for k in ("psm", "rm", "obj", "com", "comm_rate")}, result_path)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_agent_sharded_frame_equals_single_process(tmp_path):
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = torch.load(path)
+    args, sd, voxd = _frame()
+    dd = synth.build_data_dict(voxd, TYPES)
+    with torch.no_grad():
+        ref = orc.where2com_forward(dd, sd, args)
+    for k in ("psm", "rm", "obj"):
+        assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), k
+    assert got["comm_rate"] == ref["comm_rate"]
+    assert abs(float(got["com"]) - float(ref["com"])) < 1e-6
+
+
+def test_partition_agents():
+    assert [list(r) for r in partition_agents(8, 4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert [list(r) for r in partition_agents(4, 1)] == [[0, 1, 2, 3]]
+    with pytest.raises(ValueError):
+        partition_agents(5, 2)
+    with pytest.raises(ValueError):
+        partition_agents(1, 2)
+
+
+def test_single_rank_needs_no_process_group():
+    args, sd, voxd = _frame()
+    dd = synth.build_data_dict(voxd, TYPES)
+    with torch.no_grad():
+        out = ShardedFrame(OracleBackend(sd, args)).forward(dd)
+        ref = orc.where2com_forward(dd, sd, args)
+    assert torch.allclose(out["rm"], ref["rm"], rtol=1e-5, atol=1e-5)
