@@ -1,0 +1,331 @@
+// On-device detection post-processing, replacing the torch + shapely host loop
+// of VoxelPostprocessor.post_process_airv2x (data_utils/post_processor/voxel_postprocessor.py:666-839)
+// and box_utils.nms_rotated (utils/box_utils.py:823-868):
+//
+//   pp_flag      per anchor : objectness = sigmoid(obj), flag = objectness > obj_threshold
+//   pp_scan      1 workgroup: order-preserving compaction of flagged anchors (masked_select order)
+//   pp_decode    per candidate: class label, delta->box (delta_to_boxes3d :585-634), 8 corners
+//                (boxes_to_corners_3d), projection by T, size / z-range keep flag
+//   pp_scan2     compaction of kept candidates
+//   pp_rank      rank by score (descending, ties: higher index first = argsort()[::-1]), top-K order
+//   pp_iou_mask  rotated-quad IoU > threshold bit matrix over the ordered top-K (fp64 Sutherland-Hodgman)
+//   pp_greedy    1 workgroup: the sequential greedy pick over the bit matrix (rows staged in LDS)
+//   pp_final     range filter (all 8 corners inside [xmin,xmax]x[ymin,ymax]) + compaction, gather outputs
+//
+// Every count stays on the device; the host reads back one integer (n_out) at the end.
+#include "av2x_common.hpp"
+#include "block_scan.hpp"
+
+namespace {
+
+struct PPParams {
+    int H, W, A, C;
+    float obj_thr, nms_thr;
+    float zmin, zmax, xmin, xmax, ymin, ymax;
+    float T[16];
+    int order_hwl, top;
+};
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void pp_flag(const float* __restrict__ obj, PPParams p, float* __restrict__ score, int* __restrict__ flag) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NA = p.H * p.W * p.A;
+    if (n >= NA) return;
+    const int a = n % p.A, hw = n / p.A;
+    const float s = sigmoidf(obj[(size_t)a * p.H * p.W + hw]);  // obj is (1,A,H,W); n = (h*W+w)*A + a
+    score[n] = s;
+    flag[n] = s > p.obj_thr;
+}
+
+__global__ __launch_bounds__(1024) void pp_scan(const int* __restrict__ flag, int n, int* __restrict__ idx_out,
+                                                int* __restrict__ count) {
+    __shared__ int tot;
+    av2x::block_scan(n, [&](int i) { return flag[i]; }, [&](int i, int ex) { if (flag[i]) idx_out[ex] = i; }, &tot);
+    __syncthreads();
+    if (threadIdx.x == 0) count[0] = tot;
+}
+
+__global__ void pp_decode(const float* __restrict__ psm, const float* __restrict__ rm, const float* __restrict__ anchors,
+                          const float* __restrict__ score, const int* __restrict__ cand, const int* __restrict__ ncand,
+                          PPParams p, float* __restrict__ boxes, float* __restrict__ corners, float* __restrict__ cscore,
+                          int* __restrict__ label, int* __restrict__ keep) {
+    const int K = ncand[0];
+    const int HW = p.H * p.W;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int n = cand[k];
+        const int a = n % p.A, hw = n / p.A;
+        // class label: psm viewed (C, A, H, W) -> channel c*A + a; classes 1..C-1, first maximum wins
+        int best = 1;
+        float bv = sigmoidf(psm[(size_t)(1 * p.A + a) * HW + hw]);
+        for (int c = 2; c < p.C; ++c) {
+            const float v = sigmoidf(psm[(size_t)(c * p.A + a) * HW + hw]);
+            if (v > bv) { bv = v; best = c; }
+        }
+        label[k] = best;
+        cscore[k] = score[n];
+        float d[7], an[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            d[j] = rm[(size_t)(a * 7 + j) * HW + hw];  // rm (1, A*7, H, W)
+            an[j] = anchors[(size_t)n * 7 + j];
+        }
+        const float diag = sqrtf(__fadd_rn(__fmul_rn(an[4], an[4]), __fmul_rn(an[5], an[5])));
+        float b[7];
+        b[0] = __fadd_rn(__fmul_rn(d[0], diag), an[0]);
+        b[1] = __fadd_rn(__fmul_rn(d[1], diag), an[1]);
+        b[2] = __fadd_rn(__fmul_rn(d[2], an[3]), an[2]);
+        b[3] = __fmul_rn(expf(d[3]), an[3]);
+        b[4] = __fmul_rn(expf(d[4]), an[4]);
+        b[5] = __fmul_rn(expf(d[5]), an[5]);
+        b[6] = __fadd_rn(d[6], an[6]);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) boxes[(size_t)k * 7 + j] = b[j];
+        // corners: dims (l, w, h) = hwl reordered (box_utils.py:239-240), template / 2, rotate about z
+        const float l = p.order_hwl ? b[5] : b[3], w = b[4], h = p.order_hwl ? b[3] : b[5];
+        const float ca = cosf(b[6]), sa = sinf(b[6]);
+        const float tx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, ty[8] = {-1, 1, 1, -1, -1, 1, 1, -1}, tz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+        float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float px = __fmul_rn(l, tx[c] * 0.5f), py = __fmul_rn(w, ty[c] * 0.5f), pz = __fmul_rn(h, tz[c] * 0.5f);
+            // points @ [[cos, sin, 0], [-sin, cos, 0], [0, 0, 1]]
+            const float rx = __fadd_rn(__fmul_rn(px, ca), __fmul_rn(py, -sa)) + b[0];
+            const float ry = __fadd_rn(__fmul_rn(px, sa), __fmul_rn(py, ca)) + b[1];
+            const float rz = pz + b[2];
+            // T @ [x y z 1]^T
+            const float qx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p.T[0], rx), __fmul_rn(p.T[1], ry)), __fmul_rn(p.T[2], rz)), p.T[3]);
+            const float qy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p.T[4], rx), __fmul_rn(p.T[5], ry)), __fmul_rn(p.T[6], rz)), p.T[7]);
+            const float qz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p.T[8], rx), __fmul_rn(p.T[9], ry)), __fmul_rn(p.T[10], rz)), p.T[11]);
+            corners[(size_t)k * 24 + c * 3 + 0] = qx;
+            corners[(size_t)k * 24 + c * 3 + 1] = qy;
+            corners[(size_t)k * 24 + c * 3 + 2] = qz;
+            xmn = fminf(xmn, qx); xmx = fmaxf(xmx, qx);
+            ymn = fminf(ymn, qy); ymx = fmaxf(ymx, qy);
+            zmn = fminf(zmn, qz); zmx = fmaxf(zmx, qz);
+        }
+        // remove_large_pred_bbx (z_len used as a truth value, box_utils.py:1011-1012) & remove_bbx_abnormal_z
+        const bool k1 = (xmx - xmn) <= 6.f && (ymx - ymn) <= 6.f && (zmx - zmn) != 0.f;
+        const bool k2 = zmn >= p.zmin && zmx <= p.zmax;
+        keep[k] = (k1 && k2) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void pp_scan2(const int* __restrict__ keep, const int* __restrict__ ncand,
+                                                 int* __restrict__ kept, int* __restrict__ nkept) {
+    __shared__ int tot;
+    const int K = ncand[0];
+    av2x::block_scan(K, [&](int i) { return keep[i]; }, [&](int i, int ex) { if (keep[i]) kept[ex] = i; }, &tot);
+    __syncthreads();
+    if (threadIdx.x == 0) nkept[0] = tot;
+}
+
+// order[r] = position (in the kept list) of the r-th best score; ties -> higher position first
+__global__ void pp_rank(const float* __restrict__ cscore, const int* __restrict__ kept, const int* __restrict__ nkept,
+                        int top, int* __restrict__ order, int* __restrict__ ntop) {
+    const int K2 = nkept[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ntop[0] = K2 < top ? K2 : top;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K2; i += gridDim.x * blockDim.x) {
+        const float si = cscore[kept[i]];
+        int r = 0;
+        for (int j = 0; j < K2; ++j) {
+            const float sj = cscore[kept[j]];
+            r += (sj > si) || (sj == si && j > i);
+        }
+        if (r < top) order[r] = i;
+    }
+}
+
+struct P2 { double x, y; };
+
+__device__ int clip_edge(const P2* in, int n, P2 a, P2 b, P2* out) {
+    int m = 0;
+    const double ex = b.x - a.x, ey = b.y - a.y;
+    for (int i = 0; i < n; ++i) {
+        const P2 cur = in[i], nxt = in[(i + 1 == n) ? 0 : i + 1];
+        const double dc = ex * (cur.y - a.y) - ey * (cur.x - a.x);
+        const double dn = ex * (nxt.y - a.y) - ey * (nxt.x - a.x);
+        if (dc >= 0.0) out[m++] = cur;
+        if ((dc >= 0.0) != (dn >= 0.0)) {
+            const double t = dc / (dc - dn);
+            out[m].x = cur.x + t * (nxt.x - cur.x);
+            out[m].y = cur.y + t * (nxt.y - cur.y);
+            ++m;
+        }
+    }
+    return m;
+}
+
+__device__ double poly_area(const P2* p, int n) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const P2 u = p[i], v = p[(i + 1 == n) ? 0 : i + 1];
+        a += u.x * v.y - v.x * u.y;
+    }
+    return 0.5 * a;
+}
+
+__device__ double quad_iou(const float* ca, const float* cb) {
+    P2 a[4], b[4], b1[12], b2[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i].x = ca[i * 3]; a[i].y = ca[i * 3 + 1];
+        b[i].x = cb[i * 3]; b[i].y = cb[i * 3 + 1];
+    }
+    double aa = poly_area(a, 4), ab = poly_area(b, 4);
+    if (aa < 0) { const P2 t = a[1]; a[1] = a[3]; a[3] = t; aa = -aa; }
+    if (ab < 0) { const P2 t = b[1]; b[1] = b[3]; b[3] = t; ab = -ab; }
+    int n = 4;
+    P2* src = b1; P2* dst = b2;
+    for (int i = 0; i < 4; ++i) src[i] = a[i];
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        n = clip_edge(src, n, b[e], b[(e + 1) & 3], dst);
+        P2* t = src; src = dst; dst = t;
+    }
+    const double inter = n >= 3 ? fabs(poly_area(src, n)) : 0.0;
+    const double uni = aa + ab - inter;
+    return uni > 0.0 ? inter / uni : 0.0;
+}
+
+// bit (i, j) for j > i : iou(order[i], order[j]) > thr (rounded to fp32 first, common_utils.py:174)
+__global__ void pp_iou_mask(const float* __restrict__ corners, const int* __restrict__ kept, const int* __restrict__ order,
+                            const int* __restrict__ ntop, float thr, int words, unsigned long long* __restrict__ mask) {
+    const int m = ntop[0];
+    const int i = blockIdx.y;
+    const int jw = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (row, column): 64 threads = one word
+    const int j = jw;
+    if (i >= m) return;
+    bool bit = false;
+    if (j < m && j > i) {
+        const float* ca = corners + (size_t)kept[order[i]] * 24;
+        const float* cb = corners + (size_t)kept[order[j]] * 24;
+        bit = (float)quad_iou(ca, cb) > thr;
+    }
+    const unsigned long long bal = __ballot(bit);
+    if ((threadIdx.x & 63) == 0 && (j >> 6) < words) mask[(size_t)i * words + (j >> 6)] = bal;
+}
+
+__global__ __launch_bounds__(1024) void pp_greedy(const unsigned long long* __restrict__ mask, const int* __restrict__ ntop,
+                                                  int words, int staged, int* __restrict__ pick, int* __restrict__ npick) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];  // [m][words] when it fits (staged)
+    __shared__ volatile unsigned long long removed[64];
+    const int m = ntop[0];
+    if (staged)
+        for (int i = threadIdx.x; i < m * words; i += blockDim.x) rows[i] = mask[i];
+    if (threadIdx.x < 64) removed[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {  // one wave does the inherently sequential pass
+        int np = 0;
+        for (int i = 0; i < m; ++i) {
+            const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;
+            if (!dead) {
+                if (threadIdx.x == 0) pick[np] = i;
+                ++np;
+                if ((int)threadIdx.x < words)
+                    removed[threadIdx.x] |= staged ? rows[(size_t)i * words + threadIdx.x] : mask[(size_t)i * words + threadIdx.x];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (threadIdx.x == 0) npick[0] = np;
+    }
+}
+
+__global__ __launch_bounds__(1024) void pp_final(const float* __restrict__ boxes, const float* __restrict__ corners,
+                                                 const float* __restrict__ cscore, const int* __restrict__ label,
+                                                 const int* __restrict__ kept, const int* __restrict__ order,
+                                                 const int* __restrict__ pick, const int* __restrict__ npick, PPParams p,
+                                                 int* __restrict__ inr, float* __restrict__ out_corners,
+                                                 float* __restrict__ out_scores, int* __restrict__ out_labels,
+                                                 float* __restrict__ out_boxes, int* __restrict__ out_index,
+                                                 const int* __restrict__ cand, int* __restrict__ nout) {
+    __shared__ int tot;
+    const int np = npick[0];
+    for (int q = threadIdx.x; q < np; q += blockDim.x) {
+        const float* c = corners + (size_t)kept[order[pick[q]]] * 24;
+        bool ok = true;
+        for (int v = 0; v < 8; ++v)
+            ok = ok && c[v * 3] >= p.xmin && c[v * 3] <= p.xmax && c[v * 3 + 1] >= p.ymin && c[v * 3 + 1] <= p.ymax;
+        inr[q] = ok;
+    }
+    __syncthreads();
+    av2x::block_scan(
+        np, [&](int q) { return inr[q]; },
+        [&](int q, int ex) {
+            if (!inr[q]) return;
+            const int k = kept[order[pick[q]]];
+            for (int v = 0; v < 24; ++v) out_corners[(size_t)ex * 24 + v] = corners[(size_t)k * 24 + v];
+            for (int v = 0; v < 7; ++v) out_boxes[(size_t)ex * 7 + v] = boxes[(size_t)k * 7 + v];
+            out_scores[ex] = cscore[k];
+            out_labels[ex] = label[k];
+            out_index[ex] = cand[k];
+        },
+        &tot);
+    __syncthreads();
+    if (threadIdx.x == 0) nout[0] = tot;
+}
+
+}  // namespace
+
+extern "C" uint64_t av2x_postprocess_workspace_bytes(int32_t h, int32_t w, int32_t a, int32_t top) {
+    const uint64_t na = (uint64_t)h * w * a;
+    const uint64_t words = ((uint64_t)top + 63) / 64;
+    // score, flag, cand, boxes(7), corners(24), cscore, label, keep, kept | order, pick, inr (top each) | mask | 8 counters
+    return (na * (1 + 1 + 1 + 7 + 24 + 1 + 1 + 1 + 1) + 3 * (uint64_t)top + 16) * 4 + (uint64_t)top * words * 8 + 64;
+}
+
+extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* obj, const float* anchors, int32_t h,
+                                int32_t w, int32_t a, int32_t c, const float* transform16, const float* range6,
+                                float obj_threshold, float nms_threshold, int32_t order_hwl, int32_t top, void* workspace,
+                                float* out_corners, float* out_scores, int32_t* out_labels, float* out_boxes,
+                                int32_t* out_index, int32_t* counts, av2x_stream_t stream) {
+    if (!psm || !rm || !obj || !anchors || !transform16 || !range6 || !workspace || !out_corners || !out_scores ||
+        !out_labels || !out_boxes || !out_index || !counts)
+        return av2x::fail("av2x_postprocess: null argument");
+    if (h <= 0 || w <= 0 || a <= 0 || c < 2 || top <= 0 || top > 4096) return av2x::fail("av2x_postprocess: bad sizes");
+    PPParams p;
+    p.H = h; p.W = w; p.A = a; p.C = c;
+    p.obj_thr = obj_threshold; p.nms_thr = nms_threshold;
+    p.xmin = range6[0]; p.ymin = range6[1]; p.zmin = range6[2]; p.xmax = range6[3]; p.ymax = range6[4]; p.zmax = range6[5];
+    for (int i = 0; i < 16; ++i) p.T[i] = transform16[i];
+    p.order_hwl = order_hwl; p.top = top;
+    const int NA = h * w * a;
+    const int words = (top + 63) / 64;
+    hipStream_t st = av2x::as_stream(stream);
+    float* f = reinterpret_cast<float*>(workspace);
+    float* score = f; f += NA;
+    int* flag = reinterpret_cast<int*>(f); f += NA;
+    int* cand = reinterpret_cast<int*>(f); f += NA;
+    float* boxes = f; f += (size_t)NA * 7;
+    float* corners = f; f += (size_t)NA * 24;
+    float* cscore = f; f += NA;
+    int* label = reinterpret_cast<int*>(f); f += NA;
+    int* keep = reinterpret_cast<int*>(f); f += NA;
+    int* kept = reinterpret_cast<int*>(f); f += NA;
+    int* order = reinterpret_cast<int*>(f); f += top;
+    int* pick = reinterpret_cast<int*>(f); f += top;
+    int* inr = reinterpret_cast<int*>(f); f += top;
+    f += 16;
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(f) + 15) & ~uintptr_t(15));
+    // counts[0..4] = candidates, after size/z filters, NMS input (top), NMS picks, final
+    int *ncand = counts, *nkept = counts + 1, *ntop = counts + 2, *npick = counts + 3, *nout = counts + 4;
+
+    hipLaunchKernelGGL(pp_flag, dim3((NA + 255) / 256), dim3(256), 0, st, obj, p, score, flag);
+    hipLaunchKernelGGL(pp_scan, dim3(1), dim3(1024), 0, st, flag, NA, cand, ncand);
+    hipLaunchKernelGGL(pp_decode, dim3(256), dim3(256), 0, st, psm, rm, anchors, score, cand, ncand, p, boxes, corners,
+                       cscore, label, keep);
+    hipLaunchKernelGGL(pp_scan2, dim3(1), dim3(1024), 0, st, keep, ncand, kept, nkept);
+    hipLaunchKernelGGL(pp_rank, dim3(256), dim3(256), 0, st, cscore, kept, nkept, top, order, ntop);
+    hipLaunchKernelGGL(pp_iou_mask, dim3((top + 63) / 64, top), dim3(64), 0, st, corners, kept, order, ntop, nms_threshold,
+                       words, mask);
+    const size_t lds = (size_t)top * words * 8 <= 128 * 1024 ? (size_t)top * words * 8 : 0;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_greedy), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  128 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(pp_greedy, dim3(1), dim3(1024), lds, st, mask, ntop, words, lds > 0 ? 1 : 0, pick, npick);
+    hipLaunchKernelGGL(pp_final, dim3(1), dim3(1024), 0, st, boxes, corners, cscore, label, kept, order, pick, npick, p, inr,
+                       out_corners, out_scores, out_labels, out_boxes, out_index, cand, nout);
+    return av2x::check_launch("av2x_postprocess");
+}

@@ -14,6 +14,7 @@
 //   k_fill   per point : unordered append of the point index to its cell's list
 //   k_emit   per point : pos = #{j in list : j < i}; write voxels / coords / num_points
 #include "av2x_common.hpp"
+#include "block_scan.hpp"
 
 namespace {
 
@@ -41,49 +42,19 @@ __global__ void k_cell(const float4* __restrict__ pts, int n, VoxGeom g, int* __
     cell[i] = c;
 }
 
-// exclusive scan of `n` ints produced by functor f(i), single workgroup of 1024 threads
-template <class F, class G>
-__device__ void block_scan(int n, F f, G store, int* total) {
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? f(i) : 0;
-        int s = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(s, o);
-            if (lane >= o) s += t;
-        }
-        if (lane == 63) wsum[wave] = s;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wave; ++k) woff += wsum[k];
-        const int excl = carry + woff + s - v;
-        if (i < n) store(i, excl);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = excl + v;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-
 __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cell, int n, const int* __restrict__ cnt,
                                                const int* __restrict__ first, int ncell, int* __restrict__ vrank,
                                                int* __restrict__ offs, int* __restrict__ m_out, int max_voxels) {
     __shared__ int tot;
     // (a) voxel rank = number of earlier "first points"
-    block_scan(
+    av2x::block_scan(
         n, [&](int i) { const int c = cell[i]; return (c >= 0 && first[c] == i) ? 1 : 0; },
         [&](int i, int ex) { const int c = cell[i]; if (c >= 0 && first[c] == i) vrank[c] = ex; }, &tot);
     __syncthreads();
     if (threadIdx.x == 0) m_out[0] = tot < max_voxels ? tot : max_voxels;
     __syncthreads();
     // (b) list offsets in cell order
-    block_scan(ncell, [&](int c) { return cnt[c]; }, [&](int c, int ex) { offs[c] = ex; }, &tot);
+    av2x::block_scan(ncell, [&](int c) { return cnt[c]; }, [&](int c, int ex) { offs[c] = ex; }, &tot);
 }
 
 __global__ void k_fill(const int* __restrict__ cell, int n, const int* __restrict__ offs, int* __restrict__ fill,

@@ -1,0 +1,115 @@
+"""``VoxelPostprocessor`` — inference half of data_utils/post_processor/voxel_postprocessor.py
+(anchors :33-86, ``post_process_airv2x`` :666-839) with the box decoding, filters and the rotated
+NMS running on the device (av2x_postprocess) instead of torch ops + a shapely loop on the host.
+
+Same constructor (``VoxelPostprocessor(hypes["postprocess"], dataset, train)``), same
+``generate_anchor_box()`` result (numpy float64, host-side constants as in the reference) and the
+same ``post_process_airv2x(data_dict, output_dict)`` return tuple
+``(pred_box3d (K,8,3), scores (K,), labels (K,) int64, boxes3d (K,7))`` in NMS pick order.
+Label generation (training, CPU worker) is out of scope.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from ctypes import c_float, c_void_p
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class VoxelPostprocessor:
+    def __init__(self, anchor_params, dataset="airv2x", train=False):
+        self.params = anchor_params
+        self.dataset = dataset
+        self.train = train
+        self.anchor_num = self.params["anchor_args"].get("num", 2)
+        self.num_class = self.params["anchor_args"].get("num_class", 7)  # voxel_postprocessor.py:29, appendix A #19
+        self.lidar_range = self.params["anchor_args"]["cav_lidar_range"]
+        self.nms_top = 1000  # box_utils.py:849
+        self._ws = {}
+
+    def generate_anchor_box(self):
+        a = self.params["anchor_args"]
+        W, H = a["W"], a["H"]
+        r = [math.radians(e) for e in a["r"]]
+        assert self.anchor_num == len(r)
+        fs = a.get("feature_stride", 2)
+        rng = self.lidar_range
+        x = np.linspace(rng[0] + a["vw"], rng[3] - a["vw"], W // fs)
+        y = np.linspace(rng[1] + a["vh"], rng[4] - a["vh"], H // fs)
+        cx, cy = np.meshgrid(x, y)
+        cx = np.tile(cx[..., np.newaxis], self.anchor_num)
+        cy = np.tile(cy[..., np.newaxis], self.anchor_num)
+        cz = np.ones_like(cx) * -1.0
+        w, l, h = np.ones_like(cx) * a["w"], np.ones_like(cx) * a["l"], np.ones_like(cx) * a["h"]
+        r_ = np.ones_like(cx)
+        for i in range(self.anchor_num):
+            r_[..., i] = r[i]
+        if self.params["order"] == "hwl":
+            return np.stack([cx, cy, cz, h, w, l, r_], axis=-1)
+        if self.params["order"] == "lhw":
+            return np.stack([cx, cy, cz, l, h, w, r_], axis=-1)
+        raise ValueError("Unknown bbx order.")
+
+    def _buffers(self, dev, H, W, A):
+        key = (str(dev), H, W, A)
+        b = self._ws.get(key)
+        if b is None:
+            lib = _lib.load()
+            top = self.nms_top
+            b = {
+                "ws": torch.empty(int(lib.av2x_postprocess_workspace_bytes(H, W, A, top)), dtype=torch.uint8, device=dev),
+                "corners": torch.empty((top, 8, 3), dtype=torch.float32, device=dev),
+                "scores": torch.empty((top,), dtype=torch.float32, device=dev),
+                "labels": torch.empty((top,), dtype=torch.int32, device=dev),
+                "boxes": torch.empty((top, 7), dtype=torch.float32, device=dev),
+                "index": torch.empty((top,), dtype=torch.int32, device=dev),
+                "counts": torch.zeros((8,), dtype=torch.int32, device=dev),
+            }
+            self._ws[key] = b
+        return b
+
+    @torch.no_grad()
+    def post_process_airv2x(self, data_dict, output_dict, return_counts=False):
+        if len(data_dict) != 1:
+            raise NotImplementedError("intermediate fusion hands over exactly one entry ('ego'); late fusion is out of scope")
+        (cav_id, cav), = data_dict.items()
+        out = output_dict[cav_id]
+        psm, rm, obj = out["psm"], out["rm"], out["obj"]
+        if psm.device.type != "cuda":
+            raise RuntimeError("VoxelPostprocessor (MI355X build) has no CPU path")
+        if psm.shape[0] != 1:
+            raise ValueError(f"inference only has 1 batch, but got {tuple(psm.shape)}")
+        dev = psm.device
+        _, AC, H, W = psm.shape
+        C = self.num_class
+        A = AC // C
+        anchors = cav["anchor_box"]
+        anchors = anchors if isinstance(anchors, torch.Tensor) else torch.from_numpy(np.asarray(anchors))
+        anchors = anchors.reshape(-1, 7).float().to(dev).contiguous()  # .float() as delta_to_boxes3d :612
+        if anchors.shape[0] != H * W * A:
+            raise ValueError("anchor_box does not match the head resolution")
+        T = cav["transformation_matrix"]
+        T = (T.detach().cpu().numpy() if isinstance(T, torch.Tensor) else np.asarray(T)).astype(np.float32).reshape(16)
+        t16 = (c_float * 16)(*[float(v) for v in T])
+        r6 = (c_float * 6)(*[float(v) for v in self.lidar_range])
+        b = self._buffers(dev, H, W, A)
+        lib = _lib.load()
+        psm, rm, obj = psm.contiguous().float(), rm.contiguous().float(), obj.contiguous().float()
+        st = c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: c_void_p(t.data_ptr())
+        _lib.check(lib.av2x_postprocess(P(psm), P(rm), P(obj), P(anchors), H, W, A, C, ctypes.cast(t16, c_void_p),
+                                        ctypes.cast(r6, c_void_p), float(self.params["target_args"]["obj_threshold"]),
+                                        float(self.params["nms_thresh"]), 1 if self.params["order"] == "hwl" else 0,
+                                        self.nms_top, P(b["ws"]), P(b["corners"]), P(b["scores"]), P(b["labels"]),
+                                        P(b["boxes"]), P(b["index"]), P(b["counts"]), st), "av2x_postprocess")
+        counts = b["counts"][:5].tolist()  # the one host read-back of the whole post-process
+        if counts[0] == 0:
+            res = (None, None, None, None)
+        else:
+            k = counts[4]
+            res = (b["corners"][:k].clone(), b["scores"][:k].clone(), b["labels"][:k].to(torch.int64), b["boxes"][:k].clone())
+        return res + (counts, b["index"][:counts[4]].clone()) if return_counts else res

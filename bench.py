@@ -159,6 +159,25 @@ def main():
                    "launch": "hipGraph replay" if eng.graph_active() else "eager"},
     }
 
+    # ---------------- second figure: frame + on-device post-process (decode, filters, rotated NMS) ----------
+    if rank == 0 and a.mode == "replica":
+        from airv2x_perception_amd.opencood_iface.voxel_postprocessor import VoxelPostprocessor
+        post = VoxelPostprocessor(hy["postprocess"], dataset="airv2x", train=False)
+        anchors = torch.from_numpy(post.generate_anchor_box())
+        data = {"ego": {"transformation_matrix": torch.eye(4), "anchor_box": anchors}}
+        boxes = None
+        for it in range(3 + a.steps):
+            if it == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            o = model(dd)
+            boxes = post.post_process_airv2x(data, {"ego": o}, return_counts=True)
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - t0) / a.steps
+        res["with_postprocess"] = {"frames_per_s": round(1.0 / pdt, 2), "ms_per_step": round(pdt * 1e3, 3),
+                                   "counts_cand_filtered_nmsin_picked_final": boxes[4],
+                                   "note": "model + av2x_postprocess per frame, one 20-byte host read-back of the counts"}
+
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and a.mode == "replica":
         eng.use_graph = False

@@ -146,6 +146,30 @@ int av2x_voxelize(const float* points, int32_t n_points, const float* range6, co
                   int32_t max_points, int32_t max_voxels, void* workspace, float* voxels,
                   int32_t* coords, int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Detection post-processing on the device.  Replaces VoxelPostprocessor.post_process_airv2x
+ * (data_utils/post_processor/voxel_postprocessor.py:666-839: sigmoid(obj) > obj_threshold,
+ * class argmax over classes 1..C-1 of psm viewed (C,A,H,W), delta_to_boxes3d :585-634,
+ * boxes_to_corners_3d / project_box3d / remove_large_pred_bbx / remove_bbx_abnormal_z
+ * utils/box_utils.py:195-258,332-366,981-1035) and the host NMS loop box_utils.nms_rotated
+ * :823-868 (shapely polygon IoU -> fp64 convex-quad clipping; top-`top` by score, greedy
+ * removal of iou > nms_threshold) plus the final range mask :399-430.
+ *   psm (1,A*C,H,W), rm (1,A*7,H,W), obj (1,A,H,W) f32 NCHW (the heads' output layout);
+ *   anchors (H*W*A,7) f32 [x,y,z,h,w,l,yaw]; transform16 (4x4 row-major) and range6 are HOST;
+ *   workspace: av2x_postprocess_workspace_bytes(h,w,a,top) bytes;
+ *   outputs CAPACITY `top`: out_corners (top,8,3), out_scores (top,), out_labels (top,) i32,
+ *   out_boxes (top,7), out_index (top,) i32 = anchor index (h*W+w)*A+a of each result;
+ *   counts (5,) i32 device: {obj candidates, after size/z filters, NMS input, NMS picks, final}.
+ * Results are in NMS pick order (descending score), exactly the reference's output order.
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_postprocess_workspace_bytes(int32_t h, int32_t w, int32_t a, int32_t top);
+int av2x_postprocess(const float* psm, const float* rm, const float* obj, const float* anchors,
+                     int32_t h, int32_t w, int32_t a, int32_t c, const float* transform16,
+                     const float* range6, float obj_threshold, float nms_threshold,
+                     int32_t order_hwl, int32_t top, void* workspace, float* out_corners,
+                     float* out_scores, int32_t* out_labels, float* out_boxes, int32_t* out_index,
+                     int32_t* counts, av2x_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

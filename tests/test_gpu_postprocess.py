@@ -1,0 +1,74 @@
+"""GPU: on-device post-process (av2x_postprocess through the VoxelPostprocessor mirror) vs the
+reference golden vectors and the oracle.  Index bookkeeping (candidate order, keep flags, NMS picks,
+labels) must be exact; box floats agree to fp32 rounding of exp/sin/cos (1e-5 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from airv2x_perception_amd import synth
+from oracle import postprocess_oracle as po
+from tests.helpers import assert_close, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fx, psm=None, rm=None, obj=None):
+    from airv2x_perception_amd.opencood_iface.voxel_postprocessor import VoxelPostprocessor
+    hy = synth.default_hypes([float(v) for v in fx["lidar_range"]])
+    post = VoxelPostprocessor(hy["postprocess"], dataset="airv2x", train=False)
+    anchors = post.generate_anchor_box()
+    assert np.array_equal(anchors, po.generate_anchor_box(hy["postprocess"]))
+    T = torch.from_numpy(np.identity(4)).float()
+    data = {"ego": {"transformation_matrix": T, "anchor_box": torch.from_numpy(np.array(anchors))}}
+    g = lambda k, v: torch.from_numpy(fx[k] if v is None else v).cuda()
+    outd = {"ego": {"psm": g("psm", psm), "rm": g("rm", rm), "obj": g("obj", obj)}}
+    return post, post.post_process_airv2x(data, outd, return_counts=True), hy, anchors
+
+
+@pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_small_n1"])
+def test_postprocess_matches_reference_golden(name):
+    fx = load_fixture(name)
+    post, (corners, scores, labels, boxes, counts, index), hy, anchors = _run(fx)
+    assert counts[0] == fx["pp_cand_index"].shape[0]            # obj > 0.2 candidates
+    assert counts[1] == int(fx["pp_cand_keep"].sum())           # after size / z filters
+    assert counts[3] == fx["pp_nms_keep"].shape[0]              # NMS picks
+    assert counts[4] == fx["pp_scores"].shape[0]                # inside the range
+    # the anchor index of every returned box = reference's candidate -> kept -> picked -> in-range chain
+    ref_idx = fx["pp_cand_index"][fx["pp_cand_keep"]][fx["pp_nms_keep"]]
+    lo, hi = np.asarray(fx["lidar_range"][:2], np.float32), np.asarray(fx["lidar_range"][3:5], np.float32)
+    c = fx["pp_nms_in_corners"][fx["pp_nms_keep"]]
+    inr = np.all((c[:, :, :2] >= lo) & (c[:, :, :2] <= hi), axis=(1, 2))
+    assert np.array_equal(index.cpu().numpy(), ref_idx[inr])
+    assert np.array_equal(labels.cpu().numpy(), fx["pp_labels"]) and labels.dtype == torch.int64
+    assert_close(scores.cpu(), fx["pp_scores"], 1e-6, 1e-7, "scores")
+    assert_close(boxes.cpu(), fx["pp_boxes3d"], 1e-5, 1e-5, "boxes3d")
+    assert_close(corners.cpu(), fx["pp_corners"], 1e-5, 1e-4, "corners")
+    # descending score order (NMS pick order)
+    s = scores.cpu().numpy()
+    assert np.all(s[:-1] >= s[1:])
+
+
+def test_postprocess_dense_overlaps_against_oracle():
+    """Many overlapping boxes (small regression deltas -> the anchors themselves): stresses the NMS."""
+    fx = load_fixture("w2c_small_n1")
+    g = np.random.default_rng(3)
+    rm = (g.standard_normal(fx["rm"].shape) * 0.05).astype(np.float32)
+    obj = (g.standard_normal(fx["obj"].shape) * 2.0).astype(np.float32)
+    post, (corners, scores, labels, boxes, counts, index), hy, anchors = _run(fx, rm=rm, obj=obj)
+    pp = hy["postprocess"]
+    st = {}
+    ref = po.post_process(torch.from_numpy(fx["psm"]), torch.from_numpy(rm), torch.from_numpy(obj), torch.from_numpy(anchors),
+                          torch.eye(4), pp, pp["anchor_args"]["cav_lidar_range"], stages=st)
+    assert counts[0] == st["cand_scores"].numel() and counts[1] == int(st["cand_keep"].sum()) and counts[1] > 1000
+    assert counts[2] == 1000                                     # top-1000 cut of nms_rotated
+    assert counts[3] == st["nms_keep"].numel() and counts[4] == ref[1].numel()
+    assert np.array_equal(labels.cpu().numpy(), ref[2].numpy())
+    assert_close(corners.cpu(), ref[0], 1e-5, 1e-4, "corners")
+    assert_close(scores.cpu(), ref[1], 1e-6, 1e-7, "scores")
+
+
+def test_no_candidates():
+    fx = load_fixture("w2c_small_n1")
+    obj = np.full(fx["obj"].shape, -10.0, np.float32)
+    post, res, hy, anchors = _run(fx, obj=obj)
+    assert res[:4] == (None, None, None, None) and res[4][0] == 0

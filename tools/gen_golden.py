@@ -39,6 +39,10 @@ def import_reference():
     sh.geometry = _stub("shapely.geometry", Polygon=object)
     _stub("pyquaternion", Quaternion=object)
     _stub("opencood.models.common_modules.airv2x_encoder", LiftSplatShootEncoder=object)
+    # post-processor imports (label generation / visualisation are never called here)
+    _stub("open3d")
+    _stub("more_itertools", unique_everseen=lambda it: it)
+    _stub("opencood.utils.box_overlaps", bbox_overlaps=None)
     sys.path.insert(0, REF)
 
 
@@ -193,9 +197,56 @@ def run_case(name, lidar_range, types, n_points, seed, sample_stride, big_stride
         if "vfe_" + t in cap:
             pf = cap["vfe_" + t][0]["pillar_features"]
             fx["pillar_features_" + t] = pf.detach().numpy()[:: (1 if s == 1 else 16)]
+    if s == 1:
+        fx.update(postprocess_golden(name, hy_ref, hy, out))
     path = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(path, **fx)
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def postprocess_golden(name, hy_ref, hy, out):
+    """Run the reference's VoxelPostprocessor.post_process_airv2x on the reference model's own
+    outputs.  Only ``box_utils.nms_rotated`` is replaced (its shapely dependency is absent): the
+    replacement records the tensors the reference hands to the NMS and answers with the oracle's
+    NMS, so every step before it and the range filter after it are the reference's."""
+    from oracle import postprocess_oracle as po
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    from opencood.utils import box_utils
+
+    rec = {}
+
+    def fake_nms(boxes, scores, threshold):
+        rec["nms_in_corners"], rec["nms_in_scores"] = boxes.clone(), scores.clone()
+        k = po.nms_rotated(boxes, scores, threshold)
+        rec["nms_keep"] = k
+        return k
+
+    box_utils.nms_rotated = fake_nms
+    post = VoxelPostprocessor(hy_ref["postprocess"], dataset="airv2x", train=False)
+    anchors = post.generate_anchor_box()
+    my_anchors = po.generate_anchor_box(hy["postprocess"])
+    assert anchors.dtype == np.float64 and np.array_equal(anchors, my_anchors), "anchor oracle mismatch"
+    T = torch.from_numpy(np.identity(4)).float()
+    data = {"ego": {"transformation_matrix": T, "anchor_box": torch.from_numpy(np.array(anchors))}}
+    outd = {"ego": {k: out[k] for k in ("psm", "rm", "obj")}}
+    with torch.no_grad():
+        corners, scores, labels, boxes3d = post.post_process_airv2x(data, outd)
+        st = {}
+        o = po.post_process(out["psm"], out["rm"], out["obj"], torch.from_numpy(anchors), T, hy["postprocess"],
+                            hy["postprocess"]["anchor_args"]["cav_lidar_range"], stages=st)
+    assert torch.equal(st["nms_in_corners"], rec["nms_in_corners"]) and torch.equal(st["nms_in_scores"], rec["nms_in_scores"])
+    for a, b in zip(o, (corners, scores, labels, boxes3d)):
+        assert torch.equal(a, b), "post-process oracle differs from the reference"
+    print(f"[{name}] post-process: {int(st['cand_scores'].numel())} candidates (obj > 0.2), "
+          f"{int(st['cand_keep'].sum())} after size/z filters, {len(rec['nms_keep'])} after NMS, {corners.shape[0]} in range")
+    g = {"pp_anchor_sum": np.float64(anchors.sum()), "pp_anchor_corner": anchors[[0, -1], [0, -1]],
+         "pp_cand_index": st["cand_index"].numpy().astype(np.int32), "pp_cand_boxes3d": st["cand_boxes3d"].numpy(),
+         "pp_cand_scores": st["cand_scores"].numpy(), "pp_cand_labels": st["cand_labels"].numpy().astype(np.int32),
+         "pp_cand_keep": st["cand_keep"].numpy(), "pp_nms_in_corners": rec["nms_in_corners"].numpy(),
+         "pp_nms_in_scores": rec["nms_in_scores"].numpy(), "pp_nms_keep": np.asarray(rec["nms_keep"], np.int32),
+         "pp_corners": corners.numpy(), "pp_scores": scores.numpy(), "pp_labels": labels.numpy().astype(np.int32),
+         "pp_boxes3d": boxes3d.numpy()}
+    return g
 
 
 def main():
