@@ -32,12 +32,13 @@ struct ConvParams {
     int Cout, CoutP, out_ctot, out_coff;
     int ks, stride, pad, relu, mode, up;
     int M, tiles_n, cchunks, steps;
+    unsigned in_bytes, w_bytes;
 };
 
 constexpr int BK = 32;
 constexpr int LDA = 36;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DEEP>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(const ConvParams p) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -81,43 +82,49 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
         }
     }
 
-    // Register staging of the NEXT K-step (branch-free: out-of-image / out-of-range rows read a
-    // valid dummy address and are zeroed by a select, so every load is issued unconditionally and
-    // stays in flight behind the MFMAs of the current step).
-    f32x4 ra[A_LD], rb[B_LD];
-    unsigned okmask = 0;  // bit i: row i of this thread's A loads is inside the image (applied at the LDS store)
-    const float* __restrict__ gin = p.in + p.in_coff + qA * 4;
-    const float* __restrict__ gw = p.w + (size_t)n0 * 4;
-    // B tile: float4 #idx of the [8][BN] k-quad-major tile, idx = tid + 256*i -> row idx/BN, col idx%BN
+    // Register staging of the NEXT K-step through BUFFER loads (T8): the descriptor is built from
+    // kernel arguments (provably wave-uniform -> no waterfall loops), the per-row byte offset lives in
+    // a VGPR that only changes when the tap changes, the channel-chunk / weight-row offset is a scalar
+    // (soffset).  Rows outside the image (or beyond M) get voffset = 2^31 >= num_records, for which the
+    // hardware returns zeros: no address select, no branch, no zero-fill select at the LDS store, and
+    // the per-step VALU work of the gather is gone.
+    // Two register sets: with DEEP the tile of step s+2 is requested while step s computes (prefetch
+    // distance 2), else only set 0 is used (distance 1).
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned voffA[A_LD], voffB[B_LD];
+    // B tile: float4 #idx of the [8][BN] k-quad-major tile, idx = tid + NTHR*i -> row idx/BN, col idx%BN
     constexpr int ROWS_PER_PASS = NTHR / BN > 0 ? NTHR / BN : 1;
-    const int bk0 = tid / BN, bn0 = (tid % BN) * 4;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+        voffB[i] = (unsigned)(((tid / BN + i * ROWS_PER_PASS) * p.CoutP + n0 + (tid % BN)) * 16);
 
-#define AV2X_GLOAD(TAP, CC)                                                                             \
+#define AV2X_GLOAD(ra, rb, TAP, CC)                                                                     \
     {                                                                                                   \
-        const int kh_ = (TAP) / p.ks, kw_ = (TAP) - kh_ * p.ks;                                         \
-        okmask = 0;                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                              \
-            const int hi = hi0[i] + kh_, wi = wi0[i] + kw_;                                             \
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;               \
-            const int pix = ok ? (pix0[i] + hi * p.W + wi) : 0;                                         \
-            okmask |= (ok ? 1u : 0u) << i;                                                              \
-            ra[i] = *reinterpret_cast<const f32x4*>(gin + (size_t)pix * p.in_ctot + (CC)*BK);           \
+        if ((CC) == 0) { /* new tap: refresh the per-row offsets (uniform branch, every cchunks steps) */ \
+            const int kh_ = (TAP) / p.ks, kw_ = (TAP) - kh_ * p.ks;                                     \
+            _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                          \
+                const int hi = hi0[i] + kh_, wi = wi0[i] + kw_;                                         \
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;           \
+                voffA[i] = ok ? (unsigned)(((pix0[i] + hi * p.W + wi) * p.in_ctot + p.in_coff + qA * 4) * 4) : OOB; \
+            }                                                                                           \
         }                                                                                               \
-        const size_t wrow_ = (size_t)((TAP) * (p.Cin >> 2) + (CC)*8) * p.CoutP * 4;                     \
-        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) {                                              \
-            rb[i] = *reinterpret_cast<const f32x4*>(gw + wrow_ +                                        \
-                                                    (size_t)(bk0 + i * ROWS_PER_PASS) * p.CoutP * 4 + bn0); \
-        }                                                                                               \
+        const unsigned sa_ = (unsigned)((CC)*BK * 4);                                                   \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                                        \
+            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, voffA[i], sa_, 0));    \
+        const unsigned sb_ = (unsigned)(((TAP) * (p.Cin >> 2) + (CC)*8) * p.CoutP * 16);                \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) rb[i] =                                        \
+            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rwt, voffB[i], sb_, 0));    \
     }
-#define AV2X_LSTORE(BUF)                                                                                \
+#define AV2X_LSTORE(ra, rb, BUF)                                                                        \
     {                                                                                                   \
         float* a_ = As + (BUF) * (BM * LDA);                                                            \
         float* b_ = Bs + (BUF) * (8 * BN * 4);                                                          \
-        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                              \
-            const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                      \
-            *reinterpret_cast<f32x4*>(a_ + ((tid >> 3) + A_ROWS * i) * LDA + qA * 4) =                  \
-                ((okmask >> i) & 1u) ? ra[i] : z_;                                                      \
-        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                \
+            *reinterpret_cast<f32x4*>(a_ + ((tid >> 3) + A_ROWS * i) * LDA + qA * 4) = ra[i];           \
         _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                \
             *reinterpret_cast<f32x4*>(b_ + (tid + NTHR * i) * 4) = rb[i];                               \
     }
@@ -130,45 +137,92 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    int tap = 0, cc = 0;
-    AV2X_GLOAD(tap, cc);
-    AV2X_LSTORE(0);
-    __syncthreads();
-
-    const int li = lane & 31, lh = lane >> 5;
-    for (int s = 0; s < p.steps; ++s) {
-        const int buf = s & 1;
-        // prefetch step s+1 (the last iteration re-fetches the final tile: harmless, keeps the loop branch-free)
-        if (s + 1 < p.steps) {
-            if (++cc == p.cchunks) { cc = 0; ++tap; }
-        }
-        AV2X_GLOAD(tap, cc);
-        // pin the loads here: without this fence hipcc sinks them below the MFMAs (next to the
-        // ds_write that consumes them) and the whole L2/HBM latency is exposed every K-step
-        __builtin_amdgcn_sched_barrier(0);
-        const float* Ab = As + buf * (BM * LDA) + (wm0 + li) * LDA + lh * 4;
-        const float* Bb = Bs + buf * (8 * BN * 4) + (lh * BN + wn0 + li) * 4;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 fa[MT], fb[NT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDA + g * 8);
-#pragma unroll
-            for (int c = 0; c < NT; ++c) fb[c] = *reinterpret_cast<const f32x4*>(Bb + (g * 2 * BN + c * 32) * 4);
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int c = 0; c < NT; ++c) {
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[c].x, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[c].y, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[c].z, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[c].w, acc[a][c], 0, 0, 0);
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        AV2X_LSTORE(buf ^ 1);
-        __syncthreads();
+    int tap = 0, cc = 0;  // (tap, channel chunk) of the NEXT tile to request; clamps at the last tile
+    int issued = 0;
+#define AV2X_ADVANCE()                                         \
+    {                                                          \
+        if (issued + 1 < p.steps) {                            \
+            ++issued;                                          \
+            if (++cc == p.cchunks) { cc = 0; ++tap; }          \
+        }                                                      \
     }
+    const int li = lane & 31, lh = lane >> 5;
+#define AV2X_FRAGS(FA, FB, G)                                                                                       \
+    {                                                                                                               \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) FA[a] =                                                      \
+            *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDA + (G)*8);                                             \
+        _Pragma("unroll") for (int c = 0; c < NT; ++c) FB[c] =                                                      \
+            *reinterpret_cast<const f32x4*>(Bb + ((G)*2 * BN + c * 32) * 4);                                        \
+    }
+#define AV2X_MFMAS(FA, FB)                                                                                          \
+    {                                                                                                               \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) _Pragma("unroll") for (int c = 0; c < NT; ++c) {             \
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a].x, FB[c].x, acc[a][c], 0, 0, 0);                 \
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a].y, FB[c].y, acc[a][c], 0, 0, 0);                 \
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a].z, FB[c].z, acc[a][c], 0, 0, 0);                 \
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a].w, FB[c].w, acc[a][c], 0, 0, 0);                 \
+        }                                                                                                           \
+    }
+    // fragments of k-group g+1 are requested from LDS before the MFMAs of group g are issued (two
+    // fragment sets), so the ds_read latency overlaps the 64-cycle MFMA chain of the previous group
+#define AV2X_COMPUTE(BUF)                                                                                           \
+    {                                                                                                               \
+        const float* Ab = As + (BUF) * (BM * LDA) + (wm0 + li) * LDA + lh * 4;                                      \
+        const float* Bb = Bs + (BUF) * (8 * BN * 4) + (lh * BN + wn0 + li) * 4;                                     \
+        f32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];                                                                   \
+        AV2X_FRAGS(fa0, fb0, 0);                                                                                    \
+        AV2X_FRAGS(fa1, fb1, 1);                                                                                    \
+        AV2X_MFMAS(fa0, fb0);                                                                                       \
+        AV2X_FRAGS(fa0, fb0, 2);                                                                                    \
+        AV2X_MFMAS(fa1, fb1);                                                                                       \
+        AV2X_FRAGS(fa1, fb1, 3);                                                                                    \
+        AV2X_MFMAS(fa0, fb0);                                                                                       \
+        AV2X_MFMAS(fa1, fb1);                                                                                       \
+    }
+
+    AV2X_GLOAD(ra0, rb0, tap, cc);
+    AV2X_LSTORE(ra0, rb0, 0);
+    __syncthreads();
+    if constexpr (!DEEP) {
+        for (int s = 0; s < p.steps; ++s) {
+            const int buf = s & 1;
+            AV2X_ADVANCE();  // the last iteration re-fetches the final tile: harmless, keeps the loop branch-free
+            AV2X_GLOAD(ra0, rb0, tap, cc);
+            // pin the loads here: without this fence hipcc sinks them below the MFMAs (next to the
+            // ds_write that consumes them) and the whole L2/HBM latency is exposed every K-step
+            __builtin_amdgcn_sched_barrier(0);
+            AV2X_COMPUTE(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            AV2X_LSTORE(ra0, rb0, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // invariant at the top of an even step s: tile s is in LDS buffer 0, tile s+1 is in flight in set 0
+        AV2X_ADVANCE();
+        AV2X_GLOAD(ra0, rb0, tap, cc);
+        for (int s = 0; s < p.steps; s += 2) {
+            AV2X_ADVANCE();
+            AV2X_GLOAD(ra1, rb1, tap, cc);  // tile s+2
+            __builtin_amdgcn_sched_barrier(0);
+            AV2X_COMPUTE(0);
+            __builtin_amdgcn_sched_barrier(0);
+            AV2X_LSTORE(ra0, rb0, 1);  // tile s+1 -> buffer 1
+            __syncthreads();
+            if (s + 1 < p.steps) {
+                AV2X_ADVANCE();
+                AV2X_GLOAD(ra0, rb0, tap, cc);  // tile s+3
+                __builtin_amdgcn_sched_barrier(0);
+                AV2X_COMPUTE(1);
+                __builtin_amdgcn_sched_barrier(0);
+                AV2X_LSTORE(ra1, rb1, 0);  // tile s+2 -> buffer 0
+                __syncthreads();
+            }
+        }
+    }
+#undef AV2X_COMPUTE
+#undef AV2X_FRAGS
+#undef AV2X_MFMAS
+#undef AV2X_ADVANCE
 #undef AV2X_GLOAD
 #undef AV2X_LSTORE
 
@@ -209,7 +263,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DEEP = false>
 int launch(const ConvParams& p, hipStream_t st) {
     const int tiles_m = (p.M + BM - 1) / BM;
     ConvParams q = p;
@@ -217,11 +271,11 @@ int launch(const ConvParams& p, hipStream_t st) {
     const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, DEEP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN>), dim3(tiles_m * q.tiles_n), dim3(64 * (BM / WM) * (BN / WN)), lds,
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, DEEP>), dim3(tiles_m * q.tiles_n), dim3(64 * (BM / WM) * (BN / WN)), lds,
                        st, q);
     return av2x::check_launch("conv_igemm_f32");
 }
@@ -259,10 +313,17 @@ extern "C" int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float
     p.cchunks = p.Cin / BK;
     p.steps = p.ks * p.ks * p.cchunks;
     p.tiles_n = 0;
+    const unsigned long long in_bytes = (unsigned long long)d->n * d->h * d->w * d->in_ctot * 4ull;
+    const unsigned long long w_bytes = (unsigned long long)p.ks * p.ks * p.Cin * p.CoutP * 4ull;
+    if (in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31))
+        return av2x::fail("av2x_conv2d: input (%llu B) or weights (%llu B) exceed the 2 GiB buffer-descriptor window", in_bytes, w_bytes);
+    p.in_bytes = (unsigned)in_bytes;
+    p.w_bytes = (unsigned)w_bytes;
     hipStream_t st = av2x::as_stream(stream);
 
-    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x7fff;
-    const bool w8 = (d->tile & 0x8000) != 0;  // 8-wave (512-thread) variant of the same tile
+    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x3fff;
+    const bool w8 = (d->tile & 0x8000) != 0;    // 8-wave (512-thread) variant of the same tile
+    const bool deep = (d->tile & 0x4000) != 0;  // prefetch distance 2 (two register sets)
     if (d->tile == 0) {
         // Heuristic: the largest tile that still yields >= ~2 workgroups per CU (256 CUs).
         bn = (p.CoutP % 128 == 0) ? 128 : (p.CoutP % 64 == 0 ? 64 : 32);
@@ -272,6 +333,18 @@ extern "C" int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float
         if (bn == 64 && wgs(128, 64) < 512) { bm = 64; }
     }
     if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
+    if (deep) {
+        if (w8) {
+            if (bm == 128 && bn == 128) return launch<128, 128, 64, 32, true>(p, st);
+            if (bm == 128 && bn == 64) return launch<128, 64, 32, 32, true>(p, st);
+            return av2x::fail("av2x_conv2d: unsupported deep 8-wave tile %dx%d", bm, bn);
+        }
+        if (bm == 128 && bn == 128) return launch<128, 128, 64, 64, true>(p, st);
+        if (bm == 128 && bn == 64) return launch<128, 64, 64, 32, true>(p, st);
+        if (bm == 64 && bn == 64) return launch<64, 64, 32, 32, true>(p, st);
+        if (bm == 64 && bn == 128) return launch<64, 128, 32, 64, true>(p, st);
+        return av2x::fail("av2x_conv2d: unsupported deep tile %dx%d", bm, bn);
+    }
     if (w8) {
         if (bm == 128 && bn == 128) return launch<128, 128, 64, 32>(p, st);
         if (bm == 128 && bn == 64) return launch<128, 64, 32, 32>(p, st);

@@ -112,24 +112,28 @@ __global__ void pp_decode(const float* __restrict__ psm, const float* __restrict
 }
 
 __global__ __launch_bounds__(1024) void pp_scan2(const int* __restrict__ keep, const int* __restrict__ ncand,
-                                                 int* __restrict__ kept, int* __restrict__ nkept) {
+                                                 const float* __restrict__ cscore, int* __restrict__ kept,
+                                                 float* __restrict__ kscore, int* __restrict__ nkept) {
     __shared__ int tot;
     const int K = ncand[0];
-    av2x::block_scan(K, [&](int i) { return keep[i]; }, [&](int i, int ex) { if (keep[i]) kept[ex] = i; }, &tot);
+    av2x::block_scan(
+        K, [&](int i) { return keep[i]; },
+        [&](int i, int ex) { if (keep[i]) { kept[ex] = i; kscore[ex] = cscore[i]; } }, &tot);
     __syncthreads();
     if (threadIdx.x == 0) nkept[0] = tot;
 }
 
 // order[r] = position (in the kept list) of the r-th best score; ties -> higher position first
-__global__ void pp_rank(const float* __restrict__ cscore, const int* __restrict__ kept, const int* __restrict__ nkept,
-                        int top, int* __restrict__ order, int* __restrict__ ntop) {
+// kscore: scores of the kept candidates, compacted (every lane reads the same kscore[j]: one broadcast load)
+__global__ void pp_rank(const float* __restrict__ kscore, const int* __restrict__ nkept, int top, int* __restrict__ order,
+                        int* __restrict__ ntop) {
     const int K2 = nkept[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) ntop[0] = K2 < top ? K2 : top;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K2; i += gridDim.x * blockDim.x) {
-        const float si = cscore[kept[i]];
+        const float si = kscore[i];
         int r = 0;
         for (int j = 0; j < K2; ++j) {
-            const float sj = cscore[kept[j]];
+            const float sj = kscore[j];
             r += (sj > si) || (sj == si && j > i);
         }
         if (r < top) order[r] = i;
@@ -270,7 +274,7 @@ extern "C" uint64_t av2x_postprocess_workspace_bytes(int32_t h, int32_t w, int32
     const uint64_t na = (uint64_t)h * w * a;
     const uint64_t words = ((uint64_t)top + 63) / 64;
     // score, flag, cand, boxes(7), corners(24), cscore, label, keep, kept | order, pick, inr (top each) | mask | 8 counters
-    return (na * (1 + 1 + 1 + 7 + 24 + 1 + 1 + 1 + 1) + 3 * (uint64_t)top + 16) * 4 + (uint64_t)top * words * 8 + 64;
+    return (na * (1 + 1 + 1 + 7 + 24 + 1 + 1 + 1 + 1 + 1) + 3 * (uint64_t)top + 16) * 4 + (uint64_t)top * words * 8 + 64;
 }
 
 extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* obj, const float* anchors, int32_t h,
@@ -301,6 +305,7 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     int* label = reinterpret_cast<int*>(f); f += NA;
     int* keep = reinterpret_cast<int*>(f); f += NA;
     int* kept = reinterpret_cast<int*>(f); f += NA;
+    float* kscore = f; f += NA;
     int* order = reinterpret_cast<int*>(f); f += top;
     int* pick = reinterpret_cast<int*>(f); f += top;
     int* inr = reinterpret_cast<int*>(f); f += top;
@@ -313,8 +318,8 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     hipLaunchKernelGGL(pp_scan, dim3(1), dim3(1024), 0, st, flag, NA, cand, ncand);
     hipLaunchKernelGGL(pp_decode, dim3(256), dim3(256), 0, st, psm, rm, anchors, score, cand, ncand, p, boxes, corners,
                        cscore, label, keep);
-    hipLaunchKernelGGL(pp_scan2, dim3(1), dim3(1024), 0, st, keep, ncand, kept, nkept);
-    hipLaunchKernelGGL(pp_rank, dim3(256), dim3(256), 0, st, cscore, kept, nkept, top, order, ntop);
+    hipLaunchKernelGGL(pp_scan2, dim3(1), dim3(1024), 0, st, keep, ncand, cscore, kept, kscore, nkept);
+    hipLaunchKernelGGL(pp_rank, dim3(256), dim3(256), 0, st, kscore, nkept, top, order, ntop);
     hipLaunchKernelGGL(pp_iou_mask, dim3((top + 63) / 64, top), dim3(64), 0, st, corners, kept, order, ntop, nms_threshold,
                        words, mask);
     const size_t lds = (size_t)top * words * 8 <= 128 * 1024 ? (size_t)top * words * 8 : 0;

@@ -224,7 +224,7 @@ class Where2ComEngine:
         else:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
             d.tile = (bm << 16) | bn
-        bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff
+        bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff  # bn keeps the variant flags (profile key)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -237,7 +237,10 @@ class Where2ComEngine:
             self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1))
         return ho, wo
 
-    TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000), (128, 32))
+    # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2)
+    TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),
+                       (128, 128 | 0x4000), (128, 64 | 0x4000), (64, 64 | 0x4000), (64, 128 | 0x4000),
+                       (128, 128 | 0xc000), (128, 64 | 0xc000), (128, 32))
 
     def _tune(self, d, x, L, out):
         """Pick the fastest workgroup tile for this conv shape (all tiles give bit-identical results:
@@ -248,7 +251,7 @@ class Where2ComEngine:
         best, best_t = None, float("inf")
         args = (_ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(out), self.stream())
         for bm, bn in self.TILE_CANDIDATES:
-            if L.coutp % (bn & 0x7fff) or ((bn & 0x7fff) == 32 and L.coutp != 32):
+            if L.coutp % (bn & 0x3fff) or ((bn & 0x3fff) == 32 and L.coutp != 32):
                 continue
             d.tile = (bm << 16) | bn
             _lib.check(self.lib.av2x_conv2d(byref(d), *args), "av2x_conv2d")  # warm-up (module load, L2)

@@ -54,6 +54,23 @@ class VoxelPostprocessor:
             return np.stack([cx, cy, cz, l, h, w, r_], axis=-1)
         raise ValueError("Unknown bbx order.")
 
+    def _device_anchors(self, anchors, dev):
+        """fp32 device copy of the anchor tensor (``anchors.float()`` as delta_to_boxes3d :612), cached:
+        the dataset hands over the same constants every frame (a fresh 3.9 MB float64 host tensor per
+        batch in the reference), so the conversion + upload is done once.  A new tensor object is
+        recognised as the cached anchors by shape and 64 sampled rows."""
+        anchors = anchors if isinstance(anchors, torch.Tensor) else torch.from_numpy(np.asarray(anchors))
+        flat = anchors.reshape(-1, 7)
+        c = self._ws.get("anchors")
+        if c is not None and c["dev"].device == dev and c["shape"] == tuple(flat.shape):
+            if c["ptr"] == flat.data_ptr() or torch.equal(flat[c["rows"]].double().cpu(), c["sample"]):
+                return c["dev"]
+        rows = torch.linspace(0, flat.shape[0] - 1, 64).long()
+        d = flat.float().to(dev).contiguous()
+        self._ws["anchors"] = {"dev": d, "shape": tuple(flat.shape), "ptr": flat.data_ptr(), "rows": rows,
+                               "sample": flat[rows].double().cpu()}
+        return d
+
     def _buffers(self, dev, H, W, A):
         key = (str(dev), H, W, A)
         b = self._ws.get(key)
@@ -87,9 +104,7 @@ class VoxelPostprocessor:
         _, AC, H, W = psm.shape
         C = self.num_class
         A = AC // C
-        anchors = cav["anchor_box"]
-        anchors = anchors if isinstance(anchors, torch.Tensor) else torch.from_numpy(np.asarray(anchors))
-        anchors = anchors.reshape(-1, 7).float().to(dev).contiguous()  # .float() as delta_to_boxes3d :612
+        anchors = self._device_anchors(cav["anchor_box"], dev)
         if anchors.shape[0] != H * W * A:
             raise ValueError("anchor_box does not match the head resolution")
         T = cav["transformation_matrix"]

@@ -88,7 +88,7 @@ typedef struct av2x_conv_desc {
     int32_t relu;              /* 1 = ReLU after the affine                               */
     int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
     int32_t up;                /* DECONV: kernel == stride                                */
-    int32_t tile;              /* 0 = auto; else BM<<16 | BN (| 0x8000: 8-wave workgroup)   */
+    int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2) */
 } av2x_conv_desc;
 
 int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,

@@ -23,7 +23,8 @@ LAYERS = {
     "L7_shrink1x1": (100, 352, 384, 256, 1, 1),
     "L8_shrink3x3": (100, 352, 256, 256, 3, 1),
 }
-TILES = [(128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000), (256, 128 | 0x8000)]
+TILES = [(128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),
+         (128, 128 | 0x4000), (128, 64 | 0x4000), (64, 64 | 0x4000), (64, 128 | 0x4000), (128, 128 | 0xc000), (128, 64 | 0xc000)]
 
 
 def main():
@@ -34,7 +35,11 @@ def main():
     ap.add_argument("--tiles", default="")
     a = ap.parse_args()
     lib = _lib.load()
-    tiles = [(int(t.split("x")[0]), int(t.split("x")[1].rstrip("w")) | (0x8000 if t.endswith("w") else 0)) for t in a.tiles.split(",")] if a.tiles else TILES
+    def parse_tile(t):
+        bm, rest = t.split("x")
+        bn = int(rest.rstrip("wd"))
+        return int(bm), bn | (0x8000 if "w" in rest else 0) | (0x4000 if "d" in rest else 0)
+    tiles = [parse_tile(t) for t in a.tiles.split(",")] if a.tiles else TILES
     st = c_void_p(torch.cuda.current_stream().cuda_stream)
     for name, (h, w, cin, cout, ks, stride) in LAYERS.items():
         if a.layers and not any(name.startswith(p) for p in a.layers.split(",")):
@@ -51,7 +56,7 @@ def main():
         flops = 2.0 * n * ho * wo * cout * ks * ks * cin
         line = f"{name:14s} M={n*ho*wo:7d} K={ks*ks*cin:5d} N={cout:4d} {flops/1e9:7.1f} GF |"
         for bm, bn in tiles:
-            if coutp % (bn & 0x7fff):
+            if coutp % (bn & 0x3fff):
                 continue
             d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=ho, wo=wo, cout=cout, coutp=coutp,
                               out_ctot=cout, out_coff=0, ks=ks, stride=stride, pad=pad, relu=1, mode=0, up=1,
@@ -68,7 +73,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters
-            line += f" {bm}x{bn & 0x7fff}{'w8' if bn & 0x8000 else ''}: {us:6.1f}us {flops/us/1e6:5.1f}TF |"
+            line += f" {bm}x{bn & 0x3fff}{'w8' if bn & 0x8000 else ''}{'d' if bn & 0x4000 else ''}:{us:6.1f}us {flops/us/1e6:5.1f}TF|"
         print(line, flush=True)
 
 
