@@ -95,7 +95,21 @@ class Where2ComEngine:
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1) per conv launch (bench roofline pass)
+        self.agent_streams = 1      # >1 (B == 1): agents are split into this many groups that run the per-agent part
+                                    # of the frame on separate HIP streams.  Measured: no gain, off by default
+        self._streams = None
         self._desc = _lib.ConvDesc()
+
+    def share_weights(self):
+        """A second engine on the same device that shares the packed weights but owns its workspaces:
+        one engine per in-flight frame (FramePipeline)."""
+        other = Where2ComEngine(self.args, self.device)
+        for k in ("pfn", "blocks", "deblocks", "cat_c", "shrink", "feat_c", "cls_single", "head_splits", "heads",
+                  "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready"):
+            setattr(other, k, getattr(self, k))
+        other.tile_cache = self.tile_cache
+        other.autotune, other.conv_tile = self.autotune, self.conv_tile
+        return other
 
     def graph_active(self):
         return self.use_graph and len(self.graphs) > 0
@@ -344,7 +358,7 @@ class Where2ComEngine:
         s = self.run_shrink(cat, n, H, W, tag) if self.shrink else cat
         return feats, s, H, W
 
-    def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True):
+    def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True, tag="", count=None):
         B = len(record_len)
         key = ("layout", tuple(record_len), has_ego)
         lay = self.ws.get(key)
@@ -357,12 +371,13 @@ class Where2ComEngine:
                    torch.tensor(ego, dtype=torch.int32, device=self.device),
                    torch.tensor(record_len, dtype=torch.float32, device=self.device))
             self.ws[key] = lay
-        conf = self.buf("comm_conf", (n, H, W))
-        smooth = self.buf("comm_smooth", (n, H, W))
-        mask = self.buf("comm_mask", (n, H, W))
-        count = self.buf("comm_count", (B,), torch.int32)
+        conf = self.buf("comm_conf" + tag, (n, H, W))
+        smooth = self.buf("comm_smooth" + tag, (n, H, W))
+        mask = self.buf("comm_mask" + tag, (n, H, W))
         st = self.stream()
-        _lib.check(self.lib.av2x_fill_zero(_ptr(count), B * 4, st), "av2x_fill_zero")
+        if count is None:  # else: a shared counter the caller zeroed before forking the agent groups
+            count = self.buf("comm_count", (B,), torch.int32)
+            _lib.check(self.lib.av2x_fill_zero(_ptr(count), B * 4, st), "av2x_fill_zero")
         _lib.check(self.lib.av2x_comm_mask(_ptr(psm_single), n, H, W, psm_single.shape[-1], self.A * self.C,
                                            _ptr(self.gauss_w), _ptr(self.gauss_b), self.gauss_k, self.threshold,
                                            _ptr(lay[0]), _ptr(lay[1]), _ptr(conf), _ptr(smooth), _ptr(mask),
@@ -418,6 +433,9 @@ class Where2ComEngine:
     def _post_encode(self, canvas, ny, nx, record_len, trace):
         """Everything after the scatter; static shapes for a given record_len -> capturable."""
         B, n = len(record_len), sum(record_len)
+        if (B == 1 and n >= 2 and self.agent_streams > 1 and trace is None and self.profile is None
+                and not self.fcfg["fully"] and not torch.cuda.is_current_stream_capturing()):
+            return self._post_encode_groups(canvas, ny, nx, n)
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
@@ -493,6 +511,73 @@ class Where2ComEngine:
         if trace is not None:
             trace["fused_2d"] = catf.permute(0, 3, 1, 2).clone()
             trace["fused_shrink"] = fs.permute(0, 3, 1, 2).clone()
+        return heads, com, nz
+
+    def _post_encode_groups(self, canvas, ny, nx, n):
+        """B == 1 frame with the per-agent work split into agent groups on separate HIP streams.
+        Agents are independent until the attention, and every layer launch ends in a partially filled
+        last wave of workgroups; running two half-batches concurrently lets one group's layer tail overlap
+        the other group's next layer.  Results are bit-identical to the single-stream schedule."""
+        G = min(self.agent_streams, n)
+        if self._streams is None or len(self._streams) < G:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(G)]
+        main = torch.cuda.current_stream()
+        st = self.stream()
+        nz = self.buf("nonzero", (1,), torch.int64)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        count = self.buf("comm_count", (1,), torch.int32)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(count), 4, st), "av2x_fill_zero")
+        bounds = [(g * n) // G for g in range(G + 1)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        groups, H, W = [], None, None
+        for g in range(G):
+            g0, g1 = bounds[g], bounds[g + 1]
+            ng, tag = g1 - g0, f"g{g}of{G}"
+            s_g = self._streams[g]
+            s_g.wait_event(fork)
+            with torch.cuda.stream(s_g):
+                cg = canvas[g0:g1]
+                feats, s, H, W = self.trunk(cg, ng, ny, nx, tag=tag)
+                psm_single = self.buf("psm_single" + tag, (ng, H, W, self.A * self.C))
+                self.conv(self.cls_single, s, ng, H, W, psm_single)
+                (b0, h0, w0), (b1, h1, w1), (b2, h2, w2) = feats
+                if (h0, w0) != (H, W):
+                    raise NotImplementedError("mask/feature size mismatch (where2comm_fuse.py:230) never happens for AirV2X")
+                mask, _, _, _ = self.comm_mask(psm_single, ng, H, W, [ng], has_ego=(g == 0), tag=tag, count=count)
+                _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), ng, h0 * w0, b0.shape[-1], self.stream()),
+                           "av2x_apply_mask")
+                first = 1 if g == 0 else 0
+                m1 = m2 = None
+                if ng - first > 0:
+                    m1, _, _ = self.run_block(1, b0[first:], ng - first, h0, w0, "masked" + tag)
+                    m2, _, _ = self.run_block(2, m1, ng - first, h1, w1, "masked" + tag)
+                done = torch.cuda.Event()
+                done.record(s_g)
+            groups.append((g0, g1, first, b0, b1, b2, m1, m2, done))
+        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        for gr in groups:
+            main.wait_event(gr[-1])
+        dims = self.level_dims(ny, nx)
+        fused = []
+        for i, (h, w, c) in enumerate(dims):
+            f = self.buf(f"fused{i}", (1, h, w, c))
+            ptrs = []
+            for (g0, g1, first, b0, b1, b2, m1, m2, _) in groups:
+                unm, msk = (b0, None) if i == 0 else ((b1, m1) if i == 1 else (b2, m2))
+                for l in range(g1 - g0):
+                    if i == 0 or l < first:
+                        ptrs.append(unm[l].data_ptr())
+                    else:
+                        ptrs.append(msk[l - first].data_ptr())
+            self.attn(ptrs, h * w, c, f[0])
+            fused.append((f, h, w))
+        catf = self.buf("cat_fused", (1, H, W, self.cat_c))
+        self.run_deblocks(fused, 1, catf)
+        fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
+        heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fs, 1, H, W, heads)
+        com = (count.to(torch.float32) / float(n * H * W)).sum()
         return heads, com, nz
 
     # ------------------------------------------------------------------ agent-sharded frame (one frame over N GPUs)
@@ -574,3 +659,33 @@ class Where2ComEngine:
         comm_rate = int(stats[1].item()) if sync_comm_rate else stats[1]
         out.update({"mask": 0, "com": com, "comm_rate": comm_rate})
         return out
+
+
+class FramePipeline:
+    """Throughput mode: ``depth`` independent frames in flight, each on its own HIP stream with its own
+    workspaces (weights shared).  Every layer launch ends in a partially filled last round of
+    workgroups and the ego stage of a frame is a single-image tail; a second frame's kernels fill those
+    gaps.  Per-frame results are bit-identical to the sequential schedule; per-frame latency grows."""
+
+    def __init__(self, engine, depth=2):
+        self.engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
+        self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def submit(self, data_dict, **kw):
+        """Enqueue one frame; returns (output dict, event recorded on the frame's stream)."""
+        k = self.i % len(self.engines)
+        self.i += 1
+        s = self.streams[k]
+        s.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
+        with torch.cuda.stream(s):
+            out = self.engines[k].forward(data_dict, **kw)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self.events[k] = ev
+        return out, ev
+
+    def drain(self):
+        for s in self.streams:
+            torch.cuda.current_stream().wait_stream(s)

@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a captured HIP graph (1) or eager (0); "
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent frames kept in flight per GPU (separate HIP streams + workspaces, shared weights); "
+                         "1 = strictly sequential frames (latency mode, also reported as single_stream)")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica",
                     help="replica: every GPU runs its own frames (default, weak scaling); shard: ONE frame's agents are "
                          "split over the GPUs with an RCCL all-gather of the masked features (SURVEY 8e, strong scaling)")
@@ -123,6 +126,11 @@ def main():
     if a.mode == "shard":
         frame = ShardedFrame(EngineBackend(eng))
         step = lambda: frame.forward(dd)
+    elif a.inflight > 1:
+        from airv2x_perception_amd.opencood_iface.engine import FramePipeline
+        model(dd)  # weights packed, tiles tuned
+        pipe = FramePipeline(eng, a.inflight)
+        step = lambda: pipe.submit(dd)[0]
     else:
         step = lambda: model(dd)
 
@@ -138,6 +146,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    if a.mode == "replica" and a.inflight > 1:
+        pipe.drain()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -158,8 +168,21 @@ def main():
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
                    "parallelism": ("single GPU" if world == 1 else "independent frames per GPU (replicas)") if a.mode == "replica"
                    else f"one frame, {a.agents // world} agent(s) per GPU, RCCL all-gather of masked multi-scale features",
-                   "launch": "hipGraph replay" if eng.graph_active() else "eager"},
+                   "launch": "hipGraph replay" if eng.graph_active() else "eager",
+                   "frames_in_flight": a.inflight if a.mode == "replica" else 1},
     }
+    if a.mode == "replica" and a.inflight > 1 and rank == 0:
+        # latency mode for reference: strictly one frame at a time on one stream
+        for _ in range(2):
+            model(dd)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            out = model(dd)
+        torch.cuda.synchronize()
+        l1 = (time.perf_counter() - t1) / a.steps
+        res["single_stream"] = {"frames_per_s": round(1.0 / l1, 2), "ms_per_frame": round(l1 * 1e3, 3),
+                                "note": "one frame at a time (no overlap between frames)"}
 
     # ---------------- second figure: frame + on-device post-process (decode, filters, rotated NMS) ----------
     if rank == 0 and a.mode == "replica":
