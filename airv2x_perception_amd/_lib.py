@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint64, c_void_p
 
 # torch bundles its own libamdhip64; it MUST be the first HIP runtime mapped into the process so
 # that libairv2x_hip.so binds to the same runtime instance (streams and device pointers are
@@ -36,6 +36,11 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_fill_zero": (c_int32, [c_void_p, c_uint64, c_void_p]),
     "av2x_conv2d": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_conv2d_res": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "av2x_fax_attention": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_void_p]),
+    "av2x_agent_mean": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "av2x_comm_mask": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_apply_mask": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -26,6 +26,7 @@ struct ConvParams {
     const float* w;
     const float* scale;
     const float* shift;
+    const float* res;  // optional residual, same layout as out (AV2X_CONV mode only)
     float* out;
     int H, W, Cin, in_ctot, in_coff;
     int Ho, Wo, HoWo;
@@ -242,10 +243,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
                 const int m = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (!nok || m >= p.M) continue;
                 float v = acc[a][c][r] * sc + sh;
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // exact GELU (nn.GELU())
                 size_t off;
                 if (p.mode == AV2X_CONV) {
                     off = (size_t)m * p.out_ctot + p.out_coff + co;
+                    if (p.res) v += p.res[off];
                 } else {
                     const int img = m / p.HoWo, rem = m - img * p.HoWo;
                     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -282,15 +285,25 @@ int launch(const ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
+                               const float* shift, const float* residual, float* out, av2x_stream_t stream);
+
 extern "C" int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
                            const float* shift, float* out, av2x_stream_t stream) {
+    return av2x_conv2d_res(d, in, w, scale, shift, nullptr, out, stream);
+}
+
+extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
+                               const float* shift, const float* residual, float* out, av2x_stream_t stream) {
     if (!d || !in || !w || !shift || !out) return av2x::fail("av2x_conv2d: null argument");
+    if (residual && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: residual only with mode AV2X_CONV");
+    if (d->relu < 0 || d->relu > 2) return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU)", d->relu);
     if (d->cin % BK != 0) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);
     if (d->coutp % 32 != 0 || d->coutp <= 0) return av2x::fail("av2x_conv2d: coutp=%d must be a positive multiple of 32", d->coutp);
     if (d->mode < 0 || d->mode > 2) return av2x::fail("av2x_conv2d: bad mode %d", d->mode);
     if (d->in_coff % 4 || d->in_ctot % 4) return av2x::fail("av2x_conv2d: input channel offset/stride must be multiples of 4");
     ConvParams p;
-    p.in = in; p.w = w; p.scale = scale; p.shift = shift; p.out = out;
+    p.in = in; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
     p.H = d->h; p.W = d->w; p.Cin = d->cin; p.in_ctot = d->in_ctot; p.in_coff = d->in_coff;
     p.relu = d->relu; p.mode = d->mode; p.up = d->up;
     p.Cout = d->cout; p.CoutP = d->coutp; p.out_ctot = d->out_ctot; p.out_coff = d->out_coff;

@@ -1,0 +1,222 @@
+// Kernels of the CoBEVT fused-axial-attention fusion that are not GEMMs
+// (the Linear layers run on conv_igemm_f32 as 1x1 convolutions over tokens):
+//
+//   layernorm_kernel     nn.LayerNorm over C (one wave per token, 16-byte loads)           HBM-bound
+//   fax_attention_kernel window / grid attention of swap_fusion_modules.py:78-127: per (window, head)
+//                        softmax(q*scale . k^T + relative-position bias, padded agents masked) . v
+//                        with the 'b m d (x w1) (y w2)' / 'b m d (w1 x) (w2 y)' partitions done as
+//                        index arithmetic on the NHWC token buffer (no rearrange copies)
+//   agent_mean_kernel    mean over the agent axis (mlp_head Reduce, :270)                   HBM-bound
+#include "av2x_common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm
+template <int CK>  // C = 256 * CK / ... : each lane holds CK float4 (C = 256*CK)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float4* __restrict__ x, const float4* __restrict__ gamma,
+                                                        const float4* __restrict__ beta, float4* __restrict__ y,
+                                                        int n_tokens, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tokens) return;
+    constexpr int C = 256 * CK;
+    float4 v[CK];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        v[k] = x[(size_t)tok * (C / 4) + k * 64 + lane];
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);  // biased variance, as torch.nn.functional.layer_norm
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const float4 g = gamma[k * 64 + lane], b = beta[k * 64 + lane];
+        float4 r;
+        r.x = (v[k].x - mean) * rstd * g.x + b.x;
+        r.y = (v[k].y - mean) * rstd * g.y + b.y;
+        r.z = (v[k].z - mean) * rstd * g.z + b.z;
+        r.w = (v[k].w - mean) * rstd * g.w + b.w;
+        y[(size_t)tok * (C / 4) + k * 64 + lane] = r;
+    }
+}
+
+// ---------------------------------------------------------------- fused axial attention
+struct FaxParams {
+    const float* qkv;   // (L*H*W, 3*C) rows = tokens in NHWC order (agent-major)
+    const float* table; // ((2L-1)*(2ws-1)^2, heads)
+    float* out;         // (L*H*W, C)
+    int L, n_valid, H, W, ws, heads, grid;
+    float scale;
+};
+
+constexpr int DH = 32;  // dim_head (fax_fusion.dim_head, cobevt yaml)
+
+__global__ __launch_bounds__(256) void fax_attention_kernel(const FaxParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ws = p.ws, ws2 = ws * ws;
+    const int T = p.L * ws2, Tk = p.n_valid * ws2;
+    const int X = p.H / ws, Y = p.W / ws;
+    const int wx = blockIdx.x / Y, wy = blockIdx.x % Y;
+    const int C = p.heads * DH, C3 = 3 * C;
+    const int tab_n = (2 * p.L - 1) * (2 * ws - 1) * (2 * ws - 1);
+    // per-wave LDS: K[Tk][32], V[Tk][32], bias table of the current head
+    float* Kl = lds + (size_t)wave * (2 * Tk * DH + tab_n);
+    float* Vl = Kl + Tk * DH;
+    float* tab = Vl + Tk * DH;
+
+    auto token_row = [&](int t) -> int {  // token (l, w1, w2) of this window -> row of the token buffer
+        const int l = t / ws2, r = t - l * ws2, w1 = r / ws, w2 = r - w1 * ws;
+        const int ph = p.grid ? (w1 * X + wx) : (wx * ws + w1);
+        const int pw = p.grid ? (w2 * Y + wy) : (wy * ws + w2);
+        return (l * p.H + ph) * p.W + pw;
+    };
+
+    for (int h = wave; h < p.heads; h += 4) {
+        // stage K, V of the valid (un-padded) agents and this head's bias column
+        for (int j0 = 0; j0 < Tk; j0 += 8) {
+            const int j = j0 + (lane >> 3), d4 = lane & 7;
+            if (j < Tk) {
+                const float* src = p.qkv + (size_t)token_row(j) * C3 + h * DH + d4 * 4;
+                *reinterpret_cast<float4*>(Kl + j * DH + d4 * 4) = *reinterpret_cast<const float4*>(src + C);
+                *reinterpret_cast<float4*>(Vl + j * DH + d4 * 4) = *reinterpret_cast<const float4*>(src + 2 * C);
+            }
+        }
+        for (int i = lane; i < tab_n; i += 64) tab[i] = p.table[(size_t)i * p.heads + h];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+
+        for (int r0 = 0; r0 < T; r0 += 64) {
+            const int t = r0 + lane;
+            const bool act = t < T;
+            const int tt = act ? t : 0;
+            const int row = token_row(tt);
+            float q[DH], o[DH];
+            {
+                const float* src = p.qkv + (size_t)row * C3 + h * DH;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + d);
+                    q[d] = v.x * p.scale; q[d + 1] = v.y * p.scale; q[d + 2] = v.z * p.scale; q[d + 3] = v.w * p.scale;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DH; ++d) o[d] = 0.f;
+            // relative-position index (swap_fusion_modules.py:53-75): (dl + L-1)*(2ws-1)^2 + (dh + ws-1)*(2ws-1) + (dw + ws-1)
+            const int li = tt / ws2, ri = tt - li * ws2, hi = ri / ws, wi = ri - hi * ws;
+            const int s1 = 2 * ws - 1;
+            const int base_i = ((li + p.L - 1) * s1 + (hi + ws - 1)) * s1 + (wi + ws - 1);
+            float m = -INFINITY, lsum = 0.f;
+            for (int j = 0; j < Tk; ++j) {
+                const int lj = j / ws2, rj = j - lj * ws2, hj = rj / ws, wj = rj - hj * ws;
+                const float bias = tab[base_i - ((lj * s1 + hj) * s1 + wj)];
+                const float* kj = Kl + j * DH;
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(kj + d);
+                    s = fmaf(q[d], kv.x, s); s = fmaf(q[d + 1], kv.y, s); s = fmaf(q[d + 2], kv.z, s); s = fmaf(q[d + 3], kv.w, s);
+                }
+                s += bias;
+                const float mn = fmaxf(m, s);
+                const float alpha = expf(m - mn), pj = expf(s - mn);
+                lsum = lsum * alpha + pj;
+                const float* vj = Vl + j * DH;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 vv = *reinterpret_cast<const float4*>(vj + d);
+                    o[d] = fmaf(pj, vv.x, o[d] * alpha); o[d + 1] = fmaf(pj, vv.y, o[d + 1] * alpha);
+                    o[d + 2] = fmaf(pj, vv.z, o[d + 2] * alpha); o[d + 3] = fmaf(pj, vv.w, o[d + 3] * alpha);
+                }
+                m = mn;
+            }
+            if (act) {
+                const float inv = 1.0f / lsum;
+                float* dst = p.out + (size_t)row * C + h * DH;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4)
+                    *reinterpret_cast<float4*>(dst + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void agent_mean_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, int L) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = x[i];
+        for (int l = 1; l < L; ++l) {
+            const float4 v = x[i + (size_t)l * n4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float inv = (float)L;
+        y[i] = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int av2x_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens, int32_t c,
+                              float eps, av2x_stream_t stream) {
+    if (n_tokens == 0) return 0;
+    if (!x || !gamma || !beta || !y) return av2x::fail("av2x_layernorm: null argument");
+    if (n_tokens < 0 || n_tokens > (1ll << 31) - 8) return av2x::fail("av2x_layernorm: bad token count");
+    const dim3 grid((unsigned)((n_tokens + 3) / 4)), block(256);
+    hipStream_t st = av2x::as_stream(stream);
+    auto X = reinterpret_cast<const float4*>(x);
+    auto G = reinterpret_cast<const float4*>(gamma);
+    auto Bt = reinterpret_cast<const float4*>(beta);
+    auto Yp = reinterpret_cast<float4*>(y);
+    switch (c) {
+        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, X, G, Bt, Yp, (int)n_tokens, eps); break;
+        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, X, G, Bt, Yp, (int)n_tokens, eps); break;
+        default: return av2x::fail("av2x_layernorm: c=%d unsupported (256/512)", c);
+    }
+    return av2x::check_launch("layernorm_kernel");
+}
+
+extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, float* out, int32_t n_agents_padded,
+                                  int32_t n_valid, int32_t h, int32_t w, int32_t window, int32_t heads, int32_t dim_head,
+                                  int32_t grid_partition, av2x_stream_t stream) {
+    if (!qkv || !bias_table || !out) return av2x::fail("av2x_fax_attention: null argument");
+    if (dim_head != DH) return av2x::fail("av2x_fax_attention: dim_head=%d unsupported (32)", dim_head);
+    if (n_valid < 1 || n_valid > n_agents_padded || window < 1 || h % window || w % window || heads < 1)
+        return av2x::fail("av2x_fax_attention: bad sizes (L=%d valid=%d h=%d w=%d ws=%d)", n_agents_padded, n_valid, h, w, window);
+    FaxParams p;
+    p.qkv = qkv; p.table = bias_table; p.out = out;
+    p.L = n_agents_padded; p.n_valid = n_valid; p.H = h; p.W = w; p.ws = window; p.heads = heads; p.grid = grid_partition;
+    p.scale = 1.0f / sqrtf((float)dim_head);
+    const int Tk = n_valid * window * window;
+    const int tab_n = (2 * n_agents_padded - 1) * (2 * window - 1) * (2 * window - 1);
+    const size_t lds = (size_t)4 * (2 * Tk * DH + tab_n) * sizeof(float);
+    if (lds > 160 * 1024) return av2x::fail("av2x_fax_attention: %zu B of LDS needed (> 160 KiB): too many valid agents", lds);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fax_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(fax_attention_kernel, dim3((h / window) * (w / window)), dim3(256), lds, av2x::as_stream(stream), p);
+    return av2x::check_launch("fax_attention_kernel");
+}
+
+extern "C" int av2x_agent_mean(const float* x, float* y, int32_t n_agents, int64_t elems_per_agent, av2x_stream_t stream) {
+    if (!x || !y) return av2x::fail("av2x_agent_mean: null argument");
+    if (n_agents < 1 || elems_per_agent <= 0 || elems_per_agent % 4) return av2x::fail("av2x_agent_mean: bad sizes");
+    const size_t n4 = (size_t)elems_per_agent / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(agent_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n4, n_agents);
+    return av2x::check_launch("agent_mean_kernel");
+}

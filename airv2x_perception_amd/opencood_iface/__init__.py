@@ -5,3 +5,4 @@ Module / class names follow ``opencood.models`` so that the reference's name reg
 shown in INTEGRATION.md.
 """
 from .airv2x_where2com import Airv2xWhere2com  # noqa: F401
+from .airv2x_cobevt import Airv2xCoBEVT  # noqa: F401,E402

@@ -1,0 +1,141 @@
+"""Host-side driver of the CoBEVT-LiDAR path (models/airv2x_cobevt.py:112-156) on one MI355X.
+
+Per-agent trunk = the Where2Comm engine's (same encoders / backbone / shrink header).  Fusion =
+SwapFusionEncoder (swap_fusion_modules.py:233-280): the token tensor stays in ONE NHWC buffer
+``x (L, H, W, C)`` for the whole encoder; 'regroup' (fuse_utils.py:13-64) is the shrink conv
+writing the real agents into ``x[:n]`` plus a zero fill of the padded agents, and every einops
+rearrange of the reference is index arithmetic inside av2x_fax_attention.  The Linear layers are
+1x1 convolutions over tokens on conv_igemm_f32 (bias / GELU / residual fused in its epilogue).
+
+Padded agents cannot be skipped: their query tokens do attend to the valid keys and the final
+``mean`` over the agent axis includes them (swap_fusion_modules.py:270), exactly as in the reference.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+
+import torch
+
+from .. import _lib
+from .engine import ConvLayer, Where2ComEngine, _ptr
+from .packing import pack_conv_weight
+
+LN_EPS = 1e-5
+
+
+class CoBEVTEngine(Where2ComEngine):
+    def _init_config(self, args):
+        self.bb = args["base_bev_backbone"]
+        self.sh = args["shrink_header"]
+        self.fcfg = {"fully": False}
+        self.fax = args["fax_fusion"]
+        if args.get("compression", 0):
+            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        if not self.fax.get("mask", False):
+            raise NotImplementedError("SwapFusionBlock without mask (not the shipped AirV2X config)")
+        self.L = int(sum(args["max_cav"].values()))
+        self.heads_n = self.fax["input_dim"] // self.fax["dim_head"]
+
+    def share_weights(self):
+        raise NotImplementedError
+
+    def _linear(self, sd, wkey, bkey, act, up):
+        w = sd[wkey].detach().float()
+        wp, coutp = pack_conv_weight(w.view(w.shape[0], w.shape[1], 1, 1))
+        b = sd[bkey].detach().float() if bkey else torch.zeros(w.shape[0])
+        return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
+
+    def _load_fusion(self, sd, up):
+        C, ws, L = self.fax["input_dim"], self.fax["window_size"], self.L
+        from ..synth import _relative_position_index
+        expect = torch.from_numpy(_relative_position_index(L, ws))
+        self.fax_layers = []
+        for i in range(self.fax["depth"]):
+            blk = {}
+            for part in ("window", "grid"):
+                a, f = f"fusion_net.layers.{i}.{part}_attention", f"fusion_net.layers.{i}.{part}_ffd"
+                idx = sd[a + ".fn.relative_position_index"].cpu()
+                if idx.shape != expect.shape or not torch.equal(idx, expect):
+                    raise ValueError(f"{a}.fn.relative_position_index is not the index of a ({L},{ws},{ws}) window")
+                blk[part] = {
+                    "ln1": (up(sd[a + ".norm.weight"].float()), up(sd[a + ".norm.bias"].float())),
+                    "qkv": self._linear(sd, a + ".fn.to_qkv.weight", None, 0, up),
+                    "out": self._linear(sd, a + ".fn.to_out.0.weight", None, 0, up),
+                    "table": up(sd[a + ".fn.relative_position_bias_table.weight"].detach().float()),
+                    "ln2": (up(sd[f + ".norm.weight"].float()), up(sd[f + ".norm.bias"].float())),
+                    "ff1": self._linear(sd, f + ".fn.net.0.weight", f + ".fn.net.0.bias", 2, up),   # + GELU
+                    "ff2": self._linear(sd, f + ".fn.net.3.weight", f + ".fn.net.3.bias", 0, up),
+                }
+            self.fax_layers.append(blk)
+        self.head_ln = (up(sd["fusion_net.mlp_head.2.weight"].float()), up(sd["fusion_net.mlp_head.2.bias"].float()))
+        self.head_lin = self._linear(sd, "fusion_net.mlp_head.3.weight", "fusion_net.mlp_head.3.bias", 0, up)
+
+    def ln(self, x, gb, y, n_tokens, c):
+        _lib.check(self.lib.av2x_layernorm(_ptr(x), _ptr(gb[0]), _ptr(gb[1]), _ptr(y), n_tokens, c, LN_EPS, self.stream()),
+                   "av2x_layernorm")
+
+    def fax_encoder(self, x, n_valid, H, W, trace=None):
+        """x (L,H,W,C) updated in place through the depth x {window, grid} x {attention, FFN} blocks;
+        returns the (1,H,W,C) output of mlp_head."""
+        L, C, ws = self.L, self.fax["input_dim"], self.fax["window_size"]
+        if H % ws or W % ws:
+            raise ValueError(f"BEV map {H}x{W} is not divisible by the window size {ws}")
+        nt = L * H * W
+        xn = self.buf("fax_xn", (L, H, W, C))
+        qkv = self.buf("fax_qkv", (L, H, W, 3 * C))
+        att = self.buf("fax_att", (L, H, W, C))
+        hid = self.buf("fax_hid", (L, H, W, self.fax["mlp_dim"]))
+        for i, blk in enumerate(self.fax_layers):
+            for gi, part in enumerate(("window", "grid")):
+                P = blk[part]
+                self.ln(x, P["ln1"], xn, nt, C)
+                self.conv(P["qkv"], xn, L, H, W, qkv)
+                _lib.check(self.lib.av2x_fax_attention(_ptr(qkv), _ptr(P["table"]), _ptr(att), L, n_valid, H, W, ws,
+                                                       self.heads_n, self.fax["dim_head"], gi, self.stream()),
+                           "av2x_fax_attention")
+                self.conv(P["out"], att, L, H, W, x, residual=x)            # to_out(.) + x   (PreNormResidual)
+                self.ln(x, P["ln2"], xn, nt, C)
+                self.conv(P["ff1"], xn, L, H, W, hid)                        # Linear + bias + GELU
+                self.conv(P["ff2"], hid, L, H, W, x, residual=x)            # Linear + bias + x
+            if trace is not None:
+                trace[f"fax_block{i}"] = x.permute(0, 3, 1, 2).unsqueeze(0).clone()
+        mean = self.buf("fax_mean", (1, H, W, C))
+        _lib.check(self.lib.av2x_agent_mean(_ptr(x), _ptr(mean), L, H * W * C, self.stream()), "av2x_agent_mean")
+        mn = self.buf("fax_mean_ln", (1, H, W, C))
+        self.ln(mean, self.head_ln, mn, H * W, C)
+        fused = self.buf("fax_fused", (1, H, W, C))
+        self.conv(self.head_lin, mn, 1, H, W, fused)
+        return fused
+
+    @torch.no_grad()
+    def forward(self, data_dict, trace=None, sync_comm_rate=False):
+        if not self.weights_ready:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        record_len, slots = self.frame_layout(data_dict)
+        if len(record_len) != 1:
+            raise NotImplementedError("CoBEVT engine: one collaborative frame (B = 1) per call")
+        n = record_len[0]
+        if n > self.L:
+            raise ValueError(f"{n} agents exceed max_cav_num = {self.L}")
+        canvas, ny, nx = self.encode(data_dict, record_len, slots)
+        dims = self.level_dims(ny, nx)
+        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        C = self.fax["input_dim"]
+        x = self.buf("fax_x", (self.L, H, W, C))
+        # regroup (fuse_utils.py:13-64): real agents first, zero padding after; the shrink conv writes x[:n]
+        if n < self.L:
+            _lib.check(self.lib.av2x_fill_zero(_ptr(x[n:]), (self.L - n) * H * W * C * 4, self.stream()), "av2x_fill_zero")
+        _, s, H2, W2 = self.trunk(canvas, n, ny, nx, shrink_out=x[:n])
+        assert (H2, W2) == (H, W)
+        if trace is not None:
+            trace["shrink"] = x[:n].permute(0, 3, 1, 2).clone()
+        fused = self.fax_encoder(x, n, H, W, trace)
+        heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, 1, H, W, heads)
+        if trace is not None:
+            trace["fused"] = fused.permute(0, 3, 1, 2).clone()
+        outs = torch.split(heads, self.head_splits, dim=1)
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        return out

@@ -79,13 +79,7 @@ class Where2ComEngine:
         if self.device.type != "cuda":
             raise RuntimeError("Where2ComEngine runs on a HIP device only (no CPU path exists)")
         self.lib = _lib.load()
-        self.bb = args["modality_fusion"]["base_bev_backbone"]
-        self.sh = args["modality_fusion"]["shrink_header"]
-        self.fcfg = args["where2com_fusion"]
-        if not self.fcfg["multi_scale"]:
-            raise NotImplementedError("only the multi_scale Where2comm variant (the shipped AirV2X config) is built")
-        if args["modality_fusion"].get("compression", 0):
-            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        self._init_config(args)
         self.A, self.C = args["anchor_number"], args["num_class"]
         self.ws = {}
         self.weights_ready = False
@@ -99,6 +93,15 @@ class Where2ComEngine:
                                     # of the frame on separate HIP streams.  Measured: no gain, off by default
         self._streams = None
         self._desc = _lib.ConvDesc()
+
+    def _init_config(self, args):
+        self.bb = args["modality_fusion"]["base_bev_backbone"]
+        self.sh = args["modality_fusion"]["shrink_header"]
+        self.fcfg = args["where2com_fusion"]
+        if not self.fcfg["multi_scale"]:
+            raise NotImplementedError("only the multi_scale Where2comm variant (the shipped AirV2X config) is built")
+        if args["modality_fusion"].get("compression", 0):
+            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
 
     def share_weights(self):
         """A second engine on the same device that shares the packed weights but owns its workspaces:
@@ -182,6 +185,11 @@ class Where2ComEngine:
         wh, cph = pack_conv_weight(wcat)
         self.head_splits = [sd[n + ".weight"].shape[0] for n in names]
         self.heads = ConvLayer(up(wh), None, up(bcat), cin, wcat.shape[0], cph, 1, 1, 0, 0, _lib.AV2X_CONV_NCHW)
+        self._load_fusion(sd, up)
+        self.weights_ready = True
+
+    def _load_fusion(self, sd, up):
+        dev = self.device
         g = "fusion_net.naive_communication.gaussian_filter"
         comm = self.fcfg["communication"]
         if "gaussian_smooth" in comm:
@@ -193,7 +201,6 @@ class Where2ComEngine:
             self.gauss_b = torch.zeros(1, device=dev)
             self.gauss_k = 1
         self.threshold = float(comm["threshold"] or 0.0)
-        self.weights_ready = True
 
     # ------------------------------------------------------------------ buffers
     def buf(self, name, shape, dtype=torch.float32):
@@ -209,7 +216,7 @@ class Where2ComEngine:
         return c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------ kernels
-    def conv(self, L, x, n, h, w, out, in_ctot=None, in_coff=0, out_ctot=None, out_coff=0):
+    def conv(self, L, x, n, h, w, out, in_ctot=None, in_coff=0, out_ctot=None, out_coff=0, residual=None):
         """x: NHWC buffer holding >= n images of (h, w, in_ctot); returns (ho, wo)."""
         d = self._desc
         d.n, d.h, d.w, d.cin = n, h, w, L.cin
@@ -242,8 +249,8 @@ class Where2ComEngine:
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(self.lib.av2x_conv2d(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(out),
-                                        self.stream()), "av2x_conv2d")
+        _lib.check(self.lib.av2x_conv2d_res(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
+                                            _ptr(out), self.stream()), "av2x_conv2d")
         if self.profile is not None:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
@@ -263,7 +270,11 @@ class Where2ComEngine:
             bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
             return (bm << 16) | bn
         best, best_t = None, float("inf")
-        args = (_ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(out), self.stream())
+        # tune into a scratch output: `out` may alias the input / residual (in-place transformer updates)
+        ho = d.ho * (L.up if L.mode == _lib.AV2X_DECONV else 1)
+        wo = d.wo * (L.up if L.mode == _lib.AV2X_DECONV else 1)
+        scratch = torch.empty(d.n * ho * wo * max(d.out_ctot, L.cout), dtype=torch.float32, device=self.device)
+        args = (_ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(scratch), self.stream())
         for bm, bn in self.TILE_CANDIDATES:
             if L.coutp % (bn & 0x3fff) or ((bn & 0x3fff) == 32 and L.coutp != 32):
                 continue
@@ -306,10 +317,10 @@ class Where2ComEngine:
             self.conv(L, x, n, h, w, cat, out_ctot=self.cat_c, out_coff=coff)
             coff += L.cout
 
-    def run_shrink(self, x, n, h, w, tag):
+    def run_shrink(self, x, n, h, w, tag, out=None):
         cur, cin_tot = x, self.cat_c
         for li, L in enumerate(self.shrink):
-            dst = self.buf(f"shrink{li}_{tag}", (n, h, w, L.cout))
+            dst = out if (out is not None and li == len(self.shrink) - 1) else self.buf(f"shrink{li}_{tag}", (n, h, w, L.cout))
             self.conv(L, cur, n, h, w, dst, in_ctot=cin_tot)
             cur, cin_tot = dst, L.cout
         return cur
@@ -345,7 +356,7 @@ class Where2ComEngine:
                                                         _ptr(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter")
         return canvas, ny, nx
 
-    def trunk(self, canvas, n, ny, nx, tag="all", block_out=None):
+    def trunk(self, canvas, n, ny, nx, tag="all", block_out=None, shrink_out=None):
         """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""
         feats = []
         x, h, w = canvas, ny, nx
@@ -355,7 +366,7 @@ class Where2ComEngine:
         H, W = feats[0][1] * self.deblocks[0].up, feats[0][2] * self.deblocks[0].up
         cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c))
         self.run_deblocks(feats, n, cat)
-        s = self.run_shrink(cat, n, H, W, tag) if self.shrink else cat
+        s = self.run_shrink(cat, n, H, W, tag, out=shrink_out) if self.shrink else cat
         return feats, s, H, W
 
     def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True, tag="", count=None):

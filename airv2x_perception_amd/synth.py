@@ -238,6 +238,15 @@ def synthetic_tensor(key, shape, kind, seed=0):
     shape = tuple(shape)
     if kind == "count":
         return np.zeros(shape, dtype=np.int64)
+    if kind.startswith("relidx:"):
+        _, L, ws = kind.split(":")
+        return _relative_position_index(int(L), int(ws))
+    if kind == "ln_w":
+        return g.uniform(0.7, 1.3, size=shape).astype(np.float32)
+    if kind == "ln_b":
+        return g.uniform(-0.1, 0.1, size=shape).astype(np.float32)
+    if kind == "relbias":
+        return g.uniform(-1.0, 1.0, size=shape).astype(np.float32)
     if kind in ("conv", "lin", "head", "deconv"):
         if kind == "lin":
             fan_in = shape[1]
@@ -248,7 +257,7 @@ def synthetic_tensor(key, shape, kind, seed=0):
         gain = 4.0 if kind == "head" else 2.0
         b = np.sqrt(3.0 * gain / fan_in)
         w = g.uniform(-b, b, size=shape).astype(np.float32)
-        if kind == "lin":
+        if kind == "lin" and shape == (64, 10):
             # PFN input columns: abs x,y,z,intensity, cluster xyz, centre xyz.  Absolute x/y reach
             # +-140 m, so their weights are scaled down to keep pillar features O(1).
             w *= 4.0 * np.asarray([0.01, 0.02, 0.3, 1.0, 1.0, 1.0, 0.5, 2.0, 2.0, 0.02], dtype=np.float32)
@@ -423,3 +432,68 @@ def data_dict_to(dd, device):
     if isinstance(dd, torch.Tensor):
         return dd.to(device)
     return dd
+
+
+# --------------------------------------------------------------------------
+# CoBEVT (airv2x_intermediate_cobevt.yaml :148-293): same per-agent trunk, the trunk keys sit at
+# the top level of model.args and the fusion is the fused-axial-attention encoder
+# --------------------------------------------------------------------------
+
+def default_hypes_cobevt(lidar_range=None, max_cav=(3, 2, 2)):
+    hy = default_hypes(lidar_range, max_cav)
+    a = hy["model"]["args"]
+    mf = a.pop("modality_fusion")
+    a.pop("where2com_fusion")
+    a.pop("ego_type", None)
+    a["base_bev_backbone"] = mf["base_bev_backbone"]
+    a["shrink_header"] = mf["shrink_header"]
+    a["compression"] = 0
+    a["fax_fusion"] = {"input_dim": 256, "mlp_dim": 256, "window_size": 4, "dim_head": 32, "drop_out": 0.1,
+                       "depth": 3, "mask": True, "agent_size": int(sum(max_cav))}
+    hy["model"]["core_method"] = "airv2x_cobevt"
+    hy["name"] = "airv2x_intermediate_cobevt"
+    return hy
+
+
+def _relative_position_index(L, ws):
+    coords = np.stack(np.meshgrid(np.arange(L), np.arange(ws), np.arange(ws), indexing="ij")).reshape(3, -1)
+    rel = (coords[:, :, None] - coords[:, None, :]).transpose(1, 2, 0).copy()
+    rel[:, :, 0] += L - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 2] += ws - 1
+    rel[:, :, 0] *= (2 * ws - 1) * (2 * ws - 1)
+    rel[:, :, 1] *= 2 * ws - 1
+    return rel.sum(-1).astype(np.int64)
+
+
+def cobevt_param_spec(args):
+    """Ordered (key, shape, kind) manifest of Airv2xCoBEVT's state_dict (236 tensors at L = 7;
+    checked against the reference's own state_dict by tools/gen_golden.py)."""
+    w2c_like = {"collaborators": args["collaborators"],
+                "modality_fusion": {"base_bev_backbone": args["base_bev_backbone"], "shrink_header": args["shrink_header"]},
+                "where2com_fusion": {"communication": {"gaussian_smooth": {"k_size": 5}}},
+                "anchor_number": args["anchor_number"], "num_class": args["num_class"], "outC": args["outC"],
+                "obj_head": args["obj_head"]}
+    base = where2com_param_spec(w2c_like)
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
+    fax = args["fax_fusion"]
+    C, M, ws, L = fax["input_dim"], fax["mlp_dim"], fax["window_size"], fax["agent_size"]
+    nh = C // fax["dim_head"]
+    T = L * ws * ws
+    spec = list(trunk)
+    for i in range(fax["depth"]):
+        for part in ("window", "grid"):
+            p = f"fusion_net.layers.{i}.{part}_attention"
+            spec += [(p + ".norm.weight", (C,), "ln_w"), (p + ".norm.bias", (C,), "ln_b"),
+                     (p + ".fn.relative_position_index", (T, T), f"relidx:{L}:{ws}"),
+                     (p + ".fn.to_qkv.weight", (3 * C, C), "lin"),
+                     (p + ".fn.to_out.0.weight", (C, C), "lin"),
+                     (p + ".fn.relative_position_bias_table.weight", ((2 * L - 1) * (2 * ws - 1) ** 2, nh), "relbias")]
+            p = f"fusion_net.layers.{i}.{part}_ffd"
+            spec += [(p + ".norm.weight", (C,), "ln_w"), (p + ".norm.bias", (C,), "ln_b"),
+                     (p + ".fn.net.0.weight", (M, C), "lin"), (p + ".fn.net.0.bias", (M,), "bias"),
+                     (p + ".fn.net.3.weight", (C, M), "lin"), (p + ".fn.net.3.bias", (C,), "bias")]
+    spec += [("fusion_net.mlp_head.2.weight", (C,), "ln_w"), ("fusion_net.mlp_head.2.bias", (C,), "ln_b"),
+             ("fusion_net.mlp_head.3.weight", (C, C), "lin"), ("fusion_net.mlp_head.3.bias", (C,), "bias")]
+    return spec + heads

@@ -85,7 +85,7 @@ typedef struct av2x_conv_desc {
     int32_t coutp;             /* padded GEMM column count of `w`                        */
     int32_t out_ctot, out_coff;/* channel stride / offset of the output (concat support) */
     int32_t ks, stride, pad;   /* square kernel                                           */
-    int32_t relu;              /* 1 = ReLU after the affine                               */
+    int32_t relu;              /* activation after the affine: 0 none, 1 ReLU, 2 exact GELU */
     int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
     int32_t up;                /* DECONV: kernel == stride                                */
     int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2) */
@@ -93,6 +93,11 @@ typedef struct av2x_conv_desc {
 
 int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
                 const float* shift, float* out, av2x_stream_t stream);
+/* same, plus `residual` (NULL or a tensor laid out like `out`, AV2X_CONV mode): out = act(affine(acc)) + residual.
+ * Used for the transformer Linear layers (a Linear over tokens is a 1x1 convolution):
+ * PreNormResidual / FeedForward, models/cobevt_modules/base_transformer.py:6-38. */
+int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
+                    const float* shift, const float* residual, float* out, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Where2Comm communication mask.  Replaces Communication.forward, eval branch
@@ -169,6 +174,25 @@ int av2x_postprocess(const float* psm, const float* rm, const float* obj, const 
                      int32_t order_hwl, int32_t top, void* workspace, float* out_corners,
                      float* out_scores, int32_t* out_labels, float* out_boxes, int32_t* out_index,
                      int32_t* counts, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * CoBEVT fused-axial-attention pieces (models/cobevt_modules/swap_fusion_modules.py).
+ * av2x_layernorm: nn.LayerNorm over the last dim of (n_tokens, c) (base_transformer.py:9; eps 1e-5).
+ * av2x_fax_attention: Attention.forward :78-127 for ALL windows of one sample.
+ *   qkv (L*h*w, 3*heads*dim_head): to_qkv output, token rows in agent-major NHWC order;
+ *   bias_table ((2L-1)*(2*window-1)^2, heads): relative_position_bias_table.weight;
+ *   tokens of a window are ordered (agent, w1, w2); grid_partition 0 = 'b m d (x w1) (y w2)' (:167),
+ *   1 = 'b m d (w1 x) (w2 y)' (:185); keys of agents >= n_valid are masked (-inf, :103-108);
+ *   out (L*h*w, heads*dim_head) in the same token order (heads merged, before to_out).
+ * av2x_agent_mean: y = mean over the agent axis of x (n_agents, elems_per_agent)  (:270).
+ * ------------------------------------------------------------------------------------ */
+int av2x_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,
+                   int32_t c, float eps, av2x_stream_t stream);
+int av2x_fax_attention(const float* qkv, const float* bias_table, float* out, int32_t n_agents_padded,
+                       int32_t n_valid, int32_t h, int32_t w, int32_t window, int32_t heads,
+                       int32_t dim_head, int32_t grid_partition, av2x_stream_t stream);
+int av2x_agent_mean(const float* x, float* y, int32_t n_agents, int64_t elems_per_agent,
+                    av2x_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -249,6 +249,86 @@ def postprocess_golden(name, hy_ref, hy, out):
     return g
 
 
+def load_ref_hypes_cobevt(lidar_range):
+    from opencood.hypes_yaml.yaml_utils import load_yaml
+    src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_cobevt.yaml")
+    if lidar_range is None:
+        return load_yaml(src)
+    txt = open(src).read()
+    r = lidar_range
+    txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(txt)
+        path = f.name
+    h = load_yaml(path)
+    os.unlink(path)
+    return h
+
+
+def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride):
+    """Airv2xCoBEVT (fused axial attention) on the real reference vs oracle/cobevt_oracle.py."""
+    from airv2x_perception_amd import synth
+    from oracle import cobevt_oracle as cob
+    from oracle import voxelize_oracle as vox
+    from opencood.models.airv2x_cobevt import Airv2xCoBEVT
+
+    hy_ref = load_ref_hypes_cobevt(lidar_range)
+    hy = synth.default_hypes_cobevt(lidar_range)
+    a_ref = {k: v for k, v in hy_ref["model"]["args"].items()}
+    check_hypes(a_ref, {k: v for k, v in hy["model"]["args"].items() if k != "fax_fusion"})
+    args = hy["model"]["args"]
+    model = Airv2xCoBEVT(hy_ref["model"]["args"]).eval()
+    check_hypes(hy_ref["model"]["args"]["fax_fusion"], args["fax_fusion"], "fax_fusion")
+    spec = synth.cobevt_param_spec(args)
+    ref_sd = model.state_dict()
+    assert [k for k, _, _ in spec] == list(ref_sd.keys()), "cobevt state_dict key order mismatch"
+    for k, shp, _ in spec:
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    for k in ref_sd:  # the index buffers must be what the reference itself computes
+        if k.endswith("relative_position_index"):
+            assert torch.equal(ref_sd[k], sd[k]), k
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"]))
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    cap = {}
+    hs = [model.fusion_net.layers[i].register_forward_hook(lambda m, i_, o, k=i: cap.__setitem__(f"fax_block{k}", o))
+          for i in range(3)]
+    hs.append(model.fusion_net.register_forward_hook(lambda m, i_, o: cap.__setitem__("fused", o)))
+    with torch.no_grad():
+        out = model(dd)
+        tr = {}
+        o = cob.cobevt_forward(dd, sd, args, trace=tr)
+    for h in hs:
+        h.remove()
+    rep = {k: (float((o[k] - out[k]).abs().max()), float(out[k].abs().max())) for k in ("psm", "rm", "obj")}
+    print(f"[{name}] cobevt oracle-vs-reference max|diff| (max|ref|):", {k: f"{a:.3e} ({b:.3e})" for k, (a, b) in rep.items()})
+    assert all(a <= 1e-4 * max(1.0, b) for a, b in rep.values())
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types),
+          "n_points": np.int64(n_points), "cloud": np.asarray("uniform"), "sample_stride": np.int64(1),
+          "big_stride": np.int64(big_stride), "spec_keys": np.asarray([k for k, _, _ in spec]),
+          "max_cav": np.asarray([args["max_cav"][t] for t in synth.AGENT_TYPES], np.int64)}
+    for i, (v, c, n) in enumerate(voxd):
+        fx[f"vox_coords_{i}"], fx[f"vox_num_{i}"] = c, n
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k].numpy()
+    fx["fused_sum"] = np.float64(cap["fused"].double().sum().item())
+    fx["fused"] = cap["fused"][..., ::2, ::2].numpy()
+    for i in range(3):
+        t = cap[f"fax_block{i}"]
+        fx[f"fax_block{i}_sum"] = np.float64(t.double().sum().item())
+        fx[f"fax_block{i}_abssum"] = np.float64(t.double().abs().sum().item())
+        fx[f"fax_block{i}"] = t[..., ::big_stride, ::big_stride].numpy()
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def main():
     os.chdir(tempfile.mkdtemp())
     import_reference()
@@ -259,7 +339,14 @@ def main():
     run_case("w2c_small_n1", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle"], 700, 1, 1, 4)
     # default AirV2X grid, BASELINE config: 4 agents x 8192 points; strided samples + sums
     run_case("w2c_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 5, 20)
+    run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cobevt":
+        os.chdir(tempfile.mkdtemp())
+        import_reference()
+        torch.set_num_threads(8)
+        run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
+    else:
+        main()
