@@ -153,6 +153,181 @@ __global__ __launch_bounds__(256) void fax_attention_kernel(const FaxParams p) {
     }
 }
 
+// ---------------------------------------------------------------- fused axial attention on MFMA
+// One workgroup (4 wave64) per window; heads are processed one after the other, the four waves
+// take the four 32-query-row strips of the head (T = L*ws*ws <= 128 tokens), so K / V / the bias
+// column of the head are staged in LDS once and shared.  Per strip:
+//   S = (Q*scale) K^T      v_mfma_f32_32x32x2_f32, A = Q rows straight from global (each element is
+//                          used by exactly one lane), B = K rows from LDS ([j][36] padded, b128)
+//   S += bias, pad-mask    gathered from the staged table with base[row] - sub[col] (:53-75)
+//   row max / exp / sum    the C layout keeps a row in one (register, half-wave): 5 DPP/shuffle steps
+//   O = P V                P goes through LDS (C layout -> A layout), V is staged k-quad major
+//                          ([j/4][d][4]) so that a lane's four k values are one b128; O is divided
+//                          by the row sum held in the same (register, half) slot
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int KLD = 36;   // K row stride in LDS (floats)
+constexpr int PLD = 68;   // P half-strip row stride (64 keys + 4)
+
+__global__ __launch_bounds__(256) void fax_attention_mfma_kernel(const FaxParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li32 = lane & 31, lh = lane >> 5;
+    const int ws = p.ws, ws2 = ws * ws, s1 = 2 * ws - 1;
+    const int T = p.L * ws2, Tk = p.n_valid * ws2;
+    const int TkP = (Tk + 31) & ~31;                      // keys padded to whole 32-column tiles
+    const int X = p.H / ws, Y = p.W / ws;
+    const int wx = blockIdx.x / Y, wy = blockIdx.x % Y;
+    const int C = p.heads * DH, C3 = 3 * C;
+    const int tab_n = (2 * p.L - 1) * s1 * s1;
+    float* Ks = lds;                                       // [TkP][KLD]
+    float* Vs = Ks + TkP * KLD;                            // [TkP/4][32][4]
+    float* tab = Vs + TkP * DH;                            // [tab_n]
+    int* subj = reinterpret_cast<int*>(tab + ((tab_n + 3) & ~3));   // [TkP]
+    int* rowtok = subj + TkP;                              // [128] token row of every query of the window
+    int* basei = rowtok + 128;                             // [128]
+    float* Ps = reinterpret_cast<float*>(basei + 128) + wave * (32 * PLD);  // per wave [32][PLD]
+
+    auto token_row = [&](int t) -> int {
+        const int l = t / ws2, r = t - l * ws2, w1 = r / ws, w2 = r - w1 * ws;
+        const int ph = p.grid ? (w1 * X + wx) : (wx * ws + w1);
+        const int pw = p.grid ? (w2 * Y + wy) : (wy * ws + w2);
+        return (l * p.H + ph) * p.W + pw;
+    };
+    if (tid < 128) {
+        const int t = tid < T ? tid : T - 1;               // padding rows re-read the last token (never stored)
+        const int l = t / ws2, r = t - l * ws2, w1 = r / ws, w2 = r - w1 * ws;
+        rowtok[tid] = token_row(t);
+        basei[tid] = ((l + p.L - 1) * s1 + (w1 + ws - 1)) * s1 + (w2 + ws - 1);
+    }
+    for (int j = tid; j < TkP; j += 256) {
+        const int l = j / ws2, r = j - l * ws2, w1 = r / ws, w2 = r - w1 * ws;
+        subj[j] = (l * s1 + w1) * s1 + w2;
+    }
+    const int strip = wave;                                // 32 query rows [32*strip, 32*strip+32)
+    const bool strip_on = strip * 32 < T;
+
+    for (int h = 0; h < p.heads; ++h) {
+        __syncthreads();                                   // previous head fully consumed (and the index arrays visible)
+        for (int idx = tid; idx < TkP * 8; idx += 256) {
+            const int j = idx >> 3, d4 = idx & 7;
+            f32x4v kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (j < Tk) {
+                const float* src = p.qkv + (size_t)rowtok[j] * C3 + h * DH + d4 * 4;   // valid keys are tokens 0..Tk-1
+                kv = *reinterpret_cast<const f32x4v*>(src + C);
+                vv = *reinterpret_cast<const f32x4v*>(src + 2 * C);
+            }
+            *reinterpret_cast<f32x4v*>(Ks + j * KLD + d4 * 4) = kv;
+            float* vd = Vs + ((j >> 2) * DH + d4 * 4) * 4 + (j & 3);
+            vd[0] = vv.x; vd[4] = vv.y; vd[8] = vv.z; vd[12] = vv.w;
+        }
+        for (int i = tid; i < tab_n; i += 256) tab[i] = p.table[(size_t)i * p.heads + h];
+        __syncthreads();
+        if (!strip_on) continue;
+
+        // ---- S strip = (Q * scale) K^T : A fragments straight from global
+        f32x4v qa[4];
+        {
+            const float* qsrc = p.qkv + (size_t)rowtok[strip * 32 + li32] * C3 + h * DH + lh * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                qa[g] = *reinterpret_cast<const f32x4v*>(qsrc + g * 8);
+                qa[g] *= p.scale;
+            }
+        }
+        f32x16 sacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[nt][r] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt * 32 < TkP) {
+                const float* kb = Ks + (nt * 32 + li32) * KLD + lh * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v kf = *reinterpret_cast<const f32x4v*>(kb + g * 8);
+                    sacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[g].x, kf.x, sacc[nt], 0, 0, 0);
+                    sacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[g].y, kf.y, sacc[nt], 0, 0, 0);
+                    sacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[g].z, kf.z, sacc[nt], 0, 0, 0);
+                    sacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[g].w, kf.w, sacc[nt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- bias + padding mask, row max, exp, row sum (row of register r: (r&3) + 8*(r>>2) + 4*lh)
+        float rmax[16], rsum[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int bi = basei[strip * 32 + row];
+            float m = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (nt * 32 < TkP) {
+                    const int col = nt * 32 + li32;
+                    float s = sacc[nt][r] + tab[bi - subj[col]];
+                    s = col < Tk ? s : -INFINITY;
+                    sacc[nt][r] = s;
+                    m = fmaxf(m, s);
+                }
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 32));
+            rmax[r] = m;
+            float sum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (nt * 32 < TkP) {
+                    const float e = expf(sacc[nt][r] - m);
+                    sacc[nt][r] = e;
+                    sum += e;
+                }
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 32);
+            rsum[r] = sum;
+        }
+        // ---- O = P V, 64 keys at a time through the per-wave LDS transpose buffer
+        f32x16 oacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if (hh * 64 < TkP) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int nt = hh * 2 + tt;
+                    if (nt * 32 < TkP) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Ps[((r & 3) + 8 * (r >> 2) + 4 * lh) * PLD + tt * 32 + li32] = sacc[nt][r];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                const int kcols = (TkP - hh * 64) < 64 ? (TkP - hh * 64) : 64;   // 32 or 64 keys in this half
+                const float* pb = Ps + li32 * PLD + lh * 4;
+                const float* vb = Vs + ((hh * 16 + lh) * DH + li32) * 4;
+                for (int g = 0; g < kcols / 8; ++g) {
+                    const f32x4v pf = *reinterpret_cast<const f32x4v*>(pb + g * 8);
+                    const f32x4v vf = *reinterpret_cast<const f32x4v*>(vb + g * 2 * DH * 4);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.x, vf.x, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.y, vf.y, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.z, vf.z, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.w, vf.w, oacc, 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- normalise and store: row (r, lh) of the strip, column d = lane & 31
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = strip * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < T) p.out[(size_t)rowtok[row] * C + h * DH + li32] = oacc[r] / rsum[r];
+        }
+    }
+}
+
 __global__ void agent_mean_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, int L) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = x[i];
@@ -195,10 +370,24 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
         return av2x::fail("av2x_fax_attention: bad sizes (L=%d valid=%d h=%d w=%d ws=%d)", n_agents_padded, n_valid, h, w, window);
     FaxParams p;
     p.qkv = qkv; p.table = bias_table; p.out = out;
-    p.L = n_agents_padded; p.n_valid = n_valid; p.H = h; p.W = w; p.ws = window; p.heads = heads; p.grid = grid_partition;
+    p.L = n_agents_padded; p.n_valid = n_valid; p.H = h; p.W = w; p.ws = window; p.heads = heads; p.grid = grid_partition & 1;
     p.scale = 1.0f / sqrtf((float)dim_head);
     const int Tk = n_valid * window * window;
     const int tab_n = (2 * n_agents_padded - 1) * (2 * window - 1) * (2 * window - 1);
+    const int T = n_agents_padded * window * window;
+    if (T <= 128 && !(grid_partition & 2)) {  // MFMA path (bit 1 of grid_partition forces the VALU reference kernel: tests)
+        const int TkP = (Tk + 31) & ~31;
+        const size_t lds_m = ((size_t)TkP * KLD + (size_t)TkP * DH + ((tab_n + 3) & ~3) + TkP + 256 + 4 * 32 * PLD) * sizeof(float);
+        static size_t attr_m = 0;
+        if (lds_m > attr_m) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fax_attention_mfma_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+            attr_m = lds_m;
+        }
+        hipLaunchKernelGGL(fax_attention_mfma_kernel, dim3((h / window) * (w / window)), dim3(256), lds_m, av2x::as_stream(stream), p);
+        return av2x::check_launch("fax_attention_mfma_kernel");
+    }
+    p.grid = grid_partition & 1;
     const size_t lds = (size_t)4 * (2 * Tk * DH + tab_n) * sizeof(float);
     if (lds > 160 * 1024) return av2x::fail("av2x_fax_attention: %zu B of LDS needed (> 160 KiB): too many valid agents", lds);
     static size_t attr = 0;

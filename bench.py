@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a captured HIP graph (1) or eager (0); "
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
+    ap.add_argument("--model", choices=["where2com", "cobevt"], default="where2com",
+                    help="where2com = the headline metric; cobevt = BASELINE.json configs[2] fusion head on one GPU")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent frames kept in flight per GPU (separate HIP streams + workspaces, shared weights); "
                          "1 = strictly sequential frames (latency mode, also reported as single_stream)")
@@ -69,10 +71,17 @@ def parse():
     return ap.parse_args()
 
 
-def build_inputs(n_agents, n_points, device, only=None):
+def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
     from airv2x_perception_amd import synth
     from airv2x_perception_amd.opencood_iface.voxelizer import voxelize_points
-    hy = synth.default_hypes()
+    if model == "cobevt":
+        nv = sum(1 for t in synth.agent_types_for(n_agents) if t == "vehicle")
+        nr = sum(1 for t in synth.agent_types_for(n_agents) if t == "rsu")
+        nd = n_agents - nv - nr
+        # shipped max_cav is 3/2/2 (L = 7); larger frames need a larger agent axis
+        hy = synth.default_hypes_cobevt(None, (max(3, nv), max(2, nr), max(2, nd)))
+    else:
+        hy = synth.default_hypes()
     args = hy["model"]["args"]
     pp = hy["preprocess"]
     types = synth.agent_types_for(n_agents)
@@ -115,9 +124,15 @@ def main():
         mine = list(partition_agents(a.agents, world)[rank])
     else:
         mine = None
-    hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev, only=mine)
-    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
-    model = Airv2xWhere2com(args)
+    hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev, only=mine, model=a.model)
+    if a.model == "cobevt":
+        from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
+        a.inflight, a.cpu_frames = 1, 0
+        sd = synth.synthetic_state_dict(synth.cobevt_param_spec(args), seed=0)
+        model = Airv2xCoBEVT(args)
+    else:
+        sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
+        model = Airv2xWhere2com(args)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.sync_comm_rate = False  # no host sync inside the frame; comm_rate stays a device scalar
@@ -158,12 +173,12 @@ def main():
     fps = (world if a.mode == "replica" else 1) * a.steps / dt
 
     res = {
-        "metric": f"collaborative frames/sec, Where2Comm-LiDAR {a.agents}-agent",
+        "metric": f"collaborative frames/sec, {'Where2Comm' if a.model == 'where2com' else 'CoBEVT'}-LiDAR {a.agents}-agent",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"Where2Comm-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
+        "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else 'CoBEVT (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
                    "parallelism": ("single GPU" if world == 1 else "independent frames per GPU (replicas)") if a.mode == "replica"
@@ -185,7 +200,7 @@ def main():
                                 "note": "one frame at a time (no overlap between frames)"}
 
     # ---------------- second figure: frame + on-device post-process (decode, filters, rotated NMS) ----------
-    if rank == 0 and a.mode == "replica":
+    if rank == 0 and a.mode == "replica" and a.model == "where2com":
         from airv2x_perception_amd.opencood_iface.voxel_postprocessor import VoxelPostprocessor
         post = VoxelPostprocessor(hy["postprocess"], dataset="airv2x", train=False)
         anchors = torch.from_numpy(post.generate_anchor_box())

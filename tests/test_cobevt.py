@@ -80,21 +80,23 @@ def test_gpu_forward_matches_golden_and_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid", [0, 1])
-def test_gpu_fax_attention_kernel(grid):
+@pytest.mark.parametrize("grid,L,nv", [(0, 5, 3), (1, 5, 3), (2, 5, 3), (3, 5, 3), (0, 7, 7), (1, 7, 4), (0, 8, 8), (1, 8, 1), (1, 9, 6)])
+def test_gpu_fax_attention_kernel(grid, L, nv):
+    """grid bit 0: partition (window / grid); bit 1: force the VALU reference kernel instead of the MFMA one
+    (T = 16 L > 128 tokens always takes the VALU kernel)."""
     from ctypes import c_void_p
     from airv2x_perception_amd import _lib
     lib = _lib.load()
-    g = torch.Generator().manual_seed(grid)
-    L, nv, H, W, ws, heads = 5, 3, 8, 12, 4, 8
+    g = torch.Generator().manual_seed(grid + 10 * L)
+    H, W, ws, heads = 8, 12, 4, 8
     C = heads * 32
     tok = torch.randn(1, L, C, H, W, generator=g)
     sd = {"a.to_qkv.weight": torch.randn(3 * C, C, generator=g) / 16, "a.to_out.0.weight": torch.eye(C),
           "a.relative_position_index": cob.relative_position_index(L, ws),
           "a.relative_position_bias_table.weight": torch.randn((2 * L - 1) * 49, heads, generator=g)}
-    part = cob._partition(tok, ws, bool(grid))
+    part = cob._partition(tok, ws, bool(grid & 1))
     km = torch.tensor([1] * nv + [0] * (L - nv)).view(1, L, 1).expand(part.shape[0], L, ws * ws).reshape(-1, L * ws * ws)
-    ref = cob._unpartition(cob.attention(part, km, sd, "a", heads, L, ws), 1, L, C, H, W, ws, bool(grid))
+    ref = cob._unpartition(cob.attention(part, km, sd, "a", heads, L, ws), 1, L, C, H, W, ws, bool(grid & 1))
     qkv = torch.nn.functional.linear(tok.permute(0, 1, 3, 4, 2), sd["a.to_qkv.weight"])[0].contiguous().cuda()  # (L,H,W,3C)
     out = torch.empty((L, H, W, C), device="cuda")
     table = sd["a.relative_position_bias_table.weight"].cuda()
