@@ -247,6 +247,17 @@ def synthetic_tensor(key, shape, kind, seed=0):
         return g.uniform(-0.1, 0.1, size=shape).astype(np.float32)
     if kind == "relbias":
         return g.uniform(-1.0, 1.0, size=shape).astype(np.float32)
+    if kind == "rel":  # HGT relation matrices (xavier-uniform-like scale)
+        b = np.sqrt(6.0 / (shape[-1] + shape[-2]))
+        return g.uniform(-b, b, size=shape).astype(np.float32)
+    if kind == "rte_table":  # sinusoid table of RelTemporalEncoding (v2xvit_basic.py:46-53)
+        n_hid = shape[1]
+        pos = np.arange(0.0, shape[0], dtype=np.float32)[:, None]
+        div = np.exp(np.arange(0, n_hid, 2, dtype=np.float32) * np.float32(-(np.log(10000.0) / n_hid)))
+        t = np.zeros(shape, dtype=np.float32)
+        t[:, 0::2] = np.sin(pos * div) / np.float32(np.sqrt(n_hid))
+        t[:, 1::2] = np.cos(pos * div) / np.float32(np.sqrt(n_hid))
+        return t
     if kind in ("conv", "lin", "head", "deconv"):
         if kind == "lin":
             fan_in = shape[1]
@@ -497,3 +508,79 @@ def cobevt_param_spec(args):
     spec += [("fusion_net.mlp_head.2.weight", (C,), "ln_w"), ("fusion_net.mlp_head.2.bias", (C,), "ln_b"),
              ("fusion_net.mlp_head.3.weight", (C, C), "lin"), ("fusion_net.mlp_head.3.bias", (C,), "bias")]
     return spec + heads
+
+
+# --------------------------------------------------------------------------
+# V2X-ViT (airv2x_intermediate_v2xvit.yaml :150-310): Where2Comm-style nesting (modality_fusion)
+# plus the `transformer.encoder` block
+# --------------------------------------------------------------------------
+
+def default_hypes_v2xvit(lidar_range=None, max_cav=(5, 5, 5)):
+    hy = default_hypes(lidar_range, max_cav)
+    a = hy["model"]["args"]
+    a.pop("where2com_fusion")
+    a["transformer"] = {"encoder": {
+        "num_blocks": 1, "depth": 3, "use_roi_mask": True, "use_RTE": True, "RTE_ratio": 2,
+        "cav_att_config": {"dim": 256, "use_hetero": True, "use_RTE": True, "RTE_ratio": 2, "heads": 8, "dim_head": 32,
+                           "dropout": 0.3},
+        "pwindow_att_config": {"dim": 256, "heads": [16, 8, 4], "dim_head": [16, 32, 64], "dropout": 0.3,
+                               "window_size": [2, 4, 4], "relative_pos_embedding": True, "fusion_method": "split_attn"},
+        "feed_forward": {"mlp_dim": 256, "dropout": 0.3},
+        "sttf": {"voxel_size": list(DEFAULT_VOXEL), "downsample_rate": 4},
+    }}
+    hy["model"]["core_method"] = "airv2x_v2xvit"
+    hy["name"] = "airv2x_intermediate_v2xvit"
+    return hy
+
+
+def v2xvit_param_spec(args):
+    """Ordered (key, shape, kind) manifest of Airv2xV2XVit's state_dict (297 tensors; checked against the
+    reference's own state_dict by tools/gen_golden.py)."""
+    w2c_like = dict(args)
+    w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
+    base = where2com_param_spec(w2c_like)
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
+    enc = args["transformer"]["encoder"]
+    cav, pw = enc["cav_att_config"], enc["pwindow_att_config"]
+    C, inner = cav["dim"], cav["heads"] * cav["dim_head"]
+    p = "fusion_net.encoder"
+    spec = list(trunk)
+    spec += [(p + ".prior_feed.weight", (C, C + 3), "lin"), (p + ".prior_feed.bias", (C,), "bias")]
+    for d in range(enc["depth"]):
+        for nb in range(enc["num_blocks"]):
+            q = f"{p}.layers.{d}.0.layers.{nb}"
+            spec += [(q + ".0.norm.weight", (C,), "ln_w"), (q + ".0.norm.bias", (C,), "ln_b"),
+                     (q + ".0.fn.relation_att", (4, cav["heads"], cav["dim_head"], cav["dim_head"]), "rel"),
+                     (q + ".0.fn.relation_msg", (4, cav["heads"], cav["dim_head"], cav["dim_head"]), "rel")]
+            for name in ("k", "q", "v"):
+                for t in range(2):
+                    spec += [(f"{q}.0.fn.{name}_linears.{t}.weight", (inner, C), "lin"),
+                             (f"{q}.0.fn.{name}_linears.{t}.bias", (inner,), "bias")]
+            for t in range(2):
+                spec += [(f"{q}.0.fn.a_linears.{t}.weight", (C, inner), "lin"), (f"{q}.0.fn.a_linears.{t}.bias", (C,), "bias")]
+            spec += [(q + ".1.norm.weight", (C,), "ln_w"), (q + ".1.norm.bias", (C,), "ln_b")]
+            for i, (h, dh, ws) in enumerate(zip(pw["heads"], pw["dim_head"], pw["window_size"])):
+                w = f"{q}.1.fn.pwmsa.{i}"
+                spec += [(w + ".pos_embedding", (2 * ws - 1, 2 * ws - 1), "relbias"),
+                         (w + ".to_qkv.weight", (3 * h * dh, C), "lin"),
+                         (w + ".to_out.0.weight", (C, h * dh), "lin"), (w + ".to_out.0.bias", (C,), "bias")]
+            sa = f"{q}.1.fn.split_attn"
+            spec += [(sa + ".fc1.weight", (C, C), "lin"), (sa + ".bn1.weight", (C,), "ln_w"), (sa + ".bn1.bias", (C,), "ln_b"),
+                     (sa + ".fc2.weight", (3 * C, C), "lin")]
+        f = f"{p}.layers.{d}.1"
+        spec += [(f + ".norm.weight", (C,), "ln_w"), (f + ".norm.bias", (C,), "ln_b"),
+                 (f + ".fn.net.0.weight", (enc["feed_forward"]["mlp_dim"], C), "lin"),
+                 (f + ".fn.net.0.bias", (enc["feed_forward"]["mlp_dim"],), "bias"),
+                 (f + ".fn.net.3.weight", (C, enc["feed_forward"]["mlp_dim"]), "lin"), (f + ".fn.net.3.bias", (C,), "bias")]
+    spec += [(p + ".rte.emb.emb.weight", (100, C), "rte_table"), (p + ".rte.emb.lin.weight", (C, C), "lin"),
+             (p + ".rte.emb.lin.bias", (C,), "bias")]
+    return spec + heads
+
+
+def se2_correction(yaw_deg, tx, ty):
+    """4x4 float64 spatial_correction_matrix of an SE(2) motion (yaw ~ U(-10,10) deg, t ~ U(-8,8) m)."""
+    c, s = np.cos(np.deg2rad(yaw_deg)), np.sin(np.deg2rad(yaw_deg))
+    m = np.eye(4)
+    m[0, 0], m[0, 1], m[1, 0], m[1, 1], m[0, 3], m[1, 3] = c, -s, s, c, tx, ty
+    return m

@@ -329,6 +329,90 @@ def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride):
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def v2xvit_frame(synth, vox, hy, types, n_points, rng, max_cav_num):
+    """Seeded V2X-ViT test frame: per non-ego agent an SE(2) spatial correction and a time delay."""
+    pp = hy["preprocess"]
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"]))
+    dd = synth.build_data_dict(voxd, types, max_cav_num=max_cav_num)
+    g = np.random.default_rng(77)
+    for i in range(1, len(types)):
+        m = synth.se2_correction(g.uniform(-10, 10), g.uniform(-4, 4), g.uniform(-2, 2))
+        dd["spatial_correction_matrix"][0, i] = torch.from_numpy(m)
+        dd["prior_encoding"][0, i, 1] = float(i)          # time delay in frames -> RTE row dt * RTE_ratio
+        dd["prior_encoding"][0, i, 0] = float(g.uniform(0, 1))
+    return dd, voxd
+
+
+def run_v2xvit_case(name, lidar_range, types, n_points, seed, max_cav, big_stride):
+    """Airv2xV2XVit on the real reference vs oracle/v2xvit_oracle.py."""
+    from airv2x_perception_amd import synth
+    from oracle import v2xvit_oracle as vit
+    from oracle import voxelize_oracle as vox
+    from opencood.hypes_yaml.yaml_utils import load_yaml
+    from opencood.models.airv2x_v2xvit import Airv2xV2XVit
+
+    src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_v2xvit.yaml")
+    txt = open(src).read()
+    r = lidar_range
+    txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+    txt = re.sub(r"vehicle: 5\n(\s+)rsu: 5\n(\s+)drone: 5", f"vehicle: {max_cav[0]}\n\\1rsu: {max_cav[1]}\n\\2drone: {max_cav[2]}", txt)
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(txt)
+        path = f.name
+    hy_ref = load_yaml(path)
+    os.unlink(path)
+    hy = synth.default_hypes_v2xvit(lidar_range, max_cav)
+    check_hypes(hy_ref["model"]["args"], hy["model"]["args"])
+    args = hy["model"]["args"]
+    model = Airv2xV2XVit(hy_ref["model"]["args"]).eval()
+    spec = synth.v2xvit_param_spec(args)
+    ref_sd = model.state_dict()
+    assert [k for k, _, _ in spec] == list(ref_sd.keys()), "v2xvit state_dict key order mismatch"
+    for k, shp, _ in spec:
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    tab = "fusion_net.encoder.rte.emb.emb.weight"
+    assert torch.allclose(ref_sd[tab], sd[tab], atol=1e-6), "RTE sinusoid table differs from the reference's"
+    assert torch.allclose(vit.rte_table(256), ref_sd[tab], atol=1e-6)
+    model.load_state_dict(sd, strict=True)
+    dd, voxd = v2xvit_frame(synth, vox, hy, types, n_points, lidar_range, args["max_cav_num"])
+    cap = {}
+    enc = model.fusion_net.encoder
+    hs = [enc.sttf.register_forward_hook(lambda m, i_, o: cap.__setitem__("after_sttf", o))]
+    for d in range(3):
+        hs.append(enc.layers[d][1].register_forward_hook(lambda m, i_, o, k=d: cap.__setitem__(f"ffn{k}", o)))
+    with torch.no_grad():
+        out = model({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in dd.items()})
+        tr = {}
+        o = vit.v2xvit_forward(dd, sd, args, trace=tr)
+    for h in hs:
+        h.remove()
+    rep = {k: (float((o[k] - out[k]).abs().max()), float(out[k].abs().max())) for k in ("psm", "rm", "obj")}
+    print(f"[{name}] v2xvit oracle-vs-reference max|diff| (max|ref|):", {k: f"{a:.3e} ({b:.3e})" for k, (a, b) in rep.items()})
+    assert all(a <= 1e-4 * max(1.0, b) for a, b in rep.values())
+    assert float((tr["after_sttf"] - cap["after_sttf"]).abs().max()) < 1e-5
+    assert o["comm_rate"] == out["comm_rate"]
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(lidar_range, np.float64), "types": np.asarray(types),
+          "n_points": np.int64(n_points), "big_stride": np.int64(big_stride),
+          "spec_keys": np.asarray([k for k, _, _ in spec]), "max_cav": np.asarray(max_cav, np.int64),
+          "comm_rate": np.int64(out["comm_rate"]),
+          "spatial_correction_matrix": dd["spatial_correction_matrix"].numpy(), "prior_encoding": dd["prior_encoding"].numpy()}
+    for i, (v, c, n) in enumerate(voxd):
+        fx[f"vox_coords_{i}"] = c
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k].numpy()
+    fx["after_sttf"] = cap["after_sttf"][..., ::big_stride, ::big_stride, :].numpy()       # (B,L,H,W,C)
+    fx["com_mask"] = tr["com_mask"].numpy()
+    for d in range(3):
+        fx[f"layer{d}_agent0"] = tr[f"layer{d}"][:, 0, ::big_stride, ::big_stride, :].numpy()
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def main():
     os.chdir(tempfile.mkdtemp())
     import_reference()
@@ -340,6 +424,7 @@ def main():
     # default AirV2X grid, BASELINE config: 4 agents x 8192 points; strided samples + sums
     run_case("w2c_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 5, 20)
     run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
+    run_v2xvit_case("v2xvit_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4)
 
 
 if __name__ == "__main__":
@@ -348,5 +433,10 @@ if __name__ == "__main__":
         import_reference()
         torch.set_num_threads(8)
         run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
+    elif len(sys.argv) > 1 and sys.argv[1] == "v2xvit":
+        os.chdir(tempfile.mkdtemp())
+        import_reference()
+        torch.set_num_threads(8)
+        run_v2xvit_case("v2xvit_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4)
     else:
         main()
