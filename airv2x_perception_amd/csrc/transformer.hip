@@ -15,7 +15,7 @@ namespace {
 template <int CK>  // C = 256 * CK / ... : each lane holds CK float4 (C = 256*CK)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float4* __restrict__ x, const float4* __restrict__ gamma,
                                                         const float4* __restrict__ beta, float4* __restrict__ y,
-                                                        int n_tokens, float eps) {
+                                                        int n_tokens, float eps, int relu) {
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= n_tokens) return;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float4* __restrict
         r.y = (v[k].y - mean) * rstd * g.y + b.y;
         r.z = (v[k].z - mean) * rstd * g.z + b.z;
         r.w = (v[k].w - mean) * rstd * g.w + b.w;
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
         y[(size_t)tok * (C / 4) + k * 64 + lane] = r;
     }
 }
@@ -342,8 +343,16 @@ __global__ void agent_mean_kernel(const float4* __restrict__ x, float4* __restri
 
 }  // namespace
 
+extern "C" int av2x_layernorm_act(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,
+                                  int32_t c, float eps, int32_t relu, av2x_stream_t stream);
+
 extern "C" int av2x_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens, int32_t c,
                               float eps, av2x_stream_t stream) {
+    return av2x_layernorm_act(x, gamma, beta, y, n_tokens, c, eps, 0, stream);
+}
+
+extern "C" int av2x_layernorm_act(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,
+                                  int32_t c, float eps, int32_t relu, av2x_stream_t stream) {
     if (n_tokens == 0) return 0;
     if (!x || !gamma || !beta || !y) return av2x::fail("av2x_layernorm: null argument");
     if (n_tokens < 0 || n_tokens > (1ll << 31) - 8) return av2x::fail("av2x_layernorm: bad token count");
@@ -354,8 +363,8 @@ extern "C" int av2x_layernorm(const float* x, const float* gamma, const float* b
     auto Bt = reinterpret_cast<const float4*>(beta);
     auto Yp = reinterpret_cast<float4*>(y);
     switch (c) {
-        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, X, G, Bt, Yp, (int)n_tokens, eps); break;
-        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, X, G, Bt, Yp, (int)n_tokens, eps); break;
+        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, X, G, Bt, Yp, (int)n_tokens, eps, relu); break;
+        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, X, G, Bt, Yp, (int)n_tokens, eps, relu); break;
         default: return av2x::fail("av2x_layernorm: c=%d unsupported (256/512)", c);
     }
     return av2x::check_launch("layernorm_kernel");

@@ -1,0 +1,329 @@
+// Kernels of the V2X-ViT fusion that are not GEMMs / LayerNorms:
+//
+//   warp_affine_kernel     F.affine_grid + F.grid_sample(bilinear, zeros, align_corners=True) of
+//                          torch_transformation_utils.warp_affine :337-381 on NHWC maps       HBM-bound
+//   roi_mask_kernel        the same sampling with mode="nearest" of an all-ones image (:96-113),
+//                          times the cav mask -> com_mask (:15-53)
+//   add_agent_vector       x[l,:,:,c] += v[l,c]   (RTE, v2xvit_basic.py:58-80)
+//   hgt_attention_kernel   HGTCavAttention per pixel (hmsa.py:133-151) on the FOLDED projections
+//                          (relation_att / relation_msg multiplied into the q / v Linear weights on
+//                          the host), masked softmax over agents, one wave per pixel
+//   window_attn_kernel     BaseWindowAttention (mswin.py:52-96): one thread per (token, head)
+//   gap3_kernel            mean over H,W of (sw + mw + bw)             (split_attn.py:48-50)
+//   split_combine_kernel   radix softmax over the 3 branches + weighted sum + residual (:55-61)
+#include "av2x_common.hpp"
+
+namespace {
+
+// torch.linspace(-1, 1, n)[i] as ATen computes it (symmetric halves)
+__device__ __forceinline__ float lin_m1_1(int i, int n) {
+    if (n <= 1) return -1.0f;
+    const float step = 2.0f / (float)(n - 1);
+    return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+template <int CK>  // C = 64 * CK: 16 lanes x float4 per pixel chunk
+__global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ src, const float* __restrict__ theta,
+                                                          float* __restrict__ dst, int H, int W) {
+    const int t = threadIdx.x & 15;
+    const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int n = blockIdx.y;
+    if (pix >= H * W) return;
+    const int i = pix / W, j = pix - i * W;
+    const float* th = theta + n * 6;
+    const float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    const float gx = th[0] * xn + th[1] * yn + th[2];
+    const float gy = th[3] * xn + th[4] * yn + th[5];
+    const float ix = ((gx + 1.f) * 0.5f) * (float)(W - 1);   // grid_sampler_unnormalize, align_corners=True
+    const float iy = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
+    const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;  // nw, ne, sw, se
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
+    constexpr int C = 64 * CK;
+    const float* base = src + (size_t)n * H * W * C + 4 * t;
+    float* out = dst + ((size_t)n * H * W + pix) * C + 4 * t;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto add = [&](bool ok, int yy, int xx, float w) {
+            if (ok) {
+                const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * C + 64 * k);
+                acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+            }
+        };
+        add(vy0 && vx0, y0, x0, w00);
+        add(vy0 && vx1, y0, x1, w01);
+        add(vy1 && vx0, y1, x0, w10);
+        add(vy1 && vx1, y1, x1, w11);
+        *reinterpret_cast<float4*>(out + 64 * k) = acc;
+    }
+}
+
+__global__ void roi_mask_kernel(const float* __restrict__ theta, const int* __restrict__ cav_mask, float* __restrict__ mask,
+                                int n, int H, int W) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y;
+    if (pix >= H * W) return;
+    const int i = pix / W, j = pix - i * W;
+    const float* th = theta + a * 6;
+    const float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    const float gx = th[0] * xn + th[1] * yn + th[2];
+    const float gy = th[3] * xn + th[4] * yn + th[5];
+    const float ix = nearbyintf(((gx + 1.f) * 0.5f) * (float)(W - 1));   // mode="nearest": round half to even
+    const float iy = nearbyintf(((gy + 1.f) * 0.5f) * (float)(H - 1));
+    const bool in = ix >= 0.f && ix <= (float)(W - 1) && iy >= 0.f && iy <= (float)(H - 1);
+    mask[(size_t)a * H * W + pix] = (in && cav_mask[a]) ? 1.f : 0.f;
+}
+
+__global__ void add_agent_vector_kernel(float4* __restrict__ x, const float4* __restrict__ v, size_t n4_per_agent, int c4) {
+    const int a = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_agent; i += (size_t)gridDim.x * blockDim.x) {
+        float4 r = x[(size_t)a * n4_per_agent + i];
+        const float4 b = v[(size_t)a * c4 + (i % c4)];
+        r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
+        x[(size_t)a * n4_per_agent + i] = r;
+    }
+}
+
+// proj row layout (1280 floats): [q'(.->type0) | q'(.->type1) | k | v'(type0<-.) | v'(type1<-.)], 8 heads x 32 each
+struct HgtParams {
+    const float* proj;   // (n, HW, 1280)
+    const float* mask;   // (n, HW) com_mask of the KEY agent at the pixel
+    float* out;          // (n, HW, 256)
+    int n, hw;
+    int types[32];
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtParams p) {
+    const int lane = threadIdx.x & 63;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= p.hw) return;
+    const int col = lane * 4;   // head = lane / 8, 4 of its 32 dims
+    constexpr int PC = 1280;
+    for (int i = 0; i < p.n; ++i) {
+        const int ti = p.types[i];
+        const float* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
+        const float4 q0 = *reinterpret_cast<const float4*>(qi + col);         // keys of type 0
+        const float4 q1 = *reinterpret_cast<const float4*>(qi + 256 + col);   // keys of type 1
+        float m = -INFINITY, l = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < p.n; ++j) {
+            if (p.mask[(size_t)j * p.hw + pix] == 0.f) continue;   // masked_fill(mask == 0, -inf): exp(-inf) = 0
+            const float* kj = p.proj + ((size_t)j * p.hw + pix) * PC;
+            const float4 k = *reinterpret_cast<const float4*>(kj + 512 + col);
+            const float4 q = p.types[j] ? q1 : q0;
+            float s = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);   // 8 lanes = one head
+            s *= p.scale;
+            const float4 v = *reinterpret_cast<const float4*>(kj + 768 + 256 * ti + col);
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn), pj = expf(s - mn);
+            l = l * alpha + pj;
+            o.x = fmaf(pj, v.x, o.x * alpha); o.y = fmaf(pj, v.y, o.y * alpha);
+            o.z = fmaf(pj, v.z, o.z * alpha); o.w = fmaf(pj, v.w, o.w * alpha);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        *reinterpret_cast<float4*>(p.out + ((size_t)i * p.hw + pix) * 256 + col) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+    }
+}
+
+// one thread per (token, head); qkv row = [q | k | v], each heads*DHD wide, at column offset `coff` of a `ctot` row
+template <int DHD, int WS>
+__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, int ctot, int coff,
+                                                          const float* __restrict__ pos, float* __restrict__ out,
+                                                          int n, int H, int W, int heads, float scale) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n * H * W * heads;
+    if (gid >= total) return;
+    const int head = (int)(gid % heads);
+    const size_t tok = gid / heads;
+    const int pix = (int)(tok % ((size_t)H * W));
+    const int a = (int)(tok / ((size_t)H * W));
+    const int y = pix / W, x = pix - y * W;
+    const int wy0 = (y / WS) * WS, wx0 = (x / WS) * WS, iy = y - wy0, ixx = x - wx0;
+    const int inner = heads * DHD;
+    const float* row = qkv + tok * ctot + coff + head * DHD;
+    float q[DHD], o[DHD];
+#pragma unroll
+    for (int d = 0; d < DHD; d += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + d);
+        q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
+    }
+    float s[WS * WS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < WS * WS; ++j) {
+        const int jy = j / WS, jx = j % WS;
+        const float* kr = qkv + ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + inner + head * DHD;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < DHD; d += 4) {
+            const float4 k = *reinterpret_cast<const float4*>(kr + d);
+            acc = fmaf(q[d], k.x, acc); acc = fmaf(q[d + 1], k.y, acc); acc = fmaf(q[d + 2], k.z, acc); acc = fmaf(q[d + 3], k.w, acc);
+        }
+        // dots * scale + pos_embedding[rel_y][rel_x], rel = idx[j] - idx[i] + ws - 1   (mswin.py:13-18, :77-80)
+        acc = acc * scale + pos[(jy - iy + WS - 1) * (2 * WS - 1) + (jx - ixx + WS - 1)];
+        s[j] = acc;
+        m = fmaxf(m, acc);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < WS * WS; ++j) { s[j] = expf(s[j] - m); l += s[j]; }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int d = 0; d < DHD; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < WS * WS; ++j) {
+        const int jy = j / WS, jx = j % WS;
+        const float* vr = qkv + ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + 2 * inner + head * DHD;
+        const float pj = s[j] * inv;
+#pragma unroll
+        for (int d = 0; d < DHD; d += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(vr + d);
+            o[d] = fmaf(pj, v.x, o[d]); o[d + 1] = fmaf(pj, v.y, o[d + 1]); o[d + 2] = fmaf(pj, v.z, o[d + 2]); o[d + 3] = fmaf(pj, v.w, o[d + 3]);
+        }
+    }
+    float* dst = out + tok * inner + head * DHD;
+#pragma unroll
+    for (int d = 0; d < DHD; d += 4) *reinterpret_cast<float4*>(dst + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
+}
+
+// gap[a][c] = mean over pixels of (s0 + s1 + s2); grid (C/64, n), block 256 = 4 pixel groups x 64 channels
+__global__ __launch_bounds__(256) void gap3_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                   const float* __restrict__ s2, float* __restrict__ gap, int hw, int C) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, a = blockIdx.y;
+    float acc = 0.f;
+    for (int p = g; p < hw; p += 4) {
+        const size_t o = ((size_t)a * hw + p) * C + c;
+        acc += (s0[o] + s1[o]) + s2[o];
+    }
+    part[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (g == 0) gap[(size_t)a * C + c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / (float)hw;
+}
+
+__global__ void split_combine_kernel(const float4* __restrict__ s0, const float4* __restrict__ s1, const float4* __restrict__ s2,
+                                     const float* __restrict__ logits, const float4* __restrict__ res, float4* __restrict__ out,
+                                     size_t n4_per_agent, int C) {
+    const int a = blockIdx.y;
+    const int c4 = C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_agent; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4) * 4;
+        const float* lg = logits + (size_t)a * 3 * C;
+        float w[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // softmax over the radix axis: logits viewed (radix=3, C)
+            const float a0 = lg[c + e], a1 = lg[C + c + e], a2 = lg[2 * C + c + e];
+            const float mx = fmaxf(a0, fmaxf(a1, a2));
+            const float e0 = expf(a0 - mx), e1 = expf(a1 - mx), e2 = expf(a2 - mx);
+            const float inv = 1.0f / ((e0 + e1) + e2);
+            w[0][e] = e0 * inv; w[1][e] = e1 * inv; w[2][e] = e2 * inv;
+        }
+        const size_t o = (size_t)a * n4_per_agent + i;
+        const float4 x0 = s0[o], x1 = s1[o], x2 = s2[o], r = res[o];
+        float4 y;
+        y.x = ((x0.x * w[0][0] + x1.x * w[1][0]) + x2.x * w[2][0]) + r.x;
+        y.y = ((x0.y * w[0][1] + x1.y * w[1][1]) + x2.y * w[2][1]) + r.y;
+        y.z = ((x0.z * w[0][2] + x1.z * w[1][2]) + x2.z * w[2][2]) + r.z;
+        y.w = ((x0.w * w[0][3] + x1.w * w[1][3]) + x2.w * w[2][3]) + r.w;
+        out[o] = y;
+    }
+}
+
+}  // namespace
+
+extern "C" int av2x_warp_affine(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w, int32_t c,
+                                av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!src || !theta || !dst) return av2x::fail("av2x_warp_affine: null argument");
+    if (n < 0 || h <= 0 || w <= 0) return av2x::fail("av2x_warp_affine: bad sizes");
+    const dim3 grid((h * w + 15) / 16, n), block(256);
+    hipStream_t st = av2x::as_stream(stream);
+    switch (c) {
+        case 64: hipLaunchKernelGGL(warp_affine_kernel<1>, grid, block, 0, st, src, theta, dst, h, w); break;
+        case 128: hipLaunchKernelGGL(warp_affine_kernel<2>, grid, block, 0, st, src, theta, dst, h, w); break;
+        case 256: hipLaunchKernelGGL(warp_affine_kernel<4>, grid, block, 0, st, src, theta, dst, h, w); break;
+        default: return av2x::fail("av2x_warp_affine: c=%d unsupported (64/128/256)", c);
+    }
+    return av2x::check_launch("warp_affine_kernel");
+}
+
+extern "C" int av2x_roi_mask(const float* theta, const int32_t* cav_mask, float* mask, int32_t n, int32_t h, int32_t w,
+                             av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!theta || !cav_mask || !mask) return av2x::fail("av2x_roi_mask: null argument");
+    hipLaunchKernelGGL(roi_mask_kernel, dim3((h * w + 255) / 256, n), dim3(256), 0, av2x::as_stream(stream), theta, cav_mask,
+                       mask, n, h, w);
+    return av2x::check_launch("roi_mask_kernel");
+}
+
+extern "C" int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_t elems_per_agent, int32_t c, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!x || !v) return av2x::fail("av2x_add_agent_vector: null argument");
+    if (c % 4 || elems_per_agent % c) return av2x::fail("av2x_add_agent_vector: bad sizes");
+    const size_t n4 = (size_t)elems_per_agent / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(add_agent_vector_kernel, dim3((unsigned)blocks, n), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<float4*>(x), reinterpret_cast<const float4*>(v), n4, c / 4);
+    return av2x::check_launch("add_agent_vector_kernel");
+}
+
+extern "C" int av2x_hgt_attention(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
+                                  int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
+    if (!proj || !mask || !types_host || !out) return av2x::fail("av2x_hgt_attention: null argument");
+    if (heads != 8 || dim_head != 32) return av2x::fail("av2x_hgt_attention: heads=%d dim_head=%d unsupported (8 x 32)", heads, dim_head);
+    if (n < 1 || n > 32 || hw <= 0) return av2x::fail("av2x_hgt_attention: bad sizes");
+    HgtParams p;
+    p.proj = proj; p.mask = mask; p.out = out; p.n = n; p.hw = hw;
+    for (int i = 0; i < 32; ++i) p.types[i] = i < n ? (types_host[i] != 0) : 0;
+    p.scale = 1.0f / sqrtf((float)dim_head);
+    hipLaunchKernelGGL(hgt_attention_kernel, dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
+    return av2x::check_launch("hgt_attention_kernel");
+}
+
+extern "C" int av2x_window_attention(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, float* out,
+                                     int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
+                                     av2x_stream_t stream) {
+    if (!qkv || !pos_embedding || !out) return av2x::fail("av2x_window_attention: null argument");
+    if (h % window || w % window) return av2x::fail("av2x_window_attention: map %dx%d not divisible by window %d", h, w, window);
+    const size_t total = (size_t)n * h * w * heads;
+    if (total == 0) return 0;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const float scale = 1.0f / sqrtf((float)dim_head);
+    hipStream_t st = av2x::as_stream(stream);
+    if (dim_head == 16 && window == 2) hipLaunchKernelGGL((window_attn_kernel<16, 2>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+    else if (dim_head == 32 && window == 4) hipLaunchKernelGGL((window_attn_kernel<32, 4>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+    else if (dim_head == 64 && window == 4) hipLaunchKernelGGL((window_attn_kernel<64, 4>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+    else return av2x::fail("av2x_window_attention: (dim_head %d, window %d) unsupported: (16,2) (32,4) (64,4)", dim_head, window);
+    return av2x::check_launch("window_attn_kernel");
+}
+
+extern "C" int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, int32_t n, int32_t hw, int32_t c,
+                                   av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!s0 || !s1 || !s2 || !gap) return av2x::fail("av2x_split_attn_gap: null argument");
+    if (c % 64) return av2x::fail("av2x_split_attn_gap: c must be a multiple of 64");
+    hipLaunchKernelGGL(gap3_kernel, dim3(c / 64, n), dim3(256), 0, av2x::as_stream(stream), s0, s1, s2, gap, hw, c);
+    return av2x::check_launch("gap3_kernel");
+}
+
+extern "C" int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,
+                                       const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!s0 || !s1 || !s2 || !logits || !residual || !out) return av2x::fail("av2x_split_attn_combine: null argument");
+    if (c % 4) return av2x::fail("av2x_split_attn_combine: c must be a multiple of 4");
+    const size_t n4 = (size_t)hw * c / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)blocks, n), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(s0), reinterpret_cast<const float4*>(s1), reinterpret_cast<const float4*>(s2),
+                       logits, reinterpret_cast<const float4*>(residual), reinterpret_cast<float4*>(out), n4, c);
+    return av2x::check_launch("split_combine_kernel");
+}

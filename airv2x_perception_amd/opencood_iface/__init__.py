@@ -6,3 +6,4 @@ shown in INTEGRATION.md.
 """
 from .airv2x_where2com import Airv2xWhere2com  # noqa: F401
 from .airv2x_cobevt import Airv2xCoBEVT  # noqa: F401,E402
+from .airv2x_v2xvit import Airv2xV2XVit  # noqa: F401,E402

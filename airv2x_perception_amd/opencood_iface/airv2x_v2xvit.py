@@ -1,0 +1,63 @@
+"""``Airv2xV2XVit`` — drop-in for opencood/models/airv2x_v2xvit.py (det task, LiDAR) running in
+libairv2x_hip.so.  Same constructor argument, input contract (incl. ``prior_encoding`` and
+``spatial_correction_matrix``), output keys (``psm``, ``rm``, ``obj``, ``comm_rate``) and state_dict
+keys/shapes (297 tensors) as the reference."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..synth import synthetic_tensor, v2xvit_param_spec
+from .airv2x_where2com import _install
+from .v2xvit_engine import V2XViTEngine
+
+
+class Airv2xV2XVit(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if args.get("task", "det") != "det":
+            raise NotImplementedError("only the det task is on the MI355X hot path")
+        for t in args["collaborators"]:
+            if args[t]["modalities"] != ["lidar"]:
+                raise NotImplementedError("LiDAR-only agents")
+        self.args = args
+        self.collaborators = args["collaborators"]
+        self.active_sensors = args["active_sensors"]
+        self.max_cav_num = sum(args["max_cav"].values())
+        self.outC = args["outC"]
+        for key, shape, kind in v2xvit_param_spec(args):
+            if kind == "count":
+                t, buf = torch.zeros(shape, dtype=torch.long), True
+            elif kind in ("bn_m", "bn_v"):
+                t, buf = (torch.ones(shape) if kind == "bn_v" else torch.zeros(shape)), True
+            elif kind in ("bn_w", "ln_w"):
+                t, buf = torch.ones(shape), False
+            elif kind == "rte_table":
+                t, buf = torch.from_numpy(synthetic_tensor(key, shape, kind)), False
+            else:
+                t, buf = torch.zeros(shape), False
+            _install(self, key, t, buf)
+        self._engine = None
+        self._packed_version = None
+        self.sync_comm_rate = True
+
+    def _version(self):
+        return tuple(t._version for t in self.state_dict(keep_vars=True).values()) + (next(iter(self.parameters())).device,)
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("Airv2xV2XVit (MI355X build) has no CPU path: move the module to the GPU (model.to('cuda'))")
+        ver = self._version()
+        if self._engine is None or self._engine.device != dev:
+            self._engine = V2XViTEngine(self.args, dev)
+            self._packed_version = None
+        if self._packed_version != ver:
+            self._engine.load_state_dict(self.state_dict())
+            self._packed_version = ver
+        return self._engine
+
+    def forward(self, data_dict):
+        if self.training:
+            raise NotImplementedError("training is not built yet; call .eval()")
+        return self.engine().forward(data_dict, sync_comm_rate=self.sync_comm_rate)

@@ -1,0 +1,222 @@
+"""Host-side driver of the V2X-ViT-LiDAR path (models/airv2x_v2xvit.py:108-167) on one MI355X.
+
+Per-agent trunk = the Where2Comm engine's.  Fusion = V2XTransformer (v2xvit_basic.py:135-213) on one
+NHWC token buffer ``x (n, H, W, 256)`` holding only the REAL agents: padded agents are masked out as
+keys of every agent-wise attention (cav mask) and the window attention / FFN act per agent, so they
+can never influence agent 0, which is the only output (``output[:, 0]``, :212).
+
+HGT (hmsa.py): the per-relation matrices are folded into the per-type Linear weights once at load
+time (fp64 products rounded to fp32): for an agent of node type t the projection GEMM emits
+[q'(t->0) | q'(t->1) | k_t | v'(0<-t) | v'(1<-t)] so that the per-pixel kernel is a plain masked
+softmax attention over agents and the (B,M,H,W,L,L,C) ``v_msg`` tensor of the reference (8.1 GB at
+L = 15) never exists.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_int32, c_void_p
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import warp as warp_host
+from .engine import ConvLayer, Where2ComEngine, _ptr
+from .packing import pack_conv_weight
+
+LN_EPS = 1e-5
+
+
+class V2XViTEngine(Where2ComEngine):
+    def _init_config(self, args):
+        self.bb = args["modality_fusion"]["base_bev_backbone"]
+        self.sh = args["modality_fusion"]["shrink_header"]
+        self.fcfg = {"fully": False}
+        if args["modality_fusion"].get("compression", 0):
+            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        self.enc = args["transformer"]["encoder"]
+        self.cav, self.pw = self.enc["cav_att_config"], self.enc["pwindow_att_config"]
+        if not self.cav["use_hetero"] or self.pw["fusion_method"] != "split_attn" or not self.pw["relative_pos_embedding"]:
+            raise NotImplementedError("only the shipped V2X-ViT configuration (hetero attention, split_attn, relative pos)")
+        self.L = int(args["max_cav_num"])
+
+    def share_weights(self):
+        raise NotImplementedError
+
+    def _lin(self, w, b, act, up):
+        w = w.detach().float()
+        wp, coutp = pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))
+        b = b.detach().float() if b is not None else torch.zeros(w.shape[0])
+        return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
+
+    def _load_fusion(self, sd, up):
+        p = "fusion_net.encoder"
+        heads, dh = self.cav["heads"], self.cav["dim_head"]
+        self.layers = []
+        for d in range(self.enc["depth"]):
+            blocks = []
+            for nb in range(self.enc["num_blocks"]):
+                q = f"{p}.layers.{d}.0.layers.{nb}"
+                h = q + ".0.fn"
+                ratt, rmsg = sd[h + ".relation_att"].double().cpu(), sd[h + ".relation_msg"].double().cpu()
+                proj, aout = [], []
+                for t in range(2):
+                    Wq, bq = sd[f"{h}.q_linears.{t}.weight"].double().cpu(), sd[f"{h}.q_linears.{t}.bias"].double().cpu()
+                    Wk, bk = sd[f"{h}.k_linears.{t}.weight"].double().cpu(), sd[f"{h}.k_linears.{t}.bias"].double().cpu()
+                    Wv, bv = sd[f"{h}.v_linears.{t}.weight"].double().cpu(), sd[f"{h}.v_linears.{t}.bias"].double().cpu()
+                    rows_w, rows_b = [], []
+                    for tj in range(2):      # q' = w_att[e = t*2 + tj]^T q   per head (einsum 'i p, p q, j q', hmsa.py:139-141)
+                        e = t * 2 + tj
+                        for m in range(heads):
+                            sl = slice(m * dh, (m + 1) * dh)
+                            rows_w.append(ratt[e, m].t() @ Wq[sl])
+                            rows_b.append(ratt[e, m].t() @ bq[sl])
+                    rows_w.append(Wk); rows_b.append(bk)
+                    for ti in range(2):      # v' = w_msg[e = ti*2 + t]^T v   (einsum 'i j p c, j p', :150)
+                        e = ti * 2 + t
+                        for m in range(heads):
+                            sl = slice(m * dh, (m + 1) * dh)
+                            rows_w.append(rmsg[e, m].t() @ Wv[sl])
+                            rows_b.append(rmsg[e, m].t() @ bv[sl])
+                    proj.append(self._lin(torch.cat(rows_w, 0), torch.cat(rows_b, 0), 0, up))
+                    aout.append(self._lin(sd[f"{h}.a_linears.{t}.weight"], sd[f"{h}.a_linears.{t}.bias"], 0, up))
+                w = q + ".1.fn"
+                qkv_w = torch.cat([sd[f"{w}.pwmsa.{i}.to_qkv.weight"] for i in range(3)], 0)
+                blk = {
+                    "ln1": (up(sd[q + ".0.norm.weight"].float()), up(sd[q + ".0.norm.bias"].float())),
+                    "proj": proj, "aout": aout,
+                    "ln2": (up(sd[q + ".1.norm.weight"].float()), up(sd[q + ".1.norm.bias"].float())),
+                    "qkv3": self._lin(qkv_w, None, 0, up),
+                    "pos": [up(sd[f"{w}.pwmsa.{i}.pos_embedding"].float()) for i in range(3)],
+                    "wout": [self._lin(sd[f"{w}.pwmsa.{i}.to_out.0.weight"], sd[f"{w}.pwmsa.{i}.to_out.0.bias"], 0, up) for i in range(3)],
+                    "fc1": self._lin(sd[w + ".split_attn.fc1.weight"], None, 0, up),
+                    "bn1": (up(sd[w + ".split_attn.bn1.weight"].float()), up(sd[w + ".split_attn.bn1.bias"].float())),
+                    "fc2": self._lin(sd[w + ".split_attn.fc2.weight"], None, 0, up),
+                }
+                blocks.append(blk)
+            f = f"{p}.layers.{d}.1"
+            ffn = {"ln": (up(sd[f + ".norm.weight"].float()), up(sd[f + ".norm.bias"].float())),
+                   "ff1": self._lin(sd[f + ".fn.net.0.weight"], sd[f + ".fn.net.0.bias"], 2, up),
+                   "ff2": self._lin(sd[f + ".fn.net.3.weight"], sd[f + ".fn.net.3.bias"], 0, up)}
+            self.layers.append((blocks, ffn))
+        self.rte_table = up(sd[p + ".rte.emb.emb.weight"].float())
+        self.rte_lin = self._lin(sd[p + ".rte.emb.lin.weight"], sd[p + ".rte.emb.lin.bias"], 0, up)
+
+    def ln(self, x, gb, y, n_tokens, c, relu=0):
+        _lib.check(self.lib.av2x_layernorm_act(_ptr(x), _ptr(gb[0]), _ptr(gb[1]), _ptr(y), n_tokens, c, LN_EPS, relu,
+                                               self.stream()), "av2x_layernorm")
+
+    @staticmethod
+    def _groups(types):
+        """Consecutive agents of equal node type -> [(start, stop, type)] (the per-type Linear runs once per group)."""
+        out, s = [], 0
+        for i in range(1, len(types) + 1):
+            if i == len(types) or types[i] != types[s]:
+                out.append((s, i, types[s]))
+                s = i
+        return out
+
+    def encoder(self, x, n, H, W, prior, scm, trace=None):
+        C, hw, st = 256, H * W, self.stream
+        types = [int(prior[i, 2]) for i in range(n)]                      # infra flag -> node type (hmsa.py:123-127)
+        dts = [int(prior[i, 1]) for i in range(n)]
+        # ---- RTE: x[i] += lin(emb[dt_i * ratio])      (v2xvit_basic.py:58-80)
+        if self.cav["use_RTE"]:
+            rows = self.rte_table[[dt * self.cav["RTE_ratio"] for dt in dts]].contiguous()     # table rows (gather only)
+            vec = self.buf("rte_vec", (n, 1, 1, C))
+            self.conv(self.rte_lin, rows.view(n, 1, 1, C), n, 1, 1, vec)
+            _lib.check(self.lib.av2x_add_agent_vector(_ptr(x), _ptr(vec), n, hw * C, C, st()), "av2x_add_agent_vector")
+        # ---- STTF: warp agents 1.. into the ego frame; ROI x cav mask
+        d = warp_host.discretized_matrix(scm[:n], self.enc["sttf"]["voxel_size"][0], self.enc["sttf"]["downsample_rate"])
+        T = warp_host.transformation_matrix(d, (H, W))
+        theta = torch.from_numpy(warp_host.affine_theta(T, (H, W), (H, W))).to(self.device)
+        if n > 1:
+            warped = self.buf("sttf_warped", (n - 1, H, W, C))
+            _lib.check(self.lib.av2x_warp_affine(_ptr(x[1:]), _ptr(theta[1:]), _ptr(warped), n - 1, H, W, C, st()), "av2x_warp_affine")
+            x[1:].copy_(warped)
+        mask = self.buf("com_mask", (n, H, W))
+        ones = self.buf("cav_ones", (n,), torch.int32)
+        if self.enc["use_roi_mask"]:
+            ones.fill_(1)
+            _lib.check(self.lib.av2x_roi_mask(_ptr(theta), _ptr(ones), _ptr(mask), n, H, W, st()), "av2x_roi_mask")
+        else:
+            mask.fill_(1.0)
+        if trace is not None:
+            trace["after_sttf"] = x.clone()
+            trace["com_mask"] = mask.clone()
+        tarr = (c_int32 * n)(*types)
+        xn = self.buf("vit_xn", (n, H, W, C))
+        proj = self.buf("vit_proj", (n, H, W, 1280))
+        att = self.buf("vit_att", (n, H, W, C))
+        qkv3 = self.buf("vit_qkv3", (n, H, W, 2304))
+        wat = self.buf("vit_wat", (n, H, W, C))
+        br = [self.buf(f"vit_br{i}", (n, H, W, C)) for i in range(3)]
+        gap = self.buf("vit_gap", (n, 1, 1, C))
+        g1 = self.buf("vit_g1", (n, 1, 1, C))
+        g2 = self.buf("vit_g2", (n, 1, 1, C))
+        logits = self.buf("vit_logits", (n, 1, 1, 3 * C))
+        hid = self.buf("vit_hid", (n, H, W, self.enc["feed_forward"]["mlp_dim"]))
+        groups = self._groups(types)
+        for di, (blocks, ffn) in enumerate(self.layers):
+            for blk in blocks:
+                # ---- x = HGT(LN(x)) + x
+                self.ln(x, blk["ln1"], xn, n * hw, C)
+                for (a, b, t) in groups:
+                    self.conv(blk["proj"][t], xn[a:b], b - a, H, W, proj[a:b])
+                _lib.check(self.lib.av2x_hgt_attention(_ptr(proj), _ptr(mask), ctypes.cast(tarr, c_void_p), _ptr(att), n, hw,
+                                                       self.cav["heads"], self.cav["dim_head"], st()), "av2x_hgt_attention")
+                for (a, b, t) in groups:
+                    self.conv(blk["aout"][t], att[a:b], b - a, H, W, x[a:b], residual=x[a:b])
+                if trace is not None:
+                    trace[f"hgt{di}"] = x.clone()
+                # ---- x = SplitAttn(window attentions(LN(x))) + x
+                self.ln(x, blk["ln2"], xn, n * hw, C)
+                self.conv(blk["qkv3"], xn, n, H, W, qkv3)
+                for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
+                    _lib.check(self.lib.av2x_window_attention(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat), n, H, W,
+                                                              h, dh, ws, st()), "av2x_window_attention")
+                    self.conv(blk["wout"][i], wat, n, H, W, br[i])
+                _lib.check(self.lib.av2x_split_attn_gap(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(gap), n, hw, C, st()), "gap")
+                self.conv(blk["fc1"], gap, n, 1, 1, g1)
+                self.ln(g1, blk["bn1"], g2, n, C, relu=1)
+                self.conv(blk["fc2"], g2, n, 1, 1, logits)
+                _lib.check(self.lib.av2x_split_attn_combine(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), _ptr(x), _ptr(x),
+                                                            n, hw, C, st()), "combine")
+            # ---- x = FFN(LN(x)) + x
+            self.ln(x, ffn["ln"], xn, n * hw, C)
+            self.conv(ffn["ff1"], xn, n, H, W, hid)
+            self.conv(ffn["ff2"], hid, n, H, W, x, residual=x)
+            if trace is not None:
+                trace[f"layer{di}"] = x.clone()
+        return x[0:1]
+
+    @torch.no_grad()
+    def forward(self, data_dict, trace=None, sync_comm_rate=False):
+        if not self.weights_ready:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        record_len, slots = self.frame_layout(data_dict)
+        if len(record_len) != 1:
+            raise NotImplementedError("V2X-ViT engine: one collaborative frame (B = 1) per call")
+        n = record_len[0]
+        if n > self.L:
+            raise ValueError(f"{n} agents exceed max_cav_num = {self.L}")
+        canvas, ny, nx = self.encode(data_dict, record_len, slots)
+        st = self.stream()
+        nz = self.buf("nonzero", (1,), torch.int64)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        dims = self.level_dims(ny, nx)
+        H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        x = self.buf("vit_x", (n, H, Wd, 256))
+        self.trunk(canvas, n, ny, nx, shrink_out=x)
+        prior = data_dict["prior_encoding"][0].detach().cpu().numpy()           # (L,3) per-agent scalars (appendix A #12)
+        scm = data_dict["spatial_correction_matrix"][0].detach().cpu().numpy()   # (L,4,4) f64
+        fused = self.encoder(x, n, H, Wd, prior, scm, trace)
+        heads = torch.empty((1, self.heads.cout, H, Wd), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, 1, H, Wd, heads)
+        outs = torch.split(heads, self.head_splits, dim=1)
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        out["comm_rate"] = int(nz[0].item()) if sync_comm_rate else nz[0]
+        return out

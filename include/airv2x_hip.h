@@ -194,6 +194,45 @@ int av2x_fax_attention(const float* qkv, const float* bias_table, float* out, in
 int av2x_agent_mean(const float* x, float* y, int32_t n_agents, int64_t elems_per_agent,
                     av2x_stream_t stream);
 
+/* LayerNorm followed by an optional ReLU (SplitAttn: act1(bn1(fc1(.))), split_attn.py:51). */
+int av2x_layernorm_act(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,
+                       int32_t c, float eps, int32_t relu, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * V2X-ViT fusion pieces (models/v2xvit_modules/*, common_modules/torch_transformation_utils.py).
+ * av2x_warp_affine: F.affine_grid + F.grid_sample(bilinear, zeros, align_corners=True) as called by
+ *   warp_affine :337-381.  src/dst (n,h,w,c) NHWC; theta (n,2,3) DEVICE fp32 = the matrix handed to
+ *   affine_grid (the 3x3 normalise/invert chain is host-side, opencood_iface/warp.py).
+ * av2x_roi_mask: get_roi_and_cav_mask :15-53 — nearest-mode sampling of an all-ones image times the
+ *   per-agent cav mask (device i32 (n,)) -> mask (n,h,w) in {0,1}.
+ * av2x_add_agent_vector: x[a,:,:,:] += v[a,:]  (RTE, v2xvit_basic.py:58-80); x (n, elems_per_agent), v (n,c).
+ * av2x_hgt_attention: HGTCavAttention hmsa.py:133-151 per pixel on FOLDED projections, proj (n,hw,1280) =
+ *   [q'(->type0) | q'(->type1) | k | v'(type0<-) | v'(type1<-)] with relation_att / relation_msg multiplied
+ *   into the Linear weights on the host; mask (n,hw): key agent visible at the pixel; types_host: HOST
+ *   i32 (n,) node type (0/1) of every agent; out (n,hw,256) heads merged (before a_linears).
+ * av2x_window_attention: BaseWindowAttention mswin.py:52-96 for n agent maps; the [q|k|v] block of the
+ *   branch sits at column `coff` of the (n*h*w, ctot) token buffer; pos_embedding (2w-1,2w-1);
+ *   out (n*h*w, heads*dim_head).  Supported (dim_head, window): (16,2) (32,4) (64,4).
+ * av2x_split_attn_gap / _combine: SplitAttn split_attn.py:48-61 — mean over pixels of the branch sum,
+ *   then radix-3 softmax of logits (n,3c) + weighted branch sum + residual.
+ * ------------------------------------------------------------------------------------ */
+int av2x_warp_affine(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w,
+                     int32_t c, av2x_stream_t stream);
+int av2x_roi_mask(const float* theta, const int32_t* cav_mask, float* mask, int32_t n, int32_t h, int32_t w,
+                  av2x_stream_t stream);
+int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_t elems_per_agent, int32_t c,
+                          av2x_stream_t stream);
+int av2x_hgt_attention(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
+                       int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
+int av2x_window_attention(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, float* out,
+                          int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
+                          av2x_stream_t stream);
+int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, int32_t n, int32_t hw,
+                        int32_t c, av2x_stream_t stream);
+int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,
+                            const float* residual, float* out, int32_t n, int32_t hw, int32_t c,
+                            av2x_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
