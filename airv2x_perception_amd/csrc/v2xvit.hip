@@ -193,19 +193,34 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
     for (int d = 0; d < DHD; d += 4) *reinterpret_cast<float4*>(dst + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
 }
 
-// gap[a][c] = mean over pixels of (s0 + s1 + s2); grid (C/64, n), block 256 = 4 pixel groups x 64 channels
-__global__ __launch_bounds__(256) void gap3_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
-                                                   const float* __restrict__ s2, float* __restrict__ gap, int hw, int C) {
+// gap[a][c] = mean over pixels of (s0 + s1 + s2), deterministic two-stage reduction:
+//   stage 1: grid (C/64, n, GAP_CHUNKS), block 256 = 4 pixel groups x 64 channels -> part[a][chunk][c]
+//   stage 2: grid (C/64, n): sum of the chunks in fixed order, / hw
+constexpr int GAP_CHUNKS = 128;
+
+__global__ __launch_bounds__(256) void gap3_stage1(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                   const float* __restrict__ s2, float* __restrict__ partial, int hw, int C) {
     __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, a = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, a = blockIdx.y, ch = blockIdx.z;
+    const int per = (hw + GAP_CHUNKS - 1) / GAP_CHUNKS;
+    const int p0 = ch * per, p1 = min(hw, p0 + per);
     float acc = 0.f;
-    for (int p = g; p < hw; p += 4) {
+    for (int p = p0 + g; p < p1; p += 4) {
         const size_t o = ((size_t)a * hw + p) * C + c;
         acc += (s0[o] + s1[o]) + s2[o];
     }
     part[g][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (g == 0) gap[(size_t)a * C + c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / (float)hw;
+    if (g == 0)
+        partial[((size_t)a * GAP_CHUNKS + ch) * C + c] =
+            ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+
+__global__ void gap3_stage2(const float* __restrict__ partial, float* __restrict__ gap, int hw, int C) {
+    const int c = blockIdx.x * 64 + threadIdx.x, a = blockIdx.y;
+    float acc = 0.f;
+    for (int ch = 0; ch < GAP_CHUNKS; ++ch) acc += partial[((size_t)a * GAP_CHUNKS + ch) * C + c];
+    gap[(size_t)a * C + c] = acc / (float)hw;
 }
 
 __global__ void split_combine_kernel(const float4* __restrict__ s0, const float4* __restrict__ s1, const float4* __restrict__ s2,
@@ -305,13 +320,15 @@ extern "C" int av2x_window_attention(const float* qkv, int32_t ctot, int32_t cof
     return av2x::check_launch("window_attn_kernel");
 }
 
-extern "C" int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, int32_t n, int32_t hw, int32_t c,
-                                   av2x_stream_t stream) {
+extern "C" int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, float* scratch, int32_t n,
+                                   int32_t hw, int32_t c, av2x_stream_t stream) {
     if (n == 0) return 0;
-    if (!s0 || !s1 || !s2 || !gap) return av2x::fail("av2x_split_attn_gap: null argument");
+    if (!s0 || !s1 || !s2 || !gap || !scratch) return av2x::fail("av2x_split_attn_gap: null argument");
     if (c % 64) return av2x::fail("av2x_split_attn_gap: c must be a multiple of 64");
-    hipLaunchKernelGGL(gap3_kernel, dim3(c / 64, n), dim3(256), 0, av2x::as_stream(stream), s0, s1, s2, gap, hw, c);
-    return av2x::check_launch("gap3_kernel");
+    hipStream_t st = av2x::as_stream(stream);
+    hipLaunchKernelGGL(gap3_stage1, dim3(c / 64, n, GAP_CHUNKS), dim3(256), 0, st, s0, s1, s2, scratch, hw, c);
+    hipLaunchKernelGGL(gap3_stage2, dim3(c / 64, n), dim3(64), 0, st, scratch, gap, hw, c);
+    return av2x::check_launch("gap3");
 }
 
 extern "C" int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,

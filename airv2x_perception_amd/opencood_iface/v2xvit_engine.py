@@ -152,6 +152,7 @@ class V2XViTEngine(Where2ComEngine):
         wat = self.buf("vit_wat", (n, H, W, C))
         br = [self.buf(f"vit_br{i}", (n, H, W, C)) for i in range(3)]
         gap = self.buf("vit_gap", (n, 1, 1, C))
+        gap_scratch = self.buf("vit_gap_scratch", (n, 128, C))
         g1 = self.buf("vit_g1", (n, 1, 1, C))
         g2 = self.buf("vit_g2", (n, 1, 1, C))
         logits = self.buf("vit_logits", (n, 1, 1, 3 * C))
@@ -176,7 +177,8 @@ class V2XViTEngine(Where2ComEngine):
                     _lib.check(self.lib.av2x_window_attention(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat), n, H, W,
                                                               h, dh, ws, st()), "av2x_window_attention")
                     self.conv(blk["wout"][i], wat, n, H, W, br[i])
-                _lib.check(self.lib.av2x_split_attn_gap(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(gap), n, hw, C, st()), "gap")
+                _lib.check(self.lib.av2x_split_attn_gap(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(gap), _ptr(gap_scratch), n, hw, C,
+                                                        st()), "gap")
                 self.conv(blk["fc1"], gap, n, 1, 1, g1)
                 self.ln(g1, blk["bn1"], g2, n, C, relu=1)
                 self.conv(blk["fc2"], g2, n, 1, 1, logits)

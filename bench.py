@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a captured HIP graph (1) or eager (0); "
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
-    ap.add_argument("--model", choices=["where2com", "cobevt"], default="where2com",
+    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit"], default="where2com",
                     help="where2com = the headline metric; cobevt = BASELINE.json configs[2] fusion head on one GPU")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent frames kept in flight per GPU (separate HIP streams + workspaces, shared weights); "
@@ -80,6 +80,8 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
         nd = n_agents - nv - nr
         # shipped max_cav is 3/2/2 (L = 7); larger frames need a larger agent axis
         hy = synth.default_hypes_cobevt(None, (max(3, nv), max(2, nr), max(2, nd)))
+    elif model == "v2xvit":
+        hy = synth.default_hypes_v2xvit()
     else:
         hy = synth.default_hypes()
     args = hy["model"]["args"]
@@ -97,6 +99,13 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
                                     pp["args"]["max_points_per_voxel"], pp["args"]["max_voxel_test"],
                                     range_filter=True))
     dd = synth.build_data_dict_device(voxd, types_sorted, device, max_cav_num=args["max_cav_num"])
+    if model == "v2xvit":  # seeded SE(2) correction per non-ego agent; host-side (L,4,4)/(L,3) scalars
+        g = np.random.default_rng(99)
+        scm = torch.eye(4, dtype=torch.float64).repeat(1, args["max_cav_num"], 1, 1)
+        for i in range(1, len(types_sorted)):
+            scm[0, i] = torch.from_numpy(synth.se2_correction(g.uniform(-10, 10), g.uniform(-8, 8), g.uniform(-8, 8)))
+        dd["spatial_correction_matrix"] = scm
+        dd["prior_encoding"] = dd["prior_encoding"].cpu()
     return hy, args, dd, [clouds[i] for i in order], types_sorted
 
 
@@ -130,6 +139,11 @@ def main():
         a.inflight, a.cpu_frames = 1, 0
         sd = synth.synthetic_state_dict(synth.cobevt_param_spec(args), seed=0)
         model = Airv2xCoBEVT(args)
+    elif a.model == "v2xvit":
+        from airv2x_perception_amd.opencood_iface import Airv2xV2XVit
+        a.inflight, a.cpu_frames = 1, 0
+        sd = synth.synthetic_state_dict(synth.v2xvit_param_spec(args), seed=0)
+        model = Airv2xV2XVit(args)
     else:
         sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
         model = Airv2xWhere2com(args)
@@ -173,12 +187,12 @@ def main():
     fps = (world if a.mode == "replica" else 1) * a.steps / dt
 
     res = {
-        "metric": f"collaborative frames/sec, {'Where2Comm' if a.model == 'where2com' else 'CoBEVT'}-LiDAR {a.agents}-agent",
+        "metric": f"collaborative frames/sec, { {'where2com': 'Where2Comm', 'cobevt': 'CoBEVT', 'v2xvit': 'V2X-ViT'}[a.model] }-LiDAR {a.agents}-agent",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else 'CoBEVT (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
+        "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
                    "parallelism": ("single GPU" if world == 1 else "independent frames per GPU (replicas)") if a.mode == "replica"

@@ -227,8 +227,8 @@ int av2x_hgt_attention(const float* proj, const float* mask, const int32_t* type
 int av2x_window_attention(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, float* out,
                           int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
                           av2x_stream_t stream);
-int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, int32_t n, int32_t hw,
-                        int32_t c, av2x_stream_t stream);
+int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, float* scratch /* n*128*c floats */,
+                        int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
 int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,
                             const float* residual, float* out, int32_t n, int32_t hw, int32_t c,
                             av2x_stream_t stream);
