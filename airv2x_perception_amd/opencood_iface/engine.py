@@ -88,7 +88,7 @@ class Where2ComEngine:
         self.tile_cache = {}
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
-        self.profile = None         # list -> (tile, flops, ev0, ev1) per conv launch (bench roofline pass)
+        self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
         self.agent_streams = 1      # >1 (B == 1): agents are split into this many groups that run the per-agent part
                                     # of the frame on separate HIP streams.  Measured: no gain, off by default
         self._streams = None
@@ -255,7 +255,9 @@ class Where2ComEngine:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1))
+            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x3fff))
+            self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1, wgs,
+                                 (n * d.ho * d.wo, L.cin, ncols, L.ks, L.stride)))
         return ho, wo
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2)

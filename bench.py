@@ -35,6 +35,25 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
+def pmc_traffic(kernel_key, grid_counts):
+    """roofline.traffic: HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/pmc_hbm.json, made by tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` runs of this same command), weighted by this run's launch mix.  None when the
+    file has no entry for one of the (kernel, workgroup-count) pairs launched."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_hbm.json")
+    if not os.path.exists(path):
+        return None, "profiles/pmc_hbm.json absent"
+    tab = json.load(open(path))["per_kernel"].get(kernel_key, {})
+    tot, cnt = 0.0, 0
+    for wgs, c in grid_counts.items():
+        e = tab.get(str(wgs))
+        if e is None:
+            return None, f"no PMC entry for {kernel_key} with {wgs} workgroups"
+        tot += c * (e["fetch_bytes"] + e["write_bytes"])
+        cnt += c
+    return round(tot / cnt), "bytes/launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 calibration in profiles/pmc_hbm.json)"
+
+
 def usable_cores():
     """Host cores this process may actually use: min(affinity mask, cgroup v2 cpu.max quota).
     (The GPU boxes expose 256 logical CPUs but cap the container at a 16-CPU quota; asking
@@ -58,6 +77,7 @@ def parse():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--per-shape", action="store_true", help="add a per-layer-shape table to the roofline object")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a captured HIP graph (1) or eager (0); "
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
     ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit"], default="where2com",
@@ -241,26 +261,40 @@ def main():
         torch.cuda.synchronize()
         prof, eng.profile = eng.profile, None
         per = {}
-        for tile, flops, e0, e1 in prof:
+        grids = {}
+        shapes = {}
+        for tile, flops, e0, e1, wgs, shp in prof:
             d = per.setdefault(tile, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
             d[2] += e0.elapsed_time(e1) * 1e-3
+            g = grids.setdefault(tile, {})
+            g[wgs] = g.get(wgs, 0) + 1
+            sh = shapes.setdefault((shp, tile, wgs), [0, 0.0, 0.0])
+            sh[0] += 1
+            sh[1] += flops
+            sh[2] += e0.elapsed_time(e1) * 1e-3
         dom = max(per, key=lambda k: per[k][2])
         cnt, fl, sec = per[dom]
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
+        tkey = lambda k: f"{k[0]}x{k[1] & 0x3fff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}"
+        traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
             "kernel": f"conv_igemm_f32<{dom[0]},{dom[1] & 0x3fff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
                       + (" prefetch-2" if dom[1] & 0x4000 else ""), "launches_per_frame": cnt / a.steps,
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},
-            "per_tile": {f"{k[0]}x{k[1] & 0x3fff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}": {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
+            "per_tile": {tkey(k): {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
                                             "ms_per_frame": round(v[2] / a.steps * 1e3, 3)} for k, v in per.items()},
+            **({"per_shape": [{"M_cin_cout_ks_stride": list(k[0]), "tile": tkey(k[1]), "wgs": k[2], "launches_per_frame": v[0] / a.steps,
+                               "us": round(v[2] / v[0] * 1e6, 1), "tflops": round(v[1] / v[2] / 1e12, 1)}
+                              for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])]} if a.per_shape else {}),
             "timing": "second pass of K steps, hipEvent pair around every conv launch on the launch stream",
         }
 

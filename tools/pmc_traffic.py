@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 PMC passes into per-launch HBM-side traffic for every conv_igemm_f32 variant.
+
+  python tools/pmc_traffic.py --fetch gpurun_out/pmc3_bench_FETCH_SIZE --write gpurun_out/pmc3_bench_WRITE_SIZE \\
+         --calib-fetch gpurun_out/pmc3_calib_FETCH_SIZE --calib-write gpurun_out/pmc3_calib_WRITE_SIZE \\
+         -o profiles/pmc_hbm.json
+
+Each directory holds the sqlite output of ONE `rocprofv3 --kernel-trace --pmc <counter>` run (separate
+passes: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2).  Units and correction follow
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of 16 B/lane streaming reads, WRITE_SIZE is "uncalibrated".  tools/pmc_calib.py launches
+kernels with known byte counts; the scale factors measured there are stored in the output and applied."""
+import argparse, glob, json, re, sqlite3
+from collections import defaultdict
+
+
+def rows(d):
+    f = glob.glob(d.rstrip("/") + "/*/*_results.db") + glob.glob(d.rstrip("/") + "/*_results.db")
+    c = sqlite3.connect(f[0])
+    return c.execute("select kernel_name, grid_size, workgroup_size, counter_name, value from counters_collection").fetchall()
+
+
+def conv_key(name):
+    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    if not m:
+        return None
+    bm, bn, wm, wn = (int(m.group(i)) for i in range(1, 5))
+    waves = (bm // wm) * (bn // wn)
+    return f"{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if m.group(5) == 'true' else ''}"
+
+
+def calib(d, counter, kernel_sub, known_bytes):
+    v = [r[4] for r in rows(d) if r[3] == counter and kernel_sub in r[0] and r[4] > 1024]
+    return known_bytes / (sum(v) / len(v) * 1024.0), len(v)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--calib-fetch")
+    ap.add_argument("--calib-write")
+    ap.add_argument("--calib-bytes", type=int, default=576 << 20)
+    ap.add_argument("-o", "--out", required=True)
+    a = ap.parse_args()
+    fscale, wscale, cal = 2.0, 1.0, {"note": "guide defaults (no calibration run given)"}
+    if a.calib_fetch and a.calib_write:
+        f1, n1 = calib(a.calib_fetch, "FETCH_SIZE", "copyBuffer", a.calib_bytes)
+        f2, n2 = calib(a.calib_fetch, "FETCH_SIZE", "reduce_kernel", a.calib_bytes)
+        w1, n3 = calib(a.calib_write, "WRITE_SIZE", "copyBuffer", a.calib_bytes)
+        w2, n4 = calib(a.calib_write, "WRITE_SIZE", "fillBufferAligned", a.calib_bytes)
+        fscale, wscale = round((f1 + f2) / 2, 3), round((w1 + w2) / 2, 3)
+        cal = {"known_bytes": a.calib_bytes, "fetch_scale_copy": round(f1, 4), "fetch_scale_reduce": round(f2, 4),
+               "write_scale_copy": round(w1, 4), "write_scale_fill": round(w2, 4), "launches": [n1, n2, n3, n4],
+               "note": "true bytes / (counter KiB x 1024) on tools/pmc_calib.py (576 MiB streaming copy / sum / fill)"}
+    acc = defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
+    for d in (a.fetch, a.write):
+        for name, grid, wg, ctr, val in rows(d):
+            k = conv_key(name)
+            if k and ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                acc[(k, grid // wg)][ctr].append(val)
+    per = defaultdict(dict)
+    for (k, wgs), v in sorted(acc.items()):
+        if not v["FETCH_SIZE"] or not v["WRITE_SIZE"]:
+            continue
+        fb = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 1024 * fscale
+        wb = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) * 1024 * wscale
+        per[k][str(wgs)] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "launches": len(v["FETCH_SIZE"])}
+    json.dump({"counters": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes), KiB",
+               "fetch_scale": fscale, "write_scale": wscale, "calibration": cal,
+               "caveat": "TCC_EA (L2 memory-side) requests: Infinity-Cache hits are included, so this is an upper bound on HBM bytes",
+               "per_kernel": per}, open(a.out, "w"), indent=1)
+    print(f"fetch x{fscale} write x{wscale}; {sum(len(v) for v in per.values())} (kernel, grid) entries -> {a.out}")
+
+
+if __name__ == "__main__":
+    main()
