@@ -23,7 +23,7 @@ class ConvDesc(Structure):
     """struct av2x_conv_desc (include/airv2x_hip.h)."""
     _fields_ = [(n, c_int32) for n in (
         "n", "h", "w", "cin", "in_ctot", "in_coff", "ho", "wo", "cout", "coutp", "out_ctot", "out_coff",
-        "ks", "stride", "pad", "relu", "mode", "up", "tile")]
+        "ks", "stride", "pad", "relu", "mode", "up", "tile", "sk_wgs")]
 
 
 AV2X_CONV, AV2X_DECONV, AV2X_CONV_NCHW = 0, 1, 2
@@ -37,6 +37,9 @@ SIGNATURES = {
     "av2x_fill_zero": (c_int32, [c_void_p, c_uint64, c_void_p]),
     "av2x_conv2d": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_conv2d_res": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_conv2d_sk": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_uint64, c_void_p]),
+    "av2x_conv2d_sk_workspace_bytes": (c_uint64, [c_int32, c_int32]),
     "av2x_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "av2x_fax_attention": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_void_p]),

@@ -34,12 +34,90 @@ struct ConvParams {
     int ks, stride, pad, relu, mode, up;
     int M, tiles_n, cchunks, steps;
     unsigned in_bytes, w_bytes;
+    // stream-K (SK kernels only): the tiles x steps iteration space is cut into gridDim.x equal
+    // contiguous ranges of sk_per iterations; partial accumulators go to ws (see conv_fixup_f32)
+    int sk_per, sk_total;
+    float* ws;
 };
 
 constexpr int BK = 32;
 constexpr int LDA = 36;
 
-template <int BM, int BN, int WM, int WN, bool DEEP>
+// Epilogue shared by the GEMM kernel and the stream-K fix-up: folded BN / bias, activation, residual,
+// and the NHWC-slice / deconv-scatter / NCHW addressing.  C/D map of the 32x32 MFMA:
+// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[MT][NT], int mw, int nw, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int n = nw + c * 32 + li;  // GEMM column
+        int co = n, ij = 0;
+        if (p.mode == AV2X_DECONV) { ij = n / p.Cout; co = n - ij * p.Cout; }
+        const bool nok = (p.mode == AV2X_DECONV) ? (n < p.CoutP) : (n < p.Cout);
+        const float sc = (nok && p.scale) ? p.scale[co] : 1.f;
+        const float sh = nok ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (!nok || m >= p.M) continue;
+                float v = acc[a][c][r] * sc + sh;
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // exact GELU (nn.GELU())
+                size_t off;
+                if (p.mode == AV2X_CONV) {
+                    off = (size_t)m * p.out_ctot + p.out_coff + co;
+                    if (p.res) v += p.res[off];
+                } else {
+                    const int img = m / p.HoWo, rem = m - img * p.HoWo;
+                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    if (p.mode == AV2X_DECONV) {
+                        const int di = ij / p.up, dj = ij - di * p.up;
+                        off = ((size_t)(img * p.Ho * p.up + ho * p.up + di) * (p.Wo * p.up) + wo * p.up + dj) * p.out_ctot +
+                              p.out_coff + co;
+                    } else {  // NCHW
+                        off = ((size_t)(img * p.Cout + co) * p.Ho + ho) * p.Wo + wo;
+                    }
+                }
+                p.out[off] = v;
+            }
+        }
+    }
+}
+
+// Stream-K fix-up: tile t was cut between workgroups g_lo..g_hi of the SK kernel; their raw accumulators
+// (same per-thread layout as the kernel: [slot][(a*NT+c)*16+r][tid]) are summed in ascending K order
+// (deterministic) and sent through the normal epilogue.  Slot 2g holds the partial of g's FIRST
+// segment (the tile its range starts in), slot 2g+1 the partial of its last one.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_fixup_f32(const ConvParams p) {
+    constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN, NTHR = 64 * (BM / WM) * (BN / WN);
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int it0 = tile * p.steps, it1 = it0 + p.steps - 1;
+    const int g_lo = it0 / p.sk_per, g_hi = it1 / p.sk_per;
+    if (g_lo == g_hi) return;  // computed whole by one workgroup, already written
+    f32x16 acc[MT][NT];
+    for (int g = g_lo; g <= g_hi; ++g) {
+        const int slot = ((g * p.sk_per) / p.steps == tile) ? 2 * g : 2 * g + 1;
+        const float* wsp = p.ws + (size_t)slot * (BM * BN) + tid;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = wsp[((a * NT + c) * 16 + r) * NTHR];
+                    acc[a][c][r] = (g == g_lo) ? v : acc[a][c][r] + v;
+                }
+    }
+    const int wave = tid >> 6;
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    conv_epilogue<MT, NT>(p, acc, tile_m * BM + (wave / WAVES_N) * WM, tile_n * BN + (wave % WAVES_N) * WN, tid & 63);
+}
+
+template <int BM, int BN, int WM, int WN, bool DEEP, bool SK>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(const ConvParams p) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -60,9 +138,18 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     const int nb = gridDim.x, b = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    const int tile_n = swz % p.tiles_n, tile_m = swz / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    // iteration range of this workgroup: one whole tile, or (stream-K) sk_per iterations that may
+    // cover the tail of one tile, whole tiles, and the head of another
+    int it = SK ? swz * p.sk_per : swz * p.steps;
+    const int it_end = SK ? min(it + p.sk_per, p.sk_total) : it + p.steps;
+    bool first_seg = true;
+    do {
+    const int tile = SK ? it / p.steps : swz;
+    const int ks0 = SK ? it - tile * p.steps : 0;
+    const int nst = SK ? min(p.steps - ks0, it_end - it) : p.steps;
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread gather bookkeeping for the A tile: row (tid>>3)+32*i, k-quad tid&7
     const int qA = tid & 7;
@@ -103,16 +190,18 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     for (int i = 0; i < B_LD; ++i)
         voffB[i] = (unsigned)(((tid / BN + i * ROWS_PER_PASS) * p.CoutP + n0 + (tid % BN)) * 16);
 
+#define AV2X_TAPOFF(TAP)                                                                                \
+    {                                                                                                   \
+        const int kh_ = (TAP) / p.ks, kw_ = (TAP) - kh_ * p.ks;                                         \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                              \
+            const int hi = hi0[i] + kh_, wi = wi0[i] + kw_;                                             \
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;               \
+            voffA[i] = ok ? (unsigned)(((pix0[i] + hi * p.W + wi) * p.in_ctot + p.in_coff + qA * 4) * 4) : OOB; \
+        }                                                                                               \
+    }
 #define AV2X_GLOAD(ra, rb, TAP, CC)                                                                     \
     {                                                                                                   \
-        if ((CC) == 0) { /* new tap: refresh the per-row offsets (uniform branch, every cchunks steps) */ \
-            const int kh_ = (TAP) / p.ks, kw_ = (TAP) - kh_ * p.ks;                                     \
-            _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                          \
-                const int hi = hi0[i] + kh_, wi = wi0[i] + kw_;                                         \
-                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;           \
-                voffA[i] = ok ? (unsigned)(((pix0[i] + hi * p.W + wi) * p.in_ctot + p.in_coff + qA * 4) * 4) : OOB; \
-            }                                                                                           \
-        }                                                                                               \
+        if ((CC) == 0) AV2X_TAPOFF(TAP) /* new tap: refresh the per-row offsets (uniform branch) */     \
         const unsigned sa_ = (unsigned)((CC)*BK * 4);                                                   \
         _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                                        \
             __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, voffA[i], sa_, 0));    \
@@ -138,11 +227,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    int tap = 0, cc = 0;  // (tap, channel chunk) of the NEXT tile to request; clamps at the last tile
+    // (tap, channel chunk) of the NEXT K-step to request; clamps at the last step of the segment
+    int tap = SK ? ks0 / p.cchunks : 0, cc = SK ? ks0 - tap * p.cchunks : 0;
     int issued = 0;
+    if (SK && cc != 0) AV2X_TAPOFF(tap)
 #define AV2X_ADVANCE()                                         \
     {                                                          \
-        if (issued + 1 < p.steps) {                            \
+        if (issued + 1 < nst) {                                \
             ++issued;                                          \
             if (++cc == p.cchunks) { cc = 0; ++tap; }          \
         }                                                      \
@@ -185,7 +276,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     AV2X_LSTORE(ra0, rb0, 0);
     __syncthreads();
     if constexpr (!DEEP) {
-        for (int s = 0; s < p.steps; ++s) {
+        for (int s = 0; s < nst; ++s) {
             const int buf = s & 1;
             AV2X_ADVANCE();  // the last iteration re-fetches the final tile: harmless, keeps the loop branch-free
             AV2X_GLOAD(ra0, rb0, tap, cc);
@@ -201,7 +292,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
         // invariant at the top of an even step s: tile s is in LDS buffer 0, tile s+1 is in flight in set 0
         AV2X_ADVANCE();
         AV2X_GLOAD(ra0, rb0, tap, cc);
-        for (int s = 0; s < p.steps; s += 2) {
+        for (int s = 0; s < nst; s += 2) {
             AV2X_ADVANCE();
             AV2X_GLOAD(ra1, rb1, tap, cc);  // tile s+2
             __builtin_amdgcn_sched_barrier(0);
@@ -209,7 +300,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
             __builtin_amdgcn_sched_barrier(0);
             AV2X_LSTORE(ra0, rb0, 1);  // tile s+1 -> buffer 1
             __syncthreads();
-            if (s + 1 < p.steps) {
+            if (s + 1 < nst) {
                 AV2X_ADVANCE();
                 AV2X_GLOAD(ra0, rb0, tap, cc);  // tile s+3
                 __builtin_amdgcn_sched_barrier(0);
@@ -225,45 +316,24 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
 #undef AV2X_MFMAS
 #undef AV2X_ADVANCE
 #undef AV2X_GLOAD
+#undef AV2X_TAPOFF
 #undef AV2X_LSTORE
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (!SK || nst == p.steps) {
+        conv_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, lane);
+    } else {
+        float* wsp = p.ws + (size_t)(2 * swz + (first_seg ? 0 : 1)) * (BM * BN) + tid;
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const int n = n0 + wn0 + c * 32 + li;  // GEMM column
-        int co = n, ij = 0;
-        if (p.mode == AV2X_DECONV) { ij = n / p.Cout; co = n - ij * p.Cout; }
-        const bool nok = (p.mode == AV2X_DECONV) ? (n < p.CoutP) : (n < p.Cout);
-        const float sc = (nok && p.scale) ? p.scale[co] : 1.f;
-        const float sh = nok ? p.shift[co] : 0.f;
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
+            for (int c = 0; c < NT; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (!nok || m >= p.M) continue;
-                float v = acc[a][c][r] * sc + sh;
-                if (p.relu == 1) v = fmaxf(v, 0.f);
-                else if (p.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // exact GELU (nn.GELU())
-                size_t off;
-                if (p.mode == AV2X_CONV) {
-                    off = (size_t)m * p.out_ctot + p.out_coff + co;
-                    if (p.res) v += p.res[off];
-                } else {
-                    const int img = m / p.HoWo, rem = m - img * p.HoWo;
-                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    if (p.mode == AV2X_DECONV) {
-                        const int di = ij / p.up, dj = ij - di * p.up;
-                        off = ((size_t)(img * p.Ho * p.up + ho * p.up + di) * (p.Wo * p.up) + wo * p.up + dj) * p.out_ctot +
-                              p.out_coff + co;
-                    } else {  // NCHW
-                        off = ((size_t)(img * p.Cout + co) * p.Ho + ho) * p.Wo + wo;
-                    }
-                }
-                p.out[off] = v;
-            }
-        }
+                for (int r = 0; r < 16; ++r) wsp[((a * NT + c) * 16 + r) * NTHR] = acc[a][c][r];
     }
+    it += nst;
+    first_seg = false;
+    if (SK) __syncthreads();  // the next segment re-fills LDS buffer 0
+    } while (SK && it < it_end);
 }
 
 template <int BM, int BN, int WM, int WN, bool DEEP = false>
@@ -274,27 +344,70 @@ int launch(const ConvParams& p, hipStream_t st) {
     const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, DEEP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, DEEP, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, DEEP>), dim3(tiles_m * q.tiles_n), dim3(64 * (BM / WM) * (BN / WN)), lds,
-                       st, q);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, DEEP, false>), dim3(tiles_m * q.tiles_n),
+                       dim3(64 * (BM / WM) * (BN / WN)), lds, st, q);
     return av2x::check_launch("conv_igemm_f32");
+}
+
+// Stream-K launch: `wgs` persistent workgroups share tiles x steps iterations; then the fix-up.
+template <int BM, int BN, int WM, int WN>
+int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_bytes, hipStream_t st) {
+    const int tiles_m = (p.M + BM - 1) / BM;
+    ConvParams q = p;
+    q.tiles_n = p.CoutP / BN;
+    const int tiles = tiles_m * q.tiles_n;
+    const long long total = (long long)tiles * p.steps;
+    if (total >= (1ll << 31)) return av2x::fail("av2x_conv2d: stream-K iteration space too large");
+    if (wgs > total) wgs = (int)total;
+    q.sk_total = (int)total;
+    q.sk_per = (int)((total + wgs - 1) / wgs);
+    wgs = (int)((total + q.sk_per - 1) / q.sk_per);
+    q.ws = ws;
+    if (!ws || ws_bytes < 2ull * wgs * BM * BN * sizeof(float))
+        return av2x::fail("av2x_conv2d: stream-K workspace too small (%llu B, need %llu B)", ws_bytes,
+                          2ull * wgs * BM * BN * sizeof(float));
+    const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    constexpr int NTHR = 64 * (BM / WM) * (BN / WN);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true, true>), dim3(wgs), dim3(NTHR), lds, st, q);
+    if (q.sk_per % p.steps != 0)  // some tile is cut
+        hipLaunchKernelGGL((conv_fixup_f32<BM, BN, WM, WN>), dim3(tiles), dim3(NTHR), 0, st, q);
+    return av2x::check_launch("conv_igemm_f32 (stream-K)");
 }
 
 }  // namespace
 
+extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
+                              const float* shift, const float* residual, float* out, float* workspace,
+                              uint64_t workspace_bytes, av2x_stream_t stream);
+
 extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
-                               const float* shift, const float* residual, float* out, av2x_stream_t stream);
+                               const float* shift, const float* residual, float* out, av2x_stream_t stream) {
+    return av2x_conv2d_sk(d, in, w, scale, shift, residual, out, nullptr, 0, stream);
+}
+
+extern "C" uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs) {
+    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x1fff;
+    return (tile & 0x2000) ? 2ull * (unsigned)sk_wgs * bm * bn * sizeof(float) : 0ull;
+}
 
 extern "C" int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
                            const float* shift, float* out, av2x_stream_t stream) {
     return av2x_conv2d_res(d, in, w, scale, shift, nullptr, out, stream);
 }
 
-extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
-                               const float* shift, const float* residual, float* out, av2x_stream_t stream) {
+extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
+                              const float* shift, const float* residual, float* out, float* workspace,
+                              uint64_t workspace_bytes, av2x_stream_t stream) {
     if (!d || !in || !w || !shift || !out) return av2x::fail("av2x_conv2d: null argument");
     if (residual && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: residual only with mode AV2X_CONV");
     if (d->relu < 0 || d->relu > 2) return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU)", d->relu);
@@ -326,6 +439,7 @@ extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const f
     p.cchunks = p.Cin / BK;
     p.steps = p.ks * p.ks * p.cchunks;
     p.tiles_n = 0;
+    p.sk_per = 0; p.sk_total = 0; p.ws = nullptr;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->h * d->w * d->in_ctot * 4ull;
     const unsigned long long w_bytes = (unsigned long long)p.ks * p.ks * p.Cin * p.CoutP * 4ull;
     if (in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31))
@@ -334,7 +448,19 @@ extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const f
     p.w_bytes = (unsigned)w_bytes;
     hipStream_t st = av2x::as_stream(stream);
 
-    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x3fff;
+    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x1fff;
+    if (d->tile & 0x2000) {  // stream-K: sk_wgs persistent workgroups (always the prefetch-2 pipeline)
+        if (d->sk_wgs <= 0) return av2x::fail("av2x_conv2d: stream-K tile needs sk_wgs > 0");
+        if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
+        const bool w8s = (d->tile & 0x8000) != 0;
+        if (w8s && bm == 128 && bn == 128) return launch_sk<128, 128, 64, 32>(p, d->sk_wgs, workspace, workspace_bytes, st);
+        if (w8s && bm == 128 && bn == 64) return launch_sk<128, 64, 32, 32>(p, d->sk_wgs, workspace, workspace_bytes, st);
+        if (!w8s && bm == 128 && bn == 128) return launch_sk<128, 128, 64, 64>(p, d->sk_wgs, workspace, workspace_bytes, st);
+        if (!w8s && bm == 128 && bn == 64) return launch_sk<128, 64, 64, 32>(p, d->sk_wgs, workspace, workspace_bytes, st);
+        if (!w8s && bm == 64 && bn == 64) return launch_sk<64, 64, 32, 32>(p, d->sk_wgs, workspace, workspace_bytes, st);
+        if (!w8s && bm == 64 && bn == 128) return launch_sk<64, 128, 32, 64>(p, d->sk_wgs, workspace, workspace_bytes, st);
+        return av2x::fail("av2x_conv2d: unsupported stream-K tile %dx%d", bm, bn);
+    }
     const bool w8 = (d->tile & 0x8000) != 0;    // 8-wave (512-thread) variant of the same tile
     const bool deep = (d->tile & 0x4000) != 0;  // prefetch distance 2 (two register sets)
     if (d->tile == 0) {

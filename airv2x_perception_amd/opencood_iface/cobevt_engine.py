@@ -18,7 +18,7 @@ import torch
 
 from .. import _lib
 from .engine import ConvLayer, Where2ComEngine, _ptr
-from .packing import pack_conv_weight
+from .packing import fold_bn, pack_conv_weight
 
 LN_EPS = 1e-5
 
@@ -29,8 +29,11 @@ class CoBEVTEngine(Where2ComEngine):
         self.sh = args["shrink_header"]
         self.fcfg = {"fully": False}
         self.fax = args["fax_fusion"]
-        if args.get("compression", 0):
-            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        self.compression = int(args.get("compression", 0) or 0)
+        if self.compression:
+            c = self.fax["input_dim"]
+            if c % self.compression or (c // self.compression) % 32:
+                raise NotImplementedError(f"compression {self.compression}: {c}/ratio must be a multiple of 32 channels")
         if not self.fax.get("mask", False):
             raise NotImplementedError("SwapFusionBlock without mask (not the shipped AirV2X config)")
         self.L = int(sum(args["max_cav"].values()))
@@ -45,7 +48,32 @@ class CoBEVTEngine(Where2ComEngine):
         b = sd[bkey].detach().float() if bkey else torch.zeros(w.shape[0])
         return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
 
+    def _load_compressor(self, sd, up, prefix="naive_compressor"):
+        """NaiveCompressor (naive_compress.py:10-36): three Conv3x3(+bias)+BN(eps 1e-3)+ReLU layers; the conv bias
+        is folded into the BN shift.  Layer 0 is the encoder (its C/ratio-channel output is the message a
+        multi-GPU deployment would all-gather), layers 1-2 the decoder."""
+        layers = []
+        for conv, bn in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+            w = sd[f"{prefix}.{conv}.weight"].detach().float()
+            sc, sh = fold_bn(sd, f"{prefix}.{bn}")
+            sh = sh + sd[f"{prefix}.{conv}.bias"].detach().float().cpu() * sc
+            wp, coutp = pack_conv_weight(w)
+            layers.append(ConvLayer(up(wp), up(sc), up(sh), w.shape[1], w.shape[0], coutp, 3, 1, 1, 1))
+        return layers
+
+    def run_compressor(self, x, n, H, W):
+        """x (n,H,W,C) -> encoder -> decoder, result written back into x."""
+        enc, dec0, dec1 = self.compressor
+        msg = self.buf("compress_msg", (n, H, W, enc.cout))
+        self.conv(enc, x, n, H, W, msg)
+        mid = self.buf("compress_mid", (n, H, W, dec0.cout))
+        self.conv(dec0, msg, n, H, W, mid)
+        self.conv(dec1, mid, n, H, W, x)
+        return msg
+
     def _load_fusion(self, sd, up):
+        if self.compression:
+            self.compressor = self._load_compressor(sd, up)
         C, ws, L = self.fax["input_dim"], self.fax["window_size"], self.L
         from ..synth import _relative_position_index
         expect = torch.from_numpy(_relative_position_index(L, ws))
@@ -127,6 +155,8 @@ class CoBEVTEngine(Where2ComEngine):
             _lib.check(self.lib.av2x_fill_zero(_ptr(x[n:]), (self.L - n) * H * W * C * 4, self.stream()), "av2x_fill_zero")
         _, s, H2, W2 = self.trunk(canvas, n, ny, nx, shrink_out=x[:n])
         assert (H2, W2) == (H, W)
+        if self.compression:
+            self.run_compressor(x[:n], n, H, W)
         if trace is not None:
             trace["shrink"] = x[:n].permute(0, 3, 1, 2).clone()
         fused = self.fax_encoder(x, n, H, W, trace)

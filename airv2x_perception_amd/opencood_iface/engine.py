@@ -21,6 +21,7 @@ airv2x_where2com.py:117-179 + where2comm_fuse.py:198-263):
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import byref, c_float, c_void_p
 
 import torch
@@ -84,8 +85,13 @@ class Where2ComEngine:
         self.ws = {}
         self.weights_ready = False
         self.conv_tile = 0          # 0 = autotune / pick_tile(); else forced BM<<16|BN (tests / tuning)
+        self.conv_sk_wgs = 0        # persistent workgroups when conv_tile carries the stream-K flag 0x2000
         self.autotune = True        # time the candidate tiles once per distinct conv shape, keep the fastest
         self.tile_cache = {}
+        # stream-K candidates in the autotune set: faster on layers whose tile count does not fill the chip,
+        # but the K-split changes the fp32 summation order (<= ~1e-5 relative), so results then depend on
+        # the tuning outcome / agent count.  False = every candidate is bit-identical (reproducible mode).
+        self.stream_k = os.environ.get("AV2X_STREAM_K", "1") != "0"
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
@@ -111,7 +117,7 @@ class Where2ComEngine:
                   "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready"):
             setattr(other, k, getattr(self, k))
         other.tile_cache = self.tile_cache
-        other.autotune, other.conv_tile = self.autotune, self.conv_tile
+        other.autotune, other.conv_tile, other.stream_k = self.autotune, self.conv_tile, self.stream_k
         return other
 
     def graph_active(self):
@@ -233,15 +239,17 @@ class Where2ComEngine:
         d.out_ctot = out_ctot if out_ctot is not None else L.cout
         d.out_coff = out_coff
         d.ks, d.stride, d.pad, d.relu, d.mode, d.up = L.ks, L.stride, L.pad, L.relu, L.mode, L.up
+        d.sk_wgs = 0
         if self.conv_tile:
             d.tile = self.conv_tile
+            d.sk_wgs = self.conv_sk_wgs if (d.tile & 0x2000) else 0
         elif self.autotune:
-            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride)
+            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, self.stream_k)
             t = self.tile_cache.get(key)
             if t is None:
                 t = self._tune(d, x, L, out)
                 self.tile_cache[key] = t
-            d.tile = t
+            d.tile, d.sk_wgs = t
         else:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
             d.tile = (bm << 16) | bn
@@ -249,13 +257,22 @@ class Where2ComEngine:
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(self.lib.av2x_conv2d_res(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
-                                            _ptr(out), self.stream()), "av2x_conv2d")
+        if d.tile & 0x2000:
+            ws = self.sk_workspace()
+            _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
+                                               _ptr(out), _ptr(ws), ws.numel() * 4, self.stream()), "av2x_conv2d_sk")
+        else:
+            _lib.check(self.lib.av2x_conv2d_res(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
+                                                _ptr(out), self.stream()), "av2x_conv2d")
         if self.profile is not None:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x3fff))
+            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x1fff))
+            if bn & 0x2000:  # launch_sk(): equal iteration ranges, then the number of non-empty ones
+                total = wgs * L.ks * L.ks * (L.cin // 32)
+                per = -(-total // min(d.sk_wgs, total))
+                wgs = -(-total // per)
             self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1, wgs,
                                  (n * d.ho * d.wo, L.cin, ncols, L.ks, L.stride)))
         return ho, wo
@@ -265,32 +282,51 @@ class Where2ComEngine:
                        (128, 128 | 0x4000), (128, 64 | 0x4000), (64, 64 | 0x4000), (64, 128 | 0x4000),
                        (128, 128 | 0xc000), (128, 64 | 0xc000), (128, 32))
 
+    # stream-K candidates (BM, BN | flags | 0x2000, persistent workgroups); tools/sk_bench.py sweep
+    SK_CANDIDATES = ((128, 64 | 0xe000, 768), (128, 64 | 0xe000, 512), (128, 128 | 0xe000, 256), (128, 128 | 0xe000, 512),
+                     (64, 64 | 0x6000, 1024))
+    SK_MAX_TILES = 1200   # only layers with at most this many 128x64 tiles are tried with stream-K
+
+    def sk_workspace(self):
+        """Partial-accumulator scratch of av2x_conv2d_sk, sized for the largest stream-K candidate."""
+        need = max(int(self.lib.av2x_conv2d_sk_workspace_bytes((bm << 16) | bn, g)) for bm, bn, g in self.SK_CANDIDATES)
+        need = max(need, int(self.lib.av2x_conv2d_sk_workspace_bytes(self.conv_tile, self.conv_sk_wgs)) if self.conv_tile else 0)
+        return self.buf("sk_ws", (need // 4,))
+
     def _tune(self, d, x, L, out):
         """Pick the fastest workgroup tile for this conv shape (all tiles give bit-identical results:
         the K order of every output element does not depend on the tile).  Runs outside graph capture."""
         if torch.cuda.is_current_stream_capturing():
             bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
-            return (bm << 16) | bn
+            return (bm << 16) | bn, 0
         best, best_t = None, float("inf")
         # tune into a scratch output: `out` may alias the input / residual (in-place transformer updates)
         ho = d.ho * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         wo = d.wo * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         scratch = torch.empty(d.n * ho * wo * max(d.out_ctot, L.cout), dtype=torch.float32, device=self.device)
-        args = (_ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(scratch), self.stream())
-        for bm, bn in self.TILE_CANDIDATES:
-            if L.coutp % (bn & 0x3fff) or ((bn & 0x3fff) == 32 and L.coutp != 32):
+        cands = [(bm, bn, 0) for bm, bn in self.TILE_CANDIDATES]
+        if self.stream_k and -(-(d.n * d.ho * d.wo) // 128) * (L.coutp // 64 if L.coutp % 64 == 0 else 1 << 30) <= self.SK_MAX_TILES:
+            cands += list(self.SK_CANDIDATES)
+        ws = self.sk_workspace()
+        st = self.stream()
+        for bm, bn, g in cands:
+            if L.coutp % (bn & 0x1fff) or ((bn & 0x1fff) == 32 and L.coutp != 32):
                 continue
-            d.tile = (bm << 16) | bn
-            _lib.check(self.lib.av2x_conv2d(byref(d), *args), "av2x_conv2d")  # warm-up (module load, L2)
+            d.tile, d.sk_wgs = (bm << 16) | bn, g
+            call = lambda: _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), None,
+                                                              _ptr(scratch), _ptr(ws), ws.numel() * 4, st), "av2x_conv2d")
+            call()  # warm-up (module load, L2)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                _lib.check(self.lib.av2x_conv2d(byref(d), *args), "av2x_conv2d")
+                call()
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
+            if g:
+                t *= 1.03  # prefer the bit-reproducible data-parallel schedule unless stream-K is clearly faster
             if t < best_t:
-                best, best_t = d.tile, t
+                best, best_t = (d.tile, g), t
         return best
 
     def run_block(self, i, x, n, h, w, tag, out=None):
@@ -678,7 +714,9 @@ class FramePipeline:
     """Throughput mode: ``depth`` independent frames in flight, each on its own HIP stream with its own
     workspaces (weights shared).  Every layer launch ends in a partially filled last round of
     workgroups and the ego stage of a frame is a single-image tail; a second frame's kernels fill those
-    gaps.  Per-frame results are bit-identical to the sequential schedule; per-frame latency grows."""
+    gaps.  Per-frame results are bit-identical to the sequential data-parallel schedule; per-frame latency
+    grows.  Stream-K is switched off while a frame is submitted here: its persistent workgroups fill the
+    chip on their own, so overlapping frames gains nothing on top (measured: -0.8 % vs +5 % single-stream)."""
 
     def __init__(self, engine, depth=2):
         self.engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
@@ -692,8 +730,14 @@ class FramePipeline:
         self.i += 1
         s = self.streams[k]
         s.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
+        eng = self.engines[k]
+        saved, eng.stream_k = eng.stream_k, eng.stream_k and len(self.engines) == 1
+        try:
+            with torch.cuda.stream(s):
+                out = eng.forward(data_dict, **kw)
+        finally:
+            eng.stream_k = saved
         with torch.cuda.stream(s):
-            out = self.engines[k].forward(data_dict, **kw)
             ev = torch.cuda.Event()
             ev.record(s)
         self.events[k] = ev

@@ -450,7 +450,7 @@ def data_dict_to(dd, device):
 # the top level of model.args and the fusion is the fused-axial-attention encoder
 # --------------------------------------------------------------------------
 
-def default_hypes_cobevt(lidar_range=None, max_cav=(3, 2, 2)):
+def default_hypes_cobevt(lidar_range=None, max_cav=(3, 2, 2), compression=0):
     hy = default_hypes(lidar_range, max_cav)
     a = hy["model"]["args"]
     mf = a.pop("modality_fusion")
@@ -458,7 +458,7 @@ def default_hypes_cobevt(lidar_range=None, max_cav=(3, 2, 2)):
     a.pop("ego_type", None)
     a["base_bev_backbone"] = mf["base_bev_backbone"]
     a["shrink_header"] = mf["shrink_header"]
-    a["compression"] = 0
+    a["compression"] = int(compression)
     a["fax_fusion"] = {"input_dim": 256, "mlp_dim": 256, "window_size": 4, "dim_head": 32, "drop_out": 0.1,
                        "depth": 3, "mask": True, "agent_size": int(sum(max_cav))}
     hy["model"]["core_method"] = "airv2x_cobevt"
@@ -477,6 +477,21 @@ def _relative_position_index(L, ws):
     return rel.sum(-1).astype(np.int64)
 
 
+def compressor_param_spec(c, ratio, prefix="naive_compressor"):
+    """NaiveCompressor(c, ratio) state_dict manifest (models/common_modules/naive_compress.py:10-36):
+    encoder Conv3x3 c -> c/ratio + BN, decoder Conv3x3 c/ratio -> c + BN, Conv3x3 c -> c + BN (convs have biases)."""
+    if not ratio:
+        return []
+    m = c // ratio
+    spec = []
+    for name, co, ci in ((f"{prefix}.encoder.0", m, c), (f"{prefix}.decoder.0", c, m), (f"{prefix}.decoder.3", c, c)):
+        bn = name[:-1] + str(int(name[-1]) + 1)
+        spec += [(name + ".weight", (co, ci, 3, 3), "conv"), (name + ".bias", (co,), "bias"),
+                 (bn + ".weight", (co,), "bn_w"), (bn + ".bias", (co,), "bn_b"), (bn + ".running_mean", (co,), "bn_m"),
+                 (bn + ".running_var", (co,), "bn_v"), (bn + ".num_batches_tracked", (), "count")]
+    return spec
+
+
 def cobevt_param_spec(args):
     """Ordered (key, shape, kind) manifest of Airv2xCoBEVT's state_dict (236 tensors at L = 7;
     checked against the reference's own state_dict by tools/gen_golden.py)."""
@@ -492,7 +507,7 @@ def cobevt_param_spec(args):
     C, M, ws, L = fax["input_dim"], fax["mlp_dim"], fax["window_size"], fax["agent_size"]
     nh = C // fax["dim_head"]
     T = L * ws * ws
-    spec = list(trunk)
+    spec = list(trunk) + compressor_param_spec(C, args.get("compression", 0))
     for i in range(fax["depth"]):
         for part in ("window", "grid"):
             p = f"fusion_net.layers.{i}.{part}_attention"

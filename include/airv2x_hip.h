@@ -88,7 +88,9 @@ typedef struct av2x_conv_desc {
     int32_t relu;              /* activation after the affine: 0 none, 1 ReLU, 2 exact GELU */
     int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
     int32_t up;                /* DECONV: kernel == stride                                */
-    int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2) */
+    int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2)
+                                  | 0x2000 (stream-K, av2x_conv2d_sk only)                */
+    int32_t sk_wgs;            /* stream-K: number of persistent workgroups (else ignored) */
 } av2x_conv_desc;
 
 int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
@@ -98,6 +100,16 @@ int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const 
  * PreNormResidual / FeedForward, models/cobevt_modules/base_transformer.py:6-38. */
 int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
                     const float* shift, const float* residual, float* out, av2x_stream_t stream);
+/* same, with a stream-K schedule when d->tile has 0x2000 set: d->sk_wgs persistent workgroups split the
+ * (output tiles x K-steps) iteration space evenly, so a layer whose tile count does not fill the 256 CUs
+ * a whole number of times has no idle tail.  Tiles cut between workgroups are finished by a second
+ * (fix-up) launch that adds the partial accumulators from `workspace` in ascending K order, so results are
+ * deterministic; they differ from the non-stream-K schedule by fp32 summation order only.
+ * workspace: device scratch of av2x_conv2d_sk_workspace_bytes(tile, sk_wgs) bytes (unused without 0x2000). */
+int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
+                   const float* shift, const float* residual, float* out, float* workspace,
+                   uint64_t workspace_bytes, av2x_stream_t stream);
+uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs);
 
 /* ------------------------------------------------------------------------------------
  * Where2Comm communication mask.  Replaces Communication.forward, eval branch

@@ -113,10 +113,12 @@ def swap_fusion_encoder(x, mask, sd, fax, trace=None):
 
 
 def cobevt_forward(data_dict, sd, args, trace=None):
-    """models/airv2x_cobevt.py:112-156 (det task, compression 0)."""
+    """models/airv2x_cobevt.py:112-156 (det task; NaiveCompressor :121-123 when args["compression"] > 0)."""
     feats, record_len = w2c.extract_features(data_dict, sd, args)
     sf2d, _ = w2c.backbone_forward(feats, sd, args["base_bev_backbone"])
     s = w2c.shrink_conv(sf2d, sd, args["shrink_header"]) if args["shrink_header"]["use"] else sf2d
+    if args.get("compression", 0) > 0:
+        s = w2c.naive_compress(s, sd)
     L = sum(args["max_cav"].values())
     x, mask = regroup(s, record_len, L)
     fused = swap_fusion_encoder(x, mask, sd, args["fax_fusion"], trace)

@@ -145,6 +145,15 @@ def shrink_conv(x, sd, sh_cfg):
 
 
 # ---------------------------------------------------------------- a9: heads
+def naive_compress(x, sd, prefix="naive_compressor"):
+    """NaiveCompressor.forward (models/common_modules/naive_compress.py:38-42): encoder Conv3x3+BN(eps 1e-3)+ReLU,
+    decoder 2 x [Conv3x3+BN+ReLU]; the convolutions carry biases."""
+    for conv, bn in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+        x = F.conv2d(x, sd[f"{prefix}.{conv}.weight"], sd[f"{prefix}.{conv}.bias"], padding=1)
+        x = F.relu(_bn(x, sd, f"{prefix}.{bn}"))
+    return x
+
+
 def head(x, sd, name):
     """airv2x_where2com.py:60-69: 1x1 conv with bias."""
     return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"])

@@ -12,7 +12,8 @@ from tests.helpers import assert_close, load_fixture, sample
 def _case(fx):
     rng = [float(v) for v in fx["lidar_range"]]
     types = [str(t) for t in fx["types"]]
-    hy = synth.default_hypes_cobevt(rng, tuple(int(v) for v in fx["max_cav"]))
+    hy = synth.default_hypes_cobevt(rng, tuple(int(v) for v in fx["max_cav"]),
+                                    compression=int(fx["compression"]) if "compression" in fx else 0)
     args = hy["model"]["args"]
     spec = synth.cobevt_param_spec(args)
     assert [k for k, _, _ in spec] == [str(k) for k in fx["spec_keys"]]
@@ -25,8 +26,9 @@ def _case(fx):
     return hy, args, sd, synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
 
 
-def test_oracle_matches_reference_golden():
-    fx = load_fixture("cobevt_small_n3")
+@pytest.mark.parametrize("name", ["cobevt_small_n3", "cobevt_small_n2_c4"])
+def test_oracle_matches_reference_golden(name):
+    fx = load_fixture(name)
     hy, args, sd, dd = _case(fx)
     tr = {}
     with torch.no_grad():
@@ -37,7 +39,10 @@ def test_oracle_matches_reference_golden():
     for i in range(3):
         assert_close(sample(tr[f"fax_block{i}"], bs), fx[f"fax_block{i}"], 1e-5, 1e-5, f"fax_block{i}")
     assert_close(sample(tr["fused"], 2), fx["fused"], 1e-5, 1e-5, "fused")
-    assert tr["mask"].tolist() == [[1, 1, 1, 0, 0, 0, 0]]
+    nv = len(fx["types"])
+    assert tr["mask"].tolist() == [[1] * nv + [0] * (7 - nv)]
+    if name.endswith("_c4"):   # message compression (naive_compress.py): 3 x (7 tensors) more in the state_dict
+        assert sum(k.startswith("naive_compressor.") for k in sd) == 21 and sd["naive_compressor.encoder.0.weight"].shape == (64, 256, 3, 3)
 
 
 def test_partition_roundtrip_and_index():
@@ -57,9 +62,10 @@ def test_partition_roundtrip_and_index():
 
 
 @pytest.mark.gpu
-def test_gpu_forward_matches_golden_and_oracle():
+@pytest.mark.parametrize("name", ["cobevt_small_n3", "cobevt_small_n2_c4"])
+def test_gpu_forward_matches_golden_and_oracle(name):
     from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
-    fx = load_fixture("cobevt_small_n3")
+    fx = load_fixture(name)
     hy, args, sd, dd = _case(fx)
     model = Airv2xCoBEVT(args)
     assert list(model.state_dict().keys()) == [str(k) for k in fx["spec_keys"]]

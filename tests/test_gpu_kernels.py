@@ -129,6 +129,70 @@ def test_deconv_matches_torch_cpu(lib, up, cin):
     assert_close(got, ref, 1e-4, 1e-4, f"deconv up={up}")
 
 
+SK_CASES = [
+    # n, h, w, cin, cout, ks, stride, mode/up, tile, sk_wgs
+    (2, 25, 44, 256, 256, 3, 1, 0, (128 << 16) | 64 | 0xe000, 96),      # every tile cut in ~2
+    (2, 25, 44, 256, 256, 3, 1, 0, (128 << 16) | 128 | 0xe000, 37),     # uneven ranges, tail + whole + head
+    (1, 25, 44, 128, 128, 3, 1, 0, (64 << 16) | 64 | 0x6000, 1000),     # ranges shorter than a tile (middle segments)
+    (3, 13, 21, 128, 256, 3, 2, 0, (64 << 16) | 128 | 0x6000, 64),      # stride 2, ragged M
+    (1, 9, 14, 64, 64, 3, 1, 0, (128 << 16) | 64 | 0x6000, 100000),     # more workgroups than iterations
+    (2, 12, 20, 256, 256, 3, 1, 0, (128 << 16) | 128 | 0x6000, 4),      # ranges = whole tiles only (no fix-up)
+    (2, 7, 11, 128, 128, 1, 1, 2, (128 << 16) | 64 | 0xe000, 24),       # deconv up=2 scatter epilogue
+]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_conv_stream_k_matches_torch_and_data_parallel(lib, case):
+    """av2x_conv2d_sk: stream-K schedule + fix-up == torch fp32 (1e-4) and == the data-parallel schedule up to
+    summation order; residual + GELU go through the fix-up epilogue as well."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, pack_deconv_weight
+    n, h, w, cin, cout, ks, stride, up, tile, wgs = case
+    g = torch.Generator().manual_seed(99 + cin + wgs % 97)
+    x = torch.randn(n, cin, h, w, generator=g)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    pad = 1 if ks == 3 else 0
+    if up:
+        wt = torch.randn(cin, cout, up, up, generator=g) / np.sqrt(cin)
+        ref = F.conv_transpose2d(x, wt, None, stride=up) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        wp, coutp = pack_deconv_weight(wt)
+        mode = 1
+    else:
+        wt = torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks)
+        ref = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        wp, coutp = pack_conv_weight(wt)
+        mode = 0
+    ho, wo = ref.shape[2], ref.shape[3]
+    res = torch.randn(n, ho, wo, cout, generator=g)
+    ref = F.gelu(ref) + res.permute(0, 3, 1, 2)
+    xd, wd, sc, sh, rd = x.permute(0, 2, 3, 1).contiguous().cuda(), wp.cuda(), scale.cuda(), shift.cuda(), res.cuda()
+    d = _lib.ConvDesc()
+    d.n, d.h, d.w, d.cin, d.in_ctot, d.in_coff = n, h, w, cin, cin, 0
+    d.ho, d.wo = (h, w) if up else (ho, wo)
+    d.cout, d.coutp, d.out_ctot, d.out_coff = cout, coutp, cout, 0
+    d.ks, d.stride, d.pad, d.relu, d.mode, d.up = (1, 1, 0, 2, 1, up) if up else (ks, stride, pad, 2, 0, 1)
+    outs = []
+    for t, k in ((tile, wgs), (tile & ~0x2000, 0)):
+        d.tile, d.sk_wgs = t, k
+        nbytes = int(lib.av2x_conv2d_sk_workspace_bytes(t, min(k, 4096)))
+        ws = torch.empty(max(nbytes // 4, 1), device="cuda")
+        out = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+        if mode == 1:   # residual is rejected for deconv: add it on the host
+            _lib.check(lib.av2x_conv2d_sk(byref(d), _p(xd), _p(wd), _p(sc), _p(sh), _p(None), _p(out), _p(ws), nbytes,
+                                          _stream()), "conv_sk")
+            out = out + rd
+        else:
+            _lib.check(lib.av2x_conv2d_sk(byref(d), _p(xd), _p(wd), _p(sc), _p(sh), _p(rd), _p(out), _p(ws), nbytes,
+                                          _stream()), "conv_sk")
+        outs.append(out.permute(0, 3, 1, 2).cpu())
+    assert_close(outs[0], ref, 1e-4, 1e-4, f"stream-K {case}")
+    assert_close(outs[0], outs[1], 2e-5, 2e-5, f"stream-K vs data-parallel {case}")
+    # a too-small workspace is rejected, not overrun
+    d.tile, d.sk_wgs = tile, wgs
+    rc = lib.av2x_conv2d_sk(byref(d), _p(xd), _p(wd), _p(sc), _p(sh), _p(None), _p(out), _p(ws), 16, _stream())
+    assert rc != 0 and b"workspace" in lib.av2x_last_error()
+
+
 def test_conv_rejects_bad_arguments(lib):
     from airv2x_perception_amd import _lib
     d = _lib.ConvDesc()

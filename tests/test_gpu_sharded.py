@@ -20,6 +20,7 @@ def test_two_emulated_ranks_equal_single_gpu_forward():
     model.load_state_dict(sd)
     model = model.to("cuda").eval()
     eng = model.engine()
+    eng.stream_k = False   # bit-reproducible schedules only (stream-K splits K differently per agent count)
     ref = eng.forward(dd, sync_comm_rate=True)
     sends, stats, meta = [], None, None
     for r, mine in enumerate(partition_agents(4, 2)):

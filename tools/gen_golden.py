@@ -265,7 +265,7 @@ def load_ref_hypes_cobevt(lidar_range):
     return h
 
 
-def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride):
+def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride, compression=0):
     """Airv2xCoBEVT (fused axial attention) on the real reference vs oracle/cobevt_oracle.py."""
     from airv2x_perception_amd import synth
     from oracle import cobevt_oracle as cob
@@ -273,7 +273,8 @@ def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride):
     from opencood.models.airv2x_cobevt import Airv2xCoBEVT
 
     hy_ref = load_ref_hypes_cobevt(lidar_range)
-    hy = synth.default_hypes_cobevt(lidar_range)
+    hy_ref["model"]["args"]["compression"] = compression
+    hy = synth.default_hypes_cobevt(lidar_range, compression=compression)
     a_ref = {k: v for k, v in hy_ref["model"]["args"].items()}
     check_hypes(a_ref, {k: v for k, v in hy["model"]["args"].items() if k != "fax_fusion"})
     args = hy["model"]["args"]
@@ -312,7 +313,8 @@ def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride):
     fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types),
           "n_points": np.int64(n_points), "cloud": np.asarray("uniform"), "sample_stride": np.int64(1),
           "big_stride": np.int64(big_stride), "spec_keys": np.asarray([k for k, _, _ in spec]),
-          "max_cav": np.asarray([args["max_cav"][t] for t in synth.AGENT_TYPES], np.int64)}
+          "max_cav": np.asarray([args["max_cav"][t] for t in synth.AGENT_TYPES], np.int64),
+          "compression": np.int64(compression)}
     for i, (v, c, n) in enumerate(voxd):
         fx[f"vox_coords_{i}"], fx[f"vox_num_{i}"] = c, n
     for k in ("psm", "rm", "obj"):
@@ -425,6 +427,7 @@ def main():
     run_case("w2c_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 5, 20)
     run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
     run_v2xvit_case("v2xvit_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4)
+    run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
 
 
 if __name__ == "__main__":
@@ -433,6 +436,11 @@ if __name__ == "__main__":
         import_reference()
         torch.set_num_threads(8)
         run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
+    elif len(sys.argv) > 1 and sys.argv[1] == "cobevt_c4":
+        os.chdir(tempfile.mkdtemp())
+        import_reference()
+        torch.set_num_threads(8)
+        run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
     elif len(sys.argv) > 1 and sys.argv[1] == "v2xvit":
         os.chdir(tempfile.mkdtemp())
         import_reference()

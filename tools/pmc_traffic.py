@@ -17,16 +17,17 @@ from collections import defaultdict
 def rows(d):
     f = glob.glob(d.rstrip("/") + "/*/*_results.db") + glob.glob(d.rstrip("/") + "/*_results.db")
     c = sqlite3.connect(f[0])
-    return c.execute("select kernel_name, grid_size, workgroup_size, counter_name, value from counters_collection").fetchall()
+    return c.execute("select kernel_name, grid_size, workgroup_size, counter_name, value from counters_collection "
+                     "order by dispatch_id").fetchall()
 
 
 def conv_key(name):
-    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?>", name)
     if not m:
         return None
     bm, bn, wm, wn = (int(m.group(i)) for i in range(1, 5))
     waves = (bm // wm) * (bn // wn)
-    return f"{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if m.group(5) == 'true' else ''}"
+    return f"{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if m.group(5) == 'true' else ''}{'sk' if m.group(6) == 'true' else ''}"
 
 
 def calib(d, counter, kernel_sub, known_bytes):
@@ -55,10 +56,17 @@ def main():
                "note": "true bytes / (counter KiB x 1024) on tools/pmc_calib.py (576 MiB streaming copy / sum / fill)"}
     acc = defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
     for d in (a.fetch, a.write):
+        last = None  # the stream-K launch a following conv_fixup_f32 dispatch belongs to
         for name, grid, wg, ctr, val in rows(d):
+            if ctr not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            if "conv_fixup_f32" in name and last is not None:
+                last[-1] += val   # bench.py times (and counts) the GEMM + its fix-up as one launch
+                continue
             k = conv_key(name)
-            if k and ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            if k:
                 acc[(k, grid // wg)][ctr].append(val)
+                last = acc[(k, grid // wg)][ctr] if k.endswith("sk") else None
     per = defaultdict(dict)
     for (k, wgs), v in sorted(acc.items()):
         if not v["FETCH_SIZE"] or not v["WRITE_SIZE"]:
