@@ -40,6 +40,8 @@ SIGNATURES = {
     "av2x_conv2d_sk": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_uint64, c_void_p]),
     "av2x_conv2d_sk_workspace_bytes": (c_uint64, [c_int32, c_int32]),
+    "av2x_eval_tp_fp": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
     "av2x_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "av2x_fax_attention": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_void_p]),
@@ -59,6 +61,9 @@ SIGNATURES = {
     "av2x_apply_mask": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_pixel_attn_fuse": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_count_nonzero": (c_int32, [c_void_p, c_uint64, c_void_p, c_void_p]),
+    "av2x_prepare_points_workspace_bytes": (c_uint64, [c_int32]),
+    "av2x_prepare_points": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "av2x_voxelize_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
     "av2x_voxelize": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),

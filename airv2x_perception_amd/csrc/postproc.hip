@@ -268,7 +268,74 @@ __global__ __launch_bounds__(1024) void pp_final(const float* __restrict__ boxes
     if (threadIdx.x == 0) nout[0] = tot;
 }
 
+// ---- AP evaluation (utils/eval_utils_opv2v.py:41-97) --------------------------------------------
+// iou[d][g] = fp32(IoU(det[order[d]], gt[g])) (common_utils.compute_iou :150-171 returns float32)
+__global__ void eval_iou_kernel(const float* __restrict__ det, const int* __restrict__ order, int D,
+                                const float* __restrict__ gt, int G, float* __restrict__ iou) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * G) return;
+    const int d = i / G, g = i - d * G;
+    iou[i] = (float)quad_iou(det + (size_t)order[d] * 24, gt + (size_t)g * 24);
+}
+
+// Greedy matching in score order: a detection is a TP when its best IoU over the GT boxes still
+// unmatched is >= thr (`np.max(ious) < iou_thresh` -> FP, :76-79); the matched GT is the first arg-max
+// (np.argmax, :84) and leaves the list (:85).  One workgroup; the loop over detections is sequential.
+__global__ __launch_bounds__(256) void eval_match_kernel(const float* __restrict__ iou, int D, int G, float thr,
+                                                         int* __restrict__ tp, int* __restrict__ matched_gt) {
+    extern __shared__ unsigned char alive[];  // [G]
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    for (int g = threadIdx.x; g < G; g += 256) alive[g] = 1;
+    __syncthreads();
+    for (int d = 0; d < D; ++d) {
+        float best = -1.f;
+        int arg = 0x7fffffff;
+        for (int g = threadIdx.x; g < G; g += 256) {
+            if (!alive[g]) continue;
+            const float v = iou[(size_t)d * G + g];
+            if (v > best) { best = v; arg = g; }  // ascending g inside a thread: first maximum wins
+        }
+        bv[threadIdx.x] = best; bi[threadIdx.x] = arg;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                const float ov = bv[threadIdx.x + s];
+                const int oi = bi[threadIdx.x + s];
+                if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const bool hit = bi[0] != 0x7fffffff && !(bv[0] < thr);
+            tp[d] = hit ? 1 : 0;
+            matched_gt[d] = hit ? bi[0] : -1;
+            if (hit) alive[bi[0]] = 0;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+extern "C" int av2x_eval_tp_fp(const float* det_corners, const int32_t* order, int32_t n_det, const float* gt_corners,
+                               int32_t n_gt, float iou_thresh, float* iou_ws, int32_t* tp, int32_t* matched_gt,
+                               av2x_stream_t stream) {
+    if (n_det < 0 || n_gt < 0) return av2x::fail("av2x_eval_tp_fp: negative count");
+    if (n_det == 0) return 0;
+    if (!det_corners || !order || !tp || !matched_gt || (n_gt > 0 && (!gt_corners || !iou_ws)))
+        return av2x::fail("av2x_eval_tp_fp: null argument");
+    if (n_gt > 60000) return av2x::fail("av2x_eval_tp_fp: more than 60000 ground-truth boxes");
+    hipStream_t st = av2x::as_stream(stream);
+    const long long cells = (long long)n_det * n_gt;
+    if (cells >= (1ll << 31)) return av2x::fail("av2x_eval_tp_fp: IoU matrix too large");
+    if (n_gt > 0)
+        hipLaunchKernelGGL(eval_iou_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, det_corners, order, n_det,
+                           gt_corners, n_gt, iou_ws);
+    hipLaunchKernelGGL(eval_match_kernel, dim3(1), dim3(256), (size_t)(n_gt > 0 ? n_gt : 1), st, iou_ws, n_det, n_gt,
+                       iou_thresh, tp, matched_gt);
+    return av2x::check_launch("av2x_eval_tp_fp");
+}
 
 extern "C" uint64_t av2x_postprocess_workspace_bytes(int32_t h, int32_t w, int32_t a, int32_t top) {
     const uint64_t na = (uint64_t)h * w * a;

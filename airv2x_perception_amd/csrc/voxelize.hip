@@ -98,7 +98,81 @@ __global__ void k_init(int* __restrict__ cnt, int* __restrict__ first, int* __re
     first[c] = 0x7fffffff;
 }
 
+// ---- point preparation -------------------------------------------------------
+struct PrepParams {
+    float T[16];
+    float r[6];
+    int n, project, mask_ego;
+};
+
+// q = points[perm[i]] ; drop ego-box returns (pcd_utils.py:168-190, closed box, sensor frame) ; project with
+// the 4x4 (box_utils.py:1038-1067; torch's fp32 einsum = one multiply then an FMA chain over k, reproduced
+// exactly) ; keep points strictly inside the range (pcd_utils.py:136-165).
+__global__ void prep_flag(const float4* __restrict__ pts, const int* __restrict__ perm, PrepParams p,
+                          float4* __restrict__ tmp, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    float4 q = pts[perm ? perm[i] : i];
+    bool keep = true;
+    if (p.mask_ego) keep = !(q.x >= -1.95f && q.x <= 2.95f && q.y >= -1.1f && q.y <= 1.1f);
+    if (p.project) {
+        float o[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = __fmul_rn(q.x, p.T[j * 4 + 0]);
+            acc = __fmaf_rn(q.y, p.T[j * 4 + 1], acc);
+            acc = __fmaf_rn(q.z, p.T[j * 4 + 2], acc);
+            acc = __fmaf_rn(1.0f, p.T[j * 4 + 3], acc);
+            o[j] = acc;
+        }
+        q.x = o[0]; q.y = o[1]; q.z = o[2];
+    }
+    keep = keep && q.x > p.r[0] && q.x < p.r[3] && q.y > p.r[1] && q.y < p.r[4] && q.z > p.r[2] && q.z < p.r[5];
+    tmp[i] = q;
+    flag[i] = keep ? 1 : 0;
+}
+
+__global__ __launch_bounds__(1024) void prep_scan(const int* __restrict__ flag, int n, int* __restrict__ offs,
+                                                  int* __restrict__ count) {
+    av2x::block_scan(n, [&](int i) { return flag[i]; }, [&](int i, int e) { offs[i] = e; }, count);
+}
+
+__global__ void prep_emit(const float4* __restrict__ tmp, const int* __restrict__ flag, const int* __restrict__ offs, int n,
+                          float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[offs[i]] = tmp[i];
+}
+
 }  // namespace
+
+extern "C" uint64_t av2x_prepare_points_workspace_bytes(int32_t n_points) {
+    return (uint64_t)(n_points > 0 ? n_points : 0) * (sizeof(float4) + 2 * sizeof(int)) + 16;
+}
+
+extern "C" int av2x_prepare_points(const float* points, const int32_t* perm, int32_t n_points, const float* transform16,
+                                   const float* range6, int32_t mask_ego, void* workspace, float* out, int32_t* count,
+                                   av2x_stream_t stream) {
+    if (!range6 || !count) return av2x::fail("av2x_prepare_points: null argument");
+    if (n_points < 0) return av2x::fail("av2x_prepare_points: negative point count");
+    hipStream_t st = av2x::as_stream(stream);
+    if (n_points == 0) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int), st);
+        return e == hipSuccess ? 0 : av2x::fail("av2x_prepare_points: memset: %s", hipGetErrorString(e));
+    }
+    if (!points || !workspace || !out) return av2x::fail("av2x_prepare_points: null argument");
+    PrepParams p;
+    p.n = n_points; p.project = transform16 ? 1 : 0; p.mask_ego = mask_ego ? 1 : 0;
+    for (int i = 0; i < 16; ++i) p.T[i] = transform16 ? transform16[i] : 0.f;
+    for (int i = 0; i < 6; ++i) p.r[i] = range6[i];
+    float4* tmp = reinterpret_cast<float4*>(workspace);
+    int* flag = reinterpret_cast<int*>(tmp + n_points);
+    int* offs = flag + n_points;
+    const dim3 g((n_points + 255) / 256), b(256);
+    hipLaunchKernelGGL(prep_flag, g, b, 0, st, reinterpret_cast<const float4*>(points), perm, p, tmp, flag);
+    hipLaunchKernelGGL(prep_scan, dim3(1), dim3(1024), 0, st, flag, n_points, offs, count);
+    hipLaunchKernelGGL(prep_emit, g, b, 0, st, tmp, flag, offs, n_points, reinterpret_cast<float4*>(out));
+    return av2x::check_launch("av2x_prepare_points");
+}
 
 extern "C" uint64_t av2x_voxelize_workspace_bytes(int32_t n_points, int32_t nx, int32_t ny, int32_t nz) {
     const uint64_t ncell = (uint64_t)nx * ny * nz;

@@ -17,6 +17,32 @@ import torch
 from .. import _lib
 
 
+def prepare_points(points, lidar_range, transformation_matrix=None, mask_ego=True, perm=None):
+    """The per-agent point preparation of intermediate_fusion_dataset.py:591-603 on the device (av2x_prepare_points):
+    [shuffle by ``perm``] -> mask_ego_points -> project to the ego frame -> mask_points_by_range.
+    points (P,4) fp32 CUDA tensor; returns the surviving points (P',4), order preserved (one host read of P')."""
+    lib = _lib.load()
+    if points.device.type != "cuda":
+        raise RuntimeError("prepare_points runs on a HIP device only")
+    pts = points.contiguous().float()
+    n = pts.shape[0]
+    dev = pts.device
+    out = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.av2x_prepare_points_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    r6 = (c_float * 6)(*[float(v) for v in lidar_range])
+    t16 = None
+    if transformation_matrix is not None:
+        t16 = (c_float * 16)(*np.asarray(transformation_matrix, dtype=np.float32).reshape(-1).tolist())
+    pm = perm.to(device=dev, dtype=torch.int32).contiguous() if perm is not None else None
+    _lib.check(lib.av2x_prepare_points(c_void_p(pts.data_ptr()), c_void_p(pm.data_ptr()) if pm is not None else None, n,
+                                       ctypes.cast(t16, c_void_p) if t16 is not None else None, ctypes.cast(r6, c_void_p),
+                                       1 if mask_ego else 0, c_void_p(ws.data_ptr()), c_void_p(out.data_ptr()),
+                                       c_void_p(cnt.data_ptr()), c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "av2x_prepare_points")
+    return out[:int(cnt.item())]
+
+
 def voxelize_points(points, lidar_range, voxel_size, max_points=32, max_voxels=70000, range_filter=False):
     """points: (P,4) fp32 CUDA tensor -> (voxels (M,32,4), coords (M,3) i32 zyx, num (M,) i32) on the device.
     Reads M back to the host once (the reference contract has exact-shaped tensors)."""
@@ -25,10 +51,7 @@ def voxelize_points(points, lidar_range, voxel_size, max_points=32, max_voxels=7
         raise RuntimeError("voxelize_points runs on a HIP device only")
     pts = points.contiguous().float()
     if range_filter:
-        r = lidar_range
-        m = ((pts[:, 0] > r[0]) & (pts[:, 0] < r[3]) & (pts[:, 1] > r[1]) & (pts[:, 1] < r[4])
-             & (pts[:, 2] > r[2]) & (pts[:, 2] < r[5]))
-        pts = pts[m].contiguous()
+        pts = prepare_points(pts, lidar_range, None, mask_ego=False)
     n = pts.shape[0]
     if n == 0:
         # dummy points of the reference's empty-cloud branch (sp_voxel_preprocessor.py:80-90)

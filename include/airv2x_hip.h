@@ -147,6 +147,24 @@ int av2x_count_nonzero(const float* x, uint64_t n_elems, unsigned long long* res
                        av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Point preparation ahead of the voxelizer.  Replaces, for one agent's cloud, the numpy / torch sequence of
+ * intermediate_fusion_dataset.py:591-603: shuffle_points (pcd_utils.py:193-197) -> mask_ego_points (:168-190) ->
+ * project_points_by_matrix_torch (box_utils.py:1038-1067, `proj_first: true`) -> mask_points_by_range (:136-165).
+ *   points (n_points,4) f32 device; perm (n_points,) i32 device or NULL: the shuffle permutation (the
+ *   reference draws it from numpy's global RNG; results downstream only depend on it through over-full pillars);
+ *   transform16: HOST row-major 4x4 (NULL = no projection); x' = T[j][0]*x (+fma) T[j][1]*y (+fma) T[j][2]*z (+fma)
+ *   T[j][3], the fp32 evaluation order of torch's einsum on the reference's CPU path (bit-exact);
+ *   range6: HOST {xmin,ymin,zmin,xmax,ymax,zmax}, strict inequalities; mask_ego != 0: drop the closed box
+ *   x in [-1.95, 2.95], y in [-1.1, 1.1] BEFORE the projection;
+ *   workspace: av2x_prepare_points_workspace_bytes(n_points) bytes; out (n_points,4) f32: the surviving points,
+ *   order preserved, compacted to the front; count (1,) i32 device: how many.
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_prepare_points_workspace_bytes(int32_t n_points);
+int av2x_prepare_points(const float* points, const int32_t* perm, int32_t n_points, const float* transform16,
+                        const float* range6, int32_t mask_ego, void* workspace, float* out, int32_t* count,
+                        av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Pillar voxelizer (points -> voxels), deterministic.  Replaces the spconv call behind
  * SpVoxelPreprocessor.preprocess (data_utils/pre_processor/sp_voxel_preprocessor.py:93-110,
  * third-party `spconv.utils.Point2VoxelCPU3d`): c = floor((p - range_min)/voxel) in fp32, voxels
@@ -186,6 +204,21 @@ int av2x_postprocess(const float* psm, const float* rm, const float* obj, const 
                      int32_t order_hwl, int32_t top, void* workspace, float* out_corners,
                      float* out_scores, int32_t* out_labels, float* out_boxes, int32_t* out_index,
                      int32_t* counts, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * AP evaluation: true/false positives of one frame.  Replaces the shapely loop of caluclate_tp_fp
+ * (utils/eval_utils_opv2v.py:41-97; IoU = common_utils.compute_iou :150-171 on convert_format :174-191 polygons).
+ *   det_corners (n_det,8,3) / gt_corners (n_gt,8,3) f32: the first four corners' (x,y) are the BEV quad;
+ *   order (n_det,) i32: detections in descending score order (np.argsort(-score), :69);
+ *   iou_ws (n_det*n_gt,) f32 scratch, on return iou[d][g] of detection order[d] vs gt g;
+ *   tp (n_det,) i32: 1 = matched (fp = 1 - tp), in score order; matched_gt (n_det,) i32: the ORIGINAL index
+ *   of the ground-truth box removed by the match, or -1.
+ * A detection matches when max IoU over the still unmatched GT boxes is >= iou_thresh; ties take the lowest
+ * GT index (np.argmax).  IoU is computed in fp64 (convex clipping) and rounded to fp32 before the compare.
+ * ------------------------------------------------------------------------------------ */
+int av2x_eval_tp_fp(const float* det_corners, const int32_t* order, int32_t n_det, const float* gt_corners,
+                    int32_t n_gt, float iou_thresh, float* iou_ws, int32_t* tp, int32_t* matched_gt,
+                    av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * CoBEVT fused-axial-attention pieces (models/cobevt_modules/swap_fusion_modules.py).

@@ -117,3 +117,34 @@ def mask_ego_points(points):
     p = points
     m = (p[:, 0] >= -1.95) & (p[:, 0] <= 2.95) & (p[:, 1] >= -1.1) & (p[:, 1] <= 1.1)
     return p[np.logical_not(m)]
+
+
+def project_points(points_xyz, transformation_matrix):
+    """utils/box_utils.py:1038-1067 (project_points_by_matrix_torch) in fp32 exactly as torch evaluates the
+    einsum on the reference's CPU path: one rounded product, then fused multiply-adds over k = 1, 2, 3
+    (pinned bit-for-bit by tests/golden/points_small.npz).  float64 holds every fp32 product exactly, so
+    fl32(a*b + c) computed in float64 and rounded once IS the fp32 FMA."""
+    p = np.asarray(points_xyz, np.float32).astype(np.float64)
+    T = np.asarray(transformation_matrix, np.float32).astype(np.float64)
+    out = np.empty((p.shape[0], 3), np.float32)
+    for j in range(3):
+        acc = (p[:, 0] * T[j, 0]).astype(np.float32)
+        acc = (p[:, 1] * T[j, 1] + acc.astype(np.float64)).astype(np.float32)
+        acc = (p[:, 2] * T[j, 2] + acc.astype(np.float64)).astype(np.float32)
+        acc = (T[j, 3] + acc.astype(np.float64)).astype(np.float32)
+        out[:, j] = acc
+    return out
+
+
+def prepare_points(points, lidar_range, transformation_matrix=None, mask_ego=True, perm=None):
+    """datasets/airv2x/intermediate_fusion_dataset.py:591-603: shuffle -> mask_ego_points -> project (proj_first)
+    -> mask_points_by_range.  ``perm`` stands for np.random.permutation (pcd_utils.py:193-197)."""
+    p = np.asarray(points, np.float32)
+    if perm is not None:
+        p = p[np.asarray(perm)]
+    if mask_ego:
+        p = mask_ego_points(p)
+    if transformation_matrix is not None:
+        p = p.copy()
+        p[:, :3] = project_points(p[:, :3], transformation_matrix)
+    return mask_points_by_range(p, lidar_range)

@@ -43,6 +43,9 @@ def import_reference():
     _stub("open3d")
     _stub("more_itertools", unique_everseen=lambda it: it)
     _stub("opencood.utils.box_overlaps", bbox_overlaps=None)
+    # pcd_utils.py:14 (file readers only; the point filters used for the a1 fixture are plain numpy)
+    pp = _stub("pypcd")
+    pp.pypcd = _stub("pypcd.pypcd")
     sys.path.insert(0, REF)
 
 
@@ -415,6 +418,125 @@ def run_v2xvit_case(name, lidar_range, types, n_points, seed, max_cav, big_strid
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def _rand_boxes(rng, n, extent=60.0):
+    """n random BEV rectangles as (n,8,3) corner arrays (bottom 4 + top 4 corners, reference corner order)."""
+    c = rng.uniform(-extent, extent, (n, 2))
+    l, w, yaw = rng.uniform(3.0, 5.5, n), rng.uniform(1.5, 2.3, n), rng.uniform(-np.pi, np.pi, n)
+    base = np.array([[0.5, -0.5], [0.5, 0.5], [-0.5, 0.5], [-0.5, -0.5]])
+    out = np.zeros((n, 8, 3), np.float32)
+    for i in range(n):
+        R = np.array([[np.cos(yaw[i]), -np.sin(yaw[i])], [np.sin(yaw[i]), np.cos(yaw[i])]])
+        q = (base * [l[i], w[i]]) @ R.T + c[i]
+        out[i, :4, :2] = q
+        out[i, 4:, :2] = q
+        out[i, :4, 2], out[i, 4:, 2] = -1.0, 0.6
+    return out
+
+
+def points_golden(name="points_small"):
+    """Row a1: the reference's own shuffle / mask_ego_points / project_points_by_matrix_torch /
+    mask_points_by_range sequence (intermediate_fusion_dataset.py:591-603) on a seeded cloud."""
+    from oracle import voxelize_oracle as vox
+    from opencood.utils import box_utils, pcd_utils
+
+    rng = np.random.default_rng(77)
+    P = 6000
+    pts = np.empty((P, 4), np.float32)
+    pts[:, 0] = rng.uniform(-170, 170, P)
+    pts[:, 1] = rng.uniform(-60, 60, P)
+    pts[:, 2] = rng.uniform(-4.5, 2.5, P)
+    pts[:, 3] = rng.uniform(0, 1, P)
+    pts[:400, :2] = rng.uniform(-3.5, 3.5, (400, 2))           # returns on / around the ego body
+    pts[400:408, :2] = [[-1.95, 0], [2.95, 0], [0, -1.1], [0, 1.1], [-1.9500001, 0], [2.9500003, 0], [0, -1.1000001], [0, 1.1000001]]
+    yaw, pitch = 0.31, 0.02
+    Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+    Ry = np.array([[np.cos(pitch), 0, np.sin(pitch)], [0, 1, 0], [-np.sin(pitch), 0, np.cos(pitch)]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry
+    T[:3, 3] = [12.4, -3.7, 0.35]
+    T = T.astype(np.float32)
+    lidar_range = [-140.8, -40, -3, 140.8, 40, 1]
+    perm = rng.permutation(P).astype(np.int32)
+    fx = {"points": pts, "T": T, "lidar_range": np.asarray(lidar_range, np.float64), "perm": perm}
+    for tag, use_perm, ego, proj in (("full", True, True, True), ("noproj", False, True, False), ("rangeonly", False, False, False)):
+        p = pts[perm] if use_perm else pts.copy()      # shuffle_points with a recorded permutation
+        if ego:
+            p = pcd_utils.mask_ego_points(p)
+        if proj:
+            p[:, :3] = box_utils.project_points_by_matrix_torch(p[:, :3], T)
+        p = pcd_utils.mask_points_by_range(p, lidar_range)
+        mine = vox.prepare_points(pts, lidar_range, T if proj else None, ego, perm if use_perm else None)
+        assert p.dtype == np.float32 and np.array_equal(p, mine), f"point-prep oracle differs from the reference ({tag})"
+        fx[f"out_{tag}"] = p
+        print(f"[{name}] {tag}: {P} -> {p.shape[0]} points, oracle == reference bit for bit")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
+
+
+def eval_golden(name="eval_small"):
+    """utils/eval_utils_opv2v.py on seeded frames.  Only the two shapely helpers of common_utils are replaced
+    (convert_format -> (4,2) arrays, compute_iou -> the oracle's fp64 clipping IoU); the sorting, matching,
+    GT removal, cumulative statistics and VOC AP are the reference's own code."""
+    from oracle import eval_oracle as eo
+    from opencood.utils import common_utils
+    from opencood.utils import eval_utils_opv2v as ev
+
+    common_utils.convert_format = lambda boxes: np.array([np.asarray(b[:4, :2], np.float64) for b in boxes] + [None],
+                                                         dtype=object)[:-1]
+    common_utils.compute_iou = lambda box, boxes: eo.iou_row(box, boxes)
+    rng = np.random.default_rng(20240917)
+    frames = []
+    for f in range(6):
+        g = [9, 14, 0, 6, 11, 5][f]
+        gt = _rand_boxes(rng, g)
+        if f == 3:
+            frames.append((None, None, gt))      # no detections at all (det_boxes is None, :62)
+            continue
+        keep = rng.random(g) < 0.8
+        det = gt[keep].copy()
+        det[:, :, :2] += rng.normal(0, [0.05, 0.45, 0.6, 0.1, 0.7, 0.9][f], (det.shape[0], 1, 2)).astype(np.float32)
+        if f == 4:                                 # two detections of the same object: the second must become a FP
+            det = np.concatenate([det, det[:2] + 0.02])
+        det = np.concatenate([det, _rand_boxes(rng, [3, 5, 4, 0, 2, 0][f])])
+        score = rng.uniform(0.2, 1.0, det.shape[0]).astype(np.float32)
+        if f == 5:
+            score[:] = np.sort(score)[::-1]
+        frames.append((det, score, gt))
+    ths = (0.3, 0.5, 0.7)
+    ref = {t: {"tp": [], "fp": [], "gt": 0, "score": []} for t in ths}
+    mine = {t: {"tp": [], "fp": [], "gt": 0, "score": []} for t in ths}
+    fx = {"n_frames": np.int64(len(frames))}
+    for i, (det, score, gt) in enumerate(frames):
+        for t in ths:
+            n0 = len(ref[t]["tp"])
+            ev.caluclate_tp_fp(None if det is None else torch.from_numpy(det), None if det is None else torch.from_numpy(score),
+                               torch.from_numpy(gt), ref, t)
+            eo.caluclate_tp_fp(det, score, gt, mine, t)
+            fx[f"tp_{i}_{int(t * 100)}"] = np.asarray(ref[t]["tp"][n0:], np.int32)
+        fx[f"gt_{i}"] = gt
+        if det is not None:
+            fx[f"det_{i}"], fx[f"score_{i}"] = det, score
+    for t in ths:
+        assert ref[t]["tp"] == mine[t]["tp"] and ref[t]["fp"] == mine[t]["fp"] and ref[t]["gt"] == mine[t]["gt"]
+        assert ref[t]["score"] == mine[t]["score"]
+        for gs in (False, True):
+            import copy
+            a_ref = ev.calculate_ap(copy.deepcopy(ref), t, gs)
+            a_mine = eo.calculate_ap(copy.deepcopy(mine), t, gs)
+            assert a_ref[0] == a_mine[0] and a_ref[1] == a_mine[1] and a_ref[2] == a_mine[2], (t, gs)
+            fx[f"ap_{int(t * 100)}_{int(gs)}"] = np.float64(a_ref[0])
+            if t == 0.5:
+                fx[f"mrec_50_{int(gs)}"], fx[f"mpre_50_{int(gs)}"] = np.asarray(a_ref[1]), np.asarray(a_ref[2])
+        fx[f"gt_total_{int(t * 100)}"] = np.int64(ref[t]["gt"])
+    print(f"[{name}] eval: tp/fp/AP of the oracle == reference;",
+          {f"ap{int(t * 100)}": round(float(fx[f'ap_{int(t * 100)}_0']), 4) for t in ths},
+          {t: (sum(ref[t]["tp"]), sum(ref[t]["fp"]), ref[t]["gt"]) for t in ths})
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
+
+
 def main():
     os.chdir(tempfile.mkdtemp())
     import_reference()
@@ -428,6 +550,8 @@ def main():
     run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
     run_v2xvit_case("v2xvit_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4)
     run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
+    eval_golden()
+    points_golden()
 
 
 if __name__ == "__main__":
@@ -441,6 +565,14 @@ if __name__ == "__main__":
         import_reference()
         torch.set_num_threads(8)
         run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
+    elif len(sys.argv) > 1 and sys.argv[1] == "points":
+        os.chdir(tempfile.mkdtemp())
+        import_reference()
+        points_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "eval":
+        os.chdir(tempfile.mkdtemp())
+        import_reference()
+        eval_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "v2xvit":
         os.chdir(tempfile.mkdtemp())
         import_reference()
