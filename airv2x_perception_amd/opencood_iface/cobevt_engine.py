@@ -135,6 +135,64 @@ class CoBEVTEngine(Where2ComEngine):
         self.conv(self.head_lin, mn, 1, H, W, fused)
         return fused
 
+    def _heads_out(self, fused, H, W):
+        heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, 1, H, W, heads)
+        outs = torch.split(heads, self.head_splits, dim=1)
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        return out
+
+    # ------------------------------------------------------------------ agent sharding
+    @torch.no_grad()
+    def shard_local_stage(self, data_dict_local, has_ego):
+        """Per-rank half: encoders + backbone + shrink header for THIS rank's agents, written straight into the
+        all-gather send buffer (n_loc,H,W,C) -- 36.0 MB per agent at the default grid.  With message compression
+        the buffer holds the NaiveCompressor ENCODER output instead (C/ratio channels: 9.0 MB at ratio 4); the
+        decoder runs on the receiving side.  Replaces regroup()'s in-process concat (fuse_utils.py:13-64)."""
+        record_len, slots = self.frame_layout(data_dict_local)
+        if len(record_len) != 1:
+            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
+        n = record_len[0]
+        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        dims = self.level_dims(ny, nx)
+        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        C = self.fax["input_dim"]
+        cm = self.compressor[0].cout if self.compression else C
+        send = self.buf("shard_send", (n * H * W * cm,))
+        if self.compression:
+            s = self.buf("shard_shrink", (n, H, W, C))
+            self.trunk(canvas, n, ny, nx, shrink_out=s)
+            self.conv(self.compressor[0], s, n, H, W, send.view(n, H, W, cm))
+        else:
+            self.trunk(canvas, n, ny, nx, shrink_out=send.view(n, H, W, C))
+        stats = torch.zeros(2, dtype=torch.int64, device=self.device)
+        return send, stats, {"n_loc": n, "H": H, "W": W, "cm": cm}
+
+    @torch.no_grad()
+    def shard_ego_stage(self, recv, stats, meta, world, trace=None, **_):
+        """Ego half: the gathered buffer is already in frame order (rank-major = agent-major); decode it (if
+        compressed) or copy it into the padded token tensor, then fusion + heads."""
+        n_loc, H, W, cm = meta["n_loc"], meta["H"], meta["W"], meta["cm"]
+        N, C = world * n_loc, self.fax["input_dim"]
+        if recv.numel() != N * H * W * cm:
+            raise ValueError("gathered buffer has the wrong size")
+        if N > self.L:
+            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        x = self.buf("fax_x", (self.L, H, W, C))
+        if N < self.L:
+            _lib.check(self.lib.av2x_fill_zero(_ptr(x[N:]), (self.L - N) * H * W * C * 4, self.stream()), "av2x_fill_zero")
+        msg = recv.view(N, H, W, cm)
+        if self.compression:
+            mid = self.buf("compress_mid", (N, H, W, C))
+            self.conv(self.compressor[1], msg, N, H, W, mid)
+            self.conv(self.compressor[2], mid, N, H, W, x[:N])
+        else:
+            x[:N].copy_(msg)
+        fused = self.fax_encoder(x, N, H, W, trace)
+        return self._heads_out(fused, H, W)
+
     @torch.no_grad()
     def forward(self, data_dict, trace=None, sync_comm_rate=False):
         if not self.weights_ready:
@@ -160,12 +218,6 @@ class CoBEVTEngine(Where2ComEngine):
         if trace is not None:
             trace["shrink"] = x[:n].permute(0, 3, 1, 2).clone()
         fused = self.fax_encoder(x, n, H, W, trace)
-        heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
-        self.conv(self.heads, fused, 1, H, W, heads)
         if trace is not None:
             trace["fused"] = fused.permute(0, 3, 1, 2).clone()
-        outs = torch.split(heads, self.head_splits, dim=1)
-        out = {"psm": outs[0], "rm": outs[1]}
-        if self.args["obj_head"]:
-            out["obj"] = outs[2]
-        return out
+        return self._heads_out(fused, H, W)

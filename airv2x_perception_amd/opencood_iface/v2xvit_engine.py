@@ -193,6 +193,50 @@ class V2XViTEngine(Where2ComEngine):
         return x[0:1]
 
     @torch.no_grad()
+    def shard_local_stage(self, data_dict_local, has_ego):
+        """Per-rank half of an agent-sharded frame: encoders + backbone + shrink header of THIS rank's
+        agents straight into the all-gather send buffer (n_loc,H,W,256): 36.0 MB per agent at the default grid.
+        ``data_dict_local`` carries the frame-level ``prior_encoding`` / ``spatial_correction_matrix`` (host
+        metadata of ALL agents, (1,L,.)); stats = [0, canvas non-zeros] (summed over ranks = comm_rate)."""
+        record_len, slots = self.frame_layout(data_dict_local)
+        if len(record_len) != 1:
+            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
+        n = record_len[0]
+        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        st = self.stream()
+        nz = self.buf("nonzero", (1,), torch.int64)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        dims = self.level_dims(ny, nx)
+        H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        send = self.buf("shard_send", (n * H * Wd * 256,))
+        self.trunk(canvas, n, ny, nx, shrink_out=send.view(n, H, Wd, 256))
+        stats = torch.stack([torch.zeros((), dtype=torch.int64, device=self.device), nz[0]])
+        meta = {"n_loc": n, "H": H, "W": Wd,
+                "prior": data_dict_local["prior_encoding"][0].detach().cpu().numpy(),
+                "scm": data_dict_local["spatial_correction_matrix"][0].detach().cpu().numpy()}
+        return send, stats, meta
+
+    @torch.no_grad()
+    def shard_ego_stage(self, recv, stats, meta, world, trace=None, sync_comm_rate=False):
+        """Ego half: the gathered (N,H,W,256) buffer is in frame order and is consumed in place by the encoder."""
+        n_loc, H, Wd = meta["n_loc"], meta["H"], meta["W"]
+        N = world * n_loc
+        if recv.numel() != N * H * Wd * 256:
+            raise ValueError("gathered buffer has the wrong size")
+        if N > self.L:
+            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        fused = self.encoder(recv.view(N, H, Wd, 256), N, H, Wd, meta["prior"], meta["scm"], trace)
+        heads = torch.empty((1, self.heads.cout, H, Wd), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, 1, H, Wd, heads)
+        outs = torch.split(heads, self.head_splits, dim=1)
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        out["comm_rate"] = int(stats[1].item()) if sync_comm_rate else stats[1]
+        return out
+
+    @torch.no_grad()
     def forward(self, data_dict, trace=None, sync_comm_rate=False):
         if not self.weights_ready:
             raise RuntimeError("load_state_dict() must be called before forward()")

@@ -68,6 +68,77 @@ class OracleBackend:
                 "com": stats[0].float() / (n_total * H * W), "comm_rate": int(stats[1])}
 
 
+class CoBEVTOracleBackend:
+    """Same interface for the CoBEVT path: the message is the shrink output, or (compression > 0) the
+    NaiveCompressor encoder output that the receiving side decodes (naive_compress.py:12-42)."""
+
+    def __init__(self, sd, args):
+        self.sd, self.args = sd, args
+
+    def local_stage(self, dd_local, has_ego):
+        import torch.nn.functional as F
+        sd, args = self.sd, self.args
+        feats, _ = orc.extract_features(dd_local, sd, args)
+        sf2d, _ = orc.backbone_forward(feats, sd, args["base_bev_backbone"])
+        s = orc.shrink_conv(sf2d, sd, args["shrink_header"])
+        if args["compression"]:
+            s = F.conv2d(s, sd["naive_compressor.encoder.0.weight"], sd["naive_compressor.encoder.0.bias"], padding=1)
+            s = F.relu(orc._bn(s, sd, "naive_compressor.encoder.1"))
+        return s.reshape(-1), torch.zeros(2, dtype=torch.int64), {"shape": tuple(s.shape)}
+
+    def ego_stage(self, recv, stats, meta, world):
+        import torch.nn.functional as F
+        from oracle import cobevt_oracle as cob
+        sd, args = self.sd, self.args
+        n_loc, c, h, w = meta["shape"]
+        s = recv.view(world * n_loc, c, h, w)
+        if args["compression"]:
+            for conv, bn in (("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+                s = F.conv2d(s, sd[f"naive_compressor.{conv}.weight"], sd[f"naive_compressor.{conv}.bias"], padding=1)
+                s = F.relu(orc._bn(s, sd, f"naive_compressor.{bn}"))
+        L = sum(args["max_cav"].values())
+        x, mask = cob.regroup(s, torch.tensor([s.shape[0]]), L)
+        fused = cob.swap_fusion_encoder(x, mask, sd, args["fax_fusion"])
+        return {"psm": orc.head(fused, sd, "cls_head"), "rm": orc.head(fused, sd, "reg_head"), "obj": orc.head(fused, sd, "obj_head")}
+
+
+def _cobevt_frame(compression):
+    hy = synth.default_hypes_cobevt(RNG, compression=compression)
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(synth.cobevt_param_spec(args), seed=3)
+    _, _, voxd = _frame()
+    return args, sd, voxd
+
+
+def _cobevt_worker(rank, world, port, result_path, compression):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    args, sd, voxd = _cobevt_frame(compression)
+    mine = partition_agents(len(TYPES), world)[rank]
+    dd_local = synth.build_data_dict([voxd[i] for i in mine], [TYPES[i] for i in mine])
+    with torch.no_grad():
+        out = ShardedFrame(CoBEVTOracleBackend(sd, args)).forward(dd_local)
+    if rank == 0:
+        torch.save(out, result_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compression", [0, 4])
+def test_cobevt_agent_sharded_frame_equals_single_process(tmp_path, compression):
+    from oracle import cobevt_oracle as cob
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_cobevt_worker, args=(2, _free_port(), path, compression), nprocs=2, join=True)
+    got = torch.load(path)
+    args, sd, voxd = _cobevt_frame(compression)
+    dd = synth.build_data_dict(voxd, TYPES)
+    with torch.no_grad():
+        ref = cob.cobevt_forward(dd, sd, args)
+    for k in ("psm", "rm", "obj"):
+        assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), k
+
+
 def _frame():
     hy = synth.default_hypes(RNG)
     args = hy["model"]["args"]
