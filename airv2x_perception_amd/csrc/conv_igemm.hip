@@ -117,8 +117,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_fixup_f32(con
     conv_epilogue<MT, NT>(p, acc, tile_m * BM + (wave / WAVES_N) * WM, tile_n * BN + (wave % WAVES_N) * WN, tid & 63);
 }
 
-template <int BM, int BN, int WM, int WN, bool DEEP, bool SK>
+// MODE 0: data-parallel (one workgroup = one output tile)
+// MODE 1: stream-K (equal ranges of tiles x K-steps per persistent workgroup + conv_fixup_f32)
+// MODE 2: persistent, whole tiles: every workgroup walks a contiguous range of tiles as ONE flat stream of
+//         K-steps -- the loads of the next tile's first steps are already in flight while the current tile's
+//         epilogue (an HBM write burst) runs, and there is no per-tile launch / prologue bubble.  This is the
+//         schedule for short-K GEMMs (1x1 convs, transformer Linears: 8-12 K-steps per tile); results are
+//         bit-identical to MODE 0.
+template <int BM, int BN, int WM, int WN, bool DEEP, int MODE>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(const ConvParams p) {
+    constexpr bool SK = MODE == 1, PERSIST = MODE == 2;
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NTHR = 64 * (BM / WM) * (BN / WN);  // 256 (4 waves) or 512 (8 waves)
@@ -144,31 +152,44 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     int it = SK ? swz * p.sk_per : swz * p.steps;
     const int it_end = SK ? min(it + p.sk_per, p.sk_total) : it + p.steps;
     bool first_seg = true;
+    // PERSIST: tiles [pt0, pt1) of this workgroup (sk_total = number of tiles)
+    const int pq = PERSIST ? p.sk_total / nb : 0, pr = PERSIST ? p.sk_total - pq * nb : 0;
+    const int pt0 = swz * pq + min(swz, pr), pt1 = pt0 + pq + (swz < pr ? 1 : 0);
+    if (PERSIST && pt0 >= pt1) return;
     do {
-    const int tile = SK ? it / p.steps : swz;
+    const int tile = PERSIST ? pt0 : (SK ? it / p.steps : swz);
     const int ks0 = SK ? it - tile * p.steps : 0;
-    const int nst = SK ? min(p.steps - ks0, it_end - it) : p.steps;
-    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // number of K-steps of this pass: a tile, a stream-K segment, or (PERSIST) the whole flat stream
+    const int nst = PERSIST ? (pt1 - pt0) * p.steps : (SK ? min(p.steps - ks0, it_end - it) : p.steps);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
 
     // ---- per-thread gather bookkeeping for the A tile: row (tid>>3)+32*i, k-quad tid&7
     const int qA = tid & 7;
     int hi0[A_LD], wi0[A_LD], pix0[A_LD];
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-        const int m = m0 + (tid >> 3) + A_ROWS * i;
-        if (m < p.M) {
-            const int img = m / p.HoWo, rem = m - img * p.HoWo;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            hi0[i] = ho * p.stride - p.pad;
-            wi0[i] = wo * p.stride - p.pad;
-            pix0[i] = img * p.H * p.W;
-        } else {
-            hi0[i] = -(1 << 20);  // never inside the image
-            wi0[i] = 0;
-            pix0[i] = 0;
-        }
+    unsigned voffA[A_LD], voffB[B_LD];
+    // B tile: float4 #idx of the [8][BN] k-quad-major tile, idx = tid + NTHR*i -> row idx/BN, col idx%BN
+    constexpr int ROWS_PER_PASS = NTHR / BN > 0 ? NTHR / BN : 1;
+#define AV2X_TILE_SETUP(TILE)                                                                           \
+    {                                                                                                   \
+        const int tm0_ = ((TILE) / p.tiles_n) * BM, tn0_ = ((TILE) % p.tiles_n) * BN;                   \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                              \
+            const int m = tm0_ + (tid >> 3) + A_ROWS * i;                                               \
+            if (m < p.M) {                                                                              \
+                const int img = m / p.HoWo, rem = m - img * p.HoWo;                                     \
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;                                        \
+                hi0[i] = ho * p.stride - p.pad;                                                         \
+                wi0[i] = wo * p.stride - p.pad;                                                         \
+                pix0[i] = img * p.H * p.W;                                                              \
+            } else {                                                                                    \
+                hi0[i] = -(1 << 20); /* never inside the image */                                       \
+                wi0[i] = 0;                                                                             \
+                pix0[i] = 0;                                                                            \
+            }                                                                                           \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                                \
+            voffB[i] = (unsigned)(((tid / BN + i * ROWS_PER_PASS) * p.CoutP + tn0_ + (tid % BN)) * 16); \
     }
+    AV2X_TILE_SETUP(tile)
 
     // Register staging of the NEXT K-step through BUFFER loads (T8): the descriptor is built from
     // kernel arguments (provably wave-uniform -> no waterfall loops), the per-row byte offset lives in
@@ -183,12 +204,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    unsigned voffA[A_LD], voffB[B_LD];
-    // B tile: float4 #idx of the [8][BN] k-quad-major tile, idx = tid + NTHR*i -> row idx/BN, col idx%BN
-    constexpr int ROWS_PER_PASS = NTHR / BN > 0 ? NTHR / BN : 1;
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i)
-        voffB[i] = (unsigned)(((tid / BN + i * ROWS_PER_PASS) * p.CoutP + n0 + (tid % BN)) * 16);
 
 #define AV2X_TAPOFF(TAP)                                                                                \
     {                                                                                                   \
@@ -231,12 +246,34 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     int tap = SK ? ks0 / p.cchunks : 0, cc = SK ? ks0 - tap * p.cchunks : 0;
     int issued = 0;
     if (SK && cc != 0) AV2X_TAPOFF(tap)
-#define AV2X_ADVANCE()                                         \
-    {                                                          \
-        if (issued + 1 < nst) {                                \
-            ++issued;                                          \
-            if (++cc == p.cchunks) { cc = 0; ++tap; }          \
-        }                                                      \
+    int ltile = tile;            // PERSIST: tile the loader is fetching; (ctile, cstep): tile / K-step being computed
+    int ctile = tile, cstep = 0;
+    const int taps = p.ks * p.ks;
+#define AV2X_ADVANCE()                                                                  \
+    {                                                                                   \
+        if (issued + 1 < nst) {                                                         \
+            ++issued;                                                                   \
+            if (++cc == p.cchunks) {                                                    \
+                cc = 0;                                                                 \
+                ++tap;                                                                  \
+                if (PERSIST && tap == taps) { /* the loader crosses into the next tile */ \
+                    tap = 0;                                                            \
+                    ++ltile;                                                            \
+                    AV2X_TILE_SETUP(ltile)                                              \
+                }                                                                       \
+            }                                                                           \
+        }                                                                               \
+    }
+    // PERSIST: after the MFMAs of a tile's last K-step, store it and start the next one with zero accumulators
+#define AV2X_TILE_END()                                                                                   \
+    {                                                                                                     \
+        if (PERSIST && ++cstep == p.steps) {                                                              \
+            conv_epilogue<MT, NT>(p, acc, (ctile / p.tiles_n) * BM + wm0, (ctile % p.tiles_n) * BN + wn0, lane); \
+            _Pragma("unroll") for (int a = 0; a < MT; ++a) _Pragma("unroll") for (int c = 0; c < NT; ++c)  \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;                         \
+            cstep = 0;                                                                                    \
+            ++ctile;                                                                                      \
+        }                                                                                                 \
     }
     const int li = lane & 31, lh = lane >> 5;
 #define AV2X_FRAGS(FA, FB, G)                                                                                       \
@@ -286,6 +323,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
             AV2X_COMPUTE(buf);
             __builtin_amdgcn_sched_barrier(0);
             AV2X_LSTORE(ra0, rb0, buf ^ 1);
+            AV2X_TILE_END();
             __syncthreads();
         }
     } else {
@@ -299,6 +337,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
             AV2X_COMPUTE(0);
             __builtin_amdgcn_sched_barrier(0);
             AV2X_LSTORE(ra0, rb0, 1);  // tile s+1 -> buffer 1
+            AV2X_TILE_END();
             __syncthreads();
             if (s + 1 < nst) {
                 AV2X_ADVANCE();
@@ -307,6 +346,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
                 AV2X_COMPUTE(1);
                 __builtin_amdgcn_sched_barrier(0);
                 AV2X_LSTORE(ra1, rb1, 0);  // tile s+2 -> buffer 0
+                AV2X_TILE_END();
                 __syncthreads();
             }
         }
@@ -315,11 +355,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
 #undef AV2X_FRAGS
 #undef AV2X_MFMAS
 #undef AV2X_ADVANCE
+#undef AV2X_TILE_END
+#undef AV2X_TILE_SETUP
 #undef AV2X_GLOAD
 #undef AV2X_TAPOFF
 #undef AV2X_LSTORE
 
-    if (!SK || nst == p.steps) {
+    if (PERSIST) {
+        // every tile was stored by AV2X_TILE_END
+    } else if (!SK || nst == p.steps) {
         conv_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, lane);
     } else {
         float* wsp = p.ws + (size_t)(2 * swz + (first_seg ? 0 : 1)) * (BM * BN) + tid;
@@ -344,11 +388,11 @@ int launch(const ConvParams& p, hipStream_t st) {
     const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, DEEP, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, DEEP, 0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, DEEP, false>), dim3(tiles_m * q.tiles_n),
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, DEEP, 0>), dim3(tiles_m * q.tiles_n),
                        dim3(64 * (BM / WM) * (BN / WN)), lds, st, q);
     return av2x::check_launch("conv_igemm_f32");
 }
@@ -373,18 +417,39 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
     const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     constexpr int NTHR = 64 * (BM / WM) * (BN / WN);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true, true>), dim3(wgs), dim3(NTHR), lds, st, q);
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true, 1>), dim3(wgs), dim3(NTHR), lds, st, q);
     if (q.sk_per % p.steps != 0)  // some tile is cut
         hipLaunchKernelGGL((conv_fixup_f32<BM, BN, WM, WN>), dim3(tiles), dim3(NTHR), 0, st, q);
     return av2x::check_launch("conv_igemm_f32 (stream-K)");
 }
 
 }  // namespace
+
+// Persistent launch (MODE 2): `wgs` workgroups, each a contiguous range of whole tiles.
+template <int BM, int BN, int WM, int WN>
+int launch_persist(const ConvParams& p, int wgs, hipStream_t st) {
+    const int tiles_m = (p.M + BM - 1) / BM;
+    ConvParams q = p;
+    q.tiles_n = p.CoutP / BN;
+    const long long tiles = (long long)tiles_m * q.tiles_n;
+    if (tiles * p.steps >= (1ll << 31)) return av2x::fail("av2x_conv2d: persistent iteration space too large");
+    if (wgs > tiles) wgs = (int)tiles;
+    q.sk_total = (int)tiles;
+    const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true, 2>), dim3(wgs), dim3(64 * (BM / WM) * (BN / WN)), lds, st, q);
+    return av2x::check_launch("conv_igemm_f32 (persistent)");
+}
 
 extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
                               const float* shift, const float* residual, float* out, float* workspace,
@@ -396,7 +461,7 @@ extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const f
 }
 
 extern "C" uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs) {
-    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x1fff;
+    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x0fff;
     return (tile & 0x2000) ? 2ull * (unsigned)sk_wgs * bm * bn * sizeof(float) : 0ull;
 }
 
@@ -448,7 +513,19 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     p.w_bytes = (unsigned)w_bytes;
     hipStream_t st = av2x::as_stream(stream);
 
-    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x1fff;
+    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x0fff;
+    if (d->tile & 0x1000) {  // persistent whole-tile schedule: sk_wgs workgroups (prefetch-2 pipeline)
+        if (d->sk_wgs <= 0) return av2x::fail("av2x_conv2d: persistent tile needs sk_wgs > 0");
+        if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
+        const bool w8p = (d->tile & 0x8000) != 0;
+        if (w8p && bm == 128 && bn == 128) return launch_persist<128, 128, 64, 32>(p, d->sk_wgs, st);
+        if (w8p && bm == 128 && bn == 64) return launch_persist<128, 64, 32, 32>(p, d->sk_wgs, st);
+        if (!w8p && bm == 128 && bn == 128) return launch_persist<128, 128, 64, 64>(p, d->sk_wgs, st);
+        if (!w8p && bm == 128 && bn == 64) return launch_persist<128, 64, 64, 32>(p, d->sk_wgs, st);
+        if (!w8p && bm == 64 && bn == 64) return launch_persist<64, 64, 32, 32>(p, d->sk_wgs, st);
+        if (!w8p && bm == 64 && bn == 128) return launch_persist<64, 128, 32, 64>(p, d->sk_wgs, st);
+        return av2x::fail("av2x_conv2d: unsupported persistent tile %dx%d", bm, bn);
+    }
     if (d->tile & 0x2000) {  // stream-K: sk_wgs persistent workgroups (always the prefetch-2 pipeline)
         if (d->sk_wgs <= 0) return av2x::fail("av2x_conv2d: stream-K tile needs sk_wgs > 0");
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);

@@ -257,7 +257,7 @@ class Where2ComEngine:
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if d.tile & 0x2000:
+        if d.tile & 0x2000:   # stream-K needs the partial-accumulator workspace (0x1000 = persistent does not)
             ws = self.sk_workspace()
             _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
                                                _ptr(out), _ptr(ws), ws.numel() * 4, self.stream()), "av2x_conv2d_sk")
@@ -268,7 +268,7 @@ class Where2ComEngine:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x1fff))
+            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x0fff))
             if bn & 0x2000:  # launch_sk(): equal iteration ranges, then the number of non-empty ones
                 total = wgs * L.ks * L.ks * (L.cin // 32)
                 per = -(-total // min(d.sk_wgs, total))
@@ -286,6 +286,10 @@ class Where2ComEngine:
     SK_CANDIDATES = ((128, 64 | 0xe000, 768), (128, 64 | 0xe000, 512), (128, 128 | 0xe000, 256), (128, 128 | 0xe000, 512),
                      (64, 64 | 0x6000, 1024))
     SK_MAX_TILES = 1200   # only layers with at most this many 128x64 tiles are tried with stream-K
+    # persistent whole-tile candidates (flag 0x1000; bit-identical to the data-parallel schedule): short-K GEMMs
+    # (1x1 convs / Linears, <= PERSIST_MAX_STEPS K-steps per tile) where the per-tile prologue is a large share
+    PERSIST_CANDIDATES = ((128, 64 | 0xd000, 512), (128, 128 | 0xd000, 512), (64, 64 | 0x5000, 1024), (128, 64 | 0x5000, 768))
+    PERSIST_MAX_STEPS = 16
 
     def sk_workspace(self):
         """Partial-accumulator scratch of av2x_conv2d_sk, sized for the largest stream-K candidate."""
@@ -305,12 +309,14 @@ class Where2ComEngine:
         wo = d.wo * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         scratch = torch.empty(d.n * ho * wo * max(d.out_ctot, L.cout), dtype=torch.float32, device=self.device)
         cands = [(bm, bn, 0) for bm, bn in self.TILE_CANDIDATES]
+        if L.ks * L.ks * (L.cin // 32) <= self.PERSIST_MAX_STEPS:
+            cands += list(self.PERSIST_CANDIDATES)
         if self.stream_k and -(-(d.n * d.ho * d.wo) // 128) * (L.coutp // 64 if L.coutp % 64 == 0 else 1 << 30) <= self.SK_MAX_TILES:
             cands += list(self.SK_CANDIDATES)
         ws = self.sk_workspace()
         st = self.stream()
         for bm, bn, g in cands:
-            if L.coutp % (bn & 0x1fff) or ((bn & 0x1fff) == 32 and L.coutp != 32):
+            if L.coutp % (bn & 0x0fff) or ((bn & 0x0fff) == 32 and L.coutp != 32):
                 continue
             d.tile, d.sk_wgs = (bm << 16) | bn, g
             call = lambda: _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), None,
@@ -323,8 +329,11 @@ class Where2ComEngine:
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
-            if g:
-                t *= 1.03  # prefer the bit-reproducible data-parallel schedule unless stream-K is clearly faster
+            if bn & 0x2000:
+                t *= 1.03  # prefer the bit-reproducible schedules unless stream-K is clearly faster
+            if os.environ.get("AV2X_TUNE_LOG"):
+                print(f"[tune] M={d.n * d.ho * d.wo} cin={L.cin} coutp={L.coutp} ks={L.ks} tile={bm}x{bn & 0xfff} flags={bn & 0xf000:#x} "
+                      f"wgs={g}: {t / 3 * 1e3:.1f} us", flush=True)
             if t < best_t:
                 best, best_t = (d.tile, g), t
         return best

@@ -109,6 +109,7 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
     types = synth.agent_types_for(n_agents)
     order, types_sorted = synth.sort_types(types)
     clouds = [synth.synthetic_cloud(i, n_points) for i in range(n_agents)]
+    types_frame = list(types_sorted)
     if only is not None:  # agent-sharded mode: this rank's contiguous slice of the frame order
         order = [order[j] for j in only]
         types_sorted = [types_sorted[j] for j in only]
@@ -122,10 +123,13 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
     if model == "v2xvit":  # seeded SE(2) correction per non-ego agent; host-side (L,4,4)/(L,3) scalars
         g = np.random.default_rng(99)
         scm = torch.eye(4, dtype=torch.float64).repeat(1, args["max_cav_num"], 1, 1)
-        for i in range(1, len(types_sorted)):
+        for i in range(1, len(types_frame)):
             scm[0, i] = torch.from_numpy(synth.se2_correction(g.uniform(-10, 10), g.uniform(-8, 8), g.uniform(-8, 8)))
         dd["spatial_correction_matrix"] = scm
-        dd["prior_encoding"] = dd["prior_encoding"].cpu()
+        # frame-level metadata of ALL agents (a sharded rank still needs every agent's type / delay for the fusion)
+        empty = (np.zeros((0, 32, 4), np.float32), np.zeros((0, 3), np.int32), np.zeros((0,), np.int32))
+        dd["prior_encoding"] = synth.build_data_dict([empty] * len(types_frame), types_frame, "cpu",
+                                                     args["max_cav_num"])["prior_encoding"]
     return hy, args, dd, [clouds[i] for i in order], types_sorted
 
 
@@ -279,13 +283,13 @@ def main():
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{k[0]}x{k[1] & 0x1fff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}"
+        tkey = lambda k: f"{k[0]}x{k[1] & 0x0fff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": f"conv_igemm_f32<{dom[0]},{dom[1] & 0x1fff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
+            "kernel": f"conv_igemm_f32<{dom[0]},{dom[1] & 0x0fff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
                       + (" prefetch-2" if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),

@@ -89,8 +89,8 @@ typedef struct av2x_conv_desc {
     int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
     int32_t up;                /* DECONV: kernel == stride                                */
     int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2)
-                                  | 0x2000 (stream-K, av2x_conv2d_sk only)                */
-    int32_t sk_wgs;            /* stream-K: number of persistent workgroups (else ignored) */
+                                  | 0x2000 (stream-K, av2x_conv2d_sk only) | 0x1000 (persistent whole tiles) */
+    int32_t sk_wgs;            /* stream-K / persistent: number of workgroups launched (else ignored) */
 } av2x_conv_desc;
 
 int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
@@ -105,7 +105,10 @@ int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const float* w, co
  * a whole number of times has no idle tail.  Tiles cut between workgroups are finished by a second
  * (fix-up) launch that adds the partial accumulators from `workspace` in ascending K order, so results are
  * deterministic; they differ from the non-stream-K schedule by fp32 summation order only.
- * workspace: device scratch of av2x_conv2d_sk_workspace_bytes(tile, sk_wgs) bytes (unused without 0x2000). */
+ * workspace: device scratch of av2x_conv2d_sk_workspace_bytes(tile, sk_wgs) bytes (unused without 0x2000).
+ * Tile flag 0x1000 (any of the three entry points): d->sk_wgs persistent workgroups each walk a contiguous range
+ * of WHOLE tiles as one software-pipelined stream of K-steps (the next tile's loads are in flight during the
+ * current tile's epilogue); no K split, so results are bit-identical to the default schedule.  For short-K GEMMs. */
 int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
                    const float* shift, const float* residual, float* out, float* workspace,
                    uint64_t workspace_bytes, av2x_stream_t stream);
@@ -244,7 +247,7 @@ int av2x_layernorm_act(const float* x, const float* gamma, const float* beta, fl
                        int32_t c, float eps, int32_t relu, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * V2X-ViT fusion pieces (models/v2xvit_modules/*, common_modules/torch_transformation_utils.py).
+ * V2X-ViT fusion pieces (models/v2xvit_modules/, common_modules/torch_transformation_utils.py).
  * av2x_warp_affine: F.affine_grid + F.grid_sample(bilinear, zeros, align_corners=True) as called by
  *   warp_affine :337-381.  src/dst (n,h,w,c) NHWC; theta (n,2,3) DEVICE fp32 = the matrix handed to
  *   affine_grid (the 3x3 normalise/invert chain is host-side, opencood_iface/warp.py).

@@ -193,6 +193,34 @@ def test_conv_stream_k_matches_torch_and_data_parallel(lib, case):
     assert rc != 0 and b"workspace" in lib.av2x_last_error()
 
 
+@pytest.mark.parametrize("tile,wgs", [((128 << 16) | 64 | 0xd000, 7), ((128 << 16) | 128 | 0xd000, 3), ((64 << 16) | 64 | 0x5000, 1000),
+                                      ((128 << 16) | 64 | 0x5000, 5), ((128 << 16) | 128 | 0x5000, 2), ((64 << 16) | 128 | 0x5000, 11)])
+@pytest.mark.parametrize("shape", [(2, 23, 31, 256, 256, 1, 1), (1, 19, 27, 64, 128, 3, 2), (3, 9, 14, 128, 128, 3, 1)])
+def test_conv_persistent_schedule_is_bit_identical(lib, tile, wgs, shape):
+    """tile flag 0x1000: persistent workgroups over whole tiles, cross-tile software pipeline; no K split, so the
+    result must equal the data-parallel schedule bit for bit (uneven tile ranges, more workgroups than tiles,
+    ragged M, 3x3 taps crossing tile boundaries, odd K-step counts)."""
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    n, h, w, cin, cout, ks, stride = shape
+    pad = 1 if ks == 3 else 0
+    g = torch.Generator().manual_seed(cin + cout + ks + wgs)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wp, coutp = pack_conv_weight(torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks))
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    res = torch.randn(n, ho, wo, cout, generator=g).cuda()
+    from airv2x_perception_amd import _lib
+    outs = []
+    for t, k in ((tile & ~0x1000, 0), (tile, wgs)):
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=ho, wo=wo, cout=cout, coutp=coutp, out_ctot=cout,
+                          out_coff=0, ks=ks, stride=stride, pad=pad, relu=2, mode=0, up=1, tile=t, sk_wgs=k)
+        out = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+        _lib.check(lib.av2x_conv2d_res(byref(d), _p(x), _p(wp.cuda()), _p(sc), _p(sh), _p(res), _p(out), _stream()), "conv")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.isnan(outs[1]).any()
+
+
 def test_conv_rejects_bad_arguments(lib):
     from airv2x_perception_amd import _lib
     d = _lib.ConvDesc()
