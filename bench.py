@@ -291,6 +291,9 @@ def main():
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
             "kernel": f"conv_igemm_f32<{dom[0]},{dom[1] & 0x0fff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
                       + (" prefetch-2" if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
+            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x0fff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
+                             f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>"
+                             + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x0fff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},

@@ -22,12 +22,12 @@ def rows(d):
 
 
 def conv_key(name):
-    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?>", name)
+    m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false|\d))?>", name)
     if not m:
         return None
     bm, bn, wm, wn = (int(m.group(i)) for i in range(1, 5))
     waves = (bm // wm) * (bn // wn)
-    return f"{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if m.group(5) == 'true' else ''}{'sk' if m.group(6) == 'true' else ''}"
+    return f"{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if m.group(5) == 'true' else ''}{'sk' if m.group(6) in ('true', '1') else ''}{'p' if m.group(6) == '2' else ''}"
 
 
 def calib(d, counter, kernel_sub, known_bytes):
