@@ -193,6 +193,77 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
     for (int d = 0; d < DHD; d += 4) *reinterpret_cast<float4*>(dst + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
 }
 
+// MFMA form of the 4x4-window attention (T = 16 tokens): one wave per (window, head) task.
+// v_mfma_f32_16x16x4_f32: A[row = lane%16][k = lane/16], B[k = lane/16][col = lane%16],
+// D reg r of lane l = D[row = 4*(l/16) + r][col = l%16].
+//   S^T = K Q^T  (row = key j, col = query i): lane (t = l%16, h = l/16) loads float4 K[t][4(h+4g)..] and
+//         Q[t][4(h+4g)..] -- four MFMAs per float4 pair, any K-permutation is valid as A and B use the same one;
+//         D reg r of lane l = score(query i = l%16, key j = 4h + r), i.e. key (jy = h, jx = r): the softmax over
+//         keys is 4 in-lane values x the lanes l, l^16, l^32, l^48, and P is ALREADY in the A-operand layout
+//         of the second product (row = i = l%16, k-slot = h), no transpose through LDS.
+//   O   = P V    : MFMA r uses A = P reg r, B = V[key (h, r)][n0 + l%16]; D reg r' of lane l = O[query (l/16, r')][n0 + l%16].
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int DH>
+__global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __restrict__ qkv, int ctot, int coff,
+                                                               const float* __restrict__ pos, float* __restrict__ out,
+                                                               int n, int H, int W, int heads, float scale) {
+    constexpr int WS = 4, NB = DH / 16;
+    const int lane = threadIdx.x & 63;
+    const int t = lane & 15, h = lane >> 4;
+    const int wx_n = W / WS, wy_n = H / WS;
+    const long long tasks = (long long)n * wy_n * wx_n * heads;
+    const int inner = heads * DH;
+    // relative-position bias of (query i = t, key (h, r)): pos[(jy - iy + 3) * 7 + (jx - ix + 3)]
+    const int iy = t >> 2, ix = t & 3;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = pos[(h - iy + WS - 1) * (2 * WS - 1) + (r - ix + WS - 1)];
+    for (long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); task < tasks; task += (long long)gridDim.x * 4) {
+        const int head = (int)(task % heads);
+        long long wdw = task / heads;
+        const int wx = (int)(wdw % wx_n); wdw /= wx_n;
+        const int wy = (int)(wdw % wy_n);
+        const int a = (int)(wdw / wy_n);
+        const size_t pix0 = ((size_t)a * H + (size_t)wy * WS) * W + (size_t)wx * WS;
+        // token t of the window: pixel (wy*4 + t/4, wx*4 + t%4)
+        const float* rowt = qkv + (pix0 + (size_t)(t >> 2) * W + (t & 3)) * ctot + coff + head * DH;
+        f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            const float4 qq = *reinterpret_cast<const float4*>(rowt + 4 * (h + 4 * g));
+            const float4 kk = *reinterpret_cast<const float4*>(rowt + inner + 4 * (h + 4 * g));
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qq.x, st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qq.y, st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qq.z, st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qq.w, st, 0, 0, 0);
+        }
+        float sc[4], m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = st[r] * scale + bias[r]; m = fmaxf(m, sc[r]); }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = expf(sc[r] - m); l += sc[r]; }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        // V rows of the keys (jy = h, jx = r)
+        const float* vrow = qkv + (pix0 + (size_t)h * W) * ctot + coff + 2 * inner + head * DH + t;
+        float* orow = out + (pix0 + (size_t)h * W) * inner + head * DH + t;   // query (iy = h, ix = r')
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, vrow[(size_t)r * ctot + nb * 16], o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) orow[(size_t)r * inner + nb * 16] = o[r];
+        }
+    }
+}
+
 // gap[a][c] = mean over pixels of (s0 + s1 + s2), deterministic two-stage reduction:
 //   stage 1: grid (C/64, n, GAP_CHUNKS), block 256 = 4 pixel groups x 64 channels -> part[a][chunk][c]
 //   stage 2: grid (C/64, n): sum of the chunks in fixed order, / hw
@@ -307,12 +378,22 @@ extern "C" int av2x_window_attention(const float* qkv, int32_t ctot, int32_t cof
                                      int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
                                      av2x_stream_t stream) {
     if (!qkv || !pos_embedding || !out) return av2x::fail("av2x_window_attention: null argument");
-    if (h % window || w % window) return av2x::fail("av2x_window_attention: map %dx%d not divisible by window %d", h, w, window);
+    if (h % (window & 0xff) || w % (window & 0xff))
+        return av2x::fail("av2x_window_attention: map %dx%d not divisible by window %d", h, w, window & 0xff);
+    const bool force_valu = (window & 0x100) != 0;   // test hook: the scalar reference kernel
+    window &= 0xff;
     const size_t total = (size_t)n * h * w * heads;
     if (total == 0) return 0;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     const float scale = 1.0f / sqrtf((float)dim_head);
     hipStream_t st = av2x::as_stream(stream);
+    if (window == 4 && !force_valu && (dim_head == 32 || dim_head == 64)) {
+        const long long tasks = (long long)n * (h / 4) * (w / 4) * heads;
+        const unsigned wgs = (unsigned)((tasks + 3) / 4 < 256 * 16 ? (tasks + 3) / 4 : 256 * 16);
+        if (dim_head == 32) hipLaunchKernelGGL((window_attn_mfma_kernel<32>), dim3(wgs), block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+        else hipLaunchKernelGGL((window_attn_mfma_kernel<64>), dim3(wgs), block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+        return av2x::check_launch("window_attn_mfma_kernel");
+    }
     if (dim_head == 16 && window == 2) hipLaunchKernelGGL((window_attn_kernel<16, 2>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
     else if (dim_head == 32 && window == 4) hipLaunchKernelGGL((window_attn_kernel<32, 4>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
     else if (dim_head == 64 && window == 4) hipLaunchKernelGGL((window_attn_kernel<64, 4>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);

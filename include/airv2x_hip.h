@@ -260,7 +260,8 @@ int av2x_layernorm_act(const float* x, const float* gamma, const float* beta, fl
  *   i32 (n,) node type (0/1) of every agent; out (n,hw,256) heads merged (before a_linears).
  * av2x_window_attention: BaseWindowAttention mswin.py:52-96 for n agent maps; the [q|k|v] block of the
  *   branch sits at column `coff` of the (n*h*w, ctot) token buffer; pos_embedding (2w-1,2w-1);
- *   out (n*h*w, heads*dim_head).  Supported (dim_head, window): (16,2) (32,4) (64,4).
+ *   out (n*h*w, heads*dim_head).  Supported (dim_head, window): (16,2) (32,4) (64,4).  The 4x4 windows run on
+ *   v_mfma_f32_16x16x4_f32 (one wave per window x head); window | 0x100 selects the scalar kernel (tests).
  * av2x_split_attn_gap / _combine: SplitAttn split_attn.py:48-61 — mean over pixels of the branch sum,
  *   then radix-3 softmax of logits (n,3c) + weighted branch sum + residual.
  * ------------------------------------------------------------------------------------ */

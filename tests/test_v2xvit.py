@@ -106,3 +106,29 @@ def test_gpu_forward_matches_golden():
         assert_close(tr[f"layer{d}"].cpu()[0, ::bs, ::bs, :], fx[f"layer{d}_agent0"][0], 1e-3, 1e-3, f"layer{d}")
     for k in ("psm", "rm", "obj"):
         assert_close(out[k].cpu(), fx[k], 1e-3, 1e-3, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,dh,ws,force_valu", [(16, 16, 2, 0), (8, 32, 4, 0), (8, 32, 4, 1), (4, 64, 4, 0), (4, 64, 4, 1)])
+def test_gpu_window_attention_kernel(heads, dh, ws, force_valu):
+    """av2x_window_attention (MFMA 16x16x4 kernel for the 4x4 windows, scalar kernel for 2x2 / when forced) against
+    BaseWindowAttention of the oracle with identity to_qkv / to_out, inside a wider token buffer (ctot, coff)."""
+    from ctypes import c_void_p
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(heads * 100 + dh + force_valu)
+    n, H, W, inner = 3, 12, 20, heads * dh
+    qkv = torch.randn(n, H, W, 3 * inner, generator=g)
+    pos = torch.randn(2 * ws - 1, 2 * ws - 1, generator=g)
+    sd = {"w.to_qkv.weight": torch.eye(3 * inner), "w.pos_embedding": pos, "w.to_out.0.weight": torch.eye(inner),
+          "w.to_out.0.bias": torch.zeros(inner)}
+    ref = vit.window_attention(qkv.unsqueeze(0), sd, "w", heads, dh, ws)[0]          # (n,H,W,inner)
+    ctot, coff = 3 * inner + 192, 64
+    buf = torch.randn(n, H, W, ctot, generator=g)
+    buf[..., coff:coff + 3 * inner] = qkv
+    bd, pd = buf.cuda(), pos.cuda()
+    out = torch.full((n, H, W, inner), float("nan"), device="cuda")
+    P = lambda t: c_void_p(t.data_ptr())
+    _lib.check(lib.av2x_window_attention(P(bd), ctot, coff, P(pd), P(out), n, H, W, heads, dh, ws | (0x100 if force_valu else 0),
+                                         c_void_p(torch.cuda.current_stream().cuda_stream)), "window attention")
+    assert_close(out.cpu(), ref, 1e-5, 1e-5, f"window attention heads={heads} dh={dh} ws={ws}")
