@@ -329,6 +329,152 @@ __global__ __launch_bounds__(256) void fax_attention_mfma_kernel(const FaxParams
     }
 }
 
+// ---------------------------------------------------------------- ws = 4 specialisation, P kept in registers
+// Same work split as fax_attention_mfma_kernel (one workgroup per window, heads in sequence, wave = 32-query strip),
+// but the first product is computed TRANSPOSED: S^T = K (Q*scale)^T, i.e. MFMA row = key, col = query.  In the
+// 32x32 C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) every lane then owns ONE query and its
+// 16 registers per key tile are 16 different keys, so
+//   * the softmax over keys is an in-lane reduction plus ONE cross-lane step (xor 32) instead of 10 shuffles per row,
+//   * P[query i][key j] is already the A operand of O = P V (A[row = lane&31][k = lane>>5]): MFMA number r of a
+//     key tile uses A = P reg r and B = V[key j(r, half)][n = lane&31] -- no transpose through LDS,
+//   * the relative-position bias index base[i] - sub[j] has a compile-time sub[j] up to the lane half:
+//     key j = 32*tile + (r&3) + 8*(r>>2) + 4*half  ->  agent 2*tile + (r>>3), w1 = 2*((r>>2)&1) + half, w2 = r&3.
+// V is staged row-major [key][40] (conflict-free ds_read_b32 for two rows 4 apart), K as before [key][36].
+constexpr int VLD4 = 40;
+
+__global__ __launch_bounds__(256) void fax_attention_mfma4_kernel(const FaxParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int ws = 4, ws2 = 16, s1 = 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li32 = lane & 31, lh = lane >> 5;
+    const int T = p.L * ws2, Tk = p.n_valid * ws2;
+    const int TkP = (Tk + 31) & ~31;
+    const int ktiles = TkP >> 5;                           // 1..4 key tiles of 32
+    const int X = p.H / ws, Y = p.W / ws;
+    const int wx = blockIdx.x / Y, wy = blockIdx.x % Y;
+    const int C = p.heads * DH, C3 = 3 * C;
+    const int tab_n = (2 * p.L - 1) * s1 * s1;
+    float* Ks = lds;                                       // [TkP][KLD]
+    float* Vs = Ks + TkP * KLD;                            // [TkP][VLD4]
+    float* tab = Vs + TkP * VLD4;                          // [tab_n]
+    int* rowtok = reinterpret_cast<int*>(tab + ((tab_n + 3) & ~3));   // [128]
+
+    if (tid < 128) {
+        const int t = tid < T ? tid : T - 1;               // padding queries re-read the last token (never stored)
+        const int l = t >> 4, w1 = (t >> 2) & 3, w2 = t & 3;
+        const int ph = p.grid ? (w1 * X + wx) : (wx * ws + w1);
+        const int pw = p.grid ? (w2 * Y + wy) : (wy * ws + w2);
+        rowtok[tid] = (l * p.H + ph) * p.W + pw;
+    }
+    const int strip = wave;
+    const bool strip_on = strip * 32 < T;
+    // this lane's query i = 32*strip + li32: bias base index, minus the half-dependent part of sub[j]
+    int bih;
+    {
+        const int t = min(strip * 32 + li32, T - 1);
+        const int l = t >> 4, w1 = (t >> 2) & 3, w2 = t & 3;
+        bih = ((l + p.L - 1) * s1 + (w1 + ws - 1)) * s1 + (w2 + ws - 1) - lh * s1;
+    }
+    const float kLog2e = 1.4426950408889634f;
+
+    for (int h = 0; h < p.heads; ++h) {
+        __syncthreads();                                   // previous head fully consumed (and rowtok visible)
+        for (int idx = tid; idx < TkP * 8; idx += 256) {
+            const int j = idx >> 3, d4 = idx & 7;
+            f32x4v kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (j < Tk) {
+                const float* src = p.qkv + (size_t)rowtok[j] * C3 + h * DH + d4 * 4;
+                kv = *reinterpret_cast<const f32x4v*>(src + C);
+                vv = *reinterpret_cast<const f32x4v*>(src + 2 * C);
+            }
+            *reinterpret_cast<f32x4v*>(Ks + j * KLD + d4 * 4) = kv;
+            *reinterpret_cast<f32x4v*>(Vs + j * VLD4 + d4 * 4) = vv;
+        }
+        for (int i = tid; i < tab_n; i += 256) tab[i] = p.table[(size_t)i * p.heads + h];
+        __syncthreads();
+        if (!strip_on) continue;
+
+        // ---- S^T tiles: A = K rows from LDS, B = (Q * scale) rows straight from global
+        f32x4v qa[4];
+        {
+            const float* qsrc = p.qkv + (size_t)rowtok[strip * 32 + li32] * C3 + h * DH + lh * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                qa[g] = *reinterpret_cast<const f32x4v*>(qsrc + g * 8);
+                qa[g] *= p.scale;
+            }
+        }
+        f32x16 sacc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+            if (kt < ktiles) {
+                const float* kb = Ks + (kt * 32 + li32) * KLD + lh * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v kf = *reinterpret_cast<const f32x4v*>(kb + g * 8);
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qa[g].x, sacc[kt], 0, 0, 0);
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qa[g].y, sacc[kt], 0, 0, 0);
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qa[g].z, sacc[kt], 0, 0, 0);
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qa[g].w, sacc[kt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- bias, padding mask, max over keys (in-lane + xor 32)
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < ktiles) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int agent = 2 * kt + (r >> 3);                       // wave-uniform
+                    const int sub0 = (agent * s1 + 2 * ((r >> 2) & 1)) * s1 + (r & 3);   // sub[j] without the half term
+                    float sv = sacc[kt][r] + tab[bih - sub0];
+                    sv = agent < p.n_valid ? sv : -INFINITY;
+                    sacc[kt][r] = sv;
+                    m = fmaxf(m, sv);
+                }
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float mb = m * kLog2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < ktiles) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], kLog2e, -mb));   // exp(s - m)
+                    sacc[kt][r] = e;
+                    sum += e;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // ---- O = P V : A = P registers (normalised), B = V rows from LDS
+        f32x16 oacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < ktiles) {
+                const float* vb = Vs + (kt * 32 + 4 * lh) * VLD4 + li32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, vb[((r & 3) + 8 * (r >> 2)) * VLD4], oacc, 0, 0, 0);
+            }
+        }
+        // ---- store: row (r, lh) of the strip = query, column d = lane & 31
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = strip * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < T) p.out[(size_t)rowtok[row] * C + h * DH + li32] = oacc[r];
+        }
+    }
+}
+
 __global__ void agent_mean_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, int L) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = x[i];
@@ -384,7 +530,19 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
     const int Tk = n_valid * window * window;
     const int tab_n = (2 * n_agents_padded - 1) * (2 * window - 1) * (2 * window - 1);
     const int T = n_agents_padded * window * window;
-    if (T <= 128 && !(grid_partition & 2)) {  // MFMA path (bit 1 of grid_partition forces the VALU reference kernel: tests)
+    if (T <= 128 && window == 4 && !(grid_partition & 6)) {   // ws = 4: S^T form, P stays in registers
+        const int TkP = (Tk + 31) & ~31;
+        const size_t lds_4 = ((size_t)TkP * KLD + (size_t)TkP * VLD4 + ((tab_n + 3) & ~3) + 128) * sizeof(float);
+        static size_t attr_4 = 0;
+        if (lds_4 > attr_4) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fax_attention_mfma4_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_4);
+            attr_4 = lds_4;
+        }
+        hipLaunchKernelGGL(fax_attention_mfma4_kernel, dim3((h / window) * (w / window)), dim3(256), lds_4, av2x::as_stream(stream), p);
+        return av2x::check_launch("fax_attention_mfma4_kernel");
+    }
+    if (T <= 128 && !(grid_partition & 2)) {  // generic-window MFMA path (bit 1 forces the VALU reference kernel, bit 2 this one: tests)
         const int TkP = (Tk + 31) & ~31;
         const size_t lds_m = ((size_t)TkP * KLD + (size_t)TkP * DH + ((tab_n + 3) & ~3) + TkP + 256 + 4 * 32 * PLD) * sizeof(float);
         static size_t attr_m = 0;
