@@ -82,7 +82,7 @@ def parse():
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
     ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit"], default="where2com",
                     help="where2com = the headline metric; cobevt = BASELINE.json configs[2] fusion head on one GPU")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent frames kept in flight per GPU (separate HIP streams + workspaces, shared weights); "
                          "1 = strictly sequential frames (latency mode, also reported as single_stream)")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica",
