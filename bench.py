@@ -135,15 +135,24 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
 
 def main():
     a = parse()
-    torch.set_num_threads(usable_cores())  # the boxes show 256 CPUs but grant 16: keep small host ops un-throttled
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the boxes show 256 CPUs but grant a cgroup quota (16 on the 1-GPU box): share it between the ranks of the node
+    torch.set_num_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # test hooks (one-GPU boxes): AV2X_ONE_DEVICE=1 puts every rank on cuda:0, AV2X_DIST_BACKEND=gloo avoids RCCL
+        # (which refuses two ranks on one device); the driver's runs use neither
+        if os.environ.get("AV2X_ONE_DEVICE"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("AV2X_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)

@@ -62,7 +62,7 @@ def test_partition_roundtrip_and_index():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cobevt_small_n3", "cobevt_small_n2_c4"])
+@pytest.mark.parametrize("name", ["cobevt_small_n3", "cobevt_small_n2_c4", "cobevt_full_n4"])
 def test_gpu_forward_matches_golden_and_oracle(name):
     from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
     fx = load_fixture(name)
@@ -77,9 +77,13 @@ def test_gpu_forward_matches_golden_and_oracle(name):
     bs = int(fx["big_stride"])
     for i in range(3):
         assert_close(sample(tr[f"fax_block{i}"], bs), fx[f"fax_block{i}"], 3e-4, 3e-4, f"fax_block{i}")
-    assert_close(sample(tr["fused"], 2), fx["fused"], 3e-4, 3e-4, "fused")
+    assert_close(sample(tr["fused"], int(fx["fused_stride"]) if "fused_stride" in fx else 2), fx["fused"], 3e-4, 3e-4, "fused")
+    hs = int(fx["head_stride"]) if "head_stride" in fx else 1
     for k in ("psm", "rm", "obj"):
-        assert_close(out[k].cpu(), fx[k], 3e-4, 3e-4, k)
+        assert_close(sample(out[k], hs), fx[k], 3e-4, 3e-4, k)
+        if k + "_sum" in fx:   # a checksum over ALL cells of the map (full-grid fixture)
+            tot, ref = float(out[k].double().sum()), float(fx[k + "_sum"])
+            assert abs(tot - ref) <= 1e-5 * max(1.0, float(out[k].double().abs().sum())), (k, tot, ref)
     assert set(out.keys()) == {"psm", "rm", "obj"}
     o2 = model(dd)
     assert torch.equal(o2["psm"], out["psm"])

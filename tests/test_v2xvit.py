@@ -85,9 +85,12 @@ def test_gpu_warp_and_roi_mask():
 
 
 @pytest.mark.gpu
-def test_gpu_forward_matches_golden():
+@pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n4"])
+def test_gpu_forward_matches_golden(name):
+    """small grid: every tensor; full AirV2X grid (BASELINE size, 4 agents x 8192 points): strided samples + sums of
+    the reference's outputs."""
     from airv2x_perception_amd.opencood_iface import Airv2xV2XVit
-    fx = load_fixture("v2xvit_small_n3")
+    fx = load_fixture(name)
     hy, args, sd, dd = _case(fx)
     model = Airv2xV2XVit(args)
     assert list(model.state_dict().keys()) == [str(k) for k in fx["spec_keys"]]
@@ -104,8 +107,14 @@ def test_gpu_forward_matches_golden():
     assert int((tr["com_mask"].cpu().numpy() != ref_mask).sum()) <= 2
     for d in range(3):
         assert_close(tr[f"layer{d}"].cpu()[0, ::bs, ::bs, :], fx[f"layer{d}_agent0"][0], 1e-3, 1e-3, f"layer{d}")
+    hs = int(fx["head_stride"]) if "head_stride" in fx else 1
     for k in ("psm", "rm", "obj"):
-        assert_close(out[k].cpu(), fx[k], 1e-3, 1e-3, k)
+        # fp32 tolerance: 1e-3 relative + 1e-4 of the map's magnitude (heads reach |x| ~ 40 after 3 transformer
+        # layers whose activations are O(100); the small-grid fixture has magnitude ~10 -> the former 1e-3 absolute)
+        assert_close(out[k].cpu()[..., ::hs, ::hs], fx[k], 1e-3, 1e-4 * max(10.0, float(np.abs(fx[k]).max())), k)
+        if k + "_sum" in fx:   # a checksum over ALL cells of the map
+            tot, ref = float(out[k].double().sum()), float(fx[k + "_sum"])
+            assert abs(tot - ref) <= 1e-5 * max(1.0, float(out[k].double().abs().sum())), (k, tot, ref)
 
 
 @pytest.mark.gpu

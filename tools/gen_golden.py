@@ -268,7 +268,7 @@ def load_ref_hypes_cobevt(lidar_range):
     return h
 
 
-def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride, compression=0):
+def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride, compression=0, head_stride=1):
     """Airv2xCoBEVT (fused axial attention) on the real reference vs oracle/cobevt_oracle.py."""
     from airv2x_perception_amd import synth
     from oracle import cobevt_oracle as cob
@@ -317,13 +317,16 @@ def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride, compre
           "n_points": np.int64(n_points), "cloud": np.asarray("uniform"), "sample_stride": np.int64(1),
           "big_stride": np.int64(big_stride), "spec_keys": np.asarray([k for k, _, _ in spec]),
           "max_cav": np.asarray([args["max_cav"][t] for t in synth.AGENT_TYPES], np.int64),
-          "compression": np.int64(compression)}
+          "compression": np.int64(compression), "head_stride": np.int64(head_stride)}
     for i, (v, c, n) in enumerate(voxd):
         fx[f"vox_coords_{i}"], fx[f"vox_num_{i}"] = c, n
     for k in ("psm", "rm", "obj"):
-        fx[k] = out[k].numpy()
+        fx[k] = out[k][..., ::head_stride, ::head_stride].numpy()
+        fx[k + "_sum"] = np.float64(out[k].double().sum().item())
     fx["fused_sum"] = np.float64(cap["fused"].double().sum().item())
-    fx["fused"] = cap["fused"][..., ::2, ::2].numpy()
+    fs = 2 if head_stride == 1 else 2 * head_stride
+    fx["fused_stride"] = np.int64(fs)
+    fx["fused"] = cap["fused"][..., ::fs, ::fs].numpy()
     for i in range(3):
         t = cap[f"fax_block{i}"]
         fx[f"fax_block{i}_sum"] = np.float64(t.double().sum().item())
@@ -339,7 +342,7 @@ def v2xvit_frame(synth, vox, hy, types, n_points, rng, max_cav_num):
     pp = hy["preprocess"]
     voxd = []
     for i, t in enumerate(types):
-        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng or synth.DEFAULT_RANGE), pp["cav_lidar_range"])
         voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"]))
     dd = synth.build_data_dict(voxd, types, max_cav_num=max_cav_num)
     g = np.random.default_rng(77)
@@ -351,7 +354,7 @@ def v2xvit_frame(synth, vox, hy, types, n_points, rng, max_cav_num):
     return dd, voxd
 
 
-def run_v2xvit_case(name, lidar_range, types, n_points, seed, max_cav, big_stride):
+def run_v2xvit_case(name, lidar_range, types, n_points, seed, max_cav, big_stride, head_stride=1):
     """Airv2xV2XVit on the real reference vs oracle/v2xvit_oracle.py."""
     from airv2x_perception_amd import synth
     from oracle import v2xvit_oracle as vit
@@ -361,8 +364,9 @@ def run_v2xvit_case(name, lidar_range, types, n_points, seed, max_cav, big_strid
 
     src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_v2xvit.yaml")
     txt = open(src).read()
-    r = lidar_range
-    txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+    if lidar_range is not None:
+        r = lidar_range
+        txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
     txt = re.sub(r"vehicle: 5\n(\s+)rsu: 5\n(\s+)drone: 5", f"vehicle: {max_cav[0]}\n\\1rsu: {max_cav[1]}\n\\2drone: {max_cav[2]}", txt)
     with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
         f.write(txt)
@@ -400,15 +404,16 @@ def run_v2xvit_case(name, lidar_range, types, n_points, seed, max_cav, big_strid
     assert all(a <= 1e-4 * max(1.0, b) for a, b in rep.values())
     assert float((tr["after_sttf"] - cap["after_sttf"]).abs().max()) < 1e-5
     assert o["comm_rate"] == out["comm_rate"]
-    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(lidar_range, np.float64), "types": np.asarray(types),
-          "n_points": np.int64(n_points), "big_stride": np.int64(big_stride),
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(lidar_range or synth.DEFAULT_RANGE, np.float64), "types": np.asarray(types),
+          "n_points": np.int64(n_points), "big_stride": np.int64(big_stride), "head_stride": np.int64(head_stride),
           "spec_keys": np.asarray([k for k, _, _ in spec]), "max_cav": np.asarray(max_cav, np.int64),
           "comm_rate": np.int64(out["comm_rate"]),
           "spatial_correction_matrix": dd["spatial_correction_matrix"].numpy(), "prior_encoding": dd["prior_encoding"].numpy()}
     for i, (v, c, n) in enumerate(voxd):
         fx[f"vox_coords_{i}"] = c
     for k in ("psm", "rm", "obj"):
-        fx[k] = out[k].numpy()
+        fx[k] = out[k][..., ::head_stride, ::head_stride].numpy()
+        fx[k + "_sum"] = np.float64(out[k].double().sum().item())
     fx["after_sttf"] = cap["after_sttf"][..., ::big_stride, ::big_stride, :].numpy()       # (B,L,H,W,C)
     fx["com_mask"] = tr["com_mask"].numpy()
     for d in range(3):
@@ -552,6 +557,16 @@ def main():
     run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
     eval_golden()
     points_golden()
+    full_grid_transformers()
+
+
+def full_grid_transformers():
+    """Default AirV2X grid (704 x 200 pillars), 4 agents x 8192 points: strided samples + sums."""
+    if "v2xvit_only" not in sys.argv:
+        run_cobevt_case("cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 20, head_stride=5)
+    if "cobevt_only" in sys.argv:
+        return
+    run_v2xvit_case("v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, (2, 1, 1), 20, head_stride=5)
 
 
 if __name__ == "__main__":
@@ -565,6 +580,11 @@ if __name__ == "__main__":
         import_reference()
         torch.set_num_threads(8)
         run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
+    elif len(sys.argv) > 1 and sys.argv[1] == "full":
+        os.chdir(tempfile.mkdtemp())
+        import_reference()
+        torch.set_num_threads(8)
+        full_grid_transformers()
     elif len(sys.argv) > 1 and sys.argv[1] == "points":
         os.chdir(tempfile.mkdtemp())
         import_reference()
