@@ -10,7 +10,7 @@
 //
 //   k_cell   per point : cell id, cnt[cell]++, first[cell] = min(index)
 //   k_scan   1 workgroup: exclusive scan (a) over "is first point of its cell" flags in point
-//            order -> voxel rank + M, (b) over cnt in cell order -> list offsets
+//            order -> voxel rank + M, (b) over cnt of the first points, same order -> list offsets
 //   k_fill   per point : unordered append of the point index to its cell's list
 //   k_emit   per point : pos = #{j in list : j < i}; write voxels / coords / num_points
 #include "av2x_common.hpp"
@@ -53,8 +53,11 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cell, int
     __syncthreads();
     if (threadIdx.x == 0) m_out[0] = tot < max_voxels ? tot : max_voxels;
     __syncthreads();
-    // (b) list offsets in cell order
-    av2x::block_scan(ncell, [&](int c) { return cnt[c]; }, [&](int c, int ex) { offs[c] = ex; }, &tot);
+    // (b) list offsets, cells taken in order of first appearance (a scan over the points, not over the
+    //     140 800 grid cells: only occupied cells need a list)
+    av2x::block_scan(
+        n, [&](int i) { const int c = cell[i]; return (c >= 0 && first[c] == i) ? cnt[c] : 0; },
+        [&](int i, int ex) { const int c = cell[i]; if (c >= 0 && first[c] == i) offs[c] = ex; }, &tot);
 }
 
 __global__ void k_fill(const int* __restrict__ cell, int n, const int* __restrict__ offs, int* __restrict__ fill,

@@ -265,6 +265,29 @@ def main():
                                    "counts_cand_filtered_nmsin_picked_final": boxes[4],
                                    "note": "model + av2x_postprocess per frame, one 20-byte host read-back of the counts"}
 
+        # third figure: the whole chain from raw clouds (prepare -> voxelize -> model -> post-process), sequential
+        from airv2x_perception_amd.opencood_iface.voxelizer import prepare_points, voxelize_points
+        ppc = hy["preprocess"]
+        pts_dev = [torch.from_numpy(c).to(dev) for c in clouds]
+        for it in range(2 + a.steps):
+            if it == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            vv = []
+            for p_ in pts_dev:
+                q_ = prepare_points(p_, ppc["cav_lidar_range"], None, mask_ego=True)
+                vv.append(voxelize_points(q_, ppc["cav_lidar_range"], ppc["args"]["voxel_size"],
+                                          ppc["args"]["max_points_per_voxel"], ppc["args"]["max_voxel_test"]))
+            dd2 = synth.build_data_dict_device(vv, types, dev, max_cav_num=args["max_cav_num"])
+            o = model(dd2)
+            post.post_process_airv2x(data, {"ego": o}, return_counts=True)
+        torch.cuda.synchronize()
+        edt = (time.perf_counter() - t0) / a.steps
+        res["from_points"] = {"frames_per_s": round(1.0 / edt, 2), "ms_per_step": round(edt * 1e3, 3),
+                              "note": "raw (P,4) clouds resident in HBM -> av2x_prepare_points -> av2x_voxelize -> model -> "
+                                      "av2x_postprocess, one frame at a time; the exact-shape voxel tensors of the reference's "
+                                      "input contract cost two host read-backs per agent"}
+
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and a.mode == "replica":
         eng.use_graph = False
