@@ -740,7 +740,7 @@ class FramePipeline:
         s = self.streams[k]
         s.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
         eng = self.engines[k]
-        saved, eng.stream_k = eng.stream_k, eng.stream_k and len(self.engines) == 1
+        saved, eng.stream_k = eng.stream_k, eng.stream_k and (len(self.engines) == 1 or os.environ.get("AV2X_PIPE_SK") == "1")
         try:
             with torch.cuda.stream(s):
                 out = eng.forward(data_dict, **kw)

@@ -334,7 +334,9 @@ def main():
             **({"per_shape": [{"M_cin_cout_ks_stride": list(k[0]), "tile": tkey(k[1]), "wgs": k[2], "launches_per_frame": v[0] / a.steps,
                                "us": round(v[2] / v[0] * 1e6, 1), "tflops": round(v[1] / v[2] / 1e12, 1)}
                               for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])]} if a.per_shape else {}),
-            "timing": "second pass of K steps, hipEvent pair around every conv launch on the launch stream",
+            "timing": "second pass of K sequential frames (the single_stream schedule, stream-K on), hipEvent pair around every conv "
+                      "launch on the launch stream; with several frames in flight the kernels of different frames overlap and "
+                      "per-launch durations are not separable (rocprofv3 summary of this mode: profiles/*_inflight1.txt)",
         }
 
     # ---------------- CPU baseline: the oracle port on the host cores (bounded sample) ---------------------
