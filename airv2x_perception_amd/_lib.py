@@ -48,6 +48,7 @@ SIGNATURES = {
     "av2x_agent_mean": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "av2x_layernorm_act": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int32, c_void_p]),
     "av2x_warp_affine": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_warp_affine_simple": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_roi_mask": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_add_agent_vector": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "av2x_hgt_attention": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

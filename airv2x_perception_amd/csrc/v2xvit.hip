@@ -22,7 +22,9 @@ __device__ __forceinline__ float lin_m1_1(int i, int n) {
     return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
 }
 
-template <int CK>  // C = 64 * CK: 16 lanes x float4 per pixel chunk
+// AC = align_corners of F.affine_grid / F.grid_sample: true for warp_affine (:337-381), false for
+// warp_affine_simple (:327-334): base grid linspace(-1,1,n)*(n-1)/n and unnormalise ((g+1)*n - 1)/2.
+template <int CK, bool AC>  // C = 64 * CK: 16 lanes x float4 per pixel chunk
 __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ src, const float* __restrict__ theta,
                                                           float* __restrict__ dst, int H, int W) {
     const int t = threadIdx.x & 15;
@@ -31,11 +33,13 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
     if (pix >= H * W) return;
     const int i = pix / W, j = pix - i * W;
     const float* th = theta + n * 6;
-    const float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    if (!AC) { xn = (xn * (float)(W - 1)) / (float)W; yn = (yn * (float)(H - 1)) / (float)H; }
     const float gx = th[0] * xn + th[1] * yn + th[2];
     const float gy = th[3] * xn + th[4] * yn + th[5];
-    const float ix = ((gx + 1.f) * 0.5f) * (float)(W - 1);   // grid_sampler_unnormalize, align_corners=True
-    const float iy = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+    // grid_sampler_unnormalize
+    const float ix = AC ? ((gx + 1.f) * 0.5f) * (float)(W - 1) : ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    const float iy = AC ? ((gy + 1.f) * 0.5f) * (float)(H - 1) : ((gy + 1.f) * (float)H - 1.f) * 0.5f;
     const float x0f = floorf(ix), y0f = floorf(iy);
     const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
     const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
@@ -324,20 +328,31 @@ __global__ void split_combine_kernel(const float4* __restrict__ s0, const float4
 
 }  // namespace
 
-extern "C" int av2x_warp_affine(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w, int32_t c,
-                                av2x_stream_t stream) {
+template <bool AC>
+static int warp_launch(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w, int32_t c,
+                       av2x_stream_t stream) {
     if (n == 0) return 0;
     if (!src || !theta || !dst) return av2x::fail("av2x_warp_affine: null argument");
     if (n < 0 || h <= 0 || w <= 0) return av2x::fail("av2x_warp_affine: bad sizes");
     const dim3 grid((h * w + 15) / 16, n), block(256);
     hipStream_t st = av2x::as_stream(stream);
     switch (c) {
-        case 64: hipLaunchKernelGGL(warp_affine_kernel<1>, grid, block, 0, st, src, theta, dst, h, w); break;
-        case 128: hipLaunchKernelGGL(warp_affine_kernel<2>, grid, block, 0, st, src, theta, dst, h, w); break;
-        case 256: hipLaunchKernelGGL(warp_affine_kernel<4>, grid, block, 0, st, src, theta, dst, h, w); break;
+        case 64: hipLaunchKernelGGL((warp_affine_kernel<1, AC>), grid, block, 0, st, src, theta, dst, h, w); break;
+        case 128: hipLaunchKernelGGL((warp_affine_kernel<2, AC>), grid, block, 0, st, src, theta, dst, h, w); break;
+        case 256: hipLaunchKernelGGL((warp_affine_kernel<4, AC>), grid, block, 0, st, src, theta, dst, h, w); break;
         default: return av2x::fail("av2x_warp_affine: c=%d unsupported (64/128/256)", c);
     }
     return av2x::check_launch("warp_affine_kernel");
+}
+
+extern "C" int av2x_warp_affine(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w, int32_t c,
+                                av2x_stream_t stream) {
+    return warp_launch<true>(src, theta, dst, n, h, w, c, stream);
+}
+
+extern "C" int av2x_warp_affine_simple(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w,
+                                       int32_t c, av2x_stream_t stream) {
+    return warp_launch<false>(src, theta, dst, n, h, w, c, stream);
 }
 
 extern "C" int av2x_roi_mask(const float* theta, const int32_t* cav_mask, float* mask, int32_t n, int32_t h, int32_t w,

@@ -70,3 +70,19 @@ def warp_affine(src, M, dsize, mode="bilinear", padding_mode="zeros", align_corn
     _lib.check(lib.av2x_warp_affine(c_void_p(x.data_ptr()), c_void_p(theta.data_ptr()), c_void_p(y.data_ptr()), B, H, W, C,
                                     c_void_p(torch.cuda.current_stream().cuda_stream)), "av2x_warp_affine")
     return y.permute(0, 3, 1, 2).contiguous()
+
+
+def warp_affine_simple(src, M, dsize, mode="bilinear", padding_mode="zeros", align_corners=False):
+    """Reference signature (torch_transformation_utils.py:327-334): ``M`` (B,2,3) is ALREADY the normalised theta of
+    F.affine_grid; the reference ignores ``mode`` / ``padding_mode`` here (grid_sample defaults: bilinear, zeros)."""
+    B, C, H, W = src.shape
+    if tuple(dsize) != (H, W):
+        raise NotImplementedError("dsize must equal the source size")
+    lib = _lib.load()
+    theta = torch.as_tensor(M, dtype=torch.float32).to(src.device).contiguous()
+    x = src.permute(0, 2, 3, 1).contiguous().float()
+    y = torch.empty_like(x)
+    fn = lib.av2x_warp_affine if align_corners else lib.av2x_warp_affine_simple
+    _lib.check(fn(c_void_p(x.data_ptr()), c_void_p(theta.data_ptr()), c_void_p(y.data_ptr()), B, H, W, C,
+                  c_void_p(torch.cuda.current_stream().cuda_stream)), "av2x_warp_affine_simple")
+    return y.permute(0, 3, 1, 2).contiguous()

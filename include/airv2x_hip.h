@@ -270,6 +270,10 @@ int av2x_layernorm_act(const float* x, const float* gamma, const float* beta, fl
  * ------------------------------------------------------------------------------------ */
 int av2x_warp_affine(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w,
                      int32_t c, av2x_stream_t stream);
+/* warp_affine_simple :327-334: the same sampling with align_corners=False; theta is the caller's normalised 2x3
+ * (the warp used by the OPV2V-style Where2Comm / When2Com / V2VNet fusion variants, where2comm_attn.py:293-307). */
+int av2x_warp_affine_simple(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w,
+                            int32_t c, av2x_stream_t stream);
 int av2x_roi_mask(const float* theta, const int32_t* cav_mask, float* mask, int32_t n, int32_t h, int32_t w,
                   av2x_stream_t stream);
 int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_t elems_per_agent, int32_t c,

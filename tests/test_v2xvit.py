@@ -141,3 +141,21 @@ def test_gpu_window_attention_kernel(heads, dh, ws, force_valu):
     _lib.check(lib.av2x_window_attention(P(bd), ctot, coff, P(pd), P(out), n, H, W, heads, dh, ws | (0x100 if force_valu else 0),
                                          c_void_p(torch.cuda.current_stream().cuda_stream)), "window attention")
     assert_close(out.cpu(), ref, 1e-5, 1e-5, f"window attention heads={heads} dh={dh} ws={ws}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("align", [False, True])
+def test_gpu_warp_affine_simple_matches_torch(align):
+    """warp_affine_simple (torch_transformation_utils.py:327-334) = F.affine_grid + F.grid_sample on the caller's theta."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11 + int(align))
+    B, C, H, Wd = 3, 64, 25, 44
+    src = torch.randn(B, C, H, Wd, generator=g)
+    ang = torch.tensor([0.0, 0.35, -1.2])
+    M = torch.stack([torch.stack([torch.cos(ang), -torch.sin(ang) * 0.6, torch.tensor([0.0, 0.15, -0.4])], 1),
+                     torch.stack([torch.sin(ang) * 1.5, torch.cos(ang), torch.tensor([0.0, -0.2, 0.3])], 1)], 1)   # (B,2,3)
+    ref = F.grid_sample(src, F.affine_grid(M, [B, C, H, Wd], align_corners=align), align_corners=align)
+    out = W.warp_affine_simple(src.cuda(), M, (H, Wd), align_corners=align)
+    assert_close(out.cpu(), ref, 1e-4, 1e-4, f"warp_affine_simple align_corners={align}")
+    ident = W.warp_affine_simple(src.cuda(), torch.tensor([[[1.0, 0, 0], [0, 1.0, 0]]]).repeat(B, 1, 1), (H, Wd), align_corners=align)
+    assert_close(ident.cpu(), src, 1e-4, 1e-4, "identity theta")   # pixel centres up to fp32 rounding of the grid
