@@ -209,29 +209,31 @@ __global__ void pp_iou_mask(const float* __restrict__ corners, const int* __rest
     if ((threadIdx.x & 63) == 0 && (j >> 6) < words) mask[(size_t)i * words + (j >> 6)] = bal;
 }
 
-__global__ __launch_bounds__(1024) void pp_greedy(const unsigned long long* __restrict__ mask, const int* __restrict__ ntop,
-                                                  int words, int staged, int* __restrict__ pick, int* __restrict__ npick) {
+// Greedy suppression over the precomputed bit matrix: box i is picked iff no earlier pick overlaps it; a pick ORs
+// its row into `removed`.  Inherently sequential -> ONE wave; `removed` lives in registers (lane w holds word w,
+// words <= 64), the alive test is a v_readlane of the (uniform) word i>>6, rows come from LDS when they fit.
+__global__ __launch_bounds__(64) void pp_greedy(const unsigned long long* __restrict__ mask, const int* __restrict__ ntop,
+                                                int words, int staged, int* __restrict__ pick, int* __restrict__ npick) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];  // [m][words] when it fits (staged)
-    __shared__ volatile unsigned long long removed[64];
     const int m = ntop[0];
-    if (staged)
-        for (int i = threadIdx.x; i < m * words; i += blockDim.x) rows[i] = mask[i];
-    if (threadIdx.x < 64) removed[threadIdx.x] = 0;
-    __syncthreads();
-    if (threadIdx.x < 64) {  // one wave does the inherently sequential pass
-        int np = 0;
-        for (int i = 0; i < m; ++i) {
-            const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;
-            if (!dead) {
-                if (threadIdx.x == 0) pick[np] = i;
-                ++np;
-                if ((int)threadIdx.x < words)
-                    removed[threadIdx.x] |= staged ? rows[(size_t)i * words + threadIdx.x] : mask[(size_t)i * words + threadIdx.x];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (threadIdx.x == 0) npick[0] = np;
+    const int lane = threadIdx.x;
+    if (staged) {
+        for (int i = lane; i < m * words; i += 64) rows[i] = mask[i];
+        __syncthreads();
     }
+    unsigned long long removed = 0ull;   // word `lane` of the removed set
+    int np = 0;
+    for (int i = 0; i < m; ++i) {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, i >> 6);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), i >> 6);
+        const unsigned long long wrd = ((unsigned long long)hi << 32) | lo;
+        if (!((wrd >> (i & 63)) & 1ull)) {       // uniform branch
+            if (lane == 0) pick[np] = i;
+            ++np;
+            if (lane < words) removed |= staged ? rows[(size_t)i * words + lane] : mask[(size_t)i * words + lane];
+        }
+    }
+    if (lane == 0) npick[0] = np;
 }
 
 __global__ __launch_bounds__(1024) void pp_final(const float* __restrict__ boxes, const float* __restrict__ corners,
@@ -396,7 +398,7 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
                                   128 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(pp_greedy, dim3(1), dim3(1024), lds, st, mask, ntop, words, lds > 0 ? 1 : 0, pick, npick);
+    hipLaunchKernelGGL(pp_greedy, dim3(1), dim3(64), lds, st, mask, ntop, words, lds > 0 ? 1 : 0, pick, npick);
     hipLaunchKernelGGL(pp_final, dim3(1), dim3(1024), 0, st, boxes, corners, cscore, label, kept, order, pick, npick, p, inr,
                        out_corners, out_scores, out_labels, out_boxes, out_index, cand, nout);
     return av2x::check_launch("av2x_postprocess");
