@@ -733,8 +733,9 @@ class FramePipeline:
         self.events = [None] * depth
         self.i = 0
 
-    def submit(self, data_dict, **kw):
-        """Enqueue one frame; returns (output dict, event recorded on the frame's stream)."""
+    def submit(self, data_dict, after=None, **kw):
+        """Enqueue one frame; returns (output dict, event recorded on the frame's stream).  ``after(out, slot)`` is
+        called inside the frame's stream context (e.g. VoxelPostprocessor.launch): its kernels join the frame."""
         k = self.i % len(self.engines)
         self.i += 1
         s = self.streams[k]
@@ -747,6 +748,8 @@ class FramePipeline:
         finally:
             eng.stream_k = saved
         with torch.cuda.stream(s):
+            if after is not None:
+                out = after(out, k)
             ev = torch.cuda.Event()
             ev.record(s)
         self.events[k] = ev

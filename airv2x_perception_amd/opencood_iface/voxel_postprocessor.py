@@ -71,8 +71,8 @@ class VoxelPostprocessor:
                                "sample": flat[rows].double().cpu()}
         return d
 
-    def _buffers(self, dev, H, W, A):
-        key = (str(dev), H, W, A)
+    def _buffers(self, dev, H, W, A, slot=0):
+        key = (str(dev), H, W, A, slot)
         b = self._ws.get(key)
         if b is None:
             lib = _lib.load()
@@ -91,6 +91,24 @@ class VoxelPostprocessor:
 
     @torch.no_grad()
     def post_process_airv2x(self, data_dict, output_dict, return_counts=False):
+        return self.finish(self.launch(data_dict, output_dict), return_counts)
+
+    @staticmethod
+    def finish(handle, return_counts=False):
+        """Second half of post_process_airv2x: the one host read-back (5 counters) and the exact-shape slices."""
+        b = handle
+        counts = b["counts"][:5].tolist()
+        if counts[0] == 0:
+            res = (None, None, None, None)
+        else:
+            k = counts[4]
+            res = (b["corners"][:k].clone(), b["scores"][:k].clone(), b["labels"][:k].to(torch.int64), b["boxes"][:k].clone())
+        return res + (counts, b["index"][:counts[4]].clone()) if return_counts else res
+
+    @torch.no_grad()
+    def launch(self, data_dict, output_dict, slot=0):
+        """First half: enqueue av2x_postprocess on the current stream into buffer set ``slot`` and return the handle
+        for ``finish`` -- no host synchronisation (frames kept in flight by FramePipeline finish later)."""
         if len(data_dict) != 1:
             raise NotImplementedError("intermediate fusion hands over exactly one entry ('ego'); late fusion is out of scope")
         (cav_id, cav), = data_dict.items()
@@ -111,7 +129,7 @@ class VoxelPostprocessor:
         T = (T.detach().cpu().numpy() if isinstance(T, torch.Tensor) else np.asarray(T)).astype(np.float32).reshape(16)
         t16 = (c_float * 16)(*[float(v) for v in T])
         r6 = (c_float * 6)(*[float(v) for v in self.lidar_range])
-        b = self._buffers(dev, H, W, A)
+        b = self._buffers(dev, H, W, A, slot)
         lib = _lib.load()
         psm, rm, obj = psm.contiguous().float(), rm.contiguous().float(), obj.contiguous().float()
         st = c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -121,10 +139,4 @@ class VoxelPostprocessor:
                                         float(self.params["nms_thresh"]), 1 if self.params["order"] == "hwl" else 0,
                                         self.nms_top, P(b["ws"]), P(b["corners"]), P(b["scores"]), P(b["labels"]),
                                         P(b["boxes"]), P(b["index"]), P(b["counts"]), st), "av2x_postprocess")
-        counts = b["counts"][:5].tolist()  # the one host read-back of the whole post-process
-        if counts[0] == 0:
-            res = (None, None, None, None)
-        else:
-            k = counts[4]
-            res = (b["corners"][:k].clone(), b["scores"][:k].clone(), b["labels"][:k].to(torch.int64), b["boxes"][:k].clone())
-        return res + (counts, b["index"][:counts[4]].clone()) if return_counts else res
+        return b

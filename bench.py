@@ -265,6 +265,26 @@ def main():
                                    "counts_cand_filtered_nmsin_picked_final": boxes[4],
                                    "note": "model + av2x_postprocess per frame, one 20-byte host read-back of the counts"}
 
+        if a.inflight > 1:   # the same with the frames (and their post-process) kept in flight; boxes are read one lap later
+            pend = [None] * a.inflight
+            nbox = 0
+            for it in range(a.inflight + a.steps):
+                if it == a.inflight:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                k = it % a.inflight
+                if pend[k] is not None:
+                    pend[k][1].synchronize()
+                    nbox += post.finish(pend[k][0], return_counts=True)[4][4]
+                pend[k] = pipe.submit(dd, after=lambda o, slot: post.launch(data, {"ego": o}, slot=slot))
+            for h in pend:
+                h[1].synchronize()
+                post.finish(h[0])
+            torch.cuda.synchronize()
+            qdt = (time.perf_counter() - t0) / a.steps
+            res["with_postprocess"]["pipelined"] = {"frames_per_s": round(1.0 / qdt, 2), "ms_per_step": round(qdt * 1e3, 3),
+                                                    "frames_in_flight": a.inflight}
+
         # third figure: the whole chain from raw clouds (prepare -> voxelize -> model -> post-process), sequential
         from airv2x_perception_amd.opencood_iface.voxelizer import prepare_points, voxelize_points
         ppc = hy["preprocess"]
