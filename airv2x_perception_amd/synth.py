@@ -399,6 +399,36 @@ def build_data_dict(voxelized, types, device="cpu", max_cav_num=15):
     return dd
 
 
+def merge_frames(frames):
+    """Batch several B = 1 dicts of build_data_dict into one B = len(frames) dict the way the reference's collate does
+    (intermediate_fusion_dataset.py:763-867, merge_features_to_dict :1080-1121): per agent type the voxel tensors
+    are concatenated and the agent index column counts the type's agents across the whole batch; ``record_len`` holds
+    the per-sample counts and ``batch_idxs`` the samples in which the type is present."""
+    B = len(frames)
+    dd = {}
+    for t in AGENT_TYPES:
+        feats, coords, nums, rl, present, base = [], [], [], [], [], 0
+        for b, f in enumerate(frames):
+            d = f[t]
+            k = int(d["record_len"][0]) if len(d["batch_idxs"]) else 0
+            rl.append(k)
+            if k == 0:
+                continue
+            present.append(b)
+            lid = d["batch_merged_lidar_features_torch"]
+            c = lid["voxel_coords"].clone()
+            c[:, 0] += base
+            feats.append(lid["voxel_features"]); coords.append(c); nums.append(lid["voxel_num_points"])
+            base += k
+        dd[t] = {"batch_merged_lidar_features_torch": None if not present else {
+                     "voxel_features": torch.cat(feats, 0), "voxel_coords": torch.cat(coords, 0), "voxel_num_points": torch.cat(nums, 0)},
+                 "batch_merged_cam_inputs": None, "record_len": torch.tensor(rl, dtype=torch.int32), "batch_idxs": present}
+    dd["record_len"] = torch.cat([f["record_len"] for f in frames])
+    for k in ("pairwise_t_matrix_collab", "img_pairwise_t_matrix_collab", "prior_encoding", "spatial_correction_matrix"):
+        dd[k] = torch.cat([f[k] for f in frames], 0)
+    return dd
+
+
 def sort_types(types):
     order = {t: i for i, t in enumerate(AGENT_TYPES)}
     idx = sorted(range(len(types)), key=lambda i: (order[types[i]], i))

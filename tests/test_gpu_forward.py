@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from airv2x_perception_amd import synth
 from oracle import where2comm_oracle as orc
 from tests.helpers import assert_close, case_from_fixture, load_fixture, sample
 
@@ -94,3 +95,28 @@ def test_module_contract():
     assert_close(o2["rm"].cpu(), ref["rm"], 5e-4, 5e-4, "rm after reload")
     with pytest.raises(NotImplementedError):
         model.train()(dd)
+
+
+def test_batch_of_two_frames_equals_two_single_frames():
+    """B = 2 (the reference's collate layout, different agent mixes per sample): the fusion is per sample, so the batched
+    forward must reproduce the two single-frame forwards bit for bit; comm statistics are per-batch sums / means."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    fx = load_fixture("w2c_small_n3")
+    hy, args, sd, dd3, voxd, types = case_from_fixture(fx)           # sample 0: vehicle, rsu, drone
+    dd2 = synth.build_data_dict([voxd[0], voxd[2]], ["vehicle", "drone"], max_cav_num=args["max_cav_num"])   # sample 1
+    both = synth.merge_frames([dd3, dd2])
+    assert both["record_len"].tolist() == [3, 2] and both["vehicle"]["record_len"].tolist() == [1, 1]
+    assert both["rsu"]["batch_idxs"] == [0] and both["drone"]["batch_idxs"] == [0, 1]
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    o3 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd3, sync_comm_rate=True).items()}
+    o2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd2, sync_comm_rate=True).items()}
+    ob = eng.forward(both, sync_comm_rate=True)
+    for k in ("psm", "rm", "obj"):
+        assert ob[k].shape[0] == 2
+        assert torch.equal(ob[k][0:1], o3[k]) and torch.equal(ob[k][1:2], o2[k]), k
+    assert ob["comm_rate"] == o3["comm_rate"] + o2["comm_rate"]
+    assert abs(float(ob["com"]) - (float(o3["com"]) + float(o2["com"])) / 2) < 1e-6      # where2comm_fuse.py:147 mean over B
