@@ -43,9 +43,10 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
-        if (not force and os.path.exists(o) and os.path.getmtime(o) > os.path.getmtime(s)
-                and os.path.getmtime(o) > os.path.getmtime(os.path.join(CSRC, "av2x_common.hpp"))
-                and os.path.getmtime(o) > os.path.getmtime(os.path.join(ROOT, "include", "airv2x_hip.h"))):
+        # headers / .inc files are included by several sources: any of them newer than the object -> recompile
+        hdr_t = max([os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if not f.endswith(".hip")]
+                    + [os.path.getmtime(os.path.join(ROOT, "include", "airv2x_hip.h"))])
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
             continue
         cmd = [cc, *flags, "-c", s, "-o", o]
         if verbose:

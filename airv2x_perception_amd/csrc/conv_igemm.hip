@@ -14,78 +14,9 @@
 // j = 0..3, so both operands of four consecutive MFMAs come from ONE 16-byte LDS read each.
 // The workgroup->tile map is XCD-aware (block b runs on XCD b%8): every XCD walks a
 // contiguous range of tiles so that halo rows / weights are re-used out of its private L2.
-#include "av2x_common.hpp"
+#include "conv_common.hpp"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvParams {
-    const float* in;
-    const float* w;
-    const float* scale;
-    const float* shift;
-    const float* res;  // optional residual, same layout as out (AV2X_CONV mode only)
-    float* out;
-    int H, W, Cin, in_ctot, in_coff;
-    int Ho, Wo, HoWo;
-    int Cout, CoutP, out_ctot, out_coff;
-    int ks, stride, pad, relu, mode, up;
-    int M, tiles_n, cchunks, steps;
-    unsigned in_bytes, w_bytes;
-    // stream-K (SK kernels only): the tiles x steps iteration space is cut into gridDim.x equal
-    // contiguous ranges of sk_per iterations; partial accumulators go to ws (see conv_fixup_f32)
-    int sk_per, sk_total;
-    float* ws;
-};
-
-constexpr int BK = 32;
-constexpr int LDA = 36;
-
-// Epilogue shared by the GEMM kernel and the stream-K fix-up: folded BN / bias, activation, residual,
-// and the NHWC-slice / deconv-scatter / NCHW addressing.  C/D map of the 32x32 MFMA:
-// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[MT][NT], int mw, int nw, int lane) {
-    const int li = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const int n = nw + c * 32 + li;  // GEMM column
-        int co = n, ij = 0;
-        if (p.mode == AV2X_DECONV) { ij = n / p.Cout; co = n - ij * p.Cout; }
-        const bool nok = (p.mode == AV2X_DECONV) ? (n < p.CoutP) : (n < p.Cout);
-        const float sc = (nok && p.scale) ? p.scale[co] : 1.f;
-        const float sh = nok ? p.shift[co] : 0.f;
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (!nok || m >= p.M) continue;
-                float v = acc[a][c][r] * sc + sh;
-                if (p.relu == 1) v = fmaxf(v, 0.f);
-                else if (p.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // exact GELU (nn.GELU())
-                size_t off;
-                if (p.mode == AV2X_CONV) {
-                    off = (size_t)m * p.out_ctot + p.out_coff + co;
-                    if (p.res) v += p.res[off];
-                } else {
-                    const int img = m / p.HoWo, rem = m - img * p.HoWo;
-                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    if (p.mode == AV2X_DECONV) {
-                        const int di = ij / p.up, dj = ij - di * p.up;
-                        off = ((size_t)(img * p.Ho * p.up + ho * p.up + di) * (p.Wo * p.up) + wo * p.up + dj) * p.out_ctot +
-                              p.out_coff + co;
-                    } else {  // NCHW
-                        off = ((size_t)(img * p.Cout + co) * p.Ho + ho) * p.Wo + wo;
-                    }
-                }
-                p.out[off] = v;
-            }
-        }
-    }
-}
 
 // Stream-K fix-up: tile t was cut between workgroups g_lo..g_hi of the SK kernel; their raw accumulators
 // (same per-thread layout as the kernel: [slot][(a*NT+c)*16+r][tid]) are summed in ascending K order
@@ -428,6 +359,8 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
     return av2x::check_launch("conv_igemm_f32 (stream-K)");
 }
 
+#include "conv_igemm_bf16.inc"
+
 }  // namespace
 
 // Persistent launch (MODE 2): `wgs` workgroups, each a contiguous range of whole tiles.
@@ -461,7 +394,7 @@ extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const f
 }
 
 extern "C" uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs) {
-    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x0fff;
+    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x07ff;
     return (tile & 0x2000) ? 2ull * (unsigned)sk_wgs * bm * bn * sizeof(float) : 0ull;
 }
 
@@ -513,7 +446,19 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     p.w_bytes = (unsigned)w_bytes;
     hipStream_t st = av2x::as_stream(stream);
 
-    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x0fff;
+    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x07ff;
+    if (d->tile & 0x0800) {   // bf16 matrix-core operands ("AMP" mode): w is the bf16 packing [tap][cin/8][coutp][8]
+        p.w_bytes = (unsigned)(w_bytes / 2);
+        if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
+        const bool w8b = (d->tile & 0x8000) != 0;
+        if (w8b && bm == 128 && bn == 128) return launch_bf16<128, 128, 64, 32>(p, st);
+        if (w8b && bm == 128 && bn == 64) return launch_bf16<128, 64, 32, 32>(p, st);
+        if (!w8b && bm == 128 && bn == 128) return launch_bf16<128, 128, 64, 64>(p, st);
+        if (!w8b && bm == 128 && bn == 64) return launch_bf16<128, 64, 64, 32>(p, st);
+        if (!w8b && bm == 64 && bn == 64) return launch_bf16<64, 64, 32, 32>(p, st);
+        if (!w8b && bm == 128 && bn == 32) return launch_bf16<128, 32, 32, 32>(p, st);
+        return av2x::fail("av2x_conv2d: unsupported bf16 tile %dx%d", bm, bn);
+    }
     if (d->tile & 0x1000) {  // persistent whole-tile schedule: sk_wgs workgroups (prefetch-2 pipeline)
         if (d->sk_wgs <= 0) return av2x::fail("av2x_conv2d: persistent tile needs sk_wgs > 0");
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ..synth import cobevt_param_spec
-from .airv2x_where2com import _install
+from .airv2x_where2com import _amp_requested, _install
 from .cobevt_engine import CoBEVTEngine
 
 
@@ -60,4 +60,6 @@ class Airv2xCoBEVT(nn.Module):
     def forward(self, data_dict):
         if self.training:
             raise NotImplementedError("training is not built yet; call .eval()")
-        return self.engine().forward(data_dict)
+        eng = self.engine()
+        eng.amp = _amp_requested(self)
+        return eng.forward(data_dict)

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from ..synth import synthetic_tensor, v2xvit_param_spec
-from .airv2x_where2com import _install
+from .airv2x_where2com import _amp_requested, _install
 from .v2xvit_engine import V2XViTEngine
 
 
@@ -60,4 +60,6 @@ class Airv2xV2XVit(nn.Module):
     def forward(self, data_dict):
         if self.training:
             raise NotImplementedError("training is not built yet; call .eval()")
-        return self.engine().forward(data_dict, sync_comm_rate=self.sync_comm_rate)
+        eng = self.engine()
+        eng.amp = _amp_requested(self)
+        return eng.forward(data_dict, sync_comm_rate=self.sync_comm_rate)

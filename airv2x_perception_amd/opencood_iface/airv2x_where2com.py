@@ -32,6 +32,18 @@ class _Node(nn.Module):
         return len(self._modules)
 
 
+def _amp_requested(module):
+    """AMP mode = the caller wrapped the forward in ``torch.autocast("cuda", ...)`` (as the reference's train.py
+    does for its validation pass, tools/train.py:212-220) or set ``module.amp = True``: Conv2d / Linear products
+    then run on the bf16 matrix cores with fp32 accumulation (conv_igemm_bf16), everything else stays fp32."""
+    if getattr(module, "amp", None) is not None:
+        return bool(module.amp)
+    try:
+        return bool(torch.is_autocast_enabled("cuda"))
+    except TypeError:  # older signature
+        return bool(torch.is_autocast_enabled())
+
+
 def _install(root, key, tensor, is_buffer):
     parts = key.split(".")
     node = root
@@ -99,4 +111,6 @@ class Airv2xWhere2com(nn.Module):
     def forward(self, data_dict):
         if self.training:
             raise NotImplementedError("training (backward + random top-k masks) is not built yet; call .eval()")
-        return self.engine().forward(data_dict, sync_comm_rate=self.sync_comm_rate)
+        eng = self.engine()
+        eng.amp = _amp_requested(self)
+        return eng.forward(data_dict, sync_comm_rate=self.sync_comm_rate)

@@ -27,19 +27,27 @@ from ctypes import byref, c_float, c_void_p
 import torch
 
 from .. import _lib
-from .packing import fold_bn, pack_conv_weight, pack_deconv_weight
+from .packing import fold_bn, pack_conv_weight, pack_deconv_weight, to_bf16_koct
 
 AGENT_TYPES = ("vehicle", "rsu", "drone")
 TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_models"}
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
+        self._w16 = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
+
+
+def _w16(L):
+    """bf16 k-oct packing of the layer's weights (AMP mode), built from the fp32 packing on first use."""
+    if L._w16 is None:
+        L._w16 = to_bf16_koct(L.w)
+    return L._w16
 
 
 def _ptr(t):
@@ -92,6 +100,9 @@ class Where2ComEngine:
         # but the K-split changes the fp32 summation order (<= ~1e-5 relative), so results then depend on
         # the tuning outcome / agent count.  False = every candidate is bit-identical (reproducible mode).
         self.stream_k = os.environ.get("AV2X_STREAM_K", "1") != "0"
+        # AMP mode (what torch.autocast does to Conv2d / Linear): bf16 matrix-core operands, fp32 accumulation and
+        # fp32 activations in HBM (conv_igemm_bf16); LayerNorm / softmax / attention stay fp32.  Off = exact fp32.
+        self.amp = False
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
@@ -117,7 +128,7 @@ class Where2ComEngine:
                   "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready"):
             setattr(other, k, getattr(self, k))
         other.tile_cache = self.tile_cache
-        other.autotune, other.conv_tile, other.stream_k = self.autotune, self.conv_tile, self.stream_k
+        other.autotune, other.conv_tile, other.stream_k, other.amp = self.autotune, self.conv_tile, self.stream_k, self.amp
         return other
 
     def graph_active(self):
@@ -240,11 +251,12 @@ class Where2ComEngine:
         d.out_coff = out_coff
         d.ks, d.stride, d.pad, d.relu, d.mode, d.up = L.ks, L.stride, L.pad, L.relu, L.mode, L.up
         d.sk_wgs = 0
+        wgt = _w16(L) if self.amp else L.w
         if self.conv_tile:
             d.tile = self.conv_tile
             d.sk_wgs = self.conv_sk_wgs if (d.tile & 0x2000) else 0
         elif self.autotune:
-            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, self.stream_k)
+            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, self.stream_k, self.amp)
             t = self.tile_cache.get(key)
             if t is None:
                 t = self._tune(d, x, L, out)
@@ -252,23 +264,23 @@ class Where2ComEngine:
             d.tile, d.sk_wgs = t
         else:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
-            d.tile = (bm << 16) | bn
+            d.tile = (bm << 16) | bn | (0x0800 if self.amp else 0)
         bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff  # bn keeps the variant flags (profile key)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if d.tile & 0x2000:   # stream-K needs the partial-accumulator workspace (0x1000 = persistent does not)
             ws = self.sk_workspace()
-            _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
+            _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
                                                _ptr(out), _ptr(ws), ws.numel() * 4, self.stream()), "av2x_conv2d_sk")
         else:
-            _lib.check(self.lib.av2x_conv2d_res(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
+            _lib.check(self.lib.av2x_conv2d_res(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
                                                 _ptr(out), self.stream()), "av2x_conv2d")
         if self.profile is not None:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x0fff))
+            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x07ff))
             if bn & 0x2000:  # launch_sk(): equal iteration ranges, then the number of non-empty ones
                 total = wgs * L.ks * L.ks * (L.cin // 32)
                 per = -(-total // min(d.sk_wgs, total))
@@ -290,6 +302,9 @@ class Where2ComEngine:
     # (1x1 convs / Linears, <= PERSIST_MAX_STEPS K-steps per tile) where the per-tile prologue is a large share
     PERSIST_CANDIDATES = ((128, 64 | 0xd000, 512), (128, 128 | 0xd000, 512), (64, 64 | 0x5000, 1024), (128, 64 | 0x5000, 768))
     PERSIST_MAX_STEPS = 16
+    # AMP mode: conv_igemm_bf16 tiles (flag 0x0800; 0x8000 = 8 waves)
+    AMP_CANDIDATES = ((128, 128 | 0x8800, 0), (128, 64 | 0x8800, 0), (64, 64 | 0x0800, 0), (128, 64 | 0x0800, 0),
+                      (128, 128 | 0x0800, 0), (128, 32 | 0x0800, 0))
 
     def sk_workspace(self):
         """Partial-accumulator scratch of av2x_conv2d_sk, sized for the largest stream-K candidate."""
@@ -302,8 +317,9 @@ class Where2ComEngine:
         the K order of every output element does not depend on the tile).  Runs outside graph capture."""
         if torch.cuda.is_current_stream_capturing():
             bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
-            return (bm << 16) | bn, 0
+            return (bm << 16) | bn | (0x0800 if self.amp else 0), 0
         best, best_t = None, float("inf")
+        wgt = _w16(L) if self.amp else L.w
         # tune into a scratch output: `out` may alias the input / residual (in-place transformer updates)
         ho = d.ho * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         wo = d.wo * (L.up if L.mode == _lib.AV2X_DECONV else 1)
@@ -311,15 +327,17 @@ class Where2ComEngine:
         cands = [(bm, bn, 0) for bm, bn in self.TILE_CANDIDATES]
         if L.ks * L.ks * (L.cin // 32) <= self.PERSIST_MAX_STEPS:
             cands += list(self.PERSIST_CANDIDATES)
-        if self.stream_k and -(-(d.n * d.ho * d.wo) // 128) * (L.coutp // 64 if L.coutp % 64 == 0 else 1 << 30) <= self.SK_MAX_TILES:
+        if self.amp:
+            cands = list(self.AMP_CANDIDATES)
+        elif self.stream_k and -(-(d.n * d.ho * d.wo) // 128) * (L.coutp // 64 if L.coutp % 64 == 0 else 1 << 30) <= self.SK_MAX_TILES:
             cands += list(self.SK_CANDIDATES)
         ws = self.sk_workspace()
         st = self.stream()
         for bm, bn, g in cands:
-            if L.coutp % (bn & 0x0fff) or ((bn & 0x0fff) == 32 and L.coutp != 32):
+            if L.coutp % (bn & 0x07ff) or ((bn & 0x07ff) == 32 and L.coutp != 32):
                 continue
             d.tile, d.sk_wgs = (bm << 16) | bn, g
-            call = lambda: _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), None,
+            call = lambda: _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), None,
                                                               _ptr(scratch), _ptr(ws), ws.numel() * 4, st), "av2x_conv2d")
             call()  # warm-up (module load, L2)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -48,3 +48,13 @@ def pack_deconv_weight(w):
     ncol = s * s * cout
     t = w.permute(0, 2, 3, 1).reshape(cin // 4, 4, ncol).permute(0, 2, 1)
     return t.reshape(1, cin // 4, ncol, 4).contiguous(), ncol
+
+
+def to_bf16_koct(packed):
+    """fp32 k-quad packing (T, Cin/4, CoutP, 4) of pack_conv_weight / pack_deconv_weight -> the bf16 k-oct packing
+    (T, Cin/8, CoutP, 8) read by conv_igemm_bf16 (tile flag 0x0800): element [t][o][n][e] = W[k = 8 o + e][n],
+    rounded to bf16 (round-to-nearest-even, as torch.autocast does)."""
+    T, q, n, four = packed.shape
+    assert four == 4 and q % 2 == 0
+    t = packed.reshape(T, q // 2, 2, n, 4).permute(0, 1, 3, 2, 4).reshape(T, q // 2, n, 8)
+    return t.to(torch.bfloat16).contiguous()

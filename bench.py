@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); --amp runs only
 
 
 def pmc_traffic(kernel_key, grid_counts):
@@ -77,6 +78,9 @@ def parse():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--amp", action="store_true",
+                    help="AMP mode: bf16 matrix-core operands with fp32 accumulation for every Conv2d / Linear (what "
+                         "torch.autocast does in the reference's train.py validation pass); NOT the headline configuration")
     ap.add_argument("--per-shape", action="store_true", help="add a per-layer-shape table to the roofline object")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a captured HIP graph (1) or eager (0); "
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
@@ -183,7 +187,9 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.sync_comm_rate = False  # no host sync inside the frame; comm_rate stays a device scalar
+    model.amp = bool(a.amp)
     eng = model.engine()
+    eng.amp = bool(a.amp)
     eng.use_graph = bool(a.graph) and a.mode == "replica"
     if a.mode == "shard":
         frame = ShardedFrame(EngineBackend(eng))
@@ -224,7 +230,9 @@ def main():
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        **({"precision_note": "AMP mode: bf16 MFMA operands, fp32 accumulate, fp32 activations in HBM; max |err| vs the fp32 path "
+                              "is reported by tests/test_amp.py -- not comparable with the fp32 headline"} if a.amp else {}),
+        "dtype": "bf16" if a.amp else "f32", "data": "synthetic",
         "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
@@ -335,17 +343,17 @@ def main():
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{k[0]}x{k[1] & 0x0fff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}"
+        tkey = lambda k: f"{k[0]}x{k[1] & 0x07ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS), 4), "traffic": traffic, "traffic_note": traffic_note,
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": f"conv_igemm_f32<{dom[0]},{dom[1] & 0x0fff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
+            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else 'f32'}<{dom[0]},{dom[1] & 0x07ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
                       + (" prefetch-2" if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x0fff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
+            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x07ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                              f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>"
-                             + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x0fff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
+                             + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x07ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},

@@ -75,6 +75,11 @@ int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
  *   (for AV2X_DECONV the GEMM column n = (i*up+j)*cout + co and W = weight[cin][co][i][j]);
  *   coutp = GEMM columns padded with zeros to a multiple of 32; cin % 32 == 0.
  * scale/shift: (cout,) applied as y = acc*scale + shift (scale may be NULL = 1).
+ * AMP mode (tile flag 0x0800, any entry point): `w` points to the bf16 k-oct packing [tap][cin/8][coutp][8]
+ *   (packing.to_bf16_koct) and the input tile is rounded to bf16 (nearest-even) on its way into LDS; products run on
+ *   v_mfma_f32_32x32x16_bf16 with fp32 accumulation, activations stay fp32 in HBM.  The result equals an fp32
+ *   convolution of the bf16-rounded operands up to summation order = what torch.autocast computes for Conv2d /
+ *   Linear (the reference's validation pass, tools/train.py:212-220).  Tiles 128x128, 128x64, 64x64, 128x32.
  * ------------------------------------------------------------------------------------ */
 enum { AV2X_CONV = 0, AV2X_DECONV = 1, AV2X_CONV_NCHW = 2 };
 
@@ -89,7 +94,8 @@ typedef struct av2x_conv_desc {
     int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
     int32_t up;                /* DECONV: kernel == stride                                */
     int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2)
-                                  | 0x2000 (stream-K, av2x_conv2d_sk only) | 0x1000 (persistent whole tiles) */
+                                  | 0x2000 (stream-K, av2x_conv2d_sk only) | 0x1000 (persistent whole tiles)
+                                  | 0x0800 (bf16 matrix-core operands: `w` is the bf16 packing, see below)   */
     int32_t sk_wgs;            /* stream-K / persistent: number of workgroups launched (else ignored) */
 } av2x_conv_desc;
 

@@ -1,0 +1,104 @@
+"""AMP mode (bf16 matrix-core operands, fp32 accumulate): kernel-level exactness against an fp32 convolution of the
+bf16-ROUNDED operands, and model-level drift against the fp32 reference goldens (reported, bounded)."""
+from ctypes import byref, c_void_p
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import assert_close, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+CASES = [
+    # n, h, w, cin, cout, ks, stride, tile
+    (2, 23, 31, 64, 64, 3, 1, (64 << 16) | 64 | 0x0800),
+    (1, 20, 36, 256, 256, 1, 1, (128 << 16) | 128 | 0x8800),
+    (3, 17, 19, 128, 256, 3, 2, (128 << 16) | 64 | 0x8800),
+    (2, 9, 14, 256, 30, 1, 1, (128 << 16) | 32 | 0x0800),      # head-like: coutp = 32, predicate on the B tile
+    (1, 12, 20, 384, 256, 1, 1, (128 << 16) | 64 | 0x0800),
+    (2, 11, 13, 128, 128, 3, 1, (128 << 16) | 128 | 0x0800),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16_conv_equals_fp32_conv_of_rounded_operands(case):
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, to_bf16_koct
+    lib = _lib.load()
+    n, h, w, cin, cout, ks, stride, tile = case
+    pad = 1 if ks == 3 else 0
+    g = torch.Generator().manual_seed(cin + cout + ks)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.bfloat16().float(), wt.bfloat16().float(), None, stride=stride, padding=pad)   # exact products, fp32 sums
+    ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ho, wo = ref.shape[2:]
+    res = torch.randn(n, ho, wo, cout, generator=g)
+    ref = F.gelu(ref) + res.permute(0, 3, 1, 2)
+    wp, coutp = pack_conv_weight(wt)
+    wh = to_bf16_koct(wp).cuda()
+    assert wh.dtype == torch.bfloat16 and wh.shape == (ks * ks, cin // 8, coutp, 8)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=ho, wo=wo, cout=cout, coutp=coutp, out_ctot=cout,
+                      out_coff=0, ks=ks, stride=stride, pad=pad, relu=2, mode=0, up=1, tile=tile, sk_wgs=0)
+    sc, sh, rd = scale.cuda(), shift.cuda(), res.cuda()   # keep the device tensors alive across the asynchronous launch
+    _lib.check(lib.av2x_conv2d_res(byref(d), _p(xd), _p(wh), _p(sc), _p(sh), _p(rd), _p(out),
+                                   c_void_p(torch.cuda.current_stream().cuda_stream)), "conv bf16")
+    assert_close(out.permute(0, 3, 1, 2).cpu(), ref, 1e-5, 1e-5, f"bf16 conv {case}")
+
+
+def _drift(out, fx, keys=("psm", "rm", "obj")):
+    rep = {}
+    for k in keys:
+        hs = int(fx["head_stride"]) if "head_stride" in fx else 1
+        a = out[k].float().cpu().numpy()[..., ::hs, ::hs]
+        rep[k] = float(np.abs(a - fx[k]).max() / max(1e-6, np.abs(fx[k]).max()))
+    return rep
+
+
+@pytest.mark.parametrize("which", ["where2com", "cobevt", "v2xvit"])
+def test_models_under_autocast_stay_close_to_the_fp32_reference(which):
+    """torch.autocast around the forward selects AMP mode (module.amp overrides).  The drift against the reference's
+    fp32 outputs is bf16 input rounding through 25-60 GEMM layers: bounded here at 6 % of the map's magnitude."""
+    if which == "where2com":
+        from airv2x_perception_amd.opencood_iface import Airv2xWhere2com as M
+        from tests.helpers import case_from_fixture
+        fx = load_fixture("w2c_small_n3")
+        hy, args, sd, dd, _, _ = case_from_fixture(fx)
+    elif which == "cobevt":
+        from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT as M
+        import tests.test_cobevt as tc
+        fx = load_fixture("cobevt_small_n3")
+        hy, args, sd, dd = tc._case(fx)
+    else:
+        from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
+        import tests.test_v2xvit as tv
+        fx = load_fixture("v2xvit_small_n3")
+        hy, args, sd, dd = tv._case(fx)
+    model = M(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    exact = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
+    assert model.engine().amp is False
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        amp = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
+    assert model.engine().amp is True
+    again = model(dd)                                   # leaving the autocast region restores the exact path
+    assert model.engine().amp is False and torch.equal(again["psm"], exact["psm"])
+    assert not torch.equal(amp["psm"], exact["psm"])
+    rep = _drift(amp, fx)
+    print(f"[amp drift {which}] max|amp - fp32 reference| / max|reference|:", {k: f"{v:.2e}" for k, v in rep.items()})
+    assert all(v < 6e-2 for v in rep.values()), rep
+    assert all(v < 1e-3 for v in _drift(exact, fx).values())
+    model.amp = True                                    # explicit switch, no autocast context
+    forced = model(dd)
+    assert torch.equal(forced["psm"], amp["psm"])

@@ -65,7 +65,7 @@ def main():
             return e0.elapsed_time(e1) * 1e3 / a.iters
 
         for tn, (bm, bn) in TILES.items():
-            if coutp % (bn & 0x0fff):
+            if coutp % (bn & 0x07ff):
                 continue
             base = run((bm << 16) | bn, 0, y0)
             line = f"   {tn:11s} dp:{base:6.1f}us {flops/base/1e6:5.1f}TF |"
