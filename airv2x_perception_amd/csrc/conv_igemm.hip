@@ -394,7 +394,7 @@ extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const f
 }
 
 extern "C" uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs) {
-    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x07ff;
+    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x03ff;
     return (tile & 0x2000) ? 2ull * (unsigned)sk_wgs * bm * bn * sizeof(float) : 0ull;
 }
 
@@ -446,7 +446,19 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     p.w_bytes = (unsigned)w_bytes;
     hipStream_t st = av2x::as_stream(stream);
 
-    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x07ff;
+    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x03ff;
+    if (d->tile & 0x0400) {   // split-3: fp32-accurate products from three bf16 terms per operand; w = [3] bf16 planes
+        p.w_bytes = (unsigned)(w_bytes / 2 * 3);
+        if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
+        const bool w8b = (d->tile & 0x8000) != 0;
+        if (w8b && bm == 128 && bn == 128) return launch_bf16x3<128, 128, 64, 32>(p, st);
+        if (w8b && bm == 128 && bn == 64) return launch_bf16x3<128, 64, 32, 32>(p, st);
+        if (!w8b && bm == 128 && bn == 128) return launch_bf16x3<128, 128, 64, 64>(p, st);
+        if (!w8b && bm == 128 && bn == 64) return launch_bf16x3<128, 64, 64, 32>(p, st);
+        if (!w8b && bm == 64 && bn == 64) return launch_bf16x3<64, 64, 32, 32>(p, st);
+        if (!w8b && bm == 128 && bn == 32) return launch_bf16x3<128, 32, 32, 32>(p, st);
+        return av2x::fail("av2x_conv2d: unsupported split-3 tile %dx%d", bm, bn);
+    }
     if (d->tile & 0x0800) {   // bf16 matrix-core operands ("AMP" mode): w is the bf16 packing [tap][cin/8][coutp][8]
         p.w_bytes = (unsigned)(w_bytes / 2);
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);

@@ -27,18 +27,19 @@ from ctypes import byref, c_float, c_void_p
 import torch
 
 from .. import _lib
-from .packing import fold_bn, pack_conv_weight, pack_deconv_weight, to_bf16_koct
+from .packing import fold_bn, pack_conv_weight, pack_deconv_weight, to_bf16_koct, to_bf16x3_koct
 
 AGENT_TYPES = ("vehicle", "rsu", "drone")
 TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_models"}
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
         self._w16 = None
+        self._w3 = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
 
@@ -48,6 +49,13 @@ def _w16(L):
     if L._w16 is None:
         L._w16 = to_bf16_koct(L.w)
     return L._w16
+
+
+def _w3(L):
+    """split-3 bf16 planes (hi, mid, lo) of the layer's weights, built from the fp32 packing on first use."""
+    if L._w3 is None:
+        L._w3 = to_bf16x3_koct(L.w)
+    return L._w3
 
 
 def _ptr(t):
@@ -103,6 +111,10 @@ class Where2ComEngine:
         # AMP mode (what torch.autocast does to Conv2d / Linear): bf16 matrix-core operands, fp32 accumulation and
         # fp32 activations in HBM (conv_igemm_bf16); LayerNorm / softmax / attention stay fp32.  Off = exact fp32.
         self.amp = False
+        # split-3 mode: fp32-ACCURATE Conv2d / Linear products on the bf16 matrix cores (every fp32 operand = three bf16
+        # terms, six partial products, fp32 accumulation; conv_igemm_bf16x3).  Error vs fp64 is at or below the fp32-MFMA
+        # kernel's (tools/split3_bench.py), results are not bit-identical to it.  Opt-in.
+        self.split3 = False
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
@@ -129,6 +141,7 @@ class Where2ComEngine:
             setattr(other, k, getattr(self, k))
         other.tile_cache = self.tile_cache
         other.autotune, other.conv_tile, other.stream_k, other.amp = self.autotune, self.conv_tile, self.stream_k, self.amp
+        other.split3 = self.split3
         return other
 
     def graph_active(self):
@@ -251,12 +264,13 @@ class Where2ComEngine:
         d.out_coff = out_coff
         d.ks, d.stride, d.pad, d.relu, d.mode, d.up = L.ks, L.stride, L.pad, L.relu, L.mode, L.up
         d.sk_wgs = 0
-        wgt = _w16(L) if self.amp else L.w
+        wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
+        vflag = 0x0800 if self.amp else (0x0400 if self.split3 else 0)
         if self.conv_tile:
             d.tile = self.conv_tile
             d.sk_wgs = self.conv_sk_wgs if (d.tile & 0x2000) else 0
         elif self.autotune:
-            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, self.stream_k, self.amp)
+            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, self.stream_k, vflag)
             t = self.tile_cache.get(key)
             if t is None:
                 t = self._tune(d, x, L, out)
@@ -264,7 +278,7 @@ class Where2ComEngine:
             d.tile, d.sk_wgs = t
         else:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
-            d.tile = (bm << 16) | bn | (0x0800 if self.amp else 0)
+            d.tile = (bm << 16) | bn | vflag
         bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff  # bn keeps the variant flags (profile key)
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -280,7 +294,7 @@ class Where2ComEngine:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x07ff))
+            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x03ff))
             if bn & 0x2000:  # launch_sk(): equal iteration ranges, then the number of non-empty ones
                 total = wgs * L.ks * L.ks * (L.cin // 32)
                 per = -(-total // min(d.sk_wgs, total))
@@ -317,9 +331,9 @@ class Where2ComEngine:
         the K order of every output element does not depend on the tile).  Runs outside graph capture."""
         if torch.cuda.is_current_stream_capturing():
             bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
-            return (bm << 16) | bn | (0x0800 if self.amp else 0), 0
+            return (bm << 16) | bn | (0x0800 if self.amp else (0x0400 if self.split3 else 0)), 0
         best, best_t = None, float("inf")
-        wgt = _w16(L) if self.amp else L.w
+        wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         # tune into a scratch output: `out` may alias the input / residual (in-place transformer updates)
         ho = d.ho * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         wo = d.wo * (L.up if L.mode == _lib.AV2X_DECONV else 1)
@@ -329,12 +343,14 @@ class Where2ComEngine:
             cands += list(self.PERSIST_CANDIDATES)
         if self.amp:
             cands = list(self.AMP_CANDIDATES)
+        elif self.split3:
+            cands = [(bm, (bn & ~0x0800) | 0x0400, g) for bm, bn, g in self.AMP_CANDIDATES]
         elif self.stream_k and -(-(d.n * d.ho * d.wo) // 128) * (L.coutp // 64 if L.coutp % 64 == 0 else 1 << 30) <= self.SK_MAX_TILES:
             cands += list(self.SK_CANDIDATES)
         ws = self.sk_workspace()
         st = self.stream()
         for bm, bn, g in cands:
-            if L.coutp % (bn & 0x07ff) or ((bn & 0x07ff) == 32 and L.coutp != 32):
+            if L.coutp % (bn & 0x03ff) or ((bn & 0x03ff) == 32 and L.coutp != 32):
                 continue
             d.tile, d.sk_wgs = (bm << 16) | bn, g
             call = lambda: _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), None,

@@ -58,3 +58,16 @@ def to_bf16_koct(packed):
     assert four == 4 and q % 2 == 0
     t = packed.reshape(T, q // 2, 2, n, 4).permute(0, 1, 3, 2, 4).reshape(T, q // 2, n, 8)
     return t.to(torch.bfloat16).contiguous()
+
+
+def to_bf16x3_koct(packed):
+    """Split-3 packing for conv_igemm_bf16x3 (tile flag 0x0400): (3, T, Cin/8, CoutP, 8) bf16 planes hi / mid / lo with
+    hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (each subtraction is exact in fp32), so hi + mid + lo = w to 2^-24."""
+    T, q, n, four = packed.shape
+    assert four == 4 and q % 2 == 0
+    w = packed.reshape(T, q // 2, 2, n, 4).permute(0, 1, 3, 2, 4).reshape(T, q // 2, n, 8).float()
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo]).contiguous()

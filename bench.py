@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm", choices=["f32", "split3"], default="f32",
+                    help="f32: v_mfma_f32_32x32x2_f32 (default, the headline); split3: fp32-accurate products from three bf16 "
+                         "terms per operand on the bf16 matrix cores (conv_igemm_bf16x3)")
     ap.add_argument("--amp", action="store_true",
                     help="AMP mode: bf16 matrix-core operands with fp32 accumulation for every Conv2d / Linear (what "
                          "torch.autocast does in the reference's train.py validation pass); NOT the headline configuration")
@@ -190,6 +193,7 @@ def main():
     model.amp = bool(a.amp)
     eng = model.engine()
     eng.amp = bool(a.amp)
+    eng.split3 = a.gemm == "split3" and not a.amp
     eng.use_graph = bool(a.graph) and a.mode == "replica"
     if a.mode == "shard":
         frame = ShardedFrame(EngineBackend(eng))
@@ -232,7 +236,7 @@ def main():
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
         **({"precision_note": "AMP mode: bf16 MFMA operands, fp32 accumulate, fp32 activations in HBM; max |err| vs the fp32 path "
                               "is reported by tests/test_amp.py -- not comparable with the fp32 headline"} if a.amp else {}),
-        "dtype": "bf16" if a.amp else "f32", "data": "synthetic",
+        "dtype": "bf16" if a.amp else ("f32 (products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate)" if a.gemm == "split3" else "f32"), "data": "synthetic",
         "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(types)}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
@@ -253,6 +257,32 @@ def main():
         l1 = (time.perf_counter() - t1) / a.steps
         res["single_stream"] = {"frames_per_s": round(1.0 / l1, 2), "ms_per_frame": round(l1 * 1e3, 3),
                                 "note": "one frame at a time (no overlap between frames)"}
+
+    # ---------------- the same frames with the split-3 GEMM (fp32-accurate, bf16 matrix cores): reported beside the headline
+    if rank == 0 and a.mode == "replica" and a.model == "where2com" and a.gemm == "f32" and not a.amp and a.inflight > 1:
+        for e in pipe.engines:
+            e.split3 = True
+        out3 = model(dd)  # tunes the split-3 tiles
+        for _ in range(a.inflight):
+            pipe.submit(dd)
+        pipe.drain()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            pipe.submit(dd)
+        pipe.drain()
+        torch.cuda.synchronize()
+        s3 = (time.perf_counter() - t1) / a.steps
+        split3_out = {k: out3[k].clone() for k in ("psm", "rm", "obj")}
+        res["fp32_split3"] = {"frames_per_s": round(1.0 / s3, 2), "ms_per_step": round(s3 * 1e3, 3), "frames_in_flight": a.inflight,
+                              "max_abs_diff_vs_f32_mfma": {k: float((split3_out[k] - out[k]).abs().max()) for k in split3_out},
+                              "note": "opt-in engine.split3 / --gemm split3: every fp32 operand = hi+mid+lo bf16 terms, six partial "
+                                      "products per MAC on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs fp64 is at or below the "
+                                      "fp32-MFMA kernel's (tools/split3_bench.py); NOT the headline value"}
+        for e in pipe.engines:
+            e.split3 = False
+    else:
+        split3_out = None
 
     # ---------------- second figure: frame + on-device post-process (decode, filters, rotated NMS) ----------
     if rank == 0 and a.mode == "replica" and a.model == "where2com":
@@ -343,17 +373,17 @@ def main():
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{k[0]}x{k[1] & 0x07ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}"
+        tkey = lambda k: f"{k[0]}x{k[1] & 0x03ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS), 4), "traffic": traffic, "traffic_note": traffic_note,
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else 'f32'}<{dom[0]},{dom[1] & 0x07ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
+            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else 'f32')}<{dom[0]},{dom[1] & 0x03ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
                       + (" prefetch-2" if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x07ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
+            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x03ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                              f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>"
-                             + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x07ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
+                             + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x03ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},
@@ -383,6 +413,8 @@ def main():
                                "sample": f"{a.cpu_frames} frames of the same workload after 1 warm-up, torch CPU fp32 "
                                          f"de-duplicated schedule (1 backbone pass + masked blocks), {cdt / a.cpu_frames:.2f} s/frame"}
         res["parity_max_abs_err_vs_oracle"] = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("psm", "rm", "obj")}
+        if split3_out is not None:
+            res["fp32_split3"]["max_abs_err_vs_oracle"] = {k: float((split3_out[k].cpu() - ref[k]).abs().max()) for k in ("psm", "rm", "obj")}
 
     if rank == 0:
         print(json.dumps(res))

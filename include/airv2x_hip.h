@@ -80,6 +80,11 @@ int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
  *   v_mfma_f32_32x32x16_bf16 with fp32 accumulation, activations stay fp32 in HBM.  The result equals an fp32
  *   convolution of the bf16-rounded operands up to summation order = what torch.autocast computes for Conv2d /
  *   Linear (the reference's validation pass, tools/train.py:212-220).  Tiles 128x128, 128x64, 64x64, 128x32.
+ * Split-3 mode (tile flag 0x0400): `w` points to THREE bf16 planes [3][tap][cin/8][coutp][8] = hi, mid, lo with
+ *   hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (packing.to_bf16x3_koct); the input tile is split the
+ *   same way on its way into LDS and six partial products per MAC (lo.hi' + hi.lo' + mid.mid' + mid.hi' + hi.mid' +
+ *   hi.hi') are accumulated in fp32 on v_mfma_f32_32x32x16_bf16.  Per-product error <= ~4 x 2^-24: fp32-accurate
+ *   (its error against fp64 is at or below that of the default fp32-MFMA kernel), not bit-identical to it.
  * ------------------------------------------------------------------------------------ */
 enum { AV2X_CONV = 0, AV2X_DECONV = 1, AV2X_CONV_NCHW = 2 };
 
@@ -95,7 +100,8 @@ typedef struct av2x_conv_desc {
     int32_t up;                /* DECONV: kernel == stride                                */
     int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2)
                                   | 0x2000 (stream-K, av2x_conv2d_sk only) | 0x1000 (persistent whole tiles)
-                                  | 0x0800 (bf16 matrix-core operands: `w` is the bf16 packing, see below)   */
+                                  | 0x0800 (bf16 matrix-core operands: `w` is the bf16 packing, see below)
+                                  | 0x0400 (split-3: fp32-accurate products from three bf16 terms, see below) */
     int32_t sk_wgs;            /* stream-K / persistent: number of workgroups launched (else ignored) */
 } av2x_conv_desc;
 

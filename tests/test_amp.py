@@ -102,3 +102,61 @@ def test_models_under_autocast_stay_close_to_the_fp32_reference(which):
     model.amp = True                                    # explicit switch, no autocast context
     forced = model(dd)
     assert torch.equal(forced["psm"], amp["psm"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_split3_conv_is_fp32_accurate(case):
+    """conv_igemm_bf16x3 (tile flag 0x0400): hi+mid+lo bf16 split of both operands, six partial products, fp32
+    accumulation.  Against an fp64 convolution its error must not exceed the fp32-MFMA kernel's by more than 1.5x
+    (measured: it is smaller), i.e. the mode is fp32-accurate although not bit-identical to IEEE fp32 products."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, to_bf16x3_koct
+    lib = _lib.load()
+    n, h, w, cin, cout, ks, stride, tile = case
+    tile = (tile & ~0x0800) | 0x0400
+    pad = 1 if ks == 3 else 0
+    g = torch.Generator().manual_seed(3 * cin + cout + ks)
+    x = torch.randn(n, cin, h, w, generator=g) * torch.exp(torch.randn(n, cin, 1, 1, generator=g))   # wide dynamic range
+    wt = torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks)
+    ref = F.conv2d(x.double(), wt.double(), None, stride=stride, padding=pad)
+    ho, wo = ref.shape[2:]
+    wp, coutp = pack_conv_weight(wt)
+    w3 = to_bf16x3_koct(wp)
+    assert w3.shape == (3, ks * ks, cin // 8, coutp, 8) and w3.dtype == torch.bfloat16
+    back = w3.float().sum(0)                                     # hi + mid + lo reproduces the fp32 weights to 2^-24
+    full = wp.reshape(ks * ks, cin // 8, 2, coutp, 4).permute(0, 1, 3, 2, 4).reshape(ks * ks, cin // 8, coutp, 8)
+    assert float((back - full).abs().max()) <= 2.0 ** -23 * float(full.abs().max())
+    xd, w32, w3d = x.permute(0, 2, 3, 1).contiguous().cuda(), wp.cuda(), w3.cuda()
+    one, zero = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    errs = {}
+    for name, t, wgt in (("f32", (64 << 16) | (64 if coutp % 64 == 0 else 32) | (0 if coutp % 64 == 0 else 0), w32), ("split3", tile, w3d)):
+        if name == "f32" and coutp % 64:
+            t = (128 << 16) | 32
+        out = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=ho, wo=wo, cout=cout, coutp=coutp, out_ctot=cout,
+                          out_coff=0, ks=ks, stride=stride, pad=pad, relu=0, mode=0, up=1, tile=t, sk_wgs=0)
+        _lib.check(lib.av2x_conv2d(byref(d), _p(xd), _p(wgt), _p(one), _p(zero), _p(out),
+                                   c_void_p(torch.cuda.current_stream().cuda_stream)), name)
+        e = (out.permute(0, 3, 1, 2).cpu().double() - ref).abs()
+        errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    assert errs["split3"][1] <= 1.5 * errs["f32"][1] and errs["split3"][0] <= 2.0 * errs["f32"][0], errs
+    assert errs["split3"][0] <= 1e-5 * max(1.0, float(ref.abs().max())), errs
+
+
+def test_where2comm_split3_forward_meets_the_fp32_tolerance():
+    """engine.split3: the whole frame within the SAME tolerance as the fp32-MFMA path against the reference golden."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    from tests.helpers import case_from_fixture
+    for name in ("w2c_small_n3", "w2c_full_n4"):
+        fx = load_fixture(name)
+        hy, args, sd, dd, _, _ = case_from_fixture(fx)
+        model = Airv2xWhere2com(args)
+        model.load_state_dict(sd)
+        model = model.to("cuda").eval()
+        model.engine().split3 = True
+        out = model(dd)
+        hs = int(fx["sample_stride"])
+        for k in ("psm", "rm", "obj"):
+            got = out[k].cpu().numpy()
+            assert_close(got[..., ::hs, ::hs] if hs > 1 else got, fx[k], 2e-4, 2e-4, f"{name} {k} (split-3)")
+        assert int(out["comm_rate"]) == int(fx["comm_rate"])
