@@ -373,7 +373,7 @@ def main():
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{k[0]}x{k[1] & 0x03ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}"
+        tkey = lambda k: f"{k[0]}x{k[1] & 0x03ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
