@@ -137,6 +137,27 @@ extern "C" int av2x_comm_mask(const float* psm, int32_t n, int32_t h, int32_t w,
     return av2x::check_launch("comm_mask_kernel");
 }
 
+namespace {
+// com = mean over samples of count[b] / (agents[b] * hw)   (where2comm_fuse.py:137, :147), fp32 like the reference
+__global__ void comm_rate_kernel(const int* __restrict__ count, const float* __restrict__ agents, int B, float hw,
+                                 float* __restrict__ com) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += (float)count[b] / (agents[b] * hw);
+        com[0] = s / (float)B;
+    }
+}
+
+}  // namespace
+
+extern "C" int av2x_comm_rate(const int32_t* count, const float* agents_per_sample, int32_t n_samples, int32_t hw,
+                              float* com, av2x_stream_t stream) {
+    if (!count || !agents_per_sample || !com || n_samples <= 0) return av2x::fail("av2x_comm_rate: bad argument");
+    hipLaunchKernelGGL(comm_rate_kernel, dim3(1), dim3(64), 0, av2x::as_stream(stream), count, agents_per_sample, n_samples,
+                       (float)hw, com);
+    return av2x::check_launch("comm_rate_kernel");
+}
+
 extern "C" int av2x_apply_mask(float* x, const float* mask, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
     if (n == 0) return 0;
     if (!x || !mask) return av2x::fail("av2x_apply_mask: null argument");

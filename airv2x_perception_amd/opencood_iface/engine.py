@@ -450,8 +450,8 @@ class Where2ComEngine:
         s = self.run_shrink(cat, n, H, W, tag, out=shrink_out) if self.shrink else cat
         return feats, s, H, W
 
-    def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True, tag="", count=None):
-        B = len(record_len)
+    def comm_layout(self, record_len, has_ego=True):
+        """Cached device arrays of a frame layout: (sample of every agent i32, is-ego flag i32, agents per sample f32)."""
         key = ("layout", tuple(record_len), has_ego)
         lay = self.ws.get(key)
         if lay is None:
@@ -463,6 +463,11 @@ class Where2ComEngine:
                    torch.tensor(ego, dtype=torch.int32, device=self.device),
                    torch.tensor(record_len, dtype=torch.float32, device=self.device))
             self.ws[key] = lay
+        return lay
+
+    def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True, tag="", count=None):
+        B = len(record_len)
+        lay = self.comm_layout(record_len, has_ego)
         conf = self.buf("comm_conf" + tag, (n, H, W))
         smooth = self.buf("comm_smooth" + tag, (n, H, W))
         mask = self.buf("comm_mask" + tag, (n, H, W))
@@ -475,6 +480,12 @@ class Where2ComEngine:
                                            _ptr(lay[0]), _ptr(lay[1]), _ptr(conf), _ptr(smooth), _ptr(mask),
                                            _ptr(count), st), "av2x_comm_mask")
         return mask, count, smooth, lay[2]
+
+    def comm_rate(self, count, agents_per_sample, B, hw):
+        """0-dim fp32 tensor: mean over samples of count / (agents * H * W) (one tiny launch, no ATen arithmetic)."""
+        com = self.buf("comm_rate_out", (1,))
+        _lib.check(self.lib.av2x_comm_rate(_ptr(count), _ptr(agents_per_sample), B, hw, _ptr(com), self.stream()), "av2x_comm_rate")
+        return com[0]
 
     def attn(self, ptrs, hw, c, out):
         arr = (c_void_p * len(ptrs))(*ptrs)
@@ -553,7 +564,7 @@ class Where2ComEngine:
                 raise NotImplementedError("mask/feature size mismatch (bilinear resize branch, where2comm_fuse.py:230) "
                                           "is never taken by AirV2X configs")
             mask, count, smooth, rl = self.comm_mask(psm_single, n, H, W, record_len)
-            com = (count.to(torch.float32) / (rl * (H * W))).sum() / B  # where2comm_fuse.py:137,147
+            com = self.comm_rate(count, rl, B, H * W)                    # where2comm_fuse.py:137,147
             _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask")
             if trace is not None:
                 trace["comm_mask"] = mask.unsqueeze(1).clone()
@@ -669,7 +680,7 @@ class Where2ComEngine:
         fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
         heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
         self.conv(self.heads, fs, 1, H, W, heads)
-        com = (count.to(torch.float32) / float(n * H * W)).sum()
+        com = self.comm_rate(count, self.comm_layout((n,), True)[2], 1, H * W)
         return heads, com, nz
 
     # ------------------------------------------------------------------ agent-sharded frame (one frame over N GPUs)

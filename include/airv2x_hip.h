@@ -157,6 +157,11 @@ int av2x_apply_mask(float* x, const float* mask, int32_t n, int32_t hw, int32_t 
 int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents, int32_t hw, int32_t c,
                          float* out, av2x_stream_t stream);
 
+/* com = mean_b count[b] / (agents_per_sample[b] * hw): the `communication_rates` scalar of where2comm_fuse.py:137,147
+ * from the popcounts av2x_comm_mask accumulated; count (n_samples,) i32, agents_per_sample (n_samples,) f32, com (1,) f32. */
+int av2x_comm_rate(const int32_t* count, const float* agents_per_sample, int32_t n_samples, int32_t hw, float* com,
+                   av2x_stream_t stream);
+
 /* count_nonzero over a dense fp32 buffer (airv2x_where2com.py:122); result (1,) u64 += */
 int av2x_count_nonzero(const float* x, uint64_t n_elems, unsigned long long* result,
                        av2x_stream_t stream);
