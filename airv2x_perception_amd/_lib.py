@@ -69,6 +69,8 @@ SIGNATURES = {
     "av2x_voxelize_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
     "av2x_voxelize": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    "av2x_prepare_voxelize": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
+                                        c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_postprocess_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
     "av2x_postprocess": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    c_void_p, c_float, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

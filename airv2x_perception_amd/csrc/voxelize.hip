@@ -24,11 +24,45 @@ struct VoxGeom {
     int grid[3];  // x, y, z
 };
 
-__global__ void k_cell(const float4* __restrict__ pts, int n, VoxGeom g, int* __restrict__ cell,
+// Optional point preparation folded into the voxelizer (av2x_prepare_voxelize): the point the voxelizer sees at
+// position i is prepare(points[perm[i]]); dropped points simply get no cell, which leaves first-appearance voxel order
+// and in-voxel point order exactly as if the cloud had been compacted first (av2x_prepare_points).
+struct PrepInline {
+    int enabled, project, mask_ego;
+    const int* perm;
+    float T[16];
+    float r[6];
+};
+
+__device__ __forceinline__ bool prep_point(const float4* __restrict__ pts, int i, const PrepInline& P, float4* out) {
+    float4 q = pts[(P.enabled && P.perm) ? P.perm[i] : i];
+    bool keep = true;
+    if (P.enabled) {
+        if (P.mask_ego) keep = !(q.x >= -1.95f && q.x <= 2.95f && q.y >= -1.1f && q.y <= 1.1f);
+        if (P.project) {
+            float o[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float acc = __fmul_rn(q.x, P.T[j * 4 + 0]);
+                acc = __fmaf_rn(q.y, P.T[j * 4 + 1], acc);
+                acc = __fmaf_rn(q.z, P.T[j * 4 + 2], acc);
+                acc = __fmaf_rn(1.0f, P.T[j * 4 + 3], acc);
+                o[j] = acc;
+            }
+            q.x = o[0]; q.y = o[1]; q.z = o[2];
+        }
+        keep = keep && q.x > P.r[0] && q.x < P.r[3] && q.y > P.r[1] && q.y < P.r[4] && q.z > P.r[2] && q.z < P.r[5];
+    }
+    *out = q;
+    return keep;
+}
+
+__global__ void k_cell(const float4* __restrict__ pts, int n, VoxGeom g, PrepInline P, int* __restrict__ cell,
                        int* __restrict__ cnt, int* __restrict__ first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 p = pts[i];
+    float4 p;
+    if (!prep_point(pts, i, P, &p)) { cell[i] = -1; return; }
     // IEEE fp32 subtract and divide, as the CPU implementation (no reciprocal, no contraction)
     const float fx = floorf(__fdiv_rn(__fsub_rn(p.x, g.rmin[0]), g.vs[0]));
     const float fy = floorf(__fdiv_rn(__fsub_rn(p.y, g.rmin[1]), g.vs[1]));
@@ -71,7 +105,7 @@ __global__ void k_fill(const int* __restrict__ cell, int n, const int* __restric
 
 __global__ void k_emit(const float4* __restrict__ pts, const int* __restrict__ cell, int n, const int* __restrict__ cnt,
                        const int* __restrict__ first, const int* __restrict__ vrank, const int* __restrict__ offs,
-                       const int* __restrict__ list, VoxGeom g, int max_points, int max_voxels,
+                       const int* __restrict__ list, VoxGeom g, PrepInline P, int max_points, int max_voxels,
                        float4* __restrict__ voxels, int* __restrict__ coords, int* __restrict__ num) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -83,7 +117,11 @@ __global__ void k_emit(const float4* __restrict__ pts, const int* __restrict__ c
     int pos = 0;
     const int* l = list + offs[c];
     for (int j = 0; j < k; ++j) pos += l[j] < i;
-    if (pos < max_points) voxels[(size_t)v * max_points + pos] = pts[i];
+    if (pos < max_points) {
+        float4 q;
+        prep_point(pts, i, P, &q);   // the prepared (projected) point; kept by construction (it has a cell)
+        voxels[(size_t)v * max_points + pos] = q;
+    }
     if (first[c] == i) {
         const int x = c % g.grid[0], yz = c / g.grid[0];
         coords[3 * v + 0] = yz / g.grid[1];
@@ -182,9 +220,9 @@ extern "C" uint64_t av2x_voxelize_workspace_bytes(int32_t n_points, int32_t nx, 
     return (5 * ncell + 2 * (uint64_t)n_points + 4) * sizeof(int);
 }
 
-extern "C" int av2x_voxelize(const float* points, int32_t n_points, const float* range6, const float* voxel3,
-                             int32_t max_points, int32_t max_voxels, void* workspace, float* voxels, int32_t* coords,
-                             int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream) {
+static int voxelize_impl(const float* points, int32_t n_points, const PrepInline& P, const float* range6, const float* voxel3,
+                         int32_t max_points, int32_t max_voxels, void* workspace, float* voxels, int32_t* coords,
+                         int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream) {
     if (!range6 || !voxel3 || !workspace || !voxels || !coords || !num_points || !n_voxels)
         return av2x::fail("av2x_voxelize: null argument");
     if (n_points < 0 || max_points <= 0 || max_voxels <= 0) return av2x::fail("av2x_voxelize: bad sizes");
@@ -216,11 +254,33 @@ extern "C" int av2x_voxelize(const float* points, int32_t n_points, const float*
     if (!points) return av2x::fail("av2x_voxelize: null points");
     const dim3 gp((n_points + 255) / 256), bp(256);
     const float4* p4 = reinterpret_cast<const float4*>(points);
-    hipLaunchKernelGGL(k_cell, gp, bp, 0, st, p4, n_points, g, cell, cnt, first);
+    hipLaunchKernelGGL(k_cell, gp, bp, 0, st, p4, n_points, g, P, cell, cnt, first);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cell, n_points, cnt, first, ncell, vrank, offs, n_voxels,
                        max_voxels);
     hipLaunchKernelGGL(k_fill, gp, bp, 0, st, cell, n_points, offs, fill, list);
-    hipLaunchKernelGGL(k_emit, gp, bp, 0, st, p4, cell, n_points, cnt, first, vrank, offs, list, g, max_points,
+    hipLaunchKernelGGL(k_emit, gp, bp, 0, st, p4, cell, n_points, cnt, first, vrank, offs, list, g, P, max_points,
                        max_voxels, reinterpret_cast<float4*>(voxels), coords, num_points);
     return av2x::check_launch("av2x_voxelize");
+}
+
+extern "C" int av2x_voxelize(const float* points, int32_t n_points, const float* range6, const float* voxel3,
+                             int32_t max_points, int32_t max_voxels, void* workspace, float* voxels, int32_t* coords,
+                             int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream) {
+    PrepInline P;
+    P.enabled = 0; P.project = 0; P.mask_ego = 0; P.perm = nullptr;
+    return voxelize_impl(points, n_points, P, range6, voxel3, max_points, max_voxels, workspace, voxels, coords, num_points,
+                         n_voxels, stream);
+}
+
+extern "C" int av2x_prepare_voxelize(const float* points, const int32_t* perm, int32_t n_points, const float* transform16,
+                                     const float* crop_range6, int32_t mask_ego, const float* grid_range6, const float* voxel3,
+                                     int32_t max_points, int32_t max_voxels, void* workspace, float* voxels, int32_t* coords,
+                                     int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream) {
+    if (!crop_range6) return av2x::fail("av2x_prepare_voxelize: null crop range");
+    PrepInline P;
+    P.enabled = 1; P.project = transform16 ? 1 : 0; P.mask_ego = mask_ego ? 1 : 0; P.perm = perm;
+    for (int i = 0; i < 16; ++i) P.T[i] = transform16 ? transform16[i] : 0.f;
+    for (int i = 0; i < 6; ++i) P.r[i] = crop_range6[i];
+    return voxelize_impl(points, n_points, P, grid_range6, voxel3, max_points, max_voxels, workspace, voxels, coords, num_points,
+                         n_voxels, stream);
 }

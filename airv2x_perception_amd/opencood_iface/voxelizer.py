@@ -77,3 +77,50 @@ def voxelize_points(points, lidar_range, voxel_size, max_points=32, max_voxels=7
                "av2x_voxelize")
     m = int(m_dev.item())
     return voxels[:m], coords[:m], num[:m]
+
+
+def voxelize_frame(clouds, lidar_range, voxel_size, poses=None, mask_ego=True, perms=None, max_points=32, max_voxels=70000):
+    """Whole-frame front end: for every agent's raw (P,4) CUDA cloud run av2x_prepare_voxelize (ego mask -> projection by
+    ``poses[i]`` -> range crop -> pillar voxelizer, one fused pass) back to back, then read ALL pillar counts with ONE
+    host read-back and return the exact-shaped (voxels (M,32,4), coords (M,3), num (M,)) triples of the reference's
+    input contract.  Equivalent to prepare_points + voxelize_points per agent (tests/test_gpu_voxelizer.py)."""
+    lib = _lib.load()
+    grid = np.round((np.asarray(lidar_range[3:6], np.float64) - np.asarray(lidar_range[0:3], np.float64))
+                    / np.asarray(voxel_size, np.float64)).astype(np.int64)
+    r6 = (c_float * 6)(*[float(v) for v in lidar_range])
+    v3 = (c_float * 3)(*[float(v) for v in voxel_size])
+    n_agents = len(clouds)
+    dev = clouds[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("voxelize_frame runs on a HIP device only")
+    counts = torch.zeros(n_agents, dtype=torch.int32, device=dev)
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    pend = []
+    for i, pts in enumerate(clouds):
+        pts = pts.contiguous().float()
+        n = pts.shape[0]
+        cap = max(1, min(n, max_voxels))
+        ws = torch.empty(int(lib.av2x_voxelize_workspace_bytes(max(n, 1), int(grid[0]), int(grid[1]), int(grid[2]))),
+                         dtype=torch.uint8, device=dev)
+        voxels = torch.empty((cap, max_points, 4), dtype=torch.float32, device=dev)
+        coords = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+        num = torch.empty((cap,), dtype=torch.int32, device=dev)
+        t16 = None
+        if poses is not None and poses[i] is not None:
+            t16 = (c_float * 16)(*np.asarray(poses[i], dtype=np.float32).reshape(-1).tolist())
+        pm = perms[i].to(device=dev, dtype=torch.int32).contiguous() if perms is not None and perms[i] is not None else None
+        _lib.check(lib.av2x_prepare_voxelize(c_void_p(pts.data_ptr()), c_void_p(pm.data_ptr()) if pm is not None else None, n,
+                                             ctypes.cast(t16, c_void_p) if t16 is not None else None, ctypes.cast(r6, c_void_p),
+                                             1 if mask_ego else 0, ctypes.cast(r6, c_void_p), ctypes.cast(v3, c_void_p),
+                                             max_points, max_voxels, c_void_p(ws.data_ptr()), c_void_p(voxels.data_ptr()),
+                                             c_void_p(coords.data_ptr()), c_void_p(num.data_ptr()),
+                                             c_void_p(counts[i:i + 1].data_ptr()), st), "av2x_prepare_voxelize")
+        pend.append((voxels, coords, num, ws, pts, pm))
+    ms = counts.tolist()                                   # the one host read-back of the frame's front end
+    out = []
+    for i, (m, (voxels, coords, num, _, pts, pm)) in enumerate(zip(ms, pend)):
+        if m == 0:   # empty cloud after the crop: the reference's dummy-point branch (sp_voxel_preprocessor.py:80-90)
+            out.append(voxelize_points(torch.zeros((0, 4), device=dev), lidar_range, voxel_size, max_points, max_voxels))
+        else:
+            out.append((voxels[:m], coords[:m], num[:m]))
+    return out

@@ -328,27 +328,24 @@ def main():
                                                     "frames_in_flight": a.inflight}
 
         # third figure: the whole chain from raw clouds (prepare -> voxelize -> model -> post-process), sequential
-        from airv2x_perception_amd.opencood_iface.voxelizer import prepare_points, voxelize_points
+        from airv2x_perception_amd.opencood_iface.voxelizer import voxelize_frame
         ppc = hy["preprocess"]
         pts_dev = [torch.from_numpy(c).to(dev) for c in clouds]
         for it in range(2 + a.steps):
             if it == 2:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            vv = []
-            for p_ in pts_dev:
-                q_ = prepare_points(p_, ppc["cav_lidar_range"], None, mask_ego=True)
-                vv.append(voxelize_points(q_, ppc["cav_lidar_range"], ppc["args"]["voxel_size"],
-                                          ppc["args"]["max_points_per_voxel"], ppc["args"]["max_voxel_test"]))
+            vv = voxelize_frame(pts_dev, ppc["cav_lidar_range"], ppc["args"]["voxel_size"], poses=None, mask_ego=True,
+                                max_points=ppc["args"]["max_points_per_voxel"], max_voxels=ppc["args"]["max_voxel_test"])
             dd2 = synth.build_data_dict_device(vv, types, dev, max_cav_num=args["max_cav_num"])
             o = model(dd2)
             post.post_process_airv2x(data, {"ego": o}, return_counts=True)
         torch.cuda.synchronize()
         edt = (time.perf_counter() - t0) / a.steps
         res["from_points"] = {"frames_per_s": round(1.0 / edt, 2), "ms_per_step": round(edt * 1e3, 3),
-                              "note": "raw (P,4) clouds resident in HBM -> av2x_prepare_points -> av2x_voxelize -> model -> "
-                                      "av2x_postprocess, one frame at a time; the exact-shape voxel tensors of the reference's "
-                                      "input contract cost two host read-backs per agent"}
+                              "note": "raw (P,4) clouds resident in HBM -> av2x_prepare_voxelize (ego mask, range crop, voxelizer in one "
+                                      "pass per agent) -> model -> av2x_postprocess, one frame at a time; the exact-shape voxel tensors "
+                                      "of the reference's input contract cost one host read-back per frame"}
 
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and a.mode == "replica":

@@ -200,6 +200,14 @@ uint64_t av2x_voxelize_workspace_bytes(int32_t n_points, int32_t nx, int32_t ny,
 int av2x_voxelize(const float* points, int32_t n_points, const float* range6, const float* voxel3,
                   int32_t max_points, int32_t max_voxels, void* workspace, float* voxels,
                   int32_t* coords, int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream);
+/* av2x_prepare_points + av2x_voxelize in ONE pass: the point at position i is prepare(points[perm[i]]) (ego-box mask,
+ * projection by transform16, strict crop to crop_range6 -- same argument meaning as av2x_prepare_points); dropped
+ * points get no cell, so voxel order / in-voxel order are those of the compacted cloud and the voxels hold the
+ * PROJECTED coordinates.  No intermediate cloud, no host read-back between the two stages. */
+int av2x_prepare_voxelize(const float* points, const int32_t* perm, int32_t n_points, const float* transform16,
+                          const float* crop_range6, int32_t mask_ego, const float* grid_range6, const float* voxel3,
+                          int32_t max_points, int32_t max_voxels, void* workspace, float* voxels, int32_t* coords,
+                          int32_t* num_points, int32_t* n_voxels, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Detection post-processing on the device.  Replaces VoxelPostprocessor.post_process_airv2x
