@@ -12,8 +12,6 @@ Padded agents cannot be skipped: their query tokens do attend to the valid keys 
 """
 from __future__ import annotations
 
-from ctypes import c_void_p
-
 import torch
 
 from .. import _lib

@@ -16,7 +16,6 @@ from __future__ import annotations
 import ctypes
 from ctypes import c_int32, c_void_p
 
-import numpy as np
 import torch
 
 from .. import _lib

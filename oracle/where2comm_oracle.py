@@ -15,7 +15,6 @@ Every function cites the reference lines it restates (paths relative to
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch

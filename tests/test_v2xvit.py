@@ -7,7 +7,7 @@ from airv2x_perception_amd import synth
 from airv2x_perception_amd.opencood_iface import warp as W
 from oracle import v2xvit_oracle as vit
 from oracle import voxelize_oracle as vox
-from tests.helpers import assert_close, load_fixture, sample
+from tests.helpers import assert_close, load_fixture
 
 
 def _case(fx):

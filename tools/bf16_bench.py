@@ -1,4 +1,4 @@
-import os, sys
+import sys
 sys.path.insert(0, "/root/repo")
 from ctypes import byref, c_void_p
 import torch, torch.nn.functional as F
