@@ -133,9 +133,9 @@ class CoBEVTEngine(Where2ComEngine):
         self.conv(self.head_lin, mn, 1, H, W, fused)
         return fused
 
-    def _heads_out(self, fused, H, W):
-        heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
-        self.conv(self.heads, fused, 1, H, W, heads)
+    def _heads_out(self, fused, H, W, B=1):
+        heads = torch.empty((B, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, B, H, W, heads)
         outs = torch.split(heads, self.head_splits, dim=1)
         out = {"psm": outs[0], "rm": outs[1]}
         if self.args["obj_head"]:
@@ -196,26 +196,41 @@ class CoBEVTEngine(Where2ComEngine):
         if not self.weights_ready:
             raise RuntimeError("load_state_dict() must be called before forward()")
         record_len, slots = self.frame_layout(data_dict)
-        if len(record_len) != 1:
-            raise NotImplementedError("CoBEVT engine: one collaborative frame (B = 1) per call")
-        n = record_len[0]
-        if n > self.L:
-            raise ValueError(f"{n} agents exceed max_cav_num = {self.L}")
+        B, n_total = len(record_len), sum(record_len)
+        if max(record_len) > self.L:
+            raise ValueError(f"{max(record_len)} agents exceed max_cav_num = {self.L}")
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         dims = self.level_dims(ny, nx)
         H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
         C = self.fax["input_dim"]
         x = self.buf("fax_x", (self.L, H, W, C))
-        # regroup (fuse_utils.py:13-64): real agents first, zero padding after; the shrink conv writes x[:n]
-        if n < self.L:
-            _lib.check(self.lib.av2x_fill_zero(_ptr(x[n:]), (self.L - n) * H * W * C * 4, self.stream()), "av2x_fill_zero")
-        _, s, H2, W2 = self.trunk(canvas, n, ny, nx, shrink_out=x[:n])
-        assert (H2, W2) == (H, W)
+        if B == 1:
+            # regroup (fuse_utils.py:13-64): real agents first, zero padding after; the shrink conv writes x[:n]
+            n = record_len[0]
+            if n < self.L:
+                _lib.check(self.lib.av2x_fill_zero(_ptr(x[n:]), (self.L - n) * H * W * C * 4, self.stream()), "av2x_fill_zero")
+            _, s, H2, W2 = self.trunk(canvas, n, ny, nx, shrink_out=x[:n])
+            assert (H2, W2) == (H, W)
+            if self.compression:
+                self.run_compressor(x[:n], n, H, W)
+            if trace is not None:
+                trace["shrink"] = x[:n].permute(0, 3, 1, 2).clone()
+            fused = self.fax_encoder(x, n, H, W, trace)
+            if trace is not None:
+                trace["fused"] = fused.permute(0, 3, 1, 2).clone()
+            return self._heads_out(fused, H, W)
+        # B > 1 (the reference's collate layout): the trunk runs on all agents at once, the fusion per sample
+        # (regroup pads every sample to L agents, SwapFusionEncoder never mixes samples)
+        s_all = self.buf("shrink_batch", (n_total, H, W, C))
+        self.trunk(canvas, n_total, ny, nx, shrink_out=s_all)
         if self.compression:
-            self.run_compressor(x[:n], n, H, W)
-        if trace is not None:
-            trace["shrink"] = x[:n].permute(0, 3, 1, 2).clone()
-        fused = self.fax_encoder(x, n, H, W, trace)
-        if trace is not None:
-            trace["fused"] = fused.permute(0, 3, 1, 2).clone()
-        return self._heads_out(fused, H, W)
+            self.run_compressor(s_all, n_total, H, W)
+        fused_all = self.buf("fused_batch", (B, H, W, C))
+        off = 0
+        for b, n in enumerate(record_len):
+            x[:n].copy_(s_all[off:off + n])
+            if n < self.L:
+                _lib.check(self.lib.av2x_fill_zero(_ptr(x[n:]), (self.L - n) * H * W * C * 4, self.stream()), "av2x_fill_zero")
+            fused_all[b:b + 1].copy_(self.fax_encoder(x, n, H, W))
+            off += n
+        return self._heads_out(fused_all, H, W, B)

@@ -240,11 +240,9 @@ class V2XViTEngine(Where2ComEngine):
         if not self.weights_ready:
             raise RuntimeError("load_state_dict() must be called before forward()")
         record_len, slots = self.frame_layout(data_dict)
-        if len(record_len) != 1:
-            raise NotImplementedError("V2X-ViT engine: one collaborative frame (B = 1) per call")
-        n = record_len[0]
-        if n > self.L:
-            raise ValueError(f"{n} agents exceed max_cav_num = {self.L}")
+        B, n_total = len(record_len), sum(record_len)
+        if max(record_len) > self.L:
+            raise ValueError(f"{max(record_len)} agents exceed max_cav_num = {self.L}")
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
@@ -252,13 +250,21 @@ class V2XViTEngine(Where2ComEngine):
         _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
         dims = self.level_dims(ny, nx)
         H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
-        x = self.buf("vit_x", (n, H, Wd, 256))
-        self.trunk(canvas, n, ny, nx, shrink_out=x)
-        prior = data_dict["prior_encoding"][0].detach().cpu().numpy()           # (L,3) per-agent scalars (appendix A #12)
-        scm = data_dict["spatial_correction_matrix"][0].detach().cpu().numpy()   # (L,4,4) f64
-        fused = self.encoder(x, n, H, Wd, prior, scm, trace)
-        heads = torch.empty((1, self.heads.cout, H, Wd), dtype=torch.float32, device=self.device)
-        self.conv(self.heads, fused, 1, H, Wd, heads)
+        x = self.buf("vit_x", (n_total, H, Wd, 256))
+        self.trunk(canvas, n_total, ny, nx, shrink_out=x)                        # all agents of the batch at once
+        prior_all = data_dict["prior_encoding"].detach().cpu().numpy()           # (B,L,3) per-agent scalars (appendix A #12)
+        scm_all = data_dict["spatial_correction_matrix"].detach().cpu().numpy()  # (B,L,4,4) f64
+        fused_all = self.buf("vit_fused", (B, H, Wd, 256))
+        off = 0
+        for b, n in enumerate(record_len):                                       # the fusion never mixes samples
+            fused = self.encoder(x[off:off + n], n, H, Wd, prior_all[b], scm_all[b], trace if B == 1 else None)
+            if B == 1:
+                fused_all = fused
+            else:
+                fused_all[b:b + 1].copy_(fused)
+            off += n
+        heads = torch.empty((B, self.heads.cout, H, Wd), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused_all, B, H, Wd, heads)
         outs = torch.split(heads, self.head_splits, dim=1)
         out = {"psm": outs[0], "rm": outs[1]}
         if self.args["obj_head"]:

@@ -135,3 +135,25 @@ def test_gpu_layernorm_and_mean():
     m = torch.empty((40, 64), device="cuda")
     _lib.check(lib.av2x_agent_mean(P(zd), P(m), 7, 40 * 64, st), "mean")
     assert_close(m.cpu(), z.mean(0), 1e-6, 1e-6, "agent mean")
+
+
+@pytest.mark.gpu
+def test_gpu_batch_of_two_frames_equals_two_single_frames():
+    """B = 2 in the reference's collate layout: the trunk is batched over all agents, regroup + fusion run per sample."""
+    from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
+    fx = load_fixture("cobevt_small_n3")
+    hy, args, sd, dd3 = _case(fx)
+    rng = [float(v) for v in fx["lidar_range"]]
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, int(fx["n_points"]), rng), rng), rng,
+                                 hy["preprocess"]["args"]["voxel_size"]) for i in range(3)]
+    dd2 = synth.build_data_dict([voxd[0], voxd[2]], ["vehicle", "drone"], max_cav_num=args["max_cav_num"])
+    model = Airv2xCoBEVT(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    o3 = {k: v.clone() for k, v in eng.forward(dd3).items()}
+    o2 = {k: v.clone() for k, v in eng.forward(dd2).items()}
+    ob = eng.forward(synth.merge_frames([dd3, dd2]))
+    for k in ("psm", "rm", "obj"):
+        assert ob[k].shape[0] == 2 and torch.equal(ob[k][0:1], o3[k]) and torch.equal(ob[k][1:2], o2[k]), k

@@ -159,3 +159,29 @@ def test_gpu_warp_affine_simple_matches_torch(align):
     assert_close(out.cpu(), ref, 1e-4, 1e-4, f"warp_affine_simple align_corners={align}")
     ident = W.warp_affine_simple(src.cuda(), torch.tensor([[[1.0, 0, 0], [0, 1.0, 0]]]).repeat(B, 1, 1), (H, Wd), align_corners=align)
     assert_close(ident.cpu(), src, 1e-4, 1e-4, "identity theta")   # pixel centres up to fp32 rounding of the grid
+
+
+@pytest.mark.gpu
+def test_gpu_batch_of_two_frames_equals_two_single_frames():
+    """B = 2: batched trunk, per-sample STTF / HGT / window fusion with the sample's own prior_encoding and corrections."""
+    from airv2x_perception_amd.opencood_iface import Airv2xV2XVit
+    fx = load_fixture("v2xvit_small_n3")
+    hy, args, sd, dd3 = _case(fx)
+    rng = [float(v) for v in fx["lidar_range"]]
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, int(fx["n_points"]), rng), rng), rng,
+                                 hy["preprocess"]["args"]["voxel_size"]) for i in range(3)]
+    dd2 = synth.build_data_dict([voxd[0], voxd[1]], ["vehicle", "rsu"], max_cav_num=args["max_cav_num"])
+    dd2["spatial_correction_matrix"] = dd3["spatial_correction_matrix"].clone()
+    dd2["spatial_correction_matrix"][0, 1] = dd3["spatial_correction_matrix"][0, 2]     # a different correction for agent 1
+    dd2["prior_encoding"][0, 1, 1] = 2.0                                                  # and a different time delay
+    model = Airv2xV2XVit(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    o3 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd3, sync_comm_rate=True).items()}
+    o2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd2, sync_comm_rate=True).items()}
+    ob = eng.forward(synth.merge_frames([dd3, dd2]), sync_comm_rate=True)
+    for k in ("psm", "rm", "obj"):
+        assert ob[k].shape[0] == 2 and torch.equal(ob[k][0:1], o3[k]) and torch.equal(ob[k][1:2], o2[k]), k
+    assert ob["comm_rate"] == o3["comm_rate"] + o2["comm_rate"]
