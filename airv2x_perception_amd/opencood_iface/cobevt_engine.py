@@ -37,8 +37,7 @@ class CoBEVTEngine(Where2ComEngine):
         self.L = int(sum(args["max_cav"].values()))
         self.heads_n = self.fax["input_dim"] // self.fax["dim_head"]
 
-    def share_weights(self):
-        raise NotImplementedError
+    FUSION_WEIGHTS = ("fax_layers", "head_ln", "head_lin", "compressor")
 
     def _linear(self, sd, wkey, bkey, act, up):
         w = sd[wkey].detach().float()

@@ -132,13 +132,16 @@ class Where2ComEngine:
         if args["modality_fusion"].get("compression", 0):
             raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
 
+    FUSION_WEIGHTS = ()   # attribute names of the packed fusion weights a subclass loads in _load_fusion
+
     def share_weights(self):
         """A second engine on the same device that shares the packed weights but owns its workspaces:
         one engine per in-flight frame (FramePipeline)."""
-        other = Where2ComEngine(self.args, self.device)
+        other = type(self)(self.args, self.device)
         for k in ("pfn", "blocks", "deblocks", "cat_c", "shrink", "feat_c", "cls_single", "head_splits", "heads",
-                  "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready"):
-            setattr(other, k, getattr(self, k))
+                  "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready") + tuple(self.FUSION_WEIGHTS):
+            if hasattr(self, k):
+                setattr(other, k, getattr(self, k))
         other.tile_cache = self.tile_cache
         other.autotune, other.conv_tile, other.stream_k, other.amp = self.autotune, self.conv_tile, self.stream_k, self.amp
         other.split3 = self.split3

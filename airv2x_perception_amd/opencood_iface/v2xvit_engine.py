@@ -39,8 +39,7 @@ class V2XViTEngine(Where2ComEngine):
             raise NotImplementedError("only the shipped V2X-ViT configuration (hetero attention, split_attn, relative pos)")
         self.L = int(args["max_cav_num"])
 
-    def share_weights(self):
-        raise NotImplementedError
+    FUSION_WEIGHTS = ("layers", "rte_table", "rte_lin")
 
     def _lin(self, w, b, act, up):
         w = w.detach().float()

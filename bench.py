@@ -176,12 +176,12 @@ def main():
     hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev, only=mine, model=a.model)
     if a.model == "cobevt":
         from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
-        a.inflight, a.cpu_frames = 1, 0
+        a.cpu_frames = 0
         sd = synth.synthetic_state_dict(synth.cobevt_param_spec(args), seed=0)
         model = Airv2xCoBEVT(args)
     elif a.model == "v2xvit":
         from airv2x_perception_amd.opencood_iface import Airv2xV2XVit
-        a.inflight, a.cpu_frames = 1, 0
+        a.cpu_frames = 0
         sd = synth.synthetic_state_dict(synth.v2xvit_param_spec(args), seed=0)
         model = Airv2xV2XVit(args)
     else:

@@ -102,3 +102,38 @@ def test_v2xvit_emulated_ranks_equal_single_gpu_forward():
     for k in ("psm", "rm", "obj"):
         assert torch.equal(out[k], ref[k]), k
     assert out["comm_rate"] == ref["comm_rate"]
+
+
+@pytest.mark.parametrize("which", ["where2com", "cobevt", "v2xvit"])
+def test_frame_pipeline_results_equal_sequential_forward(which):
+    """FramePipeline (frames in flight on separate HIP streams, shared packed weights, own workspaces) returns, for every
+    frame, exactly what the sequential data-parallel forward returns."""
+    from airv2x_perception_amd.opencood_iface.engine import FramePipeline
+    if which == "where2com":
+        from airv2x_perception_amd.opencood_iface import Airv2xWhere2com as M
+        fx = load_fixture("w2c_small_n3")
+        hy, args, sd, dd, _, _ = case_from_fixture(fx)
+    elif which == "cobevt":
+        import tests.test_cobevt as tc
+        from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT as M
+        fx = load_fixture("cobevt_small_n3")
+        hy, args, sd, dd = tc._case(fx)
+    else:
+        import tests.test_v2xvit as tv
+        from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
+        fx = load_fixture("v2xvit_small_n3")
+        hy, args, sd, dd = tv._case(fx)
+    model = M(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    ref = {k: v.clone() for k, v in eng.forward(dd).items() if torch.is_tensor(v) and v.dim() > 0}
+    pipe = FramePipeline(eng, 3)
+    outs = [pipe.submit(dd)[0] for _ in range(5)]
+    pipe.drain()                        # the caller's stream waits for the frames' streams before touching the outputs
+    torch.cuda.synchronize()
+    outs = [{k: v for k, v in o.items() if torch.is_tensor(v) and v.dim() > 0} for o in outs[-3:]]   # one per engine
+    for o in outs:
+        for k in ("psm", "rm", "obj"):
+            assert torch.equal(o[k], ref[k]), (which, k)
