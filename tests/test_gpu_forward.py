@@ -120,3 +120,30 @@ def test_batch_of_two_frames_equals_two_single_frames():
         assert torch.equal(ob[k][0:1], o3[k]) and torch.equal(ob[k][1:2], o2[k]), k
     assert ob["comm_rate"] == o3["comm_rate"] + o2["comm_rate"]
     assert abs(float(ob["com"]) - (float(o3["com"]) + float(o2["com"])) / 2) < 1e-6      # where2comm_fuse.py:147 mean over B
+
+
+def test_full_grid_permutation_of_non_ego_agents_is_invariant():
+    """Size-independent property at the BASELINE grid (704 x 200, 5 agents x 8192 points): the ego row of the per-pixel
+    attention (where2comm_fuse.py:152-164) is a softmax-weighted SUM over agents, so permuting the non-ego agents of a
+    type must leave psm / rm / obj unchanged up to fp32 summation order, and comm statistics exactly unchanged."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    from airv2x_perception_amd.opencood_iface.voxelizer import voxelize_points
+    hy = synth.default_hypes()
+    args, pp = hy["model"]["args"], hy["preprocess"]
+    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=4)
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    types = ["vehicle", "vehicle", "vehicle", "rsu", "rsu"]
+    vox_dev = [voxelize_points(torch.from_numpy(synth.synthetic_cloud(10 + i, 8192)).cuda(), pp["cav_lidar_range"],
+                               pp["args"]["voxel_size"], 32, pp["args"]["max_voxel_test"], range_filter=True) for i in range(5)]
+    a = model(synth.build_data_dict_device(vox_dev, types, "cuda", max_cav_num=args["max_cav_num"]))
+    a = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
+    perm = [0, 2, 1, 4, 3]          # ego stays first; vehicles 1<->2, rsus 0<->1
+    b = model(synth.build_data_dict_device([vox_dev[i] for i in perm], types, "cuda", max_cav_num=args["max_cav_num"]))
+    for k in ("psm", "rm", "obj"):
+        assert_close(b[k].cpu(), a[k].cpu(), 1e-4, 1e-4, f"permutation invariance {k}")
+    assert int(b["comm_rate"]) == int(a["comm_rate"]) and abs(float(b["com"]) - float(a["com"])) < 1e-7
+    # and the ego DOES matter: a different ego changes the result
+    c = model(synth.build_data_dict_device([vox_dev[i] for i in [1, 0, 2, 3, 4]], types, "cuda", max_cav_num=args["max_cav_num"]))
+    assert float((c["psm"] - a["psm"]).abs().max()) > 1e-2
