@@ -7,3 +7,20 @@ shown in INTEGRATION.md.
 from .airv2x_where2com import Airv2xWhere2com  # noqa: F401
 from .airv2x_cobevt import Airv2xCoBEVT  # noqa: F401,E402
 from .airv2x_v2xvit import Airv2xV2XVit  # noqa: F401,E402
+
+
+def create_model(hypes):
+    """Harness counterpart of the reference's name registry (tools/train_utils.py:288-325): import the module named by
+    ``hypes["model"]["core_method"]`` from THIS package and instantiate the class whose lower-cased name equals
+    ``core_method.replace("_", "")`` with ``hypes["model"]["args"]``.  Unknown names raise (the reference prints and exits)."""
+    import importlib
+    name = hypes["model"]["core_method"]
+    try:
+        mod = importlib.import_module(f"{__name__}.{name}")
+    except ModuleNotFoundError as e:
+        raise ValueError(f"core_method {name!r}: no such model in the MI355X build (airv2x_where2com, airv2x_cobevt, airv2x_v2xvit)") from e
+    target = name.replace("_", "").lower()
+    for attr, cls in vars(mod).items():
+        if attr.lower() == target and isinstance(cls, type):
+            return cls(hypes["model"]["args"])
+    raise ValueError(f"module {mod.__name__} has no class named {target} (ignoring case)")

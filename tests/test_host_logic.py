@@ -105,3 +105,16 @@ def test_synthetic_inputs_are_reproducible():
     assert synth.agent_types_for(6) == ["vehicle", "vehicle", "rsu", "drone", "vehicle", "vehicle"]
     idx, ts = synth.sort_types(synth.agent_types_for(6))
     assert ts == ["vehicle"] * 4 + ["rsu", "drone"] and idx == [0, 1, 4, 5, 2, 3]
+
+
+def test_create_model_follows_the_reference_name_registry():
+    """tools/train_utils.py:288-325: module = core_method, class = core_method without underscores, case-insensitive."""
+    from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT, Airv2xV2XVit, create_model
+    rng = [-12.8, -6.4, -3, 12.8, 6.4, 1]
+    hy = synth.default_hypes(rng)
+    assert hy["model"]["core_method"] == "airv2x_where2com"
+    assert isinstance(create_model(hy), Airv2xWhere2com)
+    assert isinstance(create_model(synth.default_hypes_cobevt(rng)), Airv2xCoBEVT)
+    assert isinstance(create_model(synth.default_hypes_v2xvit(rng, (2, 1, 1))), Airv2xV2XVit)
+    with pytest.raises(ValueError):
+        create_model({"model": {"core_method": "point_pillar_intermediate", "args": {}}})
