@@ -90,3 +90,47 @@ def test_gpu_tp_fp_matches_reference_golden(tmp_path):
     assert int(tp3.sum()) == 0
     tp4, _, _ = ev.match_tp_fp(torch.zeros(0, 8, 3), torch.zeros(0), torch.from_numpy(gt), 0.5)
     assert tp4.numel() == 0
+
+
+@pytest.mark.gpu
+def test_gpu_iou_matrix_matches_oracle_and_analytic_properties():
+    """The fp64 convex-clipping IoU of av2x_eval_tp_fp (shared with the NMS) against the oracle's C restatement on random
+    rotated rectangles, plus the properties any polygon IoU must have (shapely itself is absent: parity unpinned)."""
+    from ctypes import c_void_p
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = np.random.default_rng(12)
+
+    def boxes(n, spread):
+        c = g.uniform(-spread, spread, (n, 2))
+        l, w, yaw = g.uniform(1.0, 6.0, n), g.uniform(0.8, 3.0, n), g.uniform(-np.pi, np.pi, n)
+        base = np.array([[0.5, -0.5], [0.5, 0.5], [-0.5, 0.5], [-0.5, -0.5]])
+        out = np.zeros((n, 8, 3), np.float32)
+        for i in range(n):
+            R = np.array([[np.cos(yaw[i]), -np.sin(yaw[i])], [np.sin(yaw[i]), np.cos(yaw[i])]])
+            out[i, :4, :2] = (base * [l[i], w[i]]) @ R.T + c[i]
+        return out
+
+    det, gt = boxes(120, 8.0), boxes(90, 8.0)      # dense: most pairs overlap partially
+    det[0], gt[0] = gt[1].copy(), gt[1].copy()     # identical boxes
+    d, t = torch.from_numpy(det).cuda(), torch.from_numpy(gt).cuda()
+    order = torch.arange(120, dtype=torch.int32, device="cuda")
+    iou = torch.empty(120 * 90, device="cuda")
+    tp = torch.empty(120, dtype=torch.int32, device="cuda")
+    mg = torch.empty(120, dtype=torch.int32, device="cuda")
+    P = lambda x: c_void_p(x.data_ptr())
+    _lib.check(lib.av2x_eval_tp_fp(P(d), P(order), 120, P(t), 90, 0.5, P(iou), P(tp), P(mg),
+                                   c_void_p(torch.cuda.current_stream().cuda_stream)), "eval")
+    m = iou.view(120, 90).cpu().numpy()
+    ref = np.array([[eo.po.quad_iou(det[i, :4, :2], gt[j, :4, :2]) for j in range(90)] for i in range(120)], np.float32)
+    assert np.abs(m - ref).max() <= 1e-6
+    assert m.min() >= 0.0 and m.max() <= 1.0 + 1e-6 and abs(m[0, 1] - 1.0) < 1e-6
+    assert (m > 0).mean() > 0.05                    # the test is not vacuous
+    # symmetry: IoU(a, b) == IoU(b, a)
+    iou2 = torch.empty(90 * 120, device="cuda")
+    tp2 = torch.empty(90, dtype=torch.int32, device="cuda")
+    mg2 = torch.empty(90, dtype=torch.int32, device="cuda")
+    o2 = torch.arange(90, dtype=torch.int32, device="cuda")
+    _lib.check(lib.av2x_eval_tp_fp(P(t), P(o2), 90, P(d), 120, 0.5, P(iou2), P(tp2), P(mg2),
+                                   c_void_p(torch.cuda.current_stream().cuda_stream)), "eval")
+    assert np.abs(iou2.view(90, 120).cpu().numpy().T - m).max() <= 1e-6
