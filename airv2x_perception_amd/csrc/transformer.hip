@@ -475,6 +475,135 @@ __global__ __launch_bounds__(256) void fax_attention_mfma4_kernel(const FaxParam
     }
 }
 
+// ---------------------------------------------------------------- ws = 4, one WAVE per (window, head): no barriers
+// The whole attention of a (window, head) lives in one wave's registers (v_mfma_f32_16x16x4_f32 tiles = one agent's 16
+// tokens): K and V fragments of the valid agents are loaded once, then for every query agent qt
+//   S^T[key tile kt][query] = K_kt (Q_qt*scale)^T   (row = key 4h+r -> (w1 = h, w2 = r), col = query lane&15)
+//   + bias tab[((qt-kt+L-1)*7 + (w1q-h+3))*7 + (w2q-r+3)], softmax over (kt, r) in-lane + lanes xor 16 / 32,
+//   O = P V with P already the A operand (see window_attn_mfma_kernel in v2xvit.hip), stored 64 B per row.
+// Wave w of a workgroup serves heads w, w+4, ... of the workgroup's windows, so its bias tables are staged once.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+template <int NV>   // compile-time bound on the valid agents: 4 or 8 key tiles held in registers
+__global__ __launch_bounds__(256) void fax_attention_wave_kernel(const FaxParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane & 15, h = lane >> 4;
+    const int X = p.H / 4, Y = p.W / 4, nwin = X * Y;
+    const int C = p.heads * DH, C3 = 3 * C;
+    const int L = p.L, nv = p.n_valid;
+    const int tab_n = (2 * L - 1) * 49, tab_s = (tab_n + 63) & ~63;
+    const int hpw = (p.heads + 3) >> 2;                     // heads per wave
+    float* tabs = lds + (size_t)wave * hpw * tab_s;
+    for (int k = 0; k < hpw; ++k) {
+        const int head = wave + 4 * k;
+        if (head < p.heads)
+            for (int i = lane; i < tab_n; i += 64) tabs[k * tab_s + i] = p.table[(size_t)i * p.heads + head];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int w1q = t >> 2, w2q = t & 3;
+    const size_t HW = (size_t)p.H * p.W;
+    const float kLog2e = 1.4426950408889634f;
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const int wx = win / Y, wy = win - wx * Y;
+        // pixel of window token (w1, w2)
+        const int ph_q = p.grid ? (w1q * X + wx) : (wx * 4 + w1q), pw_q = p.grid ? (w2q * Y + wy) : (wy * 4 + w2q);
+        const size_t pix_t = (size_t)ph_q * p.W + pw_q;      // this lane's token as key row / query column
+        const int ph_h = p.grid ? (h * X + wx) : (wx * 4 + h);
+        size_t pix_hr[4];                                     // token (w1 = h, w2 = r): V rows and output rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pix_hr[r] = (size_t)ph_h * p.W + (p.grid ? (r * Y + wy) : (wy * 4 + r));
+        for (int k = 0; k < hpw; ++k) {
+            const int head = wave + 4 * k;
+            if (head >= p.heads) break;
+            const float* tab = tabs + k * tab_s;
+            const float* base = p.qkv + head * DH;
+            f32x4w kf[NV][2];
+            float vf[NV][4][2];
+#pragma unroll
+            for (int kt = 0; kt < NV; ++kt) {
+                if (kt < nv) {
+                    const float* kr = base + ((size_t)kt * HW + pix_t) * C3 + C + 4 * h;
+                    kf[kt][0] = *reinterpret_cast<const f32x4w*>(kr);
+                    kf[kt][1] = *reinterpret_cast<const f32x4w*>(kr + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* vr = base + ((size_t)kt * HW + pix_hr[r]) * C3 + 2 * C + t;
+                        vf[kt][r][0] = vr[0];
+                        vf[kt][r][1] = vr[16];
+                    }
+                }
+            }
+            for (int qt = 0; qt < L; ++qt) {
+                const float* qr = base + ((size_t)qt * HW + pix_t) * C3 + 4 * h;
+                f32x4w q0 = *reinterpret_cast<const f32x4w*>(qr), q1 = *reinterpret_cast<const f32x4w*>(qr + 16);
+                q0 *= p.scale; q1 *= p.scale;
+                const int cq = ((qt + L - 1) * 7 + (w1q - h + 3)) * 7 + (w2q + 3);
+                f32x4w st[NV];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NV; ++kt) {
+                    if (kt < nv) {
+                        f32x4w a = {0.f, 0.f, 0.f, 0.f};
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][0].x, q0.x, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][0].y, q0.y, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][0].z, q0.z, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][0].w, q0.w, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][1].x, q1.x, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][1].y, q1.y, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][1].z, q1.z, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][1].w, q1.w, a, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            a[r] += tab[cq - kt * 49 - r];
+                            m = fmaxf(m, a[r]);
+                        }
+                        st[kt] = a;
+                    }
+                }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const float mb = m * kLog2e;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NV; ++kt) {
+                    if (kt < nv) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][r], kLog2e, -mb));
+                            st[kt][r] = e;
+                            sum += e;
+                        }
+                    }
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+                f32x4w o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < NV; ++kt) {
+                    if (kt < nv) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = st[kt][r] * inv;
+                            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vf[kt][r][0], o0, 0, 0, 0);
+                            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vf[kt][r][1], o1, 0, 0, 0);
+                        }
+                    }
+                }
+                float* ob = p.out + head * DH + t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* o = ob + ((size_t)qt * HW + pix_hr[r]) * C;
+                    o[0] = o0[r];
+                    o[16] = o1[r];
+                }
+            }
+        }
+    }
+}
+
 __global__ void agent_mean_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, int L) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = x[i];
@@ -530,7 +659,21 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
     const int Tk = n_valid * window * window;
     const int tab_n = (2 * n_agents_padded - 1) * (2 * window - 1) * (2 * window - 1);
     const int T = n_agents_padded * window * window;
-    if (T <= 128 && window == 4 && !(grid_partition & 6)) {   // ws = 4: S^T form, P stays in registers
+    // ws = 4: one wave per (window, head), everything in registers.  With more than 4 valid agents the 8-key-tile variant needs
+    // the whole register file (1 wave / SIMD) and only ties the workgroup-per-window kernel: it is used up to 4 valid agents
+    // (test hook: grid_partition bit 4 forces it for any count).
+    if (T <= 128 && window == 4 && !(grid_partition & 14) && (n_valid <= 4 || (grid_partition & 16))) {
+        const int tab_s = (tab_n + 63) & ~63;
+        const size_t lds_w = (size_t)4 * ((heads + 3) / 4) * tab_s * sizeof(float);
+        if (lds_w <= 64 * 1024) {
+            const int nwin = (h / 4) * (w / 4);
+            const dim3 grid(nwin < 2048 ? nwin : 2048);
+            if (n_valid <= 4) hipLaunchKernelGGL(fax_attention_wave_kernel<4>, grid, dim3(256), lds_w, av2x::as_stream(stream), p);
+            else hipLaunchKernelGGL(fax_attention_wave_kernel<8>, grid, dim3(256), lds_w, av2x::as_stream(stream), p);
+            return av2x::check_launch("fax_attention_wave_kernel");
+        }
+    }
+    if (T <= 128 && window == 4 && !(grid_partition & 6)) {   // ws = 4: S^T form, P stays in registers (test hook: bit 3)
         const int TkP = (Tk + 31) & ~31;
         const size_t lds_4 = ((size_t)TkP * KLD + (size_t)TkP * VLD4 + ((tab_n + 3) & ~3) + 128) * sizeof(float);
         static size_t attr_4 = 0;

@@ -257,9 +257,10 @@ int av2x_eval_tp_fp(const float* det_corners, const int32_t* order, int32_t n_de
  *   tokens of a window are ordered (agent, w1, w2); grid_partition 0 = 'b m d (x w1) (y w2)' (:167),
  *   1 = 'b m d (w1 x) (w2 y)' (:185); keys of agents >= n_valid are masked (-inf, :103-108);
  *   out (L*h*w, heads*dim_head) in the same token order (heads merged, before to_out).
- *   Kernels: window 4 and L*16 <= 128 tokens -> MFMA with the score tile computed transposed (softmax in-lane,
- *   P stays in registers); other windows -> generic MFMA kernel; > 128 tokens -> scalar kernel.  Test hooks in
- *   grid_partition: bit 1 forces the scalar kernel, bit 2 the generic MFMA kernel.
+ *   Kernels: window 4 and L*16 <= 128 tokens -> one wave per (window, head) on v_mfma_f32_16x16x4_f32 with the score
+ *   tile computed transposed (softmax in-lane, P / K / V stay in registers, no barrier); other windows -> generic MFMA
+ *   kernel; > 128 tokens -> scalar kernel.  Test hooks in grid_partition: bit 1 forces the scalar kernel, bit 2 the
+ *   generic MFMA kernel, bit 3 the workgroup-per-window transposed-score kernel.
  * av2x_agent_mean: y = mean over the agent axis of x (n_agents, elems_per_agent)  (:270).
  * ------------------------------------------------------------------------------------ */
 int av2x_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,
