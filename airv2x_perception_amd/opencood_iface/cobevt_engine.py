@@ -39,8 +39,11 @@ class CoBEVTEngine(Where2ComEngine):
 
     FUSION_WEIGHTS = ("fax_layers", "head_ln", "head_lin", "compressor")
 
-    def _linear(self, sd, wkey, bkey, act, up):
+    def _linear(self, sd, wkey, bkey, act, up, rows=None):
+        """Linear -> 1x1 conv layer; ``rows`` = slice of output features (used to split to_qkv into q | k,v)."""
         w = sd[wkey].detach().float()
+        if rows is not None:
+            w = w[rows]
         wp, coutp = pack_conv_weight(w.view(w.shape[0], w.shape[1], 1, 1))
         b = sd[bkey].detach().float() if bkey else torch.zeros(w.shape[0])
         return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
@@ -85,6 +88,9 @@ class CoBEVTEngine(Where2ComEngine):
                 blk[part] = {
                     "ln1": (up(sd[a + ".norm.weight"].float()), up(sd[a + ".norm.bias"].float())),
                     "qkv": self._linear(sd, a + ".fn.to_qkv.weight", None, 0, up),
+                    # padded agents are never keys (swap_fusion_modules.py:103-108): their K / V columns are not computed
+                    "q": self._linear(sd, a + ".fn.to_qkv.weight", None, 0, up, rows=slice(0, C)),
+                    "kv": self._linear(sd, a + ".fn.to_qkv.weight", None, 0, up, rows=slice(C, 3 * C)),
                     "out": self._linear(sd, a + ".fn.to_out.0.weight", None, 0, up),
                     "table": up(sd[a + ".fn.relative_position_bias_table.weight"].detach().float()),
                     "ln2": (up(sd[f + ".norm.weight"].float()), up(sd[f + ".norm.bias"].float())),
@@ -114,7 +120,11 @@ class CoBEVTEngine(Where2ComEngine):
             for gi, part in enumerate(("window", "grid")):
                 P = blk[part]
                 self.ln(x, P["ln1"], xn, nt, C)
-                self.conv(P["qkv"], xn, L, H, W, qkv)
+                if n_valid == L:
+                    self.conv(P["qkv"], xn, L, H, W, qkv)
+                else:   # q for all L agents (padded query tokens attend the valid keys), k | v only for the valid ones
+                    self.conv(P["q"], xn, L, H, W, qkv, out_ctot=3 * C, out_coff=0)
+                    self.conv(P["kv"], xn, n_valid, H, W, qkv, out_ctot=3 * C, out_coff=C)
                 _lib.check(self.lib.av2x_fax_attention(_ptr(qkv), _ptr(P["table"]), _ptr(att), L, n_valid, H, W, ws,
                                                        self.heads_n, self.fax["dim_head"], gi, self.stream()),
                            "av2x_fax_attention")
