@@ -98,6 +98,7 @@ struct HgtParams {
     const float* mask;   // (n, HW) com_mask of the KEY agent at the pixel
     float* out;          // (n, HW, 256)
     int n, hw;
+    int nq;              // query agents 0 .. nq-1 are computed (nq = n, or 1 when only the ego's output is consumed)
     int types[32];
     float scale;
 };
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtParams p) {
     if (pix >= p.hw) return;
     const int col = lane * 4;   // head = lane / 8, 4 of its 32 dims
     constexpr int PC = 1280;
-    for (int i = 0; i < p.n; ++i) {
+    for (int i = 0; i < p.nq; ++i) {
         const int ti = p.types[i];
         const float* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
         const float4 q0 = *reinterpret_cast<const float4*>(qi + col);         // keys of type 0
@@ -376,13 +377,22 @@ extern "C" int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_
     return av2x::check_launch("add_agent_vector_kernel");
 }
 
+extern "C" int av2x_hgt_attention_q(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
+                                    int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
+
 extern "C" int av2x_hgt_attention(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
                                   int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
+    return av2x_hgt_attention_q(proj, mask, types_host, out, n, n, hw, heads, dim_head, stream);
+}
+
+extern "C" int av2x_hgt_attention_q(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
+                                    int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
+    if (n_query < 1 || n_query > n) return av2x::fail("av2x_hgt_attention: n_query=%d outside 1..%d", n_query, n);
     if (!proj || !mask || !types_host || !out) return av2x::fail("av2x_hgt_attention: null argument");
     if (heads != 8 || dim_head != 32) return av2x::fail("av2x_hgt_attention: heads=%d dim_head=%d unsupported (8 x 32)", heads, dim_head);
     if (n < 1 || n > 32 || hw <= 0) return av2x::fail("av2x_hgt_attention: bad sizes");
     HgtParams p;
-    p.proj = proj; p.mask = mask; p.out = out; p.n = n; p.hw = hw;
+    p.proj = proj; p.mask = mask; p.out = out; p.n = n; p.hw = hw; p.nq = n_query;
     for (int i = 0; i < 32; ++i) p.types[i] = i < n ? (types_host[i] != 0) : 0;
     p.scale = 1.0f / sqrtf((float)dim_head);
     hipLaunchKernelGGL(hgt_attention_kernel, dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);

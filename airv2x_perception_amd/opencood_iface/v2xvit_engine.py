@@ -38,6 +38,8 @@ class V2XViTEngine(Where2ComEngine):
         if not self.cav["use_hetero"] or self.pw["fusion_method"] != "split_attn" or not self.pw["relative_pos_embedding"]:
             raise NotImplementedError("only the shipped V2X-ViT configuration (hetero attention, split_attn, relative pos)")
         self.L = int(args["max_cav_num"])
+        # the encoder's output is the ego's feature map only: skip what the last layer computes for the other agents
+        self.ego_only_last = True
 
     FUSION_WEIGHTS = ("layers", "rte_table", "rte_lin")
 
@@ -57,7 +59,7 @@ class V2XViTEngine(Where2ComEngine):
                 q = f"{p}.layers.{d}.0.layers.{nb}"
                 h = q + ".0.fn"
                 ratt, rmsg = sd[h + ".relation_att"].double().cpu(), sd[h + ".relation_msg"].double().cpu()
-                proj, aout = [], []
+                proj, aout, proj_kv = [], [], []
                 for t in range(2):
                     Wq, bq = sd[f"{h}.q_linears.{t}.weight"].double().cpu(), sd[f"{h}.q_linears.{t}.bias"].double().cpu()
                     Wk, bk = sd[f"{h}.k_linears.{t}.weight"].double().cpu(), sd[f"{h}.k_linears.{t}.bias"].double().cpu()
@@ -77,12 +79,14 @@ class V2XViTEngine(Where2ComEngine):
                             rows_w.append(rmsg[e, m].t() @ Wv[sl])
                             rows_b.append(rmsg[e, m].t() @ bv[sl])
                     proj.append(self._lin(torch.cat(rows_w, 0), torch.cat(rows_b, 0), 0, up))
+                    # k | v' columns only (proj[:, 512:1280]): all a non-ego agent contributes to the LAST layer
+                    proj_kv.append(self._lin(torch.cat(rows_w, 0)[512:], torch.cat(rows_b, 0)[512:], 0, up))
                     aout.append(self._lin(sd[f"{h}.a_linears.{t}.weight"], sd[f"{h}.a_linears.{t}.bias"], 0, up))
                 w = q + ".1.fn"
                 qkv_w = torch.cat([sd[f"{w}.pwmsa.{i}.to_qkv.weight"] for i in range(3)], 0)
                 blk = {
                     "ln1": (up(sd[q + ".0.norm.weight"].float()), up(sd[q + ".0.norm.bias"].float())),
-                    "proj": proj, "aout": aout,
+                    "proj": proj, "aout": aout, "proj_kv": proj_kv,
                     "ln2": (up(sd[q + ".1.norm.weight"].float()), up(sd[q + ".1.norm.bias"].float())),
                     "qkv3": self._lin(qkv_w, None, 0, up),
                     "pos": [up(sd[f"{w}.pwmsa.{i}.pos_embedding"].float()) for i in range(3)],
@@ -156,36 +160,47 @@ class V2XViTEngine(Where2ComEngine):
         logits = self.buf("vit_logits", (n, 1, 1, 3 * C))
         hid = self.buf("vit_hid", (n, H, W, self.enc["feed_forward"]["mlp_dim"]))
         groups = self._groups(types)
+        last = len(self.layers) - 1
         for di, (blocks, ffn) in enumerate(self.layers):
-            for blk in blocks:
+            for bi, blk in enumerate(blocks):
+                # V2XTransformer returns output[:, 0] (the ego) only: in the last block of the last layer the other agents
+                # are needed as KEYS / VALUES of the HGT attention and nowhere else -> m = 1 agent from there on
+                ego_only = self.ego_only_last and di == last and bi == len(blocks) - 1 and trace is None and n > 1
                 # ---- x = HGT(LN(x)) + x
                 self.ln(x, blk["ln1"], xn, n * hw, C)
-                for (a, b, t) in groups:
-                    self.conv(blk["proj"][t], xn[a:b], b - a, H, W, proj[a:b])
-                _lib.check(self.lib.av2x_hgt_attention(_ptr(proj), _ptr(mask), ctypes.cast(tarr, c_void_p), _ptr(att), n, hw,
-                                                       self.cav["heads"], self.cav["dim_head"], st()), "av2x_hgt_attention")
-                for (a, b, t) in groups:
+                if ego_only:
+                    self.conv(blk["proj"][types[0]], xn[0:1], 1, H, W, proj[0:1])
+                    for (a, b, t) in self._groups(types[1:]):
+                        self.conv(blk["proj_kv"][t], xn[a + 1:b + 1], b - a, H, W, proj[a + 1:b + 1], out_ctot=1280, out_coff=512)
+                else:
+                    for (a, b, t) in groups:
+                        self.conv(blk["proj"][t], xn[a:b], b - a, H, W, proj[a:b])
+                m = 1 if ego_only else n
+                _lib.check(self.lib.av2x_hgt_attention_q(_ptr(proj), _ptr(mask), ctypes.cast(tarr, c_void_p), _ptr(att), n, m, hw,
+                                                         self.cav["heads"], self.cav["dim_head"], st()), "av2x_hgt_attention")
+                for (a, b, t) in (self._groups(types[:1]) if ego_only else groups):
                     self.conv(blk["aout"][t], att[a:b], b - a, H, W, x[a:b], residual=x[a:b])
                 if trace is not None:
                     trace[f"hgt{di}"] = x.clone()
                 # ---- x = SplitAttn(window attentions(LN(x))) + x
-                self.ln(x, blk["ln2"], xn, n * hw, C)
-                self.conv(blk["qkv3"], xn, n, H, W, qkv3)
+                self.ln(x, blk["ln2"], xn, m * hw, C)
+                self.conv(blk["qkv3"], xn, m, H, W, qkv3)
                 for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
-                    _lib.check(self.lib.av2x_window_attention(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat), n, H, W,
+                    _lib.check(self.lib.av2x_window_attention(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat), m, H, W,
                                                               h, dh, ws, st()), "av2x_window_attention")
-                    self.conv(blk["wout"][i], wat, n, H, W, br[i])
-                _lib.check(self.lib.av2x_split_attn_gap(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(gap), _ptr(gap_scratch), n, hw, C,
+                    self.conv(blk["wout"][i], wat, m, H, W, br[i])
+                _lib.check(self.lib.av2x_split_attn_gap(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(gap), _ptr(gap_scratch), m, hw, C,
                                                         st()), "gap")
-                self.conv(blk["fc1"], gap, n, 1, 1, g1)
-                self.ln(g1, blk["bn1"], g2, n, C, relu=1)
-                self.conv(blk["fc2"], g2, n, 1, 1, logits)
+                self.conv(blk["fc1"], gap, m, 1, 1, g1)
+                self.ln(g1, blk["bn1"], g2, m, C, relu=1)
+                self.conv(blk["fc2"], g2, m, 1, 1, logits)
                 _lib.check(self.lib.av2x_split_attn_combine(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), _ptr(x), _ptr(x),
-                                                            n, hw, C, st()), "combine")
+                                                            m, hw, C, st()), "combine")
             # ---- x = FFN(LN(x)) + x
-            self.ln(x, ffn["ln"], xn, n * hw, C)
-            self.conv(ffn["ff1"], xn, n, H, W, hid)
-            self.conv(ffn["ff2"], hid, n, H, W, x, residual=x)
+            m = 1 if (self.ego_only_last and di == last and trace is None and n > 1) else n
+            self.ln(x, ffn["ln"], xn, m * hw, C)
+            self.conv(ffn["ff1"], xn, m, H, W, hid)
+            self.conv(ffn["ff2"], hid, m, H, W, x, residual=x)
             if trace is not None:
                 trace[f"layer{di}"] = x.clone()
         return x[0:1]

@@ -306,6 +306,11 @@ int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_t elems_per
                           av2x_stream_t stream);
 int av2x_hgt_attention(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
                        int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
+/* same, but only the query agents 0 .. n_query-1 are computed (keys / values: all n agents).  V2XTransformer returns the
+ * ego's feature only (v2xvit_basic.py: output[:, 0]), so in the LAST encoder layer n_query = 1 and the q columns of the
+ * other agents' rows of `proj` are never read. */
+int av2x_hgt_attention_q(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
+                         int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
 int av2x_window_attention(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, float* out,
                           int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
                           av2x_stream_t stream);
