@@ -160,3 +160,27 @@ def test_where2comm_split3_forward_meets_the_fp32_tolerance():
             got = out[k].cpu().numpy()
             assert_close(got[..., ::hs, ::hs] if hs > 1 else got, fx[k], 2e-4, 2e-4, f"{name} {k} (split-3)")
         assert int(out["comm_rate"]) == int(fx["comm_rate"])
+
+
+@pytest.mark.parametrize("which,name", [("cobevt", "cobevt_full_n4"), ("v2xvit", "v2xvit_full_n4")])
+def test_transformer_models_split3_meet_the_fp32_tolerance_at_full_grid(which, name):
+    """engine.split3 on the CoBEVT / V2X-ViT paths at the BASELINE grid: same tolerances as the fp32-MFMA tests."""
+    fx = load_fixture(name)
+    if which == "cobevt":
+        import tests.test_cobevt as tc
+        from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT as M
+        hy, args, sd, dd = tc._case(fx)
+        rtol, atol_of = 3e-4, lambda ref: 3e-4
+    else:
+        import tests.test_v2xvit as tv
+        from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
+        hy, args, sd, dd = tv._case(fx)
+        rtol, atol_of = 1e-3, lambda ref: 1e-4 * max(10.0, float(np.abs(ref).max()))
+    model = M(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    model.engine().split3 = True
+    out = model(dd)
+    hs = int(fx["head_stride"])
+    for k in ("psm", "rm", "obj"):
+        assert_close(out[k].cpu().numpy()[..., ::hs, ::hs], fx[k], rtol, atol_of(fx[k]), f"{name} {k} (split-3)")
