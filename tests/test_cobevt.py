@@ -159,3 +159,31 @@ def test_gpu_batch_of_two_frames_equals_two_single_frames():
     ob = eng.forward(synth.merge_frames([dd3, dd2]))
     for k in ("psm", "rm", "obj"):
         assert ob[k].shape[0] == 2 and torch.equal(ob[k][0:1], o3[k]) and torch.equal(ob[k][1:2], o2[k]), k
+
+
+@pytest.mark.gpu
+def test_gpu_full_house_and_empty_cloud_against_oracle():
+    """Edge cases: (a) n = L = 7 agents (no padded agent: the fused q|k|v GEMM and the 8-key-tile attention path);
+    (b) an agent whose cloud is empty after the crop -> the reference's two dummy points (sp_voxel_preprocessor.py:80-90)."""
+    from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
+    rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0]
+    hy = synth.default_hypes_cobevt(rng)
+    args, pp = hy["model"]["args"], hy["preprocess"]
+    sd = synth.synthetic_state_dict(synth.cobevt_param_spec(args), seed=11)
+    model = Airv2xCoBEVT(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    dummy = np.array([[0, 0, 0, 0], [-0.218277, -11.13425732, -80.05884552, 1.230595649e-38]], dtype=np.float32)
+    for types, empty in ((["vehicle"] * 3 + ["rsu"] * 2 + ["drone"] * 2, None), (["vehicle", "rsu", "drone"], 1)):
+        voxd = []
+        for i in range(len(types)):
+            pts = vox.mask_points_by_range(synth.synthetic_cloud(20 + i, 500, rng), rng)
+            if empty == i:
+                pts = dummy
+            voxd.append(vox.points_to_voxels(pts, rng, pp["args"]["voxel_size"]))
+        dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+        out = model(dd)
+        with torch.no_grad():
+            ref = cob.cobevt_forward(dd, sd, args)
+        for k in ("psm", "rm", "obj"):
+            assert_close(out[k].cpu(), ref[k], 3e-4, 3e-4, f"{len(types)} agents, empty={empty}: {k}")
