@@ -20,14 +20,13 @@ from .. import _lib
 def voc_ap(rec, prec):
     """VOC 2010 average precision (eval_utils_opv2v.py:15-38).  Like the reference it returns
     (ap, mrec, mpre) with the 0/1 sentinels added; unlike it the caller's lists are not modified."""
-    mrec = [0.0] + list(rec) + [1.0]
-    mpre = [0.0] + list(prec) + [0.0]
-    for i in range(len(mpre) - 2, -1, -1):
-        mpre[i] = max(mpre[i], mpre[i + 1])
+    mrec = np.concatenate(([0.0], np.asarray(rec, dtype=np.float64), [1.0]))
+    mpre = np.concatenate(([0.0], np.asarray(prec, dtype=np.float64), [0.0]))
+    mpre = np.maximum.accumulate(mpre[::-1])[::-1]            # monotone precision envelope (right to left running max)
     ap = 0.0
-    for i in range(1, len(mrec)):
-        if mrec[i] != mrec[i - 1]:
-            ap += (mrec[i] - mrec[i - 1]) * mpre[i]
+    for i in (np.flatnonzero(mrec[1:] != mrec[:-1]) + 1).tolist():   # recall steps, summed left to right in Python floats
+        ap += float(mrec[i] - mrec[i - 1]) * float(mpre[i])
+    mrec, mpre = mrec.tolist(), mpre.tolist()
     return ap, mrec, mpre
 
 
@@ -98,11 +97,10 @@ def calculate_ap(result_stat, iou, global_sort_detections):
 
 def eval_final_results(result_stat, save_path, global_sort_detections=False, eval_epoch=None):
     """eval_utils_opv2v.py:154-189: AP@0.3/0.5/0.7, dumped to ``save_path/eval_epoch{N}.yaml``."""
-    ap_30, mrec_30, mpre_30 = calculate_ap(result_stat, 0.30, global_sort_detections)
-    ap_50, mrec_50, mpre_50 = calculate_ap(result_stat, 0.50, global_sort_detections)
-    ap_70, mrec_70, mpre_70 = calculate_ap(result_stat, 0.70, global_sort_detections)
-    dump = {"ap_30": ap_30, "ap_50": ap_50, "ap_70": ap_70, "mpre_50": mpre_50, "mrec_50": mrec_50,
-            "mpre_70": mpre_70, "mrec_70": mrec_70}
+    res = {thr: calculate_ap(result_stat, thr, global_sort_detections) for thr in (0.30, 0.50, 0.70)}
+    ap_30, ap_50, ap_70 = res[0.30][0], res[0.50][0], res[0.70][0]
+    dump = {"ap_30": ap_30, "ap_50": ap_50, "ap_70": ap_70, "mpre_50": res[0.50][2], "mrec_50": res[0.50][1],
+            "mpre_70": res[0.70][2], "mrec_70": res[0.70][1]}
     name = f"eval_epoch{eval_epoch}.yaml" if not global_sort_detections else "eval_global_sort.yaml"
     if save_path is not None:
         import yaml
