@@ -34,6 +34,9 @@ SIGNATURES = {
     "av2x_last_error": (c_char_p, []),
     "av2x_pillar_vfe_scatter": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_pillar_vfe": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    "av2x_pillar_scatter": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_fill_zero": (c_int32, [c_void_p, c_uint64, c_void_p]),
     "av2x_conv2d": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_conv2d_res": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

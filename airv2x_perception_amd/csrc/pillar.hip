@@ -13,6 +13,9 @@ constexpr int kFeat = 10;  // x y z i | cluster xyz | centre xyz (airv2x_pillar_
 constexpr int kOut = 64;
 constexpr int kLdF = 12;   // padded feature row (three 16-byte reads)
 
+// DENSE = false: scatter into the NHWC canvas (the fused product path).  DENSE = true: ``canvas`` is the
+// (n_pillars, 64) ``pillar_features`` array of the stand-alone PillarVFE module (airv2x_pillar_vfe.py:156-158).
+template <bool DENSE>
 __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
     const float4* __restrict__ vox, const int4* __restrict__ coords, const int* __restrict__ npts, int n_pillars,
     const float* __restrict__ pfn_w, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
@@ -74,13 +77,29 @@ __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
             acc = fmaf(b.w, w[7], acc); acc = fmaf(d.x, w[8], acc); acc = fmaf(d.y, w[9], acc);
             best = fmaxf(best, fmaxf(fmaf(acc, sc, sh), 0.f));
         }
-        if (c.x >= 0 && c.x < n_agents && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx) {
+        if (DENSE) {
+            canvas[(size_t)pil * kOut + lane] = best;
+        } else if (c.x >= 0 && c.x < n_agents && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx) {
             const int agent = slot_map ? slot_map[c.x] : agent0 + c.x;
             // idx = z + y*nx + x with nz == 1 (point_pillar_scatter.py:59-61)
             const size_t pix = ((size_t)agent * ny + c.z) * nx + c.w + c.y;
             canvas[pix * kOut + lane] = best;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// PointPillarScatter alone (point_pillar_scatter.py:39-68): canvas[agent, y, x, :] = pillar_features[pil, :].
+// One thread per (pillar, 4 channels); the canvas is NHWC so a pillar is one contiguous C*4-byte run.
+__global__ void pillar_scatter_kernel(const float4* __restrict__ feats, const int4* __restrict__ coords, int n_pillars,
+                                      int c4, float4* __restrict__ canvas, int n_agents, int ny, int nx) {
+    const size_t total = (size_t)n_pillars * c4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pil = (int)(i / c4), q = (int)(i % c4);
+        const int4 c = coords[pil];
+        if (c.x < 0 || c.x >= n_agents || (unsigned)c.z >= (unsigned)ny || (unsigned)c.w >= (unsigned)nx) continue;
+        const size_t pix = ((size_t)c.x * ny + c.z) * nx + c.w + c.y;
+        canvas[pix * c4 + q] = feats[i];
     }
 }
 
@@ -113,11 +132,43 @@ extern "C" int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_
     if (n_pillars < 0 || ny <= 0 || nx <= 0) return av2x::fail("av2x_pillar_vfe_scatter: bad sizes");
     int blocks = (n_pillars + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(pillar_vfe_scatter_kernel, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
+    hipLaunchKernelGGL(pillar_vfe_scatter_kernel<false>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
                        voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
                        geom[4], geom[5], canvas, canvas_agent0, slot_map, n_agents_type, ny, nx);
     return av2x::check_launch("pillar_vfe_scatter_kernel");
+}
+
+extern "C" int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                               int32_t n_pillars, const float* pfn_w, const float* bn_scale, const float* bn_shift,
+                               const float* geom, float* pillar_features, av2x_stream_t stream) {
+    if (n_pillars == 0) return 0;
+    if (!voxel_features || !voxel_coords || !voxel_num_points || !pfn_w || !bn_scale || !bn_shift || !geom || !pillar_features)
+        return av2x::fail("av2x_pillar_vfe: null argument");
+    if (n_pillars < 0) return av2x::fail("av2x_pillar_vfe: bad sizes");
+    int blocks = (n_pillars + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(pillar_vfe_scatter_kernel<true>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
+                       voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
+                       geom[4], geom[5], pillar_features, 0, (const int*)nullptr, 0, 0, 0);
+    return av2x::check_launch("pillar_vfe_kernel");
+}
+
+extern "C" int av2x_pillar_scatter(const float* pillar_features, const int32_t* voxel_coords, int32_t n_pillars,
+                                   int32_t channels, float* canvas, int32_t n_agents, int32_t ny, int32_t nx,
+                                   av2x_stream_t stream) {
+    if (n_pillars == 0) return 0;
+    if (!pillar_features || !voxel_coords || !canvas) return av2x::fail("av2x_pillar_scatter: null argument");
+    if (n_pillars < 0 || channels <= 0 || channels % 4 || n_agents <= 0 || ny <= 0 || nx <= 0)
+        return av2x::fail("av2x_pillar_scatter: bad sizes (channels must be a multiple of 4)");
+    const size_t total = (size_t)n_pillars * (channels / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(pillar_scatter_kernel, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(pillar_features), reinterpret_cast<const int4*>(voxel_coords),
+                       n_pillars, channels / 4, reinterpret_cast<float4*>(canvas), n_agents, ny, nx);
+    return av2x::check_launch("pillar_scatter_kernel");
 }
 
 extern "C" int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream) {

@@ -117,6 +117,50 @@ __global__ __launch_bounds__(256) void pixel_attn_kernel(const AgentPtrs ap, int
     }
 }
 
+// Any other channel count (multiple of 4): scores first, then the weighted sum (second read of the agents' pixels
+// comes from L2).  Only the reduced test / sub-module configurations take this path.
+__global__ __launch_bounds__(256) void pixel_attn_generic_kernel(const AgentPtrs ap, int n_agents, int hw, int c, float sqrt_c,
+                                                                 float* __restrict__ out) {
+    const int t = threadIdx.x & 15;
+    const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (pix >= hw) return;
+    const size_t base = (size_t)pix * c;
+    float wgt[kMaxAgents];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kMaxAgents; ++j) {
+        wgt[j] = 0.f;
+        if (j < n_agents) {
+            float dot = 0.f;
+            for (int ch = 4 * t; ch < c; ch += 64) {
+                const float4 q = *reinterpret_cast<const float4*>(ap.p[0] + base + ch);
+                const float4 x = *reinterpret_cast<const float4*>(ap.p[j] + base + ch);
+                dot = fmaf(q.x, x.x, dot); dot = fmaf(q.y, x.y, dot); dot = fmaf(q.z, x.z, dot); dot = fmaf(q.w, x.w, dot);
+            }
+#pragma unroll
+            for (int s = 8; s >= 1; s >>= 1) dot += __shfl_xor(dot, s, 16);
+            wgt[j] = dot / sqrt_c;
+            mx = fmaxf(mx, wgt[j]);
+        }
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxAgents; ++j)
+        if (j < n_agents) { wgt[j] = expf(wgt[j] - mx); l += wgt[j]; }
+    const float inv = 1.0f / l;
+    for (int ch = 4 * t; ch < c; ch += 64) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < kMaxAgents; ++j)
+            if (j < n_agents) {
+                const float4 x = *reinterpret_cast<const float4*>(ap.p[j] + base + ch);
+                o.x = fmaf(wgt[j], x.x, o.x); o.y = fmaf(wgt[j], x.y, o.y); o.z = fmaf(wgt[j], x.z, o.z); o.w = fmaf(wgt[j], x.w, o.w);
+            }
+        o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+        *reinterpret_cast<float4*>(out + base + ch) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int av2x_comm_mask(const float* psm, int32_t n, int32_t h, int32_t w, int32_t ctot, int32_t c,
@@ -184,7 +228,10 @@ extern "C" int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents
         case 64: hipLaunchKernelGGL(pixel_attn_kernel<1>, grid, block, 0, st, ap, n_agents, hw, inv, out); break;
         case 128: hipLaunchKernelGGL(pixel_attn_kernel<2>, grid, block, 0, st, ap, n_agents, hw, inv, out); break;
         case 256: hipLaunchKernelGGL(pixel_attn_kernel<4>, grid, block, 0, st, ap, n_agents, hw, inv, out); break;
-        default: return av2x::fail("av2x_pixel_attn_fuse: c=%d unsupported (64/128/256)", c);
+        default:
+            if (c <= 0 || c % 4) return av2x::fail("av2x_pixel_attn_fuse: c=%d must be a positive multiple of 4", c);
+            hipLaunchKernelGGL(pixel_attn_generic_kernel, grid, block, 0, st, ap, n_agents, hw, c, inv, out);
+            break;
     }
     return av2x::check_launch("pixel_attn_kernel");
 }

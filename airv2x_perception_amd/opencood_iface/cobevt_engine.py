@@ -53,10 +53,11 @@ class CoBEVTEngine(Where2ComEngine):
         is folded into the BN shift.  Layer 0 is the encoder (its C/ratio-channel output is the message a
         multi-GPU deployment would all-gather), layers 1-2 the decoder."""
         layers = []
+        pre = prefix + "." if prefix else ""
         for conv, bn in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
-            w = sd[f"{prefix}.{conv}.weight"].detach().float()
-            sc, sh = fold_bn(sd, f"{prefix}.{bn}")
-            sh = sh + sd[f"{prefix}.{conv}.bias"].detach().float().cpu() * sc
+            w = sd[f"{pre}{conv}.weight"].detach().float()
+            sc, sh = fold_bn(sd, f"{pre}{bn}")
+            sh = sh + sd[f"{pre}{conv}.bias"].detach().float().cpu() * sc
             wp, coutp = pack_conv_weight(w)
             layers.append(ConvLayer(up(wp), up(sc), up(sh), w.shape[1], w.shape[0], coutp, 3, 1, 1, 1))
         return layers
@@ -71,7 +72,7 @@ class CoBEVTEngine(Where2ComEngine):
         self.conv(dec1, mid, n, H, W, x)
         return msg
 
-    def _load_fusion(self, sd, up):
+    def _load_fusion(self, sd, up, prefix="fusion_net."):
         if self.compression:
             self.compressor = self._load_compressor(sd, up)
         C, ws, L = self.fax["input_dim"], self.fax["window_size"], self.L
@@ -81,7 +82,7 @@ class CoBEVTEngine(Where2ComEngine):
         for i in range(self.fax["depth"]):
             blk = {}
             for part in ("window", "grid"):
-                a, f = f"fusion_net.layers.{i}.{part}_attention", f"fusion_net.layers.{i}.{part}_ffd"
+                a, f = f"{prefix}layers.{i}.{part}_attention", f"{prefix}layers.{i}.{part}_ffd"
                 idx = sd[a + ".fn.relative_position_index"].cpu()
                 if idx.shape != expect.shape or not torch.equal(idx, expect):
                     raise ValueError(f"{a}.fn.relative_position_index is not the index of a ({L},{ws},{ws}) window")
@@ -98,8 +99,8 @@ class CoBEVTEngine(Where2ComEngine):
                     "ff2": self._linear(sd, f + ".fn.net.3.weight", f + ".fn.net.3.bias", 0, up),
                 }
             self.fax_layers.append(blk)
-        self.head_ln = (up(sd["fusion_net.mlp_head.2.weight"].float()), up(sd["fusion_net.mlp_head.2.bias"].float()))
-        self.head_lin = self._linear(sd, "fusion_net.mlp_head.3.weight", "fusion_net.mlp_head.3.bias", 0, up)
+        self.head_ln = (up(sd[prefix + "mlp_head.2.weight"].float()), up(sd[prefix + "mlp_head.2.bias"].float()))
+        self.head_lin = self._linear(sd, prefix + "mlp_head.3.weight", prefix + "mlp_head.3.bias", 0, up)
 
     def ln(self, x, gb, y, n_tokens, c):
         _lib.check(self.lib.av2x_layernorm(_ptr(x), _ptr(gb[0]), _ptr(gb[1]), _ptr(y), n_tokens, c, LN_EPS, self.stream()),

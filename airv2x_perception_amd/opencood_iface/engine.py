@@ -164,50 +164,68 @@ class Where2ComEngine:
         return bm, bn
 
     # ------------------------------------------------------------------ weights
-    def load_state_dict(self, sd):
-        dev = self.device
-        up = lambda t: t.to(dev).contiguous() if t is not None else None
-        self.pfn = {}
-        for t in AGENT_TYPES:
-            if t not in self.args["collaborators"] or "lidar" not in self.args[t]["modalities"]:
-                continue
-            p = TYPE_PREFIX[t] + ".0.0.pfn_layers.0"
-            sc, sh = fold_bn(sd, p + ".norm")
-            cfg = self.args[t]["lidar"]
-            vs, rng = cfg["voxel_size"], cfg["lidar_range"]
-            geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
-            self.pfn[t] = (up(sd[p + ".linear.weight"].detach().float()), up(sc), up(sh), geom)
+    def _up(self, t):
+        return t.to(self.device).contiguous() if t is not None else None
+
+    def load_pfn(self, sd, prefix, voxel_size, lidar_range):
+        """PillarVFE weights under ``prefix`` -> (linear weight, folded BN scale / shift, HOST geometry array)."""
+        up = self._up
+        p = prefix + "pfn_layers.0"
+        sc, sh = fold_bn(sd, p + ".norm")
+        vs, rng = voxel_size, lidar_range
+        geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
+        return (up(sd[p + ".linear.weight"].detach().float()), up(sc), up(sh), geom)
+
+    def load_backbone(self, sd, prefix="backbone.", input_channels=64):
+        """BaseBEVBackbone weights (blocks: Conv3x3 + BN + ReLU chains, deblocks: ConvTranspose k = s + BN + ReLU)."""
+        up = self._up
         self.blocks, self.deblocks = [], []
-        cin = 64
+        cin = input_channels
         for i, (n, c, s) in enumerate(zip(self.bb["layer_nums"], self.bb["num_filters"], self.bb["layer_strides"])):
             layers = []
             idx = 1
             for li in range(n + 1):
-                w, coutp = pack_conv_weight(sd[f"backbone.blocks.{i}.{idx}.weight"])
-                sc, sh = fold_bn(sd, f"backbone.blocks.{i}.{idx + 1}")
+                w, coutp = pack_conv_weight(sd[f"{prefix}blocks.{i}.{idx}.weight"])
+                sc, sh = fold_bn(sd, f"{prefix}blocks.{i}.{idx + 1}")
                 layers.append(ConvLayer(up(w), up(sc), up(sh), cin if li == 0 else c, c, coutp, 3,
                                         s if li == 0 else 1, 1, 1))
                 idx += 3
             self.blocks.append(layers)
             cin = c
         for i, (s, cu) in enumerate(zip(self.bb["upsample_strides"], self.bb["num_upsample_filter"])):
-            w, ncol = pack_deconv_weight(sd[f"backbone.deblocks.{i}.0.weight"])
-            sc, sh = fold_bn(sd, f"backbone.deblocks.{i}.1")
+            w, ncol = pack_deconv_weight(sd[f"{prefix}deblocks.{i}.0.weight"])
+            sc, sh = fold_bn(sd, f"{prefix}deblocks.{i}.1")
             self.deblocks.append(ConvLayer(up(w), up(sc), up(sh), self.bb["num_filters"][i], cu, ncol, 1, 1, 0, 1,
                                            _lib.AV2X_DECONV, s))
         self.cat_c = sum(self.bb["num_upsample_filter"])
+
+    def load_shrink(self, sd, prefix="shrink_conv."):
+        """DownsampleConv weights: per layer Conv(k) + ReLU, Conv3x3 + ReLU (biases, no BN).  Returns the output width."""
+        up = self._up
         self.shrink = []
         cin = self.sh["input_dim"]
-        if self.sh["use"]:
+        if self.sh.get("use", True):
             for li, (k, d, s, pd) in enumerate(zip(self.sh["kernal_size"], self.sh["dim"], self.sh["stride"], self.sh["padding"])):
                 if s != 1:
                     raise NotImplementedError("shrink_header stride != 1")
-                p = f"shrink_conv.layers.{li}.double_conv"
+                p = f"{prefix}layers.{li}.double_conv"
                 w0, cp0 = pack_conv_weight(sd[p + ".0.weight"])
                 w1, cp1 = pack_conv_weight(sd[p + ".2.weight"])
                 self.shrink.append(ConvLayer(up(w0), None, up(sd[p + ".0.bias"].detach().float()), cin, d, cp0, k, 1, pd, 1))
                 self.shrink.append(ConvLayer(up(w1), None, up(sd[p + ".2.bias"].detach().float()), d, d, cp1, 3, 1, 1, 1))
                 cin = d
+        return cin
+
+    def load_state_dict(self, sd):
+        up = self._up
+        self.pfn = {}
+        for t in AGENT_TYPES:
+            if t not in self.args["collaborators"] or "lidar" not in self.args[t]["modalities"]:
+                continue
+            cfg = self.args[t]["lidar"]
+            self.pfn[t] = self.load_pfn(sd, TYPE_PREFIX[t] + ".0.0.", cfg["voxel_size"], cfg["lidar_range"])
+        self.load_backbone(sd)
+        cin = self.load_shrink(sd)
         self.feat_c = cin
         # cls head alone (per-agent confidence) and the three heads fused into one 30-column GEMM
         wc, cpc = pack_conv_weight(sd["cls_head.weight"])

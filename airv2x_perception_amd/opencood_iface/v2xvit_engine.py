@@ -49,8 +49,7 @@ class V2XViTEngine(Where2ComEngine):
         b = b.detach().float() if b is not None else torch.zeros(w.shape[0])
         return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
 
-    def _load_fusion(self, sd, up):
-        p = "fusion_net.encoder"
+    def _load_fusion(self, sd, up, p="fusion_net.encoder"):
         heads, dh = self.cav["heads"], self.cav["dim_head"]
         self.layers = []
         for d in range(self.enc["depth"]):

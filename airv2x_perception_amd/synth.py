@@ -165,6 +165,48 @@ def _bn(prefix, c):
     ]
 
 
+def pfn_param_spec(prefix=""):
+    """PillarVFE with one PFN layer (airv2x_pillar_vfe.py:69-81)."""
+    p = prefix + "pfn_layers.0"
+    return [(p + ".linear.weight", (64, 10), "lin")] + _bn(p + ".norm", 64)
+
+
+def backbone_param_spec(bb, input_channels=64, prefix=""):
+    """BaseBEVBackbone(model_cfg, input_channels) (base_bev_backbone.py:38-105)."""
+    spec = []
+    cin = input_channels
+    for i, (n, c) in enumerate(zip(bb["layer_nums"], bb["num_filters"])):
+        # Sequential: 0 ZeroPad, 1 conv, 2 bn, 3 relu, then (conv,bn,relu)*n
+        idx = 1
+        spec.append((f"{prefix}blocks.{i}.{idx}.weight", (c, cin, 3, 3), "conv"))
+        spec += _bn(f"{prefix}blocks.{i}.{idx + 1}", c)
+        idx += 3
+        for _ in range(n):
+            spec.append((f"{prefix}blocks.{i}.{idx}.weight", (c, c, 3, 3), "conv"))
+            spec += _bn(f"{prefix}blocks.{i}.{idx + 1}", c)
+            idx += 3
+        cin = c
+    for i, (s, cu) in enumerate(zip(bb["upsample_strides"], bb["num_upsample_filter"])):
+        c = bb["num_filters"][i]
+        spec.append((f"{prefix}deblocks.{i}.0.weight", (c, cu, s, s), "deconv"))
+        spec += _bn(f"{prefix}deblocks.{i}.1", cu)
+    return spec
+
+
+def shrink_param_spec(sh, prefix=""):
+    """DownsampleConv(config) (downsample_conv.py:17-31, :40-54)."""
+    spec = []
+    cin = sh["input_dim"]
+    for li, (k, d) in enumerate(zip(sh["kernal_size"], sh["dim"])):
+        p = f"{prefix}layers.{li}.double_conv"
+        spec.append((p + ".0.weight", (d, cin, k, k), "conv"))
+        spec.append((p + ".0.bias", (d,), "bias"))
+        spec.append((p + ".2.weight", (d, d, 3, 3), "conv"))
+        spec.append((p + ".2.bias", (d,), "bias"))
+        cin = d
+    return spec
+
+
 def where2com_param_spec(args):
     """Ordered (key, shape, kind) manifest of Airv2xWhere2com's state_dict.
 
@@ -177,35 +219,9 @@ def where2com_param_spec(args):
     for t in AGENT_TYPES:
         if t not in args["collaborators"]:
             continue
-        p = f"{TYPE_PREFIX[t]}.0.0.pfn_layers.0"
-        spec.append((p + ".linear.weight", (64, 10), "lin"))
-        spec += _bn(p + ".norm", 64)
-    bb = args["modality_fusion"]["base_bev_backbone"]
-    cin = 64
-    for i, (n, c) in enumerate(zip(bb["layer_nums"], bb["num_filters"])):
-        # Sequential: 0 ZeroPad, 1 conv, 2 bn, 3 relu, then (conv,bn,relu)*n
-        idx = 1
-        spec.append((f"backbone.blocks.{i}.{idx}.weight", (c, cin, 3, 3), "conv"))
-        spec += _bn(f"backbone.blocks.{i}.{idx + 1}", c)
-        idx += 3
-        for _ in range(n):
-            spec.append((f"backbone.blocks.{i}.{idx}.weight", (c, c, 3, 3), "conv"))
-            spec += _bn(f"backbone.blocks.{i}.{idx + 1}", c)
-            idx += 3
-        cin = c
-    for i, (s, cu) in enumerate(zip(bb["upsample_strides"], bb["num_upsample_filter"])):
-        c = bb["num_filters"][i]
-        spec.append((f"backbone.deblocks.{i}.0.weight", (c, cu, s, s), "deconv"))
-        spec += _bn(f"backbone.deblocks.{i}.1", cu)
-    sh = args["modality_fusion"]["shrink_header"]
-    cin = sh["input_dim"]
-    for li, (k, d) in enumerate(zip(sh["kernal_size"], sh["dim"])):
-        p = f"shrink_conv.layers.{li}.double_conv"
-        spec.append((p + ".0.weight", (d, cin, k, k), "conv"))
-        spec.append((p + ".0.bias", (d,), "bias"))
-        spec.append((p + ".2.weight", (d, d, 3, 3), "conv"))
-        spec.append((p + ".2.bias", (d,), "bias"))
-        cin = d
+        spec += pfn_param_spec(f"{TYPE_PREFIX[t]}.0.0.")
+    spec += backbone_param_spec(args["modality_fusion"]["base_bev_backbone"], 64, "backbone.")
+    spec += shrink_param_spec(args["modality_fusion"]["shrink_header"], "shrink_conv.")
     ks = args["where2com_fusion"]["communication"]["gaussian_smooth"]["k_size"]
     spec.append(("fusion_net.naive_communication.gaussian_filter.weight", (1, 1, ks, ks), "gauss_w"))
     spec.append(("fusion_net.naive_communication.gaussian_filter.bias", (1,), "gauss_b"))
@@ -514,11 +530,35 @@ def compressor_param_spec(c, ratio, prefix="naive_compressor"):
         return []
     m = c // ratio
     spec = []
-    for name, co, ci in ((f"{prefix}.encoder.0", m, c), (f"{prefix}.decoder.0", c, m), (f"{prefix}.decoder.3", c, c)):
+    pre = prefix + "." if prefix else ""
+    for name, co, ci in ((f"{pre}encoder.0", m, c), (f"{pre}decoder.0", c, m), (f"{pre}decoder.3", c, c)):
         bn = name[:-1] + str(int(name[-1]) + 1)
         spec += [(name + ".weight", (co, ci, 3, 3), "conv"), (name + ".bias", (co,), "bias"),
                  (bn + ".weight", (co,), "bn_w"), (bn + ".bias", (co,), "bn_b"), (bn + ".running_mean", (co,), "bn_m"),
                  (bn + ".running_var", (co,), "bn_v"), (bn + ".num_batches_tracked", (), "count")]
+    return spec
+
+
+def fax_param_spec(fax, prefix=""):
+    """SwapFusionEncoder(args) (swap_fusion_modules.py:233-275)."""
+    C, M, ws, L = fax["input_dim"], fax["mlp_dim"], fax["window_size"], fax["agent_size"]
+    nh = C // fax["dim_head"]
+    T = L * ws * ws
+    spec = []
+    for i in range(fax["depth"]):
+        for part in ("window", "grid"):
+            p = f"{prefix}layers.{i}.{part}_attention"
+            spec += [(p + ".norm.weight", (C,), "ln_w"), (p + ".norm.bias", (C,), "ln_b"),
+                     (p + ".fn.relative_position_index", (T, T), f"relidx:{L}:{ws}"),
+                     (p + ".fn.to_qkv.weight", (3 * C, C), "lin"),
+                     (p + ".fn.to_out.0.weight", (C, C), "lin"),
+                     (p + ".fn.relative_position_bias_table.weight", ((2 * L - 1) * (2 * ws - 1) ** 2, nh), "relbias")]
+            p = f"{prefix}layers.{i}.{part}_ffd"
+            spec += [(p + ".norm.weight", (C,), "ln_w"), (p + ".norm.bias", (C,), "ln_b"),
+                     (p + ".fn.net.0.weight", (M, C), "lin"), (p + ".fn.net.0.bias", (M,), "bias"),
+                     (p + ".fn.net.3.weight", (C, M), "lin"), (p + ".fn.net.3.bias", (C,), "bias")]
+    spec += [(prefix + "mlp_head.2.weight", (C,), "ln_w"), (prefix + "mlp_head.2.bias", (C,), "ln_b"),
+             (prefix + "mlp_head.3.weight", (C, C), "lin"), (prefix + "mlp_head.3.bias", (C,), "bias")]
     return spec
 
 
@@ -534,24 +574,8 @@ def cobevt_param_spec(args):
     trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
     fax = args["fax_fusion"]
-    C, M, ws, L = fax["input_dim"], fax["mlp_dim"], fax["window_size"], fax["agent_size"]
-    nh = C // fax["dim_head"]
-    T = L * ws * ws
-    spec = list(trunk) + compressor_param_spec(C, args.get("compression", 0))
-    for i in range(fax["depth"]):
-        for part in ("window", "grid"):
-            p = f"fusion_net.layers.{i}.{part}_attention"
-            spec += [(p + ".norm.weight", (C,), "ln_w"), (p + ".norm.bias", (C,), "ln_b"),
-                     (p + ".fn.relative_position_index", (T, T), f"relidx:{L}:{ws}"),
-                     (p + ".fn.to_qkv.weight", (3 * C, C), "lin"),
-                     (p + ".fn.to_out.0.weight", (C, C), "lin"),
-                     (p + ".fn.relative_position_bias_table.weight", ((2 * L - 1) * (2 * ws - 1) ** 2, nh), "relbias")]
-            p = f"fusion_net.layers.{i}.{part}_ffd"
-            spec += [(p + ".norm.weight", (C,), "ln_w"), (p + ".norm.bias", (C,), "ln_b"),
-                     (p + ".fn.net.0.weight", (M, C), "lin"), (p + ".fn.net.0.bias", (M,), "bias"),
-                     (p + ".fn.net.3.weight", (C, M), "lin"), (p + ".fn.net.3.bias", (C,), "bias")]
-    spec += [("fusion_net.mlp_head.2.weight", (C,), "ln_w"), ("fusion_net.mlp_head.2.bias", (C,), "ln_b"),
-             ("fusion_net.mlp_head.3.weight", (C, C), "lin"), ("fusion_net.mlp_head.3.bias", (C,), "bias")]
+    spec = list(trunk) + compressor_param_spec(fax["input_dim"], args.get("compression", 0))
+    spec += fax_param_spec(fax, "fusion_net.")
     return spec + heads
 
 
@@ -578,19 +602,11 @@ def default_hypes_v2xvit(lidar_range=None, max_cav=(5, 5, 5)):
     return hy
 
 
-def v2xvit_param_spec(args):
-    """Ordered (key, shape, kind) manifest of Airv2xV2XVit's state_dict (297 tensors; checked against the
-    reference's own state_dict by tools/gen_golden.py)."""
-    w2c_like = dict(args)
-    w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
-    base = where2com_param_spec(w2c_like)
-    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
-    heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
-    enc = args["transformer"]["encoder"]
+def v2xvit_encoder_spec(enc, p="encoder"):
+    """V2XTEncoder(args) under the key prefix ``p`` (v2xvit_basic.py:135-171)."""
     cav, pw = enc["cav_att_config"], enc["pwindow_att_config"]
     C, inner = cav["dim"], cav["heads"] * cav["dim_head"]
-    p = "fusion_net.encoder"
-    spec = list(trunk)
+    spec = []
     spec += [(p + ".prior_feed.weight", (C, C + 3), "lin"), (p + ".prior_feed.bias", (C,), "bias")]
     for d in range(enc["depth"]):
         for nb in range(enc["num_blocks"]):
@@ -620,6 +636,18 @@ def v2xvit_param_spec(args):
                  (f + ".fn.net.3.weight", (C, enc["feed_forward"]["mlp_dim"]), "lin"), (f + ".fn.net.3.bias", (C,), "bias")]
     spec += [(p + ".rte.emb.emb.weight", (100, C), "rte_table"), (p + ".rte.emb.lin.weight", (C, C), "lin"),
              (p + ".rte.emb.lin.bias", (C,), "bias")]
+    return spec
+
+
+def v2xvit_param_spec(args):
+    """Ordered (key, shape, kind) manifest of Airv2xV2XVit's state_dict (297 tensors; checked against the
+    reference's own state_dict by tools/gen_golden.py)."""
+    w2c_like = dict(args)
+    w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
+    base = where2com_param_spec(w2c_like)
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
+    spec = list(trunk) + v2xvit_encoder_spec(args["transformer"]["encoder"], "fusion_net.encoder")
     return spec + heads
 
 
@@ -629,3 +657,41 @@ def se2_correction(yaw_deg, tx, ty):
     m = np.eye(4)
     m[0, 0], m[0, 1], m[1, 0], m[1, 1], m[0, 3], m[1, 3] = c, -s, s, c, tx, ty
     return m
+
+
+# --------------------------------------------------------------------------
+# sub-module harness (tests/test_submodules.py, tools/gen_golden.py submodules): one small configuration per
+# reference sub-module of SURVEY 8b, inputs from seeded generators so that only outputs are stored as fixtures
+# --------------------------------------------------------------------------
+
+SUBMODULE_RANGE = [-6.4, -6.4, -3.0, 6.4, 6.4, 1.0]            # 32 x 32 pillars of 0.4 m
+
+
+def seeded_uniform(seed, shape, lo=-1.0, hi=1.0):
+    return np.random.default_rng(int(seed)).uniform(lo, hi, size=tuple(shape)).astype(np.float32)
+
+
+def submodule_configs():
+    return {
+        "pillar_vfe": {"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+        "scatter": {"num_features": 64, "grid_size": [32, 32, 1]},
+        "backbone": {"layer_nums": [1, 1, 2], "layer_strides": [2, 2, 2], "num_filters": [32, 64, 64],
+                     "upsample_strides": [1, 2, 4], "num_upsample_filter": [32, 32, 32]},
+        "shrink": {"kernal_size": [1], "dim": [64], "stride": [1], "padding": [0], "input_dim": 96},
+        "compressor": (64, 2),
+        "where2comm": {"fully": False, "voxel_size": list(DEFAULT_VOXEL), "downsample_rate": 2, "in_channels": 64,
+                       "multi_scale": True, "layer_nums": [1, 1, 2], "num_filters": [32, 64, 64],
+                       "communication": {"round": 1, "threshold": 0.01, "gaussian_smooth": {"k_size": 5, "c_sigma": 1.0}}},
+        "fax": {"input_dim": 256, "mlp_dim": 256, "window_size": 4, "dim_head": 32, "drop_out": 0.1, "depth": 2,
+                "mask": True, "agent_size": 3},
+        "v2xvit": default_hypes_v2xvit()["model"]["args"]["transformer"],
+    }
+
+
+def submodule_psm(n=3, h=16, w=16):
+    """Per-agent classification logits whose smoothed confidence straddles the 0.01 threshold: low everywhere,
+    raised on a different part of the map for every agent."""
+    psm = seeded_uniform(21, (n, 14, h, w), -9.0, -5.0)
+    for a in range(n):
+        psm[a, :, :, (3 * a) % w:(3 * a) % w + 6] += 3.5
+    return psm

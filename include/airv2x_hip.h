@@ -53,6 +53,17 @@ int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_t* voxel_co
                             const int32_t* slot_map, int32_t n_agents_type, int32_t ny, int32_t nx,
                             av2x_stream_t stream);
 
+/* The two halves on their own, for callers that use the reference's sub-modules separately:
+ * av2x_pillar_vfe     = PillarVFE.forward (airv2x_pillar_vfe.py:105-160): pillar_features (M,64) f32.
+ * av2x_pillar_scatter = PointPillarScatter.forward (point_pillar_scatter.py:39-80): pillar_features (M,channels),
+ *   voxel_coords (M,4) [agent,z,y,x] -> canvas (n_agents, ny, nx, channels) NHWC, zero-filled by the caller;
+ *   channels % 4 == 0; pillars whose agent / y / x fall outside the canvas are skipped. */
+int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                    int32_t n_pillars, const float* pfn_w, const float* bn_scale, const float* bn_shift,
+                    const float* geom, float* pillar_features, av2x_stream_t stream);
+int av2x_pillar_scatter(const float* pillar_features, const int32_t* voxel_coords, int32_t n_pillars, int32_t channels,
+                        float* canvas, int32_t n_agents, int32_t ny, int32_t nx, av2x_stream_t stream);
+
 int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -152,7 +163,7 @@ int av2x_apply_mask(float* x, const float* mask, int32_t n, int32_t hw, int32_t 
  * Replaces AttentionFusion.forward + ScaledDotProductAttention.forward
  * (where2comm_fuse.py:152-164, :41-45):  out[p,:] = sum_j softmax_j(x0.xj/sqrt(C)) xj.
  *   agents: HOST array of n_agents DEVICE pointers, each to an (hw, c) NHWC map (ego first);
- *   out (hw, c).  c % 64 == 0, n_agents >= 1.
+ *   out (hw, c).  c % 4 == 0 (c = 64 / 128 / 256 take the register-resident kernels), 1 <= n_agents <= 32.
  * ------------------------------------------------------------------------------------ */
 int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents, int32_t hw, int32_t c,
                          float* out, av2x_stream_t stream);

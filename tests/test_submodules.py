@@ -1,0 +1,219 @@
+"""Stand-alone sub-module mirrors (PillarVFE, PointPillarScatter, BaseBEVBackbone, DownsampleConv,
+NaiveCompressor, Where2comm, regroup, SwapFusionEncoder, V2XTransformer) against the outputs of the reference's own
+modules (tests/golden/submodules_small.npz, written by ``tools/gen_golden.py submodules``).
+
+Tolerance (fp32): |a - b| <= 2e-4 * max(1, max|ref|) for the convolution / transformer chains (different summation
+order), exact for the scatter / regroup copies and the communication rate."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from airv2x_perception_amd import synth
+from airv2x_perception_amd.opencood_iface import submodules as sm
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "submodules_small.npz")
+CFG = synth.submodule_configs()
+
+
+def _load_into(mod, spec, seed):
+    mod.load_state_dict(synth.synthetic_state_dict(spec, seed=seed), strict=True)
+    return mod.eval()
+
+
+def _close(a, ref, rel=2e-4):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    tol = rel * max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(a - ref).max())
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    assert err <= tol, f"max abs err {err:.3e} > {tol:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ CPU: contracts
+def test_state_dict_keys_follow_the_reference_manifests():
+    cases = [
+        (sm.PillarVFE(CFG["pillar_vfe"], 4, synth.DEFAULT_VOXEL, synth.SUBMODULE_RANGE, "rsu"), synth.pfn_param_spec("")),
+        (sm.BaseBEVBackbone(CFG["backbone"], 64), synth.backbone_param_spec(CFG["backbone"], 64, "")),
+        (sm.DownsampleConv(CFG["shrink"]), synth.shrink_param_spec(CFG["shrink"], "")),
+        (sm.NaiveCompressor(*CFG["compressor"]), synth.compressor_param_spec(*CFG["compressor"], prefix="")),
+        (sm.SwapFusionEncoder(CFG["fax"]), synth.fax_param_spec(CFG["fax"], "")),
+        (sm.V2XTransformer(CFG["v2xvit"]), synth.v2xvit_encoder_spec(CFG["v2xvit"]["encoder"], "encoder")),
+    ]
+    for mod, spec in cases:
+        sd = mod.state_dict()
+        assert list(sd.keys()) == [k for k, _, _ in spec], type(mod).__name__
+        for k, shp, _ in spec:
+            assert tuple(sd[k].shape) == tuple(shp), k
+    w = sm.Where2comm(CFG["where2comm"])
+    assert list(w.state_dict().keys()) == ["naive_communication.gaussian_filter.weight", "naive_communication.gaussian_filter.bias"]
+    # constructor default = the reference's init_gaussian_filter values (sigma 1)
+    np.testing.assert_allclose(w.state_dict()["naive_communication.gaussian_filter.weight"].numpy().reshape(5, 5),
+                               synth.synthetic_tensor("g", (1, 1, 5, 5), "gauss_w").reshape(5, 5), rtol=1e-6)
+    bb = sm.BaseBEVBackbone(CFG["backbone"], 64)
+    assert len(bb.blocks) == 3 and len(bb.deblocks) == 3 and bb.num_bev_features == 96
+    assert sm.PointPillarScatter(CFG["scatter"]).num_bev_features == 64
+
+
+def test_no_cpu_path():
+    bb = sm.BaseBEVBackbone(CFG["backbone"], 64).eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        bb.blocks[0](torch.zeros(1, 64, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        sm.PointPillarScatter(CFG["scatter"])({"pillar_features": torch.zeros(2, 64), "voxel_coords": torch.zeros(2, 4, dtype=torch.int32)})
+
+
+def test_regroup_matches_reference():
+    g = np.load(GOLD)
+    dense = torch.from_numpy(synth.seeded_uniform(23, (3, 4, 2, 3)))
+    rg, m = sm.regroup(dense, torch.tensor([2, 1]), 3)
+    assert rg.shape == (2, 3, 4, 2, 3)
+    np.testing.assert_array_equal(rg.numpy(), g["regroup"])
+    np.testing.assert_array_equal(m.numpy(), g["regroup_mask"])
+    assert m.dtype == torch.int64
+    with pytest.raises(ValueError):
+        sm.regroup(dense, [2, 2], 3)
+    with pytest.raises(ValueError):
+        sm.regroup(dense, [3], 2)
+
+
+# ------------------------------------------------------------------------------------------------ GPU: parity
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def trunk(gold):
+    """PillarVFE -> scatter -> backbone -> shrink, each stage checked where it is produced."""
+    dev = "cuda"
+    vfe = _load_into(sm.PillarVFE(CFG["pillar_vfe"], 4, synth.DEFAULT_VOXEL, synth.SUBMODULE_RANGE, "rsu"),
+                     synth.pfn_param_spec(""), 11).to(dev)
+    bd = {"rsu": {"batch_merged_lidar_features_torch": {
+        "voxel_features": torch.from_numpy(gold["voxel_features"]).to(dev),
+        "voxel_coords": torch.from_numpy(gold["voxel_coords"]).to(dev),
+        "voxel_num_points": torch.from_numpy(gold["voxel_num_points"]).to(dev)}}}
+    inner = vfe(bd)
+    inner = sm.PointPillarScatter(CFG["scatter"])(inner)
+    bb = _load_into(sm.BaseBEVBackbone(CFG["backbone"], 64), synth.backbone_param_spec(CFG["backbone"], 64, ""), 12).to(dev)
+    return {"inner": inner, "bb": bb, "sf": inner["spatial_features"]}
+
+
+@pytest.mark.gpu
+def test_pillar_vfe_and_scatter(gold, trunk):
+    inner = trunk["inner"]
+    assert inner is not None and inner["pillar_features"].shape == gold["pillar_features"].shape
+    _close(inner["pillar_features"], gold["pillar_features"], 1e-5)
+    sf = inner["spatial_features"]
+    assert sf.shape == (3, 64, 32, 32) and sf.is_contiguous(memory_format=torch.channels_last)
+    assert inner["spatial_features_3d"].shape == (3, 64, 1, 32, 32)
+    _close(sf, gold["spatial_features"], 1e-5)
+    # the scatter itself is a pure copy: exact against the module's own pillar features
+    pf, vc = inner["pillar_features"].cpu().numpy(), gold["voxel_coords"]
+    want = np.zeros((3, 64, 32, 32), np.float32)
+    want[vc[:, 0], :, vc[:, 2], vc[:, 3]] = pf
+    np.testing.assert_array_equal(sf.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_backbone_forward_blocks_and_deblocks(gold, trunk):
+    bb, sf = trunk["bb"], trunk["sf"]
+    d = bb({"spatial_features": sf})
+    s2d = d["spatial_features_2d"]
+    assert s2d.shape == (3, 96, 16, 16)
+    _close(s2d[:, ::2], gold["spatial_features_2d"])
+    # the Sequentials other reference code calls directly (where2comm_fuse.py:218,252), NCHW-contiguous input too
+    b0 = bb.blocks[0](sf.contiguous())
+    b1 = bb.blocks[1](b0)
+    _close(b1, gold["block1_of_block0"])
+    _close(bb.deblocks[1](b1)[:, ::4], gold["deblock1"])
+    trunk["s2d"] = s2d
+
+
+@pytest.mark.gpu
+def test_downsample_conv_and_compressor(gold, trunk):
+    s2d = trunk.get("s2d")
+    if s2d is None:
+        s2d = trunk["bb"]({"spatial_features": trunk["sf"]})["spatial_features_2d"]
+    ds = _load_into(sm.DownsampleConv(CFG["shrink"]), synth.shrink_param_spec(CFG["shrink"], ""), 13).cuda()
+    sh = ds(s2d)
+    assert sh.shape == (3, 64, 16, 16)
+    _close(sh[:, ::2], gold["shrink"])
+    nc = _load_into(sm.NaiveCompressor(*CFG["compressor"]), synth.compressor_param_spec(*CFG["compressor"], prefix=""), 14).cuda()
+    _close(nc(sh)[:, ::2], gold["compressed"])
+    # a changed parameter is re-packed on the next call (version counters)
+    with torch.no_grad():
+        ds.layers[0].double_conv[2].bias.add_(1.0)
+    sh2 = ds(s2d)
+    assert float((sh2 - sh).abs().max()) > 0.5
+
+
+@pytest.mark.gpu
+def test_where2comm_module(gold, trunk):
+    bb, sf = trunk["bb"], trunk["sf"]
+    w2c = sm.Where2comm(CFG["where2comm"]).cuda().eval()
+    psm = torch.from_numpy(synth.submodule_psm()).cuda()
+    eye = torch.eye(4, device="cuda").view(1, 1, 1, 4, 4)
+    before = sf.clone()
+    for tag, rl in (("b1", [3]), ("b2", [2, 1])):
+        xf, rate = w2c(sf, psm, torch.tensor(rl), eye.repeat(len(rl), 3, 3, 1, 1), bb)
+        assert xf.shape == (len(rl), 96, 16, 16)
+        _close(xf[:, ::2], gold[f"w2c_{tag}_fused"])
+        assert float(rate) == pytest.approx(float(gold[f"w2c_{tag}_rate"]), abs=1e-7)
+    assert torch.equal(sf, before), "the caller's feature map must not be modified"
+    cs = dict(CFG["where2comm"]); cs["multi_scale"] = False
+    w1 = sm.Where2comm(cs).cuda().eval()
+    x1 = torch.from_numpy(synth.seeded_uniform(22, (3, 64, 16, 16))).cuda()
+    keep = x1.clone()
+    xf, rate = w1(x1, psm, torch.tensor([3]), eye.repeat(1, 3, 3, 1, 1))
+    _close(xf, gold["w2c_single_fused"], 1e-5)
+    assert float(rate) == pytest.approx(float(gold["w2c_single_rate"]), abs=1e-7)
+    assert torch.equal(x1, keep)
+    xl = x1.contiguous(memory_format=torch.channels_last)
+    keep = xl.clone()
+    xf2, _ = w1(xl, psm, torch.tensor([3]), eye.repeat(1, 3, 3, 1, 1))
+    assert torch.equal(xl, keep) and torch.equal(xf2, xf)
+
+
+@pytest.mark.gpu
+def test_swap_fusion_encoder_module(gold):
+    fax = CFG["fax"]
+    enc = _load_into(sm.SwapFusionEncoder(fax), synth.fax_param_spec(fax, ""), 15).cuda()
+    x = torch.from_numpy(synth.seeded_uniform(24, (2, 3, 256, 8, 8)))
+    valid = torch.tensor([[1, 1, 1], [1, 1, 0]])
+    x = (x * valid.view(2, 3, 1, 1, 1)).cuda()
+    km = valid.view(2, 1, 1, 1, 3).repeat(1, 8, 8, 1, 1).cuda()
+    out = enc(x, mask=km)
+    assert out.shape == (2, 256, 8, 8)
+    _close(out, gold["fax_out"])
+    # regroup()'s own output (B,L,C,H,W view of a (B,L,H,W,C) buffer) and a (B,L) mask are accepted as well
+    dense = torch.cat([x[0], x[1, :2]], 0)
+    rg, m = sm.regroup(dense, torch.tensor([3, 2]), 3)
+    _close(enc(rg, mask=m), gold["fax_out"])
+    with pytest.raises(NotImplementedError):
+        enc(x, mask=torch.tensor([[1, 0, 1], [1, 1, 0]]).cuda())
+
+
+@pytest.mark.gpu
+def test_v2x_transformer_module(gold):
+    vt = _load_into(sm.V2XTransformer(CFG["v2xvit"]), synth.v2xvit_encoder_spec(CFG["v2xvit"]["encoder"], "encoder"), 16).cuda()
+    feat = torch.from_numpy(synth.seeded_uniform(25, (1, 3, 8, 8, 256)))
+    prior = torch.tensor([[[0.0, 0.0, 0.0], [0.0, 1.0, 1.0], [0.0, 0.0, 0.0]]]).view(1, 3, 1, 1, 3).repeat(1, 1, 8, 8, 1)
+    vmask = torch.tensor([[1, 1, 0]])
+    feat = feat * vmask.view(1, 3, 1, 1, 1)
+    scm = torch.eye(4, dtype=torch.float64).view(1, 1, 4, 4).repeat(1, 3, 1, 1)
+    scm[0, 1] = torch.from_numpy(synth.se2_correction(4.0, 0.9, -0.5))
+    out = vt(torch.cat([feat, prior], -1).cuda(), vmask.cuda(), scm)
+    assert out.shape == (1, 8, 8, 256)
+    _close(out, gold["vit_out"], 3e-4)
+
+
+@pytest.mark.gpu
+def test_modules_refuse_training_mode(trunk):
+    bb = trunk["bb"]
+    bb.train()
+    try:
+        with pytest.raises(NotImplementedError):
+            bb.blocks[0](trunk["sf"])
+    finally:
+        bb.eval()

@@ -542,6 +542,117 @@ def eval_golden(name="eval_small"):
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
 
 
+def submodules_golden(name="submodules_small"):
+    """Reference SUB-modules of SURVEY 8b run one by one on seeded inputs (configs: synth.submodule_configs()).
+    Weights come from the seeded manifest generators, inputs from seeded_uniform / the voxelizer restatement, so the
+    fixture holds the voxelized input and the reference's outputs only."""
+    from airv2x_perception_amd import synth
+    from oracle import voxelize_oracle as vox
+    from opencood.models.common_modules.airv2x_pillar_vfe import PillarVFE
+    from opencood.models.common_modules.point_pillar_scatter import PointPillarScatter
+    from opencood.models.common_modules.base_bev_backbone import BaseBEVBackbone
+    from opencood.models.common_modules.downsample_conv import DownsampleConv
+    from opencood.models.common_modules.naive_compress import NaiveCompressor
+    from opencood.models.common_modules.fuse_utils import regroup
+    from opencood.models.where2comm_modules.where2comm_fuse import Where2comm
+    from opencood.models.cobevt_modules.swap_fusion_modules import SwapFusionEncoder
+    from opencood.models.v2xvit_modules.v2xvit_basic import V2XTransformer
+
+    cfg = synth.submodule_configs()
+    rng_ = synth.SUBMODULE_RANGE
+    out = {}
+
+    def load(mod, spec, seed):
+        ref_sd = mod.state_dict()
+        assert [k for k, _, _ in spec] == list(ref_sd.keys()), (list(ref_sd.keys())[:8], [k for k, _, _ in spec][:8])
+        for k, shp, _ in spec:
+            assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+        mod.load_state_dict(synth.synthetic_state_dict(spec, seed=seed), strict=True)
+        return mod.eval()
+
+    with torch.no_grad():
+        # ---- PillarVFE + PointPillarScatter: 3 agents of one type
+        vf, vc, vn = [], [], []
+        for a in range(3):
+            pts = synth.synthetic_cloud(a, 260, rng_, seed=77)
+            f, c, n = vox.points_to_voxels(pts, rng_, synth.DEFAULT_VOXEL, 32, 70000)
+            vf.append(f); vn.append(n)
+            vc.append(np.concatenate([np.full((len(c), 1), a, dtype=c.dtype), c], 1))
+        vf, vc, vn = np.concatenate(vf), np.concatenate(vc), np.concatenate(vn)
+        out.update({"voxel_features": vf, "voxel_coords": vc.astype(np.int32), "voxel_num_points": vn.astype(np.int32)})
+        vfe = load(PillarVFE(cfg["pillar_vfe"], 4, synth.DEFAULT_VOXEL, rng_, "rsu"), synth.pfn_param_spec(""), 11)
+        bd = {"rsu": {"batch_merged_lidar_features_torch": {"voxel_features": torch.from_numpy(vf),
+                                                            "voxel_coords": torch.from_numpy(vc.astype(np.int32)),
+                                                            "voxel_num_points": torch.from_numpy(vn.astype(np.int32))}}}
+        inner = vfe(bd)
+        out["pillar_features"] = inner["pillar_features"].numpy()
+        sc = PointPillarScatter(cfg["scatter"]).eval()
+        inner = sc(inner)
+        sf = inner["spatial_features"]
+        out["spatial_features"] = sf.numpy()
+
+        # ---- BaseBEVBackbone (whole forward, and blocks / deblocks called directly)
+        bb = load(BaseBEVBackbone(cfg["backbone"], 64), synth.backbone_param_spec(cfg["backbone"], 64, ""), 12)
+        d = bb({"spatial_features": sf})
+        s2d = d["spatial_features_2d"]
+        out["spatial_features_2d"] = s2d[:, ::2].numpy()        # every 2nd channel (fixture size)
+        b0 = bb.blocks[0](sf)
+        out["block1_of_block0"] = bb.blocks[1](b0).numpy()
+        out["deblock1"] = bb.deblocks[1](bb.blocks[1](b0))[:, ::4].numpy()
+
+        # ---- DownsampleConv / NaiveCompressor
+        ds = load(DownsampleConv(cfg["shrink"]), synth.shrink_param_spec(cfg["shrink"], ""), 13)
+        sh = ds(s2d)
+        out["shrink"] = sh[:, ::2].numpy()
+        nc = load(NaiveCompressor(*cfg["compressor"]), synth.compressor_param_spec(*cfg["compressor"], prefix=""), 14)
+        out["compressed"] = nc(sh)[:, ::2].numpy()
+
+        # ---- Where2comm: multi-scale with the backbone (B = 1 and B = 2), single scale
+        w2c = Where2comm(cfg["where2comm"]).eval()
+        assert list(w2c.state_dict().keys()) == ["naive_communication.gaussian_filter.weight",
+                                                 "naive_communication.gaussian_filter.bias"]
+        psm = torch.from_numpy(synth.submodule_psm())
+        eye = torch.eye(4).view(1, 1, 1, 4, 4)
+        for tag, rl in (("b1", [3]), ("b2", [2, 1])):
+            xf, rate = w2c(sf, psm, torch.tensor(rl), eye.repeat(len(rl), 3, 3, 1, 1), bb)
+            out[f"w2c_{tag}_fused"] = xf[:, ::2].numpy()
+            out[f"w2c_{tag}_rate"] = np.asarray(float(rate), dtype=np.float64)
+        cs = dict(cfg["where2comm"]); cs["multi_scale"] = False
+        w1 = Where2comm(cs).eval()
+        x1 = torch.from_numpy(synth.seeded_uniform(22, (3, 64, 16, 16)))
+        xf, rate = w1(x1, psm, torch.tensor([3]), eye.repeat(1, 3, 3, 1, 1))
+        out["w2c_single_fused"] = xf.numpy()
+        out["w2c_single_rate"] = np.asarray(float(rate), dtype=np.float64)
+
+        # ---- regroup
+        dense = torch.from_numpy(synth.seeded_uniform(23, (3, 4, 2, 3)))
+        rg, m = regroup(dense, torch.tensor([2, 1]), 3)
+        out["regroup"] = rg.numpy()
+        out["regroup_mask"] = m.numpy()
+
+        # ---- SwapFusionEncoder: B = 2, 3 and 2 valid agents
+        fax = cfg["fax"]
+        enc = load(SwapFusionEncoder(fax), synth.fax_param_spec(fax, ""), 15)
+        x = torch.from_numpy(synth.seeded_uniform(24, (2, 3, 256, 8, 8)))
+        valid = torch.tensor([[1, 1, 1], [1, 1, 0]])
+        x = x * valid.view(2, 3, 1, 1, 1)                                    # regroup zero-pads the absent agent
+        km = valid.view(2, 1, 1, 1, 3).repeat(1, 8, 8, 1, 1)
+        out["fax_out"] = enc(x, mask=km).numpy()
+
+        # ---- V2XTransformer: 2 real agents of 3
+        vt = load(V2XTransformer(cfg["v2xvit"]), synth.v2xvit_encoder_spec(cfg["v2xvit"]["encoder"], "encoder"), 16)
+        feat = torch.from_numpy(synth.seeded_uniform(25, (1, 3, 8, 8, 256)))
+        prior = torch.tensor([[[0.0, 0.0, 0.0], [0.0, 1.0, 1.0], [0.0, 0.0, 0.0]]]).view(1, 3, 1, 1, 3).repeat(1, 1, 8, 8, 1)
+        vmask = torch.tensor([[1, 1, 0]])
+        feat = feat * vmask.view(1, 3, 1, 1, 1)
+        scm = torch.eye(4, dtype=torch.float64).view(1, 1, 4, 4).repeat(1, 3, 1, 1)
+        scm[0, 1] = torch.from_numpy(synth.se2_correction(4.0, 0.9, -0.5))
+        out["vit_out"] = vt(torch.cat([feat, prior], -1), vmask, scm).numpy()
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB", {k: v.shape for k, v in out.items()})
+
+
 def main():
     os.chdir(tempfile.mkdtemp())
     import_reference()
@@ -585,6 +696,10 @@ if __name__ == "__main__":
         import_reference()
         torch.set_num_threads(8)
         full_grid_transformers()
+    elif len(sys.argv) > 1 and sys.argv[1] == "submodules":
+        import_reference()
+        torch.set_num_threads(8)
+        submodules_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "points":
         os.chdir(tempfile.mkdtemp())
         import_reference()
