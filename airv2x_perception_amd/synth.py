@@ -274,6 +274,9 @@ def synthetic_tensor(key, shape, kind, seed=0):
         t[:, 0::2] = np.sin(pos * div) / np.float32(np.sqrt(n_hid))
         t[:, 1::2] = np.cos(pos * div) / np.float32(np.sqrt(n_hid))
         return t
+    if kind == "att_lin":   # query -> key projection of When2com: small, so that the softmax over agents stays mixed
+        b = 0.25 * np.sqrt(6.0 / shape[1])
+        return g.uniform(-b, b, size=shape).astype(np.float32)
     if kind in ("conv", "lin", "head", "deconv"):
         if kind == "lin":
             fan_in = shape[1]
@@ -657,6 +660,59 @@ def se2_correction(yaw_deg, tx, ty):
     m = np.eye(4)
     m[0, 0], m[0, 1], m[1, 0], m[1, 1], m[0, 3], m[1, 3] = c, -s, s, c, tx, ty
     return m
+
+
+# --------------------------------------------------------------------------
+# When2com (airv2x_intermediate_when2com.yaml :144-290): the Where2Comm trunk + `when2com_fusion`
+# --------------------------------------------------------------------------
+
+def default_hypes_when2com(lidar_range=None, max_cav=(5, 5, 5), mode="softmax"):
+    hy = default_hypes(lidar_range, max_cav)
+    a = hy["model"]["args"]
+    a.pop("where2com_fusion")
+    g = a["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]
+    a["when2com_fusion"] = {"voxel_size": list(DEFAULT_VOXEL), "downsample_rate": 4, "num_iteration": 2, "in_channels": 256,
+                            "query_size": 32, "key_size": 256, "mode": mode, "H": int(g[1]) // 2, "W": int(g[0]) // 2}
+    hy["model"]["core_method"] = "airv2x_when2com"
+    hy["name"] = "airv2x_intermediate_when2com"
+    return hy
+
+
+def when2com_pairwise(n, L):
+    """(1,L,L,4,4) fp32 ``img_pairwise_t_matrix_collab``: row 0 (ego -> j) carries a small SE(2) motion for every
+    non-ego agent.  The AirV2X dataset ships identities (proj_first); a non-trivial matrix exercises the warp."""
+    t = torch.eye(4).view(1, 1, 1, 4, 4).repeat(1, L, L, 1, 1)
+    for j in range(1, n):
+        t[0, 0, j] = torch.from_numpy(se2_correction(3.0 * j, 1.1 * j, -0.7 * j)).float()
+    return t
+
+
+def when2com_fusion_spec(cfg, prefix=""):
+    """When2comFusion(args) (when2com_modules/when2com.py:14-44): policy_net4 (5 x Conv3x3 + bias + BN + ReLU),
+    two km_generator MLPs on the flattened (256, H/4, W/4) map, and the query -> key Linear of the attention."""
+    spec = []
+    chans = [(cfg["in_channels"], 512), (512, 256), (256, 256), (256, 256), (256, 256)]
+    for i, (ci, co) in enumerate(chans, 1):
+        p = f"{prefix}query_key_net.conv{i}.cbr_unit"
+        spec += [(p + ".0.weight", (co, ci, 3, 3), "conv"), (p + ".0.bias", (co,), "bias")] + _bn(p + ".1", co)
+    nf = 256 * (cfg["H"] // 4) * (cfg["W"] // 4)
+    for net, out in (("key_net", cfg["key_size"]), ("query_net", cfg["query_size"])):
+        for li, (ci, co) in zip((0, 2, 4), ((nf, 256), (256, 128), (128, out))):
+            spec += [(f"{prefix}{net}.fc.{li}.weight", (co, ci), "lin"), (f"{prefix}{net}.fc.{li}.bias", (co,), "bias")]
+    spec += [(prefix + "attention_net.linear.weight", (cfg["key_size"], cfg["query_size"]), "att_lin"),
+             (prefix + "attention_net.linear.bias", (cfg["key_size"],), "bias")]
+    return spec
+
+
+def when2com_param_spec(args):
+    """Ordered (key, shape, kind) manifest of Airv2xWhen2com's state_dict (checked against the reference's own
+    state_dict by tools/gen_golden.py)."""
+    w2c_like = dict(args)
+    w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
+    base = where2com_param_spec(w2c_like)
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
+    return trunk + when2com_fusion_spec(args["when2com_fusion"], "fusion_net.") + heads
 
 
 # --------------------------------------------------------------------------

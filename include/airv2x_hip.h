@@ -331,6 +331,25 @@ int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, c
                             const float* residual, float* out, int32_t n, int32_t hw, int32_t c,
                             av2x_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * When2com fusion (models/when2com_modules/when2com.py).
+ * av2x_linear_rows: y (m,n) = act(x (m,k) . w (n,k)^T + bias) for a few rows m (one per agent): the km_generator
+ *   MLPs (:283-297), whose first layer streams 256*H/4*W/4 inputs per output feature (HBM-bound).  w is the
+ *   nn.Linear weight as stored (row-major (n,k)); k % 4 == 0; x, w 16-byte aligned; act 0 none / 1 ReLU; bias may be
+ *   NULL.  workspace: av2x_linear_rows_workspace_bytes(m, n, k) bytes of device scratch (split-K partials, reduced
+ *   in a fixed order: results are run-to-run identical).
+ * av2x_when2com_fuse: p = softmax_j(keys[j,:] . query) over the n_agents keys (MIMOGeneralDotProductAttention
+ *   :320-348, softmax over the key axis, `query` = attention_net.linear(query_net(ego))), out[e] = sum_j p_j *
+ *   agents[j][e] (:340-347).  agents: HOST array of n_agents device pointers, each elems_per_agent floats, 16-byte
+ *   aligned (the maps may live in different buffers, e.g. slices of an all-gather result); elems_per_agent % 4 == 0,
+ *   n_agents <= 32; coef (n_agents,) receives p (may be NULL).
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_linear_rows_workspace_bytes(int32_t m, int32_t n, int32_t k);
+int av2x_linear_rows(const float* x, const float* w, const float* bias, int32_t m, int32_t n, int32_t k, int32_t act,
+                     float* y, void* workspace, uint64_t workspace_bytes, av2x_stream_t stream);
+int av2x_when2com_fuse(const float* keys, const float* query, int32_t n_agents, int32_t key_size,
+                       const float* const* agents, uint64_t elems_per_agent, float* out, float* coef, av2x_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

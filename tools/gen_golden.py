@@ -653,6 +653,75 @@ def submodules_golden(name="submodules_small"):
     print(path, os.path.getsize(path) // 1024, "KiB", {k: v.shape for k, v in out.items()})
 
 
+def run_when2com_case(name, lidar_range, types, n_points, seed, mode="softmax", head_stride=1, big_stride=4):
+    """Airv2xWhen2com on the real reference vs oracle/when2com_oracle.py."""
+    from airv2x_perception_amd import synth
+    from oracle import when2com_oracle as w2
+    from oracle import voxelize_oracle as vox
+    _stub("opencood.models.task_heads.segmentation_head", BevSegHead=object)
+    from opencood.models.airv2x_when2com import Airv2xWhen2com
+    from opencood.hypes_yaml.yaml_utils import load_yaml
+
+    src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_when2com.yaml")
+    txt = open(src).read()
+    hy = synth.default_hypes_when2com(lidar_range, mode=mode)
+    if lidar_range is not None:
+        r = lidar_range
+        txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+        w = hy["model"]["args"]["when2com_fusion"]
+        txt = txt.replace("      H: 100", f"      H: {w['H']}").replace("      W: 352", f"      W: {w['W']}")
+    txt = txt.replace("mode: softmax", f"mode: {mode}")
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(txt)
+        path = f.name
+    hy_ref = load_yaml(path)
+    os.unlink(path)
+    check_hypes(hy_ref["model"]["args"], hy["model"]["args"])
+    args = hy["model"]["args"]
+    model = Airv2xWhen2com(hy_ref["model"]["args"]).eval()
+    spec = synth.when2com_param_spec(args)
+    ref_sd = model.state_dict()
+    assert [k for k, _, _ in spec] == list(ref_sd.keys()), "when2com state_dict key order mismatch"
+    for k, shp, _ in spec:
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"]))
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    dd["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(len(types), args["max_cav_num"])
+    cap = {}
+    h = model.fusion_net.register_forward_hook(lambda m, i_, o: cap.__setitem__("fused", o[0]))
+    with torch.no_grad():
+        out = model(dd)
+        tr = {}
+        o = w2.when2com_forward(dd, sd, args, trace=tr)
+    h.remove()
+    rep = {k: (float((o[k] - out[k]).abs().max()), float(out[k].abs().max())) for k in ("psm", "rm", "obj")}
+    print(f"[{name}] when2com oracle-vs-reference max|diff| (max|ref|):", {k: f"{a:.3e} ({b:.3e})" for k, (a, b) in rep.items()},
+          "coef", tr["coef0"].tolist(), "comm_rate", out["comm_rate"], o["comm_rate"])
+    assert all(a <= 1e-4 * max(1.0, b) for a, b in rep.values())
+    assert float(out["comm_rate"]) == float(o["comm_rate"]) and out["mask"] == 0
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types),
+          "n_points": np.int64(n_points), "spec_keys": np.asarray([k for k, _, _ in spec]), "mode": np.asarray(mode),
+          "head_stride": np.int64(head_stride), "big_stride": np.int64(big_stride),
+          "comm_rate": np.float64(out["comm_rate"]), "coef": tr["coef0"].numpy()}
+    for i, (v, c, n) in enumerate(voxd):
+        fx[f"vox_coords_{i}"], fx[f"vox_num_{i}"] = c, n
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k][..., ::head_stride, ::head_stride].numpy()
+        fx[k + "_sum"] = np.float64(out[k].double().sum().item())
+    fx["fused"] = cap["fused"][..., ::big_stride, ::big_stride].numpy()
+    fx["fused_sum"] = np.float64(cap["fused"].double().sum().item())
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def main():
     os.chdir(tempfile.mkdtemp())
     import_reference()
@@ -696,6 +765,12 @@ if __name__ == "__main__":
         import_reference()
         torch.set_num_threads(8)
         full_grid_transformers()
+    elif len(sys.argv) > 1 and sys.argv[1] == "when2com":
+        import_reference()
+        torch.set_num_threads(8)
+        small = [-25.6, -12.8, -3, 25.6, 12.8, 1]
+        run_when2com_case("when2com_small_n3", small, ["vehicle", "rsu", "drone"], 1500, 5)
+        run_when2com_case("when2com_small_n2", small, ["vehicle", "vehicle"], 1500, 6)
     elif len(sys.argv) > 1 and sys.argv[1] == "submodules":
         import_reference()
         torch.set_num_threads(8)
