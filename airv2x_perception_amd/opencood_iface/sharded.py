@@ -38,6 +38,8 @@ class ShardedFrame:
 
     @torch.no_grad()
     def forward(self, data_dict_local, **kw):
+        if isinstance(data_dict_local, dict):
+            data_dict_local.setdefault("shard_rank", self.rank)   # global agent index = rank * n_loc + j (When2com's warp)
         send, stats, meta = self.backend.local_stage(data_dict_local, has_ego=(self.rank == 0))
         if self.world == 1:
             recv = send

@@ -117,8 +117,8 @@ class When2comEngine(Where2ComEngine):
         _lib.check(self.lib.av2x_when2com_fuse(_ptr(keys), _ptr(q), n, keys.shape[1], arr, maps[0].numel(), _ptr(out),
                                                _ptr(coef), self.stream()), "av2x_when2com_fuse")
 
-    def warp(self, x, theta, n, H, W, C, tag=""):
-        warped = self.buf("w2_warped" + tag, (n, H, W, C))
+    def warp(self, x, theta, n, H, W, C, out=None):
+        warped = out if out is not None else self.buf("w2_warped", (n, H, W, C))
         th = torch.from_numpy(np.ascontiguousarray(theta, dtype=np.float32)).to(self.device)
         _lib.check(self.lib.av2x_warp_affine_simple(_ptr(x), _ptr(th), _ptr(warped), n, H, W, C, self.stream()),
                    "av2x_warp_affine_simple")
@@ -133,6 +133,68 @@ class When2comEngine(Where2ComEngine):
         out = {"psm": outs[0], "rm": outs[1]}
         if self.args["obj_head"]:
             out["obj"] = outs[2]
+        return out
+
+    # ------------------------------------------------------------------ agent sharding
+    @torch.no_grad()
+    def shard_local_stage(self, data_dict_local, has_ego):
+        """Per-rank half: trunk, warp into the ego frame, policy network and key MLP for THIS rank's agents -- i.e. all
+        of the per-agent work, 290 of the frame's ~300 GFLOP per agent.  Send buffer = [n_loc warped maps (36.0 MB
+        each at the default grid) | n_loc keys (1 KB each) | the ego's projected query (1 KB; zeros on the other
+        ranks)], so that every rank can finish the frame (SPMD).  ``data_dict_local`` carries the frame-level
+        ``img_pairwise_t_matrix_collab`` and ``shard_rank`` (set by ShardedFrame): global agent index = rank * n_loc + j."""
+        record_len, slots = self.frame_layout(data_dict_local)
+        if len(record_len) != 1:
+            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
+        n = record_len[0]
+        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        dims = self.level_dims(ny, nx)
+        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        C, ks = self.feat_c, self.key_fc[-1][0].shape[0]
+        s = self.buf("w2_shrink", (n, H, W, C))
+        self.trunk(canvas, n, ny, nx, shrink_out=s)
+        st = self.stream()
+        nz = self.buf("nonzero", (1,), torch.int64)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        _lib.check(self.lib.av2x_count_nonzero(_ptr(s), s.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        pair = data_dict_local["img_pairwise_t_matrix_collab"]
+        pair = pair.detach().cpu().numpy() if isinstance(pair, torch.Tensor) else np.asarray(pair)
+        theta = normalized_pairwise(pair, H, W, self.w2["voxel_size"][0], self.w2["downsample_rate"])
+        off = int(data_dict_local.get("shard_rank", 0)) * n
+        hwc = H * W * C
+        send = self.buf("shard_send", (n * (hwc + ks) + ks,))
+        warped = self.warp(s, theta[0, 0, off:off + n], n, H, W, C, out=send[:n * hwc].view(n, H, W, C))
+        qk, keys = self.policy_keys(warped, n, H, W)
+        send[n * hwc:n * (hwc + ks)].view(n, ks).copy_(keys)
+        if has_ego:
+            send[n * (hwc + ks):].copy_(self.query_of(qk[0:1]).view(-1))
+        else:
+            _lib.check(self.lib.av2x_fill_zero(_ptr(send[n * (hwc + ks):]), ks * 4, st), "av2x_fill_zero")
+        stats = torch.stack([torch.zeros((), dtype=torch.int64, device=self.device), nz[0]])
+        return send, stats, {"n_loc": n, "H": H, "W": W, "C": C, "ks": ks}
+
+    @torch.no_grad()
+    def shard_ego_stage(self, recv, stats, meta, world, trace=None, sync_comm_rate=False):
+        """Ego half: softmax over the gathered keys, weighted sum of the gathered warped maps (read in place from the
+        all-gather result), heads."""
+        n_loc, H, W, C, ks = meta["n_loc"], meta["H"], meta["W"], meta["C"], meta["ks"]
+        hwc, N = H * W * C, world * n_loc
+        chunk = n_loc * (hwc + ks) + ks
+        if recv.numel() != world * chunk:
+            raise ValueError("gathered buffer has the wrong size")
+        if N > 32:
+            raise ValueError(f"{N} agents exceed the 32 the fusion kernel takes")
+        per_rank = recv.view(world, chunk)
+        keys = self.buf("w2_keys_all", (N, ks))
+        keys.view(world, n_loc, ks).copy_(per_rank[:, n_loc * hwc:n_loc * (hwc + ks)].reshape(world, n_loc, ks))
+        maps = [per_rank[r, j * hwc:(j + 1) * hwc] for r in range(world) for j in range(n_loc)]
+        fused = self.buf("w2_fused", (1, H, W, C))
+        coef = self.buf("w2_coef", (1, 32))
+        self.fuse(keys, per_rank[0, n_loc * (hwc + ks):], maps, fused[0], coef[0])   # rank 0 holds the ego
+        if trace is not None:
+            trace["coef0"], trace["fused"] = coef[0, :N].clone(), fused.permute(0, 3, 1, 2).clone()
+        out = self._heads_out(fused, 1, H, W)
+        out.update({"mask": 0, "comm_rate": int(stats[1].item()) / 1 if sync_comm_rate else stats[1]})
         return out
 
     # ------------------------------------------------------------------ full forward

@@ -87,7 +87,7 @@ def parse():
     ap.add_argument("--per-shape", action="store_true", help="add a per-layer-shape table to the roofline object")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a captured HIP graph (1) or eager (0); "
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
-    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit"], default="where2com",
+    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit", "when2com"], default="where2com",
                     help="where2com = the headline metric; cobevt = BASELINE.json configs[2] fusion head on one GPU")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent frames kept in flight per GPU (separate HIP streams + workspaces, shared weights); "
@@ -109,6 +109,8 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
         hy = synth.default_hypes_cobevt(None, (max(3, nv), max(2, nr), max(2, nd)))
     elif model == "v2xvit":
         hy = synth.default_hypes_v2xvit()
+    elif model == "when2com":
+        hy = synth.default_hypes_when2com()
     else:
         hy = synth.default_hypes()
     args = hy["model"]["args"]
@@ -137,6 +139,8 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
         empty = (np.zeros((0, 32, 4), np.float32), np.zeros((0, 3), np.int32), np.zeros((0,), np.int32))
         dd["prior_encoding"] = synth.build_data_dict([empty] * len(types_frame), types_frame, "cpu",
                                                      args["max_cav_num"])["prior_encoding"]
+    if model == "when2com":   # ego -> j motions for the warp (the dataset ships identities; the cost is the same)
+        dd["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(len(types_frame), args["max_cav_num"])
     return hy, args, dd, [clouds[i] for i in order], types_sorted
 
 
@@ -184,6 +188,11 @@ def main():
         a.cpu_frames = 0
         sd = synth.synthetic_state_dict(synth.v2xvit_param_spec(args), seed=0)
         model = Airv2xV2XVit(args)
+    elif a.model == "when2com":
+        from airv2x_perception_amd.opencood_iface import Airv2xWhen2com
+        a.cpu_frames = 0
+        sd = synth.synthetic_state_dict(synth.when2com_param_spec(args), seed=0)
+        model = Airv2xWhen2com(args)
     else:
         sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
         model = Airv2xWhere2com(args)
@@ -234,7 +243,7 @@ def main():
     fps = (world if a.mode == "replica" else 1) * a.steps / dt
 
     res = {
-        "metric": f"collaborative frames/sec, { {'where2com': 'Where2Comm', 'cobevt': 'CoBEVT', 'v2xvit': 'V2X-ViT'}[a.model] }-LiDAR {a.agents}-agent",
+        "metric": f"collaborative frames/sec, { {'where2com': 'Where2Comm', 'cobevt': 'CoBEVT', 'v2xvit': 'V2X-ViT', 'when2com': 'When2com'}[a.model] }-LiDAR {a.agents}-agent",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,

@@ -104,7 +104,7 @@ def test_v2xvit_emulated_ranks_equal_single_gpu_forward():
     assert out["comm_rate"] == ref["comm_rate"]
 
 
-@pytest.mark.parametrize("which", ["where2com", "cobevt", "v2xvit"])
+@pytest.mark.parametrize("which", ["where2com", "cobevt", "v2xvit", "when2com"])
 def test_frame_pipeline_results_equal_sequential_forward(which):
     """FramePipeline (frames in flight on separate HIP streams, shared packed weights, own workspaces) returns, for every
     frame, exactly what the sequential data-parallel forward returns."""
@@ -118,6 +118,11 @@ def test_frame_pipeline_results_equal_sequential_forward(which):
         from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT as M
         fx = load_fixture("cobevt_small_n3")
         hy, args, sd, dd = tc._case(fx)
+    elif which == "when2com":
+        import tests.test_when2com as tw
+        from airv2x_perception_amd.opencood_iface import Airv2xWhen2com as M
+        fx = load_fixture("when2com_small_n3")
+        hy, args, sd, dd = tw._case(fx)
     else:
         import tests.test_v2xvit as tv
         from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
@@ -137,3 +142,35 @@ def test_frame_pipeline_results_equal_sequential_forward(which):
     for o in outs:
         for k in ("psm", "rm", "obj"):
             assert torch.equal(o[k], ref[k]), (which, k)
+
+
+def test_when2com_emulated_ranks_equal_single_gpu_forward():
+    import tests.test_when2com as tw
+    from airv2x_perception_amd.opencood_iface import Airv2xWhen2com
+    from airv2x_perception_amd.opencood_iface.sharded import partition_agents
+    fx = load_fixture("when2com_small_n3")
+    hy, args, sd, dd = tw._case(fx)
+    types = [str(t) for t in fx["types"]]
+    rng = [float(v) for v in fx["lidar_range"]]
+    from oracle import voxelize_oracle as vox
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, int(fx["n_points"]), rng), rng), rng,
+                                 hy["preprocess"]["args"]["voxel_size"]) for i in range(len(types))]
+    model = Airv2xWhen2com(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    ref = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd, sync_comm_rate=True).items()}
+    world = len(types)
+    sends, stats, meta = [], None, None
+    for r, mine in enumerate(partition_agents(len(types), world)):
+        dd_local = synth.build_data_dict([voxd[i] for i in mine], [types[i] for i in mine], max_cav_num=args["max_cav_num"])
+        dd_local["img_pairwise_t_matrix_collab"] = dd["img_pairwise_t_matrix_collab"]     # frame-level metadata
+        dd_local["shard_rank"] = r
+        send, st, meta = eng.shard_local_stage(dd_local, has_ego=(r == 0))
+        sends.append(send.clone())
+        stats = st.clone() if stats is None else stats + st
+    out = eng.shard_ego_stage(torch.cat(sends), stats, meta, world=world, sync_comm_rate=True)
+    for k in ("psm", "rm", "obj"):
+        assert torch.equal(out[k], ref[k]), k
+    assert out["comm_rate"] == ref["comm_rate"]

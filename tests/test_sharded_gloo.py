@@ -102,6 +102,90 @@ class CoBEVTOracleBackend:
         return {"psm": orc.head(fused, sd, "cls_head"), "rm": orc.head(fused, sd, "reg_head"), "obj": orc.head(fused, sd, "obj_head")}
 
 
+class When2comOracleBackend:
+    """Same interface for the When2com path: the message is the agent's map warped into the ego frame, its key and
+    (from the ego's rank) the projected query."""
+
+    def __init__(self, sd, args):
+        self.sd, self.args = sd, args
+
+    def local_stage(self, dd_local, has_ego):
+        import torch.nn.functional as F
+        from oracle import when2com_oracle as w2
+        sd, args = self.sd, self.args
+        mf, cfg = args["modality_fusion"], args["when2com_fusion"]
+        feats, _ = orc.extract_features(dd_local, sd, args)
+        sf2d, _ = orc.backbone_forward(feats, sd, mf["base_bev_backbone"])
+        s = orc.shrink_conv(sf2d, sd, mf["shrink_header"])
+        n, C, H, W = s.shape
+        t = w2.normalized_pairwise(dd_local["img_pairwise_t_matrix_collab"], H, W, cfg["voxel_size"][0], cfg["downsample_rate"])
+        off = dd_local["shard_rank"] * n
+        nb = w2.warp_affine_simple(s, t[0, 0, off:off + n], (H, W))
+        qk = w2.policy_net(nb, sd, "fusion_net.query_key_net")
+        keys = w2.km_generator(qk, sd, "fusion_net.key_net")
+        q = torch.zeros(cfg["key_size"])
+        if has_ego:
+            query = w2.km_generator(qk[0:1], sd, "fusion_net.query_net")
+            q = F.linear(query, sd["fusion_net.attention_net.linear.weight"], sd["fusion_net.attention_net.linear.bias"]).view(-1)
+        send = torch.cat([nb.reshape(-1), keys.reshape(-1), q])
+        return send, torch.tensor([0, int(s.count_nonzero())], dtype=torch.int64), {"shape": tuple(nb.shape), "ks": cfg["key_size"]}
+
+    def ego_stage(self, recv, stats, meta, world):
+        sd = self.sd
+        n, C, H, W = meta["shape"]
+        ks, per = meta["ks"], recv.numel() // world
+        chunks = recv.view(world, per)
+        maps = chunks[:, :n * C * H * W].reshape(world * n, C, H, W)
+        keys = chunks[:, n * C * H * W:n * C * H * W + n * ks].reshape(world * n, ks)
+        q = chunks[0, n * C * H * W + n * ks:]
+        coef = torch.softmax(keys @ q, 0)
+        fused = (coef.view(-1, 1, 1, 1) * maps).sum(0, keepdim=True)
+        return {"psm": orc.head(fused, sd, "cls_head"), "rm": orc.head(fused, sd, "reg_head"), "obj": orc.head(fused, sd, "obj_head"),
+                "comm_rate": int(stats[1]) / 1}
+
+
+def _when2com_frame():
+    hy = synth.default_hypes_when2com(RNG)
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(synth.when2com_param_spec(args), seed=4)
+    _, _, voxd = _frame()
+    return args, sd, voxd
+
+
+def _when2com_worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    args, sd, voxd = _when2com_frame()
+    mine = partition_agents(len(TYPES), world)[rank]
+    dd_local = synth.build_data_dict([voxd[i] for i in mine], [TYPES[i] for i in mine])
+    dd_local["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(len(TYPES), args["max_cav_num"])
+    with torch.no_grad():
+        out = ShardedFrame(When2comOracleBackend(sd, args)).forward(dd_local)   # sets shard_rank
+    gathered = [torch.empty_like(out["psm"]) for _ in range(world)]
+    dist.all_gather(gathered, out["psm"])
+    assert all(torch.equal(g, gathered[0]) for g in gathered)                   # every rank finishes the frame
+    if rank == 0:
+        torch.save(out, result_path)
+    dist.destroy_process_group()
+
+
+def test_when2com_agent_sharded_frame_equals_single_process(tmp_path):
+    from oracle import when2com_oracle as w2
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_when2com_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = torch.load(path)
+    args, sd, voxd = _when2com_frame()
+    dd = synth.build_data_dict(voxd, TYPES)
+    dd["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(len(TYPES), args["max_cav_num"])
+    with torch.no_grad():
+        ref = w2.when2com_forward(dd, sd, args)
+    for k in ("psm", "rm", "obj"):
+        assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), k
+    assert got["comm_rate"] == ref["comm_rate"]
+
+
 def _cobevt_frame(compression):
     hy = synth.default_hypes_cobevt(RNG, compression=compression)
     args = hy["model"]["args"]
