@@ -9,14 +9,17 @@
 //                        reduced in fixed order by linear_rows_finish (deterministic, no atomics).
 //   when2com_fuse_kernel softmax over the agents of key_j . q  (MIMOGeneralDotProductAttention :320-348, softmax
 //                        over the KEY axis) and out = sum_j p_j * warped_j (:340-347), 16-byte loads.
+#include <cstdlib>
+
 #include "av2x_common.hpp"
 
 namespace {
 
 constexpr int kRows = 8;     // output features per workgroup
-constexpr int kMaxM = 8;     // x rows per pass
+constexpr int kMaxRowsX = 8; // x rows per pass (the kernel is instantiated for 1 / 2 / 4 / 8)
 constexpr int kMaxAgents = 32;
 
+template <int kMaxM>
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, int M,
                                                           int N, int K, int kslice, float* __restrict__ part) {
     const int n0 = blockIdx.x * kRows;
@@ -27,22 +30,28 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
     for (int r = 0; r < kRows; ++r)
 #pragma unroll
         for (int m = 0; m < kMaxM; ++m) acc[r][m] = 0.f;
+    typedef float f4 __attribute__((ext_vector_type(4)));
     for (int k = k0 + 4 * (int)threadIdx.x; k < k1; k += 1024) {
+        // all loads of the iteration are issued before the first use: 8 weight rows (HBM, read once -> non-temporal)
+        // and the x rows (L2 resident, shared by the N/8 row groups)
+        f4 wv[kRows];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const int row = n0 + r < N ? n0 + r : N - 1;
+            wv[r] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(w + (size_t)row * K + k));
+        }
         float4 xv[kMaxM];
 #pragma unroll
         for (int m = 0; m < kMaxM; ++m)
             xv[m] = m < M ? *reinterpret_cast<const float4*>(x + (size_t)m * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
-            if (n0 + r >= N) continue;
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4 wv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(w + (size_t)(n0 + r) * K + k));  // read once
 #pragma unroll
             for (int m = 0; m < kMaxM; ++m) {
-                acc[r][m] = fmaf(wv.x, xv[m].x, acc[r][m]);
-                acc[r][m] = fmaf(wv.y, xv[m].y, acc[r][m]);
-                acc[r][m] = fmaf(wv.z, xv[m].z, acc[r][m]);
-                acc[r][m] = fmaf(wv.w, xv[m].w, acc[r][m]);
+                acc[r][m] = fmaf(wv[r].x, xv[m].x, acc[r][m]);
+                acc[r][m] = fmaf(wv[r].y, xv[m].y, acc[r][m]);
+                acc[r][m] = fmaf(wv[r].z, xv[m].z, acc[r][m]);
+                acc[r][m] = fmaf(wv[r].w, xv[m].w, acc[r][m]);
             }
         }
     }
@@ -115,9 +124,10 @@ __global__ __launch_bounds__(256) void when2com_fuse_kernel(const float* __restr
 }
 
 int nsplit_for(int N, int K) {
-    // enough workgroups to fill 256 CUs a few times over, slices of at least 4 KiB per row
+    // 4 workgroups per CU (measured optimum on the 577 MB When2com layer: tools/linrows_bench.py), slices of >= 4 KiB per row
     const int groups = (N + kRows - 1) / kRows;
-    int ns = (2048 + groups - 1) / groups;
+    static const int target = [] { const char* e = getenv("AV2X_LINROWS_WGS"); return e ? atoi(e) : 1024; }();
+    int ns = (target + groups - 1) / groups;
     const int max_ns = (K + 1023) / 1024;
     if (ns > max_ns) ns = max_ns;
     return ns < 1 ? 1 : ns;
@@ -127,7 +137,7 @@ int nsplit_for(int N, int K) {
 
 extern "C" uint64_t av2x_linear_rows_workspace_bytes(int32_t m, int32_t n, int32_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const int mm = m < kMaxM ? m : kMaxM;
+    const int mm = m < kMaxRowsX ? m : kMaxRowsX;
     return (uint64_t)nsplit_for(n, k) * mm * n * sizeof(float);
 }
 
@@ -146,10 +156,14 @@ extern "C" int av2x_linear_rows(const float* x, const float* w, const float* bia
     int kslice = (k + ns - 1) / ns;
     kslice = (kslice + 3) & ~3;
     float* part = static_cast<float*>(workspace);
-    for (int m0 = 0; m0 < m; m0 += kMaxM) {       // more than 8 rows: the weights are streamed once per group of 8
-        const int mm = (m - m0) < kMaxM ? (m - m0) : kMaxM;
-        hipLaunchKernelGGL(linear_rows_kernel, dim3((n + kRows - 1) / kRows, ns), dim3(256), 0, st, x + (size_t)m0 * k, w, mm, n, k,
-                           kslice, part);
+    for (int m0 = 0; m0 < m; m0 += kMaxRowsX) {   // more than 8 rows: the weights are streamed once per group of 8
+        const int mm = (m - m0) < kMaxRowsX ? (m - m0) : kMaxRowsX;
+        const dim3 grid((n + kRows - 1) / kRows, ns);
+        const float* xs = x + (size_t)m0 * k;
+        if (mm == 1) hipLaunchKernelGGL(linear_rows_kernel<1>, grid, dim3(256), 0, st, xs, w, mm, n, k, kslice, part);
+        else if (mm == 2) hipLaunchKernelGGL(linear_rows_kernel<2>, grid, dim3(256), 0, st, xs, w, mm, n, k, kslice, part);
+        else if (mm <= 4) hipLaunchKernelGGL(linear_rows_kernel<4>, grid, dim3(256), 0, st, xs, w, mm, n, k, kslice, part);
+        else hipLaunchKernelGGL(linear_rows_kernel<8>, grid, dim3(256), 0, st, xs, w, mm, n, k, kslice, part);
         hipLaunchKernelGGL(linear_rows_finish, dim3((mm * n + 255) / 256), dim3(256), 0, st, part, ns, mm, n, bias, act,
                            y + (size_t)m0 * n);
     }
