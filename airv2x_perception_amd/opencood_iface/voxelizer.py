@@ -124,3 +124,52 @@ def voxelize_frame(clouds, lidar_range, voxel_size, poses=None, mask_ego=True, p
         else:
             out.append((voxels[:m], coords[:m], num[:m]))
     return out
+
+
+class SpVoxelPreprocessor:
+    """Mirror of data_utils/pre_processor/sp_voxel_preprocessor.py:30-175 for pipelines that keep the clouds on the GPU
+    (the reference runs spconv's CPU voxelizer inside DataLoader workers).
+
+    Same constructor (``preprocess_params`` = ``hypes["preprocess"]``, ``train``) and methods:
+    ``preprocess(pcd)`` -> ``{"voxel_features" (M,32,4), "voxel_coords" (M,3) z,y,x, "voxel_num_points" (M,)}``
+    (empty clouds get the reference's two dummy points, :80-90) and ``collate_batch(batch)`` -> the three arrays
+    concatenated over the agents with the agent index as leading column of the coordinates (:142-175).  ``pcd`` may be
+    a numpy array or a tensor on any device; results are CUDA tensors (``numpy=True`` returns host arrays like the
+    reference).  ``collate_batch`` accepts the dict-of-lists form the AirV2X dataset uses AND the list-of-dicts form,
+    which raises NameError in the reference."""
+
+    def __init__(self, preprocess_params, train, device="cuda", numpy=False):
+        self.params = preprocess_params
+        self.train = train
+        self.lidar_range = preprocess_params["cav_lidar_range"]
+        a = preprocess_params["args"]
+        self.voxel_size = a["voxel_size"]
+        self.max_points_per_voxel = a["max_points_per_voxel"]
+        self.max_voxels = a["max_voxel_train"] if train else a["max_voxel_test"]
+        g = (np.array(self.lidar_range[3:6]) - np.array(self.lidar_range[0:3])) / np.array(self.voxel_size)
+        self.grid_size = np.round(g).astype(np.int64)
+        self.device = torch.device(device)
+        self.numpy = numpy
+
+    def preprocess(self, pcd_np):
+        pts = torch.as_tensor(pcd_np, dtype=torch.float32).to(self.device)
+        if pts.dim() != 2 or pts.shape[1] != 4:
+            raise ValueError(f"point cloud must be (P,4), got {tuple(pts.shape)}")
+        v, c, n = voxelize_points(pts, self.lidar_range, self.voxel_size, self.max_points_per_voxel, self.max_voxels)
+        if self.numpy:
+            v, c, n = v.cpu().numpy(), c.cpu().numpy(), n.cpu().numpy()
+        return {"voxel_features": v, "voxel_coords": c, "voxel_num_points": n}
+
+    @staticmethod
+    def collate_batch(batch):
+        if isinstance(batch, (list, tuple)):
+            keys = batch[0].keys()
+            batch = {k: [s[k] for s in batch] for k in keys}
+        elif not isinstance(batch, dict):
+            raise TypeError("batch must be list or dict, got {}".format(type(batch)))
+        t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))
+        feats = [t(a) for a in batch["voxel_features"]]
+        nums = [t(a) for a in batch["voxel_num_points"]]
+        coords = [t(a) for a in batch["voxel_coords"]]
+        with_idx = [torch.cat([torch.full((c.shape[0], 1), i, dtype=c.dtype, device=c.device), c], 1) for i, c in enumerate(coords)]
+        return {"voxel_features": torch.cat(feats), "voxel_coords": torch.cat(with_idx), "voxel_num_points": torch.cat(nums)}

@@ -765,6 +765,10 @@ if __name__ == "__main__":
         import_reference()
         torch.set_num_threads(8)
         full_grid_transformers()
+    elif len(sys.argv) > 1 and sys.argv[1] == "when2com_full":
+        import_reference()
+        torch.set_num_threads(8)
+        run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16)
     elif len(sys.argv) > 1 and sys.argv[1] == "when2com":
         import_reference()
         torch.set_num_threads(8)
