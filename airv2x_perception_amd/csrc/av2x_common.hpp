@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -26,6 +27,21 @@ inline int check_launch(const char* what) {
 }
 
 inline hipStream_t as_stream(av2x_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Raises a kernel's dynamic-LDS limit (needed above 64 KiB) once per (kernel, device).  One instance per kernel as a
+// function-local static; safe with several host threads and with several devices in one process.
+struct LdsLimit {
+    std::atomic<size_t> bytes[16] = {};
+    void ensure(const void* fn, size_t need) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t>& b = bytes[dev & 15];
+        if (b.load(std::memory_order_acquire) >= need) return;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        size_t cur = b.load(std::memory_order_relaxed);
+        while (cur < need && !b.compare_exchange_weak(cur, need, std::memory_order_release)) {}
+    }
+};
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 

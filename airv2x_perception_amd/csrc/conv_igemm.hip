@@ -317,12 +317,8 @@ int launch(const ConvParams& p, hipStream_t st) {
     ConvParams q = p;
     q.tiles_n = p.CoutP / BN;
     const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, DEEP, 0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static av2x::LdsLimit lds_limit;
+    lds_limit.ensure(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, DEEP, 0>), lds);
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, DEEP, 0>), dim3(tiles_m * q.tiles_n),
                        dim3(64 * (BM / WM) * (BN / WN)), lds, st, q);
     return av2x::check_launch("conv_igemm_f32");
@@ -346,12 +342,8 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
         return av2x::fail("av2x_conv2d: stream-K workspace too small (%llu B, need %llu B)", ws_bytes,
                           2ull * wgs * BM * BN * sizeof(float));
     const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static av2x::LdsLimit lds_limit;
+    lds_limit.ensure(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, 1>), lds);
     constexpr int NTHR = 64 * (BM / WM) * (BN / WN);
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true, 1>), dim3(wgs), dim3(NTHR), lds, st, q);
     if (q.sk_per % p.steps != 0)  // some tile is cut
@@ -374,12 +366,8 @@ int launch_persist(const ConvParams& p, int wgs, hipStream_t st) {
     if (wgs > tiles) wgs = (int)tiles;
     q.sk_total = (int)tiles;
     const size_t lds = (size_t)(2 * BM * LDA + 2 * 8 * BN * 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static av2x::LdsLimit lds_limit;
+    lds_limit.ensure(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, 2>), lds);
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true, 2>), dim3(wgs), dim3(64 * (BM / WM) * (BN / WN)), lds, st, q);
     return av2x::check_launch("conv_igemm_f32 (persistent)");
 }

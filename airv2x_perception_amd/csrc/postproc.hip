@@ -392,12 +392,8 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     hipLaunchKernelGGL(pp_iou_mask, dim3((top + 63) / 64, top), dim3(64), 0, st, corners, kept, order, ntop, nms_threshold,
                        words, mask);
     const size_t lds = (size_t)top * words * 8 <= 128 * 1024 ? (size_t)top * words * 8 : 0;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_greedy), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  128 * 1024);
-        attr = true;
-    }
+    static av2x::LdsLimit lds_limit;
+    lds_limit.ensure(reinterpret_cast<const void*>(&pp_greedy), 128 * 1024);
     hipLaunchKernelGGL(pp_greedy, dim3(1), dim3(64), lds, st, mask, ntop, words, lds > 0 ? 1 : 0, pick, npick);
     hipLaunchKernelGGL(pp_final, dim3(1), dim3(1024), 0, st, boxes, corners, cscore, label, kept, order, pick, npick, p, inr,
                        out_corners, out_scores, out_labels, out_boxes, out_index, cand, nout);

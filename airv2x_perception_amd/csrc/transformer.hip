@@ -676,35 +676,24 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
     if (T <= 128 && window == 4 && !(grid_partition & 6)) {   // ws = 4: S^T form, P stays in registers (test hook: bit 3)
         const int TkP = (Tk + 31) & ~31;
         const size_t lds_4 = ((size_t)TkP * KLD + (size_t)TkP * VLD4 + ((tab_n + 3) & ~3) + 128) * sizeof(float);
-        static size_t attr_4 = 0;
-        if (lds_4 > attr_4) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fax_attention_mfma4_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_4);
-            attr_4 = lds_4;
-        }
+        static av2x::LdsLimit lim_attr_4;
+        lim_attr_4.ensure(reinterpret_cast<const void*>(&fax_attention_mfma4_kernel), lds_4);
         hipLaunchKernelGGL(fax_attention_mfma4_kernel, dim3((h / window) * (w / window)), dim3(256), lds_4, av2x::as_stream(stream), p);
         return av2x::check_launch("fax_attention_mfma4_kernel");
     }
     if (T <= 128 && !(grid_partition & 2)) {  // generic-window MFMA path (bit 1 forces the VALU reference kernel, bit 2 this one: tests)
         const int TkP = (Tk + 31) & ~31;
         const size_t lds_m = ((size_t)TkP * KLD + (size_t)TkP * DH + ((tab_n + 3) & ~3) + TkP + 256 + 4 * 32 * PLD) * sizeof(float);
-        static size_t attr_m = 0;
-        if (lds_m > attr_m) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fax_attention_mfma_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
-            attr_m = lds_m;
-        }
+        static av2x::LdsLimit lim_attr_m;
+        lim_attr_m.ensure(reinterpret_cast<const void*>(&fax_attention_mfma_kernel), lds_m);
         hipLaunchKernelGGL(fax_attention_mfma_kernel, dim3((h / window) * (w / window)), dim3(256), lds_m, av2x::as_stream(stream), p);
         return av2x::check_launch("fax_attention_mfma_kernel");
     }
     p.grid = grid_partition & 1;
     const size_t lds = (size_t)4 * (2 * Tk * DH + tab_n) * sizeof(float);
     if (lds > 160 * 1024) return av2x::fail("av2x_fax_attention: %zu B of LDS needed (> 160 KiB): too many valid agents", lds);
-    static size_t attr = 0;
-    if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fax_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    static av2x::LdsLimit lim_attr;
+    lim_attr.ensure(reinterpret_cast<const void*>(&fax_attention_kernel), lds);
     hipLaunchKernelGGL(fax_attention_kernel, dim3((h / window) * (w / window)), dim3(256), lds, av2x::as_stream(stream), p);
     return av2x::check_launch("fax_attention_kernel");
 }
