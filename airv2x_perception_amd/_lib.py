@@ -36,6 +36,10 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_pillar_vfe": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "av2x_pillar_vfe_scatter_dev": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_voxelize_dummy_if_empty": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
     "av2x_pillar_scatter": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_fill_zero": (c_int32, [c_void_p, c_uint64, c_void_p]),
     "av2x_linear_rows_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),

@@ -13,11 +13,15 @@ constexpr int kFeat = 10;  // x y z i | cluster xyz | centre xyz (airv2x_pillar_
 constexpr int kOut = 64;
 constexpr int kLdF = 12;   // padded feature row (three 16-byte reads)
 
-// DENSE = false: scatter into the NHWC canvas (the fused product path).  DENSE = true: ``canvas`` is the
-// (n_pillars, 64) ``pillar_features`` array of the stand-alone PillarVFE module (airv2x_pillar_vfe.py:156-158).
-template <bool DENSE>
+// MODE 0: scatter into the NHWC canvas (the fused product path).  MODE 1: ``canvas`` is the (n_pillars, 64)
+// ``pillar_features`` array of the stand-alone PillarVFE module (airv2x_pillar_vfe.py:156-158).  MODE 2: scatter, with the
+// voxelizer's own outputs as input: coordinates (M,3) z,y,x without the agent column (the agent is ``agent0``) and
+// the pillar count read from DEVICE memory (``n_dev``; n_pillars is the buffers' capacity) -- no host round trip
+// between the voxelizer and the network.
+template <int MODE>
 __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
     const float4* __restrict__ vox, const int4* __restrict__ coords, const int* __restrict__ npts, int n_pillars,
+    const int* __restrict__ n_dev,
     const float* __restrict__ pfn_w, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
     float vx, float vy, float vz, float xoff, float yoff, float zoff, float* __restrict__ canvas, int agent0,
     const int* __restrict__ slot_map, int n_agents, int ny, int nx) {
@@ -32,8 +36,15 @@ __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
     for (int j = 0; j < kFeat; ++j) w[j] = pfn_w[lane * kFeat + j];
     const float sc = bn_scale[lane], sh = bn_shift[lane];
 
+    if (MODE == 2) n_pillars = min(n_pillars, n_dev[0]);
     for (int pil = blockIdx.x * 4 + wave; pil < n_pillars; pil += waves_total) {
-        const int4 c = coords[pil];  // agent, z, y, x
+        int4 c;  // agent, z, y, x
+        if (MODE == 2) {
+            const int* c3 = reinterpret_cast<const int*>(coords) + 3 * (size_t)pil;
+            c = make_int4(0, c3[0], c3[1], c3[2]);
+        } else {
+            c = coords[pil];
+        }
         int num = npts[pil];
         num = num < 0 ? 0 : (num > kPts ? kPts : num);
         float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
             acc = fmaf(b.w, w[7], acc); acc = fmaf(d.x, w[8], acc); acc = fmaf(d.y, w[9], acc);
             best = fmaxf(best, fmaxf(fmaf(acc, sc, sh), 0.f));
         }
-        if (DENSE) {
+        if (MODE == 1) {
             canvas[(size_t)pil * kOut + lane] = best;
         } else if (c.x >= 0 && c.x < n_agents && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx) {
             const int agent = slot_map ? slot_map[c.x] : agent0 + c.x;
@@ -132,9 +143,9 @@ extern "C" int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_
     if (n_pillars < 0 || ny <= 0 || nx <= 0) return av2x::fail("av2x_pillar_vfe_scatter: bad sizes");
     int blocks = (n_pillars + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(pillar_vfe_scatter_kernel<false>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
+    hipLaunchKernelGGL(pillar_vfe_scatter_kernel<0>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
-                       voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
+                       voxel_num_points, n_pillars, (const int*)nullptr, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
                        geom[4], geom[5], canvas, canvas_agent0, slot_map, n_agents_type, ny, nx);
     return av2x::check_launch("pillar_vfe_scatter_kernel");
 }
@@ -148,11 +159,28 @@ extern "C" int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel
     if (n_pillars < 0) return av2x::fail("av2x_pillar_vfe: bad sizes");
     int blocks = (n_pillars + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(pillar_vfe_scatter_kernel<true>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
+    hipLaunchKernelGGL(pillar_vfe_scatter_kernel<1>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
-                       voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
+                       voxel_num_points, n_pillars, (const int*)nullptr, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
                        geom[4], geom[5], pillar_features, 0, (const int*)nullptr, 0, 0, 0);
     return av2x::check_launch("pillar_vfe_kernel");
+}
+
+extern "C" int av2x_pillar_vfe_scatter_dev(const float* voxel_features, const int32_t* voxel_coords3,
+                                           const int32_t* voxel_num_points, const int32_t* n_pillars_dev, int32_t capacity,
+                                           const float* pfn_w, const float* bn_scale, const float* bn_shift, const float* geom,
+                                           float* canvas, int32_t canvas_slot, int32_t ny, int32_t nx, av2x_stream_t stream) {
+    if (capacity == 0) return 0;
+    if (!voxel_features || !voxel_coords3 || !voxel_num_points || !n_pillars_dev || !pfn_w || !bn_scale || !bn_shift || !geom || !canvas)
+        return av2x::fail("av2x_pillar_vfe_scatter_dev: null argument");
+    if (capacity < 0 || ny <= 0 || nx <= 0 || canvas_slot < 0) return av2x::fail("av2x_pillar_vfe_scatter_dev: bad sizes");
+    int blocks = (capacity + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(pillar_vfe_scatter_kernel<2>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords3),
+                       voxel_num_points, capacity, n_pillars_dev, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
+                       geom[4], geom[5], canvas, canvas_slot, (const int*)nullptr, 1, ny, nx);
+    return av2x::check_launch("pillar_vfe_scatter_kernel<2>");
 }
 
 extern "C" int av2x_pillar_scatter(const float* pillar_features, const int32_t* voxel_coords, int32_t n_pillars,

@@ -139,6 +139,35 @@ __global__ void k_init(int* __restrict__ cnt, int* __restrict__ first, int* __re
     first[c] = 0x7fffffff;
 }
 
+// The reference replaces an empty cloud by two dummy points before voxelising (sp_voxel_preprocessor.py:80-90).  With the
+// pillar count staying on the device the same substitution happens here: if the voxelizer found no pillar, voxelise the
+// two dummy points (one thread; same cell arithmetic as k_cell).
+__global__ void k_dummy_if_empty(VoxGeom g, int max_points, int max_voxels, float4* __restrict__ voxels, int* __restrict__ coords,
+                                 int* __restrict__ num, int* __restrict__ n_voxels) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || n_voxels[0] != 0) return;
+    const float4 d[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(-0.218277f, -11.13425732f, -80.05884552f, 1.230595649e-38f)};
+    int m = 0, cell0 = -1;
+    for (int i = 0; i < 2; ++i) {
+        const float fx = floorf(__fdiv_rn(__fsub_rn(d[i].x, g.rmin[0]), g.vs[0]));
+        const float fy = floorf(__fdiv_rn(__fsub_rn(d[i].y, g.rmin[1]), g.vs[1]));
+        const float fz = floorf(__fdiv_rn(__fsub_rn(d[i].z, g.rmin[2]), g.vs[2]));
+        if (!(fx >= 0.f && fx < (float)g.grid[0] && fy >= 0.f && fy < (float)g.grid[1] && fz >= 0.f && fz < (float)g.grid[2])) continue;
+        const int c = ((int)fz * g.grid[1] + (int)fy) * g.grid[0] + (int)fx;
+        if (c == cell0) {   // second point of the same pillar
+            if (num[0] < max_points) { voxels[num[0]] = d[i]; num[0] += 1; }
+            continue;
+        }
+        if (m >= max_voxels) continue;
+        if (m == 0) cell0 = c;
+        for (int r = 0; r < max_points; ++r) voxels[(size_t)m * max_points + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        voxels[(size_t)m * max_points] = d[i];
+        coords[3 * m + 0] = (int)fz; coords[3 * m + 1] = (int)fy; coords[3 * m + 2] = (int)fx;
+        num[m] = 1;
+        ++m;
+    }
+    n_voxels[0] = m;
+}
+
 // ---- point preparation -------------------------------------------------------
 struct PrepParams {
     float T[16];
@@ -283,4 +312,22 @@ extern "C" int av2x_prepare_voxelize(const float* points, const int32_t* perm, i
     for (int i = 0; i < 6; ++i) P.r[i] = crop_range6[i];
     return voxelize_impl(points, n_points, P, grid_range6, voxel3, max_points, max_voxels, workspace, voxels, coords, num_points,
                          n_voxels, stream);
+}
+
+extern "C" int av2x_voxelize_dummy_if_empty(const float* range6, const float* voxel3, int32_t max_points, int32_t max_voxels,
+                                            int32_t capacity, float* voxels, int32_t* coords, int32_t* num_points,
+                                            int32_t* n_voxels, av2x_stream_t stream) {
+    if (!range6 || !voxel3 || !voxels || !coords || !num_points || !n_voxels)
+        return av2x::fail("av2x_voxelize_dummy_if_empty: null argument");
+    if (max_points <= 0 || max_voxels <= 0 || capacity < 2) return av2x::fail("av2x_voxelize_dummy_if_empty: capacity must be >= 2 pillars");
+    VoxGeom g;
+    for (int j = 0; j < 3; ++j) {
+        g.rmin[j] = range6[j];
+        g.vs[j] = voxel3[j];
+        g.grid[j] = (int)llround(((double)range6[3 + j] - (double)range6[j]) / (double)voxel3[j]);
+        if (g.grid[j] <= 0) return av2x::fail("av2x_voxelize_dummy_if_empty: empty grid");
+    }
+    hipLaunchKernelGGL(k_dummy_if_empty, dim3(1), dim3(64), 0, av2x::as_stream(stream), g, max_points, max_voxels,
+                       reinterpret_cast<float4*>(voxels), coords, num_points, n_voxels);
+    return av2x::check_launch("k_dummy_if_empty");
 }

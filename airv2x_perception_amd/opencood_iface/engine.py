@@ -24,6 +24,7 @@ import ctypes
 import os
 from ctypes import byref, c_float, c_void_p
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -429,9 +430,73 @@ class Where2ComEngine:
 
     # ------------------------------------------------------------------ stages
     def frame_layout(self, data_dict):
+        pf = data_dict.get("points")
+        if pf is not None:   # raw-cloud input (voxelizer.points_frame): one frame, agents already in frame order
+            rank = {t: i for i, t in enumerate(AGENT_TYPES)}
+            ts = list(pf["types"])
+            if len(ts) == 0 or len(ts) != len(pf["clouds"]):
+                raise ValueError("points frame: one type per cloud, at least one agent")
+            if any(t not in self.pfn for t in ts):
+                raise ValueError("points frame: agent type without a lidar encoder in this model")
+            if any(rank[a] > rank[b] for a, b in zip(ts, ts[1:])):
+                raise ValueError("points frame: agents must come in frame order (vehicles, rsus, drones; ego first)")
+            return [len(ts)], {"__points__": pf}
         return frame_layout(self.args["collaborators"], data_dict)
 
+    def encode_points(self, pf):
+        """Raw clouds -> canvas with NO host round trip: per agent av2x_prepare_voxelize (ego-box mask, projection by the
+        agent's pose, range crop, pillar voxelizer) -> av2x_voxelize_dummy_if_empty (the reference's empty-cloud branch,
+        sp_voxel_preprocessor.py:80-90) -> av2x_pillar_vfe_scatter_dev, which reads the pillar count from device memory.
+        Same kernels and therefore the same canvas, bit for bit, as voxelize_frame + the (M,32,4) input contract."""
+        clouds, types = pf["clouds"], list(pf["types"])
+        rng, vs = [float(v) for v in pf["lidar_range"]], [float(v) for v in pf["voxel_size"]]
+        mp, mv = int(pf.get("max_points", 32)), int(pf.get("max_voxels", 70000))
+        poses, perms, mask_ego = pf.get("poses"), pf.get("perms"), bool(pf.get("mask_ego", True))
+        if mp != 32:
+            raise ValueError("the pillar feature net is built for 32 points per pillar")
+        n = len(clouds)
+        g = [int(v) for v in self.args[types[0]]["lidar"]["point_pillar_scatter"]["grid_size"]]
+        nx, ny = g[0], g[1]
+        grid = [int(round((rng[3 + j] - rng[j]) / vs[j])) for j in range(3)]
+        if grid[0] != nx or grid[1] != ny or grid[2] != 1:
+            raise ValueError(f"voxel grid {grid} of the preprocess range does not match the model's canvas {nx}x{ny}x1")
+        canvas = self.buf("canvas", (n, ny, nx, 64))
+        st = self.stream()
+        _lib.check(self.lib.av2x_fill_zero(_ptr(canvas), canvas.numel() * 4, st), "av2x_fill_zero")
+        r6, v3 = (c_float * 6)(*rng), (c_float * 3)(*vs)
+        for i, (pts, t) in enumerate(zip(clouds, types)):
+            if pts.device != self.device or pts.dtype != torch.float32 or not pts.is_contiguous():
+                pts = pts.to(self.device, torch.float32).contiguous()
+            P = int(pts.shape[0])
+            pr = max(16384, -(-P // 16384) * 16384)         # capacity classes: real clouds change size every frame
+            cap = max(2, min(pr, mv))
+            ws = self.buf(f"vox_ws{i}", (int(self.lib.av2x_voxelize_workspace_bytes(pr, nx, ny, 1)),), torch.uint8)
+            voxels = self.buf(f"vox_f{i}", (cap, mp, 4))
+            coords = self.buf(f"vox_c{i}", (cap, 3), torch.int32)
+            num = self.buf(f"vox_n{i}", (cap,), torch.int32)
+            cnt = self.buf(f"vox_m{i}", (1,), torch.int32)
+            t16 = None
+            if poses is not None and poses[i] is not None:
+                t16 = (c_float * 16)(*np.asarray(poses[i], dtype=np.float32).reshape(-1).tolist())
+            pm = None
+            if perms is not None and perms[i] is not None:
+                pm = perms[i].to(device=self.device, dtype=torch.int32).contiguous()
+            _lib.check(self.lib.av2x_prepare_voxelize(_ptr(pts), _ptr(pm), P, ctypes.cast(t16, c_void_p) if t16 is not None else None,
+                                                      ctypes.cast(r6, c_void_p), 1 if mask_ego else 0, ctypes.cast(r6, c_void_p),
+                                                      ctypes.cast(v3, c_void_p), mp, mv, _ptr(ws), _ptr(voxels), _ptr(coords),
+                                                      _ptr(num), _ptr(cnt), st), "av2x_prepare_voxelize")
+            _lib.check(self.lib.av2x_voxelize_dummy_if_empty(ctypes.cast(r6, c_void_p), ctypes.cast(v3, c_void_p), mp, mv, cap,
+                                                             _ptr(voxels), _ptr(coords), _ptr(num), _ptr(cnt), st),
+                       "av2x_voxelize_dummy_if_empty")
+            w, sc, sh, geom = self.pfn[t]
+            _lib.check(self.lib.av2x_pillar_vfe_scatter_dev(_ptr(voxels), _ptr(coords), _ptr(num), _ptr(cnt), cap, _ptr(w), _ptr(sc),
+                                                            _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), i, ny, nx, st),
+                       "av2x_pillar_vfe_scatter_dev")
+        return canvas, ny, nx
+
     def encode(self, data_dict, record_len, slots):
+        if "__points__" in slots:
+            return self.encode_points(slots["__points__"])
         n_total = sum(record_len)
         g = [int(v) for v in self.args[next(iter(slots))]["lidar"]["point_pillar_scatter"]["grid_size"]]
         nx, ny = g[0], g[1]

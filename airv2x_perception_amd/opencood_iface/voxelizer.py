@@ -126,6 +126,26 @@ def voxelize_frame(clouds, lidar_range, voxel_size, poses=None, mask_ego=True, p
     return out
 
 
+def points_frame(clouds, types, preprocess_params, poses=None, perms=None, mask_ego=True, train=False, **frame_metadata):
+    """Model input for ONE collaborative frame straight from raw clouds: ``model(points_frame(...))`` runs point
+    preparation, voxelizer, pillar feature net and scatter back to back on the device without any host read-back (the
+    (M,32,4) tensors of the reference's input contract never take their exact shape; the pillar counts stay in HBM).
+
+    clouds: list of (P,4) fp32 CUDA tensors in frame order (vehicles, rsus, drones; ego first), types: their agent
+    types, preprocess_params: ``hypes["preprocess"]`` (cav_lidar_range, voxel_size, max_points_per_voxel, max_voxel_*),
+    poses[i]: 4x4 sensor -> ego transform or None, perms[i]: the shuffle permutation or None, mask_ego: drop the
+    ego-vehicle box (intermediate_fusion_dataset.py:591-603).  ``frame_metadata``: the frame-level entries the model reads
+    besides the lidar features (``prior_encoding``, ``spatial_correction_matrix``, ``img_pairwise_t_matrix_collab``)."""
+    a = preprocess_params["args"]
+    pf = {"clouds": list(clouds), "types": list(types), "lidar_range": list(preprocess_params["cav_lidar_range"]),
+          "voxel_size": list(a["voxel_size"]), "max_points": int(a["max_points_per_voxel"]),
+          "max_voxels": int(a["max_voxel_train"] if train else a["max_voxel_test"]),
+          "poses": poses, "perms": perms, "mask_ego": bool(mask_ego)}
+    dd = {"points": pf}
+    dd.update(frame_metadata)
+    return dd
+
+
 class SpVoxelPreprocessor:
     """Mirror of data_utils/pre_processor/sp_voxel_preprocessor.py:30-175 for pipelines that keep the clouds on the GPU
     (the reference runs spconv's CPU voxelizer inside DataLoader workers).

@@ -61,6 +61,13 @@ int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_t* voxel_co
 int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
                     int32_t n_pillars, const float* pfn_w, const float* bn_scale, const float* bn_shift,
                     const float* geom, float* pillar_features, av2x_stream_t stream);
+/* av2x_pillar_vfe_scatter_dev = av2x_pillar_vfe_scatter fed straight from the voxelizer's outputs of ONE agent:
+ *   voxel_coords3 (capacity,3) z,y,x (no agent column; the agent's canvas slot is canvas_slot), pillar count read from
+ *   DEVICE memory (n_pillars_dev, clamped to capacity) -- the frame needs no host read-back between voxelizer and network. */
+int av2x_pillar_vfe_scatter_dev(const float* voxel_features, const int32_t* voxel_coords3, const int32_t* voxel_num_points,
+                                const int32_t* n_pillars_dev, int32_t capacity, const float* pfn_w, const float* bn_scale,
+                                const float* bn_shift, const float* geom, float* canvas, int32_t canvas_slot, int32_t ny,
+                                int32_t nx, av2x_stream_t stream);
 int av2x_pillar_scatter(const float* pillar_features, const int32_t* voxel_coords, int32_t n_pillars, int32_t channels,
                         float* canvas, int32_t n_agents, int32_t ny, int32_t nx, av2x_stream_t stream);
 
@@ -330,6 +337,14 @@ int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float
 int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,
                             const float* residual, float* out, int32_t n, int32_t hw, int32_t c,
                             av2x_stream_t stream);
+
+/* The reference replaces an EMPTY cloud by two dummy points before voxelising (sp_voxel_preprocessor.py:80-90).
+ * av2x_voxelize_dummy_if_empty does the same on the device after av2x_voxelize / av2x_prepare_voxelize: if *n_voxels == 0
+ * the two dummy points are voxelised into rows 0.. of the (zeroed) outputs and *n_voxels is updated; otherwise nothing
+ * happens.  capacity (pillars the output buffers hold) must be >= 2. */
+int av2x_voxelize_dummy_if_empty(const float* range6, const float* voxel3, int32_t max_points, int32_t max_voxels,
+                                 int32_t capacity, float* voxels, int32_t* coords, int32_t* num_points, int32_t* n_voxels,
+                                 av2x_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * When2com fusion (models/when2com_modules/when2com.py).
