@@ -201,6 +201,69 @@ class CoBEVTEngine(Where2ComEngine):
         fused = self.fax_encoder(x, N, H, W, trace)
         return self._heads_out(fused, H, W)
 
+    # second level: the fusion itself is split over the ranks (sharded.fusion_column_shards), 1/world of the 1.3-1.6 TFLOP each
+    fusion_sharding = True
+
+    def _gathered_tokens(self, recv, meta, world):
+        n_loc, H, W, cm = meta["n_loc"], meta["H"], meta["W"], meta["cm"]
+        N, C = world * n_loc, self.fax["input_dim"]
+        if recv.numel() != N * H * W * cm:
+            raise ValueError("gathered buffer has the wrong size")
+        if N > self.L:
+            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        msg = recv.view(N, H, W, cm)
+        if self.compression:   # decode on the receiving side
+            mid = self.buf("compress_mid", (N, H, W, C))
+            dec = self.buf("compress_dec", (N, H, W, C))
+            self.conv(self.compressor[1], msg, N, H, W, mid)
+            self.conv(self.compressor[2], mid, N, H, W, dec)
+            msg = dec
+        return msg, N, H, W, C
+
+    @torch.no_grad()
+    def shard_ego_partial(self, recv, stats, meta, world, rank):
+        """This rank's share of the fusion: its residue-group columns of every agent's map, compacted to (L, H, Wc, C), go
+        through the ordinary encoder and heads; returns the flat (heads, H, Wc) result for the second all-gather."""
+        from .sharded import fusion_column_shards
+        msg, N, H, W, C = self._gathered_tokens(recv, meta, world)
+        shards = fusion_column_shards(W, self.fax["window_size"], world)
+        cols, _ = shards[rank]
+        Wc = len(cols)
+        key = ("fusion_cols", W, world, rank)
+        ci = self.ws.get(key)
+        if ci is None:
+            ci = torch.tensor(cols, dtype=torch.int64, device=self.device)
+            self.ws[key] = ci
+        xc = self.buf("fax_xc", (self.L, H, Wc, C))
+        torch.index_select(msg, 2, ci, out=xc[:N])                      # column gather (data movement only)
+        if N < self.L:
+            _lib.check(self.lib.av2x_fill_zero(_ptr(xc[N:]), (self.L - N) * H * Wc * C * 4, self.stream()), "av2x_fill_zero")
+        fused = self.fax_encoder(xc, N, H, Wc)
+        heads = torch.empty((1, self.heads.cout, H, Wc), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, 1, H, Wc, heads)
+        return heads.view(-1), {"H": H, "W": W, "Wc": Wc, "shards": shards}
+
+    @torch.no_grad()
+    def shard_ego_finish(self, parts, ctx, world):
+        H, W, Wc, shards = ctx["H"], ctx["W"], ctx["Wc"], ctx["shards"]
+        nh = self.heads.cout
+        per_rank = parts.view(world, nh, H, Wc)
+        full = torch.empty((1, nh, H, W), dtype=torch.float32, device=self.device)
+        ws = self.fax["window_size"]
+        for r, (cols, valid) in enumerate(shards):
+            if valid == 0:
+                continue
+            strip = Wc // ws                                             # compact columns per w2 strip
+            keep = [w2 * strip + j for w2 in range(ws) for j in range(valid)]
+            src = torch.tensor(keep, dtype=torch.int64, device=self.device)
+            dst = torch.tensor([cols[k] for k in keep], dtype=torch.int64, device=self.device)
+            full[0].index_copy_(2, dst, per_rank[r].index_select(2, src))
+        outs = torch.split(full, self.head_splits, dim=1)
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        return out
+
     @torch.no_grad()
     def forward(self, data_dict, trace=None, sync_comm_rate=False):
         if not self.weights_ready:

@@ -49,6 +49,13 @@ class ShardedFrame:
             # xGMI is point-to-point, so the 7 peer transfers into each GPU run on separate links
             dist.all_gather_into_tensor(recv, send, group=self.group)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1 and getattr(self.backend, "two_level", False):
+            # second level: every rank runs the fusion on ITS share of the map and the (small) head outputs are
+            # gathered, instead of every rank repeating the whole fusion
+            part, ctx = self.backend.ego_partial(recv, stats, meta, self.world, self.rank)
+            parts = torch.empty(self.world * part.numel(), dtype=part.dtype, device=part.device)
+            dist.all_gather_into_tensor(parts, part, group=self.group)
+            return self.backend.ego_finish(parts, ctx, self.world)
         return self.backend.ego_stage(recv, stats, meta, self.world, **kw)
 
 
@@ -63,3 +70,37 @@ class EngineBackend:
 
     def ego_stage(self, recv, stats, meta, world, **kw):
         return self.engine.shard_ego_stage(recv, stats, meta, world, **kw)
+
+    @property
+    def two_level(self):
+        return hasattr(self.engine, "shard_ego_partial") and getattr(self.engine, "fusion_sharding", True)
+
+    def ego_partial(self, recv, stats, meta, world, rank):
+        return self.engine.shard_ego_partial(recv, stats, meta, world, rank)
+
+    def ego_finish(self, parts, ctx, world):
+        return self.engine.shard_ego_finish(parts, ctx, world)
+
+
+def fusion_column_shards(W, window, world):
+    """Second-level sharding of a fused-axial-attention map (swap_fusion_modules.py:154-195) WITHOUT any exchange between
+    the window and the grid halves: with Y = W / window, the window partition groups columns [window*b, window*b + window)
+    and the grid partition groups columns {w2 * Y + y : w2 < window}.  When window | Y, the set of columns whose residue
+    mod Y falls into the aligned group [window*g, window*g + window) is closed under BOTH groupings (all rows), so the
+    G = Y / window residue groups are independent sub-problems.  Rank r takes a contiguous run of ceil(G / world)
+    groups (padded by repeating the last group so that every rank solves the same shape; ``valid`` counts the real ones).
+    The compacted map (H, window * window * per) keeps both partitions intact, so the ordinary kernels run on it.
+    Returns [(column indices into the full map, number of valid compact columns per strip)] per rank."""
+    if W % (window * window):
+        raise ValueError(f"map width {W} is not a multiple of window^2 = {window * window}: no exchange-free column sharding")
+    Y = W // window
+    G = Y // window
+    per = -(-G // world)
+    out = []
+    for r in range(world):
+        gs = list(range(r * per, min((r + 1) * per, G)))
+        valid = len(gs)
+        gs = gs + [G - 1] * (per - valid)
+        cols = [w2 * Y + window * g + j for w2 in range(window) for g in gs for j in range(window)]
+        out.append((cols, valid * window))
+    return out

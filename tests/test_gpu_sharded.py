@@ -70,6 +70,16 @@ def test_cobevt_emulated_ranks_equal_single_gpu_forward(name):
     for k in ("psm", "rm", "obj"):
         assert torch.equal(out[k], ref[k]), k
         tc.assert_close(out[k].cpu(), fx[k], 3e-4, 3e-4, k)
+    # second level: every rank fuses only its residue-group columns of the map (no exchange between the window and the
+    # grid halves), the head outputs are gathered.  64 columns = 4 groups: 2 + 2 (+ an all-padding third rank for n3)
+    recv = torch.cat(sends)
+    parts, ctx = [], None
+    for r in range(world):
+        part, ctx = eng.shard_ego_partial(recv, st, meta, world, r)
+        parts.append(part.clone())
+    out2 = eng.shard_ego_finish(torch.cat(parts), ctx, world)
+    for k in ("psm", "rm", "obj"):
+        assert torch.equal(out2[k], ref[k]), ("two-level", k)
 
 
 def test_v2xvit_emulated_ranks_equal_single_gpu_forward():

@@ -72,8 +72,44 @@ class CoBEVTOracleBackend:
     """Same interface for the CoBEVT path: the message is the shrink output, or (compression > 0) the
     NaiveCompressor encoder output that the receiving side decodes (naive_compress.py:12-42)."""
 
-    def __init__(self, sd, args):
-        self.sd, self.args = sd, args
+    def __init__(self, sd, args, two_level=False):
+        self.sd, self.args, self.two_level = sd, args, two_level
+
+    def _decode(self, recv, meta, world):
+        import torch.nn.functional as F
+        sd, args = self.sd, self.args
+        n_loc, c, h, w = meta["shape"]
+        s = recv.view(world * n_loc, c, h, w)
+        if args["compression"]:
+            for conv, bn in (("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+                s = F.conv2d(s, sd[f"naive_compressor.{conv}.weight"], sd[f"naive_compressor.{conv}.bias"], padding=1)
+                s = F.relu(orc._bn(s, sd, f"naive_compressor.{bn}"))
+        return s
+
+    def ego_partial(self, recv, stats, meta, world, rank):
+        """Second level: this rank fuses its residue-group columns only (sharded.fusion_column_shards)."""
+        from airv2x_perception_amd.opencood_iface.sharded import fusion_column_shards
+        from oracle import cobevt_oracle as cob
+        sd, args = self.sd, self.args
+        s = self._decode(recv, meta, world)
+        shards = fusion_column_shards(s.shape[-1], args["fax_fusion"]["window_size"], world)
+        sc = s[..., shards[rank][0]]
+        x, mask = cob.regroup(sc, torch.tensor([sc.shape[0]]), sum(args["max_cav"].values()))
+        fused = cob.swap_fusion_encoder(x, mask, sd, args["fax_fusion"])
+        heads = torch.cat([orc.head(fused, sd, n) for n in ("cls_head", "reg_head", "obj_head")], 1)
+        return heads.reshape(-1).contiguous(), {"shards": shards, "shape": tuple(heads.shape), "W": s.shape[-1]}
+
+    def ego_finish(self, parts, ctx, world):
+        nb, nh, H, Wc = ctx["shape"]
+        full = torch.zeros(nb, nh, H, ctx["W"])
+        per = parts.view(world, nb, nh, H, Wc)
+        for r, (cols, valid) in enumerate(ctx["shards"]):
+            strip = Wc // 4
+            keep = [w2 * strip + j for w2 in range(4) for j in range(valid)]
+            full[..., [cols[k] for k in keep]] = per[r][..., keep]
+        a = self.args["anchor_number"]
+        c = a * self.args["num_class"]
+        return {"psm": full[:, :c], "rm": full[:, c:c + 7 * a], "obj": full[:, c + 7 * a:]}
 
     def local_stage(self, dd_local, has_ego):
         import torch.nn.functional as F
@@ -194,7 +230,7 @@ def _cobevt_frame(compression):
     return args, sd, voxd
 
 
-def _cobevt_worker(rank, world, port, result_path, compression):
+def _cobevt_worker(rank, world, port, result_path, compression, two_level=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -203,17 +239,19 @@ def _cobevt_worker(rank, world, port, result_path, compression):
     mine = partition_agents(len(TYPES), world)[rank]
     dd_local = synth.build_data_dict([voxd[i] for i in mine], [TYPES[i] for i in mine])
     with torch.no_grad():
-        out = ShardedFrame(CoBEVTOracleBackend(sd, args)).forward(dd_local)
+        out = ShardedFrame(CoBEVTOracleBackend(sd, args, two_level)).forward(dd_local)
     if rank == 0:
         torch.save(out, result_path)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compression", [0, 4])
-def test_cobevt_agent_sharded_frame_equals_single_process(tmp_path, compression):
+@pytest.mark.parametrize("compression,two_level", [(0, False), (4, False), (0, True)])
+def test_cobevt_agent_sharded_frame_equals_single_process(tmp_path, compression, two_level):
+    """two_level: besides the agents, the FUSION is split over the ranks by residue-group columns (no exchange between the
+    window and grid halves of a block) and the head outputs are all-gathered."""
     from oracle import cobevt_oracle as cob
     path = str(tmp_path / "out.pt")
-    mp.spawn(_cobevt_worker, args=(2, _free_port(), path, compression), nprocs=2, join=True)
+    mp.spawn(_cobevt_worker, args=(2, _free_port(), path, compression, two_level), nprocs=2, join=True)
     got = torch.load(path)
     args, sd, voxd = _cobevt_frame(compression)
     dd = synth.build_data_dict(voxd, TYPES)
@@ -287,3 +325,27 @@ def test_single_rank_needs_no_process_group():
         out = ShardedFrame(OracleBackend(sd, args)).forward(dd)
         ref = orc.where2com_forward(dd, sd, args)
     assert torch.allclose(out["rm"], ref["rm"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("W,world", [(352, 8), (352, 2), (352, 5), (64, 3), (16, 4)])
+def test_fusion_column_shards_are_closed_under_both_partitions(W, world):
+    """Every rank's column set must contain whole 4-column windows AND whole grid groups {w2 * W/4 + y}: then the window
+    and the grid attention of every SwapFusion block stay inside the rank (no exchange), and the sets tile the map."""
+    from airv2x_perception_amd.opencood_iface.sharded import fusion_column_shards
+    ws, Y = 4, W // 4
+    shards = fusion_column_shards(W, ws, world)
+    seen = []
+    for cols, valid in shards:
+        assert len(cols) == len(shards[0][0]) and len(cols) % (ws * ws) == 0          # same shape on every rank
+        strip = len(cols) // ws
+        real = {c for k, c in enumerate(cols) if k % strip < valid}
+        for c in real:
+            assert all(ws * (c // ws) + j in real for j in range(ws))                 # its window's columns
+            assert all(w2 * Y + c % Y in real for w2 in range(ws))                    # its grid group's columns
+        # the compact map keeps both groupings: compact column k = w2' * strip + y' <-> original w2' * Y + y
+        for k, c in enumerate(cols):
+            assert c // Y == k // strip and (c % Y) % ws == (k % strip) % ws
+        seen += sorted(real)
+    assert sorted(seen) == list(range(W))
+    with pytest.raises(ValueError):
+        fusion_column_shards(100, 4, 2)

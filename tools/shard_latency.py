@@ -58,12 +58,31 @@ def main():
         tl += ev[0].elapsed_time(ev[1])
         te += e0.elapsed_time(e1)
     tl, te = tl / a.steps, te / a.steps
+    tp = None
+    if hasattr(eng, "shard_ego_partial"):      # second level: this rank's share of the fusion + the gather of the head outputs
+        send, stats, meta = eng.shard_local_stage(dd, has_ego=True)
+        recv = send.repeat(a.world)
+        for _ in range(2):
+            part, ctx = eng.shard_ego_partial(recv, stats, meta, a.world, 0)
+            eng.shard_ego_finish(part.repeat(a.world), ctx, a.world)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.steps):
+            part, ctx = eng.shard_ego_partial(recv, stats, meta, a.world, 0)
+            eng.shard_ego_finish(part.repeat(a.world), ctx, a.world)
+        e1.record()
+        torch.cuda.synchronize()
+        tp = e0.elapsed_time(e1) / a.steps
     mb = send.numel() * 4 / 1e6
     link = 153.0   # GB/s per xGMI link (guide); 7 peers write into each GPU over separate links
     comm = mb / 1e3 / link * 1e3
     print(f"{a.model}: world={a.world}  local stage (1 agent) {tl:.3f} ms | message {mb:.2f} MB per agent, all-gather >= {comm:.3f} ms at "
           f"{link:.0f} GB/s per link | ego stage ({a.world} agents) {te:.3f} ms | frame >= {tl + comm + te:.3f} ms -> <= {1e3 / (tl + comm + te):.1f} frames/s per "
           f"{a.world}-GPU group (strictly sequential frames; GPU time only)")
+    if tp is not None:
+        print(f"{a.model}: two-level (fusion split by residue-group columns): partial fusion + heads + finish {tp:.3f} ms instead of {te:.3f} ms "
+              f"-> frame >= {tl + comm + tp:.3f} ms -> <= {1e3 / (tl + comm + tp):.1f} frames/s per {a.world}-GPU group")
 
 
 if __name__ == "__main__":
