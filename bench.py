@@ -254,7 +254,7 @@ def main():
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
                    "parallelism": ("single GPU" if world == 1 else "independent frames per GPU (replicas)") if a.mode == "replica"
-                   else f"one frame, {a.agents // world} agent(s) per GPU, RCCL all-gather of masked multi-scale features",
+                   else f"one frame, {a.agents // world} agent(s) per GPU, RCCL all-gather of " + {"where2com": "the masked multi-scale features (15.8 MB per agent)", "cobevt": "the shrink-header maps (36 MB per agent), fusion split over the ranks by residue-group columns + a second all-gather of the head outputs", "v2xvit": "the shrink-header maps (36 MB per agent)", "when2com": "the warped maps + keys + the ego's query (36 MB per agent)"}[a.model],
                    "launch": "hipGraph replay" if eng.graph_active() else "eager",
                    "frames_in_flight": a.inflight if a.mode == "replica" else 1},
     }
