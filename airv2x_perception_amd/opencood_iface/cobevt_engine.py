@@ -244,7 +244,7 @@ class CoBEVTEngine(Where2ComEngine):
         return heads.view(-1), {"H": H, "W": W, "Wc": Wc, "shards": shards}
 
     @torch.no_grad()
-    def shard_ego_finish(self, parts, ctx, world):
+    def shard_ego_finish(self, parts, ctx, world, **_):
         H, W, Wc, shards = ctx["H"], ctx["W"], ctx["Wc"], ctx["shards"]
         nh = self.heads.cout
         per_rank = parts.view(world, nh, H, Wc)

@@ -49,13 +49,16 @@ class ShardedFrame:
             # xGMI is point-to-point, so the 7 peer transfers into each GPU run on separate links
             dist.all_gather_into_tensor(recv, send, group=self.group)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
-        if self.world > 1 and getattr(self.backend, "two_level", False):
+        if (self.world > 1 and getattr(self.backend, "two_level", False)
+                and getattr(self.backend, "can_split", lambda m, w: True)(meta, self.world)):
+            if hasattr(self.backend, "engine"):
+                self.backend.engine.shard_group = self.group
             # second level: every rank runs the fusion on ITS share of the map and the (small) head outputs are
             # gathered, instead of every rank repeating the whole fusion
             part, ctx = self.backend.ego_partial(recv, stats, meta, self.world, self.rank)
             parts = torch.empty(self.world * part.numel(), dtype=part.dtype, device=part.device)
             dist.all_gather_into_tensor(parts, part, group=self.group)
-            return self.backend.ego_finish(parts, ctx, self.world)
+            return self.backend.ego_finish(parts, ctx, self.world, **kw)
         return self.backend.ego_stage(recv, stats, meta, self.world, **kw)
 
 
@@ -75,11 +78,16 @@ class EngineBackend:
     def two_level(self):
         return hasattr(self.engine, "shard_ego_partial") and getattr(self.engine, "fusion_sharding", True)
 
+    def can_split(self, meta, world):
+        """V2X-ViT needs the map to split into equal strips of whole windows; CoBEVT pads, so it always can."""
+        fs = getattr(self.engine, "fusion_strip", None)
+        return fs is None or fs(meta["W"], world, 0) is not None
+
     def ego_partial(self, recv, stats, meta, world, rank):
         return self.engine.shard_ego_partial(recv, stats, meta, world, rank)
 
-    def ego_finish(self, parts, ctx, world):
-        return self.engine.shard_ego_finish(parts, ctx, world)
+    def ego_finish(self, parts, ctx, world, **kw):
+        return self.engine.shard_ego_finish(parts, ctx, world, **kw)
 
 
 def fusion_column_shards(W, window, world):

@@ -117,7 +117,16 @@ class V2XViTEngine(Where2ComEngine):
                 s = i
         return out
 
-    def encoder(self, x, n, H, W, prior, scm, trace=None):
+    # second level of the agent-sharded frame: the encoder blocks run on a column strip of the map (windows of 2 / 4 are
+    # aligned to 4 columns, everything else is per pixel) and the one global quantity -- the split-attention mean over
+    # the map -- is averaged over the ranks (``gap_exchange(gap, world, index)``, default: RCCL all-reduce)
+    fusion_sharding = True
+    gap_exchange = None
+    gap_record = None      # list -> the (m,1,1,C) split-attention means of a run are appended (tests)
+
+    def encoder(self, x, n, H, W, prior, scm, trace=None, strip=None):
+        """``strip`` = (first column, number of columns, world): after RTE / STTF / ROI mask on the full maps only these
+        columns go through the blocks (returns the (1,H,Wc,C) strip of the ego's fused map)."""
         C, hw, st = 256, H * W, self.stream
         types = [int(prior[i, 2]) for i in range(n)]                      # infra flag -> node type (hmsa.py:123-127)
         dts = [int(prior[i, 1]) for i in range(n)]
@@ -145,6 +154,14 @@ class V2XViTEngine(Where2ComEngine):
         if trace is not None:
             trace["after_sttf"] = x.clone()
             trace["com_mask"] = mask.clone()
+        world = 1
+        if strip is not None:
+            c0, Wc, world = strip
+            xs = self.buf("vit_x_strip", (n, H, Wc, C))
+            ms = self.buf("com_mask_strip", (n, H, Wc))
+            xs.copy_(x[:, :, c0:c0 + Wc])                                   # column strip (data movement only)
+            ms.copy_(mask[:, :, c0:c0 + Wc])
+            x, mask, W, hw = xs, ms, Wc, H * Wc
         tarr = (c_int32 * n)(*types)
         xn = self.buf("vit_xn", (n, H, W, C))
         proj = self.buf("vit_proj", (n, H, W, 1280))
@@ -190,6 +207,10 @@ class V2XViTEngine(Where2ComEngine):
                     self.conv(blk["wout"][i], wat, m, H, W, br[i])
                 _lib.check(self.lib.av2x_split_attn_gap(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(gap), _ptr(gap_scratch), m, hw, C,
                                                         st()), "gap")
+                if world > 1:       # equal strips: the global mean is the mean of the ranks' means
+                    (self.gap_exchange or self._gap_allreduce)(gap[:m], world, di * len(blocks) + bi)
+                if self.gap_record is not None:
+                    self.gap_record.append(gap[:m].clone())
                 self.conv(blk["fc1"], gap, m, 1, 1, g1)
                 self.ln(g1, blk["bn1"], g2, m, C, relu=1)
                 self.conv(blk["fc2"], g2, m, 1, 1, logits)
@@ -203,6 +224,13 @@ class V2XViTEngine(Where2ComEngine):
             if trace is not None:
                 trace[f"layer{di}"] = x.clone()
         return x[0:1]
+
+    shard_group = None
+
+    def _gap_allreduce(self, gap, world, index):
+        import torch.distributed as dist
+        dist.all_reduce(gap, op=dist.ReduceOp.SUM, group=self.shard_group)
+        gap.mul_(1.0 / world)
 
     @torch.no_grad()
     def shard_local_stage(self, data_dict_local, has_ego):
@@ -246,6 +274,47 @@ class V2XViTEngine(Where2ComEngine):
         if self.args["obj_head"]:
             out["obj"] = outs[2]
         out["comm_rate"] = int(stats[1].item()) if sync_comm_rate else stats[1]
+        return out
+
+    def fusion_strip(self, W, world, rank):
+        """Equal column strips aligned to the 4-column windows, or None when the map does not split evenly."""
+        if world <= 1 or W % (4 * world):
+            return None
+        Wc = W // world
+        return (rank * Wc, Wc, world)
+
+    @torch.no_grad()
+    def shard_ego_partial(self, recv, stats, meta, world, rank, fusion_world=None, fusion_rank=None):
+        """This rank's column strip of the fusion (one tiny all-reduce per block for the split-attention mean) + heads.
+        ``fusion_world`` / ``fusion_rank`` default to the agent-sharding world / rank (tests split differently)."""
+        n_loc, H, Wd = meta["n_loc"], meta["H"], meta["W"]
+        N = world * n_loc
+        if recv.numel() != N * H * Wd * 256:
+            raise ValueError("gathered buffer has the wrong size")
+        if N > self.L:
+            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        fw, fr = (world, rank) if fusion_world is None else (fusion_world, fusion_rank)
+        strip = self.fusion_strip(Wd, fw, fr)
+        if strip is None:
+            raise ValueError(f"map width {Wd} does not split into {fw} strips of whole windows")
+        fused = self.encoder(recv.view(N, H, Wd, 256), N, H, Wd, meta["prior"], meta["scm"], strip=strip)
+        Wc = strip[1]
+        heads = torch.empty((1, self.heads.cout, H, Wc), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, 1, H, Wc, heads)
+        return heads.view(-1), {"H": H, "W": Wd, "Wc": Wc, "stats": stats}
+
+    @torch.no_grad()
+    def shard_ego_finish(self, parts, ctx, world, sync_comm_rate=False):
+        H, W, Wc = ctx["H"], ctx["W"], ctx["Wc"]
+        nh = self.heads.cout
+        full = torch.empty((1, nh, H, W), dtype=torch.float32, device=self.device)
+        full.view(nh, H, world, Wc).copy_(parts.view(world, nh, H, Wc).permute(1, 2, 0, 3))     # strips side by side
+        outs = torch.split(full, self.head_splits, dim=1)
+        out = {"psm": outs[0], "rm": outs[1]}
+        if self.args["obj_head"]:
+            out["obj"] = outs[2]
+        st = ctx["stats"]
+        out["comm_rate"] = int(st[1].item()) if sync_comm_rate else st[1]
         return out
 
     @torch.no_grad()

@@ -157,27 +157,31 @@ def window_attention(x, sd, p, heads, dim_head, ws):
     return F.linear(out, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
 
 
-def split_attn(windows, sd, p):
-    """SplitAttn.forward split_attn.py:40-63 (radix 3, cardinality 1)."""
+def split_attn(windows, sd, p, gap_reduce=None):
+    """SplitAttn.forward split_attn.py:40-63 (radix 3, cardinality 1).  ``gap_reduce`` (tests of the column-sharded
+    fusion): maps the local mean over this strip of the map to the mean over the whole map."""
     sw, mw, bw = windows
     B, L, _, _, C = sw.shape
     gap = (sw + mw + bw).mean((2, 3), keepdim=True)
+    if gap_reduce is not None:
+        gap = gap_reduce(gap)
     g = F.relu(_ln(F.linear(gap, sd[p + ".fc1.weight"]), sd, p + ".bn1"))
     a = F.linear(g, sd[p + ".fc2.weight"])
     a = F.softmax(a.view(B, L, 1, 3, -1), dim=3).reshape(B, -1).view(B, L, 1, 1, -1)
     return sw * a[..., 0:C] + mw * a[..., C:2 * C] + bw * a[..., 2 * C:]
 
 
-def pyramid_window_attention(x, sd, p, cfg):
+def pyramid_window_attention(x, sd, p, cfg, gap_reduce=None):
     outs = [window_attention(x, sd, f"{p}.pwmsa.{i}", h, d, w)
             for i, (h, d, w) in enumerate(zip(cfg["heads"], cfg["dim_head"], cfg["window_size"]))]
     if cfg["fusion_method"] == "split_attn":
-        return split_attn(outs, sd, p + ".split_attn")
+        return split_attn(outs, sd, p + ".split_attn", gap_reduce)
     return sum(outs) / len(outs)
 
 
-def encoder(x, mask, scm, sd, enc, trace=None):
-    """V2XTEncoder.forward v2xvit_basic.py:174-200 + V2XTransformer :210-213.  x (B,L,H,W,C+3)."""
+def encoder(x, mask, scm, sd, enc, trace=None, strip=None, gap_reduce=None):
+    """V2XTEncoder.forward v2xvit_basic.py:174-200 + V2XTransformer :210-213.  x (B,L,H,W,C+3).
+    ``strip`` = (first column, columns) + ``gap_reduce``: the blocks run on a column strip only (sharded-fusion tests)."""
     p = "fusion_net.encoder"
     cav, pw = enc["cav_att_config"], enc["pwindow_att_config"]
     prior = x[..., -3:]
@@ -193,13 +197,18 @@ def encoder(x, mask, scm, sd, enc, trace=None):
     if trace is not None:
         trace["com_mask"] = com_mask
     types = prior[:, :, 0, 0, 2].to(torch.int)
+    if strip is not None:
+        c0, wc = strip
+        x = x[:, :, :, c0:c0 + wc]
+        if com_mask.dim() == 5 and com_mask.shape[2] > 1:
+            com_mask = com_mask[:, :, c0:c0 + wc]
     for d in range(enc["depth"]):
         for nb in range(enc["num_blocks"]):
             q = f"{p}.layers.{d}.0.layers.{nb}"
             x = hgt_attention(_ln(x, sd, q + ".0.norm"), com_mask, types, sd, q + ".0.fn", cav["heads"], cav["dim_head"]) + x
             if trace is not None:
                 trace[f"hgt{d}"] = x
-            x = pyramid_window_attention(_ln(x, sd, q + ".1.norm"), sd, q + ".1.fn", pw) + x
+            x = pyramid_window_attention(_ln(x, sd, q + ".1.norm"), sd, q + ".1.fn", pw, gap_reduce) + x
         f = f"{p}.layers.{d}.1"
         h = F.gelu(F.linear(_ln(x, sd, f + ".norm"), sd[f + ".fn.net.0.weight"], sd[f + ".fn.net.0.bias"]))
         x = F.linear(h, sd[f + ".fn.net.3.weight"], sd[f + ".fn.net.3.bias"]) + x

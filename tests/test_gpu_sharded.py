@@ -112,6 +112,35 @@ def test_v2xvit_emulated_ranks_equal_single_gpu_forward():
     for k in ("psm", "rm", "obj"):
         assert torch.equal(out[k], ref[k]), k
     assert out["comm_rate"] == ref["comm_rate"]
+    # second level: 2 "ranks", each runs the encoder blocks on half of the columns; the only cross-rank quantity is the
+    # split-attention mean of every block.  The emulation feeds each rank the global means recorded from a full run (what
+    # the all-reduce would deliver) and checks separately that the ranks' local means average to them.
+    recv = torch.cat(sends)
+    eng.gap_record = []
+    eng.shard_ego_stage(recv.clone(), stats, meta, world=world)
+    global_gaps, eng.gap_record = eng.gap_record, None
+    local_gaps = {}
+
+    def exchange(gap, w, idx):
+        local_gaps.setdefault(idx, []).append(gap.clone())
+        gap.copy_(global_gaps[idx])
+    eng.gap_exchange = exchange
+    parts, ctx = [], None
+    try:
+        for r in range(2):
+            part, ctx = eng.shard_ego_partial(recv.clone(), stats, meta, world, r, fusion_world=2, fusion_rank=r)
+            parts.append(part.clone())
+    finally:
+        eng.gap_exchange = None
+    out2 = eng.shard_ego_finish(torch.cat(parts), ctx, 2, sync_comm_rate=True)
+    for k in ("psm", "rm", "obj"):
+        assert torch.equal(out2[k], ref[k]), ("two-level", k)
+    assert out2["comm_rate"] == ref["comm_rate"]
+    assert len(global_gaps) == 3 and sorted(local_gaps) == [0, 1, 2]
+    for idx, g in enumerate(global_gaps):     # mean of the two strips' means = the global mean (equal strips)
+        both = local_gaps[idx]
+        assert len(both) == 2 and both[0].shape == g.shape
+        torch.testing.assert_close((both[0] + both[1]) / 2, g, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("which", ["where2com", "cobevt", "v2xvit", "when2com"])

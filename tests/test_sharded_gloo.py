@@ -222,6 +222,111 @@ def test_when2com_agent_sharded_frame_equals_single_process(tmp_path):
     assert got["comm_rate"] == ref["comm_rate"]
 
 
+class V2XViTOracleBackend:
+    """V2X-ViT: the message is the shrink-header map; second level = column strips of the encoder blocks with ONE
+    all-reduce per block (the split-attention mean over the map), then a gather of the head outputs."""
+
+    def __init__(self, sd, args, two_level=False):
+        self.sd, self.args, self.two_level = sd, args, two_level
+
+    def local_stage(self, dd_local, has_ego):
+        sd, args = self.sd, self.args
+        mf = args["modality_fusion"]
+        feats, _ = orc.extract_features(dd_local, sd, args)
+        sf2d, _ = orc.backbone_forward(feats, sd, mf["base_bev_backbone"])
+        s = orc.shrink_conv(sf2d, sd, mf["shrink_header"])
+        meta = {"shape": tuple(s.shape), "prior": dd_local["prior_encoding"], "scm": dd_local["spatial_correction_matrix"]}
+        return s.reshape(-1), torch.tensor([0, int(feats.count_nonzero())], dtype=torch.int64), meta
+
+    def _tokens(self, recv, meta, world):
+        from oracle import cobevt_oracle as cob
+        n_loc, c, h, w = meta["shape"]
+        s = recv.view(world * n_loc, c, h, w)
+        x, mask = cob.regroup(s, torch.tensor([s.shape[0]]), self.args["max_cav_num"])
+        prior = meta["prior"].unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, h, w)
+        return torch.cat([x, prior], dim=2).permute(0, 1, 3, 4, 2).contiguous(), mask
+
+    def _heads(self, fused):
+        fused = fused.permute(0, 3, 1, 2).contiguous()
+        return torch.cat([orc.head(fused, self.sd, n) for n in ("cls_head", "reg_head", "obj_head")], 1)
+
+    def _split(self, heads, stats):
+        a = self.args["anchor_number"]
+        c = a * self.args["num_class"]
+        return {"psm": heads[:, :c], "rm": heads[:, c:c + 7 * a], "obj": heads[:, c + 7 * a:], "comm_rate": int(stats[1])}
+
+    def ego_stage(self, recv, stats, meta, world):
+        from oracle import v2xvit_oracle as vit
+        x, mask = self._tokens(recv, meta, world)
+        return self._split(self._heads(vit.encoder(x, mask, meta["scm"], self.sd, self.args["transformer"]["encoder"])), stats)
+
+    def can_split(self, meta, world):
+        return meta["shape"][-1] % (4 * world) == 0
+
+    def ego_partial(self, recv, stats, meta, world, rank):
+        from oracle import v2xvit_oracle as vit
+        x, mask = self._tokens(recv, meta, world)
+        wc = meta["shape"][-1] // world
+
+        def gap_reduce(gap):
+            g = gap.clone()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            return g / world
+        fused = vit.encoder(x, mask, meta["scm"], self.sd, self.args["transformer"]["encoder"], strip=(rank * wc, wc),
+                            gap_reduce=gap_reduce)
+        heads = self._heads(fused)
+        return heads.reshape(-1).contiguous(), {"shape": tuple(heads.shape), "stats": stats}
+
+    def ego_finish(self, parts, ctx, world):
+        nb, nh, H, wc = ctx["shape"]
+        full = parts.view(world, nb, nh, H, wc).permute(1, 2, 3, 0, 4).reshape(nb, nh, H, world * wc)
+        return self._split(full, ctx["stats"])
+
+
+def _v2xvit_frame():
+    hy = synth.default_hypes_v2xvit(RNG)
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(synth.v2xvit_param_spec(args), seed=5)
+    _, _, voxd = _frame()
+    dd = synth.build_data_dict(voxd, TYPES, max_cav_num=args["max_cav_num"])
+    scm = torch.eye(4, dtype=torch.float64).repeat(1, args["max_cav_num"], 1, 1)
+    for i in range(1, len(TYPES)):
+        scm[0, i] = torch.from_numpy(synth.se2_correction(2.0 * i, 0.6 * i, -0.3 * i))
+    dd["spatial_correction_matrix"] = scm
+    return args, sd, voxd, dd
+
+
+def _v2xvit_worker(rank, world, port, result_path, two_level):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    args, sd, voxd, dd = _v2xvit_frame()
+    mine = partition_agents(len(TYPES), world)[rank]
+    dd_local = synth.build_data_dict([voxd[i] for i in mine], [TYPES[i] for i in mine], max_cav_num=args["max_cav_num"])
+    for k in ("prior_encoding", "spatial_correction_matrix"):      # frame-level metadata of all agents
+        dd_local[k] = dd[k]
+    with torch.no_grad():
+        out = ShardedFrame(V2XViTOracleBackend(sd, args, two_level)).forward(dd_local)
+    if rank == 0:
+        torch.save(out, result_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("two_level", [False, True])
+def test_v2xvit_agent_sharded_frame_equals_single_process(tmp_path, two_level):
+    from oracle import v2xvit_oracle as vit
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_v2xvit_worker, args=(2, _free_port(), path, two_level), nprocs=2, join=True)
+    got = torch.load(path)
+    args, sd, voxd, dd = _v2xvit_frame()
+    with torch.no_grad():
+        ref = vit.v2xvit_forward(dd, sd, args)
+    for k in ("psm", "rm", "obj"):
+        assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), k
+    assert got["comm_rate"] == ref["comm_rate"]
+
+
 def _cobevt_frame(compression):
     hy = synth.default_hypes_cobevt(RNG, compression=compression)
     args = hy["model"]["args"]

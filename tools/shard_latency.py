@@ -60,6 +60,8 @@ def main():
     tl, te = tl / a.steps, te / a.steps
     tp = None
     if hasattr(eng, "shard_ego_partial"):      # second level: this rank's share of the fusion + the gather of the head outputs
+        if hasattr(eng, "gap_exchange"):       # V2X-ViT: the per-block (n, C) all-reduce is not run here (1-GPU box)
+            eng.gap_exchange = lambda g, w, i: None
         send, stats, meta = eng.shard_local_stage(dd, has_ego=True)
         recv = send.repeat(a.world)
         for _ in range(2):
@@ -81,7 +83,7 @@ def main():
           f"{link:.0f} GB/s per link | ego stage ({a.world} agents) {te:.3f} ms | frame >= {tl + comm + te:.3f} ms -> <= {1e3 / (tl + comm + te):.1f} frames/s per "
           f"{a.world}-GPU group (strictly sequential frames; GPU time only)")
     if tp is not None:
-        print(f"{a.model}: two-level (fusion split by residue-group columns): partial fusion + heads + finish {tp:.3f} ms instead of {te:.3f} ms "
+        print(f"{a.model}: two-level (fusion split over the ranks by columns): partial fusion + heads + finish {tp:.3f} ms instead of {te:.3f} ms "
               f"-> frame >= {tl + comm + tp:.3f} ms -> <= {1e3 / (tl + comm + tp):.1f} frames/s per {a.world}-GPU group")
 
 
