@@ -258,7 +258,7 @@ def main():
                    "launch": "hipGraph replay" if eng.graph_active() else "eager",
                    "frames_in_flight": a.inflight if a.mode == "replica" else 1},
     }
-    if a.mode == "replica" and a.inflight > 1 and rank == 0:
+    if a.mode == "replica" and a.inflight > 1 and rank == 0 and world == 1:   # secondary figures: single-GPU runs only
         # latency mode for reference: strictly one frame at a time on one stream
         for _ in range(2):
             model(dd)
@@ -272,7 +272,7 @@ def main():
                                 "note": "one frame at a time (no overlap between frames)"}
 
     # ---------------- the same frames with the split-3 GEMM (fp32-accurate, bf16 matrix cores): reported beside the headline
-    if rank == 0 and a.mode == "replica" and a.model == "where2com" and a.gemm == "f32" and not a.amp and a.inflight > 1:
+    if rank == 0 and world == 1 and a.mode == "replica" and a.model == "where2com" and a.gemm == "f32" and not a.amp and a.inflight > 1:
         for e in pipe.engines:
             e.split3 = True
         out3 = model(dd)  # tunes the split-3 tiles
@@ -298,7 +298,7 @@ def main():
         split3_out = None
 
     # ---------------- second figure: frame + on-device post-process (decode, filters, rotated NMS) ----------
-    if rank == 0 and a.mode == "replica" and a.model == "where2com":
+    if rank == 0 and world == 1 and a.mode == "replica" and a.model == "where2com":
         from airv2x_perception_amd.opencood_iface.voxel_postprocessor import VoxelPostprocessor
         post = VoxelPostprocessor(hy["postprocess"], dataset="airv2x", train=False)
         anchors = torch.from_numpy(post.generate_anchor_box())
