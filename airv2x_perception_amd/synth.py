@@ -321,7 +321,7 @@ def synthetic_tensor(key, shape, kind, seed=0):
 def synthetic_state_dict(spec, seed=0):
     sd = OrderedDict()
     for key, shape, kind in spec:
-        sd[key] = torch.from_numpy(np.ascontiguousarray(synthetic_tensor(key, shape, kind, seed)))
+        sd[key] = torch.from_numpy(np.ascontiguousarray(synthetic_tensor(key, shape, kind, seed))).reshape(tuple(shape))
     return sd
 
 
