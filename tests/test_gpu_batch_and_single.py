@@ -1,0 +1,78 @@
+"""GPU: for CoBEVT, V2X-ViT and When2com -- (i) a batch of two frames (the reference's collate layout, synth.merge_frames)
+gives exactly the two single-frame results, (ii) a frame with the ego alone runs and matches the CPU oracle."""
+import pytest
+import torch
+
+from airv2x_perception_amd import synth
+from oracle import voxelize_oracle as vox
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+RNG = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0]
+
+
+def _setup(which):
+    from airv2x_perception_amd import opencood_iface as oi
+    if which == "cobevt":
+        from oracle import cobevt_oracle as o
+        hy = synth.default_hypes_cobevt(RNG); spec = synth.cobevt_param_spec; M, fwd = oi.Airv2xCoBEVT, o.cobevt_forward
+    elif which == "v2xvit":
+        from oracle import v2xvit_oracle as o
+        hy = synth.default_hypes_v2xvit(RNG); spec = synth.v2xvit_param_spec; M, fwd = oi.Airv2xV2XVit, o.v2xvit_forward
+    else:
+        from oracle import when2com_oracle as o
+        hy = synth.default_hypes_when2com(RNG); spec = synth.when2com_param_spec; M, fwd = oi.Airv2xWhen2com, o.when2com_forward
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(spec(args), seed=2)
+    model = M(args)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    model.engine().stream_k = False
+    return hy, args, sd, model, fwd
+
+
+def _frame(args, types, first_cloud=0, which=""):
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(first_cloud + i, 900, RNG), RNG), RNG, [0.4, 0.4, 4.0])
+            for i in range(len(types))]
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    if which == "when2com":
+        dd["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(len(types), args["max_cav_num"])
+    if which == "v2xvit":
+        scm = torch.eye(4, dtype=torch.float64).repeat(1, args["max_cav_num"], 1, 1)
+        for i in range(1, len(types)):
+            scm[0, i] = torch.from_numpy(synth.se2_correction(2.0 * i + first_cloud, 0.5 * i, -0.3 * i))
+        dd["spatial_correction_matrix"] = scm
+    return dd
+
+
+@pytest.mark.parametrize("which", ["cobevt", "v2xvit", "when2com"])
+def test_batch_of_two_frames_equals_two_single_frames(which):
+    hy, args, sd, model, _ = _setup(which)
+    a = _frame(args, ["vehicle", "rsu", "drone"], 0, which)
+    b = _frame(args, ["vehicle", "drone"], 5, which)
+    both = synth.merge_frames([a, b])
+    assert both["record_len"].tolist() == [3, 2]
+    eng = model.engine()
+    keep = lambda o: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}
+    oa, ob = keep(eng.forward(a, sync_comm_rate=True)), keep(eng.forward(b, sync_comm_rate=True))
+    o2 = eng.forward(both, sync_comm_rate=True)
+    for k in ("psm", "rm", "obj"):
+        assert o2[k].shape[0] == 2
+        assert torch.equal(o2[k][0:1], oa[k]) and torch.equal(o2[k][1:2], ob[k]), (which, k)
+    if which == "v2xvit":
+        assert o2["comm_rate"] == oa["comm_rate"] + ob["comm_rate"]                 # count over the whole batch (:122)
+    if which == "when2com":
+        assert o2["comm_rate"] == (oa["comm_rate"] + ob["comm_rate"]) / 2            # np.sum(counts) / B (:132)
+
+
+@pytest.mark.parametrize("which", ["cobevt", "v2xvit", "when2com"])
+def test_ego_alone(which):
+    hy, args, sd, model, fwd = _setup(which)
+    dd = _frame(args, ["vehicle"], 0, which)
+    out = model(dd)
+    with torch.no_grad():
+        ref = fwd(dd, sd, args)
+    for k in ("psm", "rm", "obj"):
+        assert_close(out[k].cpu(), ref[k], 3e-4, 3e-4, f"{which} {k}")
+    if "comm_rate" in ref:
+        assert float(out["comm_rate"]) == float(ref["comm_rate"])
