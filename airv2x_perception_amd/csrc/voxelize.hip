@@ -9,7 +9,7 @@
 // by an in-cell rank count restores input order exactly, so the result is bit-reproducible.
 //
 //   k_cell   per point : cell id, cnt[cell]++, first[cell] = min(index)
-//   k_scan   1 workgroup: exclusive scan (a) over "is first point of its cell" flags in point
+//   k_scan   1 workgroup, one pass: exclusive scans (a) over "is first point of its cell" flags in point
 //            order -> voxel rank + M, (b) over cnt of the first points, same order -> list offsets
 //   k_fill   per point : unordered append of the point index to its cell's list
 //   k_emit   per point : pos = #{j in list : j < i}; write voxels / coords / num_points
@@ -79,19 +79,23 @@ __global__ void k_cell(const float4* __restrict__ pts, int n, VoxGeom g, PrepInl
 __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cell, int n, const int* __restrict__ cnt,
                                                const int* __restrict__ first, int ncell, int* __restrict__ vrank,
                                                int* __restrict__ offs, int* __restrict__ m_out, int max_voxels) {
-    __shared__ int tot;
-    // (a) voxel rank = number of earlier "first points"
-    av2x::block_scan(
-        n, [&](int i) { const int c = cell[i]; return (c >= 0 && first[c] == i) ? 1 : 0; },
-        [&](int i, int ex) { const int c = cell[i]; if (c >= 0 && first[c] == i) vrank[c] = ex; }, &tot);
+    __shared__ int tot, tot_b;
+    // one pass, two scans over the points in input order: (a) voxel rank = number of earlier "first points" (-> M),
+    // (b) list offset = points of the cells that appeared earlier (a scan over the points, not over the 140 800 grid
+    // cells: only occupied cells need a list)
+    av2x::block_scan_pair(
+        n,
+        [&](int i, int* a, int* b) {
+            const int c = cell[i];
+            if (c >= 0 && first[c] == i) { *a = 1; *b = cnt[c]; }
+        },
+        [&](int i, int ea, int eb) {
+            const int c = cell[i];
+            if (c >= 0 && first[c] == i) { vrank[c] = ea; offs[c] = eb; }
+        },
+        &tot, &tot_b);
     __syncthreads();
     if (threadIdx.x == 0) m_out[0] = tot < max_voxels ? tot : max_voxels;
-    __syncthreads();
-    // (b) list offsets, cells taken in order of first appearance (a scan over the points, not over the
-    //     140 800 grid cells: only occupied cells need a list)
-    av2x::block_scan(
-        n, [&](int i) { const int c = cell[i]; return (c >= 0 && first[c] == i) ? cnt[c] : 0; },
-        [&](int i, int ex) { const int c = cell[i]; if (c >= 0 && first[c] == i) offs[c] = ex; }, &tot);
 }
 
 __global__ void k_fill(const int* __restrict__ cell, int n, const int* __restrict__ offs, int* __restrict__ fill,
