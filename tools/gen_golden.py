@@ -4,7 +4,8 @@ container only: /root/reference) on seeded synthetic inputs.
 
 Nothing of the reference travels: only inputs (seeds / small point sets) and its
 numerical outputs are written to tests/golden/*.npz.  Re-run with
-    python tools/gen_golden.py
+    python tools/gen_golden.py            # everything; or one group:
+    python tools/gen_golden.py cobevt | cobevt_c4 | v2xvit | full | when2com | when2com_full | submodules | points | eval
 The reference is imported unmodified after registering stub modules for
 third-party packages this image lacks (cv2, efficientnet_pytorch, shapely,
 pyquaternion) and for the camera encoder module (not on the LiDAR path).
@@ -738,6 +739,11 @@ def main():
     eval_golden()
     points_golden()
     full_grid_transformers()
+    small = [-25.6, -12.8, -3, 25.6, 12.8, 1]
+    run_when2com_case("when2com_small_n3", small, ["vehicle", "rsu", "drone"], 1500, 5)
+    run_when2com_case("when2com_small_n2", small, ["vehicle", "vehicle"], 1500, 6)
+    run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16)
+    submodules_golden()
 
 
 def full_grid_transformers():
