@@ -209,28 +209,67 @@ __global__ void pp_iou_mask(const float* __restrict__ corners, const int* __rest
     if ((threadIdx.x & 63) == 0 && (j >> 6) < words) mask[(size_t)i * words + (j >> 6)] = bal;
 }
 
-// Greedy suppression over the precomputed bit matrix: box i is picked iff no earlier pick overlaps it; a pick ORs
-// its row into `removed`.  Inherently sequential -> ONE wave; `removed` lives in registers (lane w holds word w,
-// words <= 64), the alive test is a v_readlane of the (uniform) word i>>6, rows come from LDS when they fit.
-__global__ __launch_bounds__(64) void pp_greedy(const unsigned long long* __restrict__ mask, const int* __restrict__ ntop,
-                                                int words, int staged, int* __restrict__ pick, int* __restrict__ npick) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];  // [m][words] when it fits (staged)
+// Greedy suppression over the precomputed bit matrix: box i is picked iff no earlier pick overlaps it; a pick ORs its row
+// into `removed`.  Inherently sequential, so ONE wave walks the boxes -- but in blocks of 64 so that the serial chain never
+// touches memory: lane j loads the DIAGONAL word of box 64b+j (its overlaps inside the block), the block is resolved by a
+// scalar loop over the surviving boxes (v_readlane of the diagonal word + bit ops, ~20 cycles per pick), the picks of the
+// block are written in order by their own lanes (rank = popcount of the kept bits below), and only then the full rows of
+// the kept boxes are ORed into `removed` (lane w holds word w) with independent, pipelined reads.  Identical to the
+// box-by-box walk: inside a block the order is preserved, across blocks `removed` is complete before the next block starts.
+// Rows come from LDS when they fit (STAGED; copied in by the whole 1024-thread workgroup).
+template <bool STAGED>
+__global__ __launch_bounds__(1024) void pp_greedy(const unsigned long long* __restrict__ mask, const int* __restrict__ ntop,
+                                                  int words, int* __restrict__ pick, int* __restrict__ npick) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];  // [m][words] when STAGED
     const int m = ntop[0];
     const int lane = threadIdx.x;
-    if (staged) {
-        for (int i = lane; i < m * words; i += 64) rows[i] = mask[i];
+    if (STAGED) {
+        const int total = m * words;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 4 * (int)blockDim.x) {       // four loads in flight per thread
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (i0 + u * (int)blockDim.x) < total ? mask[i0 + u * (int)blockDim.x] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((i0 + u * (int)blockDim.x) < total) rows[i0 + u * (int)blockDim.x] = v[u];
+        }
         __syncthreads();
     }
+    if (threadIdx.x >= 64) return;
+    auto word_of = [&](int box, int w) -> unsigned long long {
+        return STAGED ? rows[(size_t)box * words + w] : mask[(size_t)box * words + w];
+    };
+    auto lane64 = [&](unsigned long long v, int l) -> unsigned long long {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+        return ((unsigned long long)hi << 32) | lo;
+    };
     unsigned long long removed = 0ull;   // word `lane` of the removed set
     int np = 0;
-    for (int i = 0; i < m; ++i) {
-        const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, i >> 6);
-        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), i >> 6);
-        const unsigned long long wrd = ((unsigned long long)hi << 32) | lo;
-        if (!((wrd >> (i & 63)) & 1ull)) {       // uniform branch
-            if (lane == 0) pick[np] = i;
-            ++np;
-            if (lane < words) removed |= staged ? rows[(size_t)i * words + lane] : mask[(size_t)i * words + lane];
+    for (int b = 0; b * 64 < m; ++b) {
+        const int base = b * 64;
+        const int cnt = m - base < 64 ? m - base : 64;
+        const unsigned long long diag = (lane < cnt) ? word_of(base + lane, b) : 0ull;
+        unsigned long long alive = ~lane64(removed, b);                     // uniform from here on
+        if (cnt < 64) alive &= (1ull << cnt) - 1ull;
+        unsigned long long kept = 0ull;
+        while (alive) {
+            const int j = __builtin_ctzll(alive);
+            const unsigned long long bit = 1ull << j;
+            kept |= bit;
+            alive &= ~(lane64(diag, j) | bit);
+        }
+        if (lane < cnt && ((kept >> lane) & 1ull)) pick[np + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = base + lane;
+        np += __builtin_popcountll(kept);
+        if (lane < words) {
+            unsigned long long k = kept;
+            while (k) {                                   // four independent reads in flight per trip
+                unsigned long long acc[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k) { acc[u] = word_of(base + __builtin_ctzll(k), lane); k &= k - 1ull; }
+                removed |= (acc[0] | acc[1]) | (acc[2] | acc[3]);
+            }
         }
     }
     if (lane == 0) npick[0] = np;
@@ -393,8 +432,9 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
                        words, mask);
     const size_t lds = (size_t)top * words * 8 <= 128 * 1024 ? (size_t)top * words * 8 : 0;
     static av2x::LdsLimit lds_limit;
-    lds_limit.ensure(reinterpret_cast<const void*>(&pp_greedy), 128 * 1024);
-    hipLaunchKernelGGL(pp_greedy, dim3(1), dim3(64), lds, st, mask, ntop, words, lds > 0 ? 1 : 0, pick, npick);
+    lds_limit.ensure(reinterpret_cast<const void*>(&pp_greedy<true>), 128 * 1024);
+    if (lds > 0) hipLaunchKernelGGL(pp_greedy<true>, dim3(1), dim3(1024), lds, st, mask, ntop, words, pick, npick);
+    else hipLaunchKernelGGL(pp_greedy<false>, dim3(1), dim3(1024), 0, st, mask, ntop, words, pick, npick);
     hipLaunchKernelGGL(pp_final, dim3(1), dim3(1024), 0, st, boxes, corners, cscore, label, kept, order, pick, npick, p, inr,
                        out_corners, out_scores, out_labels, out_boxes, out_index, cand, nout);
     return av2x::check_launch("av2x_postprocess");
