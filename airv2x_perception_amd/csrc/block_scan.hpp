@@ -7,10 +7,11 @@ namespace av2x {
 
 // exclusive scan of `n` ints produced by functor f(i), single workgroup of 1024 threads.
 // Every thread owns ITEMS consecutive elements per pass (in-thread prefix, then a wave scan of the
-// thread totals, then the 16 wave totals), so one pass covers 4096 elements with two barriers.
-template <class F, class G>
+// thread totals, then the 16 wave totals), so one pass covers 1024 * ITEMS elements with two barriers
+// (ITEMS = 4 by default; 16 for the 70 400-anchor compaction of the post-processor).
+template <int ITEMS = 4, class F, class G>
 __device__ inline void block_scan(int n, F f, G store, int* total) {
-    constexpr int ITEMS = 4, PASS = 1024 * ITEMS;
+    constexpr int PASS = 1024 * ITEMS;
     __shared__ int wsum[16];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;

@@ -3,7 +3,7 @@
 // and box_utils.nms_rotated (utils/box_utils.py:823-868):
 //
 //   pp_flag      per anchor : objectness = sigmoid(obj), flag = objectness > obj_threshold
-//   pp_scan      1 workgroup: order-preserving compaction of flagged anchors (masked_select order)
+//   pp_compact   order-preserving compaction of flagged anchors (masked_select order) over the whole grid
 //   pp_decode    per candidate: class label, delta->box (delta_to_boxes3d :585-634), 8 corners
 //                (boxes_to_corners_3d), projection by T, size / z-range keep flag
 //   pp_scan2     compaction of kept candidates
@@ -28,22 +28,47 @@ struct PPParams {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ void pp_flag(const float* __restrict__ obj, PPParams p, float* __restrict__ score, int* __restrict__ flag) {
+// 256 threads per workgroup; also counts the flags of the workgroup (wg_count) for the order-preserving compaction
+__global__ __launch_bounds__(256) void pp_flag(const float* __restrict__ obj, PPParams p, float* __restrict__ score,
+                                               int* __restrict__ flag, int* __restrict__ wg_count) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int NA = p.H * p.W * p.A;
-    if (n >= NA) return;
-    const int a = n % p.A, hw = n / p.A;
-    const float s = sigmoidf(obj[(size_t)a * p.H * p.W + hw]);  // obj is (1,A,H,W); n = (h*W+w)*A + a
-    score[n] = s;
-    flag[n] = s > p.obj_thr;
+    bool f = false;
+    if (n < NA) {
+        const int a = n % p.A, hw = n / p.A;
+        const float s = sigmoidf(obj[(size_t)a * p.H * p.W + hw]);  // obj is (1,A,H,W); n = (h*W+w)*A + a
+        score[n] = s;
+        f = s > p.obj_thr;
+        flag[n] = f;
+    }
+    __shared__ int wc[4];
+    const unsigned long long bal = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-__global__ __launch_bounds__(1024) void pp_scan(const int* __restrict__ flag, int n, int* __restrict__ idx_out,
-                                                int* __restrict__ count) {
-    __shared__ int tot;
-    av2x::block_scan(n, [&](int i) { return flag[i]; }, [&](int i, int ex) { if (flag[i]) idx_out[ex] = i; }, &tot);
+// Order-preserving compaction of the flagged anchors over the whole grid: a workgroup's offset is the sum of the counts of
+// the workgroups before it (<= a few hundred ints, summed by the workgroup itself), positions inside come from ballots.
+__global__ __launch_bounds__(256) void pp_compact(const int* __restrict__ flag, int n, const int* __restrict__ wg_count,
+                                                  int* __restrict__ idx_out, int* __restrict__ count) {
+    __shared__ int part[4], wc[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int s = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) s += wg_count[b];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) part[wave] = s;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && flag[i] != 0;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wc[wave] = __popcll(bal);
     __syncthreads();
-    if (threadIdx.x == 0) count[0] = tot;
+    int off = part[0] + part[1] + part[2] + part[3];
+    for (int k = 0; k < wave; ++k) off += wc[k];
+    if (f) idx_out[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        count[0] = part[0] + part[1] + part[2] + part[3] + wc[0] + wc[1] + wc[2] + wc[3];
 }
 
 __global__ void pp_decode(const float* __restrict__ psm, const float* __restrict__ rm, const float* __restrict__ anchors,
@@ -169,7 +194,20 @@ __device__ double poly_area(const P2* p, int n) {
     return 0.5 * a;
 }
 
+// Exact early-out: quads whose axis-aligned bounding boxes are strictly separated cannot intersect (IoU = 0); the
+// comparison is on the fp32 corners themselves, so it never changes a result.  Most of the K^2 pairs of a frame end here.
+__device__ __forceinline__ bool quads_separated(const float* ca, const float* cb) {
+    float ax0 = ca[0], ax1 = ca[0], ay0 = ca[1], ay1 = ca[1], bx0 = cb[0], bx1 = cb[0], by0 = cb[1], by1 = cb[1];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        ax0 = fminf(ax0, ca[i * 3]); ax1 = fmaxf(ax1, ca[i * 3]); ay0 = fminf(ay0, ca[i * 3 + 1]); ay1 = fmaxf(ay1, ca[i * 3 + 1]);
+        bx0 = fminf(bx0, cb[i * 3]); bx1 = fmaxf(bx1, cb[i * 3]); by0 = fminf(by0, cb[i * 3 + 1]); by1 = fmaxf(by1, cb[i * 3 + 1]);
+    }
+    return ax1 < bx0 || bx1 < ax0 || ay1 < by0 || by1 < ay0;
+}
+
 __device__ double quad_iou(const float* ca, const float* cb) {
+    if (quads_separated(ca, cb)) return 0.0;
     P2 a[4], b[4], b1[12], b2[12];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -381,8 +419,9 @@ extern "C" int av2x_eval_tp_fp(const float* det_corners, const int32_t* order, i
 extern "C" uint64_t av2x_postprocess_workspace_bytes(int32_t h, int32_t w, int32_t a, int32_t top) {
     const uint64_t na = (uint64_t)h * w * a;
     const uint64_t words = ((uint64_t)top + 63) / 64;
-    // score, flag, cand, boxes(7), corners(24), cscore, label, keep, kept | order, pick, inr (top each) | mask | 8 counters
-    return (na * (1 + 1 + 1 + 7 + 24 + 1 + 1 + 1 + 1 + 1) + 3 * (uint64_t)top + 16) * 4 + (uint64_t)top * words * 8 + 64;
+    // score, flag, cand, boxes(7), corners(24), cscore, label, keep, kept | order, pick, inr (top each) | per-workgroup
+    // flag counts | mask | 8 counters
+    return (na * (1 + 1 + 1 + 7 + 24 + 1 + 1 + 1 + 1 + 1) + 3 * (uint64_t)top + (na / 256 + 2) + 16) * 4 + (uint64_t)top * words * 8 + 64;
 }
 
 extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* obj, const float* anchors, int32_t h,
@@ -417,13 +456,14 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     int* order = reinterpret_cast<int*>(f); f += top;
     int* pick = reinterpret_cast<int*>(f); f += top;
     int* inr = reinterpret_cast<int*>(f); f += top;
+    int* wg_count = reinterpret_cast<int*>(f); f += NA / 256 + 2;
     f += 16;
     unsigned long long* mask = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(f) + 15) & ~uintptr_t(15));
     // counts[0..4] = candidates, after size/z filters, NMS input (top), NMS picks, final
     int *ncand = counts, *nkept = counts + 1, *ntop = counts + 2, *npick = counts + 3, *nout = counts + 4;
 
-    hipLaunchKernelGGL(pp_flag, dim3((NA + 255) / 256), dim3(256), 0, st, obj, p, score, flag);
-    hipLaunchKernelGGL(pp_scan, dim3(1), dim3(1024), 0, st, flag, NA, cand, ncand);
+    hipLaunchKernelGGL(pp_flag, dim3((NA + 255) / 256), dim3(256), 0, st, obj, p, score, flag, wg_count);
+    hipLaunchKernelGGL(pp_compact, dim3((NA + 255) / 256), dim3(256), 0, st, flag, NA, wg_count, cand, ncand);
     hipLaunchKernelGGL(pp_decode, dim3(256), dim3(256), 0, st, psm, rm, anchors, score, cand, ncand, p, boxes, corners,
                        cscore, label, keep);
     hipLaunchKernelGGL(pp_scan2, dim3(1), dim3(1024), 0, st, keep, ncand, cscore, kept, kscore, nkept);
