@@ -48,46 +48,4 @@ __device__ inline void block_scan(int n, F f, G store, int* total) {
     if (threadIdx.x == 0) *total = carry;
 }
 
-// Two independent exclusive scans in ONE pass over the elements (the functor yields a pair): the voxelizer needs the
-// rank of every first point AND the list offset of its cell, both over the same indirect loads.
-template <class F, class G>
-__device__ inline void block_scan_pair(int n, F f, G store, int* total_a, int* total_b) {
-    constexpr int ITEMS = 4, PASS = 1024 * ITEMS;
-    __shared__ int wsa[16], wsb[16];
-    __shared__ int carry_a, carry_b;
-    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += PASS) {
-        const int i0 = base + threadIdx.x * ITEMS;
-        int va[ITEMS], vb[ITEMS], ta = 0, tb = 0;
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            va[k] = 0; vb[k] = 0;
-            if (i0 + k < n) f(i0 + k, &va[k], &vb[k]);
-            ta += va[k]; tb += vb[k];
-        }
-        int sa = ta, sb = tb;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int xa = __shfl_up(sa, o), xb = __shfl_up(sb, o);
-            if (lane >= o) { sa += xa; sb += xb; }
-        }
-        if (lane == 63) { wsa[wave] = sa; wsb[wave] = sb; }
-        __syncthreads();
-        int oa = 0, ob = 0;
-        for (int k = 0; k < wave; ++k) { oa += wsa[k]; ob += wsb[k]; }
-        int ea = carry_a + oa + sa - ta, eb = carry_b + ob + sb - tb;
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            if (i0 + k < n) store(i0 + k, ea, eb);
-            ea += va[k]; eb += vb[k];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) { carry_a = ea; carry_b = eb; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { *total_a = carry_a; *total_b = carry_b; }
-}
-
 }  // namespace av2x

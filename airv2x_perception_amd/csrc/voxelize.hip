@@ -9,7 +9,7 @@
 // by an in-cell rank count restores input order exactly, so the result is bit-reproducible.
 //
 //   k_cell   per point : cell id, cnt[cell]++, first[cell] = min(index)
-//   k_scan   1 workgroup, one pass: exclusive scans (a) over "is first point of its cell" flags in point
+//   k_flagsum + k_rank  grid-wide exclusive scans (a) over "is first point of its cell" flags in point
 //            order -> voxel rank + M, (b) over cnt of the first points, same order -> list offsets
 //   k_fill   per point : unordered append of the point index to its cell's list
 //   k_emit   per point : pos = #{j in list : j < i}; write voxels / coords / num_points
@@ -76,26 +76,60 @@ __global__ void k_cell(const float4* __restrict__ pts, int n, VoxGeom g, PrepInl
     cell[i] = c;
 }
 
-__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cell, int n, const int* __restrict__ cnt,
-                                               const int* __restrict__ first, int ncell, int* __restrict__ vrank,
-                                               int* __restrict__ offs, int* __restrict__ m_out, int max_voxels) {
-    __shared__ int tot, tot_b;
-    // one pass, two scans over the points in input order: (a) voxel rank = number of earlier "first points" (-> M),
-    // (b) list offset = points of the cells that appeared earlier (a scan over the points, not over the 140 800 grid
-    // cells: only occupied cells need a list)
-    av2x::block_scan_pair(
-        n,
-        [&](int i, int* a, int* b) {
-            const int c = cell[i];
-            if (c >= 0 && first[c] == i) { *a = 1; *b = cnt[c]; }
-        },
-        [&](int i, int ea, int eb) {
-            const int c = cell[i];
-            if (c >= 0 && first[c] == i) { vrank[c] = ea; offs[c] = eb; }
-        },
-        &tot, &tot_b);
+// The two exclusive scans over the points in input order -- (a) voxel rank = number of earlier "first points" (-> M),
+// (b) list offset = points of the cells that appeared earlier (a scan over the points, not over the 140 800 grid cells:
+// only occupied cells need a list) -- as a grid-wide two-launch scan: k_flagsum leaves every 256-point workgroup's
+// totals, k_rank adds the totals of the workgroups before it (a few hundred pairs, summed by the workgroup itself) to
+// its in-workgroup prefix.  A 108 k-point cloud no longer walks through one workgroup 27 times.
+__device__ __forceinline__ void first_point_pair(const int* __restrict__ cell, const int* __restrict__ cnt,
+                                                 const int* __restrict__ first, int i, int n, int* c_out, int* a, int* b) {
+    *a = 0; *b = 0; *c_out = -1;
+    if (i < n) {
+        const int c = cell[i];
+        if (c >= 0 && first[c] == i) { *a = 1; *b = cnt[c]; *c_out = c; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flagsum(const int* __restrict__ cell, int n, const int* __restrict__ cnt,
+                                                 const int* __restrict__ first, int2* __restrict__ wg_sum) {
+    __shared__ int sa[4], sb[4];
+    int c, a, b;
+    first_point_pair(cell, cnt, first, blockIdx.x * 256 + threadIdx.x, n, &c, &a, &b);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
     __syncthreads();
-    if (threadIdx.x == 0) m_out[0] = tot < max_voxels ? tot : max_voxels;
+    if (threadIdx.x == 0) wg_sum[blockIdx.x] = make_int2(sa[0] + sa[1] + sa[2] + sa[3], sb[0] + sb[1] + sb[2] + sb[3]);
+}
+
+__global__ __launch_bounds__(256) void k_rank(const int* __restrict__ cell, int n, const int* __restrict__ cnt,
+                                              const int* __restrict__ first, const int2* __restrict__ wg_sum,
+                                              int* __restrict__ vrank, int* __restrict__ offs, int* __restrict__ m_out,
+                                              int max_voxels) {
+    __shared__ int pa[4], pb[4], wa[4], wb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int oa = 0, ob = 0;
+    for (int g = threadIdx.x; g < (int)blockIdx.x; g += 256) { const int2 v = wg_sum[g]; oa += v.x; ob += v.y; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { oa += __shfl_xor(oa, o); ob += __shfl_xor(ob, o); }
+    if (lane == 0) { pa[wave] = oa; pb[wave] = ob; }
+    int c, a, b;
+    first_point_pair(cell, cnt, first, blockIdx.x * 256 + threadIdx.x, n, &c, &a, &b);
+    int sa = a, sb = b;                                  // inclusive wave scans
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int xa = __shfl_up(sa, o), xb = __shfl_up(sb, o);
+        if (lane >= o) { sa += xa; sb += xb; }
+    }
+    if (lane == 63) { wa[wave] = sa; wb[wave] = sb; }
+    __syncthreads();
+    int ba = pa[0] + pa[1] + pa[2] + pa[3], bb = pb[0] + pb[1] + pb[2] + pb[3];
+    for (int k = 0; k < wave; ++k) { ba += wa[k]; bb += wb[k]; }
+    if (a) { vrank[c] = ba + sa - a; offs[c] = bb + sb - b; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+        const int tot = ba + sa;
+        m_out[0] = tot < max_voxels ? tot : max_voxels;
+    }
 }
 
 __global__ void k_fill(const int* __restrict__ cell, int n, const int* __restrict__ offs, int* __restrict__ fill,
@@ -250,7 +284,7 @@ extern "C" int av2x_prepare_points(const float* points, const int32_t* perm, int
 
 extern "C" uint64_t av2x_voxelize_workspace_bytes(int32_t n_points, int32_t nx, int32_t ny, int32_t nz) {
     const uint64_t ncell = (uint64_t)nx * ny * nz;
-    return (5 * ncell + 2 * (uint64_t)n_points + 4) * sizeof(int);
+    return (5 * ncell + 2 * (uint64_t)n_points + 2 * ((uint64_t)n_points / 256 + 2) + 4) * sizeof(int);
 }
 
 static int voxelize_impl(const float* points, int32_t n_points, const PrepInline& P, const float* range6, const float* voxel3,
@@ -275,6 +309,7 @@ static int voxelize_impl(const float* points, int32_t n_points, const PrepInline
         *offs = w + 4 * (size_t)ncell;
     int* cell = w + 5 * (size_t)ncell;
     int* list = cell + n_points;
+    int2* wg_sum = reinterpret_cast<int2*>(list + n_points + ((reinterpret_cast<uintptr_t>(list + n_points) & 4) ? 1 : 0));   // 8-byte aligned
     hipLaunchKernelGGL(k_init, dim3((ncell + 255) / 256), dim3(256), 0, st, cnt, first, fill, ncell);
     // outputs are capacity-sized by the caller: voxels (cap, max_points, 4) must start zeroed
     const long long cap = n_points < max_voxels ? n_points : max_voxels;
@@ -288,8 +323,8 @@ static int voxelize_impl(const float* points, int32_t n_points, const PrepInline
     const dim3 gp((n_points + 255) / 256), bp(256);
     const float4* p4 = reinterpret_cast<const float4*>(points);
     hipLaunchKernelGGL(k_cell, gp, bp, 0, st, p4, n_points, g, P, cell, cnt, first);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cell, n_points, cnt, first, ncell, vrank, offs, n_voxels,
-                       max_voxels);
+    hipLaunchKernelGGL(k_flagsum, gp, bp, 0, st, cell, n_points, cnt, first, wg_sum);
+    hipLaunchKernelGGL(k_rank, gp, bp, 0, st, cell, n_points, cnt, first, wg_sum, vrank, offs, n_voxels, max_voxels);
     hipLaunchKernelGGL(k_fill, gp, bp, 0, st, cell, n_points, offs, fill, list);
     hipLaunchKernelGGL(k_emit, gp, bp, 0, st, p4, cell, n_points, cnt, first, vrank, offs, list, g, P, max_points,
                        max_voxels, reinterpret_cast<float4*>(voxels), coords, num_points);
