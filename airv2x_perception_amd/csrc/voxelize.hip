@@ -14,7 +14,6 @@
 //   k_fill   per point : unordered append of the point index to its cell's list
 //   k_emit   per point : pos = #{j in list : j < i}; write voxels / coords / num_points
 #include "av2x_common.hpp"
-#include "block_scan.hpp"
 
 namespace {
 
@@ -216,39 +215,58 @@ struct PrepParams {
 // q = points[perm[i]] ; drop ego-box returns (pcd_utils.py:168-190, closed box, sensor frame) ; project with
 // the 4x4 (box_utils.py:1038-1067; torch's fp32 einsum = one multiply then an FMA chain over k, reproduced
 // exactly) ; keep points strictly inside the range (pcd_utils.py:136-165).
-__global__ void prep_flag(const float4* __restrict__ pts, const int* __restrict__ perm, PrepParams p,
-                          float4* __restrict__ tmp, int* __restrict__ flag) {
+__global__ __launch_bounds__(256) void prep_flag(const float4* __restrict__ pts, const int* __restrict__ perm, PrepParams p,
+                                                 float4* __restrict__ tmp, int* __restrict__ flag, int* __restrict__ wg_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    float4 q = pts[perm ? perm[i] : i];
-    bool keep = true;
-    if (p.mask_ego) keep = !(q.x >= -1.95f && q.x <= 2.95f && q.y >= -1.1f && q.y <= 1.1f);
-    if (p.project) {
-        float o[3];
+    bool keep = false;
+    if (i < p.n) {
+        float4 q = pts[perm ? perm[i] : i];
+        keep = true;
+        if (p.mask_ego) keep = !(q.x >= -1.95f && q.x <= 2.95f && q.y >= -1.1f && q.y <= 1.1f);
+        if (p.project) {
+            float o[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            float acc = __fmul_rn(q.x, p.T[j * 4 + 0]);
-            acc = __fmaf_rn(q.y, p.T[j * 4 + 1], acc);
-            acc = __fmaf_rn(q.z, p.T[j * 4 + 2], acc);
-            acc = __fmaf_rn(1.0f, p.T[j * 4 + 3], acc);
-            o[j] = acc;
+            for (int j = 0; j < 3; ++j) {
+                float acc = __fmul_rn(q.x, p.T[j * 4 + 0]);
+                acc = __fmaf_rn(q.y, p.T[j * 4 + 1], acc);
+                acc = __fmaf_rn(q.z, p.T[j * 4 + 2], acc);
+                acc = __fmaf_rn(1.0f, p.T[j * 4 + 3], acc);
+                o[j] = acc;
+            }
+            q.x = o[0]; q.y = o[1]; q.z = o[2];
         }
-        q.x = o[0]; q.y = o[1]; q.z = o[2];
+        keep = keep && q.x > p.r[0] && q.x < p.r[3] && q.y > p.r[1] && q.y < p.r[4] && q.z > p.r[2] && q.z < p.r[5];
+        tmp[i] = q;
+        flag[i] = keep ? 1 : 0;
     }
-    keep = keep && q.x > p.r[0] && q.x < p.r[3] && q.y > p.r[1] && q.y < p.r[4] && q.z > p.r[2] && q.z < p.r[5];
-    tmp[i] = q;
-    flag[i] = keep ? 1 : 0;
+    __shared__ int wc[4];
+    const unsigned long long bal = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-__global__ __launch_bounds__(1024) void prep_scan(const int* __restrict__ flag, int n, int* __restrict__ offs,
-                                                  int* __restrict__ count) {
-    av2x::block_scan(n, [&](int i) { return flag[i]; }, [&](int i, int e) { offs[i] = e; }, count);
-}
-
-__global__ void prep_emit(const float4* __restrict__ tmp, const int* __restrict__ flag, const int* __restrict__ offs, int n,
-                          float4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) out[offs[i]] = tmp[i];
+// order-preserving compaction over the whole grid: offset of a workgroup = sum of the counts before it
+__global__ __launch_bounds__(256) void prep_emit(const float4* __restrict__ tmp, const int* __restrict__ flag,
+                                                 const int* __restrict__ wg_count, int n, float4* __restrict__ out,
+                                                 int* __restrict__ count) {
+    __shared__ int part[4], wc[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int s = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) s += wg_count[b];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) part[wave] = s;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && flag[i] != 0;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wc[wave] = __popcll(bal);
+    __syncthreads();
+    int off = part[0] + part[1] + part[2] + part[3];
+    for (int k = 0; k < wave; ++k) off += wc[k];
+    if (f) out[off + __popcll(bal & ((1ull << lane) - 1ull))] = tmp[i];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        count[0] = part[0] + part[1] + part[2] + part[3] + wc[0] + wc[1] + wc[2] + wc[3];
 }
 
 }  // namespace
@@ -274,11 +292,10 @@ extern "C" int av2x_prepare_points(const float* points, const int32_t* perm, int
     for (int i = 0; i < 6; ++i) p.r[i] = range6[i];
     float4* tmp = reinterpret_cast<float4*>(workspace);
     int* flag = reinterpret_cast<int*>(tmp + n_points);
-    int* offs = flag + n_points;
+    int* wg_count = flag + n_points;          // (n_points + 255) / 256 entries of the second int array
     const dim3 g((n_points + 255) / 256), b(256);
-    hipLaunchKernelGGL(prep_flag, g, b, 0, st, reinterpret_cast<const float4*>(points), perm, p, tmp, flag);
-    hipLaunchKernelGGL(prep_scan, dim3(1), dim3(1024), 0, st, flag, n_points, offs, count);
-    hipLaunchKernelGGL(prep_emit, g, b, 0, st, tmp, flag, offs, n_points, reinterpret_cast<float4*>(out));
+    hipLaunchKernelGGL(prep_flag, g, b, 0, st, reinterpret_cast<const float4*>(points), perm, p, tmp, flag, wg_count);
+    hipLaunchKernelGGL(prep_emit, g, b, 0, st, tmp, flag, wg_count, n_points, reinterpret_cast<float4*>(out), count);
     return av2x::check_launch("av2x_prepare_points");
 }
 
