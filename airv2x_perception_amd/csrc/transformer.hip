@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void fax_attention_kernel(const FaxParams p) {
         return (l * p.H + ph) * p.W + pw;
     };
 
-    for (int h = wave; h < p.heads; h += 4) {
+    const int nwaves = blockDim.x >> 6;   // 4, or fewer when K / V of that many heads do not fit the 160 KB of LDS at once
+    for (int h = wave; h < p.heads; h += nwaves) {
         // stage K, V of the valid (un-padded) agents and this head's bias column
         for (int j0 = 0; j0 < Tk; j0 += 8) {
             const int j = j0 + (lane >> 3), d4 = lane & 7;
@@ -690,11 +691,13 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
         return av2x::check_launch("fax_attention_mfma_kernel");
     }
     p.grid = grid_partition & 1;
-    const size_t lds = (size_t)4 * (2 * Tk * DH + tab_n) * sizeof(float);
+    int nw = 4;                                  // waves per workgroup = heads whose K / V are resident at once
+    while (nw > 1 && (size_t)nw * (2 * Tk * DH + tab_n) * sizeof(float) > 160 * 1024) nw >>= 1;
+    const size_t lds = (size_t)nw * (2 * Tk * DH + tab_n) * sizeof(float);
     if (lds > 160 * 1024) return av2x::fail("av2x_fax_attention: %zu B of LDS needed (> 160 KiB): too many valid agents", lds);
     static av2x::LdsLimit lim_attr;
     lim_attr.ensure(reinterpret_cast<const void*>(&fax_attention_kernel), lds);
-    hipLaunchKernelGGL(fax_attention_kernel, dim3((h / window) * (w / window)), dim3(256), lds, av2x::as_stream(stream), p);
+    hipLaunchKernelGGL(fax_attention_kernel, dim3((h / window) * (w / window)), dim3(64 * nw), lds, av2x::as_stream(stream), p);
     return av2x::check_launch("fax_attention_kernel");
 }
 

@@ -92,11 +92,13 @@ def test_gpu_forward_matches_golden_and_oracle(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("grid,L,nv", [(0, 5, 3), (1, 5, 3), (2, 5, 3), (3, 5, 3), (4, 5, 3), (5, 5, 3), (0, 7, 7), (1, 7, 4), (4, 7, 4),
                                        (0, 8, 8), (1, 8, 1), (0, 8, 5), (1, 7, 2), (0, 3, 3), (1, 9, 6),
-                                       (8, 5, 3), (9, 7, 4), (8, 8, 8), (9, 8, 5), (16, 8, 8), (17, 8, 5), (16, 7, 6)])
+                                       (8, 5, 3), (9, 7, 4), (8, 8, 8), (9, 8, 5), (16, 8, 8), (17, 8, 5), (16, 7, 6),
+                                       (0, 12, 12), (1, 15, 10), (0, 15, 15)])
 def test_gpu_fax_attention_kernel(grid, L, nv):
     """grid bit 0: partition (window / grid); default kernel for ws = 4: one wave per (window, head), everything in
     registers (up to 4 valid agents; bit 4 forces it beyond); bit 3: the workgroup-per-window transposed-score kernel; bit 2: the generic-window MFMA kernel; bit 1: the
-    VALU reference kernel (T = 16 L > 128 tokens always takes the VALU kernel)."""
+    VALU reference kernel (T = 16 L > 128 tokens always takes the VALU kernel; with more than 8 valid agents it keeps the K / V of
+    2 or 1 heads in LDS at a time instead of 4)."""
     from ctypes import c_void_p
     from airv2x_perception_amd import _lib
     lib = _lib.load()
