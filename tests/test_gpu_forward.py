@@ -147,3 +147,31 @@ def test_full_grid_permutation_of_non_ego_agents_is_invariant():
     # and the ego DOES matter: a different ego changes the result
     c = model(synth.build_data_dict_device([vox_dev[i] for i in [1, 0, 2, 3, 4]], types, "cuda", max_cav_num=args["max_cav_num"]))
     assert float((c["psm"] - a["psm"]).abs().max()) > 1e-2
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_equals_eager_launches():
+    """engine.use_graph: everything after the scatter is captured once per frame layout and replayed; results must equal
+    the eager launches bit for bit, for repeated frames and after new inputs were scattered into the same canvas."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    fx = load_fixture("w2c_small_n3")
+    hy, args, sd, dd, voxd, types = case_from_fixture(fx)
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    keep = lambda o: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}
+    ref = keep(eng.forward(dd, sync_comm_rate=True))
+    dd2 = synth.build_data_dict([voxd[1], voxd[0], voxd[2]], types, max_cav_num=args["max_cav_num"])   # other clouds, same layout
+    ref2 = keep(eng.forward(dd2, sync_comm_rate=True))
+    eng.use_graph = True
+    try:
+        for want, inp in ((ref, dd), (ref2, dd2), (ref, dd)):
+            out = eng.forward(inp, sync_comm_rate=True)
+            assert eng.graph_active()
+            for k in ("psm", "rm", "obj"):
+                assert torch.equal(out[k], want[k]), k
+            assert out["comm_rate"] == want["comm_rate"] and float(out["com"]) == float(want["com"])
+    finally:
+        eng.use_graph = False
