@@ -175,3 +175,49 @@ def test_hipgraph_replay_equals_eager_launches():
             assert out["comm_rate"] == want["comm_rate"] and float(out["com"]) == float(want["com"])
     finally:
         eng.use_graph = False
+
+
+@pytest.mark.gpu
+def test_agent_streams_schedule_equals_single_stream():
+    """engine.agent_streams = 2: the per-agent part of a B = 1 frame runs as two agent groups on two HIP streams (a
+    schedule measured as no faster and left off by default); results must not change."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    fx = load_fixture("w2c_small_n3")
+    hy, args, sd, dd, _, _ = case_from_fixture(fx)
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    ref = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd, sync_comm_rate=True).items()}
+    eng.agent_streams = 2
+    try:
+        out = eng.forward(dd, sync_comm_rate=True)
+        torch.cuda.synchronize()
+    finally:
+        eng.agent_streams = 1
+    for k in ("psm", "rm", "obj"):
+        assert torch.equal(out[k], ref[k]), k
+    assert out["comm_rate"] == ref["comm_rate"] and float(out["com"]) == float(ref["com"])
+
+
+@pytest.mark.gpu
+def test_fully_connected_communication_matches_oracle():
+    """where2com_fusion.fully = true (where2comm_fuse.py:222-223): no confidence mask, communication rate 1."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    from oracle import where2comm_oracle as orc
+    fx = load_fixture("w2c_small_n3")
+    hy, args, sd, dd, _, _ = case_from_fixture(fx)
+    args = synth.clone_hypes(hy)["model"]["args"]
+    args["where2com_fusion"]["fully"] = True
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    out = model(dd)
+    with torch.no_grad():
+        ref = orc.where2com_forward(dd, sd, args)
+    for k in ("psm", "rm", "obj"):
+        assert_close(out[k].cpu(), ref[k], 2e-4, 2e-4, k)
+    assert int(out["com"]) == int(ref["com"]) == 1
+    masked = orc.where2com_forward(dd, sd, synth.clone_hypes(hy)["model"]["args"])
+    assert float((masked["psm"] - ref["psm"]).abs().max()) > 1e-3        # the mask does change the result on this frame
