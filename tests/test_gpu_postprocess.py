@@ -72,3 +72,47 @@ def test_no_candidates():
     obj = np.full(fx["obj"].shape, -10.0, np.float32)
     post, res, hy, anchors = _run(fx, obj=obj)
     assert res[:4] == (None, None, None, None) and res[4][0] == 0
+
+
+def test_pipelined_frames_with_postprocess_equal_sequential():
+    """FramePipeline.submit(after=post.launch) keeps model + post-process of several frames in flight (one buffer set per
+    slot, `finish` reads the counts one lap later); every frame's boxes must equal the sequential post_process_airv2x."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    from airv2x_perception_amd.opencood_iface.engine import FramePipeline
+    from airv2x_perception_amd.opencood_iface.voxel_postprocessor import VoxelPostprocessor
+    from tests.helpers import case_from_fixture
+    fx = load_fixture("w2c_small_n3")
+    hy, args, sd, dd, voxd, types = case_from_fixture(fx)
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    post = VoxelPostprocessor(hy["postprocess"], dataset="airv2x", train=False)
+    data = {"ego": {"transformation_matrix": torch.eye(4), "anchor_box": torch.from_numpy(np.array(post.generate_anchor_box()))}}
+    frames = [dd, synth.build_data_dict([voxd[1], voxd[0], voxd[2]], types, max_cav_num=args["max_cav_num"])]
+    want = []
+    for f in frames:
+        o = model(f)
+        want.append(post.post_process_airv2x(data, {"ego": o}, return_counts=True))
+    assert want[0][4] != want[1][4] or not torch.equal(want[0][1], want[1][1])       # the two frames differ
+    pipe = FramePipeline(eng, 3)
+    pend, got = [], []
+    for it in range(7):
+        if len(pend) == 3:
+            h, stream, which = pend.pop(0)
+            stream.synchronize()
+            got.append((which, post.finish(h, return_counts=True)))
+        which = it % 2
+        h, stream = pipe.submit(frames[which], after=lambda o, slot: post.launch(data, {"ego": o}, slot=slot))
+        pend.append((h, stream, which))
+    for h, stream, which in pend:
+        stream.synchronize()
+        got.append((which, post.finish(h, return_counts=True)))
+    assert len(got) == 7
+    for which, res in got:
+        ref = want[which]
+        assert res[4] == ref[4]                                                       # the five counters
+        for a, b in zip(res[:4], ref[:4]):
+            assert torch.equal(a, b)
+        assert torch.equal(res[5], ref[5])                                            # anchor indices of the boxes
