@@ -65,7 +65,7 @@ def _drift(out, fx, keys=("psm", "rm", "obj")):
     return rep
 
 
-@pytest.mark.parametrize("which", ["where2com", "cobevt", "v2xvit"])
+@pytest.mark.parametrize("which", ["where2com", "cobevt", "v2xvit", "when2com"])
 def test_models_under_autocast_stay_close_to_the_fp32_reference(which):
     """torch.autocast around the forward selects AMP mode (module.amp overrides).  The drift against the reference's
     fp32 outputs is bf16 input rounding through 25-60 GEMM layers: bounded here at 6 % of the map's magnitude."""
@@ -79,6 +79,11 @@ def test_models_under_autocast_stay_close_to_the_fp32_reference(which):
         import tests.test_cobevt as tc
         fx = load_fixture("cobevt_small_n3")
         hy, args, sd, dd = tc._case(fx)
+    elif which == "when2com":
+        from airv2x_perception_amd.opencood_iface import Airv2xWhen2com as M
+        import tests.test_when2com as tw
+        fx = load_fixture("when2com_small_n3")
+        hy, args, sd, dd = tw._case(fx)
     else:
         from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
         import tests.test_v2xvit as tv
@@ -162,7 +167,7 @@ def test_where2comm_split3_forward_meets_the_fp32_tolerance():
         assert int(out["comm_rate"]) == int(fx["comm_rate"])
 
 
-@pytest.mark.parametrize("which,name", [("cobevt", "cobevt_full_n4"), ("v2xvit", "v2xvit_full_n4")])
+@pytest.mark.parametrize("which,name", [("cobevt", "cobevt_full_n4"), ("v2xvit", "v2xvit_full_n4"), ("when2com", "when2com_full_n2")])
 def test_transformer_models_split3_meet_the_fp32_tolerance_at_full_grid(which, name):
     """engine.split3 on the CoBEVT / V2X-ViT paths at the BASELINE grid: same tolerances as the fp32-MFMA tests."""
     fx = load_fixture(name)
@@ -170,6 +175,11 @@ def test_transformer_models_split3_meet_the_fp32_tolerance_at_full_grid(which, n
         import tests.test_cobevt as tc
         from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT as M
         hy, args, sd, dd = tc._case(fx)
+        rtol, atol_of = 3e-4, lambda ref: 3e-4
+    elif which == "when2com":
+        import tests.test_when2com as tw
+        from airv2x_perception_amd.opencood_iface import Airv2xWhen2com as M
+        hy, args, sd, dd = tw._case(fx)
         rtol, atol_of = 3e-4, lambda ref: 3e-4
     else:
         import tests.test_v2xvit as tv
