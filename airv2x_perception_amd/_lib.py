@@ -85,6 +85,9 @@ SIGNATURES = {
     "av2x_prepare_voxelize": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                         c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_postprocess_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
+    "av2x_postprocess_devt": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                        c_void_p, c_float, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_postprocess": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                    c_void_p, c_float, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -104,9 +107,14 @@ def load(build_if_missing=True):
     if build_if_missing:
         try:
             _build.build()
-        except Exception as e:  # a prebuilt .so that is merely older than a touched source is still usable
+        except _build.HipccMissing as e:
+            # no compiler on this box: a prebuilt library is the only option (the GPU box ships one with the snapshot)
             if not os.path.exists(path):
                 raise RuntimeError(f"libairv2x_hip.so is missing and could not be built: {e}") from e
+            if _build.needs_build():
+                import warnings
+                warnings.warn("libairv2x_hip.so is older than its sources and hipcc is not available: using the stale binary")
+        # any other failure (compile / link error after a source edit) propagates: never run a stale binary silently
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not found: the HIP extension is required (no CPU fallback)")
     lib = ctypes.CDLL(path)

@@ -14,11 +14,15 @@ LIB = os.path.join(HERE, "libairv2x_hip.so")
 SOURCES = ["capi.hip", "conv_igemm.hip", "pillar.hip", "where2comm.hip", "postproc.hip", "voxelize.hip", "transformer.hip", "v2xvit.hip", "when2com.hip"]
 
 
+class HipccMissing(RuntimeError):
+    pass
+
+
 def hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
             return c
-    raise RuntimeError("hipcc not found: libairv2x_hip.so cannot be built (no CPU fallback exists)")
+    raise HipccMissing("hipcc not found: libairv2x_hip.so cannot be built (no CPU fallback exists)")
 
 
 def needs_build():

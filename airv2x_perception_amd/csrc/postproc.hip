@@ -23,6 +23,7 @@ struct PPParams {
     float obj_thr, nms_thr;
     float zmin, zmax, xmin, xmax, ymin, ymax;
     float T[16];
+    const float* Tdev;  // optional: the 4x4 transform in device memory (read instead of T; no host read of a device tensor)
     int order_hwl, top;
 };
 
@@ -77,6 +78,9 @@ __global__ void pp_decode(const float* __restrict__ psm, const float* __restrict
                           int* __restrict__ label, int* __restrict__ keep) {
     const int K = ncand[0];
     const int HW = p.H * p.W;
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = p.Tdev ? p.Tdev[i] : p.T[i];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
         const int n = cand[k];
         const int a = n % p.A, hw = n / p.A;
@@ -119,9 +123,9 @@ __global__ void pp_decode(const float* __restrict__ psm, const float* __restrict
             const float ry = __fadd_rn(__fmul_rn(px, sa), __fmul_rn(py, ca)) + b[1];
             const float rz = pz + b[2];
             // T @ [x y z 1]^T
-            const float qx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p.T[0], rx), __fmul_rn(p.T[1], ry)), __fmul_rn(p.T[2], rz)), p.T[3]);
-            const float qy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p.T[4], rx), __fmul_rn(p.T[5], ry)), __fmul_rn(p.T[6], rz)), p.T[7]);
-            const float qz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p.T[8], rx), __fmul_rn(p.T[9], ry)), __fmul_rn(p.T[10], rz)), p.T[11]);
+            const float qx = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], rx), __fmul_rn(T[1], ry)), __fmul_rn(T[2], rz)), T[3]);
+            const float qy = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], rx), __fmul_rn(T[5], ry)), __fmul_rn(T[6], rz)), T[7]);
+            const float qz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], rx), __fmul_rn(T[9], ry)), __fmul_rn(T[10], rz)), T[11]);
             corners[(size_t)k * 24 + c * 3 + 0] = qx;
             corners[(size_t)k * 24 + c * 3 + 1] = qy;
             corners[(size_t)k * 24 + c * 3 + 2] = qz;
@@ -148,14 +152,67 @@ __global__ __launch_bounds__(1024) void pp_scan2(const int* __restrict__ keep, c
     if (threadIdx.x == 0) nkept[0] = tot;
 }
 
+// Above PP_RANK_DIRECT kept candidates (an untrained / early-epoch model or a low obj_threshold can put all H*W*A anchors
+// above the threshold) the O(K2^2) ranking below would take seconds, so pp_select first finds the exact score of rank
+// `top` -- a bisection over the fp32 bit patterns (scores are sigmoids > 0: their unsigned bit patterns sort like the
+// values): the largest key `cut` with |{key >= cut}| >= top, hence |{key > cut}| < top -- and places the candidates whose
+// score EQUALS the cut itself: rank = |{key > cut}| + (ties at a higher position), from one scan.  pp_rank then ranks only
+// the < top candidates above the cut, each against all K2.  Result identical to the full ranking
+// (scores.argsort(descending) of box_utils.py:846-849 with ties -> higher position first).
+constexpr int PP_RANK_DIRECT = 4096;
+
+__global__ __launch_bounds__(1024) void pp_select(const float* __restrict__ kscore, const int* __restrict__ nkept, int top,
+                                                  int* __restrict__ order, unsigned* __restrict__ cutinfo) {
+    const int K2 = nkept[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (K2 <= PP_RANK_DIRECT) {  // every candidate is ranked directly (positive scores: key > 0)
+        if (tid == 0) { cutinfo[0] = 0u; cutinfo[1] = 0u; }
+        return;
+    }
+    __shared__ int red[16];
+    __shared__ int tot;
+    auto count_ge = [&](unsigned key) {
+        int c = 0;
+        for (int i = tid; i < K2; i += 1024) c += __float_as_uint(kscore[i]) >= key;
+        for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+        __syncthreads();  // red[] of the previous round has been read by everyone
+        if (lane == 0) red[wave] = c;
+        __syncthreads();
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        return t;
+    };
+    unsigned lo = 0u, hi = 0x7f800000u;  // |{key >= lo}| >= top (K2 > top), |{key >= +inf}| = 0 < top
+    while (hi - lo > 1u) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        if (count_ge(mid) >= top) lo = mid; else hi = mid;
+    }
+    const unsigned cut = lo;
+    const int c_gt = count_ge(cut + 1u), c_ge = count_ge(cut);
+    const int c_eq = c_ge - c_gt;
+    __syncthreads();
+    av2x::block_scan<16>(
+        K2, [&](int i) { return __float_as_uint(kscore[i]) == cut ? 1 : 0; },
+        [&](int i, int ex) {
+            if (__float_as_uint(kscore[i]) == cut) {
+                const int r = c_gt + (c_eq - 1 - ex);  // ties: the higher position ranks first
+                if (r < top) order[r] = i;
+            }
+        },
+        &tot);
+    if (tid == 0) { cutinfo[0] = cut; cutinfo[1] = (unsigned)c_gt; }
+}
+
 // order[r] = position (in the kept list) of the r-th best score; ties -> higher position first
 // kscore: scores of the kept candidates, compacted (every lane reads the same kscore[j]: one broadcast load)
 __global__ void pp_rank(const float* __restrict__ kscore, const int* __restrict__ nkept, int top, int* __restrict__ order,
-                        int* __restrict__ ntop) {
+                        int* __restrict__ ntop, const unsigned* __restrict__ cutinfo) {
     const int K2 = nkept[0];
+    const unsigned cut = cutinfo[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) ntop[0] = K2 < top ? K2 : top;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K2; i += gridDim.x * blockDim.x) {
         const float si = kscore[i];
+        if (__float_as_uint(si) <= cut) continue;  // at or below the rank-`top` score: placed by pp_select or cut off
         int r = 0;
         for (int j = 0; j < K2; ++j) {
             const float sj = kscore[j];
@@ -424,12 +481,12 @@ extern "C" uint64_t av2x_postprocess_workspace_bytes(int32_t h, int32_t w, int32
     return (na * (1 + 1 + 1 + 7 + 24 + 1 + 1 + 1 + 1 + 1) + 3 * (uint64_t)top + (na / 256 + 2) + 16) * 4 + (uint64_t)top * words * 8 + 64;
 }
 
-extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* obj, const float* anchors, int32_t h,
-                                int32_t w, int32_t a, int32_t c, const float* transform16, const float* range6,
-                                float obj_threshold, float nms_threshold, int32_t order_hwl, int32_t top, void* workspace,
-                                float* out_corners, float* out_scores, int32_t* out_labels, float* out_boxes,
-                                int32_t* out_index, int32_t* counts, av2x_stream_t stream) {
-    if (!psm || !rm || !obj || !anchors || !transform16 || !range6 || !workspace || !out_corners || !out_scores ||
+static int postprocess_impl(const float* psm, const float* rm, const float* obj, const float* anchors, int32_t h,
+                            int32_t w, int32_t a, int32_t c, const float* transform16, const float* transform16_dev,
+                            const float* range6, float obj_threshold, float nms_threshold, int32_t order_hwl, int32_t top,
+                            void* workspace, float* out_corners, float* out_scores, int32_t* out_labels, float* out_boxes,
+                            int32_t* out_index, int32_t* counts, av2x_stream_t stream) {
+    if (!psm || !rm || !obj || !anchors || (!transform16 && !transform16_dev) || !range6 || !workspace || !out_corners || !out_scores ||
         !out_labels || !out_boxes || !out_index || !counts)
         return av2x::fail("av2x_postprocess: null argument");
     if (h <= 0 || w <= 0 || a <= 0 || c < 2 || top <= 0 || top > 4096) return av2x::fail("av2x_postprocess: bad sizes");
@@ -437,7 +494,8 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     p.H = h; p.W = w; p.A = a; p.C = c;
     p.obj_thr = obj_threshold; p.nms_thr = nms_threshold;
     p.xmin = range6[0]; p.ymin = range6[1]; p.zmin = range6[2]; p.xmax = range6[3]; p.ymax = range6[4]; p.zmax = range6[5];
-    for (int i = 0; i < 16; ++i) p.T[i] = transform16[i];
+    for (int i = 0; i < 16; ++i) p.T[i] = transform16 ? transform16[i] : 0.f;
+    p.Tdev = transform16_dev;
     p.order_hwl = order_hwl; p.top = top;
     const int NA = h * w * a;
     const int words = (top + 63) / 64;
@@ -457,7 +515,7 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     int* pick = reinterpret_cast<int*>(f); f += top;
     int* inr = reinterpret_cast<int*>(f); f += top;
     int* wg_count = reinterpret_cast<int*>(f); f += NA / 256 + 2;
-    f += 16;
+    unsigned* cutinfo = reinterpret_cast<unsigned*>(f); f += 16;
     unsigned long long* mask = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(f) + 15) & ~uintptr_t(15));
     // counts[0..4] = candidates, after size/z filters, NMS input (top), NMS picks, final
     int *ncand = counts, *nkept = counts + 1, *ntop = counts + 2, *npick = counts + 3, *nout = counts + 4;
@@ -467,7 +525,8 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     hipLaunchKernelGGL(pp_decode, dim3(256), dim3(256), 0, st, psm, rm, anchors, score, cand, ncand, p, boxes, corners,
                        cscore, label, keep);
     hipLaunchKernelGGL(pp_scan2, dim3(1), dim3(1024), 0, st, keep, ncand, cscore, kept, kscore, nkept);
-    hipLaunchKernelGGL(pp_rank, dim3(256), dim3(256), 0, st, kscore, nkept, top, order, ntop);
+    hipLaunchKernelGGL(pp_select, dim3(1), dim3(1024), 0, st, kscore, nkept, top, order, cutinfo);
+    hipLaunchKernelGGL(pp_rank, dim3(256), dim3(256), 0, st, kscore, nkept, top, order, ntop, cutinfo);
     hipLaunchKernelGGL(pp_iou_mask, dim3((top + 63) / 64, top), dim3(64), 0, st, corners, kept, order, ntop, nms_threshold,
                        words, mask);
     const size_t lds = (size_t)top * words * 8 <= 128 * 1024 ? (size_t)top * words * 8 : 0;
@@ -478,4 +537,22 @@ extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* 
     hipLaunchKernelGGL(pp_final, dim3(1), dim3(1024), 0, st, boxes, corners, cscore, label, kept, order, pick, npick, p, inr,
                        out_corners, out_scores, out_labels, out_boxes, out_index, cand, nout);
     return av2x::check_launch("av2x_postprocess");
+}
+
+extern "C" int av2x_postprocess(const float* psm, const float* rm, const float* obj, const float* anchors, int32_t h,
+                                int32_t w, int32_t a, int32_t c, const float* transform16, const float* range6,
+                                float obj_threshold, float nms_threshold, int32_t order_hwl, int32_t top, void* workspace,
+                                float* out_corners, float* out_scores, int32_t* out_labels, float* out_boxes,
+                                int32_t* out_index, int32_t* counts, av2x_stream_t stream) {
+    return postprocess_impl(psm, rm, obj, anchors, h, w, a, c, transform16, nullptr, range6, obj_threshold, nms_threshold,
+                            order_hwl, top, workspace, out_corners, out_scores, out_labels, out_boxes, out_index, counts, stream);
+}
+
+extern "C" int av2x_postprocess_devt(const float* psm, const float* rm, const float* obj, const float* anchors, int32_t h,
+                                     int32_t w, int32_t a, int32_t c, const float* transform16_dev, const float* range6,
+                                     float obj_threshold, float nms_threshold, int32_t order_hwl, int32_t top, void* workspace,
+                                     float* out_corners, float* out_scores, int32_t* out_labels, float* out_boxes,
+                                     int32_t* out_index, int32_t* counts, av2x_stream_t stream) {
+    return postprocess_impl(psm, rm, obj, anchors, h, w, a, c, nullptr, transform16_dev, range6, obj_threshold, nms_threshold,
+                            order_hwl, top, workspace, out_corners, out_scores, out_labels, out_boxes, out_index, counts, stream);
 }

@@ -154,44 +154,44 @@ class CoBEVTEngine(Where2ComEngine):
 
     # ------------------------------------------------------------------ agent sharding
     @torch.no_grad()
-    def shard_local_stage(self, data_dict_local, has_ego):
+    def shard_local_stage(self, data_dict_local, has_ego, n_pad=None):
         """Per-rank half: encoders + backbone + shrink header for THIS rank's agents, written straight into the
-        all-gather send buffer (n_loc,H,W,C) -- 36.0 MB per agent at the default grid.  With message compression
+        all-gather send buffer (n_pad,H,W,C) -- 36.0 MB per agent at the default grid; n_pad >= the local count pads
+        an uneven frame's message (sharded.py).  With message compression
         the buffer holds the NaiveCompressor ENCODER output instead (C/ratio channels: 9.0 MB at ratio 4); the
         decoder runs on the receiving side.  Replaces regroup()'s in-process concat (fuse_utils.py:13-64)."""
-        record_len, slots = self.frame_layout(data_dict_local)
-        if len(record_len) != 1:
-            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
-        n = record_len[0]
-        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        n, record_len, slots = self.shard_frame_agents(data_dict_local)
+        n_pad = n if n_pad is None else int(n_pad)
+        if n_pad < max(n, 1):
+            raise ValueError(f"n_pad = {n_pad} is smaller than this rank's {n} agents")
+        if n > 0:
+            canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        else:
+            ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
         H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
         C = self.fax["input_dim"]
         cm = self.compressor[0].cout if self.compression else C
-        send = self.buf("shard_send", (n * H * W * cm,))
+        send = self.buf("shard_send", (n_pad * H * W * cm,))
+        stats = torch.zeros(2, dtype=torch.int64, device=self.device)
+        if n == 0:
+            return send, stats, {"n_loc": n_pad, "H": H, "W": W, "cm": cm}
         if self.compression:
             s = self.buf("shard_shrink", (n, H, W, C))
             self.trunk(canvas, n, ny, nx, shrink_out=s)
-            self.conv(self.compressor[0], s, n, H, W, send.view(n, H, W, cm))
+            self.conv(self.compressor[0], s, n, H, W, send[:n * H * W * cm].view(n, H, W, cm))
         else:
-            self.trunk(canvas, n, ny, nx, shrink_out=send.view(n, H, W, C))
-        stats = torch.zeros(2, dtype=torch.int64, device=self.device)
-        return send, stats, {"n_loc": n, "H": H, "W": W, "cm": cm}
+            self.trunk(canvas, n, ny, nx, shrink_out=send[:n * H * W * C].view(n, H, W, C))
+        return send, stats, {"n_loc": n_pad, "H": H, "W": W, "cm": cm}
 
     @torch.no_grad()
     def shard_ego_stage(self, recv, stats, meta, world, trace=None, **_):
         """Ego half: the gathered buffer is already in frame order (rank-major = agent-major); decode it (if
         compressed) or copy it into the padded token tensor, then fusion + heads."""
-        n_loc, H, W, cm = meta["n_loc"], meta["H"], meta["W"], meta["cm"]
-        N, C = world * n_loc, self.fax["input_dim"]
-        if recv.numel() != N * H * W * cm:
-            raise ValueError("gathered buffer has the wrong size")
-        if N > self.L:
-            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        msg, N, H, W, C = self._gathered_tokens(recv, meta, world, decode=False)
         x = self.buf("fax_x", (self.L, H, W, C))
         if N < self.L:
             _lib.check(self.lib.av2x_fill_zero(_ptr(x[N:]), (self.L - N) * H * W * C * 4, self.stream()), "av2x_fill_zero")
-        msg = recv.view(N, H, W, cm)
         if self.compression:
             mid = self.buf("compress_mid", (N, H, W, C))
             self.conv(self.compressor[1], msg, N, H, W, mid)
@@ -204,15 +204,24 @@ class CoBEVTEngine(Where2ComEngine):
     # second level: the fusion itself is split over the ranks (sharded.fusion_column_shards), 1/world of the 1.3-1.6 TFLOP each
     fusion_sharding = True
 
-    def _gathered_tokens(self, recv, meta, world):
+    def _gathered_tokens(self, recv, meta, world, decode=True):
+        """The real agents' messages as one (N,H,W,cm) tensor in frame order: a view of the gathered buffer when every
+        rank holds n_loc agents, else (uneven frame, meta["counts"]) the valid slots compacted into a workspace."""
         n_loc, H, W, cm = meta["n_loc"], meta["H"], meta["W"], meta["cm"]
-        N, C = world * n_loc, self.fax["input_dim"]
-        if recv.numel() != N * H * W * cm:
+        counts = meta.get("counts") or [n_loc] * world
+        N, C = sum(counts), self.fax["input_dim"]
+        if recv.numel() != world * n_loc * H * W * cm or len(counts) != world or max(counts) > n_loc:
             raise ValueError("gathered buffer has the wrong size")
         if N > self.L:
             raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
-        msg = recv.view(N, H, W, cm)
-        if self.compression:   # decode on the receiving side
+        msg = recv.view(world * n_loc, H, W, cm)
+        if N != world * n_loc:
+            from .sharded import valid_slots
+            cmp = self.buf("shard_compact", (N, H, W, cm))
+            for a, slot in enumerate(valid_slots(counts, n_loc)):
+                cmp[a].copy_(msg[slot])
+            msg = cmp
+        if self.compression and decode:   # decode on the receiving side
             mid = self.buf("compress_mid", (N, H, W, C))
             dec = self.buf("compress_dec", (N, H, W, C))
             self.conv(self.compressor[1], msg, N, H, W, mid)

@@ -571,7 +571,7 @@ class Where2ComEngine:
         """0-dim fp32 tensor: mean over samples of count / (agents * H * W) (one tiny launch, no ATen arithmetic)."""
         com = self.buf("comm_rate_out", (1,))
         _lib.check(self.lib.av2x_comm_rate(_ptr(count), _ptr(agents_per_sample), B, hw, _ptr(com), self.stream()), "av2x_comm_rate")
-        return com[0]
+        return com[0].clone()   # fresh 0-dim tensor: the caller may keep it across frames
 
     def attn(self, ptrs, hw, c, out):
         arr = (c_void_p * len(ptrs))(*ptrs)
@@ -613,9 +613,10 @@ class Where2ComEngine:
         out = {"psm": outs[0], "rm": outs[1]}
         if self.args["obj_head"]:
             out["obj"] = outs[2]
-        comm_rate = nz[0]
         if sync_comm_rate:
-            comm_rate = int(comm_rate.item())
+            comm_rate = int(nz[0].item())
+        else:
+            comm_rate = nz[0].clone()   # fresh tensor, not a view of the workspace the next frame overwrites
         out.update({"mask": 0, "com": com, "comm_rate": comm_rate})
         return out
 
@@ -777,30 +778,57 @@ class Where2ComEngine:
             dims.append((h, w, layers[0].cout))
         return dims
 
+    def canvas_dims(self):
+        """(ny, nx) of the pillar canvas from the model config (needed by a rank that holds no agent of a sharded frame)."""
+        t = next(iter(self.pfn))
+        g = [int(v) for v in self.args[t]["lidar"]["point_pillar_scatter"]["grid_size"]]
+        return g[1], g[0]
+
+    def shard_frame_agents(self, data_dict_local):
+        """Number of agents this rank holds of a sharded frame (0 for ``None`` / a dict without lidar input) + layout."""
+        if data_dict_local is None:
+            return 0, None, None
+        record_len, slots = self.frame_layout(data_dict_local)
+        if len(record_len) > 1:
+            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
+        n = record_len[0] if record_len else 0
+        return n, record_len, slots
+
     @torch.no_grad()
-    def shard_local_stage(self, data_dict_local, has_ego):
+    def shard_local_stage(self, data_dict_local, has_ego, n_pad=None):
         """Per-rank half of an agent-sharded frame: encode + trunk + confidence mask +
         masked blocks for THIS rank's agents, written straight into the all-gather send buffer
-        [level0: n_loc maps | level1 | level2] (15.77 MB per agent at the default grid).
+        [level0: n_pad maps | level1 | level2] (15.77 MB per agent at the default grid; ``n_pad`` >= the local
+        agent count is the largest count of any rank: an uneven frame pads the message, a rank without agents sends
+        only padding).
         Returns (send flat f32, stats int64[2] = [mask ones before ego override, canvas non-zeros], meta)."""
         if self.fcfg["fully"]:
             raise NotImplementedError("agent sharding with fully-connected communication")
-        record_len, slots = self.frame_layout(data_dict_local)
-        if len(record_len) != 1:
-            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
-        n = record_len[0]
-        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        n, record_len, slots = self.shard_frame_agents(data_dict_local)
+        n_pad = n if n_pad is None else int(n_pad)
+        if n_pad < max(n, 1):
+            raise ValueError(f"n_pad = {n_pad} is smaller than this rank's {n} agents")
+        if has_ego and n == 0:
+            raise ValueError("the ego's rank holds no agent")
+        if n > 0:
+            canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        else:
+            ny, nx = self.canvas_dims()
+        dims = self.level_dims(ny, nx)
+        sizes = [h * w * c for h, w, c in dims]
+        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        send = self.buf("shard_send", (n_pad * sum(sizes),))
+        meta = {"dims": dims, "n_loc": n_pad, "H": H, "W": W}
+        if n == 0:   # nothing to compute; the padding is never read by the fusion
+            return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
         _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
-        dims = self.level_dims(ny, nx)
-        sizes = [h * w * c for h, w, c in dims]
-        send = self.buf("shard_send", (n * sum(sizes),))
         lv, off = [], 0
         for (h, w, c), f in zip(dims, sizes):
             lv.append(send[off:off + n * f].view(n, h, w, c))
-            off += n * f
+            off += n_pad * f
         feats, s, H, W = self.trunk(canvas, n, ny, nx, block_out={0: lv[0]})
         psm_single = self.buf("psm_single", (n, H, W, self.A * self.C))
         self.conv(self.cls_single, s, n, H, W, psm_single)
@@ -815,22 +843,24 @@ class Where2ComEngine:
             lv[1][0].copy_(b1[0])
             lv[2][0].copy_(b2[0])
         stats = torch.stack([count.sum().to(torch.int64), nz[0]])
-        return send, stats, {"dims": dims, "n_loc": n, "H": H, "W": W}
+        return send, stats, meta
 
     @torch.no_grad()
     def shard_ego_stage(self, recv, stats, meta, world, sync_comm_rate=False):
-        """Ego half: per-pixel attention over all N = world * n_loc gathered agents (pointer
-        arithmetic into the all-gather buffer, no regroup copy), deblocks, shrink, heads."""
+        """Ego half: per-pixel attention over all gathered agents (pointer arithmetic into the all-gather buffer, no
+        regroup copy; ``meta["counts"]`` = agents per rank when the frame is uneven, else every rank holds n_loc),
+        deblocks, shrink, heads."""
         dims, n_loc, H, W = meta["dims"], meta["n_loc"], meta["H"], meta["W"]
+        counts = meta.get("counts") or [n_loc] * world
         sizes = [h * w * c for h, w, c in dims]
         per_rank = n_loc * sum(sizes)
-        if recv.numel() != world * per_rank:
+        if recv.numel() != world * per_rank or len(counts) != world or max(counts) > n_loc:
             raise ValueError("gathered buffer has the wrong size")
         base = recv.data_ptr()
         fused, off = [], 0
         for i, ((h, w, c), f) in enumerate(zip(dims, sizes)):
             out = self.buf(f"fused{i}", (1, h, w, c))
-            ptrs = [base + 4 * (r * per_rank + off + j * f) for r in range(world) for j in range(n_loc)]
+            ptrs = [base + 4 * (r * per_rank + off + j * f) for r in range(world) for j in range(counts[r])]
             self.attn(ptrs, h * w, c, out[0])
             fused.append((out, h, w))
             off += n_loc * f
@@ -843,7 +873,7 @@ class Where2ComEngine:
         out = {"psm": outs[0], "rm": outs[1]}
         if self.args["obj_head"]:
             out["obj"] = outs[2]
-        n_total = world * n_loc
+        n_total = sum(counts)
         com = stats[0].to(torch.float32) / float(n_total * H * W)
         comm_rate = int(stats[1].item()) if sync_comm_rate else stats[1]
         out.update({"mask": 0, "com": com, "comm_rate": comm_rate})

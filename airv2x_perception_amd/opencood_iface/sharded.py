@@ -7,13 +7,19 @@ reference's in-process "communication" — ``Airv2xBase.merge_output_dict_list``
 The compute is delegated to a *backend* with two methods (``Where2ComEngine`` implements them on
 the GPU; the gloo/CPU tests plug in an oracle-based backend to exercise exactly this file):
 
-    local_stage(data_dict_local, has_ego) -> (send: flat f32 tensor, stats: int64[2], meta)
+    local_stage(data_dict_local, has_ego, n_pad=k) -> (send: flat f32 tensor, stats: int64[2], meta)
     ego_stage(recv: flat f32 tensor [world * send.numel()], stats, meta, world) -> output dict
 
 Agent order: the global frame order is [vehicles.., rsus.., drones..] with the ego = vehicle 0
 (intermediate_fusion_dataset.py:129-134); rank r owns the contiguous global slice
 ``partition_agents(n, world)[r]``, so the ego is always local agent 0 of rank 0 and the gathered
-buffer is already in frame order (rank-major = agent-major).
+buffer is in frame order (rank-major = agent-major).
+
+Uneven frames (5 agents on 4 GPUs, 4 agents on 8): the slices are balanced (sizes differ by at most
+one, ranks beyond the agent count own nothing), every rank's message is sized for ``n_pad`` =
+the largest local count (an all-gather needs equal contributions) and ``meta["counts"]`` tells the
+fusion which slots of the gathered buffer hold agents.  A rank without agents still takes part
+in the collectives with an all-padding message.
 """
 from __future__ import annotations
 
@@ -22,29 +28,66 @@ import torch.distributed as dist
 
 
 def partition_agents(n_agents, world):
-    """Contiguous equal slices (all_gather needs equal counts): n_agents % world must be 0."""
-    if n_agents % world != 0 or n_agents < world:
-        raise ValueError(f"{n_agents} agents cannot be sharded evenly over {world} ranks")
-    k = n_agents // world
-    return [range(r * k, (r + 1) * k) for r in range(world)]
+    """Balanced contiguous slices of the frame order: the first ``n_agents % world`` ranks own one agent more;
+    ranks beyond the agent count own an empty range.  The ego (agent 0) is always on rank 0."""
+    if n_agents < 1 or world < 1:
+        raise ValueError(f"cannot shard {n_agents} agents over {world} ranks")
+    q, r = divmod(n_agents, world)
+    out, a = [], 0
+    for k in range(world):
+        c = q + (1 if k < r else 0)
+        out.append(range(a, a + c))
+        a += c
+    return out
+
+
+def valid_slots(counts, n_pad):
+    """Indices (into the rank-major gathered agent axis of world * n_pad slots) of the real agents, in frame order."""
+    return [r * n_pad + j for r, c in enumerate(counts) for j in range(c)]
 
 
 class ShardedFrame:
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, collectives_when_single=False):
         self.backend = backend
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # world == 1 normally skips the collectives; True issues them anyway (a 1-rank RCCL group on a one-GPU box
+        # exercises the communicator set-up and the all_gather_into_tensor call path)
+        self.collectives_when_single = collectives_when_single and dist.is_initialized()
 
     @torch.no_grad()
-    def forward(self, data_dict_local, **kw):
+    def forward(self, data_dict_local, counts=None, fusion_rank=None, **kw):
+        """One agent-sharded frame.
+
+        counts       agents per rank (``[len(s) for s in partition_agents(n, world)]``); None = every rank holds as
+                     many agents as this one (the even case, no padding).
+        fusion_rank  None: every rank finishes the frame (SPMD: all of them return the output dict).  r: only rank r
+                     runs the single-level ego stage and returns the output, the others return None right after the
+                     all-gather — with several frames in flight the caller rotates r so that the ego stages of
+                     consecutive frames run on different GPUs instead of being repeated on all of them.  Two-level
+                     backends (CoBEVT / V2X-ViT split the fusion itself over the ranks) ignore it."""
+        if counts is not None:
+            counts = [int(c) for c in counts]
+            if len(counts) != self.world:
+                raise ValueError(f"counts has {len(counts)} entries for a world of {self.world}")
+            n_pad = max(counts)
+        else:
+            n_pad = None
         if isinstance(data_dict_local, dict):
-            data_dict_local.setdefault("shard_rank", self.rank)   # global agent index = rank * n_loc + j (When2com's warp)
-        send, stats, meta = self.backend.local_stage(data_dict_local, has_ego=(self.rank == 0))
-        if self.world == 1:
+            data_dict_local.setdefault("shard_rank", self.rank)
+            if counts is not None:   # global index of this rank's first agent (When2com's warp matrices)
+                data_dict_local["shard_agent_offset"] = sum(counts[:self.rank])
+        lkw = {} if n_pad is None else {"n_pad": n_pad}
+        send, stats, meta = self.backend.local_stage(data_dict_local, has_ego=(self.rank == 0), **lkw)
+        if counts is not None:
+            meta = dict(meta, counts=counts, n_pad=n_pad)
+        if self.world == 1 and not self.collectives_when_single:
             recv = send
         else:
-            recv = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
+            rb = getattr(self.backend, "recv_buffer", None)
+            recv = rb(self.world * send.numel(), send) if rb is not None else \
+                torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
             # the feature-sharing step: every rank contributes 15.77 MB per agent (default grid);
             # xGMI is point-to-point, so the 7 peer transfers into each GPU run on separate links
             dist.all_gather_into_tensor(recv, send, group=self.group)
@@ -59,6 +102,8 @@ class ShardedFrame:
             parts = torch.empty(self.world * part.numel(), dtype=part.dtype, device=part.device)
             dist.all_gather_into_tensor(parts, part, group=self.group)
             return self.backend.ego_finish(parts, ctx, self.world, **kw)
+        if fusion_rank is not None and fusion_rank != self.rank:
+            return None
         return self.backend.ego_stage(recv, stats, meta, self.world, **kw)
 
 
@@ -68,11 +113,15 @@ class EngineBackend:
     def __init__(self, engine):
         self.engine = engine
 
-    def local_stage(self, data_dict_local, has_ego):
-        return self.engine.shard_local_stage(data_dict_local, has_ego)
+    def local_stage(self, data_dict_local, has_ego, **kw):
+        return self.engine.shard_local_stage(data_dict_local, has_ego, **kw)
 
     def ego_stage(self, recv, stats, meta, world, **kw):
         return self.engine.shard_ego_stage(recv, stats, meta, world, **kw)
+
+    def recv_buffer(self, numel, like):
+        """The all-gather destination out of the engine's workspace pool (no allocator traffic per frame)."""
+        return self.engine.buf("shard_recv", (numel,), like.dtype)
 
     @property
     def two_level(self):
@@ -88,6 +137,52 @@ class EngineBackend:
 
     def ego_finish(self, parts, ctx, world, **kw):
         return self.engine.shard_ego_finish(parts, ctx, world, **kw)
+
+
+class ShardedPipeline:
+    """``depth`` agent-sharded frames in flight per rank: frame t's all-gather (RCCL's own stream) and ego stage overlap
+    the local stage of frame t+1, which runs on another HIP stream with its own workspaces (weights shared).  Every rank
+    must submit the same frames in the same order (collectives are matched by issue order).
+
+    ``rotate``: the single-level ego stage of frame t runs on rank t % world only (ShardedFrame's ``fusion_rank``), so a
+    group of N GPUs finishes N frames' fusions concurrently instead of repeating each one N times; the output of frame t
+    is returned by that rank's ``submit`` and is None elsewhere.
+
+    ``backends``: one backend per in-flight slot (the GPU engines come from ``engine.share_weights()``; CPU / gloo tests
+    pass oracle backends, for which no streams are used)."""
+
+    def __init__(self, backends, group=None, rotate=True, device=None):
+        self.frames = [ShardedFrame(b, group) for b in backends]
+        self.world, self.rank = self.frames[0].world, self.frames[0].rank
+        self.rotate = rotate
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.streams = [torch.cuda.Stream(device=device) for _ in backends] if self.cuda else [None] * len(backends)
+        self.t = 0
+
+    @classmethod
+    def from_engine(cls, engine, depth, group=None, rotate=True):
+        engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
+        return cls([EngineBackend(e) for e in engines], group, rotate, engine.device)
+
+    def submit(self, data_dict_local, counts=None, **kw):
+        """Enqueue one frame; returns (output dict or None, event on the frame's stream or None)."""
+        k = self.t % len(self.frames)
+        fr = (self.t % self.world) if (self.rotate and self.world > 1) else None
+        self.t += 1
+        s = self.streams[k]
+        if s is None:
+            return self.frames[k].forward(data_dict_local, counts=counts, fusion_rank=fr, **kw), None
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            out = self.frames[k].forward(data_dict_local, counts=counts, fusion_rank=fr, **kw)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        return out, ev
+
+    def drain(self):
+        for s in self.streams:
+            if s is not None:
+                torch.cuda.current_stream().wait_stream(s)
 
 
 def fusion_column_shards(W, window, world):

@@ -233,40 +233,61 @@ class V2XViTEngine(Where2ComEngine):
         gap.mul_(1.0 / world)
 
     @torch.no_grad()
-    def shard_local_stage(self, data_dict_local, has_ego):
+    def shard_local_stage(self, data_dict_local, has_ego, n_pad=None):
         """Per-rank half of an agent-sharded frame: encoders + backbone + shrink header of THIS rank's
-        agents straight into the all-gather send buffer (n_loc,H,W,256): 36.0 MB per agent at the default grid.
+        agents straight into the all-gather send buffer (n_pad,H,W,256): 36.0 MB per agent at the default grid
+        (n_pad >= the local count pads an uneven frame's message, sharded.py).
         ``data_dict_local`` carries the frame-level ``prior_encoding`` / ``spatial_correction_matrix`` (host
-        metadata of ALL agents, (1,L,.)); stats = [0, canvas non-zeros] (summed over ranks = comm_rate)."""
-        record_len, slots = self.frame_layout(data_dict_local)
-        if len(record_len) != 1:
-            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
-        n = record_len[0]
-        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        metadata of ALL agents, (1,L,.)) even on a rank without agents; stats = [0, canvas non-zeros] (summed over
+        ranks = comm_rate)."""
+        n, record_len, slots = self.shard_frame_agents(data_dict_local)
+        n_pad = n if n_pad is None else int(n_pad)
+        if n_pad < max(n, 1):
+            raise ValueError(f"n_pad = {n_pad} is smaller than this rank's {n} agents")
+        if n > 0:
+            canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        else:
+            ny, nx = self.canvas_dims()
+        dims = self.level_dims(ny, nx)
+        H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        send = self.buf("shard_send", (n_pad * H * Wd * 256,))
+        meta = {"n_loc": n_pad, "H": H, "W": Wd,
+                "prior": data_dict_local["prior_encoding"][0].detach().cpu().numpy(),
+                "scm": data_dict_local["spatial_correction_matrix"][0].detach().cpu().numpy()}
+        if n == 0:
+            return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
         _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
-        dims = self.level_dims(ny, nx)
-        H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
-        send = self.buf("shard_send", (n * H * Wd * 256,))
-        self.trunk(canvas, n, ny, nx, shrink_out=send.view(n, H, Wd, 256))
+        self.trunk(canvas, n, ny, nx, shrink_out=send[:n * H * Wd * 256].view(n, H, Wd, 256))
         stats = torch.stack([torch.zeros((), dtype=torch.int64, device=self.device), nz[0]])
-        meta = {"n_loc": n, "H": H, "W": Wd,
-                "prior": data_dict_local["prior_encoding"][0].detach().cpu().numpy(),
-                "scm": data_dict_local["spatial_correction_matrix"][0].detach().cpu().numpy()}
         return send, stats, meta
+
+    def _gathered_maps(self, recv, meta, world):
+        """(N,H,W,256) maps of the real agents in frame order: the gathered buffer itself, or (uneven frame) its valid
+        slots compacted into a workspace."""
+        n_loc, H, Wd = meta["n_loc"], meta["H"], meta["W"]
+        counts = meta.get("counts") or [n_loc] * world
+        N = sum(counts)
+        if recv.numel() != world * n_loc * H * Wd * 256 or len(counts) != world or max(counts) > n_loc:
+            raise ValueError("gathered buffer has the wrong size")
+        if N > self.L:
+            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        maps = recv.view(world * n_loc, H, Wd, 256)
+        if N != world * n_loc:
+            from .sharded import valid_slots
+            cmp = self.buf("shard_compact", (N, H, Wd, 256))
+            for a, slot in enumerate(valid_slots(counts, n_loc)):
+                cmp[a].copy_(maps[slot])
+            maps = cmp
+        return maps, N, H, Wd
 
     @torch.no_grad()
     def shard_ego_stage(self, recv, stats, meta, world, trace=None, sync_comm_rate=False):
         """Ego half: the gathered (N,H,W,256) buffer is in frame order and is consumed in place by the encoder."""
-        n_loc, H, Wd = meta["n_loc"], meta["H"], meta["W"]
-        N = world * n_loc
-        if recv.numel() != N * H * Wd * 256:
-            raise ValueError("gathered buffer has the wrong size")
-        if N > self.L:
-            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
-        fused = self.encoder(recv.view(N, H, Wd, 256), N, H, Wd, meta["prior"], meta["scm"], trace)
+        maps, N, H, Wd = self._gathered_maps(recv, meta, world)
+        fused = self.encoder(maps, N, H, Wd, meta["prior"], meta["scm"], trace)
         heads = torch.empty((1, self.heads.cout, H, Wd), dtype=torch.float32, device=self.device)
         self.conv(self.heads, fused, 1, H, Wd, heads)
         outs = torch.split(heads, self.head_splits, dim=1)
@@ -287,17 +308,12 @@ class V2XViTEngine(Where2ComEngine):
     def shard_ego_partial(self, recv, stats, meta, world, rank, fusion_world=None, fusion_rank=None):
         """This rank's column strip of the fusion (one tiny all-reduce per block for the split-attention mean) + heads.
         ``fusion_world`` / ``fusion_rank`` default to the agent-sharding world / rank (tests split differently)."""
-        n_loc, H, Wd = meta["n_loc"], meta["H"], meta["W"]
-        N = world * n_loc
-        if recv.numel() != N * H * Wd * 256:
-            raise ValueError("gathered buffer has the wrong size")
-        if N > self.L:
-            raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        maps, N, H, Wd = self._gathered_maps(recv, meta, world)
         fw, fr = (world, rank) if fusion_world is None else (fusion_world, fusion_rank)
         strip = self.fusion_strip(Wd, fw, fr)
         if strip is None:
             raise ValueError(f"map width {Wd} does not split into {fw} strips of whole windows")
-        fused = self.encoder(recv.view(N, H, Wd, 256), N, H, Wd, meta["prior"], meta["scm"], strip=strip)
+        fused = self.encoder(maps, N, H, Wd, meta["prior"], meta["scm"], strip=strip)
         Wc = strip[1]
         heads = torch.empty((1, self.heads.cout, H, Wc), dtype=torch.float32, device=self.device)
         self.conv(self.heads, fused, 1, H, Wc, heads)
@@ -351,5 +367,5 @@ class V2XViTEngine(Where2ComEngine):
         out = {"psm": outs[0], "rm": outs[1]}
         if self.args["obj_head"]:
             out["obj"] = outs[2]
-        out["comm_rate"] = int(nz[0].item()) if sync_comm_rate else nz[0]
+        out["comm_rate"] = int(nz[0].item()) if sync_comm_rate else nz[0].clone()
         return out

@@ -137,20 +137,30 @@ class When2comEngine(Where2ComEngine):
 
     # ------------------------------------------------------------------ agent sharding
     @torch.no_grad()
-    def shard_local_stage(self, data_dict_local, has_ego):
+    def shard_local_stage(self, data_dict_local, has_ego, n_pad=None):
         """Per-rank half: trunk, warp into the ego frame, policy network and key MLP for THIS rank's agents -- i.e. all
         of the per-agent work, 290 of the frame's ~300 GFLOP per agent.  Send buffer = [n_loc warped maps (36.0 MB
         each at the default grid) | n_loc keys (1 KB each) | the ego's projected query (1 KB; zeros on the other
         ranks)], so that every rank can finish the frame (SPMD).  ``data_dict_local`` carries the frame-level
         ``img_pairwise_t_matrix_collab`` and ``shard_rank`` (set by ShardedFrame): global agent index = rank * n_loc + j."""
-        record_len, slots = self.frame_layout(data_dict_local)
-        if len(record_len) != 1:
-            raise ValueError("agent sharding handles one collaborative frame (B = 1) per step")
-        n = record_len[0]
-        canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        n, record_len, slots = self.shard_frame_agents(data_dict_local)
+        n_pad = n if n_pad is None else int(n_pad)
+        if n_pad < max(n, 1):
+            raise ValueError(f"n_pad = {n_pad} is smaller than this rank's {n} agents")
+        if n > 0:
+            canvas, ny, nx = self.encode(data_dict_local, record_len, slots)
+        else:
+            ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
         H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
         C, ks = self.feat_c, self.key_fc[-1][0].shape[0]
+        hwc = H * W * C
+        # message layout: [n_pad warped maps | n_pad keys | the ego's query]; only the first n slots are written
+        send = self.buf("shard_send", (n_pad * (hwc + ks) + ks,))
+        meta = {"n_loc": n_pad, "H": H, "W": W, "C": C, "ks": ks}
+        if n == 0:
+            _lib.check(self.lib.av2x_fill_zero(_ptr(send[n_pad * (hwc + ks):]), ks * 4, self.stream()), "av2x_fill_zero")
+            return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
         s = self.buf("w2_shrink", (n, H, W, C))
         self.trunk(canvas, n, ny, nx, shrink_out=s)
         st = self.stream()
@@ -160,34 +170,38 @@ class When2comEngine(Where2ComEngine):
         pair = data_dict_local["img_pairwise_t_matrix_collab"]
         pair = pair.detach().cpu().numpy() if isinstance(pair, torch.Tensor) else np.asarray(pair)
         theta = normalized_pairwise(pair, H, W, self.w2["voxel_size"][0], self.w2["downsample_rate"])
-        off = int(data_dict_local.get("shard_rank", 0)) * n
-        hwc = H * W * C
-        send = self.buf("shard_send", (n * (hwc + ks) + ks,))
+        off = data_dict_local.get("shard_agent_offset")     # global index of this rank's first agent
+        off = int(data_dict_local.get("shard_rank", 0)) * n if off is None else int(off)
         warped = self.warp(s, theta[0, 0, off:off + n], n, H, W, C, out=send[:n * hwc].view(n, H, W, C))
         qk, keys = self.policy_keys(warped, n, H, W)
-        send[n * hwc:n * (hwc + ks)].view(n, ks).copy_(keys)
+        send[n_pad * hwc:n_pad * hwc + n * ks].view(n, ks).copy_(keys)
         if has_ego:
-            send[n * (hwc + ks):].copy_(self.query_of(qk[0:1]).view(-1))
+            send[n_pad * (hwc + ks):].copy_(self.query_of(qk[0:1]).view(-1))
         else:
-            _lib.check(self.lib.av2x_fill_zero(_ptr(send[n * (hwc + ks):]), ks * 4, st), "av2x_fill_zero")
+            _lib.check(self.lib.av2x_fill_zero(_ptr(send[n_pad * (hwc + ks):]), ks * 4, st), "av2x_fill_zero")
         stats = torch.stack([torch.zeros((), dtype=torch.int64, device=self.device), nz[0]])
-        return send, stats, {"n_loc": n, "H": H, "W": W, "C": C, "ks": ks}
+        return send, stats, meta
 
     @torch.no_grad()
     def shard_ego_stage(self, recv, stats, meta, world, trace=None, sync_comm_rate=False):
         """Ego half: softmax over the gathered keys, weighted sum of the gathered warped maps (read in place from the
         all-gather result), heads."""
         n_loc, H, W, C, ks = meta["n_loc"], meta["H"], meta["W"], meta["C"], meta["ks"]
-        hwc, N = H * W * C, world * n_loc
+        counts = meta.get("counts") or [n_loc] * world
+        hwc, N = H * W * C, sum(counts)
         chunk = n_loc * (hwc + ks) + ks
-        if recv.numel() != world * chunk:
+        if recv.numel() != world * chunk or len(counts) != world or max(counts) > n_loc:
             raise ValueError("gathered buffer has the wrong size")
         if N > 32:
             raise ValueError(f"{N} agents exceed the 32 the fusion kernel takes")
         per_rank = recv.view(world, chunk)
         keys = self.buf("w2_keys_all", (N, ks))
-        keys.view(world, n_loc, ks).copy_(per_rank[:, n_loc * hwc:n_loc * (hwc + ks)].reshape(world, n_loc, ks))
-        maps = [per_rank[r, j * hwc:(j + 1) * hwc] for r in range(world) for j in range(n_loc)]
+        a = 0
+        for r, c in enumerate(counts):
+            if c:
+                keys[a:a + c].copy_(per_rank[r, n_loc * hwc:n_loc * hwc + c * ks].view(c, ks))
+                a += c
+        maps = [per_rank[r, j * hwc:(j + 1) * hwc] for r in range(world) for j in range(counts[r])]
         fused = self.buf("w2_fused", (1, H, W, C))
         coef = self.buf("w2_coef", (1, 32))
         self.fuse(keys, per_rank[0, n_loc * (hwc + ks):], maps, fused[0], coef[0])   # rank 0 holds the ego

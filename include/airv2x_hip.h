@@ -250,6 +250,15 @@ int av2x_postprocess(const float* psm, const float* rm, const float* obj, const 
                      int32_t order_hwl, int32_t top, void* workspace, float* out_corners,
                      float* out_scores, int32_t* out_labels, float* out_boxes, int32_t* out_index,
                      int32_t* counts, av2x_stream_t stream);
+/* Same, with the 4x4 ego transform (data_dict["ego"]["transformation_matrix"], voxel_postprocessor.py:701) read from
+ * DEVICE memory (16 f32, row-major): the reference's inference flow keeps the batch on the GPU, and reading the matrix
+ * on the host would drain the frame's stream every frame. */
+int av2x_postprocess_devt(const float* psm, const float* rm, const float* obj, const float* anchors,
+                          int32_t h, int32_t w, int32_t a, int32_t c, const float* transform16_dev,
+                          const float* range6, float obj_threshold, float nms_threshold,
+                          int32_t order_hwl, int32_t top, void* workspace, float* out_corners,
+                          float* out_scores, int32_t* out_labels, float* out_boxes, int32_t* out_index,
+                          int32_t* counts, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * AP evaluation: true/false positives of one frame.  Replaces the shapely loop of caluclate_tp_fp

@@ -62,7 +62,7 @@ def test_partition_roundtrip_and_index():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cobevt_small_n3", "cobevt_small_n2_c4", "cobevt_full_n4"])
+@pytest.mark.parametrize("name", ["cobevt_small_n3", "cobevt_small_n2_c4", "cobevt_full_n4", "cobevt_full_n8"])   # n8: BASELINE configs[2], L = 8
 def test_gpu_forward_matches_golden_and_oracle(name):
     from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
     fx = load_fixture(name)

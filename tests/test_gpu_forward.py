@@ -37,7 +37,7 @@ def _mask_ok(got, ref, cmap, what):
     return int(((np.asarray(got) != np.asarray(ref)) & near).sum())
 
 
-@pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_small_n1", "w2c_full_n4"])
+@pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_small_n1", "w2c_full_n2", "w2c_full_n4"])   # full_n2: BASELINE configs[0]
 def test_forward_matches_reference_golden(name):
     fx, args, sd, dd, out, tr, model = _run(name)
     s, bs = int(fx["sample_stride"]), int(fx["big_stride"])

@@ -213,3 +213,88 @@ def test_when2com_emulated_ranks_equal_single_gpu_forward():
     for k in ("psm", "rm", "obj"):
         assert torch.equal(out[k], ref[k]), k
     assert out["comm_rate"] == ref["comm_rate"]
+
+
+@pytest.mark.parametrize("n_agents,world", [(4, 3), (3, 2), (4, 8)])
+def test_uneven_emulated_ranks_equal_single_gpu_forward(n_agents, world):
+    """4 agents on 3 ranks ([2,1,1]), 3 on 2 ([2,1]), 4 on 8 (four idle ranks): padded messages, counts-driven fusion;
+    bit-identical to the single-GPU forward."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    from airv2x_perception_amd.opencood_iface.sharded import partition_agents
+    fx = load_fixture("w2c_full_n4")
+    hy, args, sd, dd, voxd, types = case_from_fixture(fx)
+    voxd, types = voxd[:n_agents], types[:n_agents]
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    ref = eng.forward(synth.build_data_dict(voxd, types), sync_comm_rate=True)
+    parts = partition_agents(n_agents, world)
+    counts = [len(p) for p in parts]
+    n_pad = max(counts)
+    sends, stats, meta = [], None, None
+    for r, mine in enumerate(parts):
+        dd_local = synth.build_data_dict([voxd[i] for i in mine], [types[i] for i in mine]) if len(mine) else None
+        send, st, meta = eng.shard_local_stage(dd_local, has_ego=(r == 0), n_pad=n_pad)
+        sends.append(send.clone() if len(mine) else torch.full_like(send, float("nan")))   # padding must never be read
+        stats = st.clone() if stats is None else stats + st
+    meta = dict(meta, counts=counts)
+    out = eng.shard_ego_stage(torch.cat(sends), stats, meta, world=world, sync_comm_rate=True)
+    for k in ("psm", "rm", "obj"):
+        assert torch.equal(out[k], ref[k]), k
+    assert out["comm_rate"] == ref["comm_rate"]
+    assert abs(float(out["com"]) - float(ref["com"])) < 1e-7
+
+
+def test_rccl_group_of_one_rank_runs_the_all_gather_path():
+    """A 1-rank "nccl" (= RCCL) process group on the box's one GPU: communicator set-up + all_gather_into_tensor +
+    all_reduce as ShardedFrame issues them (world > 1 needs more GPUs; the driver's scaling run covers that)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from airv2x_perception_amd import synth
+from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+from airv2x_perception_amd.opencood_iface.sharded import EngineBackend, ShardedFrame
+from tests.helpers import case_from_fixture, load_fixture
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+hy, args, sd, dd, voxd, types = case_from_fixture(load_fixture("w2c_small_n3"))
+m = Airv2xWhere2com(args); m.load_state_dict(sd); m = m.to("cuda").eval()
+eng = m.engine(); eng.stream_k = False
+ref = eng.forward(dd, sync_comm_rate=True)
+out = ShardedFrame(EngineBackend(eng), collectives_when_single=True).forward(dd, counts=[len(types)], sync_comm_rate=True)
+torch.cuda.synchronize()
+assert all(torch.equal(out[k], ref[k]) for k in ("psm", "rm", "obj")) and out["comm_rate"] == ref["comm_rate"]
+dist.destroy_process_group()
+print("RCCL-1-OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-1-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("extra", [[], ["--agents", "3"]])
+def test_bench_two_ranks_on_one_gpu_reports_the_sharded_frame(extra):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run), both ranks on this box's one GPU
+    over gloo (RCCL refuses two ranks per device): the JSON line is the agent-sharded frame."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AV2X_ONE_DEVICE="1", AV2X_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-roofline"] + extra
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    assert "all_gather_into_tensor" in res["config"]["parallelism"]
+    assert ("[2, 1]" if extra else "[2, 2]") in res["config"]["parallelism"]
+    assert res["replica"]["frames_per_s"] > 0 and res["single_frame_latency"]["frames_per_s"] > 0

@@ -26,9 +26,18 @@ class OracleBackend:
     def __init__(self, sd, args):
         self.sd, self.args = sd, args
 
-    def local_stage(self, dd_local, has_ego):
+    def local_stage(self, dd_local, has_ego, n_pad=None):
         sd, args = self.sd, self.args
         mf = args["modality_fusion"]
+        n = 0 if dd_local is None else sum(int(dd_local[t]["record_len"][0]) for t in ("vehicle", "rsu", "drone")
+                                            if dd_local[t]["batch_idxs"])
+        n_pad = n if n_pad is None else n_pad
+        g = args["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]
+        H, W = int(g[1]) // 2, int(g[0]) // 2
+        shapes = [(n_pad, 64, H, W), (n_pad, 128, H // 2, W // 2), (n_pad, 256, H // 4, W // 4)]
+        if n == 0:   # a rank without agents: all-padding message
+            send = torch.zeros(sum(int(np.prod(sh)) for sh in shapes))
+            return send, torch.zeros(2, dtype=torch.int64), {"shapes": shapes}
         feats, record_len = orc.extract_features(dd_local, sd, args)
         sf2d, blocks = orc.backbone_forward(feats, sd, mf["base_bev_backbone"])
         s = orc.shrink_conv(sf2d, sd, mf["shrink_header"])
@@ -41,28 +50,32 @@ class OracleBackend:
         x0 = blocks[0] * masks
         x1 = orc.backbone_block(x0, sd, 1, mf["base_bev_backbone"]["layer_nums"][1])
         x2 = orc.backbone_block(x1, sd, 2, mf["base_bev_backbone"]["layer_nums"][2])
-        send = torch.cat([x0.reshape(-1), x1.reshape(-1), x2.reshape(-1)])
+        pad = lambda x: torch.cat([x, x.new_full((n_pad - n,) + tuple(x.shape[1:]), float("nan"))], 0)  # padding must never be read
+        send = torch.cat([pad(x0).reshape(-1), pad(x1).reshape(-1), pad(x2).reshape(-1)])
         stats = torch.tensor([int(ones.sum()), int(feats.count_nonzero())], dtype=torch.int64)
-        return send, stats, {"shapes": [tuple(x0.shape), tuple(x1.shape), tuple(x2.shape)]}
+        assert [tuple(pad(x).shape) for x in (x0, x1, x2)] == shapes
+        return send, stats, {"shapes": shapes}
 
     def ego_stage(self, recv, stats, meta, world):
         sd, args = self.sd, self.args
         mf = args["modality_fusion"]
         per_rank = recv.numel() // world
+        counts = meta.get("counts") or [meta["shapes"][0][0]] * world
         levels = [[], [], []]
         for r in range(world):
             chunk, off = recv[r * per_rank:(r + 1) * per_rank], 0
             for i, shp in enumerate(meta["shapes"]):
                 n = int(np.prod(shp))
-                levels[i].append(chunk[off:off + n].view(shp))
+                levels[i].append(chunk[off:off + n].view(shp)[:counts[r]])
                 off += n
         ups = []
         for i in range(3):
             x = torch.cat(levels[i], 0)
+            assert not torch.isnan(x).any()
             f = orc.attention_fusion(x).unsqueeze(0)
             ups.append(orc.backbone_deblock(f, sd, i, mf["base_bev_backbone"]["upsample_strides"][i]))
         fs = orc.shrink_conv(torch.cat(ups, 1), sd, mf["shrink_header"])
-        n_total = sum(t.shape[0] for t in levels[0])
+        n_total = sum(counts)
         H, W = levels[0][0].shape[-2:]
         return {"psm": orc.head(fs, sd, "cls_head"), "rm": orc.head(fs, sd, "reg_head"), "obj": orc.head(fs, sd, "obj_head"),
                 "com": stats[0].float() / (n_total * H * W), "comm_rate": int(stats[1])}
@@ -414,13 +427,61 @@ def test_agent_sharded_frame_equals_single_process(tmp_path):
     assert abs(float(got["com"]) - float(ref["com"])) < 1e-6
 
 
+def _uneven_worker(rank, world, port, result_path, n_agents, rotate):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    args, sd, voxd = _frame()
+    types = TYPES[:n_agents]
+    parts = partition_agents(n_agents, world)
+    counts = [len(p) for p in parts]
+    mine = parts[rank]
+    dd_local = synth.build_data_dict([voxd[i] for i in mine], [types[i] for i in mine]) if len(mine) else None
+    from airv2x_perception_amd.opencood_iface.sharded import ShardedPipeline
+    pipe = ShardedPipeline([OracleBackend(sd, args), OracleBackend(sd, args)], rotate=rotate)
+    outs = []
+    with torch.no_grad():
+        for t in range(world):      # frame t's ego stage runs on rank t % world when rotating
+            outs.append(pipe.submit(dd_local, counts=counts)[0])
+    pipe.drain()
+    if rotate:
+        assert [o is not None for o in outs] == [t == rank for t in range(world)]
+    else:
+        assert all(o is not None for o in outs)
+    mineout = outs[rank]
+    torch.save({k: mineout[k] for k in ("psm", "rm", "obj", "com", "comm_rate")}, f"{result_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_agents,rotate", [(3, 4, True), (2, 3, False), (3, 2, True)])
+def test_uneven_agent_counts_and_rotating_ego_stage(tmp_path, world, n_agents, rotate):
+    """4 agents on 3 ranks ([2,1,1]), 3 on 2 ([2,1]) and 2 on 3 ([1,1,0]: an idle rank sends only padding -- NaNs in the
+    oracle backend, so a fusion that read them would fail): every rank's frame equals the single-process forward."""
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_uneven_worker, args=(world, _free_port(), path, n_agents, rotate), nprocs=world, join=True)
+    args, sd, voxd = _frame()
+    dd = synth.build_data_dict(voxd[:n_agents], TYPES[:n_agents])
+    with torch.no_grad():
+        ref = orc.where2com_forward(dd, sd, args)
+    for r in range(world):
+        got = torch.load(f"{path}.{r}")
+        for k in ("psm", "rm", "obj"):
+            assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), (r, k)
+        assert got["comm_rate"] == ref["comm_rate"]
+        assert abs(float(got["com"]) - float(ref["com"])) < 1e-6
+
+
 def test_partition_agents():
     assert [list(r) for r in partition_agents(8, 4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]
     assert [list(r) for r in partition_agents(4, 1)] == [[0, 1, 2, 3]]
+    assert [list(r) for r in partition_agents(5, 2)] == [[0, 1, 2], [3, 4]]
+    assert [list(r) for r in partition_agents(5, 4)] == [[0, 1], [2], [3], [4]]
+    assert [list(r) for r in partition_agents(4, 8)] == [[0], [1], [2], [3], [], [], [], []]
+    assert [list(r) for r in partition_agents(1, 2)] == [[0], []]
     with pytest.raises(ValueError):
-        partition_agents(5, 2)
-    with pytest.raises(ValueError):
-        partition_agents(1, 2)
+        partition_agents(0, 2)
 
 
 def test_single_rank_needs_no_process_group():

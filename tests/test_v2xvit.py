@@ -85,7 +85,7 @@ def test_gpu_warp_and_roi_mask():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n4"])
+@pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n4", "v2xvit_full_n8"])   # n8: BASELINE configs[3], L = 8
 def test_gpu_forward_matches_golden(name):
     """small grid: every tensor; full AirV2X grid (BASELINE size, 4 agents x 8192 points): strided samples + sums of
     the reference's outputs."""
@@ -188,7 +188,7 @@ def test_gpu_batch_of_two_frames_equals_two_single_frames():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n4"])
+@pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n4", "v2xvit_full_n8"])
 def test_gpu_ego_only_last_layer_is_exact(name):
     """V2XTransformer returns output[:, 0]: the last encoder layer computes the other agents only as HGT keys / values
     (k | v' projections).  Bit-identical to computing every agent, and within tolerance of the reference golden."""

@@ -253,14 +253,19 @@ def postprocess_golden(name, hy_ref, hy, out):
     return g
 
 
-def load_ref_hypes_cobevt(lidar_range):
+def load_ref_hypes_cobevt(lidar_range, max_cav=(3, 2, 2)):
     from opencood.hypes_yaml.yaml_utils import load_yaml
     src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_cobevt.yaml")
-    if lidar_range is None:
+    if lidar_range is None and tuple(max_cav) == (3, 2, 2):
         return load_yaml(src)
     txt = open(src).read()
-    r = lidar_range
-    txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+    if lidar_range is not None:
+        r = lidar_range
+        txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+    if tuple(max_cav) != (3, 2, 2):   # a larger agent axis: the YAML's max_cav block
+        txt, nsub = re.subn(r"vehicle: 3\n(\s+)rsu: 2\n(\s+)drone: 2",
+                            f"vehicle: {max_cav[0]}\n\\1rsu: {max_cav[1]}\n\\2drone: {max_cav[2]}", txt)
+        assert nsub == 1, "max_cav block not found in the CoBEVT YAML"
     with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
         f.write(txt)
         path = f.name
@@ -269,16 +274,16 @@ def load_ref_hypes_cobevt(lidar_range):
     return h
 
 
-def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride, compression=0, head_stride=1):
+def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride, compression=0, head_stride=1, max_cav=(3, 2, 2)):
     """Airv2xCoBEVT (fused axial attention) on the real reference vs oracle/cobevt_oracle.py."""
     from airv2x_perception_amd import synth
     from oracle import cobevt_oracle as cob
     from oracle import voxelize_oracle as vox
     from opencood.models.airv2x_cobevt import Airv2xCoBEVT
 
-    hy_ref = load_ref_hypes_cobevt(lidar_range)
+    hy_ref = load_ref_hypes_cobevt(lidar_range, max_cav)
     hy_ref["model"]["args"]["compression"] = compression
-    hy = synth.default_hypes_cobevt(lidar_range, compression=compression)
+    hy = synth.default_hypes_cobevt(lidar_range, max_cav, compression=compression)
     a_ref = {k: v for k, v in hy_ref["model"]["args"].items()}
     check_hypes(a_ref, {k: v for k, v in hy["model"]["args"].items() if k != "fax_fusion"})
     args = hy["model"]["args"]
@@ -723,80 +728,47 @@ def run_when2com_case(name, lidar_range, types, n_points, seed, mode="softmax", 
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def main():
+SMALL = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0]
+T8 = ["vehicle", "vehicle", "vehicle", "vehicle", "rsu", "rsu", "drone", "drone"]   # synth.agent_types_for(8), frame order
+
+# group name -> the calls that write its fixtures.  EVERY way of running this script goes through this table, so
+# `gen_golden.py <group>` writes exactly the files (and key sets) the bare run writes.
+GROUPS = {
+    "w2c": lambda: (run_case("w2c_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 0, 1, 4),
+                    run_case("w2c_small_n1", SMALL, ["vehicle"], 700, 1, 1, 4),
+                    # BASELINE configs[0]: 2 agents (plumbing case) on the default grid
+                    run_case("w2c_full_n2", None, ["vehicle", "rsu"], 8192, 3, 5, 20),
+                    # default AirV2X grid, BASELINE configs[1]: 4 agents x 8192 points; strided samples + sums
+                    run_case("w2c_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 5, 20)),
+    "cobevt": lambda: run_cobevt_case("cobevt_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 0, 8),
+    "cobevt_c4": lambda: run_cobevt_case("cobevt_small_n2_c4", SMALL, ["vehicle", "drone"], 700, 2, 8, compression=4),
+    "v2xvit": lambda: run_v2xvit_case("v2xvit_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4),
+    "eval": lambda: eval_golden(),
+    "points": lambda: points_golden(),
+    "cobevt_full": lambda: run_cobevt_case("cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 20, head_stride=5),
+    "v2xvit_full": lambda: run_v2xvit_case("v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, (2, 1, 1), 20,
+                                           head_stride=5),
+    # BASELINE configs[2] / [3]: 8 agents, agent axis L = 8 (max_cav 4/2/2)
+    "cobevt_n8": lambda: run_cobevt_case("cobevt_full_n8", None, T8, 8192, 0, 20, head_stride=5, max_cav=(4, 2, 2)),
+    "v2xvit_n8": lambda: run_v2xvit_case("v2xvit_full_n8", None, T8, 8192, 0, (4, 2, 2), 20, head_stride=5),
+    "when2com": lambda: (run_when2com_case("when2com_small_n3", SMALL, ["vehicle", "rsu", "drone"], 1500, 5),
+                         run_when2com_case("when2com_small_n2", SMALL, ["vehicle", "vehicle"], 1500, 6)),
+    "when2com_full": lambda: run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16),
+    "submodules": lambda: submodules_golden(),
+}
+GROUPS["full"] = lambda: (GROUPS["cobevt_full"](), GROUPS["v2xvit_full"]())
+
+
+def main(groups=None):
     os.chdir(tempfile.mkdtemp())
     import_reference()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    # small grid: 128 x 64 pillars, every tensor stored in full
-    run_case("w2c_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 1, 4)
-    run_case("w2c_small_n1", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle"], 700, 1, 1, 4)
-    # default AirV2X grid, BASELINE config: 4 agents x 8192 points; strided samples + sums
-    run_case("w2c_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 5, 20)
-    run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
-    run_v2xvit_case("v2xvit_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4)
-    run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
-    eval_golden()
-    points_golden()
-    full_grid_transformers()
-    small = [-25.6, -12.8, -3, 25.6, 12.8, 1]
-    run_when2com_case("when2com_small_n3", small, ["vehicle", "rsu", "drone"], 1500, 5)
-    run_when2com_case("when2com_small_n2", small, ["vehicle", "vehicle"], 1500, 6)
-    run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16)
-    submodules_golden()
-
-
-def full_grid_transformers():
-    """Default AirV2X grid (704 x 200 pillars), 4 agents x 8192 points: strided samples + sums."""
-    if "v2xvit_only" not in sys.argv:
-        run_cobevt_case("cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 20, head_stride=5)
-    if "cobevt_only" in sys.argv:
-        return
-    run_v2xvit_case("v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, (2, 1, 1), 20, head_stride=5)
+    for g in (groups or [g for g in GROUPS if g != "full"]):
+        if g not in GROUPS:
+            raise SystemExit(f"unknown group {g!r}; one of {sorted(GROUPS)}")
+        GROUPS[g]()
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "cobevt":
-        os.chdir(tempfile.mkdtemp())
-        import_reference()
-        torch.set_num_threads(8)
-        run_cobevt_case("cobevt_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, 8)
-    elif len(sys.argv) > 1 and sys.argv[1] == "cobevt_c4":
-        os.chdir(tempfile.mkdtemp())
-        import_reference()
-        torch.set_num_threads(8)
-        run_cobevt_case("cobevt_small_n2_c4", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "drone"], 700, 2, 8, compression=4)
-    elif len(sys.argv) > 1 and sys.argv[1] == "full":
-        os.chdir(tempfile.mkdtemp())
-        import_reference()
-        torch.set_num_threads(8)
-        full_grid_transformers()
-    elif len(sys.argv) > 1 and sys.argv[1] == "when2com_full":
-        import_reference()
-        torch.set_num_threads(8)
-        run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16)
-    elif len(sys.argv) > 1 and sys.argv[1] == "when2com":
-        import_reference()
-        torch.set_num_threads(8)
-        small = [-25.6, -12.8, -3, 25.6, 12.8, 1]
-        run_when2com_case("when2com_small_n3", small, ["vehicle", "rsu", "drone"], 1500, 5)
-        run_when2com_case("when2com_small_n2", small, ["vehicle", "vehicle"], 1500, 6)
-    elif len(sys.argv) > 1 and sys.argv[1] == "submodules":
-        import_reference()
-        torch.set_num_threads(8)
-        submodules_golden()
-    elif len(sys.argv) > 1 and sys.argv[1] == "points":
-        os.chdir(tempfile.mkdtemp())
-        import_reference()
-        points_golden()
-    elif len(sys.argv) > 1 and sys.argv[1] == "eval":
-        os.chdir(tempfile.mkdtemp())
-        import_reference()
-        eval_golden()
-    elif len(sys.argv) > 1 and sys.argv[1] == "v2xvit":
-        os.chdir(tempfile.mkdtemp())
-        import_reference()
-        torch.set_num_threads(8)
-        run_v2xvit_case("v2xvit_small_n3", [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4)
-    else:
-        main()
+    main(sys.argv[1:] or None)
