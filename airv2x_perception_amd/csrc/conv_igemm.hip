@@ -16,6 +16,13 @@
 // contiguous range of tiles so that halo rows / weights are re-used out of its private L2.
 #include "conv_common.hpp"
 
+// Test-only: -DAV2X_ABLATE=<bits> (tools/micro/ablate.sh) removes pieces of the prefetch-2 main loop to see what each costs
+// (1 global loads, 2 LDS stores, 4 barriers, 8 LDS fragment reads after the first step).  Results are garbage, only the
+// timing means something; the product library is never built with it.
+#ifndef AV2X_ABLATE
+#define AV2X_ABLATE 0
+#endif
+
 namespace {
 
 // Stream-K fix-up: tile t was cut between workgroups g_lo..g_hi of the SK kernel; their raw accumulators
@@ -207,8 +214,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
         }                                                                                                 \
     }
     const int li = lane & 31, lh = lane >> 5;
+#if AV2X_ABLATE & 8
+    f32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];   // hoisted: only the first two K-steps read their fragments
+#define AV2X_FRAG_DECL
+#define AV2X_FRAG_ON (s < 2)
+#else
+#define AV2X_FRAG_DECL f32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+#define AV2X_FRAG_ON true
+#endif
 #define AV2X_FRAGS(FA, FB, G)                                                                                       \
-    {                                                                                                               \
+    if (AV2X_FRAG_ON) {                                                                                             \
         _Pragma("unroll") for (int a = 0; a < MT; ++a) FA[a] =                                                      \
             *reinterpret_cast<const f32x4*>(Ab + a * 32 * LDA + (G)*8);                                             \
         _Pragma("unroll") for (int c = 0; c < NT; ++c) FB[c] =                                                      \
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     {                                                                                                               \
         const float* Ab = As + (BUF) * (BM * LDA) + (wm0 + li) * LDA + lh * 4;                                      \
         const float* Bb = Bs + (BUF) * (8 * BN * 4) + (lh * BN + wn0 + li) * 4;                                     \
-        f32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];                                                                   \
+        AV2X_FRAG_DECL                                                                                              \
         AV2X_FRAGS(fa0, fb0, 0);                                                                                    \
         AV2X_FRAGS(fa1, fb1, 1);                                                                                    \
         AV2X_MFMAS(fa0, fb0);                                                                                       \
@@ -259,31 +274,39 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
         }
     } else {
         // invariant at the top of an even step s: tile s is in LDS buffer 0, tile s+1 is in flight in set 0
+#define ABL_GLOAD(ra, rb) { if (!(AV2X_ABLATE & 1)) AV2X_GLOAD(ra, rb, tap, cc) }
+#define ABL_LSTORE(ra, rb, BUF) { if (!(AV2X_ABLATE & 2)) AV2X_LSTORE(ra, rb, BUF) }
+#define ABL_SYNC() { if (!(AV2X_ABLATE & 4)) __syncthreads(); }
         AV2X_ADVANCE();
         AV2X_GLOAD(ra0, rb0, tap, cc);
         for (int s = 0; s < nst; s += 2) {
             AV2X_ADVANCE();
-            AV2X_GLOAD(ra1, rb1, tap, cc);  // tile s+2
+            ABL_GLOAD(ra1, rb1);  // tile s+2
             __builtin_amdgcn_sched_barrier(0);
             AV2X_COMPUTE(0);
             __builtin_amdgcn_sched_barrier(0);
-            AV2X_LSTORE(ra0, rb0, 1);  // tile s+1 -> buffer 1
+            ABL_LSTORE(ra0, rb0, 1);  // tile s+1 -> buffer 1
             AV2X_TILE_END();
-            __syncthreads();
+            ABL_SYNC();
             if (s + 1 < nst) {
                 AV2X_ADVANCE();
-                AV2X_GLOAD(ra0, rb0, tap, cc);  // tile s+3
+                ABL_GLOAD(ra0, rb0);  // tile s+3
                 __builtin_amdgcn_sched_barrier(0);
                 AV2X_COMPUTE(1);
                 __builtin_amdgcn_sched_barrier(0);
-                AV2X_LSTORE(ra1, rb1, 0);  // tile s+2 -> buffer 0
+                ABL_LSTORE(ra1, rb1, 0);  // tile s+2 -> buffer 0
                 AV2X_TILE_END();
-                __syncthreads();
+                ABL_SYNC();
             }
         }
     }
+#undef ABL_GLOAD
+#undef ABL_LSTORE
+#undef ABL_SYNC
 #undef AV2X_COMPUTE
 #undef AV2X_FRAGS
+#undef AV2X_FRAG_DECL
+#undef AV2X_FRAG_ON
 #undef AV2X_MFMAS
 #undef AV2X_ADVANCE
 #undef AV2X_TILE_END
@@ -352,6 +375,7 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
 }
 
 #include "conv_igemm_bf16.inc"
+#include "conv_igemm_glds.inc"
 
 }  // namespace
 
@@ -382,7 +406,7 @@ extern "C" int av2x_conv2d_res(const av2x_conv_desc* d, const float* in, const f
 }
 
 extern "C" uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs) {
-    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x03ff;
+    const int bm = (tile >> 16) & 0x7fff, bn = tile & 0x01ff;
     return (tile & 0x2000) ? 2ull * (unsigned)sk_wgs * bm * bn * sizeof(float) : 0ull;
 }
 
@@ -434,7 +458,7 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     p.w_bytes = (unsigned)w_bytes;
     hipStream_t st = av2x::as_stream(stream);
 
-    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x03ff;
+    int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x01ff;
     if (d->tile & 0x0400) {   // split-3: fp32-accurate products from three bf16 terms per operand; w = [3] bf16 planes
         p.w_bytes = (unsigned)(w_bytes / 2 * 3);
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
@@ -458,6 +482,24 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
         if (!w8b && bm == 64 && bn == 64) return launch_bf16<64, 64, 32, 32>(p, st);
         if (!w8b && bm == 128 && bn == 32) return launch_bf16<128, 32, 32, 32>(p, st);
         return av2x::fail("av2x_conv2d: unsupported bf16 tile %dx%d", bm, bn);
+    }
+    if (d->tile & 0x0200) {  // LDS-DMA operand path (conv_igemm_glds.inc): 2 LDS stages, or 3 with the prefetch-2 flag
+        if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
+        const bool w8g = (d->tile & 0x8000) != 0, s3 = (d->tile & 0x4000) != 0, skg = (d->tile & 0x2000) != 0;
+        if (skg && d->sk_wgs <= 0) return av2x::fail("av2x_conv2d: stream-K tile needs sk_wgs > 0");
+#define AV2X_GLDS_CASE(W8, BMv, BNv, WMv, WNv)                                                                              \
+        if (w8g == W8 && bm == BMv && bn == BNv) {                                                                          \
+            if (skg) return s3 ? launch_glds_sk<BMv, BNv, WMv, WNv, 3>(p, d->sk_wgs, workspace, workspace_bytes, st)       \
+                               : launch_glds_sk<BMv, BNv, WMv, WNv, 2>(p, d->sk_wgs, workspace, workspace_bytes, st);      \
+            return s3 ? launch_glds<BMv, BNv, WMv, WNv, 3>(p, st) : launch_glds<BMv, BNv, WMv, WNv, 2>(p, st);             \
+        }
+        AV2X_GLDS_CASE(true, 128, 128, 64, 32)
+        AV2X_GLDS_CASE(true, 128, 64, 32, 32)
+        AV2X_GLDS_CASE(false, 128, 128, 64, 64)
+        AV2X_GLDS_CASE(false, 128, 64, 64, 32)
+        AV2X_GLDS_CASE(false, 64, 64, 32, 32)
+#undef AV2X_GLDS_CASE
+        return av2x::fail("av2x_conv2d: unsupported LDS-DMA tile %dx%d", bm, bn);
     }
     if (d->tile & 0x1000) {  // persistent whole-tile schedule: sk_wgs workgroups (prefetch-2 pipeline)
         if (d->sk_wgs <= 0) return av2x::fail("av2x_conv2d: persistent tile needs sk_wgs > 0");

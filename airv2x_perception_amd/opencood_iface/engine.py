@@ -316,7 +316,7 @@ class Where2ComEngine:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x03ff))
+            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x01ff))
             if bn & 0x2000:  # launch_sk(): equal iteration ranges, then the number of non-empty ones
                 total = wgs * L.ks * L.ks * (L.cin // 32)
                 per = -(-total // min(d.sk_wgs, total))
@@ -372,7 +372,7 @@ class Where2ComEngine:
         ws = self.sk_workspace()
         st = self.stream()
         for bm, bn, g in cands:
-            if L.coutp % (bn & 0x03ff) or ((bn & 0x03ff) == 32 and L.coutp != 32):
+            if L.coutp % (bn & 0x01ff) or ((bn & 0x01ff) == 32 and L.coutp != 32):
                 continue
             d.tile, d.sk_wgs = (bm << 16) | bn, g
             call = lambda: _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), None,
@@ -388,7 +388,7 @@ class Where2ComEngine:
             if bn & 0x2000:
                 t *= 1.03  # prefer the bit-reproducible schedules unless stream-K is clearly faster
             if os.environ.get("AV2X_TUNE_LOG"):
-                print(f"[tune] M={d.n * d.ho * d.wo} cin={L.cin} coutp={L.coutp} ks={L.ks} tile={bm}x{bn & 0xfff} flags={bn & 0xf000:#x} "
+                print(f"[tune] M={d.n * d.ho * d.wo} cin={L.cin} coutp={L.coutp} ks={L.ks} tile={bm}x{bn & 0x1ff} flags={bn & 0xfe00:#x} "
                       f"wgs={g}: {t / 3 * 1e3:.1f} us", flush=True)
             if t < best_t:
                 best, best_t = (d.tile, g), t

@@ -527,17 +527,17 @@ def main(argv=None, hooks=None, device=None):
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{k[0]}x{k[1] & 0x03ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
+        tkey = lambda k: f"{k[0]}x{k[1] & 0x01ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS), 4), "traffic": traffic, "traffic_note": traffic_note,
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else 'f32')}<{dom[0]},{dom[1] & 0x03ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
+            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else 'f32')}<{dom[0]},{dom[1] & 0x01ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
                       + (" prefetch-2" if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x03ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
+            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                              f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>"
-                             + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x03ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
+                             + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},

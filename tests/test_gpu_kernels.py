@@ -221,6 +221,74 @@ def test_conv_persistent_schedule_is_bit_identical(lib, tile, wgs, shape):
     assert not torch.isnan(outs[1]).any()
 
 
+GLDS_TILES = [(128 << 16) | 128 | 0x8200, (128 << 16) | 64 | 0x8200, (128 << 16) | 128 | 0x0200, (128 << 16) | 64 | 0x0200,
+              (64 << 16) | 64 | 0x0200, (128 << 16) | 128 | 0xc200, (128 << 16) | 64 | 0xc200, (128 << 16) | 128 | 0x4200,
+              (128 << 16) | 64 | 0x4200, (64 << 16) | 64 | 0x4200]
+
+
+@pytest.mark.parametrize("tile", GLDS_TILES)
+@pytest.mark.parametrize("shape", [(2, 23, 31, 256, 256, 1, 1, 0), (1, 19, 27, 64, 128, 3, 2, 0), (3, 9, 14, 128, 128, 3, 1, 0),
+                                   (1, 25, 88, 256, 256, 3, 1, 0), (2, 10, 12, 128, 512, 1, 1, 2)])
+def test_conv_lds_dma_tiles_are_bit_identical(lib, tile, shape):
+    """tile flag 0x0200: operands go L2 -> LDS by buffer_load ... lds (XOR-swizzled lane-linear image, zero fill of the
+    halo by the descriptor's range check) with 2 or 3 (0x4000) LDS stages.  Same K order per output element as the
+    register-staged kernel, so every tile must reproduce it bit for bit -- 1x1 and 3x3, stride 2, ragged M, deconv
+    scatter (mode 1, up = 2), residual + GELU epilogue."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, pack_deconv_weight
+    n, h, w, cin, cout, ks, stride, up = shape
+    mode = 1 if up > 0 else (2 if up < 0 else 0)
+    pad = 1 if ks == 3 else 0
+    g = torch.Generator().manual_seed(cin + cout + ks + (tile & 0xffff))
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    if mode == 1:
+        wp, coutp = pack_deconv_weight(torch.randn(cin, cout // (up * up), up, up, generator=g) / np.sqrt(cin))
+        cout_d = cout // (up * up)
+    else:
+        wp, coutp = pack_conv_weight(torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks))
+        cout_d = cout
+    if coutp % (tile & 0x1ff):
+        pytest.skip("tile does not divide the padded output width")
+    sc, sh = (torch.rand(cout_d, generator=g) + 0.5).cuda(), torch.randn(cout_d, generator=g).cuda()
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    oshape = (n, ho * max(up, 1), wo * max(up, 1), cout_d) if mode != 2 else (n, cout_d, ho, wo)
+    res = torch.randn(oshape, generator=g).cuda() if mode == 0 else None
+    outs = []
+    for t in (tile & ~0x0200, tile):
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=ho, wo=wo, cout=cout_d, coutp=coutp, out_ctot=cout_d,
+                          out_coff=0, ks=ks, stride=stride, pad=pad, relu=2 if mode == 0 else 1, mode=mode, up=max(up, 1), tile=t, sk_wgs=0)
+        out = torch.full(oshape, float("nan"), device="cuda")
+        _lib.check(lib.av2x_conv2d_res(byref(d), _p(x), _p(wp.cuda()), _p(sc), _p(sh), _p(res), _p(out), _stream()), "conv")
+        outs.append(out)
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("tile,wgs", [((128 << 16) | 64 | 0xa200, 96), ((128 << 16) | 128 | 0xe200, 37), ((64 << 16) | 64 | 0x6200, 1000),
+                                      ((128 << 16) | 64 | 0x2200, 50)])
+def test_conv_lds_dma_stream_k_equals_register_staged_stream_k(lib, tile, wgs):
+    """stream-K on the LDS-DMA kernel: same iteration ranges, same partial layout, same fix-up -> bit-identical to the
+    register-staged stream-K schedule of the same tile / workgroup count."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    n, h, w, cin, cout, ks = 2, 25, 44, 256, 256, 3
+    g = torch.Generator().manual_seed(wgs)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wp, coutp = pack_conv_weight(torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks))
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    ws = torch.empty(int(lib.av2x_conv2d_sk_workspace_bytes(tile, wgs)) // 4 + 16, device="cuda")
+    outs = []
+    for t in ((tile & ~0x0200) | 0x4000, tile):   # the register-staged stream-K kernel always runs the prefetch-2 pipeline
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=cout,
+                          out_coff=0, ks=ks, stride=1, pad=1, relu=1, mode=0, up=1, tile=t, sk_wgs=wgs)
+        out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+        _lib.check(lib.av2x_conv2d_sk(byref(d), _p(x), _p(wp.cuda()), _p(sc), _p(sh), None, _p(out), _p(ws), ws.numel() * 4,
+                                      _stream()), "conv sk")
+        outs.append(out)
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_conv_rejects_bad_arguments(lib):
     from airv2x_perception_amd import _lib
     d = _lib.ConvDesc()
