@@ -21,9 +21,11 @@ struct ConvParams {
     int ks, stride, pad, relu, mode, up;
     int M, tiles_n, cchunks, steps;
     unsigned in_bytes, w_bytes;
-    // stream-K (SK kernels only): the tiles x steps iteration space is cut into gridDim.x equal
-    // contiguous ranges of sk_per iterations; partial accumulators go to ws (see conv_fixup_f32)
-    int sk_per, sk_total;
+    // stream-K (SK kernels only): workgroup g first computes the whole tiles g, g + G, ... < sk_dp (data-parallel part:
+    // sk_dp = the largest multiple of the grid size G that fits), then its share of the REMAINDER tiles sk_dp .. tiles-1,
+    // whose (tile, K-step) iteration space of sk_total iterations is cut into contiguous ranges of sk_per; partial
+    // accumulators of cut tiles go to ws (see conv_fixup_f32).  Fewer tiles than workgroups: sk_dp = 0, pure stream-K.
+    int sk_per, sk_total, sk_dp;
     float* ws;
 };
 

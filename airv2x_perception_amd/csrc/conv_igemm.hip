@@ -32,13 +32,14 @@ namespace {
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_fixup_f32(const ConvParams p) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN, NTHR = 64 * (BM / WM) * (BN / WN);
-    const int tile = blockIdx.x, tid = threadIdx.x;
-    const int it0 = tile * p.steps, it1 = it0 + p.steps - 1;
+    const int rt = blockIdx.x, tid = threadIdx.x;   // rt: index among the remainder (stream-K) tiles
+    const int tile = p.sk_dp + rt;
+    const int it0 = rt * p.steps, it1 = it0 + p.steps - 1;
     const int g_lo = it0 / p.sk_per, g_hi = it1 / p.sk_per;
     if (g_lo == g_hi) return;  // computed whole by one workgroup, already written
     f32x16 acc[MT][NT];
     for (int g = g_lo; g <= g_hi; ++g) {
-        const int slot = ((g * p.sk_per) / p.steps == tile) ? 2 * g : 2 * g + 1;
+        const int slot = ((g * p.sk_per) / p.steps == rt) ? 2 * g : 2 * g + 1;
         const float* wsp = p.ws + (size_t)slot * (BM * BN) + tid;
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -90,15 +91,19 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
     int it = SK ? swz * p.sk_per : swz * p.steps;
     const int it_end = SK ? min(it + p.sk_per, p.sk_total) : it + p.steps;
     bool first_seg = true;
+    int dp_t = swz;   // SK: next whole tile of the data-parallel part (dp_t < p.sk_dp), before the stream-K range
+    if (SK && !(dp_t < p.sk_dp || it < it_end)) return;
     // PERSIST: tiles [pt0, pt1) of this workgroup (sk_total = number of tiles)
     const int pq = PERSIST ? p.sk_total / nb : 0, pr = PERSIST ? p.sk_total - pq * nb : 0;
     const int pt0 = swz * pq + min(swz, pr), pt1 = pt0 + pq + (swz < pr ? 1 : 0);
     if (PERSIST && pt0 >= pt1) return;
     do {
-    const int tile = PERSIST ? pt0 : (SK ? it / p.steps : swz);
-    const int ks0 = SK ? it - tile * p.steps : 0;
+    const bool dp = SK && dp_t < p.sk_dp;
+    const int rt = SK ? it / p.steps : 0;   // remainder-tile index of the stream-K range
+    const int tile = PERSIST ? pt0 : (SK ? (dp ? dp_t : p.sk_dp + rt) : swz);
+    const int ks0 = (SK && !dp) ? it - rt * p.steps : 0;
     // number of K-steps of this pass: a tile, a stream-K segment, or (PERSIST) the whole flat stream
-    const int nst = PERSIST ? (pt1 - pt0) * p.steps : (SK ? min(p.steps - ks0, it_end - it) : p.steps);
+    const int nst = PERSIST ? (pt1 - pt0) * p.steps : ((SK && !dp) ? min(p.steps - ks0, it_end - it) : p.steps);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
 
     // ---- per-thread gather bookkeeping for the A tile: row (tid>>3)+32*i, k-quad tid&7
@@ -328,10 +333,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 1) void conv_igemm_f32(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) wsp[((a * NT + c) * 16 + r) * NTHR] = acc[a][c][r];
     }
-    it += nst;
-    first_seg = false;
+    if (dp) dp_t += nb;
+    else { it += nst; first_seg = false; }
     if (SK) __syncthreads();  // the next segment re-fills LDS buffer 0
-    } while (SK && it < it_end);
+    } while (SK && (dp_t < p.sk_dp || it < it_end));
 }
 
 template <int BM, int BN, int WM, int WN, bool DEEP = false>
@@ -347,19 +352,40 @@ int launch(const ConvParams& p, hipStream_t st) {
     return av2x::check_launch("conv_igemm_f32");
 }
 
-// Stream-K launch: `wgs` persistent workgroups share tiles x steps iterations; then the fix-up.
+// Stream-K schedule of `wgs` persistent workgroups over `tiles` tiles (see ConvParams): fills sk_dp / sk_per / sk_total,
+// returns the grid size; *fix_tiles = remainder tiles the fix-up kernel has to visit (0 = none is cut).
+inline int sk_schedule(ConvParams& q, int tiles, int wgs, int* fix_tiles) {
+    const long long all = (long long)tiles * q.steps;
+    if (wgs > all) wgs = (int)all;
+    q.sk_dp = (tiles / wgs) * wgs;
+    const int rem = tiles - q.sk_dp;
+    const long long total = (long long)rem * q.steps;
+    q.sk_total = (int)total;
+    q.sk_per = 1;
+    *fix_tiles = 0;
+    int grid = wgs;
+    if (total > 0) {
+        long long per = (total + wgs - 1) / wgs;
+        const long long floor_len = q.steps < 4 ? q.steps : 4;   // no segments shorter than 4 K-steps
+        if (per < floor_len) per = floor_len;
+        q.sk_per = (int)per;
+        const int active = (int)((total + per - 1) / per);
+        if (q.sk_dp == 0) grid = active;
+        if (per % q.steps != 0) *fix_tiles = rem;
+    }
+    return grid;
+}
+
+// Stream-K launch, then the fix-up of the cut tiles.
 template <int BM, int BN, int WM, int WN>
 int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_bytes, hipStream_t st) {
     const int tiles_m = (p.M + BM - 1) / BM;
     ConvParams q = p;
     q.tiles_n = p.CoutP / BN;
     const int tiles = tiles_m * q.tiles_n;
-    const long long total = (long long)tiles * p.steps;
-    if (total >= (1ll << 31)) return av2x::fail("av2x_conv2d: stream-K iteration space too large");
-    if (wgs > total) wgs = (int)total;
-    q.sk_total = (int)total;
-    q.sk_per = (int)((total + wgs - 1) / wgs);
-    wgs = (int)((total + q.sk_per - 1) / q.sk_per);
+    if ((long long)tiles * p.steps >= (1ll << 31)) return av2x::fail("av2x_conv2d: stream-K iteration space too large");
+    int fix_tiles = 0;
+    wgs = sk_schedule(q, tiles, wgs, &fix_tiles);
     q.ws = ws;
     if (!ws || ws_bytes < 2ull * wgs * BM * BN * sizeof(float))
         return av2x::fail("av2x_conv2d: stream-K workspace too small (%llu B, need %llu B)", ws_bytes,
@@ -369,8 +395,8 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
     lds_limit.ensure(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, WM, WN, true, 1>), lds);
     constexpr int NTHR = 64 * (BM / WM) * (BN / WN);
     hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WM, WN, true, 1>), dim3(wgs), dim3(NTHR), lds, st, q);
-    if (q.sk_per % p.steps != 0)  // some tile is cut
-        hipLaunchKernelGGL((conv_fixup_f32<BM, BN, WM, WN>), dim3(tiles), dim3(NTHR), 0, st, q);
+    if (fix_tiles > 0)  // some tile is cut
+        hipLaunchKernelGGL((conv_fixup_f32<BM, BN, WM, WN>), dim3(fix_tiles), dim3(NTHR), 0, st, q);
     return av2x::check_launch("conv_igemm_f32 (stream-K)");
 }
 
@@ -449,7 +475,7 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     p.cchunks = p.Cin / BK;
     p.steps = p.ks * p.ks * p.cchunks;
     p.tiles_n = 0;
-    p.sk_per = 0; p.sk_total = 0; p.ws = nullptr;
+    p.sk_per = 0; p.sk_total = 0; p.sk_dp = 0; p.ws = nullptr;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->h * d->w * d->in_ctot * 4ull;
     const unsigned long long w_bytes = (unsigned long long)p.ks * p.ks * p.Cin * p.CoutP * 4ull;
     if (in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31))

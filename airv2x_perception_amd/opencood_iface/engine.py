@@ -105,10 +105,16 @@ class Where2ComEngine:
         self.conv_sk_wgs = 0        # persistent workgroups when conv_tile carries the stream-K flag 0x2000
         self.autotune = True        # time the candidate tiles once per distinct conv shape, keep the fastest
         self.tile_cache = {}
-        # stream-K candidates in the autotune set: faster on layers whose tile count does not fill the chip,
-        # but the K-split changes the fp32 summation order (<= ~1e-5 relative), so results then depend on
-        # the tuning outcome / agent count.  False = every candidate is bit-identical (reproducible mode).
-        self.stream_k = os.environ.get("AV2X_STREAM_K", "1") != "0"
+        # Stream-K (a K-split changes the fp32 summation order, <= ~1e-5 relative, so WHICH schedule runs must not depend on
+        # a wall-clock measurement):
+        #   "rule" (default) a layer runs stream-K iff its shape says so (sk_rule(): fewer 64x64 tiles than the 768
+        #                    persistent workgroups), always with the same tile and workgroup count -> the split points,
+        #                    and therefore every output bit, are a function of the layer shape alone; the autotuner only
+        #                    picks among implementations of that one schedule (register-staged / LDS-DMA: bit-identical);
+        #   False / "off"    data-parallel schedules only (results do not depend on how many agents share a launch:
+        #                    what the agent-sharded frame is compared against bit for bit);
+        #   "tune"           legacy: stream-K candidates compete by wall-clock (not reproducible across processes).
+        self.stream_k = {"0": False, "off": False, "1": "rule", "rule": "rule", "tune": "tune"}[os.environ.get("AV2X_STREAM_K", "rule")]
         # AMP mode (what torch.autocast does to Conv2d / Linear): bf16 matrix-core operands, fp32 accumulation and
         # fp32 activations in HBM (conv_igemm_bf16); LayerNorm / softmax / attention stay fp32.  Off = exact fp32.
         self.amp = False
@@ -292,10 +298,11 @@ class Where2ComEngine:
             d.tile = self.conv_tile
             d.sk_wgs = self.conv_sk_wgs if (d.tile & 0x2000) else 0
         elif self.autotune:
-            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, self.stream_k, vflag)
+            skc = self.sk_class(n * d.ho * d.wo, L, vflag)
+            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, skc, vflag)
             t = self.tile_cache.get(key)
             if t is None:
-                t = self._tune(d, x, L, out)
+                t = self._tune(d, x, L, out, skc, key)
                 self.tile_cache[key] = t
             d.tile, d.sk_wgs = t
         else:
@@ -317,23 +324,34 @@ class Where2ComEngine:
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
             wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x01ff))
-            if bn & 0x2000:  # launch_sk(): equal iteration ranges, then the number of non-empty ones
-                total = wgs * L.ks * L.ks * (L.cin // 32)
-                per = -(-total // min(d.sk_wgs, total))
-                wgs = -(-total // per)
+            if bn & 0x2000:  # sk_schedule() of conv_igemm.hip: whole tiles first, the remainder tiles split evenly
+                steps = L.ks * L.ks * (L.cin // 32)
+                g = min(d.sk_wgs, wgs * steps)
+                dp = (wgs // g) * g
+                total = (wgs - dp) * steps
+                if dp == 0 and total > 0:
+                    per = max(-(-total // g), min(4, steps))
+                    g = -(-total // per)
+                wgs = g
             self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1, wgs,
                                  (n * d.ho * d.wo, L.cin, ncols, L.ks, L.stride)))
         return ho, wo
 
-    # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2)
+    # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)
     TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),
                        (128, 128 | 0x4000), (128, 64 | 0x4000), (64, 64 | 0x4000), (64, 128 | 0x4000),
-                       (128, 128 | 0xc000), (128, 64 | 0xc000), (128, 32))
+                       (128, 128 | 0xc000), (128, 64 | 0xc000), (128, 32),
+                       (128, 128 | 0x8200), (128, 128 | 0xc200), (128, 64 | 0x8200), (128, 64 | 0xc200), (128, 128 | 0x0200),
+                       (128, 64 | 0x0200), (64, 64 | 0x0200), (64, 64 | 0x4200))
 
-    # stream-K candidates (BM, BN | flags | 0x2000, persistent workgroups); tools/sk_bench.py sweep
+    # "tune" mode only: stream-K candidates (BM, BN | flags | 0x2000, persistent workgroups); tools/sk_bench.py sweep
     SK_CANDIDATES = ((128, 64 | 0xe000, 768), (128, 64 | 0xe000, 512), (128, 128 | 0xe000, 256), (128, 128 | 0xe000, 512),
-                     (64, 64 | 0x6000, 1024))
+                     (64, 64 | 0x6000, 1024), (64, 64 | 0x2200, 768), (128, 64 | 0xe200, 512))
     SK_MAX_TILES = 1200   # only layers with at most this many 128x64 tiles are tried with stream-K
+    # "rule" mode: THE stream-K schedule (64x64 tiles, 768 persistent workgroups, tools/sk_bench.py) and its three
+    # bit-identical implementations the tuner may choose from
+    SK_RULE_WGS = 768
+    SK_RULE_IMPLS = ((64, 64 | 0x2200, 768), (64, 64 | 0x6200, 768), (64, 64 | 0x6000, 768))
     # persistent whole-tile candidates (flag 0x1000; bit-identical to the data-parallel schedule): short-K GEMMs
     # (1x1 convs / Linears, <= PERSIST_MAX_STEPS K-steps per tile) where the per-tile prologue is a large share
     PERSIST_CANDIDATES = ((128, 64 | 0xd000, 512), (128, 128 | 0xd000, 512), (64, 64 | 0x5000, 1024), (128, 64 | 0x5000, 768))
@@ -342,38 +360,111 @@ class Where2ComEngine:
     AMP_CANDIDATES = ((128, 128 | 0x8800, 0), (128, 64 | 0x8800, 0), (64, 64 | 0x0800, 0), (128, 64 | 0x0800, 0),
                       (128, 128 | 0x0800, 0), (128, 32 | 0x0800, 0))
 
+    def sk_class(self, m, L, vflag=0):
+        """Numerics class of a conv launch: "rule" = the fixed stream-K schedule applies (a pure function of the shape),
+        "tune" = legacy timing-driven stream-K, False = data-parallel (bit-identical whatever tile is picked)."""
+        mode = "tune" if self.stream_k is True else self.stream_k
+        if vflag or not mode:
+            return False
+        if mode == "tune":
+            return "tune" if -(-m // 128) * (L.coutp // 64 if L.coutp % 64 == 0 else 1 << 30) <= self.SK_MAX_TILES else False
+        steps = L.ks * L.ks * (L.cin // 32)
+        tiles64 = -(-m // 64) * (L.coutp // 64) if L.coutp % 64 == 0 else 0
+        return "rule" if (steps >= 8 and 64 <= tiles64 <= self.SK_RULE_WGS) else False
+
     def sk_workspace(self):
         """Partial-accumulator scratch of av2x_conv2d_sk, sized for the largest stream-K candidate."""
-        need = max(int(self.lib.av2x_conv2d_sk_workspace_bytes((bm << 16) | bn, g)) for bm, bn, g in self.SK_CANDIDATES)
+        cands = self.SK_CANDIDATES + self.SK_RULE_IMPLS
+        need = max(int(self.lib.av2x_conv2d_sk_workspace_bytes((bm << 16) | bn, g)) for bm, bn, g in cands)
         need = max(need, int(self.lib.av2x_conv2d_sk_workspace_bytes(self.conv_tile, self.conv_sk_wgs)) if self.conv_tile else 0)
         return self.buf("sk_ws", (need // 4,))
 
-    def _tune(self, d, x, L, out):
-        """Pick the fastest workgroup tile for this conv shape (all tiles give bit-identical results:
-        the K order of every output element does not depend on the tile).  Runs outside graph capture."""
+    # ---- persisted tuning results: every candidate inside a numerics class is bit-identical, so a cached (or stale) pick
+    # only affects speed.  In-tree table (made on an MI355X by tools/make_tune_table.py) first, then the user's cache.
+    TUNE_TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuned_gfx950.json")
+    _tune_disk = None
+
+    @classmethod
+    def tune_cache_path(cls):
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        return os.path.join(base, "airv2x_perception_amd", "tune_gfx950.json")
+
+    @classmethod
+    def tune_disk(cls):
+        if cls._tune_disk is None:
+            import json
+            tab = {}
+            if os.environ.get("AV2X_TUNE_CACHE", "1") != "0":
+                for path in (cls.TUNE_TABLE, cls.tune_cache_path()):
+                    try:
+                        tab.update(json.load(open(path)))
+                    except (OSError, ValueError):
+                        pass
+            cls._tune_disk = tab
+        return cls._tune_disk
+
+    @classmethod
+    def tune_store(cls, skey, value):
+        cls.tune_disk()[skey] = list(value)
+        if os.environ.get("AV2X_TUNE_CACHE", "1") == "0":
+            return
+        import json
+        try:
+            path = cls.tune_cache_path()
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            mine = {}
+            try:
+                mine = json.load(open(path))
+            except (OSError, ValueError):
+                pass
+            mine[skey] = list(value)
+            tmp = f"{path}.{os.getpid()}.tmp"
+            json.dump(mine, open(tmp, "w"), indent=0, sort_keys=True)
+            os.replace(tmp, path)
+        except OSError:
+            pass   # a read-only home only costs the next process a re-tune
+
+    def _candidates(self, d, L, skc):
+        if self.amp:
+            cands = list(self.AMP_CANDIDATES)
+        elif self.split3:
+            cands = [(bm, (bn & ~0x0800) | 0x0400, g) for bm, bn, g in self.AMP_CANDIDATES]
+        elif skc == "rule":
+            cands = list(self.SK_RULE_IMPLS)
+        else:
+            cands = [(bm, bn, 0) for bm, bn in self.TILE_CANDIDATES]
+            if L.ks * L.ks * (L.cin // 32) <= self.PERSIST_MAX_STEPS:
+                cands += list(self.PERSIST_CANDIDATES)
+            if skc == "tune":
+                cands += list(self.SK_CANDIDATES)
+        return [(bm, bn, g) for bm, bn, g in cands
+                if L.coutp % (bn & 0x01ff) == 0 and not ((bn & 0x01ff) == 32 and L.coutp != 32)]
+
+    def _tune(self, d, x, L, out, skc=False, key=None):
+        """Pick the fastest implementation for this conv shape inside its numerics class (all of a class's candidates give
+        bit-identical results: the K order of every output element does not depend on the tile; the "rule" class is ONE
+        stream-K schedule).  Runs outside graph capture; the pick is persisted (tune_store)."""
+        cands = self._candidates(d, L, skc)
         if torch.cuda.is_current_stream_capturing():
+            if skc == "rule":
+                bm, bn, g = cands[-1]
+                return (bm << 16) | bn, g
             bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
             return (bm << 16) | bn | (0x0800 if self.amp else (0x0400 if self.split3 else 0)), 0
+        skey = "|".join(str(v) for v in key) if key is not None else None
+        if skey is not None and skc != "tune":
+            hit = self.tune_disk().get(skey)
+            if hit is not None and any(((bm << 16) | bn, g) == tuple(hit) for bm, bn, g in cands):
+                return int(hit[0]), int(hit[1])
         best, best_t = None, float("inf")
         wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         # tune into a scratch output: `out` may alias the input / residual (in-place transformer updates)
         ho = d.ho * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         wo = d.wo * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         scratch = torch.empty(d.n * ho * wo * max(d.out_ctot, L.cout), dtype=torch.float32, device=self.device)
-        cands = [(bm, bn, 0) for bm, bn in self.TILE_CANDIDATES]
-        if L.ks * L.ks * (L.cin // 32) <= self.PERSIST_MAX_STEPS:
-            cands += list(self.PERSIST_CANDIDATES)
-        if self.amp:
-            cands = list(self.AMP_CANDIDATES)
-        elif self.split3:
-            cands = [(bm, (bn & ~0x0800) | 0x0400, g) for bm, bn, g in self.AMP_CANDIDATES]
-        elif self.stream_k and -(-(d.n * d.ho * d.wo) // 128) * (L.coutp // 64 if L.coutp % 64 == 0 else 1 << 30) <= self.SK_MAX_TILES:
-            cands += list(self.SK_CANDIDATES)
         ws = self.sk_workspace()
         st = self.stream()
         for bm, bn, g in cands:
-            if L.coutp % (bn & 0x01ff) or ((bn & 0x01ff) == 32 and L.coutp != 32):
-                continue
             d.tile, d.sk_wgs = (bm << 16) | bn, g
             call = lambda: _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), None,
                                                               _ptr(scratch), _ptr(ws), ws.numel() * 4, st), "av2x_conv2d")
@@ -385,13 +476,15 @@ class Where2ComEngine:
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
-            if bn & 0x2000:
+            if skc == "tune" and bn & 0x2000:
                 t *= 1.03  # prefer the bit-reproducible schedules unless stream-K is clearly faster
             if os.environ.get("AV2X_TUNE_LOG"):
                 print(f"[tune] M={d.n * d.ho * d.wo} cin={L.cin} coutp={L.coutp} ks={L.ks} tile={bm}x{bn & 0x1ff} flags={bn & 0xfe00:#x} "
                       f"wgs={g}: {t / 3 * 1e3:.1f} us", flush=True)
             if t < best_t:
                 best, best_t = (d.tile, g), t
+        if skey is not None and skc != "tune":
+            self.tune_store(skey, best)
         return best
 
     def run_block(self, i, x, n, h, w, tag, out=None):
@@ -884,9 +977,10 @@ class FramePipeline:
     """Throughput mode: ``depth`` independent frames in flight, each on its own HIP stream with its own
     workspaces (weights shared).  Every layer launch ends in a partially filled last round of
     workgroups and the ego stage of a frame is a single-image tail; a second frame's kernels fill those
-    gaps.  Per-frame results are bit-identical to the sequential data-parallel schedule; per-frame latency
-    grows.  Stream-K is switched off while a frame is submitted here: its persistent workgroups fill the
-    chip on their own, so overlapping frames gains nothing on top (measured: -0.8 % vs +5 % single-stream)."""
+    gaps.  Per-frame results are bit-identical to the sequential forward of the same engine (the "rule" stream-K
+    schedule is a function of the layer shapes and stays on); per-frame latency grows.  Only the legacy timing-driven
+    stream-K mode ("tune") is switched off here: its persistent workgroups fill the chip on their own, so overlapping
+    frames gained nothing on top (measured: -0.8 % vs +5 % single-stream)."""
 
     def __init__(self, engine, depth=2):
         self.engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
@@ -902,7 +996,10 @@ class FramePipeline:
         s = self.streams[k]
         s.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
         eng = self.engines[k]
-        saved, eng.stream_k = eng.stream_k, eng.stream_k and (len(self.engines) == 1 or os.environ.get("AV2X_PIPE_SK") == "1")
+        # "rule" stays on (a frame's bits must not depend on whether it was pipelined); the legacy timing-driven stream-K
+        # gains nothing with several frames in flight and is switched off
+        legacy = eng.stream_k is True or eng.stream_k == "tune"
+        saved, eng.stream_k = eng.stream_k, (eng.stream_k if (not legacy or len(self.engines) == 1 or os.environ.get("AV2X_PIPE_SK") == "1") else False)
         try:
             with torch.cuda.stream(s):
                 out = eng.forward(data_dict, **kw)

@@ -503,6 +503,20 @@ def main(argv=None, hooks=None, device=None):
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and a.mode == "replica":
         eng.use_graph = False
+        # what a hipEvent pair adds around ONE launch on this stream (record -> kernel start, kernel end -> record): the pair
+        # around a 4-byte fill minus that kernel's own ~1.5 us; subtracted from every per-launch figure below so that they are
+        # comparable with rocprofv3's kernel durations (profiles/)
+        from ctypes import c_void_p as _vp
+        tiny = torch.zeros(1, device=dev)
+        ovs = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.lib.av2x_fill_zero(_vp(tiny.data_ptr()), 4, eng.stream())
+            e1.record()
+            ovs.append((e0, e1))
+        torch.cuda.synchronize()
+        ev_over = max(0.0, float(np.median([x.elapsed_time(y) for x, y in ovs])) * 1e-3 - 1.5e-6)
         eng.profile = []
         for _ in range(a.steps):
             model(dd)
@@ -515,29 +529,34 @@ def main(argv=None, hooks=None, device=None):
             d = per.setdefault(tile, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
-            d[2] += e0.elapsed_time(e1) * 1e-3
+            dur = max(e0.elapsed_time(e1) * 1e-3 - ev_over * (2 if tile[1] & 0x2000 else 1), 1e-7)   # stream-K = GEMM + fix-up launch
+            d[2] += dur
             g = grids.setdefault(tile, {})
             g[wgs] = g.get(wgs, 0) + 1
             sh = shapes.setdefault((shp, tile, wgs), [0, 0.0, 0.0])
             sh[0] += 1
             sh[1] += flops
-            sh[2] += e0.elapsed_time(e1) * 1e-3
+            sh[2] += dur
         dom = max(per, key=lambda k: per[k][2])
         cnt, fl, sec = per[dom]
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{k[0]}x{k[1] & 0x01ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
+        tkey = lambda k: f"{'g' if k[1] & 0x0200 else ''}{k[0]}x{k[1] & 0x01ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS), 4), "traffic": traffic, "traffic_note": traffic_note,
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else 'f32')}<{dom[0]},{dom[1] & 0x01ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
-                      + (" prefetch-2" if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
-                             f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>"
+            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
+                      + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
+            "rocprof_rows": ((f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+                              f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
+                              f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
+            "event_pair_overhead_us": round(ev_over * 1e6, 2),
+            "sustained_clock": "fp32-MFMA loops run at 2.0 GHz on random operands (2.32 on zeros; GRBM_GUI_ACTIVE / duration, "
+                               "profiles/r02_dvfs_clock.txt): peak at that clock = 131.5 TFLOP/s; frac is against the 2.4 GHz figure",
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},
@@ -546,8 +565,8 @@ def main(argv=None, hooks=None, device=None):
             **({"per_shape": [{"M_cin_cout_ks_stride": list(k[0]), "tile": tkey(k[1]), "wgs": k[2], "launches_per_frame": v[0] / a.steps,
                                "us": round(v[2] / v[0] * 1e6, 1), "tflops": round(v[1] / v[2] / 1e12, 1)}
                               for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])]} if a.per_shape else {}),
-            "timing": "second pass of K sequential frames (the single_stream schedule, stream-K on), hipEvent pair around every conv "
-                      "launch on the launch stream; with several frames in flight the kernels of different frames overlap and "
+            "timing": "second pass of K sequential frames (the single_stream schedule), hipEvent pair around every conv "
+                      "launch on the launch stream minus event_pair_overhead_us; with several frames in flight the kernels of different frames overlap and "
                       "per-launch durations are not separable (rocprofv3 summary of this mode: profiles/*_inflight1.txt)",
         }
 

@@ -1,7 +1,10 @@
 """GPU, whole chain a1 -> a20 on seeded frames: raw clouds -> av2x_prepare_points -> av2x_voxelize -> Airv2xWhere2com ->
-av2x_postprocess -> av2x_eval_tp_fp / AP, against the same chain built from the oracles on the CPU.  The box SETS must
-agree (same anchors survive the NMS), TP/FP lists and AP@0.3/0.5/0.7 must be equal: this is the synthetic-data form of
-the north star's "AP within +-0.5 pt of the reference" (no dataset on the box)."""
+av2x_postprocess -> av2x_eval_tp_fp / AP, against the same chain built from the oracles on the CPU.  The model stage is
+compared within the fp32 tolerance; the post-process and the AP evaluation are discontinuous (score order, IoU
+thresholds), so their parity is EXACT on identical inputs (the oracle post-process / evaluation of the device's own head
+maps: same boxes, same order, same TP/FP lists, same AP@0.3/0.5/0.7) and the two complete chains must produce the same
+boxes up to threshold-sitting decisions (>= 95 % of the oracle chain's boxes within 5 cm).  This is the synthetic-data
+form of the north star's "AP within +-0.5 pt of the reference" (no dataset on the box)."""
 import numpy as np
 import pytest
 import torch
@@ -68,15 +71,27 @@ def test_points_to_ap_chain_matches_oracle_chain():
         dd = synth.build_data_dict(voxd, TYPES, max_cav_num=args["max_cav_num"])
         with torch.no_grad():
             ref = orc.where2com_forward(dd, sd, args)
-        rc, rs, rl, rb = po.post_process(ref["psm"], ref["rm"], ref["obj"], torch.from_numpy(anchors), T, hy["postprocess"],
-                                         hy["postprocess"]["anchor_args"]["cav_lidar_range"])
+        # (1) the model: head maps of the device chain vs the oracle chain, fp32 tolerance
+        for k in ("psm", "rm", "obj"):
+            np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=2e-4, atol=2e-4)
+        # (2) the post-process is discontinuous (score order, IoU > 0.15), so its EXACT parity is checked on identical
+        # inputs: the oracle post-process of the DEVICE's head maps must return the same boxes in the same order
+        rc, rs, rl, rb = po.post_process(out["psm"].cpu(), out["rm"].cpu(), out["obj"].cpu(), torch.from_numpy(anchors), T,
+                                         hy["postprocess"], hy["postprocess"]["anchor_args"]["cav_lidar_range"])
         assert (corners is None) == (rc is None)
         if rc is None:
             continue
         assert corners.shape == rc.shape, (corners.shape, rc.shape)        # the same boxes survive
         assert torch.equal(labels.cpu(), rl)
-        np.testing.assert_allclose(scores.cpu().numpy(), rs.numpy(), rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(corners.cpu().numpy(), rc.numpy(), rtol=1e-3, atol=2e-3)
+        np.testing.assert_allclose(scores.cpu().numpy(), rs.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(corners.cpu().numpy(), rc.numpy(), rtol=1e-4, atol=2e-4)
+        # (3) end to end against the oracle chain (its own head maps): up to decisions that sit on a threshold the same
+        # boxes come out -- at least 95 % of the oracle's boxes have a device box within 5 cm
+        oc = po.post_process(ref["psm"], ref["rm"], ref["obj"], torch.from_numpy(anchors), T, hy["postprocess"],
+                             hy["postprocess"]["anchor_args"]["cav_lidar_range"])[0]
+        if oc is not None:
+            dist = torch.cdist(oc.mean(1)[:, :2], corners.cpu().mean(1)[:, :2])
+            assert float((dist.min(1).values < 0.05).float().mean()) >= 0.95
         n_boxes += rc.shape[0]
         # ---- ground truth: some detections (jittered) + some unrelated boxes
         g = np.random.default_rng(100 + frame)

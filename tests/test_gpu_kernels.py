@@ -138,6 +138,10 @@ SK_CASES = [
     (1, 9, 14, 64, 64, 3, 1, 0, (128 << 16) | 64 | 0x6000, 100000),     # more workgroups than iterations
     (2, 12, 20, 256, 256, 3, 1, 0, (128 << 16) | 128 | 0x6000, 4),      # ranges = whole tiles only (no fix-up)
     (2, 7, 11, 128, 128, 1, 1, 2, (128 << 16) | 64 | 0xe000, 24),       # deconv up=2 scatter epilogue
+    (2, 25, 44, 256, 256, 3, 1, 0, (128 << 16) | 64 | 0xe000, 20),      # 72 tiles on 20 workgroups: 60 whole + 12 split
+    (2, 25, 44, 256, 256, 3, 1, 0, (128 << 16) | 64 | 0xe000, 50),      # 50 whole + 22 remainder tiles split over 50
+    (2, 25, 44, 256, 256, 3, 1, 0, (128 << 16) | 64 | 0xe000, 24),      # 72 = 3 x 24: whole tiles only, nothing is cut
+    (2, 25, 44, 256, 256, 3, 1, 0, (128 << 16) | 128 | 0xe200, 25),     # LDS-DMA kernel, 36 tiles: 25 whole + 11 split
 ]
 
 
@@ -265,7 +269,7 @@ def test_conv_lds_dma_tiles_are_bit_identical(lib, tile, shape):
 
 
 @pytest.mark.parametrize("tile,wgs", [((128 << 16) | 64 | 0xa200, 96), ((128 << 16) | 128 | 0xe200, 37), ((64 << 16) | 64 | 0x6200, 1000),
-                                      ((128 << 16) | 64 | 0x2200, 50)])
+                                      ((128 << 16) | 64 | 0x2200, 50), ((128 << 16) | 64 | 0xa200, 20), ((128 << 16) | 128 | 0xa200, 7)])
 def test_conv_lds_dma_stream_k_equals_register_staged_stream_k(lib, tile, wgs):
     """stream-K on the LDS-DMA kernel: same iteration ranges, same partial layout, same fix-up -> bit-identical to the
     register-staged stream-K schedule of the same tile / workgroup count."""

@@ -20,8 +20,9 @@ LAYERS = {
     "shrink3_n1": (1, 100, 352, 256, 256, 3, 1),
     "shrink3_n4": (4, 100, 352, 256, 256, 3, 1),
 }
-TILES = {"64x64d": (64, 64 | 0x4000), "128x64w8d": (128, 64 | 0xc000), "128x128w8d": (128, 128 | 0xc000),
-         "128x64d": (128, 64 | 0x4000), "128x128d": (128, 128 | 0x4000), "64x128d": (64, 128 | 0x4000)}
+TILES = {"128x64w8d": (128, 64 | 0xc000), "g128x64w8": (128, 64 | 0x8200), "g128x64w8s3": (128, 64 | 0xc200),
+         "128x64d": (128, 64 | 0x4000), "g128x64": (128, 64 | 0x0200),
+         "128x128w8d": (128, 128 | 0xc000), "g128x128w8": (128, 128 | 0x8200), "64x64d": (64, 64 | 0x4000), "g64x64": (64, 64 | 0x0200)}
 
 
 def main():
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--layers", default="")
     ap.add_argument("--wgs", default="256,512,768,1024")
+    ap.add_argument("--tiles", default="")
     a = ap.parse_args()
     lib = _lib.load()
     st = c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -65,7 +67,9 @@ def main():
             return e0.elapsed_time(e1) * 1e3 / a.iters
 
         for tn, (bm, bn) in TILES.items():
-            if coutp % (bn & 0x07ff):
+            if a.tiles and tn not in a.tiles.split(","):
+                continue
+            if coutp % (bn & 0x01ff):
                 continue
             base = run((bm << 16) | bn, 0, y0)
             line = f"   {tn:11s} dp:{base:6.1f}us {flops/base/1e6:5.1f}TF |"
