@@ -1,0 +1,69 @@
+"""Build recipe for `oracle/_ref/` (TEST INFRASTRUCTURE, build container only): compiles the reference's OWN C++ rotated-IoU
+(/root/reference/opencood/pcdet_utils/iou3d_nms/src/iou3d_cpu.cpp: box_overlap :128-229, iou_bev :231-238,
+boxes_iou_bev_cpu :241-262) from the sources where they lie, with g++ against the torch headers of this image and the
+CUDA toolkit headers that ship inside the triton wheel (the file includes <cuda.h> / <cuda_runtime_api.h> only for
+the `__device__` annotation macros; nothing of CUDA is linked).  Nothing is copied into the repo; the only output is
+oracle/_ref/iou3d_cpu_ref.so (git-ignored).  Used by tools/gen_golden.py (group `iou_pin`) to store the reference's
+IoUs for random rotated box pairs under tests/golden/, and by nobody else.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SRC = "/root/reference/opencood/pcdet_utils/iou3d_nms/src"
+OUT = os.path.join(HERE, "_ref", "iou3d_cpu_ref.so")
+
+
+def available():
+    return os.path.exists(os.path.join(REF_SRC, "iou3d_cpu.cpp"))
+
+
+def build(force=False):
+    """-> path of the built library, or None when the reference tree is absent (the GPU box)."""
+    if not available():
+        return OUT if os.path.exists(OUT) else None
+    src = os.path.join(REF_SRC, "iou3d_cpu.cpp")
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) > os.path.getmtime(src):
+        return OUT
+    import torch
+    import triton
+    tinc = os.path.join(os.path.dirname(torch.__file__), "include")
+    cuda_inc = os.path.join(os.path.dirname(triton.__file__), "backends", "nvidia", "include")
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", src, "-o", OUT,
+           "-I", REF_SRC, "-I", tinc, "-I", os.path.join(tinc, "torch", "csrc", "api", "include"), "-I", cuda_inc,
+           "-I", sysconfig.get_paths()["include"], "-D_GLIBCXX_USE_CXX11_ABI=" + str(int(torch._C._GLIBCXX_USE_CXX11_ABI)),
+           "-L", tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("reference iou3d_cpu.cpp did not build:\n" + r.stdout[-4000:])
+    return OUT
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    """The reference's boxes_iou_bev_cpu(boxes_a (N,7), boxes_b (M,7)) -> (N,M) float32 [x,y,z,dx,dy,dz,heading]."""
+    import ctypes
+
+    import torch
+    lib = ctypes.CDLL(build())
+    # C++ symbol: int boxes_iou_bev_cpu(at::Tensor, at::Tensor, at::Tensor) -- called through its mangled name with
+    # at::Tensor passed by value = a pointer to an intrusive_ptr holder on this ABI; go through torch.ops-free ctypes by
+    # handing over the TensorImpl pointers torch exposes
+    fn = lib._Z17boxes_iou_bev_cpuN2at6TensorES0_S0_
+    fn.restype = ctypes.c_int
+    a = boxes_a.contiguous().float()
+    b = boxes_b.contiguous().float()
+    out = torch.zeros(a.shape[0], b.shape[0])
+    # at::Tensor is a single pointer (c10::intrusive_ptr<TensorImpl>); non-trivially-copyable classes are passed by
+    # invisible reference on the Itanium ABI: the callee receives the ADDRESS of a temporary holding that pointer
+    hold = [ctypes.c_void_p(t._cdata) for t in (a, b, out)]
+    fn(ctypes.byref(hold[0]), ctypes.byref(hold[1]), ctypes.byref(hold[2]))
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force=True))

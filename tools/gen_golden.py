@@ -728,6 +728,110 @@ def run_when2com_case(name, lidar_range, types, n_points, seed, mode="softmax", 
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def _bev_quads(boxes):
+    """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,4,2) float32 BEV corners (counter-clockwise)."""
+    x, y, dx, dy, h = boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]
+    lx = np.stack([-dx, dx, dx, -dx], 1) / 2
+    ly = np.stack([-dy, -dy, dy, dy], 1) / 2
+    c, s_ = np.cos(h)[:, None], np.sin(h)[:, None]
+    return np.stack([x[:, None] + lx * c - ly * s_, y[:, None] + lx * s_ + ly * c], -1).astype(np.float32)
+
+
+def iou_pin_golden(name="iou_pin"):
+    """Rotated BEV IoU of the reference's OWN C++ (pcdet_utils/iou3d_nms/src/iou3d_cpu.cpp:128-262, built by
+    oracle/build_ref.py) on 4096 random box pairs, 2048 of them walked by bisection to within 1e-3 of the thresholds the
+    path uses (NMS 0.15, AP 0.3 / 0.5 / 0.7).  Pins oracle/nms_oracle.c and the device IoU kernels against
+    reference-held arithmetic (the shapely/GEOS polygon code itself stays absent)."""
+    sys.path.insert(0, ROOT)
+    from oracle import build_ref
+    g = np.random.default_rng(2024)
+    n = 2048
+
+    def rand_boxes(k):
+        b = np.zeros((k, 7), np.float32)
+        b[:, 0:2] = g.uniform(-50, 50, (k, 2))
+        b[:, 2] = -1.0
+        b[:, 3] = g.uniform(1.2, 6.0, k)
+        b[:, 4] = g.uniform(1.0, 2.6, k)
+        b[:, 5] = 1.6
+        b[:, 6] = g.uniform(-np.pi, np.pi, k)
+        return b
+
+    def ref_iou(a, b):   # elementwise pairs
+        out = np.empty(a.shape[0], np.float32)
+        for i0 in range(0, a.shape[0], 256):
+            m = build_ref.boxes_iou_bev(torch.from_numpy(a[i0:i0 + 256]), torch.from_numpy(b[i0:i0 + 256]))
+            out[i0:i0 + 256] = torch.diagonal(m).numpy()
+        return out
+
+    a1 = rand_boxes(n)
+    b1 = rand_boxes(n)
+    b1[:, 0:2] = a1[:, 0:2] + g.normal(0, 1.5, (n, 2)).astype(np.float32)     # overlapping neighbours
+    a2, b2 = rand_boxes(n), rand_boxes(n)
+    thr = np.array([0.15, 0.3, 0.5, 0.7], np.float32)[g.integers(0, 4, n)]
+    direction = g.uniform(0, 2 * np.pi, n)
+    b2[:, 3:5] = a2[:, 3:5] * g.uniform(0.9, 1.1, (n, 2)).astype(np.float32)
+    b2[:, 6] = a2[:, 6] + g.normal(0, 0.3, n).astype(np.float32)
+    lo, hi = np.zeros(n), np.full(n, 8.0)            # offset along `direction`: IoU falls from ~1 to 0
+    for _ in range(40):
+        mid = (lo + hi) / 2
+        b2[:, 0] = a2[:, 0] + (mid * np.cos(direction)).astype(np.float32)
+        b2[:, 1] = a2[:, 1] + (mid * np.sin(direction)).astype(np.float32)
+        v = ref_iou(a2, b2)
+        lo = np.where(v > thr, mid, lo)
+        hi = np.where(v > thr, hi, mid)
+    # leave the pairs spread within +-1e-3 of the threshold instead of exactly on it
+    mid = lo + (hi - lo) * 0.5 + g.normal(0, 2e-3, n)
+    b2[:, 0] = a2[:, 0] + (mid * np.cos(direction)).astype(np.float32)
+    b2[:, 1] = a2[:, 1] + (mid * np.sin(direction)).astype(np.float32)
+    A, B = np.concatenate([a1, a2]), np.concatenate([b1, b2])
+    iou = ref_iou(A, B)
+    near = np.abs(iou[n:] - thr) < 1e-3
+    print(f"[{name}] {int(near.sum())}/{n} constructed pairs within 1e-3 of their threshold; random pairs: "
+          f"{int((iou[:n] > 0).sum())} overlap, max {iou[:n].max():.3f}")
+    assert near.sum() > n // 2
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, boxes_a=A, boxes_b=B, quads_a=_bev_quads(A), quads_b=_bev_quads(B), iou=iou,
+                        near_threshold=np.concatenate([np.zeros(n, np.float32), thr]))
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def voxel_pin_golden(name="voxel_pin"):
+    """The reference's own numpy voxelizer (data_utils/pre_processor/voxel_preprocessor.py:30-80; not the registered
+    spconv one) on clouds where its arithmetic is well defined: 1 m voxels and integer range minima, for which its
+    `pcd - floor(min) / voxel` equals (pcd - min) / voxel.  Pins, order-independently, the SET of occupied voxels, the
+    per-voxel point counts (capped at T = 32) and WHICH points a full voxel keeps (the first T in cloud order)."""
+    cm = _stub("cumm")                                    # the package __init__ imports the spconv-based class as well
+    cm.tensorview = _stub("cumm.tensorview")
+    sp = _stub("spconv")
+    sp.utils = _stub("spconv.utils", Point2VoxelCPU3d=object)
+    sp.pytorch = _stub("spconv.pytorch")
+    sp.pytorch.utils = _stub("spconv.pytorch.utils", PointToVoxel=object)
+    from opencood.data_utils.pre_processor.voxel_preprocessor import VoxelPreprocessor
+    rng = [-64.0, -32.0, -3.0, 64.0, 32.0, 1.0]
+    params = {"args": {"vw": 1.0, "vh": 1.0, "vd": 1.0, "T": 32}, "cav_lidar_range": rng}
+    vp = VoxelPreprocessor(params, train=False)
+    g = np.random.default_rng(7)
+    n = 30000
+    pts = np.empty((n, 4), np.float32)
+    # clustered: many voxels exceed T points
+    centers = g.uniform([-60, -30, -2.5], [60, 30, 0.5], (60, 3))
+    pts[:, :3] = centers[g.integers(0, 60, n)] + g.normal(0, 0.8, (n, 3))
+    pts[:, 3] = g.uniform(0, 1, n)
+    keep = np.all((pts[:, :3] > np.array(rng[:3]) + 1e-3) & (pts[:, :3] < np.array(rng[3:]) - 1e-3), 1)
+    pts = pts[keep]
+    out = vp.preprocess(pts)
+    coords = out["voxel_coords"].astype(np.int32)                       # (V,3) z,y,x, np.unique (sorted) order
+    feats = out["voxel_features"]                                        # (V,32,7): [xyzi, xyz - mean]
+    counts = (np.abs(feats[:, :, :4]).sum(-1) > 0).sum(1).astype(np.int32)
+    print(f"[{name}] {pts.shape[0]} points -> {coords.shape[0]} voxels, {int((counts == 32).sum())} full")
+    assert (counts == 32).sum() > 20
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, points=pts, lidar_range=np.asarray(rng, np.float64), voxel_size=np.asarray([1.0, 1.0, 1.0]),
+                        coords=coords, counts=counts, points_kept=feats[:, :, :4].astype(np.float32))
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 SMALL = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0]
 T8 = ["vehicle", "vehicle", "vehicle", "vehicle", "rsu", "rsu", "drone", "drone"]   # synth.agent_types_for(8), frame order
 
@@ -755,6 +859,8 @@ GROUPS = {
                          run_when2com_case("when2com_small_n2", SMALL, ["vehicle", "vehicle"], 1500, 6)),
     "when2com_full": lambda: run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16),
     "submodules": lambda: submodules_golden(),
+    "iou_pin": lambda: iou_pin_golden(),
+    "voxel_pin": lambda: voxel_pin_golden(),
 }
 GROUPS["full"] = lambda: (GROUPS["cobevt_full"](), GROUPS["v2xvit_full"]())
 
