@@ -100,6 +100,13 @@ class Where2ComEngine:
         self._init_config(args)
         self.A, self.C = args["anchor_number"], args["num_class"]
         self.ws = {}
+        # workspace pool: one buffer per (name, shape, dtype), re-used across frames.  A scenario stream changes its frame
+        # layout (agent count) every few frames, so the pool is bounded: beyond ws_limit bytes the least recently used
+        # buffers that the CURRENT frame has not touched are dropped (and re-allocated if that layout comes back)
+        self.ws_limit = int(float(os.environ.get("AV2X_WS_LIMIT_GB", "32")) * (1 << 30))
+        self._ws_bytes = 0
+        self._ws_used = {}
+        self._frame = 0
         self.weights_ready = False
         self.conv_tile = 0          # 0 = autotune / pick_tile(); else forced BM<<16|BN (tests / tuning)
         self.conv_sk_wgs = 0        # persistent workgroups when conv_tile carries the stream-K flag 0x2000
@@ -267,7 +274,24 @@ class Where2ComEngine:
         if t is None:
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self.ws[key] = t
+            self._ws_bytes += t.numel() * t.element_size()
+            if self._ws_bytes > self.ws_limit:
+                self._evict()
+        self._ws_used[key] = self._frame
         return t
+
+    def _evict(self):
+        """Drop least-recently-used workspace buffers (never one the current frame has touched: its kernels may be queued
+        on it -- the caching allocator keeps a freed block alive for the stream that used it, but a later buf() call of the
+        same frame must see the same storage).  Captured graphs hold raw pointers into the pool and are dropped with it."""
+        old = sorted((f, k) for k, f in self._ws_used.items() if f < self._frame and k in self.ws)
+        for _, k in old:
+            if self._ws_bytes <= self.ws_limit:
+                break
+            t = self.ws.pop(k)
+            self._ws_used.pop(k, None)
+            self._ws_bytes -= t.numel() * t.element_size()
+        self.graphs.clear()
 
     @staticmethod
     def stream():
@@ -523,6 +547,7 @@ class Where2ComEngine:
 
     # ------------------------------------------------------------------ stages
     def frame_layout(self, data_dict):
+        self._frame += 1          # every forward / sharded stage starts here: the epoch the workspace LRU counts in
         pf = data_dict.get("points")
         if pf is not None:   # raw-cloud input (voxelizer.points_frame): one frame, agents already in frame order
             rank = {t: i for i, t in enumerate(AGENT_TYPES)}

@@ -91,6 +91,9 @@ def parse(argv=None):
                     help="shard mode: every rank repeats the ego stage of every frame (SPMD) instead of rank t %% N running frame t's")
     ap.add_argument("--no-secondary", action="store_true", help="shard mode: skip the replica / latency / 4-agent secondary figures")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="skip the secondary legs (split-3, post-process, raw clouds, layout cycling, CPU baseline): the timed "
+                         "frames + the roofline pass only -- the command the rocprofv3 summaries in profiles/ are taken from")
     ap.add_argument("--gemm", choices=["f32", "split3"], default="f32",
                     help="f32: v_mfma_f32_32x32x2_f32 (default, the headline); split3: fp32-accurate products from three bf16 "
                          "terms per operand on the bf16 matrix cores (conv_igemm_bf16x3)")
@@ -288,6 +291,8 @@ def main(argv=None, hooks=None, device=None):
     dev = torch.device("cpu") if cpu_harness else torch.device("cuda", local if world > 1 else 0)
     if a.mode is None:
         a.mode = "shard" if world > 1 else "replica"
+    if a.only_headline:
+        a.cpu_frames = 0
     if a.agents <= 0:
         a.agents = max(4, world) if a.mode == "shard" else 4
 
@@ -369,7 +374,8 @@ def main(argv=None, hooks=None, device=None):
                    "frames_in_flight": inflight_used},
         **res_extra,
     }
-    if a.mode == "replica" and a.inflight > 1 and rank == 0 and world == 1:   # secondary figures: single-GPU runs only
+    secondary = rank == 0 and world == 1 and a.mode == "replica" and not a.only_headline
+    if secondary and a.inflight > 1:   # secondary figures: single-GPU runs only
         # latency mode for reference: strictly one frame at a time on one stream
         for _ in range(2):
             model(dd)
@@ -383,7 +389,7 @@ def main(argv=None, hooks=None, device=None):
                                 "note": "one frame at a time (no overlap between frames)"}
 
     # ---------------- the same frames with the split-3 GEMM (fp32-accurate, bf16 matrix cores): reported beside the headline
-    if rank == 0 and world == 1 and a.mode == "replica" and a.model == "where2com" and a.gemm == "f32" and not a.amp and a.inflight > 1:
+    if secondary and a.model == "where2com" and a.gemm == "f32" and not a.amp and a.inflight > 1:
         for e in pipe.engines:
             e.split3 = True
         out3 = model(dd)  # tunes the split-3 tiles
@@ -409,7 +415,7 @@ def main(argv=None, hooks=None, device=None):
         split3_out = None
 
     # ---------------- second figure: frame + on-device post-process (decode, filters, rotated NMS) ----------
-    if rank == 0 and world == 1 and a.mode == "replica" and a.model == "where2com":
+    if secondary and a.model == "where2com":
         from airv2x_perception_amd.opencood_iface.voxel_postprocessor import VoxelPostprocessor
         post = VoxelPostprocessor(hy["postprocess"], dataset="airv2x", train=False)
         anchors = torch.from_numpy(post.generate_anchor_box())
@@ -500,23 +506,57 @@ def main(argv=None, hooks=None, device=None):
                                                "note": "raw clouds -> boxes, pillar counts stay in HBM, the only host read per frame "
                                                        "is the 20-byte box-count record one lap later"}
 
+    # ---------------- a scenario stream: the agent count changes from frame to frame ------------------------
+    if secondary and a.model == "where2com" and not a.amp and a.gemm == "f32":
+        lens = [2, 3, 4, 5]
+        dds = [build_inputs(k, a.points, dev, only=None, model=a.model)[2] for k in lens]
+        m2, e2, _ = make_model(a, args, dev)          # a fresh engine: nothing allocated, nothing tuned in this process
+        first = {}
+        for k, d_ in zip(lens, dds):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            m2(d_)
+            torch.cuda.synchronize()
+            first[str(k)] = round((time.perf_counter() - t1) * 1e3, 2)
+        for i in range(8):
+            m2(dds[i % 4])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(a.steps * 2):
+            m2(dds[i % 4])
+        torch.cuda.synchronize()
+        cdt = (time.perf_counter() - t1) / (a.steps * 2)
+        mean_gf = sum(99.4 * k + 36.33 * (k - 1) + 53.0 for k in lens) / len(lens)
+        res["layout_cycling"] = {"record_len_sequence": lens, "frames_per_s": round(1.0 / cdt, 2), "ms_per_frame": round(cdt * 1e3, 3),
+                                 "first_frame_ms": first, "workspace_gib": round(e2._ws_bytes / (1 << 30), 2),
+                                 "workspace_limit_gib": round(e2.ws_limit / (1 << 30), 1), "mean_gflop_per_frame": round(mean_gf, 1),
+                                 "note": "one frame at a time, the agent count changes EVERY frame (2,3,4,5,2,...); first_frame_ms = "
+                                         "first forward of each layout on a fresh engine (workspace allocation + schedule lookup in "
+                                         "the shipped tuning table / the user's cache, timing only what neither holds)"}
+        del m2, e2
+
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and a.mode == "replica":
         eng.use_graph = False
-        # what a hipEvent pair adds around ONE launch on this stream (record -> kernel start, kernel end -> record): the pair
-        # around a 4-byte fill minus that kernel's own ~1.5 us; subtracted from every per-launch figure below so that they are
-        # comparable with rocprofv3's kernel durations (profiles/)
+        # What a hipEvent pair adds around ONE launch when the queue is full (the marker packets either side of the kernel):
+        # with T1 = pair around one 4-byte fill and T2 = pair around two of them, T2 - T1 is one kernel + the gap to the
+        # next, so 2*T1 - T2 is the pair's own share (minus one inter-kernel gap: a conservative, i.e. small, estimate).
+        # Subtracted from every per-launch figure below so that they are comparable with rocprofv3's kernel durations
+        # (profiles/r02_kernel_stats_bench_inflight1.txt).
         from ctypes import c_void_p as _vp
         tiny = torch.zeros(1, device=dev)
-        ovs = []
-        for _ in range(200):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            eng.lib.av2x_fill_zero(_vp(tiny.data_ptr()), 4, eng.stream())
-            e1.record()
-            ovs.append((e0, e1))
+        pairs = {1: [], 2: []}
+        for _ in range(100):
+            for reps in (1, 2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _r in range(reps):
+                    eng.lib.av2x_fill_zero(_vp(tiny.data_ptr()), 4, eng.stream())
+                e1.record()
+                pairs[reps].append((e0, e1))
         torch.cuda.synchronize()
-        ev_over = max(0.0, float(np.median([x.elapsed_time(y) for x, y in ovs])) * 1e-3 - 1.5e-6)
+        t1, t2 = (float(np.median([x.elapsed_time(y) for x, y in pairs[r]])) * 1e-3 for r in (1, 2))
+        ev_over = min(max(0.0, 2 * t1 - t2), 5e-6)
         eng.profile = []
         for _ in range(a.steps):
             model(dd)
@@ -529,7 +569,7 @@ def main(argv=None, hooks=None, device=None):
             d = per.setdefault(tile, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
-            dur = max(e0.elapsed_time(e1) * 1e-3 - ev_over * (2 if tile[1] & 0x2000 else 1), 1e-7)   # stream-K = GEMM + fix-up launch
+            dur = max(e0.elapsed_time(e1) * 1e-3 - ev_over, 1e-7)   # one pair per launch (a stream-K launch = GEMM + fix-up kernel)
             d[2] += dur
             g = grids.setdefault(tile, {})
             g[wgs] = g.get(wgs, 0) + 1
