@@ -446,7 +446,8 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
                               uint64_t workspace_bytes, av2x_stream_t stream) {
     if (!d || !in || !w || !shift || !out) return av2x::fail("av2x_conv2d: null argument");
     if (residual && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: residual only with mode AV2X_CONV");
-    if (d->relu < 0 || d->relu > 2) return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU)", d->relu);
+    if (d->relu < 0 || d->relu > 4)
+        return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU, 3 sigmoid, 4 tanh [x residual])", d->relu);
     if (d->cin % BK != 0) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);
     if (d->coutp % 32 != 0 || d->coutp <= 0) return av2x::fail("av2x_conv2d: coutp=%d must be a positive multiple of 32", d->coutp);
     if (d->mode < 0 || d->mode > 2) return av2x::fail("av2x_conv2d: bad mode %d", d->mode);

@@ -8,6 +8,7 @@ from .airv2x_where2com import Airv2xWhere2com  # noqa: F401
 from .airv2x_cobevt import Airv2xCoBEVT  # noqa: F401,E402
 from .airv2x_v2xvit import Airv2xV2XVit  # noqa: F401,E402
 from .airv2x_when2com import Airv2xWhen2com  # noqa: F401,E402
+from .airv2x_v2vnet import Airv2xV2VNet  # noqa: F401,E402
 
 
 def create_model(hypes):
@@ -19,7 +20,7 @@ def create_model(hypes):
     try:
         mod = importlib.import_module(f"{__name__}.{name}")
     except ModuleNotFoundError as e:
-        raise ValueError(f"core_method {name!r}: no such model in the MI355X build (airv2x_where2com, airv2x_cobevt, airv2x_v2xvit, airv2x_when2com)") from e
+        raise ValueError(f"core_method {name!r}: no such model in the MI355X build (airv2x_where2com, airv2x_cobevt, airv2x_v2xvit, airv2x_when2com, airv2x_v2vnet)") from e
     target = name.replace("_", "").lower()
     for attr, cls in vars(mod).items():
         if attr.lower() == target and isinstance(cls, type):

@@ -1,0 +1,52 @@
+"""``Airv2xV2VNet`` — drop-in for opencood/models/airv2x_v2vnet.py:19-244 (det task, LiDAR) running in
+libairv2x_hip.so.  Same constructor argument, input contract (incl. ``img_pairwise_t_matrix_collab``), output keys
+(``psm``, ``rm``, ``obj``, ``mask``, ``comm_rate``) and state_dict keys/shapes as the reference."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from ..synth import v2vnet_param_spec
+from .airv2x_where2com import _amp_requested
+from .submodules import _declare
+from .v2vnet_engine import V2VNetEngine
+
+
+class Airv2xV2VNet(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if args.get("task", "det") != "det":
+            raise NotImplementedError("only the det task is on the MI355X hot path")
+        for t in args["collaborators"]:
+            if args[t]["modalities"] != ["lidar"]:
+                raise NotImplementedError("LiDAR-only agents")
+        self.args = args
+        self.collaborators = args["collaborators"]
+        self.active_sensors = args["active_sensors"]
+        self.outC = args["outC"]
+        _declare(self, v2vnet_param_spec(args))
+        self._engine = None
+        self._packed_version = None
+        self.sync_comm_rate = True   # the reference returns a python float (v2v_fuse.py:172)
+
+    def _version(self):
+        return tuple(t._version for t in self.state_dict(keep_vars=True).values()) + (next(iter(self.parameters())).device,)
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("Airv2xV2VNet (MI355X build) has no CPU path: move the module to the GPU (model.to('cuda'))")
+        ver = self._version()
+        if self._engine is None or self._engine.device != dev:
+            self._engine = V2VNetEngine(self.args, dev)
+            self._packed_version = None
+        if self._packed_version != ver:
+            self._engine.load_state_dict(self.state_dict())
+            self._packed_version = ver
+        return self._engine
+
+    def forward(self, data_dict):
+        if self.training:
+            raise NotImplementedError("training is not built yet; call .eval()")
+        eng = self.engine()
+        eng.amp = _amp_requested(self)
+        return eng.forward(data_dict, sync_comm_rate=self.sync_comm_rate)

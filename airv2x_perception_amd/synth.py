@@ -716,6 +716,57 @@ def when2com_param_spec(args):
 
 
 # --------------------------------------------------------------------------
+# V2VNet (models/airv2x_v2vnet.py; no AirV2X YAML ships for it: the Where2Comm trunk + the `v2vfusion` block of
+# hypes_yaml/opv2v/opv2v_v2vnet.yaml:91-102 re-sized to the AirV2X feature map)
+# --------------------------------------------------------------------------
+
+def default_hypes_v2vnet(lidar_range=None, max_cav=(5, 5, 5), agg="avg", num_iteration=2):
+    hy = default_hypes(lidar_range, max_cav)
+    a = hy["model"]["args"]
+    a.pop("where2com_fusion")
+    g = a["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]
+    a["v2vfusion"] = {"voxel_size": list(DEFAULT_VOXEL), "downsample_rate": 2, "num_iteration": num_iteration, "in_channels": 256,
+                      "gru_flag": True, "agg_operator": agg,
+                      "conv_gru": {"H": int(g[1]) // 2, "W": int(g[0]) // 2, "num_layers": 1, "kernel_size": [[3, 3]]}}
+    a["backbone_fix"] = False
+    hy["model"]["core_method"] = "airv2x_v2vnet"
+    hy["name"] = "airv2x_intermediate_v2vnet"
+    return hy
+
+
+def v2vnet_pairwise(n, L):
+    """(1,L,L,4,4) fp32 ``img_pairwise_t_matrix_collab`` with a small SE(2) motion on EVERY ordered pair (i != j): V2VNet
+    warps every node's neighbours into that node's frame (v2v_fuse.py:142-146 uses row i of the matrix)."""
+    t = torch.eye(4).view(1, 1, 1, 4, 4).repeat(1, L, L, 1, 1)
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                t[0, i, j] = torch.from_numpy(se2_correction(2.0 * (j - i), 0.9 * (j - i) + 0.3 * i, -0.6 * (j - i))).float()
+    return t
+
+
+def v2vnet_fusion_spec(cfg, prefix=""):
+    """V2VNetFusion(args) (v2vnet_modules/v2v_fuse.py:19-47): msg_cnn, one ConvGRU cell (gates + candidate), mlp."""
+    c = cfg["in_channels"]
+    p = prefix + "conv_gru.cell_list.0"
+    return [(prefix + "msg_cnn.weight", (c, 2 * c, 3, 3), "conv"), (prefix + "msg_cnn.bias", (c,), "bias"),
+            (p + ".conv_gates.weight", (2 * c, 3 * c, 3, 3), "conv"), (p + ".conv_gates.bias", (2 * c,), "bias"),
+            (p + ".conv_can.weight", (c, 3 * c, 3, 3), "conv"), (p + ".conv_can.bias", (c,), "bias"),
+            (prefix + "mlp.weight", (c, c), "lin"), (prefix + "mlp.bias", (c,), "bias")]
+
+
+def v2vnet_param_spec(args):
+    """Ordered (key, shape, kind) manifest of Airv2xV2VNet's state_dict (checked against the reference's own state_dict
+    by tools/gen_golden.py)."""
+    w2c_like = dict(args)
+    w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
+    base = where2com_param_spec(w2c_like)
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
+    return trunk + v2vnet_fusion_spec(args["v2vfusion"], "fusion_net.") + heads
+
+
+# --------------------------------------------------------------------------
 # sub-module harness (tests/test_submodules.py, tools/gen_golden.py submodules): one small configuration per
 # reference sub-module of SURVEY 8b, inputs from seeded generators so that only outputs are stored as fixtures
 # --------------------------------------------------------------------------

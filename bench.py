@@ -103,7 +103,7 @@ def parse(argv=None):
     ap.add_argument("--per-shape", action="store_true", help="add a per-layer-shape table to the roofline object")
     ap.add_argument("--graph", type=int, default=0, help="replay the frame from a captured HIP graph (1) or eager (0); "
                     "the frame is GPU-bound (75 launches in 5.7 ms), so eager is just as fast and is the default")
-    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit", "when2com"], default="where2com",
+    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit", "when2com", "v2vnet"], default="where2com",
                     help="where2com = the headline metric; cobevt = BASELINE.json configs[2] fusion head on one GPU")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent frames kept in flight per GPU (separate HIP streams + workspaces, shared weights); "
@@ -127,6 +127,8 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
         hy = synth.default_hypes_v2xvit()
     elif model == "when2com":
         hy = synth.default_hypes_when2com()
+    elif model == "v2vnet":
+        hy = synth.default_hypes_v2vnet()
     else:
         hy = synth.default_hypes()
     args = hy["model"]["args"]
@@ -157,10 +159,12 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
                                                      args["max_cav_num"])["prior_encoding"]
     if model == "when2com":   # ego -> j motions for the warp (the dataset ships identities; the cost is the same)
         dd["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(len(types_frame), args["max_cav_num"])
+    if model == "v2vnet":
+        dd["img_pairwise_t_matrix_collab"] = synth.v2vnet_pairwise(len(types_frame), args["max_cav_num"])
     return hy, args, dd, [clouds[i] for i in order], types_sorted
 
 
-MODEL_NAMES = {"where2com": "Where2Comm", "cobevt": "CoBEVT", "v2xvit": "V2X-ViT", "when2com": "When2com"}
+MODEL_NAMES = {"where2com": "Where2Comm", "cobevt": "CoBEVT", "v2xvit": "V2X-ViT", "when2com": "When2com", "v2vnet": "V2VNet"}
 MESSAGE = {"where2com": "the masked multi-scale features (15.8 MB per agent)",
            "cobevt": "the shrink-header maps (36 MB per agent), fusion split over the ranks by residue-group columns + a second "
                      "all-gather of the head outputs",
@@ -174,7 +178,8 @@ def make_model(a, args, dev):
     from airv2x_perception_amd import synth
     from airv2x_perception_amd import opencood_iface as oi
     cls, spec = {"where2com": (oi.Airv2xWhere2com, synth.where2com_param_spec), "cobevt": (oi.Airv2xCoBEVT, synth.cobevt_param_spec),
-                 "v2xvit": (oi.Airv2xV2XVit, synth.v2xvit_param_spec), "when2com": (oi.Airv2xWhen2com, synth.when2com_param_spec)}[a.model]
+                 "v2xvit": (oi.Airv2xV2XVit, synth.v2xvit_param_spec), "when2com": (oi.Airv2xWhen2com, synth.when2com_param_spec),
+                 "v2vnet": (oi.Airv2xV2VNet, synth.v2vnet_param_spec)}[a.model]
     sd = synth.synthetic_state_dict(spec(args), seed=0)
     model = cls(args)
     model.load_state_dict(sd)

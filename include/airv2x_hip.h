@@ -113,7 +113,8 @@ typedef struct av2x_conv_desc {
     int32_t coutp;             /* padded GEMM column count of `w`                        */
     int32_t out_ctot, out_coff;/* channel stride / offset of the output (concat support) */
     int32_t ks, stride, pad;   /* square kernel                                           */
-    int32_t relu;              /* activation after the affine: 0 none, 1 ReLU, 2 exact GELU */
+    int32_t relu;              /* activation after the affine: 0 none, 1 ReLU, 2 exact GELU, 3 sigmoid, 4 tanh -- with a
+                                * residual pointer code 4 multiplies by residual[m*cout + c] (a ConvGRU gate) instead of adding */
     int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
     int32_t up;                /* DECONV: kernel == stride                                */
     int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2)
@@ -259,6 +260,19 @@ int av2x_postprocess_devt(const float* psm, const float* rm, const float* obj, c
                           int32_t order_hwl, int32_t top, void* workspace, float* out_corners,
                           float* out_scores, int32_t* out_labels, float* out_boxes, int32_t* out_index,
                           int32_t* counts, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * V2VNet message aggregation (models/v2vnet_modules/v2v_fuse.py:137-165) for ONE receiving agent i:
+ *   message_j = (msg_cnn([warp_j(x_j) | x_i]) ) * roi_mask_ij      (:150-158)
+ *   agg       = mean_j / max_j message_j                              (:161-164; op 0 = "avg", 1 = "max")
+ * msg_cnn is linear in its concatenated input, so the caller hands over its two halves:
+ *   msg_a (n,h,w,c) = conv3x3(warped neighbours; W[:, :c]) without bias, ego_b (h,w,c) = conv3x3(x_i; W[:, c:]) + bias.
+ * roi_mask_ij (:110-118) = warp_affine_simple of an all-ones map with theta (n,2,3) (align_corners = False, bilinear,
+ * zero padding), i.e. the sum of the in-image bilinear weights of every output pixel: computed in the kernel.
+ *   out (h,w,c).  c % 4 == 0, n <= 32.
+ * ------------------------------------------------------------------------------------ */
+int av2x_v2v_aggregate(const float* msg_a, const float* ego_b, const float* theta, int32_t n, int32_t h, int32_t w,
+                       int32_t c, int32_t op, float* out, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * AP evaluation: true/false positives of one frame.  Replaces the shapely loop of caluclate_tp_fp
