@@ -767,6 +767,63 @@ def v2vnet_param_spec(args):
 
 
 # --------------------------------------------------------------------------
+# Camera lift-splat inputs (hypes_yaml/airv2x/camera/det/airv2x_intermediate_where2com.yaml :52-95, :180-188)
+# --------------------------------------------------------------------------
+
+def cam_args(agent_type="vehicle", final_dim=(360, 640), xy=(-140.8, 140.8, -40.0, 40.0), img_features=64):
+    """``args[agent_type]["cam"]`` of the shipped camera YAML (grid_conf / data_aug_conf anchors)."""
+    z, dd, mode = {"vehicle": ([-10, 10, 20.0], [2, 50, 48], "LID"), "rsu": ([-30, 30, 60.0], [2, 50, 48], "LID"),
+                   "drone": ([-150, -6, 144], [6, 150, 144], "UD")}[agent_type]
+    return {"grid_conf": {"xbound": [xy[0], xy[1], 0.4], "ybound": [xy[2], xy[3], 0.4], "zbound": z, "ddiscr": dd, "mode": mode},
+            "data_aug_conf": {"resize_lim": [0.65, 0.7], "final_dim": list(final_dim), "rot_lim": [0, 0], "H": 720, "W": 1280,
+                              "rand_flip": False, "bot_pct_lim": [0.0, 0.05]},
+            "img_downsample": 8, "img_features": img_features, "bevout_feature": 64, "camera_encoder": "EfficientNet",
+            "use_depth_gt": True, "depth_supervision": False}
+
+
+def camera_rig(seed, B, N, final_dim=(360, 640), drone=False):
+    """Seeded plausible camera tensors of ``batch_merged_cam_inputs``: rots / trans (camera -> ego), intrinsics of a
+    1280x720 sensor, and the resize + crop of the image augmentation as post_rots / post_trans."""
+    g = np.random.default_rng(int(seed))
+    rots, trans, intr = np.zeros((B, N, 3, 3), np.float32), np.zeros((B, N, 3), np.float32), np.zeros((B, N, 3, 3), np.float32)
+    post_rots, post_trans = np.zeros((B, N, 3, 3), np.float32), np.zeros((B, N, 3), np.float32)
+    for b in range(B):
+        for n in range(N):
+            yaw = 2 * np.pi * n / N + g.uniform(-0.1, 0.1)
+            # camera axes (x right, y down, z forward) -> ego (x forward, y left, z up); a drone camera looks down
+            base = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], np.float64)
+            if drone:
+                base = np.array([[0, -1, 0], [-1, 0, 0], [0, 0, -1]], np.float64)
+            c, s_ = np.cos(yaw), np.sin(yaw)
+            rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+            rots[b, n] = (rz @ base).astype(np.float32)
+            trans[b, n] = [g.uniform(-1, 1), g.uniform(-0.5, 0.5), 60.0 if drone else g.uniform(1.4, 2.0)]
+            f = g.uniform(550, 650)
+            intr[b, n] = [[f, 0, 640], [0, f, 360], [0, 0, 1]]
+            r = g.uniform(0.65, 0.7)
+            post_rots[b, n] = np.diag([r, r, 1.0]).astype(np.float32)
+            post_trans[b, n] = [-(1280 * r - final_dim[1]) / 2, -(720 * r - final_dim[0]) * g.uniform(0.9, 1.0), 0.0]
+    t = lambda a: torch.from_numpy(a)
+    return t(rots), t(trans), t(intr), t(post_rots), t(post_trans)
+
+
+def lifted_features(seed, B, N, D, fH, fW, C, one_hot=True):
+    """x of voxel_pooling, (B,N,D,fH,fW,C): image features x depth distribution.  one_hot = the shipped use_depth_gt
+    path (every pixel's mass in ONE depth bin); else a dense softmax over depth."""
+    g = np.random.default_rng(int(seed))
+    feat = g.standard_normal((B, N, 1, fH, fW, C)).astype(np.float32)
+    if one_hot:
+        d = g.integers(0, D, (B, N, fH, fW))
+        depth = np.zeros((B, N, D, fH, fW, 1), np.float32)
+        np.put_along_axis(depth, d[:, :, None, :, :, None], 1.0, axis=2)
+    else:
+        lg = g.standard_normal((B, N, D, fH, fW, 1)).astype(np.float32) * 2
+        e = np.exp(lg - lg.max(2, keepdims=True))
+        depth = (e / e.sum(2, keepdims=True)).astype(np.float32)
+    return torch.from_numpy(depth * feat)
+
+
+# --------------------------------------------------------------------------
 # sub-module harness (tests/test_submodules.py, tools/gen_golden.py submodules): one small configuration per
 # reference sub-module of SURVEY 8b, inputs from seeded generators so that only outputs are stored as fixtures
 # --------------------------------------------------------------------------

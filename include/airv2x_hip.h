@@ -262,6 +262,26 @@ int av2x_postprocess_devt(const float* psm, const float* rm, const float* obj, c
                           int32_t* counts, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Camera lift-splat: LiftSplatShootEncoder.get_geometry + voxel_pooling
+ * (models/common_modules/airv2x_encoder.py:133-167, 208-275; QuickCumsum utils/camera_utils.py:341-365) fused.
+ *   x           (b*n_cams*pts_per_cam, c) f32: the lifted features of every frustum point, point-major (b, n, d, fh, fw)
+ *               -- the reference's x.permute(0,1,3,4,5,2) (:185); may be NULL together with out (geometry only);
+ *   frustum     (pts_per_cam, 3) f32 = create_frustum() (:94-131) flattened (d, fh, fw);
+ *   cam_params  (b*n_cams, 24) f32 per camera: inverse(post_rots) (9, row-major), post_trans (3),
+ *               rots @ inverse(intrins) (9), trans (3) -- the per-frame host matrices of get_geometry (:147-166);
+ *   lo3 = bx - dx/2, dx3, nx3: the voxel grid of gen_dx_bx (utils/camera_utils.py:238-245);
+ *   workspace   av2x_lss_pool_workspace_bytes(b, nx, ny, nz, c) bytes (64-bit fixed-point accumulators);
+ *   out         (b, ny, nx, nz*c) f32 NHWC, channel z*c + k = the reference's torch.cat(final.unbind(2), 1) (:272);
+ *   geom_out    optional (b*n_cams*pts_per_cam, 3) f32: the ego-frame points of get_geometry (tests).
+ * Sums are accumulated as 2^-32 fixed point with integer atomics: bit-reproducible, and each voxel's sum is exact to
+ * 2^-32 per addend (the reference's cumsum-difference carries the rounding of a running sum over ALL points).
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_lss_pool_workspace_bytes(int32_t b, int32_t nx, int32_t ny, int32_t nz, int32_t c);
+int av2x_lss_voxel_pool(const float* x, const float* frustum, const float* cam_params, int32_t b, int32_t n_cams,
+                        int32_t pts_per_cam, int32_t c, const float* lo3, const float* dx3, const int32_t* nx3,
+                        void* workspace, float* out, float* geom_out, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * V2VNet message aggregation (models/v2vnet_modules/v2v_fuse.py:137-165) for ONE receiving agent i:
  *   message_j = (msg_cnn([warp_j(x_j) | x_i]) ) * roi_mask_ij      (:150-158)
  *   agg       = mean_j / max_j message_j                              (:161-164; op 0 = "avg", 1 = "max")

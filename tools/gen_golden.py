@@ -801,6 +801,72 @@ def run_v2vnet_case(name, lidar_range, types, n_points, seed, agg="avg", head_st
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def lss_golden(name, agent_type, B, N, final_dim, xy, seed, one_hot, stride):
+    """The reference's own create_frustum / get_geometry / voxel_pooling (airv2x_encoder.py:94-275), called as unbound
+    methods on a namespace (the constructor needs EfficientNet weights, torchvision and a CUDA device), on seeded camera
+    rigs and lifted features.  Stores the frustum, the geometry, the pooled BEV map and its float64 yardstick."""
+    from types import SimpleNamespace
+
+    from airv2x_perception_amd import synth
+    from oracle import lss_oracle as lo
+    tv = _stub("torchvision")
+    tv.models = _stub("torchvision.models")
+    class _AnyTransform:       # torchvision.transforms.* are image-file preprocessing: class bodies only need the names
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, im):
+            return im
+    tv.transforms = _stub("torchvision.transforms", ToTensor=_AnyTransform, Normalize=_AnyTransform, Compose=_AnyTransform,
+                          ToPILImage=_AnyTransform)
+    sys.modules["shapely.geometry"].MultiPoint = object          # camera_utils.py:8 (2-D box helper, not on this path)
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        pil = _stub("PIL")
+        pil.Image = _stub("PIL.Image")
+    _stub("opencood.models.sub_modules.lss_submodule", BevEncode=object, CamEncode=object, CamEncode_Resnet101=object)
+    _stub("opencood.models.common_modules.debug_helper", np=np, cv2=sys.modules["cv2"])   # its star-import supplies `np`
+    sys.modules.pop("opencood.models.common_modules.airv2x_encoder", None)     # import_reference() put a stub there
+    from opencood.models.common_modules.airv2x_encoder import LiftSplatShootEncoder as LSS
+    from opencood.utils.camera_utils import gen_dx_bx
+    ca = synth.cam_args(agent_type, final_dim, xy)
+    gc = ca["grid_conf"]
+    dx, bx, nx = gen_dx_bx(gc["xbound"], gc["ybound"], gc["zbound"])
+    ns = SimpleNamespace(grid_conf=gc, data_aug_conf=ca["data_aug_conf"], downsample=ca["img_downsample"], dx=dx, bx=bx, nx=nx,
+                         use_quickcumsum=True)
+    ns.frustum = LSS.create_frustum(ns)
+    D, fH, fW, _ = ns.frustum.shape
+    rig = synth.camera_rig(seed, B, N, final_dim, drone=(agent_type == "drone"))
+    geom = LSS.get_geometry(ns, *rig)
+    x = synth.lifted_features(seed + 1, B, N, D, fH, fW, ca["img_features"], one_hot=one_hot)
+    with torch.no_grad():
+        bev = LSS.voxel_pooling(ns, geom, x)
+    # oracle == reference
+    assert torch.equal(lo.create_frustum(gc, ca["data_aug_conf"], ca["img_downsample"]), ns.frustum)
+    og = lo.get_geometry(ns.frustum, *rig)
+    assert torch.equal(og, geom)
+    ob = lo.voxel_pooling(geom, x, dx, bx, nx)
+    assert torch.allclose(ob, bev, rtol=0, atol=1e-4 * float(bev.abs().max())), float((ob - bev).abs().max())
+    exact = lo.voxel_pooling_exact(geom, x, dx, bx, nx)
+    g4, kept = lo.voxel_indices(geom, dx, bx, nx, B)
+    err = float((bev.double() - exact).abs().max())
+    print(f"[{name}] {agent_type}: D={D} fH={fH} fW={fW} points={geom.numel() // 3} kept={int(kept.sum())} grid={nx.tolist()} "
+          f"max|bev|={float(bev.abs().max()):.2f} reference-vs-float64 max err {err:.3e} occupied cells {int((exact.abs().sum(1) > 0).sum())}")
+    fx = {"agent_type": np.asarray(agent_type), "B": np.int64(B), "N": np.int64(N), "final_dim": np.asarray(final_dim, np.int64),
+          "xy": np.asarray(xy, np.float64), "seed": np.int64(seed), "one_hot": np.int64(one_hot), "stride": np.int64(stride),
+          "frustum": ns.frustum.numpy(), "kept_count": np.int64(int(kept.sum())),
+          "geom": geom[:, :, ::max(1, stride // 2), ::stride, ::stride].numpy(),
+          "bev": bev[..., ::stride, ::stride].numpy(), "bev_exact": exact[..., ::stride, ::stride].float().numpy(),
+          "bev_sum": np.float64(bev.double().sum().item()), "bev_exact_sum": np.float64(exact.sum().item()),
+          "bev_exact_abssum": np.float64(exact.abs().sum().item()), "reference_max_err": np.float64(err),
+          "cell_counts": torch.bincount(((g4[kept][:, 3] * int(nx[2]) + g4[kept][:, 2]) * int(nx[1]) + g4[kept][:, 1]) * int(nx[0]) + g4[kept][:, 0],
+                                        minlength=B * int(nx[0] * nx[1] * nx[2])).view(B, int(nx[2]), int(nx[1]), int(nx[0]))[..., ::stride, ::stride].numpy().astype(np.int32)}
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _bev_quads(boxes):
     """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,4,2) float32 BEV corners (counter-clockwise)."""
     x, y, dx, dy, h = boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]
@@ -935,6 +1001,12 @@ GROUPS = {
     "v2vnet": lambda: (run_v2vnet_case("v2vnet_small_n3", SMALL, ["vehicle", "rsu", "drone"], 1500, 8),
                        run_v2vnet_case("v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 1500, 9, agg="max")),
     "v2vnet_full": lambda: run_v2vnet_case("v2vnet_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 10, head_stride=4, big_stride=16),
+    # camera lift-splat: a small rig (every tensor), and BASELINE configs[4]'s shapes (360x640 images / 8, 48 or 144 depth
+    # bins, the 704x200 BEV grid; strided samples + sums)
+    "lss": lambda: (lss_golden("lss_small", "vehicle", 2, 2, (96, 160), (-25.6, 25.6, -12.8, 12.8), 31, True, 1),
+                    lss_golden("lss_small_dense", "rsu", 1, 3, (96, 160), (-25.6, 25.6, -12.8, 12.8), 32, False, 1),
+                    lss_golden("lss_cfg4_vehicle", "vehicle", 1, 4, (360, 640), (-140.8, 140.8, -40.0, 40.0), 33, True, 4),
+                    lss_golden("lss_cfg4_drone", "drone", 1, 1, (360, 640), (-140.8, 140.8, -40.0, 40.0), 34, True, 4)),
     "iou_pin": lambda: iou_pin_golden(),
     "voxel_pin": lambda: voxel_pin_golden(),
 }
