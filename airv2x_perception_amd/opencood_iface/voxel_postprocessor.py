@@ -139,8 +139,73 @@ class DevicePostprocess:
         return b
 
 
-class VoxelPostprocessor(DevicePostprocess):
-    """Stand-alone form: the reference's constructor fields + anchors + the device post-process."""
+def _corners_hwl(boxes7):
+    """box_utils.boxes_to_corners_3d(order='hwl') :195-258 + rotate_points_along_z (common_utils.py:60-82) with the same
+    torch fp32 calls (host; anchors once per configuration, a few dozen ground-truth boxes per frame)."""
+    b = torch.from_numpy(np.asarray(boxes7)).float()[:, [0, 1, 2, 5, 4, 3, 6]]
+    template = b.new_tensor(([1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, -1], [1, -1, 1], [1, 1, 1], [-1, 1, 1], [-1, -1, 1])) / 2
+    c = b[:, None, 3:6].repeat(1, 8, 1) * template[None, :, :]
+    ang = b[:, 6]
+    cosa, sina = torch.cos(ang), torch.sin(ang)
+    z, o = ang.new_zeros(c.shape[0]), ang.new_ones(c.shape[0])
+    rot = torch.stack((cosa, sina, z, -sina, cosa, z, z, z, o), dim=1).view(-1, 3, 3).float()
+    c = torch.matmul(c.view(-1, 8, 3)[:, :, 0:3].float(), rot).view(-1, 8, 3)
+    return (c + b[:, None, 0:3]).numpy()
+
+
+def _standup(corners):
+    """box_utils.corner2d_to_standup_box :279-302 (float64 array) then the .astype(np.float32) of the call site (:266-270)."""
+    s = np.zeros((corners.shape[0], 4))
+    s[:, 0], s[:, 1] = np.min(corners[:, :, 0], axis=1), np.min(corners[:, :, 1], axis=1)
+    s[:, 2], s[:, 3] = np.max(corners[:, :, 0], axis=1), np.max(corners[:, :, 1], axis=1)
+    return np.ascontiguousarray(s).astype(np.float32)
+
+
+class DeviceLabels:
+    """``generate_label_airv2x`` (voxel_postprocessor.py:217-354) with the anchor <-> ground-truth assignment on the device
+    (av2x_generate_label): same keyword arguments, same ``label_dict`` (numpy float64 / int64 arrays of the reference's shapes).
+    Opt-in mixin: ``bind_device_postprocess(cls, labels=True)``; the stand-alone VoxelPostprocessor always has it."""
+
+    label_device = "cuda"
+
+    def generate_label_airv2x(self, **kwargs):
+        assert self.params["order"] == "hwl", "Currently Voxel only supporthwl bbx order."
+        gt_box_center, anchors, masks = kwargs["gt_box_center"], kwargs["anchors"], kwargs["mask"]
+        class_ids_valid = np.asarray(kwargs["class_ids_padded"])[np.asarray(masks) == 1]
+        H, W, A = anchors.shape[:3]
+        anchors = np.ascontiguousarray(np.asarray(anchors).reshape(-1, 7), dtype=np.float64)
+        gt_valid = np.ascontiguousarray(np.asarray(gt_box_center)[np.asarray(masks) == 1], dtype=np.float64)
+        ws = self.__dict__.setdefault("_av2x_label_ws", {})
+        dev = torch.device(self.label_device)
+        c = ws.get("anchors")
+        if c is None or c["shape"] != anchors.shape or not np.array_equal(c["rows"], anchors[:: max(1, anchors.shape[0] // 64)]):
+            c = ws["anchors"] = {"shape": anchors.shape, "rows": anchors[:: max(1, anchors.shape[0] // 64)].copy(),
+                                 "standup": torch.from_numpy(_standup(_corners_hwl(anchors))).to(dev),
+                                 "a7": torch.from_numpy(anchors).to(dev)}
+        n, NA = gt_valid.shape[0], anchors.shape[0]
+        gs = torch.from_numpy(_standup(_corners_hwl(gt_valid)) if n else np.zeros((0, 4), np.float32)).to(dev)
+        # the reference reads the regression targets from the PADDED array with indices into the VALID boxes (:311-330):
+        # identical whenever the valid boxes are a prefix (what the dataset builds); reproduced as written
+        g7 = torch.from_numpy(np.ascontiguousarray(np.asarray(gt_box_center)[:n], dtype=np.float64)).to(dev)
+        cid = torch.from_numpy(np.asarray(class_ids_valid, dtype=np.int32)).to(dev)
+        pos = torch.empty(NA, dtype=torch.float64, device=dev)
+        neg = torch.empty(NA, dtype=torch.float64, device=dev)
+        tgt = torch.empty((NA, 7), dtype=torch.float64, device=dev)
+        cls = torch.empty(NA, dtype=torch.int64, device=dev)
+        wsb = torch.empty(8 * max(n, 1), dtype=torch.uint8, device=dev)
+        lib = _lib.load()
+        P = lambda t: c_void_p(t.data_ptr()) if t.numel() else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.av2x_generate_label(P(c["standup"]), P(gs), P(c["a7"]), P(g7), P(cid), NA, n,
+                                               float(self.params["target_args"]["pos_threshold"]),
+                                               float(self.params["target_args"]["neg_threshold"]), P(wsb), P(pos), P(neg), P(tgt), P(cls),
+                                               c_void_p(torch.cuda.current_stream().cuda_stream)), "av2x_generate_label")
+        return {"pos_equal_one": pos.view(H, W, A).cpu().numpy(), "neg_equal_one": neg.view(H, W, A).cpu().numpy(),
+                "targets": tgt.view(H, W, A * 7).cpu().numpy(), "cls_labels": cls.view(H, W, A).cpu().numpy()}
+
+
+class VoxelPostprocessor(DevicePostprocess, DeviceLabels):
+    """Stand-alone form: the reference's constructor fields + anchors + the device post-process + the device label assignment."""
 
     def __init__(self, anchor_params, dataset="airv2x", train=False):
         self.params = anchor_params
@@ -174,10 +239,12 @@ class VoxelPostprocessor(DevicePostprocess):
         raise ValueError("Unknown bbx order.")
 
 
-def bind_device_postprocess(reference_cls):
+def bind_device_postprocess(reference_cls, labels=False):
     """``VoxelPostprocessor = bind_device_postprocess(VoxelPostprocessor)`` at the end of the reference's
     data_utils/post_processor/voxel_postprocessor.py: a subclass of the reference's class whose
     ``post_process_airv2x`` runs on the device; every other method (label generation, collate, GT boxes,
-    ``generate_anchor_box``, the seg branch) is inherited from the reference unchanged."""
-    return type(reference_cls.__name__, (DevicePostprocess, reference_cls), {"__doc__": reference_cls.__doc__,
-                                                                            "__module__": reference_cls.__module__})
+    ``generate_anchor_box``, the seg branch) is inherited from the reference unchanged.  ``labels=True`` also moves
+    ``generate_label_airv2x`` to the device (DataLoader workers then need a HIP context: use it with num_workers = 0 or a
+    spawn start method)."""
+    bases = (DevicePostprocess, DeviceLabels, reference_cls) if labels else (DevicePostprocess, reference_cls)
+    return type(reference_cls.__name__, bases, {"__doc__": reference_cls.__doc__, "__module__": reference_cls.__module__})

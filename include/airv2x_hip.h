@@ -262,6 +262,21 @@ int av2x_postprocess_devt(const float* psm, const float* rm, const float* obj, c
                           int32_t* counts, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training labels: VoxelPostprocessor.generate_label_airv2x (voxel_postprocessor.py:217-354) with
+ * bbox_overlaps (utils/box_overlaps.pyx:17-57) -- the anchor <-> ground-truth assignment, without the IoU matrix.
+ *   anchor_standup (n_anchors,4) / gt_standup (n_gt,4) f32: [xmin,ymin,xmax,ymax] of corner2d_to_standup_box (:266-270);
+ *   anchors7 (n_anchors,7) / gt7 (n_gt,7) f64 in the 'hwl' order [x,y,z,h,w,l,yaw]; class_ids (n_gt,) i32;
+ *   workspace: 8 * max(n_gt, 1) bytes;
+ *   pos_equal_one / neg_equal_one (n_anchors,) f64, targets (n_anchors,7) f64, cls_labels (n_anchors,) i64 -- the flat
+ *   (H, W, A[, 7]) arrays of the reference's label_dict.  n_gt = 0: no positives, every anchor negative (the sum over an
+ *   empty axis of :290-294 equals iou.shape[1] = 0 everywhere).
+ * ------------------------------------------------------------------------------------ */
+int av2x_generate_label(const float* anchor_standup, const float* gt_standup, const double* anchors7, const double* gt7,
+                        const int32_t* class_ids, int32_t n_anchors, int32_t n_gt, float pos_threshold,
+                        float neg_threshold, void* workspace, double* pos_equal_one, double* neg_equal_one,
+                        double* targets, int64_t* cls_labels, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Camera lift-splat: LiftSplatShootEncoder.get_geometry + voxel_pooling
  * (models/common_modules/airv2x_encoder.py:133-167, 208-275; QuickCumsum utils/camera_utils.py:341-365) fused.
  *   x           (b*n_cams*pts_per_cam, c) f32: the lifted features of every frustum point, point-major (b, n, d, fh, fw)

@@ -65,5 +65,44 @@ def boxes_iou_bev(boxes_a, boxes_b):
     return out
 
 
+PYX_SRC = "/root/reference/opencood/utils/box_overlaps.pyx"
+PYX_OUT_DIR = os.path.join(HERE, "_ref")
+
+
+def build_box_overlaps(force=False):
+    """The reference's own utils/box_overlaps.pyx (bbox_overlaps :17-57: the IoU behind generate_label_airv2x) compiled
+    where it lies with Cython + gcc; generated C and the module go to oracle/_ref/ only.  -> importable module path or None."""
+    import glob
+    import sys
+    have = glob.glob(os.path.join(PYX_OUT_DIR, "box_overlaps*.so"))
+    if not os.path.exists(PYX_SRC):
+        return have[0] if have else None
+    if have and not force and os.path.getmtime(have[0]) > os.path.getmtime(PYX_SRC):
+        return have[0]
+    import numpy as np
+    os.makedirs(PYX_OUT_DIR, exist_ok=True)
+    c_file = os.path.join(PYX_OUT_DIR, "box_overlaps.c")
+    r = subprocess.run([sys.executable, "-m", "cython", "-3", PYX_SRC, "-o", c_file], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("cython failed on the reference's box_overlaps.pyx:\n" + r.stdout[-3000:])
+    out = os.path.join(PYX_OUT_DIR, "box_overlaps" + sysconfig.get_config_var("EXT_SUFFIX"))
+    r = subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-w", c_file, "-o", out, "-I", sysconfig.get_paths()["include"], "-I", np.get_include()],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("gcc failed on the generated box_overlaps.c:\n" + r.stdout[-3000:])
+    return out
+
+
+def import_box_overlaps():
+    """The compiled reference module (for tools/gen_golden.py only)."""
+    import importlib.util
+    path = build_box_overlaps()
+    spec = importlib.util.spec_from_file_location("box_overlaps", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_box_overlaps(force=True))

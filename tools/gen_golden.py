@@ -867,6 +867,53 @@ def lss_golden(name, agent_type, B, N, final_dim, xy, seed, one_hot, stride):
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def labels_golden(name, lidar_range, n_gt, seed):
+    """The reference's own VoxelPostprocessor.generate_label_airv2x (voxel_postprocessor.py:217-354) with its own
+    box_overlaps.pyx (compiled by oracle/build_ref.py) on the configuration's anchors and seeded ground-truth boxes."""
+    sys.path.insert(0, ROOT)
+    from airv2x_perception_amd import synth
+    from oracle import build_ref
+    from oracle import label_oracle as lab
+    sys.modules["opencood.utils.box_overlaps"] = build_ref.import_box_overlaps()
+    for m in [k for k in sys.modules if k.startswith("opencood.data_utils.post_processor")]:
+        del sys.modules[m]
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    hy_ref = load_ref_hypes(lidar_range)
+    pp = VoxelPostprocessor(hy_ref["postprocess"], dataset="airv2x", train=True)
+    anchors = pp.generate_anchor_box()
+    rng = lidar_range or synth.DEFAULT_RANGE
+    g = np.random.default_rng(seed)
+    max_num = 100
+    gt = np.zeros((max_num, 7))
+    mask = np.zeros(max_num)
+    cls = np.zeros(max_num, dtype=int)
+    for i in range(n_gt):
+        big = i % 5 == 4                              # trucks / buses next to cars, pedestrians-sized boxes too
+        gt[i] = [g.uniform(rng[0] + 2, rng[3] - 2), g.uniform(rng[1] + 2, rng[4] - 2), g.uniform(-1.6, -0.4),
+                 g.uniform(1.4, 3.2) if big else g.uniform(1.3, 1.9), g.uniform(2.0, 2.8) if big else g.uniform(0.6, 2.1),
+                 g.uniform(6.0, 11.0) if big else g.uniform(0.7, 5.0), g.uniform(-np.pi, np.pi)]
+        mask[i] = 1
+        cls[i] = g.integers(1, 7)
+    if n_gt >= 4:                                     # two boxes almost on top of each other, one hugging the range edge
+        gt[1, :2] = gt[0, :2] + [0.3, 0.2]
+        gt[3, 0] = rng[3] - 0.7
+    out = pp.generate_label_airv2x(gt_box_center=gt, anchors=anchors, mask=mask, class_ids_padded=cls)
+    o = lab.generate_label(gt, anchors, mask, cls, hy_ref["postprocess"]["target_args"]["pos_threshold"],
+                           hy_ref["postprocess"]["target_args"]["neg_threshold"])
+    for k in out:
+        assert np.array_equal(out[k], o[k]), k
+    pos_idx = np.flatnonzero(out["pos_equal_one"].reshape(-1))
+    print(f"[{name}] {n_gt} boxes on {anchors.shape[:3]} anchors: {pos_idx.size} positives, {int(out['neg_equal_one'].sum())} negatives")
+    fx = {"lidar_range": np.asarray(rng, np.float64), "gt_box_center": gt, "mask": mask, "class_ids_padded": cls.astype(np.int64),
+          "pos_index": pos_idx.astype(np.int64), "neg_packed": np.packbits(out["neg_equal_one"].reshape(-1).astype(np.uint8)),
+          "targets_pos": out["targets"].reshape(-1, 7)[pos_idx], "targets_abssum": np.float64(np.abs(out["targets"]).sum()),
+          "cls_pos": out["cls_labels"].reshape(-1)[pos_idx].astype(np.int64), "cls_sum": np.int64(out["cls_labels"].sum()),
+          "shape": np.asarray(out["pos_equal_one"].shape, np.int64)}
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _bev_quads(boxes):
     """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,4,2) float32 BEV corners (counter-clockwise)."""
     x, y, dx, dy, h = boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]
@@ -1007,6 +1054,8 @@ GROUPS = {
                     lss_golden("lss_small_dense", "rsu", 1, 3, (96, 160), (-25.6, 25.6, -12.8, 12.8), 32, False, 1),
                     lss_golden("lss_cfg4_vehicle", "vehicle", 1, 4, (360, 640), (-140.8, 140.8, -40.0, 40.0), 33, True, 4),
                     lss_golden("lss_cfg4_drone", "drone", 1, 1, (360, 640), (-140.8, 140.8, -40.0, 40.0), 34, True, 4)),
+    "labels": lambda: (labels_golden("labels_small", SMALL, 12, 41), labels_golden("labels_full", None, 60, 42),
+                       labels_golden("labels_full_one", None, 1, 43)),
     "iou_pin": lambda: iou_pin_golden(),
     "voxel_pin": lambda: voxel_pin_golden(),
 }
