@@ -78,6 +78,7 @@ SIGNATURES = {
                                           c_int32, c_void_p]),
     "av2x_comm_mask": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_comm_mask_topk": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_apply_mask": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_pixel_attn_fuse": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_comm_rate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

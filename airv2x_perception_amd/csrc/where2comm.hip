@@ -5,6 +5,7 @@
 //   pixel_attn_kernel  per pixel softmax(x0 . xj / sqrt(C)) weighted sum over the agents
 //                      (ego row only), online softmax, 16 lanes per pixel, 16-byte loads
 #include "av2x_common.hpp"
+#include "block_scan.hpp"
 
 namespace {
 
@@ -186,6 +187,84 @@ extern "C" int av2x_comm_mask(const float* psm, int32_t n, int32_t h, int32_t w,
     hipLaunchKernelGGL(comm_mask_kernel, dim3((w + 63) / 64, (h + 3) / 4, n), dim3(64, 4), 0, st, conf, n, h, w, gauss_w, gauss_b, k,
                        threshold, sample_of_agent, is_ego, smooth, mask, count);
     return av2x::check_launch("comm_mask_kernel");
+}
+
+namespace {
+// Training proxy objective of Communication.forward (where2comm_fuse.py:104-121): every agent transmits the K cells with
+// the largest smoothed confidence (K drawn by the caller: int(H * W * random.uniform(0, 1)), :106).  One workgroup per
+// agent: the K-th largest value by bisection over an order-preserving key of the fp32 bits (exact, 32 passes over the
+// L2-resident map), then mask = value above it, plus the lowest-indexed cells equal to it until K are set (torch.topk's
+// choice among exactly tied values is unspecified; tie-free maps give the same set).  count[sample] += cells set, before
+// the ego override (:137-143).
+__device__ __forceinline__ unsigned order_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void comm_topk_kernel(const float* __restrict__ smooth, int hw, const int* __restrict__ k_of_agent,
+                                                         const int* __restrict__ sample_of, const int* __restrict__ is_ego,
+                                                         float* __restrict__ mask, int* __restrict__ count) {
+    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* v = smooth + (size_t)a * hw;
+    float* m = mask + (size_t)a * hw;
+    int K = k_of_agent[a];
+    K = K < 0 ? 0 : (K > hw ? hw : K);
+    __shared__ int red[16];
+    __shared__ int tot;
+    auto count_ge = [&](unsigned key) {
+        int c = 0;
+        for (int i = tid; i < hw; i += 1024) c += order_key(v[i]) >= key;
+        for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+        __syncthreads();
+        if (lane == 0) red[wave] = c;
+        __syncthreads();
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        return t;
+    };
+    unsigned cut = 0xffffffffu;
+    int c_gt = 0;
+    if (K > 0 && K < hw) {
+        unsigned lo = 0u, hi = 0xffffffffu;     // |{key >= lo}| = hw >= K ; |{key >= hi}| < K unless K values are +NaN-max (not for finite maps)
+        while (hi - lo > 1u) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            if (count_ge(mid) >= K) lo = mid; else hi = mid;
+        }
+        cut = lo;
+        c_gt = cut == 0xffffffffu ? 0 : count_ge(cut + 1u);
+    }
+    __syncthreads();
+    if (K == 0 || K == hw) {
+        for (int i = tid; i < hw; i += 1024) m[i] = K ? 1.f : 0.f;
+    } else {
+        const int need = K - c_gt;     // cells equal to the cut that still get a one, lowest index first
+        av2x::block_scan<16>(
+            hw, [&](int i) { return order_key(v[i]) == cut ? 1 : 0; },
+            [&](int i, int ex) {
+                const unsigned key = order_key(v[i]);
+                m[i] = (key > cut || (key == cut && ex < need)) ? 1.f : 0.f;
+            },
+            &tot);
+    }
+    __syncthreads();
+    if (tid == 0) atomicAdd(count + sample_of[a], K);
+    if (is_ego[a]) {
+        __syncthreads();
+        for (int i = tid; i < hw; i += 1024) m[i] = 1.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int av2x_comm_mask_topk(const float* smooth, int32_t n, int32_t hw, const int32_t* k_of_agent,
+                                   const int32_t* sample_of_agent, const int32_t* is_ego, float* mask, int32_t* count,
+                                   av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!smooth || !k_of_agent || !sample_of_agent || !is_ego || !mask || !count) return av2x::fail("av2x_comm_mask_topk: null argument");
+    if (n < 0 || hw <= 0) return av2x::fail("av2x_comm_mask_topk: bad sizes");
+    hipLaunchKernelGGL(comm_topk_kernel, dim3(n), dim3(1024), 0, av2x::as_stream(stream), smooth, hw, k_of_agent, sample_of_agent,
+                       is_ego, mask, count);
+    return av2x::check_launch("comm_topk_kernel");
 }
 
 namespace {

@@ -669,7 +669,10 @@ class Where2ComEngine:
             self.ws[key] = lay
         return lay
 
-    def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True, tag="", count=None):
+    def comm_mask(self, psm_single, n, H, W, record_len, has_ego=True, tag="", count=None, topk=None):
+        """Communication.forward (where2comm_fuse.py:83-149).  ``topk``: the TRAINING branch (:104-121) -- one K per sample
+        (int(H * W * random.uniform(0, 1)) in the reference): every agent of the sample transmits its K most confident cells
+        instead of the thresholded ones."""
         B = len(record_len)
         lay = self.comm_layout(record_len, has_ego)
         conf = self.buf("comm_conf" + tag, (n, H, W))
@@ -683,6 +686,13 @@ class Where2ComEngine:
                                            _ptr(self.gauss_w), _ptr(self.gauss_b), self.gauss_k, self.threshold,
                                            _ptr(lay[0]), _ptr(lay[1]), _ptr(conf), _ptr(smooth), _ptr(mask),
                                            _ptr(count), st), "av2x_comm_mask")
+        if topk is not None:
+            if len(topk) != B:
+                raise ValueError("topk: one K per sample")
+            ks = torch.tensor([int(topk[b]) for b, k in enumerate(record_len) for _ in range(k)], dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.av2x_fill_zero(_ptr(count), B * 4, st), "av2x_fill_zero")
+            _lib.check(self.lib.av2x_comm_mask_topk(_ptr(smooth), n, H * W, _ptr(ks), _ptr(lay[0]), _ptr(lay[1]), _ptr(mask), _ptr(count),
+                                                    st), "av2x_comm_mask_topk")
         return mask, count, smooth, lay[2]
 
     def comm_rate(self, count, agents_per_sample, B, hw):

@@ -178,6 +178,12 @@ int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents, int32_t h
 
 /* com = mean_b count[b] / (agents_per_sample[b] * hw): the `communication_rates` scalar of where2comm_fuse.py:137,147
  * from the popcounts av2x_comm_mask accumulated; count (n_samples,) i32, agents_per_sample (n_samples,) f32, com (1,) f32. */
+/* Training branch of Communication.forward (where2comm_fuse.py:104-121): mask = the k_of_agent[a] cells of agent a with
+ * the largest SMOOTHED confidence (`smooth` as written by av2x_comm_mask), count[sample] += that many (before the ego
+ * override), ego agents all ones.  K = int(H * W * random.uniform(0, 1)) is drawn by the caller (one draw per sample). */
+int av2x_comm_mask_topk(const float* smooth, int32_t n, int32_t hw, const int32_t* k_of_agent,
+                        const int32_t* sample_of_agent, const int32_t* is_ego, float* mask, int32_t* count,
+                        av2x_stream_t stream);
 int av2x_comm_rate(const int32_t* count, const float* agents_per_sample, int32_t n_samples, int32_t hw, float* com,
                    av2x_stream_t stream);
 

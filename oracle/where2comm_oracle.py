@@ -159,8 +159,9 @@ def head(x, sd, name):
 
 
 # ---------------------------------------------------------------- a11: communication mask
-def communication(psm_split, sd, comm_cfg):
-    """where2comm_modules/where2comm_fuse.py:83-149, eval branch.
+def communication(psm_split, sd, comm_cfg, topk=None):
+    """where2comm_modules/where2comm_fuse.py:83-149: the eval branch, or -- ``topk`` = one K per sample, the value the
+    reference draws as int(H * W * random.uniform(0, 1)) (:106) -- the training branch (:104-121).
 
     psm_split: list over samples of (L_b, A*C, H, W).  Returns (mask (sum L,1,H,W),
     rate 0-dim tensor, smoothed maps (for threshold-margin checks in tests)).
@@ -178,7 +179,11 @@ def communication(psm_split, sd, comm_cfg):
         else:
             cm = ori
         L, _, H, W = cm.shape
-        if thr:
+        if topk is not None:
+            flat = cm.reshape(L, H * W)
+            _, idx = torch.topk(flat, k=int(topk[b]), sorted=False)
+            m = torch.scatter(torch.zeros_like(flat), -1, idx, torch.ones(L, int(topk[b]))).reshape(L, 1, H, W)
+        elif thr:
             m = torch.where(cm > thr, torch.ones_like(cm), torch.zeros_like(cm))
         else:
             m = torch.ones_like(cm)

@@ -914,6 +914,40 @@ def labels_golden(name, lidar_range, n_gt, seed):
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def comm_train_golden(name="comm_train"):
+    """The reference's Communication module (where2comm_fuse.py:48-149) in TRAINING mode: K = int(H*W*random.uniform(0,1))
+    per sample from Python's seeded `random`, top-K of the smoothed confidence per agent, rate before the ego override."""
+    import random
+
+    from airv2x_perception_amd import synth
+    from oracle import where2comm_oracle as orc
+    from opencood.models.where2comm_modules.where2comm_fuse import Communication
+    cfg = {"round": 1, "threshold": 0.01, "gaussian_smooth": {"k_size": 5, "c_sigma": 1.0}}
+    comm = Communication(cfg).train()
+    sd = {"fusion_net.naive_communication." + k: v for k, v in comm.state_dict().items()}
+    lens = [3, 2]
+    H, W = 24, 40
+    psm = torch.from_numpy(synth.seeded_uniform(77, (sum(lens), 14, H, W), -6.0, 2.0))
+    split = list(torch.split(psm, lens))
+    fx = {"lens": np.asarray(lens, np.int64), "H": np.int64(H), "W": np.int64(W), "seed_psm": np.int64(77),
+          "gauss_w": comm.gaussian_filter.weight.detach().numpy(), "gauss_b": comm.gaussian_filter.bias.detach().numpy()}
+    for trial, seed in enumerate((1, 2, 3)):
+        random.seed(seed)
+        with torch.no_grad():
+            masks, rate = comm(split, len(lens))
+        random.seed(seed)
+        ks = [int(H * W * random.uniform(0, 1)) for _ in lens]
+        om, orate, _ = orc.communication(split, sd, cfg, topk=ks)
+        assert torch.equal(om, masks) and float(orate) == float(rate), (trial, ks)
+        fx[f"k_{trial}"] = np.asarray(ks, np.int64)
+        fx[f"mask_{trial}"] = np.packbits(masks.numpy().astype(np.uint8).reshape(-1))
+        fx[f"rate_{trial}"] = np.float32(rate)
+        print(f"[{name}] seed {seed}: K = {ks}, rate {float(rate):.4f}")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path}")
+
+
 def _bev_quads(boxes):
     """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,4,2) float32 BEV corners (counter-clockwise)."""
     x, y, dx, dy, h = boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]
@@ -1056,6 +1090,7 @@ GROUPS = {
                     lss_golden("lss_cfg4_drone", "drone", 1, 1, (360, 640), (-140.8, 140.8, -40.0, 40.0), 34, True, 4)),
     "labels": lambda: (labels_golden("labels_small", SMALL, 12, 41), labels_golden("labels_full", None, 60, 42),
                        labels_golden("labels_full_one", None, 1, 43)),
+    "comm_train": lambda: comm_train_golden(),
     "iou_pin": lambda: iou_pin_golden(),
     "voxel_pin": lambda: voxel_pin_golden(),
 }
