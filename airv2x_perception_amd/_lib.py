@@ -46,6 +46,11 @@ SIGNATURES = {
     "av2x_linear_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_uint64, c_void_p]),
     "av2x_when2com_fuse": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "av2x_conv2d_wgrad_workspace_bytes": (c_uint64, [POINTER(ConvDesc)]),
+    "av2x_conv2d_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_act_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_channel_sum_workspace_bytes": (c_uint64, [c_int64, c_int32]),
+    "av2x_channel_sum": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "av2x_generate_label": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_lss_pool_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32, c_int32]),

@@ -1,0 +1,272 @@
+// Backward pieces of the BEV convolutions (first slice of training on the MI355X path):
+//   av2x_conv2d_wgrad   dW[co][ci][kh][kw] = sum over output pixels of dY[p][co] * X[p shifted by the tap][ci]
+//   av2x_act_backward   dZ = dY * act'(Y) * scale[c]      (ReLU / identity, folded-BN or unit scale)
+//   av2x_channel_sum    db[c] = sum over pixels of dZ[p][c]
+// The data gradient needs no kernel of its own: for stride 1 it IS a convolution of dZ with the 180-degree-rotated,
+// channel-transposed weights (av2x_conv2d on weights packed that way); for stride 2 the same on the zero-upsampled dZ
+// (opencood_iface/autograd.py).
+//
+// wgrad as a GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): per tap C[co][ci] = A^T B with A = dY (pixels x
+// cout) and B = X shifted (pixels x cin) -- the REDUCTION runs over pixels, which are the slow axis of both NHWC operands,
+// so a K-step is 32 pixel ROWS of each (fully coalesced 4*C-byte runs).  Both stages go L2 -> LDS by LDS-DMA in their
+// natural [pixel][channel] image; an MFMA lane (i = lane & 31, h = lane >> 5) needs A[k = 2s + h][row i]: one ds_read_b64
+// fetches channels 2i, 2i+1 of pixel 2s + h, i.e. the operands of TWO accumulator tiles whose rows are interleaved
+// (tile a holds output channels 2i + a) -- a free permutation of the output rows that the store undoes.
+// The pixel axis is cut into chunks (one workgroup per (tile, tap, chunk)); the per-chunk partial dW slabs are summed
+// in ascending chunk order by a second kernel: deterministic, no atomics.
+#include "av2x_common.hpp"
+
+namespace {
+
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+typedef float f32x2b __attribute__((ext_vector_type(2)));
+
+struct WgradParams {
+    const float* x;
+    const float* dy;
+    float* part;      // [chunk][tap][Cout][Cin]
+    int H, W, Cin, in_ctot, in_coff, Ho, Wo, HoWo, Cout, dy_ctot, dy_coff, ks, stride, pad;
+    int M, chunk, nchunks, tiles_ci;
+    unsigned x_bytes, dy_bytes;
+};
+
+__device__ __forceinline__ void glds16b(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+// workgroup = 4 waves, output tile TC couts x TC cins (TC = 128: each wave 64 x 64; TC = 64: each wave 32 x 32)
+template <int TC>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int WT = TC / 2;                 // wave tile edge
+    constexpr int MT = WT / 32;                // accumulator tiles per wave edge (2 or 1)
+    constexpr int ROWB = TC * 4;               // bytes of one pixel row of a stage
+    constexpr int STAGE = 32 * ROWB;           // one operand, 32 pixels
+    constexpr int PPI = 1024 / ROWB;           // pixels per 1 KiB DMA instruction (2 or 4)
+    constexpr int INST = 32 / PPI;             // instructions per operand stage (16 or 8)
+    constexpr int LD = INST / 4;               // per wave
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.tiles_ci * ((p.Cout + TC - 1) / TC);
+    int b = blockIdx.x;
+    const int tile = b % tiles; b /= tiles;
+    const int tap = b % (p.ks * p.ks);
+    const int chunk = b / (p.ks * p.ks);
+    const int co0 = (tile / p.tiles_ci) * TC, ci0 = (tile % p.tiles_ci) * TC;
+    const int kh = tap / p.ks, kw = tap - kh * p.ks;
+    const int p0 = chunk * p.chunk, p1 = min(p0 + p.chunk, p.M);
+    const int nst = (p1 - p0 + 31) / 32;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int lpp = ROWB / 16;                 // lanes per pixel row (32 or 16)
+    const int lp = lane / lpp, lq = lane % lpp;
+
+    auto issue = [&](int step, int buf) {
+        unsigned char* sa = sm + buf * 2 * STAGE;
+        unsigned char* sb = sa + STAGE;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            const int inst = wave * LD + i;
+            const int pix = p0 + step * 32 + inst * PPI + lp;
+            unsigned va = OOB, vb = OOB;
+            if (pix < p1) {
+                const int img = pix / p.HoWo, rem = pix - img * p.HoWo;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                if (co0 + lq * 4 < p.Cout) va = (unsigned)(((size_t)pix * p.dy_ctot + p.dy_coff + co0 + lq * 4) * 4);
+                const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && ci0 + lq * 4 < p.Cin)
+                    vb = (unsigned)((((size_t)img * p.H + hi) * p.W + wi) * p.in_ctot + p.in_coff + ci0 + lq * 4) * 4u;
+            }
+            glds16b(rdy, sa + inst * 1024, va, 0);
+            glds16b(rx, sb + inst * 1024, vb, 0);
+        }
+    };
+
+    f32x16b acc[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = (wave >> 1) * WT, wc = (wave & 1) * WT;     // wave's corner inside the tile (cout, cin)
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) issue(s + 1, buf ^ 1);
+        const unsigned char* sa = sm + buf * 2 * STAGE;
+        const unsigned char* sb = sa + STAGE;
+#pragma unroll 4
+        for (int k2 = 0; k2 < 16; ++k2) {                       // 16 MFMA k-pairs = 32 pixels
+            const int row = 2 * k2 + lh;
+            float av[MT], bv[MT];
+            if constexpr (MT == 2) {
+                const f32x2b ta = *reinterpret_cast<const f32x2b*>(sa + row * ROWB + (wr + 2 * li) * 4);
+                const f32x2b tb = *reinterpret_cast<const f32x2b*>(sb + row * ROWB + (wc + 2 * li) * 4);
+                av[0] = ta.x; av[1] = ta.y; bv[0] = tb.x; bv[1] = tb.y;
+            } else {
+                av[0] = *reinterpret_cast<const float*>(sa + row * ROWB + (wr + li) * 4);
+                bv[0] = *reinterpret_cast<const float*>(sb + row * ROWB + (wc + li) * 4);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int c = 0; c < MT; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[c], acc[a][c], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); tile (a, c) row i holds
+    // cout wr + MT * i + a, column j holds cin wc + MT * j + c
+    float* out = p.part + ((size_t)chunk * p.ks * p.ks + tap) * p.Cout * p.Cin;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int co = co0 + wr + MT * i + a, ci = ci0 + wc + MT * li + c;
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[a][c][r];
+            }
+}
+
+// dw[co][ci][tap] = sum over chunks (ascending) of part[chunk][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nchunks, int taps, int cout, int cin,
+                                                           float* __restrict__ dw) {
+    const size_t n = (size_t)taps * cout * cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * n + i];
+        const int ci = (int)(i % cin);
+        const size_t r = i / cin;
+        const int co = (int)(r % cout), tap = (int)(r / cout);
+        dw[((size_t)co * cin + ci) * taps + tap] = s;
+    }
+}
+
+// dz = dy * act'(y) * scale[c]   (act 0: identity, 1: ReLU -- y is the layer's OUTPUT, y > 0 <=> pre-activation > 0)
+__global__ __launch_bounds__(256) void act_backward_kernel(const float4* __restrict__ y, const float4* __restrict__ dy,
+                                                           const float* __restrict__ scale, size_t n4, int c4, int act,
+                                                           float4* __restrict__ dz) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 g = dy[i];
+        if (act == 1) {
+            const float4 v = y[i];
+            g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
+        }
+        if (scale) {
+            const int c = (int)(i % c4) * 4;
+            g.x *= scale[c]; g.y *= scale[c + 1]; g.z *= scale[c + 2]; g.w *= scale[c + 3];
+        }
+        dz[i] = g;
+    }
+}
+
+// two-stage deterministic column sum: stage 1 = one workgroup per slab of rows, stage 2 sums the slabs in order
+__global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, size_t rows, int c, size_t slab,
+                                                          float* __restrict__ part) {
+    const size_t r0 = (size_t)blockIdx.x * slab, r1 = r0 + slab < rows ? r0 + slab : rows;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float s = 0.f;
+        for (size_t r = r0; r < r1; ++r) s += x[r * c + ch];
+        part[(size_t)blockIdx.x * c + ch] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void channel_sum_stage2(const float* __restrict__ part, int nslabs, int c, float* __restrict__ out) {
+    for (int ch = blockIdx.x * 256 + threadIdx.x; ch < c; ch += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslabs; ++k) s += part[(size_t)k * c + ch];
+        out[ch] = s;
+    }
+}
+
+constexpr int kWgradChunk = 2048;   // output pixels per workgroup (64 K-steps of 32)
+
+}  // namespace
+
+extern "C" uint64_t av2x_conv2d_wgrad_workspace_bytes(const av2x_conv_desc* d) {
+    if (!d) return 0;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long nch = (M + kWgradChunk - 1) / kWgradChunk;
+    return (uint64_t)nch * d->ks * d->ks * d->cout * d->cin * 4ull;
+}
+
+extern "C" int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const float* dy, void* workspace, float* dw,
+                                 av2x_stream_t stream) {
+    if (!d || !x || !dy || !workspace || !dw) return av2x::fail("av2x_conv2d_wgrad: null argument");
+    if (d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d_wgrad: plain convolutions only (mode AV2X_CONV)");
+    if (d->ks != 1 && d->ks != 3) return av2x::fail("av2x_conv2d_wgrad: ks=%d unsupported", d->ks);
+    if (d->cin % 4 || d->cout % 4 || d->in_ctot % 4 || d->in_coff % 4 || d->out_ctot % 4 || d->out_coff % 4)
+        return av2x::fail("av2x_conv2d_wgrad: channel counts / offsets must be multiples of 4");
+    if (d->ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1 || d->wo != (d->w + 2 * d->pad - d->ks) / d->stride + 1)
+        return av2x::fail("av2x_conv2d_wgrad: output dims inconsistent with input/stride/pad");
+    const long long M = (long long)d->n * d->ho * d->wo;
+    if (M <= 0) return av2x::fail("av2x_conv2d_wgrad: empty tensor");
+    const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->in_ctot * 4ull;
+    const unsigned long long yb = (unsigned long long)M * d->out_ctot * 4ull;
+    if (xb >= (1ull << 31) || yb >= (1ull << 31)) return av2x::fail("av2x_conv2d_wgrad: tensor exceeds the 2 GiB buffer-descriptor window");
+    WgradParams p;
+    p.x = x; p.dy = dy; p.part = reinterpret_cast<float*>(workspace);
+    p.H = d->h; p.W = d->w; p.Cin = d->cin; p.in_ctot = d->in_ctot; p.in_coff = d->in_coff;
+    p.Ho = d->ho; p.Wo = d->wo; p.HoWo = d->ho * d->wo; p.Cout = d->cout; p.dy_ctot = d->out_ctot; p.dy_coff = d->out_coff;
+    p.ks = d->ks; p.stride = d->stride; p.pad = d->pad;
+    p.M = (int)M; p.chunk = kWgradChunk; p.nchunks = (int)((M + kWgradChunk - 1) / kWgradChunk);
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+    hipStream_t st = av2x::as_stream(stream);
+    const int taps = d->ks * d->ks;
+    static av2x::LdsLimit lim128, lim64;
+    if (d->cin > 64 || d->cout > 64) {
+        p.tiles_ci = (d->cin + 127) / 128;
+        const int tiles = p.tiles_ci * ((d->cout + 127) / 128);
+        const size_t lds = 2 * 2 * 32 * 512;
+        lim128.ensure(reinterpret_cast<const void*>(&conv_wgrad_kernel<128>), lds);
+        hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3(tiles * taps * p.nchunks), dim3(256), lds, st, p);
+    } else {
+        p.tiles_ci = 1;
+        const size_t lds = 2 * 2 * 32 * 256;
+        lim64.ensure(reinterpret_cast<const void*>(&conv_wgrad_kernel<64>), lds);
+        hipLaunchKernelGGL(conv_wgrad_kernel<64>, dim3(taps * p.nchunks), dim3(256), lds, st, p);
+    }
+    if (int e = av2x::check_launch("conv_wgrad_kernel")) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(512), dim3(256), 0, st, p.part, p.nchunks, taps, d->cout, d->cin, dw);
+    return av2x::check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" int av2x_act_backward(const float* y, const float* dy, const float* scale, int64_t rows, int32_t c, int32_t act,
+                                 float* dz, av2x_stream_t stream) {
+    if (!dy || !dz || (act == 1 && !y)) return av2x::fail("av2x_act_backward: null argument");
+    if (act != 0 && act != 1) return av2x::fail("av2x_act_backward: act %d (0 identity, 1 ReLU)", act);
+    if (rows <= 0 || c <= 0 || c % 4) return av2x::fail("av2x_act_backward: bad sizes");
+    const size_t n4 = (size_t)rows * c / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(dy), scale, n4, c / 4, act,
+                       reinterpret_cast<float4*>(dz));
+    return av2x::check_launch("act_backward_kernel");
+}
+
+extern "C" uint64_t av2x_channel_sum_workspace_bytes(int64_t rows, int32_t c) {
+    const int64_t slabs = (rows + 511) / 512;
+    return (uint64_t)slabs * c * 4ull;
+}
+
+extern "C" int av2x_channel_sum(const float* x, int64_t rows, int32_t c, void* workspace, float* out, av2x_stream_t stream) {
+    if (!x || !workspace || !out || rows <= 0 || c <= 0) return av2x::fail("av2x_channel_sum: bad argument");
+    const int slabs = (int)((rows + 511) / 512);
+    hipStream_t st = av2x::as_stream(stream);
+    hipLaunchKernelGGL(channel_sum_stage1, dim3(slabs), dim3(256), 0, st, x, (size_t)rows, c, (size_t)512, reinterpret_cast<float*>(workspace));
+    hipLaunchKernelGGL(channel_sum_stage2, dim3((c + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), slabs, c, out);
+    return av2x::check_launch("channel_sum");
+}

@@ -268,6 +268,25 @@ int av2x_postprocess_devt(const float* psm, const float* rm, const float* obj, c
                           int32_t* counts, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Backward of the BEV convolutions (first slice; the reference trains through torch autograd,
+ * tools/train.py:220-247).  For y = act(scale * conv(x, w) + shift):
+ *   av2x_act_backward   dz = dy * act'(y) * scale[c]   (act 0 identity / 1 ReLU on the stored OUTPUT y; scale may be NULL)
+ *   av2x_channel_sum    d shift[c] = sum over pixels of dy * act'(y)    (rows x c, two-stage deterministic sum)
+ *   av2x_conv2d_wgrad   dw (cout, cin, ks, ks) = correlation of x with dz (desc as for the forward launch: out_ctot /
+ *                       out_coff describe dz's channel stride / offset); fp32 MFMA, pixel axis chunked, partial slabs
+ *                       in `workspace` (av2x_conv2d_wgrad_workspace_bytes) summed in a fixed order -- bit-reproducible
+ *   data gradient       av2x_conv2d of dz with the 180-degree-rotated, channel-transposed weights (stride 2: on the
+ *                       zero-upsampled dz) -- opencood_iface/autograd.py
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_conv2d_wgrad_workspace_bytes(const av2x_conv_desc* d);
+int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const float* dz, void* workspace, float* dw,
+                      av2x_stream_t stream);
+int av2x_act_backward(const float* y, const float* dy, const float* scale, int64_t rows, int32_t c, int32_t act,
+                      float* dz, av2x_stream_t stream);
+uint64_t av2x_channel_sum_workspace_bytes(int64_t rows, int32_t c);
+int av2x_channel_sum(const float* x, int64_t rows, int32_t c, void* workspace, float* out, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Training labels: VoxelPostprocessor.generate_label_airv2x (voxel_postprocessor.py:217-354) with
  * bbox_overlaps (utils/box_overlaps.pyx:17-57) -- the anchor <-> ground-truth assignment, without the IoU matrix.
  *   anchor_standup (n_anchors,4) / gt_standup (n_gt,4) f32: [xmin,ymin,xmax,ymax] of corner2d_to_standup_box (:266-270);
