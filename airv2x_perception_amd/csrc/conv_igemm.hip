@@ -489,13 +489,17 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     if (d->tile & 0x0400) {   // split-3: fp32-accurate products from three bf16 terms per operand; w = [3] bf16 planes
         p.w_bytes = (unsigned)(w_bytes / 2 * 3);
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
-        const bool w8b = (d->tile & 0x8000) != 0;
-        if (w8b && bm == 128 && bn == 128) return launch_bf16x3<128, 128, 64, 32>(p, st);
-        if (w8b && bm == 128 && bn == 64) return launch_bf16x3<128, 64, 32, 32>(p, st);
-        if (!w8b && bm == 128 && bn == 128) return launch_bf16x3<128, 128, 64, 64>(p, st);
-        if (!w8b && bm == 128 && bn == 64) return launch_bf16x3<128, 64, 64, 32>(p, st);
-        if (!w8b && bm == 64 && bn == 64) return launch_bf16x3<64, 64, 32, 32>(p, st);
-        if (!w8b && bm == 128 && bn == 32) return launch_bf16x3<128, 32, 32, 32>(p, st);
+        const bool w8b = (d->tile & 0x8000) != 0, db3 = (d->tile & 0x4000) != 0;   // 0x4000: second LDS buffer set
+#define AV2X_X3(W8, BMv, BNv, WMv, WNv)                                                                   \
+        if (w8b == W8 && bm == BMv && bn == BNv)                                                          \
+            return db3 ? launch_bf16x3<BMv, BNv, WMv, WNv, true>(p, st) : launch_bf16x3<BMv, BNv, WMv, WNv, false>(p, st);
+        AV2X_X3(true, 128, 128, 64, 32)
+        AV2X_X3(true, 128, 64, 32, 32)
+        AV2X_X3(false, 128, 128, 64, 64)
+        AV2X_X3(false, 128, 64, 64, 32)
+        AV2X_X3(false, 64, 64, 32, 32)
+        AV2X_X3(false, 128, 32, 32, 32)
+#undef AV2X_X3
         return av2x::fail("av2x_conv2d: unsupported split-3 tile %dx%d", bm, bn);
     }
     if (d->tile & 0x0800) {   // bf16 matrix-core operands ("AMP" mode): w is the bf16 packing [tap][cin/8][coutp][8]

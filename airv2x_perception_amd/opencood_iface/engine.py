@@ -451,8 +451,9 @@ class Where2ComEngine:
     def _candidates(self, d, L, skc):
         if self.amp:
             cands = list(self.AMP_CANDIDATES)
-        elif self.split3:
+        elif self.split3:   # + the double-buffered forms (0x4000: second LDS buffer set, one barrier per K-step)
             cands = [(bm, (bn & ~0x0800) | 0x0400, g) for bm, bn, g in self.AMP_CANDIDATES]
+            cands += [(bm, bn | 0x4000, g) for bm, bn, g in cands]
         elif skc == "rule":
             cands = list(self.SK_RULE_IMPLS)
         else:

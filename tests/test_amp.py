@@ -176,6 +176,17 @@ def test_split3_conv_is_fp32_accurate(case):
         errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
     assert errs["split3"][1] <= 1.5 * errs["f32"][1] and errs["split3"][0] <= 2.0 * errs["f32"][0], errs
     assert errs["split3"][0] <= 1e-5 * max(1.0, float(ref.abs().max())), errs
+    # the double-buffered form (tile flag 0x4000: second LDS buffer set, one barrier per K-step) runs the same operations
+    # in the same order: bit-identical
+    both = []
+    for t in (tile, tile | 0x4000):
+        out = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=ho, wo=wo, cout=cout, coutp=coutp, out_ctot=cout,
+                          out_coff=0, ks=ks, stride=stride, pad=pad, relu=0, mode=0, up=1, tile=t, sk_wgs=0)
+        _lib.check(lib.av2x_conv2d(byref(d), _p(xd), _p(w3d), _p(one), _p(zero), _p(out),
+                                   c_void_p(torch.cuda.current_stream().cuda_stream)), "split3")
+        both.append(out)
+    assert torch.equal(both[0], both[1]) and not torch.isnan(both[1]).any()
 
 
 def test_where2comm_split3_forward_meets_the_fp32_tolerance():

@@ -27,8 +27,10 @@ for (n, h, w, cin, cout, ks, stride) in ((2, 23, 31, 64, 64, 3, 1), (1, 20, 36, 
     y32 = None
     for tn, tile, wgt in (("f32 128x128w8d", (128 << 16) | 128 | 0xc000, w32), ("f32 64x64d", (64 << 16) | 64 | 0x4000, w32),
                           ("x3 128x128w8", (128 << 16) | 128 | 0x8400, w3), ("x3 128x64w8", (128 << 16) | 64 | 0x8400, w3),
-                          ("x3 128x128", (128 << 16) | 128 | 0x0400, w3), ("x3 128x64", (128 << 16) | 64 | 0x0400, w3), ("x3 64x64", (64 << 16) | 64 | 0x0400, w3)):
-        if coutp % (tile & 0x3ff): continue
+                          ("x3 128x128", (128 << 16) | 128 | 0x0400, w3), ("x3 128x64", (128 << 16) | 64 | 0x0400, w3), ("x3 64x64", (64 << 16) | 64 | 0x0400, w3),
+                          ("x3db 128x128w8", (128 << 16) | 128 | 0xc400, w3), ("x3db 128x64w8", (128 << 16) | 64 | 0xc400, w3),
+                          ("x3db 128x128", (128 << 16) | 128 | 0x4400, w3), ("x3db 128x64", (128 << 16) | 64 | 0x4400, w3), ("x3db 64x64", (64 << 16) | 64 | 0x4400, w3)):
+        if coutp % (tile & 0x1ff): continue
         y = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=ho, wo=wo, cout=cout, coutp=coutp, out_ctot=cout, out_coff=0, ks=ks, stride=stride, pad=pad, relu=0, mode=0, up=1, tile=tile, sk_wgs=0)
         call = lambda: _lib.check(lib.av2x_conv2d(byref(d), P(xd), P(wgt), P(sc), P(sh), P(y), st), "c")
