@@ -584,6 +584,10 @@ def main(argv=None, hooks=None, device=None):
             sh[2] += dur
         dom = max(per, key=lambda k: per[k][2])
         cnt, fl, sec = per[dom]
+        # algorithmic HBM bytes of the dominant kernel's launches: input pixels x Cin + the filter + output pixels x Cout, fp32,
+        # each once (shape = (M output pixels, Cin, Cout, kernel size, stride); a strided layer reads stride^2 x M input pixels)
+        alg_bytes = sum(v[0] * 4 * (k[0][0] * k[0][4] ** 2 * k[0][1] + k[0][3] ** 2 * k[0][1] * k[0][2] + k[0][0] * k[0][2])
+                        for k, v in shapes.items() if k[1] == dom) / cnt
         ach = fl / sec / 1e12
         tot_fl = sum(v[1] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
@@ -592,6 +596,7 @@ def main(argv=None, hooks=None, device=None):
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS), 4), "traffic": traffic, "traffic_note": traffic_note,
+            "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
             "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,

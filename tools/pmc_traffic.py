@@ -22,6 +22,11 @@ def rows(d):
 
 
 def conv_key(name):
+    g = re.search(r"conv_igemm_f32_glds<(\d+), (\d+), (\d+), (\d+), (\d), (\d)>", name)
+    if g:   # LDS-DMA kernels: bench.py's key "g<BM>x<BN>[w8][d = 3 LDS stages][sk]"
+        bm, bn, wm, wn, stages, mode = (int(g.group(i)) for i in range(1, 7))
+        waves = (bm // wm) * (bn // wn)
+        return f"g{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if stages == 3 else ''}{'sk' if mode == 1 else ''}"
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false|\d))?>", name)
     if not m:
         return None
