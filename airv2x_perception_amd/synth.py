@@ -852,6 +852,48 @@ def submodule_configs():
     }
 
 
+def w2c_attn_configs():
+    """Reduced configurations of the OPV2V-style Where2comm (where2comm_modules/where2comm_attn.py) and of the
+    BaseBEVBackbone it drives; channel counts are the real ones (64 / 128 / 256), the map is 32 x 48 cells."""
+    bb = {"layer_nums": [1, 1, 1], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+          "upsample_strides": [1, 2, 4], "num_upsample_filter": [32, 32, 32]}
+    base = {"voxel_size": list(DEFAULT_VOXEL), "downsample_rate": 2, "multi_scale": True,
+            "layer_nums": bb["layer_nums"], "num_filters": bb["num_filters"]}
+    gauss = {"thre": 0.01, "gaussian_smooth": {"k_size": 5, "c_sigma": 1.0}}
+    return {
+        "backbone": bb,
+        "ms_atten": dict(base, agg_operator={"mode": "ATTEN"}, communication=dict(gauss)),
+        "ms_max": dict(base, agg_operator={"mode": "MAX"}, communication={"thre": 0.004}),
+        "ss_atten": dict(base, multi_scale=False, agg_operator={"mode": "ATTEN", "feature_dim": 256}, communication=dict(gauss)),
+        "ss_max": dict(base, multi_scale=False, agg_operator={"mode": "MAX", "feature_dim": 64}),
+    }
+
+
+def w2c_attn_pairwise(record_len, L=5):
+    """(B,L,L,4,4) fp32: row 0 of every sample (the ego's row, the only one where2comm_attn.py:364 reads) carries a
+    different small SE(2) motion for every agent, the ego's own entry being the identity."""
+    t = torch.eye(4).view(1, 1, 1, 4, 4).repeat(len(record_len), L, L, 1, 1)
+    for b, n in enumerate(record_len):
+        for j in range(1, n):
+            t[b, 0, j] = torch.from_numpy(se2_correction(2.5 * j - 1.5 * b, 1.3 * j + 0.4 * b, -0.9 * j + 0.2 * b)).float()
+    return t
+
+
+def w2c_attn_features(seed, n, c, h, w, keep=0.35):
+    """Pillar-canvas-like input: ``keep`` of the cells carry features, the rest are exactly zero."""
+    x = seeded_uniform(seed, (n, c, h, w))
+    occ = seeded_uniform(seed + 1000, (n, 1, h, w), 0.0, 1.0) < keep
+    return (x * occ).astype(np.float32)
+
+
+def w2c_attn_psm(seed, n, h, w, anchors=2):
+    """Logits whose (smoothed) confidence straddles the thresholds of w2c_attn_configs on a band that moves with the agent."""
+    psm = seeded_uniform(seed, (n, anchors, h, w), -9.0, -5.0)
+    for a in range(n):
+        psm[a, :, :, (5 * a) % w:(5 * a) % w + 8] += 3.5
+    return psm
+
+
 def submodule_psm(n=3, h=16, w=16):
     """Per-agent classification logits whose smoothed confidence straddles the 0.01 threshold: low everywhere,
     raised on a different part of the map for every agent."""

@@ -335,6 +335,29 @@ int av2x_v2v_aggregate(const float* msg_a, const float* ego_b, const float* thet
                        int32_t c, int32_t op, float* out, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * OPV2V-style Where2comm (models/where2comm_modules/where2comm_attn.py:355-370, the multi-scale loop; :391-398 single scale):
+ *   neighbor_feature = warp_affine_simple(node_features, t_matrix[0, :N], (H, W));  x_fuse = fuse_module(neighbor_feature)
+ * in ONE kernel: the warped maps are never written.  agents: HOST array of n_agents DEVICE pointers to (h,w,c) NHWC maps
+ * (agent 0 = ego; it is sampled through its own matrix like the others); theta_host: HOST (n_agents,2,3) fp32, the
+ * normalised affine of F.affine_grid(align_corners=False) (where2comm_attn.py:293-307 prepares it);
+ * mode 0 = AttenFusion (:55-67, ScaledDotProductAttention :46-52, row 0 only), 1 = MaxFusion (:70-75).
+ *   out (h,w,c).  c in {64, 128, 256}, 1 <= n_agents <= 32.
+ * ------------------------------------------------------------------------------------ */
+int av2x_warp_fuse(const float* const* agents, const float* theta_host, int32_t n_agents, int32_t h, int32_t w,
+                   int32_t c, int32_t mode, float* out, av2x_stream_t stream);
+
+/* MaxFusion.forward (where2comm_attn.py:70-75) on already aligned maps: out[i] = max_j agents[j][i].
+ * agents: HOST array of DEVICE pointers; elems_per_agent % 4 == 0, 16-byte aligned. */
+int av2x_agent_max(const float* const* agents, int32_t n_agents, uint64_t elems_per_agent, float* out,
+                   av2x_stream_t stream);
+
+/* `(batch_x[b] * communication_mask).count_nonzero()` of Communication.forward (where2comm.py:93-95) without the
+ * product: result (1,) u64 += #{(p, ch): x[p, ch] != 0 and gate[p] > thr}; x (n_pixels, c) NHWC, gate (n_pixels,) = the
+ * smoothed confidence av2x_comm_mask wrote, thr = `thre`. */
+int av2x_count_nonzero_where(const float* x, const float* gate, float thr, uint64_t n_pixels, int32_t c,
+                             unsigned long long* result, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * AP evaluation: true/false positives of one frame.  Replaces the shapely loop of caluclate_tp_fp
  * (utils/eval_utils_opv2v.py:41-97; IoU = common_utils.compute_iou :150-171 on convert_format :174-191 polygons).
  *   det_corners (n_det,8,3) / gt_corners (n_gt,8,3) f32: the first four corners' (x,y) are the BEV quad;

@@ -1,0 +1,203 @@
+"""OPV2V-style Where2comm (reference: models/where2comm_modules/where2comm_attn.py + where2comm.py's Communication).
+
+tests/golden/w2c_attn.npz holds the outputs of the REAL reference modules (tools/gen_golden.py w2c_attn: reference
+Where2comm + reference BaseBEVBackbone on seeded inputs and weights, with per-agent SE(2) motions in the ego's row of the
+pairwise matrix).  CPU: the oracle restatement against those outputs.  GPU: the drop-in sub-module
+(opencood_iface/where2comm_attn.py -> av2x_warp_fuse / av2x_comm_mask / av2x_count_nonzero_where through the C-ABI)
+against the same outputs.
+
+Tolerance (fp32): 2e-4 * max(1, max|ref|) on the fused maps (conv chains with a different summation order feed them);
+the communication volume is an integer count and must be EQUAL -- the fixture records how far the smoothed confidence
+stays from the threshold (>= 4e-6, three orders above the arithmetic noise of the mask kernel)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from airv2x_perception_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "w2c_attn.npz")
+CFG = synth.w2c_attn_configs()
+H, W = 32, 48
+MS_CASES = (("ms_atten", [3, 2], 41), ("ms_max", [3], 42), ("ms_atten_n5", [5], 43))
+SS_CASES = (("ss_atten", [2, 2], 256, 51), ("ss_max", [3], 64, 52))
+
+
+def _gauss_sd(cfg, seed):
+    """The 'trained' smoothing filter of the fixture (tools/gen_golden.py w2c_attn_golden.gauss_sd): the constructor's
+    gaussian scaled per tap + a small bias.  {} when the configuration does not smooth."""
+    comm = cfg.get("communication", {})
+    if "gaussian_smooth" not in comm:
+        return {}
+    k, s = comm["gaussian_smooth"]["k_size"], comm["gaussian_smooth"]["c_sigma"]
+    c = k // 2
+    gx, gy = np.mgrid[0 - c:k - c, 0 - c:k - c]
+    g = torch.Tensor(1 / (2 * np.pi * s) * np.exp(-(np.square(gx) + np.square(gy)) / (2 * np.square(s)))).view(1, 1, k, k)
+    return {"naive_communication.gaussian_filter.weight": g * torch.from_numpy(synth.seeded_uniform(seed, (1, 1, k, k), 0.8, 1.2)),
+            "naive_communication.gaussian_filter.bias": torch.tensor([1e-4])}
+
+
+def _ms_inputs(tag, rl, seed):
+    n = sum(rl)
+    return (torch.from_numpy(synth.w2c_attn_features(seed, n, 64, H, W)),
+            torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H // 2, W // 2)), synth.w2c_attn_pairwise(rl))
+
+
+def _ss_inputs(rl, ch, seed):
+    n = sum(rl)
+    return (torch.from_numpy(synth.w2c_attn_features(seed, n, ch, H // 2, W // 2, keep=0.6)),
+            torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H // 2, W // 2)), synth.w2c_attn_pairwise(rl))
+
+
+def _close(a, ref, rel=2e-4):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    tol = rel * max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(a - ref).max())
+    assert err <= tol, f"max abs err {err:.3e} > {tol:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------- CPU: oracle vs reference
+@pytest.mark.parametrize("tag,rl,seed", MS_CASES)
+def test_oracle_multi_scale_matches_reference(tag, rl, seed):
+    from oracle import where2comm_attn_oracle as wa
+    g = np.load(GOLD)
+    c = CFG[tag.replace("_n5", "")]
+    bsd = {"backbone." + k: v for k, v in synth.synthetic_state_dict(synth.backbone_param_spec(CFG["backbone"], 64, ""), seed=31).items()}
+    x, rm, pw = _ms_inputs(tag, rl, seed)
+    with torch.no_grad():
+        fused, vol = wa.where2comm_attn(x, rm, rl, pw, _gauss_sd(c, seed + 500), c, bsd, CFG["backbone"])
+    _close(fused, g[f"{tag}_fused"], rel=2e-5)
+    assert float(vol) == float(g[f"{tag}_vol"])
+
+
+@pytest.mark.parametrize("tag,rl,ch,seed", SS_CASES)
+def test_oracle_single_scale_matches_reference(tag, rl, ch, seed):
+    from oracle import where2comm_attn_oracle as wa
+    g = np.load(GOLD)
+    x, rm, pw = _ss_inputs(rl, ch, seed)
+    with torch.no_grad():
+        fused, vol = wa.where2comm_attn(x, rm, rl, pw, _gauss_sd(CFG[tag], seed + 500), CFG[tag])
+    _close(fused, g[f"{tag}_fused"], rel=2e-5)
+    assert float(vol) == float(g[f"{tag}_vol"])
+
+
+def test_oracle_fusion_operators_match_reference():
+    from oracle import where2comm_attn_oracle as wa
+    g = np.load(GOLD)
+    xa = torch.from_numpy(synth.seeded_uniform(61, (3, 128, 6, 10)))
+    _close(wa.atten_fusion(xa), g["atten_fusion"], rel=1e-6)
+    np.testing.assert_array_equal(wa.max_fusion(xa).numpy(), g["max_fusion"])
+
+
+def test_drop_in_contract_on_cpu():
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    m = wm.Where2comm(CFG["ms_atten"])
+    assert list(m.state_dict().keys()) == ["naive_communication.gaussian_filter.weight", "naive_communication.gaussian_filter.bias"]
+    ref_init = _gauss_sd({"communication": {"gaussian_smooth": {"k_size": 5, "c_sigma": 1.0}}}, 0)
+    # constructor default = init_gaussian_filter's values (where2comm.py:28-45), bias zero
+    k = m.state_dict()["naive_communication.gaussian_filter.weight"]
+    g = ref_init["naive_communication.gaussian_filter.weight"] / torch.from_numpy(synth.seeded_uniform(0, (1, 1, 5, 5), 0.8, 1.2))
+    np.testing.assert_allclose(k.numpy(), g.numpy(), rtol=1e-6)
+    assert float(m.state_dict()["naive_communication.gaussian_filter.bias"]) == 0.0
+    assert list(wm.Where2comm(CFG["ms_max"]).state_dict().keys()) == []
+    assert len(m.fuse_modules) == 3 and isinstance(m.fuse_modules[0], wm.AttenFusion)
+    assert isinstance(wm.Where2comm(CFG["ss_max"]).fuse_modules, wm.MaxFusion)
+    with pytest.raises(NotImplementedError, match="Transformer"):
+        wm.Where2comm(dict(CFG["ms_atten"], agg_operator={"mode": "Transformer", "n_head": 8, "with_spe": True, "with_scm": True}))
+    # the host-side matrix preparation (where2comm_attn.py:293-307) against the oracle's, and the caller's tensor is kept
+    from oracle.when2com_oracle import normalized_pairwise
+    pw = synth.w2c_attn_pairwise([3, 2])
+    keep = pw.clone()
+    mine = wm.normalized_pairwise(pw, H, W, 0.4, 2)
+    np.testing.assert_array_equal(mine, normalized_pairwise(pw, H, W, 0.4, 2).numpy())
+    assert torch.equal(pw, keep)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        wm.Where2comm(CFG["ss_max"]).eval()(torch.zeros(1, 64, 4, 4), torch.zeros(1, 2, 4, 4), [1], torch.eye(4).view(1, 1, 1, 4, 4))
+
+
+# ---------------------------------------------------------------------------------------------- GPU: drop-in vs reference
+def _gpu_backbone():
+    from airv2x_perception_amd.opencood_iface import submodules as sm
+    bb = sm.BaseBEVBackbone(CFG["backbone"], 64)
+    bb.load_state_dict(synth.synthetic_state_dict(synth.backbone_param_spec(CFG["backbone"], 64, ""), seed=31), strict=True)
+    return bb.eval().cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,rl,seed", MS_CASES)
+def test_gpu_multi_scale_matches_reference(tag, rl, seed):
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    g = np.load(GOLD)
+    c = CFG[tag.replace("_n5", "")]
+    mod = wm.Where2comm(c)
+    sd = _gauss_sd(c, seed + 500)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.eval().cuda()
+    x, rm, pw = _ms_inputs(tag, rl, seed)
+    keep = x.clone()
+    xg = x.cuda()
+    fused, vol, extra = mod(xg, rm.cuda(), torch.tensor(rl).cuda(), pw.cuda(), _gpu_backbone(), None)
+    assert extra == {} and isinstance(vol, np.floating)
+    assert float(vol) == float(g[f"{tag}_vol"]), (float(vol), float(g[f"{tag}_vol"]), float(g[f"{tag}_margin"]))
+    _close(fused, g[f"{tag}_fused"])
+    assert torch.equal(xg.cpu(), keep), "the caller's features must not be modified"
+    # a second call on the same module (workspaces reused) gives the same bits
+    fused2, vol2, _ = mod(xg, rm.cuda(), rl, pw.cuda(), _gpu_backbone(), None)
+    assert float(vol2) == float(vol) and torch.equal(fused2, fused)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,rl,ch,seed", SS_CASES)
+def test_gpu_single_scale_matches_reference(tag, rl, ch, seed):
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    g = np.load(GOLD)
+    mod = wm.Where2comm(CFG[tag])
+    mod.load_state_dict(_gauss_sd(CFG[tag], seed + 500), strict=True)
+    mod = mod.eval().cuda()
+    x, rm, pw = _ss_inputs(rl, ch, seed)
+    xg = x.cuda()
+    fused, vol, _ = mod(xg, rm.cuda(), torch.tensor(rl), pw.cuda())
+    _close(fused, g[f"{tag}_fused"], rel=2e-5)
+    if "communication" in CFG[tag]:
+        assert float(vol) == float(g[f"{tag}_vol"])
+    else:
+        assert isinstance(vol, torch.Tensor) and int(vol) == 0 and vol.device.type == "cuda"
+    assert torch.equal(xg.cpu(), x)
+
+
+@pytest.mark.gpu
+def test_gpu_fusion_operators_match_reference():
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    g = np.load(GOLD)
+    xa = torch.from_numpy(synth.seeded_uniform(61, (3, 128, 6, 10))).cuda()
+    _close(wm.AttenFusion(128)(xa), g["atten_fusion"], rel=2e-6)
+    np.testing.assert_array_equal(wm.MaxFusion()(xa).cpu().numpy(), g["max_fusion"])
+
+
+@pytest.mark.gpu
+def test_gpu_fused_warp_equals_warp_then_fuse():
+    """The fused kernel against the two-step form on the device's own kernels (av2x_warp_affine_simple, pinned by the
+    When2com fixtures, then av2x_pixel_attn_fuse / av2x_agent_max) at the full OPV2V map size, 5 agents: the taps use the
+    same arithmetic, so MAX is bit-equal and ATTEN agrees to rounding of the online softmax (same order -> also equal)."""
+    from ctypes import c_void_p
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    from airv2x_perception_amd.opencood_iface.warp import warp_affine_simple
+    lib = _lib.load()
+    n, c, h, w = 5, 128, 50, 176
+    x = torch.from_numpy(synth.w2c_attn_features(71, n, c, h, w, keep=0.5)).cuda()
+    th = wm.normalized_pairwise(synth.w2c_attn_pairwise([n]), h, w, 0.4, 2)[0, 0, :n]
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    warped = warp_affine_simple(x, torch.from_numpy(th), (h, w))
+    ptrs = (c_void_p * n)(*[xn[j].data_ptr() for j in range(n)])
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    for mode, two_step in ((0, wm.AttenFusion(c)), (1, wm.MaxFusion())):
+        out = torch.empty((h, w, c), device="cuda")
+        _lib.check(lib.av2x_warp_fuse(ptrs, th.ctypes.data_as(c_void_p), n, h, w, c, mode, c_void_p(out.data_ptr()), st), "av2x_warp_fuse")
+        ref = two_step(warped).permute(1, 2, 0)
+        assert torch.equal(out, ref), (mode, float((out - ref).abs().max()))
+    # argument checks fail loudly
+    assert lib.av2x_warp_fuse(ptrs, th.ctypes.data_as(c_void_p), n, h, w, 96, 0, c_void_p(out.data_ptr()), st) != 0
+    assert lib.av2x_warp_fuse(ptrs, th.ctypes.data_as(c_void_p), 33, h, w, c, 0, c_void_p(out.data_ptr()), st) != 0

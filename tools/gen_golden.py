@@ -659,6 +659,93 @@ def submodules_golden(name="submodules_small"):
     print(path, os.path.getsize(path) // 1024, "KiB", {k: v.shape for k, v in out.items()})
 
 
+def w2c_attn_golden(name="w2c_attn"):
+    """The OPV2V-style Where2comm (where2comm_modules/where2comm_attn.py + where2comm.py's Communication) run on the real
+    reference modules with the reference's BaseBEVBackbone, checked against oracle/where2comm_attn_oracle.py.
+    Inputs and weights are regenerated from the seeds (synth.w2c_attn_*), the fixture holds the reference's outputs."""
+    from airv2x_perception_amd import synth
+    from oracle import where2comm_attn_oracle as wa
+    _stub("turtle", update=None)          # where2comm_attn.py:10 `from turtle import update` (unused; needs tkinter)
+    from opencood.models.common_modules.base_bev_backbone import BaseBEVBackbone
+    from opencood.models.where2comm_modules.where2comm_attn import Where2comm, AttenFusion, MaxFusion
+
+    cfg = synth.w2c_attn_configs()
+    bbc = cfg["backbone"]
+    out = {}
+    H, W = 32, 48
+    with torch.no_grad():
+        bb = BaseBEVBackbone(bbc, 64)
+        spec = synth.backbone_param_spec(bbc, 64, "")
+        assert [k for k, _, _ in spec] == list(bb.state_dict().keys())
+        bsd = synth.synthetic_state_dict(spec, seed=31)
+        bb.load_state_dict(bsd, strict=True)
+        bb.eval()
+        bsd_o = {"backbone." + k: v for k, v in bsd.items()}
+
+        def gauss_sd(mod, seed):
+            """A 'trained' smoothing filter: the constructor's gaussian scaled per tap, and a small bias."""
+            sd = mod.state_dict()
+            if not sd:
+                return {}
+            assert list(sd.keys()) == ["naive_communication.gaussian_filter.weight", "naive_communication.gaussian_filter.bias"]
+            k = sd["naive_communication.gaussian_filter.weight"].shape[-1]
+            sd["naive_communication.gaussian_filter.weight"] = sd["naive_communication.gaussian_filter.weight"] * \
+                torch.from_numpy(synth.seeded_uniform(seed, (1, 1, k, k), 0.8, 1.2))
+            sd["naive_communication.gaussian_filter.bias"] = torch.tensor([1e-4])
+            mod.load_state_dict(sd, strict=True)
+            return {k: v.clone() for k, v in sd.items()}
+
+        cases = (("ms_atten", [3, 2], 41), ("ms_max", [3], 42), ("ms_atten_n5", [5], 43))
+        for tag, rl, seed in cases:
+            c = cfg[tag.replace("_n5", "")]
+            mod = Where2comm(c).eval()
+            fsd = gauss_sd(mod, seed + 500)
+            n = sum(rl)
+            x = torch.from_numpy(synth.w2c_attn_features(seed, n, 64, H, W))
+            rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H // 2, W // 2))
+            pw = synth.w2c_attn_pairwise(rl)
+            pw0 = pw.clone()
+            fused, vol, extra = mod(x, rm, torch.tensor(rl), pw, bb, None)
+            assert extra == {} and torch.equal(pw, pw0), "the caller's matrix must not be modified"
+            tr = {}
+            of, ov = wa.where2comm_attn(x, rm, rl, pw, fsd, c, bsd_o, bbc, trace=tr)
+            err = (of - fused).abs().max().item()
+            assert err < 2e-5 and float(ov) == float(vol), (tag, err, ov, vol)
+            out[f"{tag}_fused"] = fused.numpy()
+            out[f"{tag}_vol"] = np.float64(vol)
+            out[f"{tag}_mask_frac"] = np.float64(tr["mask"].mean())
+            # distance of the smoothed confidence to the threshold: the test skips nothing, but reports it on failure
+            out[f"{tag}_margin"] = np.float64((tr["smooth"] - c["communication"]["thre"]).abs().min())
+            print(f"[{name}] {tag}: oracle vs reference {err:.2e}, volume {float(vol):.1f}, mask ones "
+                  f"{float(tr['mask'].mean()):.3f}, margin {float(out[f'{tag}_margin']):.2e}")
+
+        for tag, rl, ch, seed in (("ss_atten", [2, 2], 256, 51), ("ss_max", [3], 64, 52)):
+            c = cfg[tag]
+            mod = Where2comm(c).eval()
+            fsd = gauss_sd(mod, seed + 500)
+            n = sum(rl)
+            h, w = H // 2, W // 2
+            x = torch.from_numpy(synth.w2c_attn_features(seed, n, ch, h, w, keep=0.6))
+            rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, h, w))
+            pw = synth.w2c_attn_pairwise(rl)
+            fused, vol, _ = mod(x, rm, torch.tensor(rl), pw)
+            of, ov = wa.where2comm_attn(x, rm, rl, pw, fsd, c)
+            err = (of - fused).abs().max().item()
+            assert err < 2e-5 and float(ov) == float(vol), (tag, err, ov, vol)
+            out[f"{tag}_fused"] = fused.numpy()
+            out[f"{tag}_vol"] = np.float64(float(vol))
+            print(f"[{name}] {tag}: oracle vs reference {err:.2e}, volume {float(vol):.1f}")
+
+        xa = torch.from_numpy(synth.seeded_uniform(61, (3, 128, 6, 10)))
+        out["atten_fusion"] = AttenFusion(128)(xa).numpy()
+        out["max_fusion"] = MaxFusion()(xa).numpy()
+        assert (wa.atten_fusion(xa) - torch.from_numpy(out["atten_fusion"])).abs().max() < 1e-6
+        assert torch.equal(wa.max_fusion(xa), torch.from_numpy(out["max_fusion"]))
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB", {k: v.shape for k, v in out.items()})
+
+
 def run_when2com_case(name, lidar_range, types, n_points, seed, mode="softmax", head_stride=1, big_stride=4):
     """Airv2xWhen2com on the real reference vs oracle/when2com_oracle.py."""
     from airv2x_perception_amd import synth
@@ -1079,6 +1166,7 @@ GROUPS = {
                          run_when2com_case("when2com_small_n2", SMALL, ["vehicle", "vehicle"], 1500, 6)),
     "when2com_full": lambda: run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16),
     "submodules": lambda: submodules_golden(),
+    "w2c_attn": lambda: w2c_attn_golden(),
     "v2vnet": lambda: (run_v2vnet_case("v2vnet_small_n3", SMALL, ["vehicle", "rsu", "drone"], 1500, 8),
                        run_v2vnet_case("v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 1500, 9, agg="max")),
     "v2vnet_full": lambda: run_v2vnet_case("v2vnet_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 10, head_stride=4, big_stride=16),
