@@ -402,6 +402,7 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
 
 #include "conv_igemm_bf16.inc"
 #include "conv_igemm_glds.inc"
+#include "conv_wino.inc"
 
 }  // namespace
 
@@ -448,6 +449,8 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     if (residual && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: residual only with mode AV2X_CONV");
     if (d->relu < 0 || d->relu > 4)
         return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU, 3 sigmoid, 4 tanh [x residual])", d->relu);
+    if (d->tile & 0x40000000)   // Winograd F(2x2,3x3): `w` is the transformed packing of av2x_wino_pack_weights
+        return wino_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if (d->cin % BK != 0) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);
     if (d->coutp % 32 != 0 || d->coutp <= 0) return av2x::fail("av2x_conv2d: coutp=%d must be a positive multiple of 32", d->coutp);
     if (d->mode < 0 || d->mode > 2) return av2x::fail("av2x_conv2d: bad mode %d", d->mode);

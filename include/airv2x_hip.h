@@ -145,6 +145,16 @@ int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const float* w, con
                    uint64_t workspace_bytes, av2x_stream_t stream);
 uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs);
 
+/* Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 AV2X_CONV layer (tile flag 0x40000000 | TB << 16 | CB on any of
+ * the three entry points above; TB x CB = tiles x couts per workgroup: 32x128, 64x64, 32x64): 2.25x fewer
+ * matrix-core multiplies, still fp32 operands and fp32 accumulation on v_mfma_f32_32x32x2_f32; results agree with the
+ * direct kernel to fp32 rounding (not bit for bit).  `w` must then point to the transformed weights
+ *   u [pos = 4*xi + nu][cin/4][coutp][4] = (G g G^T)[xi][nu] in the k-quad packing of `w`,
+ * made once per layer by av2x_wino_pack_weights from the ordinary packing (av2x_wino_weight_bytes(cin, coutp) bytes).
+ * cin % 8 == 0, cout % CB == 0, relu in {0, 1}, no residual. */
+uint64_t av2x_wino_weight_bytes(int32_t cin, int32_t coutp);
+int av2x_wino_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, float* u, av2x_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Where2Comm communication mask.  Replaces Communication.forward, eval branch
  * (models/where2comm_modules/where2comm_fuse.py:83-149).

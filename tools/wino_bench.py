@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Winograd F(2x2,3x3) conv (tile flag 0x40000000) against the direct implicit-GEMM kernel on the frame's 3x3 / stride-1
+layers: time, effective TFLOP/s (direct-conv FLOPs / time) and the error of both against an fp64 convolution.
+Usage: python tools/wino_bench.py [--iters 20] [--layers name,...] [--check]"""
+import argparse, os, sys
+from ctypes import byref, c_void_p
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from airv2x_perception_amd import _lib  # noqa: E402
+from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight  # noqa: E402
+
+# name: (n, h, w, cin, cout)
+LAYERS = {
+    "shrink3_n4": (4, 100, 352, 256, 256),
+    "shrink3_n1": (1, 100, 352, 256, 256),
+    "b2_n4": (4, 25, 88, 256, 256),
+    "b2_n3": (3, 25, 88, 256, 256),
+    "b1_n4": (4, 50, 176, 128, 128),
+    "b1_n3": (3, 50, 176, 128, 128),
+    "b0_n4": (4, 100, 352, 64, 64),
+    "odd_n2": (2, 25, 87, 64, 64),
+}
+WINO = {"w32x128": (32, 128), "w64x64": (64, 64), "w32x64": (32, 64)}
+DIRECT = {"g64x64": (64, 64 | 0x0200), "g128x64w8": (128, 64 | 0x8200)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--layers", default="")
+    ap.add_argument("--check", action="store_true", help="compare against an fp64 conv (slow for the big layers)")
+    a = ap.parse_args()
+    lib = _lib.load()
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: c_void_p(t.data_ptr())
+    for name, (n, h, w, cin, cout) in LAYERS.items():
+        if a.layers and name not in a.layers.split(","):
+            continue
+        torch.manual_seed(0)
+        x = torch.randn(n, h, w, cin, device="cuda")
+        wt = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+        wp, coutp = pack_conv_weight(wt)
+        wp = wp.cuda()
+        u = torch.empty(lib.av2x_wino_weight_bytes(cin, coutp) // 4, device="cuda")
+        _lib.check(lib.av2x_wino_pack_weights(P(wp), cin, coutp, P(u), st), "pack")
+        sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.1
+        flops = 2.0 * n * h * w * cout * 9 * cin
+        print(f"{name:11s} M={n*h*w:7d} cin={cin} cout={cout} {flops/1e9:6.1f} GF  direct ideal {flops/157.3e6:6.1f} us", flush=True)
+        ref = None
+        if a.check:
+            ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.cuda().double(), padding=1)
+            ref = torch.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+
+        def run(tile, wgt):
+            out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+            d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp,
+                              out_ctot=cout, out_coff=0, ks=3, stride=1, pad=1, relu=1, mode=0, up=1, tile=tile, sk_wgs=0)
+            call = lambda: _lib.check(lib.av2x_conv2d_res(byref(d), P(x), P(wgt), P(sc), P(sh), None, P(out), st), "conv")
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / a.iters, out
+
+        base = None
+        for tn, (bm, bn) in DIRECT.items():
+            if coutp % (bn & 0x1ff) or cin % 32:
+                continue
+            us, y = run((bm << 16) | bn, wp)
+            base = y if base is None else base
+            err = f" err64={float((y.double() - ref).abs().max()):.2e}" if ref is not None else ""
+            print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF{err}", flush=True)
+        for tn, (tb, cb) in WINO.items():
+            if cout % cb:
+                continue
+            us, y = run(0x40000000 | (tb << 16) | cb, u)
+            err = f" err64={float((y.double() - ref).abs().max()):.2e}" if ref is not None else ""
+            dv = f" vs direct {float((y - base).abs().max()):.2e} (max|y| {float(base.abs().max()):.2f})" if base is not None else ""
+            print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF(eff){err}{dv} nan={int(torch.isnan(y).sum())}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
