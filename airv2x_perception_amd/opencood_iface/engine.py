@@ -35,12 +35,13 @@ TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_mod
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
         self._w16 = None
         self._w3 = None
+        self._wu = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
 
@@ -57,6 +58,17 @@ def _w3(L):
     if L._w3 is None:
         L._w3 = to_bf16x3_koct(L.w)
     return L._w3
+
+
+def _wu(L, lib, stream):
+    """Winograd-transformed weights G g G^T in the k-quad packing per position (av2x_wino_pack_weights), built on the device
+    from the fp32 packing on first use."""
+    if L._wu is None:
+        u = torch.empty(lib.av2x_wino_weight_bytes(L.cin, L.coutp) // 4, dtype=torch.float32, device=L.w.device)
+        _lib.check(lib.av2x_wino_pack_weights(c_void_p(L.w.data_ptr()), L.cin, L.coutp, c_void_p(u.data_ptr()), stream),
+                   "av2x_wino_pack_weights")
+        L._wu = u
+    return L._wu
 
 
 def _ptr(t):
@@ -122,6 +134,11 @@ class Where2ComEngine:
         #                    what the agent-sharded frame is compared against bit for bit);
         #   "tune"           legacy: stream-K candidates compete by wall-clock (not reproducible across processes).
         self.stream_k = {"0": False, "off": False, "1": "rule", "rule": "rule", "tune": "tune"}[os.environ.get("AV2X_STREAM_K", "rule")]
+        # Winograd F(2x2,3x3) for the 3x3 / stride-1 layers (conv_wino.inc): 2.25x fewer matrix-core multiplies, still fp32
+        # operands and accumulation, error against fp64 at or below the direct kernel's.  WHICH layers take it is a function
+        # of the layer's channels alone (wino_rule), never of a timing, so results stay reproducible and do not depend on
+        # how many agents share a launch.  AV2X_WINOGRAD=0: direct implicit GEMM everywhere.
+        self.winograd = os.environ.get("AV2X_WINOGRAD", "1") not in ("0", "off")
         # AMP mode (what torch.autocast does to Conv2d / Linear): bf16 matrix-core operands, fp32 accumulation and
         # fp32 activations in HBM (conv_igemm_bf16); LayerNorm / softmax / attention stay fp32.  Off = exact fp32.
         self.amp = False
@@ -158,6 +175,7 @@ class Where2ComEngine:
                 setattr(other, k, getattr(self, k))
         other.tile_cache = self.tile_cache
         other.autotune, other.conv_tile, other.stream_k, other.amp = self.autotune, self.conv_tile, self.stream_k, self.amp
+        other.winograd = self.winograd
         other.split3 = self.split3
         return other
 
@@ -318,7 +336,10 @@ class Where2ComEngine:
         d.sk_wgs = 0
         wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         vflag = 0x0800 if self.amp else (0x0400 if self.split3 else 0)
-        if self.conv_tile:
+        if self.winograd and not self.conv_tile and vflag == 0 and residual is None and self.wino_rule(L):
+            wgt = _wu(L, self.lib, self.stream())
+            d.tile = self.WINO_TILE
+        elif self.conv_tile:
             d.tile = self.conv_tile
             d.sk_wgs = self.conv_sk_wgs if (d.tile & 0x2000) else 0
         elif self.autotune:
@@ -332,7 +353,7 @@ class Where2ComEngine:
         else:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
             d.tile = (bm << 16) | bn | vflag
-        bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff  # bn keeps the variant flags (profile key)
+        bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff  # bn keeps the variant flags (profile key); bm & 0x4000 = Winograd
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -347,7 +368,10 @@ class Where2ComEngine:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x01ff))
+            if bm & 0x4000:   # Winograd: (32 x TB-tile blocks of 2x2 outputs) x (cout / CB)
+                wgs = -(-(n * ((d.ho + 1) // 2) * ((d.wo + 1) // 2)) // (bm & 0x3fff)) * (L.cout // (bn & 0x01ff))
+            else:
+                wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x01ff))
             if bn & 0x2000:  # sk_schedule() of conv_igemm.hip: whole tiles first, the remainder tiles split evenly
                 steps = L.ks * L.ks * (L.cin // 32)
                 g = min(d.sk_wgs, wgs * steps)
@@ -360,6 +384,16 @@ class Where2ComEngine:
             self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1, wgs,
                                  (n * d.ho * d.wo, L.cin, ncols, L.ks, L.stride)))
         return ho, wo
+
+    WINO_TILE = 0x40000000 | (32 << 16) | 128   # 32 tiles x 128 couts per workgroup (4 waves x 16 accumulator tiles)
+
+    @staticmethod
+    def wino_rule(L):
+        """Layers that run as Winograd F(2x2,3x3): 3x3 / stride 1 / pad 1, ReLU or no activation, >= 128 input channels
+        (16+ chunks: below that the prologue / epilogue outweigh the saved multiplies, tools/wino_bench.py) and a multiple
+        of 128 output channels."""
+        return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1)
+                and L.cin >= 128 and L.cin % 8 == 0 and L.cout % 128 == 0 and L.cout == L.coutp)
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)
     TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),

@@ -571,9 +571,10 @@ def main(argv=None, hooks=None, device=None):
         grids = {}
         shapes = {}
         for tile, flops, e0, e1, wgs, shp in prof:
-            d = per.setdefault(tile, [0, 0.0, 0.0])
+            d = per.setdefault(tile, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
+            d[3] += flops * (16.0 / 36.0 if tile[0] & 0x4000 else 1.0)   # multiplies the matrix cores EXECUTE (Winograd F(2x2,3x3): 16 per 36)
             dur = max(e0.elapsed_time(e1) * 1e-3 - ev_over, 1e-7)   # one pair per launch (a stream-K launch = GEMM + fix-up kernel)
             d[2] += dur
             g = grids.setdefault(tile, {})
@@ -583,35 +584,45 @@ def main(argv=None, hooks=None, device=None):
             sh[1] += flops
             sh[2] += dur
         dom = max(per, key=lambda k: per[k][2])
-        cnt, fl, sec = per[dom]
+        cnt, fl, sec, exe = per[dom]
         # algorithmic HBM bytes of the dominant kernel's launches: input pixels x Cin + the filter + output pixels x Cout, fp32,
         # each once (shape = (M output pixels, Cin, Cout, kernel size, stride); a strided layer reads stride^2 x M input pixels)
         alg_bytes = sum(v[0] * 4 * (k[0][0] * k[0][4] ** 2 * k[0][1] + k[0][3] ** 2 * k[0][1] * k[0][2] + k[0][0] * k[0][2])
                         for k, v in shapes.items() if k[1] == dom) / cnt
-        ach = fl / sec / 1e12
+        ach = exe / sec / 1e12          # executed matrix-core FLOPs: what the MFMA peak bounds
+        eff = fl / sec / 1e12           # direct-convolution FLOPs (SURVEY 8d's per-frame figure) over the same time
+        wino = bool(dom[0] & 0x4000)
         tot_fl = sum(v[1] for v in per.values())
+        tot_exe = sum(v[3] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{'g' if k[1] & 0x0200 else ''}{k[0]}x{k[1] & 0x01ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
+        tkey = lambda k: f"{'w' if k[0] & 0x4000 else ''}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x3fff}x{k[1] & 0x01ff}{'w8' if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS), 4), "traffic": traffic, "traffic_note": traffic_note,
             "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>" + (" 8-wave" if dom[1] & 0x8000 else "")
+            "kernel": (f"conv_wino_f32<{(dom[0] & 0x3fff) // 32},{(dom[1] & 0x01ff) // 32}> (Winograd F(2x2,3x3), {dom[0] & 0x3fff} tiles x {dom[1] & 0x01ff} couts per workgroup)" if wino else
+                       f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if dom[1] & 0x8000 else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": ((f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": (f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>" if wino else (f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
+            **({"effective_tflops": round(eff, 2),
+                "flop_accounting": "achieved / frac count the multiplies the matrix cores execute (Winograd F(2x2,3x3): 16 per 2x2 output "
+                                   "tile and channel pair instead of the direct form's 36); effective_tflops = the layer's direct-convolution "
+                                   "FLOPs (the 559.8 GFLOP/frame accounting) over the same time"} if wino else {}),
             "event_pair_overhead_us": round(ev_over * 1e6, 2),
             "sustained_clock": "fp32-MFMA loops run at 2.0 GHz on random operands (2.32 on zeros; GRBM_GUI_ACTIVE / duration, "
                                "profiles/r02_dvfs_clock.txt): peak at that clock = 131.5 TFLOP/s; frac is against the 2.4 GHz figure",
-            "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
-            "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
-                                 "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1)},
-            "per_tile": {tkey(k): {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
-                                            "ms_per_frame": round(v[2] / a.steps * 1e3, 3)} for k, v in per.items()},
+            "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(exe / cnt / 1e9, 3),
+            "all_conv_kernels": {"tflops": round(tot_exe / tot_s / 1e12, 2), "effective_tflops": round(tot_fl / tot_s / 1e12, 2),
+                                 "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
+                                 "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1), "executed_gflop_per_frame": round(tot_exe / a.steps / 1e9, 1)},
+            "per_tile": {tkey(k): {"launches_per_frame": v[0] / a.steps, "tflops": round(v[3] / v[2] / 1e12, 2),
+                                   **({"effective_tflops": round(v[1] / v[2] / 1e12, 2)} if k[0] & 0x4000 else {}),
+                                   "ms_per_frame": round(v[2] / a.steps * 1e3, 3)} for k, v in per.items()},
             **({"per_shape": [{"M_cin_cout_ks_stride": list(k[0]), "tile": tkey(k[1]), "wgs": k[2], "launches_per_frame": v[0] / a.steps,
                                "us": round(v[2] / v[0] * 1e6, 1), "tflops": round(v[1] / v[2] / 1e12, 1)}
                               for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])]} if a.per_shape else {}),

@@ -75,4 +75,6 @@ def test_ego_alone(which):
     for k in ("psm", "rm", "obj"):
         assert_close(out[k].cpu(), ref[k], 3e-4, 3e-4, f"{which} {k}")
     if "comm_rate" in ref:
-        assert float(out["comm_rate"]) == float(ref["comm_rate"])
+        # a COUNT of non-zero activations after ReLU: a pre-activation within fp32 rounding of zero may land on either side
+        # (the convolutions before it sum in a different order than the CPU's), so a handful of cells out of ~3e5 may differ
+        assert abs(float(out["comm_rate"]) - float(ref["comm_rate"])) <= 1e-5 * max(1.0, float(ref["comm_rate"]))

@@ -27,6 +27,9 @@ def conv_key(name):
         bm, bn, wm, wn, stages, mode = (int(g.group(i)) for i in range(1, 7))
         waves = (bm // wm) * (bn // wn)
         return f"g{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if stages == 3 else ''}{'sk' if mode == 1 else ''}"
+    wn = re.search(r"conv_wino_f32<(\d+), (\d+)>", name)
+    if wn:  # Winograd F(2x2,3x3): bench.py's key "w<tiles>x<couts>" per workgroup
+        return f"w{32 * int(wn.group(1))}x{32 * int(wn.group(2))}"
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false|\d))?>", name)
     if not m:
         return None
