@@ -407,3 +407,97 @@ def test_apply_mask(lib):
     xd, md = x.cuda(), m.cuda()
     _lib.check(lib.av2x_apply_mask(_p(xd), _p(md), 3, 120, 64, _stream()), "apply_mask")
     assert torch.equal(xd.cpu(), x * m.unsqueeze(-1))
+
+
+# ---------------------------------------------------------------------------------------------- Winograd F(2x2,3x3)
+WINO_TILES = {"32x128": 0x40000000 | (32 << 16) | 128, "64x64": 0x40000000 | (64 << 16) | 64, "32x64": 0x40000000 | (32 << 16) | 64}
+WINO_CASES = [
+    # n, h, w, cin, cout, relu          (odd H / W: half-empty tiles; 1-pixel-high maps; blocks that wrap rows and images)
+    (2, 25, 88, 256, 256, 1),
+    (3, 9, 13, 128, 128, 0),
+    (1, 1, 7, 64, 64, 1),
+    (2, 6, 1, 8, 64, 1),
+    (5, 3, 5, 72, 192, 0),
+]
+
+
+def _wino_weights(lib, wp, cin, coutp):
+    u = torch.empty(lib.av2x_wino_weight_bytes(cin, coutp) // 4, device="cuda")
+    from airv2x_perception_amd import _lib
+    _lib.check(lib.av2x_wino_pack_weights(_p(wp), cin, coutp, _p(u), _stream()), "av2x_wino_pack_weights")
+    return u
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv_matches_fp64_and_its_tilings_agree_bit_for_bit(lib, case):
+    """The Winograd form against an fp64 convolution of the same fp32 operands: tolerance 2e-5 * max|ref| (the direct
+    kernel's own error against fp64 is ~1e-5 at these sizes), and the three workgroup shapes give the SAME bits (each
+    output is produced by one lane from the same chunk order)."""
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    n, h, w, cin, cout, relu = case
+    g = torch.Generator().manual_seed(4321 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    wp, coutp = pack_conv_weight(wt)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    u = _wino_weights(lib, wp.cuda(), cin, coutp)
+    outs = {}
+    for name, tile in WINO_TILES.items():
+        if cout % (tile & 0x1ff):
+            continue
+        out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+        _conv_call(lib, xn, u, scale.cuda(), shift.cuda(), out, cin=cin, cout=cout, coutp=coutp, ks=3, stride=1, pad=1,
+                   relu=relu, tile=tile)
+        outs[name] = out.cpu()
+        err = float((outs[name].double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (name, err)
+    first = next(iter(outs.values()))
+    assert all(torch.equal(first, o) for o in outs.values()), list(outs)
+
+
+def test_winograd_conv_channel_slices_and_argument_checks(lib):
+    """Input read from a channel slice of a wider tensor, output written into a slice of a concatenated map (what the
+    engine's fused buffers do); everything outside the slice stays untouched.  Unsupported uses fail loudly."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    n, h, w, cin, cout = 2, 11, 14, 64, 128
+    g = torch.Generator().manual_seed(99)
+    xw = torch.randn(n, h, w, 96, generator=g)                  # the layer consumes channels 32..95
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(xw[..., 32:].permute(0, 3, 1, 2).double(), wt.double(), shift.double(), padding=1)).permute(0, 2, 3, 1)
+    wp, coutp = pack_conv_weight(wt)
+    u = _wino_weights(lib, wp.cuda(), cin, coutp)
+    out = torch.full((n, h, w, 160), -7.0, device="cuda")      # written at channels 16..143
+    _conv_call(lib, xw.cuda(), u, None, shift.cuda(), out, cin=cin, cout=cout, coutp=coutp, ks=3, stride=1, pad=1, relu=1,
+               in_coff=32, out_ctot=160, out_coff=16, tile=WINO_TILES["32x128"])
+    o = out.cpu()
+    assert float((o[..., 16:144].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert bool((o[..., :16] == -7.0).all()) and bool((o[..., 144:] == -7.0).all())
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=96, in_coff=32, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=160,
+                      out_coff=16, ks=3, stride=1, pad=1, relu=1, mode=0, up=1, tile=WINO_TILES["32x128"], sk_wgs=0)
+    args = (_p(xw.cuda()), _p(u), None, _p(shift.cuda()), None, _p(out), _stream())
+    for field, bad in (("stride", 2), ("ks", 1), ("relu", 2), ("mode", 2), ("tile", 0x40000000 | (48 << 16) | 128)):
+        keep = getattr(d, field)
+        setattr(d, field, bad)
+        if field == "stride":
+            d.ho, d.wo = (h + 1) // 2, (w + 1) // 2
+        assert lib.av2x_conv2d_res(byref(d), *args) != 0, field
+        assert b"Winograd" in lib.av2x_last_error() or b"winograd" in lib.av2x_last_error().lower(), field
+        setattr(d, field, keep)
+        d.ho, d.wo = h, w
+    assert lib.av2x_conv2d_res(byref(d), _p(xw.cuda()), _p(u), None, _p(shift.cuda()), _p(out), _p(out), _stream()) != 0   # residual
+
+
+def test_winograd_rule_is_a_function_of_the_layer_only():
+    """Which layers run as Winograd must not depend on timings or on the number of agents in the launch."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
+    mk = lambda cin, cout, ks=3, stride=1, pad=1, relu=1, mode=_lib.AV2X_CONV: ConvLayer(None, None, None, cin, cout, cout, ks, stride, pad, relu, mode)
+    rule = Where2ComEngine.wino_rule
+    assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(384, 256)) and rule(mk(128, 128, relu=0))
+    assert not rule(mk(64, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
+    assert not rule(mk(256, 64)) and not rule(mk(256, 256, relu=2)) and not rule(mk(256, 256, mode=_lib.AV2X_DECONV))
