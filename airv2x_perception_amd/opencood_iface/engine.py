@@ -67,6 +67,9 @@ def _wu(L, lib, stream):
         u = torch.empty(lib.av2x_wino_weight_bytes(L.cin, L.coutp) // 4, dtype=torch.float32, device=L.w.device)
         _lib.check(lib.av2x_wino_pack_weights(c_void_p(L.w.data_ptr()), L.cin, L.coutp, c_void_p(u.data_ptr()), stream),
                    "av2x_wino_pack_weights")
+        # once per layer: engines that share these weights launch on OTHER streams (FramePipeline, ShardedPipeline), so the
+        # transformed copy must be complete before anyone else can see it
+        torch.cuda.current_stream().synchronize()
         L._wu = u
     return L._wu
 
