@@ -91,6 +91,9 @@ SIGNATURES = {
     "av2x_warp_fuse": (c_int32, [POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_agent_max": (c_int32, [POINTER(c_void_p), c_int32, c_uint64, c_void_p, c_void_p]),
     "av2x_count_nonzero_where": (c_int32, [c_void_p, c_void_p, c_float, c_uint64, c_int32, c_void_p, c_void_p]),
+    "av2x_pp_loss_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
+    "av2x_pp_loss": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                               c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_comm_rate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_count_nonzero": (c_int32, [c_void_p, c_uint64, c_void_p, c_void_p]),
     "av2x_prepare_points_workspace_bytes": (c_uint64, [c_int32]),

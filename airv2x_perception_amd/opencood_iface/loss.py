@@ -1,0 +1,89 @@
+"""Mirror of the reference's ``opencood/loss/point_pillar_loss_multiclass.py`` (PointPillarLossMultiClass :79-179): same
+constructor argument (``{"cls_weight", "reg", "num_class"}``), ``forward(output_dict, target_dict, prefix="")`` returning the
+total loss, ``loss_dict`` with the python floats the reference logs, ``logging(epoch, batch_id, batch_len, writer)``.
+
+The forward AND the gradient with respect to ``psm`` / ``rm`` / ``obj`` are one fused pass over the anchors in
+libairv2x_hip.so (``av2x_pp_loss``); the returned tensor carries a ``torch.autograd.Function`` whose backward hands those
+gradients (scaled by the incoming one) to whatever produced the head maps.  GPU only."""
+from __future__ import annotations
+
+from ctypes import c_void_p
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+class _PPLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, psm, rm, obj, targets, pos, cls, num_class, cls_weight, reg_coe):
+        lib = _lib.load()
+        B, AC, H, W = psm.shape
+        A = AC // num_class
+        if rm.shape != (B, A * 7, H, W) or obj.shape != (B, A, H, W):
+            raise ValueError(f"head shapes psm {tuple(psm.shape)} rm {tuple(rm.shape)} obj {tuple(obj.shape)} are inconsistent")
+        if targets.numel() != B * H * W * A * 7 or pos.numel() != B * H * W * A or cls.numel() != B * H * W * A:
+            raise ValueError("label tensors do not match the head maps")
+        dev = psm.device
+        need = any(ctx.needs_input_grad[:3])
+        ws = torch.empty(lib.av2x_pp_loss_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
+        out4 = torch.empty(4, dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(t, memory_format=torch.contiguous_format) if need else None for t in (psm, rm, obj)]
+        st = c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.av2x_pp_loss(_p(psm), _p(rm), _p(obj), _p(targets), _p(pos), _p(cls), B, H, W, A, num_class,
+                                    float(cls_weight), float(reg_coe), _p(ws), _p(out4), _p(grads[0]), _p(grads[1]), _p(grads[2]),
+                                    st), "av2x_pp_loss")
+        ctx.grads = grads
+        ctx.mark_non_differentiable(out4)
+        return out4[0].clone(), out4
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        g = ctx.grads
+        out = [None] * 9
+        for i in range(3):
+            if ctx.needs_input_grad[i]:
+                out[i] = g[i] * g_total
+        return tuple(out)
+
+
+class PointPillarLossMultiClass(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.alpha, self.gamma = 0.25, 2.0          # fixed in the reference (:83-84); compiled into the kernel
+        self.cls_weight = args["cls_weight"]
+        self.reg_coe = args["reg"]
+        self.flow_weight = args["flow_weight"] if "flow_weight" in args else 1.0
+        self.loss_dict = {}
+        self.use_dir = False
+        self.cls_num = args["num_class"]
+
+    def forward(self, output_dict, target_dict, prefix=""):
+        psm, rm, obj = (output_dict[k + prefix] for k in ("psm", "rm", "obj"))
+        if psm.device.type != "cuda":
+            raise RuntimeError("PointPillarLossMultiClass (MI355X build) has no CPU path")
+        f32 = lambda t: t.detach().to(psm.device, torch.float32).contiguous()
+        cont = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+        total, parts = _PPLoss.apply(cont(psm), cont(rm), cont(obj), f32(target_dict["targets"]), f32(target_dict["pos_equal_one"]),
+                                     target_dict["class_ids"].detach().to(psm.device, torch.int32).contiguous(),
+                                     int(self.cls_num), self.cls_weight, self.reg_coe)
+        vals = parts.tolist()                     # the reference's three .item() calls (:172-177) in one read-back
+        self.loss_dict.update({"total_loss" + prefix: vals[0], "reg_loss" + prefix: vals[1], "conf_loss" + prefix: vals[2]})
+        return total
+
+    def logging(self, epoch, batch_id, batch_len, writer=None):
+        """:295-330: the progress line, and one scalar per entry of ``loss_dict`` on the tensorboard writer."""
+        total = [v for k, v in self.loss_dict.items() if "total_loss" in k]
+        total = sum(total) if len(total) > 1 else total[0]
+        msg = "[epoch {}][{}/{}], || Loss: {:.2f} ||".format(epoch, batch_id + 1, batch_len, total)
+        for k, v in self.loss_dict.items():
+            msg += "{}: {:.2f} | ".format(k.replace("_loss", "").replace("_single", ""), v)
+        if writer is not None:
+            for k, v in self.loss_dict.items():
+                writer.add_scalar(k, v, epoch * batch_len + batch_id)
+        return msg

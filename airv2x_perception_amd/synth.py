@@ -894,6 +894,26 @@ def w2c_attn_psm(seed, n, h, w, anchors=2):
     return psm
 
 
+def loss_case(seed, B=2, H=12, W=20, A=2, C=7, pos_frac=0.02, empty_sample=None):
+    """Seeded head maps + label dictionary for the loss tests: ~pos_frac of the anchors positive with a random class and
+    regression target, one regression target NaN (the reference ignores those), optionally a sample without positives."""
+    rng = np.random.default_rng(int(seed))
+    psm = rng.normal(-2.0, 1.5, (B, A * C, H, W)).astype(np.float32)
+    rm = rng.normal(0.0, 0.6, (B, A * 7, H, W)).astype(np.float32)
+    obj = rng.normal(-1.0, 1.5, (B, A, H, W)).astype(np.float32)
+    pos = (rng.uniform(size=(B, H, W, A)) < pos_frac).astype(np.float32)
+    if empty_sample is not None:
+        pos[empty_sample] = 0.0
+    cls = np.where(pos > 0, rng.integers(1, C, size=pos.shape), 0).astype(np.int64)
+    targets = (rng.normal(0.0, 0.5, (B, H, W, A * 7)) * np.repeat(pos, 7, axis=-1)).astype(np.float32)
+    idx = np.argwhere(pos > 0)
+    if len(idx):
+        b, h, w, a = idx[0]
+        targets[b, h, w, a * 7 + 2] = np.nan
+    return {"psm": psm, "rm": rm, "obj": obj, "pos_equal_one": pos, "neg_equal_one": (1.0 - pos).astype(np.float32),
+            "class_ids": cls, "targets": targets}
+
+
 def submodule_psm(n=3, h=16, w=16):
     """Per-agent classification logits whose smoothed confidence straddles the 0.01 threshold: low everywhere,
     raised on a different part of the map for every agent."""

@@ -368,6 +368,25 @@ int av2x_count_nonzero_where(const float* x, const float* gate, float thr, uint6
                              unsigned long long* result, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Detection loss and its gradient with respect to the head maps.  Replaces PointPillarLossMultiClass.forward
+ * (loss/point_pillar_loss_multiclass.py:96-179: focal classification :183-214, sin-difference + WeightedSmoothL1Loss(beta 1/9)
+ * :279-293, :13-76, objectness BCE :163-168) and the autograd pass through it.
+ *   psm (b, a*c, h, w), rm (b, a*7, h, w), obj (b, a, h, w): the head outputs, NCHW fp32;
+ *   targets (b, h, w, a*7) f32, pos_equal_one (b, h, w, a) f32, class_ids (b, h, w, a) i32: the label dictionary
+ *   (voxel_postprocessor.py:217-354 / av2x_generate_label);
+ *   out4 (4,) f32 = total_loss (= reg + conf + obj), reg_loss (x reg_coe), conf_loss (x cls_weight), obj_loss;
+ *   dpsm / drm / dobj: NULL, or buffers shaped like psm / rm / obj that receive d total_loss / d input;
+ *   workspace: av2x_pp_loss_workspace_bytes(b, h, w) bytes.  Deterministic (fixed-order fp64 partial sums).
+ * As written in the reference: every non-positive anchor is a negative with weight 1 (neg_equal_one is not read), the
+ * classification sum is divided by the batch size twice, NaN regression targets (codes 0-5) contribute nothing.
+ * a <= 8, b <= 64.
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_pp_loss_workspace_bytes(int32_t b, int32_t h, int32_t w);
+int av2x_pp_loss(const float* psm, const float* rm, const float* obj, const float* targets, const float* pos_equal_one,
+                 const int32_t* class_ids, int32_t b, int32_t h, int32_t w, int32_t a, int32_t c, float cls_weight,
+                 float reg_coe, void* workspace, float* out4, float* dpsm, float* drm, float* dobj, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * AP evaluation: true/false positives of one frame.  Replaces the shapely loop of caluclate_tp_fp
  * (utils/eval_utils_opv2v.py:41-97; IoU = common_utils.compute_iou :150-171 on convert_format :174-191 polygons).
  *   det_corners (n_det,8,3) / gt_corners (n_gt,8,3) f32: the first four corners' (x,y) are the BEV quad;

@@ -746,6 +746,36 @@ def w2c_attn_golden(name="w2c_attn"):
     print(path, os.path.getsize(path) // 1024, "KiB", {k: v.shape for k, v in out.items()})
 
 
+def loss_golden(name="loss_small"):
+    """The reference's PointPillarLossMultiClass and its autograd on seeded head maps / labels vs oracle/loss_oracle.py."""
+    from airv2x_perception_amd import synth
+    from oracle import loss_oracle as lo
+    from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
+    out = {}
+    args = {"cls_weight": 1.0, "reg": 2.0, "num_class": 7}
+    for tag, kw in (("a", dict(seed=5)), ("b", dict(seed=6, B=3, H=7, W=9, empty_sample=1)), ("c", dict(seed=7, B=1, H=25, W=44, pos_frac=0.004))):
+        c = synth.loss_case(**kw)
+        t = {k: torch.from_numpy(v) for k, v in c.items()}
+        heads = {k: t[k].clone().requires_grad_(True) for k in ("psm", "rm", "obj")}
+        crit = PointPillarLossMultiClass(args)
+        total = crit(heads, {k: t[k] for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")})
+        total.backward()
+        o = {k: t[k].clone().requires_grad_(True) for k in ("psm", "rm", "obj")}
+        mine = lo.pp_loss(o["psm"], o["rm"], o["obj"], t["targets"], t["pos_equal_one"], t["class_ids"], 7, 1.0, 2.0)
+        mine[0].backward()
+        assert float(mine[0]) == float(total) and abs(float(mine[1]) - crit.loss_dict["reg_loss"]) == 0 and \
+            abs(float(mine[2]) - crit.loss_dict["conf_loss"]) == 0, (tag, float(mine[0]), float(total))
+        for k in ("psm", "rm", "obj"):
+            assert torch.equal(o[k].grad, heads[k].grad), (tag, k)
+            out[f"{tag}_d{k}"] = heads[k].grad.numpy()
+        out[f"{tag}_losses"] = np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)
+        print(f"[{name}] {tag}: total {float(total):.6f} reg {crit.loss_dict['reg_loss']:.6f} conf {crit.loss_dict['conf_loss']:.6f}; "
+              f"oracle == reference (values and gradients)")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB")
+
+
 def run_when2com_case(name, lidar_range, types, n_points, seed, mode="softmax", head_stride=1, big_stride=4):
     """Airv2xWhen2com on the real reference vs oracle/when2com_oracle.py."""
     from airv2x_perception_amd import synth
@@ -1167,6 +1197,7 @@ GROUPS = {
     "when2com_full": lambda: run_when2com_case("when2com_full_n2", None, ["vehicle", "rsu"], 8192, 7, head_stride=4, big_stride=16),
     "submodules": lambda: submodules_golden(),
     "w2c_attn": lambda: w2c_attn_golden(),
+    "loss": lambda: loss_golden(),
     "v2vnet": lambda: (run_v2vnet_case("v2vnet_small_n3", SMALL, ["vehicle", "rsu", "drone"], 1500, 8),
                        run_v2vnet_case("v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 1500, 9, agg="max")),
     "v2vnet_full": lambda: run_v2vnet_case("v2vnet_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 10, head_stride=4, big_stride=16),
