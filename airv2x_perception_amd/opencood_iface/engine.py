@@ -339,7 +339,7 @@ class Where2ComEngine:
         d.sk_wgs = 0
         wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         vflag = 0x0800 if self.amp else (0x0400 if self.split3 else 0)
-        if self.winograd and not self.conv_tile and vflag == 0 and residual is None and self.wino_rule(L):
+        if self.winograd and not self.conv_tile and vflag == 0 and self.wino_rule(L):
             wgt = _wu(L, self.lib, self.stream())
             d.tile = self.WINO_TILE
         elif self.conv_tile:
@@ -392,10 +392,10 @@ class Where2ComEngine:
 
     @staticmethod
     def wino_rule(L):
-        """Layers that run as Winograd F(2x2,3x3): 3x3 / stride 1 / pad 1, ReLU or no activation, >= 128 input channels
+        """Layers that run as Winograd F(2x2,3x3): 3x3 / stride 1 / pad 1, ReLU / sigmoid / tanh or no activation, >= 128 input channels
         (16+ chunks: below that the prologue / epilogue outweigh the saved multiplies, tools/wino_bench.py) and a multiple
         of 128 output channels."""
-        return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1)
+        return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1, 3, 4)
                 and L.cin >= 128 and L.cin % 8 == 0 and L.cout % 128 == 0 and L.cout == L.coutp)
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)

@@ -151,7 +151,7 @@ uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs);
  * direct kernel to fp32 rounding (not bit for bit).  `w` must then point to the transformed weights
  *   u [pos = 4*xi + nu][cin/4][coutp][4] = (G g G^T)[xi][nu] in the k-quad packing of `w`,
  * made once per layer by av2x_wino_pack_weights from the ordinary packing (av2x_wino_weight_bytes(cin, coutp) bytes).
- * cin % 8 == 0, cout % CB == 0, relu in {0, 1}, no residual. */
+ * cin % 8 == 0, cout % CB == 0, activation codes 0, 1, 3, 4 (no GELU); residual as in av2x_conv2d_res. */
 uint64_t av2x_wino_weight_bytes(int32_t cin, int32_t coutp);
 int av2x_wino_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, float* u, av2x_stream_t stream);
 

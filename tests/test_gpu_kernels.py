@@ -489,7 +489,6 @@ def test_winograd_conv_channel_slices_and_argument_checks(lib):
         assert b"Winograd" in lib.av2x_last_error() or b"winograd" in lib.av2x_last_error().lower(), field
         setattr(d, field, keep)
         d.ho, d.wo = h, w
-    assert lib.av2x_conv2d_res(byref(d), _p(xw.cuda()), _p(u), None, _p(shift.cuda()), _p(out), _p(out), _stream()) != 0   # residual
 
 
 def test_winograd_rule_is_a_function_of_the_layer_only():
@@ -501,3 +500,28 @@ def test_winograd_rule_is_a_function_of_the_layer_only():
     assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(384, 256)) and rule(mk(128, 128, relu=0))
     assert not rule(mk(64, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
     assert not rule(mk(256, 64)) and not rule(mk(256, 256, relu=2)) and not rule(mk(256, 256, mode=_lib.AV2X_DECONV))
+    assert rule(mk(512, 256, relu=3)) and rule(mk(512, 256, relu=4))
+
+
+@pytest.mark.parametrize("act", [3, 4, 1])
+def test_winograd_conv_gru_epilogues(lib, act):
+    """sigmoid / tanh epilogues and the residual operand (added, or for tanh multiplied as a gate: the zero-hidden ConvGRU
+    of V2VNet) against fp64."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    n, h, w, cin, cout = 1, 13, 18, 256, 128
+    g = torch.Generator().manual_seed(500 + act)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.rand(n, h, w, cout, generator=g)
+    z = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    ref = {3: torch.sigmoid(z) + res.double(), 4: torch.tanh(z) * res.double(), 1: torch.relu(z) + res.double()}[act]
+    wp, coutp = pack_conv_weight(wt)
+    u = _wino_weights(lib, wp.cuda(), cin, coutp)
+    out = torch.empty(n, h, w, cout, device="cuda")
+    xn, rg, bg = x.permute(0, 2, 3, 1).contiguous().cuda(), res.cuda(), bias.cuda()
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=cout,
+                      out_coff=0, ks=3, stride=1, pad=1, relu=act, mode=0, up=1, tile=WINO_TILES["32x128"], sk_wgs=0)
+    _lib.check(lib.av2x_conv2d_res(byref(d), _p(xn), _p(u), None, _p(bg), _p(rg), _p(out), _stream()), "conv")
+    assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
