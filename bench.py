@@ -338,6 +338,9 @@ def main(argv=None, hooks=None, device=None):
                                                                    f"{max(1, a.inflight)} in flight each, no data-path collective"}
         model = getattr(hooks, "model", None)
         dd = None
+        if rank == 0 and isinstance(hooks, GpuShardHooks) and not a.no_roofline:
+            # the roofline pass below times whole frames of the same agent count on THIS GPU (same kernels as the sharded run)
+            _, _, dd, _, _ = build_inputs(a.agents, a.points, dev, only=None, model=a.model)
         parallelism = (f"one frame over {world} rank(s), agents per rank {info['agents_per_rank']}, RCCL all_gather_into_tensor of "
                        + MESSAGE[a.model] + f"; {info['frames_in_flight']} frame(s) in flight per rank, ego stage: {info['ego_stage']}")
         inflight_used = info["frames_in_flight"]
@@ -541,7 +544,7 @@ def main(argv=None, hooks=None, device=None):
         del m2, e2
 
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
-    if not a.no_roofline and rank == 0 and a.mode == "replica":
+    if not a.no_roofline and rank == 0 and dd is not None and model is not None and eng is not None:
         eng.use_graph = False
         # What a hipEvent pair adds around ONE launch when the queue is full (the marker packets either side of the kernel):
         # with T1 = pair around one 4-byte fill and T2 = pair around two of them, T2 - T1 is one kernel + the gap to the
@@ -631,6 +634,8 @@ def main(argv=None, hooks=None, device=None):
             **({"per_shape": [{"M_cin_cout_ks_stride": list(k[0]), "tile": tkey(k[1]), "wgs": k[2], "launches_per_frame": v[0] / a.steps,
                                "us": round(v[2] / v[0] * 1e6, 1), "tflops": round(v[1] / v[2] / 1e12, 1)}
                               for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])]} if a.per_shape else {}),
+            **({"measured_on": f"rank 0, whole {a.agents}-agent frames on one GPU (the sharded run launches the same kernels on "
+                               "each rank's share of the agents)"} if a.mode == "shard" else {}),
             "timing": "second pass of K sequential frames (the single_stream schedule), hipEvent pair around every conv "
                       "launch on the launch stream minus event_pair_overhead_us; with several frames in flight the kernels of different frames overlap and "
                       "per-launch durations are not separable (rocprofv3 summary of this mode: profiles/*_inflight1.txt)",
