@@ -388,15 +388,17 @@ class Where2ComEngine:
                                  (n * d.ho * d.wo, L.cin, ncols, L.ks, L.stride)))
         return ho, wo
 
-    WINO_TILE = 0x40000000 | (32 << 16) | 128   # 32 tiles x 128 couts per workgroup (4 waves x 16 accumulator tiles)
+    # 32 tiles x 64 couts per workgroup, 8 of the 16 positions per wave (128 accumulation registers: two workgroups per CU,
+    # one computes while the other is in its prologue / epilogue); bit-identical to the 16-positions-per-wave tilings
+    WINO_TILE = 0x40000000 | (32 << 16) | 64 | 0x8000
 
     @staticmethod
     def wino_rule(L):
-        """Layers that run as Winograd F(2x2,3x3): 3x3 / stride 1 / pad 1, ReLU / sigmoid / tanh or no activation, >= 128 input channels
-        (16+ chunks: below that the prologue / epilogue outweigh the saved multiplies, tools/wino_bench.py) and a multiple
-        of 128 output channels."""
+        """Layers that run as Winograd F(2x2,3x3): 3x3 / stride 1 / pad 1, ReLU / sigmoid / tanh or no activation, >= 64 input channels
+        (8+ chunks of 8; measured faster than the direct kernel from there on, tools/wino_bench.py) and a multiple of 64
+        output channels."""
         return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1, 3, 4)
-                and L.cin >= 128 and L.cin % 8 == 0 and L.cout % 128 == 0 and L.cout == L.coutp)
+                and L.cin >= 64 and L.cin % 8 == 0 and L.cout % 64 == 0 and L.cout == L.coutp)
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)
     TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),

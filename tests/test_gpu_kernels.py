@@ -410,7 +410,8 @@ def test_apply_mask(lib):
 
 
 # ---------------------------------------------------------------------------------------------- Winograd F(2x2,3x3)
-WINO_TILES = {"32x128": 0x40000000 | (32 << 16) | 128, "64x64": 0x40000000 | (64 << 16) | 64, "32x64": 0x40000000 | (32 << 16) | 64}
+WINO_TILES = {"32x128": 0x40000000 | (32 << 16) | 128, "64x64": 0x40000000 | (64 << 16) | 64, "32x64": 0x40000000 | (32 << 16) | 64,
+              "32x64h": 0x40000000 | (32 << 16) | 64 | 0x8000}   # h: 8 positions per wave, two workgroups per CU
 WINO_CASES = [
     # n, h, w, cin, cout, relu          (odd H / W: half-empty tiles; 1-pixel-high maps; blocks that wrap rows and images)
     (2, 25, 88, 256, 256, 1),
@@ -498,8 +499,8 @@ def test_winograd_rule_is_a_function_of_the_layer_only():
     mk = lambda cin, cout, ks=3, stride=1, pad=1, relu=1, mode=_lib.AV2X_CONV: ConvLayer(None, None, None, cin, cout, cout, ks, stride, pad, relu, mode)
     rule = Where2ComEngine.wino_rule
     assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(384, 256)) and rule(mk(128, 128, relu=0))
-    assert not rule(mk(64, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
-    assert not rule(mk(256, 64)) and not rule(mk(256, 256, relu=2)) and not rule(mk(256, 256, mode=_lib.AV2X_DECONV))
+    assert rule(mk(64, 64)) and rule(mk(256, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
+    assert not rule(mk(32, 64)) and not rule(mk(256, 96)) and not rule(mk(256, 256, relu=2)) and not rule(mk(256, 256, mode=_lib.AV2X_DECONV))
     assert rule(mk(512, 256, relu=3)) and rule(mk(512, 256, relu=4))
 
 

@@ -85,8 +85,8 @@ def test_gpu_forward_matches_golden(name):
         tot, ref = float(out[k].double().sum()), float(fx[k + "_sum"])
         assert abs(tot - ref) <= 1e-5 * max(1.0, float(out[k].double().abs().sum())), (k, tot, ref)
     # comm_rate counts the non-zeros of a ReLU output: a pre-activation within rounding of 0 may land on either side
-    # (different fp32 summation order), so the count is compared to 1e-6 relative (exact on the small fixtures)
-    assert abs(out["comm_rate"] - float(fx["comm_rate"])) <= max(0.0 if "full" not in name else 2.0, 1e-6 * float(fx["comm_rate"]))
+    # (the convolutions before it sum in a different order than the CPU's), so a couple of cells out of ~5e5 may differ
+    assert abs(out["comm_rate"] - float(fx["comm_rate"])) <= max(2.0, 1e-5 * float(fx["comm_rate"]))
     assert out["mask"] == 0
     assert set(out.keys()) == {"psm", "rm", "obj", "mask", "comm_rate"}
     o2 = model(dd)

@@ -27,6 +27,8 @@ def conv_key(name):
         bm, bn, wm, wn, stages, mode = (int(g.group(i)) for i in range(1, 7))
         waves = (bm // wm) * (bn // wn)
         return f"g{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if stages == 3 else ''}{'sk' if mode == 1 else ''}"
+    if "conv_wino_f32_h" in name:
+        return "w32x64h"
     wn = re.search(r"conv_wino_f32<(\d+), (\d+)>", name)
     if wn:  # Winograd F(2x2,3x3): bench.py's key "w<tiles>x<couts>" per workgroup
         return f"w{32 * int(wn.group(1))}x{32 * int(wn.group(2))}"
