@@ -161,6 +161,7 @@ class ShardedPipeline:
 
     @classmethod
     def from_engine(cls, engine, depth, group=None, rotate=True):
+        engine.throughput_mode = depth > 1     # tuner hint only (bit-identical candidates), see Where2ComEngine
         engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
         return cls([EngineBackend(e) for e in engines], group, rotate, engine.device)
 

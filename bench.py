@@ -385,6 +385,7 @@ def main(argv=None, hooks=None, device=None):
     secondary = rank == 0 and world == 1 and a.mode == "replica" and not a.only_headline
     if secondary and a.inflight > 1:   # secondary figures: single-GPU runs only
         # latency mode for reference: strictly one frame at a time on one stream
+        eng.throughput_mode = False   # tuner hint only: the sequential schedule may use the finer Winograd tiling
         for _ in range(2):
             model(dd)
         torch.cuda.synchronize()
@@ -397,6 +398,8 @@ def main(argv=None, hooks=None, device=None):
                                 "note": "one frame at a time (no overlap between frames)"}
 
     # ---------------- the same frames with the split-3 GEMM (fp32-accurate, bf16 matrix cores): reported beside the headline
+    if secondary and a.inflight > 1:
+        eng.throughput_mode = True    # the pipelined secondary legs below
     if secondary and a.model == "where2com" and a.gemm == "f32" and not a.amp and a.inflight > 1:
         for e in pipe.engines:
             e.split3 = True
@@ -546,6 +549,7 @@ def main(argv=None, hooks=None, device=None):
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and dd is not None and model is not None and eng is not None:
         eng.use_graph = False
+        eng.throughput_mode = False   # sequential frames below
         # What a hipEvent pair adds around ONE launch when the queue is full (the marker packets either side of the kernel):
         # with T1 = pair around one 4-byte fill and T2 = pair around two of them, T2 - T1 is one kernel + the gap to the
         # next, so 2*T1 - T2 is the pair's own share (minus one inter-kernel gap: a conservative, i.e. small, estimate).
@@ -598,7 +602,7 @@ def main(argv=None, hooks=None, device=None):
         tot_fl = sum(v[1] for v in per.values())
         tot_exe = sum(v[3] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{'w' if k[0] & 0x4000 else ''}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x3fff}x{k[1] & 0x01ff}{('h' if k[0] & 0x4000 else 'w8') if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
+        tkey = lambda k: f"{'w' if k[0] & 0x4000 else ''}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x3fff}x{k[1] & 0x01ff}{(('q' if (k[1] & 0x01ff) == 32 else 'h') if k[0] & 0x4000 else 'w8') if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         peak = PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS
         res["roofline"] = {
@@ -613,11 +617,12 @@ def main(argv=None, hooks=None, device=None):
                                          "(the algorithmic count) has 36" if wino else " (direct form: equal to achieved)")},
             "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": ((f"conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
+            "kernel": (("conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
+                        "conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
                         f"conv_wino_f32<{(dom[0] & 0x3fff) // 32},{(dom[1] & 0x01ff) // 32}> (Winograd F(2x2,3x3), {dom[0] & 0x3fff} tiles x {dom[1] & 0x01ff} couts per workgroup)") if wino else
                        f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (("conv_wino_f32_h" if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else (f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": ((("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else (f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),

@@ -411,7 +411,8 @@ def test_apply_mask(lib):
 
 # ---------------------------------------------------------------------------------------------- Winograd F(2x2,3x3)
 WINO_TILES = {"32x128": 0x40000000 | (32 << 16) | 128, "64x64": 0x40000000 | (64 << 16) | 64, "32x64": 0x40000000 | (32 << 16) | 64,
-              "32x64h": 0x40000000 | (32 << 16) | 64 | 0x8000}   # h: 8 positions per wave, two workgroups per CU
+              "32x64h": 0x40000000 | (32 << 16) | 64 | 0x8000,   # h: 8 positions per wave, two workgroups per CU
+              "32x32q": 0x40000000 | (32 << 16) | 32 | 0x8000}   # q: 4 positions per wave, three or four workgroups per CU
 WINO_CASES = [
     # n, h, w, cin, cout, relu          (odd H / W: half-empty tiles; 1-pixel-high maps; blocks that wrap rows and images)
     (2, 25, 88, 256, 256, 1),

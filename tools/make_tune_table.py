@@ -17,7 +17,7 @@ import bench  # noqa: E402
 def main(out):
     dev = torch.device("cuda", 0)
     table = {}
-    for model in ("where2com", "cobevt", "v2xvit", "when2com"):
+    for model in ("where2com", "cobevt", "v2xvit", "when2com", "v2vnet"):
         for agents in ((1, 2, 3, 4, 5, 8) if model == "where2com" else (4, 8)):
             a = bench.parse(["--model", model, "--agents", str(agents)])
             hy, args, dd, _, _ = bench.build_inputs(agents, a.points, dev, only=None, model=model)
@@ -26,6 +26,9 @@ def main(out):
                 eng.amp, m.amp, eng.split3 = amp, amp, split3
                 m(dd)
                 torch.cuda.synchronize()
+            eng.amp, m.amp, eng.split3, eng.throughput_mode = False, False, False, True   # the frames-in-flight candidate set
+            m(dd)
+            torch.cuda.synchronize()
             for k, v in eng.tile_cache.items():
                 table["|".join(str(x) for x in k)] = [int(v[0]), int(v[1])]
             print(model, agents, len(table), flush=True)

@@ -29,6 +29,8 @@ def conv_key(name):
         return f"g{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if stages == 3 else ''}{'sk' if mode == 1 else ''}"
     if "conv_wino_f32_h" in name:
         return "w32x64h"
+    if "conv_wino_f32_q" in name:
+        return "w32x32q"
     wn = re.search(r"conv_wino_f32<(\d+), (\d+)>", name)
     if wn:  # Winograd F(2x2,3x3): bench.py's key "w<tiles>x<couts>" per workgroup
         return f"w{32 * int(wn.group(1))}x{32 * int(wn.group(2))}"

@@ -22,7 +22,7 @@ LAYERS = {
     # fixed cost per workgroup: the b2_n4 geometry (144 workgroups = one round) at 1 .. 64 chunks of 8 input channels
     "k8": (4, 25, 88, 8, 256), "k32": (4, 25, 88, 32, 256), "k128": (4, 25, 88, 128, 256), "k512": (4, 25, 88, 512, 256),
 }
-WINO = {"w32x128": (32, 128), "w64x64": (64, 64), "w32x64": (32, 64), "w32x64h": (32, 64 | 0x8000)}
+WINO = {"w32x128": (32, 128), "w64x64": (64, 64), "w32x64": (32, 64), "w32x64h": (32, 64 | 0x8000), "w32x32q": (32, 32 | 0x8000)}
 DIRECT = {"g64x64": (64, 64 | 0x0200), "g128x64w8": (128, 64 | 0x8200)}
 
 
