@@ -147,7 +147,8 @@ uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs);
 
 /* Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 AV2X_CONV layer (tile flag 0x40000000 | TB << 16 | CB on any of
  * the three entry points above; TB x CB = tiles x couts per workgroup: 32x128, 64x64, 32x64, and 32x64 | 0x8000 = the
- * half-position variant: 8 of the 16 positions per wave, two workgroups per CU; all tilings give the same bits): 2.25x fewer
+ * half-position variant (8 of the 16 positions per wave, two workgroups per CU) and 32x32 | 0x8000 = the quarter-position
+ * variant (4 per wave, up to four workgroups per CU); all tilings give the same bits): 2.25x fewer
  * matrix-core multiplies, still fp32 operands and fp32 accumulation on v_mfma_f32_32x32x2_f32; results agree with the
  * direct kernel to fp32 rounding (not bit for bit).  `w` must then point to the transformed weights
  *   u [pos = 4*xi + nu][cin/4][coutp][4] = (G g G^T)[xi][nu] in the k-quad packing of `w`,
