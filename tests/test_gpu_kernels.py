@@ -473,12 +473,13 @@ def test_winograd_conv_channel_slices_and_argument_checks(lib):
     ref = F.relu(F.conv2d(xw[..., 32:].permute(0, 3, 1, 2).double(), wt.double(), shift.double(), padding=1)).permute(0, 2, 3, 1)
     wp, coutp = pack_conv_weight(wt)
     u = _wino_weights(lib, wp.cuda(), cin, coutp)
-    out = torch.full((n, h, w, 160), -7.0, device="cuda")      # written at channels 16..143
-    _conv_call(lib, xw.cuda(), u, None, shift.cuda(), out, cin=cin, cout=cout, coutp=coutp, ks=3, stride=1, pad=1, relu=1,
-               in_coff=32, out_ctot=160, out_coff=16, tile=WINO_TILES["32x128"])
-    o = out.cpu()
-    assert float((o[..., 16:144].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
-    assert bool((o[..., :16] == -7.0).all()) and bool((o[..., 144:] == -7.0).all())
+    for tname in ("32x128", "32x64h", "32x32q"):
+        out = torch.full((n, h, w, 160), -7.0, device="cuda")      # written at channels 16..143
+        _conv_call(lib, xw.cuda(), u, None, shift.cuda(), out, cin=cin, cout=cout, coutp=coutp, ks=3, stride=1, pad=1, relu=1,
+                   in_coff=32, out_ctot=160, out_coff=16, tile=WINO_TILES[tname])
+        o = out.cpu()
+        assert float((o[..., 16:144].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), tname
+        assert bool((o[..., :16] == -7.0).all()) and bool((o[..., 144:] == -7.0).all()), tname
     d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=96, in_coff=32, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=160,
                       out_coff=16, ks=3, stride=1, pad=1, relu=1, mode=0, up=1, tile=WINO_TILES["32x128"], sk_wgs=0)
     args = (_p(xw.cuda()), _p(u), None, _p(shift.cuda()), None, _p(out), _stream())
@@ -523,7 +524,12 @@ def test_winograd_conv_gru_epilogues(lib, act):
     u = _wino_weights(lib, wp.cuda(), cin, coutp)
     out = torch.empty(n, h, w, cout, device="cuda")
     xn, rg, bg = x.permute(0, 2, 3, 1).contiguous().cuda(), res.cuda(), bias.cuda()
-    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=cout,
-                      out_coff=0, ks=3, stride=1, pad=1, relu=act, mode=0, up=1, tile=WINO_TILES["32x128"], sk_wgs=0)
-    _lib.check(lib.av2x_conv2d_res(byref(d), _p(xn), _p(u), None, _p(bg), _p(rg), _p(out), _stream()), "conv")
-    assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    outs = []
+    for tname in ("32x128", "32x64h", "32x32q"):
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=cout,
+                          out_coff=0, ks=3, stride=1, pad=1, relu=act, mode=0, up=1, tile=WINO_TILES[tname], sk_wgs=0)
+        out.fill_(float("nan"))
+        _lib.check(lib.av2x_conv2d_res(byref(d), _p(xn), _p(u), None, _p(bg), _p(rg), _p(out), _stream()), "conv")
+        assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), tname
+        outs.append(out.cpu().clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
