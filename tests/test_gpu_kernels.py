@@ -533,3 +533,42 @@ def test_winograd_conv_gru_epilogues(lib, act):
         assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), tname
         outs.append(out.cpu().clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_winograd_random_shapes_against_the_direct_kernel(lib):
+    """Seeded sweep over odd shapes (1..9 images, maps from 1x1 to 23x37, Cin a multiple of 8 from 8 to 136, Cout a multiple of
+    32 or 64): every Winograd tiling that the channel count admits must agree bit for bit with the others and with the
+    direct implicit-GEMM kernel (where Cin % 32 == 0 lets that kernel run) to 3e-5 * max|y| -- two fp32 algorithms with
+    different summation orders, each ~1e-5 from fp64."""
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    rng = np.random.default_rng(20240607)
+    for trial in range(24):
+        n = int(rng.integers(1, 10))
+        h, w = int(rng.integers(1, 24)), int(rng.integers(1, 38))
+        cin = 8 * int(rng.integers(1, 18))
+        cout = int(rng.choice([32, 64, 96, 128, 192]))
+        relu = int(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(1000 + trial)
+        x = torch.randn(n, h, w, cin, generator=g).cuda()
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+        scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+        wp, coutp = pack_conv_weight(wt)
+        wp = wp.cuda()
+        u = _wino_weights(lib, wp, cin, coutp)
+        outs = {}
+        for name, tile in WINO_TILES.items():
+            if cout % (tile & 0x1ff):
+                continue
+            out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+            _conv_call(lib, x, u, scale, shift, out, cin=cin, cout=cout, coutp=coutp, ks=3, stride=1, pad=1, relu=relu, tile=tile)
+            outs[name] = out
+        assert outs, (cin, cout)
+        first = next(iter(outs.values()))
+        assert not torch.isnan(first).any(), (trial, n, h, w, cin, cout)
+        for name, o in outs.items():
+            assert torch.equal(first, o), (trial, name, n, h, w, cin, cout)
+        if cin % 32 == 0:
+            ref = torch.empty_like(first)
+            _conv_call(lib, x, wp, scale, shift, ref, cin=cin, cout=cout, coutp=coutp, ks=3, stride=1, pad=1, relu=relu, tile=0)
+            err = float((first - ref).abs().max())
+            assert err <= 3e-5 * max(1.0, float(ref.abs().max())), (trial, err, n, h, w, cin, cout)
