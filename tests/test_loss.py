@@ -64,3 +64,25 @@ def test_gpu_loss_and_gradients_match_reference(tag, kw):
         v = crit({k + "_single": t[k] for k in ("psm", "rm", "obj")},
                  {k: t[k] for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}, prefix="_single")
     assert float(v) == float(total.detach()) and "total_loss_single" in crit.loss_dict
+
+
+@pytest.mark.gpu
+def test_gpu_loss_full_head_maps():
+    """Two frames of full 100 x 352 head maps: the three scalars and strided samples / abs-sums of the gradients."""
+    from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
+    g = np.load(GOLD)
+    t = {k: torch.from_numpy(v).cuda() for k, v in synth.loss_case(seed=8, B=2, H=100, W=352, pos_frac=0.002).items()}
+    heads = {k: t[k].clone().requires_grad_(True) for k in ("psm", "rm", "obj")}
+    crit = PointPillarLossMultiClass(ARGS)
+    total = crit(heads, {k: t[k] for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")})
+    ref = g["full_losses"]
+    got = np.asarray([float(total.detach()), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]])
+    assert np.all(np.abs(got - ref) <= 2e-5 * np.abs(ref)), (got, ref)   # torch sums 2 M fp32 terms pairwise; the kernel in fp64
+    total.backward()
+    for k in ("psm", "rm", "obj"):
+        gr = heads[k].grad
+        r = g[f"full_d{k}"]
+        d = np.abs(gr[:, :, ::7, ::11].cpu().numpy() - r)
+        assert np.all(d <= 1e-7 + 2e-5 * np.abs(r)), (k, float(d.max()))
+        s_ref = float(g[f"full_d{k}_abs_sum"])
+        assert abs(float(gr.double().abs().sum()) - s_ref) <= 1e-5 * s_ref, k

@@ -201,3 +201,25 @@ def test_gpu_fused_warp_equals_warp_then_fuse():
     # argument checks fail loudly
     assert lib.av2x_warp_fuse(ptrs, th.ctypes.data_as(c_void_p), n, h, w, 96, 0, c_void_p(out.data_ptr()), st) != 0
     assert lib.av2x_warp_fuse(ptrs, th.ctypes.data_as(c_void_p), 33, h, w, c, 0, c_void_p(out.data_ptr()), st) != 0
+
+
+@pytest.mark.gpu
+def test_gpu_multi_scale_full_canvas_five_agents():
+    """The 200 x 704 AirV2X canvas, 5 agents (BASELINE-sized maps: 100x352 / 50x176 / 25x88 levels): strided samples and the
+    sums of the fused map against the reference, the communication volume equal."""
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    g = np.load(GOLD)
+    c, rl, seed = CFG["ms_atten"], [5], 44
+    mod = wm.Where2comm(c)
+    mod.load_state_dict(_gauss_sd(c, seed + 500), strict=True)
+    mod = mod.eval().cuda()
+    x = torch.from_numpy(synth.w2c_attn_features(seed, 5, 64, 200, 704, keep=0.08)).cuda()
+    rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, 5, 100, 352)).cuda()
+    fused, vol, _ = mod(x, rm, torch.tensor(rl), synth.w2c_attn_pairwise(rl).cuda(), _gpu_backbone(), None)
+    assert tuple(fused.shape) == (1, 96, 100, 352)
+    # an integer count of non-zero cells behind a threshold on a smoothed map: a handful of cells may sit on the threshold
+    assert abs(float(vol) - float(g["ms_atten_full_vol"])) <= 1e-5 * float(g["ms_atten_full_vol"])
+    _close(fused[:, ::4, ::3, ::5], g["ms_atten_full_fused"])
+    tot, ab = float(fused.double().sum()), float(fused.double().abs().sum())
+    assert abs(tot - float(g["ms_atten_full_sum"])) <= 1e-5 * float(g["ms_atten_full_abs_sum"])
+    assert abs(ab - float(g["ms_atten_full_abs_sum"])) <= 1e-5 * float(g["ms_atten_full_abs_sum"])

@@ -719,6 +719,23 @@ def w2c_attn_golden(name="w2c_attn"):
             print(f"[{name}] {tag}: oracle vs reference {err:.2e}, volume {float(vol):.1f}, mask ones "
                   f"{float(tr['mask'].mean()):.3f}, margin {float(out[f'{tag}_margin']):.2e}")
 
+        # full map (the 200 x 704 AirV2X canvas -> 100 x 352 fused), 5 agents: every 4th channel / 3rd row / 5th column + sums
+        rl, seed, c = [5], 44, cfg["ms_atten"]
+        mod = Where2comm(c).eval()
+        fsd = gauss_sd(mod, seed + 500)
+        x = torch.from_numpy(synth.w2c_attn_features(seed, 5, 64, 200, 704, keep=0.08))
+        rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, 5, 100, 352))
+        pw = synth.w2c_attn_pairwise(rl)
+        fused, vol, _ = mod(x, rm, torch.tensor(rl), pw, bb, None)
+        of, ov = wa.where2comm_attn(x, rm, rl, pw, fsd, c, bsd_o, bbc)
+        err = (of - fused).abs().max().item()
+        assert err < 2e-5 and float(ov) == float(vol), ("full", err, ov, vol)
+        out["ms_atten_full_fused"] = fused[:, ::4, ::3, ::5].numpy()
+        out["ms_atten_full_sum"] = np.float64(fused.double().sum())
+        out["ms_atten_full_abs_sum"] = np.float64(fused.double().abs().sum())
+        out["ms_atten_full_vol"] = np.float64(vol)
+        print(f"[{name}] ms_atten_full: oracle vs reference {err:.2e}, volume {float(vol):.1f}")
+
         for tag, rl, ch, seed in (("ss_atten", [2, 2], 256, 51), ("ss_max", [3], 64, 52)):
             c = cfg[tag]
             mod = Where2comm(c).eval()
@@ -771,6 +788,18 @@ def loss_golden(name="loss_small"):
         out[f"{tag}_losses"] = np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)
         print(f"[{name}] {tag}: total {float(total):.6f} reg {crit.loss_dict['reg_loss']:.6f} conf {crit.loss_dict['conf_loss']:.6f}; "
               f"oracle == reference (values and gradients)")
+    # full head maps (2 x 100 x 352 x 2 anchors): the three scalars + every 7th row / 11th column of the gradients
+    c = synth.loss_case(seed=8, B=2, H=100, W=352, pos_frac=0.002)
+    t = {k: torch.from_numpy(v) for k, v in c.items()}
+    heads = {k: t[k].clone().requires_grad_(True) for k in ("psm", "rm", "obj")}
+    crit = PointPillarLossMultiClass(args)
+    total = crit(heads, {k: t[k] for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")})
+    total.backward()
+    out["full_losses"] = np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)
+    for k in ("psm", "rm", "obj"):
+        out[f"full_d{k}"] = heads[k].grad[:, :, ::7, ::11].numpy()
+        out[f"full_d{k}_abs_sum"] = np.float64(heads[k].grad.double().abs().sum())
+    print(f"[{name}] full: total {float(total):.6f}")
     path = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB")
