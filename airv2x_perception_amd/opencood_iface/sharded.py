@@ -55,6 +55,10 @@ class ShardedFrame:
         # world == 1 normally skips the collectives; True issues them anyway (a 1-rank RCCL group on a one-GPU box
         # exercises the communicator set-up and the all_gather_into_tensor call path)
         self.collectives_when_single = collectives_when_single and dist.is_initialized()
+        # rotating ego stage (fusion_rank given): AV2X_SHARD_GATHER=1 gathers TO that rank (1/world of the bytes) instead of
+        # the all-gather.  Opt-in until it has run on a multi-GPU node: all_gather_into_tensor is the path RCCL is tuned for.
+        import os
+        self.gather_to_fusion_rank = os.environ.get("AV2X_SHARD_GATHER", "0") == "1"
 
     @torch.no_grad()
     def forward(self, data_dict_local, counts=None, fusion_rank=None, **kw):
@@ -64,8 +68,9 @@ class ShardedFrame:
                      many agents as this one (the even case, no padding).
         fusion_rank  None: every rank finishes the frame (SPMD: all of them return the output dict).  r: only rank r
                      runs the single-level ego stage and returns the output, the others return None right after the
-                     all-gather — with several frames in flight the caller rotates r so that the ego stages of
-                     consecutive frames run on different GPUs instead of being repeated on all of them.  Two-level
+                     exchange (a gather TO rank r: only it needs the messages) — with several frames in flight the caller
+                     rotates r so that the ego stages of consecutive frames run on different GPUs instead of being repeated
+                     on all of them.  Two-level
                      backends (CoBEVT / V2X-ViT split the fusion itself over the ranks) ignore it."""
         if counts is not None:
             counts = [int(c) for c in counts]
@@ -82,8 +87,22 @@ class ShardedFrame:
         send, stats, meta = self.backend.local_stage(data_dict_local, has_ego=(self.rank == 0), **lkw)
         if counts is not None:
             meta = dict(meta, counts=counts, n_pad=n_pad)
+        two_level = (self.world > 1 and getattr(self.backend, "two_level", False)
+                     and getattr(self.backend, "can_split", lambda m, w: True)(meta, self.world))
         if self.world == 1 and not self.collectives_when_single:
             recv = send
+        elif fusion_rank is not None and not two_level and self.gather_to_fusion_rank:
+            # only rank `fusion_rank` finishes this frame, so only IT needs the messages: a gather (point-to-point sends over
+            # the peers' own xGMI links into one GPU) moves 1/world of the bytes an all-gather would, and consecutive frames
+            # target different ranks.  The counters follow the same route.
+            dst = dist.get_global_rank(self.group, fusion_rank) if self.group is not None else fusion_rank
+            recv = None
+            if self.rank == fusion_rank:
+                rb = getattr(self.backend, "recv_buffer", None)
+                recv = rb(self.world * send.numel(), send) if rb is not None else \
+                    torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
+            dist.gather(send, list(recv.view(self.world, -1).unbind(0)) if recv is not None else None, dst=dst, group=self.group)
+            dist.reduce(stats, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
         else:
             rb = getattr(self.backend, "recv_buffer", None)
             recv = rb(self.world * send.numel(), send) if rb is not None else \
@@ -92,8 +111,7 @@ class ShardedFrame:
             # xGMI is point-to-point, so the 7 peer transfers into each GPU run on separate links
             dist.all_gather_into_tensor(recv, send, group=self.group)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
-        if (self.world > 1 and getattr(self.backend, "two_level", False)
-                and getattr(self.backend, "can_split", lambda m, w: True)(meta, self.world)):
+        if two_level:
             if hasattr(self.backend, "engine"):
                 self.backend.engine.shard_group = self.group
             # second level: every rank runs the fusion on ITS share of the map and the (small) head outputs are

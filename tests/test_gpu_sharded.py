@@ -269,6 +269,11 @@ ref = eng.forward(dd, sync_comm_rate=True)
 out = ShardedFrame(EngineBackend(eng), collectives_when_single=True).forward(dd, counts=[len(types)], sync_comm_rate=True)
 torch.cuda.synchronize()
 assert all(torch.equal(out[k], ref[k]) for k in ("psm", "rm", "obj")) and out["comm_rate"] == ref["comm_rate"]
+# the opt-in route of the rotating ego stage: dist.gather + dist.reduce to the fusion rank on the RCCL communicator
+os.environ["AV2X_SHARD_GATHER"] = "1"
+out2 = ShardedFrame(EngineBackend(eng), collectives_when_single=True).forward(dd, counts=[len(types)], fusion_rank=0, sync_comm_rate=True)
+torch.cuda.synchronize()
+assert all(torch.equal(out2[k], ref[k]) for k in ("psm", "rm", "obj")) and out2["comm_rate"] == ref["comm_rate"]
 dist.destroy_process_group()
 print("RCCL-1-OK")
 """

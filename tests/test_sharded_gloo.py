@@ -427,9 +427,10 @@ def test_agent_sharded_frame_equals_single_process(tmp_path):
     assert abs(float(got["com"]) - float(ref["com"])) < 1e-6
 
 
-def _uneven_worker(rank, world, port, result_path, n_agents, rotate):
+def _uneven_worker(rank, world, port, result_path, n_agents, rotate, gather=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["AV2X_SHARD_GATHER"] = "1" if gather else "0"   # rotating ego stage: gather to the fusion rank / all-gather
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     args, sd, voxd = _frame()
@@ -455,12 +456,13 @@ def _uneven_worker(rank, world, port, result_path, n_agents, rotate):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_agents,rotate", [(3, 4, True), (2, 3, False), (3, 2, True)])
-def test_uneven_agent_counts_and_rotating_ego_stage(tmp_path, world, n_agents, rotate):
+@pytest.mark.parametrize("world,n_agents,rotate,gather", [(3, 4, True, False), (2, 3, False, False), (3, 2, True, False),
+                                                         (3, 4, True, True), (3, 2, True, True)])
+def test_uneven_agent_counts_and_rotating_ego_stage(tmp_path, world, n_agents, rotate, gather):
     """4 agents on 3 ranks ([2,1,1]), 3 on 2 ([2,1]) and 2 on 3 ([1,1,0]: an idle rank sends only padding -- NaNs in the
     oracle backend, so a fusion that read them would fail): every rank's frame equals the single-process forward."""
     path = str(tmp_path / "out.pt")
-    mp.spawn(_uneven_worker, args=(world, _free_port(), path, n_agents, rotate), nprocs=world, join=True)
+    mp.spawn(_uneven_worker, args=(world, _free_port(), path, n_agents, rotate, gather), nprocs=world, join=True)
     args, sd, voxd = _frame()
     dd = synth.build_data_dict(voxd[:n_agents], TYPES[:n_agents])
     with torch.no_grad():
