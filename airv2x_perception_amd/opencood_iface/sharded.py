@@ -23,6 +23,8 @@ in the collectives with an all-padding message.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -57,7 +59,6 @@ class ShardedFrame:
         self.collectives_when_single = collectives_when_single and dist.is_initialized()
         # rotating ego stage (fusion_rank given): AV2X_SHARD_GATHER=1 gathers TO that rank (1/world of the bytes) instead of
         # the all-gather.  Opt-in until it has run on a multi-GPU node: all_gather_into_tensor is the path RCCL is tuned for.
-        import os
         self.gather_to_fusion_rank = os.environ.get("AV2X_SHARD_GATHER", "0") == "1"
 
     @torch.no_grad()
