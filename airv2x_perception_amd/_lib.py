@@ -49,6 +49,17 @@ SIGNATURES = {
     "av2x_conv2d_wgrad_workspace_bytes": (c_uint64, [POINTER(ConvDesc)]),
     "av2x_conv2d_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_act_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_bn_workspace_bytes": (c_uint64, [c_int64, c_int32]),
+    "av2x_bn_stats": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_affine_act": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "av2x_bn_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_pixel_attn_backward": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_void_p, POINTER(c_void_p), c_void_p]),
+    "av2x_pillar_train_workspace_bytes": (c_uint64, [c_int32]),
+    "av2x_pillar_moments": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_pillar_vfe_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_void_p]),
     "av2x_channel_sum_workspace_bytes": (c_uint64, [c_int64, c_int32]),
     "av2x_channel_sum": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "av2x_generate_label": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p,

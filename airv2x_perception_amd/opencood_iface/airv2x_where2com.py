@@ -6,9 +6,9 @@ contract, same output keys (``psm``, ``rm``, ``obj``, ``mask``, ``
 ``comm_rate``), and the SAME ``state_dict`` keys/shapes as the reference (162 tensors) so
 released raw-state_dict checkpoints load with ``load_state_dict``.
 
-Inference only: parameters are plain tensors registered under the reference's names; the
-packed device copies used by the kernels are rebuilt lazily whenever a parameter changes
-(``load_state_dict``, ``.to()``, in-place edits bump the version counters).
+Parameters are registered under the reference's names.  ``.eval()`` forwards run the packed inference engine (the packed
+device copies are rebuilt lazily whenever a parameter changes: ``load_state_dict``, ``.to()``, optimiser steps and other
+in-place edits bump the version counters); ``.train()`` forwards build the autograd graph of ``train_where2com.py``.
 """
 from __future__ import annotations
 
@@ -44,7 +44,7 @@ def _amp_requested(module):
         return bool(torch.is_autocast_enabled())
 
 
-def _install(root, key, tensor, is_buffer):
+def _install(root, key, tensor, is_buffer, requires_grad=False):
     parts = key.split(".")
     node = root
     for p in parts[:-1]:
@@ -56,7 +56,7 @@ def _install(root, key, tensor, is_buffer):
     if is_buffer:
         node.register_buffer(parts[-1], tensor)
     else:
-        node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+        node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=requires_grad))
 
 
 class Airv2xWhere2com(nn.Module):
@@ -80,16 +80,19 @@ class Airv2xWhere2com(nn.Module):
                 t = torch.ones(shape)
             else:
                 t = torch.zeros(shape)
-            _install(self, key, t, buf)
+            _install(self, key, t, buf, requires_grad=True)   # trainable, as the reference's nn.Modules are
+        if args.get("backbone_fix"):
+            self.backbone_fix()                                    # airv2x_where2com.py:77-78
         self._engine = None
         self._packed_version = None
         self.sync_comm_rate = True  # the reference returns a python int (airv2x_where2com.py:122)
 
-    # the reference freezes sub-modules with this (airv2x_where2com.py:80-115); all parameters
-    # here are already inference-only
     def backbone_fix(self):
-        for p in self.parameters():
-            p.requires_grad = False
+        """airv2x_where2com.py:80-115: freeze the encoders, the backbone, the shrink header and the heads (fine-tuning on time
+        delay); what is left trainable is the fusion net."""
+        for name, p in self.named_parameters():
+            if not name.startswith("fusion_net."):
+                p.requires_grad = False
 
     def _version(self):
         return tuple(t._version for t in self.state_dict(keep_vars=True).values()) + (
@@ -109,8 +112,9 @@ class Airv2xWhere2com(nn.Module):
         return self._engine
 
     def forward(self, data_dict):
-        if self.training:
-            raise NotImplementedError("training (backward + random top-k masks) is not built yet; call .eval()")
+        if self.training:   # the graph torch autograd differentiates, on the HIP forward / backward ops (train_where2com.py)
+            from .train_where2com import forward_train
+            return forward_train(self, data_dict)
         eng = self.engine()
         eng.amp = _amp_requested(self)
         return eng.forward(data_dict, sync_comm_rate=self.sync_comm_rate)

@@ -1,0 +1,411 @@
+"""Differentiable building blocks of the train-mode Where2Comm path: every forward AND backward runs in
+libairv2x_hip.so; torch only owns the tensors, the autograd graph bookkeeping and a handful of per-channel vector updates.
+
+The reference trains through torch autograd (tools/train.py:220-247) over
+
+    PFNLayer (Linear 10->64, BatchNorm1d batch statistics, ReLU, max over 32)      airv2x_pillar_vfe.py:27-49
+    PointPillarScatter                                                            point_pillar_scatter.py:39-80
+    Conv3x3 / ConvTranspose(k = s) + BatchNorm2d (batch statistics) + ReLU        base_bev_backbone.py:41-105
+    x * communication_mask, AttentionFusion per pixel                             where2comm_fuse.py:152-164,228-249
+    Conv + bias + ReLU (DownsampleConv), 1x1 heads                                downsample_conv.py:17-31
+
+Each is a ``torch.autograd.Function`` here.  Layout: NHWC fp32 on the device throughout.  Batch statistics are returned
+to the caller through ``stats_out`` (a python list that receives ``(mean, biased var, count)``) so that it can apply the
+running-statistics update as often as the reference's schedule does.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_void_p
+
+import torch
+
+from .. import _lib
+from .autograd import _P, _desc, _runner
+
+BN_EPS = 1e-3       # every BatchNorm on the path (airv2x_pillar_vfe.py:21, base_bev_backbone.py:52,65,83)
+BN_MOMENTUM = 0.01
+
+
+def _check_dev(x):
+    if x.device.type != "cuda" or x.dtype != torch.float32:
+        raise RuntimeError("the training ops run on fp32 HIP tensors only (no CPU path exists)")
+
+
+# ------------------------------------------------------------------------------------------------ weight packing (device side)
+def pack_conv_weight_dev(w):
+    """(Cout, Cin, k, k) -> (k*k, Cin/4, CoutP, 4), CoutP = Cout rounded up to 32 -- packing.pack_conv_weight without the host
+    round trip (the weights change every optimiser step)."""
+    w = w.detach()
+    cout, cin, kh, kw = w.shape
+    if cin % 4:
+        raise ValueError("cin must be a multiple of 4")
+    coutp = (cout + 31) // 32 * 32
+    t = w.permute(2, 3, 1, 0).reshape(kh * kw, cin // 4, 4, cout).permute(0, 1, 3, 2)
+    if coutp == cout:
+        return t.contiguous(), coutp
+    out = torch.zeros(kh * kw, cin // 4, coutp, 4, dtype=torch.float32, device=w.device)
+    out[:, :, :cout, :] = t
+    return out, coutp
+
+
+def pack_deconv_weight_dev(w):
+    """ConvTranspose2d weight (Cin, Cout, s, s), kernel == stride -> (1, Cin/4, s*s*Cout, 4); column = (i*s + j)*Cout + co."""
+    w = w.detach()
+    cin, cout, s, s2 = w.shape
+    if s != s2 or cin % 4 or cout % 32:
+        raise ValueError("deconv: kernel == stride, cin % 4 == 0, cout % 32 == 0")
+    ncol = s * s * cout
+    t = w.permute(0, 2, 3, 1).reshape(cin // 4, 4, ncol).permute(0, 2, 1)
+    return t.reshape(1, cin // 4, ncol, 4).contiguous(), ncol
+
+
+# ------------------------------------------------------------------------------------------------ raw launches
+def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0):
+    """act(scale * conv2d(x, w) + shift) through the engine's launcher (direct or Winograd kernels, autotuned)."""
+    from .engine import ConvLayer
+    r = _runner(x.device)
+    n, h, w, cin = x.shape
+    cout, _, ks, _ = weight.shape
+    wp, coutp = pack_conv_weight_dev(weight)
+    sh = shift if shift is not None else torch.zeros(cout, device=x.device)
+    L = ConvLayer(wp, scale, sh, cin, cout, coutp, ks, stride, pad, act)
+    if r.winograd and r.wino_rule(L):   # transformed weights on this stream, without engine._wu's cross-stream synchronise
+        u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=x.device)
+        _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u), r.stream()), "av2x_wino_pack_weights")
+        L._wu = u
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    r.conv(L, x, n, h, w, y)
+    return y
+
+
+def conv_wgrad(x, dz, weight_shape, stride, pad):
+    r = _runner(x.device)
+    n, h, w, cin = x.shape
+    cout, _, ks, _ = weight_shape
+    d, _, _ = _desc(n, h, w, cin, cout, cout, ks, stride, pad, 0)
+    ws = torch.empty(int(r.lib.av2x_conv2d_wgrad_workspace_bytes(byref(d))) // 4 + 4, device=x.device)
+    dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
+    _lib.check(r.lib.av2x_conv2d_wgrad(byref(d), _P(x), _P(dz), _P(ws), _P(dw), r.stream()), "av2x_conv2d_wgrad")
+    return dw
+
+
+def conv_dgrad(dz, weight, stride, pad, in_hw):
+    """Data gradient of conv2d: the forward kernel on the 180-degree-rotated, channel-transposed weights (stride 2: on the
+    zero-upsampled dz -- exact, the inserted zeros contribute nothing)."""
+    n, ho, wo, cout = dz.shape
+    h, w = in_hw
+    cin, ks = weight.shape[1], weight.shape[2]
+    if cout % 4:
+        raise NotImplementedError("data gradient needs cout % 4 == 0 (pad the head convolutions)")
+    wt = weight.detach().flip(2, 3).transpose(0, 1)            # (cin, cout, k, k)
+    if stride == 1:
+        if pad != ks // 2:
+            raise NotImplementedError("'same' padding only")
+        src = dz
+    elif stride == 2 and ks == 3 and pad == 1 and h == 2 * ho and w == 2 * wo:
+        src = torch.zeros((n, h, w, cout), dtype=torch.float32, device=dz.device)
+        src[:, ::2, ::2] = dz
+    else:
+        raise NotImplementedError("data gradient: stride 1, or 3x3 stride 2 pad 1 on even sizes (every layer of the BEV backbone)")
+    return conv_raw(src, wt, 1, ks // 2 if ks == 3 else 0)
+
+
+def bn_stats(z):
+    r = _runner(z.device)
+    c = z.shape[-1]
+    rows = z.numel() // c
+    ws = torch.empty(int(r.lib.av2x_bn_workspace_bytes(rows, c)) // 8 + 1, dtype=torch.float64, device=z.device)
+    mean = torch.empty(c, device=z.device)
+    var = torch.empty(c, device=z.device)
+    _lib.check(r.lib.av2x_bn_stats(_P(z), rows, c, _P(ws), _P(mean), _P(var), r.stream()), "av2x_bn_stats")
+    return mean, var, rows
+
+
+def affine_act(z, scale, shift, act, out=None):
+    r = _runner(z.device)
+    c = z.shape[-1]
+    rows = z.numel() // c
+    y = out if out is not None else torch.empty_like(z)
+    _lib.check(r.lib.av2x_affine_act(_P(z), rows, c, _P(scale), _P(shift), 1 if act else 0, _P(y), r.stream()), "av2x_affine_act")
+    return y
+
+
+def bn_backward(dy, z, mean, rstd, scale, shift, act):
+    r = _runner(z.device)
+    c = z.shape[-1]
+    rows = z.numel() // c
+    ws = torch.empty(int(r.lib.av2x_bn_workspace_bytes(rows, c)) // 8 + 1, dtype=torch.float64, device=z.device)
+    dgamma, dbeta = torch.empty(c, device=z.device), torch.empty(c, device=z.device)
+    dz = torch.empty_like(z)
+    _lib.check(r.lib.av2x_bn_backward(_P(dy), _P(z), rows, c, _P(mean), _P(rstd), _P(scale), _P(shift), 1 if act else 0, _P(ws),
+                                      _P(dgamma), _P(dbeta), _P(dz), r.stream()), "av2x_bn_backward")
+    return dz, dgamma, dbeta
+
+
+def _fold(mean, var, gamma, beta, eps):
+    rstd = torch.rsqrt(var + eps)
+    scale = gamma.detach() * rstd
+    shift = beta.detach() - mean * scale
+    return rstd, scale, shift
+
+
+def update_running_stats(running_mean, running_var, num_batches_tracked, stats, times=1, momentum=BN_MOMENTUM):
+    """nn.BatchNorm's train-mode side effect, applied ``times`` times with the same batch statistics (the reference runs
+    the backbone more than once per step on the same input: airv2x_where2com.py:119,124)."""
+    mean, var, count = stats
+    unbiased = var * (count / max(count - 1, 1))
+    with torch.no_grad():
+        for _ in range(times):
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
+        if num_batches_tracked is not None:
+            num_batches_tracked.add_(times)
+
+
+# ------------------------------------------------------------------------------------------------ Conv + BN(batch) + ReLU
+class ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, stride, pad, eps, act, stats_out):
+        _check_dev(x)
+        x = x.contiguous()
+        z = conv_raw(x, weight, stride, pad)
+        mean, var, count = bn_stats(z)
+        rstd, scale, shift = _fold(mean, var, gamma, beta, eps)
+        y = affine_act(z, scale, shift, act)
+        if stats_out is not None:
+            stats_out.append((mean, var, count))
+        ctx.save_for_backward(x, weight, z, mean, rstd, scale, shift)
+        ctx.cfg = (stride, pad, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, mean, rstd, scale, shift = ctx.saved_tensors
+        stride, pad, act = ctx.cfg
+        dz, dgamma, dbeta = bn_backward(dy.contiguous(), z, mean, rstd, scale, shift, act)
+        dw = conv_wgrad(x, dz, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3]) if ctx.needs_input_grad[0] else None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+def conv_bn_act(x, weight, gamma, beta, stride=1, pad=1, eps=BN_EPS, act=True, stats_out=None):
+    return ConvBNAct.apply(x, weight, gamma, beta, stride, pad, eps, act, stats_out)
+
+
+# ------------------------------------------------------------------------------------------------ ConvTranspose(k = s) + BN + ReLU
+def _space_to_depth(t, s):
+    n, hs, ws, c = t.shape
+    if s == 1:
+        return t
+    return t.view(n, hs // s, s, ws // s, s, c).permute(0, 1, 3, 2, 4, 5).reshape(n, hs // s, ws // s, s * s * c)
+
+
+class DeconvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, eps, act, stats_out):
+        from .engine import ConvLayer
+        _check_dev(x)
+        x = x.contiguous()
+        r = _runner(x.device)
+        n, h, w, cin = x.shape
+        _, cout, s, _ = weight.shape
+        wp, ncol = pack_deconv_weight_dev(weight)
+        L = ConvLayer(wp, None, torch.zeros(cout, device=x.device), cin, cout, ncol, 1, 1, 0, 0, _lib.AV2X_DECONV, s)
+        z = torch.empty((n, h * s, w * s, cout), dtype=torch.float32, device=x.device)
+        r.conv(L, x, n, h, w, z)
+        mean, var, count = bn_stats(z)
+        rstd, scale, shift = _fold(mean, var, gamma, beta, eps)
+        y = affine_act(z, scale, shift, act)
+        if stats_out is not None:
+            stats_out.append((mean, var, count))
+        ctx.save_for_backward(x, weight, z, mean, rstd, scale, shift)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, mean, rstd, scale, shift = ctx.saved_tensors
+        cin, cout, s, _ = weight.shape
+        dz, dgamma, dbeta = bn_backward(dy.contiguous(), z, mean, rstd, scale, shift, ctx.act)
+        d2 = _space_to_depth(dz, s).contiguous()                                   # (n, h, w, s*s*cout), column = (i, j, co)
+        dw = dx = None
+        if ctx.needs_input_grad[1]:
+            g = conv_wgrad(x, d2, (s * s * cout, cin, 1, 1), 1, 0)                 # [(i, j, co)][ci]
+            dw = g.view(s, s, cout, cin).permute(3, 2, 0, 1).contiguous()
+        if ctx.needs_input_grad[0]:
+            wb = weight.detach().permute(0, 2, 3, 1).reshape(cin, s * s * cout, 1, 1)
+            dx = conv_raw(d2, wb, 1, 0)
+        return dx, dw, dgamma, dbeta, None, None, None
+
+
+def deconv_bn_act(x, weight, gamma, beta, eps=BN_EPS, act=True, stats_out=None):
+    return DeconvBNAct.apply(x, weight, gamma, beta, eps, act, stats_out)
+
+
+# ------------------------------------------------------------------------------------------------ Conv + bias (+ ReLU)
+class ConvBiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act):
+        _check_dev(x)
+        x = x.contiguous()
+        y = conv_raw(x, weight, stride, pad, None, bias.detach(), 1 if act else 0)
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (stride, pad, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, act = ctx.cfg
+        r = _runner(x.device)
+        dy = dy.contiguous()
+        cout = weight.shape[0]
+        rows = y.numel() // cout
+        if act:
+            dz = torch.empty_like(dy)
+            _lib.check(r.lib.av2x_act_backward(_P(y), _P(dy), None, rows, cout, 1, _P(dz), r.stream()), "av2x_act_backward")
+        else:
+            dz = dy
+        db = None
+        if ctx.needs_input_grad[2]:
+            ws = torch.empty(int(r.lib.av2x_channel_sum_workspace_bytes(rows, cout)) // 4 + 4, device=x.device)
+            db = torch.empty(cout, device=x.device)
+            _lib.check(r.lib.av2x_channel_sum(_P(dz), rows, cout, _P(ws), _P(db), r.stream()), "av2x_channel_sum")
+        dw = conv_wgrad(x, dz, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3]) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None, None, None
+
+
+def conv_bias_act(x, weight, bias, stride=1, pad=1, act=True):
+    return ConvBiasAct.apply(x, weight, bias, stride, pad, act)
+
+
+# ------------------------------------------------------------------------------------------------ mask, per-pixel attention
+class MaskMul(torch.autograd.Function):
+    """x (n, h, w, c) * mask (n, h, w): `x = x * communication_masks` (where2comm_fuse.py:236); the mask carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        _check_dev(x)
+        r = _runner(x.device)
+        y = x.contiguous().clone()
+        n, h, w, c = y.shape
+        _lib.check(r.lib.av2x_apply_mask(_P(y), _P(mask), n, h * w, c, r.stream()), "av2x_apply_mask")
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        r = _runner(dy.device)
+        dx = dy.contiguous().clone()
+        n, h, w, c = dx.shape
+        _lib.check(r.lib.av2x_apply_mask(_P(dx), _P(mask), n, h * w, c, r.stream()), "av2x_apply_mask")
+        return dx, None
+
+
+class PixelAttn(torch.autograd.Function):
+    """AttentionFusion of one sample (where2comm_fuse.py:152-164): x (k, h, w, c), agent 0 = ego -> (h, w, c)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _check_dev(x)
+        r = _runner(x.device)
+        x = x.contiguous()
+        k, h, w, c = x.shape
+        out = torch.empty((h, w, c), dtype=torch.float32, device=x.device)
+        arr = (c_void_p * k)(*[x[j].data_ptr() for j in range(k)])
+        _lib.check(r.lib.av2x_pixel_attn_fuse(arr, k, h * w, c, _P(out), r.stream()), "av2x_pixel_attn_fuse")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        r = _runner(x.device)
+        k, h, w, c = x.shape
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        arr = (c_void_p * k)(*[x[j].data_ptr() for j in range(k)])
+        darr = (c_void_p * k)(*[dx[j].data_ptr() for j in range(k)])
+        _lib.check(r.lib.av2x_pixel_attn_backward(arr, k, h * w, c, _P(dout), darr, r.stream()), "av2x_pixel_attn_backward")
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------ pillar encoders + scatter
+class PillarEncode(torch.autograd.Function):
+    """Every agent type's PillarVFE (train-mode BatchNorm1d) + PointPillarScatter into one canvas (n, ny, nx, 64).
+
+    ``groups``: list of dicts {vf (M,32,4) f32, vc (M,4) i32, vn (M,) i32, slots [canvas slot of the type's agent i], geom
+    (ctypes float[6])}; ``params`` = (linear.weight, norm.weight, norm.bias) per group, flattened.  ``stats_out`` receives one
+    (mean, biased var, count) per group."""
+
+    @staticmethod
+    def forward(ctx, groups, n_total, ny, nx, eps, stats_out, *params):
+        dev = groups[0]["vf"].device
+        r = _runner(dev)
+        lib, st = r.lib, r.stream()
+        canvas = torch.zeros((n_total, ny, nx, 64), dtype=torch.float32, device=dev)
+        saved = []
+        for gi, g in enumerate(groups):
+            W, gamma, beta = params[3 * gi:3 * gi + 3]
+            vf, vc, vn = g["vf"], g["vc"], g["vn"]
+            M = int(vf.shape[0])
+            ws = torch.empty(int(lib.av2x_pillar_train_workspace_bytes(M)) // 8 + 1, dtype=torch.float64, device=dev)
+            mom = torch.empty(110, dtype=torch.float64, device=dev)
+            geom = ctypes.cast(g["geom"], c_void_p)
+            _lib.check(lib.av2x_pillar_moments(_P(vf), _P(vc), _P(vn), M, geom, _P(ws), _P(mom), st), "av2x_pillar_moments")
+            N = 32.0 * M
+            S, F = mom[:10], mom[10:].view(10, 10)
+            Wd = W.detach().double()
+            mean64 = Wd @ S / N
+            var64 = ((Wd @ F) * Wd).sum(1) / N - mean64 * mean64
+            mean, var = mean64.float(), var64.clamp_min(0).float()
+            rstd, scale, shift = _fold(mean, var, gamma, beta, eps)
+            Wc = W.detach().contiguous()
+            sl = g["slots"]
+            contiguous = sl == list(range(sl[0], sl[0] + len(sl)))
+            smap = None if contiguous else torch.tensor(sl, dtype=torch.int32, device=dev)
+            _lib.check(lib.av2x_pillar_vfe_scatter(_P(vf), _P(vc), _P(vn), M, _P(Wc), _P(scale), _P(shift), geom, _P(canvas), sl[0],
+                                                   _P(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter")
+            if stats_out is not None:
+                stats_out.append((mean, var, int(N)))
+            saved.append((S, F, mean64, rstd, scale, shift, smap, Wc))
+        ctx.groups, ctx.saved, ctx.dims = groups, saved, (ny, nx)
+        ctx.params = params
+        return canvas
+
+    @staticmethod
+    def backward(ctx, dcanvas):
+        dev = dcanvas.device
+        r = _runner(dev)
+        lib, st = r.lib, r.stream()
+        dcanvas = dcanvas.contiguous()
+        ny, nx = ctx.dims
+        grads = []
+        for gi, g in enumerate(ctx.groups):
+            S, F, mean64, rstd, scale, shift, smap, Wc = ctx.saved[gi]
+            vf, vc, vn = g["vf"], g["vc"], g["vn"]
+            M = int(vf.shape[0])
+            N = 32.0 * M
+            ws = torch.empty(int(lib.av2x_pillar_train_workspace_bytes(M)) // 8 + 1, dtype=torch.float64, device=dev)
+            out = torch.empty((64, 12), dtype=torch.float64, device=dev)
+            mean = mean64.float()
+            sl = g["slots"]
+            _lib.check(lib.av2x_pillar_vfe_backward(_P(vf), _P(vc), _P(vn), M, _P(Wc), _P(scale), _P(shift), _P(mean), _P(rstd),
+                                                    ctypes.cast(g["geom"], c_void_p), _P(dcanvas), sl[0], _P(smap), len(sl), ny, nx,
+                                                    _P(ws), _P(out), st), "av2x_pillar_vfe_backward")
+            G, dbeta, dgamma = out[:, :10], out[:, 10], out[:, 11]
+            Wd = Wc.double()
+            # d lin_r = scale (g_r - d beta / N - xhat_r d gamma / N);  dW = sum_r d lin_r (x) feat_r, with
+            # sum_r xhat_r (x) feat_r = rstd (W F - mean S^T)
+            xf = rstd.double().unsqueeze(1) * (Wd @ F - mean64.unsqueeze(1) * S.unsqueeze(0))
+            dW = scale.double().unsqueeze(1) * (G - (dbeta / N).unsqueeze(1) * S.unsqueeze(0) - (dgamma / N).unsqueeze(1) * xf)
+            grads += [dW.float(), dgamma.float(), dbeta.float()]
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def pillar_encode(groups, n_total, ny, nx, params, eps=BN_EPS, stats_out=None):
+    return PillarEncode.apply(groups, n_total, ny, nx, eps, stats_out, *params)

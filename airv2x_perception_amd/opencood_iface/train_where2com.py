@@ -1,0 +1,184 @@
+"""Train-mode forward of ``Airv2xWhere2com`` (models/airv2x_where2com.py:117-179 with ``self.training``): the graph the
+reference hands to torch autograd (tools/train.py:220-247), built from the HIP forward / backward ops of ``train_ops``.
+
+As-written schedule of the reference, kept:
+  * the backbone runs twice on the scattered canvas (:119, :124) and its blocks a third time inside the fusion
+    (where2comm_fuse.py:218).  Both full passes see the same input, so they are computed ONCE here and every BatchNorm's
+    running statistics are updated twice with the same batch statistics; blocks[0] of the fusion pass sees that input a
+    third time (third identical update), blocks[1..2] see the MASKED maps of all agents (ego included) and the deblocks the
+    fused maps: fresh batch statistics, one more update each -- ``num_batches_tracked`` advances by 3 per step;
+  * the single-agent ``psm`` only drives the communication mask (random top-K in train mode, where2comm_fuse.py:104-121:
+    K = int(H * W * random.uniform(0, 1)) from python's ``random``, one draw per sample, as the reference draws it), so
+    no gradient flows through the two full passes: they run under ``no_grad``;
+  * the loss sees the heads on the fused map only.
+"""
+from __future__ import annotations
+
+import random
+from ctypes import c_float
+
+import torch
+
+from .. import _lib
+from . import train_ops as T
+from .autograd import _P, _runner
+from .engine import AGENT_TYPES, frame_layout
+
+TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_models"}
+
+
+def _bn_update(sd, prefix, stats, times):
+    T.update_running_stats(sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd.get(prefix + ".num_batches_tracked"), stats, times)
+
+
+def _block(P, sd, i, x, n_layers, stride, times, record=True):
+    """backbone.blocks[i] (base_bev_backbone.py:41-70) in train mode; BatchNorm running statistics updated ``times`` times."""
+    idx = 1
+    for li in range(n_layers + 1):
+        st = []
+        x = T.conv_bn_act(x, P[f"backbone.blocks.{i}.{idx}.weight"], P[f"backbone.blocks.{i}.{idx + 1}.weight"],
+                          P[f"backbone.blocks.{i}.{idx + 1}.bias"], stride if li == 0 else 1, 1, stats_out=st)
+        if record:
+            _bn_update(sd, f"backbone.blocks.{i}.{idx + 1}", st[0], times)
+        idx += 3
+    return x
+
+
+def _deblock(P, sd, i, x, times):
+    st = []
+    y = T.deconv_bn_act(x, P[f"backbone.deblocks.{i}.0.weight"], P[f"backbone.deblocks.{i}.1.weight"], P[f"backbone.deblocks.{i}.1.bias"],
+                        stats_out=st)
+    _bn_update(sd, f"backbone.deblocks.{i}.1", st[0], times)
+    return y
+
+
+def _shrink(P, cfg, x):
+    if not cfg.get("use", True):
+        return x
+    for li, (k, pd) in enumerate(zip(cfg["kernal_size"], cfg["padding"])):
+        p = f"shrink_conv.layers.{li}.double_conv"
+        x = T.conv_bias_act(x, P[p + ".0.weight"], P[p + ".0.bias"], 1, pd, True)
+        x = T.conv_bias_act(x, P[p + ".2.weight"], P[p + ".2.bias"], 1, 1, True)
+    return x
+
+
+def _heads(P, names, x):
+    """The 1x1 heads as ONE convolution padded to a multiple of 32 output channels; returns the NCHW maps."""
+    w = torch.cat([P[n + ".weight"] for n in names], 0)
+    b = torch.cat([P[n + ".bias"] for n in names], 0)
+    tot = w.shape[0]
+    padc = (tot + 31) // 32 * 32 - tot
+    if padc:
+        w = torch.cat([w, w.new_zeros((padc,) + tuple(w.shape[1:]))], 0)
+        b = torch.cat([b, b.new_zeros(padc)], 0)
+    y = T.conv_bias_act(x, w, b, 1, 0, False)                       # (B, H, W, 32)
+    outs, o = [], 0
+    for n in names:
+        c = P[n + ".weight"].shape[0]
+        outs.append(y[..., o:o + c].permute(0, 3, 1, 2).contiguous())
+        o += c
+    return outs
+
+
+def forward_train(model, data_dict, topk=None, mask=None, trace=None):
+    """-> output dict of the reference (psm / rm / obj require grad).  ``topk``: one K per sample instead of the random draw;
+    ``mask`` (n, H, W): replay a recorded communication mask instead of the one computed here (the top-K cut is discontinuous
+    in the single-agent logits; parity tests replay the reference's); ``trace``: dict that receives the computed mask."""
+    args = model.args
+    P = dict(model.named_parameters())
+    sd = model.state_dict(keep_vars=True)
+    dev = next(iter(P.values())).device
+    if dev.type != "cuda":
+        raise RuntimeError("Airv2xWhere2com (MI355X build) has no CPU path: move the module to the GPU (model.to('cuda'))")
+    if not model.multi_scale:
+        raise NotImplementedError("training: the multi-scale fusion (every shipped AirV2X Where2Comm config)")
+    r = _runner(dev)
+    mf = args["modality_fusion"]
+    bb = mf["base_bev_backbone"]
+    fcfg = args["where2com_fusion"]
+    record_len, slots = frame_layout(args["collaborators"], data_dict)
+    B, n = len(record_len), sum(record_len)
+    if n == 0:
+        raise ValueError("empty frame: no agent has lidar input")
+
+    # ---- encoders: PillarVFE (BatchNorm1d batch statistics per agent type) + scatter
+    groups, params, prefixes = [], [], []
+    ny = nx = None
+    for t in AGENT_TYPES:
+        if t not in slots:
+            continue
+        lid = data_dict[t]["batch_merged_lidar_features_torch"]
+        cfg = args[t]["lidar"]
+        vs, rng = cfg["voxel_size"], cfg["lidar_range"]
+        g = [int(v) for v in cfg["point_pillar_scatter"]["grid_size"]]
+        nx, ny = g[0], g[1]
+        geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
+        groups.append({"vf": lid["voxel_features"].to(dev).contiguous().float(), "vc": lid["voxel_coords"].to(dev).contiguous().to(torch.int32),
+                       "vn": lid["voxel_num_points"].to(dev).contiguous().to(torch.int32), "slots": slots[t], "geom": geom})
+        p = f"{TYPE_PREFIX[t]}.0.0.pfn_layers.0"
+        params += [P[p + ".linear.weight"], P[p + ".norm.weight"], P[p + ".norm.bias"]]
+        prefixes.append(p + ".norm")
+    st = []
+    canvas = T.pillar_encode(groups, n, ny, nx, params, stats_out=st)
+    for p, s in zip(prefixes, st):
+        _bn_update(sd, p, s, 1)
+    nz = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(r.lib.av2x_count_nonzero(_P(canvas), canvas.numel(), _P(nz), r.stream()), "av2x_count_nonzero")
+
+    layer_nums, strides, ups = bb["layer_nums"], bb["layer_strides"], bb["upsample_strides"]
+    # ---- blocks[0] once, with the graph (the fusion pass's blocks[0] sees the same canvas): three identical updates
+    y0 = _block(P, sd, 0, canvas, layer_nums[0], strides[0], 3)
+    # ---- the two full backbone passes + shrink + cls_head: mask only, no gradient
+    with torch.no_grad():
+        feats = [y0.detach()]
+        for i in (1, 2):
+            feats.append(_block(P, sd, i, feats[-1], layer_nums[i], strides[i], 2))
+        cat = torch.cat([_deblock(P, sd, i, feats[i], 2) for i in range(3)], -1)
+        s = _shrink(P, mf["shrink_header"], cat)
+        psm_single = T.conv_raw(s, P["cls_head.weight"], 1, 0, None, P["cls_head.bias"].detach(), 0)      # (n, H, W, A*C)
+        H, W = psm_single.shape[1:3]
+        if fcfg["fully"]:
+            mask, com = None, torch.tensor(1, device=dev)
+        else:
+            if tuple(y0.shape[1:3]) != (H, W):
+                raise NotImplementedError("mask/feature size mismatch (where2comm_fuse.py:230) is never taken by AirV2X configs")
+            if topk is None:
+                topk = [int(H * W * random.uniform(0, 1)) for _ in range(B)]      # where2comm_fuse.py:106, one draw per sample
+            r.A, r.C = args["anchor_number"], args["num_class"]
+            comm = fcfg["communication"]
+            if "gaussian_smooth" in comm:
+                gw = P["fusion_net.naive_communication.gaussian_filter.weight"].detach()
+                r.gauss_w, r.gauss_b, r.gauss_k = gw.reshape(-1).contiguous(), P["fusion_net.naive_communication.gaussian_filter.bias"].detach(), int(gw.shape[-1])
+            else:
+                r.gauss_w, r.gauss_b, r.gauss_k = torch.ones(1, device=dev), torch.zeros(1, device=dev), 1
+            r.threshold = float(comm["threshold"] or 0.0)
+            r._frame += 1
+            cmask, count, _, rl = r.comm_mask(psm_single, n, H, W, record_len, topk=topk)
+            if trace is not None:
+                trace["comm_mask"] = cmask.clone()
+                trace["psm_single"] = psm_single
+            mask = cmask.clone() if mask is None else mask.to(dev, torch.float32).reshape(n, H, W).contiguous()
+            com = r.comm_rate(count, rl, B, H * W)
+
+    # ---- fusion pass with the graph
+    def fuse(x):
+        outs, a0 = [], 0
+        for k in record_len:
+            outs.append(T.PixelAttn.apply(x[a0:a0 + k]))
+            a0 += k
+        return torch.stack(outs)
+
+    x = T.MaskMul.apply(y0, mask) if mask is not None else y0
+    ups_out = [_deblock(P, sd, 0, fuse(x), 1)]
+    for i in (1, 2):
+        x = _block(P, sd, i, x, layer_nums[i], strides[i], 1)
+        ups_out.append(_deblock(P, sd, i, fuse(x), 1))
+    fused = torch.cat(ups_out, -1)
+    fs = _shrink(P, mf["shrink_header"], fused)
+    names = ["cls_head", "reg_head"] + (["obj_head"] if args["obj_head"] else [])
+    outs = _heads(P, names, fs)
+    out = {"psm": outs[0], "rm": outs[1]}
+    if args["obj_head"]:
+        out["obj"] = outs[2]
+    out.update({"mask": 0, "com": com, "comm_rate": int(nz[0].item()) if model.sync_comm_rate else nz[0]})
+    return out

@@ -299,6 +299,45 @@ uint64_t av2x_channel_sum_workspace_bytes(int64_t rows, int32_t c);
 int av2x_channel_sum(const float* x, int64_t rows, int32_t c, void* workspace, float* out, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Train-mode forward / backward pieces of the Where2Comm path (the reference trains through torch autograd,
+ * tools/train.py:220-247).  Deterministic: fixed-order fp64 partial sums in `workspace`, no floating-point atomics.
+ *   av2x_bn_stats            batch mean / BIASED variance per channel of an NHWC map z (rows x c): nn.BatchNorm2d / 1d in
+ *                            train mode (base_bev_backbone.py:52,65,83; airv2x_pillar_vfe.py:21).  workspace:
+ *                            av2x_bn_workspace_bytes(rows, c)
+ *   av2x_affine_act          y = act(z * scale[c] + shift[c]) (act 0 identity / 1 ReLU; scale / shift may be NULL); y may be z
+ *   av2x_bn_backward         for y = act(z * scale + shift), scale = gamma * rstd, shift = beta - mean * scale:
+ *                            dgamma[c] = sum g xhat, dbeta[c] = sum g, dz = scale (g - dbeta / rows - xhat dgamma / rows)
+ *                            with g = dy * act'(.), xhat = (z - mean) rstd.  dz may alias dy
+ *   av2x_pixel_attn_backward gradient of av2x_pixel_attn_fuse (AttentionFusion, where2comm_fuse.py:152-164) w.r.t. every
+ *                            agent map: agents / dagents are HOST arrays of n_agents DEVICE pointers to (hw, c) maps
+ *   av2x_pillar_moments      moments[0..9] = sum of the augmented 10-vectors over all 32 rows of all pillars (padded rows
+ *                            are zero), moments[10..109] = sum of their outer products (fp64): BatchNorm1d's batch
+ *                            statistics of PFNLayer (airv2x_pillar_vfe.py:27-49) follow as mean = W S / N,
+ *                            E[lin^2] = diag(W F W^T) / N with N = 32 n_pillars
+ *   av2x_pillar_vfe_backward PointPillarScatter + max-over-points + ReLU backward: gathers dcanvas (n, ny, nx, 64) at every
+ *                            pillar, routes it to the arg-max row of every channel; out[c][0..9] = sum g feat,
+ *                            out[c][10] = sum g (d beta), out[c][11] = sum g xhat (d gamma), fp64 (64 x 12)
+ *                            workspace for both pillar calls: av2x_pillar_train_workspace_bytes(n_pillars)
+ * ------------------------------------------------------------------------------------ */
+uint64_t av2x_bn_workspace_bytes(int64_t rows, int32_t c);
+int av2x_bn_stats(const float* z, int64_t rows, int32_t c, void* workspace, float* mean, float* var, av2x_stream_t stream);
+int av2x_affine_act(const float* z, int64_t rows, int32_t c, const float* scale, const float* shift, int32_t act, float* y,
+                    av2x_stream_t stream);
+int av2x_bn_backward(const float* dy, const float* z, int64_t rows, int32_t c, const float* mean, const float* rstd,
+                     const float* scale, const float* shift, int32_t act, void* workspace, float* dgamma, float* dbeta,
+                     float* dz, av2x_stream_t stream);
+int av2x_pixel_attn_backward(const float* const* agents, int32_t n_agents, int32_t hw, int32_t c, const float* dout,
+                             float* const* dagents, av2x_stream_t stream);
+uint64_t av2x_pillar_train_workspace_bytes(int32_t n_pillars);
+int av2x_pillar_moments(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                        int32_t n_pillars, const float* geom, void* workspace, double* moments, av2x_stream_t stream);
+int av2x_pillar_vfe_backward(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                             int32_t n_pillars, const float* pfn_w, const float* bn_scale, const float* bn_shift,
+                             const float* mean, const float* rstd, const float* geom, const float* dcanvas,
+                             int32_t canvas_agent0, const int32_t* slot_map, int32_t n_agents_type, int32_t ny, int32_t nx,
+                             void* workspace, double* out, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Training labels: VoxelPostprocessor.generate_label_airv2x (voxel_postprocessor.py:217-354) with
  * bbox_overlaps (utils/box_overlaps.pyx:17-57) -- the anchor <-> ground-truth assignment, without the IoU matrix.
  *   anchor_standup (n_anchors,4) / gt_standup (n_gt,4) f32: [xmin,ymin,xmax,ymax] of corner2d_to_standup_box (:266-270);

@@ -25,8 +25,31 @@ TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_mod
 BN_EPS = 1e-3  # every BatchNorm on the path: airv2x_pillar_vfe.py:21, base_bev_backbone.py:52,65,83
 
 
+BN_MOMENTUM = 0.01  # same lines
+_STATE = {"train": False}
+
+
+class train_mode:
+    """``with train_mode():`` -- every BatchNorm below uses batch statistics and updates the running statistics of the
+    ``state_dict`` it reads IN PLACE (momentum 0.01, ``num_batches_tracked`` += 1), as nn.BatchNorm does under ``.train()``;
+    the functions are plain differentiable torch ops, so ``torch.autograd`` of them is the checker of the HIP backward."""
+
+    def __enter__(self):
+        self.prev = _STATE["train"]
+        _STATE["train"] = True
+
+    def __exit__(self, *a):
+        _STATE["train"] = self.prev
+
+
 def _bn(x, sd, prefix):
-    """BatchNorm in eval mode (running statistics)."""
+    """BatchNorm: eval mode (running statistics) unless inside ``train_mode()``."""
+    if _STATE["train"]:
+        nbt = sd.get(prefix + ".num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                            sd[prefix + ".weight"], sd[prefix + ".bias"], True, BN_MOMENTUM, BN_EPS)
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
                         sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.0, BN_EPS)
 
@@ -212,7 +235,7 @@ def _split(x, record_len):
 
 
 # ---------------------------------------------------------------- a10: Where2comm multi-scale fusion
-def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None):
+def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None, topk=None):
     """where2comm_fuse.py:198-263 (multi_scale, not fully connected).
     x (sumN,64,H,W) canvas features; returns (fused (B,384,H/2,W/2), rate)."""
     bb = args["modality_fusion"]["base_bev_backbone"]
@@ -225,7 +248,7 @@ def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None):
             if fcfg["fully"]:
                 rate = torch.tensor(1)
             else:
-                masks, rate, maps = communication(_split(psm_single, record_len), sd, fcfg["communication"])
+                masks, rate, maps = communication(_split(psm_single, record_len), sd, fcfg["communication"], topk)
                 if x.shape[-1] != masks.shape[-1]:
                     masks = F.interpolate(masks, size=(x.shape[-2], x.shape[-1]), mode="bilinear",
                                           align_corners=False)
@@ -242,12 +265,13 @@ def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None):
 
 
 # ---------------------------------------------------------------- full forward
-def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False):
+def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False, topk=None):
     """models/airv2x_where2com.py:117-179 (det task, multi_scale, compression 0).
 
     The reference evaluates the backbone twice before the fusion (:119, :124); in
     eval mode both passes give identical tensors, so the oracle runs it once
-    unless ``reference_schedule`` is set (used only to time the as-written cost).
+    unless ``reference_schedule`` is set (to time the as-written cost; and REQUIRED inside ``train_mode()``, where every
+    pass updates the running statistics).  ``topk``: the training branch of the communication mask, one K per sample.
     The debug PNG (:137-139) has no effect on outputs and is dropped.
     """
     mf = args["modality_fusion"]
@@ -258,7 +282,7 @@ def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False)
     comm_rate = int(feats.count_nonzero().item())  # :122
     s = shrink_conv(sf2d, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else sf2d
     psm_single = head(s, sd, "cls_head")  # :145
-    fused, rate = where2comm_fuse(feats, psm_single, record_len, sd, args, trace)  # :153-159
+    fused, rate = where2comm_fuse(feats, psm_single, record_len, sd, args, trace, topk)  # :153-159
     fs = shrink_conv(fused, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else fused
     out = {"psm": head(fs, sd, "cls_head"), "rm": head(fs, sd, "reg_head")}
     if args["obj_head"]:

@@ -49,3 +49,23 @@ def assert_close(a, b, rtol, atol, what=""):
     tol = atol + rtol * np.abs(b)
     bad = err > tol
     assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.size} out of tol; max err {err.max():.3e} at |ref| {np.abs(b).flat[err.argmax()]:.3e}"
+
+
+def train_case_from_fixture(fx):
+    """-> (hypes, args, state_dict, data_dict, loss targets) of a ``train_*`` fixture (tools/gen_golden.py:train_golden)."""
+    rng = [float(v) for v in fx["lidar_range"]]
+    types = [str(t) for t in fx["types"]]
+    hy = synth.default_hypes(rng)
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=int(fx["seed"]))
+    pp = hy["preprocess"]
+    voxd = []
+    for i, _ in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, int(fx["n_points"]), rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_train"]))
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    H, W = fx["psm"].shape[-2:]
+    lc = synth.loss_case(int(fx["seed"]) + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=float(fx["pos_frac"]))
+    tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    return hy, args, sd, dd, tgt

@@ -1094,6 +1094,102 @@ def comm_train_golden(name="comm_train"):
     print(f"[{name}] wrote {path}")
 
 
+def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01):
+    """One TRAINING step of the reference's Airv2xWhere2com (train mode: BatchNorm batch statistics + running-stat updates,
+    random top-K communication mask from python's seeded `random`) + PointPillarLossMultiClass + torch autograd:
+    head maps, losses, the gradient of every parameter (strided samples + fp64 sums) and every buffer after the step.
+    oracle/where2comm_oracle.py under train_mode() + loss_oracle.pp_loss must reproduce all of it."""
+    import random
+
+    from airv2x_perception_amd import synth
+    from oracle import loss_oracle as lo
+    from oracle import voxelize_oracle as vox
+    from oracle import where2comm_oracle as orc
+    from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
+    from opencood.models.airv2x_where2com import Airv2xWhere2com
+
+    hy_ref = load_ref_hypes(lidar_range)
+    hy = synth.default_hypes(lidar_range)
+    args = hy["model"]["args"]
+    model = Airv2xWhere2com(hy_ref["model"]["args"]).train()
+    spec = synth.where2com_param_spec(args)
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), hy["preprocess"]["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, hy["preprocess"]["cav_lidar_range"], hy["preprocess"]["args"]["voxel_size"],
+                                         hy["preprocess"]["args"]["max_points_per_voxel"], hy["preprocess"]["args"]["max_voxel_train"]))
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    cap = {}
+    h = model.fusion_net.naive_communication.register_forward_hook(lambda m, i, o: cap.setdefault("comm", o))
+    os.makedirs("debug", exist_ok=True)
+    random.seed(rseed)
+    out = model(dd)
+    h.remove()
+    H, W = out["psm"].shape[-2:]
+    random.seed(rseed)
+    K = [int(H * W * random.uniform(0, 1))]
+    lc = synth.loss_case(seed + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=pos_frac)
+    tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    crit = PointPillarLossMultiClass(hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"])
+    total = crit(out, tgt)
+    total.backward()
+
+    # ---- oracle: same step on a copy of the state dict
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for k, v in sd2.items():
+        if v.is_floating_point() and k in dict(model.named_parameters()):
+            v.requires_grad_(True)
+    with orc.train_mode():
+        o = orc.where2com_forward(dd, sd2, args, reference_schedule=True, topk=K)
+    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
+    mine = lo.pp_loss(o["psm"], o["rm"], o["obj"], tgt["targets"], tgt["pos_equal_one"], tgt["class_ids"], la["num_class"],
+                      la["cls_weight"], la["reg"])
+    mine[0].backward()
+    worst = 0.0
+    for k in ("psm", "rm", "obj"):
+        worst = max(worst, (o[k] - out[k]).abs().max().item())
+    assert worst < 1e-5, worst
+    assert abs(float(mine[0]) - float(total)) < 1e-6 * max(1.0, abs(float(total))), (float(mine[0]), float(total))
+    fx = {"seed": np.int64(seed), "rseed": np.int64(rseed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types),
+          "n_points": np.int64(n_points), "pos_frac": np.float64(pos_frac), "K": np.asarray(K, np.int64),
+          "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64),
+          "mask": np.packbits(cap["comm"][0].detach().numpy().astype(np.uint8).reshape(-1)),
+          "mask_shape": np.asarray(cap["comm"][0].shape, np.int64), "com": np.float64(float(out["com"])),
+          "comm_rate": np.int64(out["comm_rate"])}
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k].detach().numpy()
+    gworst = 0.0
+    names = []
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            assert sd2[k].grad is None or float(sd2[k].grad.abs().max()) == 0.0, k
+            continue
+        g = p_.grad.detach().reshape(-1)
+        go = sd2[k].grad.reshape(-1)
+        rel = (g - go).abs().max().item() / max(g.abs().max().item(), 1e-12)
+        gworst = max(gworst, rel)
+        stride = max(1, g.numel() // 4096)
+        names.append(k)
+        fx["g:" + k] = g[::stride].numpy()
+        fx["gsum:" + k] = np.asarray([g.double().sum().item(), g.double().abs().sum().item(), g.abs().max().item()], np.float64)
+    assert gworst < 1e-3, gworst
+    fx["grad_keys"] = np.asarray(names)
+    bworst = 0.0
+    for k, b in model.named_buffers():
+        fx["b:" + k] = b.detach().numpy()
+        d = (b.double() - sd2[k].detach().double()).abs().max().item()
+        bworst = max(bworst, d / max(1.0, b.double().abs().max().item()))
+    assert bworst < 1e-5, bworst
+    print(f"[{name}] K {K} total {float(total):.6f} reg {crit.loss_dict['reg_loss']:.6f} conf {crit.loss_dict['conf_loss']:.6f}; "
+          f"oracle vs reference: heads {worst:.2e}, grads (rel to max) {gworst:.2e}, buffers {bworst:.2e}; {len(names)} gradients")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _bev_quads(boxes):
     """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,4,2) float32 BEV corners (counter-clockwise)."""
     x, y, dx, dy, h = boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]
@@ -1239,6 +1335,8 @@ GROUPS = {
     "labels": lambda: (labels_golden("labels_small", SMALL, 12, 41), labels_golden("labels_full", None, 60, 42),
                        labels_golden("labels_full_one", None, 1, 43)),
     "comm_train": lambda: comm_train_golden(),
+    "train": lambda: (train_golden("train_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 11, 3),
+                      train_golden("train_small_n2", SMALL, ["vehicle", "vehicle"], 900, 12, 4)),
     "iou_pin": lambda: iou_pin_golden(),
     "voxel_pin": lambda: voxel_pin_golden(),
 }
