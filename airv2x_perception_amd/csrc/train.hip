@@ -17,46 +17,64 @@
 
 namespace {
 
-constexpr int kSlabRows = 512;
+constexpr int kSlabRows = 128;
 
 // ---------------------------------------------------------------------------------------------------- per-channel moments
 // part layout: [slab][2][c] doubles.  MODE 0: (sum z, sum z^2).  MODE 1: (sum g, sum g * xhat) with
 // g = dy * [act ? z * scale + shift > 0 : 1], xhat = (z - mean) * rstd.
+// HBM-bound: one pass over z (and dy).  c = 4 * 2^k: a thread owns 4 channels (16-byte loads) of every (256 / (c/4))-th row of
+// its 128-row slab -- <= 32 fp32 terms per partial, then fp64 across the row lanes, the slabs (stage 2) in a fixed order.
 template <int MODE>
 __global__ __launch_bounds__(256) void moments_stage1(const float* __restrict__ z, const float* __restrict__ dy, size_t rows,
                                                       int c, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                       double* __restrict__ part) {
-    __shared__ double red[2][256];
+    __shared__ float4 red[2][256];
     const size_t r0 = (size_t)blockIdx.x * kSlabRows, r1 = r0 + kSlabRows < rows ? r0 + kSlabRows : rows;
     const int tid = threadIdx.x;
     double* out = part + (size_t)blockIdx.x * 2 * c;
-    if (c <= 256 && 256 % c == 0) {
-        // thread = (row lane, channel): coalesced c-float runs, fp32 partials of <= 512 * c / 256 values, then fp64
-        const int ch = tid % c, rl = tid / c, rstep = 256 / c;
-        float a = 0.f, b = 0.f;
-        float mu = 0.f, rs = 0.f, sc = 0.f, sh = 0.f;
-        if (MODE == 1) { mu = mean[ch]; rs = rstd[ch]; sc = scale[ch]; sh = shift[ch]; }
+    const int c4 = c >> 2;
+    if ((c & 3) == 0 && c4 <= 256 && 256 % c4 == 0) {
+        const int q = tid % c4, rl = tid / c4, rstep = 256 / c4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        float4 mu = a, rs = a, sc = a, sh = a;
+        if (MODE == 1) {
+            mu = reinterpret_cast<const float4*>(mean)[q]; rs = reinterpret_cast<const float4*>(rstd)[q];
+            sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
+        }
+        const float4* z4 = reinterpret_cast<const float4*>(z);
+        const float4* d4 = reinterpret_cast<const float4*>(dy);
+#pragma unroll 4
         for (size_t r = r0 + rl; r < r1; r += rstep) {
-            const float v = z[r * c + ch];
+            const float4 v = z4[r * c4 + q];
             if (MODE == 0) {
-                a += v;
-                b = fmaf(v, v, b);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                b.x = fmaf(v.x, v.x, b.x); b.y = fmaf(v.y, v.y, b.y); b.z = fmaf(v.z, v.z, b.z); b.w = fmaf(v.w, v.w, b.w);
             } else {
-                float g = dy[r * c + ch];
-                if (act && !(fmaf(v, sc, sh) > 0.f)) g = 0.f;
-                a += g;
-                b = fmaf(g, (v - mu) * rs, b);
+                float4 g = d4[r * c4 + q];
+                if (act) {
+                    if (!(fmaf(v.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
+                    if (!(fmaf(v.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
+                    if (!(fmaf(v.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
+                    if (!(fmaf(v.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+                }
+                a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+                b.x = fmaf(g.x, (v.x - mu.x) * rs.x, b.x); b.y = fmaf(g.y, (v.y - mu.y) * rs.y, b.y);
+                b.z = fmaf(g.z, (v.z - mu.z) * rs.z, b.z); b.w = fmaf(g.w, (v.w - mu.w) * rs.w, b.w);
             }
         }
-        red[0][tid] = (double)a;
-        red[1][tid] = (double)b;
+        red[0][tid] = a;
+        red[1][tid] = b;
         __syncthreads();
-        if (tid < c) {
-            double sa = 0.0, sb = 0.0;
-            for (int k = 0; k < rstep; ++k) { sa += red[0][k * c + tid]; sb += red[1][k * c + tid]; }
-            out[tid] = sa;
-            out[c + tid] = sb;
+        if (tid < c4) {
+            double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = 0; k < rstep; ++k) {
+                const float4 x = red[0][k * c4 + tid], y = red[1][k * c4 + tid];
+                sa[0] += x.x; sa[1] += x.y; sa[2] += x.z; sa[3] += x.w;
+                sb[0] += y.x; sb[1] += y.y; sb[2] += y.z; sb[3] += y.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { out[4 * tid + e] = sa[e]; out[c + 4 * tid + e] = sb[e]; }
         }
     } else {
         for (int ch = tid; ch < c; ch += 256) {
@@ -81,16 +99,28 @@ __global__ __launch_bounds__(256) void moments_stage1(const float* __restrict__ 
     }
 }
 
-// MODE 0: out0 = mean, out1 = biased variance.  MODE 1: out0 = sum g (d beta), out1 = sum g xhat (d gamma).
+// Sums the slab partials: a workgroup owns 8 channels, 32 lanes walk the slabs (lane l takes slabs l, l + 32, ...), then the 32
+// lane sums are added in lane order -- fixed order, fp64.  MODE 0: out0 = mean, out1 = biased variance.  MODE 1: out0 = sum g
+// (d beta), out1 = sum g xhat (d gamma).
 template <int MODE>
 __global__ __launch_bounds__(256) void moments_stage2(const double* __restrict__ part, int nslabs, int c, double n,
                                                       float* __restrict__ out0, float* __restrict__ out1) {
-    for (int ch = blockIdx.x * 256 + threadIdx.x; ch < c; ch += gridDim.x * 256) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < nslabs; ++k) {
+    __shared__ double red[2][32][8];
+    const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int ch = blockIdx.x * 8 + j;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        for (int k = sl; k < nslabs; k += 32) {
             a += part[(size_t)k * 2 * c + ch];
             b += part[(size_t)k * 2 * c + c + ch];
         }
+    }
+    red[0][sl][j] = a;
+    red[1][sl][j] = b;
+    __syncthreads();
+    if (sl == 0 && ch < c) {
+        a = 0.0; b = 0.0;
+        for (int k = 0; k < 32; ++k) { a += red[0][k][j]; b += red[1][k][j]; }
         if (MODE == 0) {
             const double m = a / n;
             double v = b / n - m * m;
@@ -101,6 +131,34 @@ __global__ __launch_bounds__(256) void moments_stage2(const double* __restrict__
             out0[ch] = (float)a;
             out1[ch] = (float)b;
         }
+    }
+}
+
+// One launch per BatchNorm layer for everything torch would do with ~12 tiny kernels: rstd = 1 / sqrt(var + eps),
+// scale = gamma * rstd, shift = beta - mean * scale, and nn.BatchNorm's train-mode side effect applied `times` times with
+// the same batch statistics: running = (1 - momentum) * running + momentum * (mean | var * n / (n - 1)).
+__global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, int c, float eps, double count, float momentum, int times,
+                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch == 0 && nbt) nbt[0] += times;
+    if (ch >= c) return;
+    const float m = mean[ch], v = var[ch];
+    const float r = 1.0f / sqrtf(v + eps);
+    const float sc = gamma[ch] * r;
+    rstd[ch] = r;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - m * sc;
+    if (running_mean && running_var) {
+        const float unb = (float)((double)v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        float rm = running_mean[ch], rv = running_var[ch];
+        for (int t = 0; t < times; ++t) {
+            rm = rm * (1.0f - momentum) + momentum * m;
+            rv = rv * (1.0f - momentum) + momentum * unb;
+        }
+        running_mean[ch] = rm;
+        running_var[ch] = rv;
     }
 }
 
@@ -260,10 +318,19 @@ __global__ __launch_bounds__(256) void pillar_moments_kernel(const float4* __res
     for (int k = threadIdx.x; k < kMom; k += 256) part[(size_t)blockIdx.x * kMom + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
 }
 
+// out[k] = sum over the parts of part[b][k]: 8 columns per workgroup, 32 lanes walk the parts, lane sums added in lane order
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int nparts, int width, double* __restrict__ out) {
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < width; k += gridDim.x * 256) {
-        double s = 0.0;
-        for (int b = 0; b < nparts; ++b) s += part[(size_t)b * width + k];
+    __shared__ double red[32][8];
+    const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int k = blockIdx.x * 8 + j;
+    double s = 0.0;
+    if (k < width)
+        for (int b = sl; b < nparts; b += 32) s += part[(size_t)b * width + k];
+    red[sl][j] = s;
+    __syncthreads();
+    if (sl == 0 && k < width) {
+        s = 0.0;
+        for (int b = 0; b < 32; ++b) s += red[b][j];
         out[k] = s;
     }
 }
@@ -373,8 +440,20 @@ extern "C" int av2x_bn_stats(const float* z, int64_t rows, int32_t c, void* work
     double* part = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(moments_stage1<0>, dim3(slabs), dim3(256), 0, st, z, (const float*)nullptr, (size_t)rows, c, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, part);
-    hipLaunchKernelGGL(moments_stage2<0>, dim3((c + 255) / 256), dim3(256), 0, st, part, slabs, c, (double)rows, mean, var);
+    hipLaunchKernelGGL(moments_stage2<0>, dim3((c + 7) / 8), dim3(256), 0, st, part, slabs, c, (double)rows, mean, var);
     return av2x::check_launch("bn_stats kernels");
+}
+
+extern "C" int av2x_bn_finalize(const float* mean, const float* var, const float* gamma, const float* beta, int32_t c, float eps,
+                                int64_t count, float momentum, int32_t times, float* rstd, float* scale, float* shift,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, av2x_stream_t stream) {
+    if (!mean || !var || !gamma || !beta || !rstd || !scale || !shift) return av2x::fail("av2x_bn_finalize: null argument");
+    if (c <= 0 || count <= 0 || times < 0) return av2x::fail("av2x_bn_finalize: bad sizes");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return av2x::fail("av2x_bn_finalize: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, av2x::as_stream(stream), mean, var, gamma, beta, c, eps,
+                       (double)count, momentum, times, rstd, scale, shift, running_mean, running_var,
+                       reinterpret_cast<long long*>(num_batches_tracked));
+    return av2x::check_launch("bn_finalize_kernel");
 }
 
 extern "C" int av2x_affine_act(const float* z, int64_t rows, int32_t c, const float* scale, const float* shift, int32_t act,
@@ -399,7 +478,7 @@ extern "C" int av2x_bn_backward(const float* dy, const float* z, int64_t rows, i
     hipStream_t st = av2x::as_stream(stream);
     double* part = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(moments_stage1<1>, dim3(slabs), dim3(256), 0, st, z, dy, (size_t)rows, c, mean, rstd, scale, shift, act, part);
-    hipLaunchKernelGGL(moments_stage2<1>, dim3((c + 255) / 256), dim3(256), 0, st, part, slabs, c, (double)rows, dbeta, dgamma);
+    hipLaunchKernelGGL(moments_stage2<1>, dim3((c + 7) / 8), dim3(256), 0, st, part, slabs, c, (double)rows, dbeta, dgamma);
     const size_t total = (size_t)rows * c;
     hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, z, mean, rstd, scale, shift, dbeta, dgamma,
                        total, c, (float)(1.0 / (double)rows), act, dz);
@@ -440,7 +519,7 @@ extern "C" int av2x_pillar_moments(const float* voxel_features, const int32_t* v
     hipLaunchKernelGGL(pillar_moments_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(voxel_features),
                        reinterpret_cast<const int4*>(voxel_coords), voxel_num_points, n_pillars, geom[0], geom[1], geom[2], geom[3],
                        geom[4], geom[5], part);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, part, blocks, kMom, moments);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((kMom + 7) / 8), dim3(256), 0, st, part, blocks, kMom, moments);
     return av2x::check_launch("pillar_moments kernels");
 }
 
@@ -459,6 +538,6 @@ extern "C" int av2x_pillar_vfe_backward(const float* voxel_features, const int32
     hipLaunchKernelGGL(pillar_backward_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(voxel_features),
                        reinterpret_cast<const int4*>(voxel_coords), voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, mean, rstd,
                        geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], dcanvas, canvas_agent0, slot_map, n_agents_type, ny, nx, part);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(3), dim3(256), 0, st, part, blocks, 64 * kBwdW, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((64 * kBwdW + 7) / 8), dim3(256), 0, st, part, blocks, 64 * kBwdW, out);
     return av2x::check_launch("pillar_vfe_backward kernels");
 }

@@ -60,6 +60,17 @@ def pack_deconv_weight_dev(w):
     return t.reshape(1, cin // 4, ncol, 4).contiguous(), ncol
 
 
+_ZEROS = {}
+
+
+def _zeros(c, device):
+    """Cached all-zero shift vector (read-only)."""
+    z = _ZEROS.get((c, device))
+    if z is None:
+        z = _ZEROS[(c, device)] = torch.zeros(c, device=device)
+    return z
+
+
 # ------------------------------------------------------------------------------------------------ raw launches
 def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0):
     """act(scale * conv2d(x, w) + shift) through the engine's launcher (direct or Winograd kernels, autotuned)."""
@@ -68,7 +79,7 @@ def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0):
     n, h, w, cin = x.shape
     cout, _, ks, _ = weight.shape
     wp, coutp = pack_conv_weight_dev(weight)
-    sh = shift if shift is not None else torch.zeros(cout, device=x.device)
+    sh = shift if shift is not None else _zeros(cout, x.device)
     L = ConvLayer(wp, scale, sh, cin, cout, coutp, ks, stride, pad, act)
     if r.winograd and r.wino_rule(L):   # transformed weights on this stream, without engine._wu's cross-stream synchronise
         u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=x.device)
@@ -151,6 +162,25 @@ def _fold(mean, var, gamma, beta, eps):
     return rstd, scale, shift
 
 
+def bn_finalize(mean, var, count, gamma, beta, eps, running=None, momentum=BN_MOMENTUM):
+    """One launch: rstd, scale = gamma * rstd, shift = beta - mean * scale and -- ``running`` = (running_mean, running_var,
+    num_batches_tracked | None, times) -- nn.BatchNorm's train-mode update applied ``times`` times with these statistics."""
+    r = _runner(mean.device)
+    c = mean.numel()
+    rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    rm = rv = nbt = None
+    times = 0
+    if running is not None:
+        rm, rv, nbt, times = running
+    _lib.check(r.lib.av2x_bn_finalize(_P(mean), _P(var), _P(gamma.detach()), _P(beta.detach()), c, float(eps), int(count), float(momentum),
+                                      int(times), _P(rstd), _P(scale), _P(shift), _P(rm), _P(rv), _P(nbt), r.stream()), "av2x_bn_finalize")
+    if running is not None:   # the kernel wrote the buffers behind torch's back: consumers key re-packing on the version counters
+        for t in (rm, rv, nbt):
+            if t is not None:
+                torch.autograd.graph.increment_version(t)
+    return rstd, scale, shift
+
+
 def update_running_stats(running_mean, running_var, num_batches_tracked, stats, times=1, momentum=BN_MOMENTUM):
     """nn.BatchNorm's train-mode side effect, applied ``times`` times with the same batch statistics (the reference runs
     the backbone more than once per step on the same input: airv2x_where2com.py:119,124)."""
@@ -167,12 +197,12 @@ def update_running_stats(running_mean, running_var, num_batches_tracked, stats, 
 # ------------------------------------------------------------------------------------------------ Conv + BN(batch) + ReLU
 class ConvBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, stride, pad, eps, act, stats_out):
+    def forward(ctx, x, weight, gamma, beta, stride, pad, eps, act, stats_out, running):
         _check_dev(x)
         x = x.contiguous()
         z = conv_raw(x, weight, stride, pad)
         mean, var, count = bn_stats(z)
-        rstd, scale, shift = _fold(mean, var, gamma, beta, eps)
+        rstd, scale, shift = bn_finalize(mean, var, count, gamma, beta, eps, running)
         y = affine_act(z, scale, shift, act)
         if stats_out is not None:
             stats_out.append((mean, var, count))
@@ -187,11 +217,12 @@ class ConvBNAct(torch.autograd.Function):
         dz, dgamma, dbeta = bn_backward(dy.contiguous(), z, mean, rstd, scale, shift, act)
         dw = conv_wgrad(x, dz, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
         dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3]) if ctx.needs_input_grad[0] else None
-        return dx, dw, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 
-def conv_bn_act(x, weight, gamma, beta, stride=1, pad=1, eps=BN_EPS, act=True, stats_out=None):
-    return ConvBNAct.apply(x, weight, gamma, beta, stride, pad, eps, act, stats_out)
+def conv_bn_act(x, weight, gamma, beta, stride=1, pad=1, eps=BN_EPS, act=True, stats_out=None, running=None):
+    """``running`` = (running_mean, running_var, num_batches_tracked | None, times): updated in place, as nn.BatchNorm does."""
+    return ConvBNAct.apply(x, weight, gamma, beta, stride, pad, eps, act, stats_out, running)
 
 
 # ------------------------------------------------------------------------------------------------ ConvTranspose(k = s) + BN + ReLU
@@ -204,7 +235,7 @@ def _space_to_depth(t, s):
 
 class DeconvBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, eps, act, stats_out):
+    def forward(ctx, x, weight, gamma, beta, eps, act, stats_out, running):
         from .engine import ConvLayer
         _check_dev(x)
         x = x.contiguous()
@@ -212,11 +243,11 @@ class DeconvBNAct(torch.autograd.Function):
         n, h, w, cin = x.shape
         _, cout, s, _ = weight.shape
         wp, ncol = pack_deconv_weight_dev(weight)
-        L = ConvLayer(wp, None, torch.zeros(cout, device=x.device), cin, cout, ncol, 1, 1, 0, 0, _lib.AV2X_DECONV, s)
+        L = ConvLayer(wp, None, _zeros(cout, x.device), cin, cout, ncol, 1, 1, 0, 0, _lib.AV2X_DECONV, s)
         z = torch.empty((n, h * s, w * s, cout), dtype=torch.float32, device=x.device)
         r.conv(L, x, n, h, w, z)
         mean, var, count = bn_stats(z)
-        rstd, scale, shift = _fold(mean, var, gamma, beta, eps)
+        rstd, scale, shift = bn_finalize(mean, var, count, gamma, beta, eps, running)
         y = affine_act(z, scale, shift, act)
         if stats_out is not None:
             stats_out.append((mean, var, count))
@@ -237,11 +268,11 @@ class DeconvBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wb = weight.detach().permute(0, 2, 3, 1).reshape(cin, s * s * cout, 1, 1)
             dx = conv_raw(d2, wb, 1, 0)
-        return dx, dw, dgamma, dbeta, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None
 
 
-def deconv_bn_act(x, weight, gamma, beta, eps=BN_EPS, act=True, stats_out=None):
-    return DeconvBNAct.apply(x, weight, gamma, beta, eps, act, stats_out)
+def deconv_bn_act(x, weight, gamma, beta, eps=BN_EPS, act=True, stats_out=None, running=None):
+    return DeconvBNAct.apply(x, weight, gamma, beta, eps, act, stats_out, running)
 
 
 # ------------------------------------------------------------------------------------------------ Conv + bias (+ ReLU)

@@ -31,25 +31,24 @@ def _bn_update(sd, prefix, stats, times):
     T.update_running_stats(sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd.get(prefix + ".num_batches_tracked"), stats, times)
 
 
-def _block(P, sd, i, x, n_layers, stride, times, record=True):
+def _running(sd, prefix, times):
+    return (sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd.get(prefix + ".num_batches_tracked"), times)
+
+
+def _block(P, sd, i, x, n_layers, stride, times):
     """backbone.blocks[i] (base_bev_backbone.py:41-70) in train mode; BatchNorm running statistics updated ``times`` times."""
     idx = 1
     for li in range(n_layers + 1):
-        st = []
-        x = T.conv_bn_act(x, P[f"backbone.blocks.{i}.{idx}.weight"], P[f"backbone.blocks.{i}.{idx + 1}.weight"],
-                          P[f"backbone.blocks.{i}.{idx + 1}.bias"], stride if li == 0 else 1, 1, stats_out=st)
-        if record:
-            _bn_update(sd, f"backbone.blocks.{i}.{idx + 1}", st[0], times)
+        bn = f"backbone.blocks.{i}.{idx + 1}"
+        x = T.conv_bn_act(x, P[f"backbone.blocks.{i}.{idx}.weight"], P[bn + ".weight"], P[bn + ".bias"], stride if li == 0 else 1, 1,
+                          running=_running(sd, bn, times))
         idx += 3
     return x
 
 
 def _deblock(P, sd, i, x, times):
-    st = []
-    y = T.deconv_bn_act(x, P[f"backbone.deblocks.{i}.0.weight"], P[f"backbone.deblocks.{i}.1.weight"], P[f"backbone.deblocks.{i}.1.bias"],
-                        stats_out=st)
-    _bn_update(sd, f"backbone.deblocks.{i}.1", st[0], times)
-    return y
+    bn = f"backbone.deblocks.{i}.1"
+    return T.deconv_bn_act(x, P[f"backbone.deblocks.{i}.0.weight"], P[bn + ".weight"], P[bn + ".bias"], running=_running(sd, bn, times))
 
 
 def _shrink(P, cfg, x):

@@ -321,6 +321,12 @@ int av2x_channel_sum(const float* x, int64_t rows, int32_t c, void* workspace, f
  * ------------------------------------------------------------------------------------ */
 uint64_t av2x_bn_workspace_bytes(int64_t rows, int32_t c);
 int av2x_bn_stats(const float* z, int64_t rows, int32_t c, void* workspace, float* mean, float* var, av2x_stream_t stream);
+/* rstd = 1 / sqrt(var + eps), scale = gamma * rstd, shift = beta - mean * scale, and -- running_mean / running_var non-NULL --
+ * nn.BatchNorm's train-mode update applied `times` times with these batch statistics (momentum; unbiased variance
+ * var * count / (count - 1)); num_batches_tracked (int64, may be NULL) += times. */
+int av2x_bn_finalize(const float* mean, const float* var, const float* gamma, const float* beta, int32_t c, float eps,
+                     int64_t count, float momentum, int32_t times, float* rstd, float* scale, float* shift,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, av2x_stream_t stream);
 int av2x_affine_act(const float* z, int64_t rows, int32_t c, const float* scale, const float* shift, int32_t act, float* y,
                     av2x_stream_t stream);
 int av2x_bn_backward(const float* dy, const float* z, int64_t rows, int32_t c, const float* mean, const float* rstd,

@@ -93,8 +93,9 @@ def test_module_contract():
     with torch.no_grad():
         ref = orc.where2com_forward(dd, sd2, args)
     assert_close(o2["rm"].cpu(), ref["rm"], 5e-4, 5e-4, "rm after reload")
-    with pytest.raises(NotImplementedError):
-        model.train()(dd)
+    ot = model.train()(dd)                                            # train mode: the autograd graph (tests/test_gpu_train.py)
+    assert ot["psm"].requires_grad and ot["psm"].shape == out["psm"].shape
+    model.eval()
 
 
 def test_batch_of_two_frames_equals_two_single_frames():

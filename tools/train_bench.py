@@ -1,0 +1,98 @@
+"""One training step of Airv2xWhere2com on the default AirV2X grid (704 x 200 canvas, N agents x 8192 points), on the device:
+train-mode forward (BatchNorm batch statistics, random top-K mask), PointPillarLossMultiClass, backward, Adam step.
+Prints one JSON line: ms per step (forward / loss+backward / optimiser), peak memory, and -- with --cpu -- the oracle's
+(torch CPU autograd) time for the same step.  Not the headline metric (BASELINE.json's is inference frames/s)."""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu", action="store_true", help="also time one oracle step on the host cores")
+    ap.add_argument("--small", action="store_true", help="128 x 64 canvas (smoke)")
+    a = ap.parse_args()
+    from airv2x_perception_amd import synth
+    from airv2x_perception_amd.opencood_iface.airv2x_where2com import Airv2xWhere2com
+    from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
+    from oracle import voxelize_oracle as vox
+    dev = torch.device("cuda", 0)
+    rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0] if a.small else None
+    hy = synth.default_hypes(rng)
+    args = hy["model"]["args"]
+    rng = rng or synth.DEFAULT_RANGE
+    types = synth.sort_types(synth.agent_types_for(a.agents))[1]
+    pp = hy["preprocess"]
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, 700 if a.small else 8192, rng), pp["cav_lidar_range"]),
+                                 pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                 pp["args"]["max_voxel_train"]) for i in range(a.agents)]
+    dd_host = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    dd = synth.data_dict_to(dd_host, dev)
+    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    model.sync_comm_rate = False
+    g = [int(v) for v in args["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]]
+    H, W = g[1] // 2, g[0] // 2
+    lc = synth.loss_case(100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=0.002)
+    tgt_host = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    tgt = {k: v.to(dev) for k, v in tgt_host.items()}
+    crit = PointPillarLossMultiClass({"cls_weight": 1.0, "reg": 2.0, "num_class": args["num_class"]})
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    random.seed(0)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    t_f = t_b = t_o = 0.0
+    losses = []
+    for step in range(a.warmup + a.steps):
+        e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+        opt.zero_grad(set_to_none=True)
+        e0.record()
+        out = model(dd)
+        e1.record()
+        loss = crit(out, tgt)
+        loss.backward()
+        e2.record()
+        opt.step()
+        e3.record()
+        torch.cuda.synchronize()
+        losses.append(float(loss))
+        if step >= a.warmup:
+            t_f += e0.elapsed_time(e1)
+            t_b += e1.elapsed_time(e2)
+            t_o += e2.elapsed_time(e3)
+    k = a.steps
+    res = {"what": "Airv2xWhere2com training step (train-mode forward + PointPillarLossMultiClass + backward + Adam)",
+           "agents": a.agents, "grid": [g[0], g[1]], "steps": k, "ms_per_step": round((t_f + t_b + t_o) / k, 3),
+           "ms_forward": round(t_f / k, 3), "ms_loss_backward": round(t_b / k, 3), "ms_optimizer": round(t_o / k, 3),
+           "steps_per_s": round(1e3 * k / (t_f + t_b + t_o), 3), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)], "dtype": "f32", "data": "synthetic"}
+    if a.cpu:
+        from oracle import loss_oracle as lo
+        from oracle import where2comm_oracle as orc
+        sd2 = {kk: v.clone() for kk, v in sd.items()}
+        for kk, v in sd2.items():
+            if v.is_floating_point() and not kk.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        t0 = time.perf_counter()
+        with orc.train_mode():
+            o = orc.where2com_forward(dd_host, sd2, args, reference_schedule=True, topk=[H * W // 2])
+        l = lo.pp_loss(o["psm"], o["rm"], o["obj"], tgt_host["targets"], tgt_host["pos_equal_one"], tgt_host["class_ids"], args["num_class"], 1.0, 2.0)
+        l[0].backward()
+        res["cpu_oracle_step_s"] = round(time.perf_counter() - t0, 2)
+        res["cpu_threads"] = torch.get_num_threads()
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
