@@ -352,3 +352,17 @@ def test_backbone_fix_freezes_everything_but_the_fusion_net():
     assert all((not p.requires_grad) or k.startswith("fusion_net.") for k, p in m.named_parameters())
     m2 = Airv2xWhere2com(args)
     assert all(p.requires_grad for p in m2.parameters())
+
+
+def test_ddp_two_ranks_average_the_gradients():
+    """tools/train.py:162 wraps the model in DistributedDataParallel: two ranks (this box's one GPU, gloo), one frame each --
+    every rank ends up with the mean of the two single-process gradients (tests/ddp_train_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", "tests/ddp_train_worker.py"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DDP-2-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
