@@ -12,8 +12,8 @@ backward (all fp32, deterministic):
     d x     = conv2d(dz * scale, rot180(w)^T)    the forward kernel itself on re-packed weights; stride 2 = the same on the
                                                  zero-upsampled dz (exact: the inserted zeros contribute nothing)
 ``scale`` is treated as a constant (a folded, frozen BatchNorm factor, or None): the reference's `backbone_fix` fine-tuning
-regime.  Batch-statistics BatchNorm, the loss and the fusion backward are NOT built yet -- the model classes still refuse
-``.train()`` forwards.
+regime.  Batch-statistics BatchNorm, the transposed convolutions, the fusion and the pillar encoders are in ``train_ops.py``;
+``train_where2com.py`` assembles them into ``Airv2xWhere2com``'s ``.train()`` forward.
 """
 from __future__ import annotations
 
