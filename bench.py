@@ -91,6 +91,7 @@ def parse(argv=None):
                     help="shard mode: every rank repeats the ego stage of every frame (SPMD) instead of rank t %% N running frame t's")
     ap.add_argument("--no-secondary", action="store_true", help="shard mode: skip the replica / latency / 4-agent secondary figures")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step figure")
     ap.add_argument("--only-headline", action="store_true",
                     help="skip the secondary legs (split-3, post-process, raw clouds, layout cycling, CPU baseline): the timed "
                          "frames + the roofline pass only -- the command the rocprofv3 summaries in profiles/ are taken from")
@@ -545,6 +546,16 @@ def main(argv=None, hooks=None, device=None):
                                          "first forward of each layout on a fresh engine (workspace allocation + schedule lookup in "
                                          "the shipped tuning table / the user's cache, timing only what neither holds)"}
         del m2, e2
+
+    # ---------------- one TRAINING step of the same model (not the headline metric) ----------
+    if secondary and a.model == "where2com" and not a.amp and a.gemm == "f32" and not a.no_train:
+        from tools.train_bench import run as train_run
+        tr = train_run(agents=a.agents, steps=10, warmup=3, dev=dev, dd=dd, args=args)
+        res["train_step"] = {k: tr[k] for k in ("ms_per_step", "steps_per_s", "ms_forward", "ms_loss_backward", "ms_optimizer",
+                                                "peak_mem_gib", "agents", "steps")}
+        res["train_step"]["note"] = ("Airv2xWhere2com.train(): train-mode forward (BatchNorm batch statistics, random top-K mask) + "
+                                     "PointPillarLossMultiClass + backward + Adam, every autograd node a HIP forward / backward "
+                                     "kernel pair (tools/train_bench.py; profiles/r02_kernel_stats_train.txt)")
 
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and dd is not None and model is not None and eng is not None:

@@ -205,7 +205,7 @@ def communication(psm_split, sd, comm_cfg, topk=None):
         if topk is not None:
             flat = cm.reshape(L, H * W)
             _, idx = torch.topk(flat, k=int(topk[b]), sorted=False)
-            m = torch.scatter(torch.zeros_like(flat), -1, idx, torch.ones(L, int(topk[b]))).reshape(L, 1, H, W)
+            m = torch.scatter(torch.zeros_like(flat), -1, idx, torch.ones(L, int(topk[b]), dtype=flat.dtype)).reshape(L, 1, H, W)
         elif thr:
             m = torch.where(cm > thr, torch.ones_like(cm), torch.zeros_like(cm))
         else:
@@ -235,7 +235,7 @@ def _split(x, record_len):
 
 
 # ---------------------------------------------------------------- a10: Where2comm multi-scale fusion
-def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None, topk=None):
+def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None, topk=None, comm_mask=None):
     """where2comm_fuse.py:198-263 (multi_scale, not fully connected).
     x (sumN,64,H,W) canvas features; returns (fused (B,384,H/2,W/2), rate)."""
     bb = args["modality_fusion"]["base_bev_backbone"]
@@ -249,6 +249,8 @@ def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None, topk=None):
                 rate = torch.tensor(1)
             else:
                 masks, rate, maps = communication(_split(psm_single, record_len), sd, fcfg["communication"], topk)
+                if comm_mask is not None:   # replay a recorded mask (the top-K / threshold cut is discontinuous in the logits)
+                    masks = comm_mask.to(x.dtype).reshape(masks.shape)
                 if x.shape[-1] != masks.shape[-1]:
                     masks = F.interpolate(masks, size=(x.shape[-2], x.shape[-1]), mode="bilinear",
                                           align_corners=False)
@@ -265,7 +267,7 @@ def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None, topk=None):
 
 
 # ---------------------------------------------------------------- full forward
-def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False, topk=None):
+def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False, topk=None, comm_mask=None):
     """models/airv2x_where2com.py:117-179 (det task, multi_scale, compression 0).
 
     The reference evaluates the backbone twice before the fusion (:119, :124); in
@@ -282,7 +284,7 @@ def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False,
     comm_rate = int(feats.count_nonzero().item())  # :122
     s = shrink_conv(sf2d, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else sf2d
     psm_single = head(s, sd, "cls_head")  # :145
-    fused, rate = where2comm_fuse(feats, psm_single, record_len, sd, args, trace, topk)  # :153-159
+    fused, rate = where2comm_fuse(feats, psm_single, record_len, sd, args, trace, topk, comm_mask)  # :153-159
     fs = shrink_conv(fused, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else fused
     out = {"psm": head(fs, sd, "cls_head"), "rm": head(fs, sd, "reg_head")}
     if args["obj_head"]:

@@ -65,7 +65,7 @@ def train_case_from_fixture(fx):
         voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
                                          pp["args"]["max_voxel_train"]))
     dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
-    H, W = fx["psm"].shape[-2:]
+    H, W = [int(v) for v in fx["psm_shape"][-2:]]
     lc = synth.loss_case(int(fx["seed"]) + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=float(fx["pos_frac"]))
     tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
     return hy, args, sd, dd, tgt

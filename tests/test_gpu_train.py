@@ -231,7 +231,7 @@ def _loss(args):
     return PointPillarLossMultiClass({"cls_weight": 1.0, "reg": 2.0, "num_class": args["num_class"]})
 
 
-@pytest.mark.parametrize("name", ["train_small_n3", "train_small_n2"])
+@pytest.mark.parametrize("name", ["train_small_n3", "train_small_n2", "train_full_n4"])
 def test_training_step_matches_the_reference(name):
     from airv2x_perception_amd.opencood_iface.train_where2com import forward_train
     fx = load_fixture(name)
@@ -251,8 +251,11 @@ def test_training_step_matches_the_reference(name):
     # 2. the step with the reference's mask replayed: heads, losses, gradients, buffers (fresh model: step 1 moved the statistics)
     model = _model(args, sd)
     out = forward_train(model, dd, topk=K, mask=ref_mask)
+    hs = int(fx["head_stride"])
     for k in ("psm", "rm", "obj"):
-        assert_close(out[k].detach().cpu(), fx[k], 2e-4, 2e-4 * float(np.abs(fx[k]).max()), k)
+        assert_close(out[k].detach()[..., ::hs, ::hs].cpu(), fx[k], 2e-4, 2e-4 * float(np.abs(fx[k]).max()), k)
+        asum = float(out[k].detach().double().abs().sum())
+        assert abs(asum - float(fx[k + "_abssum"])) <= 1e-4 * float(fx[k + "_abssum"]), k
     crit = _loss(args)
     total = crit(out, {k: v.cuda() for k, v in tgt.items()})
     total.backward()
@@ -261,27 +264,32 @@ def test_training_step_matches_the_reference(name):
     P = dict(model.named_parameters())
     keys = [str(k) for k in fx["grad_keys"]]
     assert sorted(k for k, p in P.items() if p.grad is not None) == sorted(keys)
-    # gradients: relative to the largest entry of each tensor.  The graph is ~25 layers deep with a ReLU after each and a
-    # max over points at the bottom: an activation within fp32 rounding of zero (or two near-equal maxima) routes differently
-    # on the two sides, so the deepest tensors carry the largest deviation (measured: <= 3e-3 at the pillar Linear, 1e-5 at the heads)
-    worst = {}
+    # gradients.  The graph is ~25 ReLUs deep with a max over points at the bottom: an activation within fp32 rounding of zero
+    # falls on either side of the kink in ANY fp32 evaluation order, so fp32 gradients are only defined up to that noise.  The
+    # fixture carries the yardstick: the same step in float64 (``g64:*``) and how far the REFERENCE's own fp32 gradients are
+    # from it (``gdev:*``, relative to each tensor's largest entry: 4e-3 .. 3e-2 on the small grid, 2.5e-2 median at 704 x 200).
+    # Measured: the device step is as far from the exact gradient as the reference's own fp32 step is (median 5.0e-3 / 8.0e-3 /
+    # 2.6e-2 against 3.9e-3 / 7.3e-3 / 2.5e-2; worst 6.4e-2 against 6.5e-2 at 704 x 200).  Bar: per tensor <= 3x the reference's
+    # deviation + 2x the reference's median (the noise is a few flipped activations: tensors where the reference happened to
+    # be lucky are not held to its luck), median <= 1.5x, worst <= 2.5x the reference's; the heads -- no kink between them
+    # and the loss -- within twice the reference's deviation + 2e-5.
+    dev, refdev = {}, {}
     for k in keys:
         g = P[k].grad.reshape(-1)
         stride = max(1, g.numel() // 4096)
-        gmax = fx["gsum:" + k][2]
-        err = np.abs(g[::stride].cpu().numpy().astype(np.float64) - fx["g:" + k]).max()
-        worst[k] = err / max(gmax, 1e-30)
-        asum = g.double().abs().sum().item()
-        assert abs(asum - fx["gsum:" + k][1]) <= 1e-2 * fx["gsum:" + k][1] + 1e-9, (k, asum, fx["gsum:" + k][1])
-    print("worst gradient deviations (rel. to max):", sorted(((round(v, 6), k) for k, v in worst.items()), reverse=True)[:6])
-    # (the op-level tests above exclude the kinks and hold 1e-4 .. 5e-4.)  Here: the heads -- no ReLU between them and the
-    # loss -- to 1e-3; every tensor to 1e-1; all but a few to 1e-2: one flipped activation moves a per-channel sum over the
-    # 256 cells of the coarsest map by a few per cent of the tensor's maximum.
-    heads = {k: v for k, v in worst.items() if k.endswith(("_head.weight", "_head.bias")) and v > 1e-3}
+        gmax = float(fx["g64max:" + k])
+        dev[k] = np.abs(g[::stride].cpu().numpy().astype(np.float64) - fx["g64:" + k].astype(np.float64)).max() / max(gmax, 1e-300)
+        refdev[k] = float(fx["gdev:" + k])
+    med_ref = float(np.median(list(refdev.values())))
+    med_dev = float(np.median(list(dev.values())))
+    print(f"{name}: gradient deviation from float64, rel. to max -- device median {med_dev:.2e} worst {max(dev.values()):.2e}; "
+          f"reference fp32 median {med_ref:.2e} worst {max(refdev.values()):.2e}")
+    bad = {k: (dev[k], refdev[k]) for k in keys if dev[k] > 3.0 * refdev[k] + 2.0 * med_ref + 1e-4}
+    assert not bad, bad
+    assert med_dev <= 1.5 * med_ref + 1e-4, (med_dev, med_ref)
+    assert max(dev.values()) <= 2.5 * max(refdev.values()), (max(dev.values()), max(refdev.values()))
+    heads = {k: (v, refdev[k]) for k, v in dev.items() if k.endswith(("_head.weight", "_head.bias")) and v > 2.0 * refdev[k] + 2e-5}
     assert not heads, heads
-    assert max(worst.values()) <= 1e-1, max(worst.items(), key=lambda kv: kv[1])
-    loose = [k for k, v in worst.items() if v > 1e-2]
-    assert len(loose) <= 3, {k: worst[k] for k in loose}
     for k, b in model.named_buffers():
         ref = fx["b:" + k].astype(np.float64)
         got = b.detach().cpu().numpy().astype(np.float64)

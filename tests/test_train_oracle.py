@@ -27,8 +27,9 @@ def test_train_oracle_reproduces_the_reference_step(name):
     fx = load_fixture(name)
     hy, args, sd, dd, tgt = train_case_from_fixture(fx)
     o, losses, sd2 = oracle_step(args, sd, dd, tgt, [int(k) for k in fx["K"]])
+    hs = int(fx["head_stride"])
     for k in ("psm", "rm", "obj"):
-        assert np.abs(o[k].detach().numpy() - fx[k]).max() < 1e-5, k
+        assert np.abs(o[k].detach()[..., ::hs, ::hs].numpy() - fx[k]).max() < 1e-5, k
     assert abs(float(losses[0]) - fx["losses"][0]) < 1e-4 * abs(fx["losses"][0])
     assert abs(float(losses[1]) - fx["losses"][1]) < 1e-4 * abs(fx["losses"][1])
     assert abs(float(losses[2]) - fx["losses"][2]) < 1e-4 * abs(fx["losses"][2])

@@ -14,30 +14,29 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--agents", type=int, default=4)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu", action="store_true", help="also time one oracle step on the host cores")
-    ap.add_argument("--small", action="store_true", help="128 x 64 canvas (smoke)")
-    a = ap.parse_args()
+def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None, args=None):
+    """-> dict (see the module docstring).  ``dd`` / ``args``: a frame already on the device and its model args (bench.py
+    passes the one its device voxelizer built); otherwise the frame is built here with the oracle's CPU voxelizer."""
+    from types import SimpleNamespace
+    a = SimpleNamespace(agents=agents, steps=steps, warmup=warmup, small=small, cpu=cpu)
     from airv2x_perception_amd import synth
     from airv2x_perception_amd.opencood_iface.airv2x_where2com import Airv2xWhere2com
     from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
-    from oracle import voxelize_oracle as vox
-    dev = torch.device("cuda", 0)
-    rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0] if a.small else None
-    hy = synth.default_hypes(rng)
-    args = hy["model"]["args"]
-    rng = rng or synth.DEFAULT_RANGE
-    types = synth.sort_types(synth.agent_types_for(a.agents))[1]
-    pp = hy["preprocess"]
-    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, 700 if a.small else 8192, rng), pp["cav_lidar_range"]),
-                                 pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
-                                 pp["args"]["max_voxel_train"]) for i in range(a.agents)]
-    dd_host = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
-    dd = synth.data_dict_to(dd_host, dev)
+    dev = dev or torch.device("cuda", 0)
+    dd_host = None
+    if dd is None:
+        from oracle import voxelize_oracle as vox
+        rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0] if a.small else None
+        hy = synth.default_hypes(rng)
+        args = hy["model"]["args"]
+        rng = rng or synth.DEFAULT_RANGE
+        types = synth.sort_types(synth.agent_types_for(a.agents))[1]
+        pp = hy["preprocess"]
+        voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, 700 if a.small else 8192, rng), pp["cav_lidar_range"]),
+                                     pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                     pp["args"]["max_voxel_train"]) for i in range(a.agents)]
+        dd_host = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+        dd = synth.data_dict_to(dd_host, dev)
     sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
     model = Airv2xWhere2com(args)
     model.load_state_dict(sd)
@@ -66,7 +65,7 @@ def main():
         opt.step()
         e3.record()
         torch.cuda.synchronize()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         if step >= a.warmup:
             t_f += e0.elapsed_time(e1)
             t_b += e1.elapsed_time(e2)
@@ -77,7 +76,7 @@ def main():
            "ms_forward": round(t_f / k, 3), "ms_loss_backward": round(t_b / k, 3), "ms_optimizer": round(t_o / k, 3),
            "steps_per_s": round(1e3 * k / (t_f + t_b + t_o), 3), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)], "dtype": "f32", "data": "synthetic"}
-    if a.cpu:
+    if a.cpu and dd_host is not None:
         from oracle import loss_oracle as lo
         from oracle import where2comm_oracle as orc
         sd2 = {kk: v.clone() for kk, v in sd.items()}
@@ -91,7 +90,18 @@ def main():
         l[0].backward()
         res["cpu_oracle_step_s"] = round(time.perf_counter() - t0, 2)
         res["cpu_threads"] = torch.get_num_threads()
-    print(json.dumps(res))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu", action="store_true", help="also time one oracle step on the host cores")
+    ap.add_argument("--small", action="store_true", help="128 x 64 canvas (smoke)")
+    a = ap.parse_args()
+    print(json.dumps(run(a.agents, a.steps, a.warmup, a.small, a.cpu)))
 
 
 if __name__ == "__main__":
