@@ -1,7 +1,7 @@
 // Backward pieces of the BEV convolutions (first slice of training on the MI355X path):
 //   av2x_conv2d_wgrad   dW[co][ci][kh][kw] = sum over output pixels of dY[p][co] * X[p shifted by the tap][ci]
 //   av2x_act_backward   dZ = dY * act'(Y) * scale[c]      (ReLU / identity, folded-BN or unit scale)
-//   av2x_channel_sum    db[c] = sum over pixels of dZ[p][c]
+//   (av2x_channel_sum, db[c] = sum over pixels of dZ[p][c], lives in train.hip with the other per-channel reductions)
 // The data gradient needs no kernel of its own: for stride 1 it IS a convolution of dZ with the 180-degree-rotated,
 // channel-transposed weights (av2x_conv2d on weights packed that way); for stride 2 the same on the zero-upsampled dZ
 // (opencood_iface/autograd.py).
@@ -14,6 +14,8 @@
 // (tile a holds output channels 2i + a) -- a free permutation of the output rows that the store undoes.
 // The pixel axis is cut into chunks (one workgroup per (tile, tap, chunk)); the per-chunk partial dW slabs are summed
 // in ascending chunk order by a second kernel: deterministic, no atomics.
+#include <cstdlib>
+
 #include "av2x_common.hpp"
 
 namespace {
@@ -140,6 +142,125 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
             }
 }
 
+// 3x3 / stride 1 / pad 1 layers: ONE workgroup accumulates the three kw taps of a tap row kh.  A K-step is a 32-pixel segment
+// of ONE output row, so the three taps read the same staged input pixels shifted by one: per step 32 x 128 dY + 34 x 128 X
+// (33 KiB) feed 3 x 64 MFMAs per wave -- three times the flops per staged byte of the per-tap kernel, whose L2 -> LDS
+// stream (4 TB/s at the matrix cores' rate) was its limit.  Segments past the row end and the halo columns are zero-filled
+// by the buffer bounds check.  Tile 128 couts x 128 cins, 192 accumulator registers per lane.
+struct Wgrad3Params {
+    const float* x;
+    const float* dy;
+    float* part;      // [chunk][tap = kh * 3 + kw][Cout][Cin]
+    int H, W, Cin, in_ctot, in_coff, Cout, dy_ctot, dy_coff;
+    int segs, steps_total, chunk_steps, nchunks, tiles_ci;
+    unsigned x_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(const Wgrad3Params p) {
+    constexpr int TC = 128, ROWB = TC * 4;
+    constexpr int STAGE_A = 32 * ROWB, STAGE_B = 34 * ROWB, STAGE = STAGE_A + STAGE_B;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.tiles_ci * ((p.Cout + TC - 1) / TC);
+    int b = blockIdx.x;
+    const int tile = b % tiles; b /= tiles;
+    const int kh = b % 3;
+    const int chunk = b / 3;
+    const int co0 = (tile / p.tiles_ci) * TC, ci0 = (tile % p.tiles_ci) * TC;
+    const int t0 = chunk * p.chunk_steps, t1 = min(t0 + p.chunk_steps, p.steps_total);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int lp = lane >> 5, lq = lane & 31;          // a 1 KiB DMA instruction = 2 pixel rows of 128 channels
+
+    auto issue = [&](int t, int buf) {
+        unsigned char* sa = sm + buf * STAGE;
+        unsigned char* sb = sa + STAGE_A;
+        const int seg = t % p.segs, rowid = t / p.segs;
+        const int ho = rowid % p.H, img = rowid / p.H;          // stride 1, pad 1: Ho == H, Wo == W
+        const int wo0 = seg * 32;
+        const int hi = ho + kh - 1;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int j = wave + 4 * i;                          // 16 dY instructions, then 17 X instructions
+            if (j < 16) {
+                const int q = 2 * j + lp;
+                unsigned va = OOB;
+                if (wo0 + q < p.W && co0 + lq * 4 < p.Cout)
+                    va = (unsigned)((((size_t)(img * p.H + ho) * p.W + wo0 + q) * p.dy_ctot + p.dy_coff + co0 + lq * 4) * 4);
+                glds16b(rdy, sa + j * 1024, va, 0);
+            } else if (j < 33) {
+                const int e = 2 * (j - 16) + lp;
+                const int wi = wo0 - 1 + e;
+                unsigned vb = OOB;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && ci0 + lq * 4 < p.Cin)
+                    vb = (unsigned)((((size_t)(img * p.H + hi) * p.W + wi) * p.in_ctot + p.in_coff + ci0 + lq * 4) * 4);
+                glds16b(rx, sb + (j - 16) * 1024, vb, 0);
+            }
+        }
+    };
+
+    f32x16b acc[3][2][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][a][c][r] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+
+    if (t0 < t1) {
+        issue(t0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        if (t + 1 < t1) issue(t + 1, buf ^ 1);
+        const unsigned char* sa = sm + buf * STAGE;
+        const unsigned char* sb = sa + STAGE_A;
+#pragma unroll 2
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int row = 2 * k2 + lh;
+            const f32x2b ta = *reinterpret_cast<const f32x2b*>(sa + row * ROWB + (wr + 2 * li) * 4);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x2b tb = *reinterpret_cast<const f32x2b*>(sb + (row + k) * ROWB + (wc + 2 * li) * 4);
+                acc[k][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta.x, tb.x, acc[k][0][0], 0, 0, 0);
+                acc[k][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta.x, tb.y, acc[k][0][1], 0, 0, 0);
+                acc[k][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta.y, tb.x, acc[k][1][0], 0, 0, 0);
+                acc[k][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta.y, tb.y, acc[k][1][1], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float* out = p.part + ((size_t)chunk * 9 + kh * 3 + k) * p.Cout * p.Cin;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int co = co0 + wr + 2 * i + a, ci = ci0 + wc + 2 * li;       // columns ci, ci + 1: one 8-byte store
+                if (co < p.Cout && ci + 1 < p.Cin) {
+                    f32x2b v2;
+                    v2.x = acc[k][a][0][r];
+                    v2.y = acc[k][a][1][r];
+                    *reinterpret_cast<f32x2b*>(out + (size_t)co * p.Cin + ci) = v2;
+                } else if (co < p.Cout && ci < p.Cin) {
+                    out[(size_t)co * p.Cin + ci] = acc[k][a][0][r];
+                }
+            }
+    }
+}
+
 // dw[co][ci][tap] = sum over chunks (ascending) of part[chunk][tap][co][ci]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nchunks, int taps, int cout, int cin,
                                                            float* __restrict__ dw) {
@@ -172,33 +293,53 @@ __global__ __launch_bounds__(256) void act_backward_kernel(const float4* __restr
     }
 }
 
-// two-stage deterministic column sum: stage 1 = one workgroup per slab of rows, stage 2 sums the slabs in order
-__global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, size_t rows, int c, size_t slab,
-                                                          float* __restrict__ part) {
-    const size_t r0 = (size_t)blockIdx.x * slab, r1 = r0 + slab < rows ? r0 + slab : rows;
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
-        float s = 0.f;
-        for (size_t r = r0; r < r1; ++r) s += x[r * c + ch];
-        part[(size_t)blockIdx.x * c + ch] = s;
-    }
-}
-
-__global__ __launch_bounds__(256) void channel_sum_stage2(const float* __restrict__ part, int nslabs, int c, float* __restrict__ out) {
-    for (int ch = blockIdx.x * 256 + threadIdx.x; ch < c; ch += gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nslabs; ++k) s += part[(size_t)k * c + ch];
-        out[ch] = s;
-    }
-}
-
 constexpr int kWgradChunk = 2048;   // output pixels per workgroup (64 K-steps of 32)
 
 }  // namespace
 
+// the three-taps-per-workgroup kernel: 3x3 / stride 1 / pad 1 with more than 64 channels on either side
+static bool wgrad3_applies(const av2x_conv_desc* d) {
+    static const bool off = [] { const char* e = getenv("AV2X_WGRAD3"); return e && e[0] == '0'; }();
+    return !off && d->ks == 3 && d->stride == 1 && d->pad == 1 && d->ho == d->h && d->wo == d->w && (d->cin > 64 || d->cout > 64);
+}
+
+// K-steps (32-pixel row segments) per workgroup: enough workgroups to fill the chip twice over, at least 8 steps each
+static void wgrad3_plan(const av2x_conv_desc* d, int* segs, int* steps_total, int* chunk_steps, int* nchunks) {
+    *segs = (d->w + 31) / 32;
+    *steps_total = d->n * d->h * *segs;
+    const int tiles = ((d->cin + 127) / 128) * ((d->cout + 127) / 128);
+    // one round of workgroups (<= one per CU; two extra workgroups would double the launch's duration): as many pixel chunks as
+    // fit, at least 8 K-steps each
+    static const int target = [] { const char* e = getenv("AV2X_WGRAD3_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    int max_chunks = target / (3 * tiles);
+    if (max_chunks < 1) max_chunks = 1;
+    long long cs = ((long long)*steps_total + max_chunks - 1) / max_chunks;
+    if (cs < 8) cs = 8;
+    *chunk_steps = (int)cs;
+    *nchunks = (*steps_total + *chunk_steps - 1) / *chunk_steps;
+}
+
+// per-tap kernel: output pixels per workgroup (a multiple of 32, 256 .. 2048) -- short enough that (tiles x taps x chunks) fills
+// the chip when the map is small or the layer is a 1x1 / transposed convolution with few taps
+static int wgrad_chunk(const av2x_conv_desc* d, long long M) {
+    const int tc = (d->cin > 64 || d->cout > 64) ? 128 : 64;
+    const long long tiles = (long long)((d->cin + tc - 1) / tc) * ((d->cout + tc - 1) / tc) * d->ks * d->ks;
+    long long chunk = (M * tiles / 384 + 31) / 32 * 32;
+    if (chunk < 256) chunk = 256;
+    if (chunk > kWgradChunk) chunk = kWgradChunk;
+    return (int)chunk;
+}
+
 extern "C" uint64_t av2x_conv2d_wgrad_workspace_bytes(const av2x_conv_desc* d) {
     if (!d) return 0;
+    if (wgrad3_applies(d)) {
+        int segs, st, cs, nch;
+        wgrad3_plan(d, &segs, &st, &cs, &nch);
+        return (uint64_t)nch * 9ull * d->cout * d->cin * 4ull;
+    }
     const long long M = (long long)d->n * d->ho * d->wo;
-    const long long nch = (M + kWgradChunk - 1) / kWgradChunk;
+    const int chunk = wgrad_chunk(d, M);
+    const long long nch = (M + chunk - 1) / chunk;
     return (uint64_t)nch * d->ks * d->ks * d->cout * d->cin * 4ull;
 }
 
@@ -216,12 +357,30 @@ extern "C" int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const 
     const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->in_ctot * 4ull;
     const unsigned long long yb = (unsigned long long)M * d->out_ctot * 4ull;
     if (xb >= (1ull << 31) || yb >= (1ull << 31)) return av2x::fail("av2x_conv2d_wgrad: tensor exceeds the 2 GiB buffer-descriptor window");
+    hipStream_t st3 = av2x::as_stream(stream);
+    if (wgrad3_applies(d)) {
+        Wgrad3Params q;
+        q.x = x; q.dy = dy; q.part = reinterpret_cast<float*>(workspace);
+        q.H = d->h; q.W = d->w; q.Cin = d->cin; q.in_ctot = d->in_ctot; q.in_coff = d->in_coff;
+        q.Cout = d->cout; q.dy_ctot = d->out_ctot; q.dy_coff = d->out_coff;
+        wgrad3_plan(d, &q.segs, &q.steps_total, &q.chunk_steps, &q.nchunks);
+        q.tiles_ci = (d->cin + 127) / 128;
+        q.x_bytes = (unsigned)xb; q.dy_bytes = (unsigned)yb;
+        const int tiles = q.tiles_ci * ((d->cout + 127) / 128);
+        const size_t lds = 2 * (32 + 34) * 512;
+        static av2x::LdsLimit lim3;
+        lim3.ensure(reinterpret_cast<const void*>(&conv_wgrad3_kernel), lds);
+        hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(tiles * 3 * q.nchunks), dim3(256), lds, st3, q);
+        if (int e = av2x::check_launch("conv_wgrad3_kernel")) return e;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(512), dim3(256), 0, st3, q.part, q.nchunks, 9, d->cout, d->cin, dw);
+        return av2x::check_launch("wgrad_reduce_kernel");
+    }
     WgradParams p;
     p.x = x; p.dy = dy; p.part = reinterpret_cast<float*>(workspace);
     p.H = d->h; p.W = d->w; p.Cin = d->cin; p.in_ctot = d->in_ctot; p.in_coff = d->in_coff;
     p.Ho = d->ho; p.Wo = d->wo; p.HoWo = d->ho * d->wo; p.Cout = d->cout; p.dy_ctot = d->out_ctot; p.dy_coff = d->out_coff;
     p.ks = d->ks; p.stride = d->stride; p.pad = d->pad;
-    p.M = (int)M; p.chunk = kWgradChunk; p.nchunks = (int)((M + kWgradChunk - 1) / kWgradChunk);
+    p.M = (int)M; p.chunk = wgrad_chunk(d, M); p.nchunks = (int)((M + p.chunk - 1) / p.chunk);
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
     hipStream_t st = av2x::as_stream(stream);
     const int taps = d->ks * d->ks;
@@ -255,18 +414,4 @@ extern "C" int av2x_act_backward(const float* y, const float* dy, const float* s
                        reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(dy), scale, n4, c / 4, act,
                        reinterpret_cast<float4*>(dz));
     return av2x::check_launch("act_backward_kernel");
-}
-
-extern "C" uint64_t av2x_channel_sum_workspace_bytes(int64_t rows, int32_t c) {
-    const int64_t slabs = (rows + 511) / 512;
-    return (uint64_t)slabs * c * 4ull;
-}
-
-extern "C" int av2x_channel_sum(const float* x, int64_t rows, int32_t c, void* workspace, float* out, av2x_stream_t stream) {
-    if (!x || !workspace || !out || rows <= 0 || c <= 0) return av2x::fail("av2x_channel_sum: bad argument");
-    const int slabs = (int)((rows + 511) / 512);
-    hipStream_t st = av2x::as_stream(stream);
-    hipLaunchKernelGGL(channel_sum_stage1, dim3(slabs), dim3(256), 0, st, x, (size_t)rows, c, (size_t)512, reinterpret_cast<float*>(workspace));
-    hipLaunchKernelGGL(channel_sum_stage2, dim3((c + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), slabs, c, out);
-    return av2x::check_launch("channel_sum");
 }

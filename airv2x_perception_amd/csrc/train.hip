@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void moments_stage1(const float* __restrict__ 
 
 // Sums the slab partials: a workgroup owns 8 channels, 32 lanes walk the slabs (lane l takes slabs l, l + 32, ...), then the 32
 // lane sums are added in lane order -- fixed order, fp64.  MODE 0: out0 = mean, out1 = biased variance.  MODE 1: out0 = sum g
-// (d beta), out1 = sum g xhat (d gamma).
+// (d beta), out1 = sum g xhat (d gamma).  MODE 2: out0 = the first sum only.
 template <int MODE>
 __global__ __launch_bounds__(256) void moments_stage2(const double* __restrict__ part, int nslabs, int c, double n,
                                                       float* __restrict__ out0, float* __restrict__ out1) {
@@ -127,9 +127,11 @@ __global__ __launch_bounds__(256) void moments_stage2(const double* __restrict__
             if (v < 0.0) v = 0.0;
             out0[ch] = (float)m;
             out1[ch] = (float)v;
-        } else {
+        } else if (MODE == 1) {
             out0[ch] = (float)a;
             out1[ch] = (float)b;
+        } else {
+            out0[ch] = (float)a;      // MODE 2: the plain column sum
         }
     }
 }
@@ -442,6 +444,20 @@ extern "C" int av2x_bn_stats(const float* z, int64_t rows, int32_t c, void* work
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, part);
     hipLaunchKernelGGL(moments_stage2<0>, dim3((c + 7) / 8), dim3(256), 0, st, part, slabs, c, (double)rows, mean, var);
     return av2x::check_launch("bn_stats kernels");
+}
+
+// d bias[c] = sum over rows of x[r][c] (conv_backward's bias gradient): the MODE 0 slab pass, first moment only
+extern "C" uint64_t av2x_channel_sum_workspace_bytes(int64_t rows, int32_t c) { return av2x_bn_workspace_bytes(rows, c); }
+
+extern "C" int av2x_channel_sum(const float* x, int64_t rows, int32_t c, void* workspace, float* out, av2x_stream_t stream) {
+    if (!x || !workspace || !out || rows <= 0 || c <= 0) return av2x::fail("av2x_channel_sum: bad argument");
+    const int slabs = (int)((rows + kSlabRows - 1) / kSlabRows);
+    hipStream_t st = av2x::as_stream(stream);
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(moments_stage1<0>, dim3(slabs), dim3(256), 0, st, x, (const float*)nullptr, (size_t)rows, c, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, part);
+    hipLaunchKernelGGL(moments_stage2<2>, dim3((c + 7) / 8), dim3(256), 0, st, part, slabs, c, (double)rows, out, (float*)nullptr);
+    return av2x::check_launch("channel_sum kernels");
 }
 
 extern "C" int av2x_bn_finalize(const float* mean, const float* var, const float* gamma, const float* beta, int32_t c, float eps,

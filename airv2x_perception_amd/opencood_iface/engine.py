@@ -34,6 +34,9 @@ AGENT_TYPES = ("vehicle", "rsu", "drone")
 TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_models"}
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if hasattr(torch._C, "_cuda_getDevice") else None
+
+
 class ConvLayer:
     __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu")
 
@@ -320,6 +323,10 @@ class Where2ComEngine:
 
     @staticmethod
     def stream():
+        """The current HIP stream of the current device as a raw handle (called once per kernel launch: the raw accessor is
+        ~10x cheaper than building a torch.cuda.Stream object)."""
+        if _RAW_STREAM is not None:
+            return c_void_p(_RAW_STREAM(torch._C._cuda_getDevice()))
         return c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------ kernels

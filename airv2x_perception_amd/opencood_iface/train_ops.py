@@ -72,18 +72,42 @@ def _zeros(c, device):
 
 
 # ------------------------------------------------------------------------------------------------ raw launches
-def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0):
-    """act(scale * conv2d(x, w) + shift) through the engine's launcher (direct or Winograd kernels, autotuned)."""
+_PACKED = {}       # id(parameter) -> (version, weakref, packed, coutp, winograd-transformed | None): one packing per optimiser step
+
+
+def _packed(r, weight, flipped=False):
+    """The kernel packing of a convolution weight (``flipped``: of its 180-degree-rotated, channel-transposed form -- the data
+    gradient's weights), cached per parameter and version counter: a training step uses every weight in up to three passes."""
+    import weakref
+    key = (id(weight), flipped)
+    ent = _PACKED.get(key)
+    if ent is not None and ent[0] == weight._version and ent[1]() is weight:
+        return ent[2], ent[3], ent[4]
+    src = weight.detach().flip(2, 3).transpose(0, 1) if flipped else weight
+    wp, coutp = pack_conv_weight_dev(src)
+    cout, cin, ks = src.shape[0], src.shape[1], src.shape[2]
+    u = None
+    if r.winograd and ks == 3 and cin >= 64 and cin % 8 == 0 and cout % 64 == 0 and cout == coutp:   # engine.wino_rule's weight side
+        u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=weight.device)
+        _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u), r.stream()), "av2x_wino_pack_weights")
+    if weight.is_leaf and isinstance(weight, torch.nn.Parameter):
+        if len(_PACKED) > 4096:
+            _PACKED.clear()
+        _PACKED[key] = (weight._version, weakref.ref(weight), wp, coutp, u)
+    return wp, coutp, u
+
+
+def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=False):
+    """act(scale * conv2d(x, w) + shift) through the engine's launcher (direct or Winograd kernels, autotuned).  ``flipped``:
+    convolve with the 180-degree-rotated, channel-transposed weights (the data gradient)."""
     from .engine import ConvLayer
     r = _runner(x.device)
     n, h, w, cin = x.shape
-    cout, _, ks, _ = weight.shape
-    wp, coutp = pack_conv_weight_dev(weight)
+    wp, coutp, u = _packed(r, weight, flipped)
+    cout, ks = (weight.shape[1], weight.shape[2]) if flipped else (weight.shape[0], weight.shape[2])
     sh = shift if shift is not None else _zeros(cout, x.device)
     L = ConvLayer(wp, scale, sh, cin, cout, coutp, ks, stride, pad, act)
-    if r.winograd and r.wino_rule(L):   # transformed weights on this stream, without engine._wu's cross-stream synchronise
-        u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=x.device)
-        _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u), r.stream()), "av2x_wino_pack_weights")
+    if u is not None and r.wino_rule(L):   # transformed weights made on this stream, without engine._wu's cross-stream synchronise
         L._wu = u
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
@@ -110,7 +134,6 @@ def conv_dgrad(dz, weight, stride, pad, in_hw):
     cin, ks = weight.shape[1], weight.shape[2]
     if cout % 4:
         raise NotImplementedError("data gradient needs cout % 4 == 0 (pad the head convolutions)")
-    wt = weight.detach().flip(2, 3).transpose(0, 1)            # (cin, cout, k, k)
     if stride == 1:
         if pad != ks // 2:
             raise NotImplementedError("'same' padding only")
@@ -120,7 +143,7 @@ def conv_dgrad(dz, weight, stride, pad, in_hw):
         src[:, ::2, ::2] = dz
     else:
         raise NotImplementedError("data gradient: stride 1, or 3x3 stride 2 pad 1 on even sizes (every layer of the BEV backbone)")
-    return conv_raw(src, wt, 1, ks // 2 if ks == 3 else 0)
+    return conv_raw(src, weight, 1, ks // 2 if ks == 3 else 0, flipped=True)
 
 
 def bn_stats(z):
