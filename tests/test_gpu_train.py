@@ -374,3 +374,33 @@ def test_ddp_two_ranks_average_the_gradients():
            "--master-port", "29547", "tests/ddp_train_worker.py"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "DDP-2-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_batch_of_two_frames_trains():
+    """B = 2 (the collate layout, different agent mixes per sample): per-sample masks / fusion, batch-wide BatchNorm statistics.
+    No oracle takes B > 1 (the reference's own Communication.forward documents B = 1); checked: shapes, finite values, every
+    trainable tensor that takes part receives a gradient, two identical steps give identical bits."""
+    from airv2x_perception_amd import synth
+    from airv2x_perception_amd.opencood_iface.train_where2com import forward_train
+    fx = load_fixture("train_small_n3")
+    hy, args, sd, dd3, tgt = train_case_from_fixture(fx)
+    fx2 = load_fixture("train_small_n2")
+    _, _, _, dd2, tgt2 = train_case_from_fixture(fx2)
+    both = synth.merge_frames([dd3, dd2])
+    assert both["record_len"].tolist() == [3, 2]
+    tg = {k: torch.cat([tgt[k], tgt2[k]], 0).cuda() for k in tgt}
+    grads = []
+    for rep in range(2):
+        model = _model(args, sd)
+        out = forward_train(model, both, topk=[500, 1200])
+        assert out["psm"].shape[0] == 2 and out["rm"].shape[0] == 2 and out["obj"].shape[0] == 2
+        loss = _loss(args)(out, tg)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss.detach())
+        g = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        assert all(torch.isfinite(v).all() for v in g.values())
+        assert len(g) == 85                                  # everything but the (gradient-free) gaussian filter
+        grads.append(g)
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
