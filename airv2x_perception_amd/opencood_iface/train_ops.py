@@ -428,7 +428,6 @@ class PillarEncode(torch.autograd.Function):
                 stats_out.append((mean, var, int(N)))
             saved.append((S, F, mean64, rstd, scale, shift, smap, Wc))
         ctx.groups, ctx.saved, ctx.dims = groups, saved, (ny, nx)
-        ctx.params = params
         return canvas
 
     @staticmethod

@@ -3,7 +3,6 @@ reproduces one training step of the REFERENCE model (tests/golden/train_small_*.
 head maps, losses, the gradient of every parameter and every BatchNorm buffer after the step."""
 import numpy as np
 import pytest
-import torch
 
 from oracle import loss_oracle as lo
 from oracle import where2comm_oracle as orc
