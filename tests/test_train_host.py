@@ -1,0 +1,73 @@
+"""CPU: host-side pieces of the training path (opencood_iface/train_ops.py, train_where2com.py) -- weight packings, the
+space-to-depth view of the transposed convolutions' gradients, nn.BatchNorm's running-statistics rule, parameter freezing."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from airv2x_perception_amd import synth
+from airv2x_perception_amd.opencood_iface import train_ops as T
+from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, pack_deconv_weight
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (14, 256, 1, 1), (30, 256, 1, 1), (256, 384, 1, 1), (128, 64, 3, 3)])
+def test_device_side_conv_packing_equals_the_host_packing(shape):
+    w = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    a, ca = T.pack_conv_weight_dev(w)
+    b, cb = pack_conv_weight(w)
+    assert ca == cb and a.shape == b.shape and torch.equal(a.contiguous(), b)
+
+
+@pytest.mark.parametrize("shape", [(64, 128, 1, 1), (128, 128, 2, 2), (256, 128, 4, 4)])
+def test_device_side_deconv_packing_equals_the_host_packing(shape):
+    w = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    a, na = T.pack_deconv_weight_dev(w)
+    b, nb = pack_deconv_weight(w)
+    assert na == nb and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("s", [1, 2, 4])
+def test_space_to_depth_view_is_the_transposed_convolution_s_gradient_layout(s):
+    """dx of ConvTranspose2d(k = s, stride = s) = 1x1 GEMM of the space-to-depth view of dy with W[ci][(i, j, co)]; dW likewise."""
+    g = torch.Generator().manual_seed(s)
+    n, h, w, cin, cout = 2, 3, 5, 8, 4
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cin, cout, s, s, generator=g, requires_grad=True)
+    y = torch.nn.functional.conv_transpose2d(x, wt, None, stride=s)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d2 = T._space_to_depth(gy.permute(0, 2, 3, 1).contiguous(), s)            # (n, h, w, s*s*cout), column = (i, j, co)
+    wb = wt.detach().permute(0, 2, 3, 1).reshape(cin, s * s * cout)
+    dx = torch.einsum("nhwk,ck->nhwc", d2, wb).permute(0, 3, 1, 2)
+    assert torch.allclose(dx, x.grad, atol=1e-5)
+    dwp = torch.einsum("nhwk,nhwc->kc", d2, x.detach().permute(0, 2, 3, 1))   # [(i, j, co)][ci]
+    dw = dwp.view(s, s, cout, cin).permute(3, 2, 0, 1)
+    assert torch.allclose(dw, wt.grad, atol=1e-4)
+
+
+@pytest.mark.parametrize("times", [1, 2, 3])
+def test_running_statistics_rule_is_nn_batchnorm_s(times):
+    g = torch.Generator().manual_seed(times)
+    bn = nn.BatchNorm2d(6, eps=1e-3, momentum=0.01).train()
+    x = torch.randn(3, 6, 5, 7, generator=g) * 2 + 1
+    for _ in range(times):
+        bn(x)
+    rm, rv, nbt = torch.zeros(6), torch.ones(6), torch.zeros((), dtype=torch.long)
+    xs = x.permute(0, 2, 3, 1).reshape(-1, 6)
+    T.update_running_stats(rm, rv, nbt, (xs.mean(0), xs.var(0, unbiased=False), xs.shape[0]), times)
+    assert torch.allclose(rm, bn.running_mean, atol=1e-7) and torch.allclose(rv, bn.running_var, atol=1e-6)
+    assert int(nbt) == int(bn.num_batches_tracked) == times
+
+
+def test_parameters_are_trainable_and_backbone_fix_freezes_all_but_the_fusion_net():
+    from airv2x_perception_amd.opencood_iface.airv2x_where2com import Airv2xWhere2com
+    args = synth.default_hypes([-25.6, -12.8, -3.0, 25.6, 12.8, 1.0])["model"]["args"]
+    m = Airv2xWhere2com(args)
+    assert all(p.requires_grad for p in m.parameters())
+    m.backbone_fix()
+    left = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert left and all(k.startswith("fusion_net.") for k in left)
+    frozen = Airv2xWhere2com(dict(args, backbone_fix=True))
+    assert [k for k, p in frozen.named_parameters() if p.requires_grad] == left
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.train()({})
