@@ -16,6 +16,7 @@ running-statistics update as often as the reference's schedule does.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import byref, c_void_p
 
 import torch
@@ -217,6 +218,33 @@ def update_running_stats(running_mean, running_var, num_batches_tracked, stats, 
             num_batches_tracked.add_(times)
 
 
+_SIDE = {}
+OVERLAP_WGRAD = os.environ.get("AV2X_TRAIN_OVERLAP", "1") != "0"
+
+
+def _wgrad_and_dgrad(x, dz, weight, stride, pad, need_w, need_x):
+    """The two gradients of a convolution are independent given dz: the weight gradient (one round of <= 256 workgroups, one per
+    CU) goes to a side stream, the data gradient (small maps: partially filled waves of workgroups) stays on the current one --
+    each fills what the other leaves idle.  Same kernels, same bits."""
+    if not (need_w and need_x and OVERLAP_WGRAD):
+        dw = conv_wgrad(x, dz, weight.shape, stride, pad) if need_w else None
+        dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3]) if need_x else None
+        return dw, dx
+    main = torch.cuda.current_stream(x.device)
+    side = _SIDE.get(x.device)
+    if side is None:
+        side = _SIDE[x.device] = torch.cuda.Stream(device=x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw = conv_wgrad(x, dz, weight.shape, stride, pad)
+    dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3])
+    main.wait_stream(side)
+    dw.record_stream(main)      # allocated under the side stream, consumed by autograd on the current one
+    x.record_stream(side)       # read by the side stream: the allocator must not recycle them before it is done
+    dz.record_stream(side)
+    return dw, dx
+
+
 # ------------------------------------------------------------------------------------------------ Conv + BN(batch) + ReLU
 class ConvBNAct(torch.autograd.Function):
     @staticmethod
@@ -238,8 +266,7 @@ class ConvBNAct(torch.autograd.Function):
         x, weight, z, mean, rstd, scale, shift = ctx.saved_tensors
         stride, pad, act = ctx.cfg
         dz, dgamma, dbeta = bn_backward(dy.contiguous(), z, mean, rstd, scale, shift, act)
-        dw = conv_wgrad(x, dz, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
-        dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3]) if ctx.needs_input_grad[0] else None
+        dw, dx = _wgrad_and_dgrad(x, dz, weight, stride, pad, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -327,8 +354,7 @@ class ConvBiasAct(torch.autograd.Function):
             ws = torch.empty(int(r.lib.av2x_channel_sum_workspace_bytes(rows, cout)) // 4 + 4, device=x.device)
             db = torch.empty(cout, device=x.device)
             _lib.check(r.lib.av2x_channel_sum(_P(dz), rows, cout, _P(ws), _P(db), r.stream()), "av2x_channel_sum")
-        dw = conv_wgrad(x, dz, weight.shape, stride, pad) if ctx.needs_input_grad[1] else None
-        dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3]) if ctx.needs_input_grad[0] else None
+        dw, dx = _wgrad_and_dgrad(x, dz, weight, stride, pad, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
         return dx, dw, db, None, None, None
 
 
