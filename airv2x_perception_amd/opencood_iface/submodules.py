@@ -10,7 +10,8 @@ modules return is stored ``channels_last`` (NHWC in memory = the kernels' native
 already channels_last is consumed in place; a plain-contiguous NCHW input costs one layout copy.  Chains
 of these modules therefore never transpose.
 
-Inference only (``.eval()``), CUDA/HIP device only; there is no CPU path.
+CUDA/HIP device only; there is no CPU path.  ``.eval()`` forwards everywhere; ``.train()`` forwards (autograd graph of HIP
+forward / backward ops, ``train_ops.py``) for BaseBEVBackbone and DownsampleConv, the other modules refuse them.
 """
 from __future__ import annotations
 
@@ -44,6 +45,15 @@ def _nhwc(x):
     if y.dtype != torch.float32:
         y = y.float()
     return y if y.is_contiguous() else y.contiguous()
+
+
+def _nhwc_grad(x):
+    """_nhwc that stays on the autograd graph (train mode)."""
+    if x.dim() != 4:
+        raise ValueError(f"expected a (N,C,H,W) tensor, got shape {tuple(x.shape)}")
+    if x.device.type != "cuda":
+        raise RuntimeError("MI355X build: feature maps must live on the GPU (no CPU path)")
+    return x.permute(0, 2, 3, 1).float().contiguous()
 
 
 def _nchw(y):
@@ -226,6 +236,8 @@ class BaseBEVBackbone(_HipModule):
         if len(ups) not in (0, len(model_cfg["layer_nums"])) or any(s < 1 for s in ups):
             raise NotImplementedError("BaseBEVBackbone: down-sampling deblocks / the extra final deblock are not built")
         _declare(self, backbone_param_spec(model_cfg, input_channels, ""))
+        for p_ in self.parameters():
+            p_.requires_grad_(True)          # trainable, as the reference's nn.Module is (train mode below)
         if "deblocks" not in self._modules:
             self.add_module("deblocks", _Node())
         for i in range(len(model_cfg["layer_nums"])):
@@ -263,16 +275,51 @@ class BaseBEVBackbone(_HipModule):
         r.conv(L, x, n, h, w, out, out_ctot=out_ctot, out_coff=out_coff)
         return out
 
-    @torch.no_grad()
+    # ---- train mode: BatchNorm batch statistics + running-statistic updates, differentiable in the input and in
+    #      every parameter; the nodes are train_ops' HIP forward / backward Functions
+    def _train_state(self):
+        P = dict(self.named_parameters())
+        if next(iter(P.values())).device.type != "cuda":
+            raise RuntimeError("BaseBEVBackbone (MI355X build) has no CPU path: move the module to the GPU")
+        return P, self.state_dict(keep_vars=True)
+
+    def _train_block(self, i, x):
+        from .train_where2com import _block
+        P, sd = self._train_state()
+        return _block(P, sd, i, x, self.model_cfg["layer_nums"][i], self.model_cfg["layer_strides"][i], 1, prefix="")
+
+    def _train_deblock(self, i, x):
+        from .train_where2com import _deblock
+        P, sd = self._train_state()
+        return _deblock(P, sd, i, x, 1, prefix="")
+
     def _run_block(self, i, x):
-        return _nchw(self.block_nhwc(i, _nhwc(x)))
+        if self.training:
+            return _nchw(self._train_block(i, _nhwc_grad(x)))
+        with torch.no_grad():
+            return _nchw(self.block_nhwc(i, _nhwc(x)))
 
-    @torch.no_grad()
     def _run_deblock(self, i, x):
-        return _nchw(self.deblock_nhwc(i, _nhwc(x)))
+        if self.training:
+            return _nchw(self._train_deblock(i, _nhwc_grad(x)))
+        with torch.no_grad():
+            return _nchw(self.deblock_nhwc(i, _nhwc(x)))
 
-    @torch.no_grad()
     def forward(self, data_dict):
+        if self.training:
+            x = _nhwc_grad(data_dict["spatial_features"])
+            ups = []
+            for i in range(len(self.model_cfg["layer_nums"])):
+                x = self._train_block(i, x)
+                if self.model_cfg.get("upsample_strides"):
+                    ups.append(self._train_deblock(i, x))
+            out = torch.cat(ups, -1) if len(ups) > 1 else (ups[0] if ups else x)
+            data_dict["spatial_features_2d"] = _nchw(out)
+            return data_dict
+        with torch.no_grad():
+            return self._forward_eval(data_dict)
+
+    def _forward_eval(self, data_dict):
         r = self.runner()
         x = _nhwc(data_dict["spatial_features"])
         n = x.shape[0]
@@ -307,6 +354,8 @@ class DownsampleConv(_HipModule):
         super().__init__()
         self.config = config
         _declare(self, shrink_param_spec(config, ""))
+        for p_ in self.parameters():
+            p_.requires_grad_(True)
 
     def _make_runner(self, device):
         return _Runner(device, sh=dict(self.config))
@@ -322,9 +371,15 @@ class DownsampleConv(_HipModule):
                          torch.empty((n, h, w, r.shrink[-1].cout), dtype=torch.float32, device=r.device))
         return y
 
-    @torch.no_grad()
     def forward(self, x):
-        return _nchw(self.nhwc(_nhwc(x)))
+        if self.training:   # differentiable Conv + bias + ReLU pairs (train_ops.ConvBiasAct)
+            from .train_where2com import _shrink
+            P = dict(self.named_parameters())
+            if next(iter(P.values())).device.type != "cuda":
+                raise RuntimeError("DownsampleConv (MI355X build) has no CPU path: move the module to the GPU")
+            return _nchw(_shrink(P, self.config, _nhwc_grad(x), prefix=""))
+        with torch.no_grad():
+            return _nchw(self.nhwc(_nhwc(x)))
 
 
 class NaiveCompressor(_HipModule):

@@ -35,27 +35,27 @@ def _running(sd, prefix, times):
     return (sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd.get(prefix + ".num_batches_tracked"), times)
 
 
-def _block(P, sd, i, x, n_layers, stride, times):
+def _block(P, sd, i, x, n_layers, stride, times, prefix="backbone."):
     """backbone.blocks[i] (base_bev_backbone.py:41-70) in train mode; BatchNorm running statistics updated ``times`` times."""
     idx = 1
     for li in range(n_layers + 1):
-        bn = f"backbone.blocks.{i}.{idx + 1}"
-        x = T.conv_bn_act(x, P[f"backbone.blocks.{i}.{idx}.weight"], P[bn + ".weight"], P[bn + ".bias"], stride if li == 0 else 1, 1,
+        bn = f"{prefix}blocks.{i}.{idx + 1}"
+        x = T.conv_bn_act(x, P[f"{prefix}blocks.{i}.{idx}.weight"], P[bn + ".weight"], P[bn + ".bias"], stride if li == 0 else 1, 1,
                           running=_running(sd, bn, times))
         idx += 3
     return x
 
 
-def _deblock(P, sd, i, x, times):
-    bn = f"backbone.deblocks.{i}.1"
-    return T.deconv_bn_act(x, P[f"backbone.deblocks.{i}.0.weight"], P[bn + ".weight"], P[bn + ".bias"], running=_running(sd, bn, times))
+def _deblock(P, sd, i, x, times, prefix="backbone."):
+    bn = f"{prefix}deblocks.{i}.1"
+    return T.deconv_bn_act(x, P[f"{prefix}deblocks.{i}.0.weight"], P[bn + ".weight"], P[bn + ".bias"], running=_running(sd, bn, times))
 
 
-def _shrink(P, cfg, x):
+def _shrink(P, cfg, x, prefix="shrink_conv."):
     if not cfg.get("use", True):
         return x
     for li, (k, pd) in enumerate(zip(cfg["kernal_size"], cfg["padding"])):
-        p = f"shrink_conv.layers.{li}.double_conv"
+        p = f"{prefix}layers.{li}.double_conv"
         x = T.conv_bias_act(x, P[p + ".0.weight"], P[p + ".0.bias"], 1, pd, True)
         x = T.conv_bias_act(x, P[p + ".2.weight"], P[p + ".2.bias"], 1, 1, True)
     return x

@@ -404,3 +404,64 @@ def test_batch_of_two_frames_trains():
         grads.append(g)
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+def test_backbone_and_shrink_submodules_train_like_the_reference_modules():
+    """The sub-modules other reference code reaches into in TRAIN mode: BaseBEVBackbone.forward / blocks[i] /
+    deblocks[i] and DownsampleConv.forward against torch autograd of the oracle's train-mode restatement (== the reference's
+    modules): outputs, input / parameter gradients, running statistics."""
+    from airv2x_perception_amd import synth
+    from airv2x_perception_amd.opencood_iface.submodules import BaseBEVBackbone, DownsampleConv
+    hy = synth.default_hypes([-25.6, -12.8, -3.0, 25.6, 12.8, 1.0])
+    args = hy["model"]["args"]
+    bb, sh = args["modality_fusion"]["base_bev_backbone"], args["modality_fusion"]["shrink_header"]
+    sd_all = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=21)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 32, 48, generator=g)
+    # ---- oracle graph
+    sd = {k: v.clone() for k, v in sd_all.items()}
+    pk = [k for k in sd if (k.startswith("backbone.") or k.startswith("shrink_conv.")) and sd[k].is_floating_point()
+          and not k.endswith(("running_mean", "running_var"))]
+    for k in pk:
+        sd[k].requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    with orc.train_mode():
+        sf2d, blocks = orc.backbone_forward(xr, sd, bb)
+        yr = orc.shrink_conv(sf2d, sd, sh)
+    gy = torch.randn(yr.shape, generator=g)
+    gy[yr.detach().abs() < 1e-4] = 0
+    yr.backward(gy)
+    # ---- device modules
+    m = BaseBEVBackbone(bb, 64)
+    m.load_state_dict({k[len("backbone."):]: v for k, v in sd_all.items() if k.startswith("backbone.")})
+    m = m.cuda().train()
+    s = DownsampleConv(sh)
+    s.load_state_dict({k[len("shrink_conv."):]: v for k, v in sd_all.items() if k.startswith("shrink_conv.")})
+    s = s.cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    out = m({"spatial_features": xd})
+    yd = s(out["spatial_features_2d"])
+    yd.backward(gy.cuda())
+    torch.cuda.synchronize()
+    assert_close(yd.detach().cpu(), yr.detach(), 5e-4, 5e-4 * float(yr.detach().abs().max()), "shrink(backbone(x))")
+    rel_close(xd.grad.cpu(), xr.grad, 2e-2, "dx")
+    worst = 0.0
+    for k, p in list(m.named_parameters()) + [("~" + k, p) for k, p in s.named_parameters()]:
+        ref = sd[("shrink_conv." + k[1:]) if k.startswith("~") else ("backbone." + k)].grad
+        worst = max(worst, float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-30))
+    assert worst < 3e-2, worst            # a ~20-ReLU-deep graph: see test_training_step_matches_the_reference
+    for k, b in m.named_buffers():
+        ref = sd["backbone." + k]
+        assert float((b.cpu().double() - ref.double()).abs().max()) <= 1e-4 * max(1.0, float(ref.double().abs().max())), k
+    # blocks[i] / deblocks[i] called directly, as where2comm_fuse.py:218,252 does
+    m2 = BaseBEVBackbone(bb, 64)
+    m2.load_state_dict({k[len("backbone."):]: v for k, v in sd_all.items() if k.startswith("backbone.")})
+    m2 = m2.cuda().train()
+    b0 = m2.blocks[0](x.cuda())
+    u0 = m2.deblocks[0](b0)
+    assert b0.requires_grad and u0.requires_grad
+    assert_close(b0.detach().cpu(), blocks[0].detach(), 5e-4, 5e-4 * float(blocks[0].detach().abs().max()), "blocks[0]")
+    m2.eval()
+    with torch.no_grad():
+        e0 = m2.blocks[0](x.cuda())
+    assert not e0.requires_grad

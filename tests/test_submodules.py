@@ -209,11 +209,15 @@ def test_v2x_transformer_module(gold):
 
 
 @pytest.mark.gpu
-def test_modules_refuse_training_mode(trunk):
+def test_training_mode_of_the_sub_modules(trunk):
+    """BaseBEVBackbone / DownsampleConv train (tests/test_gpu_train.py); the modules without a backward still refuse."""
     bb = trunk["bb"]
     bb.train()
     try:
-        with pytest.raises(NotImplementedError):
-            bb.blocks[0](trunk["sf"])
+        y = bb.blocks[0](trunk["sf"])
+        assert y.requires_grad
     finally:
         bb.eval()
+    vfe = sm.PillarVFE(CFG["pillar_vfe"], 4, synth.DEFAULT_VOXEL, synth.SUBMODULE_RANGE, "rsu").to("cuda").train()
+    with pytest.raises(NotImplementedError):
+        vfe.runner()
