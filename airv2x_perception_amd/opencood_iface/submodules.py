@@ -114,12 +114,12 @@ class _HipModule(nn.Module):
     def _tensors(self):
         return list(self.state_dict(keep_vars=True).values())
 
-    def runner(self):
+    def runner(self, train_ok=False):
         ts = self._tensors()
         dev = ts[0].device if ts else torch.device("cuda", torch.cuda.current_device())
         if dev.type != "cuda":
             raise RuntimeError(f"{type(self).__name__} (MI355X build) has no CPU path: move the module to the GPU")
-        if self.training:
+        if self.training and not train_ok:
             raise NotImplementedError(f"{type(self).__name__}: training is not built; call .eval()")
         ver = tuple(t._version for t in ts) + (dev,)
         if self._runner_obj is None or self._runner_obj.device != dev:
@@ -488,26 +488,56 @@ class Where2comm(_HipModule):
     def _pack(self, r, sd):
         r._load_fusion({"fusion_net." + k: v for k, v in sd.items()}, r._up)
 
-    def runner(self):
+    def runner(self, train_ok=False):
         if not self._tensors():   # no gaussian filter: nothing to version
             if self._runner_obj is None:
                 dev = torch.device("cuda", torch.cuda.current_device())
                 self.__dict__["_runner_obj"] = self._make_runner(dev)
                 self._pack(self._runner_obj, {})
-            if self.training:
-                raise NotImplementedError("Where2comm: training (random top-k masks) is not built; call .eval()")
             return self._runner_obj
-        return super().runner()
+        return super().runner(train_ok)
 
-    def _mask(self, r, psm_single, lens, H, W):
+    def _mask(self, r, psm_single, lens, H, W, topk=None):
         psm = _nhwc(psm_single)
         n, h, w, c = psm.shape
         if (h, w) != (H, W):
             raise NotImplementedError("mask / feature size mismatch (the bilinear resize branch, where2comm_fuse.py:230-236)")
         r.A, r.C = c, 1
-        mask, count, _, rl = r.comm_mask(psm, n, H, W, lens)
+        mask, count, _, rl = r.comm_mask(psm, n, H, W, lens, topk=topk)
         rate = r.comm_rate(count, rl, len(lens), H * W).clone()
         return mask, rate
+
+    def _forward_train(self, x, psm_single, lens, backbone, topk=None, mask=None):
+        """Train mode of the multi-scale fusion (where2comm_fuse.py:214-263 with ``self.training``): random top-K masks (K drawn
+        from python's ``random`` as the reference draws it, one per sample), the backbone's blocks / deblocks with batch
+        statistics, everything differentiable in x and in the backbone's parameters (train_ops' HIP forward / backward nodes).
+        ``topk`` / ``mask``: pin K / replay a recorded mask (tests)."""
+        import random
+
+        from . import train_ops as T
+        if not self.multi_scale or not isinstance(backbone, BaseBEVBackbone):
+            raise NotImplementedError("Where2comm training: the multi-scale fusion over this build's BaseBEVBackbone")
+        r = self.runner(train_ok=True)
+        cur = _nhwc_grad(x)
+        rate = torch.tensor(1, device=r.device)
+        ups = []
+        for i in range(self.num_levels):
+            cur = backbone._train_block(i, cur)
+            n, h, w, c = cur.shape
+            if i == 0 and not self.fully:
+                with torch.no_grad():
+                    if topk is None:
+                        topk = [int(h * w * random.uniform(0, 1)) for _ in lens]          # where2comm_fuse.py:106
+                    m, rate = self._mask(r, psm_single, lens, h, w, topk=topk)
+                    m = m.clone() if mask is None else mask.to(r.device, torch.float32).reshape(n, h, w).contiguous()
+                cur = T.MaskMul.apply(cur, m)
+            outs, a0 = [], 0
+            for k in lens:
+                outs.append(T.PixelAttn.apply(cur[a0:a0 + k]))
+                a0 += k
+            fused = torch.stack(outs)
+            ups.append(backbone._train_deblock(i, fused) if backbone.model_cfg.get("upsample_strides") else fused)
+        return _nchw(torch.cat(ups, -1) if len(ups) > 1 else ups[0]), rate
 
     def _fuse(self, r, x, lens, out):
         n, h, w, c = x.shape
@@ -516,15 +546,22 @@ class Where2comm(_HipModule):
             r.attn([x[j].data_ptr() for j in range(a0, a0 + k)], h * w, c, out[b])
             a0 += k
 
-    @torch.no_grad()
     def forward(self, x, psm_single, record_len, pairwise_t_matrix, backbone=None):
-        r = self.runner()
         lens = _lens(record_len)
         B = pairwise_t_matrix.shape[0]
         if B != len(lens):
             raise ValueError("pairwise_t_matrix batch size does not match record_len")
         if any(k < 1 for k in lens):
             raise ValueError("every sample needs at least the ego agent")
+        if self.training:
+            if sum(lens) != x.shape[0]:
+                raise ValueError("record_len does not sum to the number of agents")
+            return self._forward_train(x, psm_single, lens, backbone)
+        with torch.no_grad():
+            return self._forward_eval(x, psm_single, lens, B, backbone)
+
+    def _forward_eval(self, x, psm_single, lens, B, backbone):
+        r = self.runner()
         cur = _nhwc(x)
         if sum(lens) != cur.shape[0]:
             raise ValueError("record_len does not sum to the number of agents")
