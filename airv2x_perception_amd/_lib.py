@@ -62,6 +62,9 @@ SIGNATURES = {
     "av2x_pillar_vfe_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                            c_void_p]),
+    "av2x_pillar_vfe_backward_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_pillar_gather": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_channel_sum_workspace_bytes": (c_uint64, [c_int64, c_int32]),
     "av2x_channel_sum": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "av2x_generate_label": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p,

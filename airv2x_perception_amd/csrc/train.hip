@@ -339,7 +339,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 
 constexpr int kBwdW = kFeat + 2;   // per channel: G[0..9], d beta, d gamma
 
-// lane = output channel.  part: [workgroup][64][12] doubles.
+// lane = output channel.  part: [workgroup][64][12] doubles.  ROWS: ``dcanvas`` is the (n_pillars, 64) gradient of the pillar
+// features themselves (the stand-alone PillarVFE module) instead of the canvas it was scattered into.
+template <bool ROWS>
 __global__ __launch_bounds__(256) void pillar_backward_kernel(const float4* __restrict__ vox, const int4* __restrict__ coords,
                                                               const int* __restrict__ npts, int n_pillars,
                                                               const float* __restrict__ pfn_w, const float* __restrict__ bn_scale,
@@ -387,7 +389,9 @@ __global__ __launch_bounds__(256) void pillar_backward_kernel(const float4* __re
         }
         if (num < kPts && sh > best) { best = sh; best_lin = 0.f; best_q = kPts; }   // a padded row wins: features are zero
         float g = 0.f;
-        if (best_q >= 0 && c.x >= 0 && c.x < n_agents && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx) {
+        if (ROWS) {
+            if (best_q >= 0) g = dcanvas[(size_t)pil * 64 + lane];
+        } else if (best_q >= 0 && c.x >= 0 && c.x < n_agents && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx) {
             const int agent = slot_map ? slot_map[c.x] : agent0 + c.x;
             const size_t pixel = ((size_t)agent * ny + c.z) * nx + c.w + c.y;
             g = dcanvas[pixel * 64 + lane];
@@ -551,9 +555,54 @@ extern "C" int av2x_pillar_vfe_backward(const float* voxel_features, const int32
     const int blocks = pillar_blocks(n_pillars);
     hipStream_t st = av2x::as_stream(stream);
     double* part = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL(pillar_backward_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(voxel_features),
+    hipLaunchKernelGGL(pillar_backward_kernel<false>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(voxel_features),
                        reinterpret_cast<const int4*>(voxel_coords), voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, mean, rstd,
                        geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], dcanvas, canvas_agent0, slot_map, n_agents_type, ny, nx, part);
     hipLaunchKernelGGL(sum_partials_kernel, dim3((64 * kBwdW + 7) / 8), dim3(256), 0, st, part, blocks, 64 * kBwdW, out);
     return av2x::check_launch("pillar_vfe_backward kernels");
+}
+
+extern "C" int av2x_pillar_vfe_backward_rows(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                                             int32_t n_pillars, const float* pfn_w, const float* bn_scale, const float* bn_shift,
+                                             const float* mean, const float* rstd, const float* geom, const float* dfeatures,
+                                             void* workspace, double* out, av2x_stream_t stream) {
+    if (!voxel_features || !voxel_coords || !voxel_num_points || !pfn_w || !bn_scale || !bn_shift || !mean || !rstd || !geom ||
+        !dfeatures || !workspace || !out)
+        return av2x::fail("av2x_pillar_vfe_backward_rows: null argument");
+    if (n_pillars <= 0) return av2x::fail("av2x_pillar_vfe_backward_rows: bad sizes");
+    const int blocks = pillar_blocks(n_pillars);
+    hipStream_t st = av2x::as_stream(stream);
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(pillar_backward_kernel<true>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(voxel_features),
+                       reinterpret_cast<const int4*>(voxel_coords), voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, mean, rstd,
+                       geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], dfeatures, 0, (const int*)nullptr, 0, 0, 0, part);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((64 * kBwdW + 7) / 8), dim3(256), 0, st, part, blocks, 64 * kBwdW, out);
+    return av2x::check_launch("pillar_vfe_backward_rows kernels");
+}
+
+// PointPillarScatter backward (point_pillar_scatter.py:59-68): d pillar_features[pil, :] = d canvas[agent, y, x, :]
+__global__ void pillar_gather_kernel(const float4* __restrict__ dcanvas, const int4* __restrict__ coords, int n_pillars, int c4,
+                                     float4* __restrict__ dfeat, int n_agents, int ny, int nx) {
+    const size_t total = (size_t)n_pillars * c4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pil = (int)(i / c4), q = (int)(i % c4);
+        const int4 c = coords[pil];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c.x >= 0 && c.x < n_agents && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx)
+            v = dcanvas[(((size_t)c.x * ny + c.z) * nx + c.w + c.y) * c4 + q];
+        dfeat[i] = v;
+    }
+}
+
+extern "C" int av2x_pillar_gather(const float* dcanvas, const int32_t* voxel_coords, int32_t n_pillars, int32_t channels,
+                                  float* dfeatures, int32_t n_agents, int32_t ny, int32_t nx, av2x_stream_t stream) {
+    if (n_pillars == 0) return 0;
+    if (!dcanvas || !voxel_coords || !dfeatures) return av2x::fail("av2x_pillar_gather: null argument");
+    if (n_pillars < 0 || channels <= 0 || channels % 4 || n_agents <= 0 || ny <= 0 || nx <= 0)
+        return av2x::fail("av2x_pillar_gather: bad sizes (channels must be a multiple of 4)");
+    const size_t total = (size_t)n_pillars * (channels / 4);
+    hipLaunchKernelGGL(pillar_gather_kernel, dim3(ew_blocks(total)), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(dcanvas), reinterpret_cast<const int4*>(voxel_coords), n_pillars, channels / 4,
+                       reinterpret_cast<float4*>(dfeatures), n_agents, ny, nx);
+    return av2x::check_launch("pillar_gather_kernel");
 }

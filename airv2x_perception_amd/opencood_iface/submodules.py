@@ -11,7 +11,7 @@ already channels_last is consumed in place; a plain-contiguous NCHW input costs 
 of these modules therefore never transpose.
 
 CUDA/HIP device only; there is no CPU path.  ``.eval()`` forwards everywhere; ``.train()`` forwards (autograd graph of HIP
-forward / backward ops, ``train_ops.py``) for BaseBEVBackbone and DownsampleConv, the other modules refuse them.
+forward / backward ops, ``train_ops.py``) for PillarVFE, PointPillarScatter, BaseBEVBackbone, DownsampleConv and Where2comm; the other modules refuse them.
 """
 from __future__ import annotations
 
@@ -166,6 +166,8 @@ class PillarVFE(_HipModule):
         self.num_filters = list(model_cfg["num_filters"])
         self.voxel_size, self.point_cloud_range = list(voxel_size), list(point_cloud_range)
         _declare(self, pfn_param_spec(""))
+        for p_ in self.parameters():
+            p_.requires_grad_(True)          # trainable, as the reference's nn.Module is (train mode below)
 
     def get_output_feature_dim(self):
         return self.num_filters[-1]
@@ -173,8 +175,39 @@ class PillarVFE(_HipModule):
     def _pack(self, r, sd):
         r.pfn_w = r.load_pfn(sd, "", self.voxel_size, self.point_cloud_range)
 
-    @torch.no_grad()
     def forward(self, batch_dict):
+        if self.training:
+            return self._forward_train(batch_dict)
+        with torch.no_grad():
+            return self._forward_eval(batch_dict)
+
+    def _forward_train(self, batch_dict):
+        """Train mode: BatchNorm1d batch statistics (and the running-statistics update), ``pillar_features`` attached to the
+        autograd graph of the Linear / BatchNorm1d parameters (train_ops.PillarFeatures)."""
+        from ctypes import c_float
+
+        from . import train_ops as T
+        P = dict(self.named_parameters())
+        dev = next(iter(P.values())).device
+        if dev.type != "cuda":
+            raise RuntimeError("PillarVFE (MI355X build) has no CPU path: move the module to the GPU")
+        bd = batch_dict[self.agent_type]["batch_merged_lidar_features_torch"]
+        vf = bd["voxel_features"].to(dev).contiguous().float()
+        vc = bd["voxel_coords"].to(dev).contiguous().to(torch.int32)
+        vn = bd["voxel_num_points"].to(dev).contiguous().to(torch.int32)
+        if vf.shape[1:] != (32, 4):
+            raise ValueError(f"voxel_features must be (M,32,4), got {tuple(vf.shape)}")
+        vs, rng = self.voxel_size, self.point_cloud_range
+        geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
+        st = []
+        p = "pfn_layers.0"
+        out = T.PillarFeatures.apply(vf, vc, vn, geom, T.BN_EPS, st, P[p + ".linear.weight"], P[p + ".norm.weight"], P[p + ".norm.bias"])
+        sd = self.state_dict(keep_vars=True)
+        T.update_running_stats(sd[p + ".norm.running_mean"], sd[p + ".norm.running_var"], sd.get(p + ".norm.num_batches_tracked"), st[0], 1)
+        bd["pillar_features"] = out
+        return bd
+
+    def _forward_eval(self, batch_dict):
         r = self.runner()
         bd = batch_dict[self.agent_type]["batch_merged_lidar_features_torch"]
         vf = bd["voxel_features"].to(r.device).contiguous().float()
@@ -200,11 +233,25 @@ class PointPillarScatter(nn.Module):
         self.nx, self.ny, self.nz = [int(v) for v in model_cfg["grid_size"]]
         assert self.nz == 1
 
-    @torch.no_grad()
     def forward(self, batch_dict):
-        feats, coords = batch_dict["pillar_features"], batch_dict["voxel_coords"]
+        feats = batch_dict["pillar_features"]
         if feats.device.type != "cuda":
             raise RuntimeError("PointPillarScatter (MI355X build) has no CPU path")
+        if torch.is_grad_enabled() and feats.requires_grad:    # train mode upstream: keep the graph (train_ops.PillarScatter)
+            from . import train_ops as T
+            coords = batch_dict["voxel_coords"].to(feats.device).contiguous().to(torch.int32)
+            if feats.shape[1] != self.num_bev_features:
+                raise ValueError(f"pillar_features has {feats.shape[1]} channels, expected {self.num_bev_features}")
+            batch_size = int(coords[:, 0].max().item()) + 1
+            sf = _nchw(T.PillarScatter.apply(feats.float(), coords, batch_size, self.ny, self.nx))
+            batch_dict["spatial_features_3d"] = sf.unsqueeze(2)
+            batch_dict["spatial_features"] = sf
+            return batch_dict
+        with torch.no_grad():
+            return self._forward_eval(batch_dict)
+
+    def _forward_eval(self, batch_dict):
+        feats, coords = batch_dict["pillar_features"], batch_dict["voxel_coords"]
         lib = _lib.load()
         feats = feats.contiguous().float()
         coords = coords.to(feats.device).contiguous().to(torch.int32)

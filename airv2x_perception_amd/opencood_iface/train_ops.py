@@ -488,3 +488,85 @@ class PillarEncode(torch.autograd.Function):
 
 def pillar_encode(groups, n_total, ny, nx, params, eps=BN_EPS, stats_out=None):
     return PillarEncode.apply(groups, n_total, ny, nx, eps, stats_out, *params)
+
+
+# ------------------------------------------------------------------------------------------------ the stand-alone halves
+def _pillar_stats(lib, st, vf, vc, vn, geom, W, dev):
+    M = int(vf.shape[0])
+    ws = torch.empty(int(lib.av2x_pillar_train_workspace_bytes(M)) // 8 + 1, dtype=torch.float64, device=dev)
+    mom = torch.empty(110, dtype=torch.float64, device=dev)
+    _lib.check(lib.av2x_pillar_moments(_P(vf), _P(vc), _P(vn), M, geom, _P(ws), _P(mom), st), "av2x_pillar_moments")
+    N = 32.0 * M
+    S, F = mom[:10], mom[10:].view(10, 10)
+    Wd = W.detach().double()
+    mean64 = Wd @ S / N
+    var64 = ((Wd @ F) * Wd).sum(1) / N - mean64 * mean64
+    return S, F, mean64, mean64.float(), var64.clamp_min(0).float(), N
+
+
+def _pillar_param_grads(out, S, F, mean64, rstd, scale, Wc, N):
+    G, dbeta, dgamma = out[:, :10], out[:, 10], out[:, 11]
+    Wd = Wc.double()
+    xf = rstd.double().unsqueeze(1) * (Wd @ F - mean64.unsqueeze(1) * S.unsqueeze(0))
+    dW = scale.double().unsqueeze(1) * (G - (dbeta / N).unsqueeze(1) * S.unsqueeze(0) - (dgamma / N).unsqueeze(1) * xf)
+    return dW.float(), dgamma.float(), dbeta.float()
+
+
+class PillarFeatures(torch.autograd.Function):
+    """PillarVFE alone in train mode (airv2x_pillar_vfe.py:105-160): (M, 32, 4) pillars -> (M, 64) features, BatchNorm1d batch
+    statistics, differentiable in the Linear / BatchNorm1d parameters."""
+
+    @staticmethod
+    def forward(ctx, vf, vc, vn, geom, eps, stats_out, W, gamma, beta):
+        dev = vf.device
+        r = _runner(dev)
+        lib, st = r.lib, r.stream()
+        g = ctypes.cast(geom, c_void_p)
+        S, F, mean64, mean, var, N = _pillar_stats(lib, st, vf, vc, vn, g, W, dev)
+        rstd, scale, shift = _fold(mean, var, gamma, beta, eps)
+        Wc = W.detach().contiguous()
+        out = torch.empty((vf.shape[0], 64), dtype=torch.float32, device=dev)
+        _lib.check(lib.av2x_pillar_vfe(_P(vf), _P(vc), _P(vn), int(vf.shape[0]), _P(Wc), _P(scale), _P(shift), g, _P(out), st), "av2x_pillar_vfe")
+        if stats_out is not None:
+            stats_out.append((mean, var, int(N)))
+        ctx.saved = (vf, vc, vn, geom, S, F, mean64, rstd, scale, shift, Wc, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        vf, vc, vn, geom, S, F, mean64, rstd, scale, shift, Wc, N = ctx.saved
+        dev = vf.device
+        r = _runner(dev)
+        M = int(vf.shape[0])
+        ws = torch.empty(int(r.lib.av2x_pillar_train_workspace_bytes(M)) // 8 + 1, dtype=torch.float64, device=dev)
+        out = torch.empty((64, 12), dtype=torch.float64, device=dev)
+        mean = mean64.float()
+        _lib.check(r.lib.av2x_pillar_vfe_backward_rows(_P(vf), _P(vc), _P(vn), M, _P(Wc), _P(scale), _P(shift), _P(mean), _P(rstd),
+                                                       ctypes.cast(geom, c_void_p), _P(dfeat.contiguous()), _P(ws), _P(out), r.stream()),
+                   "av2x_pillar_vfe_backward_rows")
+        dW, dgamma, dbeta = _pillar_param_grads(out, S, F, mean64, rstd, scale, Wc, N)
+        return None, None, None, None, None, None, dW, dgamma, dbeta
+
+
+class PillarScatter(torch.autograd.Function):
+    """PointPillarScatter (point_pillar_scatter.py:39-80): (M, C) features + (M, 4) [agent, z, y, x] -> (n, ny, nx, C) canvas;
+    backward gathers the canvas gradient at the pillars."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, n, ny, nx):
+        r = _runner(feats.device)
+        feats = feats.contiguous()
+        M, C = feats.shape
+        canvas = torch.zeros((n, ny, nx, C), dtype=torch.float32, device=feats.device)
+        _lib.check(r.lib.av2x_pillar_scatter(_P(feats), _P(coords), M, C, _P(canvas), n, ny, nx, r.stream()), "av2x_pillar_scatter")
+        ctx.saved = (coords, M, C, n, ny, nx)
+        return canvas
+
+    @staticmethod
+    def backward(ctx, dcanvas):
+        coords, M, C, n, ny, nx = ctx.saved
+        r = _runner(dcanvas.device)
+        dcanvas = dcanvas.contiguous()
+        dfeat = torch.empty((M, C), dtype=torch.float32, device=dcanvas.device)
+        _lib.check(r.lib.av2x_pillar_gather(_P(dcanvas), _P(coords), M, C, _P(dfeat), n, ny, nx, r.stream()), "av2x_pillar_gather")
+        return dfeat, None, None, None, None

@@ -342,6 +342,15 @@ int av2x_pillar_vfe_backward(const float* voxel_features, const int32_t* voxel_c
                              const float* mean, const float* rstd, const float* geom, const float* dcanvas,
                              int32_t canvas_agent0, const int32_t* slot_map, int32_t n_agents_type, int32_t ny, int32_t nx,
                              void* workspace, double* out, av2x_stream_t stream);
+/* The stand-alone halves (PillarVFE / PointPillarScatter sub-modules in train mode): av2x_pillar_vfe_backward with the gradient
+ * of the (n_pillars, 64) pillar features instead of the canvas, and the scatter's backward,
+ * dfeatures[pil, :] = dcanvas[agent, y, x, :] (point_pillar_scatter.py:59-68). */
+int av2x_pillar_vfe_backward_rows(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                                  int32_t n_pillars, const float* pfn_w, const float* bn_scale, const float* bn_shift,
+                                  const float* mean, const float* rstd, const float* geom, const float* dfeatures,
+                                  void* workspace, double* out, av2x_stream_t stream);
+int av2x_pillar_gather(const float* dcanvas, const int32_t* voxel_coords, int32_t n_pillars, int32_t channels, float* dfeatures,
+                       int32_t n_agents, int32_t ny, int32_t nx, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Training labels: VoxelPostprocessor.generate_label_airv2x (voxel_postprocessor.py:217-354) with

@@ -260,7 +260,7 @@ def test_training_step_matches_the_reference(name):
     total = crit(out, {k: v.cuda() for k, v in tgt.items()})
     total.backward()
     torch.cuda.synchronize()
-    assert abs(float(total) - fx["losses"][0]) < 2e-4 * abs(fx["losses"][0])
+    assert abs(float(total.detach()) - fx["losses"][0]) < 2e-4 * abs(fx["losses"][0])
     P = dict(model.named_parameters())
     keys = [str(k) for k in fx["grad_keys"]]
     assert sorted(k for k, p in P.items() if p.grad is not None) == sorted(keys)
@@ -538,3 +538,43 @@ def test_where2comm_submodule_trains_like_the_reference_module():
     print(f"where2comm sub-module: Frobenius-relative deviation from float64 -- device median {np.median(list(dev.values())):.2e} worst "
           f"{max(dev.values()):.2e}; fp32 oracle median {np.median(list(ref.values())):.2e} worst {max(ref.values()):.2e}")
     assert max(dev.values()) < 5e-2 and float(np.median(list(dev.values()))) < 1e-2, max(dev.items(), key=lambda kv: kv[1])
+
+
+def test_pillar_vfe_and_scatter_submodules_train():
+    """The stand-alone PillarVFE + PointPillarScatter modules in TRAIN mode (what the reference's Airv2xBase.extract_features
+    runs, airv2x_base_model.py:128-150): canvas, parameter gradients and running statistics against autograd of the oracle."""
+    from airv2x_perception_amd.opencood_iface import submodules as sm
+    fx = load_fixture("train_small_n2")
+    hy, args, sd, dd, tgt = train_case_from_fixture(fx)
+    cfg = args["vehicle"]["lidar"]
+    key = "veh_models.0.0"
+    lid = dd["vehicle"]["batch_merged_lidar_features_torch"]
+    g0 = [int(v) for v in cfg["point_pillar_scatter"]["grid_size"]]
+    nx, ny = g0[0], g0[1]
+    # ---- oracle
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    names = [".pfn_layers.0.linear.weight", ".pfn_layers.0.norm.weight", ".pfn_layers.0.norm.bias"]
+    for suf in names:
+        sd2[key + suf].requires_grad_(True)
+    with orc.train_mode():
+        pf = orc.pillar_vfe(lid["voxel_features"], lid["voxel_num_points"], lid["voxel_coords"], sd2, key, cfg["voxel_size"], cfg["lidar_range"])
+        cref = orc.pillar_scatter(pf, lid["voxel_coords"], 2, nx, ny)
+    gy = torch.randn(cref.shape, generator=torch.Generator().manual_seed(1))
+    cref.backward(gy)
+    # ---- device modules
+    vfe = sm.PillarVFE(cfg["pillar_vfe"], 4, cfg["voxel_size"], cfg["lidar_range"], "vehicle")
+    vfe.load_state_dict({k[len(key) + 1:]: v for k, v in sd.items() if k.startswith(key + ".")})
+    vfe = vfe.cuda().train()
+    scat = sm.PointPillarScatter(cfg["point_pillar_scatter"])
+    bd = vfe({"vehicle": {"batch_merged_lidar_features_torch": {k: v.cuda() for k, v in lid.items()}}})
+    assert bd["pillar_features"].requires_grad
+    out = scat(bd)
+    out["spatial_features"].backward(gy.cuda())
+    torch.cuda.synchronize()
+    assert_close(out["spatial_features"].detach().cpu(), cref.detach(), 2e-4, 2e-4 * float(cref.detach().abs().max()), "canvas")
+    P = dict(vfe.named_parameters())
+    for suf in names:
+        rel_close(P[suf[1:]].grad.cpu(), sd2[key + suf].grad, 5e-4, suf)
+    rel_close(vfe.state_dict()["pfn_layers.0.norm.running_mean"].cpu(), sd2[key + ".pfn_layers.0.norm.running_mean"], 1e-4, "running_mean")
+    rel_close(vfe.state_dict()["pfn_layers.0.norm.running_var"].cpu(), sd2[key + ".pfn_layers.0.norm.running_var"], 1e-4, "running_var")
+    assert int(vfe.state_dict()["pfn_layers.0.norm.num_batches_tracked"]) == int(sd2[key + ".pfn_layers.0.norm.num_batches_tracked"])

@@ -210,7 +210,8 @@ def test_v2x_transformer_module(gold):
 
 @pytest.mark.gpu
 def test_training_mode_of_the_sub_modules(trunk):
-    """BaseBEVBackbone / DownsampleConv train (tests/test_gpu_train.py); the modules without a backward still refuse."""
+    """PillarVFE / PointPillarScatter / BaseBEVBackbone / DownsampleConv / Where2comm train (tests/test_gpu_train.py); the
+    modules without a backward (transformer fusions, compressor) still refuse."""
     bb = trunk["bb"]
     bb.train()
     try:
@@ -218,6 +219,6 @@ def test_training_mode_of_the_sub_modules(trunk):
         assert y.requires_grad
     finally:
         bb.eval()
-    vfe = sm.PillarVFE(CFG["pillar_vfe"], 4, synth.DEFAULT_VOXEL, synth.SUBMODULE_RANGE, "rsu").to("cuda").train()
+    fax = sm.SwapFusionEncoder(CFG["fax"]).to("cuda").train()
     with pytest.raises(NotImplementedError):
-        vfe.runner()
+        fax.runner()
