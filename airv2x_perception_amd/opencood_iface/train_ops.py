@@ -415,6 +415,30 @@ class PixelAttn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ pillar encoders + scatter
+def _pillar_stats(lib, st, vf, vc, vn, geom, W, dev):
+    M = int(vf.shape[0])
+    ws = torch.empty(int(lib.av2x_pillar_train_workspace_bytes(M)) // 8 + 1, dtype=torch.float64, device=dev)
+    mom = torch.empty(110, dtype=torch.float64, device=dev)
+    _lib.check(lib.av2x_pillar_moments(_P(vf), _P(vc), _P(vn), M, geom, _P(ws), _P(mom), st), "av2x_pillar_moments")
+    N = 32.0 * M
+    S, F = mom[:10], mom[10:].view(10, 10)
+    Wd = W.detach().double()
+    mean64 = Wd @ S / N
+    var64 = ((Wd @ F) * Wd).sum(1) / N - mean64 * mean64
+    return S, F, mean64, mean64.float(), var64.clamp_min(0).float(), N
+
+
+def _pillar_param_grads(out, S, F, mean64, rstd, scale, Wc, N):
+    """(d linear.weight, d norm.weight, d norm.bias) from the kernel's G[c][k] = sum g feat_k, d beta, d gamma and the moments:
+    d lin_r = scale (g_r - d beta / N - xhat_r d gamma / N), dW = sum_r d lin_r (x) feat_r, with
+    sum_r xhat_r (x) feat_r = rstd (W F - mean S^T)."""
+    G, dbeta, dgamma = out[:, :10], out[:, 10], out[:, 11]
+    Wd = Wc.double()
+    xf = rstd.double().unsqueeze(1) * (Wd @ F - mean64.unsqueeze(1) * S.unsqueeze(0))
+    dW = scale.double().unsqueeze(1) * (G - (dbeta / N).unsqueeze(1) * S.unsqueeze(0) - (dgamma / N).unsqueeze(1) * xf)
+    return dW.float(), dgamma.float(), dbeta.float()
+
+
 class PillarEncode(torch.autograd.Function):
     """Every agent type's PillarVFE (train-mode BatchNorm1d) + PointPillarScatter into one canvas (n, ny, nx, 64).
 
@@ -433,16 +457,8 @@ class PillarEncode(torch.autograd.Function):
             W, gamma, beta = params[3 * gi:3 * gi + 3]
             vf, vc, vn = g["vf"], g["vc"], g["vn"]
             M = int(vf.shape[0])
-            ws = torch.empty(int(lib.av2x_pillar_train_workspace_bytes(M)) // 8 + 1, dtype=torch.float64, device=dev)
-            mom = torch.empty(110, dtype=torch.float64, device=dev)
             geom = ctypes.cast(g["geom"], c_void_p)
-            _lib.check(lib.av2x_pillar_moments(_P(vf), _P(vc), _P(vn), M, geom, _P(ws), _P(mom), st), "av2x_pillar_moments")
-            N = 32.0 * M
-            S, F = mom[:10], mom[10:].view(10, 10)
-            Wd = W.detach().double()
-            mean64 = Wd @ S / N
-            var64 = ((Wd @ F) * Wd).sum(1) / N - mean64 * mean64
-            mean, var = mean64.float(), var64.clamp_min(0).float()
+            S, F, mean64, mean, var, N = _pillar_stats(lib, st, vf, vc, vn, geom, W, dev)
             rstd, scale, shift = _fold(mean, var, gamma, beta, eps)
             Wc = W.detach().contiguous()
             sl = g["slots"]
@@ -476,13 +492,7 @@ class PillarEncode(torch.autograd.Function):
             _lib.check(lib.av2x_pillar_vfe_backward(_P(vf), _P(vc), _P(vn), M, _P(Wc), _P(scale), _P(shift), _P(mean), _P(rstd),
                                                     ctypes.cast(g["geom"], c_void_p), _P(dcanvas), sl[0], _P(smap), len(sl), ny, nx,
                                                     _P(ws), _P(out), st), "av2x_pillar_vfe_backward")
-            G, dbeta, dgamma = out[:, :10], out[:, 10], out[:, 11]
-            Wd = Wc.double()
-            # d lin_r = scale (g_r - d beta / N - xhat_r d gamma / N);  dW = sum_r d lin_r (x) feat_r, with
-            # sum_r xhat_r (x) feat_r = rstd (W F - mean S^T)
-            xf = rstd.double().unsqueeze(1) * (Wd @ F - mean64.unsqueeze(1) * S.unsqueeze(0))
-            dW = scale.double().unsqueeze(1) * (G - (dbeta / N).unsqueeze(1) * S.unsqueeze(0) - (dgamma / N).unsqueeze(1) * xf)
-            grads += [dW.float(), dgamma.float(), dbeta.float()]
+            grads += list(_pillar_param_grads(out, S, F, mean64, rstd, scale, Wc, N))
         return (None, None, None, None, None, None) + tuple(grads)
 
 
@@ -491,27 +501,6 @@ def pillar_encode(groups, n_total, ny, nx, params, eps=BN_EPS, stats_out=None):
 
 
 # ------------------------------------------------------------------------------------------------ the stand-alone halves
-def _pillar_stats(lib, st, vf, vc, vn, geom, W, dev):
-    M = int(vf.shape[0])
-    ws = torch.empty(int(lib.av2x_pillar_train_workspace_bytes(M)) // 8 + 1, dtype=torch.float64, device=dev)
-    mom = torch.empty(110, dtype=torch.float64, device=dev)
-    _lib.check(lib.av2x_pillar_moments(_P(vf), _P(vc), _P(vn), M, geom, _P(ws), _P(mom), st), "av2x_pillar_moments")
-    N = 32.0 * M
-    S, F = mom[:10], mom[10:].view(10, 10)
-    Wd = W.detach().double()
-    mean64 = Wd @ S / N
-    var64 = ((Wd @ F) * Wd).sum(1) / N - mean64 * mean64
-    return S, F, mean64, mean64.float(), var64.clamp_min(0).float(), N
-
-
-def _pillar_param_grads(out, S, F, mean64, rstd, scale, Wc, N):
-    G, dbeta, dgamma = out[:, :10], out[:, 10], out[:, 11]
-    Wd = Wc.double()
-    xf = rstd.double().unsqueeze(1) * (Wd @ F - mean64.unsqueeze(1) * S.unsqueeze(0))
-    dW = scale.double().unsqueeze(1) * (G - (dbeta / N).unsqueeze(1) * S.unsqueeze(0) - (dgamma / N).unsqueeze(1) * xf)
-    return dW.float(), dgamma.float(), dbeta.float()
-
-
 class PillarFeatures(torch.autograd.Function):
     """PillarVFE alone in train mode (airv2x_pillar_vfe.py:105-160): (M, 32, 4) pillars -> (M, 64) features, BatchNorm1d batch
     statistics, differentiable in the Linear / BatchNorm1d parameters."""
