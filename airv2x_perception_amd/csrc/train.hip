@@ -99,18 +99,20 @@ __global__ __launch_bounds__(256) void moments_stage1(const float* __restrict__ 
     }
 }
 
-// Sums the slab partials: a workgroup owns 8 channels, 32 lanes walk the slabs (lane l takes slabs l, l + 32, ...), then the 32
-// lane sums are added in lane order -- fixed order, fp64.  MODE 0: out0 = mean, out1 = biased variance.  MODE 1: out0 = sum g
-// (d beta), out1 = sum g xhat (d gamma).  MODE 2: out0 = the first sum only.
+// Sums the slab partials: a workgroup owns 2 channels, 128 lanes walk the slabs (lane l takes slabs l, l + 128, ...), then the
+// lane sums are added in a fixed two-level order (16 groups of 8 lanes, then the 16 groups) -- fp64, bit-reproducible.
+// MODE 0: out0 = mean, out1 = biased variance.  MODE 1: out0 = sum g (d beta), out1 = sum g xhat (d gamma).  MODE 2: out0 = the
+// first sum only.
 template <int MODE>
 __global__ __launch_bounds__(256) void moments_stage2(const double* __restrict__ part, int nslabs, int c, double n,
                                                       float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ double red[2][32][8];
-    const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
-    const int ch = blockIdx.x * 8 + j;
+    __shared__ double red[2][128][2];
+    __shared__ double red2[2][16][2];
+    const int j = threadIdx.x & 1, sl = threadIdx.x >> 1;
+    const int ch = blockIdx.x * 2 + j;
     double a = 0.0, b = 0.0;
     if (ch < c) {
-        for (int k = sl; k < nslabs; k += 32) {
+        for (int k = sl; k < nslabs; k += 128) {
             a += part[(size_t)k * 2 * c + ch];
             b += part[(size_t)k * 2 * c + c + ch];
         }
@@ -118,9 +120,16 @@ __global__ __launch_bounds__(256) void moments_stage2(const double* __restrict__
     red[0][sl][j] = a;
     red[1][sl][j] = b;
     __syncthreads();
+    if (sl < 16) {
+        a = 0.0; b = 0.0;
+        for (int k = 0; k < 8; ++k) { a += red[0][sl * 8 + k][j]; b += red[1][sl * 8 + k][j]; }
+        red2[0][sl][j] = a;
+        red2[1][sl][j] = b;
+    }
+    __syncthreads();
     if (sl == 0 && ch < c) {
         a = 0.0; b = 0.0;
-        for (int k = 0; k < 32; ++k) { a += red[0][k][j]; b += red[1][k][j]; }
+        for (int k = 0; k < 16; ++k) { a += red2[0][k][j]; b += red2[1][k][j]; }
         if (MODE == 0) {
             const double m = a / n;
             double v = b / n - m * m;
@@ -446,7 +455,7 @@ extern "C" int av2x_bn_stats(const float* z, int64_t rows, int32_t c, void* work
     double* part = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(moments_stage1<0>, dim3(slabs), dim3(256), 0, st, z, (const float*)nullptr, (size_t)rows, c, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, part);
-    hipLaunchKernelGGL(moments_stage2<0>, dim3((c + 7) / 8), dim3(256), 0, st, part, slabs, c, (double)rows, mean, var);
+    hipLaunchKernelGGL(moments_stage2<0>, dim3((c + 1) / 2), dim3(256), 0, st, part, slabs, c, (double)rows, mean, var);
     return av2x::check_launch("bn_stats kernels");
 }
 
@@ -460,7 +469,7 @@ extern "C" int av2x_channel_sum(const float* x, int64_t rows, int32_t c, void* w
     double* part = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(moments_stage1<0>, dim3(slabs), dim3(256), 0, st, x, (const float*)nullptr, (size_t)rows, c, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, part);
-    hipLaunchKernelGGL(moments_stage2<2>, dim3((c + 7) / 8), dim3(256), 0, st, part, slabs, c, (double)rows, out, (float*)nullptr);
+    hipLaunchKernelGGL(moments_stage2<2>, dim3((c + 1) / 2), dim3(256), 0, st, part, slabs, c, (double)rows, out, (float*)nullptr);
     return av2x::check_launch("channel_sum kernels");
 }
 
@@ -498,7 +507,7 @@ extern "C" int av2x_bn_backward(const float* dy, const float* z, int64_t rows, i
     hipStream_t st = av2x::as_stream(stream);
     double* part = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(moments_stage1<1>, dim3(slabs), dim3(256), 0, st, z, dy, (size_t)rows, c, mean, rstd, scale, shift, act, part);
-    hipLaunchKernelGGL(moments_stage2<1>, dim3((c + 7) / 8), dim3(256), 0, st, part, slabs, c, (double)rows, dbeta, dgamma);
+    hipLaunchKernelGGL(moments_stage2<1>, dim3((c + 1) / 2), dim3(256), 0, st, part, slabs, c, (double)rows, dbeta, dgamma);
     const size_t total = (size_t)rows * c;
     hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, z, mean, rstd, scale, shift, dbeta, dgamma,
                        total, c, (float)(1.0 / (double)rows), act, dz);
