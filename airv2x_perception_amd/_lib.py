@@ -53,6 +53,8 @@ SIGNATURES = {
     "av2x_bn_stats": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_bn_finalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_int64, c_float, c_int32, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_bn_train_forward": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float, c_int32, c_int32, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_affine_act": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "av2x_bn_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -496,6 +496,19 @@ extern "C" int av2x_affine_act(const float* z, int64_t rows, int32_t c, const fl
     return av2x::check_launch("affine_act_kernel");
 }
 
+// stats + finalize + normalise in ONE call (four launches): what a train-mode BatchNorm forward is made of
+extern "C" int av2x_bn_train_forward(const float* z, int64_t rows, int32_t c, const float* gamma, const float* beta, float eps,
+                                     float momentum, int32_t times, int32_t act, void* workspace, float* stats5, float* y,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, av2x_stream_t stream) {
+    if (!stats5) return av2x::fail("av2x_bn_train_forward: null argument");
+    float* mean = stats5, *var = stats5 + c, *rstd = stats5 + 2 * (size_t)c, *scale = stats5 + 3 * (size_t)c, *shift = stats5 + 4 * (size_t)c;
+    if (int e = av2x_bn_stats(z, rows, c, workspace, mean, var, stream)) return e;
+    if (int e = av2x_bn_finalize(mean, var, gamma, beta, c, eps, rows, momentum, times, rstd, scale, shift, running_mean, running_var,
+                                 num_batches_tracked, stream))
+        return e;
+    return av2x_affine_act(z, rows, c, scale, shift, act, y, stream);
+}
+
 extern "C" int av2x_bn_backward(const float* dy, const float* z, int64_t rows, int32_t c, const float* mean, const float* rstd,
                                 const float* scale, const float* shift, int32_t act, void* workspace, float* dgamma, float* dbeta,
                                 float* dz, av2x_stream_t stream) {

@@ -205,6 +205,28 @@ def bn_finalize(mean, var, count, gamma, beta, eps, running=None, momentum=BN_MO
     return rstd, scale, shift
 
 
+def bn_train_forward(z, gamma, beta, eps, act, running=None, momentum=BN_MOMENTUM):
+    """Train-mode BatchNorm (+ ReLU) of an NHWC map in one C call: -> (y, mean, var, rstd, scale, shift, count)."""
+    r = _runner(z.device)
+    c = z.shape[-1]
+    rows = z.numel() // c
+    ws = torch.empty(int(r.lib.av2x_bn_workspace_bytes(rows, c)) // 8 + 1, dtype=torch.float64, device=z.device)
+    st5 = torch.empty((5, c), dtype=torch.float32, device=z.device)
+    y = torch.empty_like(z)
+    rm = rv = nbt = None
+    times = 0
+    if running is not None:
+        rm, rv, nbt, times = running
+    _lib.check(r.lib.av2x_bn_train_forward(_P(z), rows, c, _P(gamma.detach()), _P(beta.detach()), float(eps), float(momentum), int(times),
+                                           1 if act else 0, _P(ws), _P(st5), _P(y), _P(rm), _P(rv), _P(nbt), r.stream()),
+               "av2x_bn_train_forward")
+    if running is not None:   # the kernel wrote the buffers behind torch's back: consumers key re-packing on the version counters
+        for t in (rm, rv, nbt):
+            if t is not None:
+                torch.autograd.graph.increment_version(t)
+    return y, st5[0], st5[1], st5[2], st5[3], st5[4], rows
+
+
 def update_running_stats(running_mean, running_var, num_batches_tracked, stats, times=1, momentum=BN_MOMENTUM):
     """nn.BatchNorm's train-mode side effect, applied ``times`` times with the same batch statistics (the reference runs
     the backbone more than once per step on the same input: airv2x_where2com.py:119,124)."""
@@ -252,9 +274,7 @@ class ConvBNAct(torch.autograd.Function):
         _check_dev(x)
         x = x.contiguous()
         z = conv_raw(x, weight, stride, pad)
-        mean, var, count = bn_stats(z)
-        rstd, scale, shift = bn_finalize(mean, var, count, gamma, beta, eps, running)
-        y = affine_act(z, scale, shift, act)
+        y, mean, var, rstd, scale, shift, count = bn_train_forward(z, gamma, beta, eps, act, running)
         if stats_out is not None:
             stats_out.append((mean, var, count))
         ctx.save_for_backward(x, weight, z, mean, rstd, scale, shift)
@@ -296,9 +316,7 @@ class DeconvBNAct(torch.autograd.Function):
         L = ConvLayer(wp, None, _zeros(cout, x.device), cin, cout, ncol, 1, 1, 0, 0, _lib.AV2X_DECONV, s)
         z = torch.empty((n, h * s, w * s, cout), dtype=torch.float32, device=x.device)
         r.conv(L, x, n, h, w, z)
-        mean, var, count = bn_stats(z)
-        rstd, scale, shift = bn_finalize(mean, var, count, gamma, beta, eps, running)
-        y = affine_act(z, scale, shift, act)
+        y, mean, var, rstd, scale, shift, count = bn_train_forward(z, gamma, beta, eps, act, running)
         if stats_out is not None:
             stats_out.append((mean, var, count))
         ctx.save_for_backward(x, weight, z, mean, rstd, scale, shift)

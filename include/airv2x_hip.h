@@ -329,6 +329,10 @@ int av2x_bn_finalize(const float* mean, const float* var, const float* gamma, co
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, av2x_stream_t stream);
 int av2x_affine_act(const float* z, int64_t rows, int32_t c, const float* scale, const float* shift, int32_t act, float* y,
                     av2x_stream_t stream);
+/* av2x_bn_stats + av2x_bn_finalize + av2x_affine_act in one call; stats5 (5, c) receives mean, biased var, rstd, scale, shift. */
+int av2x_bn_train_forward(const float* z, int64_t rows, int32_t c, const float* gamma, const float* beta, float eps,
+                          float momentum, int32_t times, int32_t act, void* workspace, float* stats5, float* y,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, av2x_stream_t stream);
 int av2x_bn_backward(const float* dy, const float* z, int64_t rows, int32_t c, const float* mean, const float* rstd,
                      const float* scale, const float* shift, int32_t act, void* workspace, float* dgamma, float* dbeta,
                      float* dz, av2x_stream_t stream);
