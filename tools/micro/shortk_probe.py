@@ -17,19 +17,27 @@ def t_us(call, reps=20):
     for _ in range(reps): call()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
+ROT = 10      # rotate over this many buffer sets (> 1 GB in total): the 256 MB infinity cache cannot hold the working set
 for (M, cin, cout, ctot) in ((140800, 64, 128, 128), (140800, 64, 128, 384), (140800, 256, 32, 32)):
     n, h, w = 4, 100, M // 400
-    x = torch.randn(n, h, w, cin, device="cuda")
+    xs = [torch.randn(n, h, w, cin, device="cuda") for _ in range(ROT)]
     wp, coutp = pack_conv_weight(torch.randn(cout, cin, 1, 1) / cin ** 0.5)
     wp = wp.cuda(); sh = torch.zeros(cout, device="cuda")
-    y = torch.empty(n, h, w, ctot, device="cuda")
-    src = torch.empty(n, h, w, cout, device="cuda")
-    line = f"M={M} K={cin} N={cout} out_ctot={ctot}: copy-yardstick {t_us(lambda: y[..., :cout].copy_(src)):5.1f}us |"
+    ys = [torch.empty(n, h, w, ctot, device="cuda") for _ in range(ROT)]
+    srcs = [torch.empty(n, h, w, cout, device="cuda") for _ in range(ROT)]
+    it = [0]
+    def copy():
+        k = it[0] % ROT; it[0] += 1
+        ys[k][..., :cout].copy_(srcs[k])
+    line = f"M={M} K={cin} N={cout} out_ctot={ctot}: copy-yardstick {t_us(copy, 40):5.1f}us |"
     for bm, bn in Where2ComEngine.TILE_CANDIDATES:
         if (bn & 0x1ff) > coutp: continue
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=ctot, out_coff=0, ks=1, stride=1, pad=0, relu=1, mode=0, up=1, tile=(bm << 16) | bn, sk_wgs=0)
+        def call():
+            k = it[0] % ROT; it[0] += 1
+            _lib.check(lib.av2x_conv2d(byref(d), P(xs[k]), P(wp), None, P(sh), P(ys[k]), st), "c")
         try:
-            us = t_us(lambda: _lib.check(lib.av2x_conv2d(byref(d), P(x), P(wp), None, P(sh), P(y), st), "c"))
+            us = t_us(call, 40)
         except Exception as e:
             continue
         line += f" {bm}x{bn & 0x1ff}{'w8' if bn & 0x8000 else ''}{'p' if bn & 0x4000 else ''}{'g' if bn & 0x200 else ''}:{us:5.1f}"
