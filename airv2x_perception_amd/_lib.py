@@ -74,6 +74,21 @@ SIGNATURES = {
     "av2x_lss_pool_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "av2x_lss_voxel_pool": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_mean2": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "av2x_cam_stem": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                c_void_p, c_void_p]),
+    "av2x_dwconv2d": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_se_slabs": (c_int32, [c_int32]),
+    "av2x_squeeze_excite_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
+    "av2x_squeeze_excite": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                      c_void_p]),
+    "av2x_resize_bilinear": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                       c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "av2x_softmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_lss_lift_pool": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
     "av2x_v2v_aggregate": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_conv2d": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_conv2d_res": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

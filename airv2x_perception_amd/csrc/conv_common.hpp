@@ -57,10 +57,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
                 else if (p.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // exact GELU (nn.GELU())
                 else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));                              // sigmoid (ConvGRU gates)
                 else if (p.relu == 4) v = tanhf(v);   // tanh; with a residual pointer the result is GATED by it (x res, not + res)
+                else if (p.relu == 6) v = v / (1.0f + expf(-v));                                 // swish (EfficientNet MBConv)
                 size_t off;
                 if (p.mode == AV2X_CONV) {
                     off = (size_t)m * p.out_ctot + p.out_coff + co;
                     if (p.res) v = (p.relu == 4) ? v * p.res[(size_t)m * p.Cout + co] : v + p.res[off];
+                    if (p.relu == 5) v = fmaxf(v, 0.f);   // ReLU AFTER the residual add (ResNet BasicBlock)
                 } else {
                     const int img = m / p.HoWo, rem = m - img * p.HoWo;
                     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;

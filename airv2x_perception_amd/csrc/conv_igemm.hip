@@ -447,8 +447,9 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
                               uint64_t workspace_bytes, av2x_stream_t stream) {
     if (!d || !in || !w || !shift || !out) return av2x::fail("av2x_conv2d: null argument");
     if (residual && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: residual only with mode AV2X_CONV");
-    if (d->relu < 0 || d->relu > 4)
-        return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU, 3 sigmoid, 4 tanh [x residual])", d->relu);
+    if (d->relu < 0 || d->relu > 6)
+        return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU, 3 sigmoid, 4 tanh [x residual], 5 ReLU after the residual, 6 swish)", d->relu);
+    if (d->relu == 5 && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: activation 5 (ReLU after the residual) needs mode AV2X_CONV");
     if (d->tile & 0x40000000)   // Winograd F(2x2,3x3): `w` is the transformed packing of av2x_wino_pack_weights
         return wino_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if (d->cin % BK != 0) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);
@@ -465,7 +466,7 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
             return av2x::fail("av2x_conv2d: deconv needs cout %% 32 == 0 and coutp == up*up*cout");
         p.ks = 1; p.stride = 1; p.pad = 0; p.Ho = d->h; p.Wo = d->w;
     } else {
-        if (d->ks != 1 && d->ks != 3) return av2x::fail("av2x_conv2d: ks=%d unsupported", d->ks);
+        if (d->ks != 1 && d->ks != 3 && d->ks != 5 && d->ks != 7) return av2x::fail("av2x_conv2d: ks=%d unsupported (1, 3, 5, 7)", d->ks);
         p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.Ho = d->ho; p.Wo = d->wo;
         if (p.Ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1 || p.Wo != (d->w + 2 * d->pad - d->ks) / d->stride + 1)
             return av2x::fail("av2x_conv2d: output dims %dx%d inconsistent with input/stride/pad", p.Ho, p.Wo);

@@ -1,5 +1,5 @@
-"""``Airv2xWhere2com`` — drop-in for opencood/models/airv2x_where2com.py:19-227 (det task,
-LiDAR modality) whose forward runs entirely in libairv2x_hip.so.
+"""``Airv2xWhere2com`` — drop-in for opencood/models/airv2x_where2com.py:19-227 (det task; LiDAR, camera
+or both modalities per agent type) whose forward runs entirely in libairv2x_hip.so.
 
 Same constructor argument (``hypes["model"]["args"]``), same ``forward(data_dict)`` input
 contract, same output keys (``psm``, ``rm``, ``obj``, ``mask``, ``com``,
@@ -65,8 +65,8 @@ class Airv2xWhere2com(nn.Module):
         if args.get("task", "det") != "det":
             raise NotImplementedError("only the det task is on the MI355X hot path (seg branch out of scope)")
         for t in args["collaborators"]:
-            if args[t]["modalities"] != ["lidar"]:
-                raise NotImplementedError("LiDAR-only agents (camera lift is a later row of SURVEY §8f)")
+            if not args[t]["modalities"] or any(m not in ("lidar", "cam") for m in args[t]["modalities"]):
+                raise NotImplementedError(f"Modality {args[t]['modalities']} not supported for {t}.")   # airv2x_base_model.py:57,78,99
         self.args = args
         self.collaborators = args["collaborators"]
         self.active_sensors = args["active_sensors"]
@@ -113,6 +113,8 @@ class Airv2xWhere2com(nn.Module):
 
     def forward(self, data_dict):
         if self.training:   # the graph torch autograd differentiates, on the HIP forward / backward ops (train_where2com.py)
+            if any("cam" in self.args[t]["modalities"] for t in self.collaborators):
+                raise NotImplementedError("training through the camera encoder is not built (eval-mode forward only); LiDAR-only models train")
             from .train_where2com import forward_train
             return forward_train(self, data_dict)
         eng = self.engine()

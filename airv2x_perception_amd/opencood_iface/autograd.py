@@ -31,6 +31,10 @@ def _runner(device):
     if r is None:
         r = _RUNNERS[device] = _Runner(device)
         r.stream_k = False      # gradients are compared term by term: keep the data-parallel (order-independent) schedules
+        # the agent count changes per frame, so nearly every training step meets new conv shapes: timing ~20 candidates each (with
+        # synchronises, next to the weight-gradient side stream) would stall the first epoch and could persist a noisy pick.
+        # Shipped / cached table hits are still used; a miss falls back to the pick_tile rule.  All candidates are bit-identical.
+        r.tune_on_miss = False
     return r
 
 

@@ -183,6 +183,15 @@ class Where2ComEngine:
                   "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready") + tuple(self.FUSION_WEIGHTS):
             if hasattr(self, k):
                 setattr(other, k, getattr(self, k))
+        if getattr(self, "cam", None):
+            import copy as _copy
+            other.cam = {}
+            for t, c in self.cam.items():       # same packed weights, the other engine's workspace pool
+                cc = _copy.copy(c)
+                cc.eng = other
+                other.cam[t] = cc
+        else:
+            other.cam = {}
         other.tile_cache = self.tile_cache
         other.autotune, other.conv_tile, other.stream_k, other.amp = self.autotune, self.conv_tile, self.stream_k, self.amp
         other.winograd, other.throughput_mode = self.winograd, self.throughput_mode
@@ -217,6 +226,23 @@ class Where2ComEngine:
         vs, rng = voxel_size, lidar_range
         geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
         return (up(sd[p + ".linear.weight"].detach().float()), up(sc), up(sh), geom)
+
+    def load_encoders(self, sd):
+        """Airv2xBase.init_encoders (airv2x_base_model.py:36-99): ``<type>_models.<i>`` is the encoder of the type's i-th modality --
+        Sequential(PillarVFE, PointPillarScatter) for "lidar", LiftSplatShootEncoder for "cam" (opencood_iface/camera.py)."""
+        self.pfn, self.cam = {}, {}
+        for t in AGENT_TYPES:
+            if t not in self.args["collaborators"]:
+                continue
+            for mi, m in enumerate(self.args[t]["modalities"]):
+                if m == "lidar":
+                    cfg = self.args[t]["lidar"]
+                    self.pfn[t] = self.load_pfn(sd, f"{TYPE_PREFIX[t]}.{mi}.0.", cfg["voxel_size"], cfg["lidar_range"])
+                elif m == "cam":
+                    from .camera import CameraEncoder
+                    self.cam[t] = CameraEncoder(self, self.args[t]["cam"], sd, f"{TYPE_PREFIX[t]}.{mi}.", t[:3])
+                else:
+                    raise NotImplementedError(f"Modality {m} not supported for {t}.")
 
     def load_backbone(self, sd, prefix="backbone.", input_channels=64):
         """BaseBEVBackbone weights (blocks: Conv3x3 + BN + ReLU chains, deblocks: ConvTranspose k = s + BN + ReLU)."""
@@ -260,12 +286,7 @@ class Where2ComEngine:
 
     def load_state_dict(self, sd):
         up = self._up
-        self.pfn = {}
-        for t in AGENT_TYPES:
-            if t not in self.args["collaborators"] or "lidar" not in self.args[t]["modalities"]:
-                continue
-            cfg = self.args[t]["lidar"]
-            self.pfn[t] = self.load_pfn(sd, TYPE_PREFIX[t] + ".0.0.", cfg["voxel_size"], cfg["lidar_range"])
+        self.load_encoders(sd)
         self.load_backbone(sd)
         cin = self.load_shrink(sd)
         self.feat_c = cin
@@ -418,7 +439,7 @@ class Where2ComEngine:
         """Layers that run as Winograd F(2x2,3x3): 3x3 / stride 1 / pad 1, ReLU / sigmoid / tanh or no activation, >= 64 input channels
         (8+ chunks of 8; measured faster than the direct kernel from there on, tools/wino_bench.py) and a multiple of 64
         output channels."""
-        return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1, 3, 4)
+        return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1, 3, 4, 5)
                 and L.cin >= 64 and L.cin % 8 == 0 and L.cout % 64 == 0 and L.cout == L.coutp)
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)
@@ -525,8 +546,9 @@ class Where2ComEngine:
                 cands += list(self.PERSIST_CANDIDATES)
             if skc == "tune":
                 cands += list(self.SK_CANDIDATES)
+        # the 32-column tile only where nothing wider divides the GEMM width (32-column heads; the camera trunk's 96 / 160 / 480 / 672)
         return [(bm, bn, g) for bm, bn, g in cands
-                if L.coutp % (bn & 0x01ff) == 0 and not ((bn & 0x01ff) == 32 and L.coutp != 32)]
+                if L.coutp % (bn & 0x01ff) == 0 and not ((bn & 0x01ff) == 32 and L.coutp != 32 and L.coutp % 64 == 0)]
 
     def _tune(self, d, x, L, out, skc=False, key=None):
         """Pick the fastest implementation for this conv shape inside its numerics class (all of a class's candidates give
@@ -546,6 +568,16 @@ class Where2ComEngine:
             hit = self.tune_disk().get(skey)
             if hit is not None and any(((bm << 16) | bn, g) == tuple(hit) for bm, bn, g in cands):
                 return int(hit[0]), int(hit[1])
+        if not getattr(self, "tune_on_miss", True):      # table miss and no timing allowed (training runner): the static rule
+            if skc == "wino":
+                return self.WINO_TILE, 0
+            if skc == "rule":
+                bm, bn, g = cands[-1]
+                return (bm << 16) | bn, g
+            bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
+            return (bm << 16) | bn | (0x0800 if self.amp else (0x0400 if self.split3 else 0)), 0
+        if not cands:
+            raise NotImplementedError(f"no conv tile for cin={L.cin} coutp={L.coutp} ks={L.ks} (class {skc})")
         best, best_t = None, float("inf")
         wgt = _wu(L, self.lib, self.stream()) if skc == "wino" else (_w16(L) if self.amp else (_w3(L) if self.split3 else L.w))
         # tune into a scratch output: `out` may alias the input / residual (in-place transformer updates)
@@ -684,12 +716,48 @@ class Where2ComEngine:
         if "__points__" in slots:
             return self.encode_points(slots["__points__"])
         n_total = sum(record_len)
-        g = [int(v) for v in self.args[next(iter(slots))]["lidar"]["point_pillar_scatter"]["grid_size"]]
+        t0 = next(iter(slots))
+        if "lidar" in self.args[t0]:
+            g = [int(v) for v in self.args[t0]["lidar"]["point_pillar_scatter"]["grid_size"]]
+        else:
+            g = [int(v) for v in self.cam[t0].nx]
         nx, ny = g[0], g[1]
         canvas = self.buf("canvas", (n_total, ny, nx, 64))
+        cam = getattr(self, "cam", {})
+        both = [t for t in slots if t in cam and t in self.pfn]
+        lidar_canvas = self.buf("canvas_lidar", (n_total, ny, nx, 64)) if both else canvas
         st = self.stream()
-        _lib.check(self.lib.av2x_fill_zero(_ptr(canvas), canvas.numel() * 4, st), "av2x_fill_zero")
+        if any(t in self.pfn for t in slots):
+            _lib.check(self.lib.av2x_fill_zero(_ptr(lidar_canvas), lidar_canvas.numel() * 4, st), "av2x_fill_zero")
+        self.encode_lidar(data_dict, slots, lidar_canvas, ny, nx)
+        per = ny * nx * 64
         for t, sl in slots.items():
+            if t not in cam:
+                if both:    # a LiDAR-only type next to multimodal ones: its rows move from the scatter buffer to the frame canvas
+                    for s_ in sl:
+                        _lib.check(self.lib.av2x_mean2(_ptr(lidar_canvas[s_]), None, _ptr(canvas[s_]), per, st), "av2x_mean2")
+                continue
+            ci = data_dict[t].get("batch_merged_cam_inputs")
+            if ci is None:
+                raise ValueError(f"{t}: the model has a camera encoder but the frame carries no batch_merged_cam_inputs")
+            if int(ci["imgs"].shape[0]) != len(sl):
+                raise ValueError(f"{t}: {int(ci['imgs'].shape[0])} camera rigs for {len(sl)} agents")
+            contiguous = sl == list(range(sl[0], sl[0] + len(sl)))
+            if t not in self.pfn and contiguous:     # camera only: BevEncode's last conv writes the canvas rows
+                cam[t].forward(ci, out=canvas[sl[0]:sl[0] + len(sl)])
+                continue
+            bev = cam[t].forward(ci)
+            for j, s_ in enumerate(sl):             # Airv2xBase.fuse_bev (airv2x_base_model.py:167-177): mean over the modality maps
+                _lib.check(self.lib.av2x_mean2(_ptr(bev[j]), _ptr(lidar_canvas[s_]) if t in self.pfn else None, _ptr(canvas[s_]), per, st),
+                           "av2x_mean2")
+        return canvas, ny, nx
+
+    def encode_lidar(self, data_dict, slots, canvas, ny, nx):
+        """Sequential(PillarVFE, PointPillarScatter) of every agent type with a LiDAR encoder, into the (zeroed) canvas rows."""
+        st = self.stream()
+        for t, sl in slots.items():
+            if t not in self.pfn:
+                continue
             lid = data_dict[t]["batch_merged_lidar_features_torch"]
             vf, vc, vn = lid["voxel_features"], lid["voxel_coords"], lid["voxel_num_points"]
             if vf.device != self.device:
@@ -707,7 +775,6 @@ class Where2ComEngine:
             _lib.check(self.lib.av2x_pillar_vfe_scatter(_ptr(vf), _ptr(vc), _ptr(vn), vf.shape[0], _ptr(w), _ptr(sc),
                                                         _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), sl[0],
                                                         _ptr(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter")
-        return canvas, ny, nx
 
     def trunk(self, canvas, n, ny, nx, tag="all", block_out=None, shrink_out=None):
         """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""

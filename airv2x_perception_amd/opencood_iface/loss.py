@@ -62,11 +62,25 @@ class PointPillarLossMultiClass(nn.Module):
         self.loss_dict = {}
         self.use_dir = False
         self.cls_num = args["num_class"]
+        self.validate_class_ids = True
 
     def forward(self, output_dict, target_dict, prefix=""):
         psm, rm, obj = (output_dict[k + prefix] for k in ("psm", "rm", "obj"))
         if psm.device.type != "cuda":
             raise RuntimeError("PointPillarLossMultiClass (MI355X build) has no CPU path")
+        if psm.device.index is not None and psm.device.index != torch.cuda.current_device():
+            raise RuntimeError(f"the loss kernel launches on the current HIP device (cuda:{torch.cuda.current_device()}), psm is on {psm.device}")
+        ac = psm.shape[1] if psm.dim() == 4 else psm.shape[-1]
+        if ac % int(self.cls_num):
+            raise ValueError(f"psm has {ac} channels, not a multiple of num_class = {self.cls_num} (loss args vs model anchor_number * num_class)")
+        cid = target_dict["class_ids"]
+        if cid.numel() and self.validate_class_ids:
+            # the reference's one_hot scatter_ raises on an out-of-range class id (point_pillar_loss_multiclass.py:118-125); the kernel
+            # would silently train such an anchor as background.  One small reduction + read-back per step (set
+            # validate_class_ids = False to skip it once the label pipeline is trusted)
+            lo, hi = int(cid.min()), int(cid.max())
+            if lo < 0 or hi >= int(self.cls_num):
+                raise IndexError(f"class_ids outside [0, {int(self.cls_num)}): min {lo}, max {hi}")
         f32 = lambda t: t.detach().to(psm.device, torch.float32).contiguous()
         cont = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
         total, parts = _PPLoss.apply(cont(psm), cont(rm), cont(obj), f32(target_dict["targets"]), f32(target_dict["pos_equal_one"]),

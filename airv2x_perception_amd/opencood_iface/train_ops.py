@@ -31,6 +31,10 @@ BN_MOMENTUM = 0.01
 def _check_dev(x):
     if x.device.type != "cuda" or x.dtype != torch.float32:
         raise RuntimeError("the training ops run on fp32 HIP tensors only (no CPU path exists)")
+    if x.device.index is not None and x.device.index != torch.cuda.current_device():
+        # every launch goes to the CURRENT device's stream (engine.stream()); a tensor of another device would be handed to it
+        raise RuntimeError(f"the training ops launch on the current HIP device (cuda:{torch.cuda.current_device()}) but the tensor lives on "
+                           f"{x.device}: call torch.cuda.set_device(...) / wrap the step in `with torch.cuda.device(...)`")
 
 
 # ------------------------------------------------------------------------------------------------ weight packing (device side)
@@ -82,7 +86,10 @@ def _packed(r, weight, flipped=False):
     import weakref
     key = (id(weight), flipped)
     ent = _PACKED.get(key)
-    if ent is not None and ent[0] == weight._version and ent[1]() is weight:
+    # ``_version`` does not move for writes through ``.data`` nor for ``module.to(device)`` (which re-points ``.data``): the storage
+    # address and the device are part of the validity check, like the eval engine's _version()
+    stamp = (weight._version, weight.data_ptr(), weight.device)
+    if ent is not None and ent[0] == stamp and ent[1]() is weight:
         return ent[2], ent[3], ent[4]
     src = weight.detach().flip(2, 3).transpose(0, 1) if flipped else weight
     wp, coutp = pack_conv_weight_dev(src)
@@ -94,7 +101,7 @@ def _packed(r, weight, flipped=False):
     if weight.is_leaf and isinstance(weight, torch.nn.Parameter):
         if len(_PACKED) > 4096:
             _PACKED.clear()
-        _PACKED[key] = (weight._version, weakref.ref(weight), wp, coutp, u)
+        _PACKED[key] = (stamp, weakref.ref(weight), wp, coutp, u)
     return wp, coutp, u
 
 

@@ -207,6 +207,24 @@ def shrink_param_spec(sh, prefix=""):
     return spec
 
 
+def encoder_param_spec(args):
+    """Airv2xBase.init_encoders (airv2x_base_model.py:36-99): per agent type one encoder per entry of ``modalities``, in
+    that order -- ``<type>_models.<i>`` is a LiftSplatShootEncoder for "cam", Sequential(PillarVFE, PointPillarScatter)
+    for "lidar"."""
+    spec = []
+    for t in AGENT_TYPES:
+        if t not in args["collaborators"]:
+            continue
+        for i, m in enumerate(args[t]["modalities"]):
+            if m == "lidar":
+                spec += pfn_param_spec(f"{TYPE_PREFIX[t]}.{i}.0.")
+            elif m == "cam":
+                spec += lss_param_spec(args[t]["cam"], f"{TYPE_PREFIX[t]}.{i}.")
+            else:
+                raise NotImplementedError(f"Modality {m} not supported")
+    return spec
+
+
 def where2com_param_spec(args):
     """Ordered (key, shape, kind) manifest of Airv2xWhere2com's state_dict.
 
@@ -215,11 +233,7 @@ def where2com_param_spec(args):
     downsample_conv.py:17-31 (shrink), where2comm_fuse.py:58-62 (gaussian),
     airv2x_where2com.py:59-69 (heads).
     """
-    spec = []
-    for t in AGENT_TYPES:
-        if t not in args["collaborators"]:
-            continue
-        spec += pfn_param_spec(f"{TYPE_PREFIX[t]}.0.0.")
+    spec = encoder_param_spec(args)
     spec += backbone_param_spec(args["modality_fusion"]["base_bev_backbone"], 64, "backbone.")
     spec += shrink_param_spec(args["modality_fusion"]["shrink_header"], "shrink_conv.")
     ks = args["where2com_fusion"]["communication"]["gaussian_smooth"]["k_size"]
@@ -276,6 +290,15 @@ def synthetic_tensor(key, shape, kind, seed=0):
         return t
     if kind == "att_lin":   # query -> key projection of When2com: small, so that the softmax over agents stays mixed
         b = 0.25 * np.sqrt(6.0 / shape[1])
+        return g.uniform(-b, b, size=shape).astype(np.float32)
+    if kind == "se_w":    # squeeze-excite 1x1 convs: modest scale so that the sigmoid gate stays in its mixed range
+        b = np.sqrt(3.0 / int(np.prod(shape[1:])))
+        return g.uniform(-b, b, size=shape).astype(np.float32)
+    if kind == "proj":    # MBConv projection (no activation after it, gate ~0.5 before it)
+        b = np.sqrt(3.0 * 2.5 / int(np.prod(shape[1:])))
+        return g.uniform(-b, b, size=shape).astype(np.float32)
+    if kind == "img_head":   # CamEncode.image_head: the lift SUMS every frustum point of a BEV cell (tens near the camera), so the
+        b = np.sqrt(3.0 * 0.05 / int(np.prod(shape[1:])))          # per-pixel features are kept small for an O(1) pooled map
         return g.uniform(-b, b, size=shape).astype(np.float32)
     if kind in ("conv", "lin", "head", "deconv"):
         if kind == "lin":
@@ -775,7 +798,8 @@ def cam_args(agent_type="vehicle", final_dim=(360, 640), xy=(-140.8, 140.8, -40.
     z, dd, mode = {"vehicle": ([-10, 10, 20.0], [2, 50, 48], "LID"), "rsu": ([-30, 30, 60.0], [2, 50, 48], "LID"),
                    "drone": ([-150, -6, 144], [6, 150, 144], "UD")}[agent_type]
     return {"grid_conf": {"xbound": [xy[0], xy[1], 0.4], "ybound": [xy[2], xy[3], 0.4], "zbound": z, "ddiscr": dd, "mode": mode},
-            "data_aug_conf": {"resize_lim": [0.65, 0.7], "final_dim": list(final_dim), "rot_lim": [0, 0], "H": 720, "W": 1280,
+            "data_aug_conf": {"resize_lim": [0.65, 0.7], "final_dim": list(final_dim), "rot_lim": [-3.6, 3.6] if agent_type == "drone" else [0, 0],
+                              "H": 720, "W": 1280,
                               "rand_flip": False, "bot_pct_lim": [0.0, 0.05]},
             "img_downsample": 8, "img_features": img_features, "bevout_feature": 64, "camera_encoder": "EfficientNet",
             "use_depth_gt": True, "depth_supervision": False}
@@ -802,7 +826,8 @@ def camera_rig(seed, B, N, final_dim=(360, 640), drone=False):
             intr[b, n] = [[f, 0, 640], [0, f, 360], [0, 0, 1]]
             r = g.uniform(0.65, 0.7)
             post_rots[b, n] = np.diag([r, r, 1.0]).astype(np.float32)
-            post_trans[b, n] = [-(1280 * r - final_dim[1]) / 2, -(720 * r - final_dim[0]) * g.uniform(0.9, 1.0), 0.0]
+            # crop: centred in x; in y from the bottom edge (vehicle / RSU augmentation), centred for the nadir drone camera
+            post_trans[b, n] = [-(1280 * r - final_dim[1]) / 2, -(720 * r - final_dim[0]) * (0.5 if drone else g.uniform(0.9, 1.0)), 0.0]
     t = lambda a: torch.from_numpy(a)
     return t(rots), t(trans), t(intr), t(post_rots), t(post_trans)
 
@@ -821,6 +846,143 @@ def lifted_features(seed, B, N, D, fH, fW, C, one_hot=True):
         e = np.exp(lg - lg.max(2, keepdims=True))
         depth = (e / e.sum(2, keepdims=True)).astype(np.float32)
     return torch.from_numpy(depth * feat)
+
+
+# EfficientNet-B0 as the efficientnet_pytorch package lays it out (see oracle/camera_oracle.py for the restatement):
+# (repeats, kernel, stride, expand, in, out); squeeze width = max(1, int(block input * 0.25))
+EFFNET_B0_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+                    (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320))
+
+
+def effnet_b0_blocks():
+    """[(cin, cout, k, stride, expand, se_width, (pad_before, pad_after))] of the 16 MBConv blocks; the depthwise padding is
+    TensorFlow 'same' computed from the package's NOMINAL 224-pixel input (Conv2dStaticSamePadding), whatever the real size."""
+    rows, size = [], 112
+    for rep, k, s, e, ci, co in EFFNET_B0_STAGES:
+        for r in range(rep):
+            st, cin = (s, ci) if r == 0 else (1, co)
+            total = max((-(-size // st) - 1) * st + k - size, 0)
+            rows.append((cin, co, k, st, e, max(1, int(cin * 0.25)), (total // 2, total - total // 2)))
+            size = -(-size // st)
+    return rows
+
+
+def effnet_param_spec(prefix):
+    spec = [(prefix + "_conv_stem.weight", (32, 3, 3, 3), "conv")] + _bn(prefix + "_bn0", 32)
+    for i, (cin, cout, k, st, e, se, _) in enumerate(effnet_b0_blocks()):
+        q, mid = f"{prefix}_blocks.{i}.", cin * e
+        if e != 1:
+            spec += [(q + "_expand_conv.weight", (mid, cin, 1, 1), "conv")] + _bn(q + "_bn0", mid)
+        spec += [(q + "_depthwise_conv.weight", (mid, 1, k, k), "conv")] + _bn(q + "_bn1", mid)
+        spec += [(q + "_se_reduce.weight", (se, mid, 1, 1), "se_w"), (q + "_se_reduce.bias", (se,), "bias"),
+                 (q + "_se_expand.weight", (mid, se, 1, 1), "se_w"), (q + "_se_expand.bias", (mid,), "bias")]
+        spec += [(q + "_project_conv.weight", (cout, mid, 1, 1), "proj")] + _bn(q + "_bn2", cout)
+    spec += [(prefix + "_conv_head.weight", (1280, 320, 1, 1), "conv")] + _bn(prefix + "_bn1", 1280)
+    spec += [(prefix + "_fc.weight", (1000, 1280), "lin"), (prefix + "_fc.bias", (1000,), "bias")]
+    return spec
+
+
+def up_param_spec(prefix, cin, cout):
+    """lss_submodule.Up (:22-47): Conv3x3 + BN + ReLU twice, no conv bias."""
+    return ([(prefix + "conv.0.weight", (cout, cin, 3, 3), "conv")] + _bn(prefix + "conv.1", cout)
+            + [(prefix + "conv.3.weight", (cout, cout, 3, 3), "conv")] + _bn(prefix + "conv.4", cout))
+
+
+def cam_depth_bins(cam):
+    return int(cam["grid_conf"]["ddiscr"][2])
+
+
+def camencode_param_spec(cam, prefix):
+    """lss_submodule.CamEncode (:50-87) with the EfficientNet trunk, chain_channels 256."""
+    if cam["camera_encoder"] != "EfficientNet":
+        raise NotImplementedError("camera_encoder: only the EfficientNet trunk (the shipped configs) is built")
+    spec = effnet_param_spec(prefix + "trunk.") + up_param_spec(prefix + "up1.", 320 + 112, 256)
+    if cam["img_downsample"] == 8:
+        spec += up_param_spec(prefix + "up2.", 256 + 40, 256)
+    if not cam["use_depth_gt"]:
+        spec += [(prefix + "depth_head.weight", (cam_depth_bins(cam), 256, 1, 1), "head"), (prefix + "depth_head.bias", (cam_depth_bins(cam),), "bias")]
+    spec += [(prefix + "image_head.weight", (cam["img_features"], 256, 1, 1), "img_head"), (prefix + "image_head.bias", (cam["img_features"],), "bias")]
+    return spec
+
+
+def _basic_block_spec(prefix, cin, cout, stride):
+    spec = ([(prefix + "conv1.weight", (cout, cin, 3, 3), "conv")] + _bn(prefix + "bn1", cout)
+            + [(prefix + "conv2.weight", (cout, cout, 3, 3), "conv")] + _bn(prefix + "bn2", cout))
+    if stride != 1 or cin != cout:
+        spec += [(prefix + "downsample.0.weight", (cout, cin, 1, 1), "conv")] + _bn(prefix + "downsample.1", cout)
+    return spec
+
+
+def bevencode_param_spec(inC, outC, prefix):
+    """lss_submodule.BevEncode (:312-333): 7x7/s2 stem, torchvision resnet18 layer1-3, Up(64+256 -> 256, x4), up2."""
+    spec = [(prefix + "conv1.weight", (64, inC, 7, 7), "conv")] + _bn(prefix + "bn1", 64)
+    cin = 64
+    for li, c in enumerate((64, 128, 256)):
+        spec += _basic_block_spec(f"{prefix}layer{li + 1}.0.", cin, c, 1 if li == 0 else 2)
+        spec += _basic_block_spec(f"{prefix}layer{li + 1}.1.", c, c, 1)
+        cin = c
+    spec += up_param_spec(prefix + "up1.", 64 + 256, 256)
+    spec += [(prefix + "up2.1.weight", (128, 256, 3, 3), "conv")] + _bn(prefix + "up2.2", 128)
+    spec += [(prefix + "up2.4.weight", (outC, 128, 1, 1), "conv"), (prefix + "up2.4.bias", (outC,), "bias")]
+    return spec
+
+
+def lss_param_spec(cam, prefix):
+    """LiftSplatShootEncoder (airv2x_encoder.py:31-91): camencode then bevencode (dx / bx / nx / frustum are plain attributes)."""
+    return camencode_param_spec(cam, prefix + "camencode.") + bevencode_param_spec(cam["img_features"], cam["bevout_feature"], prefix + "bevencode.")
+
+
+def multimodal_hypes(modalities=("cam", "lidar"), lidar_range=None, final_dim=(360, 640), use_depth_gt=True, max_cav=(5, 5, 5)):
+    """default_hypes with a camera encoder per agent type (``args[type]["cam"]`` = the shipped camera block,
+    hypes_yaml/airv2x/camera/det/airv2x_intermediate_where2com.yaml:180-248) and ``modalities`` as given: ("cam",) is that
+    YAML, ("cam", "lidar") is BASELINE configs[4] (no shipped YAML sets both)."""
+    hy = default_hypes(lidar_range, max_cav)
+    r = hy["preprocess"]["cav_lidar_range"]
+    a = hy["model"]["args"]
+    a["active_sensors"] = list(modalities)
+    for t in AGENT_TYPES:
+        a[t]["modalities"] = list(modalities)
+        a[t]["cam"] = cam_args(t, final_dim, (r[0], r[3], r[1], r[4]))
+        a[t]["cam"]["use_depth_gt"] = bool(use_depth_gt)
+    return hy
+
+
+def camera_images(seed, B, N, final_dim=(360, 640), agent_type="vehicle"):
+    """(B, N, 4, H, W) fp32: three normalised colour planes (smooth structure + noise) and a depth plane in metres that
+    runs past both ends of the type's depth range, so that the out-of-range mask of bin_depths is exercised."""
+    g = np.random.default_rng(int(seed))
+    H, W = final_dim
+    yy, xx = np.meshgrid(np.linspace(0, 1, H, dtype=np.float32), np.linspace(0, 1, W, dtype=np.float32), indexing="ij")
+    img = np.empty((B, N, 4, H, W), np.float32)
+    lo, hi = (6.0, 150.0) if agent_type == "drone" else (2.0, 50.0)
+    for b in range(B):
+        for n in range(N):
+            for c in range(3):
+                fx, fy, ph = g.uniform(1, 9), g.uniform(1, 9), g.uniform(0, 6.28)
+                img[b, n, c] = np.sin(6.28 * (fx * xx + fy * yy) + ph) * g.uniform(0.5, 1.5) + g.standard_normal((H, W)).astype(np.float32) * 0.5
+            d = lo - 1.5 + (hi - lo + 6.0) * (0.15 + 0.85 * yy[::-1] ** 2) * (1 + 0.1 * np.sin(9 * xx + n))
+            img[b, n, 3] = d + g.uniform(-0.3, 0.3, (H, W)).astype(np.float32)
+    return torch.from_numpy(img)
+
+
+def cam_inputs_for(seed, n_agents, n_cams, final_dim=(360, 640), agent_type="vehicle"):
+    """``batch_merged_cam_inputs`` of one agent type (intermediate_fusion_dataset.py:571-583, :766-781): B = the type's agents."""
+    rots, trans, intr, post_rots, post_trans = camera_rig(seed, n_agents, n_cams, final_dim, drone=(agent_type == "drone"))
+    return {"imgs": camera_images(seed + 7, n_agents, n_cams, final_dim, agent_type), "rots": rots, "trans": trans, "intrinsics": intr,
+            "post_rots": post_rots, "post_trans": post_trans}
+
+
+CAMS_PER_AGENT = {"vehicle": 4, "rsu": 4, "drone": 1}
+
+
+def add_cameras(dd, types, seed=50, final_dim=(360, 640), cams_per_agent=None):
+    """Fill ``batch_merged_cam_inputs`` of a build_data_dict() frame for every agent type present."""
+    cpa = cams_per_agent or CAMS_PER_AGENT
+    for ti, t in enumerate(AGENT_TYPES):
+        k = sum(1 for tt in types if tt == t)
+        if k:
+            dd[t]["batch_merged_cam_inputs"] = cam_inputs_for(seed + 100 * ti, k, cpa[t], final_dim, t)
+    return dd
 
 
 # --------------------------------------------------------------------------

@@ -82,7 +82,7 @@ int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
  *   NaiveCompressor (models/common_modules/naive_compress.py:12-36),
  *   cls/reg/obj heads (models/airv2x_where2com.py:60-69).
  *
- * mode AV2X_CONV      : out[n,ho,wo, out_coff+co] NHWC, ks in {1,3}, any stride/pad.
+ * mode AV2X_CONV      : out[n,ho,wo, out_coff+co] NHWC, ks in {1,3,5,7}, any stride/pad.
  * mode AV2X_DECONV    : ConvTranspose2d with kernel == stride == up (no overlap):
  *                       out[n, ho*up+i, wo*up+j, out_coff+co]; (h,w) here are the INPUT dims.
  * mode AV2X_CONV_NCHW : as AV2X_CONV but the result is stored NCHW (out[n,co,ho,wo]); used
@@ -114,7 +114,8 @@ typedef struct av2x_conv_desc {
     int32_t out_ctot, out_coff;/* channel stride / offset of the output (concat support) */
     int32_t ks, stride, pad;   /* square kernel                                           */
     int32_t relu;              /* activation after the affine: 0 none, 1 ReLU, 2 exact GELU, 3 sigmoid, 4 tanh -- with a
-                                * residual pointer code 4 multiplies by residual[m*cout + c] (a ConvGRU gate) instead of adding */
+                                * residual pointer code 4 multiplies by residual[m*cout + c] (a ConvGRU gate) instead of adding;
+                                * 5 = ReLU applied AFTER the residual add (torchvision BasicBlock), 6 = swish x*sigmoid(x) */
     int32_t mode;              /* AV2X_CONV / AV2X_DECONV / AV2X_CONV_NCHW                */
     int32_t up;                /* DECONV: kernel == stride                                */
     int32_t tile;              /* 0 = auto; else BM<<16 | BN | 0x8000 (8 waves) | 0x4000 (prefetch distance 2)
@@ -390,6 +391,54 @@ uint64_t av2x_lss_pool_workspace_bytes(int32_t b, int32_t nx, int32_t ny, int32_
 int av2x_lss_voxel_pool(const float* x, const float* frustum, const float* cam_params, int32_t b, int32_t n_cams,
                         int32_t pts_per_cam, int32_t c, const float* lo3, const float* dx3, const int32_t* nx3,
                         void* workspace, float* out, float* geom_out, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Camera encoder (BASELINE configs[4]): the non-GEMM kernels of CamEncode / BevEncode
+ * (models/sub_modules/lss_submodule.py:22-189, 312-350) and of the efficientnet_pytorch trunk CamEncode walks (:118-146).
+ * All maps NHWC fp32; the pointwise / 3x3 / 7x7 convolutions run on av2x_conv2d.
+ *
+ * av2x_cam_stem        EfficientNet stem (trunk._conv_stem + _bn0 + swish, :124-126): imgs (n, planes >= 3, h, w) NCHW as the dataset
+ *                      stacks them (intermediate_fusion_dataset.py:561,573; plane 3 = depth, not read here); weight (27, 32) with row
+ *                      (kh*3+kw)*3+ci; 3x3 / stride 2, zero padding pad_t / pad_l before and whatever (ho, wo) needs after (the package's
+ *                      static "same" padding: 0 before, 1 after); out (n, ho, wo, 32).
+ * av2x_dwconv2d        depthwise ks x ks (3 | 5) conv + affine (folded BN) + activation (0 none, 1 ReLU, 6 swish): weight (ks*ks, c);
+ *                      asymmetric zero padding as above.  MBConv `_depthwise_conv` + `_bn1` + swish.
+ * av2x_squeeze_excite  MBConv squeeze-excite on x (n, hw, c) in place: gate = sigmoid(W_e swish(W_r mean_hw(x) + b_r) + b_e), x *= gate
+ *                      (apply = 0: only the gate, left at workspace + n * av2x_se_slabs(hw) * c floats).  w_reduce (c_se, c),
+ *                      w_expand (c, c_se).  Sums run in a fixed order (bit-reproducible).  workspace: av2x_squeeze_excite_workspace_bytes.
+ * av2x_resize_bilinear nn.Upsample(bilinear, align_corners=True) of in (n, h, w, c of in_ctot from in_coff) to (h2, w2), placed at
+ *                      (pad_t, pad_l) of the (hout, wout) output with zeros around it (F.pad in Up.forward :41-45), written to the
+ *                      channel slice [out_coff, out_coff + c) of out (n, hout, wout, out_ctot) (torch.cat :46).  h2 == h copies.
+ * av2x_softmax_channels CamEncode.get_depth_dist (:89-92): softmax over the first d of `stride` channels of every row.
+ * av2x_lss_lift_pool   CamEncode's depth (x) feature outer product (:176-186) + LiftSplatShootEncoder.get_geometry / voxel_pooling
+ *                      (airv2x_encoder.py:133-275) without the (B, N, D, fH, fW, C) volume: feat (b*n_cams, fh, fw, c) image features;
+ *                      EITHER prob (b*n_cams, fh, fw, nbins) predicted depth distribution, OR imgs (b*n_cams, planes, img_h, img_w) whose
+ *                      plane 3 is the ground-truth depth: binned as utils/camera_utils.py:247-298 (depth3 = {d_min, d_max, bin size},
+ *                      depth_mode 0 UD / 1 LID, target = CamEncode.training: clamp instead of masking), sampled at the centre of every
+ *                      downsample x downsample cell (:104-108).  frustum / cam_params / lo3 / dx3 / nx3 / workspace / out as
+ *                      av2x_lss_voxel_pool.
+ * ------------------------------------------------------------------------------------ */
+/* Airv2xBase.fuse_bev (models/common_modules/airv2x_base_model.py:167-177) for the two modality maps of an agent type:
+ * out = (a + b) / 2 elementwise (n floats, n % 4 == 0); b == NULL copies a. */
+int av2x_mean2(const float* a, const float* b, float* out, uint64_t n, av2x_stream_t stream);
+int av2x_cam_stem(const float* imgs, int32_t n, int32_t planes, int32_t h, int32_t w, const float* weight, const float* scale,
+                  const float* shift, int32_t pad_t, int32_t pad_l, int32_t ho, int32_t wo, float* out, av2x_stream_t stream);
+int av2x_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, const float* weight, const float* scale,
+                  const float* shift, int32_t ks, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t ho, int32_t wo,
+                  int32_t act, float* out, av2x_stream_t stream);
+int32_t av2x_se_slabs(int32_t hw);
+uint64_t av2x_squeeze_excite_workspace_bytes(int32_t n, int32_t hw, int32_t c);
+int av2x_squeeze_excite(float* x, int32_t n, int32_t hw, int32_t c, const float* w_reduce, const float* b_reduce, int32_t c_se,
+                        const float* w_expand, const float* b_expand, float* workspace, int32_t apply, av2x_stream_t stream);
+int av2x_resize_bilinear(const float* in, int32_t n, int32_t h, int32_t w, int32_t c, int32_t in_ctot, int32_t in_coff,
+                         int32_t h2, int32_t w2, int32_t pad_t, int32_t pad_l, int32_t hout, int32_t wout, float* out,
+                         int32_t out_ctot, int32_t out_coff, av2x_stream_t stream);
+int av2x_softmax_channels(const float* x, int64_t rows, int32_t d, int32_t stride, float* out, av2x_stream_t stream);
+int av2x_lss_lift_pool(const float* feat, const float* prob, const float* imgs, int32_t planes, int32_t img_h, int32_t img_w,
+                       int32_t downsample, const float* depth3, int32_t nbins, int32_t depth_mode, int32_t target,
+                       const float* frustum, const float* cam_params, int32_t b, int32_t n_cams, int32_t fh, int32_t fw,
+                       int32_t c, const float* lo3, const float* dx3, const int32_t* nx3, void* workspace, float* out,
+                       av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * V2VNet message aggregation (models/v2vnet_modules/v2v_fuse.py:137-165) for ONE receiving agent i:

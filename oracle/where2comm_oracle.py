@@ -98,11 +98,11 @@ def pillar_scatter(pillar_features, coords, n_agents, nx, ny):
 
 
 # ---------------------------------------------------------------- a6: encoders + repack
-def extract_features(data_dict, sd, args):
-    """models/common_modules/airv2x_base_model.py:101-248 for B=1 frames and one
-    modality per agent type: run each type's encoder, then concatenate in the
-    order vehicle, rsu, drone (``repack_batch`` iterates ``batch_dicts`` in that
-    insertion order :127-150, :215-231)."""
+def extract_features(data_dict, sd, args, trace=None):
+    """models/common_modules/airv2x_base_model.py:101-248 for B=1 frames: run each type's encoders (one per entry of
+    ``modalities``: Sequential(PillarVFE, PointPillarScatter) for "lidar", LiftSplatShootEncoder for "cam"), average the
+    modality maps (``fuse_bev`` :167-177), then concatenate in the order vehicle, rsu, drone (``repack_batch`` iterates
+    ``batch_dicts`` in that insertion order :127-150, :215-231)."""
     outs = []
     n_total = 0
     for t in AGENT_TYPES:
@@ -111,14 +111,26 @@ def extract_features(data_dict, sd, args):
         d = data_dict[t]
         if len(d["batch_idxs"]) == 0:
             continue
-        lid = d["batch_merged_lidar_features_torch"]
-        cfg = args[t]["lidar"]
-        pf = pillar_vfe(lid["voxel_features"], lid["voxel_num_points"], lid["voxel_coords"], sd,
-                        TYPE_PREFIX[t] + ".0.0", cfg["voxel_size"], cfg["lidar_range"])
-        n_t = int(lid["voxel_coords"][:, 0].max().item()) + 1  # point_pillar_scatter.py:43
-        nx, ny, nz = [int(v) for v in cfg["point_pillar_scatter"]["grid_size"]]
-        outs.append(pillar_scatter(pf, lid["voxel_coords"], n_t, nx, ny))
-        n_total += n_t
+        maps = []
+        for mi, m in enumerate(args[t]["modalities"]):
+            if m == "lidar":
+                lid = d["batch_merged_lidar_features_torch"]
+                cfg = args[t]["lidar"]
+                pf = pillar_vfe(lid["voxel_features"], lid["voxel_num_points"], lid["voxel_coords"], sd,
+                                f"{TYPE_PREFIX[t]}.{mi}.0", cfg["voxel_size"], cfg["lidar_range"])
+                n_t = int(lid["voxel_coords"][:, 0].max().item()) + 1  # point_pillar_scatter.py:43
+                nx, ny, nz = [int(v) for v in cfg["point_pillar_scatter"]["grid_size"]]
+                maps.append(pillar_scatter(pf, lid["voxel_coords"], n_t, nx, ny))
+            elif m == "cam":
+                from . import camera_oracle as cam
+                tr = {} if trace is not None else None
+                maps.append(cam.lss_encoder_forward(sd, f"{TYPE_PREFIX[t]}.{mi}.", d["batch_merged_cam_inputs"], args[t]["cam"], trace=tr))
+                if trace is not None:
+                    trace["cam_" + t] = tr
+            else:
+                raise NotImplementedError(m)
+        outs.append(maps[0] if len(maps) == 1 else torch.mean(torch.stack(maps, dim=0), dim=0))
+        n_total += outs[-1].shape[0]
     feats = torch.cat(outs, dim=0)
     record_len = torch.tensor([n_total], dtype=torch.int32)
     return feats, record_len
@@ -277,7 +289,7 @@ def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False,
     The debug PNG (:137-139) has no effect on outputs and is dropped.
     """
     mf = args["modality_fusion"]
-    feats, record_len = extract_features(data_dict, sd, args)
+    feats, record_len = extract_features(data_dict, sd, args, trace)
     if reference_schedule:
         backbone_forward(feats, sd, mf["base_bev_backbone"])
     sf2d, blocks = backbone_forward(feats, sd, mf["base_bev_backbone"])

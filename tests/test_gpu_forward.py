@@ -15,6 +15,7 @@ from tests.helpers import assert_close, case_from_fixture, load_fixture, sample
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 2e-4, 2e-4
+MAX_FLIPS = 8      # communication-mask cells allowed to sit on the other side of the threshold, each within 1e-6 of it
 
 
 def _run(name):
@@ -49,14 +50,29 @@ def test_forward_matches_reference_golden(name):
     assert_close(sample(tr["shrink"], bs), fx["shrink"], RTOL, ATOL, "shrink")
     assert_close(sample(tr["psm_single"], s), fx["psm_single"], RTOL, ATOL, "psm_single")
     assert_close(sample(tr["comm_map"], s), fx["comm_map"], 1e-4, 1e-7, "comm_map")
-    if flips == 0:
+    print(f"[{name}] communication-mask cells flipped within 1e-6 of the threshold: {flips}")
+    assert flips <= MAX_FLIPS, f"{flips} mask cells flipped at the threshold (allowed: {MAX_FLIPS})"
+    # everything downstream of the mask, UNCONDITIONALLY: the oracle (bit-equal to the reference on equal masks, asserted when the
+    # fixture was made) is run with the DEVICE's mask replayed, and every element of the fused maps and the heads is compared
+    otr = {}
+    with torch.no_grad():
+        ref = orc.where2com_forward(dd, sd, args, trace=otr, comm_mask=tr["comm_mask"].cpu())
+    for i in range(3):
+        assert_close(tr[f"fused{i}"].cpu(), otr[f"fused{i}"], RTOL, ATOL, f"fused{i} (device mask replayed)")
+    for k in ("psm", "rm", "obj"):
+        assert list(out[k].shape) == list(fx[k + "_shape"])
+        assert_close(out[k].cpu(), ref[k], RTOL, ATOL, k + " (device mask replayed)")
+    if flips == 0:   # identical masks: additionally the reference's own stored samples and sums
         for i in range(3):
             assert_close(sample(tr[f"fused{i}"][0], s), fx[f"fused{i}"], RTOL, ATOL, f"fused{i}")
         for k in ("psm", "rm", "obj"):
-            assert list(out[k].shape) == list(fx[k + "_shape"])
             assert_close(sample(out[k], s), fx[k], RTOL, ATOL, k)
             assert abs(out[k].double().sum().item() - float(fx[k + "_sum"])) <= 2e-4 * float(fx[k + "_abssum"])
         assert abs(float(out["com"]) - float(fx["com"])) < 1e-6
+    else:            # the rate counts the mask's ones: it moves by exactly the flipped cells
+        n_cells = float(np.prod(fx["comm_mask_shape"])) if "comm_mask_shape" in fx else None
+        if n_cells:
+            assert abs(float(out["com"]) - float(fx["com"])) <= flips / n_cells * len(fx["types"]) + 1e-6
 
 
 def test_forward_matches_oracle_full_grid_every_element():
@@ -70,9 +86,15 @@ def test_forward_matches_oracle_full_grid_every_element():
     assert not (differs & ~near).any()
     assert_close(tr["spatial_features"].cpu(), otr["spatial_features"], 1e-4, 1e-5, "canvas")
     assert torch.equal(tr["spatial_features"].cpu() != 0, otr["spatial_features"] != 0)
-    if not differs.any():
-        for k in ("psm", "rm", "obj"):
-            assert_close(out[k].cpu(), ref[k], RTOL, ATOL, k)
+    flips = int(differs.sum())
+    print(f"[w2c_full_n4 vs oracle] mask cells flipped within 1e-6 of the threshold: {flips}")
+    assert flips <= MAX_FLIPS
+    if flips:   # replay the device's mask: the comparison below never depends on a threshold coincidence
+        with torch.no_grad():
+            ref = orc.where2com_forward(dd, sd, args, comm_mask=tr["comm_mask"].cpu())
+    for k in ("psm", "rm", "obj"):
+        assert_close(out[k].cpu(), ref[k], RTOL, ATOL, k)
+    if not flips:
         assert abs(float(out["com"]) - float(ref["com"])) < 1e-6
     assert int(out["comm_rate"]) == ref["comm_rate"]
 

@@ -1013,6 +1013,186 @@ def lss_golden(name, agent_type, B, N, final_dim, xy, seed, one_hot, stride):
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def _import_camera_reference():
+    """The reference's camera modules, unmodified, with oracle/camera_oracle.py's restatements registered in place of the two
+    packages this image lacks (efficientnet_pytorch, torchvision.models.resnet): trunk parity is UNPINNED (stated there)."""
+    from oracle import camera_oracle as co
+    _stub("efficientnet_pytorch", EfficientNet=co.EfficientNet)
+    tv = _stub("torchvision")
+    tv.models = _stub("torchvision.models")
+    tv.models.resnet = _stub("torchvision.models.resnet", resnet18=co.resnet18, resnet101=co.resnet101)
+
+    class _AnyTransform:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, im):
+            return im
+    tv.transforms = _stub("torchvision.transforms", ToTensor=_AnyTransform, Normalize=_AnyTransform, Compose=_AnyTransform,
+                          ToPILImage=_AnyTransform)
+    sys.modules["shapely.geometry"].MultiPoint = object
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        pil = _stub("PIL")
+        pil.Image = _stub("PIL.Image")
+    _stub("opencood.models.common_modules.debug_helper", np=np, cv2=sys.modules["cv2"])
+    _stub("icecream", ic=lambda *a, **k: None)          # torch_transformation_utils.py:11 (debug printing)
+    for m in ("opencood.models.sub_modules.lss_submodule", "opencood.models.common_modules.airv2x_encoder",
+              "opencood.models.common_modules.airv2x_base_model", "opencood.models.airv2x_where2com"):
+        sys.modules.pop(m, None)
+    import opencood.models.common_modules.airv2x_encoder as enc
+    return enc
+
+
+class _CudaIsCpu:
+    """LiftSplatShootEncoder.__init__ moves its grid constants to torch.device("cuda") (airv2x_encoder.py:47-60); there is
+    no GPU in the build container, so for the duration of the constructor `.to(cuda)` is a no-op."""
+
+    def __enter__(self):
+        self.orig = torch.Tensor.to
+
+        def to(t, *a, **k):
+            a = tuple(torch.device("cpu") if (isinstance(x, torch.device) and x.type == "cuda") else x for x in a)
+            return self.orig(t, *a, **k)
+        torch.Tensor.to = to
+
+    def __exit__(self, *exc):
+        torch.Tensor.to = self.orig
+
+
+def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities, use_depth_gt, stride, cams=None):
+    """The reference's Airv2xWhere2com with camera encoders (modalities ("cam",) = the shipped camera YAML, ("cam", "lidar") =
+    BASELINE configs[4]) on seeded clouds + seeded camera inputs; also stores every camera-branch intermediate."""
+    from airv2x_perception_amd import synth
+    from oracle import voxelize_oracle as vox
+    from oracle import where2comm_oracle as orc
+    _import_camera_reference()
+    from opencood.models.airv2x_where2com import Airv2xWhere2com
+    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, use_depth_gt)
+    args = hy["model"]["args"]
+    # the reference's hypes: its own YAML, modalities / depth flag / image size edited like a user would
+    hy_ref = load_ref_hypes(lidar_range)
+    ra = hy_ref["model"]["args"]
+    ra["active_sensors"] = list(modalities)
+    for t in synth.AGENT_TYPES:
+        ra[t]["modalities"] = list(modalities)
+        ra[t]["cam"]["use_depth_gt"] = bool(use_depth_gt)
+        ra[t]["cam"]["data_aug_conf"]["final_dim"] = list(final_dim)
+        if lidar_range is not None:     # the camera BEV grid follows the (shrunk) x / y extents of the LiDAR grid
+            ra[t]["cam"]["grid_conf"]["xbound"] = [lidar_range[0], lidar_range[3], 0.4]
+            ra[t]["cam"]["grid_conf"]["ybound"] = [lidar_range[1], lidar_range[4], 0.4]
+        check_hypes(ra[t]["cam"], args[t]["cam"], f"model.args.{t}.cam")
+    with _CudaIsCpu():
+        model = Airv2xWhere2com(ra).eval()
+    spec = synth.where2com_param_spec(args)
+    ref_sd = model.state_dict()
+    assert [k for k, _, _ in spec] == list(ref_sd.keys()), [(a, b) for (a, _, _), b in zip(spec, ref_sd.keys()) if a != b][:5]
+    for k, shp, _ in spec:
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, _ in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_test"]))
+    dd = synth.add_cameras(synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"]), types, seed=seed + 50,
+                           final_dim=final_dim, cams_per_agent=cams)
+    cap = {}
+
+    def hook(key):
+        def fn(mod, inp, out):
+            cap.setdefault(key, []).append(out)
+        return fn
+    hs = []
+    for t, pre in synth.TYPE_PREFIX.items():
+        if not any(tt == t for tt in types):
+            continue
+        enc = getattr(model, pre)[list(modalities).index("cam")]
+        hs.append(enc.camencode.register_forward_hook(hook("camenc_" + t)))
+        hs.append(enc.camencode.image_head.register_forward_hook(hook("img_" + t)))
+        hs.append(enc.camencode.up1.register_forward_hook(hook("up1_" + t)))
+        hs.append(enc.camencode.trunk._blocks[0].register_forward_hook(hook("mb0_" + t)))
+        hs.append(enc.camencode.trunk._blocks[5].register_forward_hook(hook("mb5_" + t)))
+        hs.append(enc.bevencode.register_forward_hook(hook("bev_" + t)))
+        hs.append(enc.bevencode.register_forward_pre_hook(lambda m, i, t=t: cap.setdefault("pooled_" + t, []).append(i[0])))
+        hs.append(enc.bevencode.layer1.register_forward_hook(hook("l1_" + t)))
+        hs.append(enc.bevencode.layer3.register_forward_hook(hook("l3_" + t)))
+    os.makedirs("debug", exist_ok=True)
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        out = model(dd)
+    t_ref = time.time() - t0
+    for h in hs:
+        h.remove()
+    trace = {}
+    with torch.no_grad():
+        o = orc.where2com_forward(dd, sd, args, trace=trace)
+    rep = {k: ((o[k] - out[k]).abs().max().item(), out[k].abs().max().item()) for k in ("psm", "rm", "obj")}
+    print(f"[{name}] reference forward {t_ref:.1f} s; oracle-vs-reference max|diff| (max|ref|):",
+          {k: f"{a:.3e} ({b:.3e})" for k, (a, b) in rep.items()})
+    for k, (a, b) in rep.items():
+        assert a <= 2e-4 * max(1.0, b), (k, a, b)
+    assert o["comm_rate"] == out["comm_rate"]
+    s = stride
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types), "n_points": np.int64(n_points),
+          "final_dim": np.asarray(final_dim, np.int64), "modalities": np.asarray(list(modalities)), "use_depth_gt": np.int64(use_depth_gt),
+          "stride": np.int64(s), "spec_len": np.int64(len(spec)), "comm_rate": np.int64(out["comm_rate"]), "com": np.float64(float(out["com"])),
+          "cams": np.asarray([(cams or synth.CAMS_PER_AGENT)[t] for t in synth.AGENT_TYPES], np.int64)}
+
+    def put(key, t, s=s):
+        """strided sample (s > 0) + sums; s == 0: sums only (the oracle, asserted equal to the reference above, supplies the
+        full tensor to the tests)"""
+        t = t.detach().float().cpu()
+        fx[key + "_sum"] = np.float64(t.double().sum().item())
+        fx[key + "_abssum"] = np.float64(t.double().abs().sum().item())
+        fx[key + "_shape"] = np.asarray(t.shape, np.int64)
+        if s > 0:
+            fx[key] = (t[..., ::s, ::s] if s > 1 else t).numpy()
+    for k in ("psm", "rm", "obj"):
+        put(k, out[k], 1 if s == 1 else 5)
+    for t in synth.AGENT_TYPES:
+        if "bev_" + t not in cap:
+            continue
+        put("img_" + t, cap["img_" + t][0], 1 if s == 1 else 3)
+        put("up1_" + t, cap["up1_" + t][0], 0)
+        put("mb0_" + t, cap["mb0_" + t][0], 0)
+        put("mb5_" + t, cap["mb5_" + t][0], 0)
+        put("pooled_" + t, cap["pooled_" + t][0], 2 if s == 1 else s)
+        put("l1_" + t, cap["l1_" + t][0], 0)
+        put("l3_" + t, cap["l3_" + t][0], 0)
+        put("bev_" + t, cap["bev_" + t][0], 2 if s == 1 else s)
+        ce = cap["camenc_" + t][0][1]                      # new_x (BN, C, D, fH, fW)
+        fx[f"lift_{t}_abssum"] = np.float64(ce.double().abs().sum().item())
+        # the reference pools with a running fp32 sum over ALL frustum points (QuickCumsum): its own rounding error, measured against
+        # the same pooling in float64, is part of what a comparison with `pooled_<type>` can show
+        from oracle import lss_oracle as lo
+        enc = getattr(model, synth.TYPE_PREFIX[t])[list(modalities).index("cam")]
+        ci = dd[t]["batch_merged_cam_inputs"]
+        geom = enc.get_geometry(ci["rots"], ci["trans"], ci["intrinsics"], ci["post_rots"], ci["post_trans"])
+        Bt, Nt = ci["imgs"].shape[:2]
+        xl = ce.view(Bt, Nt, *ce.shape[1:]).permute(0, 1, 3, 4, 5, 2)
+        exact = lo.voxel_pooling_exact(geom, xl, enc.dx, enc.bx, enc.nx)
+        fx[f"pooled_exact_{t}"] = exact.float()[..., ::(2 if s == 1 else s), ::(2 if s == 1 else s)].numpy()
+        fx[f"pooled_ref_err_{t}"] = np.float64((cap["pooled_" + t][0].double() - exact).abs().max().item())
+        print(f"[{name}] {t}: reference pooling vs float64: max err {float(fx[f'pooled_ref_err_{t}']):.3e}")
+        # the oracle's own intermediates agree with the reference's
+        tr = trace["cam_" + t]
+        assert torch.allclose(tr["x_img"], cap["img_" + t][0], rtol=0, atol=2e-4 * float(cap["img_" + t][0].abs().max())), t
+        assert torch.allclose(tr["pooled"], cap["pooled_" + t][0], rtol=0, atol=2e-4 * float(cap["pooled_" + t][0].abs().max())), t
+        print(f"[{name}] {t}: img feat max {float(cap['img_' + t][0].abs().max()):.3f} pooled max {float(cap['pooled_' + t][0].abs().max()):.3f} "
+              f"occupied {float((cap['pooled_' + t][0].abs().sum(1) > 0).float().mean()):.3f} bev max {float(cap['bev_' + t][0].abs().max()):.3f}")
+    put("spatial_features", trace["spatial_features"], 2 if s == 1 else s)
+    print(f"[{name}] comm_rate {out['comm_rate']} com {float(out['com']):.5f} obj>0.2: {int((out['obj'].sigmoid() > 0.2).sum())}")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def labels_golden(name, lidar_range, n_gt, seed):
     """The reference's own VoxelPostprocessor.generate_label_airv2x (voxel_postprocessor.py:217-354) with its own
     box_overlaps.pyx (compiled by oracle/build_ref.py) on the configuration's anchors and seeded ground-truth boxes."""
@@ -1367,6 +1547,14 @@ GROUPS = {
                     lss_golden("lss_small_dense", "rsu", 1, 3, (96, 160), (-25.6, 25.6, -12.8, 12.8), 32, False, 1),
                     lss_golden("lss_cfg4_vehicle", "vehicle", 1, 4, (360, 640), (-140.8, 140.8, -40.0, 40.0), 33, True, 4),
                     lss_golden("lss_cfg4_drone", "drone", 1, 1, (360, 640), (-140.8, 140.8, -40.0, 40.0), 34, True, 4)),
+    # camera branch (CamEncode on the restated EfficientNet-B0, lift, BevEncode) inside the reference's Airv2xWhere2com: small rigs with
+    # every tensor (odd image size: exercises the same-padding / Up pad paths; predicted-depth softmax and ground-truth depth),
+    # the shipped camera-only YAML, and BASELINE configs[4] (8 agents, camera + LiDAR, 360x640 images, 704x200 grid)
+    "camera": lambda: (camera_case("w2c_cam_small", SMALL, ["vehicle", "rsu", "drone"], 700, 21, (104, 168), ("cam", "lidar"), True, 1,
+                                   cams={"vehicle": 2, "rsu": 1, "drone": 1}),
+                       camera_case("w2c_cam_small_softmax", SMALL, ["vehicle", "drone"], 700, 22, (104, 168), ("cam",), False, 1,
+                                   cams={"vehicle": 2, "rsu": 1, "drone": 1})),
+    "camera_full": lambda: camera_case("w2c_cam_full_n8", None, T8, 8192, 23, (360, 640), ("cam", "lidar"), True, 8),
     "labels": lambda: (labels_golden("labels_small", SMALL, 12, 41), labels_golden("labels_full", None, 60, 42),
                        labels_golden("labels_full_one", None, 1, 43)),
     "comm_train": lambda: comm_train_golden(),
@@ -1386,7 +1574,7 @@ def main(groups=None):
     import_reference()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    for g in (groups or [g for g in GROUPS if g not in ("full", "train_full")]):
+    for g in (groups or [g for g in GROUPS if g not in ("full", "train_full", "camera_full")]):
         if g not in GROUPS:
             raise SystemExit(f"unknown group {g!r}; one of {sorted(GROUPS)}")
         GROUPS[g]()
