@@ -215,7 +215,7 @@ def encoder_param_spec(args):
     for t in AGENT_TYPES:
         if t not in args["collaborators"]:
             continue
-        for i, m in enumerate(args[t]["modalities"]):
+        for i, m in enumerate(args.get(t, {}).get("modalities", ["lidar"])):
             if m == "lidar":
                 spec += pfn_param_spec(f"{TYPE_PREFIX[t]}.{i}.0.")
             elif m == "cam":

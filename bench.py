@@ -86,6 +86,9 @@ def parse(argv=None):
     ap.add_argument("--agents", type=int, default=0,
                     help="agents in the frame; 0 = 4 (BASELINE configs[1]) up to 4 GPUs, one per GPU above")
     ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--modalities", default="lidar",
+                    help="where2com only: 'lidar' (the headline), 'cam' (the shipped camera YAML) or 'cam,lidar' (BASELINE.json configs[4]: "
+                         "every agent carries 360x640 RGB-D cameras -- 4 per vehicle / RSU, 1 per drone -- next to its LiDAR; use with --agents 8)")
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames timed for cpu_baseline (0 = skip); the median is reported")
     ap.add_argument("--no-rotate", action="store_true",
                     help="shard mode: every rank repeats the ego stage of every frame (SPMD) instead of rank t %% N running frame t's")
@@ -115,7 +118,7 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
+def build_inputs(n_agents, n_points, device, only=None, model="where2com", modalities=("lidar",)):
     from airv2x_perception_amd import synth
     from airv2x_perception_amd.opencood_iface.voxelizer import voxelize_points
     if model == "cobevt":
@@ -130,6 +133,8 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
         hy = synth.default_hypes_when2com()
     elif model == "v2vnet":
         hy = synth.default_hypes_v2vnet()
+    elif tuple(modalities) != ("lidar",):
+        hy = synth.multimodal_hypes(tuple(modalities))
     else:
         hy = synth.default_hypes()
     args = hy["model"]["args"]
@@ -148,6 +153,12 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com"):
                                     pp["args"]["max_points_per_voxel"], pp["args"]["max_voxel_test"],
                                     range_filter=True))
     dd = synth.build_data_dict_device(voxd, types_sorted, device, max_cav_num=args["max_cav_num"])
+    if "cam" in modalities:     # seeded RGB-D images + camera rigs per agent type, resident in HBM like the voxel tensors
+        synth.add_cameras(dd, types_sorted, seed=50)
+        for t in synth.AGENT_TYPES:
+            ci = dd[t].get("batch_merged_cam_inputs")
+            if ci is not None:
+                ci["imgs"] = ci["imgs"].to(device)
     if model == "v2xvit":  # seeded SE(2) correction per non-ego agent; host-side (L,4,4)/(L,3) scalars
         g = np.random.default_rng(99)
         scm = torch.eye(4, dtype=torch.float64).repeat(1, args["max_cav_num"], 1, 1)
@@ -237,7 +248,7 @@ class GpuShardHooks:
         self.model = self.eng = None
 
     def inputs(self, n_agents, only):
-        hy, args, dd, _, types = build_inputs(n_agents, self.a.points, self.dev, only=only, model=self.a.model)
+        hy, args, dd, _, types = build_inputs(n_agents, self.a.points, self.dev, only=only, model=self.a.model, modalities=self.a.mods)
         return hy, args, dd, types
 
     def backends(self, args, depth):
@@ -295,6 +306,14 @@ def main(argv=None, hooks=None, device=None):
         if not cpu_harness:
             torch.cuda.set_device(0)
     dev = torch.device("cpu") if cpu_harness else torch.device("cuda", local if world > 1 else 0)
+    a.mods = tuple(m.strip() for m in a.modalities.split(",") if m.strip())
+    if a.mods != ("lidar",) and a.model != "where2com":
+        raise SystemExit("--modalities: the camera encoders are wired into the Where2Comm model (BASELINE.json configs[4])")
+    if any(m not in ("cam", "lidar") for m in a.mods) or not a.mods:
+        raise SystemExit("--modalities: lidar | cam | cam,lidar")
+    a.lidar_only = a.mods == ("lidar",)
+    if not a.lidar_only:
+        a.cpu_frames = min(a.cpu_frames, 3)      # the 8-agent camera + LiDAR oracle frame takes ~25 s of CPU
     if a.mode is None:
         a.mode = "shard" if world > 1 else "replica"
     if a.only_headline:
@@ -326,7 +345,7 @@ def main(argv=None, hooks=None, device=None):
                                                  "agents_per_rank": finfo["agents_per_rank"]}
             # (3) replicas: every rank runs its own whole frames (no data-path collective)
             if isinstance(hooks, GpuShardHooks):
-                _, _, ddr, _, _ = build_inputs(a.agents, a.points, dev, only=None, model=a.model)
+                _, _, ddr, _, _ = build_inputs(a.agents, a.points, dev, only=None, model=a.model, modalities=a.mods)
                 from airv2x_perception_amd.opencood_iface.engine import FramePipeline
                 hooks.model(ddr)
                 rp = FramePipeline(hooks.eng, max(1, a.inflight))
@@ -341,12 +360,12 @@ def main(argv=None, hooks=None, device=None):
         dd = None
         if rank == 0 and isinstance(hooks, GpuShardHooks) and not a.no_roofline:
             # the roofline pass below times whole frames of the same agent count on THIS GPU (same kernels as the sharded run)
-            _, _, dd, _, _ = build_inputs(a.agents, a.points, dev, only=None, model=a.model)
+            _, _, dd, _, _ = build_inputs(a.agents, a.points, dev, only=None, model=a.model, modalities=a.mods)
         parallelism = (f"one frame over {world} rank(s), agents per rank {info['agents_per_rank']}, RCCL all_gather_into_tensor of "
                        + MESSAGE[a.model] + f"; {info['frames_in_flight']} frame(s) in flight per rank, ego stage: {info['ego_stage']}")
         inflight_used = info["frames_in_flight"]
     else:
-        hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev, only=None, model=a.model)
+        hy, args, dd, clouds, types = build_inputs(a.agents, a.points, dev, only=None, model=a.model, modalities=a.mods)
         if a.model != "where2com":
             a.cpu_frames = 0
         model, eng, sd = make_model(a, args, dev)
@@ -368,7 +387,7 @@ def main(argv=None, hooks=None, device=None):
     ms = dt / a.steps * 1e3
 
     res = {
-        "metric": f"collaborative frames/sec, {MODEL_NAMES[a.model]}-LiDAR {a.agents}-agent",
+        "metric": f"collaborative frames/sec, {MODEL_NAMES[a.model]}-{'LiDAR' if a.lidar_only else ('camera+LiDAR' if len(a.mods) == 2 else 'camera')} {a.agents}-agent",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
@@ -377,7 +396,10 @@ def main(argv=None, hooks=None, device=None):
         "dtype": "bf16" if a.amp else ("f32 (products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate)" if a.gemm == "split3" else "f32"), "data": "synthetic",
         "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(synth.sort_types(synth.agent_types_for(a.agents))[1])}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
-                               f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if a.agents == 4 else ""),
+                               f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if (a.agents == 4 and a.lidar_only) else "")
+                               + ("" if a.lidar_only else f"; modalities {list(a.mods)}: per agent 360x640 RGB-D cameras (4 per vehicle / RSU, 1 per drone) -> "
+                                  "EfficientNet-B0 CamEncode -> lift-splat -> BevEncode -> mean with the pillar canvas, images resident in HBM"
+                                  + ("; BASELINE.json configs[4]" if (a.agents == 8 and len(a.mods) == 2) else "")),
                    "parallelism": parallelism,
                    "launch": "hipGraph replay" if (eng is not None and eng.graph_active()) else "eager",
                    "frames_in_flight": inflight_used},
@@ -401,7 +423,7 @@ def main(argv=None, hooks=None, device=None):
     # ---------------- the same frames with the split-3 GEMM (fp32-accurate, bf16 matrix cores): reported beside the headline
     if secondary and a.inflight > 1:
         eng.throughput_mode = True    # the pipelined secondary legs below
-    if secondary and a.model == "where2com" and a.gemm == "f32" and not a.amp and a.inflight > 1:
+    if secondary and a.model == "where2com" and a.lidar_only and a.gemm == "f32" and not a.amp and a.inflight > 1:
         for e in pipe.engines:
             e.split3 = True
         out3 = model(dd)  # tunes the split-3 tiles
@@ -427,7 +449,7 @@ def main(argv=None, hooks=None, device=None):
         split3_out = None
 
     # ---------------- second figure: frame + on-device post-process (decode, filters, rotated NMS) ----------
-    if secondary and a.model == "where2com":
+    if secondary and a.model == "where2com" and a.lidar_only:
         from airv2x_perception_amd.opencood_iface.voxel_postprocessor import VoxelPostprocessor
         post = VoxelPostprocessor(hy["postprocess"], dataset="airv2x", train=False)
         anchors = torch.from_numpy(post.generate_anchor_box())
@@ -519,9 +541,9 @@ def main(argv=None, hooks=None, device=None):
                                                        "is the 20-byte box-count record one lap later"}
 
     # ---------------- a scenario stream: the agent count changes from frame to frame ------------------------
-    if secondary and a.model == "where2com" and not a.amp and a.gemm == "f32":
+    if secondary and a.model == "where2com" and a.lidar_only and not a.amp and a.gemm == "f32":
         lens = [2, 3, 4, 5]
-        dds = [build_inputs(k, a.points, dev, only=None, model=a.model)[2] for k in lens]
+        dds = [build_inputs(k, a.points, dev, only=None, model=a.model, modalities=a.mods)[2] for k in lens]
         m2, e2, _ = make_model(a, args, dev)          # a fresh engine: nothing allocated, nothing tuned in this process
         first = {}
         for k, d_ in zip(lens, dds):
@@ -548,7 +570,7 @@ def main(argv=None, hooks=None, device=None):
         del m2, e2
 
     # ---------------- one TRAINING step of the same model (not the headline metric) ----------
-    if secondary and a.model == "where2com" and not a.amp and a.gemm == "f32" and not a.no_train:
+    if secondary and a.model == "where2com" and a.lidar_only and not a.amp and a.gemm == "f32" and not a.no_train:
         from tools.train_bench import run as train_run
         tr = train_run(agents=a.agents, steps=10, warmup=3, dev=dev, dd=dd, args=args)
         res["train_step"] = {k: tr[k] for k in ("ms_per_step", "steps_per_s", "ms_forward", "ms_loss_backward", "ms_optimizer",
@@ -560,7 +582,9 @@ def main(argv=None, hooks=None, device=None):
     # ---------------- roofline of the dominant kernel (second pass, events around each conv) -------------
     if not a.no_roofline and rank == 0 and dd is not None and model is not None and eng is not None:
         eng.use_graph = False
-        eng.throughput_mode = False   # sequential frames below
+        # the launches are timed one at a time (one frame at a time, events around every launch) but with the tiling the HEADLINE mode
+        # runs: with frames in flight the engine's throughput_mode hint keeps the quarter-position Winograd tile out (engine.py)
+        eng.throughput_mode = inflight_used > 1
         # What a hipEvent pair adds around ONE launch when the queue is full (the marker packets either side of the kernel):
         # with T1 = pair around one 4-byte fill and T2 = pair around two of them, T2 - T1 is one kernel + the gap to the
         # next, so 2*T1 - T2 is the pair's own share (minus one inter-kernel gap: a conservative, i.e. small, estimate).
@@ -617,15 +641,15 @@ def main(argv=None, hooks=None, device=None):
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         peak = PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS
         res["roofline"] = {
-            # achieved = ALGORITHMIC FLOPs (the direct-convolution count, 2 x pixels x Cout x 9 x Cin) over the
-            # launch time.  The Winograd kernel executes 16/36 of those multiplies, so its algorithmic rate may approach or
-            # pass the matrix-core peak; what the pipe itself sustains is in "mfma_executed".
-            "bound": "mfma", "achieved": round(eff, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(eff / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-            "mfma_executed": {"tflops": round(ach, 2), "frac": round(ach / peak, 4),
-                              "note": "multiplies the matrix cores actually execute over the same time"
-                                      + (": Winograd F(2x2,3x3) needs 16 per 2x2 output tile and channel pair where the direct form "
-                                         "(the algorithmic count) has 36" if wino else " (direct form: equal to achieved)")},
+            # achieved / frac = the multiplies the matrix cores EXECUTE over the launch time: what the MFMA peak bounds (always <= 1).
+            # A Winograd F(2x2,3x3) launch executes 16 multiplies per 2x2 output tile and channel pair where the direct form -- SURVEY
+            # 8d's algorithmic count, 2 x pixels x Cout x 9 x Cin -- has 36; the direct-form-equivalent rate is "effective_*"
+            # (it may pass the matrix-core peak: it is a speed-up figure, not a utilisation).
+            "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "effective_tflops": round(eff, 2), "effective_over_peak": round(eff / peak, 4),
+            "effective_note": ("direct-convolution (algorithmic, SURVEY 8d) FLOPs of the same launches over the same time"
+                               + (": Winograd executes 16/36 of them" if wino else ": equal to achieved (direct form)")),
             "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
             "kernel": (("conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
@@ -653,7 +677,9 @@ def main(argv=None, hooks=None, device=None):
                               for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])]} if a.per_shape else {}),
             **({"measured_on": f"rank 0, whole {a.agents}-agent frames on one GPU (the sharded run launches the same kernels on "
                                "each rank's share of the agents)"} if a.mode == "shard" else {}),
-            "timing": "second pass of K sequential frames (the single_stream schedule), hipEvent pair around every conv "
+            "tiling": ("the headline mode's (frames in flight: the quarter-position Winograd tile is not a candidate)" if inflight_used > 1
+                       else "the sequential mode's"),
+            "timing": "second pass of K sequential frames, hipEvent pair around every conv "
                       "launch on the launch stream minus event_pair_overhead_us; with several frames in flight the kernels of different frames overlap and "
                       "per-launch durations are not separable (rocprofv3 summary of this mode: profiles/*_inflight1.txt)",
         }
@@ -664,7 +690,8 @@ def main(argv=None, hooks=None, device=None):
         dd_cpu = synth.data_dict_to(dd, "cpu")
         torch.set_num_threads(usable_cores())
         with torch.no_grad():
-            for _ in range(2):
+            nwarm = 2 if a.lidar_only else 1
+            for _ in range(nwarm):
                 ref = orc.where2com_forward(dd_cpu, sd, args)  # warm-ups + parity reference
             ts = []
             for _ in range(a.cpu_frames):
@@ -673,13 +700,13 @@ def main(argv=None, hooks=None, device=None):
                 ts.append(time.perf_counter() - t0)
             med = float(np.median(ts))
             tw = []
-            for _ in range(min(3, a.cpu_frames)):   # the reference's as-written schedule (backbone evaluated again, :119/:124)
+            for _ in range(min(3, a.cpu_frames) if a.lidar_only else 1):   # the reference's as-written schedule (backbone evaluated again, :119/:124)
                 t0 = time.perf_counter()
                 orc.where2com_forward(dd_cpu, sd, args, reference_schedule=True)
                 tw.append(time.perf_counter() - t0)
         res["cpu_baseline"] = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
                                "kind": "port",
-                               "sample": f"median of {a.cpu_frames} frames of the same workload after 2 warm-ups, torch CPU fp32, "
+                               "sample": f"median of {a.cpu_frames} frames of the same workload after {nwarm} warm-up(s), torch CPU fp32, "
                                          f"de-duplicated schedule (1 backbone pass + masked blocks): {med:.2f} s/frame "
                                          f"(min {min(ts):.2f}, max {max(ts):.2f})",
                                "as_written_schedule": {"s_per_frame": round(float(np.median(tw)), 3), "frames": len(tw),
