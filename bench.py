@@ -112,6 +112,9 @@ def parse(argv=None):
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent frames kept in flight per GPU (separate HIP streams + workspaces, shared weights); "
                          "1 = strictly sequential frames (latency mode, also reported as single_stream)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no process group: validate the agent partition / padding / message sizes / second-level fusion shards of "
+                         "`--gpus N --model M --agents A` and print them with the expected bytes per xGMI link as one JSON line")
     ap.add_argument("--mode", choices=["replica", "shard"], default=None,
                     help="shard (default for N > 1): ONE frame's agents are split over the GPUs with an RCCL all-gather of the "
                          "masked features (SURVEY 8e, strong scaling); replica (default for N = 1): every GPU runs its own frames")
@@ -278,8 +281,64 @@ def shard_leg(a, rank, world, dist, dev, hooks, n_agents, steps=None, warmup=Non
     return dt, out, info
 
 
+XGMI_LINK_GBPS = 153.0     # per direction and link, 7 links per GPU (MI355X_MICROARCH.md); a fully connected 8-GPU node
+
+
+def dry_run(a):
+    """What the N-rank agent-sharded run WILL do, from the partition code the run itself uses (sharded.partition_agents,
+    fusion_column_shards, the engines' strip rule): counts, padding, bytes per message / per link, second-level shards."""
+    from airv2x_perception_amd import synth
+    from airv2x_perception_amd.opencood_iface.sharded import fusion_column_shards, partition_agents, valid_slots
+    world = a.gpus
+    n = a.agents if a.agents > 0 else max(4, world)
+    parts = partition_agents(n, world)
+    counts = [len(p) for p in parts]
+    n_pad = max(counts)
+    assert sum(counts) == n and list(parts[0])[:1] == [0], "the ego (agent 0) must be local agent 0 of rank 0"
+    slots = valid_slots(counts, n_pad)
+    assert len(slots) == n and slots == sorted(slots)
+    H, W = 100, 352                                     # feature map of the default 704 x 200 grid (stride 2)
+    if a.model == "where2com":
+        per_agent = 4 * (64 * H * W + 128 * (H // 2) * (W // 2) + 256 * (H // 4) * (W // 4))
+        what = "masked multi-scale maps (64x100x352 + 128x50x176 + 256x25x88 fp32)"
+    else:
+        per_agent = 4 * 256 * H * W
+        what = "shrink-header map (256x100x352 fp32)"
+    msg = n_pad * per_agent
+    out = {"dry_run": True, "model": a.model, "world": world, "agents": n, "agents_per_rank": counts, "n_pad": n_pad,
+           "idle_ranks": [r for r, c in enumerate(counts) if c == 0], "types": synth.sort_types(synth.agent_types_for(n))[1],
+           "ego": "rank 0, local agent 0", "message": what, "bytes_per_agent": per_agent, "bytes_per_rank_message": msg,
+           "all_gather": {"recv_bytes_per_rank": world * msg, "bytes_per_link_per_frame": msg if world > 1 else 0,
+                          "padding_bytes_per_rank": (world * n_pad - n) * per_agent,
+                          "links_used_per_gpu": max(0, world - 1),
+                          "lower_bound_us": round(msg / (XGMI_LINK_GBPS * 1e3), 1) if world > 1 else 0.0,
+                          "note": "xGMI is point-to-point: the world-1 peer messages into a GPU arrive over world-1 separate links, so the "
+                                  "all-gather is bound by ONE message per link (not by world-1 of them on one ring hop)"},
+           "rotating_ego_stage": {"frames_in_flight": max(1, a.inflight), "fusion_rank_of_frame_t": "t % world",
+                                  "opt_in_gather": {"env": "AV2X_SHARD_GATHER=1", "bytes_into_fusion_rank": (world - 1) * msg,
+                                                    "bytes_out_of_other_ranks": msg}}}
+    if a.model == "cobevt":
+        sh = fusion_column_shards(W, 4, world)
+        G = W // 16
+        out["second_level"] = {"kind": "residue-group columns (no exchange between the window and grid halves of a block)", "groups": G,
+                               "groups_per_rank": -(-G // world), "valid_columns_per_strip": [v for _, v in sh],
+                               "compact_width": len(sh[0][0]), "padded_groups": world * -(-G // world) - G,
+                               "head_gather_bytes_per_rank": 4 * 30 * H * len(sh[0][0])}
+        assert sorted(c for cols, v in sh for k, c in enumerate(cols) if k % (len(cols) // 4) < v) == list(range(W))
+    if a.model == "v2xvit":
+        ok = W % (4 * world) == 0
+        out["second_level"] = {"kind": "column strips of whole 4-column windows, one all-reduce of the split-attention mean per block",
+                               "splits": ok, "strip_width": W // world if ok else None,
+                               "fallback": None if ok else "W % (4 * world) != 0: every rank runs the whole fusion (single level)",
+                               "head_gather_bytes_per_rank": 4 * 30 * H * (W // world) if ok else 0}
+    print(json.dumps(out), flush=True)
+    return out
+
+
 def main(argv=None, hooks=None, device=None):
     a = parse(argv)
+    if a.dry_run:
+        return dry_run(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the boxes show 256 CPUs but grant a cgroup quota (16 on the 1-GPU box): share it between the ranks of the node

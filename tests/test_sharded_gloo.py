@@ -81,6 +81,22 @@ class OracleBackend:
                 "com": stats[0].float() / (n_total * H * W), "comm_rate": int(stats[1])}
 
 
+def _local_count(dd_local):
+    return 0 if dd_local is None else sum(int(dd_local[t]["record_len"][0]) for t in ("vehicle", "rsu", "drone") if dd_local[t]["batch_idxs"])
+
+
+def _real_agents(recv, meta, world):
+    """The gathered (world * n_pad, C, H, W) buffer with the padding slots of an uneven frame dropped (frame order kept)."""
+    from airv2x_perception_amd.opencood_iface.sharded import valid_slots
+    n_loc, c, h, w = meta["shape"]
+    s = recv.view(world * n_loc, c, h, w)
+    counts = meta.get("counts")
+    if counts is not None and sum(counts) != world * n_loc:
+        s = s[valid_slots(counts, n_loc)]
+    assert not torch.isnan(s).any()
+    return s
+
+
 class CoBEVTOracleBackend:
     """Same interface for the CoBEVT path: the message is the shrink output, or (compression > 0) the
     NaiveCompressor encoder output that the receiving side decodes (naive_compress.py:12-42)."""
@@ -91,8 +107,7 @@ class CoBEVTOracleBackend:
     def _decode(self, recv, meta, world):
         import torch.nn.functional as F
         sd, args = self.sd, self.args
-        n_loc, c, h, w = meta["shape"]
-        s = recv.view(world * n_loc, c, h, w)
+        s = _real_agents(recv, meta, world)
         if args["compression"]:
             for conv, bn in (("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
                 s = F.conv2d(s, sd[f"naive_compressor.{conv}.weight"], sd[f"naive_compressor.{conv}.bias"], padding=1)
@@ -124,27 +139,31 @@ class CoBEVTOracleBackend:
         c = a * self.args["num_class"]
         return {"psm": full[:, :c], "rm": full[:, c:c + 7 * a], "obj": full[:, c + 7 * a:]}
 
-    def local_stage(self, dd_local, has_ego):
+    def local_stage(self, dd_local, has_ego, n_pad=None):
         import torch.nn.functional as F
         sd, args = self.sd, self.args
+        n = _local_count(dd_local)
+        n_pad = n if n_pad is None else n_pad
+        g = args["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]
+        c = args["shrink_header"]["dim"][-1] // (args["compression"] or 1)
+        shape = (n_pad, c, int(g[1]) // 2, int(g[0]) // 2)
+        if n == 0:   # a rank without agents: an all-padding message that must never be read
+            return torch.full((int(np.prod(shape)),), float("nan")), torch.zeros(2, dtype=torch.int64), {"shape": shape}
         feats, _ = orc.extract_features(dd_local, sd, args)
         sf2d, _ = orc.backbone_forward(feats, sd, args["base_bev_backbone"])
         s = orc.shrink_conv(sf2d, sd, args["shrink_header"])
         if args["compression"]:
             s = F.conv2d(s, sd["naive_compressor.encoder.0.weight"], sd["naive_compressor.encoder.0.bias"], padding=1)
             s = F.relu(orc._bn(s, sd, "naive_compressor.encoder.1"))
-        return s.reshape(-1), torch.zeros(2, dtype=torch.int64), {"shape": tuple(s.shape)}
+        s = torch.cat([s, s.new_full((n_pad - n,) + tuple(s.shape[1:]), float("nan"))], 0)
+        assert tuple(s.shape) == shape
+        return s.reshape(-1), torch.zeros(2, dtype=torch.int64), {"shape": shape}
 
     def ego_stage(self, recv, stats, meta, world):
         import torch.nn.functional as F
         from oracle import cobevt_oracle as cob
         sd, args = self.sd, self.args
-        n_loc, c, h, w = meta["shape"]
-        s = recv.view(world * n_loc, c, h, w)
-        if args["compression"]:
-            for conv, bn in (("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
-                s = F.conv2d(s, sd[f"naive_compressor.{conv}.weight"], sd[f"naive_compressor.{conv}.bias"], padding=1)
-                s = F.relu(orc._bn(s, sd, f"naive_compressor.{bn}"))
+        s = self._decode(recv, meta, world)
         L = sum(args["max_cav"].values())
         x, mask = cob.regroup(s, torch.tensor([s.shape[0]]), L)
         fused = cob.swap_fusion_encoder(x, mask, sd, args["fax_fusion"])
@@ -242,19 +261,26 @@ class V2XViTOracleBackend:
     def __init__(self, sd, args, two_level=False):
         self.sd, self.args, self.two_level = sd, args, two_level
 
-    def local_stage(self, dd_local, has_ego):
+    def local_stage(self, dd_local, has_ego, n_pad=None):
         sd, args = self.sd, self.args
         mf = args["modality_fusion"]
+        n = _local_count(dd_local)
+        n_pad = n if n_pad is None else n_pad
+        g = args["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]
+        shape = (n_pad, mf["shrink_header"]["dim"][-1], int(g[1]) // 2, int(g[0]) // 2)
+        meta = {"shape": shape, "prior": dd_local["prior_encoding"], "scm": dd_local["spatial_correction_matrix"]}
+        if n == 0:
+            return torch.full((int(np.prod(shape)),), float("nan")), torch.zeros(2, dtype=torch.int64), meta
         feats, _ = orc.extract_features(dd_local, sd, args)
         sf2d, _ = orc.backbone_forward(feats, sd, mf["base_bev_backbone"])
         s = orc.shrink_conv(sf2d, sd, mf["shrink_header"])
-        meta = {"shape": tuple(s.shape), "prior": dd_local["prior_encoding"], "scm": dd_local["spatial_correction_matrix"]}
+        s = torch.cat([s, s.new_full((n_pad - n,) + tuple(s.shape[1:]), float("nan"))], 0)
         return s.reshape(-1), torch.tensor([0, int(feats.count_nonzero())], dtype=torch.int64), meta
 
     def _tokens(self, recv, meta, world):
         from oracle import cobevt_oracle as cob
         n_loc, c, h, w = meta["shape"]
-        s = recv.view(world * n_loc, c, h, w)
+        s = _real_agents(recv, meta, world)
         x, mask = cob.regroup(s, torch.tensor([s.shape[0]]), self.args["max_cav_num"])
         prior = meta["prior"].unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, h, w)
         return torch.cat([x, prior], dim=2).permute(0, 1, 3, 4, 2).contiguous(), mask
