@@ -129,8 +129,8 @@ class CameraEncoder:
             b["dw"] = (up(dw.contiguous()), up(_pad_vec(s1, mid_p, 1.0)), up(_pad_vec(h1, mid_p, 0.0)))
             wr = torch.zeros(se, mid_p)
             wr[:, :mid] = sd[q + "_se_reduce.weight"].detach().float().cpu().reshape(se, mid)
-            we = torch.zeros(mid_p, se)
-            we[:mid] = sd[q + "_se_expand.weight"].detach().float().cpu().reshape(mid, se)
+            we = torch.zeros(se, mid_p)                                                   # transposed: (c_se, c)
+            we[:, :mid] = sd[q + "_se_expand.weight"].detach().float().cpu().reshape(mid, se).t()
             b["se_w"] = (up(wr.contiguous()), up(sd[q + "_se_reduce.bias"].detach().float()), up(we.contiguous()),
                          up(_pad_vec(sd[q + "_se_expand.bias"], mid_p, 0.0)))
             s2, h2 = fold_bn(sd, q + "_bn2", EFF_EPS)

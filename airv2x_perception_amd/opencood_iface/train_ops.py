@@ -105,6 +105,17 @@ def _packed(r, weight, flipped=False):
     return wp, coutp, u
 
 
+# AMP training (tools/train.py:50,107-130: the forward runs under ``amp.autocast`` and the loss goes through a GradScaler): while
+# set, every Conv2d / ConvTranspose2d product of the step -- forward AND the data gradients, which autograd runs in the forward's
+# dtype -- uses bf16 matrix-core operands with fp32 accumulation (conv_igemm_bf16); BatchNorm statistics, the pillar encoder,
+# the attention, the loss and the weight gradients stay fp32, activations stay fp32 in HBM.  forward_train() sets it per step.
+AMP_STEP = [False]
+
+
+def set_amp_step(on):
+    AMP_STEP[0] = bool(on)
+
+
 def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=False):
     """act(scale * conv2d(x, w) + shift) through the engine's launcher (direct or Winograd kernels, autotuned).  ``flipped``:
     convolve with the 180-degree-rotated, channel-transposed weights (the data gradient)."""
@@ -119,7 +130,11 @@ def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=Fals
         L._wu = u
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-    r.conv(L, x, n, h, w, y)
+    r.amp = AMP_STEP[0] and cin % 8 == 0
+    try:
+        r.conv(L, x, n, h, w, y)
+    finally:
+        r.amp = False
     return y
 
 
@@ -130,7 +145,14 @@ def conv_wgrad(x, dz, weight_shape, stride, pad):
     d, _, _ = _desc(n, h, w, cin, cout, cout, ks, stride, pad, 0)
     ws = torch.empty(int(r.lib.av2x_conv2d_wgrad_workspace_bytes(byref(d))) // 4 + 4, device=x.device)
     dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
+    prof = getattr(r, "wgrad_profile", None)
+    if prof is not None:      # roofline pass of tools/train_bench.py: an event pair around the launch, on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(r.lib.av2x_conv2d_wgrad(byref(d), _P(x), _P(dz), _P(ws), _P(dw), r.stream()), "av2x_conv2d_wgrad")
+    if prof is not None:
+        e1.record()
+        prof.append((2.0 * n * d.ho * d.wo * cout * ks * ks * cin, e0, e1, (n * d.ho * d.wo, cin, cout, ks, stride)))
     return dw
 
 
@@ -322,7 +344,11 @@ class DeconvBNAct(torch.autograd.Function):
         wp, ncol = pack_deconv_weight_dev(weight)
         L = ConvLayer(wp, None, _zeros(cout, x.device), cin, cout, ncol, 1, 1, 0, 0, _lib.AV2X_DECONV, s)
         z = torch.empty((n, h * s, w * s, cout), dtype=torch.float32, device=x.device)
-        r.conv(L, x, n, h, w, z)
+        r.amp = AMP_STEP[0] and cin % 8 == 0
+        try:
+            r.conv(L, x, n, h, w, z)
+        finally:
+            r.amp = False
         y, mean, var, rstd, scale, shift, count = bn_train_forward(z, gamma, beta, eps, act, running)
         if stats_out is not None:
             stats_out.append((mean, var, count))

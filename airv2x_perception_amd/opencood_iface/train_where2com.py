@@ -92,6 +92,10 @@ def forward_train(model, data_dict, topk=None, mask=None, trace=None):
     if not model.multi_scale:
         raise NotImplementedError("training: the multi-scale fusion (every shipped AirV2X Where2Comm config)")
     r = _runner(dev)
+    # torch.autocast around the forward (tools/train.py:118) or model.amp = True -> bf16 matrix-core operands for this step's
+    # convolutions, forward and data gradients alike (train_ops.AMP_STEP); a GradScaler on top works unchanged (fp32 gradients)
+    from .airv2x_where2com import _amp_requested
+    T.set_amp_step(_amp_requested(model))
     mf = args["modality_fusion"]
     bb = mf["base_bev_backbone"]
     fcfg = args["where2com_fusion"]

@@ -633,7 +633,7 @@ def main(argv=None, hooks=None, device=None):
         from tools.train_bench import run as train_run
         tr = train_run(agents=a.agents, steps=10, warmup=3, dev=dev, dd=dd, args=args)
         res["train_step"] = {k: tr[k] for k in ("ms_per_step", "steps_per_s", "ms_forward", "ms_loss_backward", "ms_optimizer",
-                                                "peak_mem_gib", "agents", "steps")}
+                                                "peak_mem_gib", "agents", "steps", "roofline")}
         res["train_step"]["note"] = ("Airv2xWhere2com.train(): train-mode forward (BatchNorm batch statistics, random top-K mask) + "
                                      "PointPillarLossMultiClass + backward + Adam, every autograd node a HIP forward / backward "
                                      "kernel pair (tools/train_bench.py; profiles/r02_kernel_stats_train.txt)")
@@ -759,7 +759,7 @@ def main(argv=None, hooks=None, device=None):
                 ts.append(time.perf_counter() - t0)
             med = float(np.median(ts))
             tw = []
-            for _ in range(min(3, a.cpu_frames) if a.lidar_only else 1):   # the reference's as-written schedule (backbone evaluated again, :119/:124)
+            for _ in range(a.cpu_frames if a.lidar_only else 1):   # the reference's as-written schedule (backbone evaluated again, :119/:124)
                 t0 = time.perf_counter()
                 orc.where2com_forward(dd_cpu, sd, args, reference_schedule=True)
                 tw.append(time.perf_counter() - t0)

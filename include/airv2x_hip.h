@@ -405,7 +405,7 @@ int av2x_lss_voxel_pool(const float* x, const float* frustum, const float* cam_p
  *                      asymmetric zero padding as above.  MBConv `_depthwise_conv` + `_bn1` + swish.
  * av2x_squeeze_excite  MBConv squeeze-excite on x (n, hw, c) in place: gate = sigmoid(W_e swish(W_r mean_hw(x) + b_r) + b_e), x *= gate
  *                      (apply = 0: only the gate, left at workspace + n * av2x_se_slabs(hw) * c floats).  w_reduce (c_se, c),
- *                      w_expand (c, c_se).  Sums run in a fixed order (bit-reproducible).  workspace: av2x_squeeze_excite_workspace_bytes.
+ *                      w_expand TRANSPOSED to (c_se, c) (coalesced reads).  Sums run in a fixed order (bit-reproducible).  workspace: av2x_squeeze_excite_workspace_bytes.
  * av2x_resize_bilinear nn.Upsample(bilinear, align_corners=True) of in (n, h, w, c of in_ctot from in_coff) to (h2, w2), placed at
  *                      (pad_t, pad_l) of the (hout, wout) output with zeros around it (F.pad in Up.forward :41-45), written to the
  *                      channel slice [out_coff, out_coff + c) of out (n, hout, wout, out_ctot) (torch.cat :46).  h2 == h copies.

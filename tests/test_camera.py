@@ -182,7 +182,7 @@ def test_squeeze_excite_matches_torch(c, cse, hw):
     d = _dev()
     xd = x.to(d)
     ws = torch.empty(int(lib.av2x_squeeze_excite_workspace_bytes(n, hw, c)) // 4, device=d)
-    wrd, brd, wed, bed = wr.to(d), br.to(d), we.to(d), be.to(d)
+    wrd, brd, wed, bed = wr.to(d), br.to(d), we.t().contiguous().to(d), be.to(d)      # w_expand is handed over transposed (c_se, c)
     L.check(lib.av2x_squeeze_excite(_p(xd), n, hw, c, _p(wrd), _p(brd), cse, _p(wed), _p(bed), _p(ws), 1, _st()), "se")
     assert_close(xd.cpu().numpy(), y.numpy(), 2e-5, 2e-6, "squeeze-excite")
     x2 = x.to(d)

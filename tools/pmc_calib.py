@@ -5,6 +5,7 @@
   av2x_fill_zero      writes   BYTES           reads 0
   torch copy_         writes   BYTES           reads BYTES   (16 B/lane)
   torch sum           writes   ~0              reads BYTES
+  strided copy        writes   BYTES           reads BYTES   (4 B/lane, lanes 32 B apart: the dword-gather pattern)
 
 BYTES = 576 MiB (> the 256 MiB Infinity Cache).  Run under `rocprofv3 --pmc FETCH_SIZE` and
 `--pmc WRITE_SIZE` in separate passes; tools/pmc_traffic.py turns the two csv files into scale factors."""
@@ -22,5 +23,8 @@ for _ in range(3):
     _lib.check(lib.av2x_fill_zero(x.data_ptr(), BYTES, st), "fill")
     y.copy_(x)
     s = x.sum()
+    # dword-per-lane reads in 32-byte runs, every byte of every line used once per launch (the Winograd kernels' input gather pattern:
+    # lane -> one fp32 of an 8-channel run, neighbouring lanes 32 B apart): a (N, 8) -> (8, N) transposing copy
+    y.view(8, -1).copy_(x.view(-1, 8).t())
 torch.cuda.synchronize()
 print("calib done", float(s))

@@ -34,6 +34,10 @@ def conv_key(name):
     wn = re.search(r"conv_wino_f32<(\d+), (\d+)>", name)
     if wn:  # Winograd F(2x2,3x3): bench.py's key "w<tiles>x<couts>" per workgroup
         return f"w{32 * int(wn.group(1))}x{32 * int(wn.group(2))}"
+    b = re.search(r"conv_igemm_bf16<(\d+), (\d+), (\d+), (\d+)>", name)
+    if b:   # AMP kernels: bench.py's key "<BM>x<BN>[w8]_bf16"
+        bm, bn, wm, wn = (int(b.group(i)) for i in range(1, 5))
+        return f"{bm}x{bn}{'w8' if (bm // wm) * (bn // wn) == 8 else ''}_bf16"
     m = re.search(r"conv_igemm_f32<(\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false|\d))?>", name)
     if not m:
         return None
@@ -49,8 +53,8 @@ def calib(d, counter, kernel_sub, known_bytes):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--fetch", required=True)
-    ap.add_argument("--write", required=True)
+    ap.add_argument("--fetch", required=True, nargs="+", help="one or more FETCH_SIZE pass directories (several bench modes are merged)")
+    ap.add_argument("--write", required=True, nargs="+")
     ap.add_argument("--calib-fetch")
     ap.add_argument("--calib-write")
     ap.add_argument("--calib-bytes", type=int, default=576 << 20)
@@ -63,11 +67,18 @@ def main():
         w1, n3 = calib(a.calib_write, "WRITE_SIZE", "copyBuffer", a.calib_bytes)
         w2, n4 = calib(a.calib_write, "WRITE_SIZE", "fillBufferAligned", a.calib_bytes)
         fscale, wscale = round((f1 + f2) / 2, 3), round((w1 + w2) / 2, 3)
+        try:     # dword-per-lane reads in 32-byte runs (the Winograd input gather's pattern): tools/pmc_calib.py's strided copy
+            f3, n5 = calib(a.calib_fetch, "FETCH_SIZE", "elementwise_kernel", a.calib_bytes)
+        except ZeroDivisionError:
+            f3, n5 = None, 0
         cal = {"known_bytes": a.calib_bytes, "fetch_scale_copy": round(f1, 4), "fetch_scale_reduce": round(f2, 4),
+               "fetch_scale_dword_gather": (round(f3, 4) if f3 else None), "dword_gather_launches": n5,
+               "dword_gather_note": "the strided copy of tools/pmc_calib.py re-fetches every line in 8 far-apart sweeps: 0.25 here = the streaming "
+                                    "factor 2.0 / 8 re-fetches, i.e. the x 2 correction holds for dword gathers",
                "write_scale_copy": round(w1, 4), "write_scale_fill": round(w2, 4), "launches": [n1, n2, n3, n4],
                "note": "true bytes / (counter KiB x 1024) on tools/pmc_calib.py (576 MiB streaming copy / sum / fill)"}
     acc = defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
-    for d in (a.fetch, a.write):
+    for d in list(a.fetch) + list(a.write):
         last = None  # the stream-K launch a following conv_fixup_f32 dispatch belongs to
         for name, grid, wg, ctr, val in rows(d):
             if ctr not in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -76,6 +76,46 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
            "ms_forward": round(t_f / k, 3), "ms_loss_backward": round(t_b / k, 3), "ms_optimizer": round(t_o / k, 3),
            "steps_per_s": round(1e3 * k / (t_f + t_b + t_o), 3), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)], "dtype": "f32", "data": "synthetic"}
+    # ---- roofline of the step's MFMA kernels: a second pass with an event pair around every convolution launch (forward and data
+    # gradients go through the engine's launcher: its profile hook; weight gradients: train_ops' hook), weight gradients on the
+    # main stream so that the pairs do not overlap
+    from airv2x_perception_amd.opencood_iface import train_ops as T
+    from airv2x_perception_amd.opencood_iface.autograd import _runner
+    r = _runner(dev)
+    overlap, T.OVERLAP_WGRAD = T.OVERLAP_WGRAD, False
+    r.profile, r.wgrad_profile = [], []
+    psteps = max(2, min(4, a.steps))
+    for _ in range(psteps):
+        opt.zero_grad(set_to_none=True)
+        crit(model(dd), tgt).backward()
+    torch.cuda.synchronize()
+    prof, wprof = r.profile, r.wgrad_profile
+    r.profile, r.wgrad_profile, T.OVERLAP_WGRAD = None, None, overlap
+    PEAK = 157.3
+    groups = {"conv_wino_f32 (forward + data gradients)": [0, 0.0, 0.0, 0.0], "conv_igemm_f32 (forward + data gradients, 1x1 / stride 2 / deconv)": [0, 0.0, 0.0, 0.0],
+              "conv_wgrad (weight gradients)": [0, 0.0, 0.0, 0.0]}
+    for tile, flops, e0, e1, wgs, shp in prof:
+        wino = bool(tile[0] & 0x4000)
+        gk = "conv_wino_f32 (forward + data gradients)" if wino else "conv_igemm_f32 (forward + data gradients, 1x1 / stride 2 / deconv)"
+        v = groups[gk]
+        v[0] += 1; v[1] += flops; v[2] += flops * (16.0 / 36.0 if wino else 1.0); v[3] += e0.elapsed_time(e1) * 1e-3
+    for flops, e0, e1, shp in wprof:
+        v = groups["conv_wgrad (weight gradients)"]
+        v[0] += 1; v[1] += flops; v[2] += flops; v[3] += e0.elapsed_time(e1) * 1e-3
+    dom = max(groups, key=lambda kk: groups[kk][3])
+    cnt, fl, exe, sec = groups[dom]
+    tot_exe, tot_s = sum(v[2] for v in groups.values()), sum(v[3] for v in groups.values())
+    res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(exe / sec / 1e12, 2), "peak": PEAK, "unit": "TFLOP/s",
+                       "frac": round(exe / sec / 1e12 / PEAK, 4), "effective_tflops": round(fl / sec / 1e12, 2), "traffic": None,
+                       "launches_per_step": cnt / psteps, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                       "per_group": {kk: {"launches_per_step": v[0] / psteps, "ms_per_step": round(v[3] / psteps * 1e3, 3),
+                                          "executed_tflops": round(v[2] / v[3] / 1e12, 2), "frac": round(v[2] / v[3] / 1e12 / PEAK, 4)}
+                                     for kk, v in groups.items() if v[0]},
+                       "all_mfma_kernels": {"ms_per_step": round(tot_s / psteps * 1e3, 3), "executed_tflops": round(tot_exe / tot_s / 1e12, 2),
+                                            "frac": round(tot_exe / tot_s / 1e12 / PEAK, 4)},
+                       "note": "executed matrix-core FLOPs (Winograd launches: 16/36 of the direct count) over hipEvent pairs around every launch, "
+                               f"{psteps} extra steps with the weight gradients on the main stream; the BatchNorm / pillar / attention kernels are HBM-bound "
+                               "(tools/bn_bench.py) and not part of this object"}
     if a.cpu and dd_host is not None:
         from oracle import loss_oracle as lo
         from oracle import where2comm_oracle as orc
