@@ -466,7 +466,7 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
             return av2x::fail("av2x_conv2d: deconv needs cout %% 32 == 0 and coutp == up*up*cout");
         p.ks = 1; p.stride = 1; p.pad = 0; p.Ho = d->h; p.Wo = d->w;
     } else {
-        if (d->ks != 1 && d->ks != 3 && d->ks != 5 && d->ks != 7) return av2x::fail("av2x_conv2d: ks=%d unsupported (1, 3, 5, 7)", d->ks);
+        if (d->ks < 1 || d->ks > 7) return av2x::fail("av2x_conv2d: ks=%d unsupported (1 .. 7)", d->ks);
         p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.Ho = d->ho; p.Wo = d->wo;
         if (p.Ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1 || p.Wo != (d->w + 2 * d->pad - d->ks) / d->stride + 1)
             return av2x::fail("av2x_conv2d: output dims %dx%d inconsistent with input/stride/pad", p.Ho, p.Wo);

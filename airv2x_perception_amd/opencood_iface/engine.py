@@ -166,6 +166,10 @@ class Where2ComEngine:
 
     def _init_config(self, args):
         self.bb = args["modality_fusion"]["base_bev_backbone"]
+        ups = self.bb.get("upsample_strides", [])
+        if len(ups) != len(self.bb["layer_nums"]) or any(s < 1 for s in ups):
+            raise NotImplementedError("down-sampling deblocks / the extra final deblock inside the full AirV2X models (no shipped AirV2X "
+                                      "YAML has them); the stand-alone BaseBEVBackbone module runs them")
         self.sh = args["modality_fusion"]["shrink_header"]
         self.fcfg = args["where2com_fusion"]
         if not self.fcfg["multi_scale"]:
@@ -260,12 +264,67 @@ class Where2ComEngine:
                 idx += 3
             self.blocks.append(layers)
             cin = c
-        for i, (s, cu) in enumerate(zip(self.bb["upsample_strides"], self.bb["num_upsample_filter"])):
-            w, ncol = pack_deconv_weight(sd[f"{prefix}deblocks.{i}.0.weight"])
+        nlev = len(self.bb["layer_nums"])
+        for i, (s, cu) in enumerate(zip(self.bb["upsample_strides"][:nlev], self.bb["num_upsample_filter"])):
             sc, sh = fold_bn(sd, f"{prefix}deblocks.{i}.1")
-            self.deblocks.append(ConvLayer(up(w), up(sc), up(sh), self.bb["num_filters"][i], cu, ncol, 1, 1, 0, 1,
-                                           _lib.AV2X_DECONV, s))
+            if s >= 1:
+                w, ncol = pack_deconv_weight(sd[f"{prefix}deblocks.{i}.0.weight"])
+                self.deblocks.append(ConvLayer(up(w), up(sc), up(sh), self.bb["num_filters"][i], cu, ncol, 1, 1, 0, 1,
+                                               _lib.AV2X_DECONV, int(s)))
+            else:   # a "deblock" that down-samples: Conv2d(k, stride k), k = round(1 / s)  (base_bev_backbone.py:87-105)
+                k = int(round(1.0 / s))
+                w, coutp = pack_conv_weight(sd[f"{prefix}deblocks.{i}.0.weight"])
+                self.deblocks.append(ConvLayer(up(w), up(sc), up(sh), self.bb["num_filters"][i], cu, coutp, k, k, 0, 1))
         self.cat_c = sum(self.bb["num_upsample_filter"])
+        self.final_deblock = None
+        if len(self.bb["upsample_strides"]) > nlev:   # ConvTranspose2d on the concatenated map (:107-121, :151-152)
+            s = int(self.bb["upsample_strides"][-1])
+            w, ncol = pack_deconv_weight(sd[f"{prefix}deblocks.{nlev}.0.weight"])
+            sc, sh = fold_bn(sd, f"{prefix}deblocks.{nlev}.1")
+            self.final_deblock = ConvLayer(up(w), up(sc), up(sh), self.cat_c, self.cat_c, ncol, 1, 1, 0, 1, _lib.AV2X_DECONV, s)
+
+    def load_resnet(self, sd, prefix, layer_nums, layer_strides, num_filters, inplanes=64):
+        """ResNetModified(BasicBlock, ...) (coalign_modules/resblock.py:149-268, levels layer0, layer1, ...): per level a list of
+        BasicBlocks = (conv3x3/s + BN + ReLU, conv3x3 + BN with the ReLU applied AFTER the residual add [activation code 5], optional
+        1x1/s + BN on the identity)."""
+        up = self._up
+        self.res_layers, cin = [], int(inplanes)
+        for li, (n, st, c) in enumerate(zip(layer_nums, layer_strides, num_filters)):
+            blocks = []
+            for j in range(n):
+                q = f"{prefix}layer{li}.{j}."
+                s_ = st if j == 0 else 1
+                w1, cp1 = pack_conv_weight(sd[q + "conv1.weight"])
+                w2, cp2 = pack_conv_weight(sd[q + "conv2.weight"])
+                s1, h1 = fold_bn(sd, q + "bn1", 1e-5)
+                s2, h2 = fold_bn(sd, q + "bn2", 1e-5)
+                blk = {"c1": ConvLayer(up(w1), up(s1), up(h1), cin if j == 0 else c, c, cp1, 3, s_, 1, 1),
+                       "c2": ConvLayer(up(w2), up(s2), up(h2), c, c, cp2, 3, 1, 1, 5), "down": None}
+                if (q + "downsample.0.weight") in sd:
+                    wd, cpd = pack_conv_weight(sd[q + "downsample.0.weight"])
+                    sd_, hd = fold_bn(sd, q + "downsample.1", 1e-5)
+                    blk["down"] = ConvLayer(up(wd), up(sd_), up(hd), cin, c, cpd, 1, s_, 0, 0)
+                blocks.append(blk)
+            self.res_layers.append(blocks)
+            cin = c
+
+    def run_resnet_layer(self, li, x, n, h, w, tag, out=None):
+        """One level of the ResNet backbone on n images; returns (buffer, ho, wo)."""
+        cur, ch, cw = x, h, w
+        blocks = self.res_layers[li]
+        for j, blk in enumerate(blocks):
+            s_ = blk["c1"].stride
+            ho, wo, c = (ch + 2 - 3) // s_ + 1, (cw + 2 - 3) // s_ + 1, blk["c1"].cout
+            a = self.buf(f"res{li}_{j}a_{tag}", (n, ho, wo, c))
+            self.conv(blk["c1"], cur, n, ch, cw, a)
+            idt = cur
+            if blk["down"] is not None:
+                idt = self.buf(f"res{li}_{j}d_{tag}", (n, ho, wo, c))
+                self.conv(blk["down"], cur, n, ch, cw, idt)
+            o = out if (out is not None and j == len(blocks) - 1) else self.buf(f"res{li}_{j}o_{tag}", (n, ho, wo, c))
+            self.conv(blk["c2"], a, n, ho, wo, o, residual=idt)
+            cur, ch, cw = o, ho, wo
+        return cur, ch, cw
 
     def load_shrink(self, sd, prefix="shrink_conv."):
         """DownsampleConv weights: per layer Conv(k) + ReLU, Conv3x3 + ReLU (biases, no BN).  Returns the output width."""

@@ -280,8 +280,12 @@ class BaseBEVBackbone(_HipModule):
         self.model_cfg = model_cfg
         self.input_channels = input_channels
         ups = model_cfg.get("upsample_strides", [])
-        if len(ups) not in (0, len(model_cfg["layer_nums"])) or any(s < 1 for s in ups):
-            raise NotImplementedError("BaseBEVBackbone: down-sampling deblocks / the extra final deblock are not built")
+        nlev = len(model_cfg["layer_nums"])
+        if len(ups) not in (0, nlev, nlev + 1):
+            raise ValueError("upsample_strides: one per level, optionally one more for the final deblock")
+        # variants of base_bev_backbone.py:87-121 (OPV2V-style configs): deblocks that DOWN-sample (stride < 1 -> Conv2d(k, stride k)) and
+        # one more ConvTranspose2d on the concatenated map; eval mode (their training is not built)
+        self.variant = len(ups) == nlev + 1 or any(s < 1 for s in ups)
         _declare(self, backbone_param_spec(model_cfg, input_channels, ""))
         for p_ in self.parameters():
             p_.requires_grad_(True)          # trainable, as the reference's nn.Module is (train mode below)
@@ -289,8 +293,10 @@ class BaseBEVBackbone(_HipModule):
             self.add_module("deblocks", _Node())
         for i in range(len(model_cfg["layer_nums"])):
             _retype(self.blocks[i], _Stage).bind(self, "_run_block", i)
-        for i in range(len(ups)):
+        for i in range(min(len(ups), nlev)):
             _retype(self.deblocks[i], _Stage).bind(self, "_run_deblock", i)
+        if len(ups) == nlev + 1:
+            _retype(self.deblocks[nlev], _Stage).bind(self, "_run_deblock", nlev)
         self.num_bev_features = sum(model_cfg.get("num_upsample_filter", [])) if ups else model_cfg["num_filters"][-1]
 
     def _make_runner(self, device):
@@ -298,6 +304,16 @@ class BaseBEVBackbone(_HipModule):
         cfg.setdefault("upsample_strides", [])
         cfg.setdefault("num_upsample_filter", [])
         return _Runner(device, bb=cfg)
+
+    def _layer(self, i):
+        r = self.runner()
+        return r.final_deblock if i == len(r.blocks) else r.deblocks[i]
+
+    @staticmethod
+    def _out_hw(L, h, w):
+        if L.mode == _lib.AV2X_DECONV:
+            return h * L.up, w * L.up
+        return (h - L.ks) // L.stride + 1, (w - L.ks) // L.stride + 1
 
     def _pack(self, r, sd):
         r.load_backbone(sd, "", self.input_channels)
@@ -316,9 +332,10 @@ class BaseBEVBackbone(_HipModule):
     def deblock_nhwc(self, i, x, out=None, out_ctot=None, out_coff=0):
         r = self.runner()
         n, h, w, _ = x.shape
-        L = r.deblocks[i]
+        L = self._layer(i)
         if out is None:
-            out = torch.empty((n, h * L.up, w * L.up, L.cout), dtype=torch.float32, device=r.device)
+            ho, wo = self._out_hw(L, h, w)
+            out = torch.empty((n, ho, wo, L.cout), dtype=torch.float32, device=r.device)
         r.conv(L, x, n, h, w, out, out_ctot=out_ctot, out_coff=out_coff)
         return out
 
@@ -348,12 +365,16 @@ class BaseBEVBackbone(_HipModule):
 
     def _run_deblock(self, i, x):
         if self.training:
+            if self.variant:
+                raise NotImplementedError("training of the down-sampling / final-deblock variants is not built")
             return _nchw(self._train_deblock(i, _nhwc_grad(x)))
         with torch.no_grad():
             return _nchw(self.deblock_nhwc(i, _nhwc(x)))
 
     def forward(self, data_dict):
         if self.training:
+            if self.variant:
+                raise NotImplementedError("training of the down-sampling / final-deblock variants is not built")
             x = _nhwc_grad(data_dict["spatial_features"])
             ups = []
             for i in range(len(self.model_cfg["layer_nums"])):
@@ -375,22 +396,112 @@ class BaseBEVBackbone(_HipModule):
             x = self.block_nhwc(i, x)
             feats.append(x)
         if len(r.deblocks) > 0:
-            up0 = r.deblocks[0].up
-            H, W = feats[0].shape[1] * up0, feats[0].shape[2] * up0
+            H, W = self._out_hw(r.deblocks[0], feats[0].shape[1], feats[0].shape[2])
             cat = torch.empty((n, H, W, r.cat_c), dtype=torch.float32, device=r.device)
             coff = 0
             for i, f in enumerate(feats):                                   # torch.cat(ups, dim=1) written in place
-                if (f.shape[1] * r.deblocks[i].up, f.shape[2] * r.deblocks[i].up) != (H, W):
+                if self._out_hw(r.deblocks[i], f.shape[1], f.shape[2]) != (H, W):
                     raise ValueError("deblock outputs do not share one resolution")
                 self.deblock_nhwc(i, f, out=cat, out_ctot=r.cat_c, out_coff=coff)
                 coff += r.deblocks[i].cout
             out = cat
+            if r.final_deblock is not None:                                 # base_bev_backbone.py:151-152
+                out = self.deblock_nhwc(len(r.blocks), cat)
         else:
             if len(feats) != 1:
                 raise NotImplementedError("BaseBEVBackbone without deblocks: a single level only")
             out = feats[0]
         data_dict["spatial_features_2d"] = _nchw(out)
         return data_dict
+
+
+class ResNetBEVBackbone(BaseBEVBackbone):
+    """models/common_modules/base_bev_backbone_resnet.py:16-128 (the backbone of airv2x_heal / airv2x_stamp / point_pillar_coalign):
+    ``resnet`` = coalign_modules.resblock.ResNetModified(BasicBlock, layer_nums, layer_strides, num_filters, inplanes) returning the
+    level maps (levels ``layer0``, ``layer1``, ...), then BaseBEVBackbone's deblocks.  ``resnet(x)`` is callable on NCHW-shaped maps like the reference's module
+    (where2comm_attn.py:312-314 calls it).  Eval mode."""
+
+    def __init__(self, model_cfg, input_channels=64):
+        _HipModule.__init__(self)
+        from ..synth import resnet_backbone_param_spec
+        self.model_cfg = model_cfg
+        self.input_channels = int(model_cfg.get("inplanes", input_channels))      # base_bev_backbone_resnet.py:50
+        ups = model_cfg.get("upsample_strides", [])
+        nlev = len(model_cfg["layer_nums"])
+        if len(ups) not in (0, nlev, nlev + 1):
+            raise ValueError("upsample_strides: one per level, optionally one more for the final deblock")
+        self.variant = True               # no training path
+        _declare(self, resnet_backbone_param_spec(model_cfg, "", self.input_channels))
+        if "deblocks" not in self._modules:
+            self.add_module("deblocks", _Node())
+        for i in range(min(len(ups), nlev)):
+            _retype(self.deblocks[i], _Stage).bind(self, "_run_deblock", i)
+        if len(ups) == nlev + 1:
+            _retype(self.deblocks[nlev], _Stage).bind(self, "_run_deblock", nlev)
+        _retype(self.resnet, _Stage).bind(self, "_run_resnet", 0)
+        self.num_levels = nlev
+        self.num_bev_features = sum(model_cfg.get("num_upsample_filter", [])) if ups else model_cfg["num_filters"][-1]
+
+    def _pack(self, r, sd):
+        cfg = self.model_cfg
+        r.load_resnet(sd, "resnet.", cfg["layer_nums"], cfg["layer_strides"], cfg["num_filters"], self.input_channels)
+        r.blocks = [None] * len(cfg["layer_nums"])                        # level count for the shared deblock code
+        only_deblocks = {k: v for k, v in sd.items() if k.startswith("deblocks.")}
+        self._load_deblocks(r, only_deblocks)
+
+    @staticmethod
+    def _load_deblocks(r, sd):
+        """BaseBEVBackbone's deblock loader without its blocks: a runner whose ``bb`` lists zero layers per level."""
+        saved = r.bb
+        r.bb = dict(saved, layer_nums=[-1] * len(saved["layer_nums"]))   # range(n + 1) is empty: no block weights are read
+        try:
+            blocks = r.blocks
+            r.load_backbone(sd, "", 64)
+            r.blocks = blocks
+        finally:
+            r.bb = saved
+
+    def resnet_nhwc(self, x):
+        """x (n,h,w,64) -> [level maps]"""
+        r = self.runner()
+        n, h, w, _ = x.shape
+        feats, cur = [], x
+        for li in range(len(r.res_layers)):
+            c = r.res_layers[li][0]["c1"].cout
+            s_ = r.res_layers[li][0]["c1"].stride
+            out = torch.empty((n, (h + 2 - 3) // s_ + 1, (w + 2 - 3) // s_ + 1, c), dtype=torch.float32, device=r.device)
+            cur, h, w = r.run_resnet_layer(li, cur, n, h, w, "sub", out=out)
+            feats.append(cur)
+        return feats
+
+    def _run_resnet(self, _i, x):
+        with torch.no_grad():
+            return tuple(_nchw(f) for f in self.resnet_nhwc(_nhwc(x)))
+
+    def block_nhwc(self, i, x, out=None):
+        raise NotImplementedError("ResNetBEVBackbone has no blocks[i]: call resnet(x)")
+
+    def forward(self, data_dict):
+        if self.training:
+            raise NotImplementedError("ResNetBEVBackbone: training is not built; call .eval()")
+        with torch.no_grad():
+            r = self.runner()
+            feats = self.resnet_nhwc(_nhwc(data_dict["spatial_features"]))
+            n = feats[0].shape[0]
+            if len(r.deblocks) > 0:
+                H, W = self._out_hw(r.deblocks[0], feats[0].shape[1], feats[0].shape[2])
+                cat = torch.empty((n, H, W, r.cat_c), dtype=torch.float32, device=r.device)
+                coff = 0
+                for i, f in enumerate(feats):
+                    self.deblock_nhwc(i, f, out=cat, out_ctot=r.cat_c, out_coff=coff)
+                    coff += r.deblocks[i].cout
+                out = cat
+                if r.final_deblock is not None:
+                    out = self.deblock_nhwc(len(r.blocks), cat)
+            else:
+                out = torch.cat(feats, -1) if len(feats) > 1 and all(f.shape[1:3] == feats[0].shape[1:3] for f in feats) else feats[0]
+            data_dict["spatial_features_2d"] = _nchw(out)
+            return data_dict
 
 
 # ----------------------------------------------------------------------------------------------- shrink / compressor

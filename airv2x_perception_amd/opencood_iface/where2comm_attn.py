@@ -16,9 +16,11 @@ mask kernel, gated count of the non-zero cells, in-place masking] -> ONE ``av2x_
 every agent through its ego-row matrix and applies the per-pixel attention (or max) on the fly -> deblock written straight
 into its channel slice of the concatenated output.  The warped maps never exist in HBM.
 
-Not built (raises): the 'Transformer' aggregation (the reference's EncodeLayer passes a ``quality_map`` keyword that
-``nn.MultiheadAttention`` does not accept, where2comm_attn.py:108-110) and the ResNet backbone variant
-(``backbone.resnet``, base_bev_backbone_resnet.py).  Inference only, GPU only.
+The ResNet backbone variant (``backbone.resnet``, base_bev_backbone_resnet.py -> submodules.ResNetBEVBackbone) is built.
+Raises, as the reference does: the 'Transformer' aggregation -- ``Where2comm.forward`` calls ``self.fuse_modules[i](neighbor_feature)``
+with ONE argument (:360) where ``TransformerFusion.forward`` takes four (:130-136: TypeError), its EncodeLayer passes a ``quality_map``
+keyword that ``nn.MultiheadAttention`` does not accept (:105-107), and the single-scale form stores the module as ``fuse_network`` but
+calls ``fuse_modules`` (:262, :399): no configuration of that mode can run in the reference.  Inference only, GPU only.
 """
 from __future__ import annotations
 
@@ -97,8 +99,10 @@ class Where2comm(_HipModule):
         self.downsample_rate = args["downsample_rate"]
         self.agg_mode = args["agg_operator"]["mode"]
         if self.agg_mode == "Transformer":
-            raise NotImplementedError("Where2comm (MI355X build): the 'Transformer' aggregation is not built (the reference's "
-                                      "EncodeLayer calls nn.MultiheadAttention with a quality_map keyword it does not have)")
+            raise NotImplementedError("agg_operator mode 'Transformer' cannot run in the reference either: Where2comm.forward calls the "
+                                      "fusion module with one argument where TransformerFusion.forward takes four "
+                                      "(where2comm_attn.py:360 vs :130-136), and EncodeLayer passes nn.MultiheadAttention a "
+                                      "quality_map keyword it does not have (:105-107)")
         if self.agg_mode not in _MODES:
             raise ValueError(f"agg_operator mode {self.agg_mode!r}: ATTEN or MAX")
         self.multi_scale = args["multi_scale"]
@@ -226,16 +230,16 @@ class Where2comm(_HipModule):
             out = torch.empty((B,) + tuple(cur.shape[1:]), dtype=torch.float32, device=r.device)
             self._fuse(r, cur, lens, theta, out)
             return _nchw(out), self._volume(vol, B, r), {}
-        if hasattr(backbone, "resnet"):
-            raise NotImplementedError("Where2comm (MI355X build): the ResNet backbone variant is not built")
+        with_resnet = hasattr(backbone, "resnet")                  # where2comm_attn.py:312-314
         if not isinstance(backbone, BaseBEVBackbone):
             raise TypeError("Where2comm (MI355X build): `backbone` must be the BaseBEVBackbone of this build")
         br = backbone.runner()
         if len(br.blocks) < self.num_levels:
             raise ValueError("the backbone has fewer levels than the fusion configuration")
         cat, coff, ups = None, 0, []
+        feats = backbone.resnet_nhwc(cur) if with_resnet else None    # every level from the UNMASKED input, as written
         for i in range(self.num_levels):
-            cur = backbone.block_nhwc(i, cur)
+            cur = feats[i] if with_resnet else backbone.block_nhwc(i, cur)
             n, h, w, c = cur.shape
             if i == 0 and self.communication:
                 mask, vol = self._communicate(r, cur, rm, lens)

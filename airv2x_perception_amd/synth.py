@@ -186,11 +186,34 @@ def backbone_param_spec(bb, input_channels=64, prefix=""):
             spec += _bn(f"{prefix}blocks.{i}.{idx + 1}", c)
             idx += 3
         cin = c
-    for i, (s, cu) in enumerate(zip(bb["upsample_strides"], bb["num_upsample_filter"])):
+    ups, nuf = list(bb.get("upsample_strides", [])), list(bb.get("num_upsample_filter", []))
+    for i, (s, cu) in enumerate(zip(ups[:len(bb["layer_nums"])], nuf)):
         c = bb["num_filters"][i]
-        spec.append((f"{prefix}deblocks.{i}.0.weight", (c, cu, s, s), "deconv"))
+        if s >= 1:      # ConvTranspose2d(c, cu, s, stride=s)                                   (base_bev_backbone.py:73-86)
+            spec.append((f"{prefix}deblocks.{i}.0.weight", (c, cu, int(s), int(s)), "deconv"))
+        else:           # down-sampling "deblock": Conv2d(c, cu, k, stride=k), k = round(1 / s)  (:87-105)
+            k = int(round(1.0 / s))
+            spec.append((f"{prefix}deblocks.{i}.0.weight", (cu, c, k, k), "conv"))
         spec += _bn(f"{prefix}deblocks.{i}.1", cu)
+    if len(ups) > len(bb["layer_nums"]):   # one more ConvTranspose2d on the concatenated map    (:107-121)
+        c_in, s = sum(nuf), int(ups[-1])
+        i = len(bb["layer_nums"])
+        spec.append((f"{prefix}deblocks.{i}.0.weight", (c_in, c_in, s, s), "deconv"))
+        spec += _bn(f"{prefix}deblocks.{i}.1", c_in)
     return spec
+
+
+def resnet_backbone_param_spec(bb, prefix="", input_channels=64):
+    """ResNetBEVBackbone(model_cfg, input_channels) (common_modules/base_bev_backbone_resnet.py:16-110): ``resnet`` =
+    coalign_modules.resblock.ResNetModified(BasicBlock, layer_nums, layer_strides, num_filters, inplanes) -- levels ``layer0``,
+    ``layer1``, ... (:182-189), input width ``model_cfg.get("inplanes", input_channels)`` -- then the deblocks of BaseBEVBackbone."""
+    spec, cin = [], int(bb.get("inplanes", input_channels))
+    for li, (n, st, c) in enumerate(zip(bb["layer_nums"], bb["layer_strides"], bb["num_filters"])):
+        for j in range(n):
+            q = f"{prefix}resnet.layer{li}.{j}."
+            spec += _basic_block_spec(q, cin if j == 0 else c, c, st if j == 0 else 1)
+        cin = c
+    return spec + [e for e in backbone_param_spec(bb, 64, prefix) if e[0].startswith(prefix + "deblocks.")]
 
 
 def shrink_param_spec(sh, prefix=""):
@@ -1003,6 +1026,10 @@ def submodule_configs():
         "scatter": {"num_features": 64, "grid_size": [32, 32, 1]},
         "backbone": {"layer_nums": [1, 1, 2], "layer_strides": [2, 2, 2], "num_filters": [32, 64, 64],
                      "upsample_strides": [1, 2, 4], "num_upsample_filter": [32, 32, 32]},
+        # base_bev_backbone.py:87-121: a deblock that DOWN-samples (stride 0.5 -> Conv2d(2, stride 2)) and one more deblock on the concat
+        "backbone_variant": {"layer_nums": [1, 1], "layer_strides": [1, 2], "num_filters": [32, 64],
+                             "upsample_strides": [0.5, 1, 2], "num_upsample_filter": [32, 32, 0]},   # equal lengths are asserted (:25);
+                             # the final deblock's width is sum(num_upsample_filter), so its own entry has to be 0
         "shrink": {"kernal_size": [1], "dim": [64], "stride": [1], "padding": [0], "input_dim": 96},
         "compressor": (64, 2),
         "where2comm": {"fully": False, "voxel_size": list(DEFAULT_VOXEL), "downsample_rate": 2, "in_channels": 64,
@@ -1028,6 +1055,9 @@ def w2c_attn_configs():
         "ms_max": dict(base, agg_operator={"mode": "MAX"}, communication={"thre": 0.004}),
         "ss_atten": dict(base, multi_scale=False, agg_operator={"mode": "ATTEN", "feature_dim": 256}, communication=dict(gauss)),
         "ss_max": dict(base, multi_scale=False, agg_operator={"mode": "MAX", "feature_dim": 64}),
+        # the ResNet backbone variant (where2comm_attn.py:312-317: `backbone.resnet(x)` once, its three maps feed the levels)
+        "resnet_backbone": {"layer_nums": [2, 1, 2], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
+                            "upsample_strides": [1, 2, 4], "num_upsample_filter": [32, 32, 32]},
     }
 
 

@@ -82,7 +82,7 @@ int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
  *   NaiveCompressor (models/common_modules/naive_compress.py:12-36),
  *   cls/reg/obj heads (models/airv2x_where2com.py:60-69).
  *
- * mode AV2X_CONV      : out[n,ho,wo, out_coff+co] NHWC, ks in {1,3,5,7}, any stride/pad.
+ * mode AV2X_CONV      : out[n,ho,wo, out_coff+co] NHWC, square kernels ks = 1 .. 7, any stride/pad.
  * mode AV2X_DECONV    : ConvTranspose2d with kernel == stride == up (no overlap):
  *                       out[n, ho*up+i, wo*up+j, out_coff+co]; (h,w) here are the INPUT dims.
  * mode AV2X_CONV_NCHW : as AV2X_CONV but the result is stored NCHW (out[n,co,ho,wo]); used

@@ -71,7 +71,27 @@ def _split(x, record_len):
     return torch.tensor_split(x, cs)
 
 
-def where2comm_attn(x, rm, record_len, pairwise_t_matrix, sd, cfg, backbone_sd=None, bb_cfg=None, trace=None):
+def resnet_features(x, sd, bb_cfg, prefix="backbone.resnet."):
+    """ResNetModified._forward_impl (coalign_modules/resblock.py:259-268, levels layer0, layer1, ...) with BasicBlock.forward
+    (:72-88): the level maps."""
+    def bn(t, p):
+        return F.batch_norm(t, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+    outs = []
+    for li, (n, st) in enumerate(zip(bb_cfg["layer_nums"], bb_cfg["layer_strides"])):
+        for j in range(n):
+            q = f"{prefix}layer{li}.{j}."
+            s_ = st if j == 0 else 1
+            idt = x
+            if (q + "downsample.0.weight") in sd:
+                idt = bn(F.conv2d(x, sd[q + "downsample.0.weight"], None, s_), q + "downsample.1")
+            y = F.relu(bn(F.conv2d(x, sd[q + "conv1.weight"], None, s_, 1), q + "bn1"))
+            y = bn(F.conv2d(y, sd[q + "conv2.weight"], None, 1, 1), q + "bn2")
+            x = F.relu(y + idt)
+        outs.append(x)
+    return outs
+
+
+def where2comm_attn(x, rm, record_len, pairwise_t_matrix, sd, cfg, backbone_sd=None, bb_cfg=None, trace=None, with_resnet=False):
     """Where2comm.forward :269-404.  ``sd``: the fusion module's own state_dict (the gaussian filter, or empty);
     ``backbone_sd`` / ``bb_cfg``: BaseBEVBackbone's state_dict (keys "backbone.blocks..." as oracle/where2comm_oracle.py
     reads them) and config, for the multi-scale form.  -> (fused (B,C',H',W'), communication volume or tensor(0))."""
@@ -85,8 +105,9 @@ def where2comm_attn(x, rm, record_len, pairwise_t_matrix, sd, cfg, backbone_sd=N
     if cfg["multi_scale"]:
         ups = []
         n_levels = len(cfg["layer_nums"])
+        feats = resnet_features(x, backbone_sd, bb_cfg) if with_resnet else None     # :312-314: all levels from the UNMASKED input
         for i in range(n_levels):
-            x = w2c.backbone_block(x, backbone_sd, i, bb_cfg["layer_nums"][i])
+            x = feats[i] if with_resnet else w2c.backbone_block(x, backbone_sd, i, bb_cfg["layer_nums"][i])
             if i == 0 and has_comm:
                 masks, vol, maps = communication(_split(x, record_len), _split(rm, record_len), sd, cfg["communication"])
                 x = x * masks

@@ -358,7 +358,7 @@ def test_amp_training_step_autocast_and_gradscaler():
         scaler.step(opt)
         scaler.update()
         torch.cuda.synchronize()
-        runs.append((float(l16), g16))
+        runs.append((float(l16.detach()), g16))
         assert all(torch.isfinite(g).all() for g in g16.values())
         moved = sum(int(not torch.equal(before[k], p.detach())) for k, p in m16.named_parameters() if p.grad is not None)
         assert moved > 50, "GradScaler.step did not update the parameters"

@@ -131,6 +131,29 @@ def test_backbone_forward_blocks_and_deblocks(gold, trunk):
 
 
 @pytest.mark.gpu
+def test_backbone_downsampling_deblock_and_final_deblock_variant(gold, trunk):
+    """base_bev_backbone.py:87-121: upsample_strides [0.5, 1, 2] on two levels = Conv2d(2, stride 2) + ConvTranspose(1) + a final
+    ConvTranspose(2) on the concatenated map; fixture from the reference's own module."""
+    cfg = CFG["backbone_variant"]
+    bb = _load_into(sm.BaseBEVBackbone(cfg, 64), synth.backbone_param_spec(cfg, 64, ""), 19).cuda().eval()
+    sf = trunk["sf"]
+    d = bb({"spatial_features": sf})
+    assert d["spatial_features_2d"].shape == (3, 64, 32, 32) and bb.num_bev_features == 64
+    _close(d["spatial_features_2d"][:, ::2], gold["variant_spatial_features_2d"])
+    _close(bb.deblocks[0](bb.blocks[0](sf))[:, ::4], gold["variant_deblock0"])
+    assert len(bb.deblocks) == 3
+    with pytest.raises(NotImplementedError):
+        bb.train()({"spatial_features": sf})
+
+
+def test_backbone_variant_state_dict_layout():
+    cfg = CFG["backbone_variant"]
+    keys = {k: tuple(s) for k, s, _ in synth.backbone_param_spec(cfg, 64, "")}
+    assert keys["deblocks.0.0.weight"] == (32, 32, 2, 2) and keys["deblocks.1.0.weight"] == (64, 32, 1, 1) and keys["deblocks.2.0.weight"] == (64, 64, 2, 2)
+    assert list(sm.BaseBEVBackbone(cfg, 64).state_dict().keys()) == list(keys)
+
+
+@pytest.mark.gpu
 def test_downsample_conv_and_compressor(gold, trunk):
     s2d = trunk.get("s2d")
     if s2d is None:

@@ -148,6 +148,57 @@ def test_gpu_multi_scale_matches_reference(tag, rl, seed):
     assert float(vol2) == float(vol) and torch.equal(fused2, fused)
 
 
+def _resnet_inputs():
+    rl, seed = [3, 2], 45
+    return (rl, seed, torch.from_numpy(synth.w2c_attn_features(seed, 5, 64, H, W)), torch.from_numpy(synth.w2c_attn_psm(seed + 1, 5, H // 2, W // 2)),
+            synth.w2c_attn_pairwise(rl))
+
+
+def test_oracle_resnet_backbone_variant_matches_reference():
+    """where2comm_attn.py:312-314 with the reference's ResNetBEVBackbone (fixture: its own modules)."""
+    from oracle import where2comm_attn_oracle as wa
+    g = np.load(GOLD)
+    rbc = CFG["resnet_backbone"]
+    rsd = {"backbone." + k: v for k, v in synth.synthetic_state_dict(synth.resnet_backbone_param_spec(rbc, ""), seed=33).items()}
+    rl, seed, x, rm, pw = _resnet_inputs()
+    c = CFG["ms_atten"]
+    with torch.no_grad():
+        fused, vol = wa.where2comm_attn(x, rm, rl, pw, _gauss_sd(c, seed + 500), c, rsd, rbc, with_resnet=True)
+        feats = wa.resnet_features(x, rsd, rbc)
+    _close(fused, g["ms_resnet_fused"], rel=2e-5)
+    assert float(vol) == float(g["ms_resnet_vol"])
+    _close(feats[2][:, ::8], g["resnet_level2"], rel=2e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_resnet_backbone_variant_matches_reference():
+    from airv2x_perception_amd.opencood_iface import submodules as sm
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    g = np.load(GOLD)
+    rbc = CFG["resnet_backbone"]
+    spec = synth.resnet_backbone_param_spec(rbc, "")
+    bb = sm.ResNetBEVBackbone(rbc, 64)
+    assert list(bb.state_dict().keys()) == [k for k, _, _ in spec] and hasattr(bb, "resnet")
+    bb.load_state_dict(synth.synthetic_state_dict(spec, seed=33), strict=True)
+    bb = bb.eval().cuda()
+    rl, seed, x, rm, pw = _resnet_inputs()
+    c = CFG["ms_atten"]
+    mod = wm.Where2comm(c)
+    mod.load_state_dict(_gauss_sd(c, seed + 500), strict=True)
+    mod = mod.eval().cuda()
+    xg = x.cuda()
+    fused, vol, _ = mod(xg, rm.cuda(), torch.tensor(rl), pw.cuda(), bb, None)
+    assert float(vol) == float(g["ms_resnet_vol"])
+    _close(fused, g["ms_resnet_fused"])
+    # the backbone on its own: forward(data_dict) and the `resnet` callable other reference code uses
+    d = bb({"spatial_features": xg})
+    _close(d["spatial_features_2d"][:, ::2], g["resnet_backbone_2d"])
+    feats = bb.resnet(xg)
+    assert len(feats) == 3 and feats[2].shape == (5, 256, H // 8, W // 8)
+    _close(feats[2][:, ::8], g["resnet_level2"])
+    assert torch.equal(xg.cpu(), x)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,rl,ch,seed", SS_CASES)
 def test_gpu_single_scale_matches_reference(tag, rl, ch, seed):

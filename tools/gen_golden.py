@@ -606,6 +606,21 @@ def submodules_golden(name="submodules_small"):
         out["block1_of_block0"] = bb.blocks[1](b0).numpy()
         out["deblock1"] = bb.deblocks[1](bb.blocks[1](b0))[:, ::4].numpy()
 
+        # ---- the down-sampling deblock + extra final deblock variants (base_bev_backbone.py:87-121).  The constructor uses `np.int`
+        # (:88), gone from numpy >= 1.24: restored for the duration of the constructor (an environment shim, like the cuda one)
+        had = hasattr(np, "int")
+        if not had:
+            np.int = int
+        try:
+            bbv = load(BaseBEVBackbone(cfg["backbone_variant"], 64), synth.backbone_param_spec(cfg["backbone_variant"], 64, ""), 19)
+        finally:
+            if not had:
+                del np.int
+        dv = bbv({"spatial_features": sf})
+        out["variant_spatial_features_2d"] = dv["spatial_features_2d"][:, ::2].numpy()
+        out["variant_deblock0"] = bbv.deblocks[0](bbv.blocks[0](sf))[:, ::4].numpy()
+        print(f"[submodules] backbone variant: {tuple(dv['spatial_features_2d'].shape)}")
+
         # ---- DownsampleConv / NaiveCompressor
         ds = load(DownsampleConv(cfg["shrink"]), synth.shrink_param_spec(cfg["shrink"], ""), 13)
         sh = ds(s2d)
@@ -718,6 +733,36 @@ def w2c_attn_golden(name="w2c_attn"):
             out[f"{tag}_margin"] = np.float64((tr["smooth"] - c["communication"]["thre"]).abs().min())
             print(f"[{name}] {tag}: oracle vs reference {err:.2e}, volume {float(vol):.1f}, mask ones "
                   f"{float(tr['mask'].mean()):.3f}, margin {float(out[f'{tag}_margin']):.2e}")
+
+        # ---- the ResNet backbone variant (where2comm_attn.py:312-314: `backbone.resnet(x)` once, its maps feed the levels) with the
+        # reference's own ResNetBEVBackbone (common_modules/base_bev_backbone_resnet.py + resblock.py), and that module's forward
+        from opencood.models.common_modules.base_bev_backbone_resnet import ResNetBEVBackbone
+        rbc = cfg["resnet_backbone"]
+        rbb = ResNetBEVBackbone(rbc, 64)
+        rspec = synth.resnet_backbone_param_spec(rbc, "")
+        assert [k for k, _, _ in rspec] == list(rbb.state_dict().keys()), [(a, b) for (a, _, _), b in zip(rspec, rbb.state_dict().keys()) if a != b][:4]
+        for k, shp, _ in rspec:
+            assert tuple(rbb.state_dict()[k].shape) == tuple(shp), k
+        rsd = synth.synthetic_state_dict(rspec, seed=33)
+        rbb.load_state_dict(rsd, strict=True)
+        rbb.eval()
+        rsd_o = {"backbone." + k: v for k, v in rsd.items()}
+        rl, seed, c = [3, 2], 45, cfg["ms_atten"]
+        mod = Where2comm(c).eval()
+        fsd = gauss_sd(mod, seed + 500)
+        x = torch.from_numpy(synth.w2c_attn_features(seed, 5, 64, H, W))
+        rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, 5, H // 2, W // 2))
+        pw = synth.w2c_attn_pairwise(rl)
+        fused, vol, _ = mod(x, rm, torch.tensor(rl), pw, rbb, None)
+        of, ov = wa.where2comm_attn(x, rm, rl, pw, fsd, c, rsd_o, rbc, with_resnet=True)
+        err = (of - fused).abs().max().item()
+        assert err < 2e-5 and float(ov) == float(vol), ("resnet", err, ov, vol)
+        out["ms_resnet_fused"] = fused.numpy()
+        out["ms_resnet_vol"] = np.float64(vol)
+        d = rbb({"spatial_features": x})
+        out["resnet_backbone_2d"] = d["spatial_features_2d"][:, ::2].numpy()
+        out["resnet_level2"] = rbb.resnet(x)[2][:, ::8].numpy()
+        print(f"[{name}] ms_resnet: oracle vs reference {err:.2e}, volume {float(vol):.1f}, backbone out {tuple(d['spatial_features_2d'].shape)}")
 
         # full map (the 200 x 704 AirV2X canvas -> 100 x 352 fused), 5 agents: every 4th channel / 3rd row / 5th column + sums
         rl, seed, c = [5], 44, cfg["ms_atten"]
