@@ -74,6 +74,14 @@ SIGNATURES = {
     "av2x_lss_pool_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "av2x_lss_voxel_pool": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_layernorm_backward_rows": (c_int32, [c_int64]),
+    "av2x_layernorm_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "av2x_gelu": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "av2x_scale_broadcast": (c_int32, [c_void_p, c_void_p, c_int32, c_uint64, c_float, c_void_p]),
+    "av2x_dropout": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_float, c_void_p]),
+    "av2x_fax_attention_backward_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
+    "av2x_fax_attention_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                              c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_mean2": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "av2x_cam_stem": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                 c_void_p, c_void_p]),

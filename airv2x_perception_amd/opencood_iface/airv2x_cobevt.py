@@ -1,5 +1,5 @@
 """``Airv2xCoBEVT`` — drop-in for opencood/models/airv2x_cobevt.py:15-156 (det task, LiDAR) running
-in libairv2x_hip.so.  Same constructor argument, input contract, output keys (``psm``, ``rm``,
+in libairv2x_hip.so (``.eval()``: the packed inference engine; ``.train()``: the autograd graph of train_cobevt.py).  Same constructor argument, input contract, output keys (``psm``, ``rm``,
 ``obj``) and state_dict keys/shapes (236 tensors at max_cav 3/2/2) as the reference."""
 from __future__ import annotations
 
@@ -37,7 +37,9 @@ class Airv2xCoBEVT(nn.Module):
                 t, buf = torch.ones(shape), False
             else:
                 t, buf = torch.zeros(shape), False
-            _install(self, key, t, buf)
+            _install(self, key, t, buf, requires_grad=True)    # trainable, as the reference's nn.Modules are
+        if args.get("backbone_fix"):
+            self.backbone_fix()
         self._engine = None
         self._packed_version = None
 
@@ -57,9 +59,17 @@ class Airv2xCoBEVT(nn.Module):
             self._packed_version = ver
         return self._engine
 
+    def backbone_fix(self):
+        """airv2x_cobevt.py:77-110 (fine-tuning on time delay): freeze the encoders, backbone, shrink header, compressor and heads; the
+        fusion net stays trainable.  (As written the reference's method names ``self.veh_model`` and fails; this is what it intends.)"""
+        for name, p in self.named_parameters():
+            if not name.startswith("fusion_net."):
+                p.requires_grad = False
+
     def forward(self, data_dict):
-        if self.training:
-            raise NotImplementedError("training is not built yet; call .eval()")
+        if self.training:   # the graph torch autograd differentiates, on HIP forward / backward ops (train_cobevt.py)
+            from .train_cobevt import forward_train
+            return forward_train(self, data_dict)
         eng = self.engine()
         eng.amp = _amp_requested(self)
         return eng.forward(data_dict)

@@ -1,0 +1,226 @@
+"""Differentiable building blocks of the transformer-style fusion heads: forward AND backward of every node run in
+libairv2x_hip.so (csrc/train_fusion.hip + the convolution kernels); torch owns the tensors and the autograd bookkeeping.
+
+The reference trains these modules through torch autograd (tools/train.py:220-247):
+
+    nn.LayerNorm                                         base_transformer.py:9, swap_fusion_modules.py:272
+    nn.Linear (+ residual of PreNormResidual :12)        1x1 convolutions over the NHWC token buffer
+    nn.GELU                                              base_transformer.py:30
+    Attention (windows / grids over agents x 4 x 4)      swap_fusion_modules.py:78-127
+    Reduce("b m d h w -> b d h w", "mean")               swap_fusion_modules.py:270
+    nn.Dropout                                           mask drawn with torch's generator (as the reference draws it), applied on the device
+
+Token tensors are (L, H, W, C) fp32 NHWC, exactly the eval engine's layout (cobevt_engine.py).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from . import train_ops as T
+from .autograd import _P, _runner
+
+LN_EPS = 1e-5
+
+
+def _chan_sum(r, mat, rows, c):
+    """Fixed-order column sums of a (rows, c) fp32 matrix."""
+    ws = torch.empty(int(r.lib.av2x_channel_sum_workspace_bytes(rows, c)) // 4 + 4, device=mat.device)
+    out = torch.empty(c, device=mat.device)
+    _lib.check(r.lib.av2x_channel_sum(_P(mat), rows, c, _P(ws), _P(out), r.stream()), "av2x_channel_sum")
+    return out
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        T._check_dev(x)
+        r = _runner(x.device)
+        x = x.contiguous()
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        _lib.check(r.lib.av2x_layernorm(_P(x), _P(gamma.detach()), _P(beta.detach()), _P(y), x.numel() // c, c, LN_EPS, r.stream()), "av2x_layernorm")
+        ctx.save_for_backward(x, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        r = _runner(x.device)
+        dy = dy.contiguous()
+        c = x.shape[-1]
+        n = x.numel() // c
+        rows = int(r.lib.av2x_layernorm_backward_rows(n))
+        partial = torch.empty((2, rows, c), device=x.device)
+        dx = torch.empty_like(x)
+        _lib.check(r.lib.av2x_layernorm_backward(_P(x), _P(gamma.detach()), _P(dy), n, c, LN_EPS, _P(dx), _P(partial), r.stream()),
+                   "av2x_layernorm_backward")
+        dg = _chan_sum(r, partial[0], rows, c) if ctx.needs_input_grad[1] else None
+        db = _chan_sum(r, partial[1], rows, c) if ctx.needs_input_grad[2] else None
+        return dx, dg, db
+
+
+def layer_norm(x, gamma, beta):
+    return LayerNormFn.apply(x, gamma, beta)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) (+ residual) over the last axis of an (n, h, w, cin) token tensor; W is nn.Linear's (cout, cin)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        from .engine import ConvLayer
+        T._check_dev(x)
+        r = _runner(x.device)
+        x = x.contiguous()
+        n, h, w, cin = x.shape
+        cout = weight.shape[0]
+        w4 = weight.detach().view(cout, cin, 1, 1)
+        wp, coutp, _ = T._packed(r, w4)
+        L = ConvLayer(wp, None, bias.detach() if bias is not None else T._zeros(cout, x.device), cin, cout, coutp, 1, 1, 0, 0)
+        y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+        r.amp = T.AMP_STEP[0]
+        try:
+            r.conv(L, x, n, h, w, y, residual=residual.contiguous() if residual is not None else None)
+        finally:
+            r.amp = False
+        ctx.save_for_backward(x, weight)
+        ctx.has = (bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        r = _runner(x.device)
+        dy = dy.contiguous()
+        cout, cin = weight.shape
+        rows = dy.numel() // cout
+        db = _chan_sum(r, dy, rows, cout) if (ctx.has[0] and ctx.needs_input_grad[2]) else None
+        w4 = weight.detach().view(cout, cin, 1, 1)
+        dw, dx = T._wgrad_and_dgrad(x, dy, w4, 1, 0, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        if dw is not None:
+            dw = dw.view(cout, cin)
+        return dx, dw, db, (dy if (ctx.has[1] and ctx.needs_input_grad[3]) else None)
+
+
+def linear(x, weight, bias=None, residual=None):
+    return LinearFn.apply(x, weight, bias, residual)
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        T._check_dev(z)
+        r = _runner(z.device)
+        z = z.contiguous()
+        y = torch.empty_like(z)
+        _lib.check(r.lib.av2x_gelu(_P(z), None, _P(y), z.numel(), r.stream()), "av2x_gelu")
+        ctx.save_for_backward(z)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        r = _runner(z.device)
+        dz = torch.empty_like(z)
+        _lib.check(r.lib.av2x_gelu(_P(z), _P(dy.contiguous()), _P(dz), z.numel(), r.stream()), "av2x_gelu")
+        return dz
+
+
+def gelu(z):
+    return GeluFn.apply(z)
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        T._check_dev(x)
+        r = _runner(x.device)
+        x = x.contiguous()
+        # the Bernoulli draw comes from torch's generator on the device (the reference's nn.Dropout draws from the same generator;
+        # the streams differ, as they do between any two dropout implementations); the product runs in the kernel
+        mask = (torch.rand(x.shape, device=x.device) >= p).to(torch.uint8)
+        y = torch.empty_like(x)
+        scale = 1.0 / (1.0 - p)
+        _lib.check(r.lib.av2x_dropout(_P(x), _P(mask), _P(y), x.numel(), scale, r.stream()), "av2x_dropout")
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        r = _runner(dy.device)
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(r.lib.av2x_dropout(_P(dy), _P(mask), _P(dx), dy.numel(), ctx.scale, r.stream()), "av2x_dropout")
+        return dx, None
+
+
+def dropout(x, p, training=True):
+    if not training or p <= 0.0:
+        return x
+    if p >= 1.0:
+        raise ValueError("dropout probability must be < 1")
+    return DropoutFn.apply(x, float(p))
+
+
+class FaxAttentionFn(torch.autograd.Function):
+    """Attention.forward (swap_fusion_modules.py:78-127) on the to_qkv output of ALL windows of one sample: qkv (L, H, W, 3C),
+    relative-position bias table ((2L-1)(2ws-1)^2, heads) -> (L, H, W, C) (heads merged, before to_out)."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, n_valid, ws, heads, dim_head, grid):
+        T._check_dev(qkv)
+        r = _runner(qkv.device)
+        qkv = qkv.contiguous()
+        L, H, W, C3 = qkv.shape
+        out = torch.empty((L, H, W, C3 // 3), dtype=torch.float32, device=qkv.device)
+        _lib.check(r.lib.av2x_fax_attention(_P(qkv), _P(table.detach().contiguous()), _P(out), L, n_valid, H, W, ws, heads, dim_head, grid, r.stream()),
+                   "av2x_fax_attention")
+        ctx.save_for_backward(qkv, table, out)
+        ctx.cfg = (n_valid, ws, heads, dim_head, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, table, out = ctx.saved_tensors
+        n_valid, ws, heads, dim_head, grid = ctx.cfg
+        r = _runner(qkv.device)
+        L, H, W, _ = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        dtab = torch.empty_like(table)
+        wsb = torch.empty(int(r.lib.av2x_fax_attention_backward_workspace_bytes(L, ws, heads)), dtype=torch.uint8, device=qkv.device)
+        _lib.check(r.lib.av2x_fax_attention_backward(_P(qkv), _P(table.detach().contiguous()), _P(out), _P(dout.contiguous()), L, n_valid, H, W, ws,
+                                                     heads, dim_head, grid, _P(dqkv), _P(dtab), _P(wsb), r.stream()), "av2x_fax_attention_backward")
+        return dqkv, dtab, None, None, None, None, None
+
+
+def fax_attention(qkv, table, n_valid, ws, heads, dim_head, grid):
+    return FaxAttentionFn.apply(qkv, table, n_valid, ws, heads, dim_head, grid)
+
+
+class AgentMeanFn(torch.autograd.Function):
+    """(L, H, W, C) -> (1, H, W, C): the mean over the agent axis (swap_fusion_modules.py:270), padded agents included."""
+
+    @staticmethod
+    def forward(ctx, x):
+        T._check_dev(x)
+        r = _runner(x.device)
+        x = x.contiguous()
+        y = torch.empty((1,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        _lib.check(r.lib.av2x_agent_mean(_P(x), _P(y), x.shape[0], y.numel(), r.stream()), "av2x_agent_mean")
+        ctx.L = x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        r = _runner(dy.device)
+        dy = dy.contiguous()
+        dx = torch.empty((ctx.L,) + tuple(dy.shape[1:]), dtype=torch.float32, device=dy.device)
+        _lib.check(r.lib.av2x_scale_broadcast(_P(dy), _P(dx), ctx.L, dy.numel(), 1.0 / ctx.L, r.stream()), "av2x_scale_broadcast")
+        return dx
+
+
+def agent_mean(x):
+    return AgentMeanFn.apply(x)

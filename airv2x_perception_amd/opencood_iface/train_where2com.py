@@ -79,6 +79,34 @@ def _heads(P, names, x):
     return outs
 
 
+def encode_train(args, P, sd, data_dict, slots, n, dev, r):
+    """The per-type encoders in train mode: PillarVFE (BatchNorm1d batch statistics, running statistics updated once) + scatter for
+    every agent of the frame -> (canvas (n, ny, nx, 64) with its autograd graph, device counter of its non-zero elements)."""
+    groups, params, prefixes = [], [], []
+    ny = nx = None
+    for t in AGENT_TYPES:
+        if t not in slots:
+            continue
+        lid = data_dict[t]["batch_merged_lidar_features_torch"]
+        cfg = args[t]["lidar"]
+        vs, rng = cfg["voxel_size"], cfg["lidar_range"]
+        g = [int(v) for v in cfg["point_pillar_scatter"]["grid_size"]]
+        nx, ny = g[0], g[1]
+        geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
+        groups.append({"vf": lid["voxel_features"].to(dev).contiguous().float(), "vc": lid["voxel_coords"].to(dev).contiguous().to(torch.int32),
+                       "vn": lid["voxel_num_points"].to(dev).contiguous().to(torch.int32), "slots": slots[t], "geom": geom})
+        p = f"{TYPE_PREFIX[t]}.0.0.pfn_layers.0"
+        params += [P[p + ".linear.weight"], P[p + ".norm.weight"], P[p + ".norm.bias"]]
+        prefixes.append(p + ".norm")
+    st = []
+    canvas = T.pillar_encode(groups, n, ny, nx, params, stats_out=st)
+    for p, s in zip(prefixes, st):
+        _bn_update(sd, p, s, 1)
+    nz = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(r.lib.av2x_count_nonzero(_P(canvas), canvas.numel(), _P(nz), r.stream()), "av2x_count_nonzero")
+    return canvas, nz
+
+
 def forward_train(model, data_dict, topk=None, mask=None, trace=None):
     """-> output dict of the reference (psm / rm / obj require grad).  ``topk``: one K per sample instead of the random draw;
     ``mask`` (n, H, W): replay a recorded communication mask instead of the one computed here (the top-K cut is discontinuous
@@ -104,29 +132,7 @@ def forward_train(model, data_dict, topk=None, mask=None, trace=None):
     if n == 0:
         raise ValueError("empty frame: no agent has lidar input")
 
-    # ---- encoders: PillarVFE (BatchNorm1d batch statistics per agent type) + scatter
-    groups, params, prefixes = [], [], []
-    ny = nx = None
-    for t in AGENT_TYPES:
-        if t not in slots:
-            continue
-        lid = data_dict[t]["batch_merged_lidar_features_torch"]
-        cfg = args[t]["lidar"]
-        vs, rng = cfg["voxel_size"], cfg["lidar_range"]
-        g = [int(v) for v in cfg["point_pillar_scatter"]["grid_size"]]
-        nx, ny = g[0], g[1]
-        geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
-        groups.append({"vf": lid["voxel_features"].to(dev).contiguous().float(), "vc": lid["voxel_coords"].to(dev).contiguous().to(torch.int32),
-                       "vn": lid["voxel_num_points"].to(dev).contiguous().to(torch.int32), "slots": slots[t], "geom": geom})
-        p = f"{TYPE_PREFIX[t]}.0.0.pfn_layers.0"
-        params += [P[p + ".linear.weight"], P[p + ".norm.weight"], P[p + ".norm.bias"]]
-        prefixes.append(p + ".norm")
-    st = []
-    canvas = T.pillar_encode(groups, n, ny, nx, params, stats_out=st)
-    for p, s in zip(prefixes, st):
-        _bn_update(sd, p, s, 1)
-    nz = torch.zeros(1, dtype=torch.int64, device=dev)
-    _lib.check(r.lib.av2x_count_nonzero(_P(canvas), canvas.numel(), _P(nz), r.stream()), "av2x_count_nonzero")
+    canvas, nz = encode_train(args, P, sd, data_dict, slots, n, dev, r)
 
     layer_nums, strides, ups = bb["layer_nums"], bb["layer_strides"], bb["upsample_strides"]
     # ---- blocks[0] once, with the graph (the fusion pass's blocks[0] sees the same canvas): three identical updates

@@ -393,6 +393,35 @@ int av2x_lss_voxel_pool(const float* x, const float* frustum, const float* cam_p
                         void* workspace, float* out, float* geom_out, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training of the transformer-style fusion heads (Airv2xCoBEVT.train()): backward kernels of
+ * models/cobevt_modules/swap_fusion_modules.py:78-195 and base_transformer.py:6-38 (the reference differentiates them with
+ * torch autograd, tools/train.py:220-247).  Linear layers differentiate through av2x_conv2d / av2x_conv2d_wgrad (1x1 convolutions).
+ *
+ * av2x_layernorm_backward  dx (n_tokens, c) of nn.LayerNorm (statistics recomputed from x); `partial`: (2, rows, c) floats with
+ *                          rows = av2x_layernorm_backward_rows(n_tokens): per-workgroup partial sums of dgamma (first `rows` rows)
+ *                          and dbeta (the next `rows`), to be reduced in a fixed order with av2x_channel_sum.  c in {256, 512}.
+ * av2x_gelu                dy == NULL: out = gelu(z) (exact, nn.GELU()); else out = dy * gelu'(z).  n % 4 == 0.
+ * av2x_scale_broadcast     dx[l] = scale * dy for l < n_agents: backward of the mean over the agent axis (:270).
+ * av2x_dropout             y = x * mask * scale, mask = n bytes of 0 / 1 drawn by the caller (nn.Dropout forward and backward).
+ * av2x_fax_attention_backward   Attention.forward :78-127 differentiated for all windows of one sample: qkv / bias_table / window
+ *                          layout as av2x_fax_attention, `out` = that call's output, dout its gradient; writes dqkv (same layout as
+ *                          qkv; zero for the k | v of padded agents) and dbias_table (tab_n, heads) -- summed over windows as 2^-32
+ *                          fixed point in `workspace` (av2x_fax_attention_backward_workspace_bytes), so bit-reproducible.
+ *                          L * window^2 <= 128 tokens per window, dim_head 32.
+ * ------------------------------------------------------------------------------------ */
+int32_t av2x_layernorm_backward_rows(int64_t n_tokens);
+int av2x_layernorm_backward(const float* x, const float* gamma, const float* dy, int64_t n_tokens, int32_t c, float eps,
+                            float* dx, float* partial, av2x_stream_t stream);
+int av2x_gelu(const float* z, const float* dy, float* out, uint64_t n, av2x_stream_t stream);
+int av2x_scale_broadcast(const float* dy, float* dx, int32_t n_agents, uint64_t elems_per_agent, float scale, av2x_stream_t stream);
+int av2x_dropout(const float* x, const uint8_t* mask, float* y, uint64_t n, float scale, av2x_stream_t stream);
+uint64_t av2x_fax_attention_backward_workspace_bytes(int32_t n_agents_padded, int32_t window, int32_t heads);
+int av2x_fax_attention_backward(const float* qkv, const float* bias_table, const float* out, const float* dout,
+                                int32_t n_agents_padded, int32_t n_valid, int32_t h, int32_t w, int32_t window, int32_t heads,
+                                int32_t dim_head, int32_t grid_partition, float* dqkv, float* dbias_table, void* workspace,
+                                av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Camera encoder (BASELINE configs[4]): the non-GEMM kernels of CamEncode / BevEncode
  * (models/sub_modules/lss_submodule.py:22-189, 312-350) and of the efficientnet_pytorch trunk CamEncode walks (:118-146).
  * All maps NHWC fp32; the pointwise / 3x3 / 7x7 convolutions run on av2x_conv2d.

@@ -1,0 +1,218 @@
+"""GPU: the train-mode path of Airv2xCoBEVT (opencood_iface/train_fusion_ops.py, train_cobevt.py, csrc/train_fusion.hip).
+
+* every new differentiable op against torch autograd of the oracle's fp32 expression on the CPU;
+* one whole training step -- forward in train mode, PointPillarLossMultiClass, backward, BatchNorm running statistics -- against the
+  REFERENCE's step (tests/golden/train_cobevt_small_*.npz: the reference's own Airv2xCoBEVT in .train() with drop_out 0, its loss class,
+  torch autograd), with the float64 yardstick of the Where2Comm step test;
+* dropout > 0 (the shipped YAML's 0.1), optimiser steps, .eval() on the updated weights.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from airv2x_perception_amd import synth
+from oracle import cobevt_oracle as cob
+from oracle import voxelize_oracle as vox
+from tests.helpers import assert_close, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_close(got, ref, rtol, what):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max() / scale
+    assert err <= rtol, f"{what}: max err / max|ref| = {err:.3e} (max|ref| {scale:.3e})"
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_layernorm_forward_backward():
+    from airv2x_perception_amd.opencood_iface import train_fusion_ops as Fo
+    for c, shape in ((256, (3, 5, 7, 256)), (512, (1, 9, 4, 512)), (256, (2, 33, 3, 256))):
+        x = torch.randn(shape, generator=_g(c)) * 2 + 0.3
+        gm, bt = torch.rand(c, generator=_g(1)) + 0.5, torch.randn(c, generator=_g(2)) * 0.1
+        dy = torch.randn(shape, generator=_g(3))
+        xr, gr, br = x.clone().requires_grad_(), gm.clone().requires_grad_(), bt.clone().requires_grad_()
+        F.layer_norm(xr, (c,), gr, br, 1e-5).backward(dy)
+        xd, gd, bd = x.cuda().requires_grad_(), gm.cuda().requires_grad_(), bt.cuda().requires_grad_()
+        y = Fo.layer_norm(xd, gd, bd)
+        y.backward(dy.cuda())
+        assert_close(y.detach().cpu(), F.layer_norm(x, (c,), gm, bt, 1e-5), 1e-5, 1e-5, "layernorm")
+        rel_close(xd.grad.cpu(), xr.grad, 2e-5, "layernorm dx")
+        rel_close(gd.grad.cpu(), gr.grad, 2e-5, "layernorm dgamma")
+        rel_close(bd.grad.cpu(), br.grad, 2e-5, "layernorm dbeta")
+
+
+def test_gelu_linear_mean_dropout():
+    from airv2x_perception_amd.opencood_iface import train_fusion_ops as Fo
+    x = torch.randn(2, 6, 8, 256, generator=_g(4))
+    w, b = torch.randn(512, 256, generator=_g(5)) * 0.05, torch.randn(512, generator=_g(6)) * 0.1
+    w2 = torch.randn(256, 512, generator=_g(7)) * 0.05
+    dy = torch.randn(1, 6, 8, 256, generator=_g(8))
+    ref = [t.clone().requires_grad_() for t in (x, w, b, w2)]
+    yr = (F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3]) + ref[0]).mean(0, keepdim=True)
+    yr.backward(dy)
+    dev = [t.cuda().requires_grad_() for t in (x, w, b, w2)]
+    yd = Fo.agent_mean(Fo.linear(Fo.gelu(Fo.linear(dev[0], dev[1], dev[2])), dev[3], None, dev[0]))
+    yd.backward(dy.cuda())
+    rel_close(yd.detach().cpu(), yr.detach(), 2e-5, "linear-gelu-linear-residual-mean")
+    for name, a, r in zip(("dx", "dw1", "db1", "dw2"), dev, ref):
+        rel_close(a.grad.cpu(), r.grad, 5e-5, name)
+    # dropout: mask in {0, 1 / (1 - p)}, the same mask in the backward, expectation preserved
+    xd = torch.ones(4, 8, 8, 256, device="cuda", requires_grad=True)
+    yd = Fo.dropout(xd, 0.25)
+    yd.sum().backward()
+    vals = np.unique(yd.detach().cpu().numpy()).tolist()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / 0.75) < 1e-6 and torch.equal(xd.grad, yd.detach())
+    assert abs(float(yd.detach().mean()) - 1.0) < 0.02
+    assert Fo.dropout(xd, 0.25, training=False) is xd and Fo.dropout(xd, 0.0) is xd
+
+
+@pytest.mark.parametrize("L,n_valid,H,W,grid", [(3, 3, 8, 12, 0), (3, 2, 8, 8, 1), (7, 4, 8, 8, 0), (8, 8, 4, 8, 1), (7, 1, 4, 4, 0)])
+def test_fax_attention_backward_matches_autograd_of_the_oracle(L, n_valid, H, W, grid):
+    """Attention.forward (swap_fusion_modules.py:78-127) with padded agents masked as keys: dq / dk / dv and the relative-position
+    bias table gradient against torch autograd of oracle/cobevt_oracle.attention on the partitioned tokens."""
+    from airv2x_perception_amd.opencood_iface import train_fusion_ops as Fo
+    heads, dh, ws = 8, 32, 4
+    C = heads * dh
+    g = _g(L * 100 + n_valid)
+    qkv = torch.randn(L, H, W, 3 * C, generator=g) * 0.7
+    table = torch.randn((2 * L - 1) * 49, heads, generator=g)
+    dout = torch.randn(L, H, W, C, generator=g)
+    idx = cob.relative_position_index(L, ws)
+    # reference expression on partitioned tokens: (B=1, L, C, H, W) -> windows -> softmax(qk^T + bias, masked) v
+    qr, tr = qkv.clone().requires_grad_(), table.clone().requires_grad_()
+
+    def part(t):        # (L, H, W, c) -> (windows, L * 16, c), tokens ordered (l, w1, w2)
+        return cob._partition(t.permute(0, 3, 1, 2).unsqueeze(0), ws, bool(grid))
+    q, k, v = (part(qr[..., i * C:(i + 1) * C]) for i in range(3))
+    Nw, T, _ = q.shape
+    sh = lambda t: t.view(Nw, T, heads, dh).permute(0, 2, 1, 3)
+    sim = torch.matmul(sh(q) * dh ** -0.5, sh(k).transpose(-1, -2)) + tr[idx].permute(2, 0, 1)
+    km = (torch.arange(L) < n_valid).view(L, 1).expand(L, ws * ws).reshape(-1)
+    sim = sim.masked_fill(~km[None, None, None, :], -float("inf"))
+    o = torch.matmul(F.softmax(sim, -1), sh(v)).permute(0, 2, 1, 3).reshape(Nw, T, C)
+    o.backward(part(dout))
+    out_ref = cob._unpartition(o.detach(), 1, L, C, H, W, ws, bool(grid))[0].permute(0, 2, 3, 1)
+    qd, td = qkv.cuda().requires_grad_(), table.cuda().requires_grad_()
+    od = Fo.fax_attention(qd, td, n_valid, ws, heads, dh, grid)
+    od.backward(dout.cuda())
+    assert_close(od.detach().cpu(), out_ref, 2e-5, 2e-5, "attention forward")
+    gq = qr.grad.clone()
+    gq[n_valid:, :, :, C:] = 0          # k | v of padded agents: never keys (autograd gives exact zeros there too)
+    assert float(qr.grad[n_valid:, :, :, C:].abs().max() if n_valid < L else 0.0) == 0.0
+    rel_close(qd.grad.cpu(), gq, 5e-5, "dqkv")
+    rel_close(td.grad.cpu(), tr.grad, 5e-5, "d bias table")
+    # bit-reproducible (fixed-point table sums, fixed loop orders)
+    qd2, td2 = qkv.cuda().requires_grad_(), table.cuda().requires_grad_()
+    Fo.fax_attention(qd2, td2, n_valid, ws, heads, dh, grid).backward(dout.cuda())
+    assert torch.equal(qd2.grad, qd.grad) and torch.equal(td2.grad, td.grad)
+
+
+def _case(fx):
+    rng = [float(v) for v in fx["lidar_range"]]
+    types = [str(t) for t in fx["types"]]
+    hy = synth.default_hypes_cobevt(rng, tuple(int(v) for v in fx["max_cav"]))
+    hy["model"]["args"]["fax_fusion"]["drop_out"] = 0.0
+    args = hy["model"]["args"]
+    sd = synth.synthetic_state_dict(synth.cobevt_param_spec(args), seed=int(fx["seed"]))
+    pp = hy["preprocess"]
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, int(fx["n_points"]), rng), pp["cav_lidar_range"]),
+                                 pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"], pp["args"]["max_voxel_train"])
+            for i in range(len(types))]
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    H, W = fx["psm"].shape[-2:]
+    lc = synth.loss_case(int(fx["seed"]) + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=float(fx["pos_frac"]))
+    tgt = {k: torch.from_numpy(lc[k]).cuda() for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    return hy, args, sd, dd, tgt
+
+
+def _model(args, sd):
+    from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
+    m = Airv2xCoBEVT(args)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().train()
+
+
+def _loss(args):
+    from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
+    return PointPillarLossMultiClass({"cls_weight": 1.0, "reg": 2.0, "num_class": args["num_class"]})
+
+
+@pytest.mark.parametrize("name", ["train_cobevt_small_n3", "train_cobevt_small_n2"])
+def test_cobevt_training_step_matches_the_reference(name):
+    fx = load_fixture(name)
+    hy, args, sd, dd, tgt = _case(fx)
+    model = _model(args, sd)
+    out = model(dd)
+    for k in ("psm", "rm", "obj"):
+        assert out[k].requires_grad
+        assert_close(out[k].detach().cpu(), fx[k], 3e-4, 3e-4 * float(np.abs(fx[k]).max()), k)
+    total = _loss(args)(out, tgt)
+    total.backward()
+    torch.cuda.synchronize()
+    assert abs(float(total.detach()) - fx["losses"][0]) < 3e-4 * abs(fx["losses"][0])
+    P = dict(model.named_parameters())
+    keys = [str(k) for k in fx["grad_keys"]]
+    have = sorted(k for k, p in P.items() if p.grad is not None)
+    assert set(keys) <= set(have), sorted(set(keys) - set(have))
+    for k in set(have) - set(keys):      # parameters the reference reports an exactly-zero gradient for
+        assert float(P[k].grad.abs().max()) == 0.0, k
+    # the float64 yardstick of the Where2Comm step test (tests/test_gpu_train.py): the graph has the same ~25-ReLU-deep trunk under the fusion
+    dev, refdev = {}, {}
+    for k in keys:
+        g = P[k].grad.reshape(-1)
+        stride = max(1, g.numel() // 4096)
+        gmax = float(fx["g64max:" + k])
+        dev[k] = np.abs(g[::stride].cpu().numpy().astype(np.float64) - fx["g64:" + k].astype(np.float64)).max() / max(gmax, 1e-300)
+        refdev[k] = float(fx["gdev:" + k])
+    med_ref, med_dev = float(np.median(list(refdev.values()))), float(np.median(list(dev.values())))
+    print(f"{name}: gradient deviation from float64, rel. to max -- device median {med_dev:.2e} worst {max(dev.values()):.2e}; "
+          f"reference fp32 median {med_ref:.2e} worst {max(refdev.values()):.2e}")
+    bad = {k: (dev[k], refdev[k]) for k in keys if dev[k] > 3.0 * refdev[k] + 2.0 * med_ref + 1e-4}
+    assert not bad, bad
+    assert med_dev <= 1.5 * med_ref + 1e-4, (med_dev, med_ref)
+    assert max(dev.values()) <= 2.5 * max(refdev.values()) + 1e-4, (max(dev.values()), max(refdev.values()))
+    # the fusion net and the heads sit above the trunk's ReLU kinks: tight
+    tight = {k: (v, refdev[k]) for k, v in dev.items() if k.startswith(("fusion_net.", "cls_head", "reg_head", "obj_head")) and v > 2.0 * refdev[k] + 1e-4}
+    assert not tight, tight
+    for k, b in model.named_buffers():
+        ref = fx["b:" + k].astype(np.float64)
+        assert np.abs(b.detach().cpu().numpy().astype(np.float64) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+
+
+def test_cobevt_optimizer_steps_dropout_and_eval():
+    """The shipped drop_out 0.1, Adam steps, the loss goes down, and .eval() runs the packed engine on the updated weights."""
+    fx = load_fixture("train_cobevt_small_n2")
+    hy, args, sd, dd, tgt = _case(fx)
+    args["fax_fusion"]["drop_out"] = 0.1
+    model = _model(args, sd)
+    crit = _loss(args)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = crit(model(dd), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.95 * losses[0], losses
+    assert int(model.backbone.blocks[0][2].num_batches_tracked) == 6      # one update per step (the backbone runs once)
+    model.eval()
+    with torch.no_grad():
+        o1 = model(dd)
+        sd_now = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        o2 = cob.cobevt_forward(dd, sd_now, args)
+    for k in ("psm", "rm", "obj"):
+        assert_close(o1[k].cpu(), o2[k], 1e-3, 1e-3 * float(o2[k].abs().max()), k)
+    # backbone_fix: only the fusion net stays trainable
+    a2 = synth.clone_hypes(hy)["model"]["args"]
+    a2["backbone_fix"] = True
+    from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
+    m2 = Airv2xCoBEVT(a2)
+    assert all(p.requires_grad == k.startswith("fusion_net.") for k, p in m2.named_parameters())

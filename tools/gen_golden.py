@@ -1450,6 +1450,109 @@ def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01,
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2, 2), pos_frac=0.01):
+    """One TRAINING step of the reference's Airv2xCoBEVT (train mode: BatchNorm batch statistics, SwapFusionEncoder with drop_out 0 --
+    a configuration edit: dropout masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch autograd:
+    heads, losses, the gradient of every parameter (strided samples + sums), every buffer after the step, and the same step in
+    float64 as the yardstick.  oracle/cobevt_oracle.py under train_mode() must reproduce it."""
+    from airv2x_perception_amd import synth
+    from oracle import cobevt_oracle as cob
+    from oracle import loss_oracle as lo
+    from oracle import voxelize_oracle as vox
+    from oracle import where2comm_oracle as orc
+    from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
+    from opencood.models.airv2x_cobevt import Airv2xCoBEVT
+
+    hy_ref = load_ref_hypes_cobevt(lidar_range, max_cav)
+    hy_ref["model"]["args"]["fax_fusion"]["drop_out"] = 0.0
+    hy = synth.default_hypes_cobevt(lidar_range, max_cav)
+    hy["model"]["args"]["fax_fusion"]["drop_out"] = 0.0
+    args = hy["model"]["args"]
+    model = Airv2xCoBEVT(hy_ref["model"]["args"]).train()
+    spec = synth.cobevt_param_spec(args)
+    assert [k for k, _, _ in spec] == list(model.state_dict().keys())
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_train"]))
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    out = model(dd)
+    H, W = out["psm"].shape[-2:]
+    lc = synth.loss_case(seed + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=pos_frac)
+    tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
+    crit = PointPillarLossMultiClass(la)
+    total = crit(out, tgt)
+    total.backward()
+
+    def oracle_step(dtype):
+        sd2 = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k, v in sd2.items():
+            if v.is_floating_point() and k in dict(model.named_parameters()):
+                v.requires_grad_(True)
+        d2 = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+        if dtype == torch.float64:
+            for t in synth.AGENT_TYPES:
+                lid = d2[t]["batch_merged_lidar_features_torch"]
+                if lid is not None:
+                    lid["voxel_features"] = lid["voxel_features"].double()
+        with orc.train_mode():
+            o = cob.cobevt_forward(d2, sd2, args)
+        l_ = lo.pp_loss(o["psm"], o["rm"], o["obj"], tgt["targets"].to(dtype), tgt["pos_equal_one"].to(dtype), tgt["class_ids"],
+                        la["num_class"], la["cls_weight"], la["reg"])
+        l_[0].backward()
+        return o, l_, sd2
+    o, mine, sd2 = oracle_step(torch.float32)
+    worst = max((o[k] - out[k]).abs().max().item() for k in ("psm", "rm", "obj"))
+    assert worst < 1e-4 * max(1.0, max(float(out[k].abs().max()) for k in ("psm", "rm", "obj"))), worst
+    assert abs(float(mine[0]) - float(total)) < 1e-5 * max(1.0, abs(float(total))), (float(mine[0]), float(total))
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types), "n_points": np.int64(n_points),
+          "pos_frac": np.float64(pos_frac), "max_cav": np.asarray(max_cav, np.int64),
+          "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)}
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k].detach().numpy()
+    o64, l64, sd64 = oracle_step(torch.float64)
+    fx["loss64"] = np.float64(float(l64[0]))
+    names, gworst, devs = [], 0.0, []
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            assert sd2[k].grad is None or float(sd2[k].grad.abs().max()) == 0.0, k
+            continue
+        if sd2[k].grad is None:     # the reference's autograd reports an exactly-zero gradient where the oracle's graph has no path
+            assert float(p_.grad.abs().max()) == 0.0, k
+            print(f"[{name}] {k}: zero gradient in the reference, no path in the oracle")
+            continue
+        g, go, g64 = p_.grad.detach().reshape(-1), sd2[k].grad.reshape(-1), sd64[k].grad.reshape(-1)
+        gworst = max(gworst, (g - go).abs().max().item() / max(g.abs().max().item(), 1e-12))
+        stride = max(1, g.numel() // 4096)
+        names.append(k)
+        fx["g:" + k] = g[::stride].numpy()
+        fx["gsum:" + k] = np.asarray([g.double().sum().item(), g.double().abs().sum().item(), g.abs().max().item()], np.float64)
+        fx["g64:" + k] = g64[::stride].float().numpy()
+        fx["g64max:" + k] = np.float64(float(g64.abs().max()))
+        d = np.abs(fx["g:" + k].astype(np.float64) - g64[::stride].numpy()).max() / max(float(g64.abs().max()), 1e-300)
+        fx["gdev:" + k] = np.float64(d)
+        devs.append((d, k))
+    assert gworst < 2e-3, gworst
+    fx["grad_keys"] = np.asarray(names)
+    devs.sort(reverse=True)
+    bworst = 0.0
+    for k, b in model.named_buffers():
+        fx["b:" + k] = b.detach().numpy()
+        bworst = max(bworst, (b.double() - sd2[k].detach().double()).abs().max().item() / max(1.0, b.double().abs().max().item()))
+    assert bworst < 1e-5, bworst
+    print(f"[{name}] total {float(total):.6f} (float64 {float(l64[0]):.6f}); oracle vs reference: heads {worst:.2e}, grads {gworst:.2e}, buffers {bworst:.2e}; "
+          f"{len(names)} gradients; reference fp32 vs float64 gradients: worst {devs[0][0]:.2e} ({devs[0][1]}), median {devs[len(devs) // 2][0]:.2e}")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _bev_quads(boxes):
     """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,4,2) float32 BEV corners (counter-clockwise)."""
     x, y, dx, dy, h = boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]
@@ -1608,6 +1711,8 @@ GROUPS = {
     # BASELINE configs[1]'s frame (4 agents x 8192 points, 704 x 200 grid): one training step of the reference (minutes of CPU)
     "train_full": lambda: train_golden("train_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 13, 5, pos_frac=0.002,
                                        head_stride=4),
+    "train_cobevt": lambda: (train_cobevt_golden("train_cobevt_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 14),
+                             train_cobevt_golden("train_cobevt_small_n2", SMALL, ["vehicle", "vehicle"], 900, 15)),
     "iou_pin": lambda: iou_pin_golden(),
     "voxel_pin": lambda: voxel_pin_golden(),
 }
