@@ -82,6 +82,15 @@ SIGNATURES = {
     "av2x_fax_attention_backward_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
     "av2x_fax_attention_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                               c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_hgt_attention_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_window_attention_backward_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "av2x_window_attention_backward": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                                 c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_split_attn_backward_workspace_bytes": (c_uint64, [c_int32, c_int32]),
+    "av2x_split_attn_sums": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_split_attn_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_warp_affine_backward_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
+    "av2x_warp_affine_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_mean2": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "av2x_cam_stem": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                 c_void_p, c_void_p]),

@@ -1,0 +1,402 @@
+// Backward kernels of the V2X-ViT fusion (`.train()` of Airv2xV2XVit; the reference differentiates
+// models/v2xvit_modules/{hmsa.py, mswin.py, split_attn.py, v2xvit_basic.py} and torch_transformation_utils.warp_affine with torch autograd).
+//
+//   hgt_attention_backward_kernel   HGTCavAttention (hmsa.py:133-151) on the FOLDED projections [q'(->t0) | q'(->t1) | k | v'(t0<-) | v'(t1<-)]:
+//                                   one wave per pixel (lane = head x 4 of its 32 dims, as the forward kernel); scores recomputed; every
+//                                   gradient element is owned by one lane (read-modify-write of that lane's own dproj entries): no atomics
+//   window_attn_backward_q / _kv    BaseWindowAttention (mswin.py:52-96): a thread per (token, head) like the forward kernel -- pass q: row
+//                                   statistics, D = dO . O, dq, the pos_embedding gradient (2^-32 fixed point: LDS, then global atomics);
+//                                   pass kv: dk, dv of the token as a key
+//   split_sums_kernel               sum over pixels of dout * s_r per (agent, branch, channel) (gradient of the radix weights)
+//   split_backward_kernel           ds_r = a_r * dout + dgap / hw
+//   warp_affine_backward_kernel     adjoint of the bilinear sampling of warp_affine (:337-381): scattered with 2^-32 fixed-point atomics
+#include "av2x_common.hpp"
+
+namespace {
+
+constexpr float kFixF = 4294967296.0f;
+
+// ------------------------------------------------------------------------------------------------------------ HGT attention
+struct HgtBwdParams {
+    const float* proj;    // (n, HW, 1280)
+    const float* mask;    // (n, HW)
+    const float* dout;    // (n, HW, 256)
+    float* dproj;         // (n, HW, 1280), pre-zeroed
+    int n, hw;
+    int types[32];
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void hgt_attention_backward_kernel(const HgtBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= p.hw) return;
+    const int col = lane * 4;
+    constexpr int PC = 1280;
+    auto head_sum = [](float s) { s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); return s; };
+    for (int i = 0; i < p.n; ++i) {
+        const int ti = p.types[i];
+        const float* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
+        const float4 q0 = *reinterpret_cast<const float4*>(qi + col);
+        const float4 q1 = *reinterpret_cast<const float4*>(qi + 256 + col);
+        const float4 g = *reinterpret_cast<const float4*>(p.dout + ((size_t)i * p.hw + pix) * 256 + col);
+        // pass 1: row max / sum and the output row (for D = dO . O)
+        float m = -INFINITY, l = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < p.n; ++j) {
+            if (p.mask[(size_t)j * p.hw + pix] == 0.f) continue;
+            const float* kj = p.proj + ((size_t)j * p.hw + pix) * PC;
+            const float4 k = *reinterpret_cast<const float4*>(kj + 512 + col);
+            const float4 q = p.types[j] ? q1 : q0;
+            const float s = head_sum(q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w) * p.scale;
+            const float4 v = *reinterpret_cast<const float4*>(kj + 768 + 256 * ti + col);
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn), pj = expf(s - mn);
+            l = l * alpha + pj;
+            o.x = fmaf(pj, v.x, o.x * alpha); o.y = fmaf(pj, v.y, o.y * alpha);
+            o.z = fmaf(pj, v.z, o.z * alpha); o.w = fmaf(pj, v.w, o.w * alpha);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        const float Di = head_sum(g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w) * inv;
+        // pass 2: gradients
+        float4 dq0 = make_float4(0.f, 0.f, 0.f, 0.f), dq1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < p.n; ++j) {
+            if (p.mask[(size_t)j * p.hw + pix] == 0.f) continue;
+            const size_t rowj = ((size_t)j * p.hw + pix) * PC;
+            const float* kj = p.proj + rowj;
+            const float4 k = *reinterpret_cast<const float4*>(kj + 512 + col);
+            const int tj = p.types[j];
+            const float4 q = tj ? q1 : q0;
+            const float s = head_sum(q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w) * p.scale;
+            const float4 v = *reinterpret_cast<const float4*>(kj + 768 + 256 * ti + col);
+            const float pij = expf(s - m) * inv;
+            const float dp = head_sum(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w);
+            const float ds = pij * (dp - Di) * p.scale;
+            if (tj) { dq1.x = fmaf(ds, k.x, dq1.x); dq1.y = fmaf(ds, k.y, dq1.y); dq1.z = fmaf(ds, k.z, dq1.z); dq1.w = fmaf(ds, k.w, dq1.w); }
+            else { dq0.x = fmaf(ds, k.x, dq0.x); dq0.y = fmaf(ds, k.y, dq0.y); dq0.z = fmaf(ds, k.z, dq0.z); dq0.w = fmaf(ds, k.w, dq0.w); }
+            // this lane owns (pixel, agent j, its 4 columns) of dk and dv'(ti<-): plain read-modify-write, queries i in order
+            float4* dk = reinterpret_cast<float4*>(p.dproj + rowj + 512 + col);
+            float4 a = *dk;
+            a.x = fmaf(ds, q.x, a.x); a.y = fmaf(ds, q.y, a.y); a.z = fmaf(ds, q.z, a.z); a.w = fmaf(ds, q.w, a.w);
+            *dk = a;
+            float4* dv = reinterpret_cast<float4*>(p.dproj + rowj + 768 + 256 * ti + col);
+            float4 b = *dv;
+            b.x = fmaf(pij, g.x, b.x); b.y = fmaf(pij, g.y, b.y); b.z = fmaf(pij, g.z, b.z); b.w = fmaf(pij, g.w, b.w);
+            *dv = b;
+        }
+        float* dqi = p.dproj + ((size_t)i * p.hw + pix) * PC;
+        *reinterpret_cast<float4*>(dqi + col) = dq0;
+        *reinterpret_cast<float4*>(dqi + 256 + col) = dq1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ window attention
+template <int DHD, int WS>
+__global__ __launch_bounds__(256) void window_attn_backward_q(const float* __restrict__ qkv, int ctot, int coff, const float* __restrict__ pos,
+                                                              const float* __restrict__ out, const float* __restrict__ dout,
+                                                              float* __restrict__ dqkv, float* __restrict__ stats,
+                                                              unsigned long long* __restrict__ dpos, int n, int H, int W, int heads, float scale) {
+    constexpr int NP = (2 * WS - 1) * (2 * WS - 1);
+    __shared__ unsigned long long lpos[NP];
+    for (int i = threadIdx.x; i < NP; i += 256) lpos[i] = 0ull;
+    __syncthreads();
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n * H * W * heads;
+    if (gid < total) {
+        const int head = (int)(gid % heads);
+        const size_t tok = gid / heads;
+        const int pix = (int)(tok % ((size_t)H * W));
+        const int a = (int)(tok / ((size_t)H * W));
+        const int y = pix / W, x = pix - y * W;
+        const int wy0 = (y / WS) * WS, wx0 = (x / WS) * WS, iy = y - wy0, ixx = x - wx0;
+        const int inner = heads * DHD;
+        const float* row = qkv + tok * ctot + coff + head * DHD;
+        const float* orow = out + tok * inner + head * DHD;
+        const float* grow = dout + tok * inner + head * DHD;
+        float q[DHD], g[DHD], dq[DHD];
+        float Di = 0.f;
+#pragma unroll
+        for (int d = 0; d < DHD; ++d) { q[d] = row[d]; g[d] = grow[d]; dq[d] = 0.f; Di = fmaf(g[d], orow[d], Di); }
+        float s[WS * WS];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < WS * WS; ++j) {
+            const int jy = j / WS, jx = j % WS;
+            const float* kr = qkv + ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + inner + head * DHD;
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < DHD; ++d) acc = fmaf(q[d], kr[d], acc);
+            acc = acc * scale + pos[(jy - iy + WS - 1) * (2 * WS - 1) + (jx - ixx + WS - 1)];
+            s[j] = acc;
+            m = fmaxf(m, acc);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < WS * WS; ++j) l += expf(s[j] - m);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int j = 0; j < WS * WS; ++j) {
+            const int jy = j / WS, jx = j % WS;
+            const size_t krow = ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + head * DHD;
+            const float* kr = qkv + krow + inner;
+            const float* vr = qkv + krow + 2 * inner;
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < DHD; ++d) dp = fmaf(g[d], vr[d], dp);
+            const float pij = expf(s[j] - m) * inv;
+            const float ds = pij * (dp - Di);
+#pragma unroll
+            for (int d = 0; d < DHD; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
+            if (ds != 0.f) atomicAdd(&lpos[(jy - iy + WS - 1) * (2 * WS - 1) + (jx - ixx + WS - 1)], (unsigned long long)__float2ll_rn(ds * kFixF));
+        }
+        float* st = stats + gid * 3;
+        st[0] = m; st[1] = inv; st[2] = Di;
+        float* dqr = dqkv + tok * ctot + coff + head * DHD;
+#pragma unroll
+        for (int d = 0; d < DHD; ++d) dqr[d] = dq[d] * scale;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NP; i += 256)
+        if (lpos[i]) atomicAdd(dpos + i, lpos[i]);
+}
+
+template <int DHD, int WS>
+__global__ __launch_bounds__(256) void window_attn_backward_kv(const float* __restrict__ qkv, int ctot, int coff, const float* __restrict__ pos,
+                                                               const float* __restrict__ dout, const float* __restrict__ stats,
+                                                               float* __restrict__ dqkv, int n, int H, int W, int heads, float scale) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n * H * W * heads;
+    if (gid >= total) return;
+    const int head = (int)(gid % heads);
+    const size_t tok = gid / heads;
+    const int pix = (int)(tok % ((size_t)H * W));
+    const int a = (int)(tok / ((size_t)H * W));
+    const int y = pix / W, x = pix - y * W;
+    const int wy0 = (y / WS) * WS, wx0 = (x / WS) * WS, jy = y - wy0, jx = x - wx0;
+    const int inner = heads * DHD;
+    const float* row = qkv + tok * ctot + coff + head * DHD;
+    float k[DHD], v[DHD], dk[DHD], dv[DHD];
+#pragma unroll
+    for (int d = 0; d < DHD; ++d) { k[d] = row[inner + d]; v[d] = row[2 * inner + d]; dk[d] = 0.f; dv[d] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < WS * WS; ++i) {
+        const int iy = i / WS, ixx = i % WS;
+        const size_t itok = (size_t)a * H * W + (size_t)(wy0 + iy) * W + (wx0 + ixx);
+        const float* qr = qkv + itok * ctot + coff + head * DHD;
+        const float* gr = dout + itok * inner + head * DHD;
+        const float* st = stats + (itok * heads + head) * 3;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < DHD; ++d) { sc = fmaf(qr[d], k[d], sc); dp = fmaf(gr[d], v[d], dp); }
+        sc = sc * scale + pos[(jy - iy + WS - 1) * (2 * WS - 1) + (jx - ixx + WS - 1)];
+        const float pij = expf(sc - st[0]) * st[1];
+        const float ds = pij * (dp - st[2]) * scale;
+#pragma unroll
+        for (int d = 0; d < DHD; ++d) { dk[d] = fmaf(ds, qr[d], dk[d]); dv[d] = fmaf(pij, gr[d], dv[d]); }
+    }
+    float* drow = dqkv + tok * ctot + coff + head * DHD;
+#pragma unroll
+    for (int d = 0; d < DHD; ++d) { drow[inner + d] = dk[d]; drow[2 * inner + d] = dv[d]; }
+}
+
+__global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)((double)acc[i] * (1.0 / 4294967296.0));
+}
+
+// ------------------------------------------------------------------------------------------------------------ split attention
+constexpr int SPLIT_CHUNKS = 128;
+
+// partial[a][chunk][r][c] = sum over the chunk's pixels of dout * s_r; grid (C / 64, n, SPLIT_CHUNKS), block 256 = 64 channels x 4 pixel lanes
+__global__ __launch_bounds__(256) void split_sums_kernel(const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                                         const float* __restrict__ dout, float* __restrict__ partial, int hw, int C) {
+    __shared__ float part[3][4][64];
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, g = threadIdx.x >> 6, a = blockIdx.y, ch = blockIdx.z;
+    const int per = (hw + SPLIT_CHUNKS - 1) / SPLIT_CHUNKS;
+    const int p0 = ch * per, p1 = min(hw, p0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int p = p0 + g; p < p1; p += 4) {
+        const size_t o = ((size_t)a * hw + p) * C + c;
+        const float d = dout[o];
+        a0 = fmaf(d, s0[o], a0); a1 = fmaf(d, s1[o], a1); a2 = fmaf(d, s2[o], a2);
+    }
+    part[0][g][cl] = a0; part[1][g][cl] = a1; part[2][g][cl] = a2;
+    __syncthreads();
+    if (g < 3)
+        partial[(((size_t)a * SPLIT_CHUNKS + ch) * 3 + g) * C + c] = ((part[g][0][cl] + part[g][1][cl]) + part[g][2][cl]) + part[g][3][cl];
+}
+
+__global__ void split_sums_finish(const float* __restrict__ partial, float* __restrict__ da, int C) {   // da (n, 3, C)
+    const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y, a = blockIdx.z;
+    float acc = 0.f;
+    for (int ch = 0; ch < SPLIT_CHUNKS; ++ch) acc += partial[(((size_t)a * SPLIT_CHUNKS + ch) * 3 + r) * C + c];
+    da[((size_t)a * 3 + r) * C + c] = acc;
+}
+
+// ds_r = w[a][r][c] * dout + dgap[a][c] * inv_hw
+__global__ void split_backward_kernel(const float4* __restrict__ dout, const float* __restrict__ w, const float* __restrict__ dgap,
+                                      float4* __restrict__ d0, float4* __restrict__ d1, float4* __restrict__ d2, size_t n4_per_agent, int C,
+                                      float inv_hw) {
+    const int a = blockIdx.y;
+    const int c4 = C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_agent; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4) * 4;
+        const size_t o = (size_t)a * n4_per_agent + i;
+        const float4 d = dout[o];
+        const float* wa = w + (size_t)a * 3 * C;
+        const float* ga = dgap + (size_t)a * C + c;
+        const float4 gg = make_float4(ga[0] * inv_hw, ga[1] * inv_hw, ga[2] * inv_hw, ga[3] * inv_hw);
+        d0[o] = make_float4(fmaf(wa[c], d.x, gg.x), fmaf(wa[c + 1], d.y, gg.y), fmaf(wa[c + 2], d.z, gg.z), fmaf(wa[c + 3], d.w, gg.w));
+        d1[o] = make_float4(fmaf(wa[C + c], d.x, gg.x), fmaf(wa[C + c + 1], d.y, gg.y), fmaf(wa[C + c + 2], d.z, gg.z), fmaf(wa[C + c + 3], d.w, gg.w));
+        d2[o] = make_float4(fmaf(wa[2 * C + c], d.x, gg.x), fmaf(wa[2 * C + c + 1], d.y, gg.y), fmaf(wa[2 * C + c + 2], d.z, gg.z),
+                            fmaf(wa[2 * C + c + 3], d.w, gg.w));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ warp, adjoint
+__device__ __forceinline__ float lin_m1_1(int i, int n) {     // as v2xvit.hip
+    if (n <= 1) return -1.0f;
+    const float step = 2.0f / (float)(n - 1);
+    return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+template <int CK>   // C = 64 * CK; align_corners = True (warp_affine)
+__global__ __launch_bounds__(256) void warp_affine_backward_kernel(const float* __restrict__ ddst, const float* __restrict__ theta,
+                                                                   unsigned long long* __restrict__ acc, int H, int W) {
+    const int t = threadIdx.x & 15;
+    const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int n = blockIdx.y;
+    if (pix >= H * W) return;
+    const int i = pix / W, j = pix - i * W;
+    const float* th = theta + n * 6;
+    const float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    const float gx = th[0] * xn + th[1] * yn + th[2];
+    const float gy = th[3] * xn + th[4] * yn + th[5];
+    const float ix = ((gx + 1.f) * 0.5f) * (float)(W - 1);
+    const float iy = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
+    const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
+    constexpr int C = 64 * CK;
+    const float* g = ddst + ((size_t)n * H * W + pix) * C + 4 * t;
+    unsigned long long* base = acc + (size_t)n * H * W * C + 4 * t;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const float4 d = *reinterpret_cast<const float4*>(g + 64 * k);
+        auto add = [&](bool ok, int yy, int xx, float w) {
+            if (ok && w != 0.f) {
+                unsigned long long* a = base + ((size_t)yy * W + xx) * C + 64 * k;
+                atomicAdd(a + 0, (unsigned long long)__float2ll_rn(d.x * w * kFixF));
+                atomicAdd(a + 1, (unsigned long long)__float2ll_rn(d.y * w * kFixF));
+                atomicAdd(a + 2, (unsigned long long)__float2ll_rn(d.z * w * kFixF));
+                atomicAdd(a + 3, (unsigned long long)__float2ll_rn(d.w * w * kFixF));
+            }
+        };
+        add(vy0 && vx0, y0, x0, w00);
+        add(vy0 && vx1, y0, x1, w01);
+        add(vy1 && vx0, y1, x0, w10);
+        add(vy1 && vx1, y1, x1, w11);
+    }
+}
+
+}  // namespace
+
+extern "C" int av2x_hgt_attention_backward(const float* proj, const float* mask, const int32_t* types_host, const float* dout, float* dproj,
+                                           int32_t n, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
+    if (!proj || !mask || !types_host || !dout || !dproj) return av2x::fail("av2x_hgt_attention_backward: null argument");
+    if (heads != 8 || dim_head != 32) return av2x::fail("av2x_hgt_attention_backward: heads=%d dim_head=%d (8 x 32)", heads, dim_head);
+    if (n < 1 || n > 32 || hw < 1) return av2x::fail("av2x_hgt_attention_backward: bad sizes");
+    HgtBwdParams p;
+    p.proj = proj; p.mask = mask; p.dout = dout; p.dproj = dproj; p.n = n; p.hw = hw;
+    for (int i = 0; i < n; ++i) p.types[i] = types_host[i];
+    p.scale = 1.0f / sqrtf((float)dim_head);
+    hipStream_t st = av2x::as_stream(stream);
+    hipError_t e = hipMemsetAsync(dproj, 0, (size_t)n * hw * 1280 * sizeof(float), st);
+    if (e != hipSuccess) return av2x::fail("av2x_hgt_attention_backward: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(hgt_attention_backward_kernel, dim3((hw + 3) / 4), dim3(256), 0, st, p);
+    return av2x::check_launch("hgt_attention_backward_kernel");
+}
+
+extern "C" uint64_t av2x_window_attention_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t heads, int32_t window) {
+    return (uint64_t)n * h * w * heads * 3 * sizeof(float) + (uint64_t)(2 * window - 1) * (2 * window - 1) * 8ull + 64;
+}
+
+extern "C" int av2x_window_attention_backward(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, const float* out,
+                                              const float* dout, float* dqkv, float* dpos, void* workspace, int32_t n, int32_t h, int32_t w,
+                                              int32_t heads, int32_t dim_head, int32_t window, av2x_stream_t stream) {
+    if (!qkv || !pos_embedding || !out || !dout || !dqkv || !dpos || !workspace) return av2x::fail("av2x_window_attention_backward: null argument");
+    if (h % window || w % window) return av2x::fail("av2x_window_attention_backward: map %dx%d not divisible by window %d", h, w, window);
+    const size_t total = (size_t)n * h * w * heads;
+    if (total == 0) return 0;
+    const int np = (2 * window - 1) * (2 * window - 1);
+    unsigned long long* dposfix = reinterpret_cast<unsigned long long*>(workspace);
+    float* stats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (((size_t)np * 8 + 63) & ~(size_t)63));
+    hipStream_t st = av2x::as_stream(stream);
+    hipError_t e = hipMemsetAsync(dposfix, 0, (size_t)np * 8, st);
+    if (e != hipSuccess) return av2x::fail("av2x_window_attention_backward: memset: %s", hipGetErrorString(e));
+    const float scale = 1.0f / sqrtf((float)dim_head);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define AV2X_WAB(DHD, WS)                                                                                                              \
+    if (dim_head == DHD && window == WS) {                                                                                             \
+        hipLaunchKernelGGL((window_attn_backward_q<DHD, WS>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, dout, dqkv, stats, \
+                           dposfix, n, h, w, heads, scale);                                                                            \
+        hipLaunchKernelGGL((window_attn_backward_kv<DHD, WS>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, dout, stats, dqkv, n, \
+                           h, w, heads, scale);                                                                                        \
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(dposfix), dpos, (size_t)np); \
+        return av2x::check_launch("window_attn_backward");                                                                             \
+    }
+    AV2X_WAB(16, 2)
+    AV2X_WAB(32, 4)
+    AV2X_WAB(64, 4)
+#undef AV2X_WAB
+    return av2x::fail("av2x_window_attention_backward: (dim_head, window) = (%d, %d) unsupported: (16,2) (32,4) (64,4)", dim_head, window);
+}
+
+extern "C" uint64_t av2x_split_attn_backward_workspace_bytes(int32_t n, int32_t c) { return (uint64_t)n * SPLIT_CHUNKS * 3 * c * sizeof(float); }
+
+extern "C" int av2x_split_attn_sums(const float* s0, const float* s1, const float* s2, const float* dout, float* da, float* workspace,
+                                    int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+    if (!s0 || !s1 || !s2 || !dout || !da || !workspace) return av2x::fail("av2x_split_attn_sums: null argument");
+    if (c % 64 || n < 1) return av2x::fail("av2x_split_attn_sums: c must be a multiple of 64");
+    hipStream_t st = av2x::as_stream(stream);
+    hipLaunchKernelGGL(split_sums_kernel, dim3(c / 64, n, SPLIT_CHUNKS), dim3(256), 0, st, s0, s1, s2, dout, workspace, hw, c);
+    hipLaunchKernelGGL(split_sums_finish, dim3(c / 64, 3, n), dim3(64), 0, st, workspace, da, c);
+    return av2x::check_launch("split_sums");
+}
+
+extern "C" int av2x_split_attn_backward(const float* dout, const float* weights, const float* dgap, float* ds0, float* ds1, float* ds2,
+                                        int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+    if (!dout || !weights || !dgap || !ds0 || !ds1 || !ds2) return av2x::fail("av2x_split_attn_backward: null argument");
+    if (c % 4 || n < 1) return av2x::fail("av2x_split_attn_backward: c must be a multiple of 4");
+    const size_t n4 = (size_t)hw * c / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_backward_kernel, dim3((unsigned)blocks, n), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const float4*>(dout),
+                       weights, dgap, reinterpret_cast<float4*>(ds0), reinterpret_cast<float4*>(ds1), reinterpret_cast<float4*>(ds2), n4, c,
+                       1.0f / (float)hw);
+    return av2x::check_launch("split_backward_kernel");
+}
+
+extern "C" uint64_t av2x_warp_affine_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c) { return (uint64_t)n * h * w * c * 8ull; }
+
+extern "C" int av2x_warp_affine_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,
+                                         int32_t c, av2x_stream_t stream) {
+    if (!ddst || !theta || !dsrc || !workspace) return av2x::fail("av2x_warp_affine_backward: null argument");
+    if (c != 64 && c != 128 && c != 256) return av2x::fail("av2x_warp_affine_backward: c=%d (64, 128, 256)", c);
+    if (n < 1) return 0;
+    hipStream_t st = av2x::as_stream(stream);
+    const size_t total = (size_t)n * h * w * c;
+    hipError_t e = hipMemsetAsync(workspace, 0, total * 8ull, st);
+    if (e != hipSuccess) return av2x::fail("av2x_warp_affine_backward: memset: %s", hipGetErrorString(e));
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace);
+    const dim3 grid((h * w + 15) / 16, n), block(256);
+    if (c == 64) hipLaunchKernelGGL(warp_affine_backward_kernel<1>, grid, block, 0, st, ddst, theta, acc, h, w);
+    else if (c == 128) hipLaunchKernelGGL(warp_affine_backward_kernel<2>, grid, block, 0, st, ddst, theta, acc, h, w);
+    else hipLaunchKernelGGL(warp_affine_backward_kernel<4>, grid, block, 0, st, ddst, theta, acc, h, w);
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const long long*>(acc), dsrc, total);
+    return av2x::check_launch("warp_affine_backward_kernel");
+}

@@ -36,7 +36,9 @@ class Airv2xV2XVit(nn.Module):
                 t, buf = torch.from_numpy(synthetic_tensor(key, shape, kind)), False
             else:
                 t, buf = torch.zeros(shape), False
-            _install(self, key, t, buf)
+            _install(self, key, t, buf, requires_grad=True)    # trainable, as the reference's nn.Modules are
+        if args.get("backbone_fix"):
+            self.backbone_fix()
         self._engine = None
         self._packed_version = None
         self.sync_comm_rate = True
@@ -57,9 +59,16 @@ class Airv2xV2XVit(nn.Module):
             self._packed_version = ver
         return self._engine
 
+    def backbone_fix(self):
+        """airv2x_v2xvit.py backbone_fix (fine-tuning on time delay): everything but the fusion net is frozen."""
+        for name, p in self.named_parameters():
+            if not name.startswith("fusion_net."):
+                p.requires_grad = False
+
     def forward(self, data_dict):
-        if self.training:
-            raise NotImplementedError("training is not built yet; call .eval()")
+        if self.training:   # the graph torch autograd differentiates, on HIP forward / backward ops (train_v2xvit.py)
+            from .train_v2xvit import forward_train
+            return forward_train(self, data_dict)
         eng = self.engine()
         eng.amp = _amp_requested(self)
         return eng.forward(data_dict, sync_comm_rate=self.sync_comm_rate)

@@ -224,3 +224,196 @@ class AgentMeanFn(torch.autograd.Function):
 
 def agent_mean(x):
     return AgentMeanFn.apply(x)
+
+
+# ======================================================================================================= V2X-ViT nodes
+def _types_arr(types):
+    import ctypes
+    return (ctypes.c_int32 * len(types))(*[int(t) for t in types])
+
+
+class HgtAttentionFn(torch.autograd.Function):
+    """HGTCavAttention's attention core (hmsa.py:133-151) on the folded projections: proj (n, H, W, 1280) =
+    [q'(->type 0) | q'(->type 1) | k | v'(type 0 <-) | v'(type 1 <-)], mask (n, H, W) = key agent visible at the pixel ->
+    (n, H, W, 256) heads merged (before a_linears)."""
+
+    @staticmethod
+    def forward(ctx, proj, mask, types, heads, dim_head):
+        import ctypes
+        T._check_dev(proj)
+        r = _runner(proj.device)
+        proj = proj.contiguous()
+        n, H, W, _ = proj.shape
+        out = torch.empty((n, H, W, heads * dim_head), dtype=torch.float32, device=proj.device)
+        ta = _types_arr(types)
+        _lib.check(r.lib.av2x_hgt_attention(_P(proj), _P(mask), ctypes.cast(ta, ctypes.c_void_p), _P(out), n, H * W, heads, dim_head, r.stream()),
+                   "av2x_hgt_attention")
+        ctx.save_for_backward(proj, mask)
+        ctx.cfg = (list(types), heads, dim_head)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        proj, mask = ctx.saved_tensors
+        types, heads, dim_head = ctx.cfg
+        r = _runner(proj.device)
+        n, H, W, _ = proj.shape
+        dproj = torch.empty_like(proj)
+        ta = _types_arr(types)
+        _lib.check(r.lib.av2x_hgt_attention_backward(_P(proj), _P(mask), ctypes.cast(ta, ctypes.c_void_p), _P(dout.contiguous()), _P(dproj), n, H * W,
+                                                     heads, dim_head, r.stream()), "av2x_hgt_attention_backward")
+        return dproj, None, None, None, None
+
+
+def hgt_attention(proj, mask, types, heads, dim_head):
+    return HgtAttentionFn.apply(proj, mask, types, heads, dim_head)
+
+
+class PyramidWindowFn(torch.autograd.Function):
+    """The three BaseWindowAttention cores (mswin.py:52-96) of a PyramidWindowAttention on ONE [q|k|v] x 3 buffer: qkv3 (n, H, W, sum 3 h_i d_i),
+    pos_i (2 w_i - 1, 2 w_i - 1) -> three (n, H, W, h_i d_i) maps (before to_out)."""
+
+    @staticmethod
+    def forward(ctx, qkv3, pos0, pos1, pos2, cfg):
+        T._check_dev(qkv3)
+        r = _runner(qkv3.device)
+        qkv3 = qkv3.contiguous()
+        n, H, W, ctot = qkv3.shape
+        outs, coff = [], 0
+        for (h, dh, ws), pos in zip(cfg, (pos0, pos1, pos2)):
+            o = torch.empty((n, H, W, h * dh), dtype=torch.float32, device=qkv3.device)
+            _lib.check(r.lib.av2x_window_attention(_P(qkv3), ctot, coff, _P(pos.detach().contiguous()), _P(o), n, H, W, h, dh, ws, r.stream()),
+                       "av2x_window_attention")
+            outs.append(o)
+            coff += 3 * h * dh
+        ctx.save_for_backward(qkv3, pos0, pos1, pos2, *outs)
+        ctx.cfg = cfg
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        qkv3, pos0, pos1, pos2, o0, o1, o2 = ctx.saved_tensors
+        r = _runner(qkv3.device)
+        n, H, W, ctot = qkv3.shape
+        dqkv = torch.empty_like(qkv3)
+        dpos, coff = [], 0
+        for (h, dh, ws), pos, o, d in zip(ctx.cfg, (pos0, pos1, pos2), (o0, o1, o2), (d0, d1, d2)):
+            dp = torch.empty_like(pos)
+            wsb = torch.empty(int(r.lib.av2x_window_attention_backward_workspace_bytes(n, H, W, h, ws)), dtype=torch.uint8, device=qkv3.device)
+            _lib.check(r.lib.av2x_window_attention_backward(_P(qkv3), ctot, coff, _P(pos.detach().contiguous()), _P(o), _P(d.contiguous()), _P(dqkv), _P(dp),
+                                                            _P(wsb), n, H, W, h, dh, ws, r.stream()), "av2x_window_attention_backward")
+            dpos.append(dp)
+            coff += 3 * h * dh
+        return dqkv, dpos[0], dpos[1], dpos[2], None
+
+
+def pyramid_window_attention(qkv3, pos, cfg):
+    return PyramidWindowFn.apply(qkv3, pos[0], pos[1], pos[2], tuple(tuple(int(v) for v in c) for c in cfg))
+
+
+def _split_logits(gap, fc1_w, bn_w, bn_b, fc2_w):
+    """SplitAttn's squeeze path on the (n, C) mean (split_attn.py:51-53): fc1 -> LayerNorm ("bn1") -> ReLU -> fc2.  A handful of
+    C-vectors per agent: plain tensor algebra (differentiable for the backward below)."""
+    import torch.nn.functional as TF
+    g = TF.relu(TF.layer_norm(TF.linear(gap, fc1_w), (gap.shape[-1],), bn_w, bn_b, LN_EPS))
+    return TF.linear(g, fc2_w)
+
+
+class SplitAttnFn(torch.autograd.Function):
+    """SplitAttn.forward (split_attn.py:40-63) + the residual of the enclosing PreNorm block: three branch maps (n, H, W, C) -> out."""
+
+    @staticmethod
+    def forward(ctx, s0, s1, s2, res, fc1_w, bn_w, bn_b, fc2_w):
+        T._check_dev(s0)
+        r = _runner(s0.device)
+        s0, s1, s2, res = s0.contiguous(), s1.contiguous(), s2.contiguous(), res.contiguous()
+        n, H, W, C = s0.shape
+        gap = torch.empty((n, C), dtype=torch.float32, device=s0.device)
+        scratch = torch.empty((n, 128, C), dtype=torch.float32, device=s0.device)
+        _lib.check(r.lib.av2x_split_attn_gap(_P(s0), _P(s1), _P(s2), _P(gap), _P(scratch), n, H * W, C, r.stream()), "av2x_split_attn_gap")
+        with torch.no_grad():
+            logits = _split_logits(gap, fc1_w, bn_w, bn_b, fc2_w).contiguous()
+        out = torch.empty_like(s0)
+        _lib.check(r.lib.av2x_split_attn_combine(_P(s0), _P(s1), _P(s2), _P(logits), _P(res), _P(out), n, H * W, C, r.stream()), "av2x_split_attn_combine")
+        ctx.save_for_backward(s0, s1, s2, gap, fc1_w, bn_w, bn_b, fc2_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s0, s1, s2, gap, fc1_w, bn_w, bn_b, fc2_w = ctx.saved_tensors
+        r = _runner(s0.device)
+        dout = dout.contiguous()
+        n, H, W, C = s0.shape
+        da = torch.empty((n, 3, C), dtype=torch.float32, device=s0.device)
+        ws = torch.empty(int(r.lib.av2x_split_attn_backward_workspace_bytes(n, C)) // 4, dtype=torch.float32, device=s0.device)
+        _lib.check(r.lib.av2x_split_attn_sums(_P(s0), _P(s1), _P(s2), _P(dout), _P(da), _P(ws), n, H * W, C, r.stream()), "av2x_split_attn_sums")
+        with torch.enable_grad():     # the squeeze path again, on (n, C) vectors, for its vector-Jacobian product
+            g_ = gap.detach().requires_grad_(True)
+            ps = [p.detach().requires_grad_(True) for p in (fc1_w, bn_w, bn_b, fc2_w)]
+            a = torch.softmax(_split_logits(g_, *ps).view(n, 3, C), dim=1)        # RadixSoftmax(3, 1)
+            grads = torch.autograd.grad((a * da).sum(), [g_] + ps)
+        wts = a.detach().contiguous()
+        dgap = grads[0].contiguous()
+        d0, d1, d2 = torch.empty_like(s0), torch.empty_like(s0), torch.empty_like(s0)
+        _lib.check(r.lib.av2x_split_attn_backward(_P(dout), _P(wts), _P(dgap), _P(d0), _P(d1), _P(d2), n, H * W, C, r.stream()), "av2x_split_attn_backward")
+        return d0, d1, d2, dout, grads[1], grads[2], grads[3], grads[4]
+
+
+def split_attn(s0, s1, s2, res, fc1_w, bn_w, bn_b, fc2_w):
+    return SplitAttnFn.apply(s0, s1, s2, res, fc1_w, bn_w, bn_b, fc2_w)
+
+
+class WarpAffineFn(torch.autograd.Function):
+    """warp_affine (torch_transformation_utils.py:337-381: affine_grid + grid_sample, bilinear, zeros, align_corners) with a constant theta."""
+
+    @staticmethod
+    def forward(ctx, x, theta):
+        T._check_dev(x)
+        r = _runner(x.device)
+        x = x.contiguous()
+        n, H, W, C = x.shape
+        y = torch.empty_like(x)
+        _lib.check(r.lib.av2x_warp_affine(_P(x), _P(theta), _P(y), n, H, W, C, r.stream()), "av2x_warp_affine")
+        ctx.save_for_backward(theta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (theta,) = ctx.saved_tensors
+        r = _runner(dy.device)
+        dy = dy.contiguous()
+        n, H, W, C = dy.shape
+        dx = torch.empty_like(dy)
+        ws = torch.empty(int(r.lib.av2x_warp_affine_backward_workspace_bytes(n, H, W, C)), dtype=torch.uint8, device=dy.device)
+        _lib.check(r.lib.av2x_warp_affine_backward(_P(dy), _P(theta), _P(dx), _P(ws), n, H, W, C, r.stream()), "av2x_warp_affine_backward")
+        return dx, None
+
+
+def warp_affine(x, theta):
+    return WarpAffineFn.apply(x, theta)
+
+
+class AddAgentVectorFn(torch.autograd.Function):
+    """x (n, H, W, C) + v (n, C) broadcast over the map (RTE, v2xvit_basic.py:58-80)."""
+
+    @staticmethod
+    def forward(ctx, x, v):
+        T._check_dev(x)
+        r = _runner(x.device)
+        y = x.contiguous().clone()
+        n, H, W, C = y.shape
+        _lib.check(r.lib.av2x_add_agent_vector(_P(y), _P(v.detach().contiguous()), n, H * W * C, C, r.stream()), "av2x_add_agent_vector")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        r = _runner(dy.device)
+        dy = dy.contiguous()
+        n, H, W, C = dy.shape
+        dv = torch.stack([_chan_sum(r, dy[a], H * W, C) for a in range(n)]) if ctx.needs_input_grad[1] else None
+        return dy, dv
+
+
+def add_agent_vector(x, v):
+    return AddAgentVectorFn.apply(x, v)

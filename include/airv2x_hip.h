@@ -422,6 +422,36 @@ int av2x_fax_attention_backward(const float* qkv, const float* bias_table, const
                                 av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training of the V2X-ViT fusion (Airv2xV2XVit.train()): backward kernels of models/v2xvit_modules/hmsa.py:133-151,
+ * mswin.py:52-96, split_attn.py:48-61 and of warp_affine (torch_transformation_utils.py:337-381).  Layouts as the forward entry points.
+ *
+ * av2x_hgt_attention_backward      dproj (n, hw, 1280) of av2x_hgt_attention: the gradient of the FOLDED projections
+ *                                  [q'(->t0) | q'(->t1) | k | v'(t0<-) | v'(t1<-)]; the relation matrices receive theirs through the fold,
+ *                                  which the host side expresses in differentiable tensor algebra on the (small) weights.
+ * av2x_window_attention_backward   dqkv (same (n*h*w, ctot) buffer layout, block at `coff`) and dpos (2w-1, 2w-1) of
+ *                                  av2x_window_attention; `out` = that call's output.  The pos_embedding gradient is summed as 2^-32 fixed
+ *                                  point (bit-reproducible).  workspace: av2x_window_attention_backward_workspace_bytes.
+ * av2x_split_attn_sums             da (n, 3, c) = sum over pixels of dout * s_r: the gradient of the radix weights of SplitAttn.
+ * av2x_split_attn_backward         ds_r = weights[a][r][c] * dout + dgap[a][c] / hw  (weights = the radix softmax, (n, 3, c)).
+ * av2x_warp_affine_backward        dsrc of av2x_warp_affine (align_corners = True): the adjoint of the bilinear sampling, scattered with
+ *                                  2^-32 fixed-point atomics into `workspace` (8 bytes per element) -- bit-reproducible.
+ * ------------------------------------------------------------------------------------ */
+int av2x_hgt_attention_backward(const float* proj, const float* mask, const int32_t* types_host, const float* dout, float* dproj,
+                                int32_t n, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
+uint64_t av2x_window_attention_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t heads, int32_t window);
+int av2x_window_attention_backward(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, const float* out,
+                                   const float* dout, float* dqkv, float* dpos, void* workspace, int32_t n, int32_t h, int32_t w,
+                                   int32_t heads, int32_t dim_head, int32_t window, av2x_stream_t stream);
+uint64_t av2x_split_attn_backward_workspace_bytes(int32_t n, int32_t c);
+int av2x_split_attn_sums(const float* s0, const float* s1, const float* s2, const float* dout, float* da, float* workspace,
+                         int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
+int av2x_split_attn_backward(const float* dout, const float* weights, const float* dgap, float* ds0, float* ds1, float* ds2,
+                             int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
+uint64_t av2x_warp_affine_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c);
+int av2x_warp_affine_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,
+                              int32_t c, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Camera encoder (BASELINE configs[4]): the non-GEMM kernels of CamEncode / BevEncode
  * (models/sub_modules/lss_submodule.py:22-189, 312-350) and of the efficientnet_pytorch trunk CamEncode walks (:118-146).
  * All maps NHWC fp32; the pointwise / 3x3 / 7x7 convolutions run on av2x_conv2d.

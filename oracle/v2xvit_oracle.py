@@ -66,7 +66,7 @@ def affine_theta(M, src_hw, dsize):
 def warp_affine(src, M, dsize, mode="bilinear"):
     theta = affine_theta(M, src.shape[-2:], dsize)
     grid = F.affine_grid(theta, [src.shape[0], src.shape[1], dsize[0], dsize[1]], align_corners=True)
-    return F.grid_sample(src, grid, align_corners=True, mode=mode, padding_mode="zeros")
+    return F.grid_sample(src, grid.to(src.dtype), align_corners=True, mode=mode, padding_mode="zeros")   # the cast is a no-op in fp32
 
 
 def roi_and_cav_mask(shape, cav_mask, scm, discrete_ratio, downsample_rate):

@@ -343,13 +343,15 @@ def run_cobevt_case(name, lidar_range, types, n_points, seed, big_stride, compre
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def v2xvit_frame(synth, vox, hy, types, n_points, rng, max_cav_num):
+def v2xvit_frame(synth, vox, hy, types, n_points, rng, max_cav_num, train=False):
     """Seeded V2X-ViT test frame: per non-ego agent an SE(2) spatial correction and a time delay."""
     pp = hy["preprocess"]
     voxd = []
     for i, t in enumerate(types):
         p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng or synth.DEFAULT_RANGE), pp["cav_lidar_range"])
-        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"]))
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_train"]) if train else
+                    vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"]))
     dd = synth.build_data_dict(voxd, types, max_cav_num=max_cav_num)
     g = np.random.default_rng(77)
     for i in range(1, len(types)):
@@ -1553,6 +1555,123 @@ def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2,
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def _load_ref_hypes_v2xvit(lidar_range, max_cav):
+    from opencood.hypes_yaml.yaml_utils import load_yaml
+    src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_v2xvit.yaml")
+    txt = open(src).read()
+    if lidar_range is not None:
+        r = lidar_range
+        txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+    txt = re.sub(r"vehicle: 5\n(\s+)rsu: 5\n(\s+)drone: 5", f"vehicle: {max_cav[0]}\n\\1rsu: {max_cav[1]}\n\\2drone: {max_cav[2]}", txt)
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(txt)
+        path = f.name
+    hy_ref = load_yaml(path)
+    os.unlink(path)
+    return hy_ref
+
+
+def train_v2xvit_golden(name, lidar_range, types, n_points, seed, max_cav=(2, 1, 1), pos_frac=0.01):
+    """One TRAINING step of the reference's Airv2xV2XVit (train mode, every dropout probability set to 0 -- a configuration edit: dropout
+    masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch autograd; as train_cobevt_golden."""
+    from airv2x_perception_amd import synth
+    from oracle import loss_oracle as lo
+    from oracle import v2xvit_oracle as vit
+    from oracle import voxelize_oracle as vox
+    from oracle import where2comm_oracle as orc
+    from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
+    from opencood.models.airv2x_v2xvit import Airv2xV2XVit
+
+    hy_ref = _load_ref_hypes_v2xvit(lidar_range, max_cav)
+    hy = synth.default_hypes_v2xvit(lidar_range, max_cav)
+    for h_ in (hy_ref, hy):
+        e = h_["model"]["args"]["transformer"]["encoder"]
+        e["cav_att_config"]["dropout"] = 0.0
+        e["pwindow_att_config"]["dropout"] = 0.0
+        e["feed_forward"]["dropout"] = 0.0
+    args = hy["model"]["args"]
+    model = Airv2xV2XVit(hy_ref["model"]["args"]).train()
+    spec = synth.v2xvit_param_spec(args)
+    assert [k for k, _, _ in spec] == list(model.state_dict().keys())
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    dd, voxd = v2xvit_frame(synth, vox, hy, types, n_points, lidar_range, args["max_cav_num"], train=True)
+    out = model({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in dd.items()})
+    H, W = out["psm"].shape[-2:]
+    lc = synth.loss_case(seed + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=pos_frac)
+    tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
+    crit = PointPillarLossMultiClass(la)
+    total = crit(out, tgt)
+    total.backward()
+
+    def oracle_step(dtype):
+        sd2 = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k, v in sd2.items():
+            if v.is_floating_point() and k in dict(model.named_parameters()):
+                v.requires_grad_(True)
+        d2, _ = v2xvit_frame(synth, vox, hy, types, n_points, lidar_range, args["max_cav_num"], train=True)
+        if dtype == torch.float64:
+            for t in synth.AGENT_TYPES:
+                lid = d2[t]["batch_merged_lidar_features_torch"]
+                if lid is not None:
+                    lid["voxel_features"] = lid["voxel_features"].double()
+            d2["prior_encoding"] = d2["prior_encoding"].double()
+        with orc.train_mode():
+            o = vit.v2xvit_forward(d2, sd2, args)
+        l_ = lo.pp_loss(o["psm"], o["rm"], o["obj"], tgt["targets"].to(dtype), tgt["pos_equal_one"].to(dtype), tgt["class_ids"],
+                        la["num_class"], la["cls_weight"], la["reg"])
+        l_[0].backward()
+        return o, l_, sd2
+    o, mine, sd2 = oracle_step(torch.float32)
+    worst = max((o[k] - out[k]).abs().max().item() for k in ("psm", "rm", "obj"))
+    assert worst < 1e-4 * max(1.0, max(float(out[k].detach().abs().max()) for k in ("psm", "rm", "obj"))), worst
+    assert abs(float(mine[0]) - float(total)) < 1e-5 * max(1.0, abs(float(total))), (float(mine[0]), float(total))
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(lidar_range or synth.DEFAULT_RANGE, np.float64), "types": np.asarray(types),
+          "n_points": np.int64(n_points), "pos_frac": np.float64(pos_frac), "max_cav": np.asarray(max_cav, np.int64),
+          "spatial_correction_matrix": dd["spatial_correction_matrix"].numpy(), "prior_encoding": dd["prior_encoding"].numpy(),
+          "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)}
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k].detach().numpy()
+    o64, l64, sd64 = oracle_step(torch.float64)
+    fx["loss64"] = np.float64(float(l64[0]))
+    names, gworst, devs, zero = [], 0.0, [], []
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            assert sd2[k].grad is None or float(sd2[k].grad.abs().max()) == 0.0, k
+            continue
+        if sd2[k].grad is None:
+            assert float(p_.grad.abs().max()) == 0.0, k
+            zero.append(k)
+            continue
+        g, go, g64 = p_.grad.detach().reshape(-1), sd2[k].grad.reshape(-1), sd64[k].grad.reshape(-1)
+        gworst = max(gworst, (g - go).abs().max().item() / max(g.abs().max().item(), 1e-12))
+        stride = max(1, g.numel() // 4096)
+        names.append(k)
+        fx["g:" + k] = g[::stride].numpy()
+        fx["gsum:" + k] = np.asarray([g.double().sum().item(), g.double().abs().sum().item(), g.abs().max().item()], np.float64)
+        fx["g64:" + k] = g64[::stride].float().numpy()
+        fx["g64max:" + k] = np.float64(float(g64.abs().max()))
+        d = np.abs(fx["g:" + k].astype(np.float64) - g64[::stride].numpy()).max() / max(float(g64.abs().max()), 1e-300)
+        fx["gdev:" + k] = np.float64(d)
+        devs.append((d, k))
+    assert gworst < 2e-3, gworst
+    fx["grad_keys"] = np.asarray(names)
+    fx["zero_grad_keys"] = np.asarray(zero)
+    devs.sort(reverse=True)
+    bworst = 0.0
+    for k, b in model.named_buffers():
+        fx["b:" + k] = b.detach().numpy()
+        bworst = max(bworst, (b.double() - sd2[k].detach().double()).abs().max().item() / max(1.0, b.double().abs().max().item()))
+    assert bworst < 1e-5, bworst
+    print(f"[{name}] total {float(total):.6f} (float64 {float(l64[0]):.6f}); oracle vs reference: heads {worst:.2e}, grads {gworst:.2e}, buffers {bworst:.2e}; "
+          f"{len(names)} gradients ({len(zero)} exactly zero in the reference); reference fp32 vs float64 gradients: worst {devs[0][0]:.2e} ({devs[0][1]}), "
+          f"median {devs[len(devs) // 2][0]:.2e}")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _bev_quads(boxes):
     """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,4,2) float32 BEV corners (counter-clockwise)."""
     x, y, dx, dy, h = boxes[:, 0], boxes[:, 1], boxes[:, 3], boxes[:, 4], boxes[:, 6]
@@ -1713,6 +1832,8 @@ GROUPS = {
                                        head_stride=4),
     "train_cobevt": lambda: (train_cobevt_golden("train_cobevt_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 14),
                              train_cobevt_golden("train_cobevt_small_n2", SMALL, ["vehicle", "vehicle"], 900, 15)),
+    "train_v2xvit": lambda: (train_v2xvit_golden("train_v2xvit_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 16),
+                             train_v2xvit_golden("train_v2xvit_small_n2", SMALL, ["vehicle", "vehicle"], 900, 17)),
     "iou_pin": lambda: iou_pin_golden(),
     "voxel_pin": lambda: voxel_pin_golden(),
 }
