@@ -216,3 +216,39 @@ def test_cobevt_optimizer_steps_dropout_and_eval():
     from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
     m2 = Airv2xCoBEVT(a2)
     assert all(p.requires_grad == k.startswith("fusion_net.") for k, p in m2.named_parameters())
+
+
+@pytest.mark.parametrize("which,port", [("cobevt", 29551), ("v2xvit", 29552)])
+def test_ddp_two_ranks_average_the_gradients(which, port):
+    """tools/train.py:162 wraps the model in DistributedDataParallel: two ranks (this box's one GPU, gloo), one frame each -- every rank
+    ends up with the mean of the two single-process gradients (tests/ddp_fusion_worker.py), for Airv2xCoBEVT and Airv2xV2XVit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "tests/ddp_fusion_worker.py", which]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DDP-2-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_cobevt_amp_training_step():
+    """tools/train.py --amp: autocast + GradScaler around the CoBEVT training step (bf16 operands for the convolutions and Linears)."""
+    fx = load_fixture("train_cobevt_small_n2")
+    hy, args, sd, dd, tgt = _case(fx)
+    m32 = _model(args, sd)
+    l32 = _loss(args)(m32(dd), tgt)
+    model = _model(args, sd)
+    scaler = torch.amp.GradScaler("cuda", init_scale=256.0)
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = model(dd)
+        loss = _loss(args)(out, tgt)
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss.detach())) and abs(float(loss.detach()) - float(l32.detach())) <= 3e-2 * abs(float(l32.detach()))
+    assert float(loss.detach()) != float(l32.detach()), "autocast did not change the arithmetic"
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
