@@ -1,0 +1,397 @@
+// Token Linear layers of the transformer fusion heads with bf16 ACTIVATIONS in HBM (the storage torch.autocast gives the
+// outputs of nn.Linear / matmul; reference tools/train.py:118, inference_utils under autocast): SURVEY 8a a15 in AMP mode.
+//
+//   linear_bf16_kernel   out[m][n] = act(sum_k A[m][k] W[k][n] + bias[n]) (+ residual[m][n])     K = 256
+//       A   (M, 256) bf16 row-major tokens (NHWC buffer viewed as rows)
+//       W   bf16 k-oct packing [K/8][CoutP][8] of packing.to_bf16_koct with the COLUMNS of every 64-group interleaved
+//           (packing.interleave2_columns): packed column 32 c + i of a group holds logical column 2 i + c, so that an MFMA
+//           lane owns TWO CONSECUTIVE output columns of a row (one 4-byte bf16 / 8-byte fp32 store, 128 / 256 contiguous
+//           bytes per row and half-wave) while its B fragments stay fully coalesced 16-byte loads
+//       out bf16 (next Linear / attention input) or fp32 (+ fp32 residual: the residual stream x stays fp32, as under autocast
+//           where LayerNorm outputs and `x + fn(x)` are fp32)
+//
+// These layers are HBM-bound on MI355X (K = 256: 64-128 flop per byte moved at 2.5 PFLOP/s bf16), so the kernels are built
+// around bytes, not MFMA issue: a workgroup owns a PANEL of tokens, pulls it into LDS once with all its loads in flight
+// together, then walks over the output columns in chunks of 256 reading the weights straight from L2 into registers
+// (<= 1.2 MB per layer: L2-resident), so A is read from HBM exactly once whatever the output width (1280 for the HGT
+// projections, 2304 for the three window-attention QKVs).
+//   v_mfma_f32_32x32x16_bf16: lane (i = lane & 31, h = lane >> 5) supplies k = 8 h + 0..7 of row / column i
+//   C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+//
+//   layernorm_bf16_kernel   nn.LayerNorm over C = 256 of the fp32 residual stream, bf16 out (the A operand above)
+#include "av2x_common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct LinParams {
+    const __bf16* a;
+    const __bf16* w;
+    const float* bias;
+    const float* res;
+    void* out;
+    long long M;
+    int Cout, CoutP, out_ctot, out_coff, res_ctot, res_coff, act;
+    unsigned w_bytes;
+};
+
+// cache policy of the streamed operands (A panel loads, output stores): non-temporal, so that 1.3 GB of output passing through
+// the 4 MB L2 of an XCD does not evict the 1.2 MB of weights every workgroup re-reads
+constexpr int LIN_NT = 2;
+constexpr int LK = 256, LBM = 128, LROW = LK + 8;   // LDS row stride in bf16 elements: 528 B, conflict-free ds_read_b128
+
+// erf to ~1.5e-7 absolute (Abramowitz & Stegun 7.1.26): the GELU outputs of this kernel are rounded to bf16 (2^-9 relative), and
+// erff() costs more VALU time per chunk than the chunk's MFMAs
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float y = 1.0f - poly * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+
+// ---- bf16-out form (what the V2X-ViT engine calls): panels of 64 tokens (33 KB of LDS), 64 accumulator registers per wave ->
+// four workgroups = 16 waves per CU; a wave's W fragments come straight from L2 (two 16-byte loads per K-step, four steps of
+// prefetch), the epilogue rounds once to bf16, transposes 4 x 4 inside every lane quad (DPP) and stores 16 bytes per lane
+// (8 rows x 128 B per instruction: 5.3 TB/s on this pattern against 3.9 TB/s for the 4-byte stores of the raw MFMA layout,
+// tools/micro/hbm_bw.hip).
+//   wave w of 4: all 64 rows (two MFMA row tiles), columns 64 w + [0, 64) of the chunk (two tiles, interleaved pairs)
+// Measured on MI355X, 281 600 tokens (tools/lin16_bench.py): 256 -> 2304 (1.44 GB moved) 555 us, 256 -> 1280 350 us, 256 -> 256 80 us
+// = 2.5-3.7 TB/s of algorithmic bytes.  The time is close to (W-fragment phase) + (store phase): with the stores compiled out
+// the 2304-column layer takes 254 us (2.7 GB of W fragments from L2 = 10.8 TB/s of L2->CU traffic, MFMA pipe 60 % busy), the
+// stores alone take 245 us in tools/micro/hbm_bw.hip, and neither 128-token panels with two workgroups per CU, nor issuing the
+// stores of chunk i between the MFMAs of chunk i + 1 (the vector-memory counter is in order over loads AND stores: the next
+// W fragment cannot be consumed before the older stores are acknowledged), nor non-temporal hints changed the sum.  Next
+// step (not done): W tiles shared through LDS by an 8-wave workgroup to cut the L2->CU traffic four-fold.
+__global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams p) {
+    constexpr int BMO = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(lin_smem);        // [64][264]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * BMO;
+    const int rows = (int)((p.M - m0) < BMO ? (p.M - m0) : BMO);
+    const int nchunks = p.CoutP >> 8;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const unsigned voffB = (unsigned)((lh * p.CoutP + wave * 64 + li) * 16);
+    const unsigned step_stride = (unsigned)(2 * p.CoutP * 16);
+    u32x4 bf[4][2];
+    auto loadB = [&](u32x4 (&dst)[2], int ch, int s) {
+        const unsigned so = (unsigned)s * step_stride + (unsigned)ch * (256 * 16);
+        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffB, so, 0);
+        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffB + 32 * 16, so, 0);
+    };
+    loadB(bf[0], 0, 0);
+    loadB(bf[1], 0, 1);
+    loadB(bf[2], 0, 2);
+    loadB(bf[3], 0, 3);
+    {
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.a + m0 * LK), 0,
+                                                                            (unsigned)rows * (LK * 2), 0x00020000);
+        u32x4 va[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) va[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((tid + 256 * j) * 16), 0, LIN_NT);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 256 * j;
+            *reinterpret_cast<u32x4*>(As + (e >> 5) * LROW + (e & 31) * 8) = va[j];
+        }
+    }
+    __syncthreads();
+    const size_t obytes = (size_t)p.out_ctot * 2;
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)m0 * obytes, 0,
+                                                                          (unsigned)((size_t)rows * obytes), 0x00020000);
+    const __bf16* Ab = As + li * LROW + lh * 8;
+    const bool odd = li & 1, hi = li & 2;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+        const int chn = ch + 1 < nchunks ? ch + 1 : ch;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab + s * 16);
+            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + s * 16);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bf[s & 3][c]);
+                acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][c], 0, 0, 0);
+            }
+            if (s + 4 < 16) loadB(bf[s & 3], ch, s + 4);
+            else loadB(bf[s & 3], chn, s + 4 - 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: bias, activation, one rounding, 4 x 4 quad transposes, 16-byte stores (8 rows x 128 B per instruction)
+        const int n = ch * 256 + wave * 64 + 2 * li;
+        float b0 = 0.f, b1 = 0.f;
+        if (p.bias && n < p.Cout) { b0 = p.bias[n]; b1 = p.bias[n + 1]; }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        int ostride = p.out_ctot * 2;
+        asm volatile("" : "+s"(ostride));
+        const int nq = ch * 256 + wave * 64 + 2 * (li & ~3);
+        const unsigned off0 = nq < p.Cout ? (unsigned)((4 * lh + (li & 3)) * ostride + (p.out_coff + nq) * 2) : 0x80000000u;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned R[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    f32x2 v = {acc[a][0][r] + b0, acc[a][1][r] + b1};
+                    if (p.act == 1) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    } else if (p.act == 2) {
+                        v[0] = 0.5f * v[0] * (1.0f + erf_as(v[0] * 0.70710678118654752f));
+                        v[1] = 0.5f * v[1] * (1.0f + erf_as(v[1] * 0.70710678118654752f));
+                    }
+                    R[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned send = odd ? R[2 * m] : R[2 * m + 1];
+                    const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);
+                    R[2 * m] = odd ? got : R[2 * m];
+                    R[2 * m + 1] = odd ? R[2 * m + 1] : got;
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned send = hi ? R[m] : R[m + 2];
+                    const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);
+                    R[m] = hi ? got : R[m];
+                    R[m + 2] = hi ? R[m + 2] : got;
+                }
+                const u32x4 v4 = {R[0], R[1], R[2], R[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(v4, rout, off0 + (unsigned)((a * 32 + 8 * g) * ostride), 0, LIN_NT);
+            }
+    }
+}
+
+template <bool OUT16>
+__global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const LinParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(lin_smem);        // [128][264]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * LBM;
+    const int rows = (int)((p.M - m0) < LBM ? (p.M - m0) : LBM);
+    const int nchunks = p.CoutP >> 8;
+
+    // ---- weights: packed column of tile c of this wave in chunk ch = 256 ch + 64 wave + 32 c + li; k-oct 2 s + lh
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const unsigned voffB = (unsigned)((lh * p.CoutP + wave * 64 + li) * 16);
+    const unsigned step_stride = (unsigned)(2 * p.CoutP * 16);
+    u32x4 bf[4][2];   // four K-steps in flight (16 steps per chunk: the rotation phase is the same in every chunk)
+    auto loadB = [&](u32x4 (&dst)[2], int ch, int s) {
+        const unsigned so = (unsigned)s * step_stride + (unsigned)ch * (256 * 16);
+        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffB, so, 0);
+        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffB + 32 * 16, so, 0);
+    };
+    loadB(bf[0], 0, 0);
+    loadB(bf[1], 0, 1);
+    loadB(bf[2], 0, 2);
+    loadB(bf[3], 0, 3);
+
+    // ---- A panel: 128 rows x 512 B = 4096 16-byte pieces, 16 per thread, all in flight together
+    {
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.a + m0 * LK), 0,
+                                                                            (unsigned)rows * (LK * 2), 0x00020000);
+        u32x4 va[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = tid + 256 * j;
+            va[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)(e * 16), 0, 0);   // rows beyond M: zero
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = tid + 256 * j;
+            *reinterpret_cast<u32x4*>(As + (e >> 5) * LROW + (e & 31) * 8) = va[j];
+        }
+    }
+    __syncthreads();
+
+    // output / residual rows of this panel: [0, rows) x row stride bytes
+    const size_t obytes = (size_t)p.out_ctot * (OUT16 ? 2 : 4);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.out) + (size_t)m0 * obytes, 0,
+                                                                          (unsigned)((size_t)rows * obytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.res ? p.res + (size_t)m0 * p.res_ctot : nullptr), 0, p.res ? (unsigned)((size_t)rows * p.res_ctot * 4) : 0u, 0x00020000);
+    const __bf16* Ab = As + li * LROW + lh * 8;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+        const int chn = ch + 1 < nchunks ? ch + 1 : ch;   // prefetch target beyond the last chunk: a harmless re-read
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            bf16x8 fa[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(Ab + a * 32 * LROW + s * 16);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bf[s & 3][c]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb, acc[a][c], 0, 0, 0);
+            }
+            if (s + 4 < 16) loadB(bf[s & 3], ch, s + 4);
+            else loadB(bf[s & 3], chn, s + 4 - 16);
+            __builtin_amdgcn_sched_barrier(0);   // keeps the A fragments / B prefetches of later steps from being hoisted (registers)
+        }
+        // ---- epilogue of the chunk: bias, activation, residual, two consecutive columns per lane.  Row addressing is 32-bit
+        // (buffer resources based at the panel's first row) with strides made opaque per chunk: otherwise the row offsets
+        // of output and residual are hoisted out of the chunk loop as 64-bit pointers and spilled
+        const int n = ch * 256 + wave * 64 + 2 * li;
+        if (n < p.Cout) {
+            float b0 = 0.f, b1 = 0.f;
+            if (p.bias) { b0 = p.bias[n]; b1 = p.bias[n + 1]; }
+            int ostride = p.out_ctot * (OUT16 ? 2 : 4), rstride = p.res_ctot * 4;
+            asm volatile("" : "+s"(ostride), "+s"(rstride));
+            const int row0 = 4 * lh;
+            const unsigned ocol = (unsigned)((p.out_coff + n) * (OUT16 ? 2 : 4)), rcol = (unsigned)((p.res_coff + n) * 4);
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = row0 + a * 32 + (r & 3) + 8 * (r >> 2);
+                    f32x2 v = {acc[a][0][r] + b0, acc[a][1][r] + b1};
+                    if (p.act == 1) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    } else if (p.act == 2) {   // GELU (nn.GELU(): 0.5 x (1 + erf(x / sqrt 2)))
+                        if (OUT16) {
+                            v[0] = 0.5f * v[0] * (1.0f + erf_as(v[0] * 0.70710678118654752f));
+                            v[1] = 0.5f * v[1] * (1.0f + erf_as(v[1] * 0.70710678118654752f));
+                        } else {
+                            v[0] = 0.5f * v[0] * (1.0f + erff(v[0] * 0.70710678118654752f));
+                            v[1] = 0.5f * v[1] * (1.0f + erff(v[1] * 0.70710678118654752f));
+                        }
+                    }
+                    // rows beyond M: the buffer range ends at the last valid row, loads return zero and stores are dropped
+                    if (p.res) v += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, (unsigned)(ml * rstride) + rcol, 0, 0));
+                    if (OUT16)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)), rout,
+                                                              (unsigned)(ml * ostride) + ocol, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rout, (unsigned)(ml * ostride) + ocol, 0, 0);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four rows of residual loads in flight (registers)
+                }
+        }
+    }
+}
+
+// one wave per token, C = 256: the lane's four channels
+// ADD: x += delta first (delta = the bf16 output of the preceding Linear: `x + fn(x)` of PreNormResidual under autocast adds a
+// 16-bit Linear output to the fp32 stream), x written back; y == nullptr: only the add
+template <bool ADD>
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(float4* __restrict__ x, const __bf16* __restrict__ delta,
+                                                             const float4* __restrict__ gamma,
+                                                             const float4* __restrict__ beta, __bf16* __restrict__ y,
+                                                             long long n_tokens, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tokens) return;
+    constexpr int C = 256;
+    float4 v = x[(size_t)tok * (C / 4) + lane];
+    if (ADD) {
+        const uint2 u = *reinterpret_cast<const uint2*>(delta + (size_t)tok * C + 4 * lane);
+        v.x += __builtin_bit_cast(float, u.x << 16); v.y += __builtin_bit_cast(float, u.x & 0xffff0000u);
+        v.z += __builtin_bit_cast(float, u.y << 16); v.w += __builtin_bit_cast(float, u.y & 0xffff0000u);
+        x[(size_t)tok * (C / 4) + lane] = v;
+        if (!y) return;
+    }
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    float q = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    const float4 g = gamma[lane], bt = beta[lane];
+    const f32x4 r = {a * rstd * g.x + bt.x, b * rstd * g.y + bt.y, c * rstd * g.z + bt.z, d * rstd * g.w + bt.w};
+    *reinterpret_cast<bf16x4*>(y + (size_t)tok * C + 4 * lane) = __builtin_convertvector(r, bf16x4);
+}
+
+}  // namespace
+
+extern "C" int av2x_linear_bf16(const uint16_t* a, const uint16_t* w_packed, const float* bias, const float* residual, void* out,
+                                int64_t m, int32_t k, int32_t cout, int32_t coutp, int32_t out_is_bf16, int32_t out_ctot,
+                                int32_t out_coff, int32_t res_ctot, int32_t res_coff, int32_t act, av2x_stream_t stream) {
+    if (m == 0) return 0;
+    if (!a || !w_packed || !out) return av2x::fail("av2x_linear_bf16: null argument");
+    if (k != LK) return av2x::fail("av2x_linear_bf16: k=%d unsupported (256)", k);
+    if (m < 0 || coutp <= 0 || coutp % 256 || cout <= 0 || cout > coutp || cout % 2)
+        return av2x::fail("av2x_linear_bf16: bad sizes (m=%lld cout=%d coutp=%d: coutp must be a multiple of 256, cout of 2)", (long long)m, cout, coutp);
+    if (out_ctot % 2 || out_coff % 2 || out_coff + cout > out_ctot) return av2x::fail("av2x_linear_bf16: bad output slice");
+    if (residual && (res_ctot % 2 || res_coff % 2 || res_coff + cout > res_ctot)) return av2x::fail("av2x_linear_bf16: bad residual slice");
+    if (act < 0 || act > 2) return av2x::fail("av2x_linear_bf16: act=%d unsupported (0 none, 1 ReLU, 2 GELU)", act);
+    if (residual && out_is_bf16) return av2x::fail("av2x_linear_bf16: the residual stream is fp32");
+    if (out_is_bf16 && (cout % 8 || out_ctot % 8 || out_coff % 8))
+        return av2x::fail("av2x_linear_bf16: bf16 output needs cout, out_ctot and out_coff to be multiples of 8 (16-byte row stores)");
+    LinParams p;
+    p.a = reinterpret_cast<const __bf16*>(a);
+    p.w = reinterpret_cast<const __bf16*>(w_packed);
+    p.bias = bias; p.res = residual; p.out = out; p.M = m;
+    p.Cout = cout; p.CoutP = coutp; p.out_ctot = out_ctot; p.out_coff = out_coff; p.res_ctot = res_ctot; p.res_coff = res_coff; p.act = act;
+    p.w_bytes = (unsigned)((size_t)(LK / 8) * coutp * 16);
+    const size_t lds = (size_t)LBM * LROW * 2;
+    const unsigned grid = (unsigned)((m + LBM - 1) / LBM);
+    hipStream_t st = av2x::as_stream(stream);
+    if (out_is_bf16) {
+        hipLaunchKernelGGL(linear_bf16_occ_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), (size_t)64 * LROW * 2, st, p);
+    } else {
+        static av2x::LdsLimit lim;
+        lim.ensure(reinterpret_cast<const void*>(&linear_bf16_kernel<false>), lds);
+        hipLaunchKernelGGL(linear_bf16_kernel<false>, dim3(grid), dim3(256), lds, st, p);
+    }
+    return av2x::check_launch("linear_bf16_kernel");
+}
+
+extern "C" int av2x_add_layernorm_bf16(float* x, const uint16_t* delta, const float* gamma, const float* beta, uint16_t* y,
+                                       int64_t n_tokens, int32_t c, float eps, av2x_stream_t stream) {
+    if (n_tokens == 0) return 0;
+    if (!x || (!delta && !y)) return av2x::fail("av2x_add_layernorm_bf16: null argument");
+    if (y && (!gamma || !beta)) return av2x::fail("av2x_add_layernorm_bf16: gamma / beta are required with y");
+    if (c != 256) return av2x::fail("av2x_add_layernorm_bf16: c=%d unsupported (256)", c);
+    if (n_tokens < 0) return av2x::fail("av2x_add_layernorm_bf16: bad token count");
+    const dim3 grid((unsigned)((n_tokens + 3) / 4)), block(256);
+    hipStream_t st = av2x::as_stream(stream);
+    auto X = reinterpret_cast<float4*>(x);
+    auto G = reinterpret_cast<const float4*>(gamma);
+    auto Bt = reinterpret_cast<const float4*>(beta);
+    auto Y = reinterpret_cast<__bf16*>(y);
+    if (delta) hipLaunchKernelGGL(layernorm_bf16_kernel<true>, grid, block, 0, st, X, reinterpret_cast<const __bf16*>(delta), G, Bt, Y, (long long)n_tokens, eps);
+    else hipLaunchKernelGGL(layernorm_bf16_kernel<false>, grid, block, 0, st, X, (const __bf16*)nullptr, G, Bt, Y, (long long)n_tokens, eps);
+    return av2x::check_launch("layernorm_bf16_kernel");
+}
+
+extern "C" int av2x_layernorm_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y, int64_t n_tokens, int32_t c,
+                                   float eps, av2x_stream_t stream) {
+    if (n_tokens && !y) return av2x::fail("av2x_layernorm_bf16: null argument");
+    return av2x_add_layernorm_bf16(const_cast<float*>(x), nullptr, gamma, beta, y, n_tokens, c, eps, stream);
+}

@@ -15,6 +15,26 @@
 
 namespace {
 
+// ---- element access for fp32 and bf16 (AMP mode: bf16 activations in HBM, arithmetic in fp32) buffers
+__device__ __forceinline__ float bf16_bits_to_float(unsigned hi16) { return __builtin_bit_cast(float, hi16); }
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<__bf16>(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_bits_to_float(u.x << 16), bf16_bits_to_float(u.x & 0xffff0000u), bf16_bits_to_float(u.y << 16),
+                       bf16_bits_to_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
+typedef __bf16 v2x_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float v2x_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {   // round-to-nearest-even
+    const v2x_f32x4 f = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<v2x_bf16x4*>(p) = __builtin_convertvector(f, v2x_bf16x4);
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+
 // torch.linspace(-1, 1, n)[i] as ATen computes it (symmetric halves)
 __device__ __forceinline__ float lin_m1_1(int i, int n) {
     if (n <= 1) return -1.0f;
@@ -93,17 +113,19 @@ __global__ void add_agent_vector_kernel(float4* __restrict__ x, const float4* __
 }
 
 // proj row layout (1280 floats): [q'(.->type0) | q'(.->type1) | k | v'(type0<-.) | v'(type1<-.)], 8 heads x 32 each
+template <typename T>
 struct HgtParams {
-    const float* proj;   // (n, HW, 1280)
+    const T* proj;       // (n, HW, 1280)
     const float* mask;   // (n, HW) com_mask of the KEY agent at the pixel
-    float* out;          // (n, HW, 256)
+    T* out;              // (n, HW, 256)
     int n, hw;
     int nq;              // query agents 0 .. nq-1 are computed (nq = n, or 1 when only the ego's output is consumed)
     int types[32];
     float scale;
 };
 
-__global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtParams p) {
+template <typename T>
+__global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtParams<T> p) {
     const int lane = threadIdx.x & 63;
     const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= p.hw) return;
@@ -111,20 +133,20 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtParams p) {
     constexpr int PC = 1280;
     for (int i = 0; i < p.nq; ++i) {
         const int ti = p.types[i];
-        const float* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
-        const float4 q0 = *reinterpret_cast<const float4*>(qi + col);         // keys of type 0
-        const float4 q1 = *reinterpret_cast<const float4*>(qi + 256 + col);   // keys of type 1
+        const T* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
+        const float4 q0 = ld4(qi + col);         // keys of type 0
+        const float4 q1 = ld4(qi + 256 + col);   // keys of type 1
         float m = -INFINITY, l = 0.f;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < p.n; ++j) {
             if (p.mask[(size_t)j * p.hw + pix] == 0.f) continue;   // masked_fill(mask == 0, -inf): exp(-inf) = 0
-            const float* kj = p.proj + ((size_t)j * p.hw + pix) * PC;
-            const float4 k = *reinterpret_cast<const float4*>(kj + 512 + col);
+            const T* kj = p.proj + ((size_t)j * p.hw + pix) * PC;
+            const float4 k = ld4(kj + 512 + col);
             const float4 q = p.types[j] ? q1 : q0;
             float s = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);   // 8 lanes = one head
             s *= p.scale;
-            const float4 v = *reinterpret_cast<const float4*>(kj + 768 + 256 * ti + col);
+            const float4 v = ld4(kj + 768 + 256 * ti + col);
             const float mn = fmaxf(m, s);
             const float alpha = expf(m - mn), pj = expf(s - mn);
             l = l * alpha + pj;
@@ -133,14 +155,14 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtParams p) {
             m = mn;
         }
         const float inv = 1.0f / l;
-        *reinterpret_cast<float4*>(p.out + ((size_t)i * p.hw + pix) * 256 + col) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+        st4(p.out + ((size_t)i * p.hw + pix) * 256 + col, make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv));
     }
 }
 
 // one thread per (token, head); qkv row = [q | k | v], each heads*DHD wide, at column offset `coff` of a `ctot` row
-template <int DHD, int WS>
-__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, int ctot, int coff,
-                                                          const float* __restrict__ pos, float* __restrict__ out,
+template <int DHD, int WS, typename T>
+__global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ qkv, int ctot, int coff,
+                                                          const float* __restrict__ pos, T* __restrict__ out,
                                                           int n, int H, int W, int heads, float scale) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n * H * W * heads;
@@ -152,11 +174,11 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
     const int y = pix / W, x = pix - y * W;
     const int wy0 = (y / WS) * WS, wx0 = (x / WS) * WS, iy = y - wy0, ixx = x - wx0;
     const int inner = heads * DHD;
-    const float* row = qkv + tok * ctot + coff + head * DHD;
+    const T* row = qkv + tok * ctot + coff + head * DHD;
     float q[DHD], o[DHD];
 #pragma unroll
     for (int d = 0; d < DHD; d += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(row + d);
+        const float4 v = ld4(row + d);
         q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
     }
     float s[WS * WS];
@@ -164,11 +186,11 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < WS * WS; ++j) {
         const int jy = j / WS, jx = j % WS;
-        const float* kr = qkv + ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + inner + head * DHD;
+        const T* kr = qkv + ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + inner + head * DHD;
         float acc = 0.f;
 #pragma unroll
         for (int d = 0; d < DHD; d += 4) {
-            const float4 k = *reinterpret_cast<const float4*>(kr + d);
+            const float4 k = ld4(kr + d);
             acc = fmaf(q[d], k.x, acc); acc = fmaf(q[d + 1], k.y, acc); acc = fmaf(q[d + 2], k.z, acc); acc = fmaf(q[d + 3], k.w, acc);
         }
         // dots * scale + pos_embedding[rel_y][rel_x], rel = idx[j] - idx[i] + ws - 1   (mswin.py:13-18, :77-80)
@@ -185,17 +207,17 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < WS * WS; ++j) {
         const int jy = j / WS, jx = j % WS;
-        const float* vr = qkv + ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + 2 * inner + head * DHD;
+        const T* vr = qkv + ((size_t)a * H * W + (size_t)(wy0 + jy) * W + (wx0 + jx)) * ctot + coff + 2 * inner + head * DHD;
         const float pj = s[j] * inv;
 #pragma unroll
         for (int d = 0; d < DHD; d += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(vr + d);
+            const float4 v = ld4(vr + d);
             o[d] = fmaf(pj, v.x, o[d]); o[d + 1] = fmaf(pj, v.y, o[d + 1]); o[d + 2] = fmaf(pj, v.z, o[d + 2]); o[d + 3] = fmaf(pj, v.w, o[d + 3]);
         }
     }
-    float* dst = out + tok * inner + head * DHD;
+    T* dst = out + tok * inner + head * DHD;
 #pragma unroll
-    for (int d = 0; d < DHD; d += 4) *reinterpret_cast<float4*>(dst + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
+    for (int d = 0; d < DHD; d += 4) st4(dst + d, make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]));
 }
 
 // MFMA form of the 4x4-window attention (T = 16 tokens): one wave per (window, head) task.
@@ -209,9 +231,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float* __restric
 //   O   = P V    : MFMA r uses A = P reg r, B = V[key (h, r)][n0 + l%16]; D reg r' of lane l = O[query (l/16, r')][n0 + l%16].
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int DH>
-__global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __restrict__ qkv, int ctot, int coff,
-                                                               const float* __restrict__ pos, float* __restrict__ out,
+template <int DH, typename T>
+__global__ __launch_bounds__(256) void window_attn_mfma_kernel(const T* __restrict__ qkv, int ctot, int coff,
+                                                               const float* __restrict__ pos, T* __restrict__ out,
                                                                int n, int H, int W, int heads, float scale) {
     constexpr int WS = 4, NB = DH / 16;
     const int lane = threadIdx.x & 63;
@@ -232,12 +254,12 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
         const int a = (int)(wdw / wy_n);
         const size_t pix0 = ((size_t)a * H + (size_t)wy * WS) * W + (size_t)wx * WS;
         // token t of the window: pixel (wy*4 + t/4, wx*4 + t%4)
-        const float* rowt = qkv + (pix0 + (size_t)(t >> 2) * W + (t & 3)) * ctot + coff + head * DH;
+        const T* rowt = qkv + (pix0 + (size_t)(t >> 2) * W + (t & 3)) * ctot + coff + head * DH;
         f32x4_t st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
-            const float4 qq = *reinterpret_cast<const float4*>(rowt + 4 * (h + 4 * g));
-            const float4 kk = *reinterpret_cast<const float4*>(rowt + inner + 4 * (h + 4 * g));
+            const float4 qq = ld4(rowt + 4 * (h + 4 * g));
+            const float4 kk = ld4(rowt + inner + 4 * (h + 4 * g));
             st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qq.x, st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qq.y, st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qq.z, st, 0, 0, 0);
@@ -255,16 +277,16 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
         // V rows of the keys (jy = h, jx = r)
-        const float* vrow = qkv + (pix0 + (size_t)h * W) * ctot + coff + 2 * inner + head * DH + t;
-        float* orow = out + (pix0 + (size_t)h * W) * inner + head * DH + t;   // query (iy = h, ix = r')
+        const T* vrow = qkv + (pix0 + (size_t)h * W) * ctot + coff + 2 * inner + head * DH + t;
+        T* orow = out + (pix0 + (size_t)h * W) * inner + head * DH + t;   // query (iy = h, ix = r')
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             f32x4_t o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, vrow[(size_t)r * ctot + nb * 16], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, ld1(vrow + (size_t)r * ctot + nb * 16), o, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) orow[(size_t)r * inner + nb * 16] = o[r];
+            for (int r = 0; r < 4; ++r) st1(orow + (size_t)r * inner + nb * 16, o[r]);
         }
     }
 }
@@ -274,8 +296,9 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* __re
 //   stage 2: grid (C/64, n): sum of the chunks in fixed order, / hw
 constexpr int GAP_CHUNKS = 128;
 
-__global__ __launch_bounds__(256) void gap3_stage1(const float* __restrict__ s0, const float* __restrict__ s1,
-                                                   const float* __restrict__ s2, float* __restrict__ partial, int hw, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void gap3_stage1(const T* __restrict__ s0, const T* __restrict__ s1,
+                                                   const T* __restrict__ s2, float* __restrict__ partial, int hw, int C) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, a = blockIdx.y, ch = blockIdx.z;
     const int per = (hw + GAP_CHUNKS - 1) / GAP_CHUNKS;
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(256) void gap3_stage1(const float* __restrict__ s0,
     float acc = 0.f;
     for (int p = p0 + g; p < p1; p += 4) {
         const size_t o = ((size_t)a * hw + p) * C + c;
-        acc += (s0[o] + s1[o]) + s2[o];
+        acc += (ld1(s0 + o) + ld1(s1 + o)) + ld1(s2 + o);
     }
     part[g][threadIdx.x & 63] = acc;
     __syncthreads();
@@ -299,7 +322,8 @@ __global__ void gap3_stage2(const float* __restrict__ partial, float* __restrict
     gap[(size_t)a * C + c] = acc / (float)hw;
 }
 
-__global__ void split_combine_kernel(const float4* __restrict__ s0, const float4* __restrict__ s1, const float4* __restrict__ s2,
+template <typename T>
+__global__ void split_combine_kernel(const T* __restrict__ s0, const T* __restrict__ s1, const T* __restrict__ s2,
                                      const float* __restrict__ logits, const float4* __restrict__ res, float4* __restrict__ out,
                                      size_t n4_per_agent, int C) {
     const int a = blockIdx.y;
@@ -317,7 +341,7 @@ __global__ void split_combine_kernel(const float4* __restrict__ s0, const float4
             w[0][e] = e0 * inv; w[1][e] = e1 * inv; w[2][e] = e2 * inv;
         }
         const size_t o = (size_t)a * n4_per_agent + i;
-        const float4 x0 = s0[o], x1 = s1[o], x2 = s2[o], r = res[o];
+        const float4 x0 = ld4(s0 + 4 * o), x1 = ld4(s1 + 4 * o), x2 = ld4(s2 + 4 * o), r = res[o];
         float4 y;
         y.x = ((x0.x * w[0][0] + x1.x * w[1][0]) + x2.x * w[2][0]) + r.x;
         y.y = ((x0.y * w[0][1] + x1.y * w[1][1]) + x2.y * w[2][1]) + r.y;
@@ -377,34 +401,44 @@ extern "C" int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_
     return av2x::check_launch("add_agent_vector_kernel");
 }
 
+template <typename T>
+static int hgt_launch(const T* proj, const float* mask, const int32_t* types_host, T* out, int32_t n, int32_t n_query, int32_t hw,
+                      int32_t heads, int32_t dim_head, av2x_stream_t stream) {
+    if (n_query < 1 || n_query > n) return av2x::fail("av2x_hgt_attention: n_query=%d outside 1..%d", n_query, n);
+    if (!proj || !mask || !types_host || !out) return av2x::fail("av2x_hgt_attention: null argument");
+    if (heads != 8 || dim_head != 32) return av2x::fail("av2x_hgt_attention: heads=%d dim_head=%d unsupported (8 x 32)", heads, dim_head);
+    if (n < 1 || n > 32 || hw <= 0) return av2x::fail("av2x_hgt_attention: bad sizes");
+    HgtParams<T> p;
+    p.proj = proj; p.mask = mask; p.out = out; p.n = n; p.hw = hw; p.nq = n_query;
+    for (int i = 0; i < 32; ++i) p.types[i] = i < n ? (types_host[i] != 0) : 0;
+    p.scale = 1.0f / sqrtf((float)dim_head);
+    hipLaunchKernelGGL(hgt_attention_kernel<T>, dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
+    return av2x::check_launch("hgt_attention_kernel");
+}
+
 extern "C" int av2x_hgt_attention_q(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
-                                    int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
+                                    int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
+    return hgt_launch<float>(proj, mask, types_host, out, n, n_query, hw, heads, dim_head, stream);
+}
+
+extern "C" int av2x_hgt_attention_bf16(const uint16_t* proj, const float* mask, const int32_t* types_host, uint16_t* out, int32_t n,
+                                       int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
+    return hgt_launch<__bf16>(reinterpret_cast<const __bf16*>(proj), mask, types_host, reinterpret_cast<__bf16*>(out), n, n_query, hw, heads,
+                              dim_head, stream);
+}
 
 extern "C" int av2x_hgt_attention(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
                                   int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
     return av2x_hgt_attention_q(proj, mask, types_host, out, n, n, hw, heads, dim_head, stream);
 }
 
-extern "C" int av2x_hgt_attention_q(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,
-                                    int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream) {
-    if (n_query < 1 || n_query > n) return av2x::fail("av2x_hgt_attention: n_query=%d outside 1..%d", n_query, n);
-    if (!proj || !mask || !types_host || !out) return av2x::fail("av2x_hgt_attention: null argument");
-    if (heads != 8 || dim_head != 32) return av2x::fail("av2x_hgt_attention: heads=%d dim_head=%d unsupported (8 x 32)", heads, dim_head);
-    if (n < 1 || n > 32 || hw <= 0) return av2x::fail("av2x_hgt_attention: bad sizes");
-    HgtParams p;
-    p.proj = proj; p.mask = mask; p.out = out; p.n = n; p.hw = hw; p.nq = n_query;
-    for (int i = 0; i < 32; ++i) p.types[i] = i < n ? (types_host[i] != 0) : 0;
-    p.scale = 1.0f / sqrtf((float)dim_head);
-    hipLaunchKernelGGL(hgt_attention_kernel, dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
-    return av2x::check_launch("hgt_attention_kernel");
-}
-
-extern "C" int av2x_window_attention(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, float* out,
-                                     int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
-                                     av2x_stream_t stream) {
+template <typename T>
+static int window_launch(const T* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, T* out, int32_t n, int32_t h, int32_t w,
+                         int32_t heads, int32_t dim_head, int32_t window, av2x_stream_t stream) {
     if (!qkv || !pos_embedding || !out) return av2x::fail("av2x_window_attention: null argument");
     if (h % (window & 0xff) || w % (window & 0xff))
         return av2x::fail("av2x_window_attention: map %dx%d not divisible by window %d", h, w, window & 0xff);
+    if (ctot % 4 || coff % 4) return av2x::fail("av2x_window_attention: ctot / coff must be multiples of 4");
     const bool force_valu = (window & 0x100) != 0;   // test hook: the scalar reference kernel
     window &= 0xff;
     const size_t total = (size_t)n * h * w * heads;
@@ -415,38 +449,74 @@ extern "C" int av2x_window_attention(const float* qkv, int32_t ctot, int32_t cof
     if (window == 4 && !force_valu && (dim_head == 32 || dim_head == 64)) {
         const long long tasks = (long long)n * (h / 4) * (w / 4) * heads;
         const unsigned wgs = (unsigned)((tasks + 3) / 4 < 256 * 16 ? (tasks + 3) / 4 : 256 * 16);
-        if (dim_head == 32) hipLaunchKernelGGL((window_attn_mfma_kernel<32>), dim3(wgs), block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
-        else hipLaunchKernelGGL((window_attn_mfma_kernel<64>), dim3(wgs), block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+        if (dim_head == 32) hipLaunchKernelGGL((window_attn_mfma_kernel<32, T>), dim3(wgs), block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+        else hipLaunchKernelGGL((window_attn_mfma_kernel<64, T>), dim3(wgs), block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
         return av2x::check_launch("window_attn_mfma_kernel");
     }
-    if (dim_head == 16 && window == 2) hipLaunchKernelGGL((window_attn_kernel<16, 2>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
-    else if (dim_head == 32 && window == 4) hipLaunchKernelGGL((window_attn_kernel<32, 4>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
-    else if (dim_head == 64 && window == 4) hipLaunchKernelGGL((window_attn_kernel<64, 4>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+    if (dim_head == 16 && window == 2) hipLaunchKernelGGL((window_attn_kernel<16, 2, T>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+    else if (dim_head == 32 && window == 4) hipLaunchKernelGGL((window_attn_kernel<32, 4, T>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
+    else if (dim_head == 64 && window == 4) hipLaunchKernelGGL((window_attn_kernel<64, 4, T>), grid, block, 0, st, qkv, ctot, coff, pos_embedding, out, n, h, w, heads, scale);
     else return av2x::fail("av2x_window_attention: (dim_head %d, window %d) unsupported: (16,2) (32,4) (64,4)", dim_head, window);
     return av2x::check_launch("window_attn_kernel");
 }
 
-extern "C" int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, float* scratch, int32_t n,
-                                   int32_t hw, int32_t c, av2x_stream_t stream) {
+extern "C" int av2x_window_attention(const float* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, float* out,
+                                     int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
+                                     av2x_stream_t stream) {
+    return window_launch<float>(qkv, ctot, coff, pos_embedding, out, n, h, w, heads, dim_head, window, stream);
+}
+
+extern "C" int av2x_window_attention_bf16(const uint16_t* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, uint16_t* out,
+                                          int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
+                                          av2x_stream_t stream) {
+    return window_launch<__bf16>(reinterpret_cast<const __bf16*>(qkv), ctot, coff, pos_embedding, reinterpret_cast<__bf16*>(out), n, h, w, heads,
+                                 dim_head, window, stream);
+}
+
+template <typename T>
+static int gap_launch(const T* s0, const T* s1, const T* s2, float* gap, float* scratch, int32_t n, int32_t hw, int32_t c,
+                      av2x_stream_t stream) {
     if (n == 0) return 0;
     if (!s0 || !s1 || !s2 || !gap || !scratch) return av2x::fail("av2x_split_attn_gap: null argument");
     if (c % 64) return av2x::fail("av2x_split_attn_gap: c must be a multiple of 64");
     hipStream_t st = av2x::as_stream(stream);
-    hipLaunchKernelGGL(gap3_stage1, dim3(c / 64, n, GAP_CHUNKS), dim3(256), 0, st, s0, s1, s2, scratch, hw, c);
+    hipLaunchKernelGGL(gap3_stage1<T>, dim3(c / 64, n, GAP_CHUNKS), dim3(256), 0, st, s0, s1, s2, scratch, hw, c);
     hipLaunchKernelGGL(gap3_stage2, dim3(c / 64, n), dim3(64), 0, st, scratch, gap, hw, c);
     return av2x::check_launch("gap3");
 }
 
-extern "C" int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,
-                                       const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+extern "C" int av2x_split_attn_gap(const float* s0, const float* s1, const float* s2, float* gap, float* scratch, int32_t n,
+                                   int32_t hw, int32_t c, av2x_stream_t stream) {
+    return gap_launch<float>(s0, s1, s2, gap, scratch, n, hw, c, stream);
+}
+
+extern "C" int av2x_split_attn_gap_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, float* gap, float* scratch,
+                                        int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+    return gap_launch<__bf16>(reinterpret_cast<const __bf16*>(s0), reinterpret_cast<const __bf16*>(s1), reinterpret_cast<const __bf16*>(s2), gap,
+                              scratch, n, hw, c, stream);
+}
+
+template <typename T>
+static int combine_launch(const T* s0, const T* s1, const T* s2, const float* logits, const float* residual, float* out, int32_t n,
+                          int32_t hw, int32_t c, av2x_stream_t stream) {
     if (n == 0) return 0;
     if (!s0 || !s1 || !s2 || !logits || !residual || !out) return av2x::fail("av2x_split_attn_combine: null argument");
     if (c % 4) return av2x::fail("av2x_split_attn_combine: c must be a multiple of 4");
     const size_t n4 = (size_t)hw * c / 4;
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)blocks, n), dim3(256), 0, av2x::as_stream(stream),
-                       reinterpret_cast<const float4*>(s0), reinterpret_cast<const float4*>(s1), reinterpret_cast<const float4*>(s2),
-                       logits, reinterpret_cast<const float4*>(residual), reinterpret_cast<float4*>(out), n4, c);
+    hipLaunchKernelGGL(split_combine_kernel<T>, dim3((unsigned)blocks, n), dim3(256), 0, av2x::as_stream(stream), s0, s1, s2, logits,
+                       reinterpret_cast<const float4*>(residual), reinterpret_cast<float4*>(out), n4, c);
     return av2x::check_launch("split_combine_kernel");
+}
+
+extern "C" int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,
+                                       const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+    return combine_launch<float>(s0, s1, s2, logits, residual, out, n, hw, c, stream);
+}
+
+extern "C" int av2x_split_attn_combine_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
+                                            const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
+    return combine_launch<__bf16>(reinterpret_cast<const __bf16*>(s0), reinterpret_cast<const __bf16*>(s1), reinterpret_cast<const __bf16*>(s2),
+                                  logits, residual, out, n, hw, c, stream);
 }

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .packing import fold_bn, pack_conv_weight, pack_deconv_weight, to_bf16_koct, to_bf16x3_koct
+from .packing import fold_bn, interleave2_columns, pack_conv_weight, pack_deconv_weight, to_bf16_koct, to_bf16x3_koct
 
 AGENT_TYPES = ("vehicle", "rsu", "drone")
 TYPE_PREFIX = {"vehicle": "veh_models", "rsu": "rsu_models", "drone": "drone_models"}
@@ -38,13 +38,14 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if hasattr(to
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
         self._w16 = None
         self._w3 = None
         self._wu = None
+        self._w16i = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
 
@@ -54,6 +55,13 @@ def _w16(L):
     if L._w16 is None:
         L._w16 = to_bf16_koct(L.w)
     return L._w16
+
+
+def _w16i(L):
+    """(bf16 k-oct packing with the columns interleaved for av2x_linear_bf16, padded column count), built on first use."""
+    if L._w16i is None:
+        L._w16i = interleave2_columns(_w16(L))
+    return L._w16i
 
 
 def _w3(L):
@@ -159,6 +167,7 @@ class Where2ComEngine:
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
+        self.profile_hbm = None     # list -> (kernel name, algorithmic HBM bytes, flops, ev0, ev1) per launch of an HBM-bound kernel
         self.agent_streams = 1      # >1 (B == 1): agents are split into this many groups that run the per-agent part
                                     # of the frame on separate HIP streams.  Measured: no gain, off by default
         self._streams = None
@@ -376,6 +385,16 @@ class Where2ComEngine:
         self.threshold = float(comm["threshold"] or 0.0)
 
     # ------------------------------------------------------------------ buffers
+    def timed_hbm(self, name, nbytes, flops, launch):
+        """Run ``launch()``; in the bench's roofline pass (profile_hbm is a list) bracket it with an event pair on the launch stream."""
+        if self.profile_hbm is None:
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self.profile_hbm.append((name, float(nbytes), float(flops), e0, e1))
+
     def buf(self, name, shape, dtype=torch.float32):
         key = (name, tuple(shape), dtype)
         t = self.ws.get(key)

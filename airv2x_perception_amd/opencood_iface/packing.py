@@ -60,6 +60,19 @@ def to_bf16_koct(packed):
     return t.to(torch.bfloat16).contiguous()
 
 
+def interleave2_columns(w16):
+    """bf16 k-oct packing (1, K/8, CoutP, 8) -> the column order av2x_linear_bf16 reads (csrc/linear_bf16.hip): CoutP padded
+    with zero columns to a multiple of 256, and inside every group of 64 columns packed column 32 c + i = logical column
+    2 i + c, so that an MFMA lane (i) owns the two consecutive logical columns 2 i, 2 i + 1 over its two tiles (c)."""
+    T, q, n, eight = w16.shape
+    assert T == 1 and eight == 8
+    npad = (n + 255) // 256 * 256
+    if npad != n:
+        w16 = torch.cat([w16, torch.zeros(T, q, npad - n, 8, dtype=w16.dtype, device=w16.device)], 2)
+    t = w16.reshape(T, q, npad // 64, 32, 2, 8).permute(0, 1, 2, 4, 3, 5)
+    return t.reshape(T, q, npad, 8).contiguous(), npad
+
+
 def to_bf16x3_koct(packed):
     """Split-3 packing for conv_igemm_bf16x3 (tile flag 0x0400): (3, T, Cin/8, CoutP, 8) bf16 planes hi / mid / lo with
     hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (each subtraction is exact in fp32), so hi + mid + lo = w to 2^-24."""

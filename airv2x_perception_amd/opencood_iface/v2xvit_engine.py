@@ -20,7 +20,7 @@ import torch
 
 from .. import _lib
 from . import warp as warp_host
-from .engine import ConvLayer, Where2ComEngine, _ptr
+from .engine import ConvLayer, Where2ComEngine, _ptr, _w16i
 from .packing import pack_conv_weight
 
 LN_EPS = 1e-5
@@ -162,6 +162,8 @@ class V2XViTEngine(Where2ComEngine):
             xs.copy_(x[:, :, c0:c0 + Wc])                                   # column strip (data movement only)
             ms.copy_(mask[:, :, c0:c0 + Wc])
             x, mask, W, hw = xs, ms, Wc, H * Wc
+        if self.amp and self.bf16_activations and self.enc["feed_forward"]["mlp_dim"] == 256:
+            return self._blocks_bf16(x, mask, n, H, W, types, world, trace)
         tarr = (c_int32 * n)(*types)
         xn = self.buf("vit_xn", (n, H, W, C))
         proj = self.buf("vit_proj", (n, H, W, 1280))
@@ -223,6 +225,115 @@ class V2XViTEngine(Where2ComEngine):
             self.conv(ffn["ff2"], hid, m, H, W, x, residual=x)
             if trace is not None:
                 trace[f"layer{di}"] = x.clone()
+        return x[0:1]
+
+    # AMP mode: the outputs of every Linear and of the attention products are stored as bf16 (what torch.autocast stores for
+    # nn.Linear / matmul; LayerNorm statistics, softmax, accumulators and the residual stream x stay fp32), on the token-panel
+    # GEMM of csrc/linear_bf16.hip.  These layers are HBM-bound (K = 256), so bytes are what the mode saves.
+    bf16_activations = True
+
+    def lin16(self, L, a16, m_rows, out, residual=None, out_ctot=None, out_coff=0):
+        """out = act(a16 (m_rows, 256) bf16 . W + b) (+ residual): ``out`` bf16 or fp32 (dtype decides)."""
+        w, coutp = _w16i(L)
+        octot = out_ctot if out_ctot is not None else L.cout
+        esz = 2 if out.dtype == torch.bfloat16 else 4
+        self.timed_hbm(f"linear_bf16 256->{L.cout}", m_rows * (L.cin * 2 + L.cout * esz + (L.cout * 4 if residual is not None else 0)) + w.numel() * 2,
+                       2.0 * m_rows * L.cin * L.cout,
+                       lambda: _lib.check(self.lib.av2x_linear_bf16(_ptr(a16), _ptr(w), _ptr(L.shift), _ptr(residual), _ptr(out), m_rows, L.cin,
+                                                                    L.cout, coutp, 1 if esz == 2 else 0, octot, out_coff,
+                                                                    L.cout if residual is not None else 0, 0, L.relu, self.stream()),
+                                          "av2x_linear_bf16"))
+
+    def _blocks_bf16(self, x, mask, n, H, W, types, world, trace):
+        """Every Linear writes bf16 (as under autocast); the residual adds `x + fn(x)` of the fp32 stream are folded into the NEXT
+        LayerNorm pass (av2x_add_layernorm_bf16: one read-modify-write of x instead of one in the Linear's epilogue and a read
+        in the LayerNorm), the last one into a plain add."""
+        C, hw, st, bf = 256, H * W, self.stream, torch.bfloat16
+        tarr = (c_int32 * n)(*types)
+        xn = self.buf("vit16_xn", (n, H, W, C), bf)
+        proj = self.buf("vit16_proj", (n, H, W, 1280), bf)
+        att = self.buf("vit16_att", (n, H, W, C), bf)
+        qkv3 = self.buf("vit16_qkv3", (n, H, W, 2304), bf)
+        wat = self.buf("vit16_wat", (n, H, W, C), bf)
+        br = [self.buf(f"vit16_br{i}", (n, H, W, C), bf) for i in range(3)]
+        hid = self.buf("vit16_hid", (n, H, W, C), bf)
+        delta = self.buf("vit16_delta", (n, H, W, C), bf)
+        gap = self.buf("vit_gap", (n, 1, 1, C))
+        gap_scratch = self.buf("vit_gap_scratch", (n, 128, C))
+        g1 = self.buf("vit_g1", (n, 1, 1, C))
+        g2 = self.buf("vit_g2", (n, 1, 1, C))
+        logits = self.buf("vit_logits", (n, 1, 1, 3 * C))
+        groups = self._groups(types)
+        last = len(self.layers) - 1
+        pending = [0]            # agents 0 .. pending-1 of `delta` still have to be added to x
+
+        def add_ln(gb, m_tok_agents):
+            """x[:pending] += delta[:pending]; xn[:m] = LayerNorm(x[:m])"""
+            k = pending[0]
+            gp, bp = (_ptr(gb[0]), _ptr(gb[1])) if gb is not None else (c_void_p(0), c_void_p(0))
+            if k:
+                _lib.check(self.lib.av2x_add_layernorm_bf16(_ptr(x), _ptr(delta), gp, bp, _ptr(xn) if gb is not None else c_void_p(0),
+                                                            min(k, m_tok_agents) * hw, C, LN_EPS, st()), "av2x_add_layernorm_bf16")
+                if k > m_tok_agents:     # agents whose LayerNorm is not needed any more still receive their residual
+                    _lib.check(self.lib.av2x_add_layernorm_bf16(_ptr(x[m_tok_agents:k]), _ptr(delta[m_tok_agents:k]), c_void_p(0), c_void_p(0),
+                                                                c_void_p(0), (k - m_tok_agents) * hw, C, LN_EPS, st()), "av2x_add_layernorm_bf16")
+            if gb is not None and m_tok_agents > k:
+                _lib.check(self.lib.av2x_add_layernorm_bf16(_ptr(x[k:m_tok_agents]), c_void_p(0), gp, bp, _ptr(xn[k:m_tok_agents]),
+                                                            (m_tok_agents - k) * hw, C, LN_EPS, st()), "av2x_add_layernorm_bf16")
+            pending[0] = 0
+
+        for di, (blocks, ffn) in enumerate(self.layers):
+            for bi, blk in enumerate(blocks):
+                ego_only = self.ego_only_last and di == last and bi == len(blocks) - 1 and trace is None and n > 1
+                # ---- x = HGT(LN(x)) + x
+                add_ln(blk["ln1"], n)
+                if ego_only:
+                    self.lin16(blk["proj"][types[0]], xn[0:1], hw, proj[0:1])
+                    for (a, b, t) in self._groups(types[1:]):
+                        self.lin16(blk["proj_kv"][t], xn[a + 1:b + 1], (b - a) * hw, proj[a + 1:b + 1], out_ctot=1280, out_coff=512)
+                else:
+                    for (a, b, t) in groups:
+                        self.lin16(blk["proj"][t], xn[a:b], (b - a) * hw, proj[a:b])
+                m = 1 if ego_only else n
+                self.timed_hbm("hgt_attention_bf16", hw * 2 * (m * 512 + n * (256 + 256 * len(set(types[:m]))) + m * 256), 4.0 * m * n * hw * 256,
+                               lambda: _lib.check(self.lib.av2x_hgt_attention_bf16(_ptr(proj), _ptr(mask), ctypes.cast(tarr, c_void_p), _ptr(att), n, m,
+                                                                                   hw, self.cav["heads"], self.cav["dim_head"], st()),
+                                                  "av2x_hgt_attention_bf16"))
+                for (a, b, t) in (self._groups(types[:1]) if ego_only else groups):
+                    self.lin16(blk["aout"][t], att[a:b], (b - a) * hw, delta[a:b])
+                pending[0] = m
+                if trace is not None:
+                    add_ln(None, 0)
+                    trace[f"hgt{di}"] = x.clone()
+                # ---- x = SplitAttn(window attentions(LN(x))) + x
+                add_ln(blk["ln2"], m)
+                self.lin16(blk["qkv3"], xn, m * hw, qkv3)
+                for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
+                    self.timed_hbm(f"window_attention_bf16 ws{ws} dh{dh}", m * hw * 2 * (768 + 256), 4.0 * m * hw * ws * ws * 256,
+                                   lambda: _lib.check(self.lib.av2x_window_attention_bf16(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat),
+                                                                                          m, H, W, h, dh, ws, st()), "av2x_window_attention_bf16"))
+                    self.lin16(blk["wout"][i], wat, m * hw, br[i])
+                _lib.check(self.lib.av2x_split_attn_gap_bf16(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(gap), _ptr(gap_scratch), m, hw, C,
+                                                             st()), "gap")
+                if world > 1:
+                    (self.gap_exchange or self._gap_allreduce)(gap[:m], world, di * len(blocks) + bi)
+                if self.gap_record is not None:
+                    self.gap_record.append(gap[:m].clone())
+                self.conv(blk["fc1"], gap, m, 1, 1, g1)
+                self.ln(g1, blk["bn1"], g2, m, C, relu=1)
+                self.conv(blk["fc2"], g2, m, 1, 1, logits)
+                _lib.check(self.lib.av2x_split_attn_combine_bf16(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), _ptr(x), _ptr(x),
+                                                                 m, hw, C, st()), "combine")
+            # ---- x = FFN(LN(x)) + x
+            m = 1 if (self.ego_only_last and di == last and trace is None and n > 1) else n
+            add_ln(ffn["ln"], m)
+            self.lin16(ffn["ff1"], xn, m * hw, hid)
+            self.lin16(ffn["ff2"], hid, m * hw, delta)
+            pending[0] = m
+            if trace is not None:
+                add_ln(None, 0)
+                trace[f"layer{di}"] = x.clone()
+        add_ln(None, 0)
         return x[0:1]
 
     shard_group = None

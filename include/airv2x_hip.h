@@ -641,6 +641,40 @@ int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, c
                             const float* residual, float* out, int32_t n, int32_t hw, int32_t c,
                             av2x_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * V2X-ViT fusion with bf16 ACTIVATIONS in HBM (AMP mode of BASELINE configs[3]: what torch.autocast stores for the outputs
+ * of nn.Linear / matmul -- reference tools/train.py:118, tools/inference.py under autocast; LayerNorm, softmax statistics,
+ * the accumulators and the residual stream x stay fp32).  bf16 buffers are passed as uint16_t* (the upper 16 bits of the
+ * fp32 pattern, round-to-nearest-even).  Same semantics as the fp32 entry points above unless stated.
+ * av2x_layernorm_bf16: nn.LayerNorm over c = 256 of fp32 x -> bf16 y.
+ * av2x_linear_bf16: out (m, cout) = act(a (m, k) . W + bias) (+ residual): a bf16 row-major, k = 256; w_packed = the bf16
+ *   k-oct packing [k/8][coutp][8] (coutp % 256 == 0, zero columns beyond cout) whose columns are interleaved inside every
+ *   group of 64: packed column 32 c + i holds logical column 2 i + c (opencood_iface/packing.py: interleave2_columns);
+ *   bias (cout,) fp32 or NULL; out: bf16 if out_is_bf16 else fp32, slice [out_coff, out_coff + cout) of rows of out_ctot
+ *   elements; residual: fp32 slice (fp32 output only) or NULL; act 0 none / 1 ReLU / 2 GELU (erf form); cout, slices: multiples of 8 (bf16 out: 16-byte row stores) / 2 (fp32 out).
+ *   One workgroup per panel of 128 tokens: A is read from HBM once whatever cout is.
+ * av2x_hgt_attention_bf16 / av2x_window_attention_bf16: proj / qkv and out are bf16; mask, pos_embedding fp32.
+ * av2x_split_attn_gap_bf16 / _combine_bf16: the three branch maps are bf16; gap, logits, residual and out fp32.
+ * ------------------------------------------------------------------------------------ */
+int av2x_layernorm_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y, int64_t n_tokens, int32_t c,
+                        float eps, av2x_stream_t stream);
+/* x += delta (bf16: the output of the preceding Linear -- `x + fn(x)` of PreNormResidual, base_transformer.py:12, under autocast adds
+ * a 16-bit Linear output to the fp32 stream), x written back, then y = LayerNorm(x) as above.  delta NULL: no add; y NULL: only the add. */
+int av2x_add_layernorm_bf16(float* x, const uint16_t* delta, const float* gamma, const float* beta, uint16_t* y, int64_t n_tokens,
+                            int32_t c, float eps, av2x_stream_t stream);
+int av2x_linear_bf16(const uint16_t* a, const uint16_t* w_packed, const float* bias, const float* residual, void* out,
+                     int64_t m, int32_t k, int32_t cout, int32_t coutp, int32_t out_is_bf16, int32_t out_ctot,
+                     int32_t out_coff, int32_t res_ctot, int32_t res_coff, int32_t act, av2x_stream_t stream);
+int av2x_hgt_attention_bf16(const uint16_t* proj, const float* mask, const int32_t* types_host, uint16_t* out, int32_t n,
+                            int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
+int av2x_window_attention_bf16(const uint16_t* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, uint16_t* out,
+                               int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
+                               av2x_stream_t stream);
+int av2x_split_attn_gap_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, float* gap,
+                             float* scratch /* n*128*c floats */, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
+int av2x_split_attn_combine_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
+                                 const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
+
 /* The reference replaces an EMPTY cloud by two dummy points before voxelising (sp_voxel_preprocessor.py:80-90).
  * av2x_voxelize_dummy_if_empty does the same on the device after av2x_voxelize / av2x_prepare_voxelize: if *n_voxels == 0
  * the two dummy points are voxelised into rows 0.. of the (zeroed) outputs and *n_voxels is updated; otherwise nothing

@@ -1,0 +1,219 @@
+"""GPU: the bf16-ACTIVATION entry points of the V2X-ViT fusion in AMP mode (csrc/linear_bf16.hip, the bf16 instantiations of
+csrc/v2xvit.hip; BASELINE configs[3] = V2X-ViT under autocast).
+
+torch.autocast stores the outputs of nn.Linear / matmul as 16-bit tensors and keeps LayerNorm, softmax and `x + fn(x)` in fp32
+(reference tools/train.py:118).  Here:
+* av2x_linear_bf16 == an fp32 GEMM of the SAME bf16 operands (exact products, fp32 sums), bias / GELU / residual in fp32, result
+  rounded once to bf16 (or kept fp32 with the fp32 residual);
+* av2x_layernorm_bf16 == F.layer_norm in fp32, rounded once;
+* the attention / split-attention kernels are the fp32 kernels instantiated on bf16 storage: on bf16-representable inputs their
+  outputs equal the fp32 kernels' outputs rounded once (same arithmetic, same order) -- asserted BIT FOR BIT;
+* the V2X-ViT encoder in bf16-activation mode against the fp32-activation AMP mode and the fp32 reference golden (drift bound of
+  tests/test_amp.py).
+"""
+import ctypes
+from ctypes import c_int32, c_void_p
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import assert_close, load_fixture
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _st():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _pack(wt):
+    from airv2x_perception_amd.opencood_iface.packing import interleave2_columns, pack_conv_weight, to_bf16_koct
+    wp, _ = pack_conv_weight(wt.view(wt.shape[0], wt.shape[1], 1, 1))
+    return interleave2_columns(to_bf16_koct(wp))
+
+
+@pytest.mark.parametrize("m,cout,act,res,out16,ctot,coff", [
+    (300, 1280, 0, False, True, 1280, 0),      # HGT projection; m not a multiple of the 128-token panel
+    (517, 768, 0, False, True, 1280, 512),     # proj_kv: the k | v' columns of the last layer, written into the 1280-wide rows
+    (1000, 2304, 0, False, True, 2304, 0),     # three window-attention QKVs
+    (129, 256, 2, False, True, 256, 0),        # FFN first layer: GELU
+    (640, 256, 0, True, False, 256, 0),        # a_linears / FFN second layer: fp32 out + fp32 residual (in place)
+    (77, 256, 1, False, False, 256, 0),
+    (256, 104, 0, False, True, 104, 0),        # cout not a multiple of 128: zero-padded columns are never stored
+])
+def test_linear_bf16_equals_fp32_gemm_of_the_same_operands(m, cout, act, res, out16, ctot, coff):
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = _g(m + cout)
+    a = (torch.randn(m, 256, generator=g) * 1.5).to(BF)
+    wt = (torch.randn(cout, 256, generator=g) / 16).to(BF).float()
+    b = torch.randn(cout, generator=g) * 0.2
+    r = torch.randn(m, cout, generator=g) if res else None
+    ref = a.double() @ wt.double().t() + b.double()
+    if act == 1:
+        ref = ref.clamp_min(0)
+    elif act == 2:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    w16, coutp = _pack(wt)
+    assert coutp % 256 == 0
+    ad, wd, bd = a.cuda(), w16.cuda(), b.cuda()
+    if res:
+        out = r.cuda().clone()            # in place: out == residual buffer, as the engine calls it
+        rd = out
+    else:
+        out = torch.full((m, ctot), 7.0, device="cuda").to(BF if out16 else torch.float32)
+        rd = None
+    _lib.check(lib.av2x_linear_bf16(_p(ad), _p(wd), _p(bd), _p(rd), _p(out), m, 256, cout, coutp, 1 if out16 else 0, ctot, coff,
+                                    cout if res else 0, 0, act, _st()), "av2x_linear_bf16")
+    got = out.float().cpu()
+    if out16:
+        # one rounding to bf16 of a value that agrees with the float64 result to fp32 accumulation noise: within one bf16 ulp
+        want = ref.float()
+        err = (got[:, coff:coff + cout] - want).abs()
+        tol = want.abs() * 2.0 ** -8 + 1e-6
+        assert bool((err <= tol).all()), f"max err {float(err.max()):.3e}"
+        exact = (got[:, coff:coff + cout] == want.to(BF).float()).float().mean()
+        assert float(exact) > 0.98, f"only {float(exact):.4f} of the outputs are the correctly rounded value"
+        if ctot > cout:      # columns outside the slice are untouched
+            mask = torch.ones(ctot, dtype=torch.bool)
+            mask[coff:coff + cout] = False
+            assert bool((got[:, mask] == 7.0).all())
+    else:
+        assert_close(got.numpy(), ref.float().numpy(), 2e-5, 2e-5, "linear fp32 out")
+
+
+def test_layernorm_bf16():
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = _g(3)
+    x = torch.randn(1001, 256, generator=g) * 3 + 0.5
+    gm, bt = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    xd, gd, bd = x.cuda(), gm.cuda(), bt.cuda()
+    y = torch.zeros(1001, 256, device="cuda", dtype=BF)
+    _lib.check(lib.av2x_layernorm_bf16(_p(xd), _p(gd), _p(bd), _p(y), 1001, 256, 1e-5, _st()), "ln")
+    y32 = torch.empty(1001, 256, device="cuda")
+    _lib.check(lib.av2x_layernorm(_p(xd), _p(gd), _p(bd), _p(y32), 1001, 256, 1e-5, _st()), "ln")
+    assert torch.equal(y, y32.to(BF))                       # the fp32 kernel's value, rounded once
+    assert_close(y32.cpu().numpy(), F.layer_norm(x, (256,), gm, bt, 1e-5).numpy(), 1e-5, 1e-5, "layernorm")
+
+
+def test_add_layernorm_bf16():
+    """x += delta (bf16 Linear output), x written back, y = LayerNorm(x); delta NULL / y NULL forms."""
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = _g(4)
+    n = 777
+    x = torch.randn(n, 256, generator=g) * 2
+    d = torch.randn(n, 256, generator=g).to(BF)
+    gm, bt = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    xd, dd, gd, bd = x.cuda(), d.cuda(), gm.cuda(), bt.cuda()
+    y = torch.zeros(n, 256, device="cuda", dtype=BF)
+    _lib.check(lib.av2x_add_layernorm_bf16(_p(xd), _p(dd), _p(gd), _p(bd), _p(y), n, 256, 1e-5, _st()), "add_ln")
+    xs = x + d.float()
+    assert torch.equal(xd.cpu(), xs)                         # one fp32 add per element
+    y32 = torch.empty(n, 256, device="cuda")
+    xs_d = xs.cuda()
+    _lib.check(lib.av2x_layernorm(_p(xs_d), _p(gd), _p(bd), _p(y32), n, 256, 1e-5, _st()), "ln")
+    assert torch.equal(y, y32.to(BF))
+    x2 = x.cuda()
+    _lib.check(lib.av2x_add_layernorm_bf16(_p(x2), _p(dd), None, None, None, n, 256, 1e-5, _st()), "add only")
+    assert torch.equal(x2.cpu(), xs)
+
+
+def test_hgt_attention_bf16_is_the_fp32_kernel_on_bf16_storage():
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    n, hw = 5, 333
+    g = _g(11)
+    proj = (torch.randn(n, hw, 1280, generator=g)).to(BF).cuda()
+    mask = (torch.rand(n, hw, generator=g) > 0.3).float()
+    mask[0] = 1.0
+    mask = mask.cuda()
+    types = (c_int32 * n)(0, 1, 0, 1, 1)
+    for nq in (n, 1):
+        o16 = torch.zeros(n, hw, 256, device="cuda", dtype=BF)
+        o32 = torch.zeros(n, hw, 256, device="cuda")
+        p32 = proj.float()
+        _lib.check(lib.av2x_hgt_attention_bf16(_p(proj), _p(mask), ctypes.cast(types, c_void_p), _p(o16), n, nq, hw, 8, 32, _st()), "hgt16")
+        _lib.check(lib.av2x_hgt_attention_q(_p(p32), _p(mask), ctypes.cast(types, c_void_p), _p(o32), n, nq, hw, 8, 32, _st()), "hgt32")
+        assert torch.equal(o16[:nq], o32[:nq].to(BF))
+
+
+@pytest.mark.parametrize("heads,dh,ws,coff", [(16, 16, 2, 0), (8, 32, 4, 768), (4, 64, 4, 1536), (8, 32, 4 | 0x100, 768)])
+def test_window_attention_bf16_is_the_fp32_kernel_on_bf16_storage(heads, dh, ws, coff):
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    n, H, W = 3, 8, 12
+    g = _g(heads + coff)
+    qkv = torch.randn(n, H, W, 2304, generator=g).to(BF).cuda()
+    w = ws & 0xff
+    pos = torch.randn(2 * w - 1, 2 * w - 1, generator=g).cuda()
+    o16 = torch.zeros(n, H, W, 256, device="cuda", dtype=BF)
+    o32 = torch.zeros(n, H, W, 256, device="cuda")
+    q32 = qkv.float()
+    _lib.check(lib.av2x_window_attention_bf16(_p(qkv), 2304, coff, _p(pos), _p(o16), n, H, W, heads, dh, ws, _st()), "win16")
+    _lib.check(lib.av2x_window_attention(_p(q32), 2304, coff, _p(pos), _p(o32), n, H, W, heads, dh, ws, _st()), "win32")
+    assert torch.equal(o16, o32.to(BF))
+
+
+def test_split_attention_bf16_is_the_fp32_kernel_on_bf16_storage():
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    n, hw, C = 3, 700, 256
+    g = _g(5)
+    s = [torch.randn(n, hw, C, generator=g).to(BF).cuda() for _ in range(3)]
+    s32 = [t.float() for t in s]
+    gap16, gap32 = torch.zeros(n, C, device="cuda"), torch.zeros(n, C, device="cuda")
+    scratch = torch.zeros(n, 128, C, device="cuda")
+    _lib.check(lib.av2x_split_attn_gap_bf16(_p(s[0]), _p(s[1]), _p(s[2]), _p(gap16), _p(scratch), n, hw, C, _st()), "gap16")
+    _lib.check(lib.av2x_split_attn_gap(_p(s32[0]), _p(s32[1]), _p(s32[2]), _p(gap32), _p(scratch), n, hw, C, _st()), "gap32")
+    assert torch.equal(gap16, gap32)
+    logits = torch.randn(n, 3 * C, generator=g).cuda()
+    x = torch.randn(n, hw, C, generator=g).cuda()
+    o16, o32 = x.clone(), x.clone()
+    _lib.check(lib.av2x_split_attn_combine_bf16(_p(s[0]), _p(s[1]), _p(s[2]), _p(logits), _p(o16), _p(o16), n, hw, C, _st()), "c16")
+    _lib.check(lib.av2x_split_attn_combine(_p(s32[0]), _p(s32[1]), _p(s32[2]), _p(logits), _p(o32), _p(o32), n, hw, C, _st()), "c32")
+    assert torch.equal(o16, o32)
+
+
+@pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n8"])
+def test_v2xvit_bf16_activations_against_fp32_activation_amp_and_the_reference(name):
+    """The same AMP frame with bf16 and with fp32 activation storage: both within the drift bound of tests/test_amp.py against the
+    reference's fp32 outputs, and close to each other (the extra roundings are of the stored Linear / attention outputs)."""
+    from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
+    import tests.test_v2xvit as tv
+    from tests.test_amp import _drift
+    fx = load_fixture(name)
+    hy, args, sd, dd = tv._case(fx)
+    model = M(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    model.amp = True
+    assert eng.bf16_activations is True
+    a16 = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
+    eng.bf16_activations = False
+    a32 = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
+    eng.bf16_activations = True
+    again = model(dd)
+    assert torch.equal(again["psm"], a16["psm"])            # run-to-run identical
+    assert not torch.equal(a16["psm"], a32["psm"])
+    d16, d32 = _drift(a16, fx), _drift(a32, fx)
+    print(f"[{name}] drift vs the fp32 reference: bf16 activations {d16}, fp32 activations {d32}")
+    assert all(v < 6e-2 for v in d16.values()), d16
+    for k in ("psm", "rm", "obj"):
+        scale = float(a32[k].abs().max())
+        assert float((a16[k] - a32[k]).abs().max()) < 6e-2 * scale
