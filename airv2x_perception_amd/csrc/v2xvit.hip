@@ -121,6 +121,7 @@ struct HgtParams {
     int n, hw;
     int nq;              // query agents 0 .. nq-1 are computed (nq = n, or 1 when only the ego's output is consumed)
     int types[32];
+    int need_v[2];       // whether any query agent is of type 0 / 1 (which v' blocks are read)
     float scale;
 };
 
@@ -147,6 +148,56 @@ __global__ __launch_bounds__(256) void hgt_attention_kernel(const HgtParams<T> p
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);   // 8 lanes = one head
             s *= p.scale;
             const float4 v = ld4(kj + 768 + 256 * ti + col);
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn), pj = expf(s - mn);
+            l = l * alpha + pj;
+            o.x = fmaf(pj, v.x, o.x * alpha); o.y = fmaf(pj, v.y, o.y * alpha);
+            o.z = fmaf(pj, v.z, o.z * alpha); o.w = fmaf(pj, v.w, o.w * alpha);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        st4(p.out + ((size_t)i * p.hw + pix) * 256 + col, make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv));
+    }
+}
+
+// Same arithmetic in the same order, with the keys and both value projections of all n <= NMAX agents of the pixel loaded ONCE into
+// registers (the kernel above re-reads k_j and v_j for every query agent: n times the pixel's 2.5 n KB through the L1).  One wave
+// per pixel; a masked key agent is skipped exactly as above, so the results are bit-identical.
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void hgt_attention_reg_kernel(const HgtParams<T> p) {
+    const int lane = threadIdx.x & 63;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= p.hw) return;
+    const int col = lane * 4;
+    constexpr int PC = 1280;
+    float4 k[NMAX], v0[NMAX], v1[NMAX];
+    bool vis[NMAX];
+    const bool need0 = p.need_v[0], need1 = p.need_v[1];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        vis[j] = j < p.n && p.mask[(size_t)j * p.hw + pix] != 0.f;
+        if (vis[j]) {
+            const T* kj = p.proj + ((size_t)j * p.hw + pix) * PC;
+            k[j] = ld4(kj + 512 + col);
+            if (need0) v0[j] = ld4(kj + 768 + col);
+            if (need1) v1[j] = ld4(kj + 1024 + col);
+        }
+    }
+    for (int i = 0; i < p.nq; ++i) {
+        const int ti = p.types[i];
+        const T* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
+        const float4 q0 = ld4(qi + col);
+        const float4 q1 = ld4(qi + 256 + col);
+        float m = -INFINITY, l = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            if (!vis[j]) continue;
+            const float4 q = p.types[j] ? q1 : q0;
+            float s = q.x * k[j].x + q.y * k[j].y + q.z * k[j].z + q.w * k[j].w;
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s *= p.scale;
+            const float4 v = ti ? v1[j] : v0[j];
             const float mn = fmaxf(m, s);
             const float alpha = expf(m - mn), pj = expf(s - mn);
             l = l * alpha + pj;
@@ -412,7 +463,10 @@ static int hgt_launch(const T* proj, const float* mask, const int32_t* types_hos
     p.proj = proj; p.mask = mask; p.out = out; p.n = n; p.hw = hw; p.nq = n_query;
     for (int i = 0; i < 32; ++i) p.types[i] = i < n ? (types_host[i] != 0) : 0;
     p.scale = 1.0f / sqrtf((float)dim_head);
-    hipLaunchKernelGGL(hgt_attention_kernel<T>, dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
+    p.need_v[0] = p.need_v[1] = 0;
+    for (int i = 0; i < n_query; ++i) p.need_v[p.types[i]] = 1;
+    if (n <= 8) hipLaunchKernelGGL((hgt_attention_reg_kernel<T, 8>), dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
+    else hipLaunchKernelGGL(hgt_attention_kernel<T>, dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
     return av2x::check_launch("hgt_attention_kernel");
 }
 

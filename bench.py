@@ -762,7 +762,12 @@ def main(argv=None, hooks=None, device=None):
             hb_s = sum(v[3] for v in hk.values())
             res["roofline"]["hbm_bound_kernels"] = {"ms_per_frame": round(hb_s / a.steps * 1e3, 3), "per_kernel": table,
                                                     "peak_gb_per_s": PEAK_HBM_GBPS}
-            top, tv = max(hk.items(), key=lambda kv: kv[1][3])
+            fam = {}            # one device kernel per family (linear_bf16 256->N are launches of the same kernel)
+            for k, v in hk.items():
+                f = fam.setdefault(k.split()[0], [0, 0.0, 0.0, 0.0])
+                for i_ in range(4):
+                    f[i_] += v[i_]
+            top, tv = max(fam.items(), key=lambda kv: kv[1][3])
             if tv[3] > sec:     # the frame's dominant kernel is an HBM-bound one: it is what `roofline` describes
                 conv_view = {k: res["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "kernel", "launches_per_frame", "avg_launch_us",
                                                              "traffic", "algorithmic_bytes_per_launch") if k in res["roofline"]}
