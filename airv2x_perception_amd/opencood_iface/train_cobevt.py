@@ -62,7 +62,7 @@ def swap_fusion_encoder(P, x, n_valid, fax, training=True, prefix="fusion_net.")
     return F.linear(m, P[prefix + "mlp_head.3.weight"], P[prefix + "mlp_head.3.bias"])
 
 
-def forward_train(model, data_dict):
+def _forward_train(model, data_dict):
     args = model.args
     P = dict(model.named_parameters())
     sd = model.state_dict(keep_vars=True)
@@ -70,8 +70,6 @@ def forward_train(model, data_dict):
     if dev.type != "cuda":
         raise RuntimeError("Airv2xCoBEVT (MI355X build) has no CPU path: move the module to the GPU (model.to('cuda'))")
     r = _runner(dev)
-    from .airv2x_where2com import _amp_requested
-    T.set_amp_step(_amp_requested(model))
     bb, fax = args["base_bev_backbone"], args["fax_fusion"]
     record_len, slots = frame_layout(args["collaborators"], data_dict)
     B, n = len(record_len), sum(record_len)
@@ -105,3 +103,11 @@ def forward_train(model, data_dict):
     if args["obj_head"]:
         out["obj"] = outs[2]
     return out
+
+
+def forward_train(model, data_dict):
+    """One train-mode forward.  torch.autocast around the call (tools/train.py:118) or ``model.amp = True`` selects AMP for THIS
+    step only: the flag lives for the duration of the forward (train_ops.amp_scope) and every node carries it into its backward."""
+    from .airv2x_where2com import _amp_requested
+    with T.amp_scope(_amp_requested(model)):
+        return _forward_train(model, data_dict)

@@ -86,6 +86,7 @@ class LinearFn(torch.autograd.Function):
             r.amp = False
         ctx.save_for_backward(x, weight)
         ctx.has = (bias is not None, residual is not None)
+        ctx.amp = T.AMP_STEP[0]
         return y
 
     @staticmethod
@@ -97,7 +98,8 @@ class LinearFn(torch.autograd.Function):
         rows = dy.numel() // cout
         db = _chan_sum(r, dy, rows, cout) if (ctx.has[0] and ctx.needs_input_grad[2]) else None
         w4 = weight.detach().view(cout, cin, 1, 1)
-        dw, dx = T._wgrad_and_dgrad(x, dy, w4, 1, 0, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        with T.amp_scope(ctx.amp):
+            dw, dx = T._wgrad_and_dgrad(x, dy, w4, 1, 0, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
         if dw is not None:
             dw = dw.view(cout, cin)
         return dx, dw, db, (dy if (ctx.has[1] and ctx.needs_input_grad[3]) else None)

@@ -116,6 +116,25 @@ def set_amp_step(on):
     AMP_STEP[0] = bool(on)
 
 
+class amp_scope:
+    """``with amp_scope(flag):`` -- AMP_STEP inside the block, the previous value afterwards.  forward_train() wraps the forward in it
+    (the flag does NOT outlive the call: a later fp32 use of the autograd nodes -- a stand-alone sub-module, an op-level call -- must not
+    inherit the precision of somebody's last step); every node whose backward launches convolutions records the flag of ITS forward
+    in ``ctx.amp`` and re-enters the scope in backward, which autograd runs after forward_train() has returned."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = AMP_STEP[0]
+        AMP_STEP[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        AMP_STEP[0] = self.prev
+        return False
+
+
 def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=False):
     """act(scale * conv2d(x, w) + shift) through the engine's launcher (direct or Winograd kernels, autotuned).  ``flipped``:
     convolve with the 180-degree-rotated, channel-transposed weights (the data gradient)."""
@@ -303,6 +322,7 @@ class ConvBNAct(torch.autograd.Function):
         _check_dev(x)
         x = x.contiguous()
         z = conv_raw(x, weight, stride, pad)
+        ctx.amp = AMP_STEP[0]
         y, mean, var, rstd, scale, shift, count = bn_train_forward(z, gamma, beta, eps, act, running)
         if stats_out is not None:
             stats_out.append((mean, var, count))
@@ -315,7 +335,8 @@ class ConvBNAct(torch.autograd.Function):
         x, weight, z, mean, rstd, scale, shift = ctx.saved_tensors
         stride, pad, act = ctx.cfg
         dz, dgamma, dbeta = bn_backward(dy.contiguous(), z, mean, rstd, scale, shift, act)
-        dw, dx = _wgrad_and_dgrad(x, dz, weight, stride, pad, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        with amp_scope(ctx.amp):
+            dw, dx = _wgrad_and_dgrad(x, dz, weight, stride, pad, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -354,6 +375,7 @@ class DeconvBNAct(torch.autograd.Function):
             stats_out.append((mean, var, count))
         ctx.save_for_backward(x, weight, z, mean, rstd, scale, shift)
         ctx.act = act
+        ctx.amp = AMP_STEP[0]
         return y
 
     @staticmethod
@@ -368,7 +390,8 @@ class DeconvBNAct(torch.autograd.Function):
             dw = g.view(s, s, cout, cin).permute(3, 2, 0, 1).contiguous()
         if ctx.needs_input_grad[0]:
             wb = weight.detach().permute(0, 2, 3, 1).reshape(cin, s * s * cout, 1, 1)
-            dx = conv_raw(d2, wb, 1, 0)
+            with amp_scope(ctx.amp):
+                dx = conv_raw(d2, wb, 1, 0)
         return dx, dw, dgamma, dbeta, None, None, None, None
 
 
@@ -385,6 +408,7 @@ class ConvBiasAct(torch.autograd.Function):
         y = conv_raw(x, weight, stride, pad, None, bias.detach(), 1 if act else 0)
         ctx.save_for_backward(x, weight, y)
         ctx.cfg = (stride, pad, act)
+        ctx.amp = AMP_STEP[0]
         return y
 
     @staticmethod
@@ -405,7 +429,8 @@ class ConvBiasAct(torch.autograd.Function):
             ws = torch.empty(int(r.lib.av2x_channel_sum_workspace_bytes(rows, cout)) // 4 + 4, device=x.device)
             db = torch.empty(cout, device=x.device)
             _lib.check(r.lib.av2x_channel_sum(_P(dz), rows, cout, _P(ws), _P(db), r.stream()), "av2x_channel_sum")
-        dw, dx = _wgrad_and_dgrad(x, dz, weight, stride, pad, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        with amp_scope(ctx.amp):
+            dw, dx = _wgrad_and_dgrad(x, dz, weight, stride, pad, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
         return dx, dw, db, None, None, None
 
 

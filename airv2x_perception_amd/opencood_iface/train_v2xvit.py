@@ -122,7 +122,7 @@ def encoder(P, x, prior, scm, enc, training=True, p="fusion_net.encoder"):
     return x[0:1]
 
 
-def forward_train(model, data_dict):
+def _forward_train(model, data_dict):
     args = model.args
     P = dict(model.named_parameters())
     sd = model.state_dict(keep_vars=True)
@@ -130,8 +130,6 @@ def forward_train(model, data_dict):
     if dev.type != "cuda":
         raise RuntimeError("Airv2xV2XVit (MI355X build) has no CPU path: move the module to the GPU (model.to('cuda'))")
     r = _runner(dev)
-    from .airv2x_where2com import _amp_requested
-    T.set_amp_step(_amp_requested(model))
     mf = args["modality_fusion"]
     bb = mf["base_bev_backbone"]
     if mf.get("compression", 0):
@@ -163,3 +161,11 @@ def forward_train(model, data_dict):
         out["obj"] = outs[2]
     out["comm_rate"] = int(nz[0].item()) if getattr(model, "sync_comm_rate", True) else nz[0]
     return out
+
+
+def forward_train(model, data_dict):
+    """One train-mode forward.  torch.autocast around the call (tools/train.py:118) or ``model.amp = True`` selects AMP for THIS
+    step only: the flag lives for the duration of the forward (train_ops.amp_scope) and every node carries it into its backward."""
+    from .airv2x_where2com import _amp_requested
+    with T.amp_scope(_amp_requested(model)):
+        return _forward_train(model, data_dict)

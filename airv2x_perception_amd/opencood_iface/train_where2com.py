@@ -107,7 +107,7 @@ def encode_train(args, P, sd, data_dict, slots, n, dev, r):
     return canvas, nz
 
 
-def forward_train(model, data_dict, topk=None, mask=None, trace=None):
+def _forward_train(model, data_dict, topk=None, mask=None, trace=None):
     """-> output dict of the reference (psm / rm / obj require grad).  ``topk``: one K per sample instead of the random draw;
     ``mask`` (n, H, W): replay a recorded communication mask instead of the one computed here (the top-K cut is discontinuous
     in the single-agent logits; parity tests replay the reference's); ``trace``: dict that receives the computed mask."""
@@ -122,8 +122,6 @@ def forward_train(model, data_dict, topk=None, mask=None, trace=None):
     r = _runner(dev)
     # torch.autocast around the forward (tools/train.py:118) or model.amp = True -> bf16 matrix-core operands for this step's
     # convolutions, forward and data gradients alike (train_ops.AMP_STEP); a GradScaler on top works unchanged (fp32 gradients)
-    from .airv2x_where2com import _amp_requested
-    T.set_amp_step(_amp_requested(model))
     mf = args["modality_fusion"]
     bb = mf["base_bev_backbone"]
     fcfg = args["where2com_fusion"]
@@ -191,3 +189,11 @@ def forward_train(model, data_dict, topk=None, mask=None, trace=None):
         out["obj"] = outs[2]
     out.update({"mask": 0, "com": com, "comm_rate": int(nz[0].item()) if model.sync_comm_rate else nz[0]})
     return out
+
+
+def forward_train(model, data_dict, topk=None, mask=None, trace=None):
+    """One train-mode forward.  torch.autocast around the call (tools/train.py:118) or ``model.amp = True`` selects AMP for THIS
+    step only: the flag lives for the duration of the forward (train_ops.amp_scope) and every node carries it into its backward."""
+    from .airv2x_where2com import _amp_requested
+    with T.amp_scope(_amp_requested(model)):
+        return _forward_train(model, data_dict, topk=topk, mask=mask, trace=trace)

@@ -242,9 +242,16 @@ def test_cobevt_amp_training_step():
     model = _model(args, sd)
     scaler = torch.amp.GradScaler("cuda", init_scale=256.0)
     opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    from airv2x_perception_amd.opencood_iface import train_fusion_ops as Fo
+    from airv2x_perception_amd.opencood_iface import train_ops as T
     with torch.autocast("cuda", dtype=torch.float16):
         out = model(dd)
         loss = _loss(args)(out, tgt)
+    # the AMP flag is scoped to the forward (every node carries it into its own backward): anything evaluated outside an autocast
+    # step -- here a Linear node between the AMP forward and its backward -- is fp32 again
+    assert not T.AMP_STEP[0]
+    xa, wa = torch.randn(1, 4, 8, 256, generator=_g(1)).cuda(), (torch.randn(256, 256, generator=_g(2)) * 0.05).cuda()
+    rel_close(Fo.linear(xa, wa).cpu(), F.linear(xa.cpu(), wa.cpu()), 2e-5, "fp32 Linear after an AMP forward")
     scaler.scale(loss).backward()
     scaler.step(opt)
     scaler.update()
