@@ -403,6 +403,7 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
 #include "conv_igemm_bf16.inc"
 #include "conv_igemm_glds.inc"
 #include "conv_wino.inc"
+#include "conv_wino4.inc"
 
 }  // namespace
 
@@ -450,6 +451,8 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     if (d->relu < 0 || d->relu > 6)
         return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU, 3 sigmoid, 4 tanh [x residual], 5 ReLU after the residual, 6 swish)", d->relu);
     if (d->relu == 5 && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: activation 5 (ReLU after the residual) needs mode AV2X_CONV");
+    if ((d->tile & 0x60000000) == 0x60000000)   // Winograd F(4x4,3x3): `w` is the transformed packing of av2x_wino4_pack_weights
+        return wino4_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if (d->tile & 0x40000000)   // Winograd F(2x2,3x3): `w` is the transformed packing of av2x_wino_pack_weights
         return wino_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if (d->cin % BK != 0) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);

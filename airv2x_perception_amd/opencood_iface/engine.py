@@ -38,7 +38,7 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if hasattr(to
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i", "_wu4")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
@@ -46,6 +46,7 @@ class ConvLayer:
         self._w3 = None
         self._wu = None
         self._w16i = None
+        self._wu4 = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
 
@@ -83,6 +84,17 @@ def _wu(L, lib, stream):
         torch.cuda.current_stream().synchronize()
         L._wu = u
     return L._wu
+
+
+def _wu4(L, lib, stream):
+    """Winograd F(4x4,3x3)-transformed weights (av2x_wino4_pack_weights: 36 positions), built on the device on first use."""
+    if L._wu4 is None:
+        u = torch.empty(lib.av2x_wino4_weight_bytes(L.cin, L.coutp) // 4, dtype=torch.float32, device=L.w.device)
+        _lib.check(lib.av2x_wino4_pack_weights(c_void_p(L.w.data_ptr()), L.cin, L.coutp, c_void_p(u.data_ptr()), stream),
+                   "av2x_wino4_pack_weights")
+        torch.cuda.current_stream().synchronize()      # as _wu: other streams may launch with it next
+        L._wu4 = u
+    return L._wu4
 
 
 def _ptr(t):
@@ -449,7 +461,10 @@ class Where2ComEngine:
         d.sk_wgs = 0
         wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         vflag = 0x0800 if self.amp else (0x0400 if self.split3 else 0)
-        if self.winograd and not self.conv_tile and vflag == 0 and self.wino_rule(L):
+        if self.winograd and self.wino4 and not self.conv_tile and vflag == 0 and self.wino4_rule(L, n, d.ho, d.wo):
+            wgt = _wu4(L, self.lib, self.stream())      # the F(4x4,3x3) class: a pure function of the layer's shape
+            d.tile = self.WINO4_TILE
+        elif self.winograd and not self.conv_tile and vflag == 0 and self.wino_rule(L):
             wgt = _wu(L, self.lib, self.stream())
             d.tile = self.WINO_TILE
             if self.autotune:   # the Winograd tilings are bit-identical to each other: which one runs is a speed question only
@@ -488,7 +503,9 @@ class Where2ComEngine:
             e1.record()
             # algorithmic FLOPs: 2 * output pixels * real output channels * taps * cin
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
-            if bm & 0x4000:   # Winograd: (32 x TB-tile blocks of 2x2 outputs) x (cout / CB)
+            if bm & 0x2000:   # Winograd F(4x4,3x3): 32-tile blocks of 4x4 outputs x (cout / 64)
+                wgs = -(-(n * ((d.ho + 3) // 4) * ((d.wo + 3) // 4)) // 32) * (L.cout // 64)
+            elif bm & 0x4000:   # Winograd: (32 x TB-tile blocks of 2x2 outputs) x (cout / CB)
                 wgs = -(-(n * ((d.ho + 1) // 2) * ((d.wo + 1) // 2)) // (bm & 0x3fff)) * (L.cout // (bn & 0x01ff))
             else:
                 wgs = -(-(n * d.ho * d.wo) // bm) * (L.coutp // (bn & 0x01ff))
@@ -519,6 +536,23 @@ class Where2ComEngine:
         output channels."""
         return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1, 3, 4, 5)
                 and L.cin >= 64 and L.cin % 8 == 0 and L.cout % 64 == 0 and L.cout == L.coutp)
+
+    # Winograd F(4x4,3x3) (csrc/conv_wino4.inc): 2.25 multiplies per output instead of 4; one workgroup (32 tiles of 4x4 outputs x 64
+    # couts, 18 accumulator tiles per wave) occupies a CU, so a launch takes ceil(workgroups / 256) x (14 us + 2.9 us per 8 input
+    # channels) (tools/wino4_bench.py).  Taken where that beats F(2x2,3x3): a K loop of >= 16 chunks, at least half a chip of
+    # workgroups and a last round that is not nearly empty -- a pure function of the launch shape, like the F(2x2) rule.
+    WINO4_TILE = 0x60000000 | (32 << 16) | 64
+    WINO4_MIN_WGS = 128
+    WINO4_MIN_CIN = 128
+    WINO4_MIN_FILL = 0.55
+    N_CU = 256
+    wino4 = os.environ.get("AV2X_WINOGRAD4", "1") != "0"
+
+    def wino4_rule(self, L, n, h, w):
+        if not (self.wino_rule(L) and L.cin >= self.WINO4_MIN_CIN):
+            return False
+        wgs = -(-(n * ((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64)
+        return wgs >= self.WINO4_MIN_WGS and wgs / (self.N_CU * -(-wgs // self.N_CU)) >= self.WINO4_MIN_FILL
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)
     TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),

@@ -678,7 +678,7 @@ def main(argv=None, hooks=None, device=None):
             d = per.setdefault(tile, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
-            d[3] += flops * (16.0 / 36.0 if tile[0] & 0x4000 else 1.0)   # multiplies the matrix cores EXECUTE (Winograd F(2x2,3x3): 16 per 36)
+            d[3] += flops * ((36.0 / 144.0 if tile[0] & 0x2000 else 16.0 / 36.0) if tile[0] & 0x4000 else 1.0)   # multiplies the matrix cores EXECUTE (Winograd F(2x2,3x3): 16 per 36; F(4x4,3x3): 36 per 144)
             dur = max(e0.elapsed_time(e1) * 1e-3 - ev_over, 1e-7)   # one pair per launch (a stream-K launch = GEMM + fix-up kernel)
             d[2] += dur
             g = grids.setdefault(tile, {})
@@ -699,7 +699,7 @@ def main(argv=None, hooks=None, device=None):
         tot_fl = sum(v[1] for v in per.values())
         tot_exe = sum(v[3] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{'w' if k[0] & 0x4000 else ''}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x3fff}x{k[1] & 0x01ff}{(('q' if (k[1] & 0x01ff) == 32 else 'h') if k[0] & 0x4000 else 'w8') if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
+        tkey = lambda k: f"{('w4_' if k[0] & 0x2000 else 'w') if k[0] & 0x4000 else ''}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x1fff}x{k[1] & 0x01ff}{(('q' if (k[1] & 0x01ff) == 32 else 'h') if k[0] & 0x4000 else 'w8') if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         peak = PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS
         res["roofline"] = {
@@ -711,15 +711,16 @@ def main(argv=None, hooks=None, device=None):
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
             "effective_tflops": round(eff, 2), "effective_over_peak": round(eff / peak, 4),
             "effective_note": ("direct-convolution (algorithmic, SURVEY 8d) FLOPs of the same launches over the same time"
-                               + (": Winograd executes 16/36 of them" if wino else ": equal to achieved (direct form)")),
+                               + ((": Winograd F(4x4,3x3) executes 36/144 of them" if dom[0] & 0x2000 else ": Winograd executes 16/36 of them") if wino else ": equal to achieved (direct form)")),
             "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": (("conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
+            "kernel": (("conv_wino4_f32 (Winograd F(4x4,3x3), 32 tiles of 4x4 outputs x 64 couts per workgroup, 18 positions per wave, one workgroup per CU)" if dom[0] & 0x2000 else
+                        "conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
                         "conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
                         f"conv_wino_f32<{(dom[0] & 0x3fff) // 32},{(dom[1] & 0x01ff) // 32}> (Winograd F(2x2,3x3), {dom[0] & 0x3fff} tiles x {dom[1] & 0x01ff} couts per workgroup)") if wino else
                        f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": ((("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else (f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": (("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else (f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),

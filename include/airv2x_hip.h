@@ -157,6 +157,12 @@ uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs);
  * cin % 8 == 0, cout % CB == 0, activation codes 0, 1, 3, 4 (no GELU); residual as in av2x_conv2d_res. */
 uint64_t av2x_wino_weight_bytes(int32_t cin, int32_t coutp);
 int av2x_wino_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, float* u, av2x_stream_t stream);
+/* Winograd F(4x4,3x3) (tile flag 0x60000000 | 32 << 16 | 64): 36 products per 4x4 output tile = 2.25 multiplies per output (F(2x2,3x3): 4,
+ * direct: 9), fp32 operands and accumulation; cin % 8 == 0, cout % 64 == 0 and cout == coutp; `w` = the transformed packing
+ * [36][cin/4][coutp][4] made by av2x_wino4_pack_weights (av2x_wino4_weight_bytes bytes).  Results agree with the other kernels to
+ * fp32 rounding (larger transform constants: ~4x the error of F(2x2,3x3) against fp64), not bit for bit. */
+uint64_t av2x_wino4_weight_bytes(int32_t cin, int32_t coutp);
+int av2x_wino4_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, float* u, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Where2Comm communication mask.  Replaces Communication.forward, eval branch

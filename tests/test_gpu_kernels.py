@@ -460,6 +460,71 @@ def test_winograd_conv_matches_fp64_and_its_tilings_agree_bit_for_bit(lib, case)
     assert all(torch.equal(first, o) for o in outs.values()), list(outs)
 
 
+WINO4_TILE = 0x60000000 | (32 << 16) | 64
+WINO4_CASES = [
+    # n, h, w, cin, cout, relu, with residual      (H / W not multiples of 4: partly empty tiles; blocks that wrap rows and images)
+    (2, 25, 88, 256, 256, 1, False),
+    (4, 100, 352, 128, 64, 1, False),
+    (3, 9, 13, 128, 128, 0, False),
+    (1, 1, 7, 64, 64, 1, False),
+    (2, 6, 1, 8, 64, 5, True),
+    (1, 50, 176, 64, 128, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_winograd_f4x4_matches_fp64(lib, case):
+    """F(4x4,3x3) (csrc/conv_wino4.inc) against an fp64 convolution of the same fp32 operands.  Its transform constants (up to 8)
+    cost accuracy: the bound is 1e-4 * max|ref| (measured and printed next to F(2x2,3x3)'s error on the same case: ~4x), still
+    fp32-rounding level -- the model-level goldens hold at their unchanged tolerances with the rule that selects it.  Run-to-run
+    identical (every output is formed in one fixed order)."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    n, h, w, cin, cout, relu, with_res = case
+    g = torch.Generator().manual_seed(777 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, h, w, cout, generator=g) if with_res else None
+    ref = (F.conv2d(x.double(), wt.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    if relu == 1:
+        ref = F.relu(ref)
+    if with_res:
+        ref = ref + res.double()
+    if relu == 5:
+        ref = F.relu(ref)
+    wp, coutp = pack_conv_weight(wt)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    u4 = torch.empty(lib.av2x_wino4_weight_bytes(cin, coutp) // 4, device="cuda")
+    _lib.check(lib.av2x_wino4_pack_weights(_p(wp.cuda()), cin, coutp, _p(u4), _stream()), "av2x_wino4_pack_weights")
+    sc, sh, rd = scale.cuda(), shift.cuda(), (res.cuda() if with_res else None)
+
+    def run(uw, tile):
+        out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp, out_ctot=cout, out_coff=0,
+                          ks=3, stride=1, pad=1, relu=relu, mode=0, up=1, tile=tile, sk_wgs=0)
+        _lib.check(lib.av2x_conv2d_res(byref(d), _p(xn), _p(uw), _p(sc), _p(sh), _p(rd), _p(out), _stream()), "conv")
+        return out.cpu()
+    o4 = run(u4, WINO4_TILE)
+    e4 = float((o4.double() - ref).abs().max())
+    o2 = run(_wino_weights(lib, wp.cuda(), cin, coutp), WINO_TILES["32x64h"])
+    e2 = float((o2.double() - ref).abs().max())
+    print(f"F(4x4,3x3) max err {e4:.2e}, F(2x2,3x3) {e2:.2e}, max|ref| {float(ref.abs().max()):.2f}")
+    assert e4 <= 1e-4 * max(1.0, float(ref.abs().max())), e4
+    assert torch.equal(run(u4, WINO4_TILE), o4)
+
+
+def test_winograd_f4x4_rule_is_a_function_of_the_launch_shape():
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
+    mk = lambda cin, cout, ks=3, stride=1: ConvLayer(None, None, None, cin, cout, cout, ks, stride, 1 if ks == 3 else 0, 1, _lib.AV2X_CONV)
+    rule = lambda L, n, h, w: Where2ComEngine.wino4_rule(Where2ComEngine, L, n, h, w)
+    assert rule(mk(256, 256), 4, 100, 352) and rule(mk(128, 128), 4, 50, 176) and rule(mk(256, 256), 8, 25, 88)
+    assert not rule(mk(256, 256), 1, 100, 352)      # 276 workgroups: a second round at 8 % occupancy
+    assert not rule(mk(256, 256), 4, 25, 88) and not rule(mk(128, 128), 3, 50, 176) and not rule(mk(64, 64), 4, 100, 352)
+    assert not rule(mk(128, 256, stride=2), 4, 100, 352) and not rule(mk(256, 256, ks=1), 4, 100, 352)
+
+
 def test_winograd_conv_channel_slices_and_argument_checks(lib):
     """Input read from a channel slice of a wider tensor, output written into a slice of a concatenated map (what the
     engine's fused buffers do); everything outside the slice stays untouched.  Unsupported uses fail loudly."""
