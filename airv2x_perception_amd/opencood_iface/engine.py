@@ -539,20 +539,20 @@ class Where2ComEngine:
 
     # Winograd F(4x4,3x3) (csrc/conv_wino4.inc): 2.25 multiplies per output instead of 4; one workgroup (32 tiles of 4x4 outputs x 64
     # couts, 18 accumulator tiles per wave) occupies a CU, so a launch takes ceil(workgroups / 256) x (14 us + 2.9 us per 8 input
-    # channels) (tools/wino4_bench.py).  Taken where that beats F(2x2,3x3): a K loop of >= 16 chunks, at least half a chip of
-    # workgroups and a last round that is not nearly empty -- a pure function of the launch shape, like the F(2x2) rule.
+    # channels) (tools/wino4_bench.py: 1.48x faster than F(2x2,3x3) on 4 x 100 x 352 x 256 -> 256, slower on the small maps).
+    # Like the F(2x2) rule, the choice is a function of the LAYER and of the map size only, never of the number of agents in the
+    # launch: the agent-sharded frame and a batch must give the bits of the single frame (tests/test_gpu_sharded.py,
+    # test_gpu_batch_and_single.py).  Taken where ONE image already fills the chip: >= 256 workgroups per image and a K loop of
+    # >= 16 chunks -- the two 256 -> 256 shrink convolutions at 100 x 352 of the default grid.
     WINO4_TILE = 0x60000000 | (32 << 16) | 64
-    WINO4_MIN_WGS = 128
+    WINO4_MIN_WGS_PER_IMAGE = 256
     WINO4_MIN_CIN = 128
-    WINO4_MIN_FILL = 0.55
-    N_CU = 256
     wino4 = os.environ.get("AV2X_WINOGRAD4", "1") != "0"
 
     def wino4_rule(self, L, n, h, w):
         if not (self.wino_rule(L) and L.cin >= self.WINO4_MIN_CIN):
             return False
-        wgs = -(-(n * ((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64)
-        return wgs >= self.WINO4_MIN_WGS and wgs / (self.N_CU * -(-wgs // self.N_CU)) >= self.WINO4_MIN_FILL
+        return -(-(((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64) >= self.WINO4_MIN_WGS_PER_IMAGE
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)
     TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),

@@ -514,14 +514,15 @@ def test_winograd_f4x4_matches_fp64(lib, case):
     assert torch.equal(run(u4, WINO4_TILE), o4)
 
 
-def test_winograd_f4x4_rule_is_a_function_of_the_launch_shape():
+def test_winograd_f4x4_rule_is_a_function_of_the_layer_and_map_size_only():
     from airv2x_perception_amd import _lib
     from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
     mk = lambda cin, cout, ks=3, stride=1: ConvLayer(None, None, None, cin, cout, cout, ks, stride, 1 if ks == 3 else 0, 1, _lib.AV2X_CONV)
     rule = lambda L, n, h, w: Where2ComEngine.wino4_rule(Where2ComEngine, L, n, h, w)
-    assert rule(mk(256, 256), 4, 100, 352) and rule(mk(128, 128), 4, 50, 176) and rule(mk(256, 256), 8, 25, 88)
-    assert not rule(mk(256, 256), 1, 100, 352)      # 276 workgroups: a second round at 8 % occupancy
-    assert not rule(mk(256, 256), 4, 25, 88) and not rule(mk(128, 128), 3, 50, 176) and not rule(mk(64, 64), 4, 100, 352)
+    assert rule(mk(256, 256), 4, 100, 352) and rule(mk(256, 256), 1, 100, 352) and rule(mk(384, 256), 2, 100, 352)
+    # never a function of the number of agents in the launch (sharded frame == single frame, batch == single)
+    assert all(rule(mk(256, 256), n, 100, 352) for n in range(1, 16)) and not any(rule(mk(128, 128), n, 50, 176) for n in range(1, 16))
+    assert not rule(mk(256, 256), 8, 25, 88) and not rule(mk(64, 64), 4, 100, 352) and not rule(mk(256, 128), 4, 100, 352)
     assert not rule(mk(128, 256, stride=2), 4, 100, 352) and not rule(mk(256, 256, ks=1), 4, 100, 352)
 
 
