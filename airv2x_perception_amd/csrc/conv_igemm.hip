@@ -490,6 +490,14 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
         return av2x::fail("av2x_conv2d: input (%llu B) or weights (%llu B) exceed the 2 GiB buffer-descriptor window", in_bytes, w_bytes);
     p.in_bytes = (unsigned)in_bytes;
     p.w_bytes = (unsigned)w_bytes;
+    // the epilogue addresses the output with 32-bit byte offsets through a buffer descriptor
+    const unsigned long long out_bytes = d->mode == AV2X_DECONV ? (unsigned long long)d->n * d->h * d->up * d->w * d->up * d->out_ctot * 4ull
+                                        : d->mode == AV2X_CONV ? (unsigned long long)M * d->out_ctot * 4ull
+                                                               : (unsigned long long)M * d->cout * 4ull;
+    if (d->mode != AV2X_CONV && out_bytes / (unsigned long long)d->n >= (1ull << 30))
+        return av2x::fail("av2x_conv2d: one output image (%llu B) exceeds the 1 GiB window of the epilogue's 32-bit offsets", out_bytes / d->n);
+    if ((unsigned long long)d->out_ctot * 4ull * 256ull >= (1ull << 30)) return av2x::fail("av2x_conv2d: out_ctot too large");
+    p.out_bytes = out_bytes;
     hipStream_t st = av2x::as_stream(stream);
 
     int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x01ff;
