@@ -17,12 +17,14 @@ import bench  # noqa: E402
 def main(out):
     dev = torch.device("cuda", 0)
     table = {}
-    for model in ("where2com", "cobevt", "v2xvit", "when2com", "v2vnet"):
-        for agents in ((1, 2, 3, 4, 5, 8) if model == "where2com" else (4, 8)):
-            a = bench.parse(["--model", model, "--agents", str(agents)])
-            hy, args, dd, _, _ = bench.build_inputs(agents, a.points, dev, only=None, model=model)
+    runs = [(model, agents, None) for model in ("where2com", "cobevt", "v2xvit", "when2com", "v2vnet")
+            for agents in ((1, 2, 3, 4, 5, 8) if model == "where2com" else (4, 8))]
+    runs.append(("where2com", 8, "cam,lidar"))          # BASELINE configs[4]: the camera trunk's shapes
+    for model, agents, mods in runs:
+            a = bench.parse(["--model", model, "--agents", str(agents)] + (["--modalities", mods] if mods else []))
+            hy, args, dd, _, _ = bench.build_inputs(agents, a.points, dev, only=None, model=model, modalities=(tuple(mods.split(",")) if mods else ("lidar",)))
             m, eng, _ = bench.make_model(a, args, dev)
-            for amp, split3 in ((False, False), (True, False), (False, True)):
+            for amp, split3 in (((False, False),) if mods else ((False, False), (True, False), (False, True))):
                 eng.amp, m.amp, eng.split3 = amp, amp, split3
                 m(dd)
                 torch.cuda.synchronize()
