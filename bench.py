@@ -732,6 +732,12 @@ def main(argv=None, hooks=None, device=None):
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "executed_tflops": round(tot_exe / tot_s / 1e12, 2),
                                  "ms_per_frame": round(tot_s / a.steps * 1e3, 3),
                                  "gflop_per_frame": round(tot_fl / a.steps / 1e9, 1), "executed_gflop_per_frame": round(tot_exe / a.steps / 1e9, 1)},
+            # the HEADLINE schedule (frames in flight) as a whole: the conv launches' executed multiplies over the measured frame time
+            **({"whole_frame": {"executed_tflops": round(tot_exe / a.steps / (res["ms_per_step"] * 1e-3) / 1e12, 2),
+                                "frac_of_mfma_peak": round(tot_exe / a.steps / (res["ms_per_step"] * 1e-3) / 1e12 / peak, 4),
+                                "note": "executed matrix-core FLOPs of all conv launches of a frame / ms_per_step of the timed region (all "
+                                        "other kernels included in the time); per-launch figures above are from isolated sequential launches"}}
+               if world == 1 and a.mode == "replica" else {}),
             "per_tile": {tkey(k): {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
                                    **({"executed_tflops": round(v[3] / v[2] / 1e12, 2)} if k[0] & 0x4000 else {}),
                                    "ms_per_frame": round(v[2] / a.steps * 1e3, 3)} for k, v in per.items()},
