@@ -11,6 +11,8 @@
 //   window_attn_kernel     BaseWindowAttention (mswin.py:52-96): one thread per (token, head)
 //   gap3_kernel            mean over H,W of (sw + mw + bw)             (split_attn.py:48-50)
 //   split_combine_kernel   radix softmax over the 3 branches + weighted sum + residual (:55-61)
+#include <type_traits>
+
 #include "av2x_common.hpp"
 
 namespace {
@@ -207,6 +209,71 @@ __global__ __launch_bounds__(256) void hgt_attention_reg_kernel(const HgtParams<
         }
         const float inv = 1.0f / l;
         st4(p.out + ((size_t)i * p.hw + pix) * 256 + col, make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv));
+    }
+}
+
+// bf16 storage, 16-byte loads: a lane owns 8 of the 256 columns (head = lane32 / 4), a wave two pixels.  Keys and values stay packed
+// (bf16 pairs) in registers and are widened on use.  The additions happen in the order of the kernels above -- the two 4-dim partial
+// dot products of a lane are exactly what lanes 2 j and 2 j + 1 hold there, then the same butterfly over the head -- so on the same
+// inputs the result equals theirs bit for bit (tests/test_gpu_bf16_activations.py).
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 u, float4& a, float4& b) {
+    a = make_float4(bf16_bits_to_float(u.x << 16), bf16_bits_to_float(u.x & 0xffff0000u), bf16_bits_to_float(u.y << 16), bf16_bits_to_float(u.y & 0xffff0000u));
+    b = make_float4(bf16_bits_to_float(u.z << 16), bf16_bits_to_float(u.z & 0xffff0000u), bf16_bits_to_float(u.w << 16), bf16_bits_to_float(u.w & 0xffff0000u));
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(256) void hgt_attention_bf16x8_kernel(const HgtParams<__bf16> p) {
+    const int lane = threadIdx.x & 63, l32 = lane & 31;
+    const int pix = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    if (pix >= p.hw) return;
+    const int col = l32 * 8;
+    constexpr int PC = 1280;
+    uint4 k[NMAX], v0[NMAX], v1[NMAX];
+    bool vis[NMAX];
+    const bool need0 = p.need_v[0], need1 = p.need_v[1];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        vis[j] = j < p.n && p.mask[(size_t)j * p.hw + pix] != 0.f;
+        if (vis[j]) {
+            const __bf16* kj = p.proj + ((size_t)j * p.hw + pix) * PC;
+            k[j] = *reinterpret_cast<const uint4*>(kj + 512 + col);
+            if (need0) v0[j] = *reinterpret_cast<const uint4*>(kj + 768 + col);
+            if (need1) v1[j] = *reinterpret_cast<const uint4*>(kj + 1024 + col);
+        }
+    }
+    for (int i = 0; i < p.nq; ++i) {
+        const int ti = p.types[i];
+        const __bf16* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
+        float4 q0a, q0b, q1a, q1b;
+        bf16x8_to_f32(*reinterpret_cast<const uint4*>(qi + col), q0a, q0b);
+        bf16x8_to_f32(*reinterpret_cast<const uint4*>(qi + 256 + col), q1a, q1b);
+        float m = -INFINITY, l = 0.f;
+        float4 oa = make_float4(0.f, 0.f, 0.f, 0.f), ob = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            if (!vis[j]) continue;
+            float4 ka, kb, va, vb;
+            bf16x8_to_f32(k[j], ka, kb);
+            const float4 qa = p.types[j] ? q1a : q0a, qb = p.types[j] ? q1b : q0b;
+            const float sa = qa.x * ka.x + qa.y * ka.y + qa.z * ka.z + qa.w * ka.w;
+            const float sb = qb.x * kb.x + qb.y * kb.y + qb.z * kb.z + qb.w * kb.w;
+            float s = sa + sb;
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);   // 4 lanes = one head
+            s *= p.scale;
+            bf16x8_to_f32(ti ? v1[j] : v0[j], va, vb);
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn), pj = expf(s - mn);
+            l = l * alpha + pj;
+            oa.x = fmaf(pj, va.x, oa.x * alpha); oa.y = fmaf(pj, va.y, oa.y * alpha);
+            oa.z = fmaf(pj, va.z, oa.z * alpha); oa.w = fmaf(pj, va.w, oa.w * alpha);
+            ob.x = fmaf(pj, vb.x, ob.x * alpha); ob.y = fmaf(pj, vb.y, ob.y * alpha);
+            ob.z = fmaf(pj, vb.z, ob.z * alpha); ob.w = fmaf(pj, vb.w, ob.w * alpha);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        __bf16* dst = p.out + ((size_t)i * p.hw + pix) * 256 + col;
+        st4(dst, make_float4(oa.x * inv, oa.y * inv, oa.z * inv, oa.w * inv));
+        st4(dst + 4, make_float4(ob.x * inv, ob.y * inv, ob.z * inv, ob.w * inv));
     }
 }
 
@@ -465,6 +532,12 @@ static int hgt_launch(const T* proj, const float* mask, const int32_t* types_hos
     p.scale = 1.0f / sqrtf((float)dim_head);
     p.need_v[0] = p.need_v[1] = 0;
     for (int i = 0; i < n_query; ++i) p.need_v[p.types[i]] = 1;
+    if constexpr (std::is_same<T, __bf16>::value) {
+        if (n <= 8) {
+            hipLaunchKernelGGL((hgt_attention_bf16x8_kernel<8>), dim3((hw + 7) / 8), dim3(256), 0, av2x::as_stream(stream), p);
+            return av2x::check_launch("hgt_attention_bf16x8_kernel");
+        }
+    }
     if (n <= 8) hipLaunchKernelGGL((hgt_attention_reg_kernel<T, 8>), dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
     else hipLaunchKernelGGL(hgt_attention_kernel<T>, dim3((hw + 3) / 4), dim3(256), 0, av2x::as_stream(stream), p);
     return av2x::check_launch("hgt_attention_kernel");
