@@ -394,17 +394,46 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const T* __restri
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
-        // V rows of the keys (jy = h, jx = r)
-        const T* vrow = qkv + (pix0 + (size_t)h * W) * ctot + coff + 2 * inner + head * DH + t;
-        T* orow = out + (pix0 + (size_t)h * W) * inner + head * DH + t;   // query (iy = h, ix = r')
+        if constexpr (std::is_same<T, __bf16>::value) {
+            // bf16 storage: the window's V tile (16 keys x DH) comes in and its O tile goes out as 16-byte pieces through a per-wave
+            // LDS tile (the element-wise form below moves 2 bytes per lane and instruction: 2.6 TB/s at DH = 64)
+            __shared__ __attribute__((aligned(16))) __bf16 vtile[4][16 * DH], otile[4][16 * DH];
+            const int wv = threadIdx.x >> 6;
+            constexpr int PPK = DH / 8;                      // 16-byte pieces per key / query row
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+            for (int e = lane; e < 16 * PPK; e += 64) {
+                const int key = e / PPK, part = e % PPK;
+                *reinterpret_cast<uint4*>(&vtile[wv][key * DH + part * 8]) = *reinterpret_cast<const uint4*>(
+                    qkv + (pix0 + (size_t)(key >> 2) * W + (key & 3)) * ctot + coff + 2 * inner + head * DH + part * 8);
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, ld1(vrow + (size_t)r * ctot + nb * 16), o, 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4_t o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st1(orow + (size_t)r * inner + nb * 16, o[r]);
+                for (int r = 0; r < 4; ++r)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, (float)vtile[wv][(4 * h + r) * DH + nb * 16 + t], o, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) otile[wv][(4 * h + r) * DH + nb * 16 + t] = (__bf16)o[r];
+            }
+#pragma unroll
+            for (int e = lane; e < 16 * PPK; e += 64) {
+                const int qi = e / PPK, part = e % PPK;
+                *reinterpret_cast<uint4*>(out + (pix0 + (size_t)(qi >> 2) * W + (qi & 3)) * inner + head * DH + part * 8) =
+                    *reinterpret_cast<const uint4*>(&otile[wv][qi * DH + part * 8]);
+            }
+        } else {
+            // V rows of the keys (jy = h, jx = r)
+            const T* vrow = qkv + (pix0 + (size_t)h * W) * ctot + coff + 2 * inner + head * DH + t;
+            T* orow = out + (pix0 + (size_t)h * W) * inner + head * DH + t;   // query (iy = h, ix = r')
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, ld1(vrow + (size_t)r * ctot + nb * 16), o, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st1(orow + (size_t)r * inner + nb * 16, o[r]);
+            }
         }
     }
 }
