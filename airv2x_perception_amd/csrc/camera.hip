@@ -147,6 +147,13 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
         const float* pp = partial + (size_t)n * S * C + c;
         float a = 0.f;
         int s = 0;
+        for (; s + 16 <= S; s += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = pp[(size_t)(s + u) * C];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += v[u];
+        }
         for (; s + 8 <= S; s += 8) {
             float v[8];
 #pragma unroll
@@ -159,16 +166,28 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    // four rows of the reduce weights per pass and wave: their loads are all in flight before the first dependent add (one row at a
-    // time the kernel was a chain of Cse / 4 memory latencies: 44 us for 26 workgroups).  Per row the sum order is unchanged.
+    // Memory-level parallelism is what this kernel is about (26 workgroups, every load a cold miss): four reduce rows x four channel
+    // groups = 16 loads in flight per lane and pass; per row the sum order is unchanged (ascending c per lane, then the butterfly).
     for (int j0 = wave; j0 < Cse; j0 += 16) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = ln; c < C; c += 64) {
-            const float mc = mean[c];
+        for (int c0 = ln; c0 < C; c0 += 256) {
+            float wv[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + 4 * u;
-                if (j < Cse) a[u] = fmaf(wr[(size_t)j * C + c], mc, a[u]);
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 4 * u, c = c0 + 64 * g;
+                    wv[g][u] = (j < Cse && c < C) ? wr[(size_t)j * C + c] : 0.f;
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c0 + 64 * g;
+                if (c < C) {
+                    const float mc = mean[c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + 4 * u < Cse) a[u] = fmaf(wv[g][u], mc, a[u]);
+                }
             }
         }
 #pragma unroll
@@ -181,16 +200,16 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
         }
     }
     __syncthreads();
-    // we_t [Cse][C] (transposed on the host): neighbouring lanes read neighbouring floats; eight loads in flight per thread
+    // we_t [Cse][C] (transposed on the host): neighbouring lanes read neighbouring floats; sixteen loads in flight per thread
     for (int c = threadIdx.x; c < C; c += 256) {
         float a = be[c];
         int j = 0;
-        for (; j + 8 <= Cse; j += 8) {
-            float wv[8];
+        for (; j + 16 <= Cse; j += 16) {
+            float wv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) wv[u] = we[(size_t)(j + u) * C + c];
+            for (int u = 0; u < 16; ++u) wv[u] = we[(size_t)(j + u) * C + c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a = fmaf(wv[u], rr[j + u], a);
+            for (int u = 0; u < 16; ++u) a = fmaf(wv[u], rr[j + u], a);
         }
         for (; j < Cse; ++j) a = fmaf(we[(size_t)j * C + c], rr[j], a);
         gate[(size_t)n * C + c] = 1.0f / (1.0f + expf(-a));
