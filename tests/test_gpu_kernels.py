@@ -469,6 +469,8 @@ WINO4_CASES = [
     (1, 1, 7, 64, 64, 1, False),
     (2, 6, 1, 8, 64, 5, True),
     (1, 50, 176, 64, 128, 1, True),
+    (1, 13, 18, 256, 128, 3, True),      # sigmoid + residual (ConvGRU update gate of V2VNet: the GENERAL instantiation)
+    (1, 13, 18, 256, 128, 4, True),      # tanh GATED by the residual operand
 ]
 
 
@@ -489,8 +491,12 @@ def test_winograd_f4x4_matches_fp64(lib, case):
     ref = (F.conv2d(x.double(), wt.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
     if relu == 1:
         ref = F.relu(ref)
+    elif relu == 3:
+        ref = torch.sigmoid(ref)
+    elif relu == 4:
+        ref = torch.tanh(ref)
     if with_res:
-        ref = ref + res.double()
+        ref = ref * res.double() if relu == 4 else ref + res.double()
     if relu == 5:
         ref = F.relu(ref)
     wp, coutp = pack_conv_weight(wt)
