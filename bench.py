@@ -189,6 +189,23 @@ MESSAGE = {"where2com": "the masked multi-scale features (15.8 MB per agent)",
            "when2com": "the warped maps + keys + the ego's query (36 MB per agent)"}
 
 
+def hbm_kernel_traffic(family, alg_bytes_per_launch):
+    """roofline.traffic of an HBM-bound kernel family from its PMC pass (tools/pmc_lin16b.sh: counters-only FETCH_SIZE / WRITE_SIZE
+    passes over tools/lin16_bench.py at 281 600 tokens): measured bytes / algorithmic bytes of the same launches, applied to this
+    run's launch mix.  None when no pass is committed for the family."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03b_pmc_linear_bf16.json")
+    if family != "linear_bf16" or not os.path.exists(path):
+        return {"traffic": None, "traffic_over_algorithmic": None, "traffic_note": "no PMC pass committed for this kernel"}
+    d = json.load(open(path))
+    tok = d["tokens"]
+    alg = {"256->1280": tok * (256 + 1280) * 2, "256->2304": tok * (256 + 2304) * 2, "256->256": tok * 512 * 2}
+    meas = sum(d["per_shape"][k]["bytes"] for k in alg)
+    ratio = meas / sum(alg.values())
+    return {"traffic": round(alg_bytes_per_launch * ratio), "traffic_over_algorithmic": round(ratio, 3),
+            "traffic_note": "PMC (2 x FETCH_SIZE + WRITE_SIZE, profiles/r03b_pmc_linear_bf16.json) over algorithmic bytes of the same "
+                            "launches at 281 600 tokens, applied to this run's launch mix"}
+
+
 def make_model(a, args, dev):
     """The drop-in module of --model with deterministic synthetic weights, on the device, eval mode."""
     from airv2x_perception_amd import synth
@@ -780,11 +797,10 @@ def main(argv=None, hooks=None, device=None):
                                                              "traffic", "algorithmic_bytes_per_launch") if k in res["roofline"]}
                 res["roofline"].update({
                     "bound": "hbm", "achieved": round(tv[1] / tv[3] / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(tv[1] / tv[3] / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
-                    "traffic_note": "no PMC pass for this kernel yet; tools/pmc_lin16.sh holds the counter groups",
+                    "frac": round(tv[1] / tv[3] / 1e9 / PEAK_HBM_GBPS, 4), **hbm_kernel_traffic(top, tv[1] / tv[0]),
                     "kernel": f"{top} (csrc/linear_bf16.hip: 64-token panels in LDS, W fragments from L2, bf16 in / out)" if top.startswith("linear") else top,
                     "launches_per_frame": tv[0] / a.steps, "avg_launch_us": round(tv[3] / tv[0] * 1e6, 2),
-                    "algorithmic_bytes_per_launch": round(tv[1] / tv[0]), "traffic_over_algorithmic": None,
+                    "algorithmic_bytes_per_launch": round(tv[1] / tv[0]),
                     "dominant_mfma_kernel": conv_view})
 
     # ---------------- CPU baseline: the oracle port on the host cores (bounded sample) ---------------------
