@@ -23,7 +23,7 @@ class ConvDesc(Structure):
     """struct av2x_conv_desc (include/airv2x_hip.h)."""
     _fields_ = [(n, c_int32) for n in (
         "n", "h", "w", "cin", "in_ctot", "in_coff", "ho", "wo", "cout", "coutp", "out_ctot", "out_coff",
-        "ks", "stride", "pad", "relu", "mode", "up", "tile", "sk_wgs")]
+        "ks", "stride", "pad", "relu", "mode", "up", "tile", "sk_wgs", "act16")]
 
 
 AV2X_CONV, AV2X_DECONV, AV2X_CONV_NCHW = 0, 1, 2

@@ -24,6 +24,7 @@ struct ConvParams {
     int M, tiles_n, cchunks, steps;
     unsigned in_bytes, w_bytes;
     unsigned long long out_bytes;   // whole output tensor
+    int in16, out16;                // conv_igemm_bf16 only: input / output activations stored as bf16
     // stream-K (SK kernels only): workgroup g first computes the whole tiles g, g + G, ... < sk_dp (data-parallel part:
     // sk_dp = the largest multiple of the grid size G that fits), then its share of the REMAINDER tiles sk_dp .. tiles-1,
     // whose (tile, K-step) iteration space of sk_total iterations is cut into contiguous ranges of sk_per; partial
@@ -47,7 +48,7 @@ constexpr int LDA = 36;
 // stores with 32-bit byte offsets whose invalid elements (row >= M, column >= cout) get an out-of-range offset the hardware drops.
 // The epilogue is straight-line code executed once per tile from a cold instruction cache: size is cost (see conv_wino4.inc).
 // Values are formed exactly as before: bit-identical results.
-template <int MT, int NT>
+template <int MT, int NT, bool OUT16 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[MT][NT], int mw, int nw, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     // the descriptor is based at the wave's first row (CONV) / first image (DECONV, NCHW) so that the 32-bit offsets stay small
@@ -56,8 +57,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
     const int img0 = p.mode == AV2X_CONV ? 0 : mwu / p.HoWo;
     const size_t base_elem = p.mode == AV2X_CONV ? (size_t)mwu * p.out_ctot
                              : p.mode == AV2X_DECONV ? (size_t)img0 * p.HoWo * p.up * p.up * p.out_ctot : (size_t)img0 * p.Cout * p.HoWo;
-    const unsigned long long left = p.out_bytes > base_elem * 4ull ? p.out_bytes - base_elem * 4ull : 0ull;
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out + base_elem, 0, (unsigned)(left < 0x7fffffffull ? left : 0x7fffffffull), 0x00020000);
+    // OUT16: the output tensor holds bf16 (AMP mode with bf16 activations, conv_igemm_bf16 only): same element offsets, 2-byte stores
+    constexpr unsigned ESZ = OUT16 ? 2u : 4u;
+    const unsigned long long left = p.out_bytes > base_elem * ESZ ? p.out_bytes - base_elem * ESZ : 0ull;
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.out) + base_elem * ESZ, 0,
+                                                                          (unsigned)(left < 0x7fffffffull ? left : 0x7fffffffull), 0x00020000);
     constexpr unsigned BAD = 0x80000000u;
     // ---- columns
     unsigned coloff[NT];
@@ -78,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
             const int di = ij / p.up, dj = ij - di * p.up;
             o = (unsigned)((di * (p.Wo * p.up) + dj) * p.out_ctot + p.out_coff + co);
         } else o = (unsigned)(co * p.HoWo);
-        coloff[c] = nok ? o * 4u : BAD;
+        coloff[c] = nok ? o * ESZ : BAD;
     }
     const bool relu1 = p.relu == 1;
     // ---- rows: the 16 rows of a lane in a row tile are m0 + {0,1,2,3, 8,..,11, 16,.., 24,..} (m0 = mw + 32 a + 4 lh).
@@ -102,7 +106,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
                 else if (p.mode == AV2X_DECONV) ro = (unsigned)((((img - img0) * p.Ho * p.up + ho * p.up) * (p.Wo * p.up) + wo * p.up) * p.out_ctot);
                 else ro = (unsigned)((img - img0) * p.Cout * p.HoWo + ho * p.Wo + wo);
                 const bool mok = m < p.M;
-                const unsigned rowoff = ro * 4u;
+                const unsigned rowoff = ro * ESZ;
 #pragma unroll
                 for (int c = 0; c < NT; ++c) {
                     float v = acc[a][c][r] * sc[c] + sh[c];
@@ -117,11 +121,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
                         else if (p.relu == 6) v = v / (1.0f + expf(-v));                                 // swish (EfficientNet MBConv)
                         if (p.mode == AV2X_CONV) {
                             if (p.res && off != BAD)
-                                v = (p.relu == 4) ? v * p.res[(size_t)m * p.Cout + cco[c]] : v + p.res[base_elem + (off >> 2)];
+                                v = (p.relu == 4) ? v * p.res[(size_t)m * p.Cout + cco[c]] : v + p.res[base_elem + off / ESZ];
                             if (p.relu == 5) v = fmaxf(v, 0.f);   // ReLU AFTER the residual add (ResNet BasicBlock)
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
+                    if constexpr (OUT16) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rout, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
                 }
                 // next row of this lane: +1, or +5 after every fourth
                 const int step = (r & 3) == 3 ? 5 : 1;

@@ -484,16 +484,21 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     p.steps = p.ks * p.ks * p.cchunks;
     p.tiles_n = 0;
     p.sk_per = 0; p.sk_total = 0; p.sk_dp = 0; p.ws = nullptr;
-    const unsigned long long in_bytes = (unsigned long long)d->n * d->h * d->w * d->in_ctot * 4ull;
+    p.in16 = d->act16 & 1; p.out16 = (d->act16 >> 1) & 1;
+    if (d->act16 & ~3) return av2x::fail("av2x_conv2d: act16=%d (bit 0: bf16 input activations, bit 1: bf16 output)", d->act16);
+    if (d->act16 && !(d->tile & 0x0800)) return av2x::fail("av2x_conv2d: bf16 activations need the bf16 matrix-core tiles (tile flag 0x0800)");
+    if (p.out16 && residual) return av2x::fail("av2x_conv2d: no residual operand with a bf16 output");
+    const unsigned long long in_bytes = (unsigned long long)d->n * d->h * d->w * d->in_ctot * (p.in16 ? 2ull : 4ull);
     const unsigned long long w_bytes = (unsigned long long)p.ks * p.ks * p.Cin * p.CoutP * 4ull;
     if (in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31))
         return av2x::fail("av2x_conv2d: input (%llu B) or weights (%llu B) exceed the 2 GiB buffer-descriptor window", in_bytes, w_bytes);
     p.in_bytes = (unsigned)in_bytes;
     p.w_bytes = (unsigned)w_bytes;
     // the epilogue addresses the output with 32-bit byte offsets through a buffer descriptor
-    const unsigned long long out_bytes = d->mode == AV2X_DECONV ? (unsigned long long)d->n * d->h * d->up * d->w * d->up * d->out_ctot * 4ull
-                                        : d->mode == AV2X_CONV ? (unsigned long long)M * d->out_ctot * 4ull
-                                                               : (unsigned long long)M * d->cout * 4ull;
+    const unsigned long long oesz = p.out16 ? 2ull : 4ull;
+    const unsigned long long out_bytes = d->mode == AV2X_DECONV ? (unsigned long long)d->n * d->h * d->up * d->w * d->up * d->out_ctot * oesz
+                                        : d->mode == AV2X_CONV ? (unsigned long long)M * d->out_ctot * oesz
+                                                               : (unsigned long long)M * d->cout * oesz;
     if (d->mode != AV2X_CONV && out_bytes / (unsigned long long)d->n >= (1ull << 30))
         return av2x::fail("av2x_conv2d: one output image (%llu B) exceeds the 1 GiB window of the epilogue's 32-bit offsets", out_bytes / d->n);
     if ((unsigned long long)d->out_ctot * 4ull * 256ull >= (1ull << 30)) return av2x::fail("av2x_conv2d: out_ctot too large");
@@ -521,11 +526,11 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
         p.w_bytes = (unsigned)(w_bytes / 2);
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
         const bool w8b = (d->tile & 0x8000) != 0;
-        if (w8b && bm == 128 && bn == 128) return launch_bf16<128, 128, 64, 32>(p, st);
-        if (w8b && bm == 128 && bn == 64) return launch_bf16<128, 64, 32, 32>(p, st);
+        if (w8b && bm == 128 && bn == 128) return launch_bf16<128, 128, 64, 32, true>(p, st);
+        if (w8b && bm == 128 && bn == 64) return launch_bf16<128, 64, 32, 32, true>(p, st);
         if (!w8b && bm == 128 && bn == 128) return launch_bf16<128, 128, 64, 64>(p, st);
         if (!w8b && bm == 128 && bn == 64) return launch_bf16<128, 64, 64, 32>(p, st);
-        if (!w8b && bm == 64 && bn == 64) return launch_bf16<64, 64, 32, 32>(p, st);
+        if (!w8b && bm == 64 && bn == 64) return launch_bf16<64, 64, 32, 32, true>(p, st);
         if (!w8b && bm == 128 && bn == 32) return launch_bf16<128, 32, 32, 32>(p, st);
         return av2x::fail("av2x_conv2d: unsupported bf16 tile %dx%d", bm, bn);
     }

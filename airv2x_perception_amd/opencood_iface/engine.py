@@ -459,6 +459,13 @@ class Where2ComEngine:
         d.out_coff = out_coff
         d.ks, d.stride, d.pad, d.relu, d.mode, d.up = L.ks, L.stride, L.pad, L.relu, L.mode, L.up
         d.sk_wgs = 0
+        # bf16 ACTIVATIONS (AMP mode only): the tensors' dtypes say how input and output are stored (csrc/conv_igemm_bf16.inc IN16 / OUT16)
+        a16 = (1 if x.dtype == torch.bfloat16 else 0) | (2 if out.dtype == torch.bfloat16 else 0)
+        if a16 and not self.amp:
+            raise RuntimeError("bf16 activation tensors outside AMP mode")
+        if a16 & 2 and residual is not None:
+            raise RuntimeError("no residual operand with a bf16 output")
+        d.act16 = a16
         wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         vflag = 0x0800 if self.amp else (0x0400 if self.split3 else 0)
         if self.winograd and self.wino4 and not self.conv_tile and vflag == 0 and self.wino4_rule(L, n, d.ho, d.wo):
@@ -479,12 +486,14 @@ class Where2ComEngine:
             d.sk_wgs = self.conv_sk_wgs if (d.tile & 0x2000) else 0
         elif self.autotune:
             skc = self.sk_class(n * d.ho * d.wo, L, vflag)
-            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, skc, vflag)
+            key = (L.mode, n * d.ho * d.wo, L.cin, L.coutp, L.ks, L.stride, skc, vflag) + ((f"a16={a16}",) if a16 else ())
             t = self.tile_cache.get(key)
             if t is None:
                 t = self._tune(d, x, L, out, skc, key)
                 self.tile_cache[key] = t
             d.tile, d.sk_wgs = t
+        elif a16:
+            d.tile = (128 << 16) | (64 if L.coutp % 128 else 128) | 0x8800
         else:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
             d.tile = (bm << 16) | bn | vflag
@@ -576,6 +585,8 @@ class Where2ComEngine:
     # AMP mode: conv_igemm_bf16 tiles (flag 0x0800; 0x8000 = 8 waves)
     AMP_CANDIDATES = ((128, 128 | 0x8800, 0), (128, 64 | 0x8800, 0), (64, 64 | 0x0800, 0), (128, 64 | 0x0800, 0),
                       (128, 128 | 0x0800, 0), (128, 32 | 0x0800, 0))
+    # ... the ones instantiated for bf16 activation storage (ConvDesc.act16)
+    AMP_ACT16_CANDIDATES = ((128, 128 | 0x8800, 0), (128, 64 | 0x8800, 0), (64, 64 | 0x0800, 0))
 
     def sk_class(self, m, L, vflag=0):
         """Numerics class of a conv launch: "rule" = the fixed stream-K schedule applies (a pure function of the shape),
@@ -645,7 +656,9 @@ class Where2ComEngine:
         if skc == "wino":
             return [(bm, bn, 0) for bm, bn in self.WINO_CANDIDATES if L.cout % (bn & 0x01ff) == 0
                     and not (self.throughput_mode and (bn & 0x81ff) == (32 | 0x8000))]
-        if self.amp:
+        if self.amp and d.act16:
+            cands = list(self.AMP_ACT16_CANDIDATES)
+        elif self.amp:
             cands = list(self.AMP_CANDIDATES)
         elif self.split3:   # + the double-buffered forms (0x4000: second LDS buffer set, one barrier per K-step)
             cands = [(bm, (bn & ~0x0800) | 0x0400, g) for bm, bn, g in self.AMP_CANDIDATES]
@@ -673,6 +686,8 @@ class Where2ComEngine:
             if skc == "rule":
                 bm, bn, g = cands[-1]
                 return (bm << 16) | bn, g
+            if d.act16:
+                return (128 << 16) | (64 if L.coutp % 128 else 128) | 0x8800, 0
             bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
             return (bm << 16) | bn | (0x0800 if self.amp else (0x0400 if self.split3 else 0)), 0
         skey = "|".join(str(v) for v in key) if key is not None else None
@@ -686,6 +701,8 @@ class Where2ComEngine:
             if skc == "rule":
                 bm, bn, g = cands[-1]
                 return (bm << 16) | bn, g
+            if d.act16:
+                return (128 << 16) | (64 if L.coutp % 128 else 128) | 0x8800, 0
             bm, bn = self.pick_tile(d.n * d.ho * d.wo, L.coutp)
             return (bm << 16) | bn | (0x0800 if self.amp else (0x0400 if self.split3 else 0)), 0
         if not cands:
@@ -695,7 +712,7 @@ class Where2ComEngine:
         # tune into a scratch output: `out` may alias the input / residual (in-place transformer updates)
         ho = d.ho * (L.up if L.mode == _lib.AV2X_DECONV else 1)
         wo = d.wo * (L.up if L.mode == _lib.AV2X_DECONV else 1)
-        scratch = torch.empty(d.n * ho * wo * max(d.out_ctot, L.cout), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(d.n * ho * wo * max(d.out_ctot, L.cout), dtype=torch.bfloat16 if d.act16 & 2 else torch.float32, device=self.device)
         ws = self.sk_workspace()
         st = self.stream()
         for bm, bn, g in cands:
@@ -723,6 +740,13 @@ class Where2ComEngine:
             self.tune_store(skey, best)
         return best
 
+    # AMP mode of an engine whose fusion keeps bf16 activations (V2XViTEngine): the trunk's intermediate maps are stored as bf16 too
+    # (what autocast stores between two Conv2d); buffers handed in by the caller keep their own dtype
+    act16_trunk = False
+
+    def trunk_dtype(self):
+        return torch.bfloat16 if (self.amp and self.act16_trunk) else torch.float32
+
     def run_block(self, i, x, n, h, w, tag, out=None):
         """backbone.blocks[i] on n images; returns (buffer, ho, wo).  ``out``: write the block's
         result into this (n,ho,wo,c) buffer (e.g. a slice of the all-gather send buffer)."""
@@ -730,10 +754,11 @@ class Where2ComEngine:
         c = layers[0].cout
         ho = (h + 2 - 3) // layers[0].stride + 1
         wo = (w + 2 - 3) // layers[0].stride + 1
-        ping = self.buf(f"blk{i}_ping_{tag}", (n, ho, wo, c))
-        pong = self.buf(f"blk{i}_pong_{tag}", (n, ho, wo, c))
+        td = self.trunk_dtype()
+        ping = self.buf(f"blk{i}_ping_{tag}", (n, ho, wo, c), td)
+        pong = self.buf(f"blk{i}_pong_{tag}", (n, ho, wo, c), td)
         if out is None:
-            out = self.buf(f"blk{i}_out_{tag}", (n, ho, wo, c))
+            out = self.buf(f"blk{i}_out_{tag}", (n, ho, wo, c), td)
         cur, ch, cw = x, h, w
         for li, L in enumerate(layers):
             dst = out if li == len(layers) - 1 else (ping if li % 2 == 0 else pong)
@@ -752,7 +777,9 @@ class Where2ComEngine:
     def run_shrink(self, x, n, h, w, tag, out=None):
         cur, cin_tot = x, self.cat_c
         for li, L in enumerate(self.shrink):
-            dst = out if (out is not None and li == len(self.shrink) - 1) else self.buf(f"shrink{li}_{tag}", (n, h, w, L.cout))
+            last = li == len(self.shrink) - 1
+            dst = out if (out is not None and last) else self.buf(f"shrink{li}_{tag}", (n, h, w, L.cout),
+                                                                   torch.float32 if last else self.trunk_dtype())
             self.conv(L, cur, n, h, w, dst, in_ctot=cin_tot)
             cur, cin_tot = dst, L.cout
         return cur
@@ -896,7 +923,7 @@ class Where2ComEngine:
             x, h, w = self.run_block(i, x, n, h, w, tag, out=(block_out or {}).get(i))
             feats.append((x, h, w))
         H, W = feats[0][1] * self.deblocks[0].up, feats[0][2] * self.deblocks[0].up
-        cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c))
+        cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c), self.trunk_dtype())
         self.run_deblocks(feats, n, cat)
         s = self.run_shrink(cat, n, H, W, tag, out=shrink_out) if self.shrink else cat
         return feats, s, H, W

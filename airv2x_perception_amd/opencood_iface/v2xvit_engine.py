@@ -232,6 +232,10 @@ class V2XViTEngine(Where2ComEngine):
     # GEMM of csrc/linear_bf16.hip.  These layers are HBM-bound (K = 256), so bytes are what the mode saves.
     bf16_activations = True
 
+    @property
+    def act16_trunk(self):          # the trunk follows the fusion's storage mode
+        return bool(self.bf16_activations)
+
     def lin16(self, L, a16, m_rows, out, residual=None, out_ctot=None, out_coff=0):
         """out = act(a16 (m_rows, 256) bf16 . W + b) (+ residual): ``out`` bf16 or fp32 (dtype decides)."""
         w, coutp = _w16i(L)

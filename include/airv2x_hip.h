@@ -123,6 +123,9 @@ typedef struct av2x_conv_desc {
                                   | 0x0800 (bf16 matrix-core operands: `w` is the bf16 packing, see below)
                                   | 0x0400 (split-3: fp32-accurate products from three bf16 terms, see below) */
     int32_t sk_wgs;            /* stream-K / persistent: number of workgroups launched (else ignored) */
+    int32_t act16;             /* bf16 tiles (0x0800) only: bit 0 = the INPUT activations are bf16 in memory, bit 1 = the OUTPUT is written as
+                                * bf16 (AMP mode with bf16 activations: what autocast stores between two Conv2d); in_ctot / out_ctot / offsets stay
+                                * in elements; served by the 8-wave 128x128 / 128x64 and the 64x64 tiles; no residual with a bf16 output; 0 = fp32 */
 } av2x_conv_desc;
 
 int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
