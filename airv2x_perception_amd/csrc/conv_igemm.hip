@@ -404,6 +404,7 @@ int launch_sk(const ConvParams& p, int wgs, float* ws, unsigned long long ws_byt
 #include "conv_igemm_glds.inc"
 #include "conv_wino.inc"
 #include "conv_wino4.inc"
+#include "conv_halo_bf16.inc"
 
 }  // namespace
 
@@ -524,6 +525,7 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     }
     if (d->tile & 0x0800) {   // bf16 matrix-core operands ("AMP" mode): w is the bf16 packing [tap][cin/8][coutp][8]
         p.w_bytes = (unsigned)(w_bytes / 2);
+        if (d->tile & 0x10000000) return halo_bf16_dispatch(d, p, residual, st);   // halo-tile direct convolution on bf16 activations
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
         const bool w8b = (d->tile & 0x8000) != 0;
         if (w8b && bm == 128 && bn == 128) return launch_bf16<128, 128, 64, 32, true>(p, st);

@@ -38,7 +38,7 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if hasattr(to
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i", "_wu4")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i", "_wu4", "_w16h")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
@@ -47,6 +47,7 @@ class ConvLayer:
         self._wu = None
         self._w16i = None
         self._wu4 = None
+        self._w16h = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
 
@@ -63,6 +64,19 @@ def _w16i(L):
     if L._w16i is None:
         L._w16i = interleave2_columns(_w16(L))
     return L._w16i
+
+
+def _w16h(L):
+    """(bf16 k-oct packing with the columns zero-padded to a multiple of 128, that column count): what the halo-tile direct convolution
+    on bf16 activations walks (csrc/conv_halo_bf16.inc)."""
+    if L._w16h is None:
+        w = _w16(L)
+        T, q, n, eight = w.shape
+        npad = (n + 127) // 128 * 128
+        if npad != n:
+            w = torch.cat([w, torch.zeros(T, q, npad - n, 8, dtype=w.dtype, device=w.device)], 2).contiguous()
+        L._w16h = (w, npad)
+    return L._w16h
 
 
 def _w3(L):
@@ -468,7 +482,10 @@ class Where2ComEngine:
         d.act16 = a16
         wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         vflag = 0x0800 if self.amp else (0x0400 if self.split3 else 0)
-        if self.winograd and self.wino4 and not self.conv_tile and vflag == 0 and self.wino4_rule(L, n, d.ho, d.wo):
+        if (a16 & 1) and self.halo16 and not self.conv_tile and self.halo16_rule(L) and residual is None:
+            wgt, d.coutp = _w16h(L)                     # halo-tile direct convolution on bf16 activations: a rule, not a timing
+            d.tile = self.HALO16_TILE
+        elif self.winograd and self.wino4 and not self.conv_tile and vflag == 0 and self.wino4_rule(L, n, d.ho, d.wo):
             wgt = _wu4(L, self.lib, self.stream())      # the F(4x4,3x3) class: a pure function of the layer's shape
             d.tile = self.WINO4_TILE
         elif self.winograd and not self.conv_tile and vflag == 0 and self.wino_rule(L):
@@ -514,6 +531,8 @@ class Where2ComEngine:
             ncols = L.coutp if L.mode == _lib.AV2X_DECONV else L.cout
             if bm & 0x2000:   # Winograd F(4x4,3x3): 32-tile blocks of 4x4 outputs x (cout / 64)
                 wgs = -(-(n * ((d.ho + 3) // 4) * ((d.wo + 3) // 4)) // 32) * (L.cout // 64)
+            elif bm & 0x1000:   # halo-tile direct convolution on bf16 activations: 8 x 16 output pixels x 128 couts
+                wgs = n * ((d.ho + 7) // 8) * ((d.wo + 15) // 16) * (d.coutp // 128)
             elif bm & 0x4000:   # Winograd: (32 x TB-tile blocks of 2x2 outputs) x (cout / CB)
                 wgs = -(-(n * ((d.ho + 1) // 2) * ((d.wo + 1) // 2)) // (bm & 0x3fff)) * (L.cout // (bn & 0x01ff))
             else:
@@ -562,6 +581,17 @@ class Where2ComEngine:
         if not (self.wino_rule(L) and L.cin >= self.WINO4_MIN_CIN):
             return False
         return -(-(((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64) >= self.WINO4_MIN_WGS_PER_IMAGE
+
+    # AMP mode with bf16 activation storage: 1x1 / 3x3 stride-1 layers run as the halo-tile direct convolution (csrc/conv_halo_bf16.inc:
+    # every input byte crosses L2 -> CU once per 64-channel chunk instead of once per tap).  Its K order differs from conv_igemm_bf16's,
+    # so it is chosen by this rule (a function of the layer), never by timing.
+    HALO16_TILE = 0x10000000 | (128 << 16) | 128 | 0x0800
+    halo16 = os.environ.get("AV2X_HALO16", "1") != "0"
+
+    @staticmethod
+    def halo16_rule(L):
+        return (L.mode == _lib.AV2X_CONV and L.stride == 1 and L.ks in (1, 3) and L.pad == L.ks // 2 and L.relu in (0, 1)
+                and L.cin % 64 == 0 and L.cout >= 128)
 
     # BM, BN | 0x8000 (8-wave workgroup) | 0x4000 (prefetch distance 2 / third LDS stage) | 0x0200 (LDS-DMA operand path)
     TILE_CANDIDATES = ((128, 128), (128, 64), (64, 64), (64, 128), (128, 128 | 0x8000), (128, 64 | 0x8000),

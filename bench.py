@@ -716,7 +716,7 @@ def main(argv=None, hooks=None, device=None):
         tot_fl = sum(v[1] for v in per.values())
         tot_exe = sum(v[3] for v in per.values())
         tot_s = sum(v[2] for v in per.values())
-        tkey = lambda k: f"{('w4_' if k[0] & 0x2000 else 'w') if k[0] & 0x4000 else ''}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x1fff}x{k[1] & 0x01ff}{(('q' if (k[1] & 0x01ff) == 32 else 'h') if k[0] & 0x4000 else 'w8') if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
+        tkey = lambda k: f"{('w4_' if k[0] & 0x2000 else 'w') if k[0] & 0x4000 else ('halo' if k[0] & 0x1000 else '')}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x0fff}x{k[1] & 0x01ff}{(('q' if (k[1] & 0x01ff) == 32 else 'h') if k[0] & 0x4000 else 'w8') if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
         peak = PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS
         res["roofline"] = {

@@ -189,6 +189,56 @@ def test_split_attention_bf16_is_the_fp32_kernel_on_bf16_storage():
     assert torch.equal(o16, o32)
 
 
+HALO_TILE = 0x10000000 | (128 << 16) | 128 | 0x0800
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,ks,relu,out16,ctot,coff", [
+    (2, 25, 88, 256, 256, 3, 1, True, 256, 0),       # block 2 of the trunk
+    (1, 50, 176, 128, 128, 3, 1, True, 128, 0),
+    (3, 9, 13, 64, 128, 3, 0, False, 128, 0),        # partly empty 8 x 16 blocks, fp32 out (the last shrink layer)
+    (2, 20, 36, 384, 256, 1, 1, True, 256, 0),       # 1x1 over the concatenated map
+    (1, 8, 16, 128, 256, 3, 1, True, 384, 128),      # output written into a channel slice
+    (1, 1, 5, 64, 96, 3, 1, True, 96, 0),            # one-row map; cout < coutp (zero-padded weight columns are never stored)
+])
+def test_halo_conv_on_bf16_activations_equals_fp32_conv_of_the_same_operands(n, h, w, cin, cout, ks, relu, out16, ctot, coff):
+    """csrc/conv_halo_bf16.inc: bf16 input activations and weights (products exact in fp32), fp32 accumulation, folded BN + ReLU,
+    one rounding to bf16 (or fp32 out) -- against a float64 convolution of the same bf16 operands."""
+    from ctypes import byref
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, to_bf16_koct
+    lib = _lib.load()
+    g = _g(cin + cout + h + ks)
+    x = torch.randn(n, cin, h, w, generator=g).to(BF)
+    wt = (torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks)).to(BF)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), None, padding=ks // 2) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    wp, coutp = pack_conv_weight(wt.float())
+    coutp128 = (coutp + 127) // 128 * 128
+    if coutp128 != coutp:       # the halo tile walks 128 columns at a time: pad the packed weights with zero columns
+        wp = torch.cat([wp, torch.zeros(wp.shape[0], wp.shape[1], coutp128 - coutp, 4)], 2)
+    wh = to_bf16_koct(wp).cuda()
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.full((n, h, w, ctot), 7.0, device="cuda").to(BF if out16 else torch.float32)
+    sc, sh = scale.cuda(), shift.cuda()
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=cin, in_coff=0, ho=h, wo=w, cout=cout, coutp=coutp128, out_ctot=ctot, out_coff=coff,
+                      ks=ks, stride=1, pad=ks // 2, relu=relu, mode=0, up=1, tile=HALO_TILE, sk_wgs=0, act16=1 | (2 if out16 else 0))
+    _lib.check(lib.av2x_conv2d_res(byref(d), _p(xd), _p(wh), _p(sc), _p(sh), None, _p(out), _st()), "halo conv")
+    got = out.float().cpu()[..., coff:coff + cout].double()
+    if out16:
+        err = (got - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-5).all()), float(err.max())
+        assert float((got == ref.float().to(BF).double()).float().mean()) > 0.97
+    else:
+        assert_close(got.numpy(), ref.numpy(), 2e-5, 2e-5, "halo conv fp32 out")
+    if ctot > cout:
+        o = out.float().cpu()
+        assert bool((o[..., :coff] == 7.0).all()) and bool((o[..., coff + cout:] == 7.0).all())
+    # argument checks: fp32 input, stride 2, a residual
+    d.act16 = 2
+    assert lib.av2x_conv2d_res(byref(d), _p(xd), _p(wh), _p(sc), _p(sh), None, _p(out), _st()) != 0
+
+
 @pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n8"])
 def test_v2xvit_bf16_activations_against_fp32_activation_amp_and_the_reference(name):
     """The same AMP frame with bf16 and with fp32 activation storage: both within the drift bound of tests/test_amp.py against the
