@@ -140,6 +140,8 @@ SIGNATURES = {
     "av2x_add_layernorm_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "av2x_linear_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_ln_linear_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int32, c_int32,
+                                      c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     "av2x_hgt_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]),
     "av2x_window_attention_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,

@@ -19,6 +19,8 @@
 //   C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 //
 //   layernorm_bf16_kernel   nn.LayerNorm over C = 256 of the fp32 residual stream, bf16 out (the A operand above)
+#include <type_traits>
+
 #include "av2x_common.hpp"
 
 namespace {
@@ -38,7 +40,42 @@ struct LinParams {
     long long M;
     int Cout, CoutP, out_ctot, out_coff, res_ctot, res_coff, act;
     unsigned w_bytes;
+    // LayerNorm fused into the panel load (linear_bf16_occ_kernel<true, .>): the fp32 residual stream, the pending bf16 residual of the
+    // first add_rows rows, the affine parameters
+    float* x;
+    const __bf16* delta;
+    long long add_rows;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    // second Linear 256 -> 256 on the LDS-resident hidden panel (linear_bf16_occ_kernel<., true>: the FeedForward pair)
+    const __bf16* w2;
+    const float* bias2;
+    int act2;
 };
+
+// nn.LayerNorm over C = 256 of one token held as four channels per lane of a wave (the ONE definition both the stand-alone
+// LayerNorm kernel and the fused panel load use: their outputs are the same bits)
+__device__ __forceinline__ f32x4 layernorm_row_256(const float4 v, const float4 g, const float4 bt, const float eps) {
+    constexpr int C = 256;
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    float q = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    const f32x4 r = {a * rstd * g.x + bt.x, b * rstd * g.y + bt.y, c * rstd * g.z + bt.z, d * rstd * g.w + bt.w};
+    return r;
+}
+
+__device__ __forceinline__ float4 add_bf16x4(float4 v, const uint2 u) {
+    v.x += __builtin_bit_cast(float, u.x << 16); v.y += __builtin_bit_cast(float, u.x & 0xffff0000u);
+    v.z += __builtin_bit_cast(float, u.y << 16); v.w += __builtin_bit_cast(float, u.y & 0xffff0000u);
+    return v;
+}
 
 // cache policy of the streamed operands (A panel loads, output stores): non-temporal, so that 1.3 GB of output passing through
 // the 4 MB L2 of an XCD does not evict the 1.2 MB of weights every workgroup re-reads
@@ -71,6 +108,14 @@ __device__ __forceinline__ float erf_as(float x) {
 // stores of chunk i between the MFMAs of chunk i + 1 (the vector-memory counter is in order over loads AND stores: the next
 // W fragment cannot be consumed before the older stores are acknowledged), nor non-temporal hints changed the sum.  Next
 // step (not done): W tiles shared through LDS by an 8-wave workgroup to cut the L2->CU traffic four-fold.
+//
+// LN = true: the panel is LayerNorm(x (+ delta on the first add_rows rows)) of the fp32 residual stream, computed while it is loaded
+// (wave w: rows 16 w .. 16 w + 15, four channels per lane, layernorm_row_256) and x is written back where delta was added: the
+// normalised bf16 tensor never exists in HBM (288 MB written + read per LayerNorm at 8 agents).
+// FFN = true (Cout = CoutP = 256): the activated bf16 output panel goes back into the SAME LDS panel (all waves are past their K
+// loop) and a second Linear 256 -> 256 (w2, bias2, act2) runs on it: FeedForward's hidden tensor never exists in HBM either.
+// Both produce exactly the bits of the separate launches (same MFMA sequence per output, same roundings).
+template <bool LN, bool FFN>
 __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams p) {
     constexpr int BMO = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
@@ -80,22 +125,55 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
     const int li = lane & 31, lh = lane >> 5;
     const long long m0 = (long long)blockIdx.x * BMO;
     const int rows = (int)((p.M - m0) < BMO ? (p.M - m0) : BMO);
-    const int nchunks = p.CoutP >> 8;
+    const int nchunks = FFN ? 1 : (p.CoutP >> 8);
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(FFN ? p.w2 : p.w), 0, p.w_bytes, 0x00020000);
     const unsigned voffB = (unsigned)((lh * p.CoutP + wave * 64 + li) * 16);
     const unsigned step_stride = (unsigned)(2 * p.CoutP * 16);
     u32x4 bf[4][2];
-    auto loadB = [&](u32x4 (&dst)[2], int ch, int s) {
+    auto loadB = [&](u32x4 (&dst)[2], const __amdgpu_buffer_rsrc_t r, int ch, int s) {
         const unsigned so = (unsigned)s * step_stride + (unsigned)ch * (256 * 16);
-        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffB, so, 0);
-        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffB + 32 * 16, so, 0);
+        dst[0] = __builtin_amdgcn_raw_buffer_load_b128(r, voffB, so, 0);
+        dst[1] = __builtin_amdgcn_raw_buffer_load_b128(r, voffB + 32 * 16, so, 0);
     };
-    loadB(bf[0], 0, 0);
-    loadB(bf[1], 0, 1);
-    loadB(bf[2], 0, 2);
-    loadB(bf[3], 0, 3);
-    {
+    loadB(bf[0], rw, 0, 0);
+    loadB(bf[1], rw, 0, 1);
+    loadB(bf[2], rw, 0, 2);
+    loadB(bf[3], rw, 0, 3);
+    if constexpr (LN) {
+        // rows beyond M read zeros (buffer range) and their outputs are dropped by the output range below
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.x + m0 * LK, 0, (unsigned)rows * (LK * 4), 0x00020000);
+        long long addl = p.add_rows - m0;
+        const int addr = (int)(addl < 0 ? 0 : (addl > rows ? rows : addl));     // rows [0, addr) of the panel receive delta
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.delta ? p.delta + m0 * LK : nullptr), 0,
+                                                                            p.delta ? (unsigned)addr * (LK * 2) : 0u, 0x00020000);
+        const float4 g = reinterpret_cast<const float4*>(p.gamma)[lane], bt = reinterpret_cast<const float4*>(p.beta)[lane];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 xv[8];
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = wave * 16 + half * 8 + j;
+                xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(r * (LK * 4) + lane * 16), 0, LIN_NT));
+                dv[j] = __builtin_amdgcn_raw_buffer_load_b64(rd, (unsigned)(r * (LK * 2) + lane * 8), 0, LIN_NT);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = wave * 16 + half * 8 + j;
+                float4 v = make_float4(xv[j][0], xv[j][1], xv[j][2], xv[j][3]);
+                if (r < addr) {      // wave-uniform
+                    v = add_bf16x4(v, make_uint2(dv[j][0], dv[j][1]));
+                    const f32x4 vv = {v.x, v.y, v.z, v.w};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rx, (unsigned)(r * (LK * 4) + lane * 16), 0, LIN_NT);
+                }
+                const f32x4 y = layernorm_row_256(v, g, bt, p.eps);
+                *reinterpret_cast<bf16x4*>(As + r * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
+            }
+        }
+    } else {
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.a + m0 * LK), 0,
                                                                             (unsigned)rows * (LK * 2), 0x00020000);
         u32x4 va[8];
@@ -113,15 +191,15 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                                                                           (unsigned)((size_t)rows * obytes), 0x00020000);
     const __bf16* Ab = As + li * LROW + lh * 8;
     const bool odd = li & 1, hi = li & 2;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        f32x16 acc[2][2];
+    f32x16 acc[2][2];
+    // K loop of one 256-column chunk `ch` of weights `rcur`, prefetching the first four steps of chunk `chn` of `rnext`
+    auto kloop = [&](const __amdgpu_buffer_rsrc_t rcur, int ch, const __amdgpu_buffer_rsrc_t rnext, int chn) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-        const int chn = ch + 1 < nchunks ? ch + 1 : ch;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab + s * 16);
@@ -132,14 +210,18 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                 acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][c], 0, 0, 0);
                 acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][c], 0, 0, 0);
             }
-            if (s + 4 < 16) loadB(bf[s & 3], ch, s + 4);
-            else loadB(bf[s & 3], chn, s + 4 - 16);
+            if (s + 4 < 16) loadB(bf[s & 3], rcur, ch, s + 4);
+            else loadB(bf[s & 3], rnext, chn, s + 4 - 16);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- epilogue: bias, activation, one rounding, 4 x 4 quad transposes, 16-byte stores (8 rows x 128 B per instruction)
+    };
+    // epilogue: bias, activation, one rounding, 4 x 4 quad transposes, 16-byte stores (8 rows x 128 B per instruction) to the
+    // output rows -- or (TO_LDS) into the panel, as the A operand of the second Linear
+    auto epilogue = [&](int ch, const float* bias, int act, auto to_lds) {
+        constexpr bool TO_LDS = decltype(to_lds)::value;
         const int n = ch * 256 + wave * 64 + 2 * li;
         float b0 = 0.f, b1 = 0.f;
-        if (p.bias && n < p.Cout) { b0 = p.bias[n]; b1 = p.bias[n + 1]; }
+        if (bias && n < p.Cout) { b0 = bias[n]; b1 = bias[n + 1]; }
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         int ostride = p.out_ctot * 2;
@@ -155,9 +237,9 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
                     f32x2 v = {acc[a][0][r] + b0, acc[a][1][r] + b1};
-                    if (p.act == 1) {
+                    if (act == 1) {
                         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                    } else if (p.act == 2) {
+                    } else if (act == 2) {
                         v[0] = 0.5f * v[0] * (1.0f + erf_as(v[0] * 0.70710678118654752f));
                         v[1] = 0.5f * v[1] * (1.0f + erf_as(v[1] * 0.70710678118654752f));
                     }
@@ -178,8 +260,25 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                     R[m + 2] = hi ? R[m + 2] : got;
                 }
                 const u32x4 v4 = {R[0], R[1], R[2], R[3]};
-                __builtin_amdgcn_raw_buffer_store_b128(v4, rout, off0 + (unsigned)((a * 32 + 8 * g) * ostride), 0, LIN_NT);
+                if constexpr (TO_LDS)
+                    *reinterpret_cast<u32x4*>(As + (a * 32 + 8 * g + 4 * lh + (li & 3)) * LROW + wave * 64 + 2 * (li & ~3)) = v4;
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, rout, off0 + (unsigned)((a * 32 + 8 * g) * ostride), 0, LIN_NT);
             }
+    };
+    if constexpr (FFN) {
+        kloop(rw, 0, rw2, 0);
+        __syncthreads();                       // every wave is past its reads of the input panel
+        epilogue(0, p.bias, p.act, std::true_type{});
+        __syncthreads();
+        kloop(rw2, 0, rw2, 0);
+        epilogue(0, p.bias2, p.act2, std::false_type{});
+    } else {
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int chn = ch + 1 < nchunks ? ch + 1 : ch;
+            kloop(rw, ch, rw, chn);
+            epilogue(ch, p.bias, p.act, std::false_type{});
+        }
     }
 }
 
@@ -317,23 +416,11 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(float4* __restrict_
     constexpr int C = 256;
     float4 v = x[(size_t)tok * (C / 4) + lane];
     if (ADD) {
-        const uint2 u = *reinterpret_cast<const uint2*>(delta + (size_t)tok * C + 4 * lane);
-        v.x += __builtin_bit_cast(float, u.x << 16); v.y += __builtin_bit_cast(float, u.x & 0xffff0000u);
-        v.z += __builtin_bit_cast(float, u.y << 16); v.w += __builtin_bit_cast(float, u.y & 0xffff0000u);
+        v = add_bf16x4(v, *reinterpret_cast<const uint2*>(delta + (size_t)tok * C + 4 * lane));
         x[(size_t)tok * (C / 4) + lane] = v;
         if (!y) return;
     }
-    float s = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)C;
-    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-    float q = (a * a + b * b) + (c * c + d * d);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    const float4 g = gamma[lane], bt = beta[lane];
-    const f32x4 r = {a * rstd * g.x + bt.x, b * rstd * g.y + bt.y, c * rstd * g.z + bt.z, d * rstd * g.w + bt.w};
+    const f32x4 r = layernorm_row_256(v, gamma[lane], beta[lane], eps);
     *reinterpret_cast<bf16x4*>(y + (size_t)tok * C + 4 * lane) = __builtin_convertvector(r, bf16x4);
 }
 
@@ -363,13 +450,42 @@ extern "C" int av2x_linear_bf16(const uint16_t* a, const uint16_t* w_packed, con
     const unsigned grid = (unsigned)((m + LBM - 1) / LBM);
     hipStream_t st = av2x::as_stream(stream);
     if (out_is_bf16) {
-        hipLaunchKernelGGL(linear_bf16_occ_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), (size_t)64 * LROW * 2, st, p);
+        hipLaunchKernelGGL((linear_bf16_occ_kernel<false, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), (size_t)64 * LROW * 2, st, p);
     } else {
         static av2x::LdsLimit lim;
         lim.ensure(reinterpret_cast<const void*>(&linear_bf16_kernel<false>), lds);
         hipLaunchKernelGGL(linear_bf16_kernel<false>, dim3(grid), dim3(256), lds, st, p);
     }
     return av2x::check_launch("linear_bf16_kernel");
+}
+
+extern "C" int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, const float* gamma, const float* beta, float eps,
+                                   const uint16_t* w_packed, const float* bias, int32_t act, int32_t cout, int32_t coutp,
+                                   const uint16_t* w2_packed, const float* bias2, int32_t act2, uint16_t* out, int32_t out_ctot,
+                                   int32_t out_coff, int64_t m, av2x_stream_t stream) {
+    if (m == 0) return 0;
+    if (!x || !gamma || !beta || !w_packed || !out) return av2x::fail("av2x_ln_linear_bf16: null argument");
+    if (m < 0 || add_rows < 0 || add_rows > m || (add_rows && !delta))
+        return av2x::fail("av2x_ln_linear_bf16: bad row counts (m=%lld add_rows=%lld)", (long long)m, (long long)add_rows);
+    if (coutp <= 0 || coutp % 256 || cout <= 0 || cout > coutp || cout % 8 || out_ctot % 8 || out_coff % 8)
+        return av2x::fail("av2x_ln_linear_bf16: bad sizes (cout=%d coutp=%d out_ctot=%d out_coff=%d)", cout, coutp, out_ctot, out_coff);
+    if (act < 0 || act > 2 || act2 < 0 || act2 > 2) return av2x::fail("av2x_ln_linear_bf16: act unsupported (0 none, 1 ReLU, 2 GELU)");
+    if (w2_packed && (cout != 256 || coutp != 256)) return av2x::fail("av2x_ln_linear_bf16: the fused second Linear needs a hidden width of 256");
+    if (out_coff + (w2_packed ? 256 : cout) > out_ctot) return av2x::fail("av2x_ln_linear_bf16: bad output slice");
+    LinParams p = {};
+    p.a = nullptr;
+    p.w = reinterpret_cast<const __bf16*>(w_packed);
+    p.bias = bias; p.res = nullptr; p.out = out; p.M = m;
+    p.Cout = cout; p.CoutP = coutp; p.out_ctot = out_ctot; p.out_coff = out_coff; p.res_ctot = 0; p.res_coff = 0; p.act = act;
+    p.w_bytes = (unsigned)((size_t)(LK / 8) * coutp * 16);
+    p.x = x; p.delta = reinterpret_cast<const __bf16*>(delta); p.add_rows = add_rows; p.gamma = gamma; p.beta = beta; p.eps = eps;
+    p.w2 = reinterpret_cast<const __bf16*>(w2_packed); p.bias2 = bias2; p.act2 = act2;
+    hipStream_t st = av2x::as_stream(stream);
+    const dim3 grid((unsigned)((m + 63) / 64)), block(256);
+    const size_t lds = (size_t)64 * LROW * 2;
+    if (w2_packed) hipLaunchKernelGGL((linear_bf16_occ_kernel<true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((linear_bf16_occ_kernel<true, false>), grid, block, lds, st, p);
+    return av2x::check_launch("linear_bf16_occ_kernel<LN>");
 }
 
 extern "C" int av2x_add_layernorm_bf16(float* x, const uint16_t* delta, const float* gamma, const float* beta, uint16_t* y,

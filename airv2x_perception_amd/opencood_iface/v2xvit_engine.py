@@ -14,6 +14,7 @@ L = 15) never exists.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_int32, c_void_p
 
 import torch
@@ -248,6 +249,27 @@ class V2XViTEngine(Where2ComEngine):
                                                                     L.cout if residual is not None else 0, 0, L.relu, self.stream()),
                                           "av2x_linear_bf16"))
 
+    # LayerNorm (+ the pending residual add) folded into the panel load of the Linear that consumes it, FeedForward's two Linears in
+    # one launch (csrc/linear_bf16.hip linear_bf16_occ_kernel<LN, FFN>): bit-identical to the separate launches
+    fuse_ln = os.environ.get("AV2X_FUSE_LN", "1") != "0"
+
+    def ln_lin16(self, gb, L, x_rows, delta_rows, add_rows, m_rows, out, out_ctot=None, out_coff=0, L2=None):
+        """out = Linear(LayerNorm(x_rows (+ delta_rows on the first add_rows rows, written back to x_rows))) [-> second Linear L2]"""
+        w, coutp = _w16i(L)
+        w2 = _w16i(L2)[0] if L2 is not None else None
+        octot = out_ctot if out_ctot is not None else (L2.cout if L2 is not None else L.cout)
+        nbytes = m_rows * (L.cin * 4 + (L2.cout if L2 is not None else L.cout) * 2) + add_rows * (L.cin * 2 + L.cin * 4) + w.numel() * 2
+        flops = 2.0 * m_rows * L.cin * L.cout
+        if L2 is not None:
+            nbytes += w2.numel() * 2
+            flops += 2.0 * m_rows * L2.cin * L2.cout
+        self.timed_hbm(f"linear_bf16 ln+256->{L.cout}" + (f"->{L2.cout}" if L2 is not None else ""), nbytes, flops,
+                       lambda: _lib.check(self.lib.av2x_ln_linear_bf16(
+                           _ptr(x_rows), _ptr(delta_rows) if add_rows else c_void_p(0), add_rows, _ptr(gb[0]), _ptr(gb[1]), LN_EPS, _ptr(w),
+                           _ptr(L.shift), L.relu, L.cout, coutp, _ptr(w2) if L2 is not None else c_void_p(0),
+                           _ptr(L2.shift) if L2 is not None else c_void_p(0), L2.relu if L2 is not None else 0, _ptr(out), octot, out_coff,
+                           m_rows, self.stream()), "av2x_ln_linear_bf16"))
+
     def _blocks_bf16(self, x, mask, n, H, W, types, world, trace):
         """Every Linear writes bf16 (as under autocast); the residual adds `x + fn(x)` of the fp32 stream are folded into the NEXT
         LayerNorm pass (av2x_add_layernorm_bf16: one read-modify-write of x instead of one in the Linear's epilogue and a read
@@ -286,18 +308,43 @@ class V2XViTEngine(Where2ComEngine):
                                                             (m_tok_agents - k) * hw, C, LN_EPS, st()), "av2x_add_layernorm_bf16")
             pending[0] = 0
 
+        fuse = self.fuse_ln
+
+        def ln_lin(gb, L, a, b, out, out_ctot=None, out_coff=0, L2=None):
+            """agents [a, b): pending residual + LayerNorm + Linear(s) in one launch (no xn in HBM)"""
+            self.ln_lin16(gb, L, x[a:b], delta[a:b], max(0, min(pending[0], b) - a) * hw, (b - a) * hw, out, out_ctot, out_coff, L2)
+
+        def finish_pending(m_cov):
+            """agents [m_cov, pending) were not covered by the fused launches: they still receive their residual"""
+            if pending[0] > m_cov:
+                _lib.check(self.lib.av2x_add_layernorm_bf16(_ptr(x[m_cov:pending[0]]), _ptr(delta[m_cov:pending[0]]), c_void_p(0), c_void_p(0),
+                                                            c_void_p(0), (pending[0] - m_cov) * hw, C, LN_EPS, st()), "av2x_add_layernorm_bf16")
+            pending[0] = 0
+
         for di, (blocks, ffn) in enumerate(self.layers):
             for bi, blk in enumerate(blocks):
                 ego_only = self.ego_only_last and di == last and bi == len(blocks) - 1 and trace is None and n > 1
                 # ---- x = HGT(LN(x)) + x
-                add_ln(blk["ln1"], n)
+                if not fuse:
+                    add_ln(blk["ln1"], n)
                 if ego_only:
-                    self.lin16(blk["proj"][types[0]], xn[0:1], hw, proj[0:1])
+                    if fuse:
+                        ln_lin(blk["ln1"], blk["proj"][types[0]], 0, 1, proj[0:1])
+                    else:
+                        self.lin16(blk["proj"][types[0]], xn[0:1], hw, proj[0:1])
                     for (a, b, t) in self._groups(types[1:]):
-                        self.lin16(blk["proj_kv"][t], xn[a + 1:b + 1], (b - a) * hw, proj[a + 1:b + 1], out_ctot=1280, out_coff=512)
+                        if fuse:
+                            ln_lin(blk["ln1"], blk["proj_kv"][t], a + 1, b + 1, proj[a + 1:b + 1], out_ctot=1280, out_coff=512)
+                        else:
+                            self.lin16(blk["proj_kv"][t], xn[a + 1:b + 1], (b - a) * hw, proj[a + 1:b + 1], out_ctot=1280, out_coff=512)
                 else:
                     for (a, b, t) in groups:
-                        self.lin16(blk["proj"][t], xn[a:b], (b - a) * hw, proj[a:b])
+                        if fuse:
+                            ln_lin(blk["ln1"], blk["proj"][t], a, b, proj[a:b])
+                        else:
+                            self.lin16(blk["proj"][t], xn[a:b], (b - a) * hw, proj[a:b])
+                if fuse:
+                    finish_pending(n)
                 m = 1 if ego_only else n
                 self.timed_hbm("hgt_attention_bf16", hw * 2 * (m * 512 + n * (256 + 256 * len(set(types[:m]))) + m * 256), 4.0 * m * n * hw * 256,
                                lambda: _lib.check(self.lib.av2x_hgt_attention_bf16(_ptr(proj), _ptr(mask), ctypes.cast(tarr, c_void_p), _ptr(att), n, m,
@@ -310,8 +357,12 @@ class V2XViTEngine(Where2ComEngine):
                     add_ln(None, 0)
                     trace[f"hgt{di}"] = x.clone()
                 # ---- x = SplitAttn(window attentions(LN(x))) + x
-                add_ln(blk["ln2"], m)
-                self.lin16(blk["qkv3"], xn, m * hw, qkv3)
+                if fuse:
+                    ln_lin(blk["ln2"], blk["qkv3"], 0, m, qkv3)
+                    finish_pending(m)
+                else:
+                    add_ln(blk["ln2"], m)
+                    self.lin16(blk["qkv3"], xn, m * hw, qkv3)
                 for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
                     self.timed_hbm(f"window_attention_bf16 ws{ws} dh{dh}", m * hw * 2 * (768 + 256), 4.0 * m * hw * ws * ws * 256,
                                    lambda: _lib.check(self.lib.av2x_window_attention_bf16(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat),
@@ -330,9 +381,13 @@ class V2XViTEngine(Where2ComEngine):
                                                                  m, hw, C, st()), "combine")
             # ---- x = FFN(LN(x)) + x
             m = 1 if (self.ego_only_last and di == last and trace is None and n > 1) else n
-            add_ln(ffn["ln"], m)
-            self.lin16(ffn["ff1"], xn, m * hw, hid)
-            self.lin16(ffn["ff2"], hid, m * hw, delta)
+            if fuse and ffn["ff1"].cout == 256 and ffn["ff2"].cout == 256:
+                ln_lin(ffn["ln"], ffn["ff1"], 0, m, delta, L2=ffn["ff2"])     # delta rows are read (pending) before they are written: per panel
+                finish_pending(m)
+            else:
+                add_ln(ffn["ln"], m)
+                self.lin16(ffn["ff1"], xn, m * hw, hid)
+                self.lin16(ffn["ff2"], hid, m * hw, delta)
             pending[0] = m
             if trace is not None:
                 add_ln(None, 0)

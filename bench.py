@@ -468,7 +468,7 @@ def main(argv=None, hooks=None, device=None):
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
-        **({"precision_note": "AMP mode: bf16 MFMA operands, fp32 accumulate, fp32 activations in HBM; max |err| vs the fp32 path "
+        **({"precision_note": "AMP mode (autocast semantics): bf16 MFMA operands, fp32 accumulate; V2X-ViT: Linear / conv outputs stored as bf16, LayerNorm / softmax / residual sums in fp32; max |err| vs the fp32 path "
                               "is reported by tests/test_amp.py -- not comparable with the fp32 headline"} if a.amp else {}),
         "dtype": "bf16" if a.amp else ("f32 (products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate)" if a.gemm == "split3" else "f32"), "data": "synthetic",
         "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(synth.sort_types(synth.agent_types_for(a.agents))[1])}) x "
@@ -735,9 +735,10 @@ def main(argv=None, hooks=None, device=None):
                         "conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
                         "conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
                         f"conv_wino_f32<{(dom[0] & 0x3fff) // 32},{(dom[1] & 0x01ff) // 32}> (Winograd F(2x2,3x3), {dom[0] & 0x3fff} tiles x {dom[1] & 0x01ff} couts per workgroup)") if wino else
+                       "conv_halo_bf16 (halo-tile direct convolution on bf16 activations: 8 x 16 output pixels x 128 couts per workgroup, 64-channel halo chunks in LDS)" if dom[0] & 0x1000 else
                        f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else (f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": (("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),

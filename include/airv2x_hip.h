@@ -674,6 +674,17 @@ int av2x_add_layernorm_bf16(float* x, const uint16_t* delta, const float* gamma,
 int av2x_linear_bf16(const uint16_t* a, const uint16_t* w_packed, const float* bias, const float* residual, void* out,
                      int64_t m, int32_t k, int32_t cout, int32_t coutp, int32_t out_is_bf16, int32_t out_ctot,
                      int32_t out_coff, int32_t res_ctot, int32_t res_coff, int32_t act, av2x_stream_t stream);
+/* PreNormResidual(LayerNorm -> Linear [-> Linear]) in ONE pass over the fp32 stream (base_transformer.py:12-21 PreNormResidual,
+ * :24-37 FeedForward; v2xvit_basic.py:137-159 the order of the residual adds): for the m rows of x
+ *   x[r] += delta[r] for r < add_rows (written back; delta = the bf16 output of the PREVIOUS sub-layer whose residual add is pending),
+ *   h = act(LayerNorm(x) . W + bias) rounded to bf16, and out = h (w2_packed NULL: slice [out_coff, out_coff + cout) of rows of
+ *   out_ctot) or out = act2(h . W2 + bias2) (cout = coutp = 256: FeedForward's hidden tensor stays in LDS; 256 output columns).
+ * Bit-identical to av2x_add_layernorm_bf16 followed by av2x_linear_bf16 (twice); the normalised tensor (and the hidden one) never
+ * exist in HBM.  Packing and constraints of W / W2: as av2x_linear_bf16; k = 256. */
+int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, const float* gamma, const float* beta, float eps,
+                        const uint16_t* w_packed, const float* bias, int32_t act, int32_t cout, int32_t coutp,
+                        const uint16_t* w2_packed, const float* bias2, int32_t act2, uint16_t* out, int32_t out_ctot,
+                        int32_t out_coff, int64_t m, av2x_stream_t stream);
 int av2x_hgt_attention_bf16(const uint16_t* proj, const float* mask, const int32_t* types_host, uint16_t* out, int32_t n,
                             int32_t n_query, int32_t hw, int32_t heads, int32_t dim_head, av2x_stream_t stream);
 int av2x_window_attention_bf16(const uint16_t* qkv, int32_t ctot, int32_t coff, const float* pos_embedding, uint16_t* out,

@@ -267,3 +267,80 @@ def test_v2xvit_bf16_activations_against_fp32_activation_amp_and_the_reference(n
     for k in ("psm", "rm", "obj"):
         scale = float(a32[k].abs().max())
         assert float((a16[k] - a32[k]).abs().max()) < 6e-2 * scale
+
+
+@pytest.mark.parametrize("m,add_rows,cout,act,ctot,coff,ffn", [
+    (300, 300, 1280, 0, 1280, 0, False),       # ln1 -> HGT projection, every row with a pending residual; m not a multiple of 64
+    (517, 200, 768, 0, 1280, 512, False),      # proj_kv slice; the pending residual ends inside a panel (200 = 3 x 64 + 8)
+    (1000, 0, 2304, 0, 2304, 0, False),        # ln2 -> the three window QKVs, nothing pending
+    (129, 64, 256, 2, 256, 0, True),           # FeedForward: LayerNorm -> Linear + GELU -> Linear, hidden panel in LDS
+    (640, 640, 256, 2, 256, 0, True),
+    (64, 0, 256, 2, 256, 0, True),
+])
+def test_ln_linear_bf16_equals_the_separate_launches_bit_for_bit(m, add_rows, cout, act, ctot, coff, ffn):
+    """av2x_ln_linear_bf16 (LayerNorm and the pending residual add folded into the Linear's panel load, FeedForward's second Linear on
+    the LDS-resident hidden panel) against av2x_add_layernorm_bf16 + av2x_linear_bf16 (+ av2x_linear_bf16): same bits in `out` and in
+    the updated x (reference base_transformer.py:12-37)."""
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = _g(m * 7 + cout + add_rows)
+    x = torch.randn(m, 256, generator=g) * 2 + 0.3
+    dl = torch.randn(m, 256, generator=g).to(BF)
+    gm, bt = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    wt = (torch.randn(cout, 256, generator=g) / 16).to(BF).float()
+    b = torch.randn(cout, generator=g) * 0.2
+    wt2 = (torch.randn(256, 256, generator=g) / 16).to(BF).float()
+    b2 = torch.randn(256, generator=g) * 0.2
+    (w16, coutp), (w216, _) = _pack(wt), _pack(wt2)
+    gd, bd, wd, bbd, w2d, b2d, dd = gm.cuda(), bt.cuda(), w16.cuda(), b.cuda(), w216.cuda(), b2.cuda(), dl.cuda()
+    # --- separate launches
+    xs = x.cuda()
+    xn = torch.zeros(m, 256, device="cuda", dtype=BF)
+    if add_rows:
+        _lib.check(lib.av2x_add_layernorm_bf16(_p(xs), _p(dd), _p(gd), _p(bd), _p(xn), add_rows, 256, 1e-5, _st()), "add_ln")
+    if m > add_rows:
+        _lib.check(lib.av2x_add_layernorm_bf16(_p(xs[add_rows:]), None, _p(gd), _p(bd), _p(xn[add_rows:]), m - add_rows, 256, 1e-5, _st()), "ln")
+    want = torch.full((m, ctot), 7.0, device="cuda").to(BF)
+    if ffn:
+        hid = torch.zeros(m, 256, device="cuda", dtype=BF)
+        _lib.check(lib.av2x_linear_bf16(_p(xn), _p(wd), _p(bbd), None, _p(hid), m, 256, 256, coutp, 1, 256, 0, 0, 0, act, _st()), "ff1")
+        _lib.check(lib.av2x_linear_bf16(_p(hid), _p(w2d), _p(b2d), None, _p(want), m, 256, 256, 256, 1, ctot, coff, 0, 0, 0, _st()), "ff2")
+    else:
+        _lib.check(lib.av2x_linear_bf16(_p(xn), _p(wd), _p(bbd), None, _p(want), m, 256, cout, coutp, 1, ctot, coff, 0, 0, act, _st()), "lin")
+    # --- one launch
+    xf = x.cuda()
+    got = torch.full((m, ctot), 7.0, device="cuda").to(BF)
+    _lib.check(lib.av2x_ln_linear_bf16(_p(xf), _p(dd) if add_rows else None, add_rows, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp,
+                                       _p(w2d) if ffn else None, _p(b2d) if ffn else None, 0, _p(got), ctot, coff, m, _st()), "ln_linear")
+    assert torch.equal(xf, xs)
+    assert torch.equal(xf[add_rows:].cpu(), x[add_rows:])           # rows without a pending residual are not rewritten
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # argument checks
+    assert lib.av2x_ln_linear_bf16(_p(xf), None, 5, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp, None, None, 0, _p(got), ctot, coff,
+                                   m, _st()) != 0                  # pending rows without delta
+    if not ffn and cout != 256:
+        assert lib.av2x_ln_linear_bf16(_p(xf), None, 0, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp, _p(w2d), _p(b2d), 0, _p(got),
+                                       ctot, coff, m, _st()) != 0  # the fused second Linear needs a hidden width of 256
+
+
+@pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n8"])
+def test_v2xvit_fused_layernorm_linear_frame_equals_the_unfused_frame(name):
+    """The bf16-activation frame with LayerNorm folded into the Linears (default) and with separate LayerNorm launches: same bits."""
+    from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
+    import tests.test_v2xvit as tv
+    fx = load_fixture(name)
+    hy, args, sd, dd = tv._case(fx)
+    model = M(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    model.amp = True
+    assert eng.fuse_ln is True
+    fused = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
+    eng.fuse_ln = False
+    try:
+        plain = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
+    finally:
+        eng.fuse_ln = True
+    for k in ("psm", "rm", "obj"):
+        assert torch.equal(fused[k], plain[k]), k
