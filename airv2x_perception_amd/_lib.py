@@ -140,7 +140,7 @@ SIGNATURES = {
     "av2x_add_layernorm_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "av2x_linear_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "av2x_ln_linear_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int32, c_int32,
+    "av2x_ln_linear_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int32, c_int32,
                                       c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     "av2x_hgt_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p]),
@@ -149,6 +149,8 @@ SIGNATURES = {
     "av2x_split_attn_gap_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_split_attn_combine_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_void_p]),
+    "av2x_split_attn_combine_delta_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                                     c_int32, c_void_p]),
     "av2x_comm_mask": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_comm_mask_topk": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

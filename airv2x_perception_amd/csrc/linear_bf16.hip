@@ -45,6 +45,7 @@ struct LinParams {
     float* x;
     const __bf16* delta;
     long long add_rows;
+    int write_back;       // 0: x + delta feeds the LayerNorm but x is left as it is (the add stays pending for a later kernel)
     const float* gamma;
     const float* beta;
     float eps;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                 if (r < addr) {      // wave-uniform
                     v = add_bf16x4(v, make_uint2(dv[j][0], dv[j][1]));
                     const f32x4 vv = {v.x, v.y, v.z, v.w};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rx, (unsigned)(r * (LK * 4) + lane * 16), 0, LIN_NT);
+                    if (p.write_back)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rx, (unsigned)(r * (LK * 4) + lane * 16), 0, LIN_NT);
                 }
                 const f32x4 y = layernorm_row_256(v, g, bt, p.eps);
                 *reinterpret_cast<bf16x4*>(As + r * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
@@ -459,7 +461,7 @@ extern "C" int av2x_linear_bf16(const uint16_t* a, const uint16_t* w_packed, con
     return av2x::check_launch("linear_bf16_kernel");
 }
 
-extern "C" int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, const float* gamma, const float* beta, float eps,
+extern "C" int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, int32_t write_back_x, const float* gamma, const float* beta, float eps,
                                    const uint16_t* w_packed, const float* bias, int32_t act, int32_t cout, int32_t coutp,
                                    const uint16_t* w2_packed, const float* bias2, int32_t act2, uint16_t* out, int32_t out_ctot,
                                    int32_t out_coff, int64_t m, av2x_stream_t stream) {
@@ -478,7 +480,7 @@ extern "C" int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_
     p.bias = bias; p.res = nullptr; p.out = out; p.M = m;
     p.Cout = cout; p.CoutP = coutp; p.out_ctot = out_ctot; p.out_coff = out_coff; p.res_ctot = 0; p.res_coff = 0; p.act = act;
     p.w_bytes = (unsigned)((size_t)(LK / 8) * coutp * 16);
-    p.x = x; p.delta = reinterpret_cast<const __bf16*>(delta); p.add_rows = add_rows; p.gamma = gamma; p.beta = beta; p.eps = eps;
+    p.x = x; p.delta = reinterpret_cast<const __bf16*>(delta); p.add_rows = add_rows; p.write_back = write_back_x; p.gamma = gamma; p.beta = beta; p.eps = eps;
     p.w2 = reinterpret_cast<const __bf16*>(w2_packed); p.bias2 = bias2; p.act2 = act2;
     hipStream_t st = av2x::as_stream(stream);
     const dim3 grid((unsigned)((m + 63) / 64)), block(256);

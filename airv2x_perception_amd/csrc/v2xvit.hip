@@ -471,8 +471,8 @@ __global__ void gap3_stage2(const float* __restrict__ partial, float* __restrict
 
 template <typename T>
 __global__ void split_combine_kernel(const T* __restrict__ s0, const T* __restrict__ s1, const T* __restrict__ s2,
-                                     const float* __restrict__ logits, const float4* __restrict__ res, float4* __restrict__ out,
-                                     size_t n4_per_agent, int C) {
+                                     const float* __restrict__ logits, const float4* __restrict__ res,
+                                     const __bf16* __restrict__ delta, float4* __restrict__ out, size_t n4_per_agent, int C) {
     const int a = blockIdx.y;
     const int c4 = C / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_agent; i += (size_t)gridDim.x * blockDim.x) {
@@ -488,7 +488,12 @@ __global__ void split_combine_kernel(const T* __restrict__ s0, const T* __restri
             w[0][e] = e0 * inv; w[1][e] = e1 * inv; w[2][e] = e2 * inv;
         }
         const size_t o = (size_t)a * n4_per_agent + i;
-        const float4 x0 = ld4(s0 + 4 * o), x1 = ld4(s1 + 4 * o), x2 = ld4(s2 + 4 * o), r = res[o];
+        const float4 x0 = ld4(s0 + 4 * o), x1 = ld4(s1 + 4 * o), x2 = ld4(s2 + 4 * o);
+        float4 r = res[o];
+        if (delta) {     // a residual add still pending on the stream (the bf16 output of the previous sub-layer): r = res + delta first
+            const float4 dl = ld4(delta + 4 * o);
+            r.x += dl.x; r.y += dl.y; r.z += dl.z; r.w += dl.w;
+        }
         float4 y;
         y.x = ((x0.x * w[0][0] + x1.x * w[1][0]) + x2.x * w[2][0]) + r.x;
         y.y = ((x0.y * w[0][1] + x1.y * w[1][1]) + x2.y * w[2][1]) + r.y;
@@ -653,8 +658,8 @@ extern "C" int av2x_split_attn_gap_bf16(const uint16_t* s0, const uint16_t* s1, 
 }
 
 template <typename T>
-static int combine_launch(const T* s0, const T* s1, const T* s2, const float* logits, const float* residual, float* out, int32_t n,
-                          int32_t hw, int32_t c, av2x_stream_t stream) {
+static int combine_launch(const T* s0, const T* s1, const T* s2, const float* logits, const float* residual, const __bf16* delta,
+                          float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
     if (n == 0) return 0;
     if (!s0 || !s1 || !s2 || !logits || !residual || !out) return av2x::fail("av2x_split_attn_combine: null argument");
     if (c % 4) return av2x::fail("av2x_split_attn_combine: c must be a multiple of 4");
@@ -662,17 +667,24 @@ static int combine_launch(const T* s0, const T* s1, const T* s2, const float* lo
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(split_combine_kernel<T>, dim3((unsigned)blocks, n), dim3(256), 0, av2x::as_stream(stream), s0, s1, s2, logits,
-                       reinterpret_cast<const float4*>(residual), reinterpret_cast<float4*>(out), n4, c);
+                       reinterpret_cast<const float4*>(residual), delta, reinterpret_cast<float4*>(out), n4, c);
     return av2x::check_launch("split_combine_kernel");
 }
 
 extern "C" int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, const float* logits,
                                        const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
-    return combine_launch<float>(s0, s1, s2, logits, residual, out, n, hw, c, stream);
+    return combine_launch<float>(s0, s1, s2, logits, residual, nullptr, out, n, hw, c, stream);
 }
 
 extern "C" int av2x_split_attn_combine_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
                                             const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream) {
     return combine_launch<__bf16>(reinterpret_cast<const __bf16*>(s0), reinterpret_cast<const __bf16*>(s1), reinterpret_cast<const __bf16*>(s2),
-                                  logits, residual, out, n, hw, c, stream);
+                                  logits, residual, nullptr, out, n, hw, c, stream);
+}
+
+extern "C" int av2x_split_attn_combine_delta_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
+                                                  const float* residual, const uint16_t* delta, float* out, int32_t n, int32_t hw, int32_t c,
+                                                  av2x_stream_t stream) {
+    return combine_launch<__bf16>(reinterpret_cast<const __bf16*>(s0), reinterpret_cast<const __bf16*>(s1), reinterpret_cast<const __bf16*>(s2),
+                                  logits, residual, reinterpret_cast<const __bf16*>(delta), out, n, hw, c, stream);
 }

@@ -253,19 +253,21 @@ class V2XViTEngine(Where2ComEngine):
     # one launch (csrc/linear_bf16.hip linear_bf16_occ_kernel<LN, FFN>): bit-identical to the separate launches
     fuse_ln = os.environ.get("AV2X_FUSE_LN", "1") != "0"
 
-    def ln_lin16(self, gb, L, x_rows, delta_rows, add_rows, m_rows, out, out_ctot=None, out_coff=0, L2=None):
-        """out = Linear(LayerNorm(x_rows (+ delta_rows on the first add_rows rows, written back to x_rows))) [-> second Linear L2]"""
+    def ln_lin16(self, gb, L, x_rows, delta_rows, add_rows, m_rows, out, out_ctot=None, out_coff=0, L2=None, write_back=True):
+        """out = Linear(LayerNorm(x_rows (+ delta_rows on the first add_rows rows, written back to x_rows if ``write_back``))) [-> second
+        Linear L2]"""
         w, coutp = _w16i(L)
         w2 = _w16i(L2)[0] if L2 is not None else None
         octot = out_ctot if out_ctot is not None else (L2.cout if L2 is not None else L.cout)
-        nbytes = m_rows * (L.cin * 4 + (L2.cout if L2 is not None else L.cout) * 2) + add_rows * (L.cin * 2 + L.cin * 4) + w.numel() * 2
+        nbytes = (m_rows * (L.cin * 4 + (L2.cout if L2 is not None else L.cout) * 2) + add_rows * (L.cin * 2 + (L.cin * 4 if write_back else 0))
+                  + w.numel() * 2)
         flops = 2.0 * m_rows * L.cin * L.cout
         if L2 is not None:
             nbytes += w2.numel() * 2
             flops += 2.0 * m_rows * L2.cin * L2.cout
         self.timed_hbm(f"linear_bf16 ln+256->{L.cout}" + (f"->{L2.cout}" if L2 is not None else ""), nbytes, flops,
                        lambda: _lib.check(self.lib.av2x_ln_linear_bf16(
-                           _ptr(x_rows), _ptr(delta_rows) if add_rows else c_void_p(0), add_rows, _ptr(gb[0]), _ptr(gb[1]), LN_EPS, _ptr(w),
+                           _ptr(x_rows), _ptr(delta_rows) if add_rows else c_void_p(0), add_rows, 1 if write_back else 0, _ptr(gb[0]), _ptr(gb[1]), LN_EPS, _ptr(w),
                            _ptr(L.shift), L.relu, L.cout, coutp, _ptr(w2) if L2 is not None else c_void_p(0),
                            _ptr(L2.shift) if L2 is not None else c_void_p(0), L2.relu if L2 is not None else 0, _ptr(out), octot, out_coff,
                            m_rows, self.stream()), "av2x_ln_linear_bf16"))
@@ -310,9 +312,9 @@ class V2XViTEngine(Where2ComEngine):
 
         fuse = self.fuse_ln
 
-        def ln_lin(gb, L, a, b, out, out_ctot=None, out_coff=0, L2=None):
+        def ln_lin(gb, L, a, b, out, out_ctot=None, out_coff=0, L2=None, write_back=True):
             """agents [a, b): pending residual + LayerNorm + Linear(s) in one launch (no xn in HBM)"""
-            self.ln_lin16(gb, L, x[a:b], delta[a:b], max(0, min(pending[0], b) - a) * hw, (b - a) * hw, out, out_ctot, out_coff, L2)
+            self.ln_lin16(gb, L, x[a:b], delta[a:b], max(0, min(pending[0], b) - a) * hw, (b - a) * hw, out, out_ctot, out_coff, L2, write_back)
 
         def finish_pending(m_cov):
             """agents [m_cov, pending) were not covered by the fused launches: they still receive their residual"""
@@ -358,8 +360,10 @@ class V2XViTEngine(Where2ComEngine):
                     trace[f"hgt{di}"] = x.clone()
                 # ---- x = SplitAttn(window attentions(LN(x))) + x
                 if fuse:
-                    ln_lin(blk["ln2"], blk["qkv3"], 0, m, qkv3)
-                    finish_pending(m)
+                    # the HGT residual (pending == m agents here) feeds the LayerNorm but is NOT written back to x by this write-bound
+                    # launch: the combine kernel below reads x anyway and adds it there (a 16-bit read instead of an fp32 write)
+                    assert pending[0] in (0, m)
+                    ln_lin(blk["ln2"], blk["qkv3"], 0, m, qkv3, write_back=False)
                 else:
                     add_ln(blk["ln2"], m)
                     self.lin16(blk["qkv3"], xn, m * hw, qkv3)
@@ -377,8 +381,13 @@ class V2XViTEngine(Where2ComEngine):
                 self.conv(blk["fc1"], gap, m, 1, 1, g1)
                 self.ln(g1, blk["bn1"], g2, m, C, relu=1)
                 self.conv(blk["fc2"], g2, m, 1, 1, logits)
-                _lib.check(self.lib.av2x_split_attn_combine_bf16(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), _ptr(x), _ptr(x),
-                                                                 m, hw, C, st()), "combine")
+                if pending[0]:
+                    _lib.check(self.lib.av2x_split_attn_combine_delta_bf16(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), _ptr(x), _ptr(delta),
+                                                                           _ptr(x), m, hw, C, st()), "combine")
+                    pending[0] = 0
+                else:
+                    _lib.check(self.lib.av2x_split_attn_combine_bf16(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), _ptr(x), _ptr(x),
+                                                                     m, hw, C, st()), "combine")
             # ---- x = FFN(LN(x)) + x
             m = 1 if (self.ego_only_last and di == last and trace is None and n > 1) else n
             if fuse and ffn["ff1"].cout == 256 and ffn["ff2"].cout == 256:

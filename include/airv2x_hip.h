@@ -676,12 +676,14 @@ int av2x_linear_bf16(const uint16_t* a, const uint16_t* w_packed, const float* b
                      int32_t out_coff, int32_t res_ctot, int32_t res_coff, int32_t act, av2x_stream_t stream);
 /* PreNormResidual(LayerNorm -> Linear [-> Linear]) in ONE pass over the fp32 stream (base_transformer.py:12-21 PreNormResidual,
  * :24-37 FeedForward; v2xvit_basic.py:137-159 the order of the residual adds): for the m rows of x
- *   x[r] += delta[r] for r < add_rows (written back; delta = the bf16 output of the PREVIOUS sub-layer whose residual add is pending),
+ *   x[r] += delta[r] for r < add_rows (delta = the bf16 output of the PREVIOUS sub-layer whose residual add is pending; written back
+ *   to x if write_back_x, otherwise x is left untouched and the add stays pending for a later kernel, e.g.
+ *   av2x_split_attn_combine_delta_bf16: one 16-bit read there instead of an fp32 write here),
  *   h = act(LayerNorm(x) . W + bias) rounded to bf16, and out = h (w2_packed NULL: slice [out_coff, out_coff + cout) of rows of
  *   out_ctot) or out = act2(h . W2 + bias2) (cout = coutp = 256: FeedForward's hidden tensor stays in LDS; 256 output columns).
  * Bit-identical to av2x_add_layernorm_bf16 followed by av2x_linear_bf16 (twice); the normalised tensor (and the hidden one) never
  * exist in HBM.  Packing and constraints of W / W2: as av2x_linear_bf16; k = 256. */
-int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, const float* gamma, const float* beta, float eps,
+int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, int32_t write_back_x, const float* gamma, const float* beta, float eps,
                         const uint16_t* w_packed, const float* bias, int32_t act, int32_t cout, int32_t coutp,
                         const uint16_t* w2_packed, const float* bias2, int32_t act2, uint16_t* out, int32_t out_ctot,
                         int32_t out_coff, int64_t m, av2x_stream_t stream);
@@ -694,6 +696,10 @@ int av2x_split_attn_gap_bf16(const uint16_t* s0, const uint16_t* s1, const uint1
                              float* scratch /* n*128*c floats */, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
 int av2x_split_attn_combine_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
                                  const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
+/* as av2x_split_attn_combine_bf16 with residual + delta (bf16, same shape; the pending add of av2x_ln_linear_bf16) as the residual */
+int av2x_split_attn_combine_delta_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
+                                       const float* residual, const uint16_t* delta, float* out, int32_t n, int32_t hw, int32_t c,
+                                       av2x_stream_t stream);
 
 /* The reference replaces an EMPTY cloud by two dummy points before voxelising (sp_voxel_preprocessor.py:80-90).
  * av2x_voxelize_dummy_if_empty does the same on the device after av2x_voxelize / av2x_prepare_voxelize: if *n_voxels == 0

@@ -187,6 +187,12 @@ def test_split_attention_bf16_is_the_fp32_kernel_on_bf16_storage():
     _lib.check(lib.av2x_split_attn_combine_bf16(_p(s[0]), _p(s[1]), _p(s[2]), _p(logits), _p(o16), _p(o16), n, hw, C, _st()), "c16")
     _lib.check(lib.av2x_split_attn_combine(_p(s32[0]), _p(s32[1]), _p(s32[2]), _p(logits), _p(o32), _p(o32), n, hw, C, _st()), "c32")
     assert torch.equal(o16, o32)
+    # a pending residual add applied by the combine kernel == the add first (one fp32 add per element), then the plain combine
+    dl = torch.randn(n, hw, C, generator=g).to(BF).cuda()
+    od, oa = x.clone(), x + dl.float()
+    _lib.check(lib.av2x_split_attn_combine_delta_bf16(_p(s[0]), _p(s[1]), _p(s[2]), _p(logits), _p(od), _p(dl), _p(od), n, hw, C, _st()), "cd")
+    _lib.check(lib.av2x_split_attn_combine_bf16(_p(s[0]), _p(s[1]), _p(s[2]), _p(logits), _p(oa), _p(oa), n, hw, C, _st()), "c16")
+    assert torch.equal(od, oa)
 
 
 HALO_TILE = 0x10000000 | (128 << 16) | 128 | 0x0800
@@ -310,16 +316,22 @@ def test_ln_linear_bf16_equals_the_separate_launches_bit_for_bit(m, add_rows, co
     # --- one launch
     xf = x.cuda()
     got = torch.full((m, ctot), 7.0, device="cuda").to(BF)
-    _lib.check(lib.av2x_ln_linear_bf16(_p(xf), _p(dd) if add_rows else None, add_rows, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp,
+    _lib.check(lib.av2x_ln_linear_bf16(_p(xf), _p(dd) if add_rows else None, add_rows, 1, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp,
                                        _p(w2d) if ffn else None, _p(b2d) if ffn else None, 0, _p(got), ctot, coff, m, _st()), "ln_linear")
     assert torch.equal(xf, xs)
     assert torch.equal(xf[add_rows:].cpu(), x[add_rows:])           # rows without a pending residual are not rewritten
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
     # argument checks
-    assert lib.av2x_ln_linear_bf16(_p(xf), None, 5, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp, None, None, 0, _p(got), ctot, coff,
+    # write_back_x = 0: the same output, x untouched (the add stays pending: av2x_split_attn_combine_delta_bf16 applies it)
+    x0 = x.cuda()
+    got0 = torch.full((m, ctot), 7.0, device="cuda").to(BF)
+    _lib.check(lib.av2x_ln_linear_bf16(_p(x0), _p(dd) if add_rows else None, add_rows, 0, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp,
+                                       _p(w2d) if ffn else None, _p(b2d) if ffn else None, 0, _p(got0), ctot, coff, m, _st()), "ln_linear")
+    assert torch.equal(x0.cpu(), x) and torch.equal(got0.view(torch.int16), want.view(torch.int16))
+    assert lib.av2x_ln_linear_bf16(_p(xf), None, 5, 1, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp, None, None, 0, _p(got), ctot, coff,
                                    m, _st()) != 0                  # pending rows without delta
     if not ffn and cout != 256:
-        assert lib.av2x_ln_linear_bf16(_p(xf), None, 0, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp, _p(w2d), _p(b2d), 0, _p(got),
+        assert lib.av2x_ln_linear_bf16(_p(xf), None, 0, 1, _p(gd), _p(bd), 1e-5, _p(wd), _p(bbd), act, cout, coutp, _p(w2d), _p(b2d), 0, _p(got),
                                        ctot, coff, m, _st()) != 0  # the fused second Linear needs a hidden width of 256
 
 
