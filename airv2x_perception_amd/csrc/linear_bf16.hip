@@ -53,7 +53,18 @@ struct LinParams {
     const __bf16* w2;
     const float* bias2;
     int act2;
+    // window attention as the panel source (linear_bf16_occ_kernel<2 | 3, .>): the bf16 [q | k | v] rows, the relative-position table, the map
+    const __bf16* qkv;
+    const float* pos;
+    int qkv_ctot, qkv_coff, H, W, heads;
+    float scale;
 };
+
+__device__ __forceinline__ float4 ld_bf16x4(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u), __builtin_bit_cast(float, u.y << 16),
+                       __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
 
 // nn.LayerNorm over C = 256 of one token held as four channels per lane of a wave (the ONE definition both the stand-alone
 // LayerNorm kernel and the fused panel load use: their outputs are the same bits)
@@ -116,16 +127,31 @@ __device__ __forceinline__ float erf_as(float x) {
 // FFN = true (Cout = CoutP = 256): the activated bf16 output panel goes back into the SAME LDS panel (all waves are past their K
 // loop) and a second Linear 256 -> 256 (w2, bias2, act2) runs on it: FeedForward's hidden tensor never exists in HBM either.
 // Both produce exactly the bits of the separate launches (same MFMA sequence per output, same roundings).
-template <bool LN, bool FFN>
+// SRC = 2 / 3: the panel is the OUTPUT of the window attention (mswin.py:52-96 BaseWindowAttention) of a 4 x 16-pixel block of the map
+// -- four 4 x 4 windows (SRC 2: MFMA form, DH = 32 / 64) or sixteen 2 x 2 windows (SRC 3: one thread per (token, head), DH = 16) --
+// computed from the bf16 [q | k | v] rows exactly as window_attn_mfma_kernel / window_attn_kernel of v2xvit.hip do, rounded to bf16
+// into LDS, and the Linear is the branch's output projection: the attention output never exists in HBM (144 MB written + read per
+// branch at 8 agents) and a launch disappears.  Panel row r = block pixel (r >> 4, r & 15).
+constexpr int SRC_ROWS = 0, SRC_LN = 1, SRC_WIN4 = 2, SRC_WIN2 = 3;
+typedef float lin_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int SRC, bool FFN, int DH = 0>
 __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams p) {
     constexpr int BMO = 64;
+    constexpr bool LN = SRC == SRC_LN, WIN = SRC == SRC_WIN4 || SRC == SRC_WIN2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
     __bf16* As = reinterpret_cast<__bf16*>(lin_smem);        // [64][264]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * BMO;
-    const int rows = (int)((p.M - m0) < BMO ? (p.M - m0) : BMO);
+    long long m0 = (long long)blockIdx.x * BMO;
+    int rows = (int)((p.M - m0) < BMO ? (p.M - m0) : BMO);
+    if constexpr (WIN) {     // first pixel of the 4 x 16 block; the output "panel" spans 3 map rows + 16 pixels
+        const int bx = p.W >> 4, by = p.H >> 2;
+        const int tx = blockIdx.x % bx, ty = (blockIdx.x / bx) % by, ag = blockIdx.x / (bx * by);
+        m0 = ((long long)ag * p.H + 4 * ty) * p.W + 16 * tx;
+        rows = 3 * p.W + 16;
+    }
     const int nchunks = FFN ? 1 : (p.CoutP >> 8);
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, p.w_bytes, 0x00020000);
@@ -173,6 +199,114 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                 }
                 const f32x4 y = layernorm_row_256(v, g, bt, p.eps);
                 *reinterpret_cast<bf16x4*>(As + r * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
+            }
+        }
+    } else if constexpr (SRC == SRC_WIN4) {
+        // ---- window_attn_mfma_kernel of v2xvit.hip, one (window, head) task per wave at a time (same instruction sequence per task)
+        constexpr int WS = 4, NB = DH / 16;
+        const int t = lane & 15, h = lane >> 4;
+        const int inner = p.heads * DH;
+        const int iy = t >> 2, ix = t & 3;
+        float wbias[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wbias[r] = p.pos[(h - iy + WS - 1) * (2 * WS - 1) + (r - ix + WS - 1)];
+        __bf16* vt = reinterpret_cast<__bf16*>(lin_smem + (size_t)BMO * LROW * 2) + wave * (16 * DH);
+        const int ntask = 4 * p.heads;
+        for (int tk = wave; tk < ntask; tk += 4) {
+            const int head = tk % p.heads, wdw = tk / p.heads;
+            const size_t pix0 = (size_t)m0 + 4 * wdw;
+            const __bf16* rowt = p.qkv + (pix0 + (size_t)(t >> 2) * p.W + (t & 3)) * p.qkv_ctot + p.qkv_coff + head * DH;
+            lin_f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                const float4 qq = ld_bf16x4(rowt + 4 * (h + 4 * g));
+                const float4 kk = ld_bf16x4(rowt + inner + 4 * (h + 4 * g));
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qq.x, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qq.y, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qq.z, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qq.w, st, 0, 0, 0);
+            }
+            float sc[4], mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = st[r] * p.scale + wbias[r]; mx = fmaxf(mx, sc[r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = expf(sc[r] - mx); l += sc[r]; }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+            constexpr int PPK = DH / 8;
+#pragma unroll
+            for (int e = lane; e < 16 * PPK; e += 64) {
+                const int key = e / PPK, part = e % PPK;
+                *reinterpret_cast<uint4*>(&vt[key * DH + part * 8]) = *reinterpret_cast<const uint4*>(
+                    p.qkv + (pix0 + (size_t)(key >> 2) * p.W + (key & 3)) * p.qkv_ctot + p.qkv_coff + 2 * inner + head * DH + part * 8);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                lin_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, (float)vt[(4 * h + r) * DH + nb * 16 + t], o, 0, 0, 0);
+                // query (iy = h, ix = r) of window wdw = panel row 16 h + 4 wdw + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) As[(16 * h + 4 * wdw + r) * LROW + head * DH + nb * 16 + t] = (__bf16)o[r];
+            }
+        }
+    } else if constexpr (SRC == SRC_WIN2) {
+        // ---- window_attn_kernel<16, 2> of v2xvit.hip: one (token, head) pair per thread and pass, 64 tokens x 16 heads = 4 passes
+        constexpr int WS = 2, DHD = 16;
+        const int inner = p.heads * DHD;
+        for (int e = tid; e < BMO * p.heads; e += 256) {
+            const int head = e % p.heads, tok = e / p.heads;
+            const int py = tok >> 4, px = tok & 15;
+            const int wy0 = py & ~1, wx0 = px & ~1, iy = py - wy0, ixx = px - wx0;
+            const __bf16* row = p.qkv + ((size_t)m0 + (size_t)py * p.W + px) * p.qkv_ctot + p.qkv_coff + head * DHD;
+            float q[DHD], o[DHD];
+#pragma unroll
+            for (int d = 0; d < DHD; d += 4) {
+                const float4 v = ld_bf16x4(row + d);
+                q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
+            }
+            float sj[WS * WS];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < WS * WS; ++j) {
+                const int jy = j / WS, jx = j % WS;
+                const __bf16* kr = p.qkv + ((size_t)m0 + (size_t)(wy0 + jy) * p.W + (wx0 + jx)) * p.qkv_ctot + p.qkv_coff + inner + head * DHD;
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < DHD; d += 4) {
+                    const float4 k = ld_bf16x4(kr + d);
+                    acc = fmaf(q[d], k.x, acc); acc = fmaf(q[d + 1], k.y, acc); acc = fmaf(q[d + 2], k.z, acc); acc = fmaf(q[d + 3], k.w, acc);
+                }
+                acc = acc * p.scale + p.pos[(jy - iy + WS - 1) * (2 * WS - 1) + (jx - ixx + WS - 1)];
+                sj[j] = acc;
+                mx = fmaxf(mx, acc);
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < WS * WS; ++j) { sj[j] = expf(sj[j] - mx); l += sj[j]; }
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int d = 0; d < DHD; ++d) o[d] = 0.f;
+#pragma unroll
+            for (int j = 0; j < WS * WS; ++j) {
+                const int jy = j / WS, jx = j % WS;
+                const __bf16* vr = p.qkv + ((size_t)m0 + (size_t)(wy0 + jy) * p.W + (wx0 + jx)) * p.qkv_ctot + p.qkv_coff + 2 * inner + head * DHD;
+                const float pj = sj[j] * inv;
+#pragma unroll
+                for (int d = 0; d < DHD; d += 4) {
+                    const float4 v = ld_bf16x4(vr + d);
+                    o[d] = fmaf(pj, v.x, o[d]); o[d + 1] = fmaf(pj, v.y, o[d + 1]); o[d + 2] = fmaf(pj, v.z, o[d + 2]); o[d + 3] = fmaf(pj, v.w, o[d + 3]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DHD; d += 4) {
+                const f32x4 f = {o[d], o[d + 1], o[d + 2], o[d + 3]};
+                *reinterpret_cast<bf16x4*>(As + tok * LROW + head * DHD + d) = __builtin_convertvector(f, bf16x4);
             }
         }
     } else {
@@ -264,6 +398,8 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                 const u32x4 v4 = {R[0], R[1], R[2], R[3]};
                 if constexpr (TO_LDS)
                     *reinterpret_cast<u32x4*>(As + (a * 32 + 8 * g + 4 * lh + (li & 3)) * LROW + wave * 64 + 2 * (li & ~3)) = v4;
+                else if constexpr (WIN)    // panel row 32 a + 8 g + .. = block pixel (2 a + (g >> 1), 8 (g & 1) + ..)
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, rout, off0 + (unsigned)(((2 * a + (g >> 1)) * p.W + 8 * (g & 1)) * ostride), 0, LIN_NT);
                 else
                     __builtin_amdgcn_raw_buffer_store_b128(v4, rout, off0 + (unsigned)((a * 32 + 8 * g) * ostride), 0, LIN_NT);
             }
@@ -452,7 +588,7 @@ extern "C" int av2x_linear_bf16(const uint16_t* a, const uint16_t* w_packed, con
     const unsigned grid = (unsigned)((m + LBM - 1) / LBM);
     hipStream_t st = av2x::as_stream(stream);
     if (out_is_bf16) {
-        hipLaunchKernelGGL((linear_bf16_occ_kernel<false, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), (size_t)64 * LROW * 2, st, p);
+        hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_ROWS, false>), dim3((unsigned)((m + 63) / 64)), dim3(256), (size_t)64 * LROW * 2, st, p);
     } else {
         static av2x::LdsLimit lim;
         lim.ensure(reinterpret_cast<const void*>(&linear_bf16_kernel<false>), lds);
@@ -485,9 +621,41 @@ extern "C" int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_
     hipStream_t st = av2x::as_stream(stream);
     const dim3 grid((unsigned)((m + 63) / 64)), block(256);
     const size_t lds = (size_t)64 * LROW * 2;
-    if (w2_packed) hipLaunchKernelGGL((linear_bf16_occ_kernel<true, true>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((linear_bf16_occ_kernel<true, false>), grid, block, lds, st, p);
+    if (w2_packed) hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_LN, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_LN, false>), grid, block, lds, st, p);
     return av2x::check_launch("linear_bf16_occ_kernel<LN>");
+}
+
+extern "C" int av2x_window_attention_linear_bf16(const uint16_t* qkv, int32_t ctot, int32_t coff, const float* pos_embedding,
+                                                const uint16_t* w_packed, const float* bias, uint16_t* out, int32_t out_ctot,
+                                                int32_t out_coff, int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head,
+                                                int32_t window, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!qkv || !pos_embedding || !w_packed || !out) return av2x::fail("av2x_window_attention_linear_bf16: null argument");
+    if (n < 0 || h <= 0 || w <= 0 || h % 4 || w % 16)
+        return av2x::fail("av2x_window_attention_linear_bf16: the map (%d x %d) must split into 4 x 16-pixel blocks", h, w);
+    if (heads * dim_head != 256) return av2x::fail("av2x_window_attention_linear_bf16: heads x dim_head must be 256");
+    if (!((window == 4 && (dim_head == 32 || dim_head == 64)) || (window == 2 && dim_head == 16)))
+        return av2x::fail("av2x_window_attention_linear_bf16: (dim_head %d, window %d) unsupported: (16,2) (32,4) (64,4)", dim_head, window);
+    if (ctot % 8 || coff % 8 || coff + 768 > ctot || out_ctot % 8 || out_coff % 8 || out_coff + 256 > out_ctot)
+        return av2x::fail("av2x_window_attention_linear_bf16: bad slices");
+    if ((unsigned long long)(3 * (unsigned long long)w + 16) * out_ctot * 2ull >= (1ull << 31)) return av2x::fail("av2x_window_attention_linear_bf16: map too wide");
+    LinParams p = {};
+    p.w = reinterpret_cast<const __bf16*>(w_packed);
+    p.bias = bias; p.out = out; p.M = (long long)n * h * w;
+    p.Cout = 256; p.CoutP = 256; p.out_ctot = out_ctot; p.out_coff = out_coff; p.act = 0;
+    p.w_bytes = (unsigned)((size_t)(LK / 8) * 256 * 16);
+    p.qkv = reinterpret_cast<const __bf16*>(qkv); p.pos = pos_embedding; p.qkv_ctot = ctot; p.qkv_coff = coff; p.H = h; p.W = w; p.heads = heads;
+    p.scale = 1.0f / sqrtf((float)dim_head);
+    hipStream_t st = av2x::as_stream(stream);
+    const long long blocks = (long long)n * (h / 4) * (w / 16);
+    if (blocks > (1ll << 30)) return av2x::fail("av2x_window_attention_linear_bf16: too many workgroups");
+    const dim3 grid((unsigned)blocks), block(256);
+    const size_t lds = (size_t)64 * LROW * 2;
+    if (window == 2) hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_WIN2, false, 16>), grid, block, lds, st, p);
+    else if (dim_head == 32) hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_WIN4, false, 32>), grid, block, lds + 4 * 16 * 32 * 2, st, p);
+    else hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_WIN4, false, 64>), grid, block, lds + 4 * 16 * 64 * 2, st, p);
+    return av2x::check_launch("linear_bf16_occ_kernel<WIN>");
 }
 
 extern "C" int av2x_add_layernorm_bf16(float* x, const uint16_t* delta, const float* gamma, const float* beta, uint16_t* y,

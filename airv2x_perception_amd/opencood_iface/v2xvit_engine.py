@@ -252,6 +252,7 @@ class V2XViTEngine(Where2ComEngine):
     # LayerNorm (+ the pending residual add) folded into the panel load of the Linear that consumes it, FeedForward's two Linears in
     # one launch (csrc/linear_bf16.hip linear_bf16_occ_kernel<LN, FFN>): bit-identical to the separate launches
     fuse_ln = os.environ.get("AV2X_FUSE_LN", "1") != "0"
+    fuse_window_out = os.environ.get("AV2X_FUSE_WINDOW_OUT", "1") != "0"
 
     def ln_lin16(self, gb, L, x_rows, delta_rows, add_rows, m_rows, out, out_ctot=None, out_coff=0, L2=None, write_back=True):
         """out = Linear(LayerNorm(x_rows (+ delta_rows on the first add_rows rows, written back to x_rows if ``write_back``))) [-> second
@@ -368,6 +369,15 @@ class V2XViTEngine(Where2ComEngine):
                     add_ln(blk["ln2"], m)
                     self.lin16(blk["qkv3"], xn, m * hw, qkv3)
                 for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
+                    if self.fuse_window_out and H % 4 == 0 and W % 16 == 0 and h * dh == 256 and (dh, ws) in ((16, 2), (32, 4), (64, 4)):
+                        # attention + its output projection in one launch: a rule of the map shape, same bits as the two launches
+                        L = blk["wout"][i]
+                        self.timed_hbm(f"window_attention_linear_bf16 ws{ws} dh{dh}", m * hw * 2 * (768 + 256) + 256 * 256 * 2,
+                                       4.0 * m * hw * ws * ws * 256 + 2.0 * m * hw * 256 * 256,
+                                       lambda: _lib.check(self.lib.av2x_window_attention_linear_bf16(
+                                           _ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(_w16i(L)[0]), _ptr(L.shift), _ptr(br[i]), C, 0,
+                                           m, H, W, h, dh, ws, st()), "av2x_window_attention_linear_bf16"))
+                        continue
                     self.timed_hbm(f"window_attention_bf16 ws{ws} dh{dh}", m * hw * 2 * (768 + 256), 4.0 * m * hw * ws * ws * 256,
                                    lambda: _lib.check(self.lib.av2x_window_attention_bf16(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat),
                                                                                           m, H, W, h, dh, ws, st()), "av2x_window_attention_bf16"))

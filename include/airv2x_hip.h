@@ -696,6 +696,14 @@ int av2x_split_attn_gap_bf16(const uint16_t* s0, const uint16_t* s1, const uint1
                              float* scratch /* n*128*c floats */, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
 int av2x_split_attn_combine_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
                                  const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
+/* One branch of the pyramid window attention with its output projection (mswin.py:52-96 BaseWindowAttention: to_out Linear of the
+ * attention output): out[slice] = bf16(bf16(WindowAttention(qkv slice)) . W + bias), bit-identical to av2x_window_attention_bf16
+ * followed by av2x_linear_bf16; the attention output stays in LDS.  h % 4 == 0, w % 16 == 0 (4 x 16-pixel blocks);
+ * heads x dim_head = 256; (dim_head, window) in (16,2) (32,4) (64,4); w_packed as av2x_linear_bf16 (256 -> 256). */
+int av2x_window_attention_linear_bf16(const uint16_t* qkv, int32_t ctot, int32_t coff, const float* pos_embedding,
+                                      const uint16_t* w_packed, const float* bias, uint16_t* out, int32_t out_ctot, int32_t out_coff,
+                                      int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
+                                      av2x_stream_t stream);
 /* as av2x_split_attn_combine_bf16 with residual + delta (bf16, same shape; the pending add of av2x_ln_linear_bf16) as the residual */
 int av2x_split_attn_combine_delta_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
                                        const float* residual, const uint16_t* delta, float* out, int32_t n, int32_t hw, int32_t c,

@@ -169,6 +169,35 @@ def test_window_attention_bf16_is_the_fp32_kernel_on_bf16_storage(heads, dh, ws,
     assert torch.equal(o16, o32.to(BF))
 
 
+@pytest.mark.parametrize("heads,dh,ws,coff,octot,ocoff", [(16, 16, 2, 0, 256, 0), (8, 32, 4, 768, 256, 0), (4, 64, 4, 1536, 768, 256)])
+def test_window_attention_with_its_output_projection_equals_the_two_launches(heads, dh, ws, coff, octot, ocoff):
+    """av2x_window_attention_linear_bf16 (the attention output stays in LDS as the A panel of to_out, mswin.py:52-96) against
+    av2x_window_attention_bf16 + av2x_linear_bf16: same bits; the map must split into 4 x 16-pixel blocks."""
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    n, H, W = 3, 12, 48
+    g = _g(heads * 3 + coff)
+    qkv = torch.randn(n, H, W, 2304, generator=g).to(BF).cuda()
+    pos = torch.randn(2 * ws - 1, 2 * ws - 1, generator=g).cuda()
+    wt = (torch.randn(256, 256, generator=g) / 16).to(BF).float()
+    b = torch.randn(256, generator=g) * 0.2
+    w16, coutp = _pack(wt)
+    wd, bd = w16.cuda(), b.cuda()
+    wat = torch.zeros(n, H, W, 256, device="cuda", dtype=BF)
+    want = torch.full((n, H, W, octot), 7.0, device="cuda").to(BF)
+    _lib.check(lib.av2x_window_attention_bf16(_p(qkv), 2304, coff, _p(pos), _p(wat), n, H, W, heads, dh, ws, _st()), "win16")
+    _lib.check(lib.av2x_linear_bf16(_p(wat), _p(wd), _p(bd), None, _p(want), n * H * W, 256, 256, coutp, 1, octot, ocoff, 0, 0, 0, _st()), "lin")
+    got = torch.full((n, H, W, octot), 7.0, device="cuda").to(BF)
+    _lib.check(lib.av2x_window_attention_linear_bf16(_p(qkv), 2304, coff, _p(pos), _p(wd), _p(bd), _p(got), octot, ocoff, n, H, W, heads, dh, ws,
+                                                     _st()), "win+lin")
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # maps that do not split into 4 x 16 blocks, an unsupported (dim_head, window) pair
+    assert lib.av2x_window_attention_linear_bf16(_p(qkv), 2304, coff, _p(pos), _p(wd), _p(bd), _p(got), octot, ocoff, n, H, 40, heads, dh, ws,
+                                                 _st()) != 0
+    assert lib.av2x_window_attention_linear_bf16(_p(qkv), 2304, coff, _p(pos), _p(wd), _p(bd), _p(got), octot, ocoff, n, H, W, 8, 32, 2,
+                                                 _st()) != 0
+
+
 def test_split_attention_bf16_is_the_fp32_kernel_on_bf16_storage():
     from airv2x_perception_amd import _lib
     lib = _lib.load()
@@ -337,7 +366,8 @@ def test_ln_linear_bf16_equals_the_separate_launches_bit_for_bit(m, add_rows, co
 
 @pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n8"])
 def test_v2xvit_fused_layernorm_linear_frame_equals_the_unfused_frame(name):
-    """The bf16-activation frame with LayerNorm folded into the Linears (default) and with separate LayerNorm launches: same bits."""
+    """The bf16-activation frame with LayerNorm folded into the Linears and the window attention into its output projection (default)
+    and with all of them as separate launches: same bits."""
     from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
     import tests.test_v2xvit as tv
     fx = load_fixture(name)
@@ -347,12 +377,12 @@ def test_v2xvit_fused_layernorm_linear_frame_equals_the_unfused_frame(name):
     model = model.to("cuda").eval()
     eng = model.engine()
     model.amp = True
-    assert eng.fuse_ln is True
+    assert eng.fuse_ln is True and eng.fuse_window_out is True
     fused = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
-    eng.fuse_ln = False
+    eng.fuse_ln = eng.fuse_window_out = False
     try:
         plain = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
     finally:
-        eng.fuse_ln = True
+        eng.fuse_ln = eng.fuse_window_out = True
     for k in ("psm", "rm", "obj"):
         assert torch.equal(fused[k], plain[k]), k
