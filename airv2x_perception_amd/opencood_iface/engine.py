@@ -547,7 +547,7 @@ class Where2ComEngine:
                     g = -(-total // per)
                 wgs = g
             self.profile.append(((bm, bn), 2.0 * n * d.ho * d.wo * ncols * L.ks * L.ks * L.cin, e0, e1, wgs,
-                                 (n * d.ho * d.wo, L.cin, ncols, L.ks, L.stride)))
+                                 (n * d.ho * d.wo, L.cin, ncols, L.ks, L.stride, x.element_size(), 2 if self.amp else 4, out.element_size())))
         return ho, wo
 
     # 32 tiles x 64 couts per workgroup, 8 of the 16 positions per wave (128 accumulation registers: two workgroups per CU,

@@ -190,20 +190,21 @@ MESSAGE = {"where2com": "the masked multi-scale features (15.8 MB per agent)",
 
 
 def hbm_kernel_traffic(family, alg_bytes_per_launch):
-    """roofline.traffic of an HBM-bound kernel family from its PMC pass (tools/pmc_lin16b.sh: counters-only FETCH_SIZE / WRITE_SIZE
-    passes over tools/lin16_bench.py at 281 600 tokens): measured bytes / algorithmic bytes of the same launches, applied to this
-    run's launch mix.  None when no pass is committed for the family."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03b_pmc_linear_bf16.json")
-    if family != "linear_bf16" or not os.path.exists(path):
+    """roofline.traffic of an HBM-bound kernel family from its PMC pass (tools/pmc_frame_r03e.sh: counters-only FETCH_SIZE / WRITE_SIZE
+    passes over the V2X-ViT autocast frame at 8 agents, averaged over every launch of the family): measured bytes per launch over the
+    algorithmic bytes per launch of the same launch mix, applied to this run's launches.  None when no pass is committed for the family."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03e_pmc_v2xvit_amp_frame.json")
+    if not os.path.exists(path):
         return {"traffic": None, "traffic_over_algorithmic": None, "traffic_note": "no PMC pass committed for this kernel"}
     d = json.load(open(path))
-    tok = d["tokens"]
-    alg = {"256->1280": tok * (256 + 1280) * 2, "256->2304": tok * (256 + 2304) * 2, "256->256": tok * 512 * 2}
-    meas = sum(d["per_shape"][k]["bytes"] for k in alg)
-    ratio = meas / sum(alg.values())
+    fam = d["per_family"].get(family)
+    ref_alg = d.get("algorithmic_bytes_per_launch", {}).get(family)
+    if not fam or not ref_alg:
+        return {"traffic": None, "traffic_over_algorithmic": None, "traffic_note": "no PMC pass committed for this kernel"}
+    ratio = fam["bytes_per_launch"] / ref_alg
     return {"traffic": round(alg_bytes_per_launch * ratio), "traffic_over_algorithmic": round(ratio, 3),
-            "traffic_note": "PMC (2 x FETCH_SIZE + WRITE_SIZE, profiles/r03b_pmc_linear_bf16.json) over algorithmic bytes of the same "
-                            "launches at 281 600 tokens, applied to this run's launch mix"}
+            "traffic_note": "PMC (2 x FETCH_SIZE + WRITE_SIZE, profiles/r03e_pmc_v2xvit_amp_frame.json: average over the family's launches of the "
+                            "8-agent autocast frame) over the algorithmic bytes of the same launch mix, applied to this run's launches"}
 
 
 def make_model(a, args, dev):
@@ -708,7 +709,8 @@ def main(argv=None, hooks=None, device=None):
         cnt, fl, sec, exe = per[dom]
         # algorithmic HBM bytes of the dominant kernel's launches: input pixels x Cin + the filter + output pixels x Cout, fp32,
         # each once (shape = (M output pixels, Cin, Cout, kernel size, stride); a strided layer reads stride^2 x M input pixels)
-        alg_bytes = sum(v[0] * 4 * (k[0][0] * k[0][4] ** 2 * k[0][1] + k[0][3] ** 2 * k[0][1] * k[0][2] + k[0][0] * k[0][2])
+        # k[0][5:8] = element sizes of input, weights, output as launched (bf16 activations / weights in AMP mode)
+        alg_bytes = sum(v[0] * (k[0][5] * k[0][0] * k[0][4] ** 2 * k[0][1] + k[0][6] * k[0][3] ** 2 * k[0][1] * k[0][2] + k[0][7] * k[0][0] * k[0][2])
                         for k, v in shapes.items() if k[1] == dom) / cnt
         ach = exe / sec / 1e12          # executed matrix-core FLOPs: what the MFMA peak bounds
         eff = fl / sec / 1e12           # direct-convolution FLOPs (SURVEY 8d's per-frame figure) over the same time
@@ -718,6 +720,9 @@ def main(argv=None, hooks=None, device=None):
         tot_s = sum(v[2] for v in per.values())
         tkey = lambda k: f"{('w4_' if k[0] & 0x2000 else 'w') if k[0] & 0x4000 else ('halo' if k[0] & 0x1000 else '')}{'g' if k[1] & 0x0200 else ''}{k[0] & 0x0fff}x{k[1] & 0x01ff}{(('q' if (k[1] & 0x01ff) == 32 else 'h') if k[0] & 0x4000 else 'w8') if k[1] & 0x8000 else ''}{'d' if k[1] & 0x4000 else ''}{'sk' if k[1] & 0x2000 else ''}{'p' if k[1] & 0x1000 else ''}{'_bf16' if k[1] & 0x0800 else ''}{'_bf16x3' if k[1] & 0x0400 else ''}"
         traffic, traffic_note = pmc_traffic(tkey(dom), grids[dom])
+        if dom[0] & 0x1000:
+            t_ = hbm_kernel_traffic("conv_halo_bf16", alg_bytes)
+            traffic, traffic_note = t_["traffic"], t_["traffic_note"]
         peak = PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS
         res["roofline"] = {
             # achieved / frac = the multiplies the matrix cores EXECUTE over the launch time: what the MFMA peak bounds (always <= 1).
@@ -759,7 +764,7 @@ def main(argv=None, hooks=None, device=None):
             "per_tile": {tkey(k): {"launches_per_frame": v[0] / a.steps, "tflops": round(v[1] / v[2] / 1e12, 2),
                                    **({"executed_tflops": round(v[3] / v[2] / 1e12, 2)} if k[0] & 0x4000 else {}),
                                    "ms_per_frame": round(v[2] / a.steps * 1e3, 3)} for k, v in per.items()},
-            **({"per_shape": [{"M_cin_cout_ks_stride": list(k[0]), "tile": tkey(k[1]), "wgs": k[2], "launches_per_frame": v[0] / a.steps,
+            **({"per_shape": [{"M_cin_cout_ks_stride": list(k[0][:5]), "tile": tkey(k[1]), "wgs": k[2], "launches_per_frame": v[0] / a.steps,
                                "us": round(v[2] / v[0] * 1e6, 1), "tflops": round(v[1] / v[2] / 1e12, 1)}
                               for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2])]} if a.per_shape else {}),
             **({"measured_on": f"rank 0, whole {a.agents}-agent frames on one GPU (the sharded run launches the same kernels on "
@@ -789,7 +794,8 @@ def main(argv=None, hooks=None, device=None):
                                                     "peak_gb_per_s": PEAK_HBM_GBPS}
             fam = {}            # one device kernel per family (linear_bf16 256->N are launches of the same kernel)
             for k, v in hk.items():
-                f = fam.setdefault(k.split()[0], [0, 0.0, 0.0, 0.0])
+                # linear_bf16 .. and window_attention_linear_bf16 .. are panel sources of ONE device kernel (linear_bf16_occ_kernel<SRC, FFN, DH>)
+                f = fam.setdefault("linear_bf16" if "linear_bf16" in k.split()[0] else k.split()[0], [0, 0.0, 0.0, 0.0])
                 for i_ in range(4):
                     f[i_] += v[i_]
             top, tv = max(fam.items(), key=lambda kv: kv[1][3])
@@ -799,7 +805,8 @@ def main(argv=None, hooks=None, device=None):
                 res["roofline"].update({
                     "bound": "hbm", "achieved": round(tv[1] / tv[3] / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(tv[1] / tv[3] / 1e9 / PEAK_HBM_GBPS, 4), **hbm_kernel_traffic(top, tv[1] / tv[0]),
-                    "kernel": f"{top} (csrc/linear_bf16.hip: 64-token panels in LDS, W fragments from L2, bf16 in / out)" if top.startswith("linear") else top,
+                    "kernel": (f"{top}_occ_kernel<SRC, FFN, DH> (csrc/linear_bf16.hip: 64-token panels in LDS -- bf16 rows, LayerNorm of the fp32 stream or the "
+                               "window attention of a 4 x 16-pixel block as the panel source --, W fragments from L2, bf16 out)") if top.startswith("linear") else top,
                     "launches_per_frame": tv[0] / a.steps, "avg_launch_us": round(tv[3] / tv[0] * 1e6, 2),
                     "algorithmic_bytes_per_launch": round(tv[1] / tv[0]),
                     "dominant_mfma_kernel": conv_view})
