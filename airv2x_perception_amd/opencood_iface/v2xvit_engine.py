@@ -142,9 +142,12 @@ class V2XViTEngine(Where2ComEngine):
         T = warp_host.transformation_matrix(d, (H, W))
         theta = torch.from_numpy(warp_host.affine_theta(T, (H, W), (H, W))).to(self.device)
         if n > 1:
-            warped = self.buf("sttf_warped", (n - 1, H, W, C))
-            _lib.check(self.lib.av2x_warp_affine(_ptr(x[1:]), _ptr(theta[1:]), _ptr(warped), n - 1, H, W, C, st()), "av2x_warp_affine")
-            x[1:].copy_(warped)
+            # the warped maps land in a second buffer that becomes the stream from here on (the ego's map is moved there: 1 / n of the
+            # copy-back of all the warped maps)
+            xw = self.buf("sttf_out", (n, H, W, C))
+            _lib.check(self.lib.av2x_warp_affine(_ptr(x[1:]), _ptr(theta[1:]), _ptr(xw[1:]), n - 1, H, W, C, st()), "av2x_warp_affine")
+            xw[0].copy_(x[0])
+            x = xw
         mask = self.buf("com_mask", (n, H, W))
         ones = self.buf("cav_ones", (n,), torch.int32)
         if self.enc["use_roi_mask"]:
@@ -530,6 +533,10 @@ class V2XViTEngine(Where2ComEngine):
         B, n_total = len(record_len), sum(record_len)
         if max(record_len) > self.L:
             raise ValueError(f"{max(record_len)} agents exceed max_cav_num = {self.L}")
+        # host metadata first: a device -> host copy waits for everything queued on the stream, so it is read BEFORE this frame's
+        # encoders and trunk are launched, not between the trunk and the fusion
+        prior_all = data_dict["prior_encoding"].detach().cpu().numpy()           # (B,L,3) per-agent scalars (appendix A #12)
+        scm_all = data_dict["spatial_correction_matrix"].detach().cpu().numpy()  # (B,L,4,4) f64
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
@@ -539,8 +546,6 @@ class V2XViTEngine(Where2ComEngine):
         H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
         x = self.buf("vit_x", (n_total, H, Wd, 256))
         self.trunk(canvas, n_total, ny, nx, shrink_out=x)                        # all agents of the batch at once
-        prior_all = data_dict["prior_encoding"].detach().cpu().numpy()           # (B,L,3) per-agent scalars (appendix A #12)
-        scm_all = data_dict["spatial_correction_matrix"].detach().cpu().numpy()  # (B,L,4,4) f64
         fused_all = self.buf("vit_fused", (B, H, Wd, 256))
         off = 0
         for b, n in enumerate(record_len):                                       # the fusion never mixes samples
