@@ -148,6 +148,8 @@ SIGNATURES = {
                                              c_int32, c_int32, c_void_p]),
     "av2x_window_attention_linear_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                     c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_ln_qkv_window_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_split_attn_gap_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_split_attn_combine_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                c_int32, c_void_p]),

@@ -420,6 +420,283 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
     }
 }
 
+// ---- LayerNorm -> three window-attention QKVs -> window attention -> to_out of a 4 x 16-pixel block in ONE workgroup (the
+// PreNormResidual(PyramidWindowAttention) body of V2XFusionBlock, v2xvit_basic.py:137-159, mswin.py:99-145): the 2304-wide QKV
+// tensor (1.3 GB per layer at 8 agents, written and read back by the separate launches) never exists in HBM.
+//   LDS: four [64][264] bf16 panels = 132 KB -> one workgroup per CU: P0 = LayerNorm(x (+ delta)), P1 / P2 / P3 = q / k / v of the
+//   current branch (chunk 3 b + c of the packed 256 -> 2304 weights), the attention output overwrites q in place (a (window, head)
+//   task reads exactly the q region it writes), P1 is then the A panel of to_out (chunk b of the packed 256 -> 768 weights).
+//   Every GEMM is the K loop of linear_bf16_occ_kernel (same MFMA sequence per output), the q / k / v panels are rounded to bf16 as
+//   the stored tensor was, the attention is the instruction sequence of v2xvit.hip's kernels: the outputs are the bits of
+//   av2x_ln_linear_bf16 + 3 x av2x_window_attention_linear_bf16.  Eight K-steps of weight fragments in flight (one workgroup per
+//   CU: nobody else hides the L2 latency).
+struct QwParams {
+    const float* x;
+    const __bf16* delta;      // pending residual of every row (or nullptr): feeds the LayerNorm, x is not rewritten
+    const float* gamma;
+    const float* beta;
+    float eps;
+    const __bf16* w;          // 256 -> 2304: [q | k | v] of the three branches
+    const float* bias;        // or nullptr
+    const __bf16* w2;         // 256 -> 768: the three to_out
+    const float* bias2;
+    const float* pos[3];
+    __bf16* out[3];
+    int heads[3], dh[3];
+    int H, W;
+    int debug;
+};
+
+__global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const QwParams p) {
+    constexpr int PSZ = 64 * LROW, DEPTH = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
+    __bf16* P0 = reinterpret_cast<__bf16*>(lin_smem);
+    __bf16* P1 = P0 + PSZ;
+    __bf16* P2 = P1 + PSZ;
+    __bf16* P3 = P2 + PSZ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int bx = p.W >> 4, by = p.H >> 2;
+    const int tx = blockIdx.x % bx, ty = (blockIdx.x / bx) % by, ag = blockIdx.x / (bx * by);
+    const long long m0 = ((long long)ag * p.H + 4 * ty) * p.W + 16 * tx;
+    const int span = 3 * p.W + 16;                                  // tokens from the block's first pixel to its last
+
+    constexpr int CP1 = 2304, CP2 = 768;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (unsigned)((LK / 8) * CP1 * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w2), 0, (unsigned)((LK / 8) * CP2 * 16), 0x00020000);
+    const unsigned voff1 = (unsigned)((lh * CP1 + wave * 64 + li) * 16), voff2 = (unsigned)((lh * CP2 + wave * 64 + li) * 16);
+    u32x4 bf[DEPTH][2];
+    auto loadB = [&](u32x4 (&dst)[2], bool second, int ch, int s) {
+        if (second) {
+            const unsigned so = (unsigned)s * (2 * CP2 * 16) + (unsigned)ch * (256 * 16);
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw2, voff2, so, 0);
+            dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rw2, voff2 + 32 * 16, so, 0);
+        } else {
+            const unsigned so = (unsigned)s * (2 * CP1 * 16) + (unsigned)ch * (256 * 16);
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff1, so, 0);
+            dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff1 + 32 * 16, so, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) loadB(bf[s], false, 0, s);
+
+    // ---- P0 = LayerNorm(x (+ delta)): wave w = block row w, 16 pixels, four channels per lane (layernorm_row_256)
+    {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + m0 * LK, 0, (unsigned)span * (LK * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.delta ? p.delta + m0 * LK : nullptr), 0,
+                                                                            p.delta ? (unsigned)span * (LK * 2) : 0u, 0x00020000);
+        const float4 g = reinterpret_cast<const float4*>(p.gamma)[lane], bt = reinterpret_cast<const float4*>(p.beta)[lane];
+        const bool add = p.delta != nullptr;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 xv[8];
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tok = wave * p.W + half * 8 + j;
+                xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(tok * (LK * 4) + lane * 16), 0, LIN_NT));
+                dv[j] = __builtin_amdgcn_raw_buffer_load_b64(rd, (unsigned)(tok * (LK * 2) + lane * 8), 0, LIN_NT);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float4 v = make_float4(xv[j][0], xv[j][1], xv[j][2], xv[j][3]);
+                if (add) v = add_bf16x4(v, make_uint2(dv[j][0], dv[j][1]));
+                const f32x4 y = layernorm_row_256(v, g, bt, p.eps);
+                *reinterpret_cast<bf16x4*>(P0 + (wave * 16 + half * 8 + j) * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
+            }
+        }
+    }
+    __syncthreads();
+
+    const bool odd = li & 1, hi = li & 2;
+    f32x16 acc[2][2];
+    auto kloop = [&](const __bf16* A, bool second, int ch, bool nsecond, int chn) {
+        const __bf16* Ab = A + li * LROW + lh * 8;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab + s * 16);
+            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + s * 16);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bf[s & (DEPTH - 1)][c]);
+                acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][c], 0, 0, 0);
+            }
+            if (s + DEPTH < 16) loadB(bf[s & (DEPTH - 1)], second, ch, s + DEPTH);
+            else loadB(bf[s & (DEPTH - 1)], nsecond, chn, s + DEPTH - 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // bias, one rounding, quad transposes (as linear_bf16_occ_kernel's epilogue); dst: an LDS panel or the output rows of the block
+    auto epilogue = [&](int ch, const float* bias, __bf16* panel, const __amdgpu_buffer_rsrc_t rout, auto to_lds) {
+        constexpr bool TO_LDS = decltype(to_lds)::value;
+        const int n = ch * 256 + wave * 64 + 2 * li;
+        float b0 = 0.f, b1 = 0.f;
+        if (bias) { b0 = bias[n]; b1 = bias[n + 1]; }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const unsigned off0 = (unsigned)((4 * lh + (li & 3)) * 512 + (wave * 64 + 2 * (li & ~3)) * 2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned R[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const f32x2 v = {acc[a][0][r] + b0, acc[a][1][r] + b1};
+                    R[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned send = odd ? R[2 * m] : R[2 * m + 1];
+                    const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);
+                    R[2 * m] = odd ? got : R[2 * m];
+                    R[2 * m + 1] = odd ? R[2 * m + 1] : got;
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned send = hi ? R[m] : R[m + 2];
+                    const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);
+                    R[m] = hi ? got : R[m];
+                    R[m + 2] = hi ? R[m + 2] : got;
+                }
+                const u32x4 v4 = {R[0], R[1], R[2], R[3]};
+                if constexpr (TO_LDS)
+                    *reinterpret_cast<u32x4*>(panel + (a * 32 + 8 * g + 4 * lh + (li & 3)) * LROW + wave * 64 + 2 * (li & ~3)) = v4;
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, rout, off0 + (unsigned)(((2 * a + (g >> 1)) * p.W + 8 * (g & 1)) * 512), 0, LIN_NT);
+            }
+    };
+    // window_attn_mfma_kernel on the LDS panels: (window, head) tasks of the block's four 4 x 4 windows
+    auto win4 = [&](auto dhc, int heads, const float* pos) {
+        constexpr int DH = decltype(dhc)::value, WS = 4, NB = DH / 16;
+        const int t = lane & 15, h = lane >> 4;
+        const int iy = t >> 2, ix = t & 3;
+        const float scale = 1.0f / sqrtf((float)DH);
+        float wbias[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wbias[r] = pos[(h - iy + WS - 1) * (2 * WS - 1) + (r - ix + WS - 1)];
+        const int ntask = 4 * heads;
+        for (int tk = wave; tk < ntask; tk += 4) {
+            const int head = tk % heads, wdw = tk / heads;
+            const int rowt = ((t >> 2) * 16 + 4 * wdw + (t & 3)) * LROW + head * DH;
+            lin_f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                const float4 qq = ld_bf16x4(P1 + rowt + 4 * (h + 4 * g));
+                const float4 kk = ld_bf16x4(P2 + rowt + 4 * (h + 4 * g));
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qq.x, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qq.y, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qq.z, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qq.w, st, 0, 0, 0);
+            }
+            float sc[4], mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = st[r] * scale + wbias[r]; mx = fmaxf(mx, sc[r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = expf(sc[r] - mx); l += sc[r]; }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                lin_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, (float)P3[(16 * h + 4 * wdw + r) * LROW + head * DH + nb * 16 + t], o, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P1[(16 * h + 4 * wdw + r) * LROW + head * DH + nb * 16 + t] = (__bf16)o[r];
+            }
+        }
+    };
+    // window_attn_kernel<16, 2> on the LDS panels: one (token, head) pair per thread and pass
+    auto win2 = [&](int heads, const float* pos) {
+        constexpr int WS = 2, DHD = 16;
+        const float scale = 1.0f / sqrtf((float)DHD);
+        for (int e = tid; e < 64 * heads; e += 256) {
+            const int head = e % heads, tok = e / heads;
+            const int py = tok >> 4, px = tok & 15;
+            const int wy0 = py & ~1, wx0 = px & ~1, iy = py - wy0, ixx = px - wx0;
+            float q[DHD], o[DHD];
+#pragma unroll
+            for (int d = 0; d < DHD; d += 4) {
+                const float4 v = ld_bf16x4(P1 + tok * LROW + head * DHD + d);
+                q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
+            }
+            float sj[WS * WS];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < WS * WS; ++j) {
+                const int jy = j / WS, jx = j % WS;
+                const __bf16* kr = P2 + ((wy0 + jy) * 16 + wx0 + jx) * LROW + head * DHD;
+                float a_ = 0.f;
+#pragma unroll
+                for (int d = 0; d < DHD; d += 4) {
+                    const float4 k = ld_bf16x4(kr + d);
+                    a_ = fmaf(q[d], k.x, a_); a_ = fmaf(q[d + 1], k.y, a_); a_ = fmaf(q[d + 2], k.z, a_); a_ = fmaf(q[d + 3], k.w, a_);
+                }
+                a_ = a_ * scale + pos[(jy - iy + WS - 1) * (2 * WS - 1) + (jx - ixx + WS - 1)];
+                sj[j] = a_;
+                mx = fmaxf(mx, a_);
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < WS * WS; ++j) { sj[j] = expf(sj[j] - mx); l += sj[j]; }
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int d = 0; d < DHD; ++d) o[d] = 0.f;
+#pragma unroll
+            for (int j = 0; j < WS * WS; ++j) {
+                const int jy = j / WS, jx = j % WS;
+                const __bf16* vr = P3 + ((wy0 + jy) * 16 + wx0 + jx) * LROW + head * DHD;
+                const float pj = sj[j] * inv;
+#pragma unroll
+                for (int d = 0; d < DHD; d += 4) {
+                    const float4 v = ld_bf16x4(vr + d);
+                    o[d] = fmaf(pj, v.x, o[d]); o[d + 1] = fmaf(pj, v.y, o[d + 1]); o[d + 2] = fmaf(pj, v.z, o[d + 2]); o[d + 3] = fmaf(pj, v.w, o[d + 3]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DHD; d += 4) {
+                const f32x4 f = {o[d], o[d + 1], o[d + 2], o[d + 3]};
+                *reinterpret_cast<bf16x4*>(P1 + tok * LROW + head * DHD + d) = __builtin_convertvector(f, bf16x4);
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            const int ch = 3 * b + c;
+            kloop(P0, false, ch, c == 2, c == 2 ? b : ch + 1);
+            if (c == 0) __syncthreads();          // every wave is past the previous branch's to_out K loop (reads of P1)
+            epilogue(ch, p.bias, P1 + c * PSZ, rw, std::true_type{});
+        }
+        __syncthreads();                          // q, k, v of the branch are complete
+        if (p.debug == 1) {}
+        else if (p.dh[b] == 16) win2(p.heads[b], p.pos[b]);
+        else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], p.pos[b]);
+        else win4(std::integral_constant<int, 64>{}, p.heads[b], p.pos[b]);
+        __syncthreads();                          // the attention output (in P1) is complete
+        kloop(P1, true, b, false, b < 2 ? 3 * (b + 1) : 0);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out[b] + m0 * LK, 0, (unsigned)span * (LK * 2), 0x00020000);
+        epilogue(b, p.bias2, nullptr, rout, std::false_type{});
+    }
+}
+
 template <bool OUT16>
 __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const LinParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
@@ -656,6 +933,40 @@ extern "C" int av2x_window_attention_linear_bf16(const uint16_t* qkv, int32_t ct
     else if (dim_head == 32) hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_WIN4, false, 32>), grid, block, lds + 4 * 16 * 32 * 2, st, p);
     else hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_WIN4, false, 64>), grid, block, lds + 4 * 16 * 64 * 2, st, p);
     return av2x::check_launch("linear_bf16_occ_kernel<WIN>");
+}
+
+extern "C" int av2x_ln_qkv_window_attention_bf16(const float* x, const uint16_t* delta, const float* gamma, const float* beta, float eps,
+                                                const uint16_t* wqkv_packed, const float* bias_qkv, const uint16_t* wout3_packed,
+                                                const float* bias_out3, const float* const* pos_embeddings, uint16_t* const* outs,
+                                                const int32_t* heads, const int32_t* dim_heads, const int32_t* windows, int32_t n,
+                                                int32_t h, int32_t w, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!x || !gamma || !beta || !wqkv_packed || !wout3_packed || !bias_out3 || !pos_embeddings || !outs || !heads || !dim_heads || !windows)
+        return av2x::fail("av2x_ln_qkv_window_attention_bf16: null argument");
+    if (n < 0 || h <= 0 || w <= 0 || h % 4 || w % 16)
+        return av2x::fail("av2x_ln_qkv_window_attention_bf16: the map (%d x %d) must split into 4 x 16-pixel blocks", h, w);
+    if ((unsigned long long)(3 * (unsigned long long)w + 16) * 1024ull >= (1ull << 32)) return av2x::fail("av2x_ln_qkv_window_attention_bf16: map too wide");
+    QwParams p = {};
+    p.x = x; p.delta = reinterpret_cast<const __bf16*>(delta); p.gamma = gamma; p.beta = beta; p.eps = eps;
+    p.w = reinterpret_cast<const __bf16*>(wqkv_packed); p.bias = bias_qkv;
+    p.w2 = reinterpret_cast<const __bf16*>(wout3_packed); p.bias2 = bias_out3;
+    for (int b = 0; b < 3; ++b) {
+        if (!pos_embeddings[b] || !outs[b]) return av2x::fail("av2x_ln_qkv_window_attention_bf16: null argument");
+        if (heads[b] * dim_heads[b] != 256 ||
+            !((windows[b] == 4 && (dim_heads[b] == 32 || dim_heads[b] == 64)) || (windows[b] == 2 && dim_heads[b] == 16)))
+            return av2x::fail("av2x_ln_qkv_window_attention_bf16: branch %d (heads %d, dim_head %d, window %d) unsupported: heads x dim_head = 256, "
+                              "(dim_head, window) in (16,2) (32,4) (64,4)", b, heads[b], dim_heads[b], windows[b]);
+        p.pos[b] = pos_embeddings[b]; p.out[b] = reinterpret_cast<__bf16*>(outs[b]); p.heads[b] = heads[b]; p.dh[b] = dim_heads[b];
+    }
+    p.H = h; p.W = w;
+    p.debug = getenv("AV2X_QW_DEBUG") ? atoi(getenv("AV2X_QW_DEBUG")) : 0;
+    const long long blocks = (long long)n * (h / 4) * (w / 16);
+    if (blocks > (1ll << 30)) return av2x::fail("av2x_ln_qkv_window_attention_bf16: too many workgroups");
+    const size_t lds = (size_t)4 * 64 * LROW * 2;
+    static av2x::LdsLimit lim;
+    lim.ensure(reinterpret_cast<const void*>(&ln_qkv_window_out_bf16_kernel), lds);
+    hipLaunchKernelGGL(ln_qkv_window_out_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, av2x::as_stream(stream), p);
+    return av2x::check_launch("ln_qkv_window_out_bf16_kernel");
 }
 
 extern "C" int av2x_add_layernorm_bf16(float* x, const uint16_t* delta, const float* gamma, const float* beta, uint16_t* y,

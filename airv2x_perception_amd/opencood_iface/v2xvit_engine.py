@@ -256,6 +256,15 @@ class V2XViTEngine(Where2ComEngine):
     # one launch (csrc/linear_bf16.hip linear_bf16_occ_kernel<LN, FFN>): bit-identical to the separate launches
     fuse_ln = os.environ.get("AV2X_FUSE_LN", "1") != "0"
     fuse_window_out = os.environ.get("AV2X_FUSE_WINDOW_OUT", "1") != "0"
+    # ... and LayerNorm -> QKV -> window attention -> to_out of a 4 x 16-pixel block in one workgroup (ln_qkv_window_out_bf16_kernel)
+    fuse_qkv_window = os.environ.get("AV2X_FUSE_QKV_WINDOW", "1") != "0"
+
+    def _wout3(self, blk):
+        """the three to_out Linears as one packed 256 -> 768 weight (columns [256 b, 256 b + 256) = branch b) + the (768,) bias"""
+        if "wout3" not in blk:
+            ws = [_w16i(L)[0] for L in blk["wout"]]                      # each [32][256][8]: interleaving acts inside groups of 64 columns
+            blk["wout3"] = (torch.cat(ws, -2).contiguous(), torch.cat([L.shift for L in blk["wout"]]).contiguous())
+        return blk["wout3"]
 
     def ln_lin16(self, gb, L, x_rows, delta_rows, add_rows, m_rows, out, out_ctot=None, out_coff=0, L2=None, write_back=True):
         """out = Linear(LayerNorm(x_rows (+ delta_rows on the first add_rows rows, written back to x_rows if ``write_back``))) [-> second
@@ -363,7 +372,24 @@ class V2XViTEngine(Where2ComEngine):
                     add_ln(None, 0)
                     trace[f"hgt{di}"] = x.clone()
                 # ---- x = SplitAttn(window attentions(LN(x))) + x
-                if fuse:
+                pwc = list(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"]))
+                mega = (fuse and self.fuse_qkv_window and H % 4 == 0 and W % 16 == 0 and len(pwc) == 3
+                        and all(h_ * dh_ == 256 and (dh_, ws_) in ((16, 2), (32, 4), (64, 4)) for h_, dh_, ws_ in pwc))
+                if mega:
+                    assert pending[0] in (0, m)
+                    w3, b3 = self._wout3(blk)
+                    Lq = blk["qkv3"]
+                    posv = (c_void_p * 3)(*[t_.data_ptr() for t_ in blk["pos"]])
+                    outv = (c_void_p * 3)(*[t_.data_ptr() for t_ in br])
+                    hv, dv, wv = ((c_int32 * 3)(*[c_[k_] for c_ in pwc]) for k_ in range(3))
+                    self.timed_hbm("linear_bf16 ln+qkv+window+out", m * hw * (1024 + (512 if pending[0] else 0) + 3 * 512) + (2304 + 768) * 512,
+                                   2.0 * m * hw * 256 * (2304 + 768) + sum(4.0 * m * hw * ws_ * ws_ * 256 for _, _, ws_ in pwc),
+                                   lambda: _lib.check(self.lib.av2x_ln_qkv_window_attention_bf16(
+                                       _ptr(x), _ptr(delta) if pending[0] else c_void_p(0), _ptr(blk["ln2"][0]), _ptr(blk["ln2"][1]), LN_EPS,
+                                       _ptr(_w16i(Lq)[0]), _ptr(Lq.shift), _ptr(w3), _ptr(b3), ctypes.cast(posv, c_void_p), ctypes.cast(outv, c_void_p),
+                                       ctypes.cast(hv, c_void_p), ctypes.cast(dv, c_void_p), ctypes.cast(wv, c_void_p), m, H, W, st()),
+                                       "av2x_ln_qkv_window_attention_bf16"))
+                elif fuse:
                     # the HGT residual (pending == m agents here) feeds the LayerNorm but is NOT written back to x by this write-bound
                     # launch: the combine kernel below reads x anyway and adds it there (a 16-bit read instead of an fp32 write)
                     assert pending[0] in (0, m)
@@ -371,7 +397,7 @@ class V2XViTEngine(Where2ComEngine):
                 else:
                     add_ln(blk["ln2"], m)
                     self.lin16(blk["qkv3"], xn, m * hw, qkv3)
-                for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
+                for i, (h, dh, ws) in enumerate([] if mega else pwc):
                     if self.fuse_window_out and H % 4 == 0 and W % 16 == 0 and h * dh == 256 and (dh, ws) in ((16, 2), (32, 4), (64, 4)):
                         # attention + its output projection in one launch: a rule of the map shape, same bits as the two launches
                         L = blk["wout"][i]

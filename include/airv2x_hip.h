@@ -704,6 +704,19 @@ int av2x_window_attention_linear_bf16(const uint16_t* qkv, int32_t ctot, int32_t
                                       const uint16_t* w_packed, const float* bias, uint16_t* out, int32_t out_ctot, int32_t out_coff,
                                       int32_t n, int32_t h, int32_t w, int32_t heads, int32_t dim_head, int32_t window,
                                       av2x_stream_t stream);
+/* PreNormResidual(PyramidWindowAttention) up to the three branch outputs in ONE launch (v2xvit_basic.py:137-159, mswin.py:99-145):
+ * LayerNorm(x (+ delta, bf16, NULL = none; x itself is not rewritten)) -> the three [q | k | v] projections (wqkv_packed: 256 -> 2304,
+ * branch b at columns [768 b, 768 b + 768)) -> window attention of branch b (heads[b] x dim_heads[b] = 256, windows[b]; pos_embeddings[b]) ->
+ * to_out of branch b (wout3_packed: 256 -> 768, branch b at columns [256 b, 256 b + 256); bias_out3 (768,)) -> outs[b] (n, h, w, 256) bf16.
+ * One workgroup per 4 x 16-pixel block (h % 4 == 0, w % 16 == 0) holds the normalised panel and q, k, v of the current branch in LDS:
+ * neither the normalised tensor nor the 2304-wide QKV tensor nor the attention output exist in HBM.  Bit-identical to
+ * av2x_ln_linear_bf16 (write_back_x = 0) + 3 x av2x_window_attention_linear_bf16.  pos_embeddings / outs / heads / dim_heads / windows: host
+ * arrays of 3. */
+int av2x_ln_qkv_window_attention_bf16(const float* x, const uint16_t* delta, const float* gamma, const float* beta, float eps,
+                                      const uint16_t* wqkv_packed, const float* bias_qkv, const uint16_t* wout3_packed,
+                                      const float* bias_out3, const float* const* pos_embeddings, uint16_t* const* outs,
+                                      const int32_t* heads, const int32_t* dim_heads, const int32_t* windows, int32_t n, int32_t h,
+                                      int32_t w, av2x_stream_t stream);
 /* as av2x_split_attn_combine_bf16 with residual + delta (bf16, same shape; the pending add of av2x_ln_linear_bf16) as the residual */
 int av2x_split_attn_combine_delta_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
                                        const float* residual, const uint16_t* delta, float* out, int32_t n, int32_t hw, int32_t c,

@@ -198,6 +198,56 @@ def test_window_attention_with_its_output_projection_equals_the_two_launches(hea
                                                  _st()) != 0
 
 
+@pytest.mark.parametrize("with_delta,order", [(True, (0, 1, 2)), (False, (2, 0, 1))])
+def test_ln_qkv_window_attention_in_one_launch_equals_the_separate_launches(with_delta, order):
+    """av2x_ln_qkv_window_attention_bf16 (LayerNorm -> QKV -> window attention -> to_out of a 4 x 16-pixel block in one workgroup, the
+    2304-wide tensor never in HBM) against av2x_ln_linear_bf16 + 3 x av2x_window_attention_linear_bf16: same bits in the three branch maps."""
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    n, H, W = 2, 8, 32
+    cfg = [[(16, 16, 2), (8, 32, 4), (4, 64, 4)][i] for i in order]
+    g = _g(17 + order[0])
+    m = n * H * W
+    x = torch.randn(m, 256, generator=g) * 2 + 0.3
+    dl = torch.randn(m, 256, generator=g).to(BF)
+    gm, bt = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    wq = (torch.randn(2304, 256, generator=g) / 16).to(BF).float()
+    bq = torch.randn(2304, generator=g) * 0.1
+    wo = [(torch.randn(256, 256, generator=g) / 16).to(BF).float() for _ in range(3)]
+    bo = [torch.randn(256, generator=g) * 0.2 for _ in range(3)]
+    pos = [torch.randn(2 * ws - 1, 2 * ws - 1, generator=g).cuda() for _, _, ws in cfg]
+    (wq16, cqp) = _pack(wq)
+    wo16 = [_pack(w_)[0] for w_ in wo]
+    xd, dd, gd, bd, wqd, bqd = x.cuda(), dl.cuda(), gm.cuda(), bt.cuda(), wq16.cuda(), bq.cuda()
+    wod, bod = [w_.cuda() for w_ in wo16], [b_.cuda() for b_ in bo]
+    # --- separate launches
+    qkv = torch.zeros(m, 2304, device="cuda", dtype=BF)
+    x1 = xd.clone()
+    _lib.check(lib.av2x_ln_linear_bf16(_p(x1), _p(dd) if with_delta else None, m if with_delta else 0, 0, _p(gd), _p(bd), 1e-5, _p(wqd), _p(bqd),
+                                       0, 2304, cqp, None, None, 0, _p(qkv), 2304, 0, m, _st()), "ln+qkv")
+    want = [torch.zeros(n, H, W, 256, device="cuda", dtype=BF) for _ in range(3)]
+    for i, (h, dh, ws) in enumerate(cfg):
+        _lib.check(lib.av2x_window_attention_linear_bf16(_p(qkv), 2304, 768 * i, _p(pos[i]), _p(wod[i]), _p(bod[i]), _p(want[i]), 256, 0, n, H, W,
+                                                         h, dh, ws, _st()), "win+out")
+    # --- one launch
+    got = [torch.zeros(n, H, W, 256, device="cuda", dtype=BF) for _ in range(3)]
+    w3 = torch.cat(wod, -2).contiguous()
+    b3 = torch.cat(bod).contiguous()
+    posv = (c_void_p * 3)(*[t.data_ptr() for t in pos])
+    outv = (c_void_p * 3)(*[t.data_ptr() for t in got])
+    hv, dv, wv = ((c_int32 * 3)(*[c[k] for c in cfg]) for k in range(3))
+    x2 = xd.clone()
+    args = [_p(x2), _p(dd) if with_delta else None, _p(gd), _p(bd), 1e-5, _p(wqd), _p(bqd), _p(w3), _p(b3), ctypes.cast(posv, c_void_p),
+            ctypes.cast(outv, c_void_p), ctypes.cast(hv, c_void_p), ctypes.cast(dv, c_void_p), ctypes.cast(wv, c_void_p)]
+    _lib.check(lib.av2x_ln_qkv_window_attention_bf16(*args, n, H, W, _st()), "mega")
+    assert torch.equal(x2, xd)                                   # the stream is read only
+    for i in range(3):
+        assert torch.equal(got[i].view(torch.int16), want[i].view(torch.int16)), f"branch {i}"
+    assert lib.av2x_ln_qkv_window_attention_bf16(*args, n, H, 40, _st()) != 0          # not 4 x 16 blocks
+    bad = (c_int32 * 3)(8, 8, 8)
+    assert lib.av2x_ln_qkv_window_attention_bf16(*args[:11], ctypes.cast(bad, c_void_p), *args[12:], n, H, W, _st()) != 0
+
+
 def test_split_attention_bf16_is_the_fp32_kernel_on_bf16_storage():
     from airv2x_perception_amd import _lib
     lib = _lib.load()
@@ -377,12 +427,15 @@ def test_v2xvit_fused_layernorm_linear_frame_equals_the_unfused_frame(name):
     model = model.to("cuda").eval()
     eng = model.engine()
     model.amp = True
-    assert eng.fuse_ln is True and eng.fuse_window_out is True
+    assert eng.fuse_ln is True and eng.fuse_window_out is True and eng.fuse_qkv_window is True
     fused = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
-    eng.fuse_ln = eng.fuse_window_out = False
     try:
+        eng.fuse_qkv_window = False                       # LayerNorm -> QKV and attention -> to_out as separate fused launches
+        mid = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
+        eng.fuse_ln = eng.fuse_window_out = False         # every LayerNorm, Linear and attention its own launch
         plain = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
     finally:
-        eng.fuse_ln = eng.fuse_window_out = True
+        eng.fuse_ln = eng.fuse_window_out = eng.fuse_qkv_window = True
     for k in ("psm", "rm", "obj"):
         assert torch.equal(fused[k], plain[k]), k
+        assert torch.equal(mid[k], plain[k]), k
