@@ -444,7 +444,6 @@ struct QwParams {
     __bf16* out[3];
     int heads[3], dh[3];
     int H, W;
-    int debug;
 };
 
 __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const QwParams p) {
@@ -520,10 +519,16 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+        // one wave per SIMD: the A fragments of step s + 1 are requested before the MFMAs of step s (nobody else hides the LDS latency)
+        bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab);
+        bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab + s * 16);
-            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + s * 16);
+            bf16x8 fn0 = fa0, fn1 = fa1;
+            if (s + 1 < 16) {
+                fn0 = *reinterpret_cast<const bf16x8*>(Ab + (s + 1) * 16);
+                fn1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + (s + 1) * 16);
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const bf16x8 fb = __builtin_bit_cast(bf16x8, bf[s & (DEPTH - 1)][c]);
@@ -532,6 +537,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             }
             if (s + DEPTH < 16) loadB(bf[s & (DEPTH - 1)], second, ch, s + DEPTH);
             else loadB(bf[s & (DEPTH - 1)], nsecond, chn, s + DEPTH - 16);
+            fa0 = fn0; fa1 = fn1;
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -585,39 +591,65 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
         float wbias[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) wbias[r] = pos[(h - iy + WS - 1) * (2 * WS - 1) + (r - ix + WS - 1)];
-        const int ntask = 4 * heads;
-        for (int tk = wave; tk < ntask; tk += 4) {
-            const int head = tk % heads, wdw = tk / heads;
-            const int rowt = ((t >> 2) * 16 + 4 * wdw + (t & 3)) * LROW + head * DH;
-            lin_f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        const int ntask = 4 * heads;             // a multiple of 8: two independent tasks per wave and pass (one wave per SIMD: the second
+        for (int tk0 = wave; tk0 < ntask; tk0 += 8) {   // task's LDS reads and MFMAs fill the first one's latencies); per task the
+            int head[2], wdw[2], rowt[2];               // instruction sequence of window_attn_mfma_kernel
+            lin_f32x4 st[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int tk = tk0 + 4 * u;
+                head[u] = tk % heads; wdw[u] = tk / heads;
+                rowt[u] = ((t >> 2) * 16 + 4 * wdw[u] + (t & 3)) * LROW + head[u] * DH;
+                st[u] = lin_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int g = 0; g < NB; ++g) {
-                const float4 qq = ld_bf16x4(P1 + rowt + 4 * (h + 4 * g));
-                const float4 kk = ld_bf16x4(P2 + rowt + 4 * (h + 4 * g));
-                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qq.x, st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qq.y, st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qq.z, st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qq.w, st, 0, 0, 0);
+                float4 qq[2], kk[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    qq[u] = ld_bf16x4(P1 + rowt[u] + 4 * (h + 4 * g));
+                    kk[u] = ld_bf16x4(P2 + rowt[u] + 4 * (h + 4 * g));
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].x, qq[u].x, st[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].y, qq[u].y, st[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].z, qq[u].z, st[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].w, qq[u].w, st[u], 0, 0, 0);
             }
-            float sc[4], mx = -INFINITY;
+            float sc[2][4], inv[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[r] = st[r] * scale + wbias[r]; mx = fmaxf(mx, sc[r]); }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float l = 0.f;
+            for (int u = 0; u < 2; ++u) {
+                float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[r] = expf(sc[r] - mx); l += sc[r]; }
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            const float inv = 1.0f / l;
+                for (int r = 0; r < 4; ++r) { sc[u][r] = st[u][r] * scale + wbias[r]; mx = fmaxf(mx, sc[u][r]); }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float l = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[u][r] = expf(sc[u][r] - mx); l += sc[u][r]; }
+                l += __shfl_xor(l, 16);
+                l += __shfl_xor(l, 32);
+                inv[u] = 1.0f / l;
+            }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                lin_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                float vv[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[u][r] = (float)P3[(16 * h + 4 * wdw[u] + r) * LROW + head[u] * DH + nb * 16 + t];
+                lin_f32x4 o[2] = {lin_f32x4{0.f, 0.f, 0.f, 0.f}, lin_f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[r] * inv, (float)P3[(16 * h + 4 * wdw + r) * LROW + head * DH + nb * 16 + t], o, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) P1[(16 * h + 4 * wdw + r) * LROW + head * DH + nb * 16 + t] = (__bf16)o[r];
+                    for (int u = 0; u < 2; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[u][r] * inv[u], vv[u][r], o[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P1[(16 * h + 4 * wdw[u] + r) * LROW + head[u] * DH + nb * 16 + t] = (__bf16)o[u][r];
             }
         }
     };
@@ -686,8 +718,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             epilogue(ch, p.bias, P1 + c * PSZ, rw, std::true_type{});
         }
         __syncthreads();                          // q, k, v of the branch are complete
-        if (p.debug == 1) {}
-        else if (p.dh[b] == 16) win2(p.heads[b], p.pos[b]);
+        if (p.dh[b] == 16) win2(p.heads[b], p.pos[b]);
         else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], p.pos[b]);
         else win4(std::integral_constant<int, 64>{}, p.heads[b], p.pos[b]);
         __syncthreads();                          // the attention output (in P1) is complete
@@ -959,7 +990,6 @@ extern "C" int av2x_ln_qkv_window_attention_bf16(const float* x, const uint16_t*
         p.pos[b] = pos_embeddings[b]; p.out[b] = reinterpret_cast<__bf16*>(outs[b]); p.heads[b] = heads[b]; p.dh[b] = dim_heads[b];
     }
     p.H = h; p.W = w;
-    p.debug = getenv("AV2X_QW_DEBUG") ? atoi(getenv("AV2X_QW_DEBUG")) : 0;
     const long long blocks = (long long)n * (h / 4) * (w / 16);
     if (blocks > (1ll << 30)) return av2x::fail("av2x_ln_qkv_window_attention_bf16: too many workgroups");
     const size_t lds = (size_t)4 * 64 * LROW * 2;
