@@ -382,7 +382,7 @@ class V2XViTEngine(Where2ComEngine):
                     posv = (c_void_p * 3)(*[t_.data_ptr() for t_ in blk["pos"]])
                     outv = (c_void_p * 3)(*[t_.data_ptr() for t_ in br])
                     hv, dv, wv = ((c_int32 * 3)(*[c_[k_] for c_ in pwc]) for k_ in range(3))
-                    self.timed_hbm("linear_bf16 ln+qkv+window+out", m * hw * (1024 + (512 if pending[0] else 0) + 3 * 512) + (2304 + 768) * 512,
+                    self.timed_hbm("ln_qkv_window_out_bf16", m * hw * (1024 + (512 if pending[0] else 0) + 3 * 512) + (2304 + 768) * 512,
                                    2.0 * m * hw * 256 * (2304 + 768) + sum(4.0 * m * hw * ws_ * ws_ * 256 for _, _, ws_ in pwc),
                                    lambda: _lib.check(self.lib.av2x_ln_qkv_window_attention_bf16(
                                        _ptr(x), _ptr(delta) if pending[0] else c_void_p(0), _ptr(blk["ln2"][0]), _ptr(blk["ln2"][1]), LN_EPS,

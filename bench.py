@@ -802,7 +802,22 @@ def main(argv=None, hooks=None, device=None):
             if tv[3] > sec:     # the frame's dominant kernel is an HBM-bound one: it is what `roofline` describes
                 conv_view = {k: res["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "kernel", "launches_per_frame", "avg_launch_us",
                                                              "traffic", "algorithmic_bytes_per_launch") if k in res["roofline"]}
-                res["roofline"].update({
+                if top.startswith("ln_qkv_window_out"):
+                    # LayerNorm -> QKV -> window attention -> to_out in one workgroup: its HBM bytes are x in and the three branch maps
+                    # out (0.1 of the HBM peak); what it does per byte is 443 GFLOP of bf16 GEMM per 8-agent launch -> priced against MFMA
+                    res["roofline"].update({
+                        "bound": "mfma", "achieved": round(tv[2] / tv[3] / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tv[2] / tv[3] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), **hbm_kernel_traffic(top, tv[1] / tv[0]),
+                        "kernel": "ln_qkv_window_out_bf16_kernel (csrc/linear_bf16.hip: LayerNorm -> 256 -> 2304 QKV -> window attention -> to_out of a "
+                                  "4 x 16-pixel block per workgroup, four [64][264] bf16 panels in LDS, one workgroup per CU)",
+                        "limiter": "the weight fragments come from L2 once per 64-token block (1.57 MB per workgroup, 6.9 GB per 8-agent launch) and "
+                                   "one 4-wave workgroup per CU cannot hide the phase changes (K loops / epilogues into LDS / attention); "
+                                   "hbm_gb_per_s below is its algorithmic HBM rate",
+                        "hbm_gb_per_s": round(tv[1] / tv[3] / 1e9, 1),
+                        "launches_per_frame": tv[0] / a.steps, "avg_launch_us": round(tv[3] / tv[0] * 1e6, 2),
+                        "algorithmic_bytes_per_launch": round(tv[1] / tv[0]), "dominant_mfma_kernel": conv_view})
+                else:
+                  res["roofline"].update({
                     "bound": "hbm", "achieved": round(tv[1] / tv[3] / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(tv[1] / tv[3] / 1e9 / PEAK_HBM_GBPS, 4), **hbm_kernel_traffic(top, tv[1] / tv[0]),
                     "kernel": (f"{top}_occ_kernel<SRC, FFN, DH> (csrc/linear_bf16.hip: 64-token panels in LDS -- bf16 rows, LayerNorm of the fp32 stream or the "

@@ -13,7 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - <<'PY'
 import csv, glob, json, collections, os
-FAMILIES = {"linear_bf16_occ_kernel": "linear_bf16", "conv_halo_bf16": "conv_halo_bf16", "hgt_attention_bf16x8": "hgt_attention_bf16",
+FAMILIES = {"ln_qkv_window_out_bf16_kernel": "ln_qkv_window_out_bf16", "linear_bf16_occ_kernel": "linear_bf16", "conv_halo_bf16": "conv_halo_bf16", "hgt_attention_bf16x8": "hgt_attention_bf16",
             "split_combine_kernel": "split_combine", "gap3_stage1": "gap3_stage1", "layernorm_bf16_kernel": "layernorm_bf16",
             "conv_igemm_bf16": "conv_igemm_bf16", "warp_affine_kernel": "warp_affine"}
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
