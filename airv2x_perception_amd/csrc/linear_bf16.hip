@@ -453,6 +453,10 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
     __bf16* P1 = P0 + PSZ;
     __bf16* P2 = P1 + PSZ;
     __bf16* P3 = P2 + PSZ;
+    // one workgroup per CU: a global load in front of an epilogue or an attention phase is a fully exposed round trip, so the biases
+    // (2304 + 768 floats) and the three relative-position tables (<= 49 floats each) are copied into LDS once, under the panel load
+    float* biasl = reinterpret_cast<float*>(P3 + PSZ);             // [3072]
+    float* posl = biasl + 3072;                                     // [3][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -460,6 +464,24 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
     const int tx = blockIdx.x % bx, ty = (blockIdx.x / bx) % by, ag = blockIdx.x / (bx * by);
     const long long m0 = ((long long)ag * p.H + 4 * ty) * p.W + 16 * tx;
     const int span = 3 * p.W + 16;                                  // tokens from the block's first pixel to its last
+    {
+        float4 bv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i4 = tid + 256 * j;                           // float4 index: [0, 576) qkv bias, [576, 768) to_out bias
+            bv[j] = i4 < 576 ? (p.bias ? reinterpret_cast<const float4*>(p.bias)[i4] : make_float4(0.f, 0.f, 0.f, 0.f))
+                             : reinterpret_cast<const float4*>(p.bias2)[i4 - 576];
+        }
+        float pv = 0.f;
+        if (tid < 192) {
+            const int b = tid >> 6, i = tid & 63;
+            const int side = p.dh[b] == 16 ? 3 : 7;
+            if (i < side * side) pv = p.pos[b][i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) reinterpret_cast<float4*>(biasl)[tid + 256 * j] = bv[j];
+        if (tid < 192) posl[tid] = pv;
+    }
 
     constexpr int CP1 = 2304, CP2 = 768;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (unsigned)((LK / 8) * CP1 * 16), 0x00020000);
@@ -545,8 +567,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
     auto epilogue = [&](int ch, const float* bias, __bf16* panel, const __amdgpu_buffer_rsrc_t rout, auto to_lds) {
         constexpr bool TO_LDS = decltype(to_lds)::value;
         const int n = ch * 256 + wave * 64 + 2 * li;
-        float b0 = 0.f, b1 = 0.f;
-        if (bias) { b0 = bias[n]; b1 = bias[n + 1]; }
+        const float b0 = bias[n], b1 = bias[n + 1];                // LDS copy
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         const unsigned off0 = (unsigned)((4 * lh + (li & 3)) * 512 + (wave * 64 + 2 * (li & ~3)) * 2);
@@ -715,16 +736,16 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             const int ch = 3 * b + c;
             kloop(P0, false, ch, c == 2, c == 2 ? b : ch + 1);
             if (c == 0) __syncthreads();          // every wave is past the previous branch's to_out K loop (reads of P1)
-            epilogue(ch, p.bias, P1 + c * PSZ, rw, std::true_type{});
+            epilogue(ch, biasl, P1 + c * PSZ, rw, std::true_type{});
         }
         __syncthreads();                          // q, k, v of the branch are complete
-        if (p.dh[b] == 16) win2(p.heads[b], p.pos[b]);
-        else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], p.pos[b]);
-        else win4(std::integral_constant<int, 64>{}, p.heads[b], p.pos[b]);
+        if (p.dh[b] == 16) win2(p.heads[b], posl + 64 * b);
+        else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], posl + 64 * b);
+        else win4(std::integral_constant<int, 64>{}, p.heads[b], posl + 64 * b);
         __syncthreads();                          // the attention output (in P1) is complete
         kloop(P1, true, b, false, b < 2 ? 3 * (b + 1) : 0);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out[b] + m0 * LK, 0, (unsigned)span * (LK * 2), 0x00020000);
-        epilogue(b, p.bias2, nullptr, rout, std::false_type{});
+        epilogue(b, biasl + 2304, nullptr, rout, std::false_type{});
     }
 }
 
@@ -992,7 +1013,7 @@ extern "C" int av2x_ln_qkv_window_attention_bf16(const float* x, const uint16_t*
     p.H = h; p.W = w;
     const long long blocks = (long long)n * (h / 4) * (w / 16);
     if (blocks > (1ll << 30)) return av2x::fail("av2x_ln_qkv_window_attention_bf16: too many workgroups");
-    const size_t lds = (size_t)4 * 64 * LROW * 2;
+    const size_t lds = (size_t)4 * 64 * LROW * 2 + (3072 + 192) * 4;
     static av2x::LdsLimit lim;
     lim.ensure(reinterpret_cast<const void*>(&ln_qkv_window_out_bf16_kernel), lds);
     hipLaunchKernelGGL(ln_qkv_window_out_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, av2x::as_stream(stream), p);
