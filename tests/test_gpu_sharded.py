@@ -82,11 +82,13 @@ def test_cobevt_emulated_ranks_equal_single_gpu_forward(name):
         assert torch.equal(out2[k], ref[k]), ("two-level", k)
 
 
-def test_v2xvit_emulated_ranks_equal_single_gpu_forward():
+@pytest.mark.parametrize("name,amp", [("v2xvit_small_n3", False), ("v2xvit_small_n3", True), ("v2xvit_full_n8", True)])
+def test_v2xvit_emulated_ranks_equal_single_gpu_forward(name, amp):
+    """amp: the autocast frame (bf16 activations, LayerNorm / attention fused into the Linears) shards to the same bits too"""
     import tests.test_v2xvit as tv
     from airv2x_perception_amd.opencood_iface import Airv2xV2XVit
     from airv2x_perception_amd.opencood_iface.sharded import partition_agents
-    fx = load_fixture("v2xvit_small_n3")
+    fx = load_fixture(name)
     hy, args, sd, dd = tv._case(fx)
     types = [str(t) for t in fx["types"]]
     rng = [float(v) for v in fx["lidar_range"]]
@@ -98,6 +100,7 @@ def test_v2xvit_emulated_ranks_equal_single_gpu_forward():
     model = model.to("cuda").eval()
     eng = model.engine()
     eng.stream_k = False
+    eng.amp = amp
     ref = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd, sync_comm_rate=True).items()}
     world = len(types)
     sends, stats, meta = [], None, None
