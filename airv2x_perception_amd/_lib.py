@@ -146,6 +146,9 @@ SIGNATURES = {
                                           c_void_p]),
     "av2x_window_attention_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                              c_int32, c_int32, c_void_p]),
+    "av2x_combine_ln_linear_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                              c_float, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
+                                              c_int32, c_int32, c_int64, c_void_p]),
     "av2x_window_attention_linear_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                     c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_ln_qkv_window_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,

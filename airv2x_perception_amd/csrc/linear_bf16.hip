@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "av2x_common.hpp"
+#include "split_attn_rows.hpp"
 
 namespace {
 
@@ -53,6 +54,11 @@ struct LinParams {
     const __bf16* w2;
     const float* bias2;
     int act2;
+    // SplitAttn's combine as the producer of x (linear_bf16_occ_kernel<SRC_LNC, .>): x = x (+ delta) + sum_b softmax_b(logits) br_b,
+    // written back, then LayerNorm -> Linear(s): the three bf16 branch maps, the (n, 3, 256) logits, tokens per agent
+    const __bf16* br[3];
+    const float* logits;
+    long long hw;
     // window attention as the panel source (linear_bf16_occ_kernel<2 | 3, .>): the bf16 [q | k | v] rows, the relative-position table, the map
     const __bf16* qkv;
     const float* pos;
@@ -132,13 +138,13 @@ __device__ __forceinline__ float erf_as(float x) {
 // computed from the bf16 [q | k | v] rows exactly as window_attn_mfma_kernel / window_attn_kernel of v2xvit.hip do, rounded to bf16
 // into LDS, and the Linear is the branch's output projection: the attention output never exists in HBM (144 MB written + read per
 // branch at 8 agents) and a launch disappears.  Panel row r = block pixel (r >> 4, r & 15).
-constexpr int SRC_ROWS = 0, SRC_LN = 1, SRC_WIN4 = 2, SRC_WIN2 = 3;
+constexpr int SRC_ROWS = 0, SRC_LN = 1, SRC_WIN4 = 2, SRC_WIN2 = 3, SRC_LNC = 4;
 typedef float lin_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int SRC, bool FFN, int DH = 0>
 __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams p) {
     constexpr int BMO = 64;
-    constexpr bool LN = SRC == SRC_LN, WIN = SRC == SRC_WIN4 || SRC == SRC_WIN2;
+    constexpr bool LN = SRC == SRC_LN, LNC = SRC == SRC_LNC, WIN = SRC == SRC_WIN4 || SRC == SRC_WIN2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
     __bf16* As = reinterpret_cast<__bf16*>(lin_smem);        // [64][264]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -198,6 +204,54 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rx, (unsigned)(r * (LK * 4) + lane * 16), 0, LIN_NT);
                 }
                 const f32x4 y = layernorm_row_256(v, g, bt, p.eps);
+                *reinterpret_cast<bf16x4*>(As + r * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
+            }
+        }
+    } else if constexpr (LNC) {
+        // ---- x = SplitAttn combine (+ pending delta) written back, panel = LayerNorm(x): split_combine_kernel's arithmetic
+        // (split_attn_rows.hpp) and layernorm_row_256 on the rows of ONE agent (hw % 64 == 0: a panel never straddles two agents)
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.x + m0 * LK, 0, (unsigned)rows * (LK * 4), 0x00020000);
+        long long addl = p.add_rows - m0;
+        const int addr = (int)(addl < 0 ? 0 : (addl > rows ? rows : addl));
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.delta ? p.delta + m0 * LK : nullptr), 0,
+                                                                            p.delta ? (unsigned)addr * (LK * 2) : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.br[0] + m0 * LK), 0, (unsigned)rows * (LK * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.br[1] + m0 * LK), 0, (unsigned)rows * (LK * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.br[2] + m0 * LK), 0, (unsigned)rows * (LK * 2), 0x00020000);
+        const float4 g = reinterpret_cast<const float4*>(p.gamma)[lane], bt = reinterpret_cast<const float4*>(p.beta)[lane];
+        float w[3][4];
+        av2x::split_attn_weights(p.logits + (m0 / p.hw) * (3 * LK), 4 * lane, LK, w);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        auto cvt = [](const u32x2 u) {
+            return make_float4(__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                               __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u));
+        };
+#pragma unroll
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            f32x4 xv[4];
+            u32x2 dv[4], b0[4], b1[4], b2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wave * 16 + quarter * 4 + j;
+                const unsigned o16 = (unsigned)(r * (LK * 2) + lane * 8);
+                xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(r * (LK * 4) + lane * 16), 0, LIN_NT));
+                dv[j] = __builtin_amdgcn_raw_buffer_load_b64(rd, o16, 0, LIN_NT);
+                b0[j] = __builtin_amdgcn_raw_buffer_load_b64(rb0, o16, 0, LIN_NT);
+                b1[j] = __builtin_amdgcn_raw_buffer_load_b64(rb1, o16, 0, LIN_NT);
+                b2[j] = __builtin_amdgcn_raw_buffer_load_b64(rb2, o16, 0, LIN_NT);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wave * 16 + quarter * 4 + j;
+                float4 v = make_float4(xv[j][0], xv[j][1], xv[j][2], xv[j][3]);
+                if (r < addr) {      // wave-uniform: the pending residual first (r = res + delta of split_combine_kernel)
+                    const float4 dl = cvt(dv[j]);
+                    v.x += dl.x; v.y += dl.y; v.z += dl.z; v.w += dl.w;
+                }
+                const float4 y4 = av2x::split_attn_combine4(cvt(b0[j]), cvt(b1[j]), cvt(b2[j]), w, v);
+                const f32x4 yv = {y4.x, y4.y, y4.z, y4.w};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), rx, (unsigned)(r * (LK * 4) + lane * 16), 0, LIN_NT);
+                const f32x4 y = layernorm_row_256(y4, g, bt, p.eps);
                 *reinterpret_cast<bf16x4*>(As + r * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
             }
         }
@@ -953,6 +1007,38 @@ extern "C" int av2x_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_
     if (w2_packed) hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_LN, true>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_LN, false>), grid, block, lds, st, p);
     return av2x::check_launch("linear_bf16_occ_kernel<LN>");
+}
+
+extern "C" int av2x_combine_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, const uint16_t* s0, const uint16_t* s1,
+                                          const uint16_t* s2, const float* logits, int64_t hw, const float* gamma, const float* beta, float eps,
+                                          const uint16_t* w_packed, const float* bias, int32_t act, int32_t cout, int32_t coutp,
+                                          const uint16_t* w2_packed, const float* bias2, int32_t act2, uint16_t* out, int32_t out_ctot,
+                                          int32_t out_coff, int64_t m, av2x_stream_t stream) {
+    if (m == 0) return 0;
+    if (!x || !s0 || !s1 || !s2 || !logits || !gamma || !beta || !w_packed || !out) return av2x::fail("av2x_combine_ln_linear_bf16: null argument");
+    if (m < 0 || add_rows < 0 || add_rows > m || (add_rows && !delta))
+        return av2x::fail("av2x_combine_ln_linear_bf16: bad row counts (m=%lld add_rows=%lld)", (long long)m, (long long)add_rows);
+    if (hw <= 0 || hw % 64 || m % hw) return av2x::fail("av2x_combine_ln_linear_bf16: hw=%lld must be a multiple of 64 and divide m=%lld", (long long)hw, (long long)m);
+    if (coutp <= 0 || coutp % 256 || cout <= 0 || cout > coutp || cout % 8 || out_ctot % 8 || out_coff % 8)
+        return av2x::fail("av2x_combine_ln_linear_bf16: bad sizes (cout=%d coutp=%d out_ctot=%d out_coff=%d)", cout, coutp, out_ctot, out_coff);
+    if (act < 0 || act > 2 || act2 < 0 || act2 > 2) return av2x::fail("av2x_combine_ln_linear_bf16: act unsupported (0 none, 1 ReLU, 2 GELU)");
+    if (w2_packed && (cout != 256 || coutp != 256)) return av2x::fail("av2x_combine_ln_linear_bf16: the fused second Linear needs a hidden width of 256");
+    if (out_coff + (w2_packed ? 256 : cout) > out_ctot) return av2x::fail("av2x_combine_ln_linear_bf16: bad output slice");
+    LinParams p = {};
+    p.w = reinterpret_cast<const __bf16*>(w_packed);
+    p.bias = bias; p.out = out; p.M = m;
+    p.Cout = cout; p.CoutP = coutp; p.out_ctot = out_ctot; p.out_coff = out_coff; p.act = act;
+    p.w_bytes = (unsigned)((size_t)(LK / 8) * coutp * 16);
+    p.x = x; p.delta = reinterpret_cast<const __bf16*>(delta); p.add_rows = add_rows; p.write_back = 1; p.gamma = gamma; p.beta = beta; p.eps = eps;
+    p.w2 = reinterpret_cast<const __bf16*>(w2_packed); p.bias2 = bias2; p.act2 = act2;
+    p.br[0] = reinterpret_cast<const __bf16*>(s0); p.br[1] = reinterpret_cast<const __bf16*>(s1); p.br[2] = reinterpret_cast<const __bf16*>(s2);
+    p.logits = logits; p.hw = hw;
+    hipStream_t st = av2x::as_stream(stream);
+    const dim3 grid((unsigned)((m + 63) / 64)), block(256);
+    const size_t lds = (size_t)64 * LROW * 2;
+    if (w2_packed) hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_LNC, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((linear_bf16_occ_kernel<SRC_LNC, false>), grid, block, lds, st, p);
+    return av2x::check_launch("linear_bf16_occ_kernel<LNC>");
 }
 
 extern "C" int av2x_window_attention_linear_bf16(const uint16_t* qkv, int32_t ctot, int32_t coff, const float* pos_embedding,

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "av2x_common.hpp"
+#include "split_attn_rows.hpp"
 
 namespace {
 
@@ -477,16 +478,8 @@ __global__ void split_combine_kernel(const T* __restrict__ s0, const T* __restri
     const int c4 = C / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_agent; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4) * 4;
-        const float* lg = logits + (size_t)a * 3 * C;
         float w[3][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {   // softmax over the radix axis: logits viewed (radix=3, C)
-            const float a0 = lg[c + e], a1 = lg[C + c + e], a2 = lg[2 * C + c + e];
-            const float mx = fmaxf(a0, fmaxf(a1, a2));
-            const float e0 = expf(a0 - mx), e1 = expf(a1 - mx), e2 = expf(a2 - mx);
-            const float inv = 1.0f / ((e0 + e1) + e2);
-            w[0][e] = e0 * inv; w[1][e] = e1 * inv; w[2][e] = e2 * inv;
-        }
+        av2x::split_attn_weights(logits + (size_t)a * 3 * C, c, C, w);
         const size_t o = (size_t)a * n4_per_agent + i;
         const float4 x0 = ld4(s0 + 4 * o), x1 = ld4(s1 + 4 * o), x2 = ld4(s2 + 4 * o);
         float4 r = res[o];
@@ -494,11 +487,7 @@ __global__ void split_combine_kernel(const T* __restrict__ s0, const T* __restri
             const float4 dl = ld4(delta + 4 * o);
             r.x += dl.x; r.y += dl.y; r.z += dl.z; r.w += dl.w;
         }
-        float4 y;
-        y.x = ((x0.x * w[0][0] + x1.x * w[1][0]) + x2.x * w[2][0]) + r.x;
-        y.y = ((x0.y * w[0][1] + x1.y * w[1][1]) + x2.y * w[2][1]) + r.y;
-        y.z = ((x0.z * w[0][2] + x1.z * w[1][2]) + x2.z * w[2][2]) + r.z;
-        y.w = ((x0.w * w[0][3] + x1.w * w[1][3]) + x2.w * w[2][3]) + r.w;
+        const float4 y = av2x::split_attn_combine4(x0, x1, x2, w, r);
         out[o] = y;
     }
 }

@@ -258,6 +258,8 @@ class V2XViTEngine(Where2ComEngine):
     fuse_window_out = os.environ.get("AV2X_FUSE_WINDOW_OUT", "1") != "0"
     # ... and LayerNorm -> QKV -> window attention -> to_out of a 4 x 16-pixel block in one workgroup (ln_qkv_window_out_bf16_kernel)
     fuse_qkv_window = os.environ.get("AV2X_FUSE_QKV_WINDOW", "1") != "0"
+    # ... and SplitAttn's combine computed in the FeedForward launch's panel load (linear_bf16_occ_kernel<SRC_LNC, FFN>)
+    fuse_combine_ffn = os.environ.get("AV2X_FUSE_COMBINE_FFN", "1") != "0"
 
     def _wout3(self, blk):
         """the three to_out Linears as one packed 256 -> 768 weight (columns [256 b, 256 b + 256) = branch b) + the (768,) bias"""
@@ -420,7 +422,11 @@ class V2XViTEngine(Where2ComEngine):
                 self.conv(blk["fc1"], gap, m, 1, 1, g1)
                 self.ln(g1, blk["bn1"], g2, m, C, relu=1)
                 self.conv(blk["fc2"], g2, m, 1, 1, logits)
-                if pending[0]:
+                defer_combine = (fuse and self.fuse_combine_ffn and trace is None and bi == len(blocks) - 1 and hw % 64 == 0
+                                 and ffn["ff1"].cout == 256 and ffn["ff2"].cout == 256)
+                if defer_combine:
+                    pass        # the FeedForward launch below produces x = combine(...) in its panel load (one pass over x less)
+                elif pending[0]:
                     _lib.check(self.lib.av2x_split_attn_combine_delta_bf16(_ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), _ptr(x), _ptr(delta),
                                                                            _ptr(x), m, hw, C, st()), "combine")
                     pending[0] = 0
@@ -429,7 +435,19 @@ class V2XViTEngine(Where2ComEngine):
                                                                      m, hw, C, st()), "combine")
             # ---- x = FFN(LN(x)) + x
             m = 1 if (self.ego_only_last and di == last and trace is None and n > 1) else n
-            if fuse and ffn["ff1"].cout == 256 and ffn["ff2"].cout == 256:
+            if blocks and defer_combine:
+                assert pending[0] in (0, m)
+                L1, L2 = ffn["ff1"], ffn["ff2"]
+                w1, cp1 = _w16i(L1)
+                add = pending[0] * hw
+                self.timed_hbm("linear_bf16 combine+ln+256->256->256", m * hw * (1024 * 2 + 3 * 512 + 512) + add * 512 + 2 * 256 * 512,
+                               4.0 * m * hw * 256 * 256,
+                               lambda: _lib.check(self.lib.av2x_combine_ln_linear_bf16(
+                                   _ptr(x), _ptr(delta) if add else c_void_p(0), add, _ptr(br[0]), _ptr(br[1]), _ptr(br[2]), _ptr(logits), hw,
+                                   _ptr(ffn["ln"][0]), _ptr(ffn["ln"][1]), LN_EPS, _ptr(w1), _ptr(L1.shift), L1.relu, L1.cout, cp1,
+                                   _ptr(_w16i(L2)[0]), _ptr(L2.shift), L2.relu, _ptr(delta), C, 0, m * hw, st()), "av2x_combine_ln_linear_bf16"))
+                pending[0] = 0
+            elif fuse and ffn["ff1"].cout == 256 and ffn["ff2"].cout == 256:
                 ln_lin(ffn["ln"], ffn["ff1"], 0, m, delta, L2=ffn["ff2"])     # delta rows are read (pending) before they are written: per panel
                 finish_pending(m)
             else:

@@ -696,6 +696,16 @@ int av2x_split_attn_gap_bf16(const uint16_t* s0, const uint16_t* s1, const uint1
                              float* scratch /* n*128*c floats */, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
 int av2x_split_attn_combine_bf16(const uint16_t* s0, const uint16_t* s1, const uint16_t* s2, const float* logits,
                                  const float* residual, float* out, int32_t n, int32_t hw, int32_t c, av2x_stream_t stream);
+/* SplitAttn's combine (split_attn.py:55-61) as the producer of the stream in front of PreNormResidual(FeedForward)
+ * (v2xvit_basic.py:137-159): for the m rows (m % hw == 0, hw % 64 == 0: tokens per agent)
+ *   x[r] = (x[r] (+ delta[r], r < add_rows)) + sum_b softmax_b(logits[agent(r)]) s_b[r]   -- av2x_split_attn_combine(_delta)_bf16's bits,
+ *   written back; then exactly av2x_ln_linear_bf16 on the new x (LayerNorm -> Linear [-> Linear]).  One pass over x instead of the
+ * combine's read + write and the LayerNorm's read. */
+int av2x_combine_ln_linear_bf16(float* x, const uint16_t* delta, int64_t add_rows, const uint16_t* s0, const uint16_t* s1,
+                                const uint16_t* s2, const float* logits, int64_t hw, const float* gamma, const float* beta, float eps,
+                                const uint16_t* w_packed, const float* bias, int32_t act, int32_t cout, int32_t coutp,
+                                const uint16_t* w2_packed, const float* bias2, int32_t act2, uint16_t* out, int32_t out_ctot,
+                                int32_t out_coff, int64_t m, av2x_stream_t stream);
 /* One branch of the pyramid window attention with its output projection (mswin.py:52-96 BaseWindowAttention: to_out Linear of the
  * attention output): out[slice] = bf16(bf16(WindowAttention(qkv slice)) . W + bias), bit-identical to av2x_window_attention_bf16
  * followed by av2x_linear_bf16; the attention output stays in LDS.  h % 4 == 0, w % 16 == 0 (4 x 16-pixel blocks);

@@ -414,6 +414,46 @@ def test_ln_linear_bf16_equals_the_separate_launches_bit_for_bit(m, add_rows, co
                                        ctot, coff, m, _st()) != 0  # the fused second Linear needs a hidden width of 256
 
 
+@pytest.mark.parametrize("n,hw,add_agents", [(3, 128, 3), (2, 320, 0), (1, 64, 1)])
+def test_combine_in_the_feedforward_launch_equals_the_separate_launches(n, hw, add_agents):
+    """av2x_combine_ln_linear_bf16 (SplitAttn's combine computed in the FeedForward launch's panel load) against
+    av2x_split_attn_combine(_delta)_bf16 + av2x_ln_linear_bf16: same bits in the updated x and in the FeedForward output."""
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    C, m = 256, n * hw
+    g = _g(n * 11 + hw)
+    x = torch.randn(m, C, generator=g) * 2
+    dl = torch.randn(m, C, generator=g).to(BF)
+    s = [torch.randn(m, C, generator=g).to(BF).cuda() for _ in range(3)]
+    logits = torch.randn(n, 3 * C, generator=g).cuda()
+    gm, bt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    w1 = (torch.randn(C, C, generator=g) / 16).to(BF).float()
+    w2 = (torch.randn(C, C, generator=g) / 16).to(BF).float()
+    b1, b2 = torch.randn(C, generator=g) * 0.2, torch.randn(C, generator=g) * 0.2
+    (w1p, cp), (w2p, _) = _pack(w1), _pack(w2)
+    gd, bd, w1d, w2d, b1d, b2d, dd = gm.cuda(), bt.cuda(), w1p.cuda(), w2p.cuda(), b1.cuda(), b2.cuda(), dl.cuda()
+    add = add_agents * hw
+    # --- separate launches
+    xs = x.cuda()
+    if add:
+        _lib.check(lib.av2x_split_attn_combine_delta_bf16(_p(s[0]), _p(s[1]), _p(s[2]), _p(logits), _p(xs), _p(dd), _p(xs), n, hw, C, _st()), "cd")
+    else:
+        _lib.check(lib.av2x_split_attn_combine_bf16(_p(s[0]), _p(s[1]), _p(s[2]), _p(logits), _p(xs), _p(xs), n, hw, C, _st()), "c")
+    want = torch.zeros(m, C, device="cuda", dtype=BF)
+    _lib.check(lib.av2x_ln_linear_bf16(_p(xs), None, 0, 1, _p(gd), _p(bd), 1e-5, _p(w1d), _p(b1d), 2, C, cp, _p(w2d), _p(b2d), 0, _p(want), C, 0, m,
+                                       _st()), "ffn")
+    # --- one launch (the output overwrites the pending delta rows in place, as the engine calls it)
+    xf = x.cuda()
+    out = dd.clone()
+    _lib.check(lib.av2x_combine_ln_linear_bf16(_p(xf), _p(out) if add else None, add, _p(s[0]), _p(s[1]), _p(s[2]), _p(logits), hw, _p(gd), _p(bd),
+                                               1e-5, _p(w1d), _p(b1d), 2, C, cp, _p(w2d), _p(b2d), 0, _p(out), C, 0, m, _st()), "combine+ffn")
+    assert torch.equal(xf, xs)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    # hw must be a multiple of 64 (a 64-token panel belongs to one agent) and divide m
+    assert lib.av2x_combine_ln_linear_bf16(_p(xf), None, 0, _p(s[0]), _p(s[1]), _p(s[2]), _p(logits), 96, _p(gd), _p(bd), 1e-5, _p(w1d), _p(b1d), 2,
+                                           C, cp, _p(w2d), _p(b2d), 0, _p(out), C, 0, m, _st()) != 0
+
+
 @pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n8"])
 def test_v2xvit_fused_layernorm_linear_frame_equals_the_unfused_frame(name):
     """The bf16-activation frame with LayerNorm folded into the Linears and the window attention into its output projection (default)
@@ -427,15 +467,15 @@ def test_v2xvit_fused_layernorm_linear_frame_equals_the_unfused_frame(name):
     model = model.to("cuda").eval()
     eng = model.engine()
     model.amp = True
-    assert eng.fuse_ln is True and eng.fuse_window_out is True and eng.fuse_qkv_window is True
+    assert eng.fuse_ln is True and eng.fuse_window_out is True and eng.fuse_qkv_window is True and eng.fuse_combine_ffn is True
     fused = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
     try:
-        eng.fuse_qkv_window = False                       # LayerNorm -> QKV and attention -> to_out as separate fused launches
+        eng.fuse_qkv_window = eng.fuse_combine_ffn = False   # LayerNorm -> QKV and attention -> to_out as separate fused launches; own combine
         mid = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
         eng.fuse_ln = eng.fuse_window_out = False         # every LayerNorm, Linear and attention its own launch
         plain = {k: v.clone() for k, v in model(dd).items() if torch.is_tensor(v)}
     finally:
-        eng.fuse_ln = eng.fuse_window_out = eng.fuse_qkv_window = True
+        eng.fuse_ln = eng.fuse_window_out = eng.fuse_qkv_window = eng.fuse_combine_ffn = True
     for k in ("psm", "rm", "obj"):
         assert torch.equal(fused[k], plain[k]), k
         assert torch.equal(mid[k], plain[k]), k
