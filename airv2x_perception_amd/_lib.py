@@ -127,6 +127,8 @@ SIGNATURES = {
     "av2x_warp_affine_simple": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_roi_mask": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_add_agent_vector": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
+    "av2x_add_agent_vector_to": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
+    "av2x_warp_affine_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_hgt_attention": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_hgt_attention_q": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                        c_void_p]),

@@ -49,7 +49,7 @@ __device__ __forceinline__ float lin_m1_1(int i, int n) {
 // warp_affine_simple (:327-334): base grid linspace(-1,1,n)*(n-1)/n and unnormalise ((g+1)*n - 1)/2.
 template <int CK, bool AC>  // C = 64 * CK: 16 lanes x float4 per pixel chunk
 __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ src, const float* __restrict__ theta,
-                                                          float* __restrict__ dst, int H, int W) {
+                                                          float* __restrict__ dst, int H, int W, const float* __restrict__ addv) {
     const int t = threadIdx.x & 15;
     const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int n = blockIdx.y;
@@ -75,9 +75,13 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < CK; ++k) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // addv: the source map is src + addv[n] (a per-agent channel vector, e.g. the RTE embedding) inside the map, zero outside --
+        // the bits of adding the vector to the stored map first and sampling that
+        const float4 b = addv ? *reinterpret_cast<const float4*>(addv + (size_t)n * C + 4 * t + 64 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
         auto add = [&](bool ok, int yy, int xx, float w) {
             if (ok) {
-                const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * C + 64 * k);
+                float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * W + xx) * C + 64 * k);
+                if (addv) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                 acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
             }
         };
@@ -105,13 +109,13 @@ __global__ void roi_mask_kernel(const float* __restrict__ theta, const int* __re
     mask[(size_t)a * H * W + pix] = (in && cav_mask[a]) ? 1.f : 0.f;
 }
 
-__global__ void add_agent_vector_kernel(float4* __restrict__ x, const float4* __restrict__ v, size_t n4_per_agent, int c4) {
+__global__ void add_agent_vector_kernel(const float4* x, const float4* __restrict__ v, float4* out, size_t n4_per_agent, int c4) {
     const int a = blockIdx.y;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_agent; i += (size_t)gridDim.x * blockDim.x) {
         float4 r = x[(size_t)a * n4_per_agent + i];
         const float4 b = v[(size_t)a * c4 + (i % c4)];
         r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
-        x[(size_t)a * n4_per_agent + i] = r;
+        out[(size_t)a * n4_per_agent + i] = r;
     }
 }
 
@@ -496,16 +500,16 @@ __global__ void split_combine_kernel(const T* __restrict__ s0, const T* __restri
 
 template <bool AC>
 static int warp_launch(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w, int32_t c,
-                       av2x_stream_t stream) {
+                       av2x_stream_t stream, const float* addv = nullptr) {
     if (n == 0) return 0;
     if (!src || !theta || !dst) return av2x::fail("av2x_warp_affine: null argument");
     if (n < 0 || h <= 0 || w <= 0) return av2x::fail("av2x_warp_affine: bad sizes");
     const dim3 grid((h * w + 15) / 16, n), block(256);
     hipStream_t st = av2x::as_stream(stream);
     switch (c) {
-        case 64: hipLaunchKernelGGL((warp_affine_kernel<1, AC>), grid, block, 0, st, src, theta, dst, h, w); break;
-        case 128: hipLaunchKernelGGL((warp_affine_kernel<2, AC>), grid, block, 0, st, src, theta, dst, h, w); break;
-        case 256: hipLaunchKernelGGL((warp_affine_kernel<4, AC>), grid, block, 0, st, src, theta, dst, h, w); break;
+        case 64: hipLaunchKernelGGL((warp_affine_kernel<1, AC>), grid, block, 0, st, src, theta, dst, h, w, addv); break;
+        case 128: hipLaunchKernelGGL((warp_affine_kernel<2, AC>), grid, block, 0, st, src, theta, dst, h, w, addv); break;
+        case 256: hipLaunchKernelGGL((warp_affine_kernel<4, AC>), grid, block, 0, st, src, theta, dst, h, w, addv); break;
         default: return av2x::fail("av2x_warp_affine: c=%d unsupported (64/128/256)", c);
     }
     return av2x::check_launch("warp_affine_kernel");
@@ -514,6 +518,12 @@ static int warp_launch(const float* src, const float* theta, float* dst, int32_t
 extern "C" int av2x_warp_affine(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w, int32_t c,
                                 av2x_stream_t stream) {
     return warp_launch<true>(src, theta, dst, n, h, w, c, stream);
+}
+
+extern "C" int av2x_warp_affine_add(const float* src, const float* theta, const float* addv, float* dst, int32_t n, int32_t h, int32_t w,
+                                    int32_t c, av2x_stream_t stream) {
+    if (n && !addv) return av2x::fail("av2x_warp_affine_add: null argument");
+    return warp_launch<true>(src, theta, dst, n, h, w, c, stream, addv);
 }
 
 extern "C" int av2x_warp_affine_simple(const float* src, const float* theta, float* dst, int32_t n, int32_t h, int32_t w,
@@ -530,15 +540,23 @@ extern "C" int av2x_roi_mask(const float* theta, const int32_t* cav_mask, float*
     return av2x::check_launch("roi_mask_kernel");
 }
 
+extern "C" int av2x_add_agent_vector_to(const float* x, const float* v, float* out, int32_t n, int64_t elems_per_agent, int32_t c,
+                                        av2x_stream_t stream);
+
 extern "C" int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_t elems_per_agent, int32_t c, av2x_stream_t stream) {
+    return av2x_add_agent_vector_to(x, v, x, n, elems_per_agent, c, stream);
+}
+
+extern "C" int av2x_add_agent_vector_to(const float* x, const float* v, float* out, int32_t n, int64_t elems_per_agent, int32_t c,
+                                        av2x_stream_t stream) {
     if (n == 0) return 0;
-    if (!x || !v) return av2x::fail("av2x_add_agent_vector: null argument");
+    if (!x || !v || !out) return av2x::fail("av2x_add_agent_vector: null argument");
     if (c % 4 || elems_per_agent % c) return av2x::fail("av2x_add_agent_vector: bad sizes");
     const size_t n4 = (size_t)elems_per_agent / 4;
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(add_agent_vector_kernel, dim3((unsigned)blocks, n), dim3(256), 0, av2x::as_stream(stream),
-                       reinterpret_cast<float4*>(x), reinterpret_cast<const float4*>(v), n4, c / 4);
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(v), reinterpret_cast<float4*>(out), n4, c / 4);
     return av2x::check_launch("add_agent_vector_kernel");
 }
 

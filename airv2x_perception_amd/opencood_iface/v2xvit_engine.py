@@ -132,11 +132,14 @@ class V2XViTEngine(Where2ComEngine):
         types = [int(prior[i, 2]) for i in range(n)]                      # infra flag -> node type (hmsa.py:123-127)
         dts = [int(prior[i, 1]) for i in range(n)]
         # ---- RTE: x[i] += lin(emb[dt_i * ratio])      (v2xvit_basic.py:58-80)
+        vec = None
         if self.cav["use_RTE"]:
             rows = self.rte_table[[dt * self.cav["RTE_ratio"] for dt in dts]].contiguous()     # table rows (gather only)
             vec = self.buf("rte_vec", (n, 1, 1, C))
             self.conv(self.rte_lin, rows.view(n, 1, 1, C), n, 1, 1, vec)
-            _lib.check(self.lib.av2x_add_agent_vector(_ptr(x), _ptr(vec), n, hw * C, C, st()), "av2x_add_agent_vector")
+            if n == 1:
+                _lib.check(self.lib.av2x_add_agent_vector(_ptr(x), _ptr(vec), n, hw * C, C, st()), "av2x_add_agent_vector")
+            # n > 1: the add happens where the maps are read anyway -- in the STTF warp's taps (agents 1..) and in the ego's move
         # ---- STTF: warp agents 1.. into the ego frame; ROI x cav mask
         d = warp_host.discretized_matrix(scm[:n], self.enc["sttf"]["voxel_size"][0], self.enc["sttf"]["downsample_rate"])
         T = warp_host.transformation_matrix(d, (H, W))
@@ -145,8 +148,13 @@ class V2XViTEngine(Where2ComEngine):
             # the warped maps land in a second buffer that becomes the stream from here on (the ego's map is moved there: 1 / n of the
             # copy-back of all the warped maps)
             xw = self.buf("sttf_out", (n, H, W, C))
-            _lib.check(self.lib.av2x_warp_affine(_ptr(x[1:]), _ptr(theta[1:]), _ptr(xw[1:]), n - 1, H, W, C, st()), "av2x_warp_affine")
-            xw[0].copy_(x[0])
+            if vec is not None:
+                _lib.check(self.lib.av2x_warp_affine_add(_ptr(x[1:]), _ptr(theta[1:]), _ptr(vec[1:]), _ptr(xw[1:]), n - 1, H, W, C, st()),
+                           "av2x_warp_affine_add")
+                _lib.check(self.lib.av2x_add_agent_vector_to(_ptr(x[0:1]), _ptr(vec[0:1]), _ptr(xw[0:1]), 1, hw * C, C, st()), "av2x_add_agent_vector_to")
+            else:
+                _lib.check(self.lib.av2x_warp_affine(_ptr(x[1:]), _ptr(theta[1:]), _ptr(xw[1:]), n - 1, H, W, C, st()), "av2x_warp_affine")
+                xw[0].copy_(x[0])
             x = xw
         mask = self.buf("com_mask", (n, H, W))
         ones = self.buf("cav_ones", (n,), torch.int32)

@@ -632,6 +632,12 @@ int av2x_warp_affine_simple(const float* src, const float* theta, float* dst, in
                             int32_t c, av2x_stream_t stream);
 int av2x_roi_mask(const float* theta, const int32_t* cav_mask, float* mask, int32_t n, int32_t h, int32_t w,
                   av2x_stream_t stream);
+/* av2x_warp_affine on (src + addv[agent]) -- addv (n, c), e.g. the RTE embedding of v2xvit_basic.py:58-80 -- without storing the sum:
+ * the bits of av2x_add_agent_vector followed by av2x_warp_affine.  av2x_add_agent_vector_to: the add into another buffer. */
+int av2x_warp_affine_add(const float* src, const float* theta, const float* addv, float* dst, int32_t n, int32_t h, int32_t w,
+                         int32_t c, av2x_stream_t stream);
+int av2x_add_agent_vector_to(const float* x, const float* v, float* out, int32_t n, int64_t elems_per_agent, int32_t c,
+                             av2x_stream_t stream);
 int av2x_add_agent_vector(float* x, const float* v, int32_t n, int64_t elems_per_agent, int32_t c,
                           av2x_stream_t stream);
 int av2x_hgt_attention(const float* proj, const float* mask, const int32_t* types_host, float* out, int32_t n,

@@ -85,6 +85,35 @@ def test_gpu_warp_and_roi_mask():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C", [64, 256])
+def test_gpu_warp_of_map_plus_agent_vector_equals_add_then_warp(C):
+    """av2x_warp_affine_add (the RTE embedding of v2xvit_basic.py:58-80 added in the STTF warp's taps) and av2x_add_agent_vector_to
+    against av2x_add_agent_vector followed by av2x_warp_affine: same bits."""
+    from ctypes import c_void_p
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    p = lambda t: c_void_p(t.data_ptr())
+    st = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = np.random.default_rng(5)
+    n, H, Wd = 3, 24, 40
+    scm = np.stack([synth.se2_correction(g.uniform(-10, 10), g.uniform(-6, 6), g.uniform(-4, 4)) for _ in range(n)])
+    T = vit.transformation_matrix(vit.discretized_matrix(torch.from_numpy(scm)[None], 0.4, 4)[0], (H, Wd))
+    theta = torch.from_numpy(W.affine_theta(T.numpy(), (H, Wd), (H, Wd))).cuda()
+    src = torch.randn(n, H, Wd, C, generator=torch.Generator().manual_seed(C)).cuda()
+    vec = torch.randn(n, C, generator=torch.Generator().manual_seed(C + 1)).cuda()
+    summed = src.clone()
+    _lib.check(lib.av2x_add_agent_vector(p(summed), p(vec), n, H * Wd * C, C, st()), "add")
+    want = torch.empty_like(src)
+    _lib.check(lib.av2x_warp_affine(p(summed), p(theta), p(want), n, H, Wd, C, st()), "warp")
+    got = torch.empty_like(src)
+    _lib.check(lib.av2x_warp_affine_add(p(src), p(theta), p(vec), p(got), n, H, Wd, C, st()), "warp+add")
+    assert torch.equal(got, want)
+    moved = torch.empty_like(src)
+    _lib.check(lib.av2x_add_agent_vector_to(p(src), p(vec), p(moved), n, H * Wd * C, C, st()), "add to")
+    assert torch.equal(moved, summed)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["v2xvit_small_n3", "v2xvit_full_n4", "v2xvit_full_n8"])   # n8: BASELINE configs[3], L = 8
 def test_gpu_forward_matches_golden(name):
     """small grid: every tensor; full AirV2X grid (BASELINE size, 4 agents x 8192 points): strided samples + sums of
