@@ -625,6 +625,19 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         const unsigned off0 = (unsigned)((4 * lh + (li & 3)) * 512 + (wave * 64 + 2 * (li & ~3)) * 2);
+        if constexpr (TO_LDS) {
+            // into an LDS panel the raw MFMA layout is as good as any: the lane's column pair of every row as one 4-byte store (conflict-free:
+            // 32 consecutive banks per half-wave), no transposes
+            __bf16* dst = panel + (4 * lh) * LROW + wave * 64 + 2 * li;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 v = {acc[a][0][r] + b0, acc[a][1][r] + b1};
+                    *reinterpret_cast<unsigned*>(dst + (a * 32 + (r & 3) + 8 * (r >> 2)) * LROW) = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
