@@ -587,8 +587,13 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 
     const bool odd = li & 1, hi = li & 2;
     f32x16 acc[2][2];
-    auto kloop = [&](const __bf16* A, bool second, int ch, bool nsecond, int chn) {
-        const __bf16* Ab = A + li * LROW + lh * 8;
+    // q / k / v (and the attention output in q's place) are stored with the columns of row r rotated by 16 (r >> 4) elements: the attention
+    // reads rows 16 apart at the same column (four 4 x 4-window rows), which would otherwise fall into the same banks
+    auto swz = [](int row, int col) { return (col + 16 * (row >> 4)) & 255; };
+    auto kloop = [&](const __bf16* A, bool second, int ch, bool nsecond, int chn, bool rotated = false) {
+        const __bf16* Ab = A + li * LROW;
+        const int rot0 = rotated ? 16 * (li >> 4) : 0, rot1 = rotated ? 16 * (2 + (li >> 4)) : 0;
+        auto acol = [&](int s, int rot) { return (s * 16 + lh * 8 + rot) & 255; };
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -596,14 +601,14 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
         // one wave per SIMD: the A fragments of step s + 1 are requested before the MFMAs of step s (nobody else hides the LDS latency)
-        bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab);
-        bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW);
+        bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab + acol(0, rot0));
+        bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + acol(0, rot1));
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             bf16x8 fn0 = fa0, fn1 = fa1;
             if (s + 1 < 16) {
-                fn0 = *reinterpret_cast<const bf16x8*>(Ab + (s + 1) * 16);
-                fn1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + (s + 1) * 16);
+                fn0 = *reinterpret_cast<const bf16x8*>(Ab + acol(s + 1, rot0));
+                fn1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + acol(s + 1, rot1));
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -628,13 +633,16 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
         if constexpr (TO_LDS) {
             // into an LDS panel the raw MFMA layout is as good as any: the lane's column pair of every row as one 4-byte store (conflict-free:
             // 32 consecutive banks per half-wave), no transposes
-            __bf16* dst = panel + (4 * lh) * LROW + wave * 64 + 2 * li;
+            __bf16* dst = panel + (4 * lh) * LROW;
+            const int col = wave * 64 + 2 * li;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const f32x2 v = {acc[a][0][r] + b0, acc[a][1][r] + b1};
-                    *reinterpret_cast<unsigned*>(dst + (a * 32 + (r & 3) + 8 * (r >> 2)) * LROW) = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                    // row 32 a + 8 (r >> 2) + 4 lh + (r & 3): row >> 4 = 2 a + (r >> 3)
+                    *reinterpret_cast<unsigned*>(dst + (a * 32 + (r & 3) + 8 * (r >> 2)) * LROW + ((col + 16 * (2 * a + (r >> 3))) & 255)) =
+                        __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
                 }
             return;
         }
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             for (int u = 0; u < 2; ++u) {
                 const int tk = tk0 + 4 * u;
                 head[u] = tk % heads; wdw[u] = tk / heads;
-                rowt[u] = ((t >> 2) * 16 + 4 * wdw[u] + (t & 3)) * LROW + head[u] * DH;
+                rowt[u] = ((t >> 2) * 16 + 4 * wdw[u] + (t & 3)) * LROW;
                 st[u] = lin_f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -695,8 +703,9 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
                 float4 qq[2], kk[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    qq[u] = ld_bf16x4(P1 + rowt[u] + 4 * (h + 4 * g));
-                    kk[u] = ld_bf16x4(P2 + rowt[u] + 4 * (h + 4 * g));
+                    const int cq = swz((t >> 2) * 16, head[u] * DH + 4 * (h + 4 * g));
+                    qq[u] = ld_bf16x4(P1 + rowt[u] + cq);
+                    kk[u] = ld_bf16x4(P2 + rowt[u] + cq);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].x, qq[u].x, st[u], 0, 0, 0);
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[u][r] = (float)P3[(16 * h + 4 * wdw[u] + r) * LROW + head[u] * DH + nb * 16 + t];
+                    for (int r = 0; r < 4; ++r) vv[u][r] = (float)P3[(16 * h + 4 * wdw[u] + r) * LROW + swz(16 * h, head[u] * DH + nb * 16 + t)];
                 lin_f32x4 o[2] = {lin_f32x4{0.f, 0.f, 0.f, 0.f}, lin_f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) P1[(16 * h + 4 * wdw[u] + r) * LROW + head[u] * DH + nb * 16 + t] = (__bf16)o[u][r];
+                    for (int r = 0; r < 4; ++r) P1[(16 * h + 4 * wdw[u] + r) * LROW + swz(16 * h, head[u] * DH + nb * 16 + t)] = (__bf16)o[u][r];
             }
         }
     };
@@ -752,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             float q[DHD], o[DHD];
 #pragma unroll
             for (int d = 0; d < DHD; d += 4) {
-                const float4 v = ld_bf16x4(P1 + tok * LROW + head * DHD + d);
+                const float4 v = ld_bf16x4(P1 + tok * LROW + swz(tok, head * DHD + d));
                 q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
             }
             float sj[WS * WS];
@@ -760,7 +769,8 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll
             for (int j = 0; j < WS * WS; ++j) {
                 const int jy = j / WS, jx = j % WS;
-                const __bf16* kr = P2 + ((wy0 + jy) * 16 + wx0 + jx) * LROW + head * DHD;
+                const int krow = (wy0 + jy) * 16 + wx0 + jx;
+                const __bf16* kr = P2 + krow * LROW + swz(krow, head * DHD);      // 16 columns of a head: no wrap inside (16-aligned)
                 float a_ = 0.f;
 #pragma unroll
                 for (int d = 0; d < DHD; d += 4) {
@@ -780,7 +790,8 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll
             for (int j = 0; j < WS * WS; ++j) {
                 const int jy = j / WS, jx = j % WS;
-                const __bf16* vr = P3 + ((wy0 + jy) * 16 + wx0 + jx) * LROW + head * DHD;
+                const int vrow = (wy0 + jy) * 16 + wx0 + jx;
+                const __bf16* vr = P3 + vrow * LROW + swz(vrow, head * DHD);
                 const float pj = sj[j] * inv;
 #pragma unroll
                 for (int d = 0; d < DHD; d += 4) {
@@ -791,7 +802,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll
             for (int d = 0; d < DHD; d += 4) {
                 const f32x4 f = {o[d], o[d + 1], o[d + 2], o[d + 3]};
-                *reinterpret_cast<bf16x4*>(P1 + tok * LROW + head * DHD + d) = __builtin_convertvector(f, bf16x4);
+                *reinterpret_cast<bf16x4*>(P1 + tok * LROW + swz(tok, head * DHD + d)) = __builtin_convertvector(f, bf16x4);
             }
         }
     };
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
         else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], posl + 64 * b);
         else win4(std::integral_constant<int, 64>{}, p.heads[b], posl + 64 * b);
         __syncthreads();                          // the attention output (in P1) is complete
-        kloop(P1, true, b, false, b < 2 ? 3 * (b + 1) : 0);
+        kloop(P1, true, b, false, b < 2 ? 3 * (b + 1) : 0, true);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out[b] + m0 * LK, 0, (unsigned)span * (LK * 2), 0x00020000);
         epilogue(b, biasl + 2304, nullptr, rout, std::false_type{});
     }
