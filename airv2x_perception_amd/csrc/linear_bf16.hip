@@ -500,7 +500,9 @@ struct QwParams {
     int H, W;
 };
 
-__global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const QwParams p) {
+// 8 waves: waves 0-3 own the GEMMs (64 output columns each), all 8 share the LayerNorm rows and the attention tasks -- the phases that are
+// chains of dependent LDS / VALU work run two waves per SIMD
+__global__ __launch_bounds__(512, 1) void ln_qkv_window_out_bf16_kernel(const QwParams p) {
     constexpr int PSZ = 64 * LROW, DEPTH = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
     __bf16* P0 = reinterpret_cast<__bf16*>(lin_smem);
@@ -518,7 +520,8 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
     const int tx = blockIdx.x % bx, ty = (blockIdx.x / bx) % by, ag = blockIdx.x / (bx * by);
     const long long m0 = ((long long)ag * p.H + 4 * ty) * p.W + 16 * tx;
     const int span = 3 * p.W + 16;                                  // tokens from the block's first pixel to its last
-    {
+    const bool gemm = wave < 4;
+    if (tid < 256) {
         float4 bv[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -553,8 +556,10 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff1 + 32 * 16, so, 0);
         }
     };
+    if (gemm) {
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) loadB(bf[s], false, 0, s);
+        for (int s = 0; s < DEPTH; ++s) loadB(bf[s], false, 0, s);
+    }
 
     // ---- P0 = LayerNorm(x (+ delta)): wave w = block row w, 16 pixels, four channels per lane (layernorm_row_256)
     {
@@ -563,14 +568,13 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
                                                                             p.delta ? (unsigned)span * (LK * 2) : 0u, 0x00020000);
         const float4 g = reinterpret_cast<const float4*>(p.gamma)[lane], bt = reinterpret_cast<const float4*>(p.beta)[lane];
         const bool add = p.delta != nullptr;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        {   // wave w: rows 8 w .. 8 w + 7 = block row w >> 1, pixels 8 (w & 1) ..
             f32x4 xv[8];
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             u32x2 dv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int tok = wave * p.W + half * 8 + j;
+                const int tok = (wave >> 1) * p.W + 8 * (wave & 1) + j;
                 xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(tok * (LK * 4) + lane * 16), 0, LIN_NT));
                 dv[j] = __builtin_amdgcn_raw_buffer_load_b64(rd, (unsigned)(tok * (LK * 2) + lane * 8), 0, LIN_NT);
             }
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
                 float4 v = make_float4(xv[j][0], xv[j][1], xv[j][2], xv[j][3]);
                 if (add) v = add_bf16x4(v, make_uint2(dv[j][0], dv[j][1]));
                 const f32x4 y = layernorm_row_256(v, g, bt, p.eps);
-                *reinterpret_cast<bf16x4*>(P0 + (wave * 16 + half * 8 + j) * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
+                *reinterpret_cast<bf16x4*>(P0 + (wave * 8 + j) * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
             }
         }
     }
@@ -687,13 +691,13 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
         float wbias[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) wbias[r] = pos[(h - iy + WS - 1) * (2 * WS - 1) + (r - ix + WS - 1)];
-        const int ntask = 4 * heads;             // a multiple of 8: two independent tasks per wave and pass (one wave per SIMD: the second
-        for (int tk0 = wave; tk0 < ntask; tk0 += 8) {   // task's LDS reads and MFMAs fill the first one's latencies); per task the
+        const int ntask = 4 * heads;             // a multiple of 16: two independent tasks per wave and pass (one wave per SIMD: the second
+        for (int tk0 = wave; tk0 < ntask; tk0 += 16) {   // task's LDS reads and MFMAs fill the first one's latencies); per task the
             int head[2], wdw[2], rowt[2];               // instruction sequence of window_attn_mfma_kernel
             lin_f32x4 st[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int tk = tk0 + 4 * u;
+                const int tk = tk0 + 8 * u;
                 head[u] = tk % heads; wdw[u] = tk / heads;
                 rowt[u] = ((t >> 2) * 16 + 4 * wdw[u] + (t & 3)) * LROW;
                 st[u] = lin_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
     auto win2 = [&](int heads, const float* pos) {
         constexpr int WS = 2, DHD = 16;
         const float scale = 1.0f / sqrtf((float)DHD);
-        for (int e = tid; e < 64 * heads; e += 256) {
+        for (int e = tid; e < 64 * heads; e += 512) {
             const int head = e % heads, tok = e / heads;
             const int py = tok >> 4, px = tok & 15;
             const int wy0 = py & ~1, wx0 = px & ~1, iy = py - wy0, ixx = px - wx0;
@@ -812,18 +816,20 @@ __global__ __launch_bounds__(256, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll 1
         for (int c = 0; c < 3; ++c) {
             const int ch = 3 * b + c;
-            kloop(P0, false, ch, c == 2, c == 2 ? b : ch + 1);
+            if (gemm) kloop(P0, false, ch, c == 2, c == 2 ? b : ch + 1);
             if (c == 0) __syncthreads();          // every wave is past the previous branch's to_out K loop (reads of P1)
-            epilogue(ch, biasl, P1 + c * PSZ, rw, std::true_type{});
+            if (gemm) epilogue(ch, biasl, P1 + c * PSZ, rw, std::true_type{});
         }
         __syncthreads();                          // q, k, v of the branch are complete
         if (p.dh[b] == 16) win2(p.heads[b], posl + 64 * b);
         else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], posl + 64 * b);
         else win4(std::integral_constant<int, 64>{}, p.heads[b], posl + 64 * b);
         __syncthreads();                          // the attention output (in P1) is complete
-        kloop(P1, true, b, false, b < 2 ? 3 * (b + 1) : 0, true);
-        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out[b] + m0 * LK, 0, (unsigned)span * (LK * 2), 0x00020000);
-        epilogue(b, biasl + 2304, nullptr, rout, std::false_type{});
+        if (gemm) {
+            kloop(P1, true, b, false, b < 2 ? 3 * (b + 1) : 0, true);
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out[b] + m0 * LK, 0, (unsigned)span * (LK * 2), 0x00020000);
+            epilogue(b, biasl + 2304, nullptr, rout, std::false_type{});
+        }
     }
 }
 
@@ -1126,7 +1132,7 @@ extern "C" int av2x_ln_qkv_window_attention_bf16(const float* x, const uint16_t*
     const size_t lds = (size_t)4 * 64 * LROW * 2 + (3072 + 192) * 4;
     static av2x::LdsLimit lim;
     lim.ensure(reinterpret_cast<const void*>(&ln_qkv_window_out_bf16_kernel), lds);
-    hipLaunchKernelGGL(ln_qkv_window_out_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, av2x::as_stream(stream), p);
+    hipLaunchKernelGGL(ln_qkv_window_out_bf16_kernel, dim3((unsigned)blocks), dim3(512), lds, av2x::as_stream(stream), p);
     return av2x::check_launch("ln_qkv_window_out_bf16_kernel");
 }
 
