@@ -27,6 +27,8 @@ def conv_key(name):
         bm, bn, wm, wn, stages, mode = (int(g.group(i)) for i in range(1, 7))
         waves = (bm // wm) * (bn // wn)
         return f"g{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if stages == 3 else ''}{'sk' if mode == 1 else ''}"
+    if "conv_wino4_f32" in name:   # Winograd F(4x4,3x3): bench.py's key "w4_32x64"
+        return "w4_32x64"
     if "conv_wino_f32_h" in name:
         return "w32x64h"
     if "conv_wino_f32_q" in name:
@@ -58,6 +60,8 @@ def main():
     ap.add_argument("--calib-fetch")
     ap.add_argument("--calib-write")
     ap.add_argument("--calib-bytes", type=int, default=576 << 20)
+    ap.add_argument("--merge", help="an earlier output of this tool: its (kernel, workgroups) entries are kept where these passes have none, "
+                                    "and its calibration is used when no calibration pass is given")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
     fscale, wscale, cal = 2.0, 1.0, {"note": "guide defaults (no calibration run given)"}
@@ -77,6 +81,9 @@ def main():
                                     "factor 2.0 / 8 re-fetches, i.e. the x 2 correction holds for dword gathers",
                "write_scale_copy": round(w1, 4), "write_scale_fill": round(w2, 4), "launches": [n1, n2, n3, n4],
                "note": "true bytes / (counter KiB x 1024) on tools/pmc_calib.py (576 MiB streaming copy / sum / fill)"}
+    old = json.load(open(a.merge)) if a.merge else None
+    if old and not (a.calib_fetch and a.calib_write):
+        fscale, wscale, cal = old["fetch_scale"], old["write_scale"], old["calibration"]
     acc = defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
     for d in list(a.fetch) + list(a.write):
         last = None  # the stream-K launch a following conv_fixup_f32 dispatch belongs to
@@ -97,6 +104,14 @@ def main():
         fb = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 1024 * fscale
         wb = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) * 1024 * wscale
         per[k][str(wgs)] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "launches": len(v["FETCH_SIZE"])}
+    kept = 0
+    if old:
+        for k, tab in old["per_kernel"].items():
+            for wgs, e in tab.items():
+                if wgs not in per[k]:
+                    per[k][wgs] = e
+                    kept += 1
+        print(f"{kept} entries kept from {a.merge}")
     json.dump({"counters": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes), KiB",
                "fetch_scale": fscale, "write_scale": wscale, "calibration": cal,
                "caveat": "TCC_EA (L2 memory-side) requests: Infinity-Cache hits are included, so this is an upper bound on HBM bytes",
