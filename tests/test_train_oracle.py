@@ -29,9 +29,9 @@ def test_train_oracle_reproduces_the_reference_step(name):
     hs = int(fx["head_stride"])
     for k in ("psm", "rm", "obj"):
         assert np.abs(o[k].detach()[..., ::hs, ::hs].numpy() - fx[k]).max() < 1e-5, k
-    assert abs(float(losses[0]) - fx["losses"][0]) < 1e-4 * abs(fx["losses"][0])
-    assert abs(float(losses[1]) - fx["losses"][1]) < 1e-4 * abs(fx["losses"][1])
-    assert abs(float(losses[2]) - fx["losses"][2]) < 1e-4 * abs(fx["losses"][2])
+    assert abs(float(losses[0].detach()) - fx["losses"][0]) < 1e-4 * abs(fx["losses"][0])
+    assert abs(float(losses[1].detach()) - fx["losses"][1]) < 1e-4 * abs(fx["losses"][1])
+    assert abs(float(losses[2].detach()) - fx["losses"][2]) < 1e-4 * abs(fx["losses"][2])
     for k in [str(k) for k in fx["grad_keys"]]:
         g = sd2[k].grad.reshape(-1)
         stride = max(1, g.numel() // 4096)
