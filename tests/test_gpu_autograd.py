@@ -96,7 +96,7 @@ def test_two_layer_chain_trains_a_step():
 
     l = dev_loss()
     l.backward()
-    assert abs(float(l) - float(l0)) < 1e-5 * max(1.0, float(l0))
+    assert abs(float(l.detach()) - float(l0)) < 1e-5 * max(1.0, float(l0))
     assert_close(w1d.grad.cpu(), a.grad, 2e-4, 2e-5 * float(a.grad.abs().max()), "dw1 through two layers")
     assert_close(w2d.grad.cpu(), b.grad, 2e-4, 2e-5 * float(b.grad.abs().max()), "dw2")
     with torch.no_grad():
