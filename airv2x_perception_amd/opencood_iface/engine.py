@@ -573,7 +573,7 @@ class Where2ComEngine:
     # test_gpu_batch_and_single.py).  Taken where ONE image already fills the chip: >= 256 workgroups per image and a K loop of
     # >= 16 chunks -- the two 256 -> 256 shrink convolutions at 100 x 352 of the default grid.
     WINO4_TILE = 0x60000000 | (32 << 16) | 64
-    WINO4_MIN_WGS_PER_IMAGE = 256
+    WINO4_MIN_WGS_PER_IMAGE = int(os.environ.get("AV2X_WINO4_MIN_WGS", "256"))   # per IMAGE (never per launch): see above
     WINO4_MIN_CIN = 128
     wino4 = os.environ.get("AV2X_WINOGRAD4", "1") != "0"
 
