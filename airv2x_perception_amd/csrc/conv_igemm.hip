@@ -16,6 +16,11 @@
 // contiguous range of tiles so that halo rows / weights are re-used out of its private L2.
 #include "conv_common.hpp"
 
+namespace av2x {
+int wino_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, const float* scale, const float* shift,
+                     const float* residual, float* out, hipStream_t st);   // conv_wino_x3.hip
+}
+
 // Test-only: -DAV2X_ABLATE=<bits> (tools/micro/ablate.sh) removes pieces of the prefetch-2 main loop to see what each costs
 // (1 global loads, 2 LDS stores, 4 barriers, 8 LDS fragment reads after the first step).  Results are garbage, only the
 // timing means something; the product library is never built with it.
@@ -454,6 +459,8 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     if (d->relu == 5 && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: activation 5 (ReLU after the residual) needs mode AV2X_CONV");
     if ((d->tile & 0x60000000) == 0x60000000)   // Winograd F(4x4,3x3): `w` is the transformed packing of av2x_wino4_pack_weights
         return wino4_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
+    if ((d->tile & 0x40000400) == 0x40000400)   // Winograd F(2x2,3x3) with split-3 bf16 operands (conv_wino_x3.hip): `w` = av2x_wino_x3_pack_weights
+        return av2x::wino_x3_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if (d->tile & 0x40000000)   // Winograd F(2x2,3x3): `w` is the transformed packing of av2x_wino_pack_weights
         return wino_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if (d->cin % BK != 0) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);

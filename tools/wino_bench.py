@@ -24,12 +24,16 @@ LAYERS = {
 }
 WINO = {"w32x128": (32, 128), "w64x64": (64, 64), "w32x64": (32, 64), "w32x64h": (32, 64 | 0x8000), "w32x32q": (32, 32 | 0x8000)}
 DIRECT = {"g64x64": (64, 64 | 0x0200), "g128x64w8": (128, 64 | 0x8200)}
+# split-3 Winograd (csrc/conv_wino_x3.hip): three bf16 terms per fp32 operand on v_mfma_f32_32x32x16_bf16
+X3 = {"x3_64x64": (64, 64 | 0x0400), "x3_32x64": (32, 64 | 0x0400)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--only-x3", action="store_true", help="run only the split-3 tiles (profiling)")
+    ap.add_argument("--tiles", default="", help="restrict the split-3 tiles (x3_64x64,x3_32x64)")
     ap.add_argument("--check", action="store_true", help="compare against an fp64 conv (slow for the big layers)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -45,6 +49,10 @@ def main():
         wp = wp.cuda()
         u = torch.empty(lib.av2x_wino_weight_bytes(cin, coutp) // 4, device="cuda")
         _lib.check(lib.av2x_wino_pack_weights(P(wp), cin, coutp, P(u), st), "pack")
+        u3 = None
+        if cin % 16 == 0 and coutp % 64 == 0:
+            u3 = torch.empty(lib.av2x_wino_x3_weight_bytes(cin, coutp) // 2, dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.av2x_wino_x3_pack_weights(P(wp), cin, coutp, P(u3), st), "pack x3")
         sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.1
         flops = 2.0 * n * h * w * cout * 9 * cin
         print(f"{name:11s} M={n*h*w:7d} cin={cin} cout={cout} {flops/1e9:6.1f} GF  direct ideal {flops/157.3e6:6.1f} us", flush=True)
@@ -70,6 +78,8 @@ def main():
 
         base = None
         for tn, (bm, bn) in DIRECT.items():
+            if a.only_x3:
+                break
             if coutp % (bn & 0x1ff) or cin % 32:
                 continue
             us, y = run((bm << 16) | bn, wp)
@@ -77,12 +87,21 @@ def main():
             err = f" err64={float((y.double() - ref).abs().max()):.2e}" if ref is not None else ""
             print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF{err}", flush=True)
         for tn, (tb, cb) in WINO.items():
+            if a.only_x3:
+                break
             if cout % (cb & 0x1ff):
                 continue
             us, y = run(0x40000000 | (tb << 16) | cb, u)
-            err = f" err64={float((y.double() - ref).abs().max()):.2e}" if ref is not None else ""
+            err = f" err64={float((y.double() - ref).abs().max()):.2e} rms={float((y.double() - ref).pow(2).mean().sqrt()):.2e}" if ref is not None else ""
             dv = f" vs direct {float((y - base).abs().max()):.2e} (max|y| {float(base.abs().max()):.2f})" if base is not None else ""
             print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF(eff){err}{dv} nan={int(torch.isnan(y).sum())}", flush=True)
+        for tn, (tb, cb) in X3.items():
+            if u3 is None or (a.tiles and tn not in a.tiles.split(",")):
+                continue
+            us, y = run(0x40000000 | (tb << 16) | cb, u3)
+            err = f" err64={float((y.double() - ref).abs().max()):.2e} rms={float((y.double() - ref).pow(2).mean().sqrt()):.2e}" if ref is not None else ""
+            dv = f" vs direct {float((y - base).abs().max()):.2e} (max|y| {float(base.abs().max()):.2f})" if base is not None else ""
+            print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF(eff) {flops*16/36*6/us/1e6:7.1f} TF bf16 executed{err}{dv} nan={int(torch.isnan(y).sum())}", flush=True)
 
 
 if __name__ == "__main__":
