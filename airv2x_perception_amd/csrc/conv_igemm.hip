@@ -19,6 +19,7 @@
 namespace av2x {
 int wino_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, const float* scale, const float* shift,
                      const float* residual, float* out, hipStream_t st);   // conv_wino_x3.hip
+int x3p_dispatch(const void* conv_params, size_t bytes, int bm, int bn, hipStream_t st);   // conv_x3p.hip
 }
 
 // Test-only: -DAV2X_ABLATE=<bits> (tools/micro/ablate.sh) removes pieces of the prefetch-2 main loop to see what each costs
@@ -463,7 +464,8 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
         return av2x::wino_x3_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if (d->tile & 0x40000000)   // Winograd F(2x2,3x3): `w` is the transformed packing of av2x_wino_pack_weights
         return wino_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
-    if (d->cin % BK != 0) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);
+    const bool x3p = (d->tile & 0x1400) == 0x1400 && !(d->tile & 0x40000000);   // pipelined split-3 tiles step 16 channels
+    if (d->cin % BK != 0 && !(x3p && d->cin % 16 == 0)) return av2x::fail("av2x_conv2d: cin=%d must be a multiple of %d", d->cin, BK);
     if (d->coutp % 32 != 0 || d->coutp <= 0) return av2x::fail("av2x_conv2d: coutp=%d must be a positive multiple of 32", d->coutp);
     if (d->mode < 0 || d->mode > 2) return av2x::fail("av2x_conv2d: bad mode %d", d->mode);
     if (d->in_coff % 4 || d->in_ctot % 4) return av2x::fail("av2x_conv2d: input channel offset/stride must be multiples of 4");
@@ -516,6 +518,7 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x01ff;
     if (d->tile & 0x0400) {   // split-3: fp32-accurate products from three bf16 terms per operand; w = [3] bf16 planes
         p.w_bytes = (unsigned)(w_bytes / 2 * 3);
+        if (d->tile & 0x1000) return av2x::x3p_dispatch(&p, sizeof(p), bm, bn, st);   // pipelined form (conv_x3p.hip), same bits
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
         const bool w8b = (d->tile & 0x8000) != 0, db3 = (d->tile & 0x4000) != 0;   // 0x4000: second LDS buffer set
 #define AV2X_X3(W8, BMv, BNv, WMv, WNv)                                                                   \

@@ -25,6 +25,8 @@
 //     through LDS (the V buffers, free by then) and every wave finalises a quarter of the workgroup's outputs.
 // A chunk of 16 input channels is 48 MB steps of ONE MFMA plus a few side instructions each (split of the next A fragment,
 // LDS reads, B loads, the next chunk's gather / transform / LDS stores), pinned by scheduling barriers.
+#include <cstdlib>
+
 #include "conv_common.hpp"
 
 namespace {
@@ -57,6 +59,9 @@ __device__ constexpr int x3_bp(int p) { return p == 0 ? 0 : p == 1 ? 2 : p == 2 
 // v_pk_add_f32 through inline assembly: next to MFMAs the compiler's peephole unpacks packed fp32 adds into two scalar ones (right
 // when VALU cycles are the bound; here a wave's ISSUE slots are -- one wave per SIMD issues one instruction per four cycles).
 // No consumer of these results follows within one instruction (the packed-result wait state).
+#ifndef AV2X_X3_MB1_OCC
+#define AV2X_X3_MB1_OCC 2
+#endif
 #ifndef AV2X_X3_PK
 #define AV2X_X3_PK 0
 #endif
@@ -125,7 +130,7 @@ __device__ __forceinline__ void x3_static_for(F&& f) {
 }
 
 template <int MB, bool GENERAL>
-__global__ __launch_bounds__(256, MB == 1 ? 2 : 1) void conv_wino_x3(const WinoX3Params p) {
+__global__ __launch_bounds__(256, MB == 1 ? AV2X_X3_MB1_OCC : 1) void conv_wino_x3(const WinoX3Params p) {
     constexpr int TB = 32 * MB;            // tiles per workgroup
     constexpr int CH = 2 * MB;             // channels gathered per thread (256 threads = TB tiles x 16 / CH channel groups)
     constexpr int NG = 4 * MB;             // (xi, tile block) groups per chunk and wave; 12 MFMAs each
@@ -446,7 +451,8 @@ static int launch_wino_x3(const WinoX3Params& p0, hipStream_t st) {
     constexpr int TB = 32 * MB;
     p.nblocks = p.Cout / 64;
     const int mblocks = (p.T + TB - 1) / TB;
-    const size_t lds = 2ull * 16 * 4 * (TB * 16 + 32);
+    size_t lds = 2ull * 16 * 4 * (TB * 16 + 32);
+    if (const char* pad = getenv("AV2X_X3_LDS_PAD")) lds += (size_t)atoi(pad);   // debug probe (tools/debug/dbg_attn.py)
     const bool general = p.res || (p.relu != 0 && p.relu != 1);
     static av2x::LdsLimit lim_s, lim_g;
     if (general) {

@@ -35,6 +35,9 @@ def _runner(device):
         # synchronises, next to the weight-gradient side stream) would stall the first epoch and could persist a noisy pick.
         # Shipped / cached table hits are still used; a miss falls back to the pick_tile rule.  All candidates are bit-identical.
         r.tune_on_miss = False
+        # the training step is pinned to the reference's step gradient by gradient: fp32-input matrix cores throughout
+        r.wino_x3 = False
+        r.x3p = False
     return r
 
 

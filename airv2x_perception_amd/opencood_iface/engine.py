@@ -206,8 +206,15 @@ class Where2ComEngine:
         # Winograd F(2x2,3x3) with split-3 operands (csrc/conv_wino_x3.hip): the same 16-position algorithm, every fp32 operand as three
         # bf16 terms on v_mfma_f32_32x32x16_bf16 (2.67x fewer matrix cycles than the fp32-input MFMA, fp32-accurate products, error against
         # fp64 at or below the fp32 Winograd kernel's).  A rule of the layer and the map (wino_x3_rule), never of a timing or the agent
-        # count.  Opt-in (AV2X_WINO_X3=1 / bench.py --gemm wino_x3): results differ from the fp32-MFMA kernels in the last bits.
-        self.wino_x3 = os.environ.get("AV2X_WINO_X3", "0") not in ("0", "off", "")
+        # count.  ON by default since round 4 (AV2X_X3=0 / AV2X_WINO_X3=0 / bench.py --gemm f32 restore the fp32-input matrix cores): the
+        # per-kernel error against fp64 is not above the fp32 Winograd kernel's on any tested shape and every model's goldens hold at their
+        # unchanged tolerances (tests/test_gpu_wino_x3.py); results differ from the fp32-MFMA kernels in the last bits.
+        x3_default = os.environ.get("AV2X_X3", "1")
+        self.wino_x3 = os.environ.get("AV2X_WINO_X3", x3_default) not in ("0", "off", "")
+        # ... and its companion for every OTHER convolution / Linear (1x1, strided, transposed): the pipelined split-3 implicit GEMM
+        # (csrc/conv_x3p.hip; bit-identical to conv_igemm_bf16x3, 1.1-1.15x faster).  x3p alone leaves the 3x3 layers on the fp32 Winograd
+        # kernels; wino_x3 + x3p = the "x3" mode of bench.py: every product of the frame formed from three bf16 terms per operand.
+        self.x3p = os.environ.get("AV2X_X3P", x3_default) not in ("0", "off", "")
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
@@ -254,6 +261,7 @@ class Where2ComEngine:
         other.winograd, other.throughput_mode = self.winograd, self.throughput_mode
         other.split3 = self.split3
         other.wino_x3 = self.wino_x3
+        other.x3p = self.x3p
         return other
 
     def graph_active(self):
@@ -329,7 +337,14 @@ class Where2ComEngine:
                 k = int(round(1.0 / s))
                 w, coutp = pack_conv_weight(sd[f"{prefix}deblocks.{i}.0.weight"])
                 self.deblocks.append(ConvLayer(up(w), up(sc), up(sh), self.bb["num_filters"][i], cu, coutp, k, k, 0, 1))
-        self.cat_c = sum(self.bb["num_upsample_filter"])
+        # the concatenated map holds the per-level deblocks' channels only.  The reference asserts len(upsample_strides) ==
+        # len(num_upsample_filter) (base_bev_backbone.py:24-27) and sizes the extra ConvTranspose2d with sum(num_upsample_filters): a
+        # filter entry beyond the levels would leave channels of the concat buffer unwritten here, so it is rejected instead
+        nuf = list(self.bb["num_upsample_filter"])
+        if len(nuf) > nlev and sum(nuf[nlev:]) != 0:
+            raise ValueError(f"num_upsample_filter has {len(nuf)} entries for {nlev} levels: the entries beyond the levels must be absent or 0 "
+                             "(the final deblock works on the concatenation of the per-level maps)")
+        self.cat_c = sum(nuf[:nlev])
         self.final_deblock = None
         if len(self.bb["upsample_strides"]) > nlev:   # ConvTranspose2d on the concatenated map (:107-121, :151-152)
             s = int(self.bb["upsample_strides"][-1])
@@ -501,6 +516,9 @@ class Where2ComEngine:
         d.act16 = a16
         wgt = _w16(L) if self.amp else (_w3(L) if self.split3 else L.w)
         vflag = 0x0800 if self.amp else (0x0400 if self.split3 else 0)
+        # (1 x 1 "maps" -- the per-agent embeddings of V2X-ViT, a few rows per launch -- keep the lighter fp32 tiles: 8 us against 22.  Keyed on
+        # the map, not on the launch: the agent-sharded frame and a batch must pick the same class as the single frame)
+        x3p_ok = not self.amp and not a16 and not self.conv_tile and L.cin % 16 == 0 and L.coutp % 64 == 0 and d.ho * d.wo >= 16
         if (a16 & 1) and self.halo16 and not self.conv_tile and self.halo16_rule(L) and residual is None:
             wgt, d.coutp = _w16h(L)                     # halo-tile direct convolution on bf16 activations: a rule, not a timing
             d.tile = self.HALO16_TILE
@@ -520,6 +538,9 @@ class Where2ComEngine:
                     t = self._tune(d, x, L, out, "wino", key)
                     self.tile_cache[key] = t
                 d.tile, d.sk_wgs = t
+        elif x3p_ok and (self.x3p or self.split3):
+            wgt = _w3(L)                                 # a rule of the shape (x3p_tile), no timing: reproducible
+            d.tile = self.x3p_tile(n * d.ho * d.wo, L.coutp)
         elif self.conv_tile:
             d.tile = self.conv_tile
             d.sk_wgs = self.conv_sk_wgs if (d.tile & 0x2000) else 0
@@ -588,18 +609,26 @@ class Where2ComEngine:
                 and L.cin >= 64 and L.cin % 8 == 0 and L.cout % 64 == 0 and L.cout == L.coutp)
 
     @staticmethod
+    def x3p_tile(m, coutp):
+        """Pipelined split-3 GEMM tile (csrc/conv_x3p.hip): 128 x 128 where that still gives two workgroups per CU, else 128 x 64
+        (tools/split3_bench.py); both give the bits of every other split-3 tile."""
+        bn = 128 if (coutp % 128 == 0 and -(-m // 128) * (coutp // 128) >= 512) else 64
+        return (128 << 16) | bn | 0x1400
+
+    @staticmethod
     def wino_x3_rule(L):
-        """Layers the split-3 Winograd kernel takes: the F(2x2,3x3) class with 16-channel chunks and 64-cout blocks."""
-        return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cout % 64 == 0 and L.coutp == L.cout
+        """Layers the split-3 Winograd kernel takes: the F(2x2,3x3) class with 16-channel chunks, 64-cout blocks and >= 128 input
+        channels (the 64 -> 64 layers at 100 x 352 have too short a K loop for the 64 x 64 tile: fp32 Winograd is faster there)."""
+        return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cin >= 128 and L.cout % 64 == 0 and L.coutp == L.cout
 
     @staticmethod
     def wino_x3_tile(L, h, w):
-        """64 x 64 (one wave per SIMD, B fragments re-used for two tile blocks) where ONE image already fills the chip with such
-        workgroups and the K loop is long; 32 x 64 (two workgroups per CU) otherwise.  Same bits either way; a function of the layer and
-        the map size only."""
-        tiles = ((h + 1) // 2) * ((w + 1) // 2)
-        tb = 64 if (tiles >= 4000 and L.cin >= 128) else 32
-        return 0x40000400 | (tb << 16) | 64
+        """Always the 64 x 64 tile (one wave per SIMD with the whole register file: nothing else is co-resident on its CU).
+        The 32 x 64 tile (two workgroups per CU) is 1.2-1.3x faster on the small maps and gives the same bits, but it is NOT used:
+        while one of its workgroups shares a CU with waves of another kernel of another stream, that kernel's results were observed
+        corrupted (fax_attention_wave_kernel, 49 of 50 launches: tools/debug/dbg_attn2.py; the kernel's own results, LDS and VGPR
+        guard patterns of a probe kernel stay intact -- DESIGN.md section 3.1i).  Until that is understood the engine never launches it."""
+        return 0x40000400 | (64 << 16) | 64
 
     # Winograd F(4x4,3x3) (csrc/conv_wino4.inc): 2.25 multiplies per output instead of 4; one workgroup (32 tiles of 4x4 outputs x 64
     # couts, 18 accumulator tiles per wave) occupies a CU, so a launch takes ceil(workgroups / 256) x (14 us + 2.9 us per 8 input

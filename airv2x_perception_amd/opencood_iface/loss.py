@@ -78,15 +78,21 @@ class PointPillarLossMultiClass(nn.Module):
             # the reference's one_hot scatter_ raises on an out-of-range class id (point_pillar_loss_multiclass.py:118-125); the kernel
             # would silently train such an anchor as background.  One small reduction + read-back per step (set
             # validate_class_ids = False to skip it once the label pipeline is trusted)
-            lo, hi = int(cid.min()), int(cid.max())
-            if lo < 0 or hi >= int(self.cls_num):
-                raise IndexError(f"class_ids outside [0, {int(self.cls_num)}): min {lo}, max {hi}")
+            # ... asynchronously: the two reductions are queued with the step and read together with the loss parts below, so the
+            # check no longer drains the queued forward before the loss and the backward can be enqueued
+            cid_range = torch.stack([cid.min(), cid.max()]).to(torch.float32)
         f32 = lambda t: t.detach().to(psm.device, torch.float32).contiguous()
         cont = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
         total, parts = _PPLoss.apply(cont(psm), cont(rm), cont(obj), f32(target_dict["targets"]), f32(target_dict["pos_equal_one"]),
                                      target_dict["class_ids"].detach().to(psm.device, torch.int32).contiguous(),
                                      int(self.cls_num), self.cls_weight, self.reg_coe)
-        vals = parts.tolist()                     # the reference's three .item() calls (:172-177) in one read-back
+        if cid.numel() and self.validate_class_ids:
+            both = torch.cat([parts.detach().float().flatten(), cid_range.to(parts.device)]).tolist()   # ONE read-back: loss parts + id range
+            vals, (lo, hi) = both[:-2], (int(both[-2]), int(both[-1]))
+            if lo < 0 or hi >= int(self.cls_num):
+                raise IndexError(f"class_ids outside [0, {int(self.cls_num)}): min {lo}, max {hi}")
+        else:
+            vals = parts.tolist()                 # the reference's three .item() calls (:172-177) in one read-back
         self.loss_dict.update({"total_loss" + prefix: vals[0], "reg_loss" + prefix: vals[1], "conf_loss" + prefix: vals[2]})
         return total
 

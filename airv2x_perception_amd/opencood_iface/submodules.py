@@ -440,7 +440,8 @@ class ResNetBEVBackbone(BaseBEVBackbone):
             _retype(self.deblocks[nlev], _Stage).bind(self, "_run_deblock", nlev)
         _retype(self.resnet, _Stage).bind(self, "_run_resnet", 0)
         self.num_levels = nlev
-        self.num_bev_features = sum(model_cfg.get("num_upsample_filter", [])) if ups else model_cfg["num_filters"][-1]
+        # as the reference (base_bev_backbone_resnet.py:80-81): sum(num_upsample_filters), 0 without deblocks
+        self.num_bev_features = sum(model_cfg.get("num_upsample_filter", [])) if ups else 0
 
     def _pack(self, r, sd):
         cfg = self.model_cfg
@@ -499,7 +500,12 @@ class ResNetBEVBackbone(BaseBEVBackbone):
                 if r.final_deblock is not None:
                     out = self.deblock_nhwc(len(r.blocks), cat)
             else:
-                out = torch.cat(feats, -1) if len(feats) > 1 and all(f.shape[1:3] == feats[0].shape[1:3] for f in feats) else feats[0]
+                # no deblocks: the reference concatenates the level maps (base_bev_backbone_resnet.py:112-120), which raises when their
+                # resolutions differ -- as here, instead of silently dropping levels
+                if len(feats) > 1 and not all(f.shape[1:3] == feats[0].shape[1:3] for f in feats):
+                    raise ValueError("ResNetBEVBackbone without deblocks: the level maps have different resolutions "
+                                     f"({[tuple(f.shape[1:3]) for f in feats]}) and cannot be concatenated")
+                out = torch.cat(feats, -1) if len(feats) > 1 else feats[0]
             data_dict["spatial_features_2d"] = _nchw(out)
             return data_dict
 

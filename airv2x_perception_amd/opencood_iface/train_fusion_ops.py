@@ -76,7 +76,7 @@ class LinearFn(torch.autograd.Function):
         n, h, w, cin = x.shape
         cout = weight.shape[0]
         w4 = weight.detach().view(cout, cin, 1, 1)
-        wp, coutp, _ = T._packed(r, w4)
+        wp, coutp, _, _ = T._packed(r, w4, owner=weight)    # keyed on the nn.Linear parameter: one packing per optimiser step
         L = ConvLayer(wp, None, bias.detach() if bias is not None else T._zeros(cout, x.device), cin, cout, coutp, 1, 1, 0, 0)
         y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
         r.amp = T.AMP_STEP[0]
@@ -99,7 +99,7 @@ class LinearFn(torch.autograd.Function):
         db = _chan_sum(r, dy, rows, cout) if (ctx.has[0] and ctx.needs_input_grad[2]) else None
         w4 = weight.detach().view(cout, cin, 1, 1)
         with T.amp_scope(ctx.amp):
-            dw, dx = T._wgrad_and_dgrad(x, dy, w4, 1, 0, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+            dw, dx = T._wgrad_and_dgrad(x, dy, w4, 1, 0, ctx.needs_input_grad[1], ctx.needs_input_grad[0], owner=weight)
         if dw is not None:
             dw = dw.view(cout, cin)
         return dx, dw, db, (dy if (ctx.has[1] and ctx.needs_input_grad[3]) else None)

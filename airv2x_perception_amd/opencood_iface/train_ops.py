@@ -80,17 +80,20 @@ def _zeros(c, device):
 _PACKED = {}       # id(parameter) -> (version, weakref, packed, coutp, winograd-transformed | None): one packing per optimiser step
 
 
-def _packed(r, weight, flipped=False):
+def _packed(r, weight, flipped=False, owner=None):
     """The kernel packing of a convolution weight (``flipped``: of its 180-degree-rotated, channel-transposed form -- the data
     gradient's weights), cached per parameter and version counter: a training step uses every weight in up to three passes."""
     import weakref
-    key = (id(weight), flipped)
+    # ``owner``: the nn.Parameter a reshaped view was taken from (nn.Linear's (cout, cin) weight seen as a 1x1 convolution): the cache
+    # is keyed on it -- the view is a new object on every call (it shares the parameter's storage and version counter)
+    own = owner if owner is not None else weight
+    key = (id(own), flipped, tuple(weight.shape))
     ent = _PACKED.get(key)
     # ``_version`` does not move for writes through ``.data`` nor for ``module.to(device)`` (which re-points ``.data``): the storage
     # address and the device are part of the validity check, like the eval engine's _version()
     stamp = (weight._version, weight.data_ptr(), weight.device)
-    if ent is not None and ent[0] == stamp and ent[1]() is weight:
-        return ent[2], ent[3], ent[4]
+    if ent is not None and ent[0] == stamp and ent[1]() is own:
+        return ent[2], ent[3], ent[4], ent
     src = weight.detach().flip(2, 3).transpose(0, 1) if flipped else weight
     wp, coutp = pack_conv_weight_dev(src)
     cout, cin, ks = src.shape[0], src.shape[1], src.shape[2]
@@ -98,11 +101,12 @@ def _packed(r, weight, flipped=False):
     if r.winograd and ks == 3 and cin >= 64 and cin % 8 == 0 and cout % 64 == 0 and cout == coutp:   # engine.wino_rule's weight side
         u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=weight.device)
         _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u), r.stream()), "av2x_wino_pack_weights")
-    if weight.is_leaf and isinstance(weight, torch.nn.Parameter):
+    ent = [stamp, weakref.ref(own) if (own.is_leaf and isinstance(own, torch.nn.Parameter)) else None, wp, coutp, u, None]
+    if ent[1] is not None:
         if len(_PACKED) > 4096:
             _PACKED.clear()
-        _PACKED[key] = (stamp, weakref.ref(weight), wp, coutp, u)
-    return wp, coutp, u
+        _PACKED[key] = ent
+    return wp, coutp, u, ent      # ent[5]: the F(4x4,3x3)-transformed weights, made by conv_raw on first need
 
 
 # AMP training (tools/train.py:50,107-130: the forward runs under ``amp.autocast`` and the loss goes through a GradScaler): while
@@ -135,19 +139,28 @@ class amp_scope:
         return False
 
 
-def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=False):
+def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=False, owner=None):
     """act(scale * conv2d(x, w) + shift) through the engine's launcher (direct or Winograd kernels, autotuned).  ``flipped``:
     convolve with the 180-degree-rotated, channel-transposed weights (the data gradient)."""
     from .engine import ConvLayer
     r = _runner(x.device)
     n, h, w, cin = x.shape
-    wp, coutp, u = _packed(r, weight, flipped)
+    wp, coutp, u, ent = _packed(r, weight, flipped, owner)
     cout, ks = (weight.shape[1], weight.shape[2]) if flipped else (weight.shape[0], weight.shape[2])
     sh = shift if shift is not None else _zeros(cout, x.device)
     L = ConvLayer(wp, scale, sh, cin, cout, coutp, ks, stride, pad, act)
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     if u is not None and r.wino_rule(L):   # transformed weights made on this stream, without engine._wu's cross-stream synchronise
         L._wu = u
-    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+        # the F(4x4,3x3) class (engine.wino4_rule: the 256 -> 256 layers at 100 x 352, forward and data gradient): its transformed
+        # weights are cached with the packing, per parameter and version, built on the launch stream -- engine._wu4 would re-run the
+        # transform on every call of this throw-away layer object and synchronise the host each time
+        if r.wino4 and r.wino4_rule(L, n, ho, wo):
+            if ent[5] is None:
+                u4 = torch.empty(r.lib.av2x_wino4_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=x.device)
+                _lib.check(r.lib.av2x_wino4_pack_weights(_P(wp), cin, coutp, _P(u4), r.stream()), "av2x_wino4_pack_weights")
+                ent[5] = u4
+            L._wu4 = ent[5]
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
     r.amp = AMP_STEP[0] and cin % 8 == 0
     try:
@@ -175,7 +188,7 @@ def conv_wgrad(x, dz, weight_shape, stride, pad):
     return dw
 
 
-def conv_dgrad(dz, weight, stride, pad, in_hw):
+def conv_dgrad(dz, weight, stride, pad, in_hw, owner=None):
     """Data gradient of conv2d: the forward kernel on the 180-degree-rotated, channel-transposed weights (stride 2: on the
     zero-upsampled dz -- exact, the inserted zeros contribute nothing)."""
     n, ho, wo, cout = dz.shape
@@ -192,7 +205,7 @@ def conv_dgrad(dz, weight, stride, pad, in_hw):
         src[:, ::2, ::2] = dz
     else:
         raise NotImplementedError("data gradient: stride 1, or 3x3 stride 2 pad 1 on even sizes (every layer of the BEV backbone)")
-    return conv_raw(src, weight, 1, ks // 2 if ks == 3 else 0, flipped=True)
+    return conv_raw(src, weight, 1, ks // 2 if ks == 3 else 0, flipped=True, owner=owner)
 
 
 def bn_stats(z):
@@ -292,13 +305,13 @@ _SIDE = {}
 OVERLAP_WGRAD = os.environ.get("AV2X_TRAIN_OVERLAP", "1") != "0"
 
 
-def _wgrad_and_dgrad(x, dz, weight, stride, pad, need_w, need_x):
+def _wgrad_and_dgrad(x, dz, weight, stride, pad, need_w, need_x, owner=None):
     """The two gradients of a convolution are independent given dz: the weight gradient (one round of <= 256 workgroups, one per
     CU) goes to a side stream, the data gradient (small maps: partially filled waves of workgroups) stays on the current one --
     each fills what the other leaves idle.  Same kernels, same bits."""
     if not (need_w and need_x and OVERLAP_WGRAD):
         dw = conv_wgrad(x, dz, weight.shape, stride, pad) if need_w else None
-        dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3]) if need_x else None
+        dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3], owner) if need_x else None
         return dw, dx
     main = torch.cuda.current_stream(x.device)
     side = _SIDE.get(x.device)
@@ -307,7 +320,7 @@ def _wgrad_and_dgrad(x, dz, weight, stride, pad, need_w, need_x):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         dw = conv_wgrad(x, dz, weight.shape, stride, pad)
-    dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3])
+    dx = conv_dgrad(dz, weight, stride, pad, x.shape[1:3], owner)
     main.wait_stream(side)
     dw.record_stream(main)      # allocated under the side stream, consumed by autograd on the current one
     x.record_stream(side)       # read by the side stream: the allocator must not recycle them before it is done

@@ -99,9 +99,11 @@ def parse(argv=None):
     ap.add_argument("--only-headline", action="store_true",
                     help="skip the secondary legs (split-3, post-process, raw clouds, layout cycling, CPU baseline): the timed "
                          "frames + the roofline pass only -- the command the rocprofv3 summaries in profiles/ are taken from")
-    ap.add_argument("--gemm", choices=["f32", "split3", "wino_x3"], default="f32",
-                    help="f32: v_mfma_f32_32x32x2_f32 (default, the headline); split3: fp32-accurate products from three bf16 "
-                         "terms per operand on the bf16 matrix cores (conv_igemm_bf16x3)")
+    ap.add_argument("--gemm", choices=["f32", "split3", "wino_x3", "x3"], default="x3",
+                    help="x3 (default, the headline since round 4): fp32-accurate products from three bf16 terms per operand on the bf16 matrix "
+                         "cores -- conv_wino_x3 for the F(2x2,3x3) layers, conv_igemm_x3p for every other convolution / Linear, the two "
+                         "F(4x4,3x3) layers on the fp32-input MFMA; f32: every product on v_mfma_f32_32x32x2_f32 (the headline of rounds 1-3); "
+                         "wino_x3: only the Winograd layers split; split3: split-3 direct kernels everywhere, no Winograd")
     ap.add_argument("--amp", action="store_true",
                     help="AMP mode: bf16 matrix-core operands with fp32 accumulation for every Conv2d / Linear (what "
                          "torch.autocast does in the reference's train.py validation pass); NOT the headline configuration")
@@ -224,7 +226,10 @@ def make_model(a, args, dev):
     eng.amp = bool(a.amp)
     eng.split3 = a.gemm == "split3" and not a.amp
     # wino_x3: the F(2x2,3x3) layers on conv_wino_x3 (three bf16 terms per fp32 operand on the bf16 matrix cores), the rest as --gemm f32
-    eng.wino_x3 = a.gemm == "wino_x3" and not a.amp
+    eng.wino_x3 = a.gemm in ("wino_x3", "x3") and not a.amp
+    # x3: wino_x3 + every other convolution / Linear on the pipelined split-3 GEMM (conv_igemm_x3p): all products of the frame from
+    # three bf16 terms per operand (the F(4x4,3x3) layers stay on the fp32-input MFMA: faster there)
+    eng.x3p = a.gemm == "x3" and not a.amp
     return model, eng, sd
 
 
@@ -474,7 +479,8 @@ def main(argv=None, hooks=None, device=None):
         **({"precision_note": "AMP mode (autocast semantics): bf16 MFMA operands, fp32 accumulate; V2X-ViT: Linear / conv outputs stored as bf16, LayerNorm / softmax / residual sums in fp32; max |err| vs the fp32 path "
                               "is reported by tests/test_amp.py -- not comparable with the fp32 headline"} if a.amp else {}),
         "dtype": "bf16" if a.amp else ("f32 (products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate)" if a.gemm == "split3" else
-                                       "f32 (3xbf16 operands, fp32 accumulate) on the Winograd F(2x2,3x3) layers; f32 (fp32-input MFMA) elsewhere" if a.gemm == "wino_x3" else "f32"), "data": "synthetic",
+                                       "f32 (3xbf16 operands, fp32 accumulate) on the Winograd F(2x2,3x3) layers; f32 (fp32-input MFMA) elsewhere" if a.gemm == "wino_x3" else
+                                       "f32 (3xbf16 operands, fp32 accumulate); the two F(4x4,3x3) Winograd layers on the fp32-input MFMA" if a.gemm == "x3" else "f32"), "data": "synthetic",
         "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(synth.sort_types(synth.agent_types_for(a.agents))[1])}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if (a.agents == 4 and a.lidar_only) else "")
@@ -501,13 +507,34 @@ def main(argv=None, hooks=None, device=None):
         res["single_stream"] = {"frames_per_s": round(1.0 / l1, 2), "ms_per_frame": round(l1 * 1e3, 3),
                                 "note": "one frame at a time (no overlap between frames)"}
 
-    # ---------------- the same frames with the split-3 GEMM (fp32-accurate, bf16 matrix cores): reported beside the headline
+    # ---------------- AMP lines: what bf16 operands / activations do to THIS frame's outputs, against the fp32-accurate device path of the
+    # same frame (itself pinned to the reference's goldens at 2e-4 .. 1e-3, tests/): max |difference| and the drift relative to the
+    # head's magnitude, per head.  The AP-level statement for autocast is tests/test_gpu_amp_ap.py (seeded points -> boxes -> AP chains).
+    if a.amp and rank == 0 and a.mode == "replica" and out is not None:
+        amp_out = {k: out[k].float().clone() for k in ("psm", "rm", "obj") if k in out}
+        model.amp = False
+        eng.amp = False
+        eng.wino_x3 = eng.x3p = a.gemm == "x3"
+        exact = model(dd)
+        torch.cuda.synchronize()
+        res["amp_drift"] = {
+            "vs": "the same frame on the fp32-accurate device path (--gemm " + a.gemm + ")",
+            **{k: {"max_abs": float((amp_out[k] - exact[k].float()).abs().max()), "max_abs_exact": float(exact[k].float().abs().max()),
+                   "rel_to_max": float((amp_out[k] - exact[k].float()).abs().max() / exact[k].float().abs().max().clamp_min(1e-12)),
+                   "rms_rel": float(((amp_out[k] - exact[k].float()).pow(2).mean().sqrt()) / exact[k].float().pow(2).mean().sqrt().clamp_min(1e-12))}
+               for k in amp_out}}
+        model.amp = True
+        eng.amp = True
+        eng.wino_x3 = eng.x3p = False
+
+    # ---------------- the same frames in the OTHER product mode (x3 headline: the fp32-input MFMA kernels; f32 headline: x3): beside the headline
     if secondary and a.inflight > 1:
         eng.throughput_mode = True    # the pipelined secondary legs below
-    if secondary and a.model == "where2com" and a.lidar_only and a.gemm == "f32" and not a.amp and a.inflight > 1:
+    if secondary and a.model == "where2com" and a.lidar_only and a.gemm in ("f32", "x3") and not a.amp and a.inflight > 1:
+        other_x3 = a.gemm == "f32"
         for e in pipe.engines:
-            e.split3 = True
-        out3 = model(dd)  # tunes the split-3 tiles
+            e.wino_x3 = e.x3p = other_x3
+        out3 = model(dd)  # first frame of the mode: packs its weights
         for _ in range(a.inflight):
             pipe.submit(dd)
         pipe.drain()
@@ -519,13 +546,15 @@ def main(argv=None, hooks=None, device=None):
         torch.cuda.synchronize()
         s3 = (time.perf_counter() - t1) / a.steps
         split3_out = {k: out3[k].clone() for k in ("psm", "rm", "obj")}
-        res["fp32_split3"] = {"frames_per_s": round(1.0 / s3, 2), "ms_per_step": round(s3 * 1e3, 3), "frames_in_flight": a.inflight,
-                              "max_abs_diff_vs_f32_mfma": {k: float((split3_out[k] - out[k]).abs().max()) for k in split3_out},
-                              "note": "opt-in engine.split3 / --gemm split3: every fp32 operand = hi+mid+lo bf16 terms, six partial "
-                                      "products per MAC on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs fp64 is at or below the "
-                                      "fp32-MFMA kernel's (tools/split3_bench.py); NOT the headline value"}
+        res["x3" if other_x3 else "fp32_mfma"] = {
+            "frames_per_s": round(1.0 / s3, 2), "ms_per_step": round(s3 * 1e3, 3), "frames_in_flight": a.inflight,
+            "max_abs_diff_vs_headline": {k: float((split3_out[k] - out[k]).abs().max()) for k in split3_out},
+            "note": ("--gemm x3: every fp32 operand = hi + mid + lo bf16 terms, six partial products per MAC on v_mfma_f32_32x32x16_bf16, fp32 "
+                     "accumulation (conv_wino_x3, conv_igemm_x3p); error against fp64 at or below the fp32-MFMA kernels' (tests/test_gpu_wino_x3.py, "
+                     "tests/test_gpu_x3p.py)" if other_x3 else
+                     "--gemm f32 (AV2X_X3=0): every product on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32), the round-1..3 headline mode")}
         for e in pipe.engines:
-            e.split3 = False
+            e.wino_x3 = e.x3p = not other_x3
     else:
         split3_out = None
 
@@ -622,7 +651,7 @@ def main(argv=None, hooks=None, device=None):
                                                        "is the 20-byte box-count record one lap later"}
 
     # ---------------- a scenario stream: the agent count changes from frame to frame ------------------------
-    if secondary and a.model == "where2com" and a.lidar_only and not a.amp and a.gemm == "f32":
+    if secondary and a.model == "where2com" and a.lidar_only and not a.amp and a.gemm in ("f32", "x3"):
         lens = [2, 3, 4, 5]
         dds = [build_inputs(k, a.points, dev, only=None, model=a.model, modalities=a.mods)[2] for k in lens]
         m2, e2, _ = make_model(a, args, dev)          # a fresh engine: nothing allocated, nothing tuned in this process
@@ -651,7 +680,7 @@ def main(argv=None, hooks=None, device=None):
         del m2, e2
 
     # ---------------- one TRAINING step of the same model (not the headline metric) ----------
-    if secondary and a.model == "where2com" and a.lidar_only and not a.amp and a.gemm == "f32" and not a.no_train:
+    if secondary and a.model == "where2com" and a.lidar_only and not a.amp and a.gemm in ("f32", "x3") and not a.no_train:
         from tools.train_bench import run as train_run
         tr = train_run(agents=a.agents, steps=10, warmup=3, dev=dev, dd=dd, args=args)
         res["train_step"] = {k: tr[k] for k in ("ms_per_step", "steps_per_s", "ms_forward", "ms_loss_backward", "ms_optimizer",
@@ -749,16 +778,16 @@ def main(argv=None, hooks=None, device=None):
                         "conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
                         f"conv_wino_f32<{(dom[0] & 0x3fff) // 32},{(dom[1] & 0x01ff) // 32}> (Winograd F(2x2,3x3), {dom[0] & 0x3fff} tiles x {dom[1] & 0x01ff} couts per workgroup)") if wino else
                        "conv_halo_bf16 (halo-tile direct convolution on bf16 activations: 8 x 16 output pixels x 128 couts per workgroup, 64-channel halo chunks in LDS)" if dom[0] & 0x1000 else
-                       f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
+                       f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('x3p (pipelined split-3: three bf16 terms per fp32 operand, LDS-DMA weights, two LDS stages)' if (dom[1] & 0x1400) == 0x1400 else 'bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (f"conv_wino_x3<{(dom[0] & 0x3fff) // 32}, false>" if (wino and x3dom) else ("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": (f"conv_wino_x3<{(dom[0] & 0x3fff) // 32}, false>" if (wino and x3dom) else ("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_x3p<{dom[1] & 0x01ff}>" if (dom[1] & 0x1400) == 0x1400 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),
             **({"matrix_pipe": {"seconds_at_peak_per_frame_ms": round(pipe_s / a.steps * 1e3, 4),
                                 "frac_of_frame_time": round(pipe_s / a.steps / (res["ms_per_step"] * 1e-3), 4),
                                 "note": "sum over all conv launches of executed FLOPs / the peak of the pipe they run on (fp32-input MFMA 157.3, bf16 MFMA 2500 TFLOP/s), "
-                                        "over ms_per_step: how busy the matrix cores are in a mode that mixes both pipes"}} if a.gemm == "wino_x3" else {}),
+                                        "over ms_per_step: how busy the matrix cores are in a mode that mixes both pipes"}} if a.gemm in ("wino_x3", "x3") else {}),
             "event_pair_overhead_us": round(ev_over * 1e6, 2),
             "sustained_clock": "fp32-MFMA loops run at 2.0 GHz on random operands (2.32 on zeros; GRBM_GUI_ACTIVE / duration, "
                                "profiles/r02_dvfs_clock.txt): peak at that clock = 131.5 TFLOP/s; frac is against the 2.4 GHz figure",
@@ -886,7 +915,7 @@ def main(argv=None, hooks=None, device=None):
         else:
             res["parity_max_abs_err_vs_oracle"] = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("psm", "rm", "obj")}
         if split3_out is not None:
-            res["fp32_split3"]["max_abs_err_vs_oracle"] = {k: float((split3_out[k].cpu() - ref[k]).abs().max()) for k in ("psm", "rm", "obj")}
+            res["x3" if a.gemm == "f32" else "fp32_mfma"]["max_abs_err_vs_oracle"] = {k: float((split3_out[k].cpu() - ref[k]).abs().max()) for k in ("psm", "rm", "obj")}
 
     if rank == 0:
         print(json.dumps(res), flush=True)

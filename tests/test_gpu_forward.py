@@ -246,12 +246,14 @@ def test_fully_connected_communication_matches_oracle():
     assert float((masked["psm"] - ref["psm"]).abs().max()) > 1e-3        # the mask does change the result on this frame
 
 
+@pytest.mark.parametrize("mode", ["x3", "f32"])
 @pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_full_n4"])
-def test_default_forward_does_not_depend_on_the_tuning_outcome(name, monkeypatch):
+def test_default_forward_does_not_depend_on_the_tuning_outcome(name, mode, monkeypatch):
     """The module default ("rule" stream-K + autotuned tiles) must give the same bits whatever the autotuner picks: every
     candidate of a numerics class is bit-identical and the stream-K schedule is a function of the layer shape.  Engine A
     tunes by wall-clock; engine B is forced to take the LAST candidate of every class, engine C the first; a third
-    forward goes through FramePipeline.  All equal bit for bit."""
+    forward goes through FramePipeline.  All equal bit for bit.  mode "f32": the fp32-input MFMA kernels (AV2X_X3=0), where nearly every
+    layer goes through the tuner; mode "x3" (the default): the split-3 kernels are picked by shape rules, the tuner only sees what is left."""
     from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
     from airv2x_perception_amd.opencood_iface.engine import FramePipeline, Where2ComEngine
     monkeypatch.setenv("AV2X_TUNE_CACHE", "0")
@@ -265,6 +267,9 @@ def test_default_forward_does_not_depend_on_the_tuning_outcome(name, monkeypatch
         model = model.to("cuda").eval()
         eng = model.engine()
         assert eng.stream_k == "rule"
+        assert eng.wino_x3 and eng.x3p, "x3 is the default product mode"
+        if mode == "f32":
+            eng.wino_x3 = eng.x3p = False
         if which != "timed":
             def forced(d, x, L, out, skc=False, key=None, _eng=eng, _w=which):
                 c = _eng._candidates(d, L, skc)
@@ -280,9 +285,10 @@ def test_default_forward_does_not_depend_on_the_tuning_outcome(name, monkeypatch
             po, ev = pipe.submit(dd)
             ev.synchronize()
             outs.append({k: po[k].clone() for k in ("psm", "rm", "obj")})
-    assert picks[1] != picks[2]                                        # the forced engines really ran different kernels
-    assert any(len(k) > 6 and k[6] == "rule" for k in picks[0]) or name == "w2c_small_n3"   # full grid: some layers take the stream-K rule
-    assert any(k[0] == "wino" for k in picks[0])       # ... and the Winograd layers went through the tuner as well (bit-identical tilings)
+    if mode == "f32":
+        assert picks[1] != picks[2]                                        # the forced engines really ran different kernels
+        assert any(len(k) > 6 and k[6] == "rule" for k in picks[0]) or name == "w2c_small_n3"   # full grid: some layers take the stream-K rule
+        assert any(k[0] == "wino" for k in picks[0])       # ... and the Winograd layers went through the tuner as well (bit-identical tilings)
     for o in outs[1:]:
         for k in ("psm", "rm", "obj"):
             assert torch.equal(o[k], outs[0][k]), k

@@ -80,9 +80,10 @@ def test_error_against_fp64_not_above_the_fp32_winograd_kernel_and_tilings_agree
     xn = x.permute(0, 2, 3, 1).contiguous().cuda()
     errs = {}
     outs = {}
+    scale_d, shift_d = scale.cuda(), shift.cuda()
     for name, tile, wgt in [("f32", F32H, u)] + [(k, t, u3) for k, t in X3.items()]:
         out = torch.full((n, h, w, cout), float("nan"), device="cuda")
-        _run(lib, xn, wgt, scale.cuda(), shift.cuda(), None, out, tile, relu, cin, cout, coutp)
+        _run(lib, xn, wgt, scale_d, shift_d, None, out, tile, relu, cin, cout, coutp)
         o = out.cpu()
         assert not torch.isnan(o).any(), name
         e = (o.double() - ref).abs()
@@ -109,9 +110,10 @@ def test_epilogues_and_residual(lib, act, with_res):
     u, u3, coutp = _pack(lib, wt)
     xn = x.permute(0, 2, 3, 1).contiguous().cuda()
     outs = []
+    bias_d, res_d = bias.cuda(), res.cuda()
     for tile in X3.values():
         out = torch.full((n, h, w, cout), float("nan"), device="cuda")
-        _run(lib, xn, u3, None, bias.cuda(), res.cuda() if with_res else None, out, tile, act, cin, cout, coutp)
+        _run(lib, xn, u3, None, bias_d, res_d if with_res else None, out, tile, act, cin, cout, coutp)
         assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1])
@@ -127,9 +129,10 @@ def test_channel_slices_and_argument_checks(lib):
     shift = torch.randn(cout, generator=g)
     u, u3, coutp = _pack(lib, wt)
     ref = F.relu(F.conv2d(xw[..., 32:].permute(0, 3, 1, 2).double(), wt.double(), shift.double(), padding=1)).permute(0, 2, 3, 1)
+    xw_d, shift_d = xw.cuda(), shift.cuda()
     for tile in X3.values():
         out = torch.full((n, h, w, cout + 64), 7.0, device="cuda")
-        _run(lib, xw.cuda(), u3, None, shift.cuda(), None, out, tile, 1, cin, cout, coutp, in_ctot=cin + 32, in_coff=32,
+        _run(lib, xw_d, u3, None, shift_d, None, out, tile, 1, cin, cout, coutp, in_ctot=cin + 32, in_coff=32,
              out_ctot=cout + 64, out_coff=64)
         o = out.cpu()
         assert torch.all(o[..., :64] == 7.0)
@@ -149,11 +152,11 @@ def test_rule_is_a_function_of_the_layer_and_map_only():
     from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
     mk = lambda cin, cout, ks=3, stride=1, pad=1, relu=1, mode=_lib.AV2X_CONV: ConvLayer(None, None, None, cin, cout, cout, ks, stride, pad, relu, mode)
     rule = Where2ComEngine.wino_x3_rule
-    assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(64, 64)) and rule(mk(384, 256))
-    assert not rule(mk(256, 96)) and not rule(mk(72, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
+    assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(384, 256)) and not rule(mk(64, 64))
+    assert not rule(mk(256, 96)) and not rule(mk(136, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
     tile = Where2ComEngine.wino_x3_tile
-    assert (tile(mk(256, 256), 100, 352) >> 16) & 0x3fff == 64 and (tile(mk(256, 256), 25, 88) >> 16) & 0x3fff == 32
-    assert (tile(mk(64, 64), 100, 352) >> 16) & 0x3fff == 32
+    # the engine only ever launches the 64 x 64 tile (whole register file: nothing co-resident; see wino_x3_tile)
+    assert (tile(mk(256, 256), 100, 352) >> 16) & 0x3fff == 64 and (tile(mk(256, 256), 25, 88) >> 16) & 0x3fff == 64
 
 
 def test_where2comm_goldens_in_wino_x3_mode_at_unchanged_tolerances():
