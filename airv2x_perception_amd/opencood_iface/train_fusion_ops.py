@@ -318,8 +318,12 @@ def _split_logits(gap, fc1_w, bn_w, bn_b, fc2_w):
     """SplitAttn's squeeze path on the (n, C) mean (split_attn.py:51-53): fc1 -> LayerNorm ("bn1") -> ReLU -> fc2.  A handful of
     C-vectors per agent: plain tensor algebra (differentiable for the backward below)."""
     import torch.nn.functional as TF
-    g = TF.relu(TF.layer_norm(TF.linear(gap, fc1_w), (gap.shape[-1],), bn_w, bn_b, LN_EPS))
-    return TF.linear(g, fc2_w)
+    # fp32 whatever autocast region the step runs in: the kernels on either side read / write fp32 (under torch.autocast F.linear would
+    # return bf16 -- half the bytes av2x_split_attn_combine then reads: a memory fault at the BASELINE grid, garbage weights below it)
+    with torch.autocast("cuda", enabled=False):
+        f32 = lambda t: t.float()
+        g = TF.relu(TF.layer_norm(TF.linear(f32(gap), f32(fc1_w)), (gap.shape[-1],), f32(bn_w), f32(bn_b), LN_EPS))
+        return TF.linear(g, f32(fc2_w))
 
 
 class SplitAttnFn(torch.autograd.Function):

@@ -132,9 +132,16 @@ class amp_scope:
     def __enter__(self):
         self.prev = AMP_STEP[0]
         AMP_STEP[0] = self.on
+        # torch.autocast itself is switched OFF inside: AMP here means "the step's Conv2d / Linear products take bf16 matrix-core
+        # operands" (AMP_STEP, read by the kernels' launchers); the few ATen ops of the step (folded HGT projections, the RTE embedding,
+        # SplitAttn's squeeze path) feed fp32 kernels and must stay fp32 -- under autocast they returned bf16 tensors that the kernels
+        # then read as fp32 (half the bytes: garbage weights, and a memory fault at the BASELINE grid)
+        self._noautocast = torch.autocast("cuda", enabled=False)
+        self._noautocast.__enter__()
         return self
 
     def __exit__(self, *exc):
+        self._noautocast.__exit__(*exc)
         AMP_STEP[0] = self.prev
         return False
 

@@ -172,7 +172,7 @@ def _case(fx, dropout=0.0):
     dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
     dd["spatial_correction_matrix"] = torch.from_numpy(fx["spatial_correction_matrix"])
     dd["prior_encoding"] = torch.from_numpy(fx["prior_encoding"])
-    H, W = fx["psm"].shape[-2:]
+    H, W = (int(v) for v in fx["head_hw"]) if "head_hw" in fx else fx["psm"].shape[-2:]    # full-grid fixtures store strided heads
     lc = synth.loss_case(int(fx["seed"]) + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=float(fx["pos_frac"]))
     tgt = {k: torch.from_numpy(lc[k]).cuda() for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
     return hy, args, sd, dd, tgt
@@ -190,7 +190,7 @@ def _loss(args):
     return PointPillarLossMultiClass({"cls_weight": 1.0, "reg": 2.0, "num_class": args["num_class"]})
 
 
-@pytest.mark.parametrize("name", ["train_v2xvit_small_n3", "train_v2xvit_small_n2"])
+@pytest.mark.parametrize("name", ["train_v2xvit_small_n3", "train_v2xvit_small_n2", "train_v2xvit_full_n4"])
 def test_v2xvit_training_step_matches_the_reference(name):
     fx = load_fixture(name)
     hy, args, sd, dd, tgt = _case(fx)
@@ -198,7 +198,8 @@ def test_v2xvit_training_step_matches_the_reference(name):
     out = model(dd)
     for k in ("psm", "rm", "obj"):
         assert out[k].requires_grad
-        assert_close(out[k].detach().cpu(), fx[k], 3e-4, 3e-4 * float(np.abs(fx[k]).max()), k)
+        hs = int(fx["head_stride"]) if "head_stride" in fx else 1
+        assert_close(out[k].detach().cpu()[..., ::hs, ::hs], fx[k], 3e-4, 3e-4 * float(np.abs(fx[k]).max()), k)
     total = _loss(args)(out, tgt)
     total.backward()
     torch.cuda.synchronize()

@@ -1452,7 +1452,7 @@ def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01,
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2, 2), pos_frac=0.01):
+def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2, 2), pos_frac=0.01, head_stride=1):
     """One TRAINING step of the reference's Airv2xCoBEVT (train mode: BatchNorm batch statistics, SwapFusionEncoder with drop_out 0 --
     a configuration edit: dropout masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch autograd:
     heads, losses, the gradient of every parameter (strided samples + sums), every buffer after the step, and the same step in
@@ -1516,8 +1516,10 @@ def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2,
     fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types), "n_points": np.int64(n_points),
           "pos_frac": np.float64(pos_frac), "max_cav": np.asarray(max_cav, np.int64),
           "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)}
+    fx["head_stride"] = np.int64(head_stride)
+    fx["head_hw"] = np.asarray([H, W], np.int64)
     for k in ("psm", "rm", "obj"):
-        fx[k] = out[k].detach().numpy()
+        fx[k] = out[k].detach().numpy()[..., ::head_stride, ::head_stride]   # full grid: strided samples (the test strides the device's maps the same way)
     o64, l64, sd64 = oracle_step(torch.float64)
     fx["loss64"] = np.float64(float(l64[0]))
     names, gworst, devs = [], 0.0, []
@@ -1571,7 +1573,7 @@ def _load_ref_hypes_v2xvit(lidar_range, max_cav):
     return hy_ref
 
 
-def train_v2xvit_golden(name, lidar_range, types, n_points, seed, max_cav=(2, 1, 1), pos_frac=0.01):
+def train_v2xvit_golden(name, lidar_range, types, n_points, seed, max_cav=(2, 1, 1), pos_frac=0.01, head_stride=1):
     """One TRAINING step of the reference's Airv2xV2XVit (train mode, every dropout probability set to 0 -- a configuration edit: dropout
     masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch autograd; as train_cobevt_golden."""
     from airv2x_perception_amd import synth
@@ -1631,8 +1633,10 @@ def train_v2xvit_golden(name, lidar_range, types, n_points, seed, max_cav=(2, 1,
           "n_points": np.int64(n_points), "pos_frac": np.float64(pos_frac), "max_cav": np.asarray(max_cav, np.int64),
           "spatial_correction_matrix": dd["spatial_correction_matrix"].numpy(), "prior_encoding": dd["prior_encoding"].numpy(),
           "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)}
+    fx["head_stride"] = np.int64(head_stride)
+    fx["head_hw"] = np.asarray([H, W], np.int64)
     for k in ("psm", "rm", "obj"):
-        fx[k] = out[k].detach().numpy()
+        fx[k] = out[k].detach().numpy()[..., ::head_stride, ::head_stride]   # full grid: strided samples (the test strides the device's maps the same way)
     o64, l64, sd64 = oracle_step(torch.float64)
     fx["loss64"] = np.float64(float(l64[0]))
     names, gworst, devs, zero = [], 0.0, [], []
@@ -1834,6 +1838,12 @@ GROUPS = {
                              train_cobevt_golden("train_cobevt_small_n2", SMALL, ["vehicle", "vehicle"], 900, 15)),
     "train_v2xvit": lambda: (train_v2xvit_golden("train_v2xvit_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 16),
                              train_v2xvit_golden("train_v2xvit_small_n2", SMALL, ["vehicle", "vehicle"], 900, 17)),
+    # the BASELINE grid (704 x 200, 4 agents x 8192 points): one training step of the reference's CoBEVT / V2X-ViT (tens of minutes of CPU:
+    # the reference's step, the oracle's fp32 step and the oracle's float64 step)
+    "train_cobevt_full": lambda: train_cobevt_golden("train_cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 18,
+                                                     max_cav=(3, 2, 2), pos_frac=0.002, head_stride=4),
+    "train_v2xvit_full": lambda: train_v2xvit_golden("train_v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 19,
+                                                     max_cav=(2, 1, 1), pos_frac=0.002, head_stride=4),
     "iou_pin": lambda: iou_pin_golden(),
     "voxel_pin": lambda: voxel_pin_golden(),
 }
@@ -1845,7 +1855,7 @@ def main(groups=None):
     import_reference()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    for g in (groups or [g for g in GROUPS if g not in ("full", "train_full", "camera_full")]):
+    for g in (groups or [g for g in GROUPS if g not in ("full", "train_full", "camera_full", "train_cobevt_full", "train_v2xvit_full")]):
         if g not in GROUPS:
             raise SystemExit(f"unknown group {g!r}; one of {sorted(GROUPS)}")
         GROUPS[g]()

@@ -1,4 +1,4 @@
-"""One training step of Airv2xWhere2com on the default AirV2X grid (704 x 200 canvas, N agents x 8192 points), on the device:
+"""One training step of Airv2xWhere2com / Airv2xCoBEVT / Airv2xV2XVit (--model) on the default AirV2X grid (704 x 200 canvas, N agents x 8192 points), on the device:
 train-mode forward (BatchNorm batch statistics, random top-K mask), PointPillarLossMultiClass, backward, Adam step.
 Prints one JSON line: ms per step (forward / loss+backward / optimiser), peak memory, and -- with --cpu -- the oracle's
 (torch CPU autograd) time for the same step.  Not the headline metric (BASELINE.json's is inference frames/s)."""
@@ -14,20 +14,24 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None, args=None):
+def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None, args=None, model_name="where2com", amp=False):
     """-> dict (see the module docstring).  ``dd`` / ``args``: a frame already on the device and its model args (bench.py
     passes the one its device voxelizer built); otherwise the frame is built here with the oracle's CPU voxelizer."""
     from types import SimpleNamespace
     a = SimpleNamespace(agents=agents, steps=steps, warmup=warmup, small=small, cpu=cpu)
+    import numpy as np
+    from airv2x_perception_amd import opencood_iface as oi
     from airv2x_perception_amd import synth
-    from airv2x_perception_amd.opencood_iface.airv2x_where2com import Airv2xWhere2com
     from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
+    Model, hypes_fn, spec_fn = {"where2com": (oi.Airv2xWhere2com, synth.default_hypes, synth.where2com_param_spec),
+                                "cobevt": (oi.Airv2xCoBEVT, synth.default_hypes_cobevt, synth.cobevt_param_spec),
+                                "v2xvit": (oi.Airv2xV2XVit, synth.default_hypes_v2xvit, synth.v2xvit_param_spec)}[model_name]
     dev = dev or torch.device("cuda", 0)
     dd_host = None
     if dd is None:
         from oracle import voxelize_oracle as vox
         rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0] if a.small else None
-        hy = synth.default_hypes(rng)
+        hy = hypes_fn(rng)
         args = hy["model"]["args"]
         rng = rng or synth.DEFAULT_RANGE
         types = synth.sort_types(synth.agent_types_for(a.agents))[1]
@@ -36,9 +40,15 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
                                      pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
                                      pp["args"]["max_voxel_train"]) for i in range(a.agents)]
         dd_host = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+        if model_name == "v2xvit":    # seeded SE(2) correction per non-ego agent + the frame's prior encoding (bench.py build_inputs)
+            g_ = np.random.default_rng(99)
+            scm = torch.eye(4, dtype=torch.float64).repeat(1, args["max_cav_num"], 1, 1)
+            for i in range(1, a.agents):
+                scm[0, i] = torch.from_numpy(synth.se2_correction(g_.uniform(-10, 10), g_.uniform(-8, 8), g_.uniform(-8, 8)))
+            dd_host["spatial_correction_matrix"] = scm
         dd = synth.data_dict_to(dd_host, dev)
-    sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=0)
-    model = Airv2xWhere2com(args)
+    sd = synth.synthetic_state_dict(spec_fn(args), seed=0)
+    model = Model(args)
     model.load_state_dict(sd)
     model = model.to(dev).train()
     model.sync_comm_rate = False
@@ -50,6 +60,8 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
     crit = PointPillarLossMultiClass({"cls_weight": 1.0, "reg": 2.0, "num_class": args["num_class"]})
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     random.seed(0)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0) if amp else None
+    torch.cuda.reset_peak_memory_stats()
     ev = lambda: torch.cuda.Event(enable_timing=True)
     t_f = t_b = t_o = 0.0
     losses = []
@@ -57,12 +69,22 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
         e0, e1, e2, e3 = ev(), ev(), ev(), ev()
         opt.zero_grad(set_to_none=True)
         e0.record()
-        out = model(dd)
-        e1.record()
-        loss = crit(out, tgt)
-        loss.backward()
-        e2.record()
-        opt.step()
+        if amp:     # tools/train.py:50,107-130 of the reference: forward + loss under autocast, GradScaler around backward / step
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(dd)
+                e1.record()
+                loss = crit(out, tgt)
+            scaler.scale(loss).backward()
+            e2.record()
+            scaler.step(opt)
+            scaler.update()
+        else:
+            out = model(dd)
+            e1.record()
+            loss = crit(out, tgt)
+            loss.backward()
+            e2.record()
+            opt.step()
         e3.record()
         torch.cuda.synchronize()
         losses.append(float(loss.detach()))
@@ -71,11 +93,11 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
             t_b += e1.elapsed_time(e2)
             t_o += e2.elapsed_time(e3)
     k = a.steps
-    res = {"what": "Airv2xWhere2com training step (train-mode forward + PointPillarLossMultiClass + backward + Adam)",
+    res = {"what": f"{Model.__name__} training step (train-mode forward + PointPillarLossMultiClass + backward + Adam)" + (" under autocast(bf16) + GradScaler" if amp else ""),
            "agents": a.agents, "grid": [g[0], g[1]], "steps": k, "ms_per_step": round((t_f + t_b + t_o) / k, 3),
            "ms_forward": round(t_f / k, 3), "ms_loss_backward": round(t_b / k, 3), "ms_optimizer": round(t_o / k, 3),
            "steps_per_s": round(1e3 * k / (t_f + t_b + t_o), 3), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)], "dtype": "f32", "data": "synthetic"}
+           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)], "dtype": "bf16 operands (autocast), fp32 master weights" if amp else "f32", "data": "synthetic"}
     # ---- roofline of the step's MFMA kernels: a second pass with an event pair around every convolution launch (forward and data
     # gradients go through the engine's launcher: its profile hook; weight gradients: train_ops' hook), weight gradients on the
     # main stream so that the pairs do not overlap
@@ -87,11 +109,16 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
     psteps = max(2, min(4, a.steps))
     for _ in range(psteps):
         opt.zero_grad(set_to_none=True)
-        crit(model(dd), tgt).backward()
+        if amp:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                l_ = crit(model(dd), tgt)
+            scaler.scale(l_).backward()
+        else:
+            crit(model(dd), tgt).backward()
     torch.cuda.synchronize()
     prof, wprof = r.profile, r.wgrad_profile
     r.profile, r.wgrad_profile, T.OVERLAP_WGRAD = None, None, overlap
-    PEAK = 157.3
+    PEAK = 2500.0 if amp else 157.3
     groups = {"conv_wino_f32 (forward + data gradients)": [0, 0.0, 0.0, 0.0], "conv_igemm_f32 (forward + data gradients, 1x1 / stride 2 / deconv)": [0, 0.0, 0.0, 0.0],
               "conv_wgrad (weight gradients)": [0, 0.0, 0.0, 0.0]}
     for tile, flops, e0, e1, wgs, shp in prof:
@@ -105,8 +132,18 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
     dom = max(groups, key=lambda kk: groups[kk][3])
     cnt, fl, exe, sec = groups[dom]
     tot_exe, tot_s = sum(v[2] for v in groups.values()), sum(v[3] for v in groups.values())
+    # HBM-side bytes per launch of the dominant group from the committed PMC pass of this very command (tools/pmc_train_r04.sh: counters-only
+    # FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE per the guide's gfx950 correction, averaged over the group's launches)
+    traffic, traffic_note = None, "no PMC pass committed for this command (tools/pmc_train_r04.sh)"
+    pmc_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r04_pmc_train_{model_name}{'_amp' if amp else ''}.json")
+    if os.path.exists(pmc_path):
+        pm = json.load(open(pmc_path))
+        gkey = "wino" if "wino" in dom else ("wgrad" if "wgrad" in dom else "igemm")
+        if gkey in pm.get("per_group", {}):
+            traffic = round(pm["per_group"][gkey]["bytes_per_launch"])
+            traffic_note = f"profiles/{os.path.basename(pmc_path)}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, mean over {pm['per_group'][gkey]['launches']} launches of the group"
     res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(exe / sec / 1e12, 2), "peak": PEAK, "unit": "TFLOP/s",
-                       "frac": round(exe / sec / 1e12 / PEAK, 4), "effective_tflops": round(fl / sec / 1e12, 2), "traffic": None,
+                       "frac": round(exe / sec / 1e12 / PEAK, 4), "effective_tflops": round(fl / sec / 1e12, 2), "traffic": traffic, "traffic_note": traffic_note,
                        "launches_per_step": cnt / psteps, "avg_launch_us": round(sec / cnt * 1e6, 2),
                        "per_group": {kk: {"launches_per_step": v[0] / psteps, "ms_per_step": round(v[3] / psteps * 1e3, 3),
                                           "executed_tflops": round(v[2] / v[3] / 1e12, 2), "frac": round(v[2] / v[3] / 1e12 / PEAK, 4)}
@@ -140,8 +177,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu", action="store_true", help="also time one oracle step on the host cores")
     ap.add_argument("--small", action="store_true", help="128 x 64 canvas (smoke)")
+    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit"], default="where2com")
+    ap.add_argument("--amp", action="store_true", help="autocast(bf16) + GradScaler around the step (tools/train.py --amp of the reference)")
     a = ap.parse_args()
-    print(json.dumps(run(a.agents, a.steps, a.warmup, a.small, a.cpu)))
+    print(json.dumps(run(a.agents, a.steps, a.warmup, a.small, a.cpu and a.model == "where2com", model_name=a.model, amp=a.amp)))
 
 
 if __name__ == "__main__":
