@@ -175,6 +175,7 @@ SIGNATURES = {
                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_comm_rate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_count_nonzero": (c_int32, [c_void_p, c_uint64, c_void_p, c_void_p]),
+    "av2x_bf16_to_f32": (c_int32, [c_void_p, c_void_p, c_uint64, c_void_p]),
     "av2x_prepare_points_workspace_bytes": (c_uint64, [c_int32]),
     "av2x_prepare_points": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),

@@ -1159,3 +1159,39 @@ extern "C" int av2x_layernorm_bf16(const float* x, const float* gamma, const flo
     if (n_tokens && !y) return av2x::fail("av2x_layernorm_bf16: null argument");
     return av2x_add_layernorm_bf16(const_cast<float*>(x), nullptr, gamma, beta, y, n_tokens, c, eps, stream);
 }
+
+// ---- bf16 -> fp32 widening (exact): the feature-sharing message of the autocast frame is the shrink header's bf16 output (what
+// torch.autocast stores for that Conv2d; 18.0 MB per agent at the default grid); the fusion's residual stream is fp32.
+// HBM-bound: 16-byte loads of 8 values, two 16-byte stores.
+namespace {
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const uint4* __restrict__ src, float4* __restrict__ dst, size_t n8,
+                                                         const uint16_t* __restrict__ tail_src, float* __restrict__ tail_dst, int ntail) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const uint4 v = src[i];
+        float4 a, b;
+        a.x = __builtin_bit_cast(float, v.x << 16); a.y = __builtin_bit_cast(float, v.x & 0xffff0000u);
+        a.z = __builtin_bit_cast(float, v.y << 16); a.w = __builtin_bit_cast(float, v.y & 0xffff0000u);
+        b.x = __builtin_bit_cast(float, v.z << 16); b.y = __builtin_bit_cast(float, v.z & 0xffff0000u);
+        b.z = __builtin_bit_cast(float, v.w << 16); b.w = __builtin_bit_cast(float, v.w & 0xffff0000u);
+        dst[2 * i] = a;
+        dst[2 * i + 1] = b;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
+        tail_dst[threadIdx.x] = __builtin_bit_cast(float, (unsigned)tail_src[threadIdx.x] << 16);
+}
+}  // namespace
+
+extern "C" int av2x_bf16_to_f32(const uint16_t* src, float* dst, uint64_t n_elems, av2x_stream_t stream) {
+    if (n_elems == 0) return 0;
+    if (!src || !dst) return av2x::fail("av2x_bf16_to_f32: null argument");
+    if (reinterpret_cast<uintptr_t>(src) % 16 || reinterpret_cast<uintptr_t>(dst) % 16)
+        return av2x::fail("av2x_bf16_to_f32: pointers must be 16-byte aligned");
+    const size_t n8 = n_elems / 8;
+    const int ntail = (int)(n_elems - n8 * 8);
+    const size_t want = (n8 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : want > 256 * 16 ? 256 * 16 : want);
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3(blocks), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<float4*>(dst), n8, src + n8 * 8, dst + n8 * 8, ntail);
+    return av2x::check_launch("widen_bf16_kernel");
+}

@@ -65,7 +65,7 @@ class CoBEVTEngine(Where2ComEngine):
     def run_compressor(self, x, n, H, W):
         """x (n,H,W,C) -> encoder -> decoder, result written back into x."""
         enc, dec0, dec1 = self.compressor
-        msg = self.buf("compress_msg", (n, H, W, enc.cout))
+        msg = self.buf("compress_msg", (n, H, W, enc.cout), self.msg_dtype())     # autocast: the bf16 message the sharded frame sends
         self.conv(enc, x, n, H, W, msg)
         mid = self.buf("compress_mid", (n, H, W, dec0.cout))
         self.conv(dec0, msg, n, H, W, mid)
@@ -172,7 +172,7 @@ class CoBEVTEngine(Where2ComEngine):
         H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
         C = self.fax["input_dim"]
         cm = self.compressor[0].cout if self.compression else C
-        send = self.buf("shard_send", (n_pad * H * W * cm,))
+        send = self.buf("shard_send", (n_pad * H * W * cm,), self.msg_dtype())     # autocast: bf16, 18.0 MB per agent (uncompressed)
         stats = torch.zeros(2, dtype=torch.int64, device=self.device)
         if n == 0:
             return send, stats, {"n_loc": n_pad, "H": H, "W": W, "cm": cm}
@@ -196,6 +196,8 @@ class CoBEVTEngine(Where2ComEngine):
             mid = self.buf("compress_mid", (N, H, W, C))
             self.conv(self.compressor[1], msg, N, H, W, mid)
             self.conv(self.compressor[2], mid, N, H, W, x[:N])
+        elif msg.dtype == torch.bfloat16:
+            self.widen(msg, x[:N])
         else:
             x[:N].copy_(msg)
         fused = self.fax_encoder(x, N, H, W, trace)
@@ -217,7 +219,7 @@ class CoBEVTEngine(Where2ComEngine):
         msg = recv.view(world * n_loc, H, W, cm)
         if N != world * n_loc:
             from .sharded import valid_slots
-            cmp = self.buf("shard_compact", (N, H, W, cm))
+            cmp = self.buf("shard_compact", (N, H, W, cm), recv.dtype)
             for a, slot in enumerate(valid_slots(counts, n_loc)):
                 cmp[a].copy_(msg[slot])
             msg = cmp
@@ -244,7 +246,12 @@ class CoBEVTEngine(Where2ComEngine):
             ci = torch.tensor(cols, dtype=torch.int64, device=self.device)
             self.ws[key] = ci
         xc = self.buf("fax_xc", (self.L, H, Wc, C))
-        torch.index_select(msg, 2, ci, out=xc[:N])                      # column gather (data movement only)
+        if msg.dtype == torch.bfloat16:                                  # the uncompressed autocast message: gather, then widen
+            xc16 = self.buf("fax_xc16", (N, H, Wc, C), torch.bfloat16)
+            torch.index_select(msg, 2, ci, out=xc16)
+            self.widen(xc16, xc[:N])
+        else:
+            torch.index_select(msg, 2, ci, out=xc[:N])                  # column gather (data movement only)
         if N < self.L:
             _lib.check(self.lib.av2x_fill_zero(_ptr(xc[N:]), (self.L - N) * H * Wc * C * 4, self.stream()), "av2x_fill_zero")
         fused = self.fax_encoder(xc, N, H, Wc)
@@ -291,7 +298,13 @@ class CoBEVTEngine(Where2ComEngine):
             n = record_len[0]
             if n < self.L:
                 _lib.check(self.lib.av2x_fill_zero(_ptr(x[n:]), (self.L - n) * H * W * C * 4, self.stream()), "av2x_fill_zero")
-            _, s, H2, W2 = self.trunk(canvas, n, ny, nx, shrink_out=x[:n])
+            m16 = self.msg_dtype() == torch.bfloat16 and not self.compression
+            if m16:   # autocast: the shrink header's output is the bf16 message (with compression: the encoder's, in run_compressor)
+                x16 = self.buf("fax_x16", (n, H, W, C), torch.bfloat16)
+                _, s, H2, W2 = self.trunk(canvas, n, ny, nx, shrink_out=x16)
+                self.widen(x16, x[:n])
+            else:
+                _, s, H2, W2 = self.trunk(canvas, n, ny, nx, shrink_out=x[:n])
             assert (H2, W2) == (H, W)
             if self.compression:
                 self.run_compressor(x[:n], n, H, W)
@@ -304,7 +317,12 @@ class CoBEVTEngine(Where2ComEngine):
         # B > 1 (the reference's collate layout): the trunk runs on all agents at once, the fusion per sample
         # (regroup pads every sample to L agents, SwapFusionEncoder never mixes samples)
         s_all = self.buf("shrink_batch", (n_total, H, W, C))
-        self.trunk(canvas, n_total, ny, nx, shrink_out=s_all)
+        if self.msg_dtype() == torch.bfloat16 and not self.compression:
+            s16 = self.buf("shrink_batch16", (n_total, H, W, C), torch.bfloat16)
+            self.trunk(canvas, n_total, ny, nx, shrink_out=s16)
+            self.widen(s16, s_all)
+        else:
+            self.trunk(canvas, n_total, ny, nx, shrink_out=s_all)
         if self.compression:
             self.run_compressor(s_all, n_total, H, W)
         fused_all = self.buf("fused_batch", (B, H, W, C))

@@ -842,6 +842,20 @@ class Where2ComEngine:
     def trunk_dtype(self):
         return torch.bfloat16 if (self.amp and self.act16_trunk) else torch.float32
 
+    # The feature-sharing message of the autocast frame (CoBEVT / V2X-ViT: the shrink header's -- or the compressor encoder's -- output) is
+    # bf16: what torch.autocast stores for that Conv2d in the reference, and half the bytes per xGMI link (18.0 MB per agent at the default
+    # grid).  The single-process autocast frame rounds the same tensor the same way, so the sharded frame keeps its bits.
+    bf16_message = True
+
+    def msg_dtype(self):
+        return torch.bfloat16 if (self.amp and self.bf16_message) else torch.float32
+
+    def widen(self, src16, dst32):
+        """dst32 = float(src16): bf16 message -> the fusion's fp32 stream (exact)."""
+        assert src16.dtype == torch.bfloat16 and dst32.dtype == torch.float32 and src16.numel() == dst32.numel()
+        _lib.check(self.lib.av2x_bf16_to_f32(_ptr(src16), _ptr(dst32), src16.numel(), self.stream()), "av2x_bf16_to_f32")
+        return dst32
+
     def run_block(self, i, x, n, h, w, tag, out=None):
         """backbone.blocks[i] on n images; returns (buffer, ho, wo).  ``out``: write the block's
         result into this (n,ho,wo,c) buffer (e.g. a slice of the all-gather send buffer)."""

@@ -494,7 +494,7 @@ class V2XViTEngine(Where2ComEngine):
             ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
         H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
-        send = self.buf("shard_send", (n_pad * H * Wd * 256,))
+        send = self.buf("shard_send", (n_pad * H * Wd * 256,), self.msg_dtype())     # autocast: the bf16 message, 18.0 MB per agent
         meta = {"n_loc": n_pad, "H": H, "W": Wd,
                 "prior": data_dict_local["prior_encoding"][0].detach().cpu().numpy(),
                 "scm": data_dict_local["spatial_correction_matrix"][0].detach().cpu().numpy()}
@@ -519,6 +519,15 @@ class V2XViTEngine(Where2ComEngine):
         if N > self.L:
             raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
         maps = recv.view(world * n_loc, H, Wd, 256)
+        if maps.dtype == torch.bfloat16:        # autocast message: widened into the fp32 stream (and compacted on the way)
+            from .sharded import valid_slots
+            wide = self.buf("shard_maps32", (N, H, Wd, 256))
+            if N == world * n_loc:
+                self.widen(maps, wide)
+            else:
+                for a, slot in enumerate(valid_slots(counts, n_loc)):
+                    self.widen(maps[slot], wide[a])
+            return wide, N, H, Wd
         if N != world * n_loc:
             from .sharded import valid_slots
             cmp = self.buf("shard_compact", (N, H, Wd, 256))
@@ -597,7 +606,12 @@ class V2XViTEngine(Where2ComEngine):
         dims = self.level_dims(ny, nx)
         H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
         x = self.buf("vit_x", (n_total, H, Wd, 256))
-        self.trunk(canvas, n_total, ny, nx, shrink_out=x)                        # all agents of the batch at once
+        if self.msg_dtype() == torch.bfloat16:   # the shrink header's output is the (bf16) message: same rounding as the sharded frame
+            x16 = self.buf("vit_x16", (n_total, H, Wd, 256), torch.bfloat16)
+            self.trunk(canvas, n_total, ny, nx, shrink_out=x16)
+            self.widen(x16, x)
+        else:
+            self.trunk(canvas, n_total, ny, nx, shrink_out=x)                    # all agents of the batch at once
         fused_all = self.buf("vit_fused", (B, H, Wd, 256))
         off = 0
         for b, n in enumerate(record_len):                                       # the fusion never mixes samples

@@ -331,9 +331,16 @@ def dry_run(a):
         per_agent = 4 * 256 * H * W
         what = "shrink-header map (256x100x352 fp32)"
     msg = n_pad * per_agent
+    # autocast (--amp) frame of CoBEVT / V2X-ViT: the message is the bf16 shrink-header output (engine.msg_dtype), half the bytes per link;
+    # Where2Comm's masked maps stay fp32 (its autocast frame keeps fp32 activations)
+    msg16 = msg // 2 if a.model in ("cobevt", "v2xvit") else None
     out = {"dry_run": True, "model": a.model, "world": world, "agents": n, "agents_per_rank": counts, "n_pad": n_pad,
            "idle_ranks": [r for r, c in enumerate(counts) if c == 0], "types": synth.sort_types(synth.agent_types_for(n))[1],
            "ego": "rank 0, local agent 0", "message": what, "bytes_per_agent": per_agent, "bytes_per_rank_message": msg,
+           "autocast_message": None if msg16 is None else {
+               "dtype": "bf16", "bytes_per_agent": per_agent // 2, "bytes_per_rank_message": msg16,
+               "bytes_per_link_per_frame": msg16 if world > 1 else 0,
+               "lower_bound_us": round(msg16 / (XGMI_LINK_GBPS * 1e3), 1) if world > 1 else 0.0},
            "all_gather": {"recv_bytes_per_rank": world * msg, "bytes_per_link_per_frame": msg if world > 1 else 0,
                           "padding_bytes_per_rank": (world * n_pad - n) * per_agent,
                           "links_used_per_gpu": max(0, world - 1),

@@ -680,6 +680,11 @@ int av2x_split_attn_combine(const float* s0, const float* s1, const float* s2, c
  * av2x_hgt_attention_bf16 / av2x_window_attention_bf16: proj / qkv and out are bf16; mask, pos_embedding fp32.
  * av2x_split_attn_gap_bf16 / _combine_bf16: the three branch maps are bf16; gap, logits, residual and out fp32.
  * ------------------------------------------------------------------------------------ */
+/* dst[i] = (float)src[i] (exact widening) -- the bf16 feature-sharing message of the autocast frame (the shrink header's / compressor's
+ * bf16 output: what torch.autocast stores for that Conv2d, 18.0 MB per agent at the default grid; replaces the in-process tensor hand-over
+ * of airv2x_base_model.py:250-283 + fuse_utils.py:13-63 at half the bytes per xGMI link) back to the fp32 residual stream of the fusion.
+ * Pointers 16-byte aligned. */
+int av2x_bf16_to_f32(const uint16_t* src, float* dst, uint64_t n_elems, av2x_stream_t stream);
 int av2x_layernorm_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y, int64_t n_tokens, int32_t c,
                         float eps, av2x_stream_t stream);
 /* x += delta (bf16: the output of the preceding Linear -- `x + fn(x)` of PreNormResidual, base_transformer.py:12, under autocast adds

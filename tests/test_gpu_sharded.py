@@ -38,10 +38,12 @@ def test_two_emulated_ranks_equal_single_gpu_forward():
     assert torch.equal(one["psm"], ref["psm"]) and one["comm_rate"] == ref["comm_rate"]
 
 
-@pytest.mark.parametrize("name", ["cobevt_small_n2_c4", "cobevt_small_n3"])
-def test_cobevt_emulated_ranks_equal_single_gpu_forward(name):
+@pytest.mark.parametrize("name,amp", [("cobevt_small_n2_c4", False), ("cobevt_small_n3", False), ("cobevt_small_n2_c4", True),
+                                      ("cobevt_small_n3", True)])
+def test_cobevt_emulated_ranks_equal_single_gpu_forward(name, amp):
     """CoBEVT: rank r runs the trunk (and, with compression, the NaiveCompressor encoder) of its agents; the
-    gathered messages are decoded / regrouped and fused on the ego side.  n3 is emulated as 3 ranks x 1 agent."""
+    gathered messages are decoded / regrouped and fused on the ego side.  n3 is emulated as 3 ranks x 1 agent.
+    amp: the autocast frame -- the message is bf16 (half the bytes per link) and the sharded frame still has the single frame's bits."""
     import tests.test_cobevt as tc
     from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT
     from airv2x_perception_amd.opencood_iface.sharded import partition_agents
@@ -57,6 +59,7 @@ def test_cobevt_emulated_ranks_equal_single_gpu_forward(name):
     model = model.to("cuda").eval()
     eng = model.engine()
     eng.stream_k = False
+    eng.amp = amp
     ref = {k: v.clone() for k, v in eng.forward(dd).items()}
     world = len(types)
     sends, meta = [], None
@@ -66,10 +69,14 @@ def test_cobevt_emulated_ranks_equal_single_gpu_forward(name):
         sends.append(send.clone())
     if int(fx["compression"]) if "compression" in fx else 0:
         assert sends[0].numel() * 4 == meta["H"] * meta["W"] * 256   # the message is 4x smaller than the feature map
+    assert sends[0].dtype == (torch.bfloat16 if amp else torch.float32)       # autocast: 2 bytes per element on the link
     out = eng.shard_ego_stage(torch.cat(sends), st, meta, world=world)
     for k in ("psm", "rm", "obj"):
         assert torch.equal(out[k], ref[k]), k
-        tc.assert_close(out[k].cpu(), fx[k], 3e-4, 3e-4, k)
+        if not amp:
+            tc.assert_close(out[k].cpu(), fx[k], 3e-4, 3e-4, k)
+        else:   # the autocast drift bound of tests/test_amp.py
+            assert float((out[k].cpu() - torch.from_numpy(fx[k])).abs().max()) <= 6e-2 * float(abs(fx[k]).max()), k
     # second level: every rank fuses only its residue-group columns of the map (no exchange between the window and the
     # grid halves), the head outputs are gathered.  64 columns = 4 groups: 2 + 2 (+ an all-padding third rank for n3)
     recv = torch.cat(sends)
@@ -109,6 +116,7 @@ def test_v2xvit_emulated_ranks_equal_single_gpu_forward(name, amp):
         for k in ("prior_encoding", "spatial_correction_matrix"):   # frame-level metadata of all agents
             dd_local[k] = dd[k]
         send, st, meta = eng.shard_local_stage(dd_local, has_ego=(r == 0))
+        assert send.dtype == (torch.bfloat16 if amp else torch.float32)       # autocast: the 18.0 MB-per-agent message of SURVEY 8e
         sends.append(send.clone())
         stats = st.clone() if stats is None else stats + st
     out = eng.shard_ego_stage(torch.cat(sends), stats, meta, world=world, sync_comm_rate=True)

@@ -258,8 +258,10 @@ class V2XViTOracleBackend:
     """V2X-ViT: the message is the shrink-header map; second level = column strips of the encoder blocks with ONE
     all-reduce per block (the split-attention mean over the map), then a gather of the head outputs."""
 
-    def __init__(self, sd, args, two_level=False):
-        self.sd, self.args, self.two_level = sd, args, two_level
+    def __init__(self, sd, args, two_level=False, msg_dtype=torch.float32):
+        # msg_dtype bfloat16: the autocast frame's message (engine.msg_dtype on the GPU side): rounded once by the sender, widened exactly
+        # by the receiver -- 2 bytes per element through the all-gather
+        self.sd, self.args, self.two_level, self.msg_dtype = sd, args, two_level, msg_dtype
 
     def local_stage(self, dd_local, has_ego, n_pad=None):
         sd, args = self.sd, self.args
@@ -270,17 +272,18 @@ class V2XViTOracleBackend:
         shape = (n_pad, mf["shrink_header"]["dim"][-1], int(g[1]) // 2, int(g[0]) // 2)
         meta = {"shape": shape, "prior": dd_local["prior_encoding"], "scm": dd_local["spatial_correction_matrix"]}
         if n == 0:
-            return torch.full((int(np.prod(shape)),), float("nan")), torch.zeros(2, dtype=torch.int64), meta
+            return torch.full((int(np.prod(shape)),), float("nan"), dtype=self.msg_dtype), torch.zeros(2, dtype=torch.int64), meta
         feats, _ = orc.extract_features(dd_local, sd, args)
         sf2d, _ = orc.backbone_forward(feats, sd, mf["base_bev_backbone"])
         s = orc.shrink_conv(sf2d, sd, mf["shrink_header"])
         s = torch.cat([s, s.new_full((n_pad - n,) + tuple(s.shape[1:]), float("nan"))], 0)
-        return s.reshape(-1), torch.tensor([0, int(feats.count_nonzero())], dtype=torch.int64), meta
+        return s.reshape(-1).to(self.msg_dtype), torch.tensor([0, int(feats.count_nonzero())], dtype=torch.int64), meta
 
     def _tokens(self, recv, meta, world):
         from oracle import cobevt_oracle as cob
         n_loc, c, h, w = meta["shape"]
-        s = _real_agents(recv, meta, world)
+        assert recv.dtype == self.msg_dtype
+        s = _real_agents(recv, meta, world).float()
         x, mask = cob.regroup(s, torch.tensor([s.shape[0]]), self.args["max_cav_num"])
         prior = meta["prior"].unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, h, w)
         return torch.cat([x, prior], dim=2).permute(0, 1, 3, 4, 2).contiguous(), mask
@@ -335,7 +338,7 @@ def _v2xvit_frame():
     return args, sd, voxd, dd
 
 
-def _v2xvit_worker(rank, world, port, result_path, two_level):
+def _v2xvit_worker(rank, world, port, result_path, two_level, msg_dtype=torch.float32):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -346,7 +349,7 @@ def _v2xvit_worker(rank, world, port, result_path, two_level):
     for k in ("prior_encoding", "spatial_correction_matrix"):      # frame-level metadata of all agents
         dd_local[k] = dd[k]
     with torch.no_grad():
-        out = ShardedFrame(V2XViTOracleBackend(sd, args, two_level)).forward(dd_local)
+        out = ShardedFrame(V2XViTOracleBackend(sd, args, two_level, msg_dtype)).forward(dd_local)
     if rank == 0:
         torch.save(out, result_path)
     dist.destroy_process_group()
@@ -364,6 +367,26 @@ def test_v2xvit_agent_sharded_frame_equals_single_process(tmp_path, two_level):
     for k in ("psm", "rm", "obj"):
         assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), k
     assert got["comm_rate"] == ref["comm_rate"]
+
+
+@pytest.mark.parametrize("two_level", [False, True])
+def test_v2xvit_bf16_message_sharded_frame_equals_single_process(tmp_path, two_level):
+    """The autocast frame's message is bf16 (18.0 MB per agent at the default grid instead of 36.0): two ranks exchanging bf16 over the
+    all-gather give the bits of ONE process that rounds the shrink-header output the same way (world 1, same backend)."""
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_v2xvit_worker, args=(2, _free_port(), path, two_level, torch.bfloat16), nprocs=2, join=True)
+    got = torch.load(path)
+    args, sd, voxd, dd = _v2xvit_frame()
+    with torch.no_grad():
+        one = ShardedFrame(V2XViTOracleBackend(sd, args, False, torch.bfloat16)).forward(dd)
+        exact = ShardedFrame(V2XViTOracleBackend(sd, args, False)).forward(dd)
+    for k in ("psm", "rm", "obj"):
+        assert torch.allclose(got[k], one[k], rtol=1e-4, atol=1e-4), k          # strips: summation order of the split-attention mean
+        if not two_level:
+            assert torch.equal(got[k], one[k]), k
+        assert not torch.equal(one[k], exact[k])                                  # the rounding is real ...
+        assert float((one[k] - exact[k]).abs().max()) <= 2e-2 * float(exact[k].abs().max())   # ... and small
+    assert got["comm_rate"] == one["comm_rate"]
 
 
 def _cobevt_frame(compression):

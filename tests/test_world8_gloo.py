@@ -208,6 +208,10 @@ def test_bench_dry_run_describes_the_8_rank_layout(model, agents, capsys):
     per = {"where2com": 15769600, "cobevt": 36044800, "v2xvit": 36044800}[model]
     assert r["bytes_per_agent"] == per and r["all_gather"]["bytes_per_link_per_frame"] == per
     assert r["all_gather"]["recv_bytes_per_rank"] == 8 * per and r["all_gather"]["padding_bytes_per_rank"] == (8 - n) * per
+    if model == "where2com":
+        assert r["autocast_message"] is None
+    else:   # the 18.0 MB bf16 message SURVEY 8e quotes for the autocast frame
+        assert r["autocast_message"]["bytes_per_agent"] == 18022400 and r["autocast_message"]["bytes_per_link_per_frame"] == 18022400
     if model == "cobevt":
         assert r["second_level"]["groups"] == 22 and r["second_level"]["valid_columns_per_strip"] == [12] * 7 + [4]
         assert r["second_level"]["padded_groups"] == 2
