@@ -116,6 +116,8 @@ SIGNATURES = {
     "av2x_wino_pack_weights": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_wino_x3_weight_bytes": (c_uint64, [c_int32, c_int32]),
     "av2x_wino_x3_pack_weights": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_wino4_x3_weight_bytes": (c_uint64, [c_int32, c_int32]),
+    "av2x_wino4_x3_pack_weights": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_wino4_weight_bytes": (c_uint64, [c_int32, c_int32]),
     "av2x_wino4_pack_weights": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_eval_tp_fp": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p,

@@ -11,7 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libairv2x_hip.so")
-SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino_x3.hip", "conv_x3p.hip", "pillar.hip", "where2comm.hip", "where2comm_attn.hip", "postproc.hip", "voxelize.hip", "transformer.hip", "v2xvit.hip", "linear_bf16.hip", "when2com.hip", "v2vnet.hip", "lss.hip", "camera.hip", "labels.hip", "conv_backward.hip", "loss.hip", "train.hip", "train_fusion.hip", "train_v2xvit.hip"]
+SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino_x3.hip", "conv_wino4_x3.hip", "conv_x3p.hip", "pillar.hip", "where2comm.hip", "where2comm_attn.hip", "postproc.hip", "voxelize.hip", "transformer.hip", "v2xvit.hip", "linear_bf16.hip", "when2com.hip", "v2vnet.hip", "lss.hip", "camera.hip", "labels.hip", "conv_backward.hip", "loss.hip", "train.hip", "train_fusion.hip", "train_v2xvit.hip"]
+
+
+# per-source flags.  The split-3 Winograd kernels keep their channel-pair arithmetic scalar on purpose (a packed fp32 instruction beside
+# MFMAs costs more than the two scalar ones it replaces): neither the SLP vectoriser nor VectorCombine may re-pack it.
+_SCALAR_F32 = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
+EXTRA_FLAGS = {"conv_wino_x3.hip": _SCALAR_F32, "conv_wino4_x3.hip": _SCALAR_F32}
 
 
 class HipccMissing(RuntimeError):
@@ -52,7 +58,7 @@ def build(force=False, verbose=False):
                     + [os.path.getmtime(os.path.join(ROOT, "include", "airv2x_hip.h"))])
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
             continue
-        cmd = [cc, *flags, "-c", s, "-o", o]
+        cmd = [cc, *flags, *EXTRA_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -19,6 +19,8 @@
 namespace av2x {
 int wino_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, const float* scale, const float* shift,
                      const float* residual, float* out, hipStream_t st);   // conv_wino_x3.hip
+int wino4_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, const float* scale, const float* shift,
+                      const float* residual, float* out, hipStream_t st);   // conv_wino4_x3.hip
 int x3p_dispatch(const void* conv_params, size_t bytes, int bm, int bn, hipStream_t st);   // conv_x3p.hip
 }
 
@@ -458,6 +460,8 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     if (d->relu < 0 || d->relu > 6)
         return av2x::fail("av2x_conv2d: relu/activation code %d (0 none, 1 ReLU, 2 GELU, 3 sigmoid, 4 tanh [x residual], 5 ReLU after the residual, 6 swish)", d->relu);
     if (d->relu == 5 && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: activation 5 (ReLU after the residual) needs mode AV2X_CONV");
+    if ((d->tile & 0x60000400) == 0x60000400)   // Winograd F(4x4,3x3) with split-3 bf16 operands (conv_wino4_x3.hip): `w` = av2x_wino4_x3_pack_weights
+        return av2x::wino4_x3_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if ((d->tile & 0x60000000) == 0x60000000)   // Winograd F(4x4,3x3): `w` is the transformed packing of av2x_wino4_pack_weights
         return wino4_dispatch(d, in, w, scale, shift, residual, out, av2x::as_stream(stream));
     if ((d->tile & 0x40000400) == 0x40000400)   // Winograd F(2x2,3x3) with split-3 bf16 operands (conv_wino_x3.hip): `w` = av2x_wino_x3_pack_weights

@@ -38,7 +38,7 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if hasattr(to
 
 
 class ConvLayer:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i", "_wu4", "_w16h", "_wu3")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "coutp", "ks", "stride", "pad", "relu", "mode", "up", "_w16", "_w3", "_wu", "_w16i", "_wu4", "_w16h", "_wu3", "_wu43")
 
     def __init__(self, w, scale, shift, cin, cout, coutp, ks, stride, pad, relu, mode=_lib.AV2X_CONV, up=1):
         self.w, self.scale, self.shift = w, scale, shift
@@ -48,6 +48,7 @@ class ConvLayer:
         self._w16i = None
         self._wu4 = None
         self._wu3 = None
+        self._wu43 = None
         self._w16h = None
         self.cin, self.cout, self.coutp = cin, cout, coutp
         self.ks, self.stride, self.pad, self.relu, self.mode, self.up = ks, stride, pad, relu, mode, up
@@ -122,6 +123,18 @@ def _wu3(L, lib, stream):
         torch.cuda.current_stream().synchronize()      # as _wu: other streams may launch with it next
         L._wu3 = u
     return L._wu3
+
+
+def _wu43(L, lib, stream):
+    """Winograd F(4x4,3x3)-transformed weights as split-3 bf16 planes (av2x_wino4_x3_pack_weights: 36 positions, G g G^T in fp64, hi / mid /
+    lo there), built on the device on first use."""
+    if L._wu43 is None:
+        u = torch.empty(lib.av2x_wino4_x3_weight_bytes(L.cin, L.coutp) // 2, dtype=torch.bfloat16, device=L.w.device)
+        _lib.check(lib.av2x_wino4_x3_pack_weights(c_void_p(L.w.data_ptr()), L.cin, L.coutp, c_void_p(u.data_ptr()), stream),
+                   "av2x_wino4_x3_pack_weights")
+        torch.cuda.current_stream().synchronize()      # as _wu: other streams may launch with it next
+        L._wu43 = u
+    return L._wu43
 
 
 def _ptr(t):
@@ -215,6 +228,9 @@ class Where2ComEngine:
         # (csrc/conv_x3p.hip; bit-identical to conv_igemm_bf16x3, 1.1-1.15x faster).  x3p alone leaves the 3x3 layers on the fp32 Winograd
         # kernels; wino_x3 + x3p = the "x3" mode of bench.py: every product of the frame formed from three bf16 terms per operand.
         self.x3p = os.environ.get("AV2X_X3P", x3_default) not in ("0", "off", "")
+        # ... and the split-3 form of the F(4x4,3x3) class (csrc/conv_wino4_x3.hip): the layers wino4_rule selects run the 36-position
+        # algorithm on the bf16 matrix cores too (needs wino_x3; error against fp64 at or below the fp32 F(4x4) kernel's)
+        self.wino4_x3 = os.environ.get("AV2X_WINO4_X3", x3_default) not in ("0", "off", "")
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
@@ -262,6 +278,7 @@ class Where2ComEngine:
         other.split3 = self.split3
         other.wino_x3 = self.wino_x3
         other.x3p = self.x3p
+        other.wino4_x3 = self.wino4_x3
         return other
 
     def graph_active(self):
@@ -523,8 +540,12 @@ class Where2ComEngine:
             wgt, d.coutp = _w16h(L)                     # halo-tile direct convolution on bf16 activations: a rule, not a timing
             d.tile = self.HALO16_TILE
         elif self.winograd and self.wino4 and not self.conv_tile and vflag == 0 and self.wino4_rule(L, n, d.ho, d.wo):
-            wgt = _wu4(L, self.lib, self.stream())      # the F(4x4,3x3) class: a pure function of the layer's shape
-            d.tile = self.WINO4_TILE
+            if self.wino_x3 and self.wino4_x3 and L.cin % 32 == 0:   # the same class on the bf16 matrix cores (split-3 operands)
+                wgt = _wu43(L, self.lib, self.stream())
+                d.tile = self.WINO4_X3_TILE
+            else:
+                wgt = _wu4(L, self.lib, self.stream())  # the F(4x4,3x3) class: a pure function of the layer's shape
+                d.tile = self.WINO4_TILE
         elif self.winograd and self.wino_x3 and not self.conv_tile and vflag == 0 and self.wino_x3_rule(L):
             wgt = _wu3(L, self.lib, self.stream())
             d.tile = self.wino_x3_tile(L, d.ho, d.wo)
@@ -638,6 +659,7 @@ class Where2ComEngine:
     # test_gpu_batch_and_single.py).  Taken where ONE image already fills the chip: >= 256 workgroups per image and a K loop of
     # >= 16 chunks -- the two 256 -> 256 shrink convolutions at 100 x 352 of the default grid.
     WINO4_TILE = 0x60000000 | (32 << 16) | 64
+    WINO4_X3_TILE = 0x60000400 | (32 << 16) | 64
     WINO4_MIN_WGS_PER_IMAGE = int(os.environ.get("AV2X_WINO4_MIN_WGS", "256"))   # per IMAGE (never per launch): see above
     WINO4_MIN_CIN = 128
     wino4 = os.environ.get("AV2X_WINOGRAD4", "1") != "0"

@@ -101,8 +101,8 @@ def parse(argv=None):
                          "frames + the roofline pass only -- the command the rocprofv3 summaries in profiles/ are taken from")
     ap.add_argument("--gemm", choices=["f32", "split3", "wino_x3", "x3"], default="x3",
                     help="x3 (default, the headline since round 4): fp32-accurate products from three bf16 terms per operand on the bf16 matrix "
-                         "cores -- conv_wino_x3 for the F(2x2,3x3) layers, conv_igemm_x3p for every other convolution / Linear, the two "
-                         "F(4x4,3x3) layers on the fp32-input MFMA; f32: every product on v_mfma_f32_32x32x2_f32 (the headline of rounds 1-3); "
+                         "cores -- conv_wino_x3 for the F(2x2,3x3) layers, conv_wino4_x3 for the two F(4x4,3x3) layers, conv_igemm_x3p for every other "
+                         "convolution / Linear; f32: every product on v_mfma_f32_32x32x2_f32 (the headline of rounds 1-3); "
                          "wino_x3: only the Winograd layers split; split3: split-3 direct kernels everywhere, no Winograd")
     ap.add_argument("--amp", action="store_true",
                     help="AMP mode: bf16 matrix-core operands with fp32 accumulation for every Conv2d / Linear (what "
@@ -487,7 +487,7 @@ def main(argv=None, hooks=None, device=None):
                               "is reported by tests/test_amp.py -- not comparable with the fp32 headline"} if a.amp else {}),
         "dtype": "bf16" if a.amp else ("f32 (products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulate)" if a.gemm == "split3" else
                                        "f32 (3xbf16 operands, fp32 accumulate) on the Winograd F(2x2,3x3) layers; f32 (fp32-input MFMA) elsewhere" if a.gemm == "wino_x3" else
-                                       "f32 (3xbf16 operands, fp32 accumulate); the two F(4x4,3x3) Winograd layers on the fp32-input MFMA" if a.gemm == "x3" else "f32"), "data": "synthetic",
+                                       "f32 (3xbf16 operands on the bf16 MFMA, fp32 accumulate)" if a.gemm == "x3" else "f32"), "data": "synthetic",
         "config": {"workload": f"{'Where2Comm' if a.model == 'where2com' else a.model + ' (L=' + str(args['max_cav_num']) + ')'}-LiDAR collaborative frame, {a.agents} agents ({','.join(synth.sort_types(synth.agent_types_for(a.agents))[1])}) x "
                                f"{a.points} pts, 704x200x1 pillars (0.4 m), B=1, pre-voxelised inputs resident in HBM, "
                                f"psm/rm/obj out" + ("; BASELINE.json configs[1]" if (a.agents == 4 and a.lidar_only) else "")
@@ -779,7 +779,8 @@ def main(argv=None, hooks=None, device=None):
                                + ((": Winograd F(4x4,3x3) executes 36/144 of them" if dom[0] & 0x2000 else ": Winograd executes 16/36 of them") if wino else ": equal to achieved (direct form)")),
             "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
-            "kernel": (f"conv_wino_x3<{(dom[0] & 0x3fff) // 32}> (Winograd F(2x2,3x3), split-3 operands: three bf16 terms per fp32 value, six products on v_mfma_f32_32x32x16_bf16; {dom[0] & 0x3fff} tiles x 64 couts per workgroup, 4 positions per wave)" if (wino and x3dom) else
+            "kernel": ("conv_wino4_x3 (Winograd F(4x4,3x3), split-3 operands: three bf16 terms per fp32 value, six products on v_mfma_f32_32x32x16_bf16; 32 tiles of 4x4 outputs x 64 couts per workgroup, 9 positions per wave, one workgroup per CU)" if (wino and x3dom and dom[0] & 0x2000) else
+                       f"conv_wino_x3<{(dom[0] & 0x1fff) // 32}> (Winograd F(2x2,3x3), split-3 operands: three bf16 terms per fp32 value, six products on v_mfma_f32_32x32x16_bf16; {dom[0] & 0x3fff} tiles x 64 couts per workgroup, 4 positions per wave)" if (wino and x3dom) else
                        ("conv_wino4_f32 (Winograd F(4x4,3x3), 32 tiles of 4x4 outputs x 64 couts per workgroup, 18 positions per wave, one workgroup per CU)" if dom[0] & 0x2000 else
                         "conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
                         "conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
@@ -787,7 +788,7 @@ def main(argv=None, hooks=None, device=None):
                        "conv_halo_bf16 (halo-tile direct convolution on bf16 activations: 8 x 16 output pixels x 128 couts per workgroup, 64-channel halo chunks in LDS)" if dom[0] & 0x1000 else
                        f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('x3p (pipelined split-3: three bf16 terms per fp32 operand, LDS-DMA weights, two LDS stages)' if (dom[1] & 0x1400) == 0x1400 else 'bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": (f"conv_wino_x3<{(dom[0] & 0x3fff) // 32}, false>" if (wino and x3dom) else ("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_x3p<{dom[1] & 0x01ff}>" if (dom[1] & 0x1400) == 0x1400 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": ("conv_wino4_x3<false>" if (wino and x3dom and dom[0] & 0x2000) else f"conv_wino_x3<{(dom[0] & 0x1fff) // 32}, false>" if (wino and x3dom) else ("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_x3p<{dom[1] & 0x01ff}>" if (dom[1] & 0x1400) == 0x1400 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),

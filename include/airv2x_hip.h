@@ -169,6 +169,16 @@ int av2x_wino_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, fl
  * from av2x_wino_x3_pack_weights (G g G^T in fp64, split there); cin % 16 == 0, cout % 64 == 0, activations 0, 1, 3, 4, 5. */
 uint64_t av2x_wino_x3_weight_bytes(int32_t cin, int32_t coutp);
 int av2x_wino_x3_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, void* u3, av2x_stream_t stream);
+
+/* Winograd F(4x4,3x3) with split-3 operands (tile = 0x60000000 | 0x0400 | (32 << 16) | 64; csrc/conv_wino4_x3.hip): the 36-position
+ * algorithm of av2x_wino4_pack_weights' kernel (2.25 multiplies per output) with every fp32 operand entering the bf16 matrix core as
+ * three terms, six partial products accumulated in fp32 -- fp32-accurate products, fp32 transforms: the error against an fp64
+ * convolution is that of the fp32 F(4x4) kernel or below (tests/test_gpu_wino4_x3.py).  Same layers as that kernel (the 3x3 / stride 1
+ * convolutions of downsample_conv.py:8-54 / base_bev_backbone.py:6-154 the engine's wino4 rule selects).  `w` = u3
+ * [pos 36][cin/16][plane hi,mid,lo][k half][coutp][8] bf16 from av2x_wino4_x3_pack_weights; cin % 32 == 0, cout % 64 == 0,
+ * activations 0, 1, 3, 4, 5. */
+uint64_t av2x_wino4_x3_weight_bytes(int32_t cin, int32_t coutp);
+int av2x_wino4_x3_pack_weights(const float* w_packed, int32_t cin, int32_t coutp, void* u3, av2x_stream_t stream);
 /* Winograd F(4x4,3x3) (tile flag 0x60000000 | 32 << 16 | 64): 36 products per 4x4 output tile = 2.25 multiplies per output (F(2x2,3x3): 4,
  * direct: 9), fp32 operands and accumulation; cin % 8 == 0, cout % 64 == 0 and cout == coutp; `w` = the transformed packing
  * [36][cin/4][coutp][4] made by av2x_wino4_pack_weights (av2x_wino4_weight_bytes bytes).  Results agree with the other kernels to

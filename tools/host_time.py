@@ -7,7 +7,7 @@ import bench
 sys.argv = [sys.argv[0], "--cpu-frames", "0"]
 a = bench.parse()
 torch.set_num_threads(2)
-hy, args, dd, clouds, types = bench.build_inputs(a.agents, a.points, torch.device("cuda"), model="where2com")
+hy, args, dd, clouds, types = bench.build_inputs(a.agents if a.agents > 0 else 4, a.points, torch.device("cuda"), model="where2com")
 from airv2x_perception_amd import synth
 from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
 from airv2x_perception_amd.opencood_iface.engine import FramePipeline

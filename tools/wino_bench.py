@@ -95,6 +95,20 @@ def main():
             err = f" err64={float((y.double() - ref).abs().max()):.2e} rms={float((y.double() - ref).pow(2).mean().sqrt()):.2e}" if ref is not None else ""
             dv = f" vs direct {float((y - base).abs().max()):.2e} (max|y| {float(base.abs().max()):.2f})" if base is not None else ""
             print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF(eff){err}{dv} nan={int(torch.isnan(y).sum())}", flush=True)
+        if cin % 32 == 0 and coutp % 64 == 0 and cout == coutp and not (a.tiles and "w4" not in a.tiles):
+            # F(4x4,3x3): fp32-input MFMA (conv_wino4_f32) and split-3 operands on the bf16 MFMA (conv_wino4_x3)
+            u4 = torch.empty(lib.av2x_wino4_weight_bytes(cin, coutp) // 4, device="cuda")
+            _lib.check(lib.av2x_wino4_pack_weights(P(wp), cin, coutp, P(u4), st), "pack w4")
+            u43 = torch.empty(lib.av2x_wino4_x3_weight_bytes(cin, coutp) // 2, dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.av2x_wino4_x3_pack_weights(P(wp), cin, coutp, P(u43), st), "pack w4 x3")
+            for tn, tile, wgt in (("w4_f32", 0x60000000 | (32 << 16) | 64, u4), ("w4_x3", 0x60000400 | (32 << 16) | 64, u43)):
+                if a.only_x3 and tn == "w4_f32":
+                    continue
+                us, y = run(tile, wgt)
+                err = f" err64={float((y.double() - ref).abs().max()):.2e} rms={float((y.double() - ref).pow(2).mean().sqrt()):.2e}" if ref is not None else ""
+                dv = f" vs direct {float((y - base).abs().max()):.2e} (max|y| {float(base.abs().max()):.2f})" if base is not None else ""
+                ex = f" {flops*36/144*6/us/1e6:7.1f} TF bf16 executed" if tn == "w4_x3" else f" {flops*36/144/us/1e6:7.1f} TF executed"
+                print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF(eff){ex}{err}{dv} nan={int(torch.isnan(y).sum())}", flush=True)
         for tn, (tb, cb) in X3.items():
             if u3 is None or (a.tiles and tn not in a.tiles.split(",")):
                 continue
