@@ -45,6 +45,12 @@ SIGNATURES = {
     "av2x_linear_rows_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
     "av2x_linear_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_uint64, c_void_p]),
+    "av2x_linear_rows_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                            c_void_p, c_void_p]),
+    "av2x_when2com_fuse_backward_workspace_bytes": (c_uint64, [c_int32]),
+    "av2x_when2com_fuse_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p]),
+    "av2x_warp_affine_simple_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_when2com_fuse": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
     "av2x_conv2d_wgrad_workspace_bytes": (c_uint64, [POINTER(ConvDesc)]),
     "av2x_conv2d_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

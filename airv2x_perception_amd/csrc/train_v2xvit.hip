@@ -261,7 +261,7 @@ __device__ __forceinline__ float lin_m1_1(int i, int n) {     // as v2xvit.hip
     return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
 }
 
-template <int CK>   // C = 64 * CK; align_corners = True (warp_affine)
+template <int CK, bool AC>   // C = 64 * CK; AC = align_corners: true for warp_affine, false for warp_affine_simple (as v2xvit.hip)
 __global__ __launch_bounds__(256) void warp_affine_backward_kernel(const float* __restrict__ ddst, const float* __restrict__ theta,
                                                                    unsigned long long* __restrict__ acc, int H, int W) {
     const int t = threadIdx.x & 15;
@@ -270,11 +270,12 @@ __global__ __launch_bounds__(256) void warp_affine_backward_kernel(const float* 
     if (pix >= H * W) return;
     const int i = pix / W, j = pix - i * W;
     const float* th = theta + n * 6;
-    const float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    if (!AC) { xn = (xn * (float)(W - 1)) / (float)W; yn = (yn * (float)(H - 1)) / (float)H; }
     const float gx = th[0] * xn + th[1] * yn + th[2];
     const float gy = th[3] * xn + th[4] * yn + th[5];
-    const float ix = ((gx + 1.f) * 0.5f) * (float)(W - 1);
-    const float iy = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+    const float ix = AC ? ((gx + 1.f) * 0.5f) * (float)(W - 1) : ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    const float iy = AC ? ((gy + 1.f) * 0.5f) * (float)(H - 1) : ((gy + 1.f) * (float)H - 1.f) * 0.5f;
     const float x0f = floorf(ix), y0f = floorf(iy);
     const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
     const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
@@ -383,20 +384,31 @@ extern "C" int av2x_split_attn_backward(const float* dout, const float* weights,
 
 extern "C" uint64_t av2x_warp_affine_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c) { return (uint64_t)n * h * w * c * 8ull; }
 
-extern "C" int av2x_warp_affine_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,
-                                         int32_t c, av2x_stream_t stream) {
-    if (!ddst || !theta || !dsrc || !workspace) return av2x::fail("av2x_warp_affine_backward: null argument");
-    if (c != 64 && c != 128 && c != 256) return av2x::fail("av2x_warp_affine_backward: c=%d (64, 128, 256)", c);
+template <bool AC>
+static int warp_affine_backward_launch(const char* who, const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,
+                                       int32_t c, av2x_stream_t stream) {
+    if (!ddst || !theta || !dsrc || !workspace) return av2x::fail("%s: null argument", who);
+    if (c != 64 && c != 128 && c != 256) return av2x::fail("%s: c=%d (64, 128, 256)", who, c);
     if (n < 1) return 0;
     hipStream_t st = av2x::as_stream(stream);
     const size_t total = (size_t)n * h * w * c;
     hipError_t e = hipMemsetAsync(workspace, 0, total * 8ull, st);
-    if (e != hipSuccess) return av2x::fail("av2x_warp_affine_backward: memset: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return av2x::fail("%s: memset: %s", who, hipGetErrorString(e));
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace);
     const dim3 grid((h * w + 15) / 16, n), block(256);
-    if (c == 64) hipLaunchKernelGGL(warp_affine_backward_kernel<1>, grid, block, 0, st, ddst, theta, acc, h, w);
-    else if (c == 128) hipLaunchKernelGGL(warp_affine_backward_kernel<2>, grid, block, 0, st, ddst, theta, acc, h, w);
-    else hipLaunchKernelGGL(warp_affine_backward_kernel<4>, grid, block, 0, st, ddst, theta, acc, h, w);
+    if (c == 64) hipLaunchKernelGGL((warp_affine_backward_kernel<1, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
+    else if (c == 128) hipLaunchKernelGGL((warp_affine_backward_kernel<2, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
+    else hipLaunchKernelGGL((warp_affine_backward_kernel<4, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
     hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const long long*>(acc), dsrc, total);
     return av2x::check_launch("warp_affine_backward_kernel");
+}
+
+extern "C" int av2x_warp_affine_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,
+                                         int32_t c, av2x_stream_t stream) {
+    return warp_affine_backward_launch<true>("av2x_warp_affine_backward", ddst, theta, dsrc, workspace, n, h, w, c, stream);
+}
+
+extern "C" int av2x_warp_affine_simple_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h,
+                                                int32_t w, int32_t c, av2x_stream_t stream) {
+    return warp_affine_backward_launch<false>("av2x_warp_affine_simple_backward", ddst, theta, dsrc, workspace, n, h, w, c, stream);
 }

@@ -1,0 +1,210 @@
+// Backward kernels of the When2com fusion head (training; forward kernels: when2com.hip).  What the reference gets from torch autograd of
+// models/when2com_modules/when2com.py: km_generator's Linear stack (:283-297, the first layer streams 256 * H/4 * W/4 inputs per output
+// feature: 577 MB of weights at the default grid) and MIMOGeneralDotProductAttention (:320-348, softmax over the keys, weighted sum of the
+// warped maps).  All of it is HBM-bound streaming; every reduction runs in one fixed order (run-to-run identical gradients).
+//
+//   linear_rows_dx_kernel   dx (m, k) = dz (m, n) . W (n, k): W is read ONCE, a thread owns four consecutive k for all m <= 8 rows
+//   linear_rows_dw_kernel   dW (n, k) = dz^T x: a thread keeps its four k of all m rows of x in registers and writes 32 rows of dW
+//   (dz = dy where the forward's ReLU passed, else 0; db = column sums of dz -- both formed from the (m, n) operands in LDS)
+//   fuse_dot_kernel / fuse_small_kernel / fuse_scale_kernel
+//                           dcoef_j = <dout, map_j> (two-stage), softmax backward + dkeys / dquery (one workgroup), dmap_j = coef_j dout
+#include <cstdint>
+
+#include "av2x_common.hpp"
+#include "airv2x_hip.h"
+
+namespace {
+
+constexpr int kMaxM = 8;         // x rows per pass
+constexpr int kMaxAgents = 32;   // as when2com.hip
+constexpr int kDotChunks = 512;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// dz[i][j] = (act && y[i][j] <= 0) ? 0 : dy[i][j] into LDS, [i][n] row-major
+__device__ __forceinline__ void load_dz(float* sdz, const float* __restrict__ dy, const float* __restrict__ y, int m, int n, int act) {
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) sdz[e] = (act && y[e] <= 0.f) ? 0.f : dy[e];
+    __syncthreads();
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void linear_rows_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ y,
+                                                             int m, int n, int k, int act, float* __restrict__ dx, float* __restrict__ db) {
+    extern __shared__ float sdz[];
+    load_dz(sdz, dy, y, m, n, act);
+    if (db && blockIdx.x == 0) {      // bias gradient: column sums of dz, rows in order
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            float s = 0.f;
+            for (int i = 0; i < m; ++i) s += sdz[i * n + j];
+            db[j] = s;
+        }
+    }
+    const size_t k4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k4 * 4 >= (size_t)k) return;
+    f4 acc[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    const f4* wp = reinterpret_cast<const f4*>(w) + k4;
+    const size_t rs = (size_t)k / 4;
+    for (int j = 0; j < n; ++j) {
+        const f4 wv = __builtin_nontemporal_load(wp + (size_t)j * rs);
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+            if (i < m) {
+                const float d = sdz[i * n + j];
+                acc[i].x = fmaf(d, wv.x, acc[i].x); acc[i].y = fmaf(d, wv.y, acc[i].y);
+                acc[i].z = fmaf(d, wv.z, acc[i].z); acc[i].w = fmaf(d, wv.w, acc[i].w);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+        if (i < m) reinterpret_cast<f4*>(dx)[(size_t)i * rs + k4] = acc[i];
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void linear_rows_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                                             int m, int n, int k, int act, int accumulate, float* __restrict__ dw) {
+    extern __shared__ float sdz[];
+    load_dz(sdz, dy, y, m, n, act);
+    const size_t k4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k4 * 4 >= (size_t)k) return;
+    const size_t rs = (size_t)k / 4;
+    f4 xv[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) xv[i] = i < m ? reinterpret_cast<const f4*>(x)[(size_t)i * rs + k4] : f4{0.f, 0.f, 0.f, 0.f};
+    const int j0 = blockIdx.y * 32, j1 = min(n, j0 + 32);
+    for (int j = j0; j < j1; ++j) {
+        f4 o = accumulate ? reinterpret_cast<const f4*>(dw)[(size_t)j * rs + k4] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+            if (i < m) {
+                const float d = sdz[i * n + j];
+                o.x = fmaf(d, xv[i].x, o.x); o.y = fmaf(d, xv[i].y, o.y); o.z = fmaf(d, xv[i].z, o.z); o.w = fmaf(d, xv[i].w, o.w);
+            }
+        __builtin_nontemporal_store(o, reinterpret_cast<f4*>(dw) + (size_t)j * rs + k4);
+    }
+}
+
+struct AgentPtrs { const f4* p[kMaxAgents]; };
+struct AgentOut { f4* p[kMaxAgents]; };
+
+__global__ __launch_bounds__(256) void fuse_dot_kernel(const f4* __restrict__ dout, const AgentPtrs agents, size_t hwc4, float* __restrict__ part) {
+    const int j = blockIdx.y;
+    const f4* a = agents.p[j];
+    double s = 0.0;     // fixed assignment of elements to threads and a fixed tree: run-to-run identical
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hwc4; i += (size_t)gridDim.x * blockDim.x) {
+        const f4 d = dout[i], v = a[i];
+        s += (double)(d.x * v.x + d.y * v.y) + (double)(d.z * v.z + d.w * v.w);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)j * gridDim.x + blockIdx.x] = (float)red[0];
+}
+
+__global__ __launch_bounds__(256) void fuse_small_kernel(const float* __restrict__ keys, const float* __restrict__ q, const float* __restrict__ coef,
+                                                         const float* __restrict__ part, int chunks, int n, int ks,
+                                                         float* __restrict__ dkeys, float* __restrict__ dq) {
+    __shared__ float dlog[kMaxAgents];
+    __shared__ double dco[kMaxAgents];
+    if ((int)threadIdx.x < n) {
+        double s = 0.0;
+        for (int c = 0; c < chunks; ++c) s += (double)part[(size_t)threadIdx.x * chunks + c];
+        dco[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {     // softmax backward over the keys: dlogit_j = p_j (dp_j - sum_i p_i dp_i)
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t += (double)coef[j] * dco[j];
+        for (int j = 0; j < n; ++j) dlog[j] = (float)((double)coef[j] * (dco[j] - t));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ks; c += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) {
+            if (dkeys) dkeys[(size_t)j * ks + c] = dlog[j] * q[c];
+            s = fmaf(dlog[j], keys[(size_t)j * ks + c], s);
+        }
+        if (dq) dq[c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void fuse_scale_kernel(const f4* __restrict__ dout, const float* __restrict__ coef, const AgentOut dagents, size_t hwc4) {
+    const int j = blockIdx.y;
+    const float p = coef[j];
+    f4* o = dagents.p[j];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hwc4; i += (size_t)gridDim.x * blockDim.x) {
+        const f4 d = dout[i];
+        o[i] = f4{p * d.x, p * d.y, p * d.z, p * d.w};
+    }
+}
+
+}  // namespace
+
+extern "C" int av2x_linear_rows_backward(const float* x, const float* w, const float* y, const float* dy, int32_t m, int32_t n, int32_t k,
+                                         int32_t act, float* dx, float* dw, float* db, av2x_stream_t stream) {
+    if (m == 0) return 0;
+    if (!x || !w || !dy || (act && !y)) return av2x::fail("av2x_linear_rows_backward: null argument");
+    if (m < 0 || n <= 0 || k <= 0 || k % 4) return av2x::fail("av2x_linear_rows_backward: bad sizes (m=%d n=%d k=%d; k %% 4 == 0)", m, n, k);
+    if (act < 0 || act > 1) return av2x::fail("av2x_linear_rows_backward: activation code %d (0 none, 1 ReLU)", act);
+    if ((size_t)kMaxM * n * sizeof(float) > 64 * 1024) return av2x::fail("av2x_linear_rows_backward: n=%d too wide (8 x n floats of LDS)", n);
+    for (const void* q : {(const void*)x, (const void*)w, (const void*)dx, (const void*)dw})
+        if (reinterpret_cast<uintptr_t>(q) % 16) return av2x::fail("av2x_linear_rows_backward: x, w, dx, dw must be 16-byte aligned");
+    hipStream_t st = av2x::as_stream(stream);
+    const unsigned kb = (unsigned)((k / 4 + 255) / 256);
+    for (int m0 = 0; m0 < m; m0 += kMaxM) {    // more than 8 rows: W is streamed once per group of 8 (dW accumulates over the groups)
+        const int mm = (m - m0) < kMaxM ? (m - m0) : kMaxM;
+        const size_t lds = (size_t)mm * n * sizeof(float);
+        const float* ys = y ? y + (size_t)m0 * n : nullptr;
+        if (dx || db) {
+            float* dbp = m0 == 0 ? db : nullptr;   // rows beyond the first group: folded in below
+            if (mm <= 4) hipLaunchKernelGGL(linear_rows_dx_kernel<4>, dim3(kb), dim3(256), lds, st, w, dy + (size_t)m0 * n, ys, mm, n, k, act,
+                                            dx ? dx + (size_t)m0 * k : nullptr, dbp);
+            else hipLaunchKernelGGL(linear_rows_dx_kernel<8>, dim3(kb), dim3(256), lds, st, w, dy + (size_t)m0 * n, ys, mm, n, k, act,
+                                    dx ? dx + (size_t)m0 * k : nullptr, dbp);
+        }
+        if (dw) {
+            const dim3 grid(kb, (unsigned)((n + 31) / 32));
+            if (mm <= 4) hipLaunchKernelGGL(linear_rows_dw_kernel<4>, grid, dim3(256), lds, st, x + (size_t)m0 * k, dy + (size_t)m0 * n, ys, mm, n, k,
+                                            act, m0 > 0 ? 1 : 0, dw);
+            else hipLaunchKernelGGL(linear_rows_dw_kernel<8>, grid, dim3(256), lds, st, x + (size_t)m0 * k, dy + (size_t)m0 * n, ys, mm, n, k, act,
+                                    m0 > 0 ? 1 : 0, dw);
+        }
+    }
+    if (db && m > kMaxM) return av2x::fail("av2x_linear_rows_backward: the bias gradient is formed for m <= %d rows", kMaxM);
+    return av2x::check_launch("linear_rows_backward");
+}
+
+extern "C" uint64_t av2x_when2com_fuse_backward_workspace_bytes(int32_t n_agents) { return (uint64_t)(n_agents > 0 ? n_agents : 0) * kDotChunks * sizeof(float); }
+
+extern "C" int av2x_when2com_fuse_backward(const float* keys, const float* query, const float* coef, int32_t n_agents, int32_t key_size,
+                                           const float* const* agents, uint64_t elems_per_agent, const float* dout, float* const* dagents,
+                                           float* dkeys, float* dquery, void* workspace, av2x_stream_t stream) {
+    if (!keys || !query || !coef || !agents || !dout || !workspace) return av2x::fail("av2x_when2com_fuse_backward: null argument");
+    if (n_agents < 1 || n_agents > kMaxAgents) return av2x::fail("av2x_when2com_fuse_backward: n_agents=%d outside [1,%d]", n_agents, kMaxAgents);
+    if (key_size <= 0 || elems_per_agent == 0 || elems_per_agent % 4)
+        return av2x::fail("av2x_when2com_fuse_backward: bad sizes (elements per agent must be a multiple of 4)");
+    const size_t hwc4 = elems_per_agent / 4;
+    AgentPtrs am;
+    AgentOut ao;
+    for (int j = 0; j < kMaxAgents; ++j) {
+        am.p[j] = j < n_agents ? reinterpret_cast<const f4*>(agents[j]) : nullptr;
+        ao.p[j] = (j < n_agents && dagents) ? reinterpret_cast<f4*>(dagents[j]) : nullptr;
+        if (j < n_agents && (!agents[j] || reinterpret_cast<uintptr_t>(agents[j]) % 16 || (dagents && (!dagents[j] || reinterpret_cast<uintptr_t>(dagents[j]) % 16))))
+            return av2x::fail("av2x_when2com_fuse_backward: agent map %d is null or not 16-byte aligned", j);
+    }
+    hipStream_t st = av2x::as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(fuse_dot_kernel, dim3(kDotChunks, n_agents), dim3(256), 0, st, reinterpret_cast<const f4*>(dout), am, hwc4, part);
+    hipLaunchKernelGGL(fuse_small_kernel, dim3(1), dim3(256), 0, st, keys, query, coef, part, kDotChunks, n_agents, key_size, dkeys, dquery);
+    if (dagents) {
+        size_t blocks = (hwc4 + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(fuse_scale_kernel, dim3((unsigned)blocks, n_agents), dim3(256), 0, st, reinterpret_cast<const f4*>(dout), coef, ao, hwc4);
+    }
+    return av2x::check_launch("when2com_fuse_backward");
+}

@@ -998,7 +998,8 @@ class Where2ComEngine:
         lidar_canvas = self.buf("canvas_lidar", (n_total, ny, nx, 64)) if both else canvas
         st = self.stream()
         if any(t in self.pfn for t in slots):
-            _lib.check(self.lib.av2x_fill_zero(_ptr(lidar_canvas), lidar_canvas.numel() * 4, st), "av2x_fill_zero")
+            self.timed_hbm("canvas clear (hipMemsetAsync)", lidar_canvas.numel() * 4, 0.0,
+                           lambda: _lib.check(self.lib.av2x_fill_zero(_ptr(lidar_canvas), lidar_canvas.numel() * 4, st), "av2x_fill_zero"))
         self.encode_lidar(data_dict, slots, lidar_canvas, ny, nx)
         per = ny * nx * 64
         for t, sl in slots.items():
@@ -1042,9 +1043,10 @@ class Where2ComEngine:
             smap = None
             if not contiguous:
                 smap = torch.tensor(sl, dtype=torch.int32, device=self.device)
-            _lib.check(self.lib.av2x_pillar_vfe_scatter(_ptr(vf), _ptr(vc), _ptr(vn), vf.shape[0], _ptr(w), _ptr(sc),
-                                                        _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), sl[0],
-                                                        _ptr(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter")
+            self.timed_hbm("pillar_vfe_scatter", vf.shape[0] * (512 + 12 + 4 + 256), 2.0 * 32 * 10 * 64 * vf.shape[0],
+                           lambda: _lib.check(self.lib.av2x_pillar_vfe_scatter(_ptr(vf), _ptr(vc), _ptr(vn), vf.shape[0], _ptr(w), _ptr(sc),
+                                                                               _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), sl[0],
+                                                                               _ptr(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter"))
 
     def trunk(self, canvas, n, ny, nx, tag="all", block_out=None, shrink_out=None):
         """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""
@@ -1087,10 +1089,12 @@ class Where2ComEngine:
         if count is None:  # else: a shared counter the caller zeroed before forking the agent groups
             count = self.buf("comm_count", (B,), torch.int32)
             _lib.check(self.lib.av2x_fill_zero(_ptr(count), B * 4, st), "av2x_fill_zero")
-        _lib.check(self.lib.av2x_comm_mask(_ptr(psm_single), n, H, W, psm_single.shape[-1], self.A * self.C,
-                                           _ptr(self.gauss_w), _ptr(self.gauss_b), self.gauss_k, self.threshold,
-                                           _ptr(lay[0]), _ptr(lay[1]), _ptr(conf), _ptr(smooth), _ptr(mask),
-                                           _ptr(count), st), "av2x_comm_mask")
+        # reads the (n,H,W,A*C) single-agent scores once, writes confidence, smoothed map and mask (1.97 MB + 0.14 MB x 3 per agent)
+        self.timed_hbm("comm_mask (confidence + Gaussian + threshold)", n * H * W * (psm_single.shape[-1] + 3) * 4, 0.0,
+                       lambda: _lib.check(self.lib.av2x_comm_mask(_ptr(psm_single), n, H, W, psm_single.shape[-1], self.A * self.C,
+                                                                  _ptr(self.gauss_w), _ptr(self.gauss_b), self.gauss_k, self.threshold,
+                                                                  _ptr(lay[0]), _ptr(lay[1]), _ptr(conf), _ptr(smooth), _ptr(mask),
+                                                                  _ptr(count), st), "av2x_comm_mask"))
         if topk is not None:
             if len(topk) != B:
                 raise ValueError("topk: one K per sample")
@@ -1108,8 +1112,9 @@ class Where2ComEngine:
 
     def attn(self, ptrs, hw, c, out):
         arr = (c_void_p * len(ptrs))(*ptrs)
-        _lib.check(self.lib.av2x_pixel_attn_fuse(arr, len(ptrs), hw, c, _ptr(out), self.stream()),
-                   "av2x_pixel_attn_fuse")
+        # every agent's map read once, the ego's fused row written (15.77 MB x N + 15.77 MB over the three scales)
+        self.timed_hbm("pixel_attn_fuse", (len(ptrs) + 1) * hw * c * 4, 4.0 * len(ptrs) * hw * c,
+                       lambda: _lib.check(self.lib.av2x_pixel_attn_fuse(arr, len(ptrs), hw, c, _ptr(out), self.stream()), "av2x_pixel_attn_fuse"))
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
@@ -1162,7 +1167,8 @@ class Where2ComEngine:
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
-        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        self.timed_hbm("count_nonzero (comm_rate)", canvas.numel() * 4, 0.0,
+                       lambda: _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero"))
 
         feats, s, H, W = self.trunk(canvas, n, ny, nx)
         psm_single = self.buf("psm_single", (n, H, W, self.A * self.C))
@@ -1185,7 +1191,8 @@ class Where2ComEngine:
                                           "is never taken by AirV2X configs")
             mask, count, smooth, rl = self.comm_mask(psm_single, n, H, W, record_len)
             com = self.comm_rate(count, rl, B, H * W)                    # where2comm_fuse.py:137,147
-            _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask")
+            self.timed_hbm("apply_mask (in place)", n * h0 * w0 * (2 * b0.shape[-1] + 1) * 4, 0.0,
+                           lambda: _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask"))
             if trace is not None:
                 trace["comm_mask"] = mask.unsqueeze(1).clone()
                 trace["comm_map"] = smooth.unsqueeze(1).clone()

@@ -478,6 +478,9 @@ int av2x_split_attn_backward(const float* dout, const float* weights, const floa
 uint64_t av2x_warp_affine_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c);
 int av2x_warp_affine_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,
                               int32_t c, av2x_stream_t stream);
+/* the same for av2x_warp_affine_simple (align_corners = False; the warp of the When2com / V2VNet / OPV2V-style Where2comm fusions) */
+int av2x_warp_affine_simple_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,
+                                     int32_t c, av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Camera encoder (BASELINE configs[4]): the non-GEMM kernels of CamEncode / BevEncode
@@ -783,6 +786,20 @@ int av2x_voxelize_dummy_if_empty(const float* range6, const float* voxel3, int32
  *   aligned (the maps may live in different buffers, e.g. slices of an all-gather result); elems_per_agent % 4 == 0,
  *   n_agents <= 32; coef (n_agents,) receives p (may be NULL).
  * ------------------------------------------------------------------------------------ */
+/* Training (what torch autograd of when2com.py gives the reference):
+ * av2x_linear_rows_backward: with dz = dy where the forward's ReLU passed (act 1: y > 0; act 0: everywhere) --
+ *   dx (m,k) = dz . w, dw (n,k) = dz^T . x, db (n) = column sums of dz; any of the three may be NULL.  w is streamed once (dx) and dw
+ *   written once per group of 8 rows; fixed summation orders.  y (m,n) = the forward output (needed for act 1); db: m <= 8.
+ * av2x_when2com_fuse_backward: gradients of av2x_when2com_fuse given dout (elems_per_agent): dagents[j] = p_j dout (HOST array of device
+ *   pointers, may be NULL), dkeys (n_agents, key_size) and dquery (key_size) through the softmax over the keys (either may be NULL);
+ *   coef = the p the forward returned; workspace: av2x_when2com_fuse_backward_workspace_bytes(n_agents).
+ * av2x_warp_affine_simple_backward (declared with av2x_warp_affine_backward): the adjoint of av2x_warp_affine_simple. */
+int av2x_linear_rows_backward(const float* x, const float* w, const float* y, const float* dy, int32_t m, int32_t n, int32_t k,
+                              int32_t act, float* dx, float* dw, float* db, av2x_stream_t stream);
+uint64_t av2x_when2com_fuse_backward_workspace_bytes(int32_t n_agents);
+int av2x_when2com_fuse_backward(const float* keys, const float* query, const float* coef, int32_t n_agents, int32_t key_size,
+                                const float* const* agents, uint64_t elems_per_agent, const float* dout, float* const* dagents,
+                                float* dkeys, float* dquery, void* workspace, av2x_stream_t stream);
 uint64_t av2x_linear_rows_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int av2x_linear_rows(const float* x, const float* w, const float* bias, int32_t m, int32_t n, int32_t k, int32_t act,
                      float* y, void* workspace, uint64_t workspace_bytes, av2x_stream_t stream);

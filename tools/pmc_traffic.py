@@ -27,6 +27,14 @@ def conv_key(name):
         bm, bn, wm, wn, stages, mode = (int(g.group(i)) for i in range(1, 7))
         waves = (bm // wm) * (bn // wn)
         return f"g{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if stages == 3 else ''}{'sk' if mode == 1 else ''}"
+    x3 = re.search(r"conv_wino_x3<(\d+), (true|false)>", name)
+    if x3:  # split-3 Winograd F(2x2,3x3): bench.py's key "w<tiles>x64_bf16x3"
+        return f"w{32 * int(x3.group(1))}x64_bf16x3"
+    if "conv_wino4_x3" in name:    # split-3 Winograd F(4x4,3x3)
+        return "w4_32x64_bf16x3"
+    xp = re.search(r"conv_igemm_x3p<(\d+)>", name)
+    if xp:  # pipelined split-3 implicit GEMM: "128x<BN>p_bf16x3"
+        return f"128x{int(xp.group(1))}p_bf16x3"
     if "conv_wino4_f32" in name:   # Winograd F(4x4,3x3): bench.py's key "w4_32x64"
         return "w4_32x64"
     if "conv_wino_f32_h" in name:
