@@ -141,14 +141,19 @@ def when2com_attention(keys, q, maps):
     return When2comFuseFn.apply(keys, q, maps)
 
 
+POLICY_BN_EPS, POLICY_BN_MOMENTUM = 1e-5, 0.1       # nn.BatchNorm2d defaults (conv2DBatchNormRelu :160-163), not the backbone's 1e-3 / 0.01
+
+
 def _policy(P, sd, x, prefix="fusion_net.query_key_net."):
     """policy_net4 (:300-317): conv2DBatchNormRelu x 5.  The convolutions carry a bias in front of their BatchNorm: it cancels in the
     normalised output (its gradient is exactly zero) but is part of the batch mean nn.BatchNorm folds into ``running_mean``."""
     for i, s in enumerate((1, 1, 2, 1, 2), 1):
         p = f"{prefix}conv{i}.cbr_unit"
-        x = T.conv_bn_act(x, P[p + ".0.weight"], P[p + ".1.weight"], P[p + ".1.bias"], s, 1, running=_running(sd, p + ".1", 1))
-        with torch.no_grad():       # (1 - m) rm + m (mean(conv) + b) = [the update above] + m b
-            sd[p + ".1.running_mean"].add_(P[p + ".0.bias"].detach(), alpha=T.BN_MOMENTUM)
+        st = []
+        x = T.conv_bn_act(x, P[p + ".0.weight"], P[p + ".1.weight"], P[p + ".1.bias"], s, 1, eps=POLICY_BN_EPS, stats_out=st)
+        mean, var, count = st[0]
+        T.update_running_stats(sd[p + ".1.running_mean"], sd[p + ".1.running_var"], sd.get(p + ".1.num_batches_tracked"),
+                               (mean + P[p + ".0.bias"].detach(), var, count), 1, momentum=POLICY_BN_MOMENTUM)
     return x
 
 

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from . import where2comm_oracle as w2c
 
 BN_EPS = 1e-5   # nn.BatchNorm2d default (conv2DBatchNormRelu, when2com.py:160-163) -- NOT the backbone's 1e-3
+BN_MOMENTUM = 0.1   # nn.BatchNorm2d default, likewise (the backbone's BatchNorms are built with 0.01)
 
 
 def normalized_pairwise(pairwise_t_matrix, H, W, discrete_ratio, downsample_rate):
@@ -36,9 +37,18 @@ def warp_affine_simple(src, M, dsize):
 
 
 def _cbr(x, sd, p, stride):
+    """conv2DBatchNormRelu :137-170: Conv2d (with bias) + BatchNorm2d (default eps 1e-5, momentum 0.1) + ReLU; inside
+    ``where2comm_oracle.train_mode()`` the BatchNorm uses batch statistics and updates its running statistics, as ``.train()`` does."""
     x = F.conv2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], stride=stride, padding=1)
-    x = F.batch_norm(x, sd[p + ".1.running_mean"], sd[p + ".1.running_var"], sd[p + ".1.weight"], sd[p + ".1.bias"],
-                     False, 0.0, BN_EPS)
+    if w2c._STATE["train"]:
+        nbt = sd.get(p + ".1.num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+        x = F.batch_norm(x, sd[p + ".1.running_mean"], sd[p + ".1.running_var"], sd[p + ".1.weight"], sd[p + ".1.bias"],
+                         True, BN_MOMENTUM, BN_EPS)
+    else:
+        x = F.batch_norm(x, sd[p + ".1.running_mean"], sd[p + ".1.running_var"], sd[p + ".1.weight"], sd[p + ".1.bias"],
+                         False, 0.0, BN_EPS)
     return F.relu(x)
 
 

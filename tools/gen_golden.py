@@ -1557,6 +1557,128 @@ def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2,
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def train_when2com_golden(name, lidar_range, types, n_points, seed, pos_frac=0.01, head_stride=1):
+    """One TRAINING step of the reference's Airv2xWhen2com (train mode: BatchNorm batch statistics in the trunk AND in policy_net4)
+    + PointPillarLossMultiClass + torch autograd; layout of train_cobevt_golden: heads, losses, the gradient of every parameter
+    (strided samples + sums), every buffer after the step, and the same step in float64 as the yardstick.  oracle/when2com_oracle.py
+    under train_mode() must reproduce it."""
+    from airv2x_perception_amd import synth
+    from oracle import loss_oracle as lo
+    from oracle import voxelize_oracle as vox
+    from oracle import when2com_oracle as w2
+    from oracle import where2comm_oracle as orc
+    _stub("opencood.models.task_heads.segmentation_head", BevSegHead=object)
+    from opencood.hypes_yaml.yaml_utils import load_yaml
+    from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
+    from opencood.models.airv2x_when2com import Airv2xWhen2com
+
+    src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_when2com.yaml")
+    txt = open(src).read()
+    hy = synth.default_hypes_when2com(lidar_range)
+    if lidar_range is not None:
+        r = lidar_range
+        txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+        w = hy["model"]["args"]["when2com_fusion"]
+        txt = txt.replace("      H: 100", f"      H: {w['H']}").replace("      W: 352", f"      W: {w['W']}")
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(txt)
+        path = f.name
+    hy_ref = load_yaml(path)
+    os.unlink(path)
+    check_hypes(hy_ref["model"]["args"], hy["model"]["args"])
+    args = hy["model"]["args"]
+    model = Airv2xWhen2com(hy_ref["model"]["args"]).train()
+    spec = synth.when2com_param_spec(args)
+    assert [k for k, _, _ in spec] == list(model.state_dict().keys())
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_train"]))
+    pair = synth.when2com_pairwise(len(types), args["max_cav_num"])
+
+    def data():
+        d = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+        d["img_pairwise_t_matrix_collab"] = pair.clone()
+        return d
+    out = model(data())
+    H, W = out["psm"].shape[-2:]
+    lc = synth.loss_case(seed + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=pos_frac)
+    tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
+    crit = PointPillarLossMultiClass(la)
+    total = crit(out, tgt)
+    total.backward()
+
+    def oracle_step(dtype):
+        sd2 = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k, v in sd2.items():
+            if v.is_floating_point() and k in dict(model.named_parameters()):
+                v.requires_grad_(True)
+        d2 = data()
+        if dtype == torch.float64:
+            d2["img_pairwise_t_matrix_collab"] = d2["img_pairwise_t_matrix_collab"].double()
+            for t in synth.AGENT_TYPES:
+                lid = d2[t]["batch_merged_lidar_features_torch"]
+                if lid is not None:
+                    lid["voxel_features"] = lid["voxel_features"].double()
+        with orc.train_mode():
+            o = w2.when2com_forward(d2, sd2, args)
+        l_ = lo.pp_loss(o["psm"], o["rm"], o["obj"], tgt["targets"].to(dtype), tgt["pos_equal_one"].to(dtype), tgt["class_ids"],
+                        la["num_class"], la["cls_weight"], la["reg"])
+        l_[0].backward()
+        return o, l_, sd2
+    o, mine, sd2 = oracle_step(torch.float32)
+    worst = max((o[k] - out[k]).abs().max().item() for k in ("psm", "rm", "obj"))
+    assert worst < 1e-4 * max(1.0, max(float(out[k].abs().max()) for k in ("psm", "rm", "obj"))), worst
+    assert abs(float(mine[0]) - float(total)) < 1e-5 * max(1.0, abs(float(total))), (float(mine[0]), float(total))
+    fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types), "n_points": np.int64(n_points),
+          "pos_frac": np.float64(pos_frac), "comm_rate": np.float64(out["comm_rate"]),
+          "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)}
+    fx["head_stride"] = np.int64(head_stride)
+    fx["head_hw"] = np.asarray([H, W], np.int64)
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k].detach().numpy()[..., ::head_stride, ::head_stride]
+    o64, l64, sd64 = oracle_step(torch.float64)
+    fx["loss64"] = np.float64(float(l64[0]))
+    names, gworst, devs = [], 0.0, []
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            assert sd2[k].grad is None or float(sd2[k].grad.abs().max()) == 0.0, k
+            continue
+        if sd2[k].grad is None:
+            assert float(p_.grad.abs().max()) == 0.0, k
+            continue
+        g, go, g64 = p_.grad.detach().reshape(-1), sd2[k].grad.reshape(-1), sd64[k].grad.reshape(-1)
+        gworst = max(gworst, (g - go).abs().max().item() / max(g.abs().max().item(), 1e-12))
+        stride = max(1, g.numel() // 4096)
+        names.append(k)
+        fx["g:" + k] = g[::stride].numpy()
+        fx["gsum:" + k] = np.asarray([g.double().sum().item(), g.double().abs().sum().item(), g.abs().max().item()], np.float64)
+        fx["g64:" + k] = g64[::stride].float().numpy()
+        fx["g64max:" + k] = np.float64(float(g64.abs().max()))
+        d = np.abs(fx["g:" + k].astype(np.float64) - g64[::stride].numpy()).max() / max(float(g64.abs().max()), 1e-300)
+        fx["gdev:" + k] = np.float64(d)
+        devs.append((d, k))
+    assert gworst < 2e-3, gworst
+    fx["grad_keys"] = np.asarray(names)
+    devs.sort(reverse=True)
+    bworst = 0.0
+    for k, b in model.named_buffers():
+        fx["b:" + k] = b.detach().numpy()
+        bworst = max(bworst, (b.double() - sd2[k].detach().double()).abs().max().item() / max(1.0, b.double().abs().max().item()))
+    assert bworst < 1e-5, bworst
+    print(f"[{name}] total {float(total):.6f} (float64 {float(l64[0]):.6f}); oracle vs reference: heads {worst:.2e}, grads {gworst:.2e}, buffers {bworst:.2e}; "
+          f"{len(names)} gradients; reference fp32 vs float64 gradients: worst {devs[0][0]:.2e} ({devs[0][1]}), median {devs[len(devs) // 2][0]:.2e}")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _load_ref_hypes_v2xvit(lidar_range, max_cav):
     from opencood.hypes_yaml.yaml_utils import load_yaml
     src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_v2xvit.yaml")
@@ -1840,6 +1962,8 @@ GROUPS = {
                              train_v2xvit_golden("train_v2xvit_small_n2", SMALL, ["vehicle", "vehicle"], 900, 17)),
     # the BASELINE grid (704 x 200, 4 agents x 8192 points): one training step of the reference's CoBEVT / V2X-ViT (tens of minutes of CPU:
     # the reference's step, the oracle's fp32 step and the oracle's float64 step)
+    "train_when2com": lambda: (train_when2com_golden("train_when2com_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 24),
+                               train_when2com_golden("train_when2com_small_n2", SMALL, ["vehicle", "vehicle"], 900, 25)),
     "train_cobevt_full": lambda: train_cobevt_golden("train_cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 18,
                                                      max_cav=(3, 2, 2), pos_frac=0.002, head_stride=4),
     "train_v2xvit_full": lambda: train_v2xvit_golden("train_v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 19,
