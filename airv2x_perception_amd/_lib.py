@@ -47,6 +47,10 @@ SIGNATURES = {
                                    c_uint64, c_void_p]),
     "av2x_linear_rows_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),
+    "av2x_gru_gate": (c_int32, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
+    "av2x_gru_gate_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "av2x_agent_argmax": (c_int32, [c_void_p, c_int32, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "av2x_agent_argmax_backward": (c_int32, [c_void_p, c_void_p, c_int32, c_uint64, c_void_p, c_void_p]),
     "av2x_when2com_fuse_backward_workspace_bytes": (c_uint64, [c_int32]),
     "av2x_when2com_fuse_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),

@@ -143,7 +143,101 @@ __global__ __launch_bounds__(256) void fuse_scale_kernel(const f4* __restrict__ 
     }
 }
 
+// ---- V2VNet (models/v2vnet_modules/v2v_fuse.py:110-170, convgru.py:52-73): the one-step ConvGRU with a zero hidden state reduces to
+// out = sigmoid(update gate) * tanh(candidate); the "max" aggregation over the neighbours' messages routes the gradient to the first maximum.
+__global__ __launch_bounds__(256) void gru_gate_kernel(const f4* __restrict__ beta, const f4* __restrict__ cnm, f4* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f4 b = beta[i], c = cnm[i];
+        out[i] = f4{tanhf(c.x) / (1.f + expf(-b.x)), tanhf(c.y) / (1.f + expf(-b.y)), tanhf(c.z) / (1.f + expf(-b.z)), tanhf(c.w) / (1.f + expf(-b.w))};
+    }
+}
+
+struct GateGrad { float db, dc; };
+__device__ __forceinline__ GateGrad gru_gate_grad(float b, float c, float d) {
+    const float u = 1.f / (1.f + expf(-b)), t = tanhf(c);
+    return GateGrad{d * t * u * (1.f - u), d * u * (1.f - t * t)};
+}
+
+__global__ __launch_bounds__(256) void gru_gate_backward_kernel(const f4* __restrict__ beta, const f4* __restrict__ cnm, const f4* __restrict__ dout,
+                                                                f4* __restrict__ dbeta, f4* __restrict__ dcnm, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f4 b = beta[i], c = cnm[i], d = dout[i];
+        const GateGrad g0 = gru_gate_grad(b.x, c.x, d.x), g1 = gru_gate_grad(b.y, c.y, d.y), g2 = gru_gate_grad(b.z, c.z, d.z),
+                       g3 = gru_gate_grad(b.w, c.w, d.w);
+        dbeta[i] = f4{g0.db, g1.db, g2.db, g3.db};
+        dcnm[i] = f4{g0.dc, g1.dc, g2.dc, g3.dc};
+    }
+}
+
+__global__ __launch_bounds__(256) void agent_max_kernel(const float* __restrict__ x, int n, size_t elems, float* __restrict__ out, uint8_t* __restrict__ idx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+        float m = x[i];
+        int k = 0;
+        for (int j = 1; j < n; ++j) {
+            const float v = x[(size_t)j * elems + i];
+            if (v > m) { m = v; k = j; }        // the FIRST maximum keeps the gradient (torch.max over a dim on ties)
+        }
+        out[i] = m;
+        idx[i] = (uint8_t)k;
+    }
+}
+
+__global__ __launch_bounds__(256) void agent_max_backward_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ idx, int n, size_t elems,
+                                                                 float* __restrict__ dx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = dout[i];
+        const int k = idx[i];
+        for (int j = 0; j < n; ++j) dx[(size_t)j * elems + i] = j == k ? d : 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int av2x_gru_gate(const float* beta, const float* cnm, uint64_t n_elems, float* out, av2x_stream_t stream) {
+    if (n_elems == 0) return 0;
+    if (!beta || !cnm || !out) return av2x::fail("av2x_gru_gate: null argument");
+    if (n_elems % 4) return av2x::fail("av2x_gru_gate: element count must be a multiple of 4");
+    size_t blocks = (n_elems / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gru_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const f4*>(beta),
+                       reinterpret_cast<const f4*>(cnm), reinterpret_cast<f4*>(out), (size_t)(n_elems / 4));
+    return av2x::check_launch("gru_gate_kernel");
+}
+
+extern "C" int av2x_gru_gate_backward(const float* beta, const float* cnm, const float* dout, uint64_t n_elems, float* dbeta, float* dcnm,
+                                      av2x_stream_t stream) {
+    if (n_elems == 0) return 0;
+    if (!beta || !cnm || !dout || !dbeta || !dcnm) return av2x::fail("av2x_gru_gate_backward: null argument");
+    if (n_elems % 4) return av2x::fail("av2x_gru_gate_backward: element count must be a multiple of 4");
+    size_t blocks = (n_elems / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gru_gate_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const f4*>(beta),
+                       reinterpret_cast<const f4*>(cnm), reinterpret_cast<const f4*>(dout), reinterpret_cast<f4*>(dbeta), reinterpret_cast<f4*>(dcnm),
+                       (size_t)(n_elems / 4));
+    return av2x::check_launch("gru_gate_backward_kernel");
+}
+
+extern "C" int av2x_agent_argmax(const float* x, int32_t n_agents, uint64_t elems_per_agent, float* out, uint8_t* index, av2x_stream_t stream) {
+    if (elems_per_agent == 0) return 0;
+    if (!x || !out || !index) return av2x::fail("av2x_agent_argmax: null argument");
+    if (n_agents < 1 || n_agents > 255) return av2x::fail("av2x_agent_argmax: n_agents=%d outside [1,255]", n_agents);
+    size_t blocks = (elems_per_agent + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(agent_max_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), x, n_agents, (size_t)elems_per_agent, out, index);
+    return av2x::check_launch("agent_max_kernel");
+}
+
+extern "C" int av2x_agent_argmax_backward(const float* dout, const uint8_t* index, int32_t n_agents, uint64_t elems_per_agent, float* dx,
+                                       av2x_stream_t stream) {
+    if (elems_per_agent == 0) return 0;
+    if (!dout || !index || !dx) return av2x::fail("av2x_agent_argmax_backward: null argument");
+    if (n_agents < 1 || n_agents > 255) return av2x::fail("av2x_agent_argmax_backward: n_agents=%d outside [1,255]", n_agents);
+    size_t blocks = (elems_per_agent + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(agent_max_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), dout, index, n_agents,
+                       (size_t)elems_per_agent, dx);
+    return av2x::check_launch("agent_max_backward_kernel");
+}
 
 extern "C" int av2x_linear_rows_backward(const float* x, const float* w, const float* y, const float* dy, int32_t m, int32_t n, int32_t k,
                                          int32_t act, float* dx, float* dw, float* db, av2x_stream_t stream) {

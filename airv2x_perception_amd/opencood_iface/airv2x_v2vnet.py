@@ -24,6 +24,10 @@ class Airv2xV2VNet(nn.Module):
         self.active_sensors = args["active_sensors"]
         self.outC = args["outC"]
         _declare(self, v2vnet_param_spec(args))
+        for p in self.parameters():        # trainable, as the reference's nn.Modules are (train_v2vnet.py is the train-mode forward)
+            p.requires_grad_(True)
+        if args.get("backbone_fix"):
+            self.backbone_fix()
         self._engine = None
         self._packed_version = None
         self.sync_comm_rate = True   # the reference returns a python float (v2v_fuse.py:172)
@@ -44,9 +48,17 @@ class Airv2xV2VNet(nn.Module):
             self._packed_version = ver
         return self._engine
 
+    def backbone_fix(self):
+        """airv2x_v2vnet.py:143-189 (fine-tuning on time delay): freeze the encoders, backbone, shrink header and heads; the fusion net
+        stays trainable."""
+        for name, p in self.named_parameters():
+            if not name.startswith("fusion_net."):
+                p.requires_grad = False
+
     def forward(self, data_dict):
-        if self.training:
-            raise NotImplementedError("training is not built yet; call .eval()")
+        if self.training:      # HIP forward / backward ops under torch autograd (train_v2vnet.py)
+            from .train_v2vnet import forward_train
+            return forward_train(self, data_dict)
         eng = self.engine()
         eng.amp = _amp_requested(self)
         return eng.forward(data_dict, sync_comm_rate=self.sync_comm_rate)

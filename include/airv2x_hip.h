@@ -796,6 +796,16 @@ int av2x_voxelize_dummy_if_empty(const float* range6, const float* voxel3, int32
  * av2x_warp_affine_simple_backward (declared with av2x_warp_affine_backward): the adjoint of av2x_warp_affine_simple. */
 int av2x_linear_rows_backward(const float* x, const float* w, const float* y, const float* dy, int32_t m, int32_t n, int32_t k,
                               int32_t act, float* dx, float* dw, float* db, av2x_stream_t stream);
+/* V2VNet training pieces (v2vnet_modules/v2v_fuse.py:110-170, convgru.py:52-73; forward: av2x_v2v_aggregate):
+ * av2x_gru_gate: the one-step ConvGRU with a zero hidden state, out = sigmoid(beta) * tanh(cnm) over n_elems (% 4 == 0) elements
+ *   (beta = the update-gate half of conv_gates, cnm = conv_can; the reset gate multiplies the zero state), and its gradient.
+ * av2x_agent_argmax: out[e] = max_j x[j][e] with index[e] = the first maximising agent (torch.max over dim 0), and the gradient routed to it. */
+int av2x_gru_gate(const float* beta, const float* cnm, uint64_t n_elems, float* out, av2x_stream_t stream);
+int av2x_gru_gate_backward(const float* beta, const float* cnm, const float* dout, uint64_t n_elems, float* dbeta, float* dcnm,
+                           av2x_stream_t stream);
+int av2x_agent_argmax(const float* x, int32_t n_agents, uint64_t elems_per_agent, float* out, uint8_t* index, av2x_stream_t stream);
+int av2x_agent_argmax_backward(const float* dout, const uint8_t* index, int32_t n_agents, uint64_t elems_per_agent, float* dx,
+                            av2x_stream_t stream);
 uint64_t av2x_when2com_fuse_backward_workspace_bytes(int32_t n_agents);
 int av2x_when2com_fuse_backward(const float* keys, const float* query, const float* coef, int32_t n_agents, int32_t key_size,
                                 const float* const* agents, uint64_t elems_per_agent, const float* dout, float* const* dagents,

@@ -1557,59 +1557,19 @@ def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2,
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def train_when2com_golden(name, lidar_range, types, n_points, seed, pos_frac=0.01, head_stride=1):
-    """One TRAINING step of the reference's Airv2xWhen2com (train mode: BatchNorm batch statistics in the trunk AND in policy_net4)
-    + PointPillarLossMultiClass + torch autograd; layout of train_cobevt_golden: heads, losses, the gradient of every parameter
-    (strided samples + sums), every buffer after the step, and the same step in float64 as the yardstick.  oracle/when2com_oracle.py
-    under train_mode() must reproduce it."""
+def _train_step_fixture(name, model, sd, args, la, data, oracle_forward, seed, rng, types, n_points, pos_frac, head_stride, extra=None):
+    """The common part of the training-step fixtures of the models that share the Where2Comm trunk: the reference ``model`` (in .train())
+    on ``data()`` + PointPillarLossMultiClass + torch autograd -> heads, losses, the gradient of every parameter (strided samples + sums),
+    every buffer after the step, and the same step in float64 (``oracle_forward(d, sd, args)`` under train_mode()) as the yardstick; the
+    fp32 oracle step must reproduce the reference's."""
     from airv2x_perception_amd import synth
     from oracle import loss_oracle as lo
-    from oracle import voxelize_oracle as vox
-    from oracle import when2com_oracle as w2
     from oracle import where2comm_oracle as orc
-    _stub("opencood.models.task_heads.segmentation_head", BevSegHead=object)
-    from opencood.hypes_yaml.yaml_utils import load_yaml
     from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
-    from opencood.models.airv2x_when2com import Airv2xWhen2com
-
-    src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_when2com.yaml")
-    txt = open(src).read()
-    hy = synth.default_hypes_when2com(lidar_range)
-    if lidar_range is not None:
-        r = lidar_range
-        txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
-        w = hy["model"]["args"]["when2com_fusion"]
-        txt = txt.replace("      H: 100", f"      H: {w['H']}").replace("      W: 352", f"      W: {w['W']}")
-    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
-        f.write(txt)
-        path = f.name
-    hy_ref = load_yaml(path)
-    os.unlink(path)
-    check_hypes(hy_ref["model"]["args"], hy["model"]["args"])
-    args = hy["model"]["args"]
-    model = Airv2xWhen2com(hy_ref["model"]["args"]).train()
-    spec = synth.when2com_param_spec(args)
-    assert [k for k, _, _ in spec] == list(model.state_dict().keys())
-    sd = synth.synthetic_state_dict(spec, seed=seed)
-    model.load_state_dict(sd, strict=True)
-    rng = lidar_range or synth.DEFAULT_RANGE
-    pp = hy["preprocess"]
-    voxd = []
-    for i, t in enumerate(types):
-        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
-        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
-                                         pp["args"]["max_voxel_train"]))
-    pair = synth.when2com_pairwise(len(types), args["max_cav_num"])
-
-    def data():
-        d = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
-        d["img_pairwise_t_matrix_collab"] = pair.clone()
-        return d
     out = model(data())
     H, W = out["psm"].shape[-2:]
     lc = synth.loss_case(seed + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=pos_frac)
     tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
-    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
     crit = PointPillarLossMultiClass(la)
     total = crit(out, tgt)
     total.backward()
@@ -1627,7 +1587,7 @@ def train_when2com_golden(name, lidar_range, types, n_points, seed, pos_frac=0.0
                 if lid is not None:
                     lid["voxel_features"] = lid["voxel_features"].double()
         with orc.train_mode():
-            o = w2.when2com_forward(d2, sd2, args)
+            o = oracle_forward(d2, sd2, args)
         l_ = lo.pp_loss(o["psm"], o["rm"], o["obj"], tgt["targets"].to(dtype), tgt["pos_equal_one"].to(dtype), tgt["class_ids"],
                         la["num_class"], la["cls_weight"], la["reg"])
         l_[0].backward()
@@ -1637,7 +1597,7 @@ def train_when2com_golden(name, lidar_range, types, n_points, seed, pos_frac=0.0
     assert worst < 1e-4 * max(1.0, max(float(out[k].abs().max()) for k in ("psm", "rm", "obj"))), worst
     assert abs(float(mine[0]) - float(total)) < 1e-5 * max(1.0, abs(float(total))), (float(mine[0]), float(total))
     fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types), "n_points": np.int64(n_points),
-          "pos_frac": np.float64(pos_frac), "comm_rate": np.float64(out["comm_rate"]),
+          "pos_frac": np.float64(pos_frac), "comm_rate": np.float64(out["comm_rate"]), **(extra or {}),
           "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)}
     fx["head_stride"] = np.int64(head_stride)
     fx["head_hw"] = np.asarray([H, W], np.int64)
@@ -1677,6 +1637,101 @@ def train_when2com_golden(name, lidar_range, types, n_points, seed, pos_frac=0.0
     path = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(path, **fx)
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+
+
+def train_when2com_golden(name, lidar_range, types, n_points, seed, pos_frac=0.01, head_stride=1):
+    """One TRAINING step of the reference's Airv2xWhen2com (train mode: BatchNorm batch statistics in the trunk AND in policy_net4)
+    + PointPillarLossMultiClass + torch autograd; layout of train_cobevt_golden: heads, losses, the gradient of every parameter
+    (strided samples + sums), every buffer after the step, and the same step in float64 as the yardstick.  oracle/when2com_oracle.py
+    under train_mode() must reproduce it."""
+    from airv2x_perception_amd import synth
+    from oracle import loss_oracle as lo
+    from oracle import voxelize_oracle as vox
+    from oracle import when2com_oracle as w2
+    from oracle import where2comm_oracle as orc
+    _stub("opencood.models.task_heads.segmentation_head", BevSegHead=object)
+    from opencood.hypes_yaml.yaml_utils import load_yaml
+    from opencood.models.airv2x_when2com import Airv2xWhen2com
+
+    src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_when2com.yaml")
+    txt = open(src).read()
+    hy = synth.default_hypes_when2com(lidar_range)
+    if lidar_range is not None:
+        r = lidar_range
+        txt = txt.replace("-140.8, -40,", f"{r[0]}, {r[1]},").replace("140.8, 40,", f"{r[3]}, {r[4]},")
+        w = hy["model"]["args"]["when2com_fusion"]
+        txt = txt.replace("      H: 100", f"      H: {w['H']}").replace("      W: 352", f"      W: {w['W']}")
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write(txt)
+        path = f.name
+    hy_ref = load_yaml(path)
+    os.unlink(path)
+    check_hypes(hy_ref["model"]["args"], hy["model"]["args"])
+    args = hy["model"]["args"]
+    model = Airv2xWhen2com(hy_ref["model"]["args"]).train()
+    spec = synth.when2com_param_spec(args)
+    assert [k for k, _, _ in spec] == list(model.state_dict().keys())
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_train"]))
+    pair = synth.when2com_pairwise(len(types), args["max_cav_num"])
+
+    def data():
+        d = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+        d["img_pairwise_t_matrix_collab"] = pair.clone()
+        return d
+    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
+    _train_step_fixture(name, model, sd, args, la, data, w2.when2com_forward, seed, rng, types, n_points, pos_frac, head_stride)
+
+
+def train_v2vnet_golden(name, lidar_range, types, n_points, seed, agg="avg", pos_frac=0.01, head_stride=1):
+    """One TRAINING step of the reference's Airv2xV2VNet (constructed as run_v2vnet_case does: the maintained base class, the Where2Comm
+    AirV2X YAML's trunk + a `v2vfusion` block) + PointPillarLossMultiClass + torch autograd; layout of train_when2com_golden."""
+    from airv2x_perception_amd import synth
+    from oracle import v2vnet_oracle as v2v
+    from oracle import voxelize_oracle as vox
+    _stub("opencood.models.task_heads.segmentation_head", BevSegHead=object)
+    from opencood.models.common_modules.airv2x_base_model import Airv2xBase
+    _stub("opencood.models.airv2x_bm2cp", Airv2xBase=Airv2xBase)
+    from opencood.models.airv2x_v2vnet import Airv2xV2VNet
+
+    hy = synth.default_hypes_v2vnet(lidar_range, agg=agg)
+    args = hy["model"]["args"]
+    hy_ref = load_ref_hypes(lidar_range)
+    a_ref = hy_ref["model"]["args"]
+    a_ref.pop("where2com_fusion")
+    a_ref["v2vfusion"] = synth.clone_hypes(args["v2vfusion"])
+    a_ref["backbone_fix"] = False
+    check_hypes(a_ref, args)
+    model = Airv2xV2VNet(a_ref).train()
+    spec = synth.v2vnet_param_spec(args)
+    assert [k for k, _, _ in spec] == list(model.state_dict().keys())
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, t in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_train"]))
+    pair = synth.v2vnet_pairwise(len(types), args["max_cav_num"])
+
+    def data():
+        d = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+        d["img_pairwise_t_matrix_collab"] = pair.clone()
+        return d
+    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
+    _train_step_fixture(name, model, sd, args, la, data, v2v.v2vnet_forward, seed, rng, types, n_points, pos_frac, head_stride,
+                        extra={"agg": np.asarray(agg)})
 
 
 def _load_ref_hypes_v2xvit(lidar_range, max_cav):
@@ -1964,6 +2019,8 @@ GROUPS = {
     # the reference's step, the oracle's fp32 step and the oracle's float64 step)
     "train_when2com": lambda: (train_when2com_golden("train_when2com_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 24),
                                train_when2com_golden("train_when2com_small_n2", SMALL, ["vehicle", "vehicle"], 900, 25)),
+    "train_v2vnet": lambda: (train_v2vnet_golden("train_v2vnet_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 26),
+                             train_v2vnet_golden("train_v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 900, 27, agg="max")),
     "train_cobevt_full": lambda: train_cobevt_golden("train_cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 18,
                                                      max_cav=(3, 2, 2), pos_frac=0.002, head_stride=4),
     "train_v2xvit_full": lambda: train_v2xvit_golden("train_v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 19,
