@@ -72,7 +72,7 @@ def _model(args, sd):
     return m.cuda().train()
 
 
-@pytest.mark.parametrize("name", ["train_v2vnet_small_n3", "train_v2vnet_small_n2_max"])
+@pytest.mark.parametrize("name", ["train_v2vnet_small_n3", "train_v2vnet_small_n2_max", "train_v2vnet_full_n3"])
 def test_v2vnet_training_step_matches_the_reference(name):
     fx = load_fixture(name)
     hy, args, sd, dd, tgt = _case(fx)

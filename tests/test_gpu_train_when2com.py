@@ -133,7 +133,7 @@ def _loss(args):
     return PointPillarLossMultiClass({"cls_weight": 1.0, "reg": 2.0, "num_class": args["num_class"]})
 
 
-@pytest.mark.parametrize("name", ["train_when2com_small_n3", "train_when2com_small_n2"])
+@pytest.mark.parametrize("name", ["train_when2com_small_n3", "train_when2com_small_n2", "train_when2com_full_n3"])
 def test_when2com_training_step_matches_the_reference(name):
     fx = load_fixture(name)
     hy, args, sd, dd, tgt = _case(fx)

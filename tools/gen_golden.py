@@ -2021,6 +2021,8 @@ GROUPS = {
                                train_when2com_golden("train_when2com_small_n2", SMALL, ["vehicle", "vehicle"], 900, 25)),
     "train_v2vnet": lambda: (train_v2vnet_golden("train_v2vnet_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 26),
                              train_v2vnet_golden("train_v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 900, 27, agg="max")),
+    "train_when2com_full": lambda: train_when2com_golden("train_when2com_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 28, head_stride=4),
+    "train_v2vnet_full": lambda: train_v2vnet_golden("train_v2vnet_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 29, head_stride=4),
     "train_cobevt_full": lambda: train_cobevt_golden("train_cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 18,
                                                      max_cav=(3, 2, 2), pos_frac=0.002, head_stride=4),
     "train_v2xvit_full": lambda: train_v2xvit_golden("train_v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 19,
@@ -2036,7 +2038,7 @@ def main(groups=None):
     import_reference()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    for g in (groups or [g for g in GROUPS if g not in ("full", "train_full", "camera_full", "train_cobevt_full", "train_v2xvit_full")]):
+    for g in (groups or [g for g in GROUPS if g not in ("full", "train_full", "camera_full", "train_cobevt_full", "train_v2xvit_full", "train_when2com_full", "train_v2vnet_full")]):
         if g not in GROUPS:
             raise SystemExit(f"unknown group {g!r}; one of {sorted(GROUPS)}")
         GROUPS[g]()

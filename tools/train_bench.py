@@ -1,4 +1,4 @@
-"""One training step of Airv2xWhere2com / Airv2xCoBEVT / Airv2xV2XVit (--model) on the default AirV2X grid (704 x 200 canvas, N agents x 8192 points), on the device:
+"""One training step of Airv2xWhere2com / Airv2xCoBEVT / Airv2xV2XVit / Airv2xWhen2com / Airv2xV2VNet (--model) on the default AirV2X grid (704 x 200 canvas, N agents x 8192 points), on the device:
 train-mode forward (BatchNorm batch statistics, random top-K mask), PointPillarLossMultiClass, backward, Adam step.
 Prints one JSON line: ms per step (forward / loss+backward / optimiser), peak memory, and -- with --cpu -- the oracle's
 (torch CPU autograd) time for the same step.  Not the headline metric (BASELINE.json's is inference frames/s)."""
@@ -25,7 +25,9 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
     from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
     Model, hypes_fn, spec_fn = {"where2com": (oi.Airv2xWhere2com, synth.default_hypes, synth.where2com_param_spec),
                                 "cobevt": (oi.Airv2xCoBEVT, synth.default_hypes_cobevt, synth.cobevt_param_spec),
-                                "v2xvit": (oi.Airv2xV2XVit, synth.default_hypes_v2xvit, synth.v2xvit_param_spec)}[model_name]
+                                "v2xvit": (oi.Airv2xV2XVit, synth.default_hypes_v2xvit, synth.v2xvit_param_spec),
+                                "when2com": (oi.Airv2xWhen2com, synth.default_hypes_when2com, synth.when2com_param_spec),
+                                "v2vnet": (oi.Airv2xV2VNet, synth.default_hypes_v2vnet, synth.v2vnet_param_spec)}[model_name]
     dev = dev or torch.device("cuda", 0)
     dd_host = None
     if dd is None:
@@ -46,6 +48,10 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
             for i in range(1, a.agents):
                 scm[0, i] = torch.from_numpy(synth.se2_correction(g_.uniform(-10, 10), g_.uniform(-8, 8), g_.uniform(-8, 8)))
             dd_host["spatial_correction_matrix"] = scm
+        if model_name == "when2com":
+            dd_host["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(a.agents, args["max_cav_num"])
+        if model_name == "v2vnet":
+            dd_host["img_pairwise_t_matrix_collab"] = synth.v2vnet_pairwise(a.agents, args["max_cav_num"])
         dd = synth.data_dict_to(dd_host, dev)
     sd = synth.synthetic_state_dict(spec_fn(args), seed=0)
     model = Model(args)
@@ -177,7 +183,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu", action="store_true", help="also time one oracle step on the host cores")
     ap.add_argument("--small", action="store_true", help="128 x 64 canvas (smoke)")
-    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit"], default="where2com")
+    ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit", "when2com", "v2vnet"], default="where2com")
     ap.add_argument("--amp", action="store_true", help="autocast(bf16) + GradScaler around the step (tools/train.py --amp of the reference)")
     a = ap.parse_args()
     print(json.dumps(run(a.agents, a.steps, a.warmup, a.small, a.cpu and a.model == "where2com", model_name=a.model, amp=a.amp)))
