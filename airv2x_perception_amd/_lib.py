@@ -47,6 +47,17 @@ SIGNATURES = {
                                    c_uint64, c_void_p]),
     "av2x_linear_rows_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),
+    "av2x_unary_forward": (c_int32, [c_void_p, c_uint64, c_int32, c_void_p, c_void_p]),
+    "av2x_unary_backward": (c_int32, [c_void_p, c_void_p, c_uint64, c_int32, c_void_p, c_void_p]),
+    "av2x_add_act": (c_int32, [c_void_p, c_void_p, c_uint64, c_int32, c_void_p, c_void_p]),
+    "av2x_gap_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
+    "av2x_gap": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "av2x_channel_broadcast": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p]),
+    "av2x_resize_bilinear_backward_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
+    "av2x_resize_bilinear_backward": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "av2x_lss_lift_pool_backward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                              c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
     "av2x_gru_gate": (c_int32, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
     "av2x_gru_gate_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
     "av2x_agent_argmax": (c_int32, [c_void_p, c_int32, c_uint64, c_void_p, c_void_p, c_void_p]),

@@ -524,6 +524,70 @@ extern "C" int av2x_lss_lift_pool(const float* feat, const float* prob, const fl
     return av2x::check_launch("lift_pool");
 }
 
+// ---- training: the adjoint of the ground-truth-depth lift (what torch autograd gives the reference for voxel_pooling's index_put /
+// cumsum trick, airv2x_encoder.py:208-275, and the one-hot product of CamEncode.forward :170-175): every feature pixel went to ONE voxel
+// (or none), so its gradient is a gather from that voxel -- no atomics, run-to-run identical.
+template <int LPP>
+__global__ __launch_bounds__(256) void lift_pool_gt_backward_kernel(const float* __restrict__ dout, const float* __restrict__ imgs, int planes, int H,
+                                                                    int W, int ds, DepthBins db, const float* __restrict__ frustum,
+                                                                    const LiftCam* __restrict__ cams, LiftGrid g, int fH, int fW, int cams_per_batch,
+                                                                    long long npix, int C, float* __restrict__ dfeat) {
+    const int t = threadIdx.x % LPP;
+    const long long p = (long long)blockIdx.x * (256 / LPP) + threadIdx.x / LPP;
+    if (p >= npix) return;
+    const int fw = (int)(p % fW);
+    const long long r = p / fW;
+    const int fh = (int)(r % fH);
+    const int cam = (int)(r / fH);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d = imgs[(((size_t)cam * planes + 3) * H + (ds / 2 + fh * ds)) * W + (ds / 2 + fw * ds)];
+    d = fminf(d, db.dmax);
+    float idx;
+    if (db.mode == 0) idx = __fdiv_rn(__fsub_rn(d, db.dmin), db.bin);
+    else idx = __fadd_rn(-0.5f, __fmul_rn(0.5f, __fsqrt_rn(__fadd_rn(1.0f, __fdiv_rn(__fmul_rn(8.0f, __fsub_rn(d, db.dmin)), db.bin)))));
+    const bool bad = (idx < 0.f) || (idx >= (float)db.nbins) || !isfinite(idx);
+    if (!(bad && !db.target)) {
+        int bin;
+        if (!isfinite(idx)) bin = db.nbins - 1;
+        else if (idx < 0.f) bin = 0;
+        else if (idx >= (float)db.nbins) bin = db.nbins - 1;
+        else bin = (int)idx;
+        const int fp = (bin * fH + fh) * fW + fw;
+        int ix, iy, iz;
+        if (lift_voxel(cams[cam], g, frustum[3 * fp + 0], frustum[3 * fp + 1], frustum[3 * fp + 2], ix, iy, iz)) {
+            const int b = cam / cams_per_batch;
+            const size_t cell = (((size_t)b * g.nx[2] + iz) * g.nx[1] + iy) * g.nx[0] + ix;
+            o = *reinterpret_cast<const float4*>(dout + cell * C + 4 * t);
+        }
+    }
+    *reinterpret_cast<float4*>(dfeat + (size_t)p * C + 4 * t) = o;
+}
+
+extern "C" int av2x_lss_lift_pool_backward(const float* dout, const float* imgs, int32_t planes, int32_t img_h, int32_t img_w, int32_t downsample,
+                                           const float* depth3, int32_t nbins, int32_t depth_mode, int32_t target, const float* frustum,
+                                           const float* cam_params, int32_t b, int32_t n_cams, int32_t fh, int32_t fw, int32_t c, const float* lo3,
+                                           const float* dx3, const int32_t* nx3, float* dfeat, av2x_stream_t stream) {
+    if (!dout || !imgs || !depth3 || !frustum || !cam_params || !lo3 || !dx3 || !nx3 || !dfeat) return av2x::fail("av2x_lss_lift_pool_backward: null argument");
+    if (b <= 0 || n_cams <= 0 || fh <= 0 || fw <= 0 || nbins <= 0) return av2x::fail("av2x_lss_lift_pool_backward: bad sizes");
+    if (c != 32 && c != 64 && c != 128) return av2x::fail("av2x_lss_lift_pool_backward: c=%d (32, 64 or 128 feature channels)", c);
+    if (planes < 4) return av2x::fail("av2x_lss_lift_pool_backward: the ground-truth depth is plane 3 of a (>= 4)-plane image");
+    if (downsample <= 0 || downsample / 2 + (fh - 1) * downsample >= img_h || downsample / 2 + (fw - 1) * downsample >= img_w)
+        return av2x::fail("av2x_lss_lift_pool_backward: feature map %dx%d x downsample %d exceeds the image %dx%d", fh, fw, downsample, img_h, img_w);
+    if (depth_mode != 0 && depth_mode != 1) return av2x::fail("av2x_lss_lift_pool_backward: depth_mode %d (0 UD, 1 LID)", depth_mode);
+    LiftGrid g;
+    for (int i = 0; i < 3; ++i) { g.lo[i] = lo3[i]; g.dx[i] = dx3[i]; g.nx[i] = nx3[i]; }
+    hipStream_t st = av2x::as_stream(stream);
+    const LiftCam* cams = reinterpret_cast<const LiftCam*>(cam_params);
+    const long long npix = (long long)b * n_cams * fh * fw;
+    DepthBins db{depth3[0], depth3[1], depth3[2], nbins, depth_mode, target};
+#define AV2X_LIFT_GTB(LPP)                                                                                                                       \
+    hipLaunchKernelGGL(lift_pool_gt_backward_kernel<LPP>, dim3((unsigned)((npix + (256 / LPP) - 1) / (256 / LPP))), dim3(256), 0, st, dout, imgs, \
+                       planes, img_h, img_w, downsample, db, frustum, cams, g, fh, fw, n_cams, npix, c, dfeat)
+    if (c == 32) AV2X_LIFT_GTB(8); else if (c == 64) AV2X_LIFT_GTB(16); else AV2X_LIFT_GTB(32);
+#undef AV2X_LIFT_GTB
+    return av2x::check_launch("lift_pool_gt_backward_kernel");
+}
+
 extern "C" int av2x_mean2(const float* a, const float* b, float* out, uint64_t n, av2x_stream_t stream) {
     if (!a || !out || n % 4) return av2x::fail("av2x_mean2: null argument or n %% 4 != 0");
     if (n == 0) return 0;

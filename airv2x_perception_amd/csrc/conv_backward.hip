@@ -347,7 +347,7 @@ extern "C" int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const 
                                  av2x_stream_t stream) {
     if (!d || !x || !dy || !workspace || !dw) return av2x::fail("av2x_conv2d_wgrad: null argument");
     if (d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d_wgrad: plain convolutions only (mode AV2X_CONV)");
-    if (d->ks != 1 && d->ks != 3) return av2x::fail("av2x_conv2d_wgrad: ks=%d unsupported", d->ks);
+    if (d->ks != 1 && d->ks != 3 && d->ks != 5 && d->ks != 7) return av2x::fail("av2x_conv2d_wgrad: ks=%d unsupported (1, 3, 5, 7)", d->ks);
     if (d->cin % 4 || d->cout % 4 || d->in_ctot % 4 || d->in_coff % 4 || d->out_ctot % 4 || d->out_coff % 4)
         return av2x::fail("av2x_conv2d_wgrad: channel counts / offsets must be multiples of 4");
     if (d->ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1 || d->wo != (d->w + 2 * d->pad - d->ks) / d->stride + 1)

@@ -29,18 +29,19 @@ __device__ __forceinline__ void load_dz(float* sdz, const float* __restrict__ dy
 
 template <int M>
 __global__ __launch_bounds__(256) void linear_rows_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ y,
-                                                             int m, int n, int k, int act, float* __restrict__ dx, float* __restrict__ db) {
+                                                             int m, int n, int k, int act, float* __restrict__ dx, float* __restrict__ db,
+                                                             int db_acc) {
     extern __shared__ float sdz[];
     load_dz(sdz, dy, y, m, n, act);
-    if (db && blockIdx.x == 0) {      // bias gradient: column sums of dz, rows in order
+    if (db && blockIdx.x == 0) {      // bias gradient: column sums of dz, rows in order (db_acc: on top of the earlier row groups')
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
-            float s = 0.f;
+            float s = db_acc ? db[j] : 0.f;
             for (int i = 0; i < m; ++i) s += sdz[i * n + j];
             db[j] = s;
         }
     }
     const size_t k4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k4 * 4 >= (size_t)k) return;
+    if (k4 * 4 >= (size_t)k || !dx) return;
     f4 acc[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
@@ -255,11 +256,10 @@ extern "C" int av2x_linear_rows_backward(const float* x, const float* w, const f
         const size_t lds = (size_t)mm * n * sizeof(float);
         const float* ys = y ? y + (size_t)m0 * n : nullptr;
         if (dx || db) {
-            float* dbp = m0 == 0 ? db : nullptr;   // rows beyond the first group: folded in below
             if (mm <= 4) hipLaunchKernelGGL(linear_rows_dx_kernel<4>, dim3(kb), dim3(256), lds, st, w, dy + (size_t)m0 * n, ys, mm, n, k, act,
-                                            dx ? dx + (size_t)m0 * k : nullptr, dbp);
+                                            dx ? dx + (size_t)m0 * k : nullptr, db, m0 > 0 ? 1 : 0);
             else hipLaunchKernelGGL(linear_rows_dx_kernel<8>, dim3(kb), dim3(256), lds, st, w, dy + (size_t)m0 * n, ys, mm, n, k, act,
-                                    dx ? dx + (size_t)m0 * k : nullptr, dbp);
+                                    dx ? dx + (size_t)m0 * k : nullptr, db, m0 > 0 ? 1 : 0);
         }
         if (dw) {
             const dim3 grid(kb, (unsigned)((n + 31) / 32));
@@ -269,7 +269,6 @@ extern "C" int av2x_linear_rows_backward(const float* x, const float* w, const f
                                     m0 > 0 ? 1 : 0, dw);
         }
     }
-    if (db && m > kMaxM) return av2x::fail("av2x_linear_rows_backward: the bias gradient is formed for m <= %d rows", kMaxM);
     return av2x::check_launch("linear_rows_backward");
 }
 

@@ -113,8 +113,7 @@ class Airv2xWhere2com(nn.Module):
 
     def forward(self, data_dict):
         if self.training:   # the graph torch autograd differentiates, on the HIP forward / backward ops (train_where2com.py)
-            if any("cam" in self.args[t]["modalities"] for t in self.collaborators):
-                raise NotImplementedError("training through the camera encoder is not built (eval-mode forward only); LiDAR-only models train")
+            # camera branches train too (train_camera.py): EfficientNet-B0 CamEncode, the ground-truth-depth lift, BevEncode
             from .train_where2com import forward_train
             return forward_train(self, data_dict)
         eng = self.engine()

@@ -53,6 +53,51 @@ def _place_cin(w, segments, cin_p):
     return out
 
 
+class CameraGeometry:
+    """The weight-free part of one agent type's LiftSplatShootEncoder: frustum, BEV grid, depth bins and the per-camera matrices
+    (airv2x_encoder.py:31-167).  The training forward (train_camera.py) uses it on its own; CameraEncoder builds the same values."""
+
+    def __init__(self, cam_args, device):
+        self.cfg, self.device = cam_args, device
+        if cam_args["camera_encoder"] != "EfficientNet":
+            raise NotImplementedError("camera_encoder: only the EfficientNet trunk (the shipped AirV2X configs) is built")
+        if cam_args["img_downsample"] != 8:
+            raise NotImplementedError("img_downsample: 8 (the shipped AirV2X configs)")
+        g = cam_args["grid_conf"]
+        self.dx, self.bx, self.nx = gen_dx_bx(g["xbound"], g["ybound"], g["zbound"])
+        self.ds = int(cam_args["img_downsample"])
+        self.C = int(cam_args["img_features"])
+        self.outC = int(cam_args["bevout_feature"])
+        fr = create_frustum(g, cam_args["data_aug_conf"], self.ds)
+        self.D, self.fH, self.fW = [int(v) for v in fr.shape[:3]]
+        self.frustum = fr.contiguous().view(-1, 3).to(device)
+        lo = self.bx - self.dx / 2.0
+        self._lo = (c_float * 3)(*[float(v) for v in lo])
+        self._dx = (c_float * 3)(*[float(v) for v in self.dx])
+        self._nx = (c_int32 * 3)(*[int(v) for v in self.nx])
+        dmin, dmax, nb = g["ddiscr"]
+        if g["mode"] == "UD":
+            bin_size, self.depth_mode = (dmax - dmin) / nb, 0
+        elif g["mode"] == "LID":
+            bin_size, self.depth_mode = 2 * (dmax - dmin) / (nb * (1 + nb)), 1
+        else:
+            raise NotImplementedError(f"depth discretisation {g['mode']} (UD / LID)")
+        self._depth3 = (c_float * 3)(float(dmin), float(dmax), float(bin_size))
+        self.nbins = int(nb)
+        self.use_gt = bool(cam_args["use_depth_gt"])
+        if int(self.nx[2]) != 1:
+            raise NotImplementedError("camera BEV grid with more than one z cell")
+
+    def _cam_params(self, ci):
+        """(B*N, 24) device rows [inverse(post_rots) | post_trans | rots @ inverse(intrins) | trans] (airv2x_encoder.py:147-166)."""
+        f = lambda k: ci[k].detach().to("cpu", torch.float32)
+        rots, trans, intr, prot, ptr = f("rots"), f("trans"), f("intrinsics"), f("post_rots"), f("post_trans")
+        B, N = trans.shape[:2]
+        rows = torch.cat([torch.inverse(prot).reshape(B * N, 9), ptr.reshape(B * N, 3), rots.matmul(torch.inverse(intr)).reshape(B * N, 9),
+                          trans.reshape(B * N, 3)], 1).contiguous()
+        return rows.to(self.device)
+
+
 class CameraEncoder:
     """Packed weights + launch sequence of one agent type's LiftSplatShootEncoder.  ``eng``: the owning engine (workspace pool,
     conv launcher with its tile tuner, stream)."""

@@ -207,12 +207,14 @@ def conv_dgrad(dz, weight, stride, pad, in_hw, owner=None):
         if pad != ks // 2:
             raise NotImplementedError("'same' padding only")
         src = dz
-    elif stride == 2 and ks == 3 and pad == 1 and h == 2 * ho and w == 2 * wo:
+    elif stride == 2 and ks % 2 == 1 and pad == ks // 2 and 2 * (ho - 1) < h and 2 * (wo - 1) < w:
+        # y[i] = sum_k xpad[2 i + k] w[k]  =>  dx = the stride-1 'same' correlation of u (u[2 i] = dz[i], zeros elsewhere) with the flipped
+        # taps: 3x3 (the BEV backbone), 1x1 (ResNet's downsample shortcut) and 7x7 (BevEncode's first convolution) alike, even or odd sizes
         src = torch.zeros((n, h, w, cout), dtype=torch.float32, device=dz.device)
-        src[:, ::2, ::2] = dz
+        src[:, 0:2 * ho:2, 0:2 * wo:2] = dz
     else:
-        raise NotImplementedError("data gradient: stride 1, or 3x3 stride 2 pad 1 on even sizes (every layer of the BEV backbone)")
-    return conv_raw(src, weight, 1, ks // 2 if ks == 3 else 0, flipped=True, owner=owner)
+        raise NotImplementedError("data gradient: stride 1, or an odd kernel with stride 2 and pad = ks // 2")
+    return conv_raw(src, weight, 1, ks // 2, flipped=True, owner=owner)
 
 
 def bn_stats(z):

@@ -79,14 +79,21 @@ def _heads(P, names, x):
     return outs
 
 
-def encode_train(args, P, sd, data_dict, slots, n, dev, r):
+_CAM_GEOMETRY = {}
+
+
+def encode_train(args, P, sd, data_dict, slots, n, dev, r, model=None):
     """The per-type encoders in train mode: PillarVFE (BatchNorm1d batch statistics, running statistics updated once) + scatter for
-    every agent of the frame -> (canvas (n, ny, nx, 64) with its autograd graph, device counter of its non-zero elements)."""
+    every agent of the frame -> (canvas (n, ny, nx, 64) with its autograd graph, device counter of its non-zero elements).
+    Agent types with a camera encoder (``model`` gives the packed geometry of its eval engine): LiftSplatShootEncoder in train mode
+    (train_camera.py), and the mean over the modality maps where a type carries both (Airv2xBase.fuse_bev)."""
     groups, params, prefixes = [], [], []
     ny = nx = None
+    cam_types = [t for t in AGENT_TYPES if t in slots and "cam" in args[t]["modalities"]]
     for t in AGENT_TYPES:
-        if t not in slots:
+        if t not in slots or "lidar" not in args[t]["modalities"]:
             continue
+        mi = args[t]["modalities"].index("lidar")
         lid = data_dict[t]["batch_merged_lidar_features_torch"]
         cfg = args[t]["lidar"]
         vs, rng = cfg["voxel_size"], cfg["lidar_range"]
@@ -95,13 +102,38 @@ def encode_train(args, P, sd, data_dict, slots, n, dev, r):
         geom = (c_float * 6)(vs[0], vs[1], vs[2], vs[0] / 2 + rng[0], vs[1] / 2 + rng[1], vs[2] / 2 + rng[2])
         groups.append({"vf": lid["voxel_features"].to(dev).contiguous().float(), "vc": lid["voxel_coords"].to(dev).contiguous().to(torch.int32),
                        "vn": lid["voxel_num_points"].to(dev).contiguous().to(torch.int32), "slots": slots[t], "geom": geom})
-        p = f"{TYPE_PREFIX[t]}.0.0.pfn_layers.0"
+        p = f"{TYPE_PREFIX[t]}.{mi}.0.pfn_layers.0"
         params += [P[p + ".linear.weight"], P[p + ".norm.weight"], P[p + ".norm.bias"]]
         prefixes.append(p + ".norm")
-    st = []
-    canvas = T.pillar_encode(groups, n, ny, nx, params, stats_out=st)
-    for p, s in zip(prefixes, st):
-        _bn_update(sd, p, s, 1)
+    canvas = None
+    if groups:
+        st = []
+        canvas = T.pillar_encode(groups, n, ny, nx, params, stats_out=st)
+        for p, s in zip(prefixes, st):
+            _bn_update(sd, p, s, 1)
+    if cam_types:
+        from . import train_camera as TC
+        from .camera import CameraGeometry
+        geo = _CAM_GEOMETRY.setdefault(id(args), {})
+        rows = [None] * n
+        if canvas is not None:
+            for t in AGENT_TYPES:
+                if t in slots and "lidar" in args[t]["modalities"]:
+                    for s_ in slots[t]:
+                        rows[s_] = canvas[s_:s_ + 1]
+        for t in cam_types:
+            mi = args[t]["modalities"].index("cam")
+            ci = data_dict[t].get("batch_merged_cam_inputs")
+            if ci is None:
+                raise ValueError(f"{t}: the model has a camera encoder but the frame carries no batch_merged_cam_inputs")
+            if int(ci["imgs"].shape[0]) != len(slots[t]):
+                raise ValueError(f"{t}: {int(ci['imgs'].shape[0])} camera rigs for {len(slots[t])} agents")
+            if (t, dev) not in geo:        # frustum / grid / depth bins of the type: weight-free, built once per model configuration
+                geo[(t, dev)] = CameraGeometry(args[t]["cam"], dev)
+            bev = TC.lss_encoder_train(P, sd, f"{TYPE_PREFIX[t]}.{mi}.", geo[(t, dev)], ci, True if model is None else model.training)
+            for j, s_ in enumerate(slots[t]):
+                rows[s_] = bev[j:j + 1] if rows[s_] is None else TC.Mean2Fn.apply(bev[j:j + 1], rows[s_])
+        canvas = torch.cat(rows, 0)
     nz = torch.zeros(1, dtype=torch.int64, device=dev)
     _lib.check(r.lib.av2x_count_nonzero(_P(canvas), canvas.numel(), _P(nz), r.stream()), "av2x_count_nonzero")
     return canvas, nz
@@ -130,7 +162,7 @@ def _forward_train(model, data_dict, topk=None, mask=None, trace=None):
     if n == 0:
         raise ValueError("empty frame: no agent has lidar input")
 
-    canvas, nz = encode_train(args, P, sd, data_dict, slots, n, dev, r)
+    canvas, nz = encode_train(args, P, sd, data_dict, slots, n, dev, r, model)
 
     layer_nums, strides, ups = bb["layer_nums"], bb["layer_strides"], bb["upsample_strides"]
     # ---- blocks[0] once, with the graph (the fusion pass's blocks[0] sees the same canvas): three identical updates

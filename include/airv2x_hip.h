@@ -531,6 +531,34 @@ int av2x_lss_lift_pool(const float* feat, const float* prob, const float* imgs, 
                        av2x_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training of the camera branch (what torch autograd gives the reference for the non-convolution pieces of CamEncode / BevEncode,
+ * lss_submodule.py:22-189, 312-350, the efficientnet_pytorch MBConv blocks, and voxel_pooling airv2x_encoder.py:208-275).
+ *   av2x_unary_forward / _backward      y = act(x), dx = dy * act'(x) from the PRE-activation x; act 3 sigmoid, 6 swish (x * sigmoid(x))
+ *   av2x_add_act                        y = a + b, or relu(a + b) (BasicBlock's ReLU after the residual add; its gradient: av2x_act_backward on y)
+ *   av2x_gap                            out (n, c) = scale * sum_p x (n, hw, c) [* w (n, hw, c)]: the squeeze (scale 1 / hw) and -- w = dy -- the
+ *                                       gate gradient of the excite; workspace: av2x_gap_workspace_bytes(n, hw, c); fixed summation order
+ *   av2x_channel_broadcast              out (n, hw, c) = g (n, c) * scale [* y (n, hw, c)]: the excite (y = x), its data gradient (y = dy) and the
+ *                                       adjoint of the squeeze (y NULL, scale 1 / hw)
+ *   av2x_resize_bilinear_backward       adjoint of the (h, w) -> (h2, w2) align_corners = True enlargement of av2x_resize_bilinear; workspace:
+ *                                       av2x_resize_bilinear_backward_workspace_bytes(n, h, w, c) (64-bit fixed-point sums: order-independent)
+ *   av2x_lss_lift_pool_backward         adjoint of av2x_lss_lift_pool in its ground-truth-depth form: dfeat (b * n_cams, fh, fw, c) gathered from
+ *                                       dout (b, nz, ny, nx, c) at the voxel each feature pixel was lifted to (zeros where it left the grid)
+ * ------------------------------------------------------------------------------------ */
+int av2x_unary_forward(const float* x, uint64_t n_elems, int32_t act, float* y, av2x_stream_t stream);
+int av2x_unary_backward(const float* x, const float* dy, uint64_t n_elems, int32_t act, float* dx, av2x_stream_t stream);
+int av2x_add_act(const float* a, const float* b, uint64_t n_elems, int32_t relu, float* y, av2x_stream_t stream);
+uint64_t av2x_gap_workspace_bytes(int32_t n, int32_t hw, int32_t c);
+int av2x_gap(const float* x, const float* w, int32_t n, int32_t hw, int32_t c, float scale, float* workspace, float* out, av2x_stream_t stream);
+int av2x_channel_broadcast(const float* g, const float* y, int32_t n, int32_t hw, int32_t c, float scale, float* out, av2x_stream_t stream);
+uint64_t av2x_resize_bilinear_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c);
+int av2x_resize_bilinear_backward(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t h2, int32_t w2, void* workspace, float* dx,
+                                  av2x_stream_t stream);
+int av2x_lss_lift_pool_backward(const float* dout, const float* imgs, int32_t planes, int32_t img_h, int32_t img_w, int32_t downsample,
+                                const float* depth3, int32_t nbins, int32_t depth_mode, int32_t target, const float* frustum,
+                                const float* cam_params, int32_t b, int32_t n_cams, int32_t fh, int32_t fw, int32_t c, const float* lo3,
+                                const float* dx3, const int32_t* nx3, float* dfeat, av2x_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * V2VNet message aggregation (models/v2vnet_modules/v2v_fuse.py:137-165) for ONE receiving agent i:
  *   message_j = (msg_cnn([warp_j(x_j) | x_i]) ) * roi_mask_ij      (:150-158)
  *   agg       = mean_j / max_j message_j                              (:161-164; op 0 = "avg", 1 = "max")
@@ -789,7 +817,7 @@ int av2x_voxelize_dummy_if_empty(const float* range6, const float* voxel3, int32
 /* Training (what torch autograd of when2com.py gives the reference):
  * av2x_linear_rows_backward: with dz = dy where the forward's ReLU passed (act 1: y > 0; act 0: everywhere) --
  *   dx (m,k) = dz . w, dw (n,k) = dz^T . x, db (n) = column sums of dz; any of the three may be NULL.  w is streamed once (dx) and dw
- *   written once per group of 8 rows; fixed summation orders.  y (m,n) = the forward output (needed for act 1); db: m <= 8.
+ *   written once per group of 8 rows; fixed summation orders.  y (m,n) = the forward output (needed for act 1).
  * av2x_when2com_fuse_backward: gradients of av2x_when2com_fuse given dout (elems_per_agent): dagents[j] = p_j dout (HOST array of device
  *   pointers, may be NULL), dkeys (n_agents, key_size) and dquery (key_size) through the softmax over the keys (either may be NULL);
  *   coef = the p the forward returned; workspace: av2x_when2com_fuse_backward_workspace_bytes(n_agents).

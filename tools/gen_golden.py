@@ -1734,6 +1734,129 @@ def train_v2vnet_golden(name, lidar_range, types, n_points, seed, agg="avg", pos
                         extra={"agg": np.asarray(agg)})
 
 
+def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim, modalities, cams, pos_frac=0.01):
+    """One TRAINING step of the reference's Airv2xWhere2com WITH camera encoders (train mode: BatchNorm batch statistics in the
+    EfficientNet-B0 trunk, the Up blocks and BevEncode; ground-truth depth with the training-mode clipping of bin_depths; stochastic depth
+    switched off -- a configuration edit: random masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch
+    autograd.  Layout of train_golden: heads, losses, the recorded communication mask + K, the gradient of every parameter (strided
+    samples + sums), every buffer after the step; the float64 yardstick is the SAME reference model in double precision.  The trunk is
+    oracle/camera_oracle.py's restatement (efficientnet_pytorch / torchvision are absent: trunk parity unpinned)."""
+    import random
+
+    from airv2x_perception_amd import synth
+    from oracle import voxelize_oracle as vox
+    _import_camera_reference()
+    from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
+    from opencood.models.airv2x_where2com import Airv2xWhere2com
+    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, True)
+    args = hy["model"]["args"]
+    hy_ref = load_ref_hypes(lidar_range)
+    ra = hy_ref["model"]["args"]
+    ra["active_sensors"] = list(modalities)
+    for t in synth.AGENT_TYPES:
+        ra[t]["modalities"] = list(modalities)
+        ra[t]["cam"]["use_depth_gt"] = True
+        ra[t]["cam"]["data_aug_conf"]["final_dim"] = list(final_dim)
+        if lidar_range is not None:
+            ra[t]["cam"]["grid_conf"]["xbound"] = [lidar_range[0], lidar_range[3], 0.4]
+            ra[t]["cam"]["grid_conf"]["ybound"] = [lidar_range[1], lidar_range[4], 0.4]
+        check_hypes(ra[t]["cam"], args[t]["cam"], f"model.args.{t}.cam")
+    spec = synth.where2com_param_spec(args)
+    sd = synth.synthetic_state_dict(spec, seed=seed)
+    rng = lidar_range or synth.DEFAULT_RANGE
+    pp = hy["preprocess"]
+    voxd = []
+    for i, _ in enumerate(types):
+        p = vox.mask_points_by_range(synth.synthetic_cloud(i, n_points, rng), pp["cav_lidar_range"])
+        voxd.append(vox.points_to_voxels(p, pp["cav_lidar_range"], pp["args"]["voxel_size"], pp["args"]["max_points_per_voxel"],
+                                         pp["args"]["max_voxel_train"]))
+    mi = list(modalities).index("cam")
+
+    def build(dtype):
+        with _CudaIsCpu():
+            m = Airv2xWhere2com(synth.clone_hypes(hy_ref)["model"]["args"]).train()
+        assert [k for k, _, _ in spec] == list(m.state_dict().keys())
+        m.load_state_dict(sd, strict=True)
+        for pre in synth.TYPE_PREFIX.values():
+            if hasattr(m, pre):
+                getattr(m, pre)[mi].camencode.trunk._global_params.drop_connect_rate = 0.0
+        d = synth.add_cameras(synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"]), types, seed=seed + 50, final_dim=final_dim,
+                              cams_per_agent=cams)
+        if dtype == torch.float64:
+            m = m.double()
+            for t in synth.AGENT_TYPES:
+                lid = d[t]["batch_merged_lidar_features_torch"]
+                if lid is not None:
+                    lid["voxel_features"] = lid["voxel_features"].double()
+                ci = d[t].get("batch_merged_cam_inputs")
+                if ci is not None:
+                    for k in list(ci):
+                        if torch.is_tensor(ci[k]) and ci[k].is_floating_point():
+                            ci[k] = ci[k].double()
+        return m, d
+    os.makedirs("debug", exist_ok=True)
+    model, dd = build(torch.float32)
+    cap = {}
+    h = model.fusion_net.naive_communication.register_forward_hook(lambda m, i, o: cap.setdefault("comm", o))
+    random.seed(rseed)
+    out = model(dd)
+    h.remove()
+    H, W = out["psm"].shape[-2:]
+    random.seed(rseed)
+    K = [int(H * W * random.uniform(0, 1))]
+    lc = synth.loss_case(seed + 100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=pos_frac)
+    tgt = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    la = hy_ref["loss"]["det"]["args"] if "det" in hy_ref["loss"] else hy_ref["loss"]["args"]
+    crit = PointPillarLossMultiClass(la)
+    total = crit(out, tgt)
+    total.backward()
+    # the reference's voxel_pooling allocates its output with the DEFAULT dtype (airv2x_encoder.py:262-268): the float64 pass runs with
+    # float64 as that default
+    torch.set_default_dtype(torch.float64)
+    try:
+        m64, d64 = build(torch.float64)
+        random.seed(rseed)
+        o64 = m64(d64)
+        l64 = PointPillarLossMultiClass(la)(o64, {k: (v.double() if v.is_floating_point() else v) for k, v in tgt.items()})
+        l64.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    g64s = {k: p_.grad for k, p_ in m64.named_parameters()}
+    fx = {"seed": np.int64(seed), "rseed": np.int64(rseed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types),
+          "n_points": np.int64(n_points), "pos_frac": np.float64(pos_frac), "K": np.asarray(K, np.int64),
+          "final_dim": np.asarray(final_dim, np.int64), "modalities": np.asarray(list(modalities)),
+          "cams": np.asarray([(cams or synth.CAMS_PER_AGENT)[t] for t in synth.AGENT_TYPES], np.int64),
+          "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64), "loss64": np.float64(float(l64)),
+          "mask": np.packbits(cap["comm"][0].detach().numpy().astype(np.uint8).reshape(-1)),
+          "mask_shape": np.asarray(cap["comm"][0].shape, np.int64), "com": np.float64(float(out["com"])), "comm_rate": np.int64(out["comm_rate"]),
+          "head_stride": np.int64(1), "head_hw": np.asarray([H, W], np.int64)}
+    for k in ("psm", "rm", "obj"):
+        fx[k] = out[k].detach().numpy()
+    names, devs = [], []
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            continue
+        g, g64 = p_.grad.detach().reshape(-1), g64s[k].reshape(-1)
+        stride = 4 * max(1, g.numel() // 4096)           # ~900 tensors: a quarter of the other fixtures' sample, no fp32 copy
+        names.append(k)
+        fx["gsum:" + k] = np.asarray([g.double().sum().item(), g.double().abs().sum().item(), g.abs().max().item()], np.float64)
+        fx["g64:" + k] = g64[::stride].float().numpy()
+        fx["g64max:" + k] = np.float64(float(g64.abs().max()))
+        d = np.abs(g[::stride].double().numpy() - g64[::stride].numpy()).max() / max(float(g64.abs().max()), 1e-300)
+        fx["gdev:" + k] = np.float64(d)
+        devs.append((d, k))
+    fx["gsub"] = np.int64(4)
+    fx["grad_keys"] = np.asarray(names)
+    devs.sort(reverse=True)
+    for k, b in model.named_buffers():
+        fx["b:" + k] = b.detach().numpy()
+    print(f"[{name}] total {float(total):.6f} (float64 {float(l64):.6f}); {len(names)} gradients; reference fp32 vs float64 gradients: "
+          f"worst {devs[0][0]:.2e} ({devs[0][1]}), median {devs[len(devs) // 2][0]:.2e}; K {K}")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _load_ref_hypes_v2xvit(lidar_range, max_cav):
     from opencood.hypes_yaml.yaml_utils import load_yaml
     src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_v2xvit.yaml")
@@ -2023,6 +2146,12 @@ GROUPS = {
                              train_v2vnet_golden("train_v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 900, 27, agg="max")),
     "train_when2com_full": lambda: train_when2com_golden("train_when2com_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 28, head_stride=4),
     "train_v2vnet_full": lambda: train_v2vnet_golden("train_v2vnet_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 29, head_stride=4),
+    "train_cam": lambda: (train_cam_golden("train_cam_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 31, 5, (104, 168), ("cam", "lidar"),
+                                           {"vehicle": 2, "rsu": 1, "drone": 1}),
+                          train_cam_golden("train_cam_small_camonly_n2", SMALL, ["vehicle", "drone"], 700, 32, 6, (104, 168), ("cam",),
+                                           {"vehicle": 2, "rsu": 1, "drone": 1})),
+    "train_cam_b": lambda: train_cam_golden("train_cam_small_camonly_n2b", SMALL, ["vehicle", "rsu"], 700, 41, 9, (104, 168), ("cam",),
+                                            {"vehicle": 2, "rsu": 1, "drone": 1}),
     "train_cobevt_full": lambda: train_cobevt_golden("train_cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 18,
                                                      max_cav=(3, 2, 2), pos_frac=0.002, head_stride=4),
     "train_v2xvit_full": lambda: train_v2xvit_golden("train_v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 19,
