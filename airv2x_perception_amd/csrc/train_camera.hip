@@ -16,7 +16,6 @@
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr float kFix = 4294967296.0f;   // 2^32
 constexpr int kSlab = 256;              // pixels per slab of the per-(image, channel) reductions
 
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -89,38 +88,119 @@ __global__ __launch_bounds__(256) void bcast_kernel(const float* __restrict__ g,
     }
 }
 
-// adjoint of the align_corners = True bilinear enlargement (h, w) -> (h2, w2): every enlarged pixel hands its gradient to its four sources
+// adjoint of the align_corners = True bilinear enlargement (h, w) -> (h2, w2), as a GATHER: a thread owns one source pixel (x channel quad)
+// and walks the enlarged rows / columns whose taps can land on it (source coordinate within one pixel), re-deriving every tap with the
+// forward's own float arithmetic (resize_bilinear_kernel, camera.hip) -- so exactly the forward's (pixel, weight) pairs are summed, in
+// ascending (y2, x2) order, with no atomics.
+__device__ __forceinline__ float resize_tap_weight(int src, int o, float scale, int extent) {
+    const float f = scale * (float)o;
+    const int i0 = (int)f;
+    const int i1 = i0 + (i0 < extent - 1 ? 1 : 0);
+    const float l = f - (float)i0;
+    float wgt = 0.f;
+    if (i0 == src) wgt += 1.0f - l;
+    if (i1 == src) wgt += l;
+    return wgt;
+}
+
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, int h, int w, int C, int H2, int W2, float sy, float sx,
-                                                         unsigned long long* __restrict__ acc, long long total) {
+                                                         float isy, float isx, float* __restrict__ dx, long long total) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
     const int CQ = C >> 2;
     const int cq = (int)(gid % CQ);
     const long long pix = gid / CQ;
-    const int x2 = (int)(pix % W2);
-    const long long r = pix / W2;
-    const int y2 = (int)(r % H2);
-    const long long n = r / H2;
-    const float fy = sy * (float)y2, fx = sx * (float)x2;       // as resize_bilinear_kernel (camera.hip)
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
-    const float hy = 1.0f - ly, hx = 1.0f - lx;
-    const f4 d = *reinterpret_cast<const f4*>(dy + (size_t)pix * C + cq * 4);
-    unsigned long long* base = acc + (size_t)n * h * w * C + cq * 4;
-    auto add = [&](int yy, int xx, float wgt) {
-        if (wgt == 0.f) return;
-        unsigned long long* a = base + ((size_t)yy * w + xx) * C;
-        atomicAdd(a + 0, (unsigned long long)__float2ll_rn(d.x * wgt * kFix));
-        atomicAdd(a + 1, (unsigned long long)__float2ll_rn(d.y * wgt * kFix));
-        atomicAdd(a + 2, (unsigned long long)__float2ll_rn(d.z * wgt * kFix));
-        atomicAdd(a + 3, (unsigned long long)__float2ll_rn(d.w * wgt * kFix));
-    };
-    add(y0, x0, hy * hx); add(y0, x1, hy * lx); add(y1, x0, ly * hx); add(y1, x1, ly * lx);
+    const int x = (int)(pix % w);
+    const long long r = pix / w;
+    const int y = (int)(r % h);
+    const long long n = r / h;
+    // candidates: source coordinate in (y - 1, y + 1), one enlarged row of slack either side for the float rounding of sy * y2
+    const int ya = max(0, (int)floorf((float)(y - 1) * isy) - 1), yb = min(H2 - 1, (int)ceilf((float)(y + 1) * isy) + 1);
+    const int xa = max(0, (int)floorf((float)(x - 1) * isx) - 1), xb = min(W2 - 1, (int)ceilf((float)(x + 1) * isx) + 1);
+    f4 a = f4{0.f, 0.f, 0.f, 0.f};
+    for (int y2 = ya; y2 <= yb; ++y2) {
+        const float wy = resize_tap_weight(y, y2, sy, h);
+        if (wy == 0.f) continue;
+        const float* row = dy + (((size_t)n * H2 + y2) * W2) * C + cq * 4;
+        for (int x2 = xa; x2 <= xb; ++x2) {
+            const float wx = resize_tap_weight(x, x2, sx, w);
+            if (wx == 0.f) continue;
+            const f4 d = *reinterpret_cast<const f4*>(row + (size_t)x2 * C);
+            // the forward's products: (hy * hx), (hy * lx), (ly * hx), (ly * lx) -- when both taps of an axis fall on this pixel (the last
+            // row / column) their weights were already added above
+            const float wgt = wy * wx;
+            a.x = fmaf(d.x, wgt, a.x); a.y = fmaf(d.y, wgt, a.y); a.z = fmaf(d.z, wgt, a.z); a.w = fmaf(d.w, wgt, a.w);
+        }
+    }
+    *reinterpret_cast<f4*>(dx + (size_t)pix * C + cq * 4) = a;
 }
 
-__global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)((double)acc[i] * (1.0 / 4294967296.0));
+// ------------------------------------------------------------------------------------------ depthwise conv: weight gradient
+// dw[tap][c] = sum over (n, ho, wo) of dy[n][ho][wo][c] * x[n][ho * stride - pad + kh][wo * stride - pad + kw][c] (zero outside the image).
+// grid (ceil(C / 64), slabs); block 256 = 16 channel quads x 16 pixel lanes; a thread keeps all K * K taps of its channel quad in registers
+// over its pixels of the slab (stride 16), the 16 lanes are summed in a fixed order (2 shuffles inside the wave, the 4 waves through LDS) and
+// the slabs by gap_finish_kernel -- bit-reproducible.  x is read K * K / stride^2 times, all but the first from L1 / L2.
+template <int K>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int H, int W, int C, int stride,
+                                                       int pad, int Ho, int Wo, long long npix, int slab, float* __restrict__ partial) {
+    __shared__ f4 red[4][K * K][16];
+    const int ql = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int cq = blockIdx.x * 16 + ql;
+    const long long p0 = (long long)blockIdx.y * slab, p1 = min(npix, p0 + (long long)slab);
+    f4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    if (cq * 4 < C) {
+        for (long long p = p0 + lane; p < p1; p += 16) {
+            const int wo = (int)(p % Wo);
+            const long long r = p / Wo;
+            const int ho = (int)(r % Ho);
+            const long long n = r / Ho;
+            const f4 d = *reinterpret_cast<const f4*>(dy + (size_t)p * C + cq * 4);
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                const int hi = ho * stride - pad + kh;
+                if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const int wi = wo * stride - pad + kw;
+                    if ((unsigned)wi >= (unsigned)W) continue;
+                    const f4 v = *reinterpret_cast<const f4*>(x + (((size_t)n * H + hi) * W + wi) * C + cq * 4);
+                    f4& a = acc[kh * K + kw];
+                    a.x = fmaf(v.x, d.x, a.x); a.y = fmaf(v.y, d.y, a.y); a.z = fmaf(v.z, d.z, a.z); a.w = fmaf(v.w, d.w, a.w);
+                }
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        f4 a = acc[t];
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
+        }
+        if ((threadIdx.x & 48) == 0) red[wave][t][ql] = a;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * K * 16; e += 256) {
+        const int t = e >> 4, q = e & 15;
+        const int c4 = (blockIdx.x * 16 + q) * 4;
+        if (c4 >= C) continue;
+        f4 a = red[0][t][q];
+        const f4 b1 = red[1][t][q], b2 = red[2][t][q], b3 = red[3][t][q];
+        a.x = ((a.x + b1.x) + b2.x) + b3.x; a.y = ((a.y + b1.y) + b2.y) + b3.y;
+        a.z = ((a.z + b1.z) + b2.z) + b3.z; a.w = ((a.w + b1.w) + b2.w) + b3.w;
+        *reinterpret_cast<f4*>(partial + ((size_t)blockIdx.y * K * K + t) * C + c4) = a;
+    }
+}
+
+constexpr int kDwSlabMin = 256, kDwSlabMax = 4096;
+static int dw_slab(long long npix, int c) {      // >= ~1024 workgroups where the map allows it, slabs of a multiple of 16 pixels
+    const long long groups = (c + 63) / 64;
+    long long slab = npix * groups / 1024;
+    slab = (slab + 15) / 16 * 16;
+    return (int)(slab < kDwSlabMin ? kDwSlabMin : slab > kDwSlabMax ? kDwSlabMax : slab);
 }
 
 unsigned blocks_for(size_t n) {
@@ -192,23 +272,47 @@ extern "C" int av2x_channel_broadcast(const float* g, const float* y, int32_t n,
     return av2x::check_launch("bcast_kernel");
 }
 
-extern "C" uint64_t av2x_resize_bilinear_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c) { return (uint64_t)n * h * w * c * 8ull; }
+extern "C" uint64_t av2x_resize_bilinear_backward_workspace_bytes(int32_t, int32_t, int32_t, int32_t) { return 0; }
 
-// dy (n, h2, w2, c) = gradient of the (h, w) -> (h2, w2) align_corners = True enlargement; dx (n, h, w, c)
+// dy (n, h2, w2, c) = gradient of the (h, w) -> (h2, w2) align_corners = True enlargement; dx (n, h, w, c).  `workspace` is unused (may be NULL).
 extern "C" int av2x_resize_bilinear_backward(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t h2, int32_t w2, void* workspace,
                                              float* dx, av2x_stream_t stream) {
+    (void)workspace;
     if (n == 0) return 0;
-    if (!dy || !workspace || !dx) return av2x::fail("av2x_resize_bilinear_backward: null argument");
+    if (!dy || !dx) return av2x::fail("av2x_resize_bilinear_backward: null argument");
     if (n < 0 || h <= 0 || w <= 0 || h2 <= 0 || w2 <= 0 || c <= 0 || c % 4) return av2x::fail("av2x_resize_bilinear_backward: bad sizes (c %% 4 == 0)");
     hipStream_t st = av2x::as_stream(stream);
-    const size_t total_in = (size_t)n * h * w * c;
-    hipError_t e = hipMemsetAsync(workspace, 0, total_in * 8ull, st);
-    if (e != hipSuccess) return av2x::fail("av2x_resize_bilinear_backward: memset: %s", hipGetErrorString(e));
     const float sy = h2 > 1 ? (float)(h - 1) / (float)(h2 - 1) : 0.f;
     const float sx = w2 > 1 ? (float)(w - 1) / (float)(w2 - 1) : 0.f;
-    const long long total = (long long)n * h2 * w2 * (c / 4);
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, h, w, c, h2, w2, sy, sx,
-                       reinterpret_cast<unsigned long long*>(workspace), total);
-    hipLaunchKernelGGL(fixed_to_float_kernel, dim3(blocks_for(total_in)), dim3(256), 0, st, reinterpret_cast<const long long*>(workspace), dx, total_in);
+    // inverse scales for the candidate window; a degenerate axis (one source row: every enlarged row reads it) scans the whole axis
+    const float isy = sy > 0.f ? 1.0f / sy : (float)h2, isx = sx > 0.f ? 1.0f / sx : (float)w2;
+    const long long total = (long long)n * h * w * (c / 4);
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, h, w, c, h2, w2, sy, sx, isy, isx, dx, total);
     return av2x::check_launch("resize_bwd_kernel");
+}
+
+extern "C" uint64_t av2x_dwconv2d_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t c, int32_t ks) {
+    if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || ks <= 0) return 0;
+    const long long npix = (long long)n * ho * wo;
+    const int slab = dw_slab(npix, c);
+    return (uint64_t)((npix + slab - 1) / slab) * ks * ks * c * sizeof(float);
+}
+
+// dw (ks*ks, c) of the depthwise conv av2x_dwconv2d ran with (stride, pad_t = pad_l = pad): x (n, h, w, c), dy (n, ho, wo, c)
+extern "C" int av2x_dwconv2d_wgrad(const float* x, const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride, int32_t pad,
+                                   int32_t ho, int32_t wo, void* workspace, float* dw, av2x_stream_t stream) {
+    if (!x || !dy || !workspace || !dw) return av2x::fail("av2x_dwconv2d_wgrad: null argument");
+    if (n <= 0 || h <= 0 || w <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 4) return av2x::fail("av2x_dwconv2d_wgrad: bad sizes (c %% 4 == 0)");
+    if ((ks != 3 && ks != 5) || (stride != 1 && stride != 2) || pad < 0) return av2x::fail("av2x_dwconv2d_wgrad: ks %d (3 | 5), stride %d (1 | 2)", ks, stride);
+    const long long npix = (long long)n * ho * wo;
+    const int slab = dw_slab(npix, c);
+    const int slabs = (int)((npix + slab - 1) / slab);
+    hipStream_t st = av2x::as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    const dim3 grid((c + 63) / 64, slabs);
+    if (ks == 3) hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, st, x, dy, h, w, c, stride, pad, ho, wo, npix, slab, part);
+    else hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, st, x, dy, h, w, c, stride, pad, ho, wo, npix, slab, part);
+    const int tc = ks * ks * c;
+    hipLaunchKernelGGL(gap_finish_kernel, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, st, part, 1, tc, slabs, 1.0f, dw);
+    return av2x::check_launch("dw_wgrad_kernel");
 }

@@ -47,7 +47,23 @@ __global__ __launch_bounds__(256) void linear_rows_dx_kernel(const float* __rest
     for (int i = 0; i < M; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
     const f4* wp = reinterpret_cast<const f4*>(w) + k4;
     const size_t rs = (size_t)k / 4;
-    for (int j = 0; j < n; ++j) {
+    // four rows of W in flight per step (the loop is one dependent chain of loads otherwise: 1 152 of them for a squeeze-excite expand layer)
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        f4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = __builtin_nontemporal_load(wp + (size_t)(j + u) * rs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+                if (i < m) {
+                    const float d = sdz[i * n + j + u];
+                    acc[i].x = fmaf(d, wv[u].x, acc[i].x); acc[i].y = fmaf(d, wv[u].y, acc[i].y);
+                    acc[i].z = fmaf(d, wv[u].z, acc[i].z); acc[i].w = fmaf(d, wv[u].w, acc[i].w);
+                }
+    }
+    for (; j < n; ++j) {
         const f4 wv = __builtin_nontemporal_load(wp + (size_t)j * rs);
 #pragma unroll
         for (int i = 0; i < M; ++i)

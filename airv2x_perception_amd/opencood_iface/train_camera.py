@@ -216,15 +216,10 @@ class DwConvFn(torch.autograd.Function):
             wf = w.view(k, k, c).flip(0, 1).reshape(k * k, c).contiguous()
             dx = _dw_launch(r, g, wf, k, 1, k - 1 - pa, k - 1 - pa, h, wd)
         if ctx.needs_input_grad[1]:
-            # dw[ky, kx, c] = sum_{n, i, j} dy[n, i, j, c] * xpad[n, s i + ky, s j + kx, c]: one fixed-order reduction per tap
-            xp = Fn.pad(x, (0, 0, pa, pb + s, pa, pb + s))
-            rows = n * ho * wo                                # all images as ONE row axis: the reduction covers the batch too
-            ws = torch.empty(int(r.lib.av2x_gap_workspace_bytes(1, rows, c)) // 4 + 1, dtype=torch.float32, device=x.device)
+            # dw[ky, kx, c] = sum_{n, i, j} dy[n, i, j, c] * xpad[n, s i + ky, s j + kx, c]: all taps in one launch, fixed summation order
+            ws = torch.empty(int(r.lib.av2x_dwconv2d_wgrad_workspace_bytes(n, ho, wo, c, k)) // 4 + 1, dtype=torch.float32, device=x.device)
             dw = torch.empty((k * k, c), dtype=torch.float32, device=x.device)
-            for ky in range(k):
-                for kx in range(k):
-                    tap = xp[:, ky:ky + s * (ho - 1) + 1:s, kx:kx + s * (wo - 1) + 1:s].contiguous()
-                    _lib.check(r.lib.av2x_gap(_P(tap), _P(dy), 1, rows, c, 1.0, _P(ws), _P(dw[ky * k + kx]), r.stream()), "av2x_gap")
+            _lib.check(r.lib.av2x_dwconv2d_wgrad(_P(x), _P(dy), n, h, wd, c, k, s, pa, ho, wo, _P(ws), _P(dw), r.stream()), "av2x_dwconv2d_wgrad")
         return dx, dw, None, None, None
 
 
@@ -302,8 +297,7 @@ class ResizeFn(torch.autograd.Function):
         n, h, w, c, h2, w2 = ctx.cfg
         r = _runner(dy.device)
         dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
-        ws = torch.empty(int(r.lib.av2x_resize_bilinear_backward_workspace_bytes(n, h, w, c)), dtype=torch.uint8, device=dy.device)
-        _lib.check(r.lib.av2x_resize_bilinear_backward(_P(dy.contiguous()), n, h, w, c, h2, w2, _P(ws), _P(dx), r.stream()), "av2x_resize_bilinear_backward")
+        _lib.check(r.lib.av2x_resize_bilinear_backward(_P(dy.contiguous()), n, h, w, c, h2, w2, None, _P(dx), r.stream()), "av2x_resize_bilinear_backward")
         return dx, None
 
 

@@ -539,8 +539,10 @@ int av2x_lss_lift_pool(const float* feat, const float* prob, const float* imgs, 
  *                                       gate gradient of the excite; workspace: av2x_gap_workspace_bytes(n, hw, c); fixed summation order
  *   av2x_channel_broadcast              out (n, hw, c) = g (n, c) * scale [* y (n, hw, c)]: the excite (y = x), its data gradient (y = dy) and the
  *                                       adjoint of the squeeze (y NULL, scale 1 / hw)
- *   av2x_resize_bilinear_backward       adjoint of the (h, w) -> (h2, w2) align_corners = True enlargement of av2x_resize_bilinear; workspace:
- *                                       av2x_resize_bilinear_backward_workspace_bytes(n, h, w, c) (64-bit fixed-point sums: order-independent)
+ *   av2x_resize_bilinear_backward       adjoint of the (h, w) -> (h2, w2) align_corners = True enlargement of av2x_resize_bilinear, gathered per
+ *                                       source pixel in a fixed order (no atomics; `workspace` unused, _workspace_bytes returns 0)
+ *   av2x_dwconv2d_wgrad                 dw (ks*ks, c) of av2x_dwconv2d (ks 3 | 5, stride 1 | 2, pad_t = pad_l = pad): per-slab partial sums in
+ *                                       `workspace` (av2x_dwconv2d_wgrad_workspace_bytes), summed in slab order -- bit-reproducible
  *   av2x_lss_lift_pool_backward         adjoint of av2x_lss_lift_pool in its ground-truth-depth form: dfeat (b * n_cams, fh, fw, c) gathered from
  *                                       dout (b, nz, ny, nx, c) at the voxel each feature pixel was lifted to (zeros where it left the grid)
  * ------------------------------------------------------------------------------------ */
@@ -553,6 +555,9 @@ int av2x_channel_broadcast(const float* g, const float* y, int32_t n, int32_t hw
 uint64_t av2x_resize_bilinear_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c);
 int av2x_resize_bilinear_backward(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t h2, int32_t w2, void* workspace, float* dx,
                                   av2x_stream_t stream);
+uint64_t av2x_dwconv2d_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t c, int32_t ks);
+int av2x_dwconv2d_wgrad(const float* x, const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride, int32_t pad,
+                        int32_t ho, int32_t wo, void* workspace, float* dw, av2x_stream_t stream);
 int av2x_lss_lift_pool_backward(const float* dout, const float* imgs, int32_t planes, int32_t img_h, int32_t img_w, int32_t downsample,
                                 const float* depth3, int32_t nbins, int32_t depth_mode, int32_t target, const float* frustum,
                                 const float* cam_params, int32_t b, int32_t n_cams, int32_t fh, int32_t fw, int32_t c, const float* lo3,

@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None, args=None, model_name="where2com", amp=False):
+def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None, args=None, model_name="where2com", amp=False, modalities=None):
     """-> dict (see the module docstring).  ``dd`` / ``args``: a frame already on the device and its model args (bench.py
     passes the one its device voxelizer built); otherwise the frame is built here with the oracle's CPU voxelizer."""
     from types import SimpleNamespace
@@ -33,7 +33,12 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
     if dd is None:
         from oracle import voxelize_oracle as vox
         rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0] if a.small else None
-        hy = hypes_fn(rng)
+        if modalities:           # camera branch (LSS encoder per agent type, gt-depth lift): Airv2xWhere2com only
+            assert model_name == "where2com" and not amp
+            fd = (104, 168) if a.small else (360, 640)
+            hy = synth.multimodal_hypes(tuple(modalities), rng, fd, True)
+        else:
+            hy = hypes_fn(rng)
         args = hy["model"]["args"]
         rng = rng or synth.DEFAULT_RANGE
         types = synth.sort_types(synth.agent_types_for(a.agents))[1]
@@ -52,6 +57,8 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
             dd_host["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(a.agents, args["max_cav_num"])
         if model_name == "v2vnet":
             dd_host["img_pairwise_t_matrix_collab"] = synth.v2vnet_pairwise(a.agents, args["max_cav_num"])
+        if modalities:
+            dd_host = synth.add_cameras(dd_host, types, seed=50, final_dim=fd)
         dd = synth.data_dict_to(dd_host, dev)
     sd = synth.synthetic_state_dict(spec_fn(args), seed=0)
     model = Model(args)
@@ -60,6 +67,9 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
     model.sync_comm_rate = False
     g = [int(v) for v in args["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]]
     H, W = g[1] // 2, g[0] // 2
+    if modalities:
+        res_ = args["vehicle"]["cam"]["grid_conf"]["xbound"][2] / 0.4      # camera BEV cell over the lidar voxel
+        H, W = int(round(g[1] / res_)) // 2, int(round(g[0] / res_)) // 2
     lc = synth.loss_case(100, B=1, H=H, W=W, A=args["anchor_number"], C=args["num_class"], pos_frac=0.002)
     tgt_host = {k: torch.from_numpy(lc[k]) for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
     tgt = {k: v.to(dev) for k, v in tgt_host.items()}
@@ -100,7 +110,7 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
             t_o += e2.elapsed_time(e3)
     k = a.steps
     res = {"what": f"{Model.__name__} training step (train-mode forward + PointPillarLossMultiClass + backward + Adam)" + (" under autocast(bf16) + GradScaler" if amp else ""),
-           "agents": a.agents, "grid": [g[0], g[1]], "steps": k, "ms_per_step": round((t_f + t_b + t_o) / k, 3),
+           "agents": a.agents, "grid": [g[0], g[1]], "modalities": list(modalities) if modalities else ["lidar"], "steps": k, "ms_per_step": round((t_f + t_b + t_o) / k, 3),
            "ms_forward": round(t_f / k, 3), "ms_loss_backward": round(t_b / k, 3), "ms_optimizer": round(t_o / k, 3),
            "steps_per_s": round(1e3 * k / (t_f + t_b + t_o), 3), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)], "dtype": "bf16 operands (autocast), fp32 master weights" if amp else "f32", "data": "synthetic"}
@@ -185,8 +195,11 @@ def main():
     ap.add_argument("--small", action="store_true", help="128 x 64 canvas (smoke)")
     ap.add_argument("--model", choices=["where2com", "cobevt", "v2xvit", "when2com", "v2vnet"], default="where2com")
     ap.add_argument("--amp", action="store_true", help="autocast(bf16) + GradScaler around the step (tools/train.py --amp of the reference)")
+    ap.add_argument("--modalities", default=None, help="e.g. cam,lidar or cam: the camera configuration (where2com only)")
     a = ap.parse_args()
-    print(json.dumps(run(a.agents, a.steps, a.warmup, a.small, a.cpu and a.model == "where2com", model_name=a.model, amp=a.amp)))
+    mods = a.modalities.split(",") if a.modalities else None
+    print(json.dumps(run(a.agents, a.steps, a.warmup, a.small, a.cpu and a.model == "where2com" and not mods, model_name=a.model, amp=a.amp,
+                         modalities=mods)))
 
 
 if __name__ == "__main__":
