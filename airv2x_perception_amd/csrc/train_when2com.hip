@@ -47,23 +47,7 @@ __global__ __launch_bounds__(256) void linear_rows_dx_kernel(const float* __rest
     for (int i = 0; i < M; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
     const f4* wp = reinterpret_cast<const f4*>(w) + k4;
     const size_t rs = (size_t)k / 4;
-    // four rows of W in flight per step (the loop is one dependent chain of loads otherwise: 1 152 of them for a squeeze-excite expand layer)
-    int j = 0;
-    for (; j + 4 <= n; j += 4) {
-        f4 wv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wv[u] = __builtin_nontemporal_load(wp + (size_t)(j + u) * rs);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-                if (i < m) {
-                    const float d = sdz[i * n + j + u];
-                    acc[i].x = fmaf(d, wv[u].x, acc[i].x); acc[i].y = fmaf(d, wv[u].y, acc[i].y);
-                    acc[i].z = fmaf(d, wv[u].z, acc[i].z); acc[i].w = fmaf(d, wv[u].w, acc[i].w);
-                }
-    }
-    for (; j < n; ++j) {
+    for (int j = 0; j < n; ++j) {
         const f4 wv = __builtin_nontemporal_load(wp + (size_t)j * rs);
 #pragma unroll
         for (int i = 0; i < M; ++i)
@@ -76,6 +60,75 @@ __global__ __launch_bounds__(256) void linear_rows_dx_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < M; ++i)
         if (i < m) reinterpret_cast<f4*>(dx)[(size_t)i * rs + k4] = acc[i];
+}
+
+// The same product for SMALL k (a squeeze-excite layer: k = 48 .. 1 152, n = 1 152 .. 48, W <= 221 KB): the streaming kernel above would
+// run 12 .. 288 threads through one dependent chain of n loads.  Here a workgroup = KQ k-quads x JL j-lanes (KQ * JL = 256): the rows of W
+// are split over the j-lanes (four loads in flight each), the JL partial sums meet in LDS and are added in lane order.
+template <int KQ, int JL>
+__global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ y,
+                                                              int m, int n, int k, int act, float* __restrict__ dx, float* __restrict__ db,
+                                                              int db_acc) {
+    extern __shared__ float sdz[];                    // [m][n] dz, then [JL][kMaxM][KQ] quads
+    f4* red = reinterpret_cast<f4*>(sdz + ((m * n + 3) & ~3));
+    load_dz(sdz, dy, y, m, n, act);
+    if (db && blockIdx.x == 0) {
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            float s = db_acc ? db[j] : 0.f;
+            for (int i = 0; i < m; ++i) s += sdz[i * n + j];
+            db[j] = s;
+        }
+    }
+    if (!dx) return;
+    const int ql = threadIdx.x % KQ, jl = threadIdx.x / KQ;
+    const int kq = blockIdx.x * KQ + ql;
+    const size_t rs = (size_t)k / 4;
+    f4 acc[kMaxM];
+#pragma unroll
+    for (int i = 0; i < kMaxM; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    if ((size_t)kq < rs) {
+        const f4* wp = reinterpret_cast<const f4*>(w) + kq;
+        int j = jl;
+        for (; j + 3 * JL < n; j += 4 * JL) {
+            f4 wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wv[u] = wp[(size_t)(j + u * JL) * rs];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < kMaxM; ++i)
+                    if (i < m) {
+                        const float d = sdz[i * n + j + u * JL];
+                        acc[i].x = fmaf(d, wv[u].x, acc[i].x); acc[i].y = fmaf(d, wv[u].y, acc[i].y);
+                        acc[i].z = fmaf(d, wv[u].z, acc[i].z); acc[i].w = fmaf(d, wv[u].w, acc[i].w);
+                    }
+        }
+        for (; j < n; j += JL) {
+            const f4 wv = wp[(size_t)j * rs];
+#pragma unroll
+            for (int i = 0; i < kMaxM; ++i)
+                if (i < m) {
+                    const float d = sdz[i * n + j];
+                    acc[i].x = fmaf(d, wv.x, acc[i].x); acc[i].y = fmaf(d, wv.y, acc[i].y);
+                    acc[i].z = fmaf(d, wv.z, acc[i].z); acc[i].w = fmaf(d, wv.w, acc[i].w);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxM; ++i)
+        if (i < m) red[(jl * kMaxM + i) * KQ + ql] = acc[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < m * KQ; e += 256) {
+        const int i = e / KQ, q = e % KQ;
+        const size_t kk = (size_t)blockIdx.x * KQ + q;
+        if (kk >= rs) continue;
+        f4 a = red[i * KQ + q];
+        for (int l = 1; l < JL; ++l) {
+            const f4 b = red[(l * kMaxM + i) * KQ + q];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<f4*>(dx)[(size_t)i * rs + kk] = a;
+    }
 }
 
 template <int M>
@@ -271,7 +324,21 @@ extern "C" int av2x_linear_rows_backward(const float* x, const float* w, const f
         const int mm = (m - m0) < kMaxM ? (m - m0) : kMaxM;
         const size_t lds = (size_t)mm * n * sizeof(float);
         const float* ys = y ? y + (size_t)m0 * n : nullptr;
-        if (dx || db) {
+        if ((dx || db) && k <= 4096) {      // small k: rows of W split over j-lanes (see linear_small_dx_kernel)
+            const size_t lds2 = (((size_t)mm * n + 3) & ~(size_t)3) * sizeof(float) + (size_t)256 * kMaxM * 16;
+            float* dxs = dx ? dx + (size_t)m0 * k : nullptr;
+            if (k >= 256) {
+                static av2x::LdsLimit lim;
+                lim.ensure(reinterpret_cast<const void*>(&linear_small_dx_kernel<64, 4>), lds2);
+                hipLaunchKernelGGL((linear_small_dx_kernel<64, 4>), dim3((unsigned)((k / 4 + 63) / 64)), dim3(256), lds2, st, w, dy + (size_t)m0 * n, ys, mm,
+                                   n, k, act, dxs, db, m0 > 0 ? 1 : 0);
+            } else {
+                static av2x::LdsLimit lim;
+                lim.ensure(reinterpret_cast<const void*>(&linear_small_dx_kernel<16, 16>), lds2);
+                hipLaunchKernelGGL((linear_small_dx_kernel<16, 16>), dim3((unsigned)((k / 4 + 15) / 16)), dim3(256), lds2, st, w, dy + (size_t)m0 * n, ys, mm,
+                                   n, k, act, dxs, db, m0 > 0 ? 1 : 0);
+            }
+        } else if (dx || db) {
             if (mm <= 4) hipLaunchKernelGGL(linear_rows_dx_kernel<4>, dim3(kb), dim3(256), lds, st, w, dy + (size_t)m0 * n, ys, mm, n, k, act,
                                             dx ? dx + (size_t)m0 * k : nullptr, db, m0 > 0 ? 1 : 0);
             else hipLaunchKernelGGL(linear_rows_dx_kernel<8>, dim3(kb), dim3(256), lds, st, w, dy + (size_t)m0 * n, ys, mm, n, k, act,
