@@ -7,6 +7,8 @@
 //                        with the 'b m d (x w1) (y w2)' / 'b m d (w1 x) (w2 y)' partitions done as
 //                        index arithmetic on the NHWC token buffer (no rearrange copies)
 //   agent_mean_kernel    mean over the agent axis (mlp_head Reduce, :270)                   HBM-bound
+#include <cstdlib>
+
 #include "av2x_common.hpp"
 
 namespace {
@@ -663,13 +665,25 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
     // ws = 4: one wave per (window, head), everything in registers.  With more than 4 valid agents the 8-key-tile variant needs
     // the whole register file (1 wave / SIMD) and only ties the workgroup-per-window kernel: it is used up to 4 valid agents
     // (test hook: grid_partition bit 4 forces it for any count).
-    if (T <= 128 && window == 4 && !(grid_partition & 14) && (n_valid <= 4 || (grid_partition & 16))) {
+    static const bool no_wave = getenv("AV2X_FAX_NO_WAVE") != nullptr;     // probe: always the workgroup-per-window kernel
+    if (T <= 128 && window == 4 && !(grid_partition & 14) && (n_valid <= 4 || (grid_partition & 16)) && !(no_wave && !(grid_partition & 16))) {
         const int tab_s = (tab_n + 63) & ~63;
-        const size_t lds_w = (size_t)4 * ((heads + 3) / 4) * tab_s * sizeof(float);
-        if (lds_w <= 64 * 1024) {
+        const size_t lds_w0 = (size_t)4 * ((heads + 3) / 4) * tab_s * sizeof(float);
+        if (lds_w0 <= 48 * 1024) {
             const int nwin = (h / 4) * (w / 4);
             const dim3 grid(nwin < 2048 ? nwin : 2048);
-            if (n_valid <= 4) hipLaunchKernelGGL(fax_attention_wave_kernel<4>, grid, dim3(256), lds_w, av2x::as_stream(stream), p);
+            static const bool force8 = getenv("AV2X_FAX_NV8") != nullptr;      // debug probe (tools/micro/pipe_t32.py)
+            // The wave kernel OWNS its CU: it asks for 124 KB of LDS (it uses lds_w0 of them), so that no workgroup of the split-3 kernels
+            // (conv_igemm_x3p 37 - 50 KB, conv_wino_x3's 32-tile form 68 KB) can become co-resident.  Measured (tools/micro/coreside.py,
+            // pipe_t32.py): while its waves share a CU with waves of those kernels from another stream, some (query, head) rows of its
+            // output come out wrong (up to 0.2 abs) for n_valid <= 4 -- its LDS table, VGPR / AGPR guard patterns and every other
+            // kernel stay intact, the cause is not understood.  AV2X_FAX_SHARE_CU=1 restores the shared launch (probe).
+            static const bool share = getenv("AV2X_FAX_SHARE_CU") != nullptr;
+            const size_t lds_w = share ? lds_w0 : (lds_w0 > (size_t)124 * 1024 ? lds_w0 : (size_t)124 * 1024);
+            static av2x::LdsLimit lim_w4, lim_w8;
+            lim_w4.ensure(reinterpret_cast<const void*>(&fax_attention_wave_kernel<4>), lds_w);
+            lim_w8.ensure(reinterpret_cast<const void*>(&fax_attention_wave_kernel<8>), lds_w);
+            if (n_valid <= 4 && !force8) hipLaunchKernelGGL(fax_attention_wave_kernel<4>, grid, dim3(256), lds_w, av2x::as_stream(stream), p);
             else hipLaunchKernelGGL(fax_attention_wave_kernel<8>, grid, dim3(256), lds_w, av2x::as_stream(stream), p);
             return av2x::check_launch("fax_attention_wave_kernel");
         }
@@ -711,3 +725,4 @@ extern "C" int av2x_agent_mean(const float* x, float* y, int32_t n_agents, int64
                        reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n4, n_agents);
     return av2x::check_launch("agent_mean_kernel");
 }
+

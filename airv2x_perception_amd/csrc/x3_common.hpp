@@ -23,7 +23,7 @@ __device__ constexpr int x3_bp(int p) { return p == 0 ? 0 : p == 1 ? 2 : p == 2 
 // the two scalar ones it replaces (v_pk_add_f32: ~+13 cycles each, MI355X_MICROARCH.md "price of one filler"), so these are written --
 // and, with -fno-slp-vectorize for the translation units that include this header (build.py), stay -- scalar.
 #ifndef AV2X_X3_MB1_OCC
-#define AV2X_X3_MB1_OCC 2
+#define AV2X_X3_MB1_OCC 1
 #endif
 __device__ __forceinline__ x3_f32x2 x3_pk_add(x3_f32x2 a, x3_f32x2 b) {
     x3_f32x2 r;

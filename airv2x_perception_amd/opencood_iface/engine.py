@@ -642,14 +642,17 @@ class Where2ComEngine:
         channels (the 64 -> 64 layers at 100 x 352 have too short a K loop for the 64 x 64 tile: fp32 Winograd is faster there)."""
         return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cin >= 128 and L.cout % 64 == 0 and L.coutp == L.cout
 
-    @staticmethod
-    def wino_x3_tile(L, h, w):
-        """Always the 64 x 64 tile (one wave per SIMD with the whole register file: nothing else is co-resident on its CU).
-        The 32 x 64 tile (two workgroups per CU) is 1.2-1.3x faster on the small maps and gives the same bits, but it is NOT used:
-        while one of its workgroups shares a CU with waves of another kernel of another stream, that kernel's results were observed
-        corrupted (fax_attention_wave_kernel, 49 of 50 launches: tools/debug/dbg_attn2.py; the kernel's own results, LDS and VGPR
-        guard patterns of a probe kernel stay intact -- DESIGN.md section 3.1i).  Until that is understood the engine never launches it."""
-        return 0x40000400 | (64 << 16) | 64
+    WINO_X3_T32 = os.environ.get("AV2X_WINO_X3_T32", "0") == "1"
+    WINO_X3_T32_MAX_PIXELS = 50 * 176
+
+    @classmethod
+    def wino_x3_tile(cls, L, h, w):
+        """64 x 64 tile (one wave per SIMD with the whole register file) by default.  The 32 x 64 tile (two workgroups per CU, same
+        bits) is 1.2-1.3x faster per launch on the small maps (<= 50 x 176 pixels per image: a function of the map only, so that the
+        sharded / batched frame keeps the single frame's bits) but gains nothing once three frames are in flight (other frames fill the
+        CUs the 64-tile launches leave idle): AV2X_WINO_X3_T32=1 switches it on for single-stream / latency use."""
+        tb = 32 if (cls.WINO_X3_T32 and h * w <= cls.WINO_X3_T32_MAX_PIXELS) else 64
+        return 0x40000400 | (tb << 16) | 64
 
     # Winograd F(4x4,3x3) (csrc/conv_wino4.inc): 2.25 multiplies per output instead of 4; one workgroup (32 tiles of 4x4 outputs x 64
     # couts, 18 accumulator tiles per wave) occupies a CU, so a launch takes ceil(workgroups / 256) x (14 us + 2.9 us per 8 input

@@ -1,0 +1,114 @@
+"""GPU: kernels of DIFFERENT frames run side by side on the same CUs when several frames are in flight (FramePipeline, ShardedPipeline).
+Round 4 found that `fax_attention_wave_kernel` (CoBEVT's attention for <= 4 valid agents, swap_fusion_modules.py:78-127) returned wrong rows
+(up to 0.2 abs) while its waves shared a CU with waves of the split-3 kernels (`conv_igemm_x3p`, the 32-tile `conv_wino_x3`) of another
+stream -- in the DEFAULT mode, for every pipelined CoBEVT frame with <= 4 agents; the kernel now owns its CU.
+(a) the C-ABI entry points themselves: an attention launch on one stream between split-3 GEMM / Winograd launches on another equals the
+    attention launched alone, bit for bit;
+(b) the frame: every frame of a 3-deep FramePipeline at the BASELINE grid equals the single-stream frame, for every model."""
+from ctypes import byref, c_void_p
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _s(stream):
+    return c_void_p(stream.cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from airv2x_perception_amd import _lib
+    return _lib.load()
+
+
+def _aggressors(lib):
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, to_bf16x3_koct
+    g = torch.Generator().manual_seed(3)
+    # a token Linear of the fusion (7 x 100 x 352 tokens, 256 -> 256) on conv_igemm_x3p, and a 3x3 layer on the 32-tile conv_wino_x3
+    lx = torch.randn(7, 100, 352, 256, generator=g).cuda()
+    lw, lcp = pack_conv_weight(torch.randn(256, 256, 1, 1, generator=g) / 16.0)
+    lw3 = to_bf16x3_koct(lw.cuda())
+    lout = torch.empty(7, 100, 352, 256, device="cuda")
+    cx = torch.randn(4, 25, 88, 256, generator=g).cuda()
+    cw, ccp = pack_conv_weight(torch.randn(256, 256, 3, 3, generator=g) / 48.0)
+    cw = cw.cuda()
+    cu3 = torch.empty(lib.av2x_wino_x3_weight_bytes(256, ccp) // 2, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.av2x_wino_x3_pack_weights(_p(cw), 256, ccp, _p(cu3), _s(torch.cuda.current_stream())), "pack")
+    cout = torch.empty(4, 25, 88, 256, device="cuda")
+    one, zero = torch.ones(256).cuda(), torch.zeros(256).cuda()
+    torch.cuda.synchronize()
+
+    def x3p(stream, bn):
+        d = _lib.ConvDesc(n=7, h=100, w=352, cin=256, in_ctot=256, in_coff=0, ho=100, wo=352, cout=256, coutp=lcp, out_ctot=256, out_coff=0,
+                          ks=1, stride=1, pad=0, relu=0, mode=0, up=1, tile=(128 << 16) | bn | 0x1400, sk_wgs=0)
+        _lib.check(lib.av2x_conv2d_res(byref(d), _p(lx), _p(lw3), _p(one), _p(zero), None, _p(lout), _s(stream)), "x3p")
+
+    def wino32(stream):
+        d = _lib.ConvDesc(n=4, h=25, w=88, cin=256, in_ctot=256, in_coff=0, ho=25, wo=88, cout=256, coutp=ccp, out_ctot=256, out_coff=0,
+                          ks=3, stride=1, pad=1, relu=1, mode=0, up=1, tile=0x40000400 | (32 << 16) | 64, sk_wgs=0)
+        _lib.check(lib.av2x_conv2d_res(byref(d), _p(cx), _p(cu3), _p(one), _p(zero), None, _p(cout), _s(stream)), "wino_x3 32")
+    return {"conv_igemm_x3p<128>": lambda s: [x3p(s, 128) for _ in range(2)], "conv_igemm_x3p<64>": lambda s: [x3p(s, 64) for _ in range(2)],
+            "conv_wino_x3 32-tile": lambda s: [wino32(s) for _ in range(6)]}
+
+
+@pytest.mark.parametrize("L,nv", [(7, 4), (4, 4), (7, 2), (8, 8)])
+def test_fax_attention_next_to_split3_kernels_of_another_stream(lib, L, nv):
+    from airv2x_perception_amd import _lib
+    g = torch.Generator().manual_seed(5 + L + nv)
+    H, W, heads = 100, 352, 8
+    qkv = torch.randn(L * H * W, 3 * heads * 32, generator=g).cuda()
+    table = (torch.randn((2 * L - 1) * 49, heads, generator=g) * 0.1).cuda()
+    out = torch.empty(L * H * W, heads * 32, device="cuda")
+
+    def fax(stream):
+        _lib.check(lib.av2x_fax_attention(_p(qkv), _p(table), _p(out), L, nv, H, W, 4, heads, 32, 0, _s(stream)), "av2x_fax_attention")
+    fax(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    alone = out.clone()
+    sa, sv = torch.cuda.Stream(), torch.cuda.Stream()
+    for name, agg in _aggressors(lib).items():
+        for rep in range(6):
+            out.zero_()
+            torch.cuda.synchronize()
+            agg(sa)
+            fax(sv)
+            agg(sa)
+            torch.cuda.synchronize()
+            assert torch.equal(out, alone), (name, rep, float((out - alone).abs().max()))
+
+
+@pytest.mark.parametrize("model_name,agents", [("where2com", 4), ("cobevt", 4), ("cobevt", 8), ("v2xvit", 4), ("v2xvit", 8)])
+def test_every_pipelined_frame_equals_the_single_stream_frame_at_the_baseline_grid(model_name, agents):
+    import bench
+    from airv2x_perception_amd.opencood_iface.engine import FramePipeline
+    dev = torch.device("cuda", 0)
+    a = SimpleNamespace(model=model_name, amp=False, gemm="x3", agents=agents, points=8192, mods=("lidar",))
+    hy, args, dd, clouds, types = bench.build_inputs(agents, 8192, dev, only=None, model=model_name, modalities=("lidar",))
+    model, eng, sd = bench.make_model(a, args, dev)
+    out = model(dd)
+    torch.cuda.synchronize()
+    keys = [k for k in ("psm", "rm", "obj") if k in out]
+    ref = {k: out[k].clone() for k in keys}
+    pipe = FramePipeline(eng, 3)
+    pending, bad = [], []
+    for f in range(24):
+        pending.append((f,) + pipe.submit(dd))
+        if len(pending) == 3:                                   # a slot's buffers are re-used three submits later: check before that
+            i, o, ev = pending.pop(0)
+            ev.synchronize()
+            if not all(torch.equal(o[k], ref[k]) for k in keys):
+                bad.append((i, max(float((o[k] - ref[k]).abs().max()) for k in keys)))
+    for i, o, ev in pending:
+        ev.synchronize()
+        if not all(torch.equal(o[k], ref[k]) for k in keys):
+            bad.append((i, max(float((o[k] - ref[k]).abs().max()) for k in keys)))
+    assert not bad, bad
