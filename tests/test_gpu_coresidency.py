@@ -8,7 +8,6 @@ stream -- in the DEFAULT mode, for every pipelined CoBEVT frame with <= 4 agents
 from ctypes import byref, c_void_p
 from types import SimpleNamespace
 
-import numpy as np
 import pytest
 import torch
 
@@ -86,12 +85,13 @@ def test_fax_attention_next_to_split3_kernels_of_another_stream(lib, L, nv):
             assert torch.equal(out, alone), (name, rep, float((out - alone).abs().max()))
 
 
-@pytest.mark.parametrize("model_name,agents", [("where2com", 4), ("cobevt", 4), ("cobevt", 8), ("v2xvit", 4), ("v2xvit", 8)])
-def test_every_pipelined_frame_equals_the_single_stream_frame_at_the_baseline_grid(model_name, agents):
+@pytest.mark.parametrize("model_name,agents,amp", [("where2com", 4, False), ("cobevt", 4, False), ("cobevt", 8, False), ("v2xvit", 4, False),
+                                                   ("v2xvit", 8, False), ("where2com", 4, True), ("cobevt", 4, True), ("v2xvit", 8, True)])
+def test_every_pipelined_frame_equals_the_single_stream_frame_at_the_baseline_grid(model_name, agents, amp):
     import bench
     from airv2x_perception_amd.opencood_iface.engine import FramePipeline
     dev = torch.device("cuda", 0)
-    a = SimpleNamespace(model=model_name, amp=False, gemm="x3", agents=agents, points=8192, mods=("lidar",))
+    a = SimpleNamespace(model=model_name, amp=amp, gemm="x3", agents=agents, points=8192, mods=("lidar",))
     hy, args, dd, clouds, types = bench.build_inputs(agents, 8192, dev, only=None, model=model_name, modalities=("lidar",))
     model, eng, sd = bench.make_model(a, args, dev)
     out = model(dd)
