@@ -1101,7 +1101,18 @@ class Where2ComEngine:
         if topk is not None:
             if len(topk) != B:
                 raise ValueError("topk: one K per sample")
-            ks = torch.tensor([int(topk[b]) for b, k in enumerate(record_len) for _ in range(k)], dtype=torch.int32, device=self.device)
+            # one K per agent, uploaded from a pinned staging buffer: a pageable torch.tensor(..., device=) copy waits for the stream to
+            # drain (1 ms of host stall per training step).  Four buffers in rotation: a buffer is rewritten four steps after its copy
+            # was queued.
+            vals = [int(topk[b]) for b, k in enumerate(record_len) for _ in range(k)]
+            ring = getattr(self, "_ks_ring", None)
+            if ring is None or ring[0][0].numel() < len(vals):
+                ring = self._ks_ring = [[torch.empty(max(len(vals), 16), dtype=torch.int32).pin_memory() for _ in range(4)], 0]
+            pin = ring[0][ring[1] % 4]
+            ring[1] += 1
+            pin[:len(vals)] = torch.tensor(vals, dtype=torch.int32)
+            ks = self.buf("comm_topk_k" + tag, (len(vals),), torch.int32)
+            ks.copy_(pin[:len(vals)], non_blocking=True)
             _lib.check(self.lib.av2x_fill_zero(_ptr(count), B * 4, st), "av2x_fill_zero")
             _lib.check(self.lib.av2x_comm_mask_topk(_ptr(smooth), n, H * W, _ptr(ks), _ptr(lay[0]), _ptr(lay[1]), _ptr(mask), _ptr(count),
                                                     st), "av2x_comm_mask_topk")

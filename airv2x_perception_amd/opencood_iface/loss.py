@@ -19,6 +19,76 @@ def _p(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+class _LossDict(dict):
+    """``loss_dict`` of the reference holds python floats read back with three ``.item()`` calls inside ``forward``
+    (point_pillar_loss_multiclass.py:172-177) -- a host wait for the whole queued forward before the backward can be issued.  Here the
+    values (and the class-id range check) travel to a pinned host buffer asynchronously and become floats at the FIRST READ of the
+    dict (``logging``, ``loss_dict[...]``, iteration) -- or at a later ``forward`` once the copy has landed; an out-of-range class id
+    raises there."""
+
+    def __init__(self):
+        super().__init__()
+        self._pending = []
+
+    def _push(self, prefix, host, event, num_class, checked):
+        self._pending.append((prefix, host, event, num_class, checked))
+
+    def _flush(self, block=True):
+        """block=False (the next forward): only the read-backs that have already landed, in order -- no host wait."""
+        while self._pending:
+            prefix, host, event, num_class, checked = self._pending[0]
+            if not block and not event.query():
+                return
+            self._pending.pop(0)
+            event.synchronize()
+            vals = host.tolist()
+            dict.update(self, {"total_loss" + prefix: vals[0], "reg_loss" + prefix: vals[1], "conf_loss" + prefix: vals[2]})
+            if checked:
+                lo, hi = int(vals[-2]), int(vals[-1])
+                if lo < 0 or hi >= num_class:
+                    raise IndexError(f"class_ids outside [0, {num_class}): min {lo}, max {hi}")
+
+    def __getitem__(self, k):
+        self._flush()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._flush()
+        return dict.get(self, k, default)
+
+    def items(self):
+        self._flush()
+        return dict.items(self)
+
+    def values(self):
+        self._flush()
+        return dict.values(self)
+
+    def keys(self):
+        self._flush()
+        return dict.keys(self)
+
+    def __iter__(self):
+        self._flush()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._flush()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._flush()
+        return dict.__contains__(self, k)
+
+    def __repr__(self):
+        self._flush()
+        return dict.__repr__(self)
+
+    def copy(self):
+        self._flush()
+        return dict(self)
+
+
 class _PPLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, psm, rm, obj, targets, pos, cls, num_class, cls_weight, reg_coe):
@@ -59,7 +129,7 @@ class PointPillarLossMultiClass(nn.Module):
         self.cls_weight = args["cls_weight"]
         self.reg_coe = args["reg"]
         self.flow_weight = args["flow_weight"] if "flow_weight" in args else 1.0
-        self.loss_dict = {}
+        self.loss_dict = _LossDict()
         self.use_dir = False
         self.cls_num = args["num_class"]
         self.validate_class_ids = True
@@ -86,14 +156,18 @@ class PointPillarLossMultiClass(nn.Module):
         total, parts = _PPLoss.apply(cont(psm), cont(rm), cont(obj), f32(target_dict["targets"]), f32(target_dict["pos_equal_one"]),
                                      target_dict["class_ids"].detach().to(psm.device, torch.int32).contiguous(),
                                      int(self.cls_num), self.cls_weight, self.reg_coe)
-        if cid.numel() and self.validate_class_ids:
-            both = torch.cat([parts.detach().float().flatten(), cid_range.to(parts.device)]).tolist()   # ONE read-back: loss parts + id range
-            vals, (lo, hi) = both[:-2], (int(both[-2]), int(both[-1]))
-            if lo < 0 or hi >= int(self.cls_num):
-                raise IndexError(f"class_ids outside [0, {int(self.cls_num)}): min {lo}, max {hi}")
-        else:
-            vals = parts.tolist()                 # the reference's three .item() calls (:172-177) in one read-back
-        self.loss_dict.update({"total_loss" + prefix: vals[0], "reg_loss" + prefix: vals[1], "conf_loss" + prefix: vals[2]})
+        if not isinstance(self.loss_dict, _LossDict):      # a caller replaced it with a plain dict: keep its entries, restore the lazy one
+            ld = _LossDict()
+            dict.update(ld, self.loss_dict)
+            self.loss_dict = ld
+        self.loss_dict._flush(block=False)                 # read-backs of earlier calls that have landed (their class-id verdict with them)
+        checked = bool(cid.numel() and self.validate_class_ids)
+        dev_vals = torch.cat([parts.detach().float().flatten(), cid_range.to(parts.device)]) if checked else parts.detach().float().flatten()
+        host = torch.empty(dev_vals.numel(), dtype=torch.float32).pin_memory()
+        host.copy_(dev_vals, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self.loss_dict._push(prefix, host, event, int(self.cls_num), checked)
         return total
 
     def logging(self, epoch, batch_id, batch_len, writer=None):

@@ -67,6 +67,33 @@ def test_gpu_loss_and_gradients_match_reference(tag, kw):
 
 
 @pytest.mark.gpu
+def test_gpu_loss_dict_is_read_back_lazily_and_an_out_of_range_class_id_raises_at_the_read():
+    """forward() queues the three scalars (and the class-id range of point_pillar_loss_multiclass.py:118-125's one_hot) to a pinned buffer
+    without waiting for the device; the floats -- and the IndexError the reference's scatter_ would raise -- appear at the first read."""
+    from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
+    tag, kw = CASES[0]
+    t = {k: torch.from_numpy(v).cuda() for k, v in synth.loss_case(**kw).items()}
+    heads = {k: t[k].clone().requires_grad_(True) for k in ("psm", "rm", "obj")}
+    tgt = {k: t[k] for k in ("targets", "pos_equal_one", "neg_equal_one", "class_ids")}
+    crit = PointPillarLossMultiClass(ARGS)
+    total = crit(heads, tgt)
+    assert crit.loss_dict._pending and not dict.__len__(crit.loss_dict)          # nothing read back yet
+    total.backward()
+    assert abs(crit.loss_dict["total_loss"] - float(total.detach())) <= 1e-6 * abs(float(total.detach()))
+    assert not crit.loss_dict._pending
+    assert "Loss" in crit.logging(0, 0, 1)
+    bad = dict(tgt)
+    bad["class_ids"] = tgt["class_ids"].clone()
+    bad["class_ids"].view(-1)[3] = ARGS["num_class"]
+    crit(heads, bad)
+    with pytest.raises(IndexError):
+        crit.loss_dict["total_loss"]
+    crit.validate_class_ids = False
+    crit(heads, bad)
+    assert crit.loss_dict["total_loss"] == crit.loss_dict["total_loss"]
+
+
+@pytest.mark.gpu
 def test_gpu_loss_full_head_maps():
     """Two frames of full 100 x 352 head maps: the three scalars and strided samples / abs-sums of the gradients."""
     from airv2x_perception_amd.opencood_iface.loss import PointPillarLossMultiClass
