@@ -20,7 +20,8 @@ The ResNet backbone variant (``backbone.resnet``, base_bev_backbone_resnet.py ->
 Raises, as the reference does: the 'Transformer' aggregation -- ``Where2comm.forward`` calls ``self.fuse_modules[i](neighbor_feature)``
 with ONE argument (:360) where ``TransformerFusion.forward`` takes four (:130-136: TypeError), its EncodeLayer passes a ``quality_map``
 keyword that ``nn.MultiheadAttention`` does not accept (:105-107), and the single-scale form stores the module as ``fuse_network`` but
-calls ``fuse_modules`` (:262, :399): no configuration of that mode can run in the reference.  Inference only, GPU only.
+calls ``fuse_modules`` (:262, :399): no configuration of that mode can run in the reference.  GPU only; ``.train()`` forwards are
+differentiable in x and in the backbone's parameters (``_forward_train``; the ResNet backbone variant trains in the reference only).
 """
 from __future__ import annotations
 
@@ -32,7 +33,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .engine import _ptr
-from .submodules import BaseBEVBackbone, _HipModule, _Runner, _declare, _lens, _nchw, _nhwc
+from .submodules import BaseBEVBackbone, _HipModule, _Runner, _declare, _lens, _nchw, _nhwc, _nhwc_grad
 
 _MODES = {"ATTEN": 0, "MAX": 1}
 
@@ -138,11 +139,11 @@ class Where2comm(_HipModule):
             r.gauss_b = sd["naive_communication.gaussian_filter.bias"].detach().to(r.device, torch.float32).reshape(1).contiguous()
             r.gauss_k = int(w.shape[-1])
 
-    def runner(self):
+    def runner(self, train_ok=False):
         if self._tensors():
-            return super().runner()
-        if self.training:
-            raise NotImplementedError("Where2comm: training is not built; call .eval()")
+            return super().runner(train_ok=train_ok)
+        if self.training and not train_ok:
+            raise NotImplementedError("Where2comm: this forward has no training form; call .eval()")
         if self._runner_obj is None:
             self.__dict__["_runner_obj"] = self._make_runner(torch.device("cuda", torch.cuda.current_device()))
             self._pack(self._runner_obj, {})
@@ -195,11 +196,71 @@ class Where2comm(_HipModule):
                                             r.stream()), "av2x_warp_fuse")
             a0 += k
 
+    # ------------------------------------------------------------------ train mode
+    def _forward_train(self, x, rm, lens, pairwise_t_matrix, backbone):
+        """Train mode of where2comm_attn.py:275-404: the same schedule on differentiable nodes (HIP forward / backward pairs) --
+        backbone blocks / deblocks with BatchNorm batch statistics (submodules.BaseBEVBackbone), the communication mask as a constant
+        (torch.where over constants carries no gradient, where2comm.py:84-86), ``warp_affine_simple`` with its adjoint, the per-pixel
+        attention / the maximum over the warped agents.  Differentiable in x and in the backbone's parameters (the module itself has
+        none that receive a gradient: the smoothing filter only shapes the mask)."""
+        from . import train_ops as T
+        from .train_v2vnet import AgentMaxFn
+        from .train_when2com import warp_affine_simple
+        r = self.runner(train_ok=True)
+        _, C, H, W = x.shape
+        B = len(lens)
+        theta = normalized_pairwise(pairwise_t_matrix, H, W, self.discrete_ratio, self.downsample_rate)
+        th = [torch.from_numpy(np.ascontiguousarray(theta[b, 0, :k], dtype=np.float32)).to(r.device) for b, k in enumerate(lens)]
+
+        def fuse(cur):
+            outs, a0 = [], 0
+            for b, k in enumerate(lens):
+                warped = warp_affine_simple(cur[a0:a0 + k], th[b])
+                outs.append(T.PixelAttn.apply(warped) if self.agg_mode == "ATTEN" else AgentMaxFn.apply(warped)[0])
+                a0 += k
+            return torch.stack(outs)
+
+        cur = _nhwc_grad(x)
+        vol = None
+        if not self.multi_scale:
+            if self.communication:
+                with torch.no_grad():
+                    mask, vol = self._communicate(r, cur.detach(), rm, lens)
+                    # as written (:394): the mask of GLOBAL agent b for every agent of sample b
+                    m = torch.cat([mask[b:b + 1].expand(k, -1, -1) for b, k in enumerate(lens)]).contiguous()
+                cur = T.MaskMul.apply(cur, m)
+            return _nchw(fuse(cur)), self._volume(vol, B, r), {}
+        if hasattr(backbone, "resnet") or not isinstance(backbone, BaseBEVBackbone):
+            raise NotImplementedError("Where2comm training: the multi-scale fusion over this build's BaseBEVBackbone (not the ResNet variant)")
+        ups = []
+        for i in range(self.num_levels):
+            cur = backbone._train_block(i, cur)
+            if i == 0 and self.communication:
+                with torch.no_grad():
+                    mask, vol = self._communicate(r, cur.detach(), rm, lens)
+                    mask = mask.clone()
+                cur = T.MaskMul.apply(cur, mask)
+            fused = fuse(cur)
+            ups.append(backbone._train_deblock(i, fused) if backbone.model_cfg.get("upsample_strides") else fused)
+        if len(ups) > 1 and not backbone.model_cfg.get("upsample_strides"):
+            raise NotImplementedError("multi-scale Where2comm without deblocks needs a single level")
+        return _nchw(torch.cat(ups, -1) if len(ups) > 1 else ups[0]), self._volume(vol, B, r), {}
+
     # ------------------------------------------------------------------ forward
-    @torch.no_grad()
     def forward(self, x, rm, record_len, pairwise_t_matrix, backbone=None, heads=None):
         if x.device.type != "cuda":
             raise RuntimeError("Where2comm (MI355X build) has no CPU path: move the module and its inputs to the GPU")
+        if self.training:
+            lens = _lens(record_len)
+            if any(k < 1 for k in lens):
+                raise ValueError("every sample needs at least the ego agent")
+            if pairwise_t_matrix.shape[0] != len(lens) or max(lens) > pairwise_t_matrix.shape[1] or sum(lens) != x.shape[0]:
+                raise ValueError("pairwise_t_matrix / record_len do not match the agents")
+            return self._forward_train(x, rm, lens, pairwise_t_matrix, backbone)
+        with torch.no_grad():
+            return self._forward_eval(x, rm, record_len, pairwise_t_matrix, backbone, heads)
+
+    def _forward_eval(self, x, rm, record_len, pairwise_t_matrix, backbone=None, heads=None):
         r = self.runner()
         lens = _lens(record_len)
         if any(k < 1 for k in lens):

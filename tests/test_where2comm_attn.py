@@ -274,3 +274,63 @@ def test_gpu_multi_scale_full_canvas_five_agents():
     tot, ab = float(fused.double().sum()), float(fused.double().abs().sum())
     assert abs(tot - float(g["ms_atten_full_sum"])) <= 1e-5 * float(g["ms_atten_full_abs_sum"])
     assert abs(ab - float(g["ms_atten_full_abs_sum"])) <= 1e-5 * float(g["ms_atten_full_abs_sum"])
+
+
+# ---------------------------------------------------------------------------------------------------- train mode
+TRAIN_GOLD = os.path.join(os.path.dirname(__file__), "golden", "train_w2c_attn.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,single", [("ms_atten", False), ("ms_max", False), ("ss_atten", True)])
+def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
+    """`Where2comm.train()` (where2comm_attn.py:275-404 under autograd, the reference's BaseBEVBackbone with batch statistics):
+    fused map, dL/dx, every backbone parameter's gradient and the BatchNorm buffers of one step against
+    tests/golden/train_w2c_attn.npz (tools/gen_golden.py train_w2c_attn: the reference's own modules; gradients from its float64 pass)."""
+    from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
+    from airv2x_perception_amd.opencood_iface.submodules import BaseBEVBackbone
+    g = np.load(TRAIN_GOLD)
+    c = CFG[tag]
+    rl, seed = [int(v) for v in g[f"{tag}_rl"]], int(g[f"{tag}_seed"])
+    mod = wm.Where2comm(c)
+    mod.load_state_dict(_gauss_sd(c, seed + 500), strict=True)
+    mod = mod.cuda().train()
+    n = sum(rl)
+    if single:
+        x = torch.from_numpy(synth.w2c_attn_features(seed, n, 256, H // 2, W // 2, keep=0.6))
+        rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H // 2, W // 2))
+        bb = None
+    else:
+        x = torch.from_numpy(synth.w2c_attn_features(seed, n, 64, H, W))
+        rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H // 2, W // 2))
+        bb = BaseBEVBackbone(CFG["backbone"], 64)
+        bb.load_state_dict(synth.synthetic_state_dict(synth.backbone_param_spec(CFG["backbone"], 64, ""), seed=31), strict=True)
+        bb = bb.cuda().train()
+        for p_ in bb.parameters():
+            p_.requires_grad_(True)
+    xg = x.cuda().requires_grad_(True)
+    pw = synth.w2c_attn_pairwise(rl).cuda()
+    fused, vol, extra = mod(xg, rm.cuda(), torch.tensor(rl).cuda(), pw) if single else mod(xg, rm.cuda(), torch.tensor(rl).cuda(), pw, bb, None)
+    assert extra == {} and fused.requires_grad and float(vol) == float(g[f"{tag}_vol"])
+    _close(fused, g[f"{tag}_fused"])
+    G = torch.from_numpy(synth.seeded_uniform(seed + 9, tuple(fused.shape), -1.0, 1.0)).cuda()
+    (fused * G).sum().backward()
+    got = {"x": xg.grad}
+    if bb is not None:
+        got.update({k: p_.grad for k, p_ in bb.named_parameters()})
+    keys = [str(k) for k in g[f"{tag}_grad_keys"]]
+    assert len(keys) == (1 if single else 28)
+    worst = 0.0
+    for k in keys:
+        assert got[k] is not None, k
+        gm = max(float(g[f"{tag}_g64max:{k}"]), 1e-30)
+        v = got[k].reshape(-1)
+        stride = max(1, v.numel() // 4096)
+        d = np.abs(v[::stride].cpu().numpy().astype(np.float64) - g[f"{tag}_g64:{k}"].astype(np.float64)).max() / gm
+        a = abs(float(v.double().abs().sum()) - float(g[f"{tag}_g64abs:{k}"])) / max(float(g[f"{tag}_g64abs:{k}"]), 1e-30)
+        worst = max(worst, d)
+        assert d <= 3e-4 and a <= 3e-4, (k, d, a, float(g[f"{tag}_gdev:{k}"]))
+    print(f"{tag}: {len(keys)} gradients, worst deviation from the float64 step {worst:.2e} of the gradient's maximum")
+    if bb is not None:
+        for k, b in bb.named_buffers():
+            ref = g[f"{tag}_b:{k}"].astype(np.float64)
+            assert np.abs(b.detach().cpu().numpy().astype(np.float64) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), k

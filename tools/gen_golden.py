@@ -1857,6 +1857,83 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def train_w2c_attn_golden(name="train_w2c_attn"):
+    """One differentiable forward + backward of the OPV2V-style Where2comm (where2comm_modules/where2comm_attn.py) in TRAIN mode on the
+    reference's own modules (its BaseBEVBackbone with BatchNorm batch statistics): L = <fused, G> with a seeded G; the fixture holds
+    fused, dL/dx, the gradient of every backbone parameter, the BatchNorm buffers after the step -- in fp32 and from a float64 pass
+    (the yardstick of the other training fixtures).  Inputs and weights are regenerated from the seeds (synth.w2c_attn_*)."""
+    from airv2x_perception_amd import synth
+    _stub("turtle", update=None)
+    from opencood.models.common_modules.base_bev_backbone import BaseBEVBackbone
+    from opencood.models.where2comm_modules.where2comm_attn import Where2comm
+    cfg = synth.w2c_attn_configs()
+    bbc = cfg["backbone"]
+    H, W = 32, 48
+    out = {}
+    spec = synth.backbone_param_spec(bbc, 64, "")
+    bsd = synth.synthetic_state_dict(spec, seed=31)
+
+    def gauss(mod, seed):
+        sd = mod.state_dict()
+        if sd:
+            k = sd["naive_communication.gaussian_filter.weight"].shape[-1]
+            sd["naive_communication.gaussian_filter.weight"] = sd["naive_communication.gaussian_filter.weight"] * \
+                torch.from_numpy(synth.seeded_uniform(seed, (1, 1, k, k), 0.8, 1.2)).to(sd["naive_communication.gaussian_filter.weight"].dtype)
+            sd["naive_communication.gaussian_filter.bias"] = torch.tensor([1e-4], dtype=sd["naive_communication.gaussian_filter.bias"].dtype)
+            mod.load_state_dict(sd, strict=True)
+
+    def run(tag, rl, seed, dtype, ch=64, hw=(H, W), single=False):
+        c = cfg[tag]
+        mod = Where2comm(c).train()
+        gauss(mod, seed + 500)
+        bb = BaseBEVBackbone(bbc, 64)
+        bb.load_state_dict(bsd, strict=True)
+        bb.train()
+        if dtype == torch.float64:
+            mod, bb = mod.double(), bb.double()
+        n = sum(rl)
+        x = torch.from_numpy(synth.w2c_attn_features(seed, n, ch, hw[0], hw[1], keep=0.6 if single else 0.35)).to(dtype).requires_grad_(True)
+        rmh = (hw[0], hw[1]) if single else (hw[0] // 2, hw[1] // 2)
+        rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, rmh[0], rmh[1])).to(dtype)
+        pw = synth.w2c_attn_pairwise(rl).to(dtype)
+        fused, vol, _ = mod(x, rm, torch.tensor(rl), pw) if single else mod(x, rm, torch.tensor(rl), pw, bb, None)
+        G = torch.from_numpy(synth.seeded_uniform(seed + 9, tuple(fused.shape), -1.0, 1.0)).to(dtype)
+        (fused * G).sum().backward()
+        grads = {"x": x.grad.detach()}
+        if not single:
+            grads.update({k: p_.grad.detach() for k, p_ in bb.named_parameters() if p_.grad is not None})
+        bufs = {} if single else {k: b.detach().clone() for k, b in bb.named_buffers()}
+        return fused.detach(), float(vol), grads, bufs
+
+    for tag, rl, seed, kw in (("ms_atten", [3, 2], 61, {}), ("ms_max", [3], 62, {}),
+                              ("ss_atten", [2, 2], 63, dict(ch=256, hw=(H // 2, W // 2), single=True))):
+        f32, vol, g32, b32 = run(tag, rl, seed, torch.float32, **kw)
+        f64, vol64, g64, _ = run(tag, rl, seed, torch.float64, **kw)
+        assert vol == vol64, (tag, vol, vol64)
+        out[f"{tag}_fused"] = f32.numpy()
+        out[f"{tag}_vol"] = np.float64(vol)
+        out[f"{tag}_rl"] = np.asarray(rl, np.int64)
+        out[f"{tag}_seed"] = np.int64(seed)
+        devs = []
+        for k, g in g32.items():
+            gm = float(g64[k].abs().max())
+            stride = max(1, g.numel() // 4096)                    # strided sample + the abs-sum of the whole gradient
+            out[f"{tag}_g64:{k}"] = g64[k].reshape(-1)[::stride].float().numpy()
+            out[f"{tag}_g64abs:{k}"] = np.float64(float(g64[k].abs().sum()))
+            out[f"{tag}_g64max:{k}"] = np.float64(gm)
+            d = float((g.double() - g64[k]).abs().max()) / max(gm, 1e-300)
+            out[f"{tag}_gdev:{k}"] = np.float64(d)
+            devs.append(d)
+        out[f"{tag}_grad_keys"] = np.asarray(list(g32.keys()))
+        for k, b in b32.items():
+            out[f"{tag}_b:{k}"] = b.numpy()
+        print(f"[{name}] {tag}: fused {tuple(f32.shape)}, volume {vol:.1f}, {len(g32)} gradients, fp32 vs float64 worst {max(devs):.2e} median {sorted(devs)[len(devs) // 2]:.2e}; "
+              f"forward fp32 vs float64 {float((f32.double() - f64).abs().max()):.2e}")
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def _load_ref_hypes_v2xvit(lidar_range, max_cav):
     from opencood.hypes_yaml.yaml_utils import load_yaml
     src = os.path.join(REF, "opencood/hypes_yaml/airv2x/lidar/det/airv2x_intermediate_v2xvit.yaml")
@@ -2146,6 +2223,7 @@ GROUPS = {
                              train_v2vnet_golden("train_v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 900, 27, agg="max")),
     "train_when2com_full": lambda: train_when2com_golden("train_when2com_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 28, head_stride=4),
     "train_v2vnet_full": lambda: train_v2vnet_golden("train_v2vnet_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 29, head_stride=4),
+    "train_w2c_attn": train_w2c_attn_golden,
     "train_cam": lambda: (train_cam_golden("train_cam_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 31, 5, (104, 168), ("cam", "lidar"),
                                            {"vehicle": 2, "rsu": 1, "drone": 1}),
                           train_cam_golden("train_cam_small_camonly_n2", SMALL, ["vehicle", "drone"], 700, 32, 6, (104, 168), ("cam",),
