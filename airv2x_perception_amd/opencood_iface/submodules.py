@@ -419,7 +419,7 @@ class ResNetBEVBackbone(BaseBEVBackbone):
     """models/common_modules/base_bev_backbone_resnet.py:16-128 (the backbone of airv2x_heal / airv2x_stamp / point_pillar_coalign):
     ``resnet`` = coalign_modules.resblock.ResNetModified(BasicBlock, layer_nums, layer_strides, num_filters, inplanes) returning the
     level maps (levels ``layer0``, ``layer1``, ...), then BaseBEVBackbone's deblocks.  ``resnet(x)`` is callable on NCHW-shaped maps like the reference's module
-    (where2comm_attn.py:312-314 calls it).  Eval mode."""
+    (where2comm_attn.py:312-314 calls it).  Eval and train mode."""
 
     def __init__(self, model_cfg, input_channels=64):
         _HipModule.__init__(self)
@@ -430,7 +430,7 @@ class ResNetBEVBackbone(BaseBEVBackbone):
         nlev = len(model_cfg["layer_nums"])
         if len(ups) not in (0, nlev, nlev + 1):
             raise ValueError("upsample_strides: one per level, optionally one more for the final deblock")
-        self.variant = True               # no training path
+        self.variant = True               # BaseBEVBackbone's blocks[i] / packed deblock variants do not apply; see _train_check
         _declare(self, resnet_backbone_param_spec(model_cfg, "", self.input_channels))
         if "deblocks" not in self._modules:
             self.add_module("deblocks", _Node())
@@ -475,16 +475,49 @@ class ResNetBEVBackbone(BaseBEVBackbone):
             feats.append(cur)
         return feats
 
+    # ---- train mode: resblock.py's BasicBlocks (conv3x3 - BN - ReLU - conv3x3 - BN, 1x1 downsample, add, ReLU; nn.BatchNorm2d defaults)
+    #      on train_camera's nodes (the same block BevEncode trains with), BaseBEVBackbone's deblocks
+    def _train_check(self):
+        ups = self.model_cfg.get("upsample_strides", [])
+        if len(ups) > self.num_levels or any(u < 1 for u in ups):
+            raise NotImplementedError("ResNetBEVBackbone training: one up-sampling deblock per level (no down-sampling / final deblock)")
+
+    def _train_resnet(self, x):
+        from . import train_camera as TC
+        P, sd = self._train_state()
+        feats, cur = [], x
+        for li, (nb, stride) in enumerate(zip(self.model_cfg["layer_nums"], self.model_cfg["layer_strides"])):
+            for bi in range(nb):
+                cur = TC.basic_block(P, sd, f"resnet.layer{li}.{bi}.", cur, stride if bi == 0 else 1)
+            feats.append(cur)
+        return feats
+
     def _run_resnet(self, _i, x):
+        if self.training:
+            return tuple(_nchw(f) for f in self._train_resnet(_nhwc_grad(x)))
         with torch.no_grad():
             return tuple(_nchw(f) for f in self.resnet_nhwc(_nhwc(x)))
+
+    def _run_deblock(self, i, x):
+        if self.training:
+            self._train_check()
+            return _nchw(self._train_deblock(i, _nhwc_grad(x)))
+        with torch.no_grad():
+            return _nchw(self.deblock_nhwc(i, _nhwc(x)))
 
     def block_nhwc(self, i, x, out=None):
         raise NotImplementedError("ResNetBEVBackbone has no blocks[i]: call resnet(x)")
 
     def forward(self, data_dict):
         if self.training:
-            raise NotImplementedError("ResNetBEVBackbone: training is not built; call .eval()")
+            self._train_check()
+            feats = self._train_resnet(_nhwc_grad(data_dict["spatial_features"]))
+            if self.model_cfg.get("upsample_strides"):
+                feats = [self._train_deblock(i, f) for i, f in enumerate(feats)]
+            elif len(feats) > 1 and not all(f.shape[1:3] == feats[0].shape[1:3] for f in feats):
+                raise ValueError("ResNetBEVBackbone without deblocks: the level maps have different resolutions and cannot be concatenated")
+            data_dict["spatial_features_2d"] = _nchw(torch.cat(feats, -1) if len(feats) > 1 else feats[0])
+            return data_dict
         with torch.no_grad():
             r = self.runner()
             feats = self.resnet_nhwc(_nhwc(data_dict["spatial_features"]))

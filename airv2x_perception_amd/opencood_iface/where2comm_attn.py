@@ -21,7 +21,7 @@ Raises, as the reference does: the 'Transformer' aggregation -- ``Where2comm.for
 with ONE argument (:360) where ``TransformerFusion.forward`` takes four (:130-136: TypeError), its EncodeLayer passes a ``quality_map``
 keyword that ``nn.MultiheadAttention`` does not accept (:105-107), and the single-scale form stores the module as ``fuse_network`` but
 calls ``fuse_modules`` (:262, :399): no configuration of that mode can run in the reference.  GPU only; ``.train()`` forwards are
-differentiable in x and in the backbone's parameters (``_forward_train``; the ResNet backbone variant trains in the reference only).
+differentiable in x and in the backbone's parameters (``_forward_train``), over either backbone.
 """
 from __future__ import annotations
 
@@ -230,11 +230,15 @@ class Where2comm(_HipModule):
                     m = torch.cat([mask[b:b + 1].expand(k, -1, -1) for b, k in enumerate(lens)]).contiguous()
                 cur = T.MaskMul.apply(cur, m)
             return _nchw(fuse(cur)), self._volume(vol, B, r), {}
-        if hasattr(backbone, "resnet") or not isinstance(backbone, BaseBEVBackbone):
-            raise NotImplementedError("Where2comm training: the multi-scale fusion over this build's BaseBEVBackbone (not the ResNet variant)")
+        if not isinstance(backbone, BaseBEVBackbone):
+            raise TypeError("Where2comm (MI355X build): `backbone` must be the BaseBEVBackbone / ResNetBEVBackbone of this build")
+        with_resnet = hasattr(backbone, "resnet")                  # :312-314: every level from the UNMASKED input, as written
+        if with_resnet:
+            backbone._train_check()
+            feats = backbone._train_resnet(cur)
         ups = []
         for i in range(self.num_levels):
-            cur = backbone._train_block(i, cur)
+            cur = feats[i] if with_resnet else backbone._train_block(i, cur)
             if i == 0 and self.communication:
                 with torch.no_grad():
                     mask, vol = self._communicate(r, cur.detach(), rm, lens)

@@ -281,15 +281,16 @@ TRAIN_GOLD = os.path.join(os.path.dirname(__file__), "golden", "train_w2c_attn.n
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,single", [("ms_atten", False), ("ms_max", False), ("ss_atten", True)])
+@pytest.mark.parametrize("tag,single", [("ms_atten", False), ("ms_max", False), ("ss_atten", True), ("ms_resnet", False), ("resnet_alone", False)])
 def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
     """`Where2comm.train()` (where2comm_attn.py:275-404 under autograd, the reference's BaseBEVBackbone with batch statistics):
     fused map, dL/dx, every backbone parameter's gradient and the BatchNorm buffers of one step against
     tests/golden/train_w2c_attn.npz (tools/gen_golden.py train_w2c_attn: the reference's own modules; gradients from its float64 pass)."""
     from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
-    from airv2x_perception_amd.opencood_iface.submodules import BaseBEVBackbone
+    from airv2x_perception_amd.opencood_iface.submodules import BaseBEVBackbone, ResNetBEVBackbone
     g = np.load(TRAIN_GOLD)
-    c = CFG[tag]
+    resnet, alone = tag in ("ms_resnet", "resnet_alone"), tag == "resnet_alone"
+    c = CFG["ms_atten" if resnet else tag]
     rl, seed = [int(v) for v in g[f"{tag}_rl"]], int(g[f"{tag}_seed"])
     mod = wm.Where2comm(c)
     mod.load_state_dict(_gauss_sd(c, seed + 500), strict=True)
@@ -302,14 +303,21 @@ def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
     else:
         x = torch.from_numpy(synth.w2c_attn_features(seed, n, 64, H, W))
         rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H // 2, W // 2))
-        bb = BaseBEVBackbone(CFG["backbone"], 64)
-        bb.load_state_dict(synth.synthetic_state_dict(synth.backbone_param_spec(CFG["backbone"], 64, ""), seed=31), strict=True)
+        if resnet:     # base_bev_backbone_resnet.py + resblock.py in train mode
+            bb = ResNetBEVBackbone(CFG["resnet_backbone"], 64)
+            bb.load_state_dict(synth.synthetic_state_dict(synth.resnet_backbone_param_spec(CFG["resnet_backbone"], ""), seed=33), strict=True)
+        else:
+            bb = BaseBEVBackbone(CFG["backbone"], 64)
+            bb.load_state_dict(synth.synthetic_state_dict(synth.backbone_param_spec(CFG["backbone"], 64, ""), seed=31), strict=True)
         bb = bb.cuda().train()
         for p_ in bb.parameters():
             p_.requires_grad_(True)
     xg = x.cuda().requires_grad_(True)
     pw = synth.w2c_attn_pairwise(rl).cuda()
-    fused, vol, extra = mod(xg, rm.cuda(), torch.tensor(rl).cuda(), pw) if single else mod(xg, rm.cuda(), torch.tensor(rl).cuda(), pw, bb, None)
+    if alone:
+        fused, vol, extra = bb({"spatial_features": xg})["spatial_features_2d"], 0.0, {}
+    else:
+        fused, vol, extra = mod(xg, rm.cuda(), torch.tensor(rl).cuda(), pw) if single else mod(xg, rm.cuda(), torch.tensor(rl).cuda(), pw, bb, None)
     assert extra == {} and fused.requires_grad and float(vol) == float(g[f"{tag}_vol"])
     _close(fused, g[f"{tag}_fused"])
     G = torch.from_numpy(synth.seeded_uniform(seed + 9, tuple(fused.shape), -1.0, 1.0)).cuda()
@@ -318,7 +326,7 @@ def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
     if bb is not None:
         got.update({k: p_.grad for k, p_ in bb.named_parameters()})
     keys = [str(k) for k in g[f"{tag}_grad_keys"]]
-    assert len(keys) == (1 if single else 28)
+    assert len(keys) == (1 if single else 49 if resnet else 28)
     worst = 0.0
     for k in keys:
         assert got[k] is not None, k

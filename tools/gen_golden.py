@@ -1882,12 +1882,20 @@ def train_w2c_attn_golden(name="train_w2c_attn"):
             sd["naive_communication.gaussian_filter.bias"] = torch.tensor([1e-4], dtype=sd["naive_communication.gaussian_filter.bias"].dtype)
             mod.load_state_dict(sd, strict=True)
 
-    def run(tag, rl, seed, dtype, ch=64, hw=(H, W), single=False):
+    from opencood.models.common_modules.base_bev_backbone_resnet import ResNetBEVBackbone
+    rbc = cfg["resnet_backbone"]
+    rsd = synth.synthetic_state_dict(synth.resnet_backbone_param_spec(rbc, ""), seed=33)
+
+    def run(tag, rl, seed, dtype, ch=64, hw=(H, W), single=False, resnet=False, alone=False):
         c = cfg[tag]
         mod = Where2comm(c).train()
         gauss(mod, seed + 500)
-        bb = BaseBEVBackbone(bbc, 64)
-        bb.load_state_dict(bsd, strict=True)
+        if resnet:
+            bb = ResNetBEVBackbone(rbc, 64)
+            bb.load_state_dict(rsd, strict=True)
+        else:
+            bb = BaseBEVBackbone(bbc, 64)
+            bb.load_state_dict(bsd, strict=True)
         bb.train()
         if dtype == torch.float64:
             mod, bb = mod.double(), bb.double()
@@ -1896,7 +1904,10 @@ def train_w2c_attn_golden(name="train_w2c_attn"):
         rmh = (hw[0], hw[1]) if single else (hw[0] // 2, hw[1] // 2)
         rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, rmh[0], rmh[1])).to(dtype)
         pw = synth.w2c_attn_pairwise(rl).to(dtype)
-        fused, vol, _ = mod(x, rm, torch.tensor(rl), pw) if single else mod(x, rm, torch.tensor(rl), pw, bb, None)
+        if alone:            # the backbone's own forward (base_bev_backbone_resnet.py:101-128)
+            fused, vol = bb({"spatial_features": x})["spatial_features_2d"], 0.0
+        else:
+            fused, vol, _ = mod(x, rm, torch.tensor(rl), pw) if single else mod(x, rm, torch.tensor(rl), pw, bb, None)
         G = torch.from_numpy(synth.seeded_uniform(seed + 9, tuple(fused.shape), -1.0, 1.0)).to(dtype)
         (fused * G).sum().backward()
         grads = {"x": x.grad.detach()}
@@ -1906,9 +1917,11 @@ def train_w2c_attn_golden(name="train_w2c_attn"):
         return fused.detach(), float(vol), grads, bufs
 
     for tag, rl, seed, kw in (("ms_atten", [3, 2], 61, {}), ("ms_max", [3], 62, {}),
-                              ("ss_atten", [2, 2], 63, dict(ch=256, hw=(H // 2, W // 2), single=True))):
-        f32, vol, g32, b32 = run(tag, rl, seed, torch.float32, **kw)
-        f64, vol64, g64, _ = run(tag, rl, seed, torch.float64, **kw)
+                              ("ss_atten", [2, 2], 63, dict(ch=256, hw=(H // 2, W // 2), single=True)),
+                              ("ms_resnet", [3, 2], 64, dict(resnet=True)), ("resnet_alone", [3], 65, dict(resnet=True, alone=True))):
+        cfg_tag = {"ms_resnet": "ms_atten", "resnet_alone": "ms_atten"}.get(tag, tag)
+        f32, vol, g32, b32 = run(cfg_tag, rl, seed, torch.float32, **kw)
+        f64, vol64, g64, _ = run(cfg_tag, rl, seed, torch.float64, **kw)
         assert vol == vol64, (tag, vol, vol64)
         out[f"{tag}_fused"] = f32.numpy()
         out[f"{tag}_vol"] = np.float64(vol)
