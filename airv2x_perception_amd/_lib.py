@@ -56,6 +56,9 @@ SIGNATURES = {
     "av2x_dwconv2d_wgrad_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "av2x_dwconv2d_wgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                       c_void_p, c_void_p]),
+    "av2x_lss_lift_pool_prob_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                                   c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "av2x_softmax_channels_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_resize_bilinear_backward_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32]),
     "av2x_resize_bilinear_backward": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "av2x_lss_lift_pool_backward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32,

@@ -588,6 +588,85 @@ extern "C" int av2x_lss_lift_pool_backward(const float* dout, const float* imgs,
     return av2x::check_launch("lift_pool_gt_backward_kernel");
 }
 
+// ---- training: the adjoint of the predicted-depth lift (CamEncode.forward :176-186 + voxel_pooling): out[voxel(p, d)] += prob[p][d] * feat[p],
+// so dfeat[p] = sum_d prob[p][d] * dout[voxel(p, d)] and dprob[p][d] = <feat[p], dout[voxel(p, d)]> -- gathers, no atomics.  One group of
+// LPP lanes per feature pixel walks its D bins; the dot product is reduced over the group's lanes with xor shuffles (fixed order).
+template <int LPP>
+__global__ __launch_bounds__(256) void lift_pool_prob_backward_kernel(const float* __restrict__ dout, const float* __restrict__ feat,
+                                                                      const float* __restrict__ prob, int D, const float* __restrict__ frustum,
+                                                                      const LiftCam* __restrict__ cams, LiftGrid g, int fH, int fW, int cams_per_batch,
+                                                                      long long npix, int C, float* __restrict__ dfeat, float* __restrict__ dprob) {
+    const int t = threadIdx.x % LPP;
+    const long long p = (long long)blockIdx.x * (256 / LPP) + threadIdx.x / LPP;
+    if (p >= npix) return;                               // whole groups leave together (256 % LPP == 0): the shuffles below stay inside a group
+    const int fw = (int)(p % fW);
+    const long long r = p / fW;
+    const int fh = (int)(r % fH);
+    const int cam = (int)(r / fH);
+    const int b = cam / cams_per_batch;
+    const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)p * C + 4 * t);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int bin = 0; bin < D; ++bin) {
+        const int fp = (bin * fH + fh) * fW + fw;
+        int ix, iy, iz;
+        float s = 0.f;
+        if (lift_voxel(cams[cam], g, frustum[3 * fp + 0], frustum[3 * fp + 1], frustum[3 * fp + 2], ix, iy, iz)) {
+            const size_t cell = (((size_t)b * g.nx[2] + iz) * g.nx[1] + iy) * g.nx[0] + ix;
+            const float4 d4 = *reinterpret_cast<const float4*>(dout + cell * C + 4 * t);
+            const float pr = prob[p * D + bin];
+            o.x = fmaf(pr, d4.x, o.x); o.y = fmaf(pr, d4.y, o.y); o.z = fmaf(pr, d4.z, o.z); o.w = fmaf(pr, d4.w, o.w);
+            s = fmaf(f.x, d4.x, fmaf(f.y, d4.y, fmaf(f.z, d4.z, f.w * d4.w)));
+        }
+#pragma unroll
+        for (int off = LPP / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (t == 0) dprob[p * D + bin] = s;
+    }
+    *reinterpret_cast<float4*>(dfeat + (size_t)p * C + 4 * t) = o;
+}
+
+// dlogit = prob * (dprob - <prob, dprob>): one wave per pixel (rows, D)
+__global__ __launch_bounds__(256) void softmax_channels_backward_kernel(const float* __restrict__ prob, const float* __restrict__ dprob, long long rows,
+                                                                        int D, int stride, float* __restrict__ dlogit) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ln = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = ln; c < D; c += 64) s = fmaf(prob[row * D + c], dprob[row * D + c], s);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    for (int c = ln; c < stride; c += 64) dlogit[row * stride + c] = c < D ? prob[row * D + c] * (dprob[row * D + c] - s) : 0.f;
+}
+
+extern "C" int av2x_lss_lift_pool_prob_backward(const float* dout, const float* feat, const float* prob, int32_t nbins, const float* frustum,
+                                                const float* cam_params, int32_t b, int32_t n_cams, int32_t fh, int32_t fw, int32_t c,
+                                                const float* lo3, const float* dx3, const int32_t* nx3, float* dfeat, float* dprob,
+                                                av2x_stream_t stream) {
+    if (!dout || !feat || !prob || !frustum || !cam_params || !lo3 || !dx3 || !nx3 || !dfeat || !dprob)
+        return av2x::fail("av2x_lss_lift_pool_prob_backward: null argument");
+    if (b <= 0 || n_cams <= 0 || fh <= 0 || fw <= 0 || nbins <= 0) return av2x::fail("av2x_lss_lift_pool_prob_backward: bad sizes");
+    if (c != 32 && c != 64 && c != 128) return av2x::fail("av2x_lss_lift_pool_prob_backward: c=%d (32, 64 or 128 feature channels)", c);
+    LiftGrid g;
+    for (int i = 0; i < 3; ++i) { g.lo[i] = lo3[i]; g.dx[i] = dx3[i]; g.nx[i] = nx3[i]; }
+    hipStream_t st = av2x::as_stream(stream);
+    const LiftCam* cams = reinterpret_cast<const LiftCam*>(cam_params);
+    const long long npix = (long long)b * n_cams * fh * fw;
+#define AV2X_LIFT_PRB(LPP)                                                                                                                       \
+    hipLaunchKernelGGL(lift_pool_prob_backward_kernel<LPP>, dim3((unsigned)((npix + (256 / LPP) - 1) / (256 / LPP))), dim3(256), 0, st, dout, feat, \
+                       prob, nbins, frustum, cams, g, fh, fw, n_cams, npix, c, dfeat, dprob)
+    if (c == 32) AV2X_LIFT_PRB(8); else if (c == 64) AV2X_LIFT_PRB(16); else AV2X_LIFT_PRB(32);
+#undef AV2X_LIFT_PRB
+    return av2x::check_launch("lift_pool_prob_backward_kernel");
+}
+
+// prob, dprob (rows, d) -> dlogit (rows, stride): the gradient of av2x_softmax_channels with respect to its first d input channels (the rest: 0)
+extern "C" int av2x_softmax_channels_backward(const float* prob, const float* dprob, int64_t rows, int32_t d, int32_t stride, float* dlogit,
+                                              av2x_stream_t stream) {
+    if (!prob || !dprob || !dlogit || rows <= 0 || d <= 0 || stride < d) return av2x::fail("av2x_softmax_channels_backward: bad argument");
+    hipLaunchKernelGGL(softmax_channels_backward_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, av2x::as_stream(stream), prob, dprob,
+                       (long long)rows, d, stride, dlogit);
+    return av2x::check_launch("softmax_channels_backward_kernel");
+}
+
 extern "C" int av2x_mean2(const float* a, const float* b, float* out, uint64_t n, av2x_stream_t stream) {
     if (!a || !out || n % 4) return av2x::fail("av2x_mean2: null argument or n %% 4 != 0");
     if (n == 0) return 0;

@@ -336,6 +336,65 @@ class LiftGtFn(torch.autograd.Function):
         return dfeat, None, None, None, None, None, None
 
 
+class SoftmaxChFn(torch.autograd.Function):
+    """CamEncode.get_depth_dist (:89-92): softmax over the first ``d`` channels of (n, h, w, stride) logits -> (n, h, w, d)."""
+
+    @staticmethod
+    def forward(ctx, logit, d):
+        T._check_dev(logit)
+        r = _runner(logit.device)
+        logit = logit.contiguous()
+        n, h, w, stride = logit.shape
+        prob = torch.empty((n, h, w, d), dtype=torch.float32, device=logit.device)
+        _lib.check(r.lib.av2x_softmax_channels(_P(logit), n * h * w, d, stride, _P(prob), r.stream()), "av2x_softmax_channels")
+        ctx.save_for_backward(prob)
+        ctx.stride = stride
+        return prob
+
+    @staticmethod
+    def backward(ctx, dprob):
+        (prob,) = ctx.saved_tensors
+        r = _runner(dprob.device)
+        n, h, w, d = prob.shape
+        dlogit = torch.empty((n, h, w, ctx.stride), dtype=torch.float32, device=dprob.device)
+        _lib.check(r.lib.av2x_softmax_channels_backward(_P(prob), _P(dprob.contiguous()), n * h * w, d, ctx.stride, _P(dlogit), r.stream()),
+                   "av2x_softmax_channels_backward")
+        return dlogit, None
+
+
+class LiftProbFn(torch.autograd.Function):
+    """Predicted depth distribution (x) image features, lifted along the camera rays and summed into the BEV grid (CamEncode.forward
+    :176-186 + voxel_pooling; av2x_lss_lift_pool with ``prob``): the (B, N, D, fH, fW, C) volume exists in neither direction."""
+
+    @staticmethod
+    def forward(ctx, feat, prob, enc, params, B, N):
+        T._check_dev(feat)
+        r = _runner(feat.device)
+        feat, prob = feat.contiguous(), prob.contiguous()
+        ny, nx = int(enc.nx[1]), int(enc.nx[0])
+        pooled = torch.empty((B, ny, nx, enc.C), dtype=torch.float32, device=feat.device)
+        ws = torch.empty(int(r.lib.av2x_lss_pool_workspace_bytes(B, nx, ny, 1, enc.C)), dtype=torch.uint8, device=feat.device)
+        _lib.check(r.lib.av2x_lss_lift_pool(_P(feat), _P(prob), None, 0, 0, 0, enc.ds, ctypes.cast(enc._depth3, c_void_p), enc.nbins,
+                                            enc.depth_mode, 0, _P(enc.frustum), _P(params), B, N, enc.fH, enc.fW, enc.C,
+                                            ctypes.cast(enc._lo, c_void_p), ctypes.cast(enc._dx, c_void_p), ctypes.cast(enc._nx, c_void_p),
+                                            _P(ws), _P(pooled), r.stream()), "av2x_lss_lift_pool")
+        ctx.save_for_backward(feat, prob, params)
+        ctx.cfg = (enc, B, N)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, prob, params = ctx.saved_tensors
+        enc, B, N = ctx.cfg
+        r = _runner(dout.device)
+        dfeat, dprob = torch.empty_like(feat), torch.empty_like(prob)
+        _lib.check(r.lib.av2x_lss_lift_pool_prob_backward(_P(dout.contiguous()), _P(feat), _P(prob), enc.nbins, _P(enc.frustum), _P(params), B, N,
+                                                          enc.fH, enc.fW, enc.C, ctypes.cast(enc._lo, c_void_p), ctypes.cast(enc._dx, c_void_p),
+                                                          ctypes.cast(enc._nx, c_void_p), _P(dfeat), _P(dprob), r.stream()),
+                   "av2x_lss_lift_pool_prob_backward")
+        return dfeat, dprob, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ the modules
 def _conv_bn(P, sd, x, wkey, bn, stride, pad, eps, mom, act, cin_p=None, weight=None):
     """Conv2d (no bias) + BatchNorm (batch statistics) [+ ReLU] on channel-padded NHWC maps; the BatchNorm's running statistics
@@ -404,9 +463,10 @@ def up_block(P, sd, p, x1, x2, c_skip, scale):
     return _conv_bn(P, sd, x, p + "conv.3.weight", p + "conv.4", 1, 1, TV_EPS, TV_MOM, True)
 
 
-def cam_features(P, sd, p, flat, training, drop_connect=None):
+def cam_features(P, sd, p, flat, training, drop_connect=None, depth_bins=0):
     """CamEncode.get_eff_features + image_head (:118-165): flat (BN, 4, H, W) device images -> (BN, fH, fW, C) NHWC.
-    ``drop_connect``: the trunk's stochastic-depth rate (None: DROP_CONNECT, efficientnet-b0's 0.2; 0 switches it off)."""
+    ``drop_connect``: the trunk's stochastic-depth rate (None: DROP_CONNECT, efficientnet-b0's 0.2; 0 switches it off).
+    ``depth_bins`` D > 0 (use_depth_gt false): also the depth distribution softmax(depth_head(features)) (:180-181) -> (feat, prob)."""
     if drop_connect is None:
         drop_connect = DROP_CONNECT
     t = p + "trunk."
@@ -424,7 +484,13 @@ def cam_features(P, sd, p, flat, training, drop_connect=None):
     r3, r4, r5 = ends[2], ends[3], ends[4]
     u1 = up_block(P, sd, p + "up1.", r5, r4, 112, 2)
     f = up_block(P, sd, p + "up2.", u1, r3, 40, 2)
-    return T.conv_bias_act(f, P[p + "image_head.weight"], P[p + "image_head.bias"], 1, 0, False)
+    feat = T.conv_bias_act(f, P[p + "image_head.weight"], P[p + "image_head.bias"], 1, 0, False)
+    if not depth_bins:
+        return feat
+    dp = _p32(depth_bins)                               # the head's output channels padded to a multiple of 32; softmax over the real ones
+    wd = Fn.pad(P[p + "depth_head.weight"], (0, 0, 0, 0, 0, 0, 0, dp - depth_bins))
+    logit = T.conv_bias_act(f, wd, _padv(P[p + "depth_head.bias"], dp), 1, 0, False)
+    return feat, SoftmaxChFn.apply(logit, depth_bins)
 
 
 def basic_block(P, sd, q, x, stride):
@@ -451,20 +517,22 @@ def bev_encode(P, sd, b, x):
 def lss_encoder_train(P, sd, prefix, enc, cam_inputs, training=True):
     """One agent type's LiftSplatShootEncoder in train mode -> spatial_features (B, ny, nx, bevout) NHWC with its autograd graph.
     ``enc``: the type's packed ``camera.CameraEncoder`` (geometry only: frustum, grid, depth bins -- no weights are read from it)."""
-    if not enc.use_gt:
-        raise NotImplementedError("camera training: use_depth_gt (the shipped AirV2X camera configuration)")
     dev = next(iter(P.values())).device
     imgs = cam_inputs["imgs"]
     if imgs.device != dev or imgs.dtype != torch.float32 or not imgs.is_contiguous():
         imgs = imgs.to(dev, torch.float32).contiguous()
     B, N, planes, H, W = imgs.shape
-    if planes < 4:
+    if enc.use_gt and planes < 4:
         raise ValueError("use_depth_gt: the images need a 4th (depth) plane")
     if (H // enc.ds, W // enc.ds) != (enc.fH, enc.fW):
         raise ValueError(f"camera images are {H}x{W}; data_aug_conf.final_dim says {enc.fH * enc.ds}x{enc.fW * enc.ds}")
     flat = imgs.view(B * N, planes, H, W)
-    feat = cam_features(P, sd, prefix + "camencode.", flat, training)
+    out = cam_features(P, sd, prefix + "camencode.", flat, training, depth_bins=0 if enc.use_gt else enc.nbins)
+    feat = out if enc.use_gt else out[0]
     if tuple(feat.shape[1:3]) != (enc.fH, enc.fW):
         raise ValueError(f"camera image {H}x{W}: the stride-8 feature map is {tuple(feat.shape[1:3])}, the frustum expects {(enc.fH, enc.fW)}")
-    pooled = LiftGtFn.apply(feat, enc, flat, enc._cam_params(cam_inputs), B, N, training)
+    if enc.use_gt:
+        pooled = LiftGtFn.apply(feat, enc, flat, enc._cam_params(cam_inputs), B, N, training)
+    else:
+        pooled = LiftProbFn.apply(feat, out[1], enc, enc._cam_params(cam_inputs), B, N)
     return bev_encode(P, sd, prefix + "bevencode.", pooled)

@@ -543,6 +543,9 @@ int av2x_lss_lift_pool(const float* feat, const float* prob, const float* imgs, 
  *                                       source pixel in a fixed order (no atomics; `workspace` unused, _workspace_bytes returns 0)
  *   av2x_dwconv2d_wgrad                 dw (ks*ks, c) of av2x_dwconv2d (ks 3 | 5, stride 1 | 2, pad_t = pad_l = pad): per-slab partial sums in
  *                                       `workspace` (av2x_dwconv2d_wgrad_workspace_bytes), summed in slab order -- bit-reproducible
+ *   av2x_lss_lift_pool_prob_backward    adjoint of av2x_lss_lift_pool in its predicted-depth form: dfeat (b * n_cams, fh, fw, c) = sum over the bins of
+ *                                       prob * dout[voxel], dprob (b * n_cams, fh, fw, nbins) = <feat, dout[voxel]> (gathers; 0 outside the grid)
+ *   av2x_softmax_channels_backward      dlogit (rows, stride) = prob * (dprob - <prob, dprob>) for the first d channels, 0 for the padding ones
  *   av2x_lss_lift_pool_backward         adjoint of av2x_lss_lift_pool in its ground-truth-depth form: dfeat (b * n_cams, fh, fw, c) gathered from
  *                                       dout (b, nz, ny, nx, c) at the voxel each feature pixel was lifted to (zeros where it left the grid)
  * ------------------------------------------------------------------------------------ */
@@ -558,6 +561,11 @@ int av2x_resize_bilinear_backward(const float* dy, int32_t n, int32_t h, int32_t
 uint64_t av2x_dwconv2d_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t c, int32_t ks);
 int av2x_dwconv2d_wgrad(const float* x, const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride, int32_t pad,
                         int32_t ho, int32_t wo, void* workspace, float* dw, av2x_stream_t stream);
+int av2x_lss_lift_pool_prob_backward(const float* dout, const float* feat, const float* prob, int32_t nbins, const float* frustum,
+                                     const float* cam_params, int32_t b, int32_t n_cams, int32_t fh, int32_t fw, int32_t c, const float* lo3,
+                                     const float* dx3, const int32_t* nx3, float* dfeat, float* dprob, av2x_stream_t stream);
+int av2x_softmax_channels_backward(const float* prob, const float* dprob, int64_t rows, int32_t d, int32_t stride, float* dlogit,
+                                   av2x_stream_t stream);
 int av2x_lss_lift_pool_backward(const float* dout, const float* imgs, int32_t planes, int32_t img_h, int32_t img_w, int32_t downsample,
                                 const float* depth3, int32_t nbins, int32_t depth_mode, int32_t target, const float* frustum,
                                 const float* cam_params, int32_t b, int32_t n_cams, int32_t fh, int32_t fw, int32_t c, const float* lo3,

@@ -131,13 +131,43 @@ def test_lift_adjoint_is_the_gather_of_the_forward_scatter():
     assert float(feat.grad.abs().max()) > 0
 
 
+def test_predicted_depth_lift_and_channel_softmax_adjoints():
+    """The lift is bilinear in (features, depth distribution): <Lift(f, p), dout> = <f, df> = <p, dp>; the channel softmax's backward against
+    torch autograd (CamEncode.get_depth_dist, lss_submodule.py:89-92) with padded logit channels."""
+    from airv2x_perception_amd.opencood_iface import train_camera as TC
+    from airv2x_perception_amd.opencood_iface.camera import CameraGeometry
+    rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0]
+    ca = synth.cam_args("vehicle", (104, 168), (rng[0], rng[3], rng[1], rng[4]))
+    geo = CameraGeometry(ca, torch.device("cuda"))
+    ci = synth.cam_inputs_for(7, 2, 2, (104, 168), "vehicle")
+    g = _g(11)
+    feat = torch.randn(4, geo.fH, geo.fW, geo.C, generator=g).cuda().requires_grad_()
+    dpad = (geo.nbins + 31) // 32 * 32
+    logit = torch.randn(4, geo.fH, geo.fW, dpad, generator=g).cuda().requires_grad_()
+    prob = TC.SoftmaxChFn.apply(logit, geo.nbins)
+    prob.retain_grad()
+    pooled = TC.LiftProbFn.apply(feat, prob, geo, geo._cam_params(ci), 2, 2)
+    dout = torch.randn(pooled.shape, generator=g).cuda()
+    pooled.backward(dout)
+    lhs = float((pooled.detach().double() * dout.double()).sum())
+    for name, a, b in (("features", feat, feat.grad), ("distribution", prob, prob.grad)):
+        rhs = float((a.detach().double() * b.double()).sum())
+        assert abs(lhs - rhs) <= 2e-5 * max(1.0, abs(lhs)), (name, lhs, rhs)
+    lr = logit.detach().cpu().double().requires_grad_()
+    pr = torch.softmax(lr[..., :geo.nbins], -1)
+    pr.backward(prob.grad.cpu().double())
+    rel_close(prob.detach().cpu(), pr.detach().float(), 2e-6, "softmax forward")
+    rel_close(logit.grad.cpu(), lr.grad.float(), 2e-5, "softmax backward")
+    assert float(logit.grad[..., geo.nbins:].abs().max()) == 0.0
+
+
 def _case(fx):
     rng = [float(v) for v in fx["lidar_range"]]
     types = [str(t) for t in fx["types"]]
     final_dim = tuple(int(v) for v in fx["final_dim"])
     mods = tuple(str(m) for m in fx["modalities"])
     cams = {t: int(v) for t, v in zip(synth.AGENT_TYPES, fx["cams"])}
-    hy = synth.multimodal_hypes(mods, rng, final_dim, True)
+    hy = synth.multimodal_hypes(mods, rng, final_dim, bool(int(fx["use_depth_gt"])) if "use_depth_gt" in fx else True)
     args = hy["model"]["args"]
     sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=int(fx["seed"]))
     pp = hy["preprocess"]
@@ -152,7 +182,7 @@ def _case(fx):
     return hy, args, sd, dd, tgt
 
 
-@pytest.mark.parametrize("name", ["train_cam_small_n3", "train_cam_small_camonly_n2", "train_cam_small_camonly_n2b"])
+@pytest.mark.parametrize("name", ["train_cam_small_n3", "train_cam_small_camonly_n2", "train_cam_small_camonly_n2b", "train_cam_small_softmax_n2"])
 def test_camera_training_step_matches_the_reference(name, monkeypatch):
     from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
     from airv2x_perception_amd.opencood_iface import train_camera as TC

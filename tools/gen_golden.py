@@ -1734,7 +1734,7 @@ def train_v2vnet_golden(name, lidar_range, types, n_points, seed, agg="avg", pos
                         extra={"agg": np.asarray(agg)})
 
 
-def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim, modalities, cams, pos_frac=0.01):
+def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim, modalities, cams, pos_frac=0.01, use_depth_gt=True):
     """One TRAINING step of the reference's Airv2xWhere2com WITH camera encoders (train mode: BatchNorm batch statistics in the
     EfficientNet-B0 trunk, the Up blocks and BevEncode; ground-truth depth with the training-mode clipping of bin_depths; stochastic depth
     switched off -- a configuration edit: random masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch
@@ -1748,14 +1748,14 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
     _import_camera_reference()
     from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
     from opencood.models.airv2x_where2com import Airv2xWhere2com
-    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, True)
+    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, use_depth_gt)
     args = hy["model"]["args"]
     hy_ref = load_ref_hypes(lidar_range)
     ra = hy_ref["model"]["args"]
     ra["active_sensors"] = list(modalities)
     for t in synth.AGENT_TYPES:
         ra[t]["modalities"] = list(modalities)
-        ra[t]["cam"]["use_depth_gt"] = True
+        ra[t]["cam"]["use_depth_gt"] = bool(use_depth_gt)
         ra[t]["cam"]["data_aug_conf"]["final_dim"] = list(final_dim)
         if lidar_range is not None:
             ra[t]["cam"]["grid_conf"]["xbound"] = [lidar_range[0], lidar_range[3], 0.4]
@@ -1793,6 +1793,27 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
                     for k in list(ci):
                         if torch.is_tensor(ci[k]) and ci[k].is_floating_point():
                             ci[k] = ci[k].double()
+            # The yardstick measures ARITHMETIC, not the discrete voxel assignment: frustum points within rounding of a voxel face fall into
+            # different voxels in fp32 and float64 (with the predicted-depth lift every pixel has D points: the two passes' gradients then
+            # differ by 20 %).  The float64 pass therefore takes the fp32 pass's voxel of every point: get_geometry runs in fp32, the index
+            # of airv2x_encoder.py:226 is formed in fp32, and the geometry handed on is the centre of that voxel.
+            import types as _types
+            for mod_ in m.modules():
+                if hasattr(mod_, "get_geometry") and hasattr(mod_, "voxel_pooling"):
+                    orig = type(mod_).get_geometry
+
+                    def gg(self, rots, trans, intrins, post_rots, post_trans, _orig=orig):
+                        fr = self.frustum
+                        self.frustum = fr.float()
+                        try:
+                            g32 = _orig(self, rots.float(), trans.float(), intrins.float(), post_rots.float(), post_trans.float())
+                        finally:
+                            self.frustum = fr
+                        bx, dx = self.bx.float(), self.dx.float()
+                        idx = ((g32 - (bx - dx / 2.0)) / dx).long().double()
+                        half = torch.where(idx >= 0, torch.full_like(idx, 0.5), torch.full_like(idx, -0.5))
+                        return (idx + half) * self.dx.double() + (self.bx.double() - self.dx.double() / 2.0)
+                    mod_.get_geometry = _types.MethodType(gg, mod_)
         return m, d
     os.makedirs("debug", exist_ok=True)
     model, dd = build(torch.float32)
@@ -1816,7 +1837,16 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
     try:
         m64, d64 = build(torch.float64)
         random.seed(rseed)
+        # ... and the fp32 pass's communication mask (a top-K over near-equal confidences picks other cells in another precision)
+        flips = []
+
+        def same_mask(mod_, inp, o):
+            flips.append(int((o[0].float() != cap["comm"][0].float()).sum()))
+            return (cap["comm"][0].to(o[0].dtype),) + tuple(o[1:])
+        h64 = m64.fusion_net.naive_communication.register_forward_hook(same_mask)
         o64 = m64(d64)
+        h64.remove()
+        print(f"[{name}] float64 pass: {flips} mask cells differed from the fp32 pass's (replaced)")
         l64 = PointPillarLossMultiClass(la)(o64, {k: (v.double() if v.is_floating_point() else v) for k, v in tgt.items()})
         l64.backward()
     finally:
@@ -1829,7 +1859,7 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
           "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64), "loss64": np.float64(float(l64)),
           "mask": np.packbits(cap["comm"][0].detach().numpy().astype(np.uint8).reshape(-1)),
           "mask_shape": np.asarray(cap["comm"][0].shape, np.int64), "com": np.float64(float(out["com"])), "comm_rate": np.int64(out["comm_rate"]),
-          "head_stride": np.int64(1), "head_hw": np.asarray([H, W], np.int64)}
+          "head_stride": np.int64(1), "head_hw": np.asarray([H, W], np.int64), "use_depth_gt": np.int64(1 if use_depth_gt else 0)}
     for k in ("psm", "rm", "obj"):
         fx[k] = out[k].detach().numpy()
     names, devs = [], []
@@ -2243,6 +2273,8 @@ GROUPS = {
                                            {"vehicle": 2, "rsu": 1, "drone": 1})),
     "train_cam_b": lambda: train_cam_golden("train_cam_small_camonly_n2b", SMALL, ["vehicle", "rsu"], 700, 41, 9, (104, 168), ("cam",),
                                             {"vehicle": 2, "rsu": 1, "drone": 1}),
+    "train_cam_softmax": lambda: train_cam_golden("train_cam_small_softmax_n2", SMALL, ["vehicle", "rsu"], 700, 43, 11, (104, 168), ("cam",),
+                                                  {"vehicle": 2, "rsu": 1, "drone": 1}, use_depth_gt=False),
     "train_cobevt_full": lambda: train_cobevt_golden("train_cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 18,
                                                      max_cav=(3, 2, 2), pos_frac=0.002, head_stride=4),
     "train_v2xvit_full": lambda: train_v2xvit_golden("train_v2xvit_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 19,
