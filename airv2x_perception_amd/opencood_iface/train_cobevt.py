@@ -86,9 +86,17 @@ def _forward_train(model, data_dict):
     s = torch.cat([_deblock(P, sd, i, f, 1) for i, f in enumerate(feats)], -1)
     s = _shrink(P, args["shrink_header"], s)
     if int(args.get("compression", 0) or 0) > 0:
-        # NaiveCompressor's convolutions carry a bias in front of their BatchNorm: it cancels in the normalised output but shifts the
-        # RUNNING mean, which conv_bn_act does not see.  No shipped AirV2X configuration compresses.
-        raise NotImplementedError("training with message compression > 0 is not built (eval mode supports it)")
+        # NaiveCompressor (naive_compress.py:10-44): Conv3x3 + BN + ReLU down to C / ratio, two back up.  Its convolutions carry a bias in
+        # front of their BatchNorm: it cancels in the normalised output (its gradient is exactly zero -- the parameter keeps grad None)
+        # but is part of the batch mean nn.BatchNorm folds into running_mean.
+        for name in ("encoder.0", "decoder.0", "decoder.3"):
+            cv = "naive_compressor." + name
+            bn = cv[:-1] + str(int(cv[-1]) + 1)
+            st = []
+            s = T.conv_bn_act(s, P[cv + ".weight"], P[bn + ".weight"], P[bn + ".bias"], 1, 1, stats_out=st)
+            mean, var, count = st[0]
+            T.update_running_stats(sd[bn + ".running_mean"], sd[bn + ".running_var"], sd.get(bn + ".num_batches_tracked"),
+                                   (mean + P[cv + ".bias"].detach(), var, count), 1)
     fused, a0 = [], 0
     for k in record_len:                    # regroup (fuse_utils.py:13-64): zero-pad every sample to L agents, fuse per sample
         xs = s[a0:a0 + k]

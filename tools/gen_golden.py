@@ -1452,7 +1452,7 @@ def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01,
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2, 2), pos_frac=0.01, head_stride=1):
+def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2, 2), pos_frac=0.01, head_stride=1, compression=0):
     """One TRAINING step of the reference's Airv2xCoBEVT (train mode: BatchNorm batch statistics, SwapFusionEncoder with drop_out 0 --
     a configuration edit: dropout masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch autograd:
     heads, losses, the gradient of every parameter (strided samples + sums), every buffer after the step, and the same step in
@@ -1469,6 +1469,8 @@ def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2,
     hy_ref["model"]["args"]["fax_fusion"]["drop_out"] = 0.0
     hy = synth.default_hypes_cobevt(lidar_range, max_cav)
     hy["model"]["args"]["fax_fusion"]["drop_out"] = 0.0
+    if compression:
+        hy_ref["model"]["args"]["compression"] = hy["model"]["args"]["compression"] = int(compression)
     args = hy["model"]["args"]
     model = Airv2xCoBEVT(hy_ref["model"]["args"]).train()
     spec = synth.cobevt_param_spec(args)
@@ -1514,7 +1516,7 @@ def train_cobevt_golden(name, lidar_range, types, n_points, seed, max_cav=(3, 2,
     assert worst < 1e-4 * max(1.0, max(float(out[k].abs().max()) for k in ("psm", "rm", "obj"))), worst
     assert abs(float(mine[0]) - float(total)) < 1e-5 * max(1.0, abs(float(total))), (float(mine[0]), float(total))
     fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types), "n_points": np.int64(n_points),
-          "pos_frac": np.float64(pos_frac), "max_cav": np.asarray(max_cav, np.int64),
+          "pos_frac": np.float64(pos_frac), "max_cav": np.asarray(max_cav, np.int64), "compression": np.int64(compression),
           "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64)}
     fx["head_stride"] = np.int64(head_stride)
     fx["head_hw"] = np.asarray([H, W], np.int64)
@@ -2256,6 +2258,7 @@ GROUPS = {
                                        head_stride=4),
     "train_cobevt": lambda: (train_cobevt_golden("train_cobevt_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 14),
                              train_cobevt_golden("train_cobevt_small_n2", SMALL, ["vehicle", "vehicle"], 900, 15)),
+    "train_cobevt_c4": lambda: train_cobevt_golden("train_cobevt_small_n2_c4", SMALL, ["vehicle", "rsu"], 900, 16, compression=4),
     "train_v2xvit": lambda: (train_v2xvit_golden("train_v2xvit_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 16),
                              train_v2xvit_golden("train_v2xvit_small_n2", SMALL, ["vehicle", "vehicle"], 900, 17)),
     # the BASELINE grid (704 x 200, 4 agents x 8192 points): one training step of the reference's CoBEVT / V2X-ViT (tens of minutes of CPU:
