@@ -17,7 +17,16 @@ SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino_x3.hip", "conv_wino4_x3.hip"
 # per-source flags.  The split-3 Winograd kernels keep their channel-pair arithmetic scalar on purpose (a packed fp32 instruction beside
 # MFMAs costs more than the two scalar ones it replaces): neither the SLP vectoriser nor VectorCombine may re-pack it.
 _SCALAR_F32 = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
-EXTRA_FLAGS = {"conv_wino_x3.hip": _SCALAR_F32, "conv_wino4_x3.hip": _SCALAR_F32}
+# gfx950 hazard found in round 4 (tools/micro/coreside.py + guard.hip): a packed-fp32 VOP3P instruction whose OP_SEL bit of
+# the SECOND (or third) source is set -- v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[0,1], v_pk_fma_f32 ... op_sel:[0,1,0] -- returns wrong
+# lanes while ANOTHER wave on the same SIMD issues v_mfma_f32_32x32x16_bf16 (the split-3 and bf16 kernels of another in-flight frame).
+# op_sel_hi-only (broadcast), neg_* and first-source op_sel forms are not affected.  The compiler forms the bad pattern when it folds a
+# lane swap into a packed op; the files where it did are compiled without packed-fp32 instructions (they are HBM-bound kernels), and
+# lint_isa() below rejects the pattern in EVERY kernel of the library at build time.
+_NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA_FLAGS = {"conv_wino_x3.hip": _SCALAR_F32, "conv_wino4_x3.hip": _SCALAR_F32,
+               **{f: _NO_PACKED_F32 for f in ("transformer.hip", "postproc.hip", "train.hip", "loss.hip", "pillar.hip", "lss.hip", "camera.hip",
+                                              "voxelize.hip")}}
 
 
 class HipccMissing(RuntimeError):
@@ -58,7 +67,7 @@ def build(force=False, verbose=False):
                     + [os.path.getmtime(os.path.join(ROOT, "include", "airv2x_hip.h"))])
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
             continue
-        cmd = [cc, *flags, *EXTRA_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
+        cmd = [cc, *flags, *EXTRA_FLAGS.get(os.path.basename(s), []), "-save-temps=obj", "-c", s, "-o", o]    # keeps the device ISA for lint_isa
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -68,11 +77,41 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
+    for f in os.listdir(objdir):        # -save-temps leaves ~10 files per source; only the device ISA is kept
+        if f.endswith((".bc", ".hipi", ".out", ".hipfb", ".resolution.txt")) or f.endswith("-host-x86_64-unknown-linux-gnu.s") \
+                or f.endswith("-hip-amdgcn-amd-amdhsa-gfx950.o"):
+            os.remove(os.path.join(objdir, f))
+    bad = lint_isa(objdir)
+    if bad:
+        raise RuntimeError("packed-fp32 instructions with a second / third source OP_SEL bit (wrong results next to bf16-MFMA waves on gfx950, "
+                           "see build.py) in:\n" + "\n".join(f"  {f}: {k}: {ins}" for f, k, ins in bad[:20]))
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     return LIB
+
+
+def lint_isa(objdir=None):
+    """[(file, kernel, instruction)] for every packed-fp32 instruction of the device ISA (the *-gfx950.s files -save-temps leaves beside the
+    objects) whose op_sel sets the bit of the second or third source."""
+    import glob
+    import re
+    objdir = objdir or os.path.join(HERE, "build")
+    pat = re.compile(r"^\s+(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[(\d(?:,\d)+)\]")
+    bad = []
+    for f in sorted(glob.glob(os.path.join(objdir, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))):
+        if not any(os.path.basename(f).startswith(os.path.splitext(s)[0] + "-hip-") for s in SOURCES):
+            continue            # a stale file of a source that left the build
+        kernel = None
+        for line in open(f):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                kernel = m.group(1)
+            m = pat.match(line)
+            if m and "1" in m.group(2).split(",")[1:]:
+                bad.append((os.path.basename(f), kernel, line.strip()))
+    return bad
 
 
 if __name__ == "__main__":

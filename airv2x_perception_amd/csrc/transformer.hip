@@ -673,13 +673,13 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
             const int nwin = (h / 4) * (w / 4);
             const dim3 grid(nwin < 2048 ? nwin : 2048);
             static const bool force8 = getenv("AV2X_FAX_NV8") != nullptr;      // debug probe (tools/micro/pipe_t32.py)
-            // The wave kernel OWNS its CU: it asks for 124 KB of LDS (it uses lds_w0 of them), so that no workgroup of the split-3 kernels
-            // (conv_igemm_x3p 37 - 50 KB, conv_wino_x3's 32-tile form 68 KB) can become co-resident.  Measured (tools/micro/coreside.py,
-            // pipe_t32.py): while its waves share a CU with waves of those kernels from another stream, some (query, head) rows of its
-            // output come out wrong (up to 0.2 abs) for n_valid <= 4 -- its LDS table, VGPR / AGPR guard patterns and every other
-            // kernel stay intact, the cause is not understood.  AV2X_FAX_SHARE_CU=1 restores the shared launch (probe).
-            static const bool share = getenv("AV2X_FAX_SHARE_CU") != nullptr;
-            const size_t lds_w = share ? lds_w0 : (lds_w0 > (size_t)124 * 1024 ? lds_w0 : (size_t)124 * 1024);
+            // Round 4: this kernel returned wrong rows while its waves shared a SIMD with v_mfma_f32_32x32x16_bf16 waves of another stream.
+            // Cause (tools/micro/coreside.py, guard.hip): its bias add compiled to v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0],
+            // and a packed-fp32 op with the second source's OP_SEL bit set is disturbed by bf16 MFMAs of a co-resident wave on gfx950.
+            // This file is now compiled without packed-fp32 instructions and build.py's lint_isa() rejects the pattern library-wide.
+            // AV2X_FAX_OWN_CU=1 (probe) makes the kernel ask for 124 KB of LDS so that no split-3 workgroup can join it on a CU.
+            static const bool own = getenv("AV2X_FAX_OWN_CU") != nullptr;
+            const size_t lds_w = own ? (size_t)124 * 1024 : lds_w0;
             static av2x::LdsLimit lim_w4, lim_w8;
             lim_w4.ensure(reinterpret_cast<const void*>(&fax_attention_wave_kernel<4>), lds_w);
             lim_w8.ensure(reinterpret_cast<const void*>(&fax_attention_wave_kernel<8>), lds_w);

@@ -100,14 +100,17 @@ def victims():
         return err
     extra = {"guard_lds20k": guard} if gl is not None else {}
     if gl is not None:
-        couts = {k: torch.zeros(1024 * 256, device="cuda") for k in range(4)}
+        couts = {k: torch.zeros(1024 * 256, device="cuda") for k in range(13)}
 
         def chain(kind):
             def f(stream):
                 gl.chain_launch(kind, c_void_p(couts[kind].data_ptr()), 1024, 64, 40, c_void_p(stream.cuda_stream))
                 return couts[kind]
             return f
-        extra.update({"chain_mfma16x16x4f32": chain(0), "chain_mfma32x32x2f32": chain(1), "chain_exp_shfl": chain(2), "chain_valu": chain(3)})
+        extra.update({"chain_mfma16x16x4f32": chain(0), "chain_mfma32x32x2f32": chain(1), "chain_exp_shfl": chain(2), "chain_valu": chain(3),
+                      "chain_pk_add_opsel": chain(4), "chain_pk_add_plain": chain(5), "chain_pkv_add_hi10": chain(6), "chain_pkv_add_sel01": chain(7),
+                      "chain_pkv_mul_swap": chain(8), "chain_pkv_fma_hi101": chain(9), "chain_pkv_fma_sel010": chain(10),
+                      "chain_pkv_add_neg": chain(11), "chain_pkv_add_swap_src0": chain(12)})
     if os.environ.get("ONLY"):
         extra = {k: v for k, v in extra.items() if os.environ["ONLY"] in k}
     if os.environ.get("ONLY"):
@@ -124,6 +127,11 @@ def main():
     lin_out = torch.empty(7, 100, 352, 256, device="cuda")
     X3P = {"x3p64": (128 << 16) | 64 | 0x1400, "x3p128": (128 << 16) | 128 | 0x1400, "ig_f32": 0}
     sa, sv = torch.cuda.Stream(), torch.cuda.Stream()
+    MM = {}
+    MICRO = torch.zeros(4096 * 256, device="cuda")
+    for nm, dt in (("mm_bf16", torch.bfloat16), ("mm_f16", torch.float16), ("mm_f32", torch.float32)):
+        a_, b_ = torch.randn(8192, 1024, device="cuda").to(dt), torch.randn(1024, 1024, device="cuda").to(dt)
+        MM[nm] = (a_, b_, torch.empty(8192, 1024, device="cuda", dtype=dt))
     V = victims()
     run_conv(agg, TILES["x3_64"], agg_out, torch.cuda.current_stream())
     torch.cuda.synchronize()
@@ -131,13 +139,22 @@ def main():
     for vname, vfn in V.items():
         ref = vfn(torch.cuda.current_stream()).clone()
         torch.cuda.synchronize()
-        for aname in ("x3p128", "x3_32", "f32_h", "none"):
+        for aname in os.environ.get("AGG", "x3p128,x3_32,f32_h,none").split(","):
             bad = 0
             worst = 0.0
             agg_bad = 0
             for _ in range(reps):
                 def aggress():
-                    if aname in X3P:
+                    if aname.startswith("micro_"):       # one instruction class per kernel (tools/micro/guard.hip aggressor_kernel)
+                        import ctypes
+                        gl_ = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libablate_guard.so"))
+                        kind = {"micro_cvt_pk_bf16": 0, "micro_mfma_bf16": 1, "micro_mfma_f32": 2, "micro_cvt_vec": 3}[aname]
+                        gl_.aggressor_launch(kind, c_void_p(MICRO.data_ptr()), 4096, 20000 if kind in (0, 3) else 3000, c_void_p(sa.cuda_stream))
+                    elif aname.startswith("mm_"):          # a library GEMM (rocBLAS / hipBLASLt through torch) on the aggressor stream
+                        with torch.cuda.stream(sa):
+                            for _k in range(4):
+                                torch.matmul(MM[aname][0], MM[aname][1], out=MM[aname][2])
+                    elif aname in X3P:
                         for _k in range(2):
                             run_linear(lin, X3P[aname], lin_out, sa)
                     elif aname != "none":
