@@ -647,10 +647,9 @@ class Where2ComEngine:
 
     @classmethod
     def wino_x3_tile(cls, L, h, w):
-        """64 x 64 tile (one wave per SIMD with the whole register file) by default.  The 32 x 64 tile (two workgroups per CU, same
-        bits) is 1.2-1.3x faster per launch on the small maps (<= 50 x 176 pixels per image: a function of the map only, so that the
-        sharded / batched frame keeps the single frame's bits) but gains nothing once three frames are in flight (other frames fill the
-        CUs the 64-tile launches leave idle): AV2X_WINO_X3_T32=1 switches it on for single-stream / latency use."""
+        """64 x 64 tile (one wave per SIMD with the whole register file).  The 32 x 64 tile (two workgroups per CU, same bits) is faster
+        per isolated launch on the small maps but slower at frame level in every mode measured; AV2X_WINO_X3_T32=1
+        switches it on for maps of <= 50 x 176 pixels per image (a function of the map only: sharded / batched frames keep their bits)."""
         tb = 32 if (cls.WINO_X3_T32 and h * w <= cls.WINO_X3_T32_MAX_PIXELS) else 64
         return 0x40000400 | (tb << 16) | 64
 
