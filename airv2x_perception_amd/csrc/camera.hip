@@ -265,6 +265,34 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     *reinterpret_cast<float4*>(out + pix * out_ctot + out_coff + cq * 4) = o;
 }
 
+// ------------------------------------------------------------------------------------------------------------ max pool
+// nn.MaxPool2d(ks, stride, pad) on NHWC maps (the 3x3 / 2 / 1 pool of a torchvision ResNet stem): thread -> (output pixel, channel quad);
+// padding cells do not take part (torch pads with -inf)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int H, int W, int C, int ks, int stride, int pad, int Ho, int Wo,
+                                                      long long total, float* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int CQ = C >> 2;
+    const int cq = (int)(gid % CQ);
+    const long long pix = gid / CQ;
+    const int wo = (int)(pix % Wo);
+    const long long r = pix / Wo;
+    const int ho = (int)(r % Ho);
+    const long long n = r / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int kh = 0; kh < ks; ++kh) {
+        const int hi = ho * stride - pad + kh;
+        if ((unsigned)hi >= (unsigned)H) continue;
+        for (int kw = 0; kw < ks; ++kw) {
+            const int wi = wo * stride - pad + kw;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((n * H + hi) * (long long)W + wi) * C + cq * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(out + pix * C + cq * 4) = m;
+}
+
 // ------------------------------------------------------------------------------------------------------------ softmax
 // one wave per pixel: softmax over the first D of `stride` channels, written to out (rows, D)
 __global__ __launch_bounds__(256) void softmax_channels_kernel(const float* __restrict__ x, long long rows, int D, int stride,
@@ -474,6 +502,19 @@ extern "C" int av2x_resize_bilinear(const float* in, int32_t n, int32_t h, int32
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for(total)), dim3(256), 0, av2x::as_stream(stream), in, h, w, c, in_ctot, in_coff, h2,
                        w2, sy, sx, pad_t, pad_l, hout, wout, out, out_ctot, out_coff, total);
     return av2x::check_launch("resize_bilinear_kernel");
+}
+
+extern "C" int av2x_maxpool2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride, int32_t pad, int32_t ho,
+                              int32_t wo, float* out, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!x || !out) return av2x::fail("av2x_maxpool2d: null argument");
+    if (n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 4 || ks <= 0 || stride <= 0 || pad < 0 || 2 * pad > ks)
+        return av2x::fail("av2x_maxpool2d: bad sizes (c %% 4 == 0, pad <= ks / 2)");
+    if (ho != (h + 2 * pad - ks) / stride + 1 || wo != (w + 2 * pad - ks) / stride + 1) return av2x::fail("av2x_maxpool2d: output size mismatch");
+    const long long total = (long long)n * ho * wo * (c / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, av2x::as_stream(stream), x, h, w, c, ks, stride, pad, ho,
+                       wo, total, out);
+    return av2x::check_launch("maxpool_kernel");
 }
 
 extern "C" int av2x_softmax_channels(const float* x, int64_t rows, int32_t d, int32_t stride, float* out, av2x_stream_t stream) {

@@ -59,8 +59,8 @@ class CameraGeometry:
 
     def __init__(self, cam_args, device):
         self.cfg, self.device = cam_args, device
-        if cam_args["camera_encoder"] != "EfficientNet":
-            raise NotImplementedError("camera_encoder: only the EfficientNet trunk (the shipped AirV2X configs) is built")
+        if cam_args["camera_encoder"] not in ("EfficientNet", "Resnet101"):
+            raise NotImplementedError(f"camera_encoder {cam_args['camera_encoder']!r}: EfficientNet or Resnet101 (airv2x_encoder.py:67-86)")
         if cam_args["img_downsample"] != 8:
             raise NotImplementedError("img_downsample: 8 (the shipped AirV2X configs)")
         g = cam_args["grid_conf"]
@@ -108,8 +108,9 @@ class CameraEncoder:
     def __init__(self, eng, cam_args, sd, prefix, tag):
         from .engine import ConvLayer
         self.eng, self.tag, self.cfg = eng, tag, cam_args
-        if cam_args["camera_encoder"] != "EfficientNet":
-            raise NotImplementedError("camera_encoder: only the EfficientNet trunk (the shipped AirV2X configs) is built")
+        if cam_args["camera_encoder"] not in ("EfficientNet", "Resnet101"):
+            raise NotImplementedError(f"camera_encoder {cam_args['camera_encoder']!r}: EfficientNet or Resnet101 (airv2x_encoder.py:67-86)")
+        self.resnet = cam_args["camera_encoder"] == "Resnet101"
         if cam_args["img_downsample"] != 8:
             raise NotImplementedError("img_downsample: 8 (the shipped AirV2X configs)")
         self.lib = eng.lib
@@ -155,9 +156,42 @@ class CameraEncoder:
             pw, coutp = pack_conv_weight(w)
             return ConvLayer(up(pw), up(scale) if scale is not None else None, up(shift.detach().float()), cin_p, real, coutp, k, stride, pad, relu)
 
+        # ---- Up blocks of CamEncode: concat layouts [skip map (padded) | upsampled map]
+        def up_block(pp, c_skip, c_up):
+            cs_p = _pad32(c_skip)
+            w0 = _place_cin(sd[pp + "conv.0.weight"], [(0, c_skip, 0), (c_skip, c_skip + c_up, cs_p)], cs_p + c_up)
+            sa, ha = fold_bn(sd, pp + "conv.1", TV_EPS)
+            sb, hb = fold_bn(sd, pp + "conv.4", TV_EPS)
+            return {"cs_p": cs_p, "c_up": c_up, "c0": conv(w0, sa, ha, 1, pad=1), "c1": conv(sd[pp + "conv.3.weight"], sb, hb, 1, pad=1)}
+
         p = prefix + "camencode."
         t = p + "trunk."
+        if self.resnet:
+            # ---- CamEncode_Resnet101 (lss_submodule.py:191-310): conv1 7x7/2 (image channels padded to 16) + bn1 + relu, maxpool 3x3/2,
+            # torchvision resnet101's layer1 (3 bottlenecks) and layer2 (4, stride 2) -> 512 channels at stride 8; BatchNorms folded
+            from ..synth import RESNET101_LAYERS
+            s0, h0 = fold_bn(sd, p + "bn1", TV_EPS)
+            self.r_stem = conv(sd[p + "conv1.weight"], s0, h0, 1, stride=2, pad=3, cin_p=16)
+            self.r_blocks = []
+            for li, (planes, nb, stride) in enumerate(RESNET101_LAYERS, 1):
+                for bi in range(nb):
+                    q = f"{p}layer{li}.{bi}."
+                    st_ = stride if bi == 0 else 1
+                    b1, b2, b3 = (fold_bn(sd, q + f"bn{j}", TV_EPS) for j in (1, 2, 3))
+                    blk = {"c1": conv(sd[q + "conv1.weight"], b1[0], b1[1], 1), "c2": conv(sd[q + "conv2.weight"], b2[0], b2[1], 1, stride=st_, pad=1),
+                           "c3": conv(sd[q + "conv3.weight"], b3[0], b3[1], RELU_AFTER_RES), "down": None}
+                    if (q + "downsample.0.weight") in sd:
+                        sd_, hd = fold_bn(sd, q + "downsample.1", TV_EPS)
+                        blk["down"] = conv(sd[q + "downsample.0.weight"], sd_, hd, 0, stride=st_)
+                    self.r_blocks.append(blk)
         # ---- EfficientNet-B0 trunk
+        if not self.resnet:
+            self._build_effnet(sd, p, t, conv, up, up_block)
+        self.image_head = conv(sd[p + "image_head.weight"], None, sd[p + "image_head.bias"], 0)
+        self.depth_head = None if self.use_gt else conv(sd[p + "depth_head.weight"], None, sd[p + "depth_head.bias"], 0)
+        self._build_bevencode(sd, prefix, conv, up_block)
+
+    def _build_effnet(self, sd, p, t, conv, up, up_block):
         sc, sh = fold_bn(sd, t + "_bn0", EFF_EPS)
         self.stem = (up(sd[t + "_conv_stem.weight"].detach().float().cpu().permute(2, 3, 1, 0).reshape(27, 32).contiguous()), up(sc), up(sh))
         self.blocks = []
@@ -181,17 +215,10 @@ class CameraEncoder:
             s2, h2 = fold_bn(sd, q + "_bn2", EFF_EPS)
             b["project"] = conv(sd[q + "_project_conv.weight"], s2, h2, 0, cin_p=mid_p, cout_p=cout_p)
             self.blocks.append(b)
-        # ---- Up blocks of CamEncode: concat layouts [skip map (padded) | upsampled map]
-        def up_block(pp, c_skip, c_up):
-            cs_p = _pad32(c_skip)
-            w0 = _place_cin(sd[pp + "conv.0.weight"], [(0, c_skip, 0), (c_skip, c_skip + c_up, cs_p)], cs_p + c_up)
-            sa, ha = fold_bn(sd, pp + "conv.1", TV_EPS)
-            sb, hb = fold_bn(sd, pp + "conv.4", TV_EPS)
-            return {"cs_p": cs_p, "c_up": c_up, "c0": conv(w0, sa, ha, 1, pad=1), "c1": conv(sd[pp + "conv.3.weight"], sb, hb, 1, pad=1)}
         self.up1 = up_block(p + "up1.", 112, 320)
         self.up2 = up_block(p + "up2.", 40, 256)
-        self.image_head = conv(sd[p + "image_head.weight"], None, sd[p + "image_head.bias"], 0)
-        self.depth_head = None if self.use_gt else conv(sd[p + "depth_head.weight"], None, sd[p + "depth_head.bias"], 0)
+
+    def _build_bevencode(self, sd, prefix, conv, up_block):
         # ---- BevEncode
         b = prefix + "bevencode."
         s, h = fold_bn(sd, b + "bn1", TV_EPS)
@@ -270,6 +297,8 @@ class CameraEncoder:
     def features(self, imgs, n, planes, H, W, tag, feat, prob, trace=None):
         """CamEncode.get_eff_features + heads on n images (device NCHW) -> feat (n,fH,fW,C), and (predicted depth) prob (n,fH,fW,D)."""
         e, lib, st, P = self.eng, self.lib, self.eng.stream(), lambda t: c_void_p(t.data_ptr())
+        if self.resnet:
+            return self._features_resnet(imgs, n, planes, H, W, tag, feat, prob, trace)
         h, w = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1          # static "same" padding of the 224-nominal stem: 0 before, 1 after
         x = e.buf(f"cam_stem_{tag}", (n, h, w, 32))
         sw, ssc, ssh = self.stem
@@ -296,6 +325,46 @@ class CameraEncoder:
             _lib.check(lib.av2x_softmax_channels(P(logit), n * h3 * w3, self.nbins, self.nbins, P(prob), st), "av2x_softmax_channels")
         if trace is not None:
             trace["up1"] = u1.permute(0, 3, 1, 2).clone()
+            trace["x_img"] = feat.permute(0, 3, 1, 2).clone()
+
+    def _features_resnet(self, imgs, n, planes, H, W, tag, feat, prob, trace=None):
+        """CamEncode_Resnet101.resnet101_forward + heads (lss_submodule.py:262-310) on n images (device NCHW planes)."""
+        e, lib, st, P = self.eng, self.lib, self.eng.stream(), lambda t: c_void_p(t.data_ptr())
+        x0 = e.buf(f"cam_rin_{tag}", (n, H, W, 16))                       # NHWC, the three colour planes in 16 channel slots (zeros behind them)
+        x0.zero_()
+        x0[..., :3] = imgs[:, :3].permute(0, 2, 3, 1)
+        h, w = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        a = e.buf(f"cam_rstem_{tag}", (n, h, w, 64))
+        e.conv(self.r_stem, x0, n, H, W, a)
+        hp, wp = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        cur = e.buf(f"cam_rpool_{tag}", (n, hp, wp, 64))
+        _lib.check(lib.av2x_maxpool2d(P(a), n, h, w, 64, 3, 2, 1, hp, wp, P(cur), st), "av2x_maxpool2d")
+        ch, cw = hp, wp
+        for bi, blk in enumerate(self.r_blocks):
+            s_ = blk["c2"].stride
+            ho, wo = (ch + 2 - 3) // s_ + 1, (cw + 2 - 3) // s_ + 1
+            y1 = e.buf(f"cam_rb{bi}a_{tag}", (n, ch, cw, blk["c1"].cout))
+            e.conv(blk["c1"], cur, n, ch, cw, y1)
+            y2 = e.buf(f"cam_rb{bi}b_{tag}", (n, ho, wo, blk["c2"].cout))
+            e.conv(blk["c2"], y1, n, ch, cw, y2)
+            idt = cur
+            if blk["down"] is not None:
+                idt = e.buf(f"cam_rb{bi}d_{tag}", (n, ho, wo, blk["c3"].cout))
+                e.conv(blk["down"], cur, n, ch, cw, idt)
+            o = e.buf(f"cam_rb{bi}o_{tag}", (n, ho, wo, blk["c3"].cout))
+            e.conv(blk["c3"], y2, n, ho, wo, o, residual=idt)
+            cur, ch, cw = o, ho, wo
+            if trace is not None and bi == 2:
+                trace["layer1"] = cur.permute(0, 3, 1, 2).clone()
+        if (ch, cw) != (H // self.ds, W // self.ds):
+            raise ValueError(f"camera image {H}x{W}: the stride-8 feature map is {ch}x{cw}, the frustum expects {H // self.ds}x{W // self.ds}")
+        e.conv(self.image_head, cur, n, ch, cw, feat)
+        if not self.use_gt:
+            logit = e.buf(f"cam_logit_{tag}", (n, ch, cw, self.nbins))
+            e.conv(self.depth_head, cur, n, ch, cw, logit)
+            _lib.check(lib.av2x_softmax_channels(P(logit), n * ch * cw, self.nbins, self.nbins, P(prob), st), "av2x_softmax_channels")
+        if trace is not None:
+            trace["features"] = cur.permute(0, 3, 1, 2).clone()
             trace["x_img"] = feat.permute(0, 3, 1, 2).clone()
 
     def bev_encode(self, x, n, h, w, out, tag, trace=None):

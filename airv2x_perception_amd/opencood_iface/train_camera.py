@@ -517,6 +517,8 @@ def bev_encode(P, sd, b, x):
 def lss_encoder_train(P, sd, prefix, enc, cam_inputs, training=True):
     """One agent type's LiftSplatShootEncoder in train mode -> spatial_features (B, ny, nx, bevout) NHWC with its autograd graph.
     ``enc``: the type's packed ``camera.CameraEncoder`` (geometry only: frustum, grid, depth bins -- no weights are read from it)."""
+    if enc.cfg["camera_encoder"] != "EfficientNet":
+        raise NotImplementedError("camera training: the EfficientNet trunk (CamEncode_Resnet101 runs in eval mode only)")
     dev = next(iter(P.values())).device
     imgs = cam_inputs["imgs"]
     if imgs.device != dev or imgs.dtype != torch.float32 or not imgs.is_contiguous():

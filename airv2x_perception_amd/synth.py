@@ -915,10 +915,40 @@ def cam_depth_bins(cam):
     return int(cam["grid_conf"]["ddiscr"][2])
 
 
+RESNET101_LAYERS = ((64, 3, 1), (128, 4, 2))       # (planes, bottlenecks, stride) of torchvision resnet101's layer1 / layer2: all CamEncode_Resnet101 keeps
+
+
+def _bottleneck_spec(prefix, cin, planes, stride):
+    """torchvision Bottleneck (expansion 4): 1x1 -> 3x3 (stride) -> 1x1, a 1x1 / stride downsample when the shape changes."""
+    spec = ([(prefix + "conv1.weight", (planes, cin, 1, 1), "conv")] + _bn(prefix + "bn1", planes)
+            + [(prefix + "conv2.weight", (planes, planes, 3, 3), "conv")] + _bn(prefix + "bn2", planes)
+            + [(prefix + "conv3.weight", (4 * planes, planes, 1, 1), "conv")] + _bn(prefix + "bn3", 4 * planes))
+    if stride != 1 or cin != 4 * planes:
+        spec += [(prefix + "downsample.0.weight", (4 * planes, cin, 1, 1), "conv")] + _bn(prefix + "downsample.1", 4 * planes)
+    return spec
+
+
+def camencode_resnet101_param_spec(cam, prefix):
+    """lss_submodule.CamEncode_Resnet101 (:191-224): conv1 / bn1 / layer1 / layer2 of a torchvision resnet101 (registration order of the
+    module), depth_head (512 -> D, only without use_depth_gt), image_head (512 -> C)."""
+    spec = [(prefix + "conv1.weight", (64, 3, 7, 7), "conv")] + _bn(prefix + "bn1", 64)
+    cin = 64
+    for li, (planes, nb, stride) in enumerate(RESNET101_LAYERS, 1):
+        for bi in range(nb):
+            spec += _bottleneck_spec(f"{prefix}layer{li}.{bi}.", cin, planes, stride if bi == 0 else 1)
+            cin = 4 * planes
+    if not cam["use_depth_gt"]:
+        spec += [(prefix + "depth_head.weight", (cam_depth_bins(cam), 512, 1, 1), "head"), (prefix + "depth_head.bias", (cam_depth_bins(cam),), "bias")]
+    spec += [(prefix + "image_head.weight", (cam["img_features"], 512, 1, 1), "img_head"), (prefix + "image_head.bias", (cam["img_features"],), "bias")]
+    return spec
+
+
 def camencode_param_spec(cam, prefix):
-    """lss_submodule.CamEncode (:50-87) with the EfficientNet trunk, chain_channels 256."""
+    """lss_submodule.CamEncode (:50-87) with the EfficientNet trunk, chain_channels 256; ``camera_encoder: Resnet101`` -> CamEncode_Resnet101."""
+    if cam["camera_encoder"] == "Resnet101":
+        return camencode_resnet101_param_spec(cam, prefix)
     if cam["camera_encoder"] != "EfficientNet":
-        raise NotImplementedError("camera_encoder: only the EfficientNet trunk (the shipped configs) is built")
+        raise NotImplementedError(f"camera_encoder {cam['camera_encoder']!r}: EfficientNet or Resnet101 (airv2x_encoder.py:67-86)")
     spec = effnet_param_spec(prefix + "trunk.") + up_param_spec(prefix + "up1.", 320 + 112, 256)
     if cam["img_downsample"] == 8:
         spec += up_param_spec(prefix + "up2.", 256 + 40, 256)
@@ -955,7 +985,8 @@ def lss_param_spec(cam, prefix):
     return camencode_param_spec(cam, prefix + "camencode.") + bevencode_param_spec(cam["img_features"], cam["bevout_feature"], prefix + "bevencode.")
 
 
-def multimodal_hypes(modalities=("cam", "lidar"), lidar_range=None, final_dim=(360, 640), use_depth_gt=True, max_cav=(5, 5, 5)):
+def multimodal_hypes(modalities=("cam", "lidar"), lidar_range=None, final_dim=(360, 640), use_depth_gt=True, max_cav=(5, 5, 5),
+                     camera_encoder="EfficientNet"):
     """default_hypes with a camera encoder per agent type (``args[type]["cam"]`` = the shipped camera block,
     hypes_yaml/airv2x/camera/det/airv2x_intermediate_where2com.yaml:180-248) and ``modalities`` as given: ("cam",) is that
     YAML, ("cam", "lidar") is BASELINE configs[4] (no shipped YAML sets both)."""
@@ -967,6 +998,7 @@ def multimodal_hypes(modalities=("cam", "lidar"), lidar_range=None, final_dim=(3
         a[t]["modalities"] = list(modalities)
         a[t]["cam"] = cam_args(t, final_dim, (r[0], r[3], r[1], r[4]))
         a[t]["cam"]["use_depth_gt"] = bool(use_depth_gt)
+        a[t]["cam"]["camera_encoder"] = camera_encoder
     return hy
 
 

@@ -523,6 +523,10 @@ int av2x_squeeze_excite(float* x, int32_t n, int32_t hw, int32_t c, const float*
 int av2x_resize_bilinear(const float* in, int32_t n, int32_t h, int32_t w, int32_t c, int32_t in_ctot, int32_t in_coff,
                          int32_t h2, int32_t w2, int32_t pad_t, int32_t pad_l, int32_t hout, int32_t wout, float* out,
                          int32_t out_ctot, int32_t out_coff, av2x_stream_t stream);
+/* av2x_maxpool2d: nn.MaxPool2d(ks, stride, pad) on an NHWC map (the 3x3 / 2 / 1 pool of CamEncode_Resnet101's stem, lss_submodule.py:262-266);
+ * padding cells are ignored as torch's -inf padding is. */
+int av2x_maxpool2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride, int32_t pad, int32_t ho, int32_t wo,
+                   float* out, av2x_stream_t stream);
 int av2x_softmax_channels(const float* x, int64_t rows, int32_t d, int32_t stride, float* out, av2x_stream_t stream);
 int av2x_lss_lift_pool(const float* feat, const float* prob, const float* imgs, int32_t planes, int32_t img_h, int32_t img_w,
                        int32_t downsample, const float* depth3, int32_t nbins, int32_t depth_mode, int32_t target,

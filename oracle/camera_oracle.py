@@ -180,8 +180,49 @@ def resnet18(pretrained=False, zero_init_residual=False, **kw):
     return ResNet18(zero_init_residual)
 
 
-def resnet101(*a, **k):      # imported by lss_submodule.py:9, only used by CamEncode_Resnet101 (not built)
-    raise NotImplementedError("resnet101 trunk is not restated")
+class Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (expansion 4, stride on the 3x3), restated from its published definition."""
+
+    def __init__(self, cin, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, 4 * planes, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(4 * planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != 4 * planes:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, 4 * planes, 1, stride, bias=False), nn.BatchNorm2d(4 * planes))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        return self.relu(self.bn3(self.conv3(y)) + idt)
+
+
+class ResNet101Front(nn.Module):
+    """The part of torchvision's resnet101 CamEncode_Resnet101 keeps (lss_submodule.py:206-216): conv1, bn1, maxpool, layer1 (3 bottlenecks,
+    planes 64), layer2 (4 bottlenecks, planes 128, stride 2).  layer3 / layer4 / fc are never registered there, so they are not built."""
+
+    def __init__(self, zero_init_residual=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = nn.Sequential(Bottleneck(64, 64, 1), Bottleneck(256, 64, 1), Bottleneck(256, 64, 1))
+        self.layer2 = nn.Sequential(Bottleneck(256, 128, 2), *[Bottleneck(512, 128, 1) for _ in range(3)])
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.zeros_(m.bn3.weight)
+
+
+def resnet101(pretrained=False, zero_init_residual=False, **kw):      # lss_submodule.py:206
+    return ResNet101Front(zero_init_residual)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -255,8 +296,11 @@ def cam_encode(sd, p, imgs, cam_args, training=False):
     if ds != 8:
         raise NotImplementedError("img_downsample 8 (the shipped AirV2X camera configuration)")
     dmin, dmax, nb = cam_args["grid_conf"]["ddiscr"]
-    r3, r4, r5 = effnet_features(sd, p + "trunk.", imgs[:, :3])
-    f = up_block(sd, p + "up2.", up_block(sd, p + "up1.", r5, r4, 2), r3, 2)
+    if cam_args.get("camera_encoder", "EfficientNet") == "Resnet101":
+        f = resnet101_features(sd, p, imgs[:, :3])                                  # CamEncode_Resnet101.forward :280-310 (512 channels)
+    else:
+        r3, r4, r5 = effnet_features(sd, p + "trunk.", imgs[:, :3])
+        f = up_block(sd, p + "up2.", up_block(sd, p + "up1.", r5, r4, 2), r3, 2)
     x_img = F.conv2d(f, sd[p + "image_head.weight"], sd[p + "image_head.bias"])
     if cam_args["use_depth_gt"]:
         d = torch.clamp(imgs[:, 3], max=dmax)                                       # :103 (clamp_max_)
@@ -268,6 +312,25 @@ def cam_encode(sd, p, imgs, cam_args, training=False):
         return x_img, dist.float()
     logit = F.conv2d(f, sd[p + "depth_head.weight"], sd[p + "depth_head.bias"])
     return x_img, F.softmax(logit, 1)
+
+
+def bottleneck(sd, p, x, stride):
+    idt = x
+    if (p + "downsample.0.weight") in sd:
+        idt = _bn(sd, p + "downsample.1", F.conv2d(x, sd[p + "downsample.0.weight"], stride=stride), 1e-5)
+    y = F.relu(_bn(sd, p + "bn1", F.conv2d(x, sd[p + "conv1.weight"]), 1e-5))
+    y = F.relu(_bn(sd, p + "bn2", F.conv2d(y, sd[p + "conv2.weight"], stride=stride, padding=1), 1e-5))
+    return F.relu(_bn(sd, p + "bn3", F.conv2d(y, sd[p + "conv3.weight"]), 1e-5) + idt)
+
+
+def resnet101_features(sd, p, x):
+    """CamEncode_Resnet101.resnet101_forward (:262-270): conv1 7x7/2 + bn1 + relu + maxpool 3x3/2 + layer1 + layer2 -> (BN, 512, H/8, W/8)."""
+    x = F.relu(_bn(sd, p + "bn1", F.conv2d(x, sd[p + "conv1.weight"], stride=2, padding=3), 1e-5))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (nb, stride) in enumerate(((3, 1), (4, 2)), 1):
+        for bi in range(nb):
+            x = bottleneck(sd, f"{p}layer{li}.{bi}.", x, stride if bi == 0 else 1)
+    return x
 
 
 def basic_block(sd, p, x, stride):

@@ -1108,7 +1108,7 @@ class _CudaIsCpu:
         torch.Tensor.to = self.orig
 
 
-def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities, use_depth_gt, stride, cams=None):
+def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities, use_depth_gt, stride, cams=None, camera_encoder="EfficientNet"):
     """The reference's Airv2xWhere2com with camera encoders (modalities ("cam",) = the shipped camera YAML, ("cam", "lidar") =
     BASELINE configs[4]) on seeded clouds + seeded camera inputs; also stores every camera-branch intermediate."""
     from airv2x_perception_amd import synth
@@ -1116,7 +1116,7 @@ def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities,
     from oracle import where2comm_oracle as orc
     _import_camera_reference()
     from opencood.models.airv2x_where2com import Airv2xWhere2com
-    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, use_depth_gt)
+    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, use_depth_gt, camera_encoder=camera_encoder)
     args = hy["model"]["args"]
     # the reference's hypes: its own YAML, modalities / depth flag / image size edited like a user would
     hy_ref = load_ref_hypes(lidar_range)
@@ -1125,6 +1125,7 @@ def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities,
     for t in synth.AGENT_TYPES:
         ra[t]["modalities"] = list(modalities)
         ra[t]["cam"]["use_depth_gt"] = bool(use_depth_gt)
+        ra[t]["cam"]["camera_encoder"] = camera_encoder
         ra[t]["cam"]["data_aug_conf"]["final_dim"] = list(final_dim)
         if lidar_range is not None:     # the camera BEV grid follows the (shrunk) x / y extents of the LiDAR grid
             ra[t]["cam"]["grid_conf"]["xbound"] = [lidar_range[0], lidar_range[3], 0.4]
@@ -1161,9 +1162,13 @@ def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities,
         enc = getattr(model, pre)[list(modalities).index("cam")]
         hs.append(enc.camencode.register_forward_hook(hook("camenc_" + t)))
         hs.append(enc.camencode.image_head.register_forward_hook(hook("img_" + t)))
-        hs.append(enc.camencode.up1.register_forward_hook(hook("up1_" + t)))
-        hs.append(enc.camencode.trunk._blocks[0].register_forward_hook(hook("mb0_" + t)))
-        hs.append(enc.camencode.trunk._blocks[5].register_forward_hook(hook("mb5_" + t)))
+        if camera_encoder == "EfficientNet":
+            hs.append(enc.camencode.up1.register_forward_hook(hook("up1_" + t)))
+            hs.append(enc.camencode.trunk._blocks[0].register_forward_hook(hook("mb0_" + t)))
+            hs.append(enc.camencode.trunk._blocks[5].register_forward_hook(hook("mb5_" + t)))
+        else:
+            hs.append(enc.camencode.layer1.register_forward_hook(hook("rl1_" + t)))
+            hs.append(enc.camencode.layer2.register_forward_hook(hook("rl2_" + t)))
         hs.append(enc.bevencode.register_forward_hook(hook("bev_" + t)))
         hs.append(enc.bevencode.register_forward_pre_hook(lambda m, i, t=t: cap.setdefault("pooled_" + t, []).append(i[0])))
         hs.append(enc.bevencode.layer1.register_forward_hook(hook("l1_" + t)))
@@ -1188,7 +1193,7 @@ def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities,
     s = stride
     fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types), "n_points": np.int64(n_points),
           "final_dim": np.asarray(final_dim, np.int64), "modalities": np.asarray(list(modalities)), "use_depth_gt": np.int64(use_depth_gt),
-          "stride": np.int64(s), "spec_len": np.int64(len(spec)), "comm_rate": np.int64(out["comm_rate"]), "com": np.float64(float(out["com"])),
+          "camera_encoder": np.asarray(camera_encoder), "stride": np.int64(s), "spec_len": np.int64(len(spec)), "comm_rate": np.int64(out["comm_rate"]), "com": np.float64(float(out["com"])),
           "cams": np.asarray([(cams or synth.CAMS_PER_AGENT)[t] for t in synth.AGENT_TYPES], np.int64)}
 
     def put(key, t, s=s):
@@ -1206,9 +1211,9 @@ def camera_case(name, lidar_range, types, n_points, seed, final_dim, modalities,
         if "bev_" + t not in cap:
             continue
         put("img_" + t, cap["img_" + t][0], 1 if s == 1 else 3)
-        put("up1_" + t, cap["up1_" + t][0], 0)
-        put("mb0_" + t, cap["mb0_" + t][0], 0)
-        put("mb5_" + t, cap["mb5_" + t][0], 0)
+        for key in ("up1_", "mb0_", "mb5_", "rl1_", "rl2_"):          # EfficientNet / Resnet101 trunk intermediates, whichever exist
+            if key + t in cap:
+                put(key + t, cap[key + t][0], 0)
         put("pooled_" + t, cap["pooled_" + t][0], 2 if s == 1 else s)
         put("l1_" + t, cap["l1_" + t][0], 0)
         put("l3_" + t, cap["l3_" + t][0], 0)
@@ -2247,6 +2252,10 @@ GROUPS = {
                                    cams={"vehicle": 2, "rsu": 1, "drone": 1}),
                        camera_case("w2c_cam_small_softmax", SMALL, ["vehicle", "drone"], 700, 22, (104, 168), ("cam",), False, 1,
                                    cams={"vehicle": 2, "rsu": 1, "drone": 1})),
+    "camera_resnet101": lambda: (camera_case("w2c_cam_small_resnet101", SMALL, ["vehicle", "drone"], 700, 24, (104, 168), ("cam",), True, 1,
+                                             {"vehicle": 2, "rsu": 1, "drone": 1}, camera_encoder="Resnet101"),
+                                 camera_case("w2c_cam_small_resnet101_softmax", SMALL, ["vehicle", "rsu"], 700, 25, (104, 168), ("cam", "lidar"), False, 1,
+                                             {"vehicle": 1, "rsu": 2, "drone": 1}, camera_encoder="Resnet101")),
     "camera_full": lambda: camera_case("w2c_cam_full_n8", None, T8, 8192, 23, (360, 640), ("cam", "lidar"), True, 8),
     "labels": lambda: (labels_golden("labels_small", SMALL, 12, 41), labels_golden("labels_full", None, 60, 42),
                        labels_golden("labels_full_one", None, 1, 43)),
