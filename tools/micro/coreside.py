@@ -100,7 +100,7 @@ def victims():
         return err
     extra = {"guard_lds20k": guard} if gl is not None else {}
     if gl is not None:
-        couts = {k: torch.zeros(1024 * 256, device="cuda") for k in range(13)}
+        couts = {k: torch.zeros(1024 * 256, device="cuda") for k in range(15)}
 
         def chain(kind):
             def f(stream):
@@ -110,7 +110,8 @@ def victims():
         extra.update({"chain_mfma16x16x4f32": chain(0), "chain_mfma32x32x2f32": chain(1), "chain_exp_shfl": chain(2), "chain_valu": chain(3),
                       "chain_pk_add_opsel": chain(4), "chain_pk_add_plain": chain(5), "chain_pkv_add_hi10": chain(6), "chain_pkv_add_sel01": chain(7),
                       "chain_pkv_mul_swap": chain(8), "chain_pkv_fma_hi101": chain(9), "chain_pkv_fma_sel010": chain(10),
-                      "chain_pkv_add_neg": chain(11), "chain_pkv_add_swap_src0": chain(12)})
+                      "chain_pkv_add_neg": chain(11), "chain_pkv_add_swap_src0": chain(12), "chain_pkv_f16_sel01": chain(13),
+                      "chain_pkv_u16_sel01": chain(14)})
     if os.environ.get("ONLY"):
         extra = {k: v for k, v in extra.items() if os.environ["ONLY"] in k}
     if os.environ.get("ONLY"):

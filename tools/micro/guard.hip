@@ -85,6 +85,14 @@ __global__ __launch_bounds__(256) void chain_kernel(float* out, int iters, int s
                 a *= 0.5f;
             }
             res += a.x + 2.0f * a.y;
+        } else if (KIND == 13 || KIND == 14) {   // 16-bit packed ops with the second source's OP_SEL bit: are they disturbed too?
+            unsigned a = 0x3c003800u ^ (gid & 0xff), b = 0x34003000u;      // two f16 / u16 halves
+            for (int i = 0; i < iters; ++i) {
+                if (KIND == 13) asm volatile("v_pk_add_f16 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(a) : "v"(b));
+                if (KIND == 14) asm volatile("v_pk_add_u16 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(a) : "v"(b));
+                a = (a & 0x83ff83ffu) | 0x38003800u;
+            }
+            res += (float)(a & 0xffff) + 3.0f * (float)(a >> 16);
         } else if (KIND == 5) {     // the same without op_sel
             typedef float v2f __attribute__((ext_vector_type(2)));
             v2f a = {x, y}, b = {y * 3.0f, x * 5.0f + 1.0f};
@@ -116,6 +124,8 @@ extern "C" int chain_launch(int kind, float* out, int blocks, int iters, int spi
     else if (kind == 10) hipLaunchKernelGGL(chain_kernel<10>, dim3(blocks), dim3(256), 0, st, out, iters, spins);
     else if (kind == 11) hipLaunchKernelGGL(chain_kernel<11>, dim3(blocks), dim3(256), 0, st, out, iters, spins);
     else if (kind == 12) hipLaunchKernelGGL(chain_kernel<12>, dim3(blocks), dim3(256), 0, st, out, iters, spins);
+    else if (kind == 13) hipLaunchKernelGGL(chain_kernel<13>, dim3(blocks), dim3(256), 0, st, out, iters, spins);
+    else if (kind == 14) hipLaunchKernelGGL(chain_kernel<14>, dim3(blocks), dim3(256), 0, st, out, iters, spins);
     else hipLaunchKernelGGL(chain_kernel<3>, dim3(blocks), dim3(256), 0, st, out, iters, spins);
     return (int)hipGetLastError();
 }
