@@ -88,6 +88,10 @@ class _LossDict(dict):
         self._flush()
         return dict(self)
 
+    def __reduce__(self):                 # pickling / deepcopy of the criterion: the floats, as a plain dict (events do not travel)
+        self._flush()
+        return (dict, (dict(dict.items(self)),))
+
 
 class _PPLoss(torch.autograd.Function):
     @staticmethod
