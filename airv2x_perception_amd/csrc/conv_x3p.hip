@@ -123,11 +123,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const f32x4 v = r[i];
+#ifdef AV2X_X3P_NOSPLIT      // timing experiment only (wrong results): what the kernel costs without the hi / mid / lo split
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 raw = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
+            const p3_bf16x4 h0 = __builtin_bit_cast(p3_bf16x4, raw), h1 = h0, h2 = h0;
+#else
             const p3_bf16x4 h0 = __builtin_convertvector(v, p3_bf16x4);
             const f32x4 r1 = v - __builtin_convertvector(h0, f32x4);
             const p3_bf16x4 h1 = __builtin_convertvector(r1, p3_bf16x4);
             const f32x4 r2 = r1 - __builtin_convertvector(h1, f32x4);
             const p3_bf16x4 h2 = __builtin_convertvector(r2, p3_bf16x4);
+#endif
             *reinterpret_cast<p3_bf16x4*>(st + i * 1024) = h0;
             *reinterpret_cast<p3_bf16x4*>(st + i * 1024 + A_PL) = h1;
             *reinterpret_cast<p3_bf16x4*>(st + i * 1024 + 2 * A_PL) = h2;
