@@ -151,7 +151,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
     const unsigned rA = (unsigned)(lh * AOS + (wm0 + li) * 16);
     const unsigned rB = (unsigned)(A_BYTES + lh * BOS + (wn0 + li) * 16);
     auto compute = [&](int buf) {
+#ifdef AV2X_X3P_NOLDS        // timing experiment only (wrong results): every step reads the fragments of stage 0's first rows -- same instruction
+        (void)buf;               // count, but the loads hit the same few LDS lines (no bank / bandwidth pressure)
+        const unsigned char* st = smem_p3 - rA + (threadIdx.x & 63) * 16;
+#else
         const unsigned char* st = smem_p3 + buf * STAGE;
+#endif
         p3_bf16x8 fa[3][MT], fb[3][NT];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
