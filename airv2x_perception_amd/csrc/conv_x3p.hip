@@ -30,6 +30,12 @@ __device__ __forceinline__ void p3_glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 #endif
 }
 
+#ifdef AV2X_X3P_NOBARRIER       // timing experiment only (races): the per-step workgroup barrier left out
+#define P3_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define P3_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
     constexpr int BM = 128, MT = 2, NT = BN / 64;          // 4 waves as 2 x 2; wave tile 64 x (BN / 2)
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
         compute(0);
         lstore_a(ra[1], 1);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        P3_STEP_BARRIER();
         if (s + 1 < nst) {
             issue_b(0);                                       // step s + 2
             advance();
@@ -197,10 +203,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
             compute(1);
             lstore_a(ra[0], 0);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            P3_STEP_BARRIER();
         }
     }
+#ifdef AV2X_X3P_NOEPI           // timing experiment only: one store per lane instead of the 64-value epilogue
+    {
+        float keep = 0.f;       // every accumulator tile stays live (no MFMA may be optimised away)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) keep += acc[a][c][(a * NT + c) & 15];
+        if (keep == 123456.f) p.out[threadIdx.x] = keep;
+    }
+#else
     conv_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, lane);
+#endif
 }
 
 template <int BN>
