@@ -15,6 +15,7 @@
 //     instructions per value pair and stored with three ds_write_b64 -- 36 VALU per wave and step beside 24 MFMAs;
 //   * a wave owns 64 x 64 (BN = 128) or 64 x 32 (BN = 64) of the tile: per 16 k it reads 12 (9) fragments of 1 KB for 24 (12) MFMAs.
 // Per CU and step that is 40 KB through the texture path and 96 KB of LDS reads per 1536 matrix cycles: the matrix cores bound it.
+#include <cstdlib>
 #include <cstring>
 
 #include "conv_common.hpp"
