@@ -798,7 +798,9 @@ def main(argv=None, hooks=None, device=None):
                                         "over ms_per_step: how busy the matrix cores are in a mode that mixes both pipes"}} if a.gemm in ("wino_x3", "x3") else {}),
             "event_pair_overhead_us": round(ev_over * 1e6, 2),
             "sustained_clock": "fp32-MFMA loops run at 2.0 GHz on random operands (2.32 on zeros; GRBM_GUI_ACTIVE / duration, "
-                               "profiles/r02_dvfs_clock.txt): peak at that clock = 131.5 TFLOP/s; frac is against the 2.4 GHz figure",
+                               "profiles/r02_dvfs_clock.txt): peak at that clock = 131.5 TFLOP/s; the bf16-MFMA split-3 kernels sustain 2.16 GHz "
+                               "(conv_wino4_x3) and 1.59 GHz (conv_igemm_x3p; profiles/r04c_pmc_sq_conv_wino4_x3.txt, r04d_pmc_sq_conv_igemm_x3p.txt); "
+                               "frac is against the 2.4 GHz figure",
             "avg_launch_us": round(sec / cnt * 1e6, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "executed_gflop_per_launch": round(exe / cnt / 1e9, 3),
             "all_conv_kernels": {"tflops": round(tot_fl / tot_s / 1e12, 2), "executed_tflops": round(tot_exe / tot_s / 1e12, 2),
