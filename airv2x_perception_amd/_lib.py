@@ -53,6 +53,8 @@ SIGNATURES = {
     "av2x_gap_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
     "av2x_gap": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "av2x_channel_broadcast": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p]),
+    "av2x_maxpool2d_backward": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                          c_void_p]),
     "av2x_dwconv2d_wgrad_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "av2x_dwconv2d_wgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                       c_void_p, c_void_p]),

@@ -203,6 +203,42 @@ static int dw_slab(long long npix, int c) {      // >= ~1024 workgroups where th
     return (int)(slab < kDwSlabMin ? kDwSlabMin : slab > kDwSlabMax ? kDwSlabMax : slab);
 }
 
+// ---- nn.MaxPool2d backward as a gather: an input pixel collects dy from every window that contains it and whose FIRST maximum (scan order
+// kh, kw: torch's forward keeps the first element that is greater) sits on it -- no atomics, no saved indices
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int H, int W, int C, int ks,
+                                                          int stride, int pad, int Ho, int Wo, long long total, float* __restrict__ dx) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % C);
+    const long long pix = gid / C;
+    const int wi = (int)(pix % W);
+    const long long r = pix / W;
+    const int hi = (int)(r % H);
+    const long long n = r / H;
+    const float* xi = x + (size_t)n * H * W * C + c;
+    float g = 0.f;
+    // windows (ho, wo) with ho * stride - pad <= hi < ho * stride - pad + ks
+    const int ho1 = min(Ho - 1, (hi + pad) / stride), wo1 = min(Wo - 1, (wi + pad) / stride);
+    const int ho0 = max(0, (hi + pad - ks + stride) / stride), wo0 = max(0, (wi + pad - ks + stride) / stride);
+    for (int ho = ho0; ho <= ho1; ++ho)
+        for (int wo = wo0; wo <= wo1; ++wo) {
+            float m = -INFINITY;
+            int mh = -1, mw = -1;
+            for (int kh = 0; kh < ks; ++kh) {
+                const int h2 = ho * stride - pad + kh;
+                if ((unsigned)h2 >= (unsigned)H) continue;
+                for (int kw = 0; kw < ks; ++kw) {
+                    const int w2 = wo * stride - pad + kw;
+                    if ((unsigned)w2 >= (unsigned)W) continue;
+                    const float v = xi[((size_t)h2 * W + w2) * C];
+                    if (v > m || mh < 0) { m = v; mh = h2; mw = w2; }
+                }
+            }
+            if (mh == hi && mw == wi) g += dy[(((size_t)n * Ho + ho) * Wo + wo) * C + c];
+        }
+    dx[gid] = g;
+}
+
 unsigned blocks_for(size_t n) {
     size_t b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : b > 8192 ? 8192 : b);
@@ -289,6 +325,19 @@ extern "C" int av2x_resize_bilinear_backward(const float* dy, int32_t n, int32_t
     const long long total = (long long)n * h * w * (c / 4);
     hipLaunchKernelGGL(resize_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, h, w, c, h2, w2, sy, sx, isy, isx, dx, total);
     return av2x::check_launch("resize_bwd_kernel");
+}
+
+// dx (n, h, w, c) of av2x_maxpool2d: x its input, dy (n, ho, wo, c)
+extern "C" int av2x_maxpool2d_backward(const float* x, const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride,
+                                       int32_t pad, int32_t ho, int32_t wo, float* dx, av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!x || !dy || !dx) return av2x::fail("av2x_maxpool2d_backward: null argument");
+    if (n < 0 || h <= 0 || w <= 0 || c <= 0 || ks <= 0 || stride <= 0 || pad < 0 || 2 * pad > ks) return av2x::fail("av2x_maxpool2d_backward: bad sizes");
+    if (ho != (h + 2 * pad - ks) / stride + 1 || wo != (w + 2 * pad - ks) / stride + 1) return av2x::fail("av2x_maxpool2d_backward: output size mismatch");
+    const long long total = (long long)n * h * w * c;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, av2x::as_stream(stream), x, dy, h, w, c, ks, stride, pad,
+                       ho, wo, total, dx);
+    return av2x::check_launch("maxpool_bwd_kernel");
 }
 
 extern "C" uint64_t av2x_dwconv2d_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t c, int32_t ks) {

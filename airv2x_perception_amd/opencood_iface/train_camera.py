@@ -336,6 +336,34 @@ class LiftGtFn(torch.autograd.Function):
         return dfeat, None, None, None, None, None, None
 
 
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(ks, stride, pad) on NHWC maps (the stem pool of CamEncode_Resnet101); the gradient goes to the first maximum of a window."""
+
+    @staticmethod
+    def forward(ctx, x, ks, stride, pad):
+        T._check_dev(x)
+        r = _runner(x.device)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+        y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        _lib.check(r.lib.av2x_maxpool2d(_P(x), n, h, w, c, ks, stride, pad, ho, wo, _P(y), r.stream()), "av2x_maxpool2d")
+        ctx.save_for_backward(x)
+        ctx.cfg = (ks, stride, pad, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        ks, stride, pad, ho, wo = ctx.cfg
+        r = _runner(x.device)
+        n, h, w, c = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(r.lib.av2x_maxpool2d_backward(_P(x), _P(dy.contiguous()), n, h, w, c, ks, stride, pad, ho, wo, _P(dx), r.stream()),
+                   "av2x_maxpool2d_backward")
+        return dx, None, None, None
+
+
 class SoftmaxChFn(torch.autograd.Function):
     """CamEncode.get_depth_dist (:89-92): softmax over the first ``d`` channels of (n, h, w, stride) logits -> (n, h, w, d)."""
 
@@ -493,6 +521,36 @@ def cam_features(P, sd, p, flat, training, drop_connect=None, depth_bins=0):
     return feat, SoftmaxChFn.apply(logit, depth_bins)
 
 
+def bottleneck(P, sd, q, x, stride):
+    """torchvision Bottleneck (1x1 -> 3x3 / stride -> 1x1, expansion 4) in train mode."""
+    idt = x
+    if (q + "downsample.0.weight") in P:
+        idt = _conv_bn(P, sd, x, q + "downsample.0.weight", q + "downsample.1", stride, 0, TV_EPS, TV_MOM, False)
+    y = _conv_bn(P, sd, x, q + "conv1.weight", q + "bn1", 1, 0, TV_EPS, TV_MOM, True)
+    y = _conv_bn(P, sd, y, q + "conv2.weight", q + "bn2", stride, 1, TV_EPS, TV_MOM, True)
+    y = _conv_bn(P, sd, y, q + "conv3.weight", q + "bn3", 1, 0, TV_EPS, TV_MOM, False)
+    return add_act(y, idt, True)
+
+
+def cam_features_resnet101(P, sd, p, flat, depth_bins=0):
+    """CamEncode_Resnet101.resnet101_forward + heads (lss_submodule.py:262-310) in train mode: flat (BN, 4, H, W) -> feat (BN, fH, fW, C)
+    [, softmax depth distribution]."""
+    from ..synth import RESNET101_LAYERS
+    x = Fn.pad(flat[:, :3].permute(0, 2, 3, 1), (0, 29)).contiguous()              # NHWC, the colour planes in 32 channel slots
+    x = _conv_bn(P, sd, x, p + "conv1.weight", p + "bn1", 2, 3, TV_EPS, TV_MOM, True)
+    x = MaxPoolFn.apply(x, 3, 2, 1)
+    for li, (planes, nb, stride) in enumerate(RESNET101_LAYERS, 1):
+        for bi in range(nb):
+            x = bottleneck(P, sd, f"{p}layer{li}.{bi}.", x, stride if bi == 0 else 1)
+    feat = T.conv_bias_act(x, P[p + "image_head.weight"], P[p + "image_head.bias"], 1, 0, False)
+    if not depth_bins:
+        return feat
+    dp = _p32(depth_bins)
+    wd = Fn.pad(P[p + "depth_head.weight"], (0, 0, 0, 0, 0, 0, 0, dp - depth_bins))
+    logit = T.conv_bias_act(x, wd, _padv(P[p + "depth_head.bias"], dp), 1, 0, False)
+    return feat, SoftmaxChFn.apply(logit, depth_bins)
+
+
 def basic_block(P, sd, q, x, stride):
     idt = x
     if (q + "downsample.0.weight") in P:
@@ -517,8 +575,6 @@ def bev_encode(P, sd, b, x):
 def lss_encoder_train(P, sd, prefix, enc, cam_inputs, training=True):
     """One agent type's LiftSplatShootEncoder in train mode -> spatial_features (B, ny, nx, bevout) NHWC with its autograd graph.
     ``enc``: the type's packed ``camera.CameraEncoder`` (geometry only: frustum, grid, depth bins -- no weights are read from it)."""
-    if enc.cfg["camera_encoder"] != "EfficientNet":
-        raise NotImplementedError("camera training: the EfficientNet trunk (CamEncode_Resnet101 runs in eval mode only)")
     dev = next(iter(P.values())).device
     imgs = cam_inputs["imgs"]
     if imgs.device != dev or imgs.dtype != torch.float32 or not imgs.is_contiguous():
@@ -529,7 +585,10 @@ def lss_encoder_train(P, sd, prefix, enc, cam_inputs, training=True):
     if (H // enc.ds, W // enc.ds) != (enc.fH, enc.fW):
         raise ValueError(f"camera images are {H}x{W}; data_aug_conf.final_dim says {enc.fH * enc.ds}x{enc.fW * enc.ds}")
     flat = imgs.view(B * N, planes, H, W)
-    out = cam_features(P, sd, prefix + "camencode.", flat, training, depth_bins=0 if enc.use_gt else enc.nbins)
+    if enc.cfg["camera_encoder"] == "Resnet101":
+        out = cam_features_resnet101(P, sd, prefix + "camencode.", flat, depth_bins=0 if enc.use_gt else enc.nbins)
+    else:
+        out = cam_features(P, sd, prefix + "camencode.", flat, training, depth_bins=0 if enc.use_gt else enc.nbins)
     feat = out if enc.use_gt else out[0]
     if tuple(feat.shape[1:3]) != (enc.fH, enc.fW):
         raise ValueError(f"camera image {H}x{W}: the stride-8 feature map is {tuple(feat.shape[1:3])}, the frustum expects {(enc.fH, enc.fW)}")

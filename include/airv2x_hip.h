@@ -562,6 +562,8 @@ int av2x_channel_broadcast(const float* g, const float* y, int32_t n, int32_t hw
 uint64_t av2x_resize_bilinear_backward_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t c);
 int av2x_resize_bilinear_backward(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t h2, int32_t w2, void* workspace, float* dx,
                                   av2x_stream_t stream);
+int av2x_maxpool2d_backward(const float* x, const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride, int32_t pad,
+                            int32_t ho, int32_t wo, float* dx, av2x_stream_t stream);   /* adjoint of av2x_maxpool2d (first maximum of a window) */
 uint64_t av2x_dwconv2d_wgrad_workspace_bytes(int32_t n, int32_t ho, int32_t wo, int32_t c, int32_t ks);
 int av2x_dwconv2d_wgrad(const float* x, const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ks, int32_t stride, int32_t pad,
                         int32_t ho, int32_t wo, void* workspace, float* dw, av2x_stream_t stream);

@@ -131,6 +131,24 @@ def test_lift_adjoint_is_the_gather_of_the_forward_scatter():
     assert float(feat.grad.abs().max()) > 0
 
 
+@pytest.mark.parametrize("n,h,w,c", [(2, 52, 84, 64), (1, 7, 9, 32)])
+def test_maxpool_backward_matches_torch(n, h, w, c):
+    """nn.MaxPool2d(3, 2, 1) (the stem pool of CamEncode_Resnet101): forward bit-exact, the gradient lands on torch's positions (distinct values:
+    no ties)."""
+    from airv2x_perception_amd.opencood_iface import train_camera as TC
+    g = _g(h + w)
+    x = torch.randn(n, c, h, w, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = torch.nn.functional.max_pool2d(xr, 3, 2, 1)
+    d = torch.randn(yr.shape, generator=g)
+    yr.backward(d)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
+    yd = TC.MaxPoolFn.apply(xd, 3, 2, 1)
+    yd.backward(d.permute(0, 2, 3, 1).contiguous().cuda())
+    assert torch.equal(yd.detach().cpu().permute(0, 3, 1, 2), yr.detach())
+    assert torch.equal(xd.grad.cpu().permute(0, 3, 1, 2), xr.grad)
+
+
 def test_predicted_depth_lift_and_channel_softmax_adjoints():
     """The lift is bilinear in (features, depth distribution): <Lift(f, p), dout> = <f, df> = <p, dp>; the channel softmax's backward against
     torch autograd (CamEncode.get_depth_dist, lss_submodule.py:89-92) with padded logit channels."""
@@ -167,7 +185,8 @@ def _case(fx):
     final_dim = tuple(int(v) for v in fx["final_dim"])
     mods = tuple(str(m) for m in fx["modalities"])
     cams = {t: int(v) for t, v in zip(synth.AGENT_TYPES, fx["cams"])}
-    hy = synth.multimodal_hypes(mods, rng, final_dim, bool(int(fx["use_depth_gt"])) if "use_depth_gt" in fx else True)
+    hy = synth.multimodal_hypes(mods, rng, final_dim, bool(int(fx["use_depth_gt"])) if "use_depth_gt" in fx else True,
+                                camera_encoder=str(fx["camera_encoder"]) if "camera_encoder" in fx else "EfficientNet")
     args = hy["model"]["args"]
     sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=int(fx["seed"]))
     pp = hy["preprocess"]
@@ -182,7 +201,8 @@ def _case(fx):
     return hy, args, sd, dd, tgt
 
 
-@pytest.mark.parametrize("name", ["train_cam_small_n3", "train_cam_small_camonly_n2", "train_cam_small_camonly_n2b", "train_cam_small_softmax_n2"])
+@pytest.mark.parametrize("name", ["train_cam_small_n3", "train_cam_small_camonly_n2", "train_cam_small_camonly_n2b", "train_cam_small_softmax_n2",
+                                  "train_cam_small_resnet101_n2"])
 def test_camera_training_step_matches_the_reference(name, monkeypatch):
     from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
     from airv2x_perception_amd.opencood_iface import train_camera as TC

@@ -1741,7 +1741,8 @@ def train_v2vnet_golden(name, lidar_range, types, n_points, seed, agg="avg", pos
                         extra={"agg": np.asarray(agg)})
 
 
-def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim, modalities, cams, pos_frac=0.01, use_depth_gt=True):
+def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim, modalities, cams, pos_frac=0.01, use_depth_gt=True,
+                     camera_encoder="EfficientNet"):
     """One TRAINING step of the reference's Airv2xWhere2com WITH camera encoders (train mode: BatchNorm batch statistics in the
     EfficientNet-B0 trunk, the Up blocks and BevEncode; ground-truth depth with the training-mode clipping of bin_depths; stochastic depth
     switched off -- a configuration edit: random masks of two implementations cannot be compared) + PointPillarLossMultiClass + torch
@@ -1755,7 +1756,7 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
     _import_camera_reference()
     from opencood.loss.point_pillar_loss_multiclass import PointPillarLossMultiClass
     from opencood.models.airv2x_where2com import Airv2xWhere2com
-    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, use_depth_gt)
+    hy = synth.multimodal_hypes(modalities, lidar_range, final_dim, use_depth_gt, camera_encoder=camera_encoder)
     args = hy["model"]["args"]
     hy_ref = load_ref_hypes(lidar_range)
     ra = hy_ref["model"]["args"]
@@ -1763,6 +1764,7 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
     for t in synth.AGENT_TYPES:
         ra[t]["modalities"] = list(modalities)
         ra[t]["cam"]["use_depth_gt"] = bool(use_depth_gt)
+        ra[t]["cam"]["camera_encoder"] = camera_encoder
         ra[t]["cam"]["data_aug_conf"]["final_dim"] = list(final_dim)
         if lidar_range is not None:
             ra[t]["cam"]["grid_conf"]["xbound"] = [lidar_range[0], lidar_range[3], 0.4]
@@ -1785,7 +1787,7 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
         assert [k for k, _, _ in spec] == list(m.state_dict().keys())
         m.load_state_dict(sd, strict=True)
         for pre in synth.TYPE_PREFIX.values():
-            if hasattr(m, pre):
+            if hasattr(m, pre) and camera_encoder == "EfficientNet":
                 getattr(m, pre)[mi].camencode.trunk._global_params.drop_connect_rate = 0.0
         d = synth.add_cameras(synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"]), types, seed=seed + 50, final_dim=final_dim,
                               cams_per_agent=cams)
@@ -1866,7 +1868,8 @@ def train_cam_golden(name, lidar_range, types, n_points, seed, rseed, final_dim,
           "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64), "loss64": np.float64(float(l64)),
           "mask": np.packbits(cap["comm"][0].detach().numpy().astype(np.uint8).reshape(-1)),
           "mask_shape": np.asarray(cap["comm"][0].shape, np.int64), "com": np.float64(float(out["com"])), "comm_rate": np.int64(out["comm_rate"]),
-          "head_stride": np.int64(1), "head_hw": np.asarray([H, W], np.int64), "use_depth_gt": np.int64(1 if use_depth_gt else 0)}
+          "head_stride": np.int64(1), "head_hw": np.asarray([H, W], np.int64), "use_depth_gt": np.int64(1 if use_depth_gt else 0),
+          "camera_encoder": np.asarray(camera_encoder)}
     for k in ("psm", "rm", "obj"):
         fx[k] = out[k].detach().numpy()
     names, devs = [], []
@@ -2285,6 +2288,8 @@ GROUPS = {
                                            {"vehicle": 2, "rsu": 1, "drone": 1})),
     "train_cam_b": lambda: train_cam_golden("train_cam_small_camonly_n2b", SMALL, ["vehicle", "rsu"], 700, 41, 9, (104, 168), ("cam",),
                                             {"vehicle": 2, "rsu": 1, "drone": 1}),
+    "train_cam_resnet101": lambda: train_cam_golden("train_cam_small_resnet101_n2", SMALL, ["vehicle", "drone"], 700, 44, 12, (104, 168), ("cam",),
+                                                    {"vehicle": 2, "rsu": 1, "drone": 1}, camera_encoder="Resnet101"),
     "train_cam_softmax": lambda: train_cam_golden("train_cam_small_softmax_n2", SMALL, ["vehicle", "rsu"], 700, 43, 11, (104, 168), ("cam",),
                                                   {"vehicle": 2, "rsu": 1, "drone": 1}, use_depth_gt=False),
     "train_cobevt_full": lambda: train_cobevt_golden("train_cobevt_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 18,
