@@ -353,8 +353,22 @@ class BaseBEVBackbone(_HipModule):
         return _block(P, sd, i, x, self.model_cfg["layer_nums"][i], self.model_cfg["layer_strides"][i], 1, prefix="")
 
     def _train_deblock(self, i, x):
-        from .train_where2com import _deblock
+        """deblocks[i] in train mode: ConvTranspose(k = s) + BN + ReLU; a DOWN-sampling one (stride 1 / k, base_bev_backbone.py:87-105) is
+        Conv2d(k, stride k) + BN + ReLU = a 1x1 convolution of the space-to-depth map (k x k x cin channels per coarse pixel), so its data
+        and weight gradients run on the same nodes; the final deblock (index = number of levels) is an ordinary one on the concatenation."""
+        from . import train_ops as T
+        from .train_where2com import _deblock, _running
         P, sd = self._train_state()
+        ups = self.model_cfg.get("upsample_strides", [])
+        if i < len(self.model_cfg["layer_nums"]) and ups[i] < 1:
+            k = int(round(1.0 / ups[i]))
+            n, h, w, c = x.shape
+            if h % k or w % k:
+                raise ValueError(f"down-sampling deblock {i}: the {h}x{w} map is not divisible by {k}")
+            wt = P[f"deblocks.{i}.0.weight"]                                        # (cout, cin, k, k)
+            w1 = wt.permute(0, 2, 3, 1).reshape(wt.shape[0], k * k * c, 1, 1)       # (dh, dw, c) = _space_to_depth's channel order
+            bn = f"deblocks.{i}.1"
+            return T.conv_bn_act(T._space_to_depth(x, k).contiguous(), w1, P[bn + ".weight"], P[bn + ".bias"], 1, 0, running=_running(sd, bn, 1))
         return _deblock(P, sd, i, x, 1, prefix="")
 
     def _run_block(self, i, x):
@@ -365,23 +379,21 @@ class BaseBEVBackbone(_HipModule):
 
     def _run_deblock(self, i, x):
         if self.training:
-            if self.variant:
-                raise NotImplementedError("training of the down-sampling / final-deblock variants is not built")
             return _nchw(self._train_deblock(i, _nhwc_grad(x)))
         with torch.no_grad():
             return _nchw(self.deblock_nhwc(i, _nhwc(x)))
 
     def forward(self, data_dict):
         if self.training:
-            if self.variant:
-                raise NotImplementedError("training of the down-sampling / final-deblock variants is not built")
             x = _nhwc_grad(data_dict["spatial_features"])
-            ups = []
-            for i in range(len(self.model_cfg["layer_nums"])):
+            ups, nlev = [], len(self.model_cfg["layer_nums"])
+            for i in range(nlev):
                 x = self._train_block(i, x)
                 if self.model_cfg.get("upsample_strides"):
                     ups.append(self._train_deblock(i, x))
             out = torch.cat(ups, -1) if len(ups) > 1 else (ups[0] if ups else x)
+            if len(self.model_cfg.get("upsample_strides", [])) > nlev:          # base_bev_backbone.py:151-152
+                out = self._train_deblock(nlev, out)
             data_dict["spatial_features_2d"] = _nchw(out)
             return data_dict
         with torch.no_grad():
@@ -430,7 +442,7 @@ class ResNetBEVBackbone(BaseBEVBackbone):
         nlev = len(model_cfg["layer_nums"])
         if len(ups) not in (0, nlev, nlev + 1):
             raise ValueError("upsample_strides: one per level, optionally one more for the final deblock")
-        self.variant = True               # BaseBEVBackbone's blocks[i] / packed deblock variants do not apply; see _train_check
+        self.variant = True               # BaseBEVBackbone's blocks[i] / packed deblock variants do not apply
         _declare(self, resnet_backbone_param_spec(model_cfg, "", self.input_channels))
         if "deblocks" not in self._modules:
             self.add_module("deblocks", _Node())
@@ -477,11 +489,6 @@ class ResNetBEVBackbone(BaseBEVBackbone):
 
     # ---- train mode: resblock.py's BasicBlocks (conv3x3 - BN - ReLU - conv3x3 - BN, 1x1 downsample, add, ReLU; nn.BatchNorm2d defaults)
     #      on train_camera's nodes (the same block BevEncode trains with), BaseBEVBackbone's deblocks
-    def _train_check(self):
-        ups = self.model_cfg.get("upsample_strides", [])
-        if len(ups) > self.num_levels or any(u < 1 for u in ups):
-            raise NotImplementedError("ResNetBEVBackbone training: one up-sampling deblock per level (no down-sampling / final deblock)")
-
     def _train_resnet(self, x):
         from . import train_camera as TC
         P, sd = self._train_state()
@@ -500,7 +507,6 @@ class ResNetBEVBackbone(BaseBEVBackbone):
 
     def _run_deblock(self, i, x):
         if self.training:
-            self._train_check()
             return _nchw(self._train_deblock(i, _nhwc_grad(x)))
         with torch.no_grad():
             return _nchw(self.deblock_nhwc(i, _nhwc(x)))
@@ -510,13 +516,15 @@ class ResNetBEVBackbone(BaseBEVBackbone):
 
     def forward(self, data_dict):
         if self.training:
-            self._train_check()
             feats = self._train_resnet(_nhwc_grad(data_dict["spatial_features"]))
             if self.model_cfg.get("upsample_strides"):
                 feats = [self._train_deblock(i, f) for i, f in enumerate(feats)]
             elif len(feats) > 1 and not all(f.shape[1:3] == feats[0].shape[1:3] for f in feats):
                 raise ValueError("ResNetBEVBackbone without deblocks: the level maps have different resolutions and cannot be concatenated")
-            data_dict["spatial_features_2d"] = _nchw(torch.cat(feats, -1) if len(feats) > 1 else feats[0])
+            out = torch.cat(feats, -1) if len(feats) > 1 else feats[0]
+            if len(self.model_cfg.get("upsample_strides", [])) > self.num_levels:      # base_bev_backbone_resnet.py:127-128
+                out = self._train_deblock(self.num_levels, out)
+            data_dict["spatial_features_2d"] = _nchw(out)
             return data_dict
         with torch.no_grad():
             r = self.runner()

@@ -234,7 +234,6 @@ class Where2comm(_HipModule):
             raise TypeError("Where2comm (MI355X build): `backbone` must be the BaseBEVBackbone / ResNetBEVBackbone of this build")
         with_resnet = hasattr(backbone, "resnet")                  # :312-314: every level from the UNMASKED input, as written
         if with_resnet:
-            backbone._train_check()
             feats = backbone._train_resnet(cur)
         ups = []
         for i in range(self.num_levels):
@@ -248,7 +247,10 @@ class Where2comm(_HipModule):
             ups.append(backbone._train_deblock(i, fused) if backbone.model_cfg.get("upsample_strides") else fused)
         if len(ups) > 1 and not backbone.model_cfg.get("upsample_strides"):
             raise NotImplementedError("multi-scale Where2comm without deblocks needs a single level")
-        return _nchw(torch.cat(ups, -1) if len(ups) > 1 else ups[0]), self._volume(vol, B, r), {}
+        out = torch.cat(ups, -1) if len(ups) > 1 else ups[0]
+        if len(backbone.model_cfg.get("upsample_strides", [])) > self.num_levels:            # where2comm_attn.py:369-370
+            out = backbone._train_deblock(self.num_levels, out)
+        return _nchw(out), self._volume(vol, B, r), {}
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, rm, record_len, pairwise_t_matrix, backbone=None, heads=None):

@@ -1085,11 +1085,15 @@ def w2c_attn_configs():
         "backbone": bb,
         "ms_atten": dict(base, agg_operator={"mode": "ATTEN"}, communication=dict(gauss)),
         "ms_max": dict(base, agg_operator={"mode": "MAX"}, communication={"thre": 0.004}),
+        "ms_atten2": dict(base, layer_nums=[1, 1], num_filters=[64, 128], agg_operator={"mode": "ATTEN"}, communication=dict(gauss)),   # two levels
         "ss_atten": dict(base, multi_scale=False, agg_operator={"mode": "ATTEN", "feature_dim": 256}, communication=dict(gauss)),
         "ss_max": dict(base, multi_scale=False, agg_operator={"mode": "MAX", "feature_dim": 64}),
         # the ResNet backbone variant (where2comm_attn.py:312-317: `backbone.resnet(x)` once, its three maps feed the levels)
         "resnet_backbone": {"layer_nums": [2, 1, 2], "layer_strides": [2, 2, 2], "num_filters": [64, 128, 256],
                             "upsample_strides": [1, 2, 4], "num_upsample_filter": [32, 32, 32]},
+        # base_bev_backbone_resnet.py:57-110: a down-sampling deblock and the final deblock on the concatenation
+        "resnet_backbone_variant": {"layer_nums": [1, 1], "layer_strides": [1, 2], "num_filters": [64, 128],
+                                    "upsample_strides": [0.5, 1, 2], "num_upsample_filter": [32, 32, 0]},
     }
 
 

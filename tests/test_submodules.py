@@ -142,8 +142,9 @@ def test_backbone_downsampling_deblock_and_final_deblock_variant(gold, trunk):
     _close(d["spatial_features_2d"][:, ::2], gold["variant_spatial_features_2d"])
     _close(bb.deblocks[0](bb.blocks[0](sf))[:, ::4], gold["variant_deblock0"])
     assert len(bb.deblocks) == 3
-    with pytest.raises(NotImplementedError):
-        bb.train()({"spatial_features": sf})
+    # train mode is built too (tests/test_where2comm_attn.py's variant_alone case holds the gradients): batch statistics, an autograd graph
+    out = bb.train()({"spatial_features": sf})["spatial_features_2d"]
+    assert out.shape == (3, 64, 32, 32) and out.requires_grad
 
 
 def test_backbone_variant_state_dict_layout():

@@ -281,7 +281,8 @@ TRAIN_GOLD = os.path.join(os.path.dirname(__file__), "golden", "train_w2c_attn.n
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,single", [("ms_atten", False), ("ms_max", False), ("ss_atten", True), ("ms_resnet", False), ("resnet_alone", False)])
+@pytest.mark.parametrize("tag,single", [("ms_atten", False), ("ms_max", False), ("ss_atten", True), ("ms_resnet", False), ("resnet_alone", False),
+                                        ("variant_alone", False), ("resnet_variant_ms", False)])
 def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
     """`Where2comm.train()` (where2comm_attn.py:275-404 under autograd, the reference's BaseBEVBackbone with batch statistics):
     fused map, dL/dx, every backbone parameter's gradient and the BatchNorm buffers of one step against
@@ -289,8 +290,9 @@ def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
     from airv2x_perception_amd.opencood_iface import where2comm_attn as wm
     from airv2x_perception_amd.opencood_iface.submodules import BaseBEVBackbone, ResNetBEVBackbone
     g = np.load(TRAIN_GOLD)
-    resnet, alone = tag in ("ms_resnet", "resnet_alone"), tag == "resnet_alone"
-    c = CFG["ms_atten" if resnet else tag]
+    resnet, alone = tag in ("ms_resnet", "resnet_alone", "resnet_variant_ms"), tag in ("resnet_alone", "variant_alone")
+    variant = tag in ("variant_alone", "resnet_variant_ms")
+    c = CFG["ms_atten2" if tag == "resnet_variant_ms" else "ms_atten" if resnet or variant else tag]
     rl, seed = [int(v) for v in g[f"{tag}_rl"]], int(g[f"{tag}_seed"])
     mod = wm.Where2comm(c)
     mod.load_state_dict(_gauss_sd(c, seed + 500), strict=True)
@@ -303,7 +305,15 @@ def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
     else:
         x = torch.from_numpy(synth.w2c_attn_features(seed, n, 64, H, W))
         rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H // 2, W // 2))
-        if resnet:     # base_bev_backbone_resnet.py + resblock.py in train mode
+        if variant and resnet:   # base_bev_backbone_resnet.py:57-110 under the two-level fusion; level 0 has stride 1, so the confidence map is H x W
+            rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, H, W))
+            bb = ResNetBEVBackbone(CFG["resnet_backbone_variant"], 64)
+            bb.load_state_dict(synth.synthetic_state_dict(synth.resnet_backbone_param_spec(CFG["resnet_backbone_variant"], ""), seed=37), strict=True)
+        elif variant:  # base_bev_backbone.py:87-121: a deblock that DOWN-samples (Conv2d(2, stride 2)) and the final deblock on the concatenation
+            vbc = synth.submodule_configs()["backbone_variant"]
+            bb = BaseBEVBackbone(vbc, 64)
+            bb.load_state_dict(synth.synthetic_state_dict(synth.backbone_param_spec(vbc, 64, ""), seed=35), strict=True)
+        elif resnet:   # base_bev_backbone_resnet.py + resblock.py in train mode
             bb = ResNetBEVBackbone(CFG["resnet_backbone"], 64)
             bb.load_state_dict(synth.synthetic_state_dict(synth.resnet_backbone_param_spec(CFG["resnet_backbone"], ""), seed=33), strict=True)
         else:
@@ -326,7 +336,7 @@ def test_gpu_train_mode_forward_and_gradients_match_the_reference(tag, single):
     if bb is not None:
         got.update({k: p_.grad for k, p_ in bb.named_parameters()})
     keys = [str(k) for k in g[f"{tag}_grad_keys"]]
-    assert len(keys) == (1 if single else 49 if resnet else 28)
+    assert len(keys) == (1 if single else 25 if resnet and variant else 49 if resnet else 22 if variant else 28)
     worst = 0.0
     for k in keys:
         assert got[k] is not None, k

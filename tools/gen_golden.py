@@ -1926,11 +1926,27 @@ def train_w2c_attn_golden(name="train_w2c_attn"):
     rbc = cfg["resnet_backbone"]
     rsd = synth.synthetic_state_dict(synth.resnet_backbone_param_spec(rbc, ""), seed=33)
 
-    def run(tag, rl, seed, dtype, ch=64, hw=(H, W), single=False, resnet=False, alone=False):
+    vbc = synth.submodule_configs()["backbone_variant"]      # base_bev_backbone.py:87-121: a down-sampling deblock + the final deblock
+    vsd = synth.synthetic_state_dict(synth.backbone_param_spec(vbc, 64, ""), seed=35)
+
+    rvc = cfg["resnet_backbone_variant"]
+    rvsd = synth.synthetic_state_dict(synth.resnet_backbone_param_spec(rvc, ""), seed=37)
+
+    def run(tag, rl, seed, dtype, ch=64, hw=(H, W), single=False, resnet=False, alone=False, variant=False, rm_full=False):
         c = cfg[tag]
         mod = Where2comm(c).train()
         gauss(mod, seed + 500)
-        if resnet:
+        if variant:
+            had = hasattr(np, "int")
+            if not had:
+                np.int = int                 # the constructors use `np.int` (base_bev_backbone.py:90), gone from this image's numpy
+            try:
+                bb = ResNetBEVBackbone(rvc, 64) if resnet else BaseBEVBackbone(vbc, 64)
+            finally:
+                if not had:
+                    del np.int
+            bb.load_state_dict(rvsd if resnet else vsd, strict=True)
+        elif resnet:
             bb = ResNetBEVBackbone(rbc, 64)
             bb.load_state_dict(rsd, strict=True)
         else:
@@ -1941,7 +1957,7 @@ def train_w2c_attn_golden(name="train_w2c_attn"):
             mod, bb = mod.double(), bb.double()
         n = sum(rl)
         x = torch.from_numpy(synth.w2c_attn_features(seed, n, ch, hw[0], hw[1], keep=0.6 if single else 0.35)).to(dtype).requires_grad_(True)
-        rmh = (hw[0], hw[1]) if single else (hw[0] // 2, hw[1] // 2)
+        rmh = (hw[0], hw[1]) if single or rm_full else (hw[0] // 2, hw[1] // 2)        # the resolution of level 0
         rm = torch.from_numpy(synth.w2c_attn_psm(seed + 1, n, rmh[0], rmh[1])).to(dtype)
         pw = synth.w2c_attn_pairwise(rl).to(dtype)
         if alone:            # the backbone's own forward (base_bev_backbone_resnet.py:101-128)
@@ -1958,8 +1974,10 @@ def train_w2c_attn_golden(name="train_w2c_attn"):
 
     for tag, rl, seed, kw in (("ms_atten", [3, 2], 61, {}), ("ms_max", [3], 62, {}),
                               ("ss_atten", [2, 2], 63, dict(ch=256, hw=(H // 2, W // 2), single=True)),
-                              ("ms_resnet", [3, 2], 64, dict(resnet=True)), ("resnet_alone", [3], 65, dict(resnet=True, alone=True))):
-        cfg_tag = {"ms_resnet": "ms_atten", "resnet_alone": "ms_atten"}.get(tag, tag)
+                              ("ms_resnet", [3, 2], 64, dict(resnet=True)), ("resnet_alone", [3], 65, dict(resnet=True, alone=True)),
+                              ("variant_alone", [3], 66, dict(variant=True, alone=True)),
+                              ("resnet_variant_ms", [2, 1], 67, dict(variant=True, resnet=True, rm_full=True))):
+        cfg_tag = tag if tag in ("ms_max", "ss_atten") else "ms_atten2" if tag == "resnet_variant_ms" else "ms_atten"
         f32, vol, g32, b32 = run(cfg_tag, rl, seed, torch.float32, **kw)
         f64, vol64, g64, _ = run(cfg_tag, rl, seed, torch.float64, **kw)
         assert vol == vol64, (tag, vol, vol64)
