@@ -261,17 +261,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(const Wgrad3Params 
     }
 }
 
-// dw[co][ci][tap] = sum over chunks (ascending) of part[chunk][tap][co][ci]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nchunks, int taps, int cout, int cin,
+// dw[co][ci][tap] = sum over chunks (ascending) of part[chunk][tap][co][ci].  The launch reads nchunks x taps x cout x cin floats (50 MB for
+// every layer of the three-tap kernel: one slab per workgroup) and is HBM / L2 bound: four channels per lane as one 16-byte load, eight
+// chunks' loads in flight; the additions stay in ascending chunk order (bit-identical to a scalar loop).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ part, int nchunks, int taps, int cout, int cin,
                                                            float* __restrict__ dw) {
-    const size_t n = (size_t)taps * cout * cin;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * n + i];
-        const int ci = (int)(i % cin);
-        const size_t r = i / cin;
+    const size_t n4 = (size_t)taps * cout * cin / 4;
+    const int cin4 = cin / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* p = part + i;
+        int c = 0;
+        for (; c + 8 <= nchunks; c += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(c + j) * n4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+        }
+        for (; c < nchunks; ++c) {
+            const float4 v = p[(size_t)c * n4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int ci = (int)(i % cin4) * 4;
+        const size_t r = i / cin4;
         const int co = (int)(r % cout), tap = (int)(r / cout);
-        dw[((size_t)co * cin + ci) * taps + tap] = s;
+        float* o = dw + ((size_t)co * cin + ci) * taps + tap;
+        o[0] = s.x; o[taps] = s.y; o[2 * (size_t)taps] = s.z; o[3 * (size_t)taps] = s.w;
     }
 }
 
@@ -290,6 +306,30 @@ __global__ __launch_bounds__(256) void act_backward_kernel(const float4* __restr
             g.x *= scale[c]; g.y *= scale[c + 1]; g.z *= scale[c + 2]; g.w *= scale[c + 3];
         }
         dz[i] = g;
+    }
+}
+
+// wp[tap][ci / 4][co (padded to coutp)][ci % 4] of a convolution with `cout` outputs and `cin` inputs, from the nn.Conv2d parameter:
+// flipped == 0: w is (cout, cin, k, k); flipped == 1: w is (cin, cout, k, k) and the taps are rotated by 180 degrees -- the data
+// gradient's weights.  One float4 of the packing per lane; the weights change every optimiser step, so this runs per layer and step.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int coutp, int ks, int flipped,
+                                                          float4* __restrict__ wp) {
+    const int taps = ks * ks, q4 = cin / 4;
+    const size_t n = (size_t)taps * q4 * coutp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % coutp);
+        const size_t r = i / coutp;
+        const int q = (int)(r % q4), t = (int)(r / q4);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (co < cout) {
+            const int ts = flipped ? taps - 1 - t : t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = 4 * q + e;
+                v[e] = flipped ? w[((size_t)ci * cout + co) * taps + ts] : w[((size_t)co * cin + ci) * taps + ts];
+            }
+        }
+        wp[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -330,6 +370,11 @@ static int wgrad_chunk(const av2x_conv_desc* d, long long M) {
     return (int)chunk;
 }
 
+static unsigned wgrad_reduce_blocks(int taps, const av2x_conv_desc* d) {
+    const size_t b = ((size_t)taps * d->cout * d->cin / 4 + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+}
+
 extern "C" uint64_t av2x_conv2d_wgrad_workspace_bytes(const av2x_conv_desc* d) {
     if (!d) return 0;
     if (wgrad3_applies(d)) {
@@ -354,6 +399,7 @@ extern "C" int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const 
         return av2x::fail("av2x_conv2d_wgrad: output dims inconsistent with input/stride/pad");
     const long long M = (long long)d->n * d->ho * d->wo;
     if (M <= 0) return av2x::fail("av2x_conv2d_wgrad: empty tensor");
+    if (reinterpret_cast<uintptr_t>(workspace) % 16) return av2x::fail("av2x_conv2d_wgrad: the workspace must be 16-byte aligned");
     const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->in_ctot * 4ull;
     const unsigned long long yb = (unsigned long long)M * d->out_ctot * 4ull;
     if (xb >= (1ull << 31) || yb >= (1ull << 31)) return av2x::fail("av2x_conv2d_wgrad: tensor exceeds the 2 GiB buffer-descriptor window");
@@ -372,7 +418,8 @@ extern "C" int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const 
         lim3.ensure(reinterpret_cast<const void*>(&conv_wgrad3_kernel), lds);
         hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(tiles * 3 * q.nchunks), dim3(256), lds, st3, q);
         if (int e = av2x::check_launch("conv_wgrad3_kernel")) return e;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(512), dim3(256), 0, st3, q.part, q.nchunks, 9, d->cout, d->cin, dw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(9, d)), dim3(256), 0, st3, reinterpret_cast<const float4*>(q.part), q.nchunks, 9,
+                           d->cout, d->cin, dw);
         return av2x::check_launch("wgrad_reduce_kernel");
     }
     WgradParams p;
@@ -398,8 +445,22 @@ extern "C" int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const 
         hipLaunchKernelGGL(conv_wgrad_kernel<64>, dim3(taps * p.nchunks), dim3(256), lds, st, p);
     }
     if (int e = av2x::check_launch("conv_wgrad_kernel")) return e;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(512), dim3(256), 0, st, p.part, p.nchunks, taps, d->cout, d->cin, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(taps, d)), dim3(256), 0, st, reinterpret_cast<const float4*>(p.part), p.nchunks, taps,
+                       d->cout, d->cin, dw);
     return av2x::check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" int av2x_pack_conv_weight(const float* w, int32_t cout, int32_t cin, int32_t ks, int32_t flipped, float* wp, av2x_stream_t stream) {
+    if (!w || !wp) return av2x::fail("av2x_pack_conv_weight: null argument");
+    if (cout <= 0 || cin <= 0 || cin % 4 || ks <= 0 || ks > 7) return av2x::fail("av2x_pack_conv_weight: bad sizes (cin %% 4 == 0, ks <= 7)");
+    if (reinterpret_cast<uintptr_t>(wp) % 16) return av2x::fail("av2x_pack_conv_weight: wp must be 16-byte aligned");
+    const int coutp = (cout + 31) / 32 * 32;
+    const size_t n = (size_t)ks * ks * (cin / 4) * coutp;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), w, cout, cin, coutp, ks, flipped != 0,
+                       reinterpret_cast<float4*>(wp));
+    return av2x::check_launch("pack_weight_kernel");
 }
 
 extern "C" int av2x_act_backward(const float* y, const float* dy, const float* scale, int64_t rows, int32_t c, int32_t act,

@@ -38,19 +38,22 @@ def _check_dev(x):
 
 
 # ------------------------------------------------------------------------------------------------ weight packing (device side)
-def pack_conv_weight_dev(w):
-    """(Cout, Cin, k, k) -> (k*k, Cin/4, CoutP, 4), CoutP = Cout rounded up to 32 -- packing.pack_conv_weight without the host
-    round trip (the weights change every optimiser step)."""
+def pack_conv_weight_dev(w, flipped=False):
+    """(Cout, Cin, k, k) -> (k*k, Cin/4, CoutP, 4), CoutP = Cout rounded up to 32 -- packing.pack_conv_weight on the device, one launch
+    (the weights change every optimiser step).  ``flipped``: the packing of ``w.flip(2, 3).transpose(0, 1)`` -- the data gradient's
+    weights -- read straight from the parameter."""
     w = w.detach()
-    cout, cin, kh, kw = w.shape
-    if cin % 4:
-        raise ValueError("cin must be a multiple of 4")
+    if w.dtype != torch.float32 or w.device.type != "cuda":
+        raise RuntimeError("pack_conv_weight_dev: fp32 HIP tensors only (no CPU path exists)")
+    if not w.is_contiguous():
+        w = w.contiguous()
+    cout, cin, kh, kw = (w.shape[1], w.shape[0], w.shape[2], w.shape[3]) if flipped else w.shape
+    if cin % 4 or kh != kw:
+        raise ValueError("square kernels, cin a multiple of 4")
     coutp = (cout + 31) // 32 * 32
-    t = w.permute(2, 3, 1, 0).reshape(kh * kw, cin // 4, 4, cout).permute(0, 1, 3, 2)
-    if coutp == cout:
-        return t.contiguous(), coutp
-    out = torch.zeros(kh * kw, cin // 4, coutp, 4, dtype=torch.float32, device=w.device)
-    out[:, :, :cout, :] = t
+    r = _runner(w.device)
+    out = torch.empty(kh * kw, cin // 4, coutp, 4, dtype=torch.float32, device=w.device)
+    _lib.check(r.lib.av2x_pack_conv_weight(_P(w), cout, cin, kh, 1 if flipped else 0, _P(out), r.stream()), "av2x_pack_conv_weight")
     return out, coutp
 
 
@@ -94,9 +97,8 @@ def _packed(r, weight, flipped=False, owner=None):
     stamp = (weight._version, weight.data_ptr(), weight.device)
     if ent is not None and ent[0] == stamp and ent[1]() is own:
         return ent[2], ent[3], ent[4], ent
-    src = weight.detach().flip(2, 3).transpose(0, 1) if flipped else weight
-    wp, coutp = pack_conv_weight_dev(src)
-    cout, cin, ks = src.shape[0], src.shape[1], src.shape[2]
+    wp, coutp = pack_conv_weight_dev(weight, flipped)
+    cout, cin, ks = (weight.shape[1], weight.shape[0], weight.shape[2]) if flipped else (weight.shape[0], weight.shape[1], weight.shape[2])
     u = None
     if r.winograd and ks == 3 and cin >= 64 and cin % 8 == 0 and cout % 64 == 0 and cout == coutp:   # engine.wino_rule's weight side
         u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=weight.device)

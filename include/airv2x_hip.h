@@ -315,11 +315,15 @@ int av2x_postprocess_devt(const float* psm, const float* rm, const float* obj, c
  *   av2x_channel_sum    d shift[c] = sum over pixels of dy * act'(y)    (rows x c, two-stage deterministic sum)
  *   av2x_conv2d_wgrad   dw (cout, cin, ks, ks) = correlation of x with dz (desc as for the forward launch: out_ctot /
  *                       out_coff describe dz's channel stride / offset); fp32 MFMA, pixel axis chunked, partial slabs
- *                       in `workspace` (av2x_conv2d_wgrad_workspace_bytes) summed in a fixed order -- bit-reproducible
+ *                       in `workspace` (av2x_conv2d_wgrad_workspace_bytes; 16-byte aligned) summed in a fixed order -- bit-reproducible
  *   data gradient       av2x_conv2d of dz with the 180-degree-rotated, channel-transposed weights (stride 2: on the
  *                       zero-upsampled dz) -- opencood_iface/autograd.py
  * ------------------------------------------------------------------------------------ */
 uint64_t av2x_conv2d_wgrad_workspace_bytes(const av2x_conv_desc* d);
+/* the kernels' weight packing (ks*ks, cin/4, coutp = cout rounded up to 32, 4) of an nn.Conv2d parameter, on the device (the weights change
+ * every optimiser step): flipped 0: w is (cout, cin, ks, ks); flipped 1: w is (cin, cout, ks, ks) and the taps are rotated by 180 degrees --
+ * the weights of the data gradient (autograd of F.conv2d, base_bev_backbone.py:41-60).  wp: 16-byte aligned, padded columns are zeroed. */
+int av2x_pack_conv_weight(const float* w, int32_t cout, int32_t cin, int32_t ks, int32_t flipped, float* wp, av2x_stream_t stream);
 int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const float* dz, void* workspace, float* dw,
                       av2x_stream_t stream);
 int av2x_act_backward(const float* y, const float* dy, const float* scale, int64_t rows, int32_t c, int32_t act,
