@@ -173,6 +173,62 @@ __global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* 
     }
 }
 
+// moments_stage2<0> + bn_finalize_kernel in one launch (av2x_bn_train_forward): the same two-level fp64 sums, mean / variance rounded to
+// fp32 and the fold computed FROM the rounded values -- bit-identical to the two kernels run one after the other.
+__global__ __launch_bounds__(256) void moments_finalize_kernel(const double* __restrict__ part, int nslabs, int c, double n,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               float momentum, int times, float* __restrict__ stats5,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               long long* __restrict__ nbt) {
+    __shared__ double red[2][128][2];
+    __shared__ double red2[2][16][2];
+    const int j = threadIdx.x & 1, sl = threadIdx.x >> 1;
+    const int ch = blockIdx.x * 2 + j;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        for (int k = sl; k < nslabs; k += 128) {
+            a += part[(size_t)k * 2 * c + ch];
+            b += part[(size_t)k * 2 * c + c + ch];
+        }
+    }
+    red[0][sl][j] = a;
+    red[1][sl][j] = b;
+    __syncthreads();
+    if (sl < 16) {
+        a = 0.0; b = 0.0;
+        for (int k = 0; k < 8; ++k) { a += red[0][sl * 8 + k][j]; b += red[1][sl * 8 + k][j]; }
+        red2[0][sl][j] = a;
+        red2[1][sl][j] = b;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += times;
+    if (sl == 0 && ch < c) {
+        a = 0.0; b = 0.0;
+        for (int k = 0; k < 16; ++k) { a += red2[0][k][j]; b += red2[1][k][j]; }
+        const double md = a / n;
+        double vd = b / n - md * md;
+        if (vd < 0.0) vd = 0.0;
+        const float m = (float)md, v = (float)vd;
+        const float r = 1.0f / sqrtf(v + eps);
+        const float sc = gamma[ch] * r;
+        stats5[ch] = m;
+        stats5[c + ch] = v;
+        stats5[2 * (size_t)c + ch] = r;
+        stats5[3 * (size_t)c + ch] = sc;
+        stats5[4 * (size_t)c + ch] = beta[ch] - m * sc;
+        if (running_mean && running_var) {
+            const float unb = (float)((double)v * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+            float rm = running_mean[ch], rv = running_var[ch];
+            for (int t = 0; t < times; ++t) {
+                rm = rm * (1.0f - momentum) + momentum * m;
+                rv = rv * (1.0f - momentum) + momentum * unb;
+            }
+            running_mean[ch] = rm;
+            running_var[ch] = rv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void affine_act_kernel(const float4* __restrict__ z, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, size_t n4, int c4, int act,
                                                          float4* __restrict__ y) {
@@ -496,16 +552,22 @@ extern "C" int av2x_affine_act(const float* z, int64_t rows, int32_t c, const fl
     return av2x::check_launch("affine_act_kernel");
 }
 
-// stats + finalize + normalise in ONE call (four launches): what a train-mode BatchNorm forward is made of
+// stats + finalize + normalise in ONE call (three launches): what a train-mode BatchNorm forward is made of
 extern "C" int av2x_bn_train_forward(const float* z, int64_t rows, int32_t c, const float* gamma, const float* beta, float eps,
                                      float momentum, int32_t times, int32_t act, void* workspace, float* stats5, float* y,
                                      float* running_mean, float* running_var, int64_t* num_batches_tracked, av2x_stream_t stream) {
-    if (!stats5) return av2x::fail("av2x_bn_train_forward: null argument");
-    float* mean = stats5, *var = stats5 + c, *rstd = stats5 + 2 * (size_t)c, *scale = stats5 + 3 * (size_t)c, *shift = stats5 + 4 * (size_t)c;
-    if (int e = av2x_bn_stats(z, rows, c, workspace, mean, var, stream)) return e;
-    if (int e = av2x_bn_finalize(mean, var, gamma, beta, c, eps, rows, momentum, times, rstd, scale, shift, running_mean, running_var,
-                                 num_batches_tracked, stream))
-        return e;
+    if (!stats5 || !z || !workspace || !gamma || !beta) return av2x::fail("av2x_bn_train_forward: null argument");
+    if (rows <= 0 || c <= 0 || times < 0) return av2x::fail("av2x_bn_train_forward: bad sizes");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return av2x::fail("av2x_bn_train_forward: running_mean and running_var go together");
+    float* scale = stats5 + 3 * (size_t)c, *shift = stats5 + 4 * (size_t)c;
+    const int slabs = (int)((rows + kSlabRows - 1) / kSlabRows);
+    hipStream_t st = av2x::as_stream(stream);
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(moments_stage1<0>, dim3(slabs), dim3(256), 0, st, z, (const float*)nullptr, (size_t)rows, c, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, part);
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3((c + 1) / 2), dim3(256), 0, st, part, slabs, c, (double)rows, gamma, beta, eps, momentum, times,
+                       stats5, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
+    if (int e = av2x::check_launch("bn_train_forward statistics")) return e;
     return av2x_affine_act(z, rows, c, scale, shift, act, y, stream);
 }
 

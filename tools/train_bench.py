@@ -114,6 +114,17 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
            "ms_forward": round(t_f / k, 3), "ms_loss_backward": round(t_b / k, 3), "ms_optimizer": round(t_o / k, 3),
            "steps_per_s": round(1e3 * k / (t_f + t_b + t_o), 3), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)], "dtype": "bf16 operands (autocast), fp32 master weights" if amp else "f32", "data": "synthetic"}
+    # ---- the same K steps WITHOUT a host synchronisation per step (the loss dictionary is read back lazily, loss.py; a loop that logs every
+    # N-th step): the host issues step i + 1 while the GPU finishes step i -- wall clock over K steps, a synchronise on both sides
+    if not amp:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            opt.zero_grad(set_to_none=True)
+            crit(model(dd), tgt).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        res["ms_per_step_no_host_sync"] = round(1e3 * (time.perf_counter() - t0) / a.steps, 3)
     # ---- roofline of the step's MFMA kernels: a second pass with an event pair around every convolution launch (forward and data
     # gradients go through the engine's launcher: its profile hook; weight gradients: train_ops' hook), weight gradients on the
     # main stream so that the pairs do not overlap
