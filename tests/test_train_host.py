@@ -10,12 +10,14 @@ from airv2x_perception_amd.opencood_iface import train_ops as T
 from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, pack_deconv_weight
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (14, 256, 1, 1), (30, 256, 1, 1), (256, 384, 1, 1), (128, 64, 3, 3)])
-def test_device_side_conv_packing_equals_the_host_packing(shape):
-    w = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
-    a, ca = T.pack_conv_weight_dev(w)
+def test_conv_weight_packing_has_no_cpu_path():
+    """The packing of a convolution weight is a HIP launch (av2x_pack_conv_weight; tests/test_gpu_train.py checks it against
+    packing.pack_conv_weight bit for bit): a CPU tensor fails loudly instead of falling back to torch ops."""
+    w = torch.randn(64, 64, 3, 3, generator=torch.Generator().manual_seed(1))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        T.pack_conv_weight_dev(w)
     b, cb = pack_conv_weight(w)
-    assert ca == cb and a.shape == b.shape and torch.equal(a.contiguous(), b)
+    assert cb == 64 and b.shape == (9, 16, 64, 4)
 
 
 @pytest.mark.parametrize("shape", [(64, 128, 1, 1), (128, 128, 2, 2), (256, 128, 4, 4)])
