@@ -11,6 +11,8 @@
 //                               per table entry and wave): integer sums, bit-reproducible whatever the order
 //   scale_broadcast_kernel      backward of the mean over the agent axis (mlp_head's Reduce, :270)
 //   dropout_kernel              x * mask * scale (forward and backward of nn.Dropout with a caller-supplied Bernoulli mask)
+#include <cstdlib>
+
 #include "av2x_common.hpp"
 
 namespace {
@@ -311,6 +313,243 @@ __global__ __launch_bounds__(128) void fax_attention_backward_kernel(const FaxBw
     }
 }
 
+// ---------------------------------------------------------------- ws = 4, one WAVE per (window, head), everything in registers
+// The backward of fax_attention_wave_kernel (transformer.hip) in the same register tiling: v_mfma_f32_16x16x4_f32 tiles = one agent's 16
+// tokens; lane (t = lane & 15, h = lane >> 4) holds X[token t][d = 4h .. 4h+3, 16+4h .. 16+4h+3] of K, V, Q, dO -- one register set that
+// serves as the A operand (row = t) and as the B operand (column = t) alike.  Per query agent qt:
+//   S^T[key 4h+r][query t] = K (Q scale)^T + bias, softmax over (kt, r) and the lanes xor 16 / 32       -> P^T     (as the forward)
+//   dP^T = V dO^T, D = dO . O,  dS^T = P^T (dP^T - D)   -> the bias-table gradient (2^-32 fixed point, LDS atomics: integer sums)
+//   dQ = dS K: dS^T in the accumulator layout IS the A operand (row = query t, k = key (h, r)); B = K rows of token (h, r)
+//   the same products with the operands swapped give S, dP with row = query 4h+r, column = key t (statistics of query 4h+r by ds_bpermute):
+//   dK += dS^T(A) Q(B), dV += P^T(A) dO(B) accumulate over qt in registers.
+// Nothing is staged in LDS but the bias column and its gradient, which a wave keeps across all the windows it walks (persistent grid): one
+// 64-bit global atomic per table entry, head and WAVE at the end instead of per window.  The 128-thread kernel above (a lane per token,
+// K / V / Q / dO broadcast from LDS, one wave per SIMD) took 12.4 ms per launch at the BASELINE grid; this one is matrix-core work.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+template <int NV>
+__global__ __launch_bounds__(256) void fax_attention_backward_wave_kernel(const FaxBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane & 15, h = lane >> 4;
+    const int X = p.H / 4, Y = p.W / 4, nwin = X * Y;
+    const int C = p.heads * DH, C3 = 3 * C;
+    const int L = p.L, nv = p.n_valid;
+    const int tab_n = (2 * L - 1) * 49, tab_s = (tab_n + 63) & ~63;
+    const int hpw = (p.heads + 3) >> 2;                     // heads per wave
+    float* wl = lds + (size_t)wave * hpw * tab_s * 3;       // per head: bias column [tab_s] | its gradient [tab_s] x 64 bit
+    for (int k = 0; k < hpw; ++k) {
+        const int head = wave + 4 * k;
+        if (head < p.heads) {
+            float* tab = wl + (size_t)k * tab_s * 3;
+            unsigned long long* dtab = reinterpret_cast<unsigned long long*>(tab + tab_s);
+            for (int i = lane; i < tab_s; i += 64) { tab[i] = i < tab_n ? p.table[(size_t)i * p.heads + head] : 0.f; dtab[i] = 0ull; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int w1q = t >> 2, w2q = t & 3;
+    const size_t HW = (size_t)p.H * p.W;
+    const float kLog2e = 1.4426950408889634f;
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const int wx = win / Y, wy = win - wx * Y;
+        const int ph_q = p.grid ? (w1q * X + wx) : (wx * 4 + w1q), pw_q = p.grid ? (w2q * Y + wy) : (wy * 4 + w2q);
+        const size_t pix_t = (size_t)ph_q * p.W + pw_q;      // token t = (w1q, w2q): A rows / B columns
+        const int ph_h = p.grid ? (h * X + wx) : (wx * 4 + h);
+        size_t pix_hr[4];                                     // token (w1 = h, w2 = r): B rows of the second products, output rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pix_hr[r] = (size_t)ph_h * p.W + (p.grid ? (r * Y + wy) : (wy * 4 + r));
+        for (int k = 0; k < hpw; ++k) {
+            const int head = wave + 4 * k;
+            if (head >= p.heads) break;
+            const float* tab = wl + (size_t)k * tab_s * 3;
+            unsigned long long* dtab = reinterpret_cast<unsigned long long*>(const_cast<float*>(tab) + tab_s);
+            const float* base = p.qkv + head * DH;
+            f32x4w kf[NV][2], vf[NV][2], dk[NV][2], dv[NV][2];
+#pragma unroll
+            for (int kt = 0; kt < NV; ++kt) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    dk[kt][c] = (f32x4w){0.f, 0.f, 0.f, 0.f};
+                    dv[kt][c] = (f32x4w){0.f, 0.f, 0.f, 0.f};
+                }
+                if (kt < nv) {
+                    const float* kr = base + ((size_t)kt * HW + pix_t) * C3 + C + 4 * h;
+                    kf[kt][0] = *reinterpret_cast<const f32x4w*>(kr);
+                    kf[kt][1] = *reinterpret_cast<const f32x4w*>(kr + 16);
+                    vf[kt][0] = *reinterpret_cast<const f32x4w*>(kr + C);
+                    vf[kt][1] = *reinterpret_cast<const f32x4w*>(kr + C + 16);
+                }
+            }
+            for (int qt = 0; qt < L; ++qt) {
+                const size_t row_t = (size_t)qt * HW + pix_t;
+                const float* qr = base + row_t * C3 + 4 * h;
+                f32x4w q[2] = {*reinterpret_cast<const f32x4w*>(qr), *reinterpret_cast<const f32x4w*>(qr + 16)};
+                q[0] *= p.scale; q[1] *= p.scale;
+                const float* gr = p.dout + row_t * C + head * DH + 4 * h;
+                const f32x4w g[2] = {*reinterpret_cast<const f32x4w*>(gr), *reinterpret_cast<const f32x4w*>(gr + 16)};
+                float Dq;
+                {
+                    const float* orow = p.out + row_t * C + head * DH + 4 * h;
+                    const f32x4w o0 = *reinterpret_cast<const f32x4w*>(orow), o1 = *reinterpret_cast<const f32x4w*>(orow + 16);
+                    float a = g[0].x * o0.x;
+                    a = fmaf(g[0].y, o0.y, a); a = fmaf(g[0].z, o0.z, a); a = fmaf(g[0].w, o0.w, a);
+                    a = fmaf(g[1].x, o1.x, a); a = fmaf(g[1].y, o1.y, a); a = fmaf(g[1].z, o1.z, a); a = fmaf(g[1].w, o1.w, a);
+                    a += __shfl_xor(a, 16);
+                    a += __shfl_xor(a, 32);
+                    Dq = a;                                  // D of query t, in its four h lanes
+                }
+                // ---- S^T, P^T (row = key 4h + r, column = query t): exactly the forward
+                const int cq = ((qt + L - 1) * 7 + (w1q - h + 3)) * 7 + (w2q + 3);
+                f32x4w st[NV];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NV; ++kt) {
+                    if (kt < nv) {
+                        f32x4w a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][c].x, q[c].x, a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][c].y, q[c].y, a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][c].z, q[c].z, a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][c].w, q[c].w, a, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            a[r] += tab[cq - kt * 49 - r];
+                            m = fmaxf(m, a[r]);
+                        }
+                        st[kt] = a;
+                    }
+                }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const float mb = m * kLog2e;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NV; ++kt) {
+                    if (kt < nv) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][r], kLog2e, -mb));
+                            st[kt][r] = e;
+                            sum += e;
+                        }
+                    }
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+                // ---- dP^T = V dO^T, dS^T = P^T (dP^T - D): bias-table gradient, dQ = dS K
+                f32x4w dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < NV; ++kt) {
+                    if (kt < nv) {
+                        f32x4w a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][c].x, g[c].x, a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][c].y, g[c].y, a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][c].z, g[c].z, a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][c].w, g[c].w, a, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float ds = st[kt][r] * inv * (a[r] - Dq);
+                            if (ds != 0.f) atomicAdd(dtab + (cq - kt * 49 - r), (unsigned long long)__float2ll_rn(ds * kFixF));
+                            const float* kb = base + ((size_t)kt * HW + pix_hr[r]) * C3 + C + t;     // K of token (h, r): d = t, t + 16
+                            dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kb[0], dq0, 0, 0, 0);
+                            dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kb[16], dq1, 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                // dq rows = query 4h + r = token (h, r), columns d = t, t + 16
+                    float* dst = p.dqkv + ((size_t)qt * HW + pix_hr[r]) * C3 + head * DH + t;
+                    dst[0] = dq0[r] * p.scale;
+                    dst[16] = dq1[r] * p.scale;
+                }
+                // ---- the other orientation (row = query 4h + r, column = key t): dK += dS^T Q, dV += P^T dO
+                float m2[4], inv2[4], D2[4], qb[4][2], gb[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m2[r] = __shfl(mb, 4 * h + r);
+                    inv2[r] = __shfl(inv, 4 * h + r);
+                    D2[r] = __shfl(Dq, 4 * h + r);
+                    const size_t row = (size_t)qt * HW + pix_hr[r];
+                    const float* qq = base + row * C3 + t;
+                    qb[r][0] = qq[0] * p.scale;
+                    qb[r][1] = qq[16] * p.scale;
+                    const float* gg = p.dout + row * C + head * DH + t;
+                    gb[r][0] = gg[0];
+                    gb[r][1] = gg[16];
+                }
+                const int c2 = ((qt + L - 1) * 7 + (h - w1q + 3)) * 7 + (3 - w2q);
+#pragma unroll
+                for (int kt = 0; kt < NV; ++kt) {
+                    if (kt < nv) {
+                        f32x4w s2 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].x, kf[kt][c].x, s2, 0, 0, 0);
+                            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].y, kf[kt][c].y, s2, 0, 0, 0);
+                            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].z, kf[kt][c].z, s2, 0, 0, 0);
+                            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].w, kf[kt][c].w, s2, 0, 0, 0);
+                            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].x, vf[kt][c].x, d2, 0, 0, 0);
+                            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].y, vf[kt][c].y, d2, 0, 0, 0);
+                            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].z, vf[kt][c].z, d2, 0, 0, 0);
+                            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].w, vf[kt][c].w, d2, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sv = s2[r] + tab[c2 - kt * 49 + r];
+                            const float pr = __builtin_amdgcn_exp2f(fmaf(sv, kLog2e, -m2[r])) * inv2[r];
+                            const float ds = pr * (d2[r] - D2[r]);
+                            dk[kt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, qb[r][0], dk[kt][0], 0, 0, 0);
+                            dk[kt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, qb[r][1], dk[kt][1], 0, 0, 0);
+                            dv[kt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, gb[r][0], dv[kt][0], 0, 0, 0);
+                            dv[kt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, gb[r][1], dv[kt][1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // ---- dk, dv rows = key 4h + r = token (h, r) of agent kt; padded agents are never keys (:103-108): zeros
+#pragma unroll
+            for (int kt = 0; kt < NV; ++kt) {
+                if (kt < nv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* dst = p.dqkv + ((size_t)kt * HW + pix_hr[r]) * C3 + head * DH + t;
+                        dst[C] = dk[kt][0][r];
+                        dst[C + 16] = dk[kt][1][r];
+                        dst[2 * C] = dv[kt][0][r];
+                        dst[2 * C + 16] = dv[kt][1][r];
+                    }
+                }
+            }
+            for (int kt = nv; kt < L; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* dst = p.dqkv + ((size_t)kt * HW + pix_hr[r]) * C3 + head * DH + t;
+                    dst[C] = 0.f; dst[C + 16] = 0.f; dst[2 * C] = 0.f; dst[2 * C + 16] = 0.f;
+                }
+            }
+        }
+    }
+    // ---- this wave's share of the bias-table gradient into the global fixed-point table
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int k = 0; k < hpw; ++k) {
+        const int head = wave + 4 * k;
+        if (head >= p.heads) break;
+        const unsigned long long* dtab = reinterpret_cast<const unsigned long long*>(wl + (size_t)k * tab_s * 3 + tab_s);
+        for (int i = lane; i < tab_n; i += 64) {
+            const unsigned long long v = dtab[i];
+            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(p.dtable) + (size_t)i * p.heads + head, v);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (float)((double)acc[i] * (1.0 / 4294967296.0));
@@ -383,7 +622,6 @@ extern "C" int av2x_fax_attention_backward(const float* qkv, const float* bias_t
     const int tab_n = (2 * n_agents_padded - 1) * (2 * window - 1) * (2 * window - 1);
     const int tab_p = (tab_n + 3) & ~3;
     const size_t lds = 2 * ((size_t)4 * T * DH + 3 * T + tab_p + 2 * (size_t)tab_p) * sizeof(float);
-    if (lds > 160 * 1024) return av2x::fail("av2x_fax_attention_backward: %d tokens per window need %zu bytes of LDS (max 160 KB)", T, lds);
     FaxBwdParams p;
     p.qkv = qkv; p.table = bias_table; p.out = out; p.dout = dout; p.dqkv = dqkv; p.dtable = reinterpret_cast<long long*>(workspace);
     p.L = n_agents_padded; p.n_valid = n_valid; p.H = h; p.W = w; p.ws = window; p.heads = heads; p.grid = grid_partition & 1;
@@ -391,9 +629,26 @@ extern "C" int av2x_fax_attention_backward(const float* qkv, const float* bias_t
     hipStream_t st = av2x::as_stream(stream);
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)tab_n * heads * 8ull, st);
     if (e != hipSuccess) return av2x::fail("av2x_fax_attention_backward: memset: %s", hipGetErrorString(e));
-    static av2x::LdsLimit lim;
-    lim.ensure(reinterpret_cast<const void*>(&fax_attention_backward_kernel), lds);
-    hipLaunchKernelGGL(fax_attention_backward_kernel, dim3((h / window) * (w / window)), dim3(128), lds, st, p);
+    static const bool no_wave = [] { const char* e = getenv("AV2X_FAX_BWD_NO_WAVE"); return e && e[0] == '1'; }();
+    const int tab_s = (tab_n + 63) & ~63;
+    const size_t lds_w = (size_t)4 * ((heads + 3) / 4) * tab_s * 3 * sizeof(float);
+    if (window == 4 && n_valid <= 8 && lds_w <= 160 * 1024 && !no_wave) {      // the register-tile kernel: one wave per (window, head)
+        static av2x::LdsLimit lw4, lw8;
+        const int nwin = (h / 4) * (w / 4);
+        const dim3 grid(nwin < 512 ? nwin : 512);
+        if (n_valid <= 4) {
+            lw4.ensure(reinterpret_cast<const void*>(&fax_attention_backward_wave_kernel<4>), lds_w);
+            hipLaunchKernelGGL(fax_attention_backward_wave_kernel<4>, grid, dim3(256), lds_w, st, p);
+        } else {
+            lw8.ensure(reinterpret_cast<const void*>(&fax_attention_backward_wave_kernel<8>), lds_w);
+            hipLaunchKernelGGL(fax_attention_backward_wave_kernel<8>, grid, dim3(256), lds_w, st, p);
+        }
+    } else {
+        if (lds > 160 * 1024) return av2x::fail("av2x_fax_attention_backward: %d tokens per window need %zu bytes of LDS (max 160 KB)", T, lds);
+        static av2x::LdsLimit lim;
+        lim.ensure(reinterpret_cast<const void*>(&fax_attention_backward_kernel), lds);
+        hipLaunchKernelGGL(fax_attention_backward_kernel, dim3((h / window) * (w / window)), dim3(128), lds, st, p);
+    }
     hipLaunchKernelGGL(fixed_to_float_kernel, dim3((tab_n * heads + 255) / 256), dim3(256), 0, st, reinterpret_cast<const long long*>(workspace),
                        dbias_table, tab_n * heads);
     return av2x::check_launch("fax_attention_backward_kernel");
