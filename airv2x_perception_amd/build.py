@@ -25,7 +25,7 @@ _SCALAR_F32 = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
 # lint_isa() below rejects the pattern in EVERY kernel of the library at build time.
 _NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {"conv_x3p.hip": ([f"-D{os.environ['AV2X_X3P_ABLATE']}"] if os.environ.get("AV2X_X3P_ABLATE") else []), "conv_wino_x3.hip": _SCALAR_F32, "conv_wino4_x3.hip": _SCALAR_F32,
-               **{f: _NO_PACKED_F32 for f in ("transformer.hip", "postproc.hip", "train.hip", "loss.hip", "pillar.hip", "lss.hip", "camera.hip", "train_fusion.hip",
+               **{f: _NO_PACKED_F32 for f in ("transformer.hip", "postproc.hip", "train.hip", "loss.hip", "pillar.hip", "lss.hip", "camera.hip", "train_fusion.hip", "train_v2xvit.hip",
                                               "voxelize.hip")}}
 
 

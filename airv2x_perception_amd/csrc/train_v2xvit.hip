@@ -9,7 +9,9 @@
 //                                   pass kv: dk, dv of the token as a key
 //   split_sums_kernel               sum over pixels of dout * s_r per (agent, branch, channel) (gradient of the radix weights)
 //   split_backward_kernel           ds_r = a_r * dout + dgap / hw
-//   warp_affine_backward_kernel     adjoint of the bilinear sampling of warp_affine (:337-381): scattered with 2^-32 fixed-point atomics
+//   warp_affine_backward_gather_kernel   adjoint of the bilinear sampling of warp_affine (:337-381) as a GATHER over the few output pixels whose
+//                                   footprint holds the source pixel (the warp is affine: their bounding box follows from theta); degenerate
+//                                   thetas fall back, per image, to warp_affine_backward_kernel: scattered with 2^-32 fixed-point atomics
 #include "av2x_common.hpp"
 
 namespace {
@@ -261,6 +263,98 @@ __device__ __forceinline__ float lin_m1_1(int i, int n) {     // as v2xvit.hip
     return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
 }
 
+// The warp is affine in the pixel indices: (ix, iy)(i, j) = (Ax j + Bx i + Cx, Ay j + By i + Cy).  A source pixel (sy, sx) receives from the
+// output pixels with |ix - sx| < 1 and |iy - sy| < 1: a parallelogram around M^-1 (s - C) whose bounding box has half-widths
+// (|By| + |Bx|) / |det| columns and (|Ay| + |Ax|) / |det| rows.  `small`: that box (with a safety margin) holds at most 64 candidates -- every
+// rigid transform of a V2X scene; the adjoint is then a GATHER (no atomics, no 8-byte workspace traffic).  Anything else (a degenerate
+// theta) keeps the fixed-point scatter below.  The predicate is a pure function of theta, evaluated identically by the three kernels.
+struct WarpBox { float Ax, Bx, Ay, By, Cx, Cy, inv_det, ej, ei; bool small; };
+
+template <bool AC>
+__device__ __forceinline__ void warp_src(const float* __restrict__ th, int i, int j, int H, int W, float& ix, float& iy) {
+    float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
+    if (!AC) { xn = (xn * (float)(W - 1)) / (float)W; yn = (yn * (float)(H - 1)) / (float)H; }
+    const float gx = th[0] * xn + th[1] * yn + th[2];
+    const float gy = th[3] * xn + th[4] * yn + th[5];
+    ix = AC ? ((gx + 1.f) * 0.5f) * (float)(W - 1) : ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    iy = AC ? ((gy + 1.f) * 0.5f) * (float)(H - 1) : ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+}
+
+template <bool AC>
+__device__ __forceinline__ WarpBox warp_box(const float* __restrict__ th, int H, int W) {
+    WarpBox b;
+    const float sx = AC ? (float)(W - 1) : (float)W, sy = AC ? (float)(H - 1) : (float)H;
+    b.Ax = th[0]; b.Bx = th[1] * sx / sy; b.Ay = th[3] * sy / sx; b.By = th[4];
+    warp_src<AC>(th, 0, 0, H, W, b.Cx, b.Cy);
+    const float det = b.Ax * b.By - b.Bx * b.Ay;
+    b.inv_det = 1.0f / det;
+    const float m = 0.05f + 1e-5f * (float)(H + W);          // rounding of the centre over a map of this size, generously
+    b.ej = (fabsf(b.By) + fabsf(b.Bx)) * fabsf(b.inv_det) + m;
+    b.ei = (fabsf(b.Ay) + fabsf(b.Ax)) * fabsf(b.inv_det) + m;
+    const float cand = (2.f * b.ej + 2.f) * (2.f * b.ei + 2.f);
+    b.small = (H > 1 && W > 1) && fabsf(det) > 1e-6f && cand <= 64.f && fabsf(b.Cx) < 1e6f && fabsf(b.Cy) < 1e6f;   // false for NaN / inf too
+    return b;
+}
+
+// gather: thread -> (source pixel, channel quad), as the scatter kernel's (output pixel, channel quad).  Candidates in row-major order, the
+// sampling position and the weights of each recomputed with the forward's expressions: float sums in a fixed order -- bit-reproducible.
+template <int CK, bool AC>
+__global__ __launch_bounds__(256) void warp_affine_backward_gather_kernel(const float* __restrict__ ddst, const float* __restrict__ theta,
+                                                                          float* __restrict__ dsrc, unsigned long long* __restrict__ acc, int H, int W) {
+    const int t = threadIdx.x & 15;
+    const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int n = blockIdx.y;
+    if (pix >= H * W) return;
+    const float* th = theta + n * 6;
+    const WarpBox b = warp_box<AC>(th, H, W);
+    constexpr int C = 64 * CK;
+    if (!b.small) {        // this image goes through the scatter kernel: zero the pixel's fixed-point accumulators
+        unsigned long long* a = acc + ((size_t)n * H * W + pix) * C + 4 * t;
+#pragma unroll
+        for (int k = 0; k < CK; ++k) { a[64 * k] = 0ull; a[64 * k + 1] = 0ull; a[64 * k + 2] = 0ull; a[64 * k + 3] = 0ull; }
+        return;
+    }
+    const int sy = pix / W, sx = pix - sy * W;
+    const float ux = (float)sx - b.Cx, uy = (float)sy - b.Cy;
+    const float jc = (b.By * ux - b.Bx * uy) * b.inv_det, ic = (b.Ax * uy - b.Ay * ux) * b.inv_det;
+    const int j0 = max(0, (int)ceilf(jc - b.ej)), j1 = min(W - 1, (int)floorf(jc + b.ej));
+    const int i0 = max(0, (int)ceilf(ic - b.ei)), i1 = min(H - 1, (int)floorf(ic + b.ei));
+    float4 s[CK];
+#pragma unroll
+    for (int k = 0; k < CK; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) {
+            float ix, iy;
+            warp_src<AC>(th, i, j, H, W, ix, iy);
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const float wx = x0 == sx ? (x0f + 1.f) - ix : (x0 + 1 == sx ? ix - x0f : 0.f);
+            const float wy = y0 == sy ? (y0f + 1.f) - iy : (y0 + 1 == sy ? iy - y0f : 0.f);
+            const float w = wx * wy;
+            if (w != 0.f) {
+                const float* g = ddst + (((size_t)n * H + i) * W + j) * C + 4 * t;
+#pragma unroll
+                for (int k = 0; k < CK; ++k) {
+                    const float4 d = *reinterpret_cast<const float4*>(g + 64 * k);
+                    s[k].x = fmaf(d.x, w, s[k].x); s[k].y = fmaf(d.y, w, s[k].y); s[k].z = fmaf(d.z, w, s[k].z); s[k].w = fmaf(d.w, w, s[k].w);
+                }
+            }
+        }
+    float* o = dsrc + ((size_t)n * H * W + pix) * C + 4 * t;
+#pragma unroll
+    for (int k = 0; k < CK; ++k) *reinterpret_cast<float4*>(o + 64 * k) = s[k];
+}
+
+// the images the gather kernel left to the scatter: fixed point -> float
+template <bool AC>
+__global__ __launch_bounds__(256) void warp_fixed_to_float_kernel(const long long* __restrict__ acc, const float* __restrict__ theta, float* __restrict__ out,
+                                                                  size_t per_image, int H, int W) {
+    const int n = blockIdx.y;
+    if (warp_box<AC>(theta + n * 6, H, W).small) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_image; i += (size_t)gridDim.x * 256)
+        out[(size_t)n * per_image + i] = (float)((double)acc[(size_t)n * per_image + i] * (1.0 / 4294967296.0));
+}
+
 template <int CK, bool AC>   // C = 64 * CK; AC = align_corners: true for warp_affine, false for warp_affine_simple (as v2xvit.hip)
 __global__ __launch_bounds__(256) void warp_affine_backward_kernel(const float* __restrict__ ddst, const float* __restrict__ theta,
                                                                    unsigned long long* __restrict__ acc, int H, int W) {
@@ -270,12 +364,9 @@ __global__ __launch_bounds__(256) void warp_affine_backward_kernel(const float* 
     if (pix >= H * W) return;
     const int i = pix / W, j = pix - i * W;
     const float* th = theta + n * 6;
-    float xn = lin_m1_1(j, W), yn = lin_m1_1(i, H);
-    if (!AC) { xn = (xn * (float)(W - 1)) / (float)W; yn = (yn * (float)(H - 1)) / (float)H; }
-    const float gx = th[0] * xn + th[1] * yn + th[2];
-    const float gy = th[3] * xn + th[4] * yn + th[5];
-    const float ix = AC ? ((gx + 1.f) * 0.5f) * (float)(W - 1) : ((gx + 1.f) * (float)W - 1.f) * 0.5f;
-    const float iy = AC ? ((gy + 1.f) * 0.5f) * (float)(H - 1) : ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    if (warp_box<AC>(th, H, W).small) return;          // done by warp_affine_backward_gather_kernel
+    float ix, iy;
+    warp_src<AC>(th, i, j, H, W, ix, iy);
     const float x0f = floorf(ix), y0f = floorf(iy);
     const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
     const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
@@ -392,15 +483,26 @@ static int warp_affine_backward_launch(const char* who, const float* ddst, const
     if (n < 1) return 0;
     hipStream_t st = av2x::as_stream(stream);
     const size_t total = (size_t)n * h * w * c;
-    hipError_t e = hipMemsetAsync(workspace, 0, total * 8ull, st);
-    if (e != hipSuccess) return av2x::fail("%s: memset: %s", who, hipGetErrorString(e));
+    // per image: the gather (every well-conditioned theta), or -- the gather kernel zeroes the image's accumulators instead -- the fixed-point
+    // scatter + conversion, which return at once for the gathered images
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace);
     const dim3 grid((h * w + 15) / 16, n), block(256);
-    if (c == 64) hipLaunchKernelGGL((warp_affine_backward_kernel<1, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
-    else if (c == 128) hipLaunchKernelGGL((warp_affine_backward_kernel<2, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
-    else hipLaunchKernelGGL((warp_affine_backward_kernel<4, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
-    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const long long*>(acc), dsrc, total);
-    return av2x::check_launch("warp_affine_backward_kernel");
+    if (c == 64) {
+        hipLaunchKernelGGL((warp_affine_backward_gather_kernel<1, AC>), grid, block, 0, st, ddst, theta, dsrc, acc, h, w);
+        hipLaunchKernelGGL((warp_affine_backward_kernel<1, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
+    } else if (c == 128) {
+        hipLaunchKernelGGL((warp_affine_backward_gather_kernel<2, AC>), grid, block, 0, st, ddst, theta, dsrc, acc, h, w);
+        hipLaunchKernelGGL((warp_affine_backward_kernel<2, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
+    } else {
+        hipLaunchKernelGGL((warp_affine_backward_gather_kernel<4, AC>), grid, block, 0, st, ddst, theta, dsrc, acc, h, w);
+        hipLaunchKernelGGL((warp_affine_backward_kernel<4, AC>), grid, block, 0, st, ddst, theta, acc, h, w);
+    }
+    const size_t per_image = (size_t)h * w * c;
+    const size_t cb = (per_image + 255) / 256;
+    hipLaunchKernelGGL((warp_fixed_to_float_kernel<AC>), dim3((unsigned)(cb < 1024 ? cb : 1024), n), dim3(256), 0, st, reinterpret_cast<const long long*>(acc), theta,
+                       dsrc, per_image, h, w);
+    (void)total;
+    return av2x::check_launch("warp_affine_backward kernels");
 }
 
 extern "C" int av2x_warp_affine_backward(const float* ddst, const float* theta, float* dsrc, void* workspace, int32_t n, int32_t h, int32_t w,

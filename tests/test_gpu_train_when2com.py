@@ -53,6 +53,36 @@ def test_warp_affine_simple_forward_backward(n, H, W, C):
     rel_close(xd.grad.cpu().permute(0, 3, 1, 2), xr.grad, 2e-5, "warp dx")
 
 
+def test_warp_adjoint_gather_and_scatter_paths_agree_with_autograd():
+    """The adjoint of the warp is a gather over the output pixels around M^-1 (s - C) for every well-conditioned theta and, per image, the
+    fixed-point scatter for the rest (zoom-in by 10: hundreds of output pixels per source pixel; a singular theta; all zeros): both against
+    torch autograd of grid_sample, in ONE launch with mixed images; a zoom-out, a shear and a flip take the gather."""
+    from airv2x_perception_amd.opencood_iface import train_when2com as Tw
+    from airv2x_perception_amd.opencood_iface import train_fusion_ops as Fo
+    g = _g(77)
+    H, W, C = 20, 28, 128
+    ths = [[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], [[0.1, 0.0, 0.3], [0.0, 0.1, -0.2]], [[3.0, 0.4, 0.1], [-0.3, 2.5, 0.2]],
+           [[1.0, 1.0, 0.0], [1.0, 1.0, 0.0]], [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]], [[-1.0, 0.3, 0.05], [0.1, -0.9, -0.1]],
+           [[0.7, -0.7 * H / W, 0.4], [0.7 * W / H, 0.7, -0.6]], [[1.0, 0.0, 2.5], [0.0, 1.0, 0.0]]]
+    th = torch.tensor(ths, dtype=torch.float32)
+    n = th.shape[0]
+    x = torch.randn(n, C, H, W, generator=g)
+    dy = torch.randn(n, C, H, W, generator=g)
+    for simple in (True, False):
+        xr = x.clone().requires_grad_()
+        grid = F.affine_grid(th, [n, C, H, W], align_corners=not simple)
+        F.grid_sample(xr, grid, align_corners=not simple).backward(dy)
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
+        op = Tw.warp_affine_simple if simple else Fo.warp_affine
+        op(xd, th.cuda().contiguous()).backward(dy.permute(0, 2, 3, 1).contiguous().cuda())
+        got, ref = xd.grad.cpu().permute(0, 3, 1, 2), xr.grad
+        for k in range(n):
+            rel_close(got[k], ref[k], 3e-5, f"warp adjoint, simple={simple}, theta {k}")
+        xd2 = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
+        op(xd2, th.cuda().contiguous()).backward(dy.permute(0, 2, 3, 1).contiguous().cuda())
+        assert torch.equal(xd2.grad, xd.grad)          # fixed candidate order / fixed-point sums: bit-reproducible
+
+
 @pytest.mark.parametrize("m,n,k,act", [(3, 256, 4096, 1), (1, 128, 256, 1), (7, 32, 128, 0), (11, 64, 1024, 1), (2, 256, 50688, 1)])
 def test_linear_rows_forward_backward(m, n, k, act):
     from airv2x_perception_amd.opencood_iface import train_when2com as Tw
