@@ -78,6 +78,7 @@ SIGNATURES = {
     "av2x_conv2d_wgrad_workspace_bytes": (c_uint64, [POINTER(ConvDesc)]),
     "av2x_conv2d_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_pack_conv_weight": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_split3_koct": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_act_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_bn_workspace_bytes": (c_uint64, [c_int64, c_int32]),
     "av2x_bn_stats": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

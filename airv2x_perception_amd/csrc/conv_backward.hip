@@ -333,6 +333,39 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// the split-3 bf16 planes conv_igemm_x3p reads, (3, taps, cin / 8, coutp, 8): hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (both
+// subtractions exact in fp32; round to nearest even as torch's conversion), from the fp32 k-quad packing (taps, cin / 4, coutp, 4) --
+// packing.to_bf16x3_koct in one launch, for weights that change every optimiser step
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__global__ __launch_bounds__(256) void split3_koct_kernel(const float4* __restrict__ wp, int taps, int q4, int coutp, uint2* __restrict__ out) {
+    const size_t n = (size_t)taps * q4 * coutp;
+    const size_t plane = n;                                   // uint2 (four bf16) per float4, per plane
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % coutp);
+        const size_t r = i / coutp;
+        const int qq = (int)(r % q4), t = (int)(r / q4);
+        const float4 v = wp[i];
+        const float w[4] = {v.x, v.y, v.z, v.w};
+        unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = bf16_rne(w[e]);
+            const float r1 = w[e] - __uint_as_float(hi[e] << 16);
+            mi[e] = bf16_rne(r1);
+            lo[e] = bf16_rne(r1 - __uint_as_float(mi[e] << 16));
+        }
+        const size_t o = (((size_t)t * (q4 / 2) + (qq >> 1)) * coutp + co) * 2 + (qq & 1);
+        out[o] = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+        out[plane + o] = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+        out[2 * plane + o] = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+    }
+}
+
 constexpr int kWgradChunk = 2048;   // output pixels per workgroup (64 K-steps of 32)
 
 }  // namespace
@@ -461,6 +494,18 @@ extern "C" int av2x_pack_conv_weight(const float* w, int32_t cout, int32_t cin, 
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), w, cout, cin, coutp, ks, flipped != 0,
                        reinterpret_cast<float4*>(wp));
     return av2x::check_launch("pack_weight_kernel");
+}
+
+extern "C" int av2x_split3_koct(const float* packed, int32_t taps, int32_t cin, int32_t coutp, void* planes, av2x_stream_t stream) {
+    if (!packed || !planes) return av2x::fail("av2x_split3_koct: null argument");
+    if (taps <= 0 || cin <= 0 || cin % 8 || coutp <= 0) return av2x::fail("av2x_split3_koct: bad sizes (cin %% 8 == 0)");
+    if (reinterpret_cast<uintptr_t>(packed) % 16 || reinterpret_cast<uintptr_t>(planes) % 8) return av2x::fail("av2x_split3_koct: misaligned buffer");
+    const size_t n = (size_t)taps * (cin / 4) * coutp;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split3_koct_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const float4*>(packed), taps, cin / 4,
+                       coutp, reinterpret_cast<uint2*>(planes));
+    return av2x::check_launch("split3_koct_kernel");
 }
 
 extern "C" int av2x_act_backward(const float* y, const float* dy, const float* scale, int64_t rows, int32_t c, int32_t act,

@@ -17,6 +17,7 @@ regime.  Batch-statistics BatchNorm, the transposed convolutions, the fusion and
 """
 from __future__ import annotations
 
+import os
 from ctypes import byref, c_void_p
 
 import torch
@@ -35,9 +36,12 @@ def _runner(device):
         # synchronises, next to the weight-gradient side stream) would stall the first epoch and could persist a noisy pick.
         # Shipped / cached table hits are still used; a miss falls back to the pick_tile rule.  All candidates are bit-identical.
         r.tune_on_miss = False
-        # the training step is pinned to the reference's step gradient by gradient: fp32-input matrix cores throughout
+        # the training step is pinned to the reference's step gradient by gradient.  3x3 convolutions: fp32-input matrix cores (the Winograd
+        # kernels; their split-3 versions gain nothing on single-stream launches).  1x1 / strided / transposed convolutions and the token
+        # Linears of the transformer fusions: the pipelined split-3 GEMM (conv_igemm_x3p: products as exact as fp32 products, 1.3-1.5x the
+        # fp32-input MFMA's rate); AV2X_TRAIN_X3P=0 restores the fp32-input GEMM
         r.wino_x3 = False
-        r.x3p = False
+        r.x3p = os.environ.get("AV2X_TRAIN_X3P", "1") != "0"
     return r
 
 

@@ -76,8 +76,9 @@ class LinearFn(torch.autograd.Function):
         n, h, w, cin = x.shape
         cout = weight.shape[0]
         w4 = weight.detach().view(cout, cin, 1, 1)
-        wp, coutp, _, _ = T._packed(r, w4, owner=weight)    # keyed on the nn.Linear parameter: one packing per optimiser step
+        wp, coutp, _, ent = T._packed(r, w4, owner=weight)    # keyed on the nn.Linear parameter: one packing per optimiser step
         L = ConvLayer(wp, None, bias.detach() if bias is not None else T._zeros(cout, x.device), cin, cout, coutp, 1, 1, 0, 0)
+        T.seed_x3p(r, L, ent)
         y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
         r.amp = T.AMP_STEP[0]
         try:

@@ -57,6 +57,31 @@ def pack_conv_weight_dev(w, flipped=False):
     return out, coutp
 
 
+def split3_dev(wp):
+    """packing.to_bf16x3_koct of a packed weight (taps, cin/4, coutp, 4) on the device, one launch: (3, taps, cin/8, coutp, 8) bf16."""
+    taps, q4, coutp, four = wp.shape
+    if four != 4 or q4 % 2 or wp.dtype != torch.float32 or wp.device.type != "cuda" or not wp.is_contiguous():
+        raise RuntimeError("split3_dev: a contiguous fp32 HIP packing with cin % 8 == 0")
+    r = _runner(wp.device)
+    out = torch.empty((3, taps, q4 // 2, coutp, 8), dtype=torch.bfloat16, device=wp.device)
+    _lib.check(r.lib.av2x_split3_koct(_P(wp), taps, 4 * q4, coutp, _P(out), r.stream()), "av2x_split3_koct")
+    return out
+
+
+def seed_x3p(r, L, ent=None):
+    """The step's 1x1 / strided / transposed convolutions and token Linears run on the pipelined split-3 GEMM (engine.conv's x3p class:
+    fp32 operands as three bf16 terms, six products, fp32 accumulation -- products as exact as fp32 products): hand the launcher the
+    split planes, made by one launch and cached with the parameter's packing, instead of its lazy torch chain."""
+    if not r.x3p or AMP_STEP[0] or L.cin % 16 or L.coutp % 64:
+        return
+    if ent is not None and ent[6] is not None:
+        L._w3 = ent[6]
+        return
+    L._w3 = split3_dev(L.w)
+    if ent is not None:
+        ent[6] = L._w3
+
+
 def pack_deconv_weight_dev(w):
     """ConvTranspose2d weight (Cin, Cout, s, s), kernel == stride -> (1, Cin/4, s*s*Cout, 4); column = (i*s + j)*Cout + co."""
     w = w.detach()
@@ -103,12 +128,12 @@ def _packed(r, weight, flipped=False, owner=None):
     if r.winograd and ks == 3 and cin >= 64 and cin % 8 == 0 and cout % 64 == 0 and cout == coutp:   # engine.wino_rule's weight side
         u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=weight.device)
         _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u), r.stream()), "av2x_wino_pack_weights")
-    ent = [stamp, weakref.ref(own) if (own.is_leaf and isinstance(own, torch.nn.Parameter)) else None, wp, coutp, u, None]
+    ent = [stamp, weakref.ref(own) if (own.is_leaf and isinstance(own, torch.nn.Parameter)) else None, wp, coutp, u, None, None]
     if ent[1] is not None:
         if len(_PACKED) > 4096:
             _PACKED.clear()
         _PACKED[key] = ent
-    return wp, coutp, u, ent      # ent[5]: the F(4x4,3x3)-transformed weights, made by conv_raw on first need
+    return wp, coutp, u, ent      # ent[5]: the F(4x4,3x3)-transformed weights, made by conv_raw on first need; ent[6]: the split-3 planes (seed_x3p)
 
 
 # AMP training (tools/train.py:50,107-130: the forward runs under ``amp.autocast`` and the loss goes through a GradScaler): while
@@ -170,6 +195,8 @@ def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=Fals
                 _lib.check(r.lib.av2x_wino4_pack_weights(_P(wp), cin, coutp, _P(u4), r.stream()), "av2x_wino4_pack_weights")
                 ent[5] = u4
             L._wu4 = ent[5]
+    else:
+        seed_x3p(r, L, ent)
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
     r.amp = AMP_STEP[0] and cin % 8 == 0
     try:
@@ -388,6 +415,7 @@ class DeconvBNAct(torch.autograd.Function):
         _, cout, s, _ = weight.shape
         wp, ncol = pack_deconv_weight_dev(weight)
         L = ConvLayer(wp, None, _zeros(cout, x.device), cin, cout, ncol, 1, 1, 0, 0, _lib.AV2X_DECONV, s)
+        seed_x3p(r, L)
         z = torch.empty((n, h * s, w * s, cout), dtype=torch.float32, device=x.device)
         r.amp = AMP_STEP[0] and cin % 8 == 0
         try:

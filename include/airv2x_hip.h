@@ -324,6 +324,9 @@ uint64_t av2x_conv2d_wgrad_workspace_bytes(const av2x_conv_desc* d);
  * every optimiser step): flipped 0: w is (cout, cin, ks, ks); flipped 1: w is (cin, cout, ks, ks) and the taps are rotated by 180 degrees --
  * the weights of the data gradient (autograd of F.conv2d, base_bev_backbone.py:41-60).  wp: 16-byte aligned, padded columns are zeroed. */
 int av2x_pack_conv_weight(const float* w, int32_t cout, int32_t cin, int32_t ks, int32_t flipped, float* wp, av2x_stream_t stream);
+/* the split-3 bf16 planes of a packed weight, (3, taps, cin/8, coutp, 8) = hi | mid | lo with hi + mid + lo = w to 2^-24: what the
+ * pipelined split-3 GEMM (tile flag 0x1400) reads; from the fp32 packing (taps, cin/4, coutp, 4) in one launch.  cin % 8 == 0. */
+int av2x_split3_koct(const float* packed, int32_t taps, int32_t cin, int32_t coutp, void* planes, av2x_stream_t stream);
 int av2x_conv2d_wgrad(const av2x_conv_desc* d, const float* x, const float* dz, void* workspace, float* dw,
                       av2x_stream_t stream);
 int av2x_act_backward(const float* y, const float* dy, const float* scale, int64_t rows, int32_t c, int32_t act,

@@ -652,3 +652,15 @@ def test_device_weight_packing_equals_the_host_packing(cout, cin, ks, flipped):
     ref, cp_ref = pack_conv_weight(w.flip(2, 3).transpose(0, 1) if flipped else w)
     got, cp = T.pack_conv_weight_dev(w.cuda(), flipped)
     assert cp == cp_ref and got.shape == ref.shape and torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("taps,cin,coutp", [(1, 256, 768), (9, 64, 128), (4, 16, 64)])
+def test_device_split3_planes_equal_the_host_packing(taps, cin, coutp):
+    """av2x_split3_koct == packing.to_bf16x3_koct bit for bit (hi / mid / lo bf16 planes of the packed weight)."""
+    from airv2x_perception_amd.opencood_iface import train_ops as T
+    from airv2x_perception_amd.opencood_iface.packing import to_bf16x3_koct
+    g = torch.Generator().manual_seed(taps + cin)
+    wp = torch.randn(taps, cin // 4, coutp, 4, generator=g) * torch.logspace(-6, 2, coutp).view(1, 1, coutp, 1)
+    ref = to_bf16x3_koct(wp)
+    got = T.split3_dev(wp.cuda())
+    assert got.shape == ref.shape and torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
