@@ -231,6 +231,7 @@ class Where2ComEngine:
         # ... and the split-3 form of the F(4x4,3x3) class (csrc/conv_wino4_x3.hip): the layers wino4_rule selects run the 36-position
         # algorithm on the bf16 matrix cores too (needs wino_x3; error against fp64 at or below the fp32 F(4x4) kernel's)
         self.wino4_x3 = os.environ.get("AV2X_WINO4_X3", x3_default) not in ("0", "off", "")
+        self.wino2_x3 = True        # the F(2x2,3x3) class follows wino_x3; the training runner keeps it on the fp32-input kernel (single-stream launches)
         self.use_graph = False      # replay everything after the scatter from a captured hipGraph
         self.graphs = {}
         self.profile = None         # list -> (tile, flops, ev0, ev1, workgroups, shape) per conv launch (bench roofline pass)
@@ -279,6 +280,7 @@ class Where2ComEngine:
         other.wino_x3 = self.wino_x3
         other.x3p = self.x3p
         other.wino4_x3 = self.wino4_x3
+        other.wino2_x3 = self.wino2_x3
         return other
 
     def graph_active(self):
@@ -546,7 +548,7 @@ class Where2ComEngine:
             else:
                 wgt = _wu4(L, self.lib, self.stream())  # the F(4x4,3x3) class: a pure function of the layer's shape
                 d.tile = self.WINO4_TILE
-        elif self.winograd and self.wino_x3 and not self.conv_tile and vflag == 0 and self.wino_x3_rule(L):
+        elif self.winograd and self.wino_x3 and self.wino2_x3 and not self.conv_tile and vflag == 0 and self.wino_x3_rule(L):
             wgt = _wu3(L, self.lib, self.stream())
             d.tile = self.wino_x3_tile(L, d.ho, d.wo)
         elif self.winograd and not self.conv_tile and vflag == 0 and self.wino_rule(L):

@@ -149,13 +149,16 @@ def run(agents=4, steps=10, warmup=3, small=False, cpu=False, dev=None, dd=None,
     groups = {"conv_wino_f32 (forward + data gradients)": [0, 0.0, 0.0, 0.0], "conv_igemm_f32 (forward + data gradients, 1x1 / stride 2 / deconv)": [0, 0.0, 0.0, 0.0],
               "conv_wgrad (weight gradients)": [0, 0.0, 0.0, 0.0]}
     X3P = "conv_igemm_x3p (forward + data gradients, 1x1 / stride 2 / deconv / Linear: split-3 operands, six bf16 MFMA products per fp32 product)"
-    gpeak = {X3P: 2500.0}
+    W4X3 = "conv_wino4_x3 (forward + data gradients of the F(4x4,3x3) class: split-3 operands on the bf16 matrix cores)"
+    gpeak = {X3P: 2500.0, W4X3: 2500.0}
     for tile, flops, e0, e1, wgs, shp in prof:
         wino = bool(tile[0] & 0x4000)
+        f4 = wino and bool(tile[0] & 0x2000)                    # F(4x4,3x3): 36 products per 16 outputs = 1/4 of the direct count
+        w4x3 = f4 and bool(tile[1] & 0x0400)
         x3p = not wino and not amp and bool(tile[1] & 0x1000)
-        gk = "conv_wino_f32 (forward + data gradients)" if wino else (X3P if x3p else "conv_igemm_f32 (forward + data gradients, 1x1 / stride 2 / deconv)")
+        gk = W4X3 if w4x3 else "conv_wino_f32 (forward + data gradients)" if wino else (X3P if x3p else "conv_igemm_f32 (forward + data gradients, 1x1 / stride 2 / deconv)")
         v = groups.setdefault(gk, [0, 0.0, 0.0, 0.0])
-        v[0] += 1; v[1] += flops; v[2] += flops * (16.0 / 36.0 if wino else 6.0 if x3p else 1.0); v[3] += e0.elapsed_time(e1) * 1e-3
+        v[0] += 1; v[1] += flops; v[2] += flops * (1.5 if w4x3 else 0.25 if f4 else 16.0 / 36.0 if wino else 6.0 if x3p else 1.0); v[3] += e0.elapsed_time(e1) * 1e-3
     for flops, e0, e1, shp in wprof:
         v = groups["conv_wgrad (weight gradients)"]
         v[0] += 1; v[1] += flops; v[2] += flops; v[3] += e0.elapsed_time(e1) * 1e-3
