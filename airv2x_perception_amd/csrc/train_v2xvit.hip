@@ -12,6 +12,8 @@
 //   warp_affine_backward_gather_kernel   adjoint of the bilinear sampling of warp_affine (:337-381) as a GATHER over the few output pixels whose
 //                                   footprint holds the source pixel (the warp is affine: their bounding box follows from theta); degenerate
 //                                   thetas fall back, per image, to warp_affine_backward_kernel: scattered with 2^-32 fixed-point atomics
+#include <cstdlib>
+
 #include "av2x_common.hpp"
 
 namespace {
@@ -200,6 +202,143 @@ __global__ __launch_bounds__(256) void window_attn_backward_kv(const float* __re
     float* drow = dqkv + tok * ctot + coff + head * DHD;
 #pragma unroll
     for (int d = 0; d < DHD; ++d) { drow[inner + d] = dk[d]; drow[2 * inner + d] = dv[d]; }
+}
+
+// window = 4: the 16 tokens of a window are one v_mfma_f32_16x16x4_f32 tile -- the register tiling of fax_attention_backward_wave_kernel
+// (train_fusion.hip) with one query / key "agent": a wave per (agent, window, head); lane (t = lane & 15, h = lane >> 4) holds
+// X[token t][d = 16c + 4h .. + 3] of Q, K, V, dO (A operand with row = t, B operand with column = t alike);
+//   S^T, P^T, dP^T, dS^T with row = key 4h + r, column = query t  ->  pos_embedding gradient (fixed point, LDS), dQ = dS K (dS^T IS the A operand)
+//   S, P, dP, dS with row = query 4h + r, column = key t (operands swapped; statistics of query 4h + r by ds_bpermute)  ->  dK = dS^T Q, dV = P^T dO
+// No stats buffer, no second pass over the keys, one launch.  The thread-per-(token, head) kernels above read every K / V row of the window
+// from global memory per thread: 1.1 + 0.84 ms (dim_head 32) and 1.7 + 1.15 ms (64) per launch at the BASELINE grid.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int DHD>
+__global__ __launch_bounds__(256) void window_attn_backward_wave_kernel(const float* __restrict__ qkv, int ctot, int coff, const float* __restrict__ pos,
+                                                                        const float* __restrict__ out, const float* __restrict__ dout,
+                                                                        float* __restrict__ dqkv, unsigned long long* __restrict__ dpos, int n, int H, int W,
+                                                                        int heads, float scale) {
+    constexpr int NC = DHD / 16;
+    __shared__ float lpos[64];
+    __shared__ unsigned long long ldpos[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane & 15, h = lane >> 4;
+    if (threadIdx.x < 64) lpos[threadIdx.x] = threadIdx.x < 49 ? pos[threadIdx.x] : 0.f;
+    ldpos[wave][lane] = 0ull;
+    __syncthreads();
+    const int X = H / 4, Y = W / 4;
+    const long long items = (long long)n * X * Y * heads;
+    const int inner = heads * DHD;
+    const int w1q = t >> 2, w2q = t & 3;
+    const float kLog2e = 1.4426950408889634f;
+    for (long long it = (long long)blockIdx.x * 4 + wave; it < items; it += (long long)gridDim.x * 4) {
+        const int head = (int)(it % heads);
+        const long long wi = it / heads;
+        const int win = (int)(wi % (X * Y)), a = (int)(wi / (X * Y));
+        const int wx = win / Y, wy = win - wx * Y;
+        const size_t tok_t = ((size_t)a * H + wx * 4 + w1q) * W + wy * 4 + w2q;
+        size_t tok_hr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tok_hr[r] = ((size_t)a * H + wx * 4 + h) * W + wy * 4 + r;
+        const float* base = qkv + coff + head * DHD;
+        f32x4v q[NC], kf[NC], vf[NC], g[NC];
+        float Dq = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float* row = base + tok_t * ctot + 16 * c + 4 * h;
+            q[c] = *reinterpret_cast<const f32x4v*>(row);
+            q[c] *= scale;
+            kf[c] = *reinterpret_cast<const f32x4v*>(row + inner);
+            vf[c] = *reinterpret_cast<const f32x4v*>(row + 2 * inner);
+            g[c] = *reinterpret_cast<const f32x4v*>(dout + tok_t * inner + head * DHD + 16 * c + 4 * h);
+            const f32x4v o = *reinterpret_cast<const f32x4v*>(out + tok_t * inner + head * DHD + 16 * c + 4 * h);
+            Dq = fmaf(g[c].x, o.x, Dq); Dq = fmaf(g[c].y, o.y, Dq); Dq = fmaf(g[c].z, o.z, Dq); Dq = fmaf(g[c].w, o.w, Dq);
+        }
+        Dq += __shfl_xor(Dq, 16);
+        Dq += __shfl_xor(Dq, 32);
+        // ---- row = key (h, r), column = query t
+        f32x4v st = {0.f, 0.f, 0.f, 0.f}, dpT = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].x, q[c].x, st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].y, q[c].y, st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].z, q[c].z, st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].w, q[c].w, st, 0, 0, 0);
+            dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c].x, g[c].x, dpT, 0, 0, 0);
+            dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c].y, g[c].y, dpT, 0, 0, 0);
+            dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c].z, g[c].z, dpT, 0, 0, 0);
+            dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c].w, g[c].w, dpT, 0, 0, 0);
+        }
+        const int iT = (h - w1q + 3) * 7 + (3 - w2q);            // + r: pos index of key (h, r) against query (w1q, w2q)
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[r] += lpos[iT + r]; m = fmaxf(m, st[r]); }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float mb = m * kLog2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], kLog2e, -mb)); sum += st[r]; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        f32x4v dq[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dq[c] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ds = st[r] * inv * (dpT[r] - Dq);
+            if (ds != 0.f) atomicAdd(&ldpos[wave][iT + r], (unsigned long long)__float2ll_rn(ds * kFixF));
+            const float* kb = base + tok_hr[r] * ctot + inner + t;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kb[16 * c], dq[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* dst = dqkv + tok_hr[r] * ctot + coff + head * DHD + t;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dst[16 * c] = dq[c][r] * scale;
+        }
+        // ---- row = query (h, r), column = key t
+        f32x4v s2 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].x, kf[c].x, s2, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].y, kf[c].y, s2, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].z, kf[c].z, s2, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].w, kf[c].w, s2, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].x, vf[c].x, d2, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].y, vf[c].y, d2, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].z, vf[c].z, d2, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[c].w, vf[c].w, d2, 0, 0, 0);
+        }
+        const int i2 = (w1q - h + 3) * 7 + (w2q + 3);              // - r: pos index of key (w1q, w2q) against query (h, r)
+        f32x4v dk[NC], dv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { dk[c] = (f32x4v){0.f, 0.f, 0.f, 0.f}; dv[c] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m2 = __shfl(mb, 4 * h + r), inv2 = __shfl(inv, 4 * h + r), D2 = __shfl(Dq, 4 * h + r);
+            const float pr = __builtin_amdgcn_exp2f(fmaf(s2[r] + lpos[i2 - r], kLog2e, -m2)) * inv2;
+            const float ds = pr * (d2[r] - D2);
+            const float* qq = base + tok_hr[r] * ctot + t;
+            const float* gg = dout + tok_hr[r] * inner + head * DHD + t;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                dk[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, qq[16 * c] * scale, dk[c], 0, 0, 0);
+                dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, gg[16 * c], dv[c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* dst = dqkv + tok_hr[r] * ctot + coff + head * DHD + t;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { dst[inner + 16 * c] = dk[c][r]; dst[2 * inner + 16 * c] = dv[c][r]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane < 49 && ldpos[wave][lane]) atomicAdd(dpos + lane, ldpos[wave][lane]);
 }
 
 __global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, size_t n) {
@@ -440,6 +579,18 @@ extern "C" int av2x_window_attention_backward(const float* qkv, int32_t ctot, in
                            h, w, heads, scale);                                                                                        \
         hipLaunchKernelGGL(fixed_to_float_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(dposfix), dpos, (size_t)np); \
         return av2x::check_launch("window_attn_backward");                                                                             \
+    }
+    static const bool no_wave = [] { const char* e = getenv("AV2X_WIN_BWD_NO_WAVE"); return e && e[0] == '1'; }();
+    if (window == 4 && (dim_head == 32 || dim_head == 64) && h % 4 == 0 && w % 4 == 0 && ctot % 4 == 0 && coff % 4 == 0 && !no_wave) {
+        const long long items = (long long)n * (h / 4) * (w / 4) * heads;
+        const long long wgs = (items + 3) / 4;
+        const dim3 g2((unsigned)(wgs < 2048 ? wgs : 2048));
+        if (dim_head == 32)
+            hipLaunchKernelGGL((window_attn_backward_wave_kernel<32>), g2, block, 0, st, qkv, ctot, coff, pos_embedding, out, dout, dqkv, dposfix, n, h, w, heads, scale);
+        else
+            hipLaunchKernelGGL((window_attn_backward_wave_kernel<64>), g2, block, 0, st, qkv, ctot, coff, pos_embedding, out, dout, dqkv, dposfix, n, h, w, heads, scale);
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const long long*>(dposfix), dpos, (size_t)np);
+        return av2x::check_launch("window_attn_backward_wave_kernel");
     }
     AV2X_WAB(16, 2)
     AV2X_WAB(32, 4)
