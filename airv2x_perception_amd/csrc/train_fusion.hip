@@ -138,6 +138,32 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float4* __restrict__
     }
 }
 
+// nn.Dropout with the Bernoulli draw in the kernel: Philox4x32-10 keyed by a 64-bit seed the caller draws from torch's generator, counter =
+// the float4's index -- forward and backward regenerate the same keep-mask from the seed, so no mask tensor exists (three torch launches and
+// 1 + 4 + 1 bytes per element of HBM traffic per site before).  Element e of quad i is kept iff (r_e >> 8) * 2^-24 >= p.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void dropout_seeded_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, float p, float scale,
+                                                             unsigned k0, unsigned k1) {
+    const float k24 = 1.0f / 16777216.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(i >> 32), 0u, 0u), k0, k1);
+        const float4 v = x[i];
+        y[i] = make_float4((float)(r.x >> 8) * k24 >= p ? v.x * scale : 0.f, (float)(r.y >> 8) * k24 >= p ? v.y * scale : 0.f,
+                           (float)(r.z >> 8) * k24 >= p ? v.z * scale : 0.f, (float)(r.w >> 8) * k24 >= p ? v.w * scale : 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------- fused axial attention, backward
 struct FaxBwdParams {
     const float* qkv;    // (L*H*W, 3C)
@@ -604,6 +630,15 @@ extern "C" int av2x_dropout(const float* x, const uint8_t* mask, float* y, uint6
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4)), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const unsigned*>(mask), reinterpret_cast<float4*>(y), (size_t)(n / 4), scale);
     return av2x::check_launch("dropout_kernel");
+}
+
+extern "C" int av2x_dropout_seeded(const float* x, float* y, uint64_t n, float p, uint64_t seed, av2x_stream_t stream) {
+    if (!x || !y || n % 4) return av2x::fail("av2x_dropout_seeded: null argument or n %% 4 != 0");
+    if (!(p >= 0.f && p < 1.f)) return av2x::fail("av2x_dropout_seeded: p = %g (0 <= p < 1)", (double)p);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_seeded_kernel, dim3(grid_for(n / 4)), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<float4*>(y), (size_t)(n / 4), p, 1.0f / (1.0f - p), (unsigned)seed, (unsigned)(seed >> 32));
+    return av2x::check_launch("dropout_seeded_kernel");
 }
 
 extern "C" uint64_t av2x_fax_attention_backward_workspace_bytes(int32_t n_agents_padded, int32_t window, int32_t heads) {

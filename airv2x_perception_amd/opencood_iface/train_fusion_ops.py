@@ -140,23 +140,23 @@ class DropoutFn(torch.autograd.Function):
         T._check_dev(x)
         r = _runner(x.device)
         x = x.contiguous()
-        # the Bernoulli draw comes from torch's generator on the device (the reference's nn.Dropout draws from the same generator;
-        # the streams differ, as they do between any two dropout implementations); the product runs in the kernel
-        mask = (torch.rand(x.shape, device=x.device) >= p).to(torch.uint8)
+        # the Bernoulli draw happens IN the kernel (Philox keyed by a seed from torch's generator: torch.manual_seed governs it, as it does
+        # the reference's nn.Dropout; the streams differ, as they do between any two dropout implementations).  The backward regenerates
+        # the keep-mask from the seed: no mask tensor, no torch.rand / compare / cast launches
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         y = torch.empty_like(x)
-        scale = 1.0 / (1.0 - p)
-        _lib.check(r.lib.av2x_dropout(_P(x), _P(mask), _P(y), x.numel(), scale, r.stream()), "av2x_dropout")
-        ctx.save_for_backward(mask)
-        ctx.scale = scale
+        if x.numel() % 4:
+            raise ValueError("dropout: the element count must be a multiple of 4")
+        _lib.check(r.lib.av2x_dropout_seeded(_P(x), _P(y), x.numel(), p, seed, r.stream()), "av2x_dropout_seeded")
+        ctx.seed, ctx.p = seed, p
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (mask,) = ctx.saved_tensors
         r = _runner(dy.device)
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        _lib.check(r.lib.av2x_dropout(_P(dy), _P(mask), _P(dx), dy.numel(), ctx.scale, r.stream()), "av2x_dropout")
+        _lib.check(r.lib.av2x_dropout_seeded(_P(dy), _P(dx), dy.numel(), ctx.p, ctx.seed, r.stream()), "av2x_dropout_seeded")
         return dx, None
 
 

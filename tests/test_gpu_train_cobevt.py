@@ -71,6 +71,21 @@ def test_gelu_linear_mean_dropout():
     assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / 0.75) < 1e-6 and torch.equal(xd.grad, yd.detach())
     assert abs(float(yd.detach().mean()) - 1.0) < 0.02
     assert Fo.dropout(xd, 0.25, training=False) is xd and Fo.dropout(xd, 0.0) is xd
+    # the draw happens in the kernel (Philox keyed by a seed from torch's generator): governed by torch.manual_seed, a new mask per call,
+    # keep rate 1 - p, neighbouring elements independent
+    big = torch.ones(64, 100, 352, 4, device="cuda")
+    for pdrop in (0.1, 0.5, 0.9):
+        keep = (Fo.dropout(big, pdrop) != 0).float()
+        assert abs(float(keep.mean()) - (1 - pdrop)) < 2e-3, (pdrop, float(keep.mean()))
+        k = keep.reshape(-1, 4)
+        for e in range(3):        # lanes of one Philox call are uncorrelated
+            c = float(((k[:, e] - (1 - pdrop)) * (k[:, e + 1] - (1 - pdrop))).mean()) / (pdrop * (1 - pdrop))
+            assert abs(c) < 5e-3, (pdrop, e, c)
+    torch.manual_seed(123)
+    a1, a2 = Fo.dropout(big, 0.3), Fo.dropout(big, 0.3)
+    torch.manual_seed(123)
+    b1 = Fo.dropout(big, 0.3)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
 
 
 @pytest.mark.parametrize("L,n_valid,H,W,grid", [(3, 3, 8, 12, 0), (3, 2, 8, 8, 1), (7, 4, 8, 8, 0), (8, 8, 4, 8, 1), (7, 1, 4, 4, 0)])
