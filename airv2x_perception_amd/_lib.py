@@ -110,7 +110,7 @@ SIGNATURES = {
     "av2x_gelu": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "av2x_scale_broadcast": (c_int32, [c_void_p, c_void_p, c_int32, c_uint64, c_float, c_void_p]),
     "av2x_dropout": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_float, c_void_p]),
-    "av2x_dropout_seeded": (c_int32, [c_void_p, c_void_p, c_uint64, c_float, c_uint64, c_void_p]),
+    "av2x_dropout_seeded": (c_int32, [c_void_p, c_void_p, c_void_p, c_uint64, c_float, c_uint64, c_void_p]),
     "av2x_fax_attention_backward_workspace_bytes": (c_uint64, [c_int32, c_int32, c_int32]),
     "av2x_fax_attention_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                               c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

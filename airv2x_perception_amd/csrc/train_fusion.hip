@@ -153,14 +153,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, unsigned k0, unsigned k1
     return c;
 }
 
-__global__ __launch_bounds__(256) void dropout_seeded_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, float p, float scale,
-                                                             unsigned k0, unsigned k1) {
+__global__ __launch_bounds__(256) void dropout_seeded_kernel(const float4* __restrict__ x, const float4* __restrict__ res, float4* __restrict__ y, size_t n4,
+                                                             float p, float scale, unsigned k0, unsigned k1) {
     const float k24 = 1.0f / 16777216.0f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(i >> 32), 0u, 0u), k0, k1);
         const float4 v = x[i];
-        y[i] = make_float4((float)(r.x >> 8) * k24 >= p ? v.x * scale : 0.f, (float)(r.y >> 8) * k24 >= p ? v.y * scale : 0.f,
-                           (float)(r.z >> 8) * k24 >= p ? v.z * scale : 0.f, (float)(r.w >> 8) * k24 >= p ? v.w * scale : 0.f);
+        float4 o = make_float4((float)(r.x >> 8) * k24 >= p ? v.x * scale : 0.f, (float)(r.y >> 8) * k24 >= p ? v.y * scale : 0.f,
+                               (float)(r.z >> 8) * k24 >= p ? v.z * scale : 0.f, (float)(r.w >> 8) * k24 >= p ? v.w * scale : 0.f);
+        if (res) { const float4 a = res[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }      // the residual the block adds after its dropout
+        y[i] = o;
     }
 }
 
@@ -632,12 +634,13 @@ extern "C" int av2x_dropout(const float* x, const uint8_t* mask, float* y, uint6
     return av2x::check_launch("dropout_kernel");
 }
 
-extern "C" int av2x_dropout_seeded(const float* x, float* y, uint64_t n, float p, uint64_t seed, av2x_stream_t stream) {
+extern "C" int av2x_dropout_seeded(const float* x, const float* residual, float* y, uint64_t n, float p, uint64_t seed, av2x_stream_t stream) {
     if (!x || !y || n % 4) return av2x::fail("av2x_dropout_seeded: null argument or n %% 4 != 0");
     if (!(p >= 0.f && p < 1.f)) return av2x::fail("av2x_dropout_seeded: p = %g (0 <= p < 1)", (double)p);
     if (n == 0) return 0;
     hipLaunchKernelGGL(dropout_seeded_kernel, dim3(grid_for(n / 4)), dim3(256), 0, av2x::as_stream(stream), reinterpret_cast<const float4*>(x),
-                       reinterpret_cast<float4*>(y), (size_t)(n / 4), p, 1.0f / (1.0f - p), (unsigned)seed, (unsigned)(seed >> 32));
+                       reinterpret_cast<const float4*>(residual), reinterpret_cast<float4*>(y), (size_t)(n / 4), p, 1.0f / (1.0f - p), (unsigned)seed,
+                       (unsigned)(seed >> 32));
     return av2x::check_launch("dropout_seeded_kernel");
 }
 

@@ -48,13 +48,13 @@ def swap_fusion_encoder(P, x, n_valid, fax, training=True, prefix="fusion_net.")
             qkv = F.linear(xn, P[a + ".fn.to_qkv.weight"])
             att = F.fax_attention(qkv, P[a + ".fn.relative_position_bias_table.weight"], n_valid, ws, heads, dh, gi)
             if p_drop > 0 and training:     # to_out = Sequential(Linear, Dropout) (:42-44): the residual is added after the dropout
-                x = F.dropout(F.linear(att, P[a + ".fn.to_out.0.weight"]), p_drop) + x
+                x = F.dropout(F.linear(att, P[a + ".fn.to_out.0.weight"]), p_drop, True, x)
             else:
                 x = F.linear(att, P[a + ".fn.to_out.0.weight"], None, x)
             xn = F.layer_norm(x, P[f + ".norm.weight"], P[f + ".norm.bias"])
             hdn = F.gelu(F.linear(xn, P[f + ".fn.net.0.weight"], P[f + ".fn.net.0.bias"]))
             if p_drop > 0 and training:     # FeedForward = Linear, GELU, Dropout, Linear, Dropout (base_transformer.py:28-35)
-                x = F.dropout(F.linear(F.dropout(hdn, p_drop), P[f + ".fn.net.3.weight"], P[f + ".fn.net.3.bias"]), p_drop) + x
+                x = F.dropout(F.linear(F.dropout(hdn, p_drop), P[f + ".fn.net.3.weight"], P[f + ".fn.net.3.bias"]), p_drop, True, x)
             else:
                 x = F.linear(hdn, P[f + ".fn.net.3.weight"], P[f + ".fn.net.3.bias"], x)
     m = F.agent_mean(x)

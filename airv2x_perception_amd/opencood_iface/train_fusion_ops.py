@@ -136,10 +136,14 @@ def gelu(z):
 
 class DropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p):
+    def forward(ctx, x, p, residual):
         T._check_dev(x)
         r = _runner(x.device)
         x = x.contiguous()
+        if residual is not None:
+            if residual.shape != x.shape:
+                raise ValueError("dropout: the residual must have the input's shape")
+            residual = residual.contiguous()
         # the Bernoulli draw happens IN the kernel (Philox keyed by a seed from torch's generator: torch.manual_seed governs it, as it does
         # the reference's nn.Dropout; the streams differ, as they do between any two dropout implementations).  The backward regenerates
         # the keep-mask from the seed: no mask tensor, no torch.rand / compare / cast launches
@@ -147,8 +151,8 @@ class DropoutFn(torch.autograd.Function):
         y = torch.empty_like(x)
         if x.numel() % 4:
             raise ValueError("dropout: the element count must be a multiple of 4")
-        _lib.check(r.lib.av2x_dropout_seeded(_P(x), _P(y), x.numel(), p, seed, r.stream()), "av2x_dropout_seeded")
-        ctx.seed, ctx.p = seed, p
+        _lib.check(r.lib.av2x_dropout_seeded(_P(x), _P(residual), _P(y), x.numel(), p, seed, r.stream()), "av2x_dropout_seeded")
+        ctx.seed, ctx.p, ctx.has_res = seed, p, residual is not None
         return y
 
     @staticmethod
@@ -156,16 +160,17 @@ class DropoutFn(torch.autograd.Function):
         r = _runner(dy.device)
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        _lib.check(r.lib.av2x_dropout_seeded(_P(dy), _P(dx), dy.numel(), ctx.p, ctx.seed, r.stream()), "av2x_dropout_seeded")
-        return dx, None
+        _lib.check(r.lib.av2x_dropout_seeded(_P(dy), None, _P(dx), dy.numel(), ctx.p, ctx.seed, r.stream()), "av2x_dropout_seeded")
+        return dx, None, (dy if (ctx.has_res and ctx.needs_input_grad[2]) else None)
 
 
-def dropout(x, p, training=True):
+def dropout(x, p, training=True, residual=None):
+    """nn.Dropout(p)(x) (+ residual: the skip connection added right after it, in the same launch)."""
     if not training or p <= 0.0:
-        return x
+        return x if residual is None else x + residual
     if p >= 1.0:
         raise ValueError("dropout probability must be < 1")
-    return DropoutFn.apply(x, float(p))
+    return DropoutFn.apply(x, float(p), residual)
 
 
 class FaxAttentionFn(torch.autograd.Function):

@@ -96,7 +96,7 @@ def encoder(P, x, prior, scm, enc, training=True, p="fusion_net.encoder"):
             outs = []
             for (a, b, t) in groups:
                 if cav["dropout"] > 0 and training:     # out = drop_out(to_out(out)) (hmsa.py:153-154), residual added by PreNorm's caller
-                    outs.append(F.dropout(F.linear(att[a:b], P[f"{h}.a_linears.{t}.weight"], P[f"{h}.a_linears.{t}.bias"]), cav["dropout"]) + x[a:b])
+                    outs.append(F.dropout(F.linear(att[a:b], P[f"{h}.a_linears.{t}.weight"], P[f"{h}.a_linears.{t}.bias"]), cav["dropout"], True, x[a:b]))
                 else:
                     outs.append(F.linear(att[a:b], P[f"{h}.a_linears.{t}.weight"], P[f"{h}.a_linears.{t}.bias"], x[a:b]))
             x = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
@@ -116,7 +116,7 @@ def encoder(P, x, prior, scm, enc, training=True, p="fusion_net.encoder"):
         xn = F.layer_norm(x, P[f + ".norm.weight"], P[f + ".norm.bias"])
         hdn = F.gelu(F.linear(xn, P[f + ".fn.net.0.weight"], P[f + ".fn.net.0.bias"]))
         if pdrop > 0 and training:
-            x = F.dropout(F.linear(F.dropout(hdn, pdrop), P[f + ".fn.net.3.weight"], P[f + ".fn.net.3.bias"]), pdrop) + x
+            x = F.dropout(F.linear(F.dropout(hdn, pdrop), P[f + ".fn.net.3.weight"], P[f + ".fn.net.3.bias"]), pdrop, True, x)
         else:
             x = F.linear(hdn, P[f + ".fn.net.3.weight"], P[f + ".fn.net.3.bias"], x)
     return x[0:1]

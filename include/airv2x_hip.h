@@ -450,9 +450,10 @@ int av2x_layernorm_backward(const float* x, const float* gamma, const float* dy,
 int av2x_gelu(const float* z, const float* dy, float* out, uint64_t n, av2x_stream_t stream);
 int av2x_scale_broadcast(const float* dy, float* dx, int32_t n_agents, uint64_t elems_per_agent, float scale, av2x_stream_t stream);
 int av2x_dropout(const float* x, const uint8_t* mask, float* y, uint64_t n, float scale, av2x_stream_t stream);
-/* nn.Dropout with the draw in the kernel: y = x * keep / (1 - p), keep regenerated from `seed` (Philox4x32-10, counter = index / 4) -- the
- * backward is the same call on dy with the forward's seed; no mask tensor.  n % 4 == 0, 0 <= p < 1. */
-int av2x_dropout_seeded(const float* x, float* y, uint64_t n, float p, uint64_t seed, av2x_stream_t stream);
+/* nn.Dropout with the draw in the kernel: y = x * keep / (1 - p) (+ residual, may be NULL: the skip connection a block adds after its
+ * dropout), keep regenerated from `seed` (Philox4x32-10, counter = index / 4) -- the backward is the same call on dy with the forward's seed
+ * and no residual; no mask tensor.  n % 4 == 0, 0 <= p < 1. */
+int av2x_dropout_seeded(const float* x, const float* residual, float* y, uint64_t n, float p, uint64_t seed, av2x_stream_t stream);
 uint64_t av2x_fax_attention_backward_workspace_bytes(int32_t n_agents_padded, int32_t window, int32_t heads);
 int av2x_fax_attention_backward(const float* qkv, const float* bias_table, const float* out, const float* dout,
                                 int32_t n_agents_padded, int32_t n_valid, int32_t h, int32_t w, int32_t window, int32_t heads,

@@ -86,6 +86,17 @@ def test_gelu_linear_mean_dropout():
     torch.manual_seed(123)
     b1 = Fo.dropout(big, 0.3)
     assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    # the skip connection added in the same launch: dropout(x) + r with the same draw; d r = dy, d x = the masked dy
+    xs, rs = torch.randn(3, 8, 12, 256, device="cuda", requires_grad=True), torch.randn(3, 8, 12, 256, device="cuda", requires_grad=True)
+    torch.manual_seed(5)
+    plain = Fo.dropout(xs.detach(), 0.2)
+    torch.manual_seed(5)
+    fused = Fo.dropout(xs, 0.2, True, rs)
+    assert torch.equal(fused.detach(), plain + rs.detach())
+    gy = torch.randn_like(fused)
+    fused.backward(gy)
+    assert torch.equal(rs.grad, gy) and torch.equal(xs.grad, gy * (plain != 0).float() / 0.8)
+    assert torch.equal(Fo.dropout(xs.detach(), 0.2, False, rs.detach()), xs.detach() + rs.detach())
 
 
 @pytest.mark.parametrize("L,n_valid,H,W,grid", [(3, 3, 8, 12, 0), (3, 2, 8, 8, 1), (7, 4, 8, 8, 0), (8, 8, 4, 8, 1), (7, 1, 4, 4, 0)])
