@@ -95,6 +95,88 @@ __global__ __launch_bounds__(256) void hgt_attention_backward_kernel(const HgtBw
     }
 }
 
+// The same for n <= NMAX agents with every key / value row of the pixel and every dk / dv accumulator in registers: proj is read once and
+// dproj written once (no read-modify-write per (query, key) pair, no pre-zeroing pass over the 1280-column gradient); the sums run over the
+// queries in the same order as above -- bit-identical to it.
+template <int NMAX>
+__global__ __launch_bounds__(256) void hgt_attention_backward_reg_kernel(const HgtBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= p.hw) return;
+    const int col = lane * 4;
+    constexpr int PC = 1280;
+    auto head_sum = [](float s) { s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); return s; };
+    float4 k[NMAX], v0[NMAX], v1[NMAX], dk[NMAX], dv0[NMAX], dv1[NMAX];
+    bool on[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        on[j] = false;
+        dk[j] = dv0[j] = dv1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < p.n) {
+            on[j] = p.mask[(size_t)j * p.hw + pix] != 0.f;
+            const float* kj = p.proj + ((size_t)j * p.hw + pix) * PC;
+            k[j] = *reinterpret_cast<const float4*>(kj + 512 + col);
+            v0[j] = *reinterpret_cast<const float4*>(kj + 768 + col);
+            v1[j] = *reinterpret_cast<const float4*>(kj + 1024 + col);
+        }
+    }
+    for (int i = 0; i < p.n; ++i) {
+        const int ti = p.types[i];
+        const float* qi = p.proj + ((size_t)i * p.hw + pix) * PC;
+        const float4 q0 = *reinterpret_cast<const float4*>(qi + col);
+        const float4 q1 = *reinterpret_cast<const float4*>(qi + 256 + col);
+        const float4 g = *reinterpret_cast<const float4*>(p.dout + ((size_t)i * p.hw + pix) * 256 + col);
+        float m = -INFINITY, l = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            if (j < p.n && on[j]) {
+                const float4 q = p.types[j] ? q1 : q0;
+                const float s = head_sum(q.x * k[j].x + q.y * k[j].y + q.z * k[j].z + q.w * k[j].w) * p.scale;
+                const float4 v = ti ? v1[j] : v0[j];
+                const float mn = fmaxf(m, s);
+                const float alpha = expf(m - mn), pj = expf(s - mn);
+                l = l * alpha + pj;
+                o.x = fmaf(pj, v.x, o.x * alpha); o.y = fmaf(pj, v.y, o.y * alpha);
+                o.z = fmaf(pj, v.z, o.z * alpha); o.w = fmaf(pj, v.w, o.w * alpha);
+                m = mn;
+            }
+        }
+        const float inv = 1.0f / l;
+        const float Di = head_sum(g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w) * inv;
+        float4 dq0 = make_float4(0.f, 0.f, 0.f, 0.f), dq1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            if (j < p.n && on[j]) {
+                const int tj = p.types[j];
+                const float4 q = tj ? q1 : q0;
+                const float s = head_sum(q.x * k[j].x + q.y * k[j].y + q.z * k[j].z + q.w * k[j].w) * p.scale;
+                const float4 v = ti ? v1[j] : v0[j];
+                const float pij = expf(s - m) * inv;
+                const float dp = head_sum(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w);
+                const float ds = pij * (dp - Di) * p.scale;
+                if (tj) { dq1.x = fmaf(ds, k[j].x, dq1.x); dq1.y = fmaf(ds, k[j].y, dq1.y); dq1.z = fmaf(ds, k[j].z, dq1.z); dq1.w = fmaf(ds, k[j].w, dq1.w); }
+                else { dq0.x = fmaf(ds, k[j].x, dq0.x); dq0.y = fmaf(ds, k[j].y, dq0.y); dq0.z = fmaf(ds, k[j].z, dq0.z); dq0.w = fmaf(ds, k[j].w, dq0.w); }
+                dk[j].x = fmaf(ds, q.x, dk[j].x); dk[j].y = fmaf(ds, q.y, dk[j].y); dk[j].z = fmaf(ds, q.z, dk[j].z); dk[j].w = fmaf(ds, q.w, dk[j].w);
+                if (ti) { dv1[j].x = fmaf(pij, g.x, dv1[j].x); dv1[j].y = fmaf(pij, g.y, dv1[j].y); dv1[j].z = fmaf(pij, g.z, dv1[j].z); dv1[j].w = fmaf(pij, g.w, dv1[j].w); }
+                else { dv0[j].x = fmaf(pij, g.x, dv0[j].x); dv0[j].y = fmaf(pij, g.y, dv0[j].y); dv0[j].z = fmaf(pij, g.z, dv0[j].z); dv0[j].w = fmaf(pij, g.w, dv0[j].w); }
+            }
+        }
+        float* dqi = p.dproj + ((size_t)i * p.hw + pix) * PC;
+        *reinterpret_cast<float4*>(dqi + col) = dq0;
+        *reinterpret_cast<float4*>(dqi + 256 + col) = dq1;
+    }
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        if (j < p.n) {
+            float* dj = p.dproj + ((size_t)j * p.hw + pix) * PC;
+            *reinterpret_cast<float4*>(dj + 512 + col) = dk[j];
+            *reinterpret_cast<float4*>(dj + 768 + col) = dv0[j];
+            *reinterpret_cast<float4*>(dj + 1024 + col) = dv1[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ window attention
 template <int DHD, int WS>
 __global__ __launch_bounds__(256) void window_attn_backward_q(const float* __restrict__ qkv, int ctot, int coff, const float* __restrict__ pos,
@@ -546,6 +628,12 @@ extern "C" int av2x_hgt_attention_backward(const float* proj, const float* mask,
     for (int i = 0; i < n; ++i) p.types[i] = types_host[i];
     p.scale = 1.0f / sqrtf((float)dim_head);
     hipStream_t st = av2x::as_stream(stream);
+    static const bool no_reg = [] { const char* e = getenv("AV2X_HGT_BWD_NO_REG"); return e && e[0] == '1'; }();
+    if (n <= 8 && !no_reg) {          // every column of dproj is written: no pre-zeroing
+        if (n <= 4) hipLaunchKernelGGL(hgt_attention_backward_reg_kernel<4>, dim3((hw + 3) / 4), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(hgt_attention_backward_reg_kernel<8>, dim3((hw + 3) / 4), dim3(256), 0, st, p);
+        return av2x::check_launch("hgt_attention_backward_reg_kernel");
+    }
     hipError_t e = hipMemsetAsync(dproj, 0, (size_t)n * hw * 1280 * sizeof(float), st);
     if (e != hipSuccess) return av2x::fail("av2x_hgt_attention_backward: memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(hgt_attention_backward_kernel, dim3((hw + 3) / 4), dim3(256), 0, st, p);
