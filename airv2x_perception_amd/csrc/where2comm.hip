@@ -211,9 +211,25 @@ __global__ __launch_bounds__(1024) void comm_topk_kernel(const float* __restrict
     K = K < 0 ? 0 : (K > hw ? hw : K);
     __shared__ int red[16];
     __shared__ int tot;
+    // the lane's cells as order keys in registers when the map fits (36 x 1024 cells: the 100 x 352 map does): the 33 bisection passes
+    // compare registers instead of re-reading the map from L2 (171 -> ~40 us per launch)
+    constexpr int KPT = 36;
+    const bool cached = hw <= KPT * 1024;
+    unsigned keys[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = tid + u * 1024;
+        keys[u] = (cached && i < hw) ? order_key(v[i]) : 0u;
+    }
+    const int mine = cached ? (hw > tid ? (hw - tid + 1023) / 1024 : 0) : 0;      // cells of this lane
     auto count_ge = [&](unsigned key) {
         int c = 0;
-        for (int i = tid; i < hw; i += 1024) c += order_key(v[i]) >= key;
+        if (cached) {
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) c += (u < mine && keys[u] >= key) ? 1 : 0;
+        } else {
+            for (int i = tid; i < hw; i += 1024) c += order_key(v[i]) >= key;
+        }
         for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
         __syncthreads();
         if (lane == 0) red[wave] = c;
