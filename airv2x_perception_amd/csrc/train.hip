@@ -487,6 +487,15 @@ inline int pillar_blocks(int n_pillars) {
     return blocks;
 }
 
+// pillar_moments_kernel ends with a 110-value fp64 wave reduction per wave (1 320 cross-lane moves) and a workgroup's pillars are few: one
+// round of workgroups (a CU each) instead of four amortises that epilogue (113 -> see profiles/r04l) and quarters the partials
+inline int pillar_moment_blocks(int n_pillars) {
+    int blocks = (n_pillars + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
 inline int ew_blocks(size_t n) {
     size_t b = (n + 255) / 256;
     if (b > 8192) b = 8192;
@@ -617,7 +626,7 @@ extern "C" int av2x_pillar_moments(const float* voxel_features, const int32_t* v
     if (!voxel_features || !voxel_coords || !voxel_num_points || !geom || !workspace || !moments)
         return av2x::fail("av2x_pillar_moments: null argument");
     if (n_pillars <= 0) return av2x::fail("av2x_pillar_moments: no pillars");
-    const int blocks = pillar_blocks(n_pillars);
+    const int blocks = pillar_moment_blocks(n_pillars);
     hipStream_t st = av2x::as_stream(stream);
     double* part = reinterpret_cast<double*>(workspace);
     hipLaunchKernelGGL(pillar_moments_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(voxel_features),
