@@ -53,6 +53,20 @@ def _place_cin(w, segments, cin_p):
     return out
 
 
+def _cam_calibration_on_host(ci):
+    """rots, trans, intrinsics, post_rots, post_trans of a camera batch as fp32 CPU tensors.  Device-resident inputs come back in ONE
+    read-back (concatenated on the device) instead of five: every .to("cpu") is a stream synchronise of its own."""
+    keys = ("rots", "trans", "intrinsics", "post_rots", "post_trans")
+    ts = [ci[k].detach() for k in keys]
+    if all(t.device.type == "cpu" for t in ts):
+        return [t.to(torch.float32) for t in ts]
+    B, N = ts[1].shape[:2]
+    dev = next(t.device for t in ts if t.device.type != "cpu")
+    flat = torch.cat([t.to(dev, torch.float32).reshape(B * N, -1) for t in ts], 1).to("cpu")
+    return [flat[:, 0:9].reshape(B, N, 3, 3), flat[:, 9:12].reshape(B, N, 3), flat[:, 12:21].reshape(B, N, 3, 3), flat[:, 21:30].reshape(B, N, 3, 3),
+            flat[:, 30:33].reshape(B, N, 3)]
+
+
 class CameraGeometry:
     """The weight-free part of one agent type's LiftSplatShootEncoder: frustum, BEV grid, depth bins and the per-camera matrices
     (airv2x_encoder.py:31-167).  The training forward (train_camera.py) uses it on its own; CameraEncoder builds the same values."""
@@ -90,8 +104,7 @@ class CameraGeometry:
 
     def _cam_params(self, ci):
         """(B*N, 24) device rows [inverse(post_rots) | post_trans | rots @ inverse(intrins) | trans] (airv2x_encoder.py:147-166)."""
-        f = lambda k: ci[k].detach().to("cpu", torch.float32)
-        rots, trans, intr, prot, ptr = f("rots"), f("trans"), f("intrinsics"), f("post_rots"), f("post_trans")
+        rots, trans, intr, prot, ptr = _cam_calibration_on_host(ci)
         B, N = trans.shape[:2]
         rows = torch.cat([torch.inverse(prot).reshape(B * N, 9), ptr.reshape(B * N, 3), rots.matmul(torch.inverse(intr)).reshape(B * N, 9),
                           trans.reshape(B * N, 3)], 1).contiguous()
@@ -247,8 +260,7 @@ class CameraEncoder:
     def _cam_params(self, ci):
         """(B*N, 24) device rows [inverse(post_rots) | post_trans | rots @ inverse(intrins) | trans] (airv2x_encoder.py:147-166),
         computed on the host in fp32 with the reference's own torch calls, like the V2X-ViT correction matrices."""
-        f = lambda k: ci[k].detach().to("cpu", torch.float32)
-        rots, trans, intr, prot, ptr = f("rots"), f("trans"), f("intrinsics"), f("post_rots"), f("post_trans")
+        rots, trans, intr, prot, ptr = _cam_calibration_on_host(ci)
         B, N = trans.shape[:2]
         rows = torch.cat([torch.inverse(prot).reshape(B * N, 9), ptr.reshape(B * N, 3), rots.matmul(torch.inverse(intr)).reshape(B * N, 9),
                           trans.reshape(B * N, 3)], 1).contiguous()
