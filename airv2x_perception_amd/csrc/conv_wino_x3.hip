@@ -29,6 +29,15 @@
 
 #include "x3_common.hpp"
 
+// timing experiments only (tools/micro/wx3_ablate.hip builds its OWN binary with this set; the library never defines it): bit 0 no
+// hi / mid / lo split, 1 no B fragment loads, 2 no patch gathers, 3 no input transform + LDS stores, 4 no A fragment reads, 5 no barrier
+#ifndef AV2X_WX3_ABLATE
+#define AV2X_WX3_ABLATE 0
+#endif
+#ifndef AV2X_WX3_SCHED
+#define AV2X_WX3_SCHED 1
+#endif
+
 namespace {
 
 struct WinoX3Params {
@@ -45,12 +54,20 @@ struct WinoX3Params {
     unsigned in_bytes, u_bytes, out_bytes;
 };
 
-template <int MB, bool GENERAL>
-__global__ __launch_bounds__(256, MB == 1 ? AV2X_X3_MB1_OCC : 1) void conv_wino_x3(const WinoX3Params p) {
+// MB = 32-tile blocks, NBK = 32-cout blocks per workgroup (MB x NBK x 4 positions = the accumulator tiles of a wave):
+//   (2, 2)  64 tiles x  64 couts: 256 accumulation registers, one wave per SIMD; an A fragment (split once) feeds 12 MFMAs
+//   (1, 2)  32 tiles x  64 couts: 128 registers, two workgroups per CU
+//   (1, 4)  32 tiles x 128 couts: 256 registers; an A fragment feeds 24 MFMAs -- HALF the split / transform instructions per MFMA
+//           (2.5 instead of 5: the (2, 2) form is issue-bound at one wave per SIMD), at the price of one B fragment per MFMA pair
+template <int MB, int NBK, bool GENERAL>
+__global__ __launch_bounds__(256, (MB == 1 && NBK == 2) ? AV2X_X3_MB1_OCC : 1) void conv_wino_x3(const WinoX3Params p) {
     constexpr int TB = 32 * MB;            // tiles per workgroup
     constexpr int CH = 2 * MB;             // channels gathered per thread (256 threads = TB tiles x 16 / CH channel groups)
-    constexpr int NG = 4 * MB;             // (xi, tile block) groups per chunk and wave; 12 MFMAs each
-    constexpr int STEPS = 12 * NG;
+    constexpr int NG = 4 * MB;             // (xi, tile block) groups per chunk and wave; GSZ MFMAs each
+    constexpr int GSZ = 6 * NBK;           // six partial products x NBK cout blocks per A fragment
+    constexpr int SPL = NBK / 2;           // the 12 split steps of the next fragment go to every SPL-th step of a group
+    constexpr int STEPS = GSZ * NG;
+    constexpr bool SPREAD = MB == 2 && NBK == 2 && AV2X_WX3_SCHED == 1;
     constexpr int NCG = 16 / CH;           // channel groups per tile and chunk
     constexpr int KQS = TB * 16 + 32;      // bytes per k quad: [tile TB][4 floats] + 32 (the pad keeps the gather threads' stores conflict-free)
     constexpr int POSB = 4 * KQS;          // bytes per position in a V stage: [k quad 4][tile TB][4 floats]
@@ -64,7 +81,7 @@ __global__ __launch_bounds__(256, MB == 1 ? AV2X_X3_MB1_OCC : 1) void conv_wino_
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
     const int mblock = swz / p.nblocks, nblock = swz - mblock * p.nblocks;
     const int t0 = mblock * TB;
-    const int n0 = nblock * 64;
+    const int n0 = nblock * (32 * NBK);
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.u), 0, p.u_bytes, 0x00020000);
@@ -73,21 +90,21 @@ __global__ __launch_bounds__(256, MB == 1 ? AV2X_X3_MB1_OCC : 1) void conv_wino_
     const unsigned voffU = (unsigned)(((lane >> 5) * p.CoutP + n0 + (lane & 31)) * 16);
     const int plane_stride = 32 * p.CoutP;                           // bytes
     const int kb_stride = 3 * plane_stride, pos_stride = (p.Cin >> 4) * kb_stride;
-    x3_u32x4 bs[2][2][3];                                           // [set][32-cout block][plane]
+    x3_u32x4 bs[2][NBK][3];                                         // [set][32-cout block][plane]
     auto load_b = [&](auto set_c, auto i_c, int xi, int kb) {       // i = 3 nb + plane
         constexpr int set = decltype(set_c)::value, i = decltype(i_c)::value;
         bs[set][i / 3][i % 3] = __builtin_bit_cast(x3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(
             ru, voffU + (i / 3) * 512, (4 * xi + nu) * pos_stride + kb * kb_stride + (i % 3) * plane_stride, 0));
     };
-    x3_static_for<0, 6>([&](auto i) { load_b(std::integral_constant<int, 0>{}, i, 0, 0); });
+    x3_static_for<0, 3 * NBK>([&](auto i) { load_b(std::integral_constant<int, 0>{}, i, 0, 0); });
 
-    f32x16 acc[4][MB][2];
+    f32x16 acc[4][MB][NBK];
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[xi][mb][nb][r] = 0.f;
 
@@ -191,8 +208,11 @@ __global__ __launch_bounds__(256, MB == 1 ? AV2X_X3_MB1_OCC : 1) void conv_wino_
     //                      fragment of chunk c was read in group NG - 3)
     //   groups NG-2, NG-1  read the first two A fragments of chunk c + 1; group NG-1 splits the first one -> no bubble between chunks
     //   steps GS ..        the patch of chunk c + 2 (its registers are free once V(c + 1) is stored)
-    constexpr int BST = 12 * (NG - 2) - 1;
-    constexpr int RS = MB == 2 ? 12 : 0, WS0 = RS + 8 * MB, WST = MB == 2 ? 2 : 1, GS = MB == 2 ? 60 : 24;
+    // (1, 4): the 12 B fragments of the next position go out in the first half of a group and the patch of chunk c + 2 in the second half
+    // of group 2 (+ 4 steps): the wait for the B fragments at the next group's first MFMA then leaves the younger patch loads in flight.
+    constexpr int BST = GSZ * (NG - 2) - 1;
+    constexpr int RS = MB == 2 ? 12 : 0, WS0 = RS + 8 * MB + (NBK == 4 ? 1 : 0), WST = (MB == 2 || NBK == 4) ? 2 : 1;
+    constexpr int GS = NBK == 4 ? 60 : MB == 2 ? 60 : 24;
     static_assert(WS0 + 15 * WST <= BST && GS + 16 <= STEPS && GS >= WS0 + 15 * WST, "schedule");
     for (int c = 0; c < p.chunks; ++c) {
         // branch-free body: V(c + 1) is always written (the last pass stores the re-fetched last chunk into the idle stage) and
@@ -201,80 +221,126 @@ __global__ __launch_bounds__(256, MB == 1 ? AV2X_X3_MB1_OCC : 1) void conv_wino_
         const int st = c & 1;
         x3_static_for<0, STEPS>([&](auto ss) {
             constexpr int s = decltype(ss)::value;
-            constexpr int g = s / 12, j = s % 12, xi = g / MB, mb = g % MB, pr = j >> 1, nb = j & 1;
+            constexpr int g = s / GSZ, j = s % GSZ, xi = g / MB, mb = g % MB, pr = j / NBK, nb = j % NBK;
             acc[xi][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 x3_frag(pl[g & 1][x3_ap(pr)]), __builtin_bit_cast(x3_bf16x8, bs[xi & 1][nb][x3_bp(pr)]),
                 acc[xi][mb][nb], 0, 0, 0);
+            constexpr int AB = AV2X_WX3_ABLATE;
             // split of the next group's A fragment (the last group: the first fragment of the next chunk)
-            x3_split_step<j>(raw[(g + 1) & 1], pl[(g + 1) & 1], sp);
+            if constexpr (j % SPL == 0 && !(AB & 1)) x3_split_step<j / SPL>(raw[(g + 1) & 1], pl[(g + 1) & 1], sp);
+            if constexpr (j == 0 && (AB & 1)) asm volatile("" :: "v"(raw[(g + 1) & 1][0]), "v"(raw[(g + 1) & 1][1]), "v"(raw[(g + 1) & 1][2]), "v"(raw[(g + 1) & 1][3]));
             // raw A fragment of group g + 2 (of the next chunk from group NG - 2 on) into the buffer the split of group g has released
-            if constexpr (j == 4 || j == 9) {
-                using HALF = std::integral_constant<int, j == 4 ? 0 : 1>;
+            if constexpr ((j == 4 * SPL || j == 9 * SPL) && !(AB & 16)) {
+                using HALF = std::integral_constant<int, j == 4 * SPL ? 0 : 1>;
                 if constexpr (g + 2 < NG) read_a(std::integral_constant<int, g & 1>{}, HALF{}, g + 2, st);
                 else read_a(std::integral_constant<int, g & 1>{}, HALF{}, g + 2 - NG, st ^ 1);
             }
             // B fragments of the NEXT position into the other register set (its last reader was position xi - 1)
-            if constexpr (mb == 0 && (j == 1 || j == 2 || j == 3 || j == 6 || j == 7 || j == 8)) {
-                using IB = std::integral_constant<int, j < 4 ? j - 1 : j - 3>;
-                if constexpr (xi < 3) load_b(std::integral_constant<int, (xi + 1) & 1>{}, IB{}, xi + 1, c);
-                else load_b(I0{}, IB{}, 0, c1);
+            if constexpr (SPREAD) {
+                // (2, 2), spread form: the vector-memory path (64 B/clk per CU: a 1-KB wave-load is 16 cycles of it, 160 KB per chunk = 2 560
+                // of the chunk's 3 072 matrix cycles) is what the four in-order waves block on, so no two memory instructions share a step and
+                // no burst fills the queue: B fragments on the odd steps 1..11 of a position, patch loads on its odd steps 13..23 -- AFTER the
+                // B loads, so that the wait for the B fragments at the next position's first MFMA leaves them in flight --, LDS stores on even
+                // steps.  Patch row a = k >> 2 of chunk c + 2 is loaded as soon as (B^T d) B of that row of chunk c + 1 has been stored.
+                constexpr int sl = s % (2 * GSZ);
+                if constexpr ((sl & 1) && sl < 12 && !(AB & 2)) {
+                    using IB = std::integral_constant<int, sl / 2>;
+                    if constexpr (xi < 3) load_b(std::integral_constant<int, (xi + 1) & 1>{}, IB{}, xi + 1, c);
+                    else load_b(I0{}, IB{}, 0, c1);
+                }
+                constexpr int gk = xi == 1 ? (sl - 13) / 2 : xi == 2 ? 4 + (sl - 13) / 2 : xi == 3 ? 10 + (sl - 13) / 2 : -1;
+                if constexpr ((sl & 1) && sl >= 13 && gk >= 0 && gk < (xi == 1 ? 4 : xi == 2 ? 10 : 16) && !(AB & 4))
+                    gather(std::integral_constant<int, gk>{}, c2);
+            } else {
+                constexpr bool bld = NBK == 4 ? (j < 12) : (j == 1 || j == 2 || j == 3 || j == 6 || j == 7 || j == 8);
+                if constexpr (mb == 0 && bld && !(AB & 2)) {
+                    using IB = std::integral_constant<int, NBK == 4 ? j : (j < 4 ? j - 1 : j - 3)>;
+                    if constexpr (xi < 3) load_b(std::integral_constant<int, (xi + 1) & 1>{}, IB{}, xi + 1, c);
+                    else load_b(I0{}, IB{}, 0, c1);
+                }
+                if constexpr (s >= GS && s < GS + 16 && !(AB & 4)) gather(std::integral_constant<int, s - GS>{}, c2);
             }
-            if constexpr (s >= RS && s < RS + 8 * MB) rows(std::integral_constant<int, s - RS>{});
-            if constexpr (s >= WS0 && s <= WS0 + 15 * WST && (s - WS0) % WST == 0) cols(std::integral_constant<int, (s - WS0) / WST>{}, st ^ 1);
-            if constexpr (s >= GS && s < GS + 16) gather(std::integral_constant<int, s - GS>{}, c2);
-            if constexpr (s == BST) x3_lds_barrier();   // LDS traffic only: the register prefetches stay in flight
+            if constexpr (s >= RS && s < RS + 8 * MB && !(AB & 8)) rows(std::integral_constant<int, s - RS>{});
+            if constexpr (s >= WS0 && s <= WS0 + 15 * WST && (s - WS0) % WST == 0 && !(AB & 8)) cols(std::integral_constant<int, (s - WS0) / WST>{}, st ^ 1);
+            if constexpr (s == BST && !(AB & 32)) x3_lds_barrier();   // LDS traffic only: the register prefetches stay in flight
             __builtin_amdgcn_sched_barrier(0);
         });
     }
     __syncthreads();
+    if constexpr ((AV2X_WX3_ABLATE & 64) != 0) {   // timing only: no exchange, no output transform, one store per lane
+        float t = 0.f;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[xi][mb][nb][r];
+        p.out[(size_t)b * 256 + tid] = t;
+        return;
+    }
 
-    // ---- Z[a] = A^T over xi (lane-local): Z[0] = (M0 + M1) + M2, Z[1] = (M1 - M2) - M3; every wave publishes its Z for all of its
-    // 64 MB (tile block, cout block, row, a) slots; wave w then finalises slots [16 MB w, 16 MB (w + 1)) x {a}: y[a][0] = (Z0 + Z1) + Z2,
-    // y[a][1] = (Z1 - Z2) - Z3 over the four waves' Z
-    float* X = reinterpret_cast<float*>(smem);   // [nu][slot = ((mb 2 + nb) 16 + r) 2 + a][64 lanes]
-    constexpr int NSLOT = MB * 2 * 16 * 2;
+    // ---- Z[a] = A^T over xi (lane-local): Z[0] = (M0 + M1) + M2, Z[1] = (M1 - M2) - M3.  Every wave publishes its (Z[0], Z[1]) pairs
+    // through LDS as X[nu][slot = (mb NBK + nb) 16 + r][lane][a] (one ds_write_b64 per accumulator row).  The finalising side reads them
+    // COUT-MAJOR: four consecutive lanes of a slot are four consecutive couts of one tile, so a thread takes (tile, cout quad) items --
+    // two ds_read_b128 per position column -- computes y[a][0] = (Z0 + Z1) + Z2, y[a][1] = (Z1 - Z2) - Z3 over the four waves' Z for
+    // its four couts and stores each of the 2 x 2 output pixels as ONE 16-byte store; 16 (32) consecutive lanes write the 256 (512)
+    // contiguous bytes of a pixel.  (Round 4 stored one dword per lane and pixel: 64 store instructions per lane, 6.9 of a 49-us launch.)
+    float* X = reinterpret_cast<float*>(smem);
+    constexpr int NS = MB * NBK * 16;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float* xp = X + ((nu * NSLOT + ((mb * 2 + nb) * 16 + r) * 2) * 64) + lane;
-                xp[0] = acc[0][mb][nb][r] + acc[1][mb][nb][r] + acc[2][mb][nb][r];
-                xp[64] = acc[1][mb][nb][r] - acc[2][mb][nb][r] - acc[3][mb][nb][r];
+                x3_f32x2 zz;
+                zz.x = acc[0][mb][nb][r] + acc[1][mb][nb][r] + acc[2][mb][nb][r];
+                zz.y = acc[1][mb][nb][r] - acc[2][mb][nb][r] - acc[3][mb][nb][r];
+                *reinterpret_cast<x3_f32x2*>(X + ((nu * NS + (mb * NBK + nb) * 16 + r) * 64 + lane) * 2) = zz;
             }
     __syncthreads();
-    // wave w finalises: MB = 2: (mb, nb) = (w >> 1, w & 1), rows 0..15;  MB = 1: nb = w & 1, rows 8 (w >> 1) .. + 7
-    constexpr int NR = MB == 2 ? 16 : 8;
-    const int fmb = MB == 2 ? (nu >> 1) : 0, fnb = nu & 1, r0 = MB == 2 ? 0 : 8 * (nu >> 1);
-    const int n = n0 + fnb * 32 + (lane & 31);
+    constexpr int CQ = 8 * NBK;                    // cout quads of the workgroup
+    constexpr int RW = 4 * MB;                     // accumulator rows (of the 16 MB row slots) a wave finalises
+    constexpr int ITS = RW * 2 * CQ / 64;          // items per lane
+    const int q = lane % CQ, fnb = q >> 3, j4 = (q & 7) * 4;
+    const int n = n0 + fnb * 32 + j4;
     const bool nok = n < p.Cout;
-    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-    const float sh = nok ? p.shift[n] : 0.f;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (nok) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    }
     const bool relu1 = p.relu == 1;
-    // row r of a 32 x 32 accumulator tile is tile (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the block
-    int t = t0 + 32 * fmb + 4 * (lane >> 5) + (r0 & 3) + 8 * (r0 >> 2);
-    int img = t / p.tiles_per_img;
-    int ty = (t - img * p.tiles_per_img) / p.TW;
-    int tx = t - img * p.tiles_per_img - ty * p.TW;
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const unsigned ocol = (unsigned)((p.out_coff + n) * 4);
     const int opix = p.out_ctot * 4;
-    const int slot0 = ((fmb * 2 + fnb) * 16 + r0) * 2;
 #pragma unroll
-    for (int rs = 0; rs < NR; ++rs) {
-        float z[2][4];
+    for (int it = 0; it < ITS; ++it) {
+        const int idx = lane / CQ + (64 / CQ) * it;        // (row of the wave's RW, half-wave of the accumulator tile)
+        const int gr = nu * RW + (idx >> 1), kh = idx & 1;
+        const int fmb = gr >> 4, r = gr & 15;
+        // row r of a 32 x 32 accumulator tile is tile (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the block
+        const int t = t0 + 32 * fmb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int img = t / p.tiles_per_img, rem = t - img * p.tiles_per_img;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        f32x4 z[4][2];                                      // [position column v][4 couts x (Z0, Z1)]
+        const float* xs = X + (((fmb * NBK + fnb) * 16 + r) * 64 + kh * 32 + j4) * 2;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            z[0][v] = X[(v * NSLOT + slot0 + rs * 2) * 64 + lane];
-            z[1][v] = X[(v * NSLOT + slot0 + rs * 2 + 1) * 64 + lane];
+            z[v][0] = *reinterpret_cast<const f32x4*>(xs + v * NS * 128);
+            z[v][1] = *reinterpret_cast<const f32x4*>(xs + v * NS * 128 + 4);
         }
-        float y[2][2];
+        f32x4 y[2][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            y[a][0] = (z[a][0] + z[a][1]) + z[a][2];
-            y[a][1] = (z[a][1] - z[a][2]) - z[a][3];
-        }
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int w = cc >> 1, e = (cc & 1) * 2 + a;
+                y[a][0][cc] = (z[0][w][e] + z[1][w][e]) + z[2][w][e];
+                y[a][1][cc] = (z[1][w][e] - z[2][w][e]) - z[3][w][e];
+            }
         const bool tvalid = nok && t < p.T;
         const int py = 2 * ty, px = 2 * tx;
         const unsigned pix = (unsigned)(((img * p.H + py) * p.W + px) * opix) + ocol;    // < 2^31 (checked by the host)
@@ -284,29 +350,29 @@ __global__ __launch_bounds__(256, MB == 1 ? AV2X_X3_MB1_OCC : 1) void conv_wino_
             for (int e = 0; e < 2; ++e) {
                 const bool ok = tvalid && py + a < p.H && px + e < p.W;
                 const unsigned off = ok ? pix + (unsigned)((a * p.W + e) * opix) : 0x80000000u;
-                float v = y[a][e] * sc + sh;
+                f32x4 v = y[a][e] * sc + sh;
                 if (GENERAL) {
-                    if (p.relu == 1) v = fmaxf(v, 0.f);
-                    else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
-                    else if (p.relu == 4) v = tanhf(v);
+                    f32x4 rs = {0.f, 0.f, 0.f, 0.f};
                     if (p.res && ok) {
                         const size_t m = (size_t)(off - ocol) / (size_t)opix;
-                        v = (p.relu == 4) ? v * p.res[m * p.Cout + n] : v + p.res[m * p.out_ctot + p.out_coff + n];
+                        rs = *reinterpret_cast<const f32x4*>(p.relu == 4 ? p.res + m * p.Cout + n : p.res + m * p.out_ctot + p.out_coff + n);
                     }
-                    if (p.relu == 5) v = fmaxf(v, 0.f);                  // ReLU after the residual add (ResNet BasicBlock)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        float u = v[cc];
+                        if (p.relu == 1) u = fmaxf(u, 0.f);
+                        else if (p.relu == 3) u = 1.0f / (1.0f + expf(-u));
+                        else if (p.relu == 4) u = tanhf(u);
+                        if (p.res && ok) u = (p.relu == 4) ? u * rs[cc] : u + rs[cc];
+                        if (p.relu == 5) u = fmaxf(u, 0.f);                  // ReLU after the residual add (ResNet BasicBlock)
+                        v[cc] = u;
+                    }
                 } else {
-                    v = relu1 ? fmaxf(v, 0.f) : v;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) v[cc] = relu1 ? fmaxf(v[cc], 0.f) : v[cc];
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(x3_u32x4, v), rout, off, 0, 0);
             }
-        // next row of this lane: +1 tile, or +5 after every fourth (rows 4k+3 -> 4(k+1) skip the other half-wave's four)
-        const int step = (rs & 3) == 3 ? 5 : 1;
-        t += step;
-        tx += step;
-        while (tx >= p.TW) {
-            tx -= p.TW;
-            if (++ty >= p.TH) { ty = 0; ++img; }
-        }
     }
 }
 
@@ -357,22 +423,23 @@ __global__ void wino_x3_pack_kernel(const float* __restrict__ w, unsigned short*
     }
 }
 
-template <int MB>
+template <int MB, int NBK>
 static int launch_wino_x3(const WinoX3Params& p0, hipStream_t st) {
     WinoX3Params p = p0;
     constexpr int TB = 32 * MB;
-    p.nblocks = p.Cout / 64;
+    p.nblocks = p.Cout / (32 * NBK);
     const int mblocks = (p.T + TB - 1) / TB;
     size_t lds = 2ull * 16 * 4 * (TB * 16 + 32);
+    if (lds < 4ull * (MB * NBK * 32) * 64 * 4) lds = 4ull * (MB * NBK * 32) * 64 * 4;    // the output exchange: [wave][slot][lane] fp32
     if (const char* pad = getenv("AV2X_X3_LDS_PAD")) lds += (size_t)atoi(pad);   // debug probe (tools/debug/dbg_attn.py)
     const bool general = p.res || (p.relu != 0 && p.relu != 1);
     static av2x::LdsLimit lim_s, lim_g;
     if (general) {
-        lim_g.ensure(reinterpret_cast<const void*>(&conv_wino_x3<MB, true>), lds);
-        hipLaunchKernelGGL((conv_wino_x3<MB, true>), dim3(mblocks * p.nblocks), dim3(256), lds, st, p);
+        lim_g.ensure(reinterpret_cast<const void*>(&conv_wino_x3<MB, NBK, true>), lds);
+        hipLaunchKernelGGL((conv_wino_x3<MB, NBK, true>), dim3(mblocks * p.nblocks), dim3(256), lds, st, p);
     } else {
-        lim_s.ensure(reinterpret_cast<const void*>(&conv_wino_x3<MB, false>), lds);
-        hipLaunchKernelGGL((conv_wino_x3<MB, false>), dim3(mblocks * p.nblocks), dim3(256), lds, st, p);
+        lim_s.ensure(reinterpret_cast<const void*>(&conv_wino_x3<MB, NBK, false>), lds);
+        hipLaunchKernelGGL((conv_wino_x3<MB, NBK, false>), dim3(mblocks * p.nblocks), dim3(256), lds, st, p);
     }
     return av2x::check_launch("conv_wino_x3");
 }
@@ -391,6 +458,7 @@ int wino_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, co
     if (d->cin % 16 || d->cout % 64 || d->coutp % 64 || d->cout > d->coutp)
         return fail("av2x_conv2d: split-3 Winograd needs cin %% 16 == 0 and cout %% 64 == 0 (cin=%d cout=%d)", d->cin, d->cout);
     if (d->in_coff % 4 || d->in_ctot % 4) return fail("av2x_conv2d: input channel offset/stride must be multiples of 4");
+    if (d->out_coff % 4 || d->out_ctot % 4) return fail("av2x_conv2d: split-3 Winograd stores 16-byte cout quads: output channel offset/stride must be multiples of 4");
     WinoX3Params p;
     p.in = in; p.u = u; p.scale = scale; p.shift = shift; p.res = residual; p.out = out;
     p.H = d->h; p.W = d->w; p.Cin = d->cin; p.in_ctot = d->in_ctot; p.in_coff = d->in_coff;
@@ -412,10 +480,10 @@ int wino_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, co
     if (out_bytes >= (1ull << 31)) return fail("av2x_conv2d: output (%llu B) exceeds the 2 GiB buffer-descriptor window", out_bytes);
     p.out_bytes = (unsigned)out_bytes;
     const int tb = (d->tile >> 16) & 0x3fff, cb = d->tile & 0x01ff;
-    if (cb != 64) return fail("av2x_conv2d: the split-3 Winograd tiles are 64 x 64 and 32 x 64 (tile %dx%d)", tb, cb);
-    if (tb == 64) return launch_wino_x3<2>(p, st);
-    if (tb == 32) return launch_wino_x3<1>(p, st);
-    return fail("av2x_conv2d: the split-3 Winograd tiles are 64 x 64 and 32 x 64 (tile %dx%d)", tb, cb);
+    if (tb == 64 && cb == 64) return launch_wino_x3<2, 2>(p, st);
+    if (tb == 32 && cb == 64) return launch_wino_x3<1, 2>(p, st);
+    if (tb == 32 && cb == 128 && d->cout % 128 == 0) return launch_wino_x3<1, 4>(p, st);
+    return fail("av2x_conv2d: the split-3 Winograd tiles are 64 x 64, 32 x 64 and 32 x 128 (tile %dx%d, cout %d)", tb, cb, d->cout);
 }
 
 }  // namespace av2x

@@ -16,7 +16,12 @@ from tests.helpers import assert_close, load_fixture
 
 pytestmark = pytest.mark.gpu
 
-X3 = {"64x64": 0x40000400 | (64 << 16) | 64, "32x64": 0x40000400 | (32 << 16) | 64}
+X3 = {"64x64": 0x40000400 | (64 << 16) | 64, "32x64": 0x40000400 | (32 << 16) | 64, "32x128": 0x40000400 | (32 << 16) | 128}
+
+
+def _tiles(cout):
+    """the 32 x 128 form (an A fragment split once for 128 couts) needs whole 128-cout blocks"""
+    return {k: t for k, t in X3.items() if k != "32x128" or cout % 128 == 0}
 F32H = 0x40000000 | (32 << 16) | 64 | 0x8000
 CASES = [
     # n, h, w, cin, cout, relu
@@ -81,7 +86,7 @@ def test_error_against_fp64_not_above_the_fp32_winograd_kernel_and_tilings_agree
     errs = {}
     outs = {}
     scale_d, shift_d = scale.cuda(), shift.cuda()
-    for name, tile, wgt in [("f32", F32H, u)] + [(k, t, u3) for k, t in X3.items()]:
+    for name, tile, wgt in [("f32", F32H, u)] + [(k, t, u3) for k, t in _tiles(cout).items()]:
         out = torch.full((n, h, w, cout), float("nan"), device="cuda")
         _run(lib, xn, wgt, scale_d, shift_d, None, out, tile, relu, cin, cout, coutp)
         o = out.cpu()
@@ -89,7 +94,9 @@ def test_error_against_fp64_not_above_the_fp32_winograd_kernel_and_tilings_agree
         e = (o.double() - ref).abs()
         errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
         outs[name] = o
-    assert torch.equal(outs["64x64"], outs["32x64"]), "the two split-3 tilings must give the same bits"
+    assert torch.equal(outs["64x64"], outs["32x64"]), "the split-3 tilings must give the same bits"
+    if "32x128" in outs:
+        assert torch.equal(outs["64x64"], outs["32x128"]), "the split-3 tilings must give the same bits"
     floor = 2.0 ** -23 * max(1.0, float(ref.abs().max()))          # one fp32 ulp of the largest output
     assert errs["64x64"][1] <= errs["f32"][1] * 1.02 + 0.02 * floor, errs     # rms: not above the fp32-MFMA kernel's
     assert errs["64x64"][0] <= errs["f32"][0] * 1.10 + floor, errs            # max: a single element, allow its rounding
@@ -111,12 +118,12 @@ def test_epilogues_and_residual(lib, act, with_res):
     xn = x.permute(0, 2, 3, 1).contiguous().cuda()
     outs = []
     bias_d, res_d = bias.cuda(), res.cuda()
-    for tile in X3.values():
+    for tile in _tiles(cout).values():
         out = torch.full((n, h, w, cout), float("nan"), device="cuda")
         _run(lib, xn, u3, None, bias_d, res_d if with_res else None, out, tile, act, cin, cout, coutp)
         assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
         outs.append(out.cpu())
-    assert torch.equal(outs[0], outs[1])
+    assert len(outs) == 3 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_channel_slices_and_argument_checks(lib):
@@ -130,7 +137,7 @@ def test_channel_slices_and_argument_checks(lib):
     u, u3, coutp = _pack(lib, wt)
     ref = F.relu(F.conv2d(xw[..., 32:].permute(0, 3, 1, 2).double(), wt.double(), shift.double(), padding=1)).permute(0, 2, 3, 1)
     xw_d, shift_d = xw.cuda(), shift.cuda()
-    for tile in X3.values():
+    for tile in _tiles(cout).values():
         out = torch.full((n, h, w, cout + 64), 7.0, device="cuda")
         _run(lib, xw_d, u3, None, shift_d, None, out, tile, 1, cin, cout, coutp, in_ctot=cin + 32, in_coff=32,
              out_ctot=cout + 64, out_coff=64)

@@ -1,0 +1,48 @@
+// Timing harness for conv_wino_x3 with pieces of its K loop removed (AV2X_WX3_ABLATE, see csrc/conv_wino_x3.hip): which of the side
+// streams (split, B fragments from L2, patch gathers, transform + LDS stores, A reads, barrier) the MFMA steps wait for.  Results of
+// the ablated builds are numerically meaningless; only the durations are read.  Build + run: tools/micro/wx3_ablate.sh
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../airv2x_perception_amd/csrc/conv_wino_x3.hip"
+
+int main(int argc, char** argv) {
+    const int tb = argc > 1 ? atoi(argv[1]) : 64, cb = argc > 2 ? atoi(argv[2]) : 64;
+    const int n = argc > 3 ? atoi(argv[3]) : 4, h = argc > 4 ? atoi(argv[4]) : 25, w = argc > 5 ? atoi(argv[5]) : 88;
+    const int cin = argc > 6 ? atoi(argv[6]) : 256, cout = 256;
+    const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
+    float *in, *out, *wp, *shift;
+    void* u;
+    hipMalloc(&in, in_e * 4); hipMalloc(&out, out_e * 4); hipMalloc(&wp, 9ull * cin * cout * 4); hipMalloc(&shift, cout * 4);
+    hipMalloc(&u, av2x_wino_x3_weight_bytes(cin, cout));
+    std::vector<float> hin(in_e), hw(9ull * cin * cout);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+    for (auto& v : hin) v = rnd();
+    for (auto& v : hw) v = rnd() * 0.05f;
+    hipMemcpy(in, hin.data(), in_e * 4, hipMemcpyHostToDevice);
+    hipMemcpy(wp, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(shift, 0, cout * 4);
+    if (av2x_wino_x3_pack_weights(wp, cin, cout, u, nullptr)) { printf("pack failed: %s\n", av2x_last_error()); return 1; }
+    av2x_conv_desc d{};
+    d.n = n; d.h = h; d.w = w; d.cin = cin; d.in_ctot = cin; d.in_coff = 0; d.ho = h; d.wo = w; d.cout = cout; d.coutp = cout;
+    d.out_ctot = cout; d.out_coff = 0; d.ks = 3; d.stride = 1; d.pad = 1; d.relu = 1; d.mode = AV2X_CONV; d.up = 1;
+    d.tile = 0x40000400 | (tb << 16) | cb;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i)
+        if (av2x::wino_x3_dispatch(&d, in, u, nullptr, shift, nullptr, out, nullptr)) { printf("launch failed: %s\n", av2x_last_error()); return 1; }
+    hipDeviceSynchronize();
+    const int iters = 50;
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) av2x::wino_x3_dispatch(&d, in, u, nullptr, shift, nullptr, out, nullptr);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 2.0 * n * h * w * cout * 9 * cin;
+    printf("ablate=%2d tile %dx%d n=%d %dx%d cin=%d: %.1f us  (%.1f TF bf16 executed)\n", AV2X_WX3_ABLATE, tb, cb, n, h, w, cin, ms * 1e3 / iters,
+           flops * 16 / 36 * 6 / (ms * 1e-3 / iters) / 1e12);
+    return 0;
+}

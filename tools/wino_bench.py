@@ -25,7 +25,7 @@ LAYERS = {
 WINO = {"w32x128": (32, 128), "w64x64": (64, 64), "w32x64": (32, 64), "w32x64h": (32, 64 | 0x8000), "w32x32q": (32, 32 | 0x8000)}
 DIRECT = {"g64x64": (64, 64 | 0x0200), "g128x64w8": (128, 64 | 0x8200)}
 # split-3 Winograd (csrc/conv_wino_x3.hip): three bf16 terms per fp32 operand on v_mfma_f32_32x32x16_bf16
-X3 = {"x3_64x64": (64, 64 | 0x0400), "x3_32x64": (32, 64 | 0x0400)}
+X3 = {"x3_64x64": (64, 64 | 0x0400), "x3_32x64": (32, 64 | 0x0400), "x3_32x128": (32, 128 | 0x0400)}
 
 
 def main():
@@ -110,7 +110,7 @@ def main():
                 ex = f" {flops*36/144*6/us/1e6:7.1f} TF bf16 executed" if tn == "w4_x3" else f" {flops*36/144/us/1e6:7.1f} TF executed"
                 print(f"   {tn:10s} {us:7.1f} us {flops/us/1e6:6.1f} TF(eff){ex}{err}{dv} nan={int(torch.isnan(y).sum())}", flush=True)
         for tn, (tb, cb) in X3.items():
-            if u3 is None or (a.tiles and tn not in a.tiles.split(",")):
+            if u3 is None or (a.tiles and tn not in a.tiles.split(",")) or cout % (cb & 0x1ff):
                 continue
             us, y = run(0x40000000 | (tb << 16) | cb, u3)
             err = f" err64={float((y.double() - ref).abs().max()):.2e} rms={float((y.double() - ref).pow(2).mean().sqrt()):.2e}" if ref is not None else ""
