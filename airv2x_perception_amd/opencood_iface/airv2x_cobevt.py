@@ -17,8 +17,8 @@ class Airv2xCoBEVT(nn.Module):
         if args.get("task", "det") != "det":
             raise NotImplementedError("only the det task is on the MI355X hot path")
         for t in args["collaborators"]:
-            if args[t]["modalities"] != ["lidar"]:
-                raise NotImplementedError("LiDAR-only agents")
+            if not args[t]["modalities"] or any(m not in ("lidar", "cam") for m in args[t]["modalities"]):
+                raise NotImplementedError(f"Modality {args[t]['modalities']} not supported for {t}.")   # airv2x_base_model.py:57,78,99
         self.args = args
         self.collaborators = args["collaborators"]
         self.active_sensors = args["active_sensors"]

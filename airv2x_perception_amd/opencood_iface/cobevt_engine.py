@@ -48,30 +48,6 @@ class CoBEVTEngine(Where2ComEngine):
         b = sd[bkey].detach().float() if bkey else torch.zeros(w.shape[0])
         return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
 
-    def _load_compressor(self, sd, up, prefix="naive_compressor"):
-        """NaiveCompressor (naive_compress.py:10-36): three Conv3x3(+bias)+BN(eps 1e-3)+ReLU layers; the conv bias
-        is folded into the BN shift.  Layer 0 is the encoder (its C/ratio-channel output is the message a
-        multi-GPU deployment would all-gather), layers 1-2 the decoder."""
-        layers = []
-        pre = prefix + "." if prefix else ""
-        for conv, bn in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
-            w = sd[f"{pre}{conv}.weight"].detach().float()
-            sc, sh = fold_bn(sd, f"{pre}{bn}")
-            sh = sh + sd[f"{pre}{conv}.bias"].detach().float().cpu() * sc
-            wp, coutp = pack_conv_weight(w)
-            layers.append(ConvLayer(up(wp), up(sc), up(sh), w.shape[1], w.shape[0], coutp, 3, 1, 1, 1))
-        return layers
-
-    def run_compressor(self, x, n, H, W):
-        """x (n,H,W,C) -> encoder -> decoder, result written back into x."""
-        enc, dec0, dec1 = self.compressor
-        msg = self.buf("compress_msg", (n, H, W, enc.cout), self.msg_dtype())     # autocast: the bf16 message the sharded frame sends
-        self.conv(enc, x, n, H, W, msg)
-        mid = self.buf("compress_mid", (n, H, W, dec0.cout))
-        self.conv(dec0, msg, n, H, W, mid)
-        self.conv(dec1, mid, n, H, W, x)
-        return msg
-
     def _load_fusion(self, sd, up, prefix="fusion_net."):
         if self.compression:
             self.compressor = self._load_compressor(sd, up)

@@ -132,8 +132,8 @@ def _forward_train(model, data_dict):
     r = _runner(dev)
     mf = args["modality_fusion"]
     bb = mf["base_bev_backbone"]
-    if mf.get("compression", 0):
-        raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+    from ..synth import model_compression
+    compression = model_compression(args)          # NaiveCompressor(256, args["compression"]) behind the shrink header, as the reference reads it
     record_len, slots = frame_layout(args["collaborators"], data_dict)
     B, n = len(record_len), sum(record_len)
     if n == 0:
@@ -147,6 +147,9 @@ def _forward_train(model, data_dict):
         feats.append(x)
     s = torch.cat([_deblock(P, sd, i, f, 1) for i, f in enumerate(feats)], -1)
     s = _shrink(P, mf["shrink_header"], s)
+    if compression:
+        from .train_cobevt import _compressor
+        s = _compressor(P, sd, s)
     prior = data_dict["prior_encoding"].detach().cpu().numpy()
     scm = data_dict["spatial_correction_matrix"].detach().cpu().numpy()
     fused, a0 = [], 0

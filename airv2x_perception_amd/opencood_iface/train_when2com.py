@@ -193,8 +193,8 @@ def _forward_train(model, data_dict):
     bb, w2 = mf["base_bev_backbone"], args["when2com_fusion"]
     if w2["mode"] != "softmax":
         raise NotImplementedError("When2com mode %r: only the shipped 'softmax' mode is built" % (w2["mode"],))
-    if mf.get("compression", 0):
-        raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+    from ..synth import model_compression
+    compression = model_compression(args)          # NaiveCompressor(256, args["compression"]) behind the shrink header, as the reference reads it
     record_len, slots = frame_layout(args["collaborators"], data_dict)
     B, n = len(record_len), sum(record_len)
     if n == 0:
@@ -206,6 +206,9 @@ def _forward_train(model, data_dict):
         feats.append(x)
     s = torch.cat([_deblock(P, sd, i, f, 1) for i, f in enumerate(feats)], -1)
     s = _shrink(P, mf["shrink_header"], s)
+    if compression:
+        from .train_cobevt import _compressor
+        s = _compressor(P, sd, s)
     H, W = s.shape[1:3]
     # communication_rates (:118): non-zeros of the maps the agents share
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -32,8 +32,10 @@ class V2XViTEngine(Where2ComEngine):
         self.bb = args["modality_fusion"]["base_bev_backbone"]
         self.sh = args["modality_fusion"]["shrink_header"]
         self.fcfg = {"fully": False}
-        if args["modality_fusion"].get("compression", 0):
-            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        from ..synth import model_compression
+        self.compression = model_compression(args)     # airv2x_v2xvit.py:42-44: NaiveCompressor(256, args["compression"]) in front of the fusion
+        if self.compression and (256 % self.compression or (256 // self.compression) % 32):
+            raise NotImplementedError(f"compression {self.compression}: 256/ratio must be a multiple of 32 channels")
         self.enc = args["transformer"]["encoder"]
         self.cav, self.pw = self.enc["cav_att_config"], self.enc["pwindow_att_config"]
         if not self.cav["use_hetero"] or self.pw["fusion_method"] != "split_attn" or not self.pw["relative_pos_embedding"]:
@@ -42,7 +44,7 @@ class V2XViTEngine(Where2ComEngine):
         # the encoder's output is the ego's feature map only: skip what the last layer computes for the other agents
         self.ego_only_last = True
 
-    FUSION_WEIGHTS = ("layers", "rte_table", "rte_lin")
+    FUSION_WEIGHTS = ("layers", "rte_table", "rte_lin", "compressor")
 
     def _lin(self, w, b, act, up):
         w = w.detach().float()
@@ -51,6 +53,7 @@ class V2XViTEngine(Where2ComEngine):
         return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
 
     def _load_fusion(self, sd, up, p="fusion_net.encoder"):
+        self.compressor = self._load_compressor(sd, up) if self.compression else None
         heads, dh = self.cav["heads"], self.cav["dim_head"]
         self.layers = []
         for d in range(self.enc["depth"]):
@@ -484,6 +487,9 @@ class V2XViTEngine(Where2ComEngine):
         ``data_dict_local`` carries the frame-level ``prior_encoding`` / ``spatial_correction_matrix`` (host
         metadata of ALL agents, (1,L,.)) even on a rank without agents; stats = [0, canvas non-zeros] (summed over
         ranks = comm_rate)."""
+        if getattr(self, "compression", 0):
+            raise NotImplementedError("agent-sharded %s frame with a NaiveCompressor: the encoder-side message is built for CoBEVT only "
+                                      "(cobevt_engine.shard_local_stage); run this model unsharded" % "V2X-ViT")
         n, record_len, slots = self.shard_frame_agents(data_dict_local)
         n_pad = n if n_pad is None else int(n_pad)
         if n_pad < max(n, 1):
@@ -612,6 +618,8 @@ class V2XViTEngine(Where2ComEngine):
             self.widen(x16, x)
         else:
             self.trunk(canvas, n_total, ny, nx, shrink_out=x)                    # all agents of the batch at once
+        if self.compression:                                                     # airv2x_v2xvit.py:122-123
+            self.run_compressor(x, n_total, H, Wd)
         fused_all = self.buf("vit_fused", (B, H, Wd, 256))
         off = 0
         for b, n in enumerate(record_len):                                       # the fusion never mixes samples

@@ -40,16 +40,19 @@ class When2comEngine(Where2ComEngine):
         mf = args["modality_fusion"]
         self.bb, self.sh = mf["base_bev_backbone"], mf["shrink_header"]
         self.fcfg = {"fully": False}
-        if mf.get("compression", 0):
-            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        from ..synth import model_compression
+        self.compression = model_compression(args)     # airv2x_when2com.py:50-52: NaiveCompressor(256, args["compression"]) in front of the fusion
+        if self.compression and (256 % self.compression or (256 // self.compression) % 32):
+            raise NotImplementedError(f"compression {self.compression}: 256/ratio must be a multiple of 32 channels")
         self.w2 = args["when2com_fusion"]
         if self.w2["mode"] != "softmax":
             raise NotImplementedError("When2com mode %r: only the shipped 'softmax' mode is built (the reference's "
                                       "'activated' branch raises IndexError, when2com.py:58)" % (self.w2["mode"],))
 
-    FUSION_WEIGHTS = ("policy", "key_fc", "query_fc", "att_lin")
+    FUSION_WEIGHTS = ("policy", "key_fc", "query_fc", "att_lin", "compressor")
 
     def _load_fusion(self, sd, up, prefix="fusion_net."):
+        self.compressor = self._load_compressor(sd, up) if self.compression else None
         self.policy = []
         for i, stride in enumerate(POLICY_STRIDES, 1):
             p = f"{prefix}query_key_net.conv{i}.cbr_unit"
@@ -143,6 +146,9 @@ class When2comEngine(Where2ComEngine):
         each at the default grid) | n_loc keys (1 KB each) | the ego's projected query (1 KB; zeros on the other
         ranks)], so that every rank can finish the frame (SPMD).  ``data_dict_local`` carries the frame-level
         ``img_pairwise_t_matrix_collab`` and ``shard_rank`` (set by ShardedFrame): global agent index = rank * n_loc + j."""
+        if getattr(self, "compression", 0):
+            raise NotImplementedError("agent-sharded %s frame with a NaiveCompressor: the encoder-side message is built for CoBEVT only "
+                                      "(cobevt_engine.shard_local_stage); run this model unsharded" % "When2com")
         n, record_len, slots = self.shard_frame_agents(data_dict_local)
         n_pad = n if n_pad is None else int(n_pad)
         if n_pad < max(n, 1):
@@ -224,6 +230,8 @@ class When2comEngine(Where2ComEngine):
         C = self.feat_c
         s_all = self.buf("w2_shrink", (n_total, H, W, C))
         self.trunk(canvas, n_total, ny, nx, shrink_out=s_all)
+        if self.compression:                                   # airv2x_when2com.py:122-123
+            self.run_compressor(s_all, n_total, H, W)
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)            # communication_rates: non-zeros of the shared maps (:118)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")

@@ -614,7 +614,7 @@ def fax_param_spec(fax, prefix=""):
 def cobevt_param_spec(args):
     """Ordered (key, shape, kind) manifest of Airv2xCoBEVT's state_dict (236 tensors at L = 7;
     checked against the reference's own state_dict by tools/gen_golden.py)."""
-    w2c_like = {"collaborators": args["collaborators"],
+    w2c_like = {"collaborators": args["collaborators"], **{t: args[t] for t in AGENT_TYPES if t in args},     # per-type modalities / cam blocks
                 "modality_fusion": {"base_bev_backbone": args["base_bev_backbone"], "shrink_header": args["shrink_header"]},
                 "where2com_fusion": {"communication": {"gaussian_smooth": {"k_size": 5}}},
                 "anchor_number": args["anchor_number"], "num_class": args["num_class"], "outC": args["outC"],
@@ -696,8 +696,17 @@ def v2xvit_param_spec(args):
     base = where2com_param_spec(w2c_like)
     trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
-    spec = list(trunk) + v2xvit_encoder_spec(args["transformer"]["encoder"], "fusion_net.encoder")
+    spec = list(trunk) + compressor_param_spec(256, model_compression(args)) + v2xvit_encoder_spec(args["transformer"]["encoder"], "fusion_net.encoder")
     return spec + heads
+
+
+def model_compression(args):
+    """NaiveCompressor ratio of the Where2Comm-nested models as the reference reads it (airv2x_v2xvit.py:42-44, airv2x_when2com.py:50-52):
+    switched on by ``modality_fusion.compression > 0``, ratio taken from the TOP-LEVEL ``compression`` key (a KeyError in the reference when
+    only the first is given -- the same here); 0 = no compressor."""
+    if not args["modality_fusion"].get("compression", 0) > 0:
+        return 0
+    return int(args["compression"])
 
 
 def se2_correction(yaw_deg, tx, ty):
@@ -758,7 +767,7 @@ def when2com_param_spec(args):
     base = where2com_param_spec(w2c_like)
     trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
-    return trunk + when2com_fusion_spec(args["when2com_fusion"], "fusion_net.") + heads
+    return trunk + compressor_param_spec(256, model_compression(args)) + when2com_fusion_spec(args["when2com_fusion"], "fusion_net.") + heads
 
 
 # --------------------------------------------------------------------------
@@ -990,7 +999,13 @@ def multimodal_hypes(modalities=("cam", "lidar"), lidar_range=None, final_dim=(3
     """default_hypes with a camera encoder per agent type (``args[type]["cam"]`` = the shipped camera block,
     hypes_yaml/airv2x/camera/det/airv2x_intermediate_where2com.yaml:180-248) and ``modalities`` as given: ("cam",) is that
     YAML, ("cam", "lidar") is BASELINE configs[4] (no shipped YAML sets both)."""
-    hy = default_hypes(lidar_range, max_cav)
+    return add_camera_modalities(default_hypes(lidar_range, max_cav), modalities, final_dim, use_depth_gt, camera_encoder)
+
+
+def add_camera_modalities(hy, modalities=("cam",), final_dim=(360, 640), use_depth_gt=True, camera_encoder="EfficientNet"):
+    """Give every agent type of a model's hypes (default_hypes / default_hypes_cobevt / _v2xvit / _when2com / _v2vnet) the camera block
+    of the shipped camera YAMLs (hypes_yaml/airv2x/camera/det/airv2x_intermediate_{where2com,cobevt,v2xvit,when2com}.yaml: the
+    ``vehicle / rsu / drone`` entries are the same in all four) and set ``modalities``; the BEV grid follows the hypes' LiDAR range."""
     r = hy["preprocess"]["cav_lidar_range"]
     a = hy["model"]["args"]
     a["active_sensors"] = list(modalities)

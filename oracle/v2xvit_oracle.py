@@ -218,12 +218,14 @@ def encoder(x, mask, scm, sd, enc, trace=None, strip=None, gap_reduce=None):
 
 
 def v2xvit_forward(data_dict, sd, args, trace=None):
-    """models/airv2x_v2xvit.py:108-167 (det task, compression 0)."""
+    """models/airv2x_v2xvit.py:108-167 (det task)."""
     mf = args["modality_fusion"]
     feats, record_len = w2c.extract_features(data_dict, sd, args)
     comm_rate = int(feats.count_nonzero().item())
     sf2d, _ = w2c.backbone_forward(feats, sd, mf["base_bev_backbone"])
     s = w2c.shrink_conv(sf2d, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else sf2d
+    if mf.get("compression", 0) > 0:      # NaiveCompressor(256, args["compression"]) (airv2x_v2xvit.py:42-44,122-123; airv2x_when2com.py:50-52,122-123)
+        s = w2c.naive_compress(s, sd)
     L = args["max_cav_num"]
     x, mask = regroup(s, record_len, L)                                          # b l c h w
     prior = data_dict["prior_encoding"].unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, x.shape[3], x.shape[4])

@@ -99,6 +99,8 @@ def when2com_forward(data_dict, sd, args, trace=None):
     mf = args["modality_fusion"]
     sf2d, _ = w2c.backbone_forward(feats, sd, mf["base_bev_backbone"])
     s = w2c.shrink_conv(sf2d, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else sf2d
+    if mf.get("compression", 0) > 0:      # NaiveCompressor(256, args["compression"]) (airv2x_v2xvit.py:42-44,122-123; airv2x_when2com.py:50-52,122-123)
+        s = w2c.naive_compress(s, sd)
     fused, rate = when2com_fuse(s, record_len, data_dict["img_pairwise_t_matrix_collab"], sd, args["when2com_fusion"], trace=trace)
     out = {"psm": w2c.head(fused, sd, "cls_head"), "rm": w2c.head(fused, sd, "reg_head")}
     if args["obj_head"]:
