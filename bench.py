@@ -91,7 +91,7 @@ def parse(argv=None):
                     help="agents in the frame; 0 = 4 (BASELINE configs[1]) up to 4 GPUs, one per GPU above")
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--modalities", default="lidar",
-                    help="where2com only: 'lidar' (the headline), 'cam' (the shipped camera YAML) or 'cam,lidar' (BASELINE.json configs[4]: "
+                    help="'lidar' (the headline), 'cam' (the shipped camera YAML) or 'cam,lidar' (BASELINE.json configs[4]: "
                          "every agent carries 360x640 RGB-D cameras -- 4 per vehicle / RSU, 1 per drone -- next to its LiDAR; use with --agents 8)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip); the median is reported (3 frames "
                     "+ the as-written schedule once keep the default command under ~2 minutes with the `configs` legs in it)")
@@ -151,6 +151,8 @@ def build_inputs(n_agents, n_points, device, only=None, model="where2com", modal
         hy = synth.multimodal_hypes(tuple(modalities))
     else:
         hy = synth.default_hypes()
+    if model != "where2com" and tuple(modalities) != ("lidar",):    # camera (+ LiDAR) agents through the other fusion heads (round 5)
+        synth.add_camera_modalities(hy, tuple(modalities))
     args = hy["model"]["args"]
     pp = hy["preprocess"]
     types = synth.agent_types_for(n_agents)
@@ -453,8 +455,6 @@ def main(argv=None, hooks=None, device=None, quiet=False):
             torch.cuda.set_device(0)
     dev = torch.device("cpu") if cpu_harness else torch.device("cuda", local if world > 1 else 0)
     a.mods = tuple(m.strip() for m in a.modalities.split(",") if m.strip())
-    if a.mods != ("lidar",) and a.model != "where2com":
-        raise SystemExit("--modalities: the camera encoders are wired into the Where2Comm model (BASELINE.json configs[4])")
     if any(m not in ("cam", "lidar") for m in a.mods) or not a.mods:
         raise SystemExit("--modalities: lidar | cam | cam,lidar")
     a.lidar_only = a.mods == ("lidar",)
