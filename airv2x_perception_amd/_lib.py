@@ -140,6 +140,15 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
     "av2x_v2v_aggregate": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_points_in_boxes_cpu": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "av2x_points_in_boxes_gpu": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_roiaware_pool3d_workspace_bytes": (c_uint64, [c_int32, c_int32]),
+    "av2x_roiaware_pool3d_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                               c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "av2x_roiaware_pool3d_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                                c_int32, c_void_p]),
+    "av2x_bbox_overlaps": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32]),
+    "av2x_box_vote": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_conv2d": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_conv2d_res": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_conv2d_sk": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

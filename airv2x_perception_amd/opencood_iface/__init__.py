@@ -26,3 +26,31 @@ def create_model(hypes):
         if attr.lower() == target and isinstance(cls, type):
             return cls(hypes["model"]["args"])
     raise ValueError(f"module {mod.__name__} has no class named {target} (ignoring case)")
+
+
+def install_import_shims(force=False):
+    """Register the two native modules the reference's callers import before any model runs under the reference's
+    own module names, so that its UNMODIFIED ``build_dataset`` / ``build_postprocessor`` import on a ROCm box:
+    ``opencood.pcdet_utils.roiaware_pool3d.roiaware_pool3d_cuda`` (intermediate_fusion_dataset.py:24-26 -> roiaware_pool3d_utils.py:5) and
+    ``opencood.utils.box_overlaps`` (voxel_postprocessor.py:20).  An already importable module of that name (a CUDA build) is left alone
+    unless ``force``.  Returns the names that were registered."""
+    import importlib.util
+    import sys
+    from . import box_overlaps, roiaware_pool3d_cuda
+    done = []
+    for name, mod in (("opencood.pcdet_utils.roiaware_pool3d.roiaware_pool3d_cuda", roiaware_pool3d_cuda),
+                      ("opencood.utils.box_overlaps", box_overlaps)):
+        if not force:
+            if name in sys.modules:
+                continue
+            try:
+                if importlib.util.find_spec(name) is not None:
+                    continue
+            except (ImportError, ValueError, AttributeError):
+                pass
+        sys.modules[name] = mod
+        parent, _, leaf = name.rpartition(".")
+        if parent in sys.modules:
+            setattr(sys.modules[parent], leaf, mod)
+        done.append(name)
+    return done

@@ -874,6 +874,42 @@ int av2x_linear_rows(const float* x, const float* w, const float* bias, int32_t 
 int av2x_when2com_fuse(const float* keys, const float* query, int32_t n_agents, int32_t key_size,
                        const float* const* agents, uint64_t elems_per_agent, float* out, float* coef, av2x_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Import-time native modules of the reference's callers on this path: without them the reference's unmodified
+ * build_dataset / build_postprocessor raise ImportError on a ROCm box.  Python shims with the reference's module names and signatures:
+ * airv2x_perception_amd/opencood_iface/roiaware_pool3d_cuda.py, box_overlaps.py (install_import_shims() registers them in sys.modules).
+ *
+ * roiaware_pool3d_cuda (pcdet_utils/roiaware_pool3d/src/roiaware_pool3d.cpp:27-183, roiaware_pool3d_kernel.cu:1-359;
+ * boxes are [x, y, z, dx, dy, dz, heading] with (x, y, z) the centre):
+ * av2x_points_in_boxes_cpu: HOST arrays; pts_indices (n_boxes, n_pts) = 1 where the point lies in the box (margin 1e-2 in x / y, :128).
+ * av2x_points_in_boxes_gpu: boxes (batch, n_boxes, 7), pts (batch, n_pts, 3) on the device; box_idx_of_points (batch, n_pts) receives the index
+ *   of the FIRST box holding the point and is left untouched otherwise (the caller pre-fills -1, roiaware_pool3d_utils.py:61-63); margin 1e-5.
+ * av2x_roiaware_pool3d_forward: rois (boxes_num, 7), pts (pts_num, 3), pts_feature (pts_num, channels) -> pts_idx_of_voxels
+ *   (boxes_num, out_x, out_y, out_z, max_pts_each_voxel) int32 [slot 0 = count, then the point indices in increasing order, at most
+ *   max_pts_each_voxel - 1], pooled_features (boxes_num, out_x, out_y, out_z, channels) and, for pool_method 0 (max), argmax (same shape,
+ *   -1 = empty voxel).  pts_idx_of_voxels and pooled_features must be ZERO on entry (the reference's new_zeros); pool_method 1 = average.
+ *   workspace: av2x_roiaware_pool3d_workspace_bytes(boxes_num, pts_num) bytes of device scratch (the (box, point) voxel codes).
+ * av2x_roiaware_pool3d_backward: grad_in (pts_num, channels) += the pooled gradients (atomic adds; zero it first).
+ *
+ * box_overlaps (utils/box_overlaps.pyx:17-143; HOST float32 arrays, boxes are [x1, y1, x2, y2] with the "+1" pixel convention):
+ * av2x_bbox_overlaps: out (n, k) = IoU of boxes[i] and query[j]; intersections_only != 0: intersection / area(query[j]) (bbox_intersections).
+ * av2x_box_vote: dets are rows of `cols` >= 5 floats (x1, y1, x2, y2, score, ...): out[i] = score-weighted mean of the dets_all boxes with
+ *   IoU >= 0.5 to dets_nms[i] (nan where none), out[i][4] = the original score, further columns 0.
+ * ------------------------------------------------------------------------------------ */
+int av2x_points_in_boxes_cpu(const float* boxes, const float* pts, int32_t n_boxes, int32_t n_pts, int32_t* pts_indices);
+int av2x_points_in_boxes_gpu(const float* boxes, const float* pts, int32_t batch, int32_t n_boxes, int32_t n_pts,
+                             int32_t* box_idx_of_points, av2x_stream_t stream);
+uint64_t av2x_roiaware_pool3d_workspace_bytes(int32_t boxes_num, int32_t pts_num);
+int av2x_roiaware_pool3d_forward(const float* rois, const float* pts, const float* pts_feature, int32_t boxes_num, int32_t pts_num,
+                                 int32_t channels, int32_t max_pts_each_voxel, int32_t out_x, int32_t out_y, int32_t out_z,
+                                 int32_t* argmax, int32_t* pts_idx_of_voxels, float* pooled_features, int32_t pool_method,
+                                 void* workspace, av2x_stream_t stream);
+int av2x_roiaware_pool3d_backward(const int32_t* pts_idx_of_voxels, const int32_t* argmax, const float* grad_out, int32_t boxes_num,
+                                  int32_t out_x, int32_t out_y, int32_t out_z, int32_t channels, int32_t max_pts_each_voxel,
+                                  float* grad_in, int32_t pool_method, av2x_stream_t stream);
+int av2x_bbox_overlaps(const float* boxes, const float* query, int32_t n, int32_t k, float* out, int32_t intersections_only);
+int av2x_box_vote(const float* dets_nms, const float* dets_all, int32_t n, int32_t m, int32_t cols, float* out);
+
 #ifdef __cplusplus
 }
 #endif

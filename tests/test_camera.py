@@ -94,7 +94,7 @@ def test_oracle_matches_reference_fixture(name):
     assert np.array_equal(sampled(trace["spatial_features"], 2), fx["spatial_features"])
 
 
-def test_model_refuses_training_and_unknown_modalities():
+def test_model_refuses_unknown_modalities_and_runs_only_on_the_device():
     from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
     hy = synth.multimodal_hypes(("cam", "lidar"), [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], (104, 168))
     m = Airv2xWhere2com(hy["model"]["args"])

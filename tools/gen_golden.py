@@ -1363,6 +1363,42 @@ def camera_model_case(name, which, lidar_range, types, n_points, seed, final_dim
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def box_overlaps_pin_golden(name="box_overlaps_pin"):
+    """Outputs of the REFERENCE's own utils/box_overlaps.pyx (compiled where it lies by oracle/build_ref.py, Cython + gcc) for seeded
+    boxes at three coordinate scales: bbox_overlaps, bbox_intersections, box_vote.  Pins airv2x_perception_amd/opencood_iface/box_overlaps.py
+    (host code behind av2x_bbox_overlaps / av2x_box_vote) bit for bit."""
+    from oracle import build_ref
+    ref = build_ref.import_box_overlaps()
+    g = np.random.default_rng(2024)
+    fx = {}
+    for si, scale in enumerate((1.0, 50.0, 1000.0)):
+        def boxes(n):
+            xy = g.uniform(0, scale, (n, 2)).astype(np.float32)
+            wh = g.uniform(0, 0.4 * scale, (n, 2)).astype(np.float32)
+            return np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        a, b = boxes(120), boxes(90)
+        a[3], b[5] = b[7], a[11]                     # identical boxes, a degenerate (zero-size) one, a disjoint pair
+        a[4, 2:], b[6] = a[4, :2], np.float32([5 * scale, 5 * scale, 6 * scale, 6 * scale])
+        d1 = np.concatenate([boxes(30), g.uniform(0.1, 1, (30, 1)).astype(np.float32)], 1)
+        d2 = np.concatenate([np.concatenate([d1[:, :4] + g.normal(0, 0.02 * scale, (30, 4)).astype(np.float32),
+                                             g.uniform(0.1, 1, (30, 1)).astype(np.float32)], 1), d1[:20],
+                             np.concatenate([boxes(60), g.uniform(0.1, 1, (60, 1)).astype(np.float32)], 1)], 0).astype(np.float32)
+        fx[f"a{si}"], fx[f"b{si}"], fx[f"d1_{si}"], fx[f"d2_{si}"] = a, b, d1, d2
+        fx[f"overlaps{si}"], fx[f"intersections{si}"] = ref.bbox_overlaps(a, b), ref.bbox_intersections(a, b)
+        fx[f"vote{si}"] = ref.box_vote(d1, d2)
+        assert fx[f"overlaps{si}"][3, 7] > 0.9999 and fx[f"overlaps{si}"][:, 6].max() == 0.0
+    # nothing overlaps a kept detection: the reference divides 0 by 0 (nan box, score kept)
+    lone = np.float32([[0, 0, 1, 1, 0.5]])
+    far = np.float32([[10, 10, 11, 11, 0.9]])
+    with np.errstate(all="ignore"):
+        fx["vote_lone"] = ref.box_vote(lone, far)
+    fx["lone"], fx["far"] = lone, far
+    fx["scales"] = np.float64([1.0, 50.0, 1000.0])
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); vote_lone = {fx['vote_lone']}")
+
+
 def labels_golden(name, lidar_range, n_gt, seed):
     """The reference's own VoxelPostprocessor.generate_label_airv2x (voxel_postprocessor.py:217-354) with its own
     box_overlaps.pyx (compiled by oracle/build_ref.py) on the configuration's anchors and seeded ground-truth boxes."""
@@ -2398,6 +2434,7 @@ GROUPS = {
     "camera_full": lambda: camera_case("w2c_cam_full_n8", None, T8, 8192, 23, (360, 640), ("cam", "lidar"), True, 8),
     # round 5: camera (and camera + LiDAR) agents through the OTHER fusion heads, built from the reference's own camera YAMLs
     # (hypes_yaml/airv2x/camera/det/airv2x_intermediate_{cobevt,v2xvit,when2com}.yaml), and the NaiveCompressor of V2X-ViT / When2com
+    "box_overlaps_pin": lambda: box_overlaps_pin_golden(),
     "camera_models": lambda: (
         camera_model_case("cobevt_cam_small", "cobevt", SMALL, ["vehicle", "rsu", "drone"], 700, 61, (104, 168), ("cam",), {"vehicle": 2, "rsu": 1, "drone": 1}, (3, 2, 2)),
         camera_model_case("cobevt_camlidar_small_c4", "cobevt", SMALL, ["vehicle", "drone"], 700, 62, (104, 168), ("cam", "lidar"), {"vehicle": 1, "rsu": 1, "drone": 1}, (3, 2, 2), compression=4),
