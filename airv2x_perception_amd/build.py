@@ -24,7 +24,9 @@ _SCALAR_F32 = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
 # lane swap into a packed op; the files where it did are compiled without packed-fp32 instructions (they are HBM-bound kernels), and
 # lint_isa() below rejects the pattern in EVERY kernel of the library at build time.
 _NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-EXTRA_FLAGS = {"conv_x3p.hip": ([f"-D{os.environ['AV2X_X3P_ABLATE']}"] if os.environ.get("AV2X_X3P_ABLATE") else []), "conv_wino_x3.hip": _SCALAR_F32, "conv_wino4_x3.hip": _SCALAR_F32,
+# (Timing-only ablation macros -- AV2X_X3P_NOSPLIT / NOLDS / NOEPI, AV2X_WX3_ABLATE, AV2X_W4X3_ABLATE: wrong results by design -- are never part
+# of this build: the harnesses under tools/micro/ compile their OWN binaries / libraries from the same sources.)
+EXTRA_FLAGS = {"conv_wino_x3.hip": _SCALAR_F32, "conv_wino4_x3.hip": _SCALAR_F32,
                **{f: _NO_PACKED_F32 for f in ("transformer.hip", "postproc.hip", "train.hip", "loss.hip", "pillar.hip", "lss.hip", "camera.hip", "train_fusion.hip", "train_v2xvit.hip",
                                               "voxelize.hip")}}
 
@@ -40,9 +42,28 @@ def hipcc():
     raise HipccMissing("hipcc not found: libairv2x_hip.so cannot be built (no CPU fallback exists)")
 
 
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"]
+
+
+def _flag_sig(src):
+    import hashlib
+    return hashlib.sha256(" ".join([*BASE_FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), [])]).encode()).hexdigest()
+
+
+def _object_current(src, objdir):
+    """The object of ``src`` was made with today's flags and its device-ISA listing (what lint_isa scans) is there."""
+    o = os.path.join(objdir, os.path.basename(src) + ".o")
+    isa = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+    sig_path = o + ".flags"
+    return os.path.exists(o) and os.path.exists(isa) and os.path.exists(sig_path) and open(sig_path).read().strip() == _flag_sig(src)
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
+    objdir = os.path.join(HERE, "build")
+    if os.path.isdir(objdir) and not all(_object_current(s, objdir) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))):
+        return True     # (no object directory at all = a shipped .so on a box that only runs it: nothing to compare)
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "airv2x_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -55,13 +76,17 @@ def build(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
-             "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    flags = [*BASE_FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     objs = []
     procs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
+        # an object is only as good as the command line that made it: the flags (global + per file) are hashed into <object>.flags and a
+        # mismatch -- or a missing device-ISA listing, which lint_isa() needs -- recompiles, whatever the time stamps say
+        if not _object_current(s, objdir) and os.path.exists(o):
+            os.remove(o)
+        open(o + ".flags", "w").write(_flag_sig(s))
         # headers / .inc files are included by several sources: any of them newer than the object -> recompile
         hdr_t = max([os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if not f.endswith(".hip")]
                     + [os.path.getmtime(os.path.join(ROOT, "include", "airv2x_hip.h"))])
@@ -81,6 +106,10 @@ def build(force=False, verbose=False):
         if f.endswith((".bc", ".hipi", ".out", ".hipfb", ".resolution.txt")) or f.endswith("-host-x86_64-unknown-linux-gnu.s") \
                 or f.endswith("-hip-amdgcn-amd-amdhsa-gfx950.o"):
             os.remove(os.path.join(objdir, f))
+    missing = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))
+               and not os.path.exists(os.path.join(objdir, os.path.splitext(s)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s"))]
+    if missing:
+        raise RuntimeError("no device ISA listing (-save-temps) for " + ", ".join(missing) + ": the packed-fp32 OP_SEL lint cannot vouch for them")
     bad = lint_isa(objdir)
     if bad:
         raise RuntimeError("packed-fp32 instructions with a second / third source OP_SEL bit (wrong results next to bf16-MFMA waves on gfx950, "

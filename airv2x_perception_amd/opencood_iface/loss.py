@@ -136,6 +136,11 @@ class PointPillarLossMultiClass(nn.Module):
         self.loss_dict = _LossDict()
         self.use_dir = False
         self.cls_num = args["num_class"]
+        # class-id range check (the reference's one_hot scatter_ raises on an out-of-range id, point_pillar_loss_multiclass.py:118-125):
+        #   True    (default) checked asynchronously -- the verdict rides with the lazy loss read-back, so a bad id raises IndexError at the
+        #           first READ of loss_dict (logging(), repr, the next forward's flush), i.e. AFTER this step's backward / optimizer.step();
+        #   "sync"  checked before forward() returns (one blocking 8-byte read-back per step): raises where the reference raises;
+        #   False   not checked (the kernel trains such an anchor as background).
         self.validate_class_ids = True
 
     def forward(self, output_dict, target_dict, prefix=""):
@@ -155,6 +160,10 @@ class PointPillarLossMultiClass(nn.Module):
             # ... asynchronously: the two reductions are queued with the step and read together with the loss parts below, so the
             # check no longer drains the queued forward before the loss and the backward can be enqueued
             cid_range = torch.stack([cid.min(), cid.max()]).to(torch.float32)
+            if self.validate_class_ids == "sync":
+                lo, hi = (int(v) for v in cid_range.tolist())
+                if lo < 0 or hi >= int(self.cls_num):
+                    raise IndexError(f"class_ids out of range [0, {int(self.cls_num)}): min {lo}, max {hi} (the reference's one_hot scatter_ raises here)")
         f32 = lambda t: t.detach().to(psm.device, torch.float32).contiguous()
         cont = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
         total, parts = _PPLoss.apply(cont(psm), cont(rm), cont(obj), f32(target_dict["targets"]), f32(target_dict["pos_equal_one"]),
@@ -165,12 +174,12 @@ class PointPillarLossMultiClass(nn.Module):
             dict.update(ld, self.loss_dict)
             self.loss_dict = ld
         self.loss_dict._flush(block=False)                 # read-backs of earlier calls that have landed (their class-id verdict with them)
-        checked = bool(cid.numel() and self.validate_class_ids)
+        checked = bool(cid.numel() and self.validate_class_ids and self.validate_class_ids != "sync")
         dev_vals = torch.cat([parts.detach().float().flatten(), cid_range.to(parts.device)]) if checked else parts.detach().float().flatten()
         host = torch.empty(dev_vals.numel(), dtype=torch.float32).pin_memory()
         host.copy_(dev_vals, non_blocking=True)
         event = torch.cuda.Event()
-        event.record()
+        event.record(torch.cuda.current_stream(psm.device))     # the stream the copy above was queued on (psm's device, checked above)
         self.loss_dict._push(prefix, host, event, int(self.cls_num), checked)
         return total
 

@@ -78,8 +78,10 @@ class AgentMaxFn(torch.autograd.Function):
         return dx
 
 
-def v2vnet_fusion(P, s, record_len, theta, cfg, prefix="fusion_net."):
-    """s (sum n, H, W, C) shrink-header maps -> (B, H, W, C); theta (B, L, L, 2, 3) numpy: the normalised pairwise matrices."""
+def v2vnet_fusion(P, s, record_len, theta, cfg, prefix="fusion_net.", comm=None):
+    """s (sum n, H, W, C) shrink-header maps -> (B, H, W, C); theta (B, L, L, 2, 3) numpy: the normalised pairwise matrices.
+    ``comm``: a (1,) int64 device counter that receives the reference's comm_rates bookkeeping (v2v_fuse.py:138: the non-zeros of the
+    sample's node features, appended once per node and iteration) -- one device reduction per (sample, iteration), no host read."""
     if cfg["conv_gru"]["num_layers"] != 1:
         raise NotImplementedError("one ConvGRU layer (every shipped v2vfusion block)")
     if cfg["agg_operator"] not in ("avg", "max"):
@@ -103,6 +105,12 @@ def v2vnet_fusion(P, s, record_len, theta, cfg, prefix="fusion_net."):
             rois = [warp_affine_simple(ones, th)[..., 0].contiguous() for th in ths]
         for _ in range(cfg["num_iteration"]):
             upd = []
+            if comm is not None:
+                nd = nodes.detach().contiguous()
+                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                r_ = _runner(dev)
+                _lib.check(r_.lib.av2x_count_nonzero(_P(nd), nd.numel(), _P(cnt), r_.stream()), "av2x_count_nonzero")
+                comm.add_(cnt * k)
             for i in range(k):
                 nb = warp_affine_simple(nodes, ths[i])
                 ego = nodes[i:i + 1].expand(k, -1, -1, -1)
@@ -149,15 +157,16 @@ def _forward_train(model, data_dict):
     if pair.shape[0] != B:
         raise ValueError("img_pairwise_t_matrix_collab batch size does not match record_len")
     theta = normalized_pairwise(pair, H, W, cfg["voxel_size"][0], cfg["downsample_rate"])
-    fused = v2vnet_fusion(P, s, record_len, theta, cfg)
+    comm = torch.zeros(1, dtype=torch.int64, device=dev)
+    fused = v2vnet_fusion(P, s, record_len, theta, cfg, comm=comm)
     names = ["cls_head", "reg_head"] + (["obj_head"] if args["obj_head"] else [])
     outs = _heads(P, names, fused)
     out = {"psm": outs[0], "rm": outs[1]}
     if args["obj_head"]:
         out["obj"] = outs[2]
-    # comm_rates (:138): the non-zeros of every sample's node features, counted once per (iteration, node) -- not reproduced in train
-    # mode (it would put num_iteration x n device reductions + a host read-back into every step; the loss does not use it)
-    out.update({"mask": 0, "comm_rate": 0.0})
+    # comm_rates (:138): the non-zeros of every sample's node features, counted once per (iteration, node), / B (:172): a python float as
+    # in the reference unless model.sync_comm_rate is False (then the device scalar: no host read-back in the step)
+    out.update({"mask": 0, "comm_rate": (float(comm.item()) / B) if getattr(model, "sync_comm_rate", True) else comm[0].double() / B})
     return out
 
 

@@ -14,6 +14,8 @@ As-written schedule of the reference, kept:
 """
 from __future__ import annotations
 
+import json
+
 import random
 from ctypes import c_float
 
@@ -114,7 +116,7 @@ def encode_train(args, P, sd, data_dict, slots, n, dev, r, model=None):
     if cam_types:
         from . import train_camera as TC
         from .camera import CameraGeometry
-        geo = _CAM_GEOMETRY.setdefault(id(args), {})
+        geo = _CAM_GEOMETRY      # keyed by the CONTENT of the type's camera block (an id(args) key can be re-used by a later model's dict)
         rows = [None] * n
         if canvas is not None:
             for t in AGENT_TYPES:
@@ -128,9 +130,10 @@ def encode_train(args, P, sd, data_dict, slots, n, dev, r, model=None):
                 raise ValueError(f"{t}: the model has a camera encoder but the frame carries no batch_merged_cam_inputs")
             if int(ci["imgs"].shape[0]) != len(slots[t]):
                 raise ValueError(f"{t}: {int(ci['imgs'].shape[0])} camera rigs for {len(slots[t])} agents")
-            if (t, dev) not in geo:        # frustum / grid / depth bins of the type: weight-free, built once per model configuration
-                geo[(t, dev)] = CameraGeometry(args[t]["cam"], dev)
-            bev = TC.lss_encoder_train(P, sd, f"{TYPE_PREFIX[t]}.{mi}.", geo[(t, dev)], ci, True if model is None else model.training)
+            gkey = (t, str(dev), json.dumps(args[t]["cam"], sort_keys=True, default=str))
+            if gkey not in geo:            # frustum / grid / depth bins of the type: weight-free, built once per camera configuration
+                geo[gkey] = CameraGeometry(args[t]["cam"], dev)
+            bev = TC.lss_encoder_train(P, sd, f"{TYPE_PREFIX[t]}.{mi}.", geo[gkey], ci, True if model is None else model.training)
             for j, s_ in enumerate(slots[t]):
                 rows[s_] = bev[j:j + 1] if rows[s_] is None else TC.Mean2Fn.apply(bev[j:j + 1], rows[s_])
         canvas = torch.cat(rows, 0)

@@ -238,7 +238,7 @@ def make_model(a, args, dev):
     # wino_x3: the F(2x2,3x3) layers on conv_wino_x3 (three bf16 terms per fp32 operand on the bf16 matrix cores), the rest as --gemm f32
     eng.wino_x3 = a.gemm in ("wino_x3", "x3") and not a.amp
     # x3: wino_x3 + every other convolution / Linear on the pipelined split-3 GEMM (conv_igemm_x3p): all products of the frame from
-    # three bf16 terms per operand (the F(4x4,3x3) layers stay on the fp32-input MFMA: faster there)
+    # three bf16 terms per operand (the F(4x4,3x3) class runs as conv_wino4_x3 in this mode: engine.wino4_x3)
     eng.x3p = a.gemm == "x3" and not a.amp
     return model, eng, sd
 

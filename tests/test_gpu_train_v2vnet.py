@@ -82,6 +82,9 @@ def test_v2vnet_training_step_matches_the_reference(name):
         assert out[k].requires_grad
         hs = int(fx["head_stride"])
         assert_close(out[k].detach().cpu()[..., ::hs, ::hs], fx[k], 3e-4, 3e-4 * float(np.abs(fx[k]).max()), k)
+    # comm_rates (v2v_fuse.py:138,172) is kept in train mode too: non-zeros of the node features per (node, iteration) / B -- ReLU zeros, so
+    # only elements within rounding of zero can differ from the reference's count
+    assert isinstance(out["comm_rate"], float) and abs(out["comm_rate"] - float(fx["comm_rate"])) <= 1e-3 * float(fx["comm_rate"]), (out["comm_rate"], float(fx["comm_rate"]))
     total = _loss(args)(out, tgt)
     total.backward()
     torch.cuda.synchronize()

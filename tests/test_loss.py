@@ -88,6 +88,10 @@ def test_gpu_loss_dict_is_read_back_lazily_and_an_out_of_range_class_id_raises_a
     crit(heads, bad)
     with pytest.raises(IndexError):
         crit.loss_dict["total_loss"]
+    crit.validate_class_ids = "sync"            # strict mode: raises before forward() returns, where the reference's one_hot scatter_ does
+    with pytest.raises(IndexError, match="out of range"):
+        crit(heads, bad)
+    assert float(crit(heads, tgt).detach()) == float(total.detach())
     crit.validate_class_ids = False
     crit(heads, bad)
     assert crit.loss_dict["total_loss"] == crit.loss_dict["total_loss"]
