@@ -294,72 +294,86 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_x3(const Wino4X3Params p) {
             for (int r = 0; r < 16; ++r) xp[r * 64] = acc[2 * lp + nb][r];
         });
         __syncthreads();
-        const int n = n0 + nb * 32 + (lane & 31);
+        // finalising side, COUT-MAJOR (as conv_wino_x3): four consecutive lanes of an X row are four consecutive couts of one tile, so thread
+        // (quad q = tid & 7, accumulator row = tid >> 4, half-wave kh = (tid >> 3) & 1) takes ONE (tile, cout quad) item of the pass: 36
+        // ds_read_b128, the two transforms on four couts at once, 16 pixel stores of 16 bytes (16 consecutive threads write the 128 bytes of
+        // a pixel's 32 couts).  Round 4: one dword per lane and pixel -- 64 store instructions per lane and pass.
+        const int q = tid & 7, kh = (tid >> 3) & 1, row = tid >> 4;
+        const int n = n0 + nb * 32 + q * 4;
         const bool nok = n < p.Cout;
-        const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-        const float sh = nok ? p.shift[n] : 0.f;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (nok) {
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        }
         const unsigned ocol = (unsigned)((p.out_coff + n) * 4);
-        // row r = 4 wv + rs of the accumulator tile is tile rs + 8 wv + 4 (lane >> 5) of the block
-        int t = t0 + 8 * wv + 4 * (lane >> 5);
-        int img = t / p.tiles_per_img;
-        int ty = (t - img * p.tiles_per_img) / p.TW;
-        int tx = t - img * p.tiles_per_img - ty * p.TW;
+        // row r of the accumulator tile is tile (r & 3) + 8 (r >> 2) + 4 kh of the block
+        const int t = t0 + (row & 3) + 8 * (row >> 2) + 4 * kh;
+        const int img = t / p.tiles_per_img;
+        const int ty = (t - img * p.tiles_per_img) / p.TW;
+        const int tx = t - img * p.tiles_per_img - ty * p.TW;
+        const float* xq = X + row * 64 + kh * 32 + q * 4;
+        f32x4 z[4][6];
 #pragma unroll
-        for (int rs = 0; rs < 4; ++rs) {
-            const float* xq = X + (4 * wv + rs) * 64 + lane;
-            float z[4][6];
+        for (int nu = 0; nu < 6; ++nu) {
+            f32x4 m[6];
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) {
-                const float m0 = xq[((0 * 6 + nu) * 16) * 64], m1 = xq[((1 * 6 + nu) * 16) * 64], m2 = xq[((2 * 6 + nu) * 16) * 64];
-                const float m3 = xq[((3 * 6 + nu) * 16) * 64], m4 = xq[((4 * 6 + nu) * 16) * 64], m5 = xq[((5 * 6 + nu) * 16) * 64];
-                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-                z[0][nu] = (m0 + s12) + s34;
-                z[1][nu] = fmaf(2.f, d34, d12);
-                z[2][nu] = fmaf(4.f, s34, s12);
-                z[3][nu] = fmaf(8.f, d34, d12) + m5;
+            for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(xq + ((xi * 6 + nu) * 16) * 64);
+            const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            z[0][nu] = (m[0] + s12) + s34;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z[1][nu][e] = fmaf(2.f, d34[e], d12[e]);
+                z[2][nu][e] = fmaf(4.f, s34[e], s12[e]);
+                z[3][nu][e] = fmaf(8.f, d34[e], d12[e]) + m[5][e];
             }
-            const bool tvalid = nok && t < p.T;
-            const int py = 4 * ty, px = 4 * tx;
-            const unsigned pix = (unsigned)(((img * p.H + py) * p.W + px) * opix) + ocol;    // < 2^31 (checked by the host)
-            bool colok[4];
+        }
+        const bool tvalid = nok && t < p.T;
+        const int py = 4 * ty, px = 4 * tx;
+        const unsigned pix = (unsigned)(((img * p.H + py) * p.W + px) * opix) + ocol;    // < 2^31 (checked by the host)
+        bool colok[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) colok[e] = tvalid && px + e < p.W;
+        for (int e = 0; e < 4; ++e) colok[e] = tvalid && px + e < p.W;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const float s12 = z[a][1] + z[a][2], d12 = z[a][1] - z[a][2], s34 = z[a][3] + z[a][4], d34 = z[a][3] - z[a][4];
-                float y[4];
-                y[0] = (z[a][0] + s12) + s34;
-                y[1] = fmaf(2.f, d34, d12);
-                y[2] = fmaf(4.f, s34, s12);
-                y[3] = fmaf(8.f, d34, d12) + z[a][5];
-                const bool rowok = py + a < p.H;
-                const unsigned rowoff = pix + (unsigned)(a * p.W * opix);
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 s12 = z[a][1] + z[a][2], d12 = z[a][1] - z[a][2], s34 = z[a][3] + z[a][4], d34 = z[a][3] - z[a][4];
+            f32x4 y[4];
+            y[0] = (z[a][0] + s12) + s34;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = fmaf(y[e], sc, sh);
-                    const unsigned off = (rowok && colok[e]) ? rowoff + (unsigned)(e * opix) : 0x80000000u;   // invalid: outside the range
-                    if (GENERAL) {
-                        if (p.relu == 1) v = fmaxf(v, 0.f);
-                        else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
-                        else if (p.relu == 4) v = tanhf(v);
-                        if (p.res && off < 0x80000000u) {
-                            const size_t m = (size_t)(off - ocol) / (size_t)opix;
-                            v = (p.relu == 4) ? v * p.res[m * p.Cout + n] : v + p.res[m * p.out_ctot + p.out_coff + n];
-                        }
-                        if (p.relu == 5) v = fmaxf(v, 0.f);
-                    } else {
-                        v = relu1 ? fmaxf(v, 0.f) : v;
+            for (int c = 0; c < 4; ++c) {
+                y[1][c] = fmaf(2.f, d34[c], d12[c]);
+                y[2][c] = fmaf(4.f, s34[c], s12[c]);
+                y[3][c] = fmaf(8.f, d34[c], d12[c]) + z[a][5][c];
+            }
+            const bool rowok = py + a < p.H;
+            const unsigned rowoff = pix + (unsigned)(a * p.W * opix);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned off = (rowok && colok[e]) ? rowoff + (unsigned)(e * opix) : 0x80000000u;   // invalid: outside the range
+                f32x4 v;
+                f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+                if (GENERAL) {
+                    if (p.res && off < 0x80000000u) {
+                        const size_t m_ = (size_t)(off - ocol) / (size_t)opix;
+                        rs = *reinterpret_cast<const f32x4*>(p.relu == 4 ? p.res + m_ * p.Cout + n : p.res + m_ * p.out_ctot + p.out_coff + n);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, off, 0, 0);
                 }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float u = fmaf(y[e][c], sc[c], sh[c]);
+                    if (GENERAL) {
+                        if (p.relu == 1) u = fmaxf(u, 0.f);
+                        else if (p.relu == 3) u = 1.0f / (1.0f + expf(-u));
+                        else if (p.relu == 4) u = tanhf(u);
+                        if (p.res && off < 0x80000000u) u = (p.relu == 4) ? u * rs[c] : u + rs[c];
+                        if (p.relu == 5) u = fmaxf(u, 0.f);
+                    } else {
+                        u = relu1 ? fmaxf(u, 0.f) : u;
+                    }
+                    v[c] = u;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(x3_u32x4, v), rout, off, 0, 0);
             }
-            t += 1;
-            tx += 1;
-            if (tx >= p.TW) {
-                tx -= p.TW;
-                if (++ty >= p.TH) { ty = 0; ++img; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     });
 }
@@ -409,6 +423,7 @@ int wino4_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, c
     if (d->cin % 32 || d->cout % 64 || d->coutp % 64 || d->cout > d->coutp)
         return fail("av2x_conv2d: split-3 Winograd F(4x4,3x3) needs cin %% 32 == 0 and cout %% 64 == 0 (cin=%d cout=%d)", d->cin, d->cout);
     if (d->in_coff % 4 || d->in_ctot % 4) return fail("av2x_conv2d: input channel offset/stride must be multiples of 4");
+    if (d->out_coff % 4 || d->out_ctot % 4) return fail("av2x_conv2d: split-3 Winograd stores 16-byte cout quads: output channel offset/stride must be multiples of 4");
     if (((d->tile >> 16) & 0x1fff) != 32 || (d->tile & 0x01ff) != 64)
         return fail("av2x_conv2d: the split-3 Winograd F(4x4,3x3) tile is 32 tiles x 64 couts");
     Wino4X3Params p;

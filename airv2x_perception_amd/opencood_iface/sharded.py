@@ -48,6 +48,9 @@ def valid_slots(counts, n_pad):
     return [r * n_pad + j for r, c in enumerate(counts) for j in range(c)]
 
 
+GATHER_MIN_WORLD = 4
+
+
 class ShardedFrame:
     def __init__(self, backend, group=None, collectives_when_single=False):
         self.backend = backend
@@ -57,9 +60,12 @@ class ShardedFrame:
         # world == 1 normally skips the collectives; True issues them anyway (a 1-rank RCCL group on a one-GPU box
         # exercises the communicator set-up and the all_gather_into_tensor call path)
         self.collectives_when_single = collectives_when_single and dist.is_initialized()
-        # rotating ego stage (fusion_rank given): AV2X_SHARD_GATHER=1 gathers TO that rank (1/world of the bytes) instead of
-        # the all-gather.  Opt-in until it has run on a multi-GPU node: all_gather_into_tensor is the path RCCL is tuned for.
-        self.gather_to_fusion_rank = os.environ.get("AV2X_SHARD_GATHER", "0") == "1"
+        # rotating ego stage (fusion_rank given): the messages are GATHERED TO that rank (1/world of the bytes of the all-gather, and the other
+        # ranks' links stay free for the next frame's exchange) from GATHER_MIN_WORLD ranks on -- below that the all-gather moves at most twice
+        # the bytes and is the collective RCCL is tuned for.  AV2X_SHARD_GATHER=1 / 0 forces either path (the default is unmeasured on
+        # hardware: no multi-GPU node has been available to this build; both paths are covered over gloo at world 2 / 3 / 8).
+        env = os.environ.get("AV2X_SHARD_GATHER", "auto")
+        self.gather_to_fusion_rank = (self.world >= GATHER_MIN_WORLD) if env not in ("0", "1") else env == "1"
 
     @torch.no_grad()
     def forward(self, data_dict_local, counts=None, fusion_rank=None, **kw):

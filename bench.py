@@ -324,7 +324,11 @@ def dry_run(a):
     """What the N-rank agent-sharded run WILL do, from the partition code the run itself uses (sharded.partition_agents,
     fusion_column_shards, the engines' strip rule): counts, padding, bytes per message / per link, second-level shards."""
     from airv2x_perception_amd import synth
-    from airv2x_perception_amd.opencood_iface.sharded import fusion_column_shards, partition_agents, valid_slots
+    from airv2x_perception_amd.opencood_iface.sharded import GATHER_MIN_WORLD, fusion_column_shards, partition_agents, valid_slots
+    # launches per stage, counted from profiles/r05b_timeline_inflight1.txt (Where2Comm: per-agent part 23 + mask 6, ego part 33) and the
+    # kernel tables of the other models (profiles/r04e_kernel_stats_cobevt_n8.txt, r04k_*): orders of magnitude for the floor, not exact counts
+    LOCAL_STAGE_LAUNCHES = {"where2com": 29, "cobevt": 24, "v2xvit": 24, "when2com": 40, "v2vnet": 24}
+    EGO_STAGE_LAUNCHES = {"where2com": 33, "cobevt": 110, "v2xvit": 140, "when2com": 12, "v2vnet": 60}
     world = a.gpus
     n = a.agents if a.agents > 0 else max(4, world)
     parts = partition_agents(n, world)
@@ -358,8 +362,19 @@ def dry_run(a):
                           "note": "xGMI is point-to-point: the world-1 peer messages into a GPU arrive over world-1 separate links, so the "
                                   "all-gather is bound by ONE message per link (not by world-1 of them on one ring hop)"},
            "rotating_ego_stage": {"frames_in_flight": max(1, a.inflight), "fusion_rank_of_frame_t": "t % world",
-                                  "opt_in_gather": {"env": "AV2X_SHARD_GATHER=1", "bytes_into_fusion_rank": (world - 1) * msg,
-                                                    "bytes_out_of_other_ranks": msg}}}
+                                  "exchange": ("gather to the fusion rank" if world >= GATHER_MIN_WORLD else "all_gather_into_tensor")
+                                              + f" (default: gather from {GATHER_MIN_WORLD} ranks on; AV2X_SHARD_GATHER=0 / 1 forces all-gather / gather)",
+                                  "gather": {"bytes_into_fusion_rank": (world - 1) * msg, "bytes_out_of_other_ranks": msg,
+                                             "bytes_per_link_per_frame": msg if world > 1 else 0,
+                                             "lower_bound_us": round(msg / (XGMI_LINK_GBPS * 1e3), 1) if world > 1 else 0.0}},
+           # what bounds an 8-GPU frame besides the links: the per-rank stages are short (one agent's trunk) and launch-bound
+           "launch_floor": {"local_stage_launches": LOCAL_STAGE_LAUNCHES.get(a.model), "ego_stage_launches": EGO_STAGE_LAUNCHES.get(a.model),
+                            "us_per_launch": 16.0, "local_stage_floor_ms": round(LOCAL_STAGE_LAUNCHES.get(a.model, 0) * 16e-3, 3),
+                            "ego_stage_floor_ms": round(EGO_STAGE_LAUNCHES.get(a.model, 0) * 16e-3, 3),
+                            "note": "the eager host path (python + ctypes + hipLaunchKernel) issues one launch per ~16 us (tools/host_overhead.py: 75 launches of a "
+                                    "tiny-grid frame in 1.2 ms); one agent's share of the GPU work per launch is shorter than that on most layers, so a rank's "
+                                    "stage cannot finish faster than its launch count x 16 us unless frames in flight overlap the gaps (they do: 2-3 per rank) "
+                                    "or the stage is replayed from a hipGraph (engine.use_graph covers the single-GPU forward; the shard stages are not captured: DESIGN.md 6)"}}
     if a.model == "cobevt":
         sh = fusion_column_shards(W, 4, world)
         G = W // 16

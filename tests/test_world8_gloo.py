@@ -51,7 +51,10 @@ def _local(voxd, types, mine, **kw):
 
 # ------------------------------------------------------------------------------------------------------- Where2Comm
 def _w2c_worker(rank, port, path, n_agents, gather, depth):
-    os.environ["AV2X_SHARD_GATHER"] = "1" if gather else "0"
+    if gather is None:
+        os.environ.pop("AV2X_SHARD_GATHER", None)        # the default: gather to the fusion rank from 4 ranks on
+    else:
+        os.environ["AV2X_SHARD_GATHER"] = "1" if gather else "0"
     _init(rank, port)
     hy = synth.default_hypes(RNG)
     args = hy["model"]["args"]
@@ -61,6 +64,7 @@ def _w2c_worker(rank, port, path, n_agents, gather, depth):
     counts = [len(p) for p in parts]
     dd_local = _local(voxd, types, parts[rank]) if len(parts[rank]) else None
     pipe = ShardedPipeline([OracleBackend(sd, args) for _ in range(depth)], rotate=True)
+    assert all(f.gather_to_fusion_rank == (True if gather is None else gather) for f in pipe.frames)
     outs = []
     with torch.no_grad():
         for t in range(WORLD):
@@ -72,7 +76,7 @@ def _w2c_worker(rank, port, path, n_agents, gather, depth):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_agents,gather,depth", [(8, False, 2), (4, False, 2), (5, True, 2)])
+@pytest.mark.parametrize("n_agents,gather,depth", [(8, False, 2), (4, None, 2), (5, True, 2)])
 def test_where2comm_world8(tmp_path, n_agents, gather, depth):
     path = str(tmp_path / "o")
     mp.spawn(_w2c_worker, args=(_free_port(), path, n_agents, gather, depth), nprocs=WORLD, join=True)
