@@ -37,6 +37,9 @@
 #ifndef AV2X_WX3_SCHED
 #define AV2X_WX3_SCHED 1
 #endif
+#ifndef AV2X_WX3_XCDMAP
+#define AV2X_WX3_XCDMAP 1
+#endif
 
 namespace {
 
@@ -78,8 +81,21 @@ __global__ __launch_bounds__(256, (MB == 1 && NBK == 2) ? AV2X_X3_MB1_OCC : 1) v
     const int nu = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = column of the 4 x 4 position grid
     const int nbk = gridDim.x, b = blockIdx.x;
     const int q8 = nbk >> 3, r8 = nbk & 7, xcd = b & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    const int mblock = swz / p.nblocks, nblock = swz - mblock * p.nblocks;
+    int mblock, nblock;
+    if (AV2X_WX3_XCDMAP && (8 % p.nblocks) == 0) {
+        // XCD-aware map for the WEIGHT stream (workgroup b runs on XCD b % 8, observed; speed only): XCD x takes cout block x % nblocks for
+        // every (8 / nblocks)-th tile block, so an XCD's L2 streams 1 / nblocks of the layer's split planes (1.6 MB of the 6.3 MB of a
+        // 256 -> 256 layer: it fits the 4 MB L2, and the cold fetch from HBM / Infinity Cache at the head of every in-frame launch drops
+        // from 8 x 6.3 to 8 x 1.6 MB) at the price of 1 / (8 / nblocks) instead of 1 / 8 of the -- just written, cache-warm -- input map.
+        // The hardware's workgroups-per-XCD counts (q8 + (x < r8)) are exactly the counts this assignment needs.
+        const int G = 8 / p.nblocks;
+        nblock = xcd % p.nblocks;
+        mblock = xcd / p.nblocks + (b >> 3) * G;
+    } else {
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+        mblock = swz / p.nblocks;
+        nblock = swz - mblock * p.nblocks;
+    }
     const int t0 = mblock * TB;
     const int n0 = nblock * (32 * NBK);
 
