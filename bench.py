@@ -875,7 +875,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
             "algorithmic_bytes_per_launch": round(alg_bytes), "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
             "workgroups_launches": {str(w): c / a.steps for w, c in sorted(grids[dom].items())},
             "kernel": ("conv_wino4_x3 (Winograd F(4x4,3x3), split-3 operands: three bf16 terms per fp32 value, six products on v_mfma_f32_32x32x16_bf16; 32 tiles of 4x4 outputs x 64 couts per workgroup, 9 positions per wave, one workgroup per CU)" if (wino and x3dom and dom[0] & 0x2000) else
-                       f"conv_wino_x3<{(dom[0] & 0x1fff) // 32}> (Winograd F(2x2,3x3), split-3 operands: three bf16 terms per fp32 value, six products on v_mfma_f32_32x32x16_bf16; {dom[0] & 0x3fff} tiles x 64 couts per workgroup, 4 positions per wave)" if (wino and x3dom) else
+                       f"conv_wino_x3<{(dom[0] & 0x1fff) // 32},{(dom[1] & 0x01ff) // 32}> (Winograd F(2x2,3x3), split-3 operands: three bf16 terms per fp32 value, six products on v_mfma_f32_32x32x16_bf16; {dom[0] & 0x3fff} tiles x {dom[1] & 0x01ff} couts per workgroup, 4 positions per wave)" if (wino and x3dom) else
                        ("conv_wino4_f32 (Winograd F(4x4,3x3), 32 tiles of 4x4 outputs x 64 couts per workgroup, 18 positions per wave, one workgroup per CU)" if dom[0] & 0x2000 else
                         "conv_wino_f32_q (Winograd F(2x2,3x3), 32 tiles x 32 couts per workgroup, 4 positions per wave, up to four workgroups per CU)" if (dom[1] & 0x81ff) == (0x8000 | 32) else
                         "conv_wino_f32_h (Winograd F(2x2,3x3), 32 tiles x 64 couts per workgroup, 8 positions per wave, two workgroups per CU)" if dom[1] & 0x8000 else
@@ -883,7 +883,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                        "conv_halo_bf16 (halo-tile direct convolution on bf16 activations: 8 x 16 output pixels x 128 couts per workgroup, 64-channel halo chunks in LDS)" if dom[0] & 0x1000 else
                        f"conv_igemm_{'bf16' if dom[1] & 0x0800 else ('x3p (pipelined split-3: three bf16 terms per fp32 operand, LDS-DMA weights, two LDS stages)' if (dom[1] & 0x1400) == 0x1400 else 'bf16x3' if dom[1] & 0x0400 else ('f32_glds' if dom[1] & 0x0200 else 'f32'))}<{dom[0]},{dom[1] & 0x01ff}>") + (" 8-wave" if (dom[1] & 0x8000 and not wino) else "")
                       + ((" 3 LDS stages" if dom[1] & 0x0200 else " prefetch-2") if dom[1] & 0x4000 else "") + (" stream-K" if dom[1] & 0x2000 else ""), "launches_per_frame": cnt / a.steps,
-            "rocprof_rows": ("conv_wino4_x3<false>" if (wino and x3dom and dom[0] & 0x2000) else f"conv_wino_x3<{(dom[0] & 0x1fff) // 32}, false>" if (wino and x3dom) else ("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_x3p<{dom[1] & 0x01ff}>" if (dom[1] & 0x1400) == 0x1400 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
+            "rocprof_rows": ("conv_wino4_x3<false>" if (wino and x3dom and dom[0] & 0x2000) else f"conv_wino_x3<{(dom[0] & 0x1fff) // 32}, {(dom[1] & 0x01ff) // 32}, false>" if (wino and x3dom) else ("conv_wino4_f32" if dom[0] & 0x2000 else ("conv_wino_f32_q" if (dom[1] & 0x01ff) == 32 else "conv_wino_f32_h") if dom[1] & 0x8000 else f"conv_wino_f32<{(dom[0] & 0x3fff) // 32}, {(dom[1] & 0x01ff) // 32}>") if wino else ("conv_halo_bf16<KS, OUT16>" if dom[0] & 0x1000 else f"conv_igemm_x3p<{dom[1] & 0x01ff}>" if (dom[1] & 0x1400) == 0x1400 else f"conv_igemm_f32_glds<{dom[0]}, {dom[1] & 0x01ff}, ..., {3 if dom[1] & 0x4000 else 2}, {1 if dom[1] & 0x2000 else 0}>" if dom[1] & 0x0200 else
                               f"conv_igemm_f32<{dom[0]}, {dom[1] & 0x01ff}, ..., {'true' if dom[1] & 0x4000 else 'false'}, "
                               f"{1 if dom[1] & 0x2000 else (2 if dom[1] & 0x1000 else 0)}>")
                              + (f" + conv_fixup_f32<{dom[0]}, {dom[1] & 0x01ff}, ...> (one launch here = GEMM + its fix-up)" if dom[1] & 0x2000 else "")),

@@ -27,9 +27,9 @@ def conv_key(name):
         bm, bn, wm, wn, stages, mode = (int(g.group(i)) for i in range(1, 7))
         waves = (bm // wm) * (bn // wn)
         return f"g{bm}x{bn}{'w8' if waves == 8 else ''}{'d' if stages == 3 else ''}{'sk' if mode == 1 else ''}"
-    x3 = re.search(r"conv_wino_x3<(\d+), (true|false)>", name)
-    if x3:  # split-3 Winograd F(2x2,3x3): bench.py's key "w<tiles>x64_bf16x3"
-        return f"w{32 * int(x3.group(1))}x64_bf16x3"
+    x3 = re.search(r"conv_wino_x3<(\d+), (?:(\d+), )?(true|false)>", name)
+    if x3:  # split-3 Winograd F(2x2,3x3): bench.py's key "w<tiles>x<couts>_bf16x3" (<MB, NBK, GENERAL> since round 5; <MB, GENERAL> before)
+        return f"w{32 * int(x3.group(1))}x{32 * int(x3.group(2) or 2)}_bf16x3"
     if "conv_wino4_x3" in name:    # split-3 Winograd F(4x4,3x3)
         return "w4_32x64_bf16x3"
     xp = re.search(r"conv_igemm_x3p<(\d+)>", name)
