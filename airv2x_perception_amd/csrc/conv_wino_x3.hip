@@ -37,8 +37,11 @@
 #ifndef AV2X_WX3_SCHED
 #define AV2X_WX3_SCHED 1
 #endif
+// XCD-aware weight map (round 5 experiment, OFF): an XCD takes ONE cout block and streams 1 / nblocks of the layer's split planes.  Measured
+// (profiles/r05_pmc_hbm.json vs r04_pmc_hbm.json): -1.5 us on the in-frame 25 x 88 launches, but the input map is then fetched by 8 / nblocks
+// XCDs instead of one and the L2-side traffic goes UP (144 workgroups 63 -> 75 MB, 208: 29 -> 61, 276: 48 -> 88 MB per launch).  Not kept.
 #ifndef AV2X_WX3_XCDMAP
-#define AV2X_WX3_XCDMAP 1
+#define AV2X_WX3_XCDMAP 0
 #endif
 
 namespace {
