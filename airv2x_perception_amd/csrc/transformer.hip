@@ -478,6 +478,252 @@ __global__ __launch_bounds__(256) void fax_attention_mfma4_kernel(const FaxParam
     }
 }
 
+// ---------------------------------------------------------------- ws = 4, split-3 operands on the bf16 matrix cores (round 5)
+// fax_attention_mfma4_kernel's work split and S^T trick (one workgroup per window, heads in sequence, wave = 32-query strip, every lane owns
+// ONE query so P stays in registers), with both contractions on v_mfma_f32_32x32x16_bf16: every fp32 operand -- K, V, the scaled Q and the
+// normalised probabilities P -- enters as hi + mid + lo bf16 terms (the value to 2^-24), six partial products accumulated in fp32, smallest
+// first, exactly as the convolutions of the x3 mode (conv_x3p.hip).  gfx950's fp32-input MFMA runs at 1/16 of this pipe: 96 bf16 MFMAs of 32
+// cycles replace 128 fp32 MFMAs of 64 cycles per (strip, head).  K and V are split ONCE per (window, head) while they are staged into LDS
+// (amortised over the four strips): K as three [key][32 d] bf16 planes (80-byte rows: conflict-free 16-byte A fragments), V TRANSPOSED as
+// three [d][key slot] planes so that a B fragment (8 consecutive k of one column) is one 16-byte read; the key slots follow the register
+// order of P -- lane half hh, element e of k16-step s of a 32-key tile holds key 16 s + 8 (e >> 2) + 4 hh + (e & 3) -- so P's registers
+// 8 s .. 8 s + 7 ARE the A fragment of step s.
+typedef __bf16 fx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned fx_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int KROW3 = 40;                                   // bf16 per K row (32 + 8 pad)
+
+typedef float fx_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fx_bf16x2 __attribute__((ext_vector_type(2)));
+// (a, b) = hi + mid + lo per component (each subtraction exact): three packed bf16 pairs (a in the low half) -- one v_cvt_pk_bf16_f32 per
+// plane, the converted pair back as fp32 with a shift and a mask: 11 VALU per pair, as x3_split_step of the convolutions
+__device__ __forceinline__ void fx_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(fx_f32x2{a, b}, fx_bf16x2));
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(fx_f32x2{ra, rb}, fx_bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, mid << 16), sb = rb - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(fx_f32x2{sa, sb}, fx_bf16x2));
+}
+// eight values -> three A / B fragments (planes hi, mid, lo), element e in bits 16 (e & 1) of dword e >> 1
+__device__ __forceinline__ void fx_split8(const float (&v)[8], fx_u32x4 (&pl)[3]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned h, m, l;
+        fx_split2(v[2 * q], v[2 * q + 1], h, m, l);
+        pl[0][q] = h; pl[1][q] = m; pl[2][q] = l;
+    }
+}
+// the six partial products >= 2^-16 of the full product, smallest first (A plane, B plane): lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+template <bool FIRST = false>      // FIRST: the accumulator starts at zero (an inline-constant C operand: no 16 register moves)
+__device__ __forceinline__ f32x16 fx_mma6(const fx_u32x4 (&a)[3], const fx_u32x4 (&b)[3], f32x16 acc) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    if constexpr (FIRST) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fx_bf16x8, a[PA[0]]), __builtin_bit_cast(fx_bf16x8, b[PB[0]]), z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = FIRST ? 1 : 0; i < 6; ++i)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fx_bf16x8, a[PA[i]]), __builtin_bit_cast(fx_bf16x8, b[PB[i]]), acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(256, 2) void fax_attention_x3_kernel(const FaxParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    constexpr int ws = 4, ws2 = 16, s1 = 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li32 = lane & 31, lh = lane >> 5;
+    const int T = p.L * ws2, Tk = p.n_valid * ws2;
+    const int TkP = (Tk + 31) & ~31;
+    const int ktiles = TkP >> 5;                           // 1..4 key tiles of 32
+    const int X = p.H / ws, Y = p.W / ws;
+    const int wx = blockIdx.x / Y, wy = blockIdx.x % Y;
+    const int C = p.heads * DH, C3 = 3 * C;
+    const int tab_n = (2 * p.L - 1) * s1 * s1;
+    const int VROW = TkP + 8;                              // bf16 per V^T row (key slots + pad: conflict-free 16-byte B fragments)
+    const int KPL = TkP * KROW3 * 2, VPL = DH * VROW * 2;  // bytes per plane
+    unsigned char* Kp = lds3;                              // [3][TkP][KROW3] bf16
+    unsigned char* Vt = Kp + 3 * KPL;                      // [3][32 d][VROW] bf16
+    float* tab = reinterpret_cast<float*>(Vt + 3 * VPL);   // [tab_n]
+    int* rowtok = reinterpret_cast<int*>(tab + ((tab_n + 3) & ~3));   // [128]
+
+    if (tid < 128) {
+        const int t = tid < T ? tid : T - 1;               // padding queries re-read the last token (never stored)
+        const int l = t >> 4, w1 = (t >> 2) & 3, w2 = t & 3;
+        const int ph = p.grid ? (w1 * X + wx) : (wx * ws + w1);
+        const int pw = p.grid ? (w2 * Y + wy) : (wy * ws + w2);
+        rowtok[tid] = (l * p.H + ph) * p.W + pw;
+    }
+    const int strip = wave;
+    const bool strip_on = strip * 32 < T;
+    int bih;                                               // this lane's query i = 32 strip + li32: bias base index (see fax_attention_mfma4_kernel)
+    {
+        const int t = min(strip * 32 + li32, T - 1);
+        const int l = t >> 4, w1 = (t >> 2) & 3, w2 = t & 3;
+        bih = ((l + p.L - 1) * s1 + (w1 + ws - 1)) * s1 + (w2 + ws - 1) - lh * s1;
+    }
+    const float kLog2e = 1.4426950408889634f;
+
+    // K / V / Q of head h + 1 are fetched into registers while head h is computed (two workgroups of 8 waves per CU hide little of a
+    // global round trip per head otherwise): kreg / vreg / qreg hold the raw fp32 rows, split and stored at the top of the next iteration
+    f32x4v kreg[4], vreg[2][2], qreg[4];
+    float treg[4];                                         // this thread's entries of the head's bias-table column (tab_n <= 1024)
+    auto fetch = [&](int h) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it;
+            treg[it] = i < tab_n ? p.table[(size_t)i * p.heads + h] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it, j = idx >> 3, d4 = idx & 7;
+            kreg[it] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (idx < TkP * 8 && j < Tk) kreg[it] = *reinterpret_cast<const f32x4v*>(p.qkv + (size_t)rowtok[j] * C3 + C + h * DH + d4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 256 * it, j = 2 * (idx >> 3), d4 = idx & 7;
+            vreg[it][0] = vreg[it][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (idx < TkP * 4) {
+                if (j < Tk) vreg[it][0] = *reinterpret_cast<const f32x4v*>(p.qkv + (size_t)rowtok[j] * C3 + 2 * C + h * DH + d4 * 4);
+                if (j + 1 < Tk) vreg[it][1] = *reinterpret_cast<const f32x4v*>(p.qkv + (size_t)rowtok[j + 1] * C3 + 2 * C + h * DH + d4 * 4);
+            }
+        }
+        if (strip_on) {
+            const float* qsrc = p.qkv + (size_t)rowtok[strip * 32 + li32] * C3 + h * DH + lh * 8;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qreg[2 * s] = *reinterpret_cast<const f32x4v*>(qsrc + 16 * s);
+                qreg[2 * s + 1] = *reinterpret_cast<const f32x4v*>(qsrc + 16 * s + 4);
+            }
+        }
+    };
+    __syncthreads();                                       // rowtok visible
+    fetch(0);
+    for (int h = 0; h < p.heads; ++h) {
+        __syncthreads();                                   // previous head fully consumed
+        // ---- K: (key j, d quad) items, split, 8 bytes per plane
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it, j = idx >> 3, d4 = idx & 7;
+            if (idx < TkP * 8) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                fx_split2(kreg[it][0], kreg[it][1], h0, m0, l0);
+                fx_split2(kreg[it][2], kreg[it][3], h1, m1, l1);
+                typedef unsigned fx_u32x2 __attribute__((ext_vector_type(2)));
+                unsigned char* dst = Kp + (j * KROW3 + d4 * 4) * 2;
+                *reinterpret_cast<fx_u32x2*>(dst) = fx_u32x2{h0, h1};
+                *reinterpret_cast<fx_u32x2*>(dst + KPL) = fx_u32x2{m0, m1};
+                *reinterpret_cast<fx_u32x2*>(dst + 2 * KPL) = fx_u32x2{l0, l1};
+            }
+        }
+        // ---- V transposed: (key pair, d quad) items; keys 2 jp, 2 jp + 1 share a dword of every d row
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 256 * it, j = 2 * (idx >> 3), d4 = idx & 7;
+            if (idx < TkP * 4) {
+                const int kk = j & 31, rem = kk & 15;
+                const int slot = (j & ~31) + 16 * (kk >> 4) + 8 * ((rem >> 2) & 1) + 4 * (rem >> 3) + (rem & 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hv, mv, lv;
+                    fx_split2(vreg[it][0][e], vreg[it][1][e], hv, mv, lv);
+                    unsigned char* dst = Vt + ((d4 * 4 + e) * VROW + slot) * 2;
+                    *reinterpret_cast<unsigned*>(dst) = hv;
+                    *reinterpret_cast<unsigned*>(dst + VPL) = mv;
+                    *reinterpret_cast<unsigned*>(dst + 2 * VPL) = lv;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (tid + 256 * it < tab_n) tab[tid + 256 * it] = treg[it];
+        // ---- Q * scale of this lane's query, d = 16 s + 8 lh .. + 7, split in registers
+        fx_u32x4 qpl[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4v a = qreg[2 * s], b = qreg[2 * s + 1];
+            const float v[8] = {a.x * p.scale, a.y * p.scale, a.z * p.scale, a.w * p.scale, b.x * p.scale, b.y * p.scale, b.z * p.scale, b.w * p.scale};
+            fx_split8(v, qpl[s]);
+        }
+        if (h + 1 < p.heads) fetch(h + 1);                 // in flight during this head's products and softmax
+        __syncthreads();
+        if (!strip_on) continue;
+
+        // ---- S^T tiles: A = K planes from LDS (row = key), B = Q planes (column = query)
+        f32x16 sacc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < ktiles) {             // (tiles beyond ktiles are never read: every use below is under the same condition)
+                const unsigned char* kb = Kp + ((kt * 32 + li32) * KROW3 + lh * 8) * 2;
+                fx_u32x4 ka[2][3];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) ka[s][pl] = *reinterpret_cast<const fx_u32x4*>(kb + pl * KPL + s * 32);
+                sacc[kt] = fx_mma6<true>(ka[0], qpl[0], sacc[kt]);
+                sacc[kt] = fx_mma6(ka[1], qpl[1], sacc[kt]);
+            }
+        }
+        // ---- bias, padding mask, max over keys (in-lane + xor 32): as fax_attention_mfma4_kernel
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < ktiles) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int agent = 2 * kt + (r >> 3);                       // wave-uniform
+                    const int sub0 = (agent * s1 + 2 * ((r >> 2) & 1)) * s1 + (r & 3);   // sub[j] without the half term
+                    float sv = sacc[kt][r] + tab[bih - sub0];
+                    sv = agent < p.n_valid ? sv : -INFINITY;
+                    sacc[kt][r] = sv;
+                    m = fmaxf(m, sv);
+                }
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float mb = m * kLog2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < ktiles) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], kLog2e, -mb));   // exp(s - m)
+                    sacc[kt][r] = e;
+                    sum += e;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // ---- O = P V: A = P registers 8 s .. 8 s + 7 (normalised, split), B = V^T planes from LDS
+        f32x16 oacc;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < ktiles) {
+                const unsigned char* vb = Vt + (li32 * VROW + kt * 32 + lh * 8) * 2;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float pv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = sacc[kt][8 * s + e] * inv;
+                    fx_u32x4 pa[3], vv[3];
+                    fx_split8(pv, pa);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) vv[pl] = *reinterpret_cast<const fx_u32x4*>(vb + pl * VPL + s * 32);
+                    if (kt == 0 && s == 0) oacc = fx_mma6<true>(pa, vv, oacc);      // ktiles >= 1: the first product starts the accumulator
+                    else oacc = fx_mma6(pa, vv, oacc);
+                }
+            }
+        }
+        // ---- store: row (r, lh) of the strip = query, column d = lane & 31
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = strip * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < T) p.out[(size_t)rowtok[row] * C + h * DH + li32] = oacc[r];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- ws = 4, one WAVE per (window, head): no barriers
 // The whole attention of a (window, head) lives in one wave's registers (v_mfma_f32_16x16x4_f32 tiles = one agent's 16
 // tokens): K and V fragments of the valid agents are loaded once, then for every query agent qt
@@ -687,6 +933,15 @@ extern "C" int av2x_fax_attention(const float* qkv, const float* bias_table, flo
             else hipLaunchKernelGGL(fax_attention_wave_kernel<8>, grid, dim3(256), lds_w, av2x::as_stream(stream), p);
             return av2x::check_launch("fax_attention_wave_kernel");
         }
+    }
+    if (T <= 128 && window == 4 && !(grid_partition & 6) && (grid_partition & 32) && tab_n <= 1024) {
+        // bit 5: split-3 operands on the bf16 matrix cores (the engine's x3 mode; fp32-accurate products, not the bits of the fp32-input MFMA kernel)
+        const int TkP = (Tk + 31) & ~31;
+        const size_t lds_3 = (size_t)3 * TkP * KROW3 * 2 + (size_t)3 * DH * (TkP + 8) * 2 + ((size_t)((tab_n + 3) & ~3) + 128) * sizeof(float);
+        static av2x::LdsLimit lim_attr_3;
+        lim_attr_3.ensure(reinterpret_cast<const void*>(&fax_attention_x3_kernel), lds_3);
+        hipLaunchKernelGGL(fax_attention_x3_kernel, dim3((h / window) * (w / window)), dim3(256), lds_3, av2x::as_stream(stream), p);
+        return av2x::check_launch("fax_attention_x3_kernel");
     }
     if (T <= 128 && window == 4 && !(grid_partition & 6)) {   // ws = 4: S^T form, P stays in registers (test hook: bit 3)
         const int TkP = (Tk + 31) & ~31;

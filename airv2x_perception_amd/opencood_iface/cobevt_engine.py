@@ -19,6 +19,7 @@ from .engine import ConvLayer, Where2ComEngine, _ptr
 from .packing import fold_bn, pack_conv_weight
 
 LN_EPS = 1e-5
+_FAX_X3 = __import__("os").environ.get("AV2X_FAX_X3", "1") not in ("0", "off", "")
 
 
 class CoBEVTEngine(Where2ComEngine):
@@ -38,6 +39,11 @@ class CoBEVTEngine(Where2ComEngine):
         self.heads_n = self.fax["input_dim"] // self.fax["dim_head"]
 
     FUSION_WEIGHTS = ("fax_layers", "head_ln", "head_lin", "compressor")
+
+    def fax_x3(self):
+        """x3 mode (every product of the frame from three bf16 terms per operand on the bf16 matrix cores): the attention contractions too
+        (fax_attention_x3_kernel, > 4 valid agents; AV2X_FAX_X3=0 keeps them on the fp32-input MFMA)."""
+        return bool(self.x3p) and not self.amp and _FAX_X3
 
     def _linear(self, sd, wkey, bkey, act, up, rows=None):
         """Linear -> 1x1 conv layer; ``rows`` = slice of output features (used to split to_qkv into q | k,v)."""
@@ -103,7 +109,7 @@ class CoBEVTEngine(Where2ComEngine):
                     self.conv(P["q"], xn, L, H, W, qkv, out_ctot=3 * C, out_coff=0)
                     self.conv(P["kv"], xn, n_valid, H, W, qkv, out_ctot=3 * C, out_coff=C)
                 _lib.check(self.lib.av2x_fax_attention(_ptr(qkv), _ptr(P["table"]), _ptr(att), L, n_valid, H, W, ws,
-                                                       self.heads_n, self.fax["dim_head"], gi, self.stream()),
+                                                       self.heads_n, self.fax["dim_head"], gi | (32 if self.fax_x3() else 0), self.stream()),
                            "av2x_fax_attention")
                 self.conv(P["out"], att, L, H, W, x, residual=x)            # to_out(.) + x   (PreNormResidual)
                 self.ln(x, P["ln2"], xn, nt, C)

@@ -670,7 +670,10 @@ int av2x_eval_tp_fp(const float* det_corners, const int32_t* order, int32_t n_de
  *   Kernels: window 4 and L*16 <= 128 tokens -> one wave per (window, head) on v_mfma_f32_16x16x4_f32 with the score
  *   tile computed transposed (softmax in-lane, P / K / V stay in registers, no barrier); other windows -> generic MFMA
  *   kernel; > 128 tokens -> scalar kernel.  Test hooks in grid_partition: bit 1 forces the scalar kernel, bit 2 the
- *   generic MFMA kernel, bit 3 the workgroup-per-window transposed-score kernel.
+ *   generic MFMA kernel, bit 3 the workgroup-per-window transposed-score kernel.  Bit 5 (32): with more than 4 valid agents (window 4)
+ *   both contractions run on the bf16 matrix cores with split-3 operands (hi + mid + lo bf16 terms of K, V, the scaled Q and the
+ *   probabilities; fp32 accumulation; fax_attention_x3_kernel) -- fp32-accurate, not the bits of the fp32-input MFMA kernel; what the
+ *   engines' x3 mode requests.
  * av2x_agent_mean: y = mean over the agent axis of x (n_agents, elems_per_agent)  (:270).
  * ------------------------------------------------------------------------------------ */
 int av2x_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,

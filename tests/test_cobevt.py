@@ -93,9 +93,11 @@ def test_gpu_forward_matches_golden_and_oracle(name):
 @pytest.mark.parametrize("grid,L,nv", [(0, 5, 3), (1, 5, 3), (2, 5, 3), (3, 5, 3), (4, 5, 3), (5, 5, 3), (0, 7, 7), (1, 7, 4), (4, 7, 4),
                                        (0, 8, 8), (1, 8, 1), (0, 8, 5), (1, 7, 2), (0, 3, 3), (1, 9, 6),
                                        (8, 5, 3), (9, 7, 4), (8, 8, 8), (9, 8, 5), (16, 8, 8), (17, 8, 5), (16, 7, 6),
-                                       (0, 12, 12), (1, 15, 10), (0, 15, 15)])
+                                       (0, 12, 12), (1, 15, 10), (0, 15, 15),
+                                       (32, 8, 8), (33, 8, 5), (32, 7, 6), (33, 8, 7), (32, 5, 5), (33, 6, 6), (32, 8, 3)])
 def test_gpu_fax_attention_kernel(grid, L, nv):
-    """grid bit 0: partition (window / grid); default kernel for ws = 4: one wave per (window, head), everything in
+    """grid bit 5 (round 5): the split-3 kernel on the bf16 matrix cores (more than 4 valid agents; x3 mode of the engine).
+    grid bit 0: partition (window / grid); default kernel for ws = 4: one wave per (window, head), everything in
     registers (up to 4 valid agents; bit 4 forces it beyond); bit 3: the workgroup-per-window transposed-score kernel; bit 2: the generic-window MFMA kernel; bit 1: the
     VALU reference kernel (T = 16 L > 128 tokens always takes the VALU kernel; with more than 8 valid agents it keeps the K / V of
     2 or 1 heads in LDS at a time instead of 4)."""
@@ -119,6 +121,47 @@ def test_gpu_fax_attention_kernel(grid, L, nv):
     _lib.check(lib.av2x_fax_attention(P(qkv), P(table), P(out), L, nv, H, W, ws, heads, 32, grid,
                                       c_void_p(torch.cuda.current_stream().cuda_stream)), "fax")
     assert_close(out.permute(0, 3, 1, 2).cpu(), ref[0], 1e-4, 1e-5, "fax attention")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,nv,grid", [(8, 8, 0), (8, 6, 1), (7, 5, 0)])
+def test_gpu_fax_attention_split3_error_against_fp64_not_above_the_fp32_mfma_kernel(L, nv, grid):
+    """fax_attention_x3_kernel (K, V, scaled Q and P as hi + mid + lo bf16 terms on v_mfma_f32_32x32x16_bf16) against an fp64 evaluation of
+    Attention.forward (swap_fusion_modules.py:78-127) on operands with a wide dynamic range: max and rms error not above those of
+    fax_attention_mfma4_kernel (fp32-input MFMA) on the same operands -- the criterion of the split-3 convolutions (tests/test_gpu_wino_x3.py)."""
+    from ctypes import c_void_p
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(31 * L + nv)
+    H, W, ws, heads = 16, 24, 4, 8
+    C = heads * 32
+    qkv = torch.randn(L, H, W, 3 * C, generator=g) * torch.exp(0.7 * torch.randn(L, H, W, 1, generator=g))
+    table = torch.randn((2 * L - 1) * 49, heads, generator=g)
+    idx = cob.relative_position_index(L, ws)
+    # fp64 reference on partitioned tokens
+    def part(t):
+        return cob._partition(t.permute(0, 3, 1, 2).unsqueeze(0).double(), ws, bool(grid))
+    q, k, v = (part(qkv[..., i * C:(i + 1) * C]) for i in range(3))
+    Nw, T, _ = q.shape
+    q, k, v = (t.view(Nw, T, heads, 32).permute(0, 2, 1, 3) for t in (q, k, v))
+    sim = (q * (32 ** -0.5)) @ k.transpose(-1, -2) + table.double()[idx].permute(2, 0, 1).unsqueeze(0)
+    km = torch.tensor([1] * nv + [0] * (L - nv)).view(L, 1).expand(L, ws * ws).reshape(-1).bool()
+    sim = sim.masked_fill(~km.view(1, 1, 1, T), float("-inf"))
+    o = (sim.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(Nw, T, C)
+    ref = cob._unpartition(o, 1, L, C, H, W, ws, bool(grid))[0].permute(0, 2, 3, 1)         # (L, H, W, C)
+    qd, td = qkv.cuda().contiguous(), table.cuda()
+    errs = {}
+    P = lambda t: c_void_p(t.data_ptr())
+    for name, flag in (("f32", 8), ("x3", 32)):
+        out = torch.full((L, H, W, C), float("nan"), device="cuda")
+        _lib.check(lib.av2x_fax_attention(P(qd), P(td), P(out), L, nv, H, W, ws, heads, 32, grid | flag,
+                                          c_void_p(torch.cuda.current_stream().cuda_stream)), "fax")
+        e = (out.cpu().double() - ref).abs()
+        assert not torch.isnan(e).any(), name
+        errs[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    floor = 2.0 ** -23 * max(1.0, float(ref.abs().max()))
+    assert errs["x3"][1] <= errs["f32"][1] * 1.05 + 0.02 * floor, errs
+    assert errs["x3"][0] <= errs["f32"][0] * 1.25 + floor, errs
 
 
 @pytest.mark.gpu
