@@ -1402,6 +1402,29 @@ class Where2ComEngine:
         meta = {"dims": dims, "n_loc": n_pad, "H": H, "W": W}
         if n == 0:   # nothing to compute; the padding is never read by the fusion
             return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
+        body = lambda: self._shard_local_body(canvas, send, n, n_pad, has_ego, ny, nx, record_len, dims, sizes)
+        stats = self._graphed(("shard_local", n, n_pad, bool(has_ego), ny, nx, canvas.data_ptr(), send.data_ptr()), body)
+        return send, stats, meta
+
+    def _graphed(self, key, body):
+        """``body()`` -> tensor(s), eagerly or -- with ``use_graph`` -- replayed from a hipGraph captured on first use (the per-rank stages of
+        an agent-sharded frame are 29 / 33 launches of one agent's share of the work: launch-bound from ~4 ranks on, bench.py --dry-run).
+        Everything ``body`` touches must live at addresses that are part of ``key`` (pool buffers); results are cloned out of the graph's pool."""
+        if not self.use_graph or self.profile is not None or torch.cuda.is_current_stream_capturing():
+            return body()
+        ent = self.graphs.get(key)
+        if ent is None:
+            body()                                  # one eager pass: workspace buffers, tile choices, packed weights exist before the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static = body()
+            ent = self.graphs[key] = (g, static)
+        g, static = ent
+        g.replay()
+        return static.clone() if isinstance(static, torch.Tensor) else tuple(t.clone() for t in static)
+
+    def _shard_local_body(self, canvas, send, n, n_pad, has_ego, ny, nx, record_len, dims, sizes):
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
@@ -1423,8 +1446,7 @@ class Where2ComEngine:
         if has_ego:  # the ego's mask is all ones: its "masked" features are the unmasked ones
             lv[1][0].copy_(b1[0])
             lv[2][0].copy_(b2[0])
-        stats = torch.stack([count.sum().to(torch.int64), nz[0]])
-        return send, stats, meta
+        return torch.stack([count.sum().to(torch.int64), nz[0]])
 
     @torch.no_grad()
     def shard_ego_stage(self, recv, stats, meta, world, sync_comm_rate=False):
@@ -1437,19 +1459,23 @@ class Where2ComEngine:
         per_rank = n_loc * sum(sizes)
         if recv.numel() != world * per_rank or len(counts) != world or max(counts) > n_loc:
             raise ValueError("gathered buffer has the wrong size")
-        base = recv.data_ptr()
-        fused, off = [], 0
-        for i, ((h, w, c), f) in enumerate(zip(dims, sizes)):
-            out = self.buf(f"fused{i}", (1, h, w, c))
-            ptrs = [base + 4 * (r * per_rank + off + j * f) for r in range(world) for j in range(counts[r])]
-            self.attn(ptrs, h * w, c, out[0])
-            fused.append((out, h, w))
-            off += n_loc * f
-        catf = self.buf("cat_fused", (1, H, W, self.cat_c))
-        self.run_deblocks(fused, 1, catf)
-        fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
-        heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
-        self.conv(self.heads, fs, 1, H, W, heads)
+        def body():
+            base = recv.data_ptr()
+            fused, off = [], 0
+            for i, ((h, w, c), f) in enumerate(zip(dims, sizes)):
+                out = self.buf(f"fused{i}", (1, h, w, c))
+                ptrs = [base + 4 * (r * per_rank + off + j * f) for r in range(world) for j in range(counts[r])]
+                self.attn(ptrs, h * w, c, out[0])
+                fused.append((out, h, w))
+                off += n_loc * f
+            catf = self.buf("cat_fused", (1, H, W, self.cat_c))
+            self.run_deblocks(fused, 1, catf)
+            fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
+            heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
+            self.conv(self.heads, fs, 1, H, W, heads)
+            return heads
+        # the gathered buffer's address is part of the key: the sharded frame receives into a pool buffer (EngineBackend.recv_buffer)
+        heads = self._graphed(("shard_ego", recv.data_ptr(), world, tuple(counts), n_loc, H, W), body)
         outs = torch.split(heads, self.head_splits, dim=1)
         out = {"psm": outs[0], "rm": outs[1]}
         if self.args["obj_head"]:

@@ -371,10 +371,13 @@ def dry_run(a):
            "launch_floor": {"local_stage_launches": LOCAL_STAGE_LAUNCHES.get(a.model), "ego_stage_launches": EGO_STAGE_LAUNCHES.get(a.model),
                             "us_per_launch": 16.0, "local_stage_floor_ms": round(LOCAL_STAGE_LAUNCHES.get(a.model, 0) * 16e-3, 3),
                             "ego_stage_floor_ms": round(EGO_STAGE_LAUNCHES.get(a.model, 0) * 16e-3, 3),
-                            "note": "the eager host path (python + ctypes + hipLaunchKernel) issues one launch per ~16 us (tools/host_overhead.py: 75 launches of a "
-                                    "tiny-grid frame in 1.2 ms); one agent's share of the GPU work per launch is shorter than that on most layers, so a rank's "
-                                    "stage cannot finish faster than its launch count x 16 us unless frames in flight overlap the gaps (they do: 2-3 per rank) "
-                                    "or the stage is replayed from a hipGraph (engine.use_graph covers the single-GPU forward; the shard stages are not captured: DESIGN.md 6)"}}
+                            "measured_one_agent_per_rank": {"local_stage_ms": 1.14, "ego_stage_ms_8_agents": 0.35, "wall_ms_eager": 1.465, "wall_ms_hipgraph": 1.493,
+                                                            "source": "profiles/r05h_shard_latency_graph_vs_eager.txt (tools/shard_latency.py on one MI355X, Where2Comm)"},
+                            "note": "the eager host path issues one launch per ~16 us (tools/host_overhead.py), i.e. 0.46 / 0.53 ms for the two stages -- BELOW the GPU time "
+                                    "of even a ONE-agent local stage (1.14 ms: the single-image launches under-fill the chip but are not short), so the per-rank stages "
+                                    "are GPU-bound, not launch-bound: replaying them from hipGraphs (engine.use_graph, built and tested in round 5) measures 1.49 vs 1.47 ms "
+                                    "per frame.  Bound of an 8-GPU group by GPU time alone: local 1.14 + gather >= 0.10 + ego 0.35 ms = 1.59 ms -> <= 630 frames/s for "
+                                    "strictly sequential frames; frames in flight overlap the stages of consecutive frames"}}
     if a.model == "cobevt":
         sh = fusion_column_shards(W, 4, world)
         G = W // 16

@@ -38,6 +38,49 @@ def test_two_emulated_ranks_equal_single_gpu_forward():
     assert torch.equal(one["psm"], ref["psm"]) and one["comm_rate"] == ref["comm_rate"]
 
 
+def test_shard_stages_replayed_from_hipgraphs_equal_the_eager_stages():
+    """engine.use_graph: the per-rank local stage (after the scatter) and the ego stage of the agent-sharded Where2Comm frame are captured
+    once per layout and replayed (they are launch-bound from ~4 ranks on: bench.py --dry-run `launch_floor`).  Same bits as the eager
+    stages, on every replay, and the graphs read the CURRENT frame's buffers (two different frames through the same graphs)."""
+    from airv2x_perception_amd.opencood_iface import Airv2xWhere2com
+    from airv2x_perception_amd.opencood_iface.sharded import partition_agents
+    fx = load_fixture("w2c_full_n4")
+    hy, args, sd, dd, voxd, types = case_from_fixture(fx)
+    model = Airv2xWhere2com(args)
+    model.load_state_dict(sd)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    parts = partition_agents(4, 2)
+    assert types[0] == types[1]
+    frames = [voxd, [voxd[1], voxd[0], voxd[2], voxd[3]]]          # frame B: the two vehicles' clouds swapped (another ego)
+    tys = [types, types]
+
+    def run(frame, use_graph):
+        eng.use_graph = use_graph
+        recv = eng.buf("test_recv", (2 * eng.shard_local_stage(synth.build_data_dict([frames[frame][i] for i in parts[0]],
+                                                                                      [tys[frame][i] for i in parts[0]]), has_ego=True)[0].numel(),))
+        stats = None
+        for r, mine in enumerate(parts):
+            dd_local = synth.build_data_dict([frames[frame][i] for i in mine], [tys[frame][i] for i in mine])
+            send, st, meta = eng.shard_local_stage(dd_local, has_ego=(r == 0))
+            recv[r * send.numel():(r + 1) * send.numel()].copy_(send)
+            stats = st.clone() if stats is None else stats + st
+        out = eng.shard_ego_stage(recv, stats, meta, world=2, sync_comm_rate=True)
+        return {k: out[k].clone() for k in ("psm", "rm", "obj")}, out["comm_rate"], float(out["com"])
+
+    eager = [run(f, False) for f in (0, 1)]
+    assert not torch.equal(eager[0][0]["psm"], eager[1][0]["psm"])
+    for rep in range(2):
+        for f in (0, 1):
+            got = run(f, True)
+            for k in ("psm", "rm", "obj"):
+                assert torch.equal(got[0][k], eager[f][0][k]), (rep, f, k)
+            assert got[1] == eager[f][1] and got[2] == eager[f][2]
+    assert sum(1 for k in eng.graphs if k[0] in ("shard_local", "shard_ego")) >= 2
+    eng.use_graph = False
+
+
 @pytest.mark.parametrize("name,amp", [("cobevt_small_n2_c4", False), ("cobevt_small_n3", False), ("cobevt_small_n2_c4", True),
                                       ("cobevt_small_n3", True)])
 def test_cobevt_emulated_ranks_equal_single_gpu_forward(name, amp):
