@@ -666,9 +666,10 @@ class Where2ComEngine:
 
     @staticmethod
     def wino_x3_rule(L):
-        """Layers the split-3 Winograd kernel takes: the F(2x2,3x3) class with 16-channel chunks, 64-cout blocks and >= 128 input
-        channels (the 64 -> 64 layers at 100 x 352 have too short a K loop for the 64 x 64 tile: fp32 Winograd is faster there)."""
-        return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cin >= 128 and L.cout % 64 == 0 and L.coutp == L.cout
+        """Layers the split-3 Winograd kernel takes: the F(2x2,3x3) class with 16-channel chunks and 64-cout blocks.  Round 5: from 64 input
+        channels on (the 64 -> 64 block-0 layers at 100 x 352: 51.6 vs 59.6 us at 4 agents, 17.2 vs 21.5 at one, 92 vs 103-108 at eight once
+        the kernel's epilogue and memory schedule were fixed, profiles/r05i_b0_layers.txt; round 4 kept them on the fp32 Winograd)."""
+        return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cin >= 64 and L.cout % 64 == 0 and L.coutp == L.cout
 
     WINO_X3_T32 = os.environ.get("AV2X_WINO_X3_T32", "0") == "1"
     WINO_X3_T32_MAX_PIXELS = 50 * 176

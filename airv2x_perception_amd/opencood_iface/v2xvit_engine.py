@@ -53,7 +53,7 @@ class V2XViTEngine(Where2ComEngine):
         return ConvLayer(up(wp), None, up(b), w.shape[1], w.shape[0], coutp, 1, 1, 0, act)
 
     def _load_fusion(self, sd, up, p="fusion_net.encoder"):
-        self.compressor = self._load_compressor(sd, up) if self.compression else None
+        self.compressor = self._load_compressor(sd, up) if getattr(self, "compression", 0) else None
         heads, dh = self.cav["heads"], self.cav["dim_head"]
         self.layers = []
         for d in range(self.enc["depth"]):

@@ -52,7 +52,7 @@ class When2comEngine(Where2ComEngine):
     FUSION_WEIGHTS = ("policy", "key_fc", "query_fc", "att_lin", "compressor")
 
     def _load_fusion(self, sd, up, prefix="fusion_net."):
-        self.compressor = self._load_compressor(sd, up) if self.compression else None
+        self.compressor = self._load_compressor(sd, up) if getattr(self, "compression", 0) else None
         self.policy = []
         for i, stride in enumerate(POLICY_STRIDES, 1):
             p = f"{prefix}query_key_net.conv{i}.cbr_unit"

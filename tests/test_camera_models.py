@@ -145,7 +145,9 @@ def test_hip_model_vs_reference_fixture_and_oracle(name):
         assert_close(got[..., ::hs, ::hs], fx[k], RTOL[which], RTOL[which] * scale, f"{name} {k} vs the reference")
         assert_close(got, o[k].numpy(), RTOL[which], RTOL[which] * scale, f"{name} {k} vs the oracle, every element")
     if "comm_rate" in fx:
-        assert float(out["comm_rate"]) == float(fx["comm_rate"])
+        # V2X-ViT: non-zeros of the scattered canvas (exact).  When2com: non-zeros of the shared fp32 maps after ReLU -- an element within
+        # rounding of zero may land on either side (1 of 8e5 here): relative 1e-5
+        assert abs(float(out["comm_rate"]) - float(fx["comm_rate"])) <= (0 if which == "v2xvit" else 1e-5 * float(fx["comm_rate"]))
     o2 = model(synth.data_dict_to(dd, "cuda"))          # run to run: same bits
     assert torch.equal(o2["psm"], out["psm"])
 

@@ -159,7 +159,7 @@ def test_rule_is_a_function_of_the_layer_and_map_only():
     from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
     mk = lambda cin, cout, ks=3, stride=1, pad=1, relu=1, mode=_lib.AV2X_CONV: ConvLayer(None, None, None, cin, cout, cout, ks, stride, pad, relu, mode)
     rule = Where2ComEngine.wino_x3_rule
-    assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(384, 256)) and not rule(mk(64, 64))
+    assert rule(mk(256, 256)) and rule(mk(128, 128)) and rule(mk(384, 256)) and rule(mk(64, 64)) and not rule(mk(32, 64)) and not rule(mk(48, 64))
     assert not rule(mk(256, 96)) and not rule(mk(136, 64)) and not rule(mk(128, 256, stride=2)) and not rule(mk(256, 256, ks=1, pad=0))
     tile = Where2ComEngine.wino_x3_tile
     # the engine only ever launches the 64 x 64 tile (whole register file: nothing co-resident; see wino_x3_tile)

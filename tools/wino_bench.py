@@ -18,6 +18,8 @@ LAYERS = {
     "b1_n4": (4, 50, 176, 128, 128),
     "b1_n3": (3, 50, 176, 128, 128),
     "b0_n4": (4, 100, 352, 64, 64),
+    "b0_n1": (1, 100, 352, 64, 64),
+    "b0_n8": (8, 100, 352, 64, 64),
     "odd_n2": (2, 25, 87, 64, 64),
     # fixed cost per workgroup: the b2_n4 geometry (144 workgroups = one round) at 1 .. 64 chunks of 8 input channels
     "k8": (4, 25, 88, 8, 256), "k32": (4, 25, 88, 32, 256), "k128": (4, 25, 88, 128, 256), "k512": (4, 25, 88, 512, 256),
