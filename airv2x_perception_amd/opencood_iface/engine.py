@@ -168,6 +168,9 @@ def frame_layout(collaborators, data_dict):
     return record_len, slots
 
 
+WINO_X3_MIN_CIN = int(os.environ.get("AV2X_WINO_X3_MIN_CIN", "64"))    # 128 = the round-4 rule (block-0 layers on the fp32 Winograd kernels)
+
+
 class Where2ComEngine:
     def __init__(self, args, device="cuda"):
         self.args = args
@@ -669,7 +672,7 @@ class Where2ComEngine:
         """Layers the split-3 Winograd kernel takes: the F(2x2,3x3) class with 16-channel chunks and 64-cout blocks.  Round 5: from 64 input
         channels on (the 64 -> 64 block-0 layers at 100 x 352: 51.6 vs 59.6 us at 4 agents, 17.2 vs 21.5 at one, 92 vs 103-108 at eight once
         the kernel's epilogue and memory schedule were fixed, profiles/r05i_b0_layers.txt; round 4 kept them on the fp32 Winograd)."""
-        return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cin >= 64 and L.cout % 64 == 0 and L.coutp == L.cout
+        return Where2ComEngine.wino_rule(L) and L.cin % 16 == 0 and L.cin >= WINO_X3_MIN_CIN and L.cout % 64 == 0 and L.coutp == L.cout
 
     WINO_X3_T32 = os.environ.get("AV2X_WINO_X3_T32", "0") == "1"
     WINO_X3_T32_MAX_PIXELS = 50 * 176
