@@ -81,6 +81,21 @@ def test_points_in_boxes_cpu_matches_the_restatement_and_known_answers():
         rp.points_in_boxes_cpu(box, p, torch.zeros((2, 5), dtype=torch.int32))
 
 
+def test_empty_inputs_are_no_ops():
+    from airv2x_perception_amd.opencood_iface import box_overlaps as bo, roiaware_pool3d_cuda as rp
+    out = torch.zeros((0, 7), dtype=torch.int32)
+    assert rp.points_in_boxes_cpu(torch.zeros((0, 7)), torch.zeros((7, 3)), out) == 1 and out.numel() == 0
+    out = torch.full((3, 0), 5, dtype=torch.int32)
+    assert rp.points_in_boxes_cpu(torch.zeros((3, 7)), torch.zeros((0, 3)), out) == 1 and out.shape == (3, 0)
+    assert bo.bbox_overlaps(np.zeros((2, 4), np.float32), np.zeros((0, 4), np.float32)).shape == (2, 0)
+    assert bo.bbox_intersections(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32)).shape == (0, 0)
+    assert bo.box_vote(np.zeros((0, 5), np.float32), np.zeros((4, 5), np.float32)).shape == (0, 5)
+    # a degenerate (zero-extent) box holds only what its margin allows
+    o = torch.zeros((1, 2), dtype=torch.int32)
+    rp.points_in_boxes_cpu(torch.tensor([[0, 0, 0, 0, 0, 0, 0.0]]), torch.tensor([[0.005, 0.0, 0.0], [0.02, 0.0, 0.0]]), o)
+    assert o.tolist() == [[1, 0]]
+
+
 def test_install_import_shims_registers_the_references_module_names():
     import airv2x_perception_amd.opencood_iface as iface
     names = ("opencood", "opencood.pcdet_utils", "opencood.pcdet_utils.roiaware_pool3d", "opencood.utils")
