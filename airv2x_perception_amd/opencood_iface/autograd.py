@@ -36,15 +36,16 @@ def _runner(device):
         # synchronises, next to the weight-gradient side stream) would stall the first epoch and could persist a noisy pick.
         # Shipped / cached table hits are still used; a miss falls back to the pick_tile rule.  All candidates are bit-identical.
         r.tune_on_miss = False
-        # the training step is pinned to the reference's step gradient by gradient.  3x3 convolutions of the F(2x2,3x3) class: fp32-input
-        # matrix cores (their split-3 version gains nothing on single-stream launches).  1x1 / strided / transposed convolutions and the token
+        # the training step is pinned to the reference's step gradient by gradient.  1x1 / strided / transposed convolutions and the token
         # Linears of the transformer fusions: the pipelined split-3 GEMM (conv_igemm_x3p: products as exact as fp32 products, 1.3-1.5x the
         # fp32-input MFMA's rate); AV2X_TRAIN_X3P=0 restores the fp32-input GEMM
         r.x3p = os.environ.get("AV2X_TRAIN_X3P", "1") != "0"
-        # the F(4x4,3x3) class (the 256 -> 256 layers at 100 x 352) likewise on its split-3 kernel (conv_wino4_x3: 1.3x conv_wino4_f32);
-        # the F(2x2,3x3) class stays on the fp32-input kernel
+        # the F(4x4,3x3) class (the 256 -> 256 layers at 100 x 352) likewise on its split-3 kernel (conv_wino4_x3: 1.3x conv_wino4_f32), and
+        # since round 5 the F(2x2,3x3) class with >= 64 channels on conv_wino_x3, forward and data gradient (round 4's kernel gained nothing
+        # on these single-stream launches; round 5's: Where2Comm step 11.99 -> 11.51 ms, When2com 31.0 -> 30.2, V2VNet unchanged,
+        # profiles/r05o_train_wino2_x3_ab.txt); AV2X_TRAIN_WINO2_X3=0 restores the fp32-input Winograd kernel
         r.wino_x3 = r.wino4_x3 = r.x3p
-        r.wino2_x3 = False
+        r.wino2_x3 = r.x3p and os.environ.get("AV2X_TRAIN_WINO2_X3", "1") != "0"
     return r
 
 

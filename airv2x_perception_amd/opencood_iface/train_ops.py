@@ -128,12 +128,14 @@ def _packed(r, weight, flipped=False, owner=None):
     if r.winograd and ks == 3 and cin >= 64 and cin % 8 == 0 and cout % 64 == 0 and cout == coutp:   # engine.wino_rule's weight side
         u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=weight.device)
         _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u), r.stream()), "av2x_wino_pack_weights")
-    ent = [stamp, weakref.ref(own) if (own.is_leaf and isinstance(own, torch.nn.Parameter)) else None, wp, coutp, u, None, None, None]
+    ent = [stamp, weakref.ref(own) if (own.is_leaf and isinstance(own, torch.nn.Parameter)) else None, wp, coutp, u, None, None, None, None]
     if ent[1] is not None:
         if len(_PACKED) > 4096:
             _PACKED.clear()
         _PACKED[key] = ent
-    return wp, coutp, u, ent      # ent[5]: the F(4x4,3x3)-transformed weights, made by conv_raw on first need; ent[6]: the split-3 planes (seed_x3p); ent[7]: the F(4x4) class as split-3 planes
+    # ent[5]: the F(4x4,3x3)-transformed weights, made by conv_raw on first need; ent[6]: the split-3 planes (seed_x3p); ent[7]: the F(4x4)
+    # class as split-3 planes; ent[8]: the F(2x2) class as split-3 planes
+    return wp, coutp, u, ent
 
 
 # AMP training (tools/train.py:50,107-130: the forward runs under ``amp.autocast`` and the loss goes through a GradScaler): while
@@ -202,6 +204,12 @@ def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=Fals
                     _lib.check(r.lib.av2x_wino4_pack_weights(_P(wp), cin, coutp, _P(u4), r.stream()), "av2x_wino4_pack_weights")
                     ent[5] = u4
                 L._wu4 = ent[5]
+        elif r.wino_x3 and r.wino2_x3 and r.wino_x3_rule(L) and not AMP_STEP[0]:      # engine.conv's next choice: conv_wino_x3
+            if ent[8] is None:
+                u3 = torch.empty(r.lib.av2x_wino_x3_weight_bytes(cin, coutp) // 2, dtype=torch.bfloat16, device=x.device)
+                _lib.check(r.lib.av2x_wino_x3_pack_weights(_P(wp), cin, coutp, _P(u3), r.stream()), "av2x_wino_x3_pack_weights")
+                ent[8] = u3
+            L._wu3 = ent[8]
     else:
         seed_x3p(r, L, ent)
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
