@@ -124,17 +124,15 @@ def _packed(r, weight, flipped=False, owner=None):
         return ent[2], ent[3], ent[4], ent
     wp, coutp = pack_conv_weight_dev(weight, flipped)
     cout, cin, ks = (weight.shape[1], weight.shape[0], weight.shape[2]) if flipped else (weight.shape[0], weight.shape[1], weight.shape[2])
-    u = None
-    if r.winograd and ks == 3 and cin >= 64 and cin % 8 == 0 and cout % 64 == 0 and cout == coutp:   # engine.wino_rule's weight side
-        u = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=weight.device)
-        _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u), r.stream()), "av2x_wino_pack_weights")
-    ent = [stamp, weakref.ref(own) if (own.is_leaf and isinstance(own, torch.nn.Parameter)) else None, wp, coutp, u, None, None, None, None]
+    # engine.wino_rule's weight side: the class's transformed weights are made by conv_raw, for the kernel it picks, on first need
+    u = bool(r.winograd and ks == 3 and cin >= 64 and cin % 8 == 0 and cout % 64 == 0 and cout == coutp)
+    ent = [stamp, weakref.ref(own) if (own.is_leaf and isinstance(own, torch.nn.Parameter)) else None, wp, coutp, u, None, None, None, None, None]
     if ent[1] is not None:
         if len(_PACKED) > 4096:
             _PACKED.clear()
         _PACKED[key] = ent
-    # ent[5]: the F(4x4,3x3)-transformed weights, made by conv_raw on first need; ent[6]: the split-3 planes (seed_x3p); ent[7]: the F(4x4)
-    # class as split-3 planes; ent[8]: the F(2x2) class as split-3 planes
+    # ent[4]: Winograd-eligible weight (bool); ent[5]: the F(4x4,3x3)-transformed weights; ent[6]: the split-3 planes (seed_x3p); ent[7]: the
+    # F(4x4) class as split-3 planes; ent[8]: the F(2x2) class as split-3 planes; ent[9]: the F(2x2) class's fp32 transformed weights
     return wp, coutp, u, ent
 
 
@@ -186,12 +184,13 @@ def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=Fals
     sh = shift if shift is not None else _zeros(cout, x.device)
     L = ConvLayer(wp, scale, sh, cin, cout, coutp, ks, stride, pad, act)
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    if u is not None and r.wino_rule(L):   # transformed weights made on this stream, without engine._wu's cross-stream synchronise
-        L._wu = u
+    if u and r.wino_rule(L):   # transformed weights made on this stream, without engine._wu's cross-stream synchronise
         # the F(4x4,3x3) class (engine.wino4_rule: the 256 -> 256 layers at 100 x 352, forward and data gradient): its transformed
         # weights are cached with the packing, per parameter and version, built on the launch stream -- engine._wu4 would re-run the
         # transform on every call of this throw-away layer object and synchronise the host each time
-        if r.wino4 and r.wino4_rule(L, n, ho, wo):
+        if AMP_STEP[0] and cin % 8 == 0:
+            pass                                    # r.amp below: the bf16-operand GEMM takes the layer, no Winograd weights are read
+        elif r.wino4 and r.wino4_rule(L, n, ho, wo):
             if r.wino_x3 and r.wino4_x3 and cin % 32 == 0 and not AMP_STEP[0]:      # engine.conv's choice: the split-3 form of the class
                 if ent[7] is None:
                     u43 = torch.empty(r.lib.av2x_wino4_x3_weight_bytes(cin, coutp) // 2, dtype=torch.bfloat16, device=x.device)
@@ -210,6 +209,12 @@ def conv_raw(x, weight, stride, pad, scale=None, shift=None, act=0, flipped=Fals
                 _lib.check(r.lib.av2x_wino_x3_pack_weights(_P(wp), cin, coutp, _P(u3), r.stream()), "av2x_wino_x3_pack_weights")
                 ent[8] = u3
             L._wu3 = ent[8]
+        else:
+            if ent[9] is None:
+                u2 = torch.empty(r.lib.av2x_wino_weight_bytes(cin, coutp) // 4, dtype=torch.float32, device=x.device)
+                _lib.check(r.lib.av2x_wino_pack_weights(_P(wp), cin, coutp, _P(u2), r.stream()), "av2x_wino_pack_weights")
+                ent[9] = u2
+            L._wu = ent[9]
     else:
         seed_x3p(r, L, ent)
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
