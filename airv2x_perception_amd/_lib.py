@@ -38,6 +38,11 @@ SIGNATURES = {
                                   c_void_p]),
     "av2x_pillar_vfe_scatter_dev": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_pillar_vfe_scatter_count": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_pillar_vfe_scatter_dev_count": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "av2x_nonzero_slots_sum": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "av2x_voxelize_dummy_if_empty": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
     "av2x_pillar_scatter": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

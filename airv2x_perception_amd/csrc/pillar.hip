@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
     const int* __restrict__ n_dev,
     const float* __restrict__ pfn_w, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
     float vx, float vy, float vz, float xoff, float yoff, float zoff, float* __restrict__ canvas, int agent0,
-    const int* __restrict__ slot_map, int n_agents, int ny, int nx) {
+    const int* __restrict__ slot_map, int n_agents, int ny, int nx, unsigned long long* __restrict__ nonzero) {
     __shared__ __attribute__((aligned(16))) float feats[4][kPts][kLdF];
+    unsigned written_nz = 0;    // non-zero values this wave has put on the canvas (wave-uniform)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves_total = gridDim.x * 4;
@@ -95,8 +96,22 @@ __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
             // idx = z + y*nx + x with nz == 1 (point_pillar_scatter.py:59-61)
             const size_t pix = ((size_t)agent * ny + c.z) * nx + c.w + c.y;
             canvas[pix * kOut + lane] = best;
+            written_nz += (unsigned)__popcll(__ballot(best != 0.f));
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    // count_nonzero of the (zeroed, then scattered) canvas without reading it back: every cell is written by at most one pillar (the
+    // voxelizer's coordinates are unique per agent), so the canvas's non-zero count is the sum of the written non-zeros
+    // Same-address atomics serialise in L2 (~10 ns each: one per wave of a 2 048-workgroup launch was 80 us of tail), hence ONE per
+    // workgroup, spread over AV2X_NZ_SLOTS counters that live 128 bytes apart (different lines, different channels); the count is their sum.
+    if (MODE != 1 && nonzero != nullptr) {
+        __shared__ unsigned wave_nz[4];
+        if (lane == 0) wave_nz[wave] = written_nz;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = wave_nz[0] + wave_nz[1] + wave_nz[2] + wave_nz[3];
+            if (t) atomicAdd(nonzero + (size_t)(blockIdx.x % AV2X_NZ_SLOTS) * AV2X_NZ_STRIDE, (unsigned long long)t);
+        }
     }
 }
 
@@ -135,13 +150,27 @@ __global__ void count_nonzero_kernel(const float4* __restrict__ x, size_t n4, co
     }
 }
 
+// result[0] = sum of the AV2X_NZ_SLOTS strided counters of the counting scatter (one wave)
+__global__ void nonzero_slots_sum_kernel(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ result) {
+    unsigned long long c = threadIdx.x < AV2X_NZ_SLOTS ? slots[(size_t)threadIdx.x * AV2X_NZ_STRIDE] : 0ull;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if (threadIdx.x == 0) result[0] = c;
+}
+
 }  // namespace
 
-extern "C" int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_t* voxel_coords,
+extern "C" int av2x_nonzero_slots_sum(const unsigned long long* slots, unsigned long long* result, av2x_stream_t stream) {
+    if (!slots || !result) return av2x::fail("av2x_nonzero_slots_sum: null argument");
+    hipLaunchKernelGGL(nonzero_slots_sum_kernel, dim3(1), dim3(64), 0, av2x::as_stream(stream), slots, result);
+    return av2x::check_launch("nonzero_slots_sum_kernel");
+}
+
+extern "C" int av2x_pillar_vfe_scatter_count(const float* voxel_features, const int32_t* voxel_coords,
                                        const int32_t* voxel_num_points, int32_t n_pillars, const float* pfn_w,
                                        const float* bn_scale, const float* bn_shift, const float* geom, float* canvas,
                                        int32_t canvas_agent0, const int32_t* slot_map, int32_t n_agents_type, int32_t ny,
-                                       int32_t nx, av2x_stream_t stream) {
+                                       int32_t nx, unsigned long long* nonzero, av2x_stream_t stream) {
     if (n_pillars == 0) return 0;
     if (!voxel_features || !voxel_coords || !voxel_num_points || !pfn_w || !bn_scale || !bn_shift || !geom || !canvas)
         return av2x::fail("av2x_pillar_vfe_scatter: null argument");
@@ -151,8 +180,17 @@ extern "C" int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_
     hipLaunchKernelGGL(pillar_vfe_scatter_kernel<0>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
                        voxel_num_points, n_pillars, (const int*)nullptr, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
-                       geom[4], geom[5], canvas, canvas_agent0, slot_map, n_agents_type, ny, nx);
+                       geom[4], geom[5], canvas, canvas_agent0, slot_map, n_agents_type, ny, nx, nonzero);
     return av2x::check_launch("pillar_vfe_scatter_kernel");
+}
+
+extern "C" int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_t* voxel_coords,
+                                       const int32_t* voxel_num_points, int32_t n_pillars, const float* pfn_w,
+                                       const float* bn_scale, const float* bn_shift, const float* geom, float* canvas,
+                                       int32_t canvas_agent0, const int32_t* slot_map, int32_t n_agents_type, int32_t ny,
+                                       int32_t nx, av2x_stream_t stream) {
+    return av2x_pillar_vfe_scatter_count(voxel_features, voxel_coords, voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, geom, canvas,
+                                         canvas_agent0, slot_map, n_agents_type, ny, nx, nullptr, stream);
 }
 
 extern "C" int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
@@ -167,14 +205,15 @@ extern "C" int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel
     hipLaunchKernelGGL(pillar_vfe_scatter_kernel<1>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
                        voxel_num_points, n_pillars, (const int*)nullptr, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
-                       geom[4], geom[5], pillar_features, 0, (const int*)nullptr, 0, 0, 0);
+                       geom[4], geom[5], pillar_features, 0, (const int*)nullptr, 0, 0, 0, (unsigned long long*)nullptr);
     return av2x::check_launch("pillar_vfe_kernel");
 }
 
-extern "C" int av2x_pillar_vfe_scatter_dev(const float* voxel_features, const int32_t* voxel_coords3,
+extern "C" int av2x_pillar_vfe_scatter_dev_count(const float* voxel_features, const int32_t* voxel_coords3,
                                            const int32_t* voxel_num_points, const int32_t* n_pillars_dev, int32_t capacity,
                                            const float* pfn_w, const float* bn_scale, const float* bn_shift, const float* geom,
-                                           float* canvas, int32_t canvas_slot, int32_t ny, int32_t nx, av2x_stream_t stream) {
+                                           float* canvas, int32_t canvas_slot, int32_t ny, int32_t nx, unsigned long long* nonzero,
+                                                 av2x_stream_t stream) {
     if (capacity == 0) return 0;
     if (!voxel_features || !voxel_coords3 || !voxel_num_points || !n_pillars_dev || !pfn_w || !bn_scale || !bn_shift || !geom || !canvas)
         return av2x::fail("av2x_pillar_vfe_scatter_dev: null argument");
@@ -184,8 +223,16 @@ extern "C" int av2x_pillar_vfe_scatter_dev(const float* voxel_features, const in
     hipLaunchKernelGGL(pillar_vfe_scatter_kernel<2>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords3),
                        voxel_num_points, capacity, n_pillars_dev, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
-                       geom[4], geom[5], canvas, canvas_slot, (const int*)nullptr, 1, ny, nx);
+                       geom[4], geom[5], canvas, canvas_slot, (const int*)nullptr, 1, ny, nx, nonzero);
     return av2x::check_launch("pillar_vfe_scatter_kernel<2>");
+}
+
+extern "C" int av2x_pillar_vfe_scatter_dev(const float* voxel_features, const int32_t* voxel_coords3,
+                                           const int32_t* voxel_num_points, const int32_t* n_pillars_dev, int32_t capacity,
+                                           const float* pfn_w, const float* bn_scale, const float* bn_shift, const float* geom,
+                                           float* canvas, int32_t canvas_slot, int32_t ny, int32_t nx, av2x_stream_t stream) {
+    return av2x_pillar_vfe_scatter_dev_count(voxel_features, voxel_coords3, voxel_num_points, n_pillars_dev, capacity, pfn_w, bn_scale, bn_shift,
+                                             geom, canvas, canvas_slot, ny, nx, nullptr, stream);
 }
 
 extern "C" int av2x_pillar_scatter(const float* pillar_features, const int32_t* voxel_coords, int32_t n_pillars,

@@ -985,6 +985,7 @@ class Where2ComEngine:
         canvas = self.buf("canvas", (n, ny, nx, 64))
         st = self.stream()
         _lib.check(self.lib.av2x_fill_zero(_ptr(canvas), canvas.numel() * 4, st), "av2x_fill_zero")
+        nz = self._nz_begin(st)
         r6, v3 = (c_float * 6)(*rng), (c_float * 3)(*vs)
         for i, (pts, t) in enumerate(zip(clouds, types)):
             if pts.device != self.device or pts.dtype != torch.float32 or not pts.is_contiguous():
@@ -1011,9 +1012,10 @@ class Where2ComEngine:
                                                              _ptr(voxels), _ptr(coords), _ptr(num), _ptr(cnt), st),
                        "av2x_voxelize_dummy_if_empty")
             w, sc, sh, geom = self.pfn[t]
-            _lib.check(self.lib.av2x_pillar_vfe_scatter_dev(_ptr(voxels), _ptr(coords), _ptr(num), _ptr(cnt), cap, _ptr(w), _ptr(sc),
-                                                            _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), i, ny, nx, st),
-                       "av2x_pillar_vfe_scatter_dev")
+            _lib.check(self.lib.av2x_pillar_vfe_scatter_dev_count(_ptr(voxels), _ptr(coords), _ptr(num), _ptr(cnt), cap, _ptr(w), _ptr(sc),
+                                                                  _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), i, ny, nx, _ptr(nz), st),
+                       "av2x_pillar_vfe_scatter_dev_count")
+        self._nz_canvas = canvas if nz is not None else None
         return canvas, ny, nx
 
     def encode(self, data_dict, record_len, slots):
@@ -1034,7 +1036,10 @@ class Where2ComEngine:
         if any(t in self.pfn for t in slots):
             self.timed_hbm("canvas clear (hipMemsetAsync)", lidar_canvas.numel() * 4, 0.0,
                            lambda: _lib.check(self.lib.av2x_fill_zero(_ptr(lidar_canvas), lidar_canvas.numel() * 4, st), "av2x_fill_zero"))
-        self.encode_lidar(data_dict, slots, lidar_canvas, ny, nx)
+        # a LiDAR-only frame: the scatter counts the non-zeros it writes (comm_rate, airv2x_where2com.py:122) -- no read-back pass over the canvas
+        nz = self._nz_begin(st) if not any(t in cam for t in slots) else None
+        self.encode_lidar(data_dict, slots, lidar_canvas, ny, nx, nz)
+        self._nz_canvas = canvas if nz is not None else None
         per = ny * nx * 64
         for t, sl in slots.items():
             if t not in cam:
@@ -1057,8 +1062,34 @@ class Where2ComEngine:
                            "av2x_mean2")
         return canvas, ny, nx
 
-    def encode_lidar(self, data_dict, slots, canvas, ny, nx):
-        """Sequential(PillarVFE, PointPillarScatter) of every agent type with a LiDAR encoder, into the (zeroed) canvas rows."""
+    FOLD_COUNT = os.environ.get("AV2X_FOLD_COUNT", "1") != "0"
+    _nz_canvas = None       # the canvas whose non-zero count the scatter has already put into buf("nonzero") (see count_canvas)
+
+    def _nz_begin(self, st):
+        """Zeroed counter for a counting scatter, or None when the fold is switched off (AV2X_FOLD_COUNT=0: count by read-back)."""
+        if not self.FOLD_COUNT:
+            return None
+        nz = self.buf("nonzero_slots", (32 * 16,), torch.int64)       # AV2X_NZ_SLOTS counters, AV2X_NZ_STRIDE apart (include/airv2x_hip.h)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), nz.numel() * 8, st), "av2x_fill_zero")
+        return nz
+
+    def count_canvas(self, canvas, st):
+        """comm_rate = spatial_features.count_nonzero() (airv2x_where2com.py:122) -> device counter (1,) i64.  encode() of a LiDAR-only frame
+        has counted while scattering (every cell is written at most once into a zeroed canvas); any other canvas (camera rows, a caller's
+        own tensor) is counted by a read-back pass."""
+        nz = self.buf("nonzero", (1,), torch.int64)
+        if self._nz_canvas is canvas and canvas is not None:
+            self._nz_canvas = None
+            _lib.check(self.lib.av2x_nonzero_slots_sum(_ptr(self.buf("nonzero_slots", (32 * 16,), torch.int64)), _ptr(nz), st), "av2x_nonzero_slots_sum")
+            return nz
+        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        self.timed_hbm("count_nonzero (comm_rate)", canvas.numel() * 4, 0.0,
+                       lambda: _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero"))
+        return nz
+
+    def encode_lidar(self, data_dict, slots, canvas, ny, nx, nz=None):
+        """Sequential(PillarVFE, PointPillarScatter) of every agent type with a LiDAR encoder, into the (zeroed) canvas rows; ``nz``: the
+        device counter the scatter adds its written non-zeros to."""
         st = self.stream()
         for t, sl in slots.items():
             if t not in self.pfn:
@@ -1078,9 +1109,10 @@ class Where2ComEngine:
             if not contiguous:
                 smap = torch.tensor(sl, dtype=torch.int32, device=self.device)
             self.timed_hbm("pillar_vfe_scatter", vf.shape[0] * (512 + 12 + 4 + 256), 2.0 * 32 * 10 * 64 * vf.shape[0],
-                           lambda: _lib.check(self.lib.av2x_pillar_vfe_scatter(_ptr(vf), _ptr(vc), _ptr(vn), vf.shape[0], _ptr(w), _ptr(sc),
-                                                                               _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), sl[0],
-                                                                               _ptr(smap), len(sl), ny, nx, st), "av2x_pillar_vfe_scatter"))
+                           lambda: _lib.check(self.lib.av2x_pillar_vfe_scatter_count(_ptr(vf), _ptr(vc), _ptr(vn), vf.shape[0], _ptr(w), _ptr(sc),
+                                                                                     _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), sl[0],
+                                                                                     _ptr(smap), len(sl), ny, nx, _ptr(nz), st),
+                                              "av2x_pillar_vfe_scatter_count"))
 
     def trunk(self, canvas, n, ny, nx, tag="all", block_out=None, shrink_out=None):
         """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""
@@ -1210,10 +1242,7 @@ class Where2ComEngine:
                 and not self.fcfg["fully"] and not torch.cuda.is_current_stream_capturing()):
             return self._post_encode_groups(canvas, ny, nx, n)
         st = self.stream()
-        nz = self.buf("nonzero", (1,), torch.int64)
-        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
-        self.timed_hbm("count_nonzero (comm_rate)", canvas.numel() * 4, 0.0,
-                       lambda: _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero"))
+        nz = self.count_canvas(canvas, st)
 
         feats, s, H, W = self.trunk(canvas, n, ny, nx)
         psm_single = self.buf("psm_single", (n, H, W, self.A * self.C))
@@ -1298,8 +1327,7 @@ class Where2ComEngine:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(G)]
         main = torch.cuda.current_stream()
         st = self.stream()
-        nz = self.buf("nonzero", (1,), torch.int64)
-        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
+        nz = self.count_canvas(canvas, st)
         count = self.buf("comm_count", (1,), torch.int32)
         _lib.check(self.lib.av2x_fill_zero(_ptr(count), 4, st), "av2x_fill_zero")
         bounds = [(g * n) // G for g in range(G + 1)]
@@ -1330,7 +1358,6 @@ class Where2ComEngine:
                 done = torch.cuda.Event()
                 done.record(s_g)
             groups.append((g0, g1, first, b0, b1, b2, m1, m2, done))
-        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
         for gr in groups:
             main.wait_event(gr[-1])
         dims = self.level_dims(ny, nx)
@@ -1430,9 +1457,7 @@ class Where2ComEngine:
 
     def _shard_local_body(self, canvas, send, n, n_pad, has_ego, ny, nx, record_len, dims, sizes):
         st = self.stream()
-        nz = self.buf("nonzero", (1,), torch.int64)
-        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
-        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        nz = self.count_canvas(canvas, st)
         lv, off = [], 0
         for (h, w, c), f in zip(dims, sizes):
             lv.append(send[off:off + n * f].view(n, h, w, c))

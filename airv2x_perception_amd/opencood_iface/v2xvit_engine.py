@@ -507,9 +507,7 @@ class V2XViTEngine(Where2ComEngine):
         if n == 0:
             return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
         st = self.stream()
-        nz = self.buf("nonzero", (1,), torch.int64)
-        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
-        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        nz = self.count_canvas(canvas, st)
         self.trunk(canvas, n, ny, nx, shrink_out=send[:n * H * Wd * 256].view(n, H, Wd, 256))
         stats = torch.stack([torch.zeros((), dtype=torch.int64, device=self.device), nz[0]])
         return send, stats, meta
@@ -606,9 +604,7 @@ class V2XViTEngine(Where2ComEngine):
         scm_all = data_dict["spatial_correction_matrix"].detach().cpu().numpy()  # (B,L,4,4) f64
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         st = self.stream()
-        nz = self.buf("nonzero", (1,), torch.int64)
-        _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")
-        _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero")
+        nz = self.count_canvas(canvas, st)
         dims = self.level_dims(ny, nx)
         H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
         x = self.buf("vit_x", (n_total, H, Wd, 256))

@@ -70,6 +70,26 @@ int av2x_pillar_vfe_scatter_dev(const float* voxel_features, const int32_t* voxe
                                 int32_t nx, av2x_stream_t stream);
 int av2x_pillar_scatter(const float* pillar_features, const int32_t* voxel_coords, int32_t n_pillars, int32_t channels,
                         float* canvas, int32_t n_agents, int32_t ny, int32_t nx, av2x_stream_t stream);
+/* The two scatter entries that also COUNT what they write: nonzero (device; NULL = no count) is an array of AV2X_NZ_SLOTS u64 counters
+ * that live AV2X_NZ_STRIDE u64 (128 bytes) apart -- AV2X_NZ_SLOTS * AV2X_NZ_STRIDE * 8 = 4096 bytes, zeroed by the caller; workgroup b
+ * adds the number of non-zero values it put on the canvas to counter b % AV2X_NZ_SLOTS (one atomic per workgroup, spread over cache
+ * lines: thousands of same-address atomics serialise in L2), and the count is the SUM of the array.  With a canvas the caller
+ * zero-filled and coordinates that are unique per agent (the voxelizer's are) that is torch.count_nonzero of the scattered canvas -- the `comm_rate` of the LiDAR-only frame (airv2x_where2com.py:122,
+ * batch_spatial_features.count_nonzero()) -- without the 144 MB read-back pass of av2x_count_nonzero at the BASELINE grid. */
+#define AV2X_NZ_SLOTS 32
+#define AV2X_NZ_STRIDE 16
+/* result[0] = the sum of the AV2X_NZ_SLOTS counters (a store, not an add) */
+int av2x_nonzero_slots_sum(const unsigned long long* slots, unsigned long long* result, av2x_stream_t stream);
+int av2x_pillar_vfe_scatter_count(const float* voxel_features, const int32_t* voxel_coords,
+                                  const int32_t* voxel_num_points, int32_t n_pillars,
+                                  const float* pfn_w, const float* bn_scale, const float* bn_shift,
+                                  const float* geom, float* canvas, int32_t canvas_agent0,
+                                  const int32_t* slot_map, int32_t n_agents_type, int32_t ny, int32_t nx,
+                                  unsigned long long* nonzero, av2x_stream_t stream);
+int av2x_pillar_vfe_scatter_dev_count(const float* voxel_features, const int32_t* voxel_coords3, const int32_t* voxel_num_points,
+                                      const int32_t* n_pillars_dev, int32_t capacity, const float* pfn_w, const float* bn_scale,
+                                      const float* bn_shift, const float* geom, float* canvas, int32_t canvas_slot, int32_t ny,
+                                      int32_t nx, unsigned long long* nonzero, av2x_stream_t stream);
 
 int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
 

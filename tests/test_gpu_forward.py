@@ -324,3 +324,20 @@ def test_workspace_pool_is_bounded_when_the_frame_layout_keeps_changing():
             assert torch.equal(out[key], want[k][key]), (it, key)
         peak = max(peak, eng._ws_bytes)
     assert peak <= eng.ws_limit + one        # bounded: the limit plus at most the frame in progress
+
+
+def test_comm_rate_counted_in_the_scatter_equals_the_read_back_count():
+    """comm_rate = spatial_features.count_nonzero() (airv2x_where2com.py:122): the LiDAR-only frame counts while it scatters
+    (av2x_pillar_vfe_scatter_count); with the fold switched off the same engine counts by reading the canvas back.  Same integer, and the
+    one the reference's own model produced (fixture)."""
+    fx, args, sd, dd, out, tr, model = _run("w2c_small_n3")
+    eng = model.engine()
+    assert eng.FOLD_COUNT
+    a = eng.forward(dd, sync_comm_rate=True)["comm_rate"]
+    eng.FOLD_COUNT = False
+    try:
+        b = eng.forward(dd, sync_comm_rate=True)["comm_rate"]
+    finally:
+        eng.FOLD_COUNT = True
+    c = eng.forward(dd, sync_comm_rate=True)["comm_rate"]
+    assert a == b == c == int(fx["comm_rate"])

@@ -351,6 +351,19 @@ def test_pillar_vfe_scatter(lib, agent_type):
     nz = torch.zeros(1, dtype=torch.int64, device="cuda")
     _lib.check(lib.av2x_count_nonzero(_p(canvas), canvas.numel(), _p(nz), _stream()), "nz")
     assert int(nz.item()) == int(ref.count_nonzero().item())
+    # the counting entry: same canvas, and the counter it adds to equals count_nonzero of what it wrote (here on top of a preset value)
+    canvas2 = torch.zeros((3, ny, nx, 64), device="cuda")
+    nz2 = torch.zeros(32 * 16, dtype=torch.int64, device="cuda")       # AV2X_NZ_SLOTS counters, AV2X_NZ_STRIDE apart
+    nz2[16] = 7
+    _lib.check(lib.av2x_pillar_vfe_scatter_count(_p(d_vf), _p(d_vc), _p(d_vn), vf.shape[0], _p(d_w), _p(d_sc), _p(d_sh),
+                                                 ctypes.cast(geom, c_void_p), _p(canvas2), 0, _p(smap), 2, ny, nx, _p(nz2),
+                                                 _stream()), "pillar count")
+    assert torch.equal(canvas2, canvas)
+    assert int(nz2.sum().item()) == 7 + int(nz.item())
+    assert int(nz2.view(32, 16)[:, 1:].abs().sum().item()) == 0      # only the strided slots are touched
+    tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.check(lib.av2x_nonzero_slots_sum(_p(nz2), _p(tot), _stream()), "slots sum")
+    assert int(tot.item()) == 7 + int(nz.item())
 
 
 def test_comm_mask(lib):
