@@ -19,6 +19,7 @@
 //   C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 //
 //   layernorm_bf16_kernel   nn.LayerNorm over C = 256 of the fp32 residual stream, bf16 out (the A operand above)
+#include <cstdlib>
 #include <type_traits>
 
 #include "av2x_common.hpp"
@@ -484,6 +485,9 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
 //   the stored tensor was, the attention is the instruction sequence of v2xvit.hip's kernels: the outputs are the bits of
 //   av2x_ln_linear_bf16 + 3 x av2x_window_attention_linear_bf16.  Eight K-steps of weight fragments in flight (one workgroup per
 //   CU: nobody else hides the L2 latency).
+#ifndef AV2X_QW_ABLATE      // timing experiments of tools/micro/qw_ablate.sh (wrong results): 1 no weight stream after the first fragments,
+#define AV2X_QW_ABLATE 0    // 2 no attention phases, 4 no output stores, (slab kernel) 8 no q / k / v panel stores, 16 no QKV K loops; the library never defines it
+#endif
 struct QwParams {
     const float* x;
     const __bf16* delta;      // pending residual of every row (or nullptr): feeds the LayerNorm, x is not rewritten
@@ -545,7 +549,9 @@ __global__ __launch_bounds__(512, 1) void ln_qkv_window_out_bf16_kernel(const Qw
     const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w2), 0, (unsigned)((LK / 8) * CP2 * 16), 0x00020000);
     const unsigned voff1 = (unsigned)((lh * CP1 + wave * 64 + li) * 16), voff2 = (unsigned)((lh * CP2 + wave * 64 + li) * 16);
     u32x4 bf[DEPTH][2];
+    bool qw_first = true;
     auto loadB = [&](u32x4 (&dst)[2], bool second, int ch, int s) {
+        if constexpr ((AV2X_QW_ABLATE & 1) != 0) { if (!qw_first) return; }
         if (second) {
             const unsigned so = (unsigned)s * (2 * CP2 * 16) + (unsigned)ch * (256 * 16);
             dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw2, voff2, so, 0);
@@ -560,6 +566,7 @@ __global__ __launch_bounds__(512, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) loadB(bf[s], false, 0, s);
     }
+    qw_first = false;
 
     // ---- P0 = LayerNorm(x (+ delta)): wave w = block row w, 16 pixels, four channels per lane (layernorm_row_256)
     {
@@ -821,16 +828,403 @@ __global__ __launch_bounds__(512, 1) void ln_qkv_window_out_bf16_kernel(const Qw
             if (gemm) epilogue(ch, biasl, P1 + c * PSZ, rw, std::true_type{});
         }
         __syncthreads();                          // q, k, v of the branch are complete
-        if (p.dh[b] == 16) win2(p.heads[b], posl + 64 * b);
-        else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], posl + 64 * b);
-        else win4(std::integral_constant<int, 64>{}, p.heads[b], posl + 64 * b);
+        if constexpr ((AV2X_QW_ABLATE & 2) == 0) {
+            if (p.dh[b] == 16) win2(p.heads[b], posl + 64 * b);
+            else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, p.heads[b], posl + 64 * b);
+            else win4(std::integral_constant<int, 64>{}, p.heads[b], posl + 64 * b);
+        }
         __syncthreads();                          // the attention output (in P1) is complete
         if (gemm) {
             kloop(P1, true, b, false, b < 2 ? 3 * (b + 1) : 0, true);
             const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out[b] + m0 * LK, 0, (unsigned)span * (LK * 2), 0x00020000);
-            epilogue(b, biasl + 2304, nullptr, rout, std::false_type{});
+            if constexpr ((AV2X_QW_ABLATE & 4) == 0) epilogue(b, biasl + 2304, nullptr, rout, std::false_type{});
+            else if (acc[0][0][0] + acc[1][1][5] == 123.f) epilogue(b, biasl + 2304, nullptr, rout, std::false_type{});
         }
     }
+}
+
+// ---- The same fused layer with TWO workgroups per CU (round 5).  ln_qkv_window_out_bf16_kernel above holds four 33-KB panels (132 KB of
+// LDS): one workgroup per CU, and its phases -- panel load + LayerNorm, twelve K loops on four of the eight waves, the attention tasks,
+// the output stores -- run one after the other with nothing to overlap them (timing-only builds, tools/micro/qw_ablate.sh: without the
+// weight stream 852 -> 780 us per 8-agent launch, without the attention phases 665, without both and the stores 519 = 2.5 x the MFMA time of
+// its K loops; the weight stream the round-4 notes blamed is NOT what bounds it).  Here a workgroup is four waves and works through the
+// 2304 QKV columns in HEAD SLABS of 64 columns: q, k, v of one slab (three [64][72] bf16 panels) -> the attention of the slab's heads ->
+// its [64][72] output panel is the K = 64 slice 4 j .. 4 j + 3 of to_out's K loop, accumulated in registers across the four slabs of a
+// branch.  LDS: the LayerNorm panel 33 KB + four slab panels 36 KB + the position tables = 71.4 KB -> two workgroups per CU, one in its
+// attention / epilogue / store phases while the other one's MFMAs run.  Per slab and workgroup: wave 0 = q (64 x 64), wave 1 = k, waves 2 / 3
+// = the even / odd columns of v (64 x 32 each: a B fragment of an interleaved-pair group holds one parity), every wave one 64-column group
+// of to_out.  Every output sees the MFMA sequence of the kernel above (same fragments, same K order: to_out's K steps 0..15 in order over
+// the slabs), the same bf16 roundings of q / k / v / attention output, and the attention instruction sequence per (window, head): the bits
+// of av2x_ln_linear_bf16 + 3 x av2x_window_attention_linear_bf16 (tests/test_gpu_bf16_activations.py).
+constexpr int SROW = 64 + 8;    // slab panel row stride in bf16 elements (144 B: conflict-free ds_read_b128 over 16 rows)
+
+__global__ __launch_bounds__(256, 2) void ln_qkv_window_out_slab_kernel(const QwParams p) {
+    constexpr int PSZ = 64 * LROW, SSZ = 64 * SROW, DEPTH = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
+    __bf16* P0 = reinterpret_cast<__bf16*>(lin_smem);
+    __bf16* Qs = P0 + PSZ;
+    __bf16* Ks = Qs + SSZ;
+    __bf16* Vs = Ks + SSZ;
+    __bf16* Os = Vs + SSZ;
+    float* posl = reinterpret_cast<float*>(Os + SSZ);              // [3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int bx = p.W >> 4, by = p.H >> 2;
+    const int tx = blockIdx.x % bx, ty = (blockIdx.x / bx) % by, ag = blockIdx.x / (bx * by);
+    const long long m0 = ((long long)ag * p.H + 4 * ty) * p.W + 16 * tx;
+    const int span = 3 * p.W + 16;                                  // tokens from the block's first pixel to its last
+    if (tid < 192) {
+        const int b = tid >> 6, i = tid & 63;
+        const int side = p.dh[b] == 16 ? 3 : 7;
+        posl[tid] = i < side * side ? p.pos[b][i] : 0.f;
+    }
+
+    constexpr int CP1 = 2304, CP2 = 768;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (unsigned)((LK / 8) * CP1 * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w2), 0, (unsigned)((LK / 8) * CP2 * 16), 0x00020000);
+    // role of the wave in a slab's QKV product: which of q / k / v (the chunk of the branch), and for v which column parity (B tile)
+    // (the q / k waves issue twice the MFMAs of the v waves: the two workgroups of a CU should not both put them on SIMDs 0 and 1 -- workgroups
+    // b and b + 256 are the likely first pair of a CU (round-robin over 8 XCDs x 32 CUs), so bit 8 of the index swaps the wave pairs)
+    const int rwv = wave ^ (2 * ((blockIdx.x >> 8) & 1));
+    const int role = rwv < 2 ? rwv : 2;                             // 0 q, 1 k, 2 v
+    const int cv = rwv < 2 ? 0 : rwv - 2;                           // v: B tile (= parity of the logical columns) of this wave
+    const bool pair = rwv < 2;                                      // q / k waves own both tiles of the slab's group
+    u32x4 bq[DEPTH][2];                                             // QKV ring: DEPTH K-steps x (up to) two B tiles
+    u32x4 bt[4][2];                                                 // to_out: the four K-steps of a slab x two B tiles
+    bool qw_first = true;
+    auto load_q = [&](u32x4 (&dst)[2], int b, int j, int s) __attribute__((always_inline)) {       // step s of slab j of branch b, this wave's columns
+        if constexpr ((AV2X_QW_ABLATE & 1) != 0) { if (!qw_first) return; }
+        const unsigned vo = (unsigned)((lh * CP1 + j * 64 + li) * 16);
+        const unsigned so = (unsigned)s * (2 * CP1 * 16) + (unsigned)(3 * b + role) * (256 * 16);
+        if (pair) {
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, vo, so, 0);
+            dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rw, vo + 32 * 16, so, 0);
+        } else {
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rw, vo + (unsigned)cv * (32 * 16), so, 0);
+        }
+    };
+    auto load_t = [&](int b, int j) __attribute__((always_inline)) {                               // to_out of branch b: K-steps 4 j .. 4 j + 3, columns 64 wave ..
+        if constexpr ((AV2X_QW_ABLATE & 1) != 0) { if (b + j > 0) return; }
+        const unsigned vo = (unsigned)((lh * CP2 + wave * 64 + li) * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned so = (unsigned)(4 * j + t) * (2 * CP2 * 16) + (unsigned)b * (256 * 16);
+            bt[t][0] = __builtin_amdgcn_raw_buffer_load_b128(rw2, vo, so, 0);
+            bt[t][1] = __builtin_amdgcn_raw_buffer_load_b128(rw2, vo + 32 * 16, so, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) load_q(bq[s], 0, 0, s);
+    qw_first = false;
+
+    // ---- P0 = LayerNorm(x (+ delta)): wave w = block row w (16 pixels, two passes of eight), four channels per lane (layernorm_row_256)
+    {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + m0 * LK, 0, (unsigned)span * (LK * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.delta ? p.delta + m0 * LK : nullptr), 0,
+                                                                            p.delta ? (unsigned)span * (LK * 2) : 0u, 0x00020000);
+        const float4 g = reinterpret_cast<const float4*>(p.gamma)[lane], bta = reinterpret_cast<const float4*>(p.beta)[lane];
+        const bool add = p.delta != nullptr;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        f32x4 xv[16];
+        u32x2 dv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int tok = wave * p.W + j;
+            xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(tok * (LK * 4) + lane * 16), 0, LIN_NT));
+            dv[j] = __builtin_amdgcn_raw_buffer_load_b64(rd, (unsigned)(tok * (LK * 2) + lane * 8), 0, LIN_NT);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float4 v = make_float4(xv[j][0], xv[j][1], xv[j][2], xv[j][3]);
+            if (add) v = add_bf16x4(v, make_uint2(dv[j][0], dv[j][1]));
+            const f32x4 y = layernorm_row_256(v, g, bta, p.eps);
+            *reinterpret_cast<bf16x4*>(P0 + (wave * 16 + j) * LROW + 4 * lane) = __builtin_convertvector(y, bf16x4);
+        }
+    }
+    __syncthreads();
+
+    const bool odd = li & 1, hi = li & 2;
+    f32x16 acc[2][2], acct[2][2];
+    // slab panels: the columns of row r are rotated by 16 (r >> 4) elements (mod 64): the attention reads rows 16 apart at the same column
+    auto swz = [](int row, int col) __attribute__((always_inline)) { return (col + 16 * (row >> 4)) & 63; };
+
+    // QKV product of a slab: 64 rows x this wave's columns, K = 256 from the LayerNorm panel; the ring holds steps 0 .. DEPTH - 1 on entry
+    auto kloop_qkv = [&](int b, int j) __attribute__((always_inline)) {
+        const __bf16* Ab = P0 + li * LROW + lh * 8;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+        bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab);
+        bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            bf16x8 fn0 = fa0, fn1 = fa1;
+            if (s + 1 < 16) {
+                fn0 = *reinterpret_cast<const bf16x8*>(Ab + (s + 1) * 16);
+                fn1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * LROW + (s + 1) * 16);
+            }
+            {
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s & (DEPTH - 1)][0]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][0], 0, 0, 0);
+            }
+            if (pair) {
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bq[s & (DEPTH - 1)][1]);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][1], 0, 0, 0);
+            }
+            if (s + DEPTH < 16) load_q(bq[s & (DEPTH - 1)], b, j, s + DEPTH);
+            fa0 = fn0; fa1 = fn1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // bias, one rounding to bf16, into the wave's slab panel in the raw MFMA layout (rows rotated as swz): q / k waves store the lane's column
+    // pair (4 bytes), the v waves their parity's column (2 bytes)
+    auto epilogue_qkv = [&](int b, int j) __attribute__((always_inline)) {
+        __bf16* panel = Qs + role * SSZ + (4 * lh) * SROW;          // Qs, Ks, Vs are consecutive
+        const int n = (3 * b + role) * 256 + j * 64 + 2 * li;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        if (pair) {
+            const float b0 = p.bias ? p.bias[n] : 0.f, b1 = p.bias ? p.bias[n + 1] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 v = {acc[a][0][r] + b0, acc[a][1][r] + b1};
+                    *reinterpret_cast<unsigned*>(panel + (a * 32 + (r & 3) + 8 * (r >> 2)) * SROW + ((2 * li + 16 * (2 * a + (r >> 3))) & 63)) =
+                        __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                }
+        } else {
+            const float b0 = p.bias ? p.bias[n + cv] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    panel[(a * 32 + (r & 3) + 8 * (r >> 2)) * SROW + ((2 * li + cv + 16 * (2 * a + (r >> 3))) & 63)] = (__bf16)(acc[a][0][r] + b0);
+        }
+    };
+    // K-steps 4 j .. 4 j + 3 of to_out on the slab's attention output (rotated rows), this wave's 64 columns
+    auto kloop_out = [&]() __attribute__((always_inline)) {
+        const __bf16* Ab = Os + li * SROW;
+        const int rot0 = 16 * (li >> 4), rot1 = 16 * (2 + (li >> 4));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Ab + ((t * 16 + lh * 8 + rot0) & 63));
+            const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * SROW + ((t * 16 + lh * 8 + rot1) & 63));
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bt[t][c]);
+                acct[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acct[0][c], 0, 0, 0);
+                acct[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acct[1][c], 0, 0, 0);
+            }
+        }
+    };
+    // to_out's epilogue of branch b (as the kernel above): bias, one rounding, quad transposes, 16-byte stores into the block's output rows
+    auto epilogue_out = [&](int b) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out[b] + m0 * LK, 0, (unsigned)span * (LK * 2), 0x00020000);
+        const int n = b * 256 + wave * 64 + 2 * li;
+        const float b0 = p.bias2[n], b1 = p.bias2[n + 1];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const unsigned off0 = (unsigned)((4 * lh + (li & 3)) * 512 + (wave * 64 + 2 * (li & ~3)) * 2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned R[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int r = 4 * g + jj;
+                    const f32x2 v = {acct[a][0][r] + b0, acct[a][1][r] + b1};
+                    R[jj] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned send = odd ? R[2 * m] : R[2 * m + 1];
+                    const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);
+                    R[2 * m] = odd ? got : R[2 * m];
+                    R[2 * m + 1] = odd ? R[2 * m + 1] : got;
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned send = hi ? R[m] : R[m + 2];
+                    const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);
+                    R[m] = hi ? got : R[m];
+                    R[m + 2] = hi ? R[m + 2] : got;
+                }
+                const u32x4 v4 = {R[0], R[1], R[2], R[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(v4, rout, off0 + (unsigned)(((2 * a + (g >> 1)) * p.W + 8 * (g & 1)) * 512), 0, LIN_NT);
+            }
+    };
+    // window_attn_mfma_kernel on the slab panels: (window, head-of-the-slab) tasks of the block's four 4 x 4 windows, output -> Os
+    auto win4 = [&](auto dhc, const float* pos) __attribute__((always_inline)) {
+        constexpr int DH = decltype(dhc)::value, WS = 4, NB = DH / 16, HS = 64 / DH, U = HS;   // 4 HS tasks: U per wave
+        const int t = lane & 15, h = lane >> 4;
+        const int iy = t >> 2, ix = t & 3;
+        const float scale = 1.0f / sqrtf((float)DH);
+        float wbias[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wbias[r] = pos[(h - iy + WS - 1) * (2 * WS - 1) + (r - ix + WS - 1)];
+        int head[U], wdw[U], rowt[U];
+        lin_f32x4 st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tk = wave + 4 * u;
+            head[u] = tk % HS; wdw[u] = tk / HS;
+            rowt[u] = ((t >> 2) * 16 + 4 * wdw[u] + (t & 3)) * SROW;
+            st[u] = lin_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            float4 qq[U], kk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cq = swz((t >> 2) * 16, head[u] * DH + 4 * (h + 4 * g));
+                qq[u] = ld_bf16x4(Qs + rowt[u] + cq);
+                kk[u] = ld_bf16x4(Ks + rowt[u] + cq);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].x, qq[u].x, st[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].y, qq[u].y, st[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].z, qq[u].z, st[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[u].w, qq[u].w, st[u], 0, 0, 0);
+        }
+        float sc[U][4], inv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[u][r] = st[u][r] * scale + wbias[r]; mx = fmaxf(mx, sc[u][r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[u][r] = expf(sc[u][r] - mx); l += sc[u][r]; }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            inv[u] = 1.0f / l;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float vv[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[u][r] = (float)Vs[(16 * h + 4 * wdw[u] + r) * SROW + swz(16 * h, head[u] * DH + nb * 16 + t)];
+            lin_f32x4 o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) o[u] = lin_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int u = 0; u < U; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[u][r] * inv[u], vv[u][r], o[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Os[(16 * h + 4 * wdw[u] + r) * SROW + swz(16 * h, head[u] * DH + nb * 16 + t)] = (__bf16)o[u][r];
+        }
+    };
+    // window_attn_kernel<16, 2> on the slab panels: one (token, head-of-the-slab) pair per thread
+    auto win2 = [&](const float* pos) __attribute__((always_inline)) {
+        constexpr int WS = 2, DHD = 16, HS = 4;
+        const float scale = 1.0f / sqrtf((float)DHD);
+        const int head = tid % HS, tok = tid / HS;
+        const int py = tok >> 4, px = tok & 15;
+        const int wy0 = py & ~1, wx0 = px & ~1, iy = py - wy0, ixx = px - wx0;
+        float q[DHD], o[DHD];
+#pragma unroll
+        for (int d = 0; d < DHD; d += 4) {
+            const float4 v = ld_bf16x4(Qs + tok * SROW + swz(tok, head * DHD + d));
+            q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
+        }
+        float sj[WS * WS];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < WS * WS; ++jj) {
+            const int jy = jj / WS, jx = jj % WS;
+            const int krow = (wy0 + jy) * 16 + wx0 + jx;
+            const __bf16* kr = Ks + krow * SROW + swz(krow, head * DHD);      // 16 columns of a head: no wrap inside (16-aligned)
+            float a_ = 0.f;
+#pragma unroll
+            for (int d = 0; d < DHD; d += 4) {
+                const float4 k = ld_bf16x4(kr + d);
+                a_ = fmaf(q[d], k.x, a_); a_ = fmaf(q[d + 1], k.y, a_); a_ = fmaf(q[d + 2], k.z, a_); a_ = fmaf(q[d + 3], k.w, a_);
+            }
+            a_ = a_ * scale + pos[(jy - iy + WS - 1) * (2 * WS - 1) + (jx - ixx + WS - 1)];
+            sj[jj] = a_;
+            mx = fmaxf(mx, a_);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < WS * WS; ++jj) { sj[jj] = expf(sj[jj] - mx); l += sj[jj]; }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < DHD; ++d) o[d] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < WS * WS; ++jj) {
+            const int jy = jj / WS, jx = jj % WS;
+            const int vrow = (wy0 + jy) * 16 + wx0 + jx;
+            const __bf16* vr = Vs + vrow * SROW + swz(vrow, head * DHD);
+            const float pj = sj[jj] * inv;
+#pragma unroll
+            for (int d = 0; d < DHD; d += 4) {
+                const float4 v = ld_bf16x4(vr + d);
+                o[d] = fmaf(pj, v.x, o[d]); o[d + 1] = fmaf(pj, v.y, o[d + 1]); o[d + 2] = fmaf(pj, v.z, o[d + 2]); o[d + 3] = fmaf(pj, v.w, o[d + 3]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DHD; d += 4) {
+            const f32x4 f = {o[d], o[d + 1], o[d + 2], o[d + 3]};
+            *reinterpret_cast<bf16x4*>(Os + tok * SROW + swz(tok, head * DHD + d)) = __builtin_convertvector(f, bf16x4);
+        }
+    };
+
+    // ---- the twelve slabs.  Phase A of slab g: to_out's K slice of slab g - 1 (its attention output is complete: barrier 2 of g - 1), the
+    // finished branch's output stores, the QKV product of slab g and its epilogue into the slab panels (the attention of g - 1 no longer
+    // reads them).  Barrier 1.  Phase B: the attention of slab g -> Os (every wave is past its to_out reads of Os).  Barrier 2.
+    auto out_slice = [&](int gp) __attribute__((always_inline)) {    // to_out's K slice of slab gp (and the branch's stores after its last slab)
+        const int bp = gp >> 2, jp = gp & 3;
+        if (jp == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acct[a][c][r] = 0.f;
+        }
+        kloop_out();
+        if constexpr ((AV2X_QW_ABLATE & 4) == 0) { if (jp == 3) epilogue_out(bp); }
+        else if (jp == 3 && acct[0][0][0] + acct[1][1][5] == 123.f) epilogue_out(bp);
+    };
+#pragma unroll 1
+    for (int g = 0; g < 12; ++g) {
+        const int b = g >> 2, j = g & 3;
+        if (g > 0) out_slice(g - 1);
+        if constexpr ((AV2X_QW_ABLATE & 16) == 0) kloop_qkv(b, j);
+        if (g + 1 < 12) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) load_q(bq[s], (g + 1) >> 2, (g + 1) & 3, s);
+        }
+        if constexpr ((AV2X_QW_ABLATE & 8) == 0) epilogue_qkv(b, j);
+        else if (acc[0][0][0] + acc[1][0][5] == 123.f) epilogue_qkv(b, j);
+        __syncthreads();
+        load_t(b, j);
+        if constexpr ((AV2X_QW_ABLATE & 2) == 0) {
+            if (p.dh[b] == 16) win2(posl + 64 * b);
+            else if (p.dh[b] == 32) win4(std::integral_constant<int, 32>{}, posl + 64 * b);
+            else win4(std::integral_constant<int, 64>{}, posl + 64 * b);
+        }
+        __syncthreads();
+    }
+    out_slice(11);
 }
 
 template <bool OUT16>
@@ -1129,6 +1523,16 @@ extern "C" int av2x_ln_qkv_window_attention_bf16(const float* x, const uint16_t*
     p.H = h; p.W = w;
     const long long blocks = (long long)n * (h / 4) * (w / 16);
     if (blocks > (1ll << 30)) return av2x::fail("av2x_ln_qkv_window_attention_bf16: too many workgroups");
+    // AV2X_QW_SLAB=0: the one-workgroup-per-CU form (four full-width panels); default: head slabs, two workgroups per CU (same bits)
+    static const bool slab = [] { const char* e = getenv("AV2X_QW_SLAB"); return !(e && e[0] == '0'); }();
+    if (slab) {
+        size_t lds = (size_t)(64 * LROW + 4 * 64 * SROW) * 2 + 192 * 4;
+        if (const char* pad = getenv("AV2X_QW_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy probe (tools/qw_bench.py): > 10 KB leaves one workgroup per CU
+        static av2x::LdsLimit lim2;
+        lim2.ensure(reinterpret_cast<const void*>(&ln_qkv_window_out_slab_kernel), lds);
+        hipLaunchKernelGGL(ln_qkv_window_out_slab_kernel, dim3((unsigned)blocks), dim3(256), lds, av2x::as_stream(stream), p);
+        return av2x::check_launch("ln_qkv_window_out_slab_kernel");
+    }
     const size_t lds = (size_t)4 * 64 * LROW * 2 + (3072 + 192) * 4;
     static av2x::LdsLimit lim;
     lim.ensure(reinterpret_cast<const void*>(&ln_qkv_window_out_bf16_kernel), lds);

@@ -267,7 +267,7 @@ class V2XViTEngine(Where2ComEngine):
     # one launch (csrc/linear_bf16.hip linear_bf16_occ_kernel<LN, FFN>): bit-identical to the separate launches
     fuse_ln = os.environ.get("AV2X_FUSE_LN", "1") != "0"
     fuse_window_out = os.environ.get("AV2X_FUSE_WINDOW_OUT", "1") != "0"
-    # ... and LayerNorm -> QKV -> window attention -> to_out of a 4 x 16-pixel block in one workgroup (ln_qkv_window_out_bf16_kernel)
+    # ... and LayerNorm -> QKV -> window attention -> to_out of a 4 x 16-pixel block in one workgroup (ln_qkv_window_out_slab_kernel)
     fuse_qkv_window = os.environ.get("AV2X_FUSE_QKV_WINDOW", "1") != "0"
     # ... and SplitAttn's combine computed in the FeedForward launch's panel load (linear_bf16_occ_kernel<SRC_LNC, FFN>)
     fuse_combine_ffn = os.environ.get("AV2X_FUSE_COMBINE_FFN", "1") != "0"

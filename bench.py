@@ -957,10 +957,12 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                     res["roofline"].update({
                         "bound": "mfma", "achieved": round(tv[2] / tv[3] / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tv[2] / tv[3] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), **hbm_kernel_traffic(top, tv[1] / tv[0]),
-                        "kernel": "ln_qkv_window_out_bf16_kernel (csrc/linear_bf16.hip: LayerNorm -> 256 -> 2304 QKV -> window attention -> to_out of a "
-                                  "4 x 16-pixel block per workgroup, four [64][264] bf16 panels in LDS, one workgroup per CU)",
-                        "limiter": "the weight fragments come from L2 once per 64-token block (1.57 MB per workgroup, 6.9 GB per 8-agent launch) and "
-                                   "one 4-wave workgroup per CU cannot hide the phase changes (K loops / epilogues into LDS / attention); "
+                        "kernel": "ln_qkv_window_out_slab_kernel (csrc/linear_bf16.hip: LayerNorm -> 256 -> 2304 QKV -> window attention -> to_out of a "
+                                  "4 x 16-pixel block per workgroup, in 64-column head slabs: 71 KB of LDS, two workgroups per CU; "
+                                  "AV2X_QW_SLAB=0: ln_qkv_window_out_bf16_kernel, four full-width panels, one workgroup per CU, same bits)",
+                        "limiter": "a chain of short phases per slab (K loop, panel stores, attention tasks, barriers) at two waves per SIMD: latency, "
+                                   "not a pipe -- timing-only ablations in profiles/r05r_qw_ablations.txt (the weight stream from L2 is 8 % of it, "
+                                   "the attention phases 18-22 %, the K loops run at ~55 % of their MFMA time); "
                                    "hbm_gb_per_s below is its algorithmic HBM rate",
                         "hbm_gb_per_s": round(tv[1] / tv[3] / 1e9, 1),
                         "launches_per_frame": tv[0] / a.steps, "avg_launch_us": round(tv[3] / tv[0] * 1e6, 2),

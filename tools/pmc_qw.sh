@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of ln_qkv_window_out_bf16_kernel alone (tools/qw_bench.py), one counters-only pass per group.
+# SQ counters of ln_qkv_window_out_slab_kernel (AV2X_QW_SLAB=0: ln_qkv_window_out_bf16_kernel) alone (tools/qw_bench.py), one counters-only pass per group.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 i=0

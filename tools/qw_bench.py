@@ -7,7 +7,12 @@ from airv2x_perception_amd import _lib
 from airv2x_perception_amd.opencood_iface.packing import interleave2_columns, pack_conv_weight, to_bf16_koct
 
 BF = torch.bfloat16
-lib = _lib.load()
+if os.environ.get("AV2X_QW_LIB"):      # an ablation build of linear_bf16.hip alone (tools/micro/qw_ablate.sh): timing only
+    lib = ctypes.CDLL(os.environ["AV2X_QW_LIB"])
+    res, args = _lib.SIGNATURES["av2x_ln_qkv_window_attention_bf16"]
+    lib.av2x_ln_qkv_window_attention_bf16.restype, lib.av2x_ln_qkv_window_attention_bf16.argtypes = res, args
+else:
+    lib = _lib.load()
 p = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 st = lambda: c_void_p(torch.cuda.current_stream().cuda_stream)
 
