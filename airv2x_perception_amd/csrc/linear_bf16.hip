@@ -488,6 +488,9 @@ __global__ __launch_bounds__(256, 4) void linear_bf16_occ_kernel(const LinParams
 #ifndef AV2X_QW_ABLATE      // timing experiments of tools/micro/qw_ablate.sh (wrong results): 1 no weight stream after the first fragments,
 #define AV2X_QW_ABLATE 0    // 2 no attention phases, 4 no output stores, (slab kernel) 8 no q / k / v panel stores, 16 no QKV K loops; the library never defines it
 #endif
+#ifndef AV2X_QW_DEPTH
+#define AV2X_QW_DEPTH 4
+#endif
 struct QwParams {
     const float* x;
     const __bf16* delta;      // pending residual of every row (or nullptr): feeds the LayerNorm, x is not rewritten
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(512, 1) void ln_qkv_window_out_bf16_kernel(const Qw
 constexpr int SROW = 64 + 8;    // slab panel row stride in bf16 elements (144 B: conflict-free ds_read_b128 over 16 rows)
 
 __global__ __launch_bounds__(256, 2) void ln_qkv_window_out_slab_kernel(const QwParams p) {
-    constexpr int PSZ = 64 * LROW, SSZ = 64 * SROW, DEPTH = 4;
+    constexpr int PSZ = 64 * LROW, SSZ = 64 * SROW, DEPTH = AV2X_QW_DEPTH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lin_smem[];
     __bf16* P0 = reinterpret_cast<__bf16*>(lin_smem);
     __bf16* Qs = P0 + PSZ;
