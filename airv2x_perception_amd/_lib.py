@@ -39,9 +39,11 @@ SIGNATURES = {
     "av2x_pillar_vfe_scatter_dev": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "av2x_pillar_vfe_scatter_count": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
-                                                c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+                                                c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "av2x_pillar_vfe_scatter_dev_count": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
-                                                    c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+                                                    c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "av2x_conv3x3s2_sparse": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                        c_int32, c_void_p]),
     "av2x_nonzero_slots_sum": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "av2x_voxelize_dummy_if_empty": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),

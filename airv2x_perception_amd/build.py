@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libairv2x_hip.so")
-SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino_x3.hip", "conv_wino4_x3.hip", "conv_x3p.hip", "pillar.hip", "where2comm.hip", "where2comm_attn.hip", "postproc.hip", "voxelize.hip", "transformer.hip", "v2xvit.hip", "linear_bf16.hip", "when2com.hip", "v2vnet.hip", "lss.hip", "camera.hip", "labels.hip", "conv_backward.hip", "loss.hip", "train.hip", "train_fusion.hip", "train_v2xvit.hip", "train_when2com.hip", "train_camera.hip", "roiaware.hip"]
+SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino_x3.hip", "conv_wino4_x3.hip", "conv_x3p.hip", "pillar.hip", "where2comm.hip", "where2comm_attn.hip", "postproc.hip", "voxelize.hip", "transformer.hip", "v2xvit.hip", "linear_bf16.hip", "when2com.hip", "v2vnet.hip", "lss.hip", "camera.hip", "labels.hip", "conv_backward.hip", "loss.hip", "train.hip", "train_fusion.hip", "train_v2xvit.hip", "train_when2com.hip", "train_camera.hip", "roiaware.hip", "sparse_conv.hip"]
 
 
 # per-source flags.  The split-3 Winograd kernels keep their channel-pair arithmetic scalar on purpose (a packed fp32 instruction beside

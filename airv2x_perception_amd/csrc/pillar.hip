@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
     const int* __restrict__ n_dev,
     const float* __restrict__ pfn_w, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
     float vx, float vy, float vz, float xoff, float yoff, float zoff, float* __restrict__ canvas, int agent0,
-    const int* __restrict__ slot_map, int n_agents, int ny, int nx, unsigned long long* __restrict__ nonzero) {
+    const int* __restrict__ slot_map, int n_agents, int ny, int nx, unsigned long long* __restrict__ nonzero,
+    unsigned char* __restrict__ occupancy) {
     __shared__ __attribute__((aligned(16))) float feats[4][kPts][kLdF];
     unsigned written_nz = 0;    // non-zero values this wave has put on the canvas (wave-uniform)
     const int lane = threadIdx.x & 63;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void pillar_vfe_scatter_kernel(
             // idx = z + y*nx + x with nz == 1 (point_pillar_scatter.py:59-61)
             const size_t pix = ((size_t)agent * ny + c.z) * nx + c.w + c.y;
             canvas[pix * kOut + lane] = best;
+            if (occupancy != nullptr && lane == 0) occupancy[pix] = 1;
             written_nz += (unsigned)__popcll(__ballot(best != 0.f));
         }
         __builtin_amdgcn_wave_barrier();
@@ -170,7 +172,7 @@ extern "C" int av2x_pillar_vfe_scatter_count(const float* voxel_features, const 
                                        const int32_t* voxel_num_points, int32_t n_pillars, const float* pfn_w,
                                        const float* bn_scale, const float* bn_shift, const float* geom, float* canvas,
                                        int32_t canvas_agent0, const int32_t* slot_map, int32_t n_agents_type, int32_t ny,
-                                       int32_t nx, unsigned long long* nonzero, av2x_stream_t stream) {
+                                       int32_t nx, unsigned long long* nonzero, uint8_t* occupancy, av2x_stream_t stream) {
     if (n_pillars == 0) return 0;
     if (!voxel_features || !voxel_coords || !voxel_num_points || !pfn_w || !bn_scale || !bn_shift || !geom || !canvas)
         return av2x::fail("av2x_pillar_vfe_scatter: null argument");
@@ -180,7 +182,7 @@ extern "C" int av2x_pillar_vfe_scatter_count(const float* voxel_features, const 
     hipLaunchKernelGGL(pillar_vfe_scatter_kernel<0>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
                        voxel_num_points, n_pillars, (const int*)nullptr, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
-                       geom[4], geom[5], canvas, canvas_agent0, slot_map, n_agents_type, ny, nx, nonzero);
+                       geom[4], geom[5], canvas, canvas_agent0, slot_map, n_agents_type, ny, nx, nonzero, occupancy);
     return av2x::check_launch("pillar_vfe_scatter_kernel");
 }
 
@@ -190,7 +192,7 @@ extern "C" int av2x_pillar_vfe_scatter(const float* voxel_features, const int32_
                                        int32_t canvas_agent0, const int32_t* slot_map, int32_t n_agents_type, int32_t ny,
                                        int32_t nx, av2x_stream_t stream) {
     return av2x_pillar_vfe_scatter_count(voxel_features, voxel_coords, voxel_num_points, n_pillars, pfn_w, bn_scale, bn_shift, geom, canvas,
-                                         canvas_agent0, slot_map, n_agents_type, ny, nx, nullptr, stream);
+                                         canvas_agent0, slot_map, n_agents_type, ny, nx, nullptr, nullptr, stream);
 }
 
 extern "C" int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
@@ -205,7 +207,7 @@ extern "C" int av2x_pillar_vfe(const float* voxel_features, const int32_t* voxel
     hipLaunchKernelGGL(pillar_vfe_scatter_kernel<1>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords),
                        voxel_num_points, n_pillars, (const int*)nullptr, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
-                       geom[4], geom[5], pillar_features, 0, (const int*)nullptr, 0, 0, 0, (unsigned long long*)nullptr);
+                       geom[4], geom[5], pillar_features, 0, (const int*)nullptr, 0, 0, 0, (unsigned long long*)nullptr, (unsigned char*)nullptr);
     return av2x::check_launch("pillar_vfe_kernel");
 }
 
@@ -213,7 +215,7 @@ extern "C" int av2x_pillar_vfe_scatter_dev_count(const float* voxel_features, co
                                            const int32_t* voxel_num_points, const int32_t* n_pillars_dev, int32_t capacity,
                                            const float* pfn_w, const float* bn_scale, const float* bn_shift, const float* geom,
                                            float* canvas, int32_t canvas_slot, int32_t ny, int32_t nx, unsigned long long* nonzero,
-                                                 av2x_stream_t stream) {
+                                                 uint8_t* occupancy, av2x_stream_t stream) {
     if (capacity == 0) return 0;
     if (!voxel_features || !voxel_coords3 || !voxel_num_points || !n_pillars_dev || !pfn_w || !bn_scale || !bn_shift || !geom || !canvas)
         return av2x::fail("av2x_pillar_vfe_scatter_dev: null argument");
@@ -223,7 +225,7 @@ extern "C" int av2x_pillar_vfe_scatter_dev_count(const float* voxel_features, co
     hipLaunchKernelGGL(pillar_vfe_scatter_kernel<2>, dim3(blocks), dim3(256), 0, av2x::as_stream(stream),
                        reinterpret_cast<const float4*>(voxel_features), reinterpret_cast<const int4*>(voxel_coords3),
                        voxel_num_points, capacity, n_pillars_dev, pfn_w, bn_scale, bn_shift, geom[0], geom[1], geom[2], geom[3],
-                       geom[4], geom[5], canvas, canvas_slot, (const int*)nullptr, 1, ny, nx, nonzero);
+                       geom[4], geom[5], canvas, canvas_slot, (const int*)nullptr, 1, ny, nx, nonzero, occupancy);
     return av2x::check_launch("pillar_vfe_scatter_kernel<2>");
 }
 
@@ -232,7 +234,7 @@ extern "C" int av2x_pillar_vfe_scatter_dev(const float* voxel_features, const in
                                            const float* pfn_w, const float* bn_scale, const float* bn_shift, const float* geom,
                                            float* canvas, int32_t canvas_slot, int32_t ny, int32_t nx, av2x_stream_t stream) {
     return av2x_pillar_vfe_scatter_dev_count(voxel_features, voxel_coords3, voxel_num_points, n_pillars_dev, capacity, pfn_w, bn_scale, bn_shift,
-                                             geom, canvas, canvas_slot, ny, nx, nullptr, stream);
+                                             geom, canvas, canvas_slot, ny, nx, nullptr, nullptr, stream);
 }
 
 extern "C" int av2x_pillar_scatter(const float* pillar_features, const int32_t* voxel_coords, int32_t n_pillars,

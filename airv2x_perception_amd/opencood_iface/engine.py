@@ -927,7 +927,8 @@ class Where2ComEngine:
         cur, ch, cw = x, h, w
         for li, L in enumerate(layers):
             dst = out if li == len(layers) - 1 else (ping if li % 2 == 0 else pong)
-            self.conv(L, cur, n, ch, cw, dst)
+            if not (i == 0 and li == 0 and self.sparse_first_conv(L, cur, n, ch, cw, dst)):
+                self.conv(L, cur, n, ch, cw, dst)
             cur, ch, cw = dst, ho, wo
         return out, ho, wo
 
@@ -986,6 +987,7 @@ class Where2ComEngine:
         st = self.stream()
         _lib.check(self.lib.av2x_fill_zero(_ptr(canvas), canvas.numel() * 4, st), "av2x_fill_zero")
         nz = self._nz_begin(st)
+        occ = self._occ_begin(st, canvas, n, ny, nx)
         r6, v3 = (c_float * 6)(*rng), (c_float * 3)(*vs)
         for i, (pts, t) in enumerate(zip(clouds, types)):
             if pts.device != self.device or pts.dtype != torch.float32 or not pts.is_contiguous():
@@ -1013,7 +1015,7 @@ class Where2ComEngine:
                        "av2x_voxelize_dummy_if_empty")
             w, sc, sh, geom = self.pfn[t]
             _lib.check(self.lib.av2x_pillar_vfe_scatter_dev_count(_ptr(voxels), _ptr(coords), _ptr(num), _ptr(cnt), cap, _ptr(w), _ptr(sc),
-                                                                  _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), i, ny, nx, _ptr(nz), st),
+                                                                  _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), i, ny, nx, _ptr(nz), _ptr(occ), st),
                        "av2x_pillar_vfe_scatter_dev_count")
         self._nz_canvas = canvas if nz is not None else None
         return canvas, ny, nx
@@ -1037,8 +1039,10 @@ class Where2ComEngine:
             self.timed_hbm("canvas clear (hipMemsetAsync)", lidar_canvas.numel() * 4, 0.0,
                            lambda: _lib.check(self.lib.av2x_fill_zero(_ptr(lidar_canvas), lidar_canvas.numel() * 4, st), "av2x_fill_zero"))
         # a LiDAR-only frame: the scatter counts the non-zeros it writes (comm_rate, airv2x_where2com.py:122) -- no read-back pass over the canvas
-        nz = self._nz_begin(st) if not any(t in cam for t in slots) else None
-        self.encode_lidar(data_dict, slots, lidar_canvas, ny, nx, nz)
+        lidar_only = not any(t in cam for t in slots)
+        nz = self._nz_begin(st) if lidar_only else None
+        occ = self._occ_begin(st, canvas, n_total, ny, nx) if lidar_only else self._occ_begin(st, None, 0, 0, 0)
+        self.encode_lidar(data_dict, slots, lidar_canvas, ny, nx, nz, occ)
         self._nz_canvas = canvas if nz is not None else None
         per = ny * nx * 64
         for t, sl in slots.items():
@@ -1087,9 +1091,41 @@ class Where2ComEngine:
                        lambda: _lib.check(self.lib.av2x_count_nonzero(_ptr(canvas), canvas.numel(), _ptr(nz), st), "av2x_count_nonzero"))
         return nz
 
-    def encode_lidar(self, data_dict, slots, canvas, ny, nx, nz=None):
+    SPARSE_CONV0 = os.environ.get("AV2X_SPARSE_CONV0", "1") != "0"
+    _occ_info = None        # (frame, canvas data_ptr, agents, ny, nx, occupancy bytes): the scattered canvas of THIS frame (see sparse_first_conv)
+
+    def _occ_begin(self, st, canvas, n, ny, nx):
+        """Zeroed occupancy bytes (one per canvas cell) for the counting scatter of a LiDAR-only frame -- the first backbone convolution then
+        gathers the occupied taps only (csrc/sparse_conv.hip) --, or None (camera rows in the canvas, AV2X_SPARSE_CONV0=0, autocast)."""
+        self._occ_info = None
+        if canvas is None or not self.SPARSE_CONV0 or self.amp or canvas.dtype != torch.float32:
+            return None
+        occ = self.buf("canvas_occ", (n, ny, nx), torch.uint8)
+        _lib.check(self.lib.av2x_fill_zero(_ptr(occ), occ.numel(), st), "av2x_fill_zero")
+        self._occ_info = (self._frame, canvas.data_ptr(), n, ny, nx, occ)
+        return occ
+
+    def sparse_first_conv(self, L, x, n, h, w, out):
+        """Conv2d(64, 64, 3, stride 2) + folded BatchNorm + ReLU of block 0 on (rows of) this frame's scattered canvas: the gather over occupied
+        taps (av2x_conv3x3s2_sparse).  A rule of the layer and of the frame kind (LiDAR-only, fp32-accurate mode), never of the agent count:
+        batches, agent groups and the sharded frame take it alike.  Returns False when the input is not that canvas."""
+        info = self._occ_info
+        if (info is None or info[0] != self._frame or self.amp or self.conv_tile or L.ks != 3 or L.stride != 2 or L.pad != 1 or L.cin != 64
+                or L.cout != 64 or L.coutp != 64 or L.mode != _lib.AV2X_CONV or x.dtype != torch.float32 or out.dtype != torch.float32
+                or (h, w) != (info[3], info[4]) or L.relu not in (0, 1)):
+            return False
+        per = h * w * 64 * 4
+        off = x.data_ptr() - info[1]
+        if off < 0 or off % per or off // per + n > info[2]:
+            return False
+        occ = info[5][off // per: off // per + n]
+        _lib.check(self.lib.av2x_conv3x3s2_sparse(_ptr(x), _ptr(occ), _ptr(L.w), _ptr(L.scale), _ptr(L.shift), L.relu, _ptr(out), n, h, w, 64, 64,
+                                                  self.stream()), "av2x_conv3x3s2_sparse")
+        return True
+
+    def encode_lidar(self, data_dict, slots, canvas, ny, nx, nz=None, occ=None):
         """Sequential(PillarVFE, PointPillarScatter) of every agent type with a LiDAR encoder, into the (zeroed) canvas rows; ``nz``: the
-        device counter the scatter adds its written non-zeros to."""
+        device counter the scatter adds its written non-zeros to; ``occ``: the occupancy bytes it sets."""
         st = self.stream()
         for t, sl in slots.items():
             if t not in self.pfn:
@@ -1111,7 +1147,7 @@ class Where2ComEngine:
             self.timed_hbm("pillar_vfe_scatter", vf.shape[0] * (512 + 12 + 4 + 256), 2.0 * 32 * 10 * 64 * vf.shape[0],
                            lambda: _lib.check(self.lib.av2x_pillar_vfe_scatter_count(_ptr(vf), _ptr(vc), _ptr(vn), vf.shape[0], _ptr(w), _ptr(sc),
                                                                                      _ptr(sh), ctypes.cast(geom, c_void_p), _ptr(canvas), sl[0],
-                                                                                     _ptr(smap), len(sl), ny, nx, _ptr(nz), st),
+                                                                                     _ptr(smap), len(sl), ny, nx, _ptr(nz), _ptr(occ), st),
                                               "av2x_pillar_vfe_scatter_count"))
 
     def trunk(self, canvas, n, ny, nx, tag="all", block_out=None, shrink_out=None):

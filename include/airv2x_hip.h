@@ -85,11 +85,19 @@ int av2x_pillar_vfe_scatter_count(const float* voxel_features, const int32_t* vo
                                   const float* pfn_w, const float* bn_scale, const float* bn_shift,
                                   const float* geom, float* canvas, int32_t canvas_agent0,
                                   const int32_t* slot_map, int32_t n_agents_type, int32_t ny, int32_t nx,
-                                  unsigned long long* nonzero, av2x_stream_t stream);
+                                  unsigned long long* nonzero, uint8_t* occupancy, av2x_stream_t stream);
 int av2x_pillar_vfe_scatter_dev_count(const float* voxel_features, const int32_t* voxel_coords3, const int32_t* voxel_num_points,
                                       const int32_t* n_pillars_dev, int32_t capacity, const float* pfn_w, const float* bn_scale,
                                       const float* bn_shift, const float* geom, float* canvas, int32_t canvas_slot, int32_t ny,
-                                      int32_t nx, unsigned long long* nonzero, av2x_stream_t stream);
+                                      int32_t nx, unsigned long long* nonzero, uint8_t* occupancy, av2x_stream_t stream);
+/* occupancy (device; NULL = none): one byte per canvas cell, (canvas slots, ny, nx), zero-filled by the caller; the scatter sets the byte
+ * of every cell it writes.  Reader: av2x_conv3x3s2_sparse -- the first convolution of the backbone (base_bev_backbone.py:30-48: ZeroPad2d(1),
+ * Conv2d(64, 64, 3, stride 2), BatchNorm folded to scale / shift, ReLU) as a gather over the occupied taps only:
+ *   out[n] = act(scale[n] * sum over occupied taps (row-major), channels ascending, of in[2 oy + ky - 1][2 ox + kx - 1][c] W[ky][kx][c][n] + shift[n])
+ * in fp32 FMAs; a zero tap contributes exactly 0, so this IS the dense convolution of the scattered canvas (up to the order of fp32
+ * roundings).  in (n, h, w, 64) NHWC, w_packed = the (9, 16, 64, 4) packing of the dense entries, scale may be NULL (= 1), out (n, ho, wo, 64). */
+int av2x_conv3x3s2_sparse(const float* in, const uint8_t* occupancy, const float* w_packed, const float* scale, const float* shift,
+                          int32_t relu, float* out, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, av2x_stream_t stream);
 
 int av2x_fill_zero(void* ptr, uint64_t bytes, av2x_stream_t stream);
 

@@ -341,3 +341,23 @@ def test_comm_rate_counted_in_the_scatter_equals_the_read_back_count():
         eng.FOLD_COUNT = True
     c = eng.forward(dd, sync_comm_rate=True)["comm_rate"]
     assert a == b == c == int(fx["comm_rate"])
+
+
+def test_sparse_first_convolution_of_the_frame_equals_the_dense_one():
+    """The first backbone convolution of a LiDAR-only frame gathers the occupied taps of the scattered canvas (av2x_conv3x3s2_sparse);
+    switched off, the same engine runs the dense split-3 GEMM on the whole canvas.  Same frame: block 0 and the heads within fp32 rounding
+    of each other, the communication mask and comm_rate identical."""
+    fx, args, sd, dd, out, tr, model = _run("w2c_small_n3")
+    eng = model.engine()
+    assert eng.SPARSE_CONV0
+    eng.SPARSE_CONV0 = False
+    try:
+        tr2 = {}
+        out2 = eng.forward(dd, trace=tr2, sync_comm_rate=True)
+    finally:
+        eng.SPARSE_CONV0 = True
+    assert out2["comm_rate"] == out["comm_rate"]
+    assert torch.equal(tr2["spatial_features"], tr["spatial_features"])
+    assert_close(tr2["block0"].cpu(), tr["block0"].cpu().numpy(), 1e-5, 1e-5, "block0 dense vs sparse first conv")
+    for k in ("psm", "rm"):
+        assert_close(out2[k].cpu(), out[k].cpu().numpy(), 1e-4, 1e-4, k)

@@ -354,16 +354,54 @@ def test_pillar_vfe_scatter(lib, agent_type):
     # the counting entry: same canvas, and the counter it adds to equals count_nonzero of what it wrote (here on top of a preset value)
     canvas2 = torch.zeros((3, ny, nx, 64), device="cuda")
     nz2 = torch.zeros(32 * 16, dtype=torch.int64, device="cuda")       # AV2X_NZ_SLOTS counters, AV2X_NZ_STRIDE apart
+    occ2 = torch.zeros((3, ny, nx), dtype=torch.uint8, device="cuda")
     nz2[16] = 7
     _lib.check(lib.av2x_pillar_vfe_scatter_count(_p(d_vf), _p(d_vc), _p(d_vn), vf.shape[0], _p(d_w), _p(d_sc), _p(d_sh),
-                                                 ctypes.cast(geom, c_void_p), _p(canvas2), 0, _p(smap), 2, ny, nx, _p(nz2),
+                                                 ctypes.cast(geom, c_void_p), _p(canvas2), 0, _p(smap), 2, ny, nx, _p(nz2), _p(occ2),
                                                  _stream()), "pillar count")
     assert torch.equal(canvas2, canvas)
+    want_occ = torch.zeros((3, ny, nx), dtype=torch.uint8)
+    inside = (vc[:, 2] >= 0) & (vc[:, 2] < ny) & (vc[:, 3] >= 0) & (vc[:, 3] < nx)
+    want_occ[torch.tensor([2, 0])[vc[inside, 0].long()], vc[inside, 2].long(), vc[inside, 3].long()] = 1
+    assert torch.equal(occ2.cpu(), want_occ)                       # the occupancy bytes: exactly the cells a pillar was written to
     assert int(nz2.sum().item()) == 7 + int(nz.item())
     assert int(nz2.view(32, 16)[:, 1:].abs().sum().item()) == 0      # only the strided slots are touched
     tot = torch.zeros(1, dtype=torch.int64, device="cuda")
     _lib.check(lib.av2x_nonzero_slots_sum(_p(nz2), _p(tot), _stream()), "slots sum")
     assert int(tot.item()) == 7 + int(nz.item())
+
+
+@pytest.mark.parametrize("n,h,w,relu,with_scale", [(2, 18, 26, 1, True), (1, 8, 130, 0, False), (3, 31, 17, 1, True)])
+def test_sparse_first_conv_equals_the_dense_convolution(lib, n, h, w, relu, with_scale):
+    """av2x_conv3x3s2_sparse (the first backbone convolution as a gather over the occupied taps) against F.conv2d in float64 on the same
+    scattered canvas: ZeroPad2d(1) + Conv2d(64, 64, 3, stride 2) + folded BatchNorm (+ ReLU), base_bev_backbone.py:30-48.  Occupied cells
+    include one whose 64 values are all zero; odd sizes and a pixel count that is not a multiple of the 64-pixel batches."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight
+    g = torch.Generator().manual_seed(5 + n)
+    occ = (torch.rand(n, h, w, generator=g) < 0.12)
+    canvas = torch.relu(torch.randn(n, h, w, 64, generator=g)) * occ[..., None]
+    iy, ix = [int(v[0]) for v in torch.nonzero(occ[0], as_tuple=True)]
+    canvas[0, iy, ix] = 0.0                                        # a pillar whose features are all zero stays "occupied"
+    wt = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    scale = torch.rand(64, generator=g) + 0.5 if with_scale else None
+    shift = torch.randn(64, generator=g) * 0.3
+    ref = F.conv2d(canvas.permute(0, 3, 1, 2).double(), wt.double(), None, stride=2, padding=1)
+    ref = ref * (scale.double().view(1, -1, 1, 1) if with_scale else 1.0) + shift.double().view(1, -1, 1, 1)
+    if relu:
+        ref = torch.relu(ref)
+    ho, wo = ref.shape[2], ref.shape[3]
+    wp, coutp = pack_conv_weight(wt)
+    assert coutp == 64
+    d_c, d_o, d_w = canvas.cuda(), occ.to(torch.uint8).cuda(), wp.cuda()
+    d_sc, d_sh = (scale.cuda() if with_scale else None), shift.cuda()
+    out = torch.full((n, ho, wo, 64), float("nan"), device="cuda")
+    _lib.check(lib.av2x_conv3x3s2_sparse(_p(d_c), _p(d_o), _p(d_w), _p(d_sc) if with_scale else None, _p(d_sh), relu, _p(out), n, h, w, 64, 64,
+                                         _stream()), "sparse conv")
+    got = out.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert lib.av2x_conv3x3s2_sparse(_p(d_c), _p(d_o), _p(d_w), None, _p(d_sh), relu, _p(out), n, h, w, 32, 64, _stream()) != 0
 
 
 def test_comm_mask(lib):
