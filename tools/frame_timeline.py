@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 --kernel-trace CSV (*_kernel_trace.csv) of a single-stream bench run -> the launch-by-launch timeline of ONE steady-state
 frame: start offset, duration, gap to the previous kernel's end, workgroups, kernel.  The frame is delimited by the first kernel of the
-frame (pillar_vfe_scatter by default).  Usage: python tools/frame_timeline.py <kernel_trace.csv> [--marker name] [--frame k]"""
+frame period, marked by a kernel that runs once per frame (the sparse first convolution; count_nonzero_kernel in traces made before round 5).  Usage: python tools/frame_timeline.py <kernel_trace.csv> [--marker name] [--frame k]"""
 import argparse
 import csv
 import re
@@ -16,12 +16,16 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("path")
-    ap.add_argument("--marker", default="count_nonzero_kernel")
+    ap.add_argument("--marker", default=None, help="a kernel that runs once per frame (default: conv3x3s2_sparse_kernel, else count_nonzero_kernel)")
     ap.add_argument("--frame", type=int, default=-3, help="which frame (index into the marker occurrences; negative = from the end)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]]
+    for mk in ([a.marker] if a.marker else ["conv3x3s2_sparse_kernel", "count_nonzero_kernel"]):
+        marks = [i for i, r in enumerate(rows) if mk in r["Kernel_Name"]]
+        if marks:
+            a.marker = mk
+            break
     i0 = marks[a.frame]
     i1 = marks[a.frame + 1] if a.frame + 1 < 0 or a.frame + 1 < len(marks) else len(rows)
     t0 = int(rows[i0]["Start_Timestamp"])
