@@ -695,13 +695,23 @@ class Where2ComEngine:
     WINO4_TILE = 0x60000000 | (32 << 16) | 64
     WINO4_X3_TILE = 0x60000400 | (32 << 16) | 64
     WINO4_MIN_WGS_PER_IMAGE = int(os.environ.get("AV2X_WINO4_MIN_WGS", "256"))   # per IMAGE (never per launch): see above
+    # THROUGHPUT mode (engine.throughput_mode: FramePipeline / ShardedPipeline with more than one frame in flight): what counts is the
+    # CU-time of a layer (workgroups x workgroup time), not how long one launch takes -- other frames' kernels fill the CUs a launch leaves
+    # idle -- and there the F(4x4) class is cheaper for the 128 -> 128 layers at 50 x 176 (36 workgroups per image) and the 256 -> 256 layers
+    # at 25 x 88 (20) too: round 5, split-3 kernels, 4 agents pipelined 505-519 -> 532-533 frames/s, while one frame at a time falls from 357
+    # to 296 (profiles/r05u_wino4_threshold_x3.txt).  Still a function of the layer, the map and the MODE only: every frame of an engine in
+    # throughput mode has the same bits, pipelined or not; they differ from the latency-mode frame within the fp32 rounding of the two Winograd
+    # classes (both pinned by the same goldens at the same tolerances, tests/test_gpu_forward.py).
+    WINO4_MIN_WGS_PER_IMAGE_T = int(os.environ.get("AV2X_WINO4_MIN_WGS_T", "20"))
+    throughput_mode = False
     WINO4_MIN_CIN = 128
     wino4 = os.environ.get("AV2X_WINOGRAD4", "1") != "0"
 
     def wino4_rule(self, L, n, h, w):
         if not (self.wino_rule(L) and L.cin >= self.WINO4_MIN_CIN):
             return False
-        return -(-(((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64) >= self.WINO4_MIN_WGS_PER_IMAGE
+        need = min(self.WINO4_MIN_WGS_PER_IMAGE, self.WINO4_MIN_WGS_PER_IMAGE_T) if self.throughput_mode else self.WINO4_MIN_WGS_PER_IMAGE
+        return -(-(((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64) >= need
 
     # AMP mode with bf16 activation storage: 1x1 / 3x3 stride-1 layers run as the halo-tile direct convolution (csrc/conv_halo_bf16.inc:
     # every input byte crosses L2 -> CU once per 64-channel chunk instead of once per tap).  Its K order differs from conv_igemm_bf16's,

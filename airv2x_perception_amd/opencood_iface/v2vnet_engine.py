@@ -28,6 +28,9 @@ from .when2com_engine import normalized_pairwise
 
 
 class V2VNetEngine(Where2ComEngine):
+    # throughput mode keeps the latency-mode Winograd classes here: handing the 128- / 256-channel backbone layers to F(4x4,3x3) with frames in
+    # flight measured SLOWER for this model (240 vs 249 / 134 vs 136 frames/s at 4 agents, profiles/r05u_wino4_threshold_x3.txt)
+    WINO4_MIN_WGS_PER_IMAGE_T = Where2ComEngine.WINO4_MIN_WGS_PER_IMAGE
     def _init_config(self, args):
         mf = args["modality_fusion"]
         self.bb, self.sh = mf["base_bev_backbone"], mf["shrink_header"]

@@ -600,7 +600,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
     secondary = rank == 0 and world == 1 and a.mode == "replica" and not a.only_headline
     if secondary and a.inflight > 1:   # secondary figures: single-GPU runs only
         # latency mode for reference: strictly one frame at a time on one stream
-        eng.throughput_mode = False   # tuner hint only: the sequential schedule may use the finer Winograd tiling
+        eng.throughput_mode = False   # latency mode: F(2x2,3x3) for the 128 / 256-channel backbone layers (engine.wino4_rule), finer Winograd tiling allowed
         for _ in range(2):
             model(dd)
         torch.cuda.synchronize()
@@ -798,7 +798,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
     if not a.no_roofline and rank == 0 and dd is not None and model is not None and eng is not None:
         eng.use_graph = False
         # the launches are timed one at a time (one frame at a time, events around every launch) but with the tiling the HEADLINE mode
-        # runs: with frames in flight the engine's throughput_mode hint keeps the quarter-position Winograd tile out (engine.py)
+        # runs: with frames in flight the engine is in throughput mode (engine.wino4_rule: more layers on the F(4x4,3x3) class; quarter-position tile out)
         eng.throughput_mode = inflight_used > 1
         # What a hipEvent pair adds around ONE launch when the queue is full (the marker packets either side of the kernel):
         # with T1 = pair around one 4-byte fill and T2 = pair around two of them, T2 - T1 is one kernel + the gap to the
@@ -1041,6 +1041,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
         # whole feature column on or off); the cells where the two masks differ are counted separately
         if a.model == "where2com" and a.mode == "replica":
             trace = {}
+            model.engine().throughput_mode = inflight_used > 1      # the mode `out` (the timed region's last frame) was computed in
             model.engine().forward(dd, trace=trace, sync_comm_rate=True)
             torch.cuda.synchronize()
             otr = {}

@@ -96,7 +96,8 @@ def test_every_pipelined_frame_equals_the_single_stream_frame_at_the_baseline_gr
     a = SimpleNamespace(model=model_name, amp=amp, gemm="x3", agents=agents, points=8192, mods=("lidar",))
     hy, args, dd, clouds, types = bench.build_inputs(agents, 8192, dev, only=None, model=model_name, modalities=("lidar",))
     model, eng, sd = bench.make_model(a, args, dev)
-    out = model(dd)
+    eng.throughput_mode = True      # what FramePipeline(depth > 1) sets: the reference frame is the single-stream frame of the SAME mode
+    out = model(dd)                 # (throughput mode hands more layers to the F(4x4,3x3) class: engine.wino4_rule)
     torch.cuda.synchronize()
     keys = [k for k in ("psm", "rm", "obj") if k in out]
     ref = {k: out[k].clone() for k in keys}

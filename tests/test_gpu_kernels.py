@@ -581,6 +581,12 @@ def test_winograd_f4x4_rule_is_a_function_of_the_layer_and_map_size_only():
     assert all(rule(mk(256, 256), n, 100, 352) for n in range(1, 16)) and not any(rule(mk(128, 128), n, 50, 176) for n in range(1, 16))
     assert not rule(mk(256, 256), 8, 25, 88) and not rule(mk(64, 64), 4, 100, 352) and not rule(mk(256, 128), 4, 100, 352)
     assert not rule(mk(128, 256, stride=2), 4, 100, 352) and not rule(mk(256, 256, ks=1), 4, 100, 352)
+    # throughput mode (frames in flight): the 128 -> 128 layers at 50 x 176 and the 256 -> 256 layers at 25 x 88 join the class -- again whatever n
+    class T(Where2ComEngine):
+        throughput_mode = True
+    rule_t = lambda L, n, h, w: Where2ComEngine.wino4_rule(T, L, n, h, w)
+    assert all(rule_t(mk(128, 128), n, 50, 176) and rule_t(mk(256, 256), n, 25, 88) and rule_t(mk(256, 256), n, 100, 352) for n in range(1, 16))
+    assert not rule_t(mk(64, 64), 4, 100, 352) and not rule_t(mk(256, 256), 4, 12, 44) and not rule_t(mk(128, 256, stride=2), 4, 100, 352)
 
 
 def test_winograd_conv_channel_slices_and_argument_checks(lib):

@@ -226,6 +226,7 @@ def test_frame_pipeline_results_equal_sequential_forward(which):
     model = model.to("cuda").eval()
     eng = model.engine()
     eng.stream_k = False
+    eng.throughput_mode = True          # the mode FramePipeline(depth > 1) puts the engine in (engine.wino4_rule): same mode, same bits
     ref = {k: v.clone() for k, v in eng.forward(dd).items() if torch.is_tensor(v) and v.dim() > 0}
     pipe = FramePipeline(eng, 3)
     outs = [pipe.submit(dd)[0] for _ in range(5)]
