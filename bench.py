@@ -563,6 +563,11 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                                        "frames_per_s_iqr": [round(q1, 2), round(q3, 2)], "frames_per_s_min_max": [round(min(wfps), 2), round(max(wfps), 2)],
                                        "note": "the headline's K-step window repeated back to back on this box (value = the FIRST window after the warm-up)"}
             evs = []
+            tmode = eng.throughput_mode if eng is not None else False
+            if eng is not None:
+                eng.throughput_mode = False        # one frame at a time = latency mode (engine.wino4_rule), as the `single_stream` leg below
+                for _ in range(2):
+                    model(dd)
             for _ in range(max(10, a.steps)):      # one frame at a time, hipEvent pair around the whole frame on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -570,10 +575,12 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                 e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
+            if eng is not None:
+                eng.throughput_mode = tmode
             fms = [x.elapsed_time(y) for x, y in evs]
             res_extra["dispersion"]["single_frame_ms"] = {"frames": len(fms), "median": round(float(np.median(fms)), 4),
                                                           "iqr": [round(float(np.percentile(fms, 25)), 4), round(float(np.percentile(fms, 75)), 4)],
-                                                          "note": "hipEvent pair around one whole frame, one frame at a time"}
+                                                          "note": "hipEvent pair around one whole frame, one frame at a time (latency mode of the engine)"}
     ms = dt / a.steps * 1e3
 
     res = {
@@ -594,7 +601,10 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                                   + ("; BASELINE.json configs[4]" if (a.agents == 8 and len(a.mods) == 2) else "")),
                    "parallelism": parallelism,
                    "launch": "hipGraph replay" if (eng is not None and eng.graph_active()) else "eager",
-                   "frames_in_flight": inflight_used},
+                   "frames_in_flight": inflight_used,
+                   "engine_mode": ("throughput (frames in flight: the 128- / 256-channel backbone layers on the Winograd F(4x4,3x3) class too, "
+                                   "engine.wino4_rule; same goldens, same tolerances)" if (eng is not None and eng.throughput_mode and inflight_used > 1)
+                                   else "latency (one frame at a time)")},
         **res_extra,
     }
     secondary = rank == 0 and world == 1 and a.mode == "replica" and not a.only_headline
