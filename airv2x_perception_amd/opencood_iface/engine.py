@@ -707,8 +707,10 @@ class Where2ComEngine:
     WINO4_MIN_CIN = 128
     wino4 = os.environ.get("AV2X_WINOGRAD4", "1") != "0"
 
+    WINO4_MIN_CIN_T = int(os.environ.get("AV2X_WINO4_MIN_CIN_T", "128"))      # throughput mode's channel floor
+
     def wino4_rule(self, L, n, h, w):
-        if not (self.wino_rule(L) and L.cin >= self.WINO4_MIN_CIN):
+        if not (self.wino_rule(L) and L.cin >= (min(self.WINO4_MIN_CIN, self.WINO4_MIN_CIN_T) if self.throughput_mode else self.WINO4_MIN_CIN)):
             return False
         need = min(self.WINO4_MIN_WGS_PER_IMAGE, self.WINO4_MIN_WGS_PER_IMAGE_T) if self.throughput_mode else self.WINO4_MIN_WGS_PER_IMAGE
         return -(-(((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64) >= need
