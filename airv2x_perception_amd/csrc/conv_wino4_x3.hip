@@ -33,7 +33,7 @@
 #include "x3_common.hpp"
 
 // timing experiments only (tools/micro/w4x3_ablate.hip): pieces of the K loop removed -- 1 B loads, 2 split, 4 transforms, 8 gathers,
-// 16 LDS stores, 32 MFMAs, 64 A-fragment reads.  0 in the library.
+// 16 LDS stores, 32 MFMAs, 64 A-fragment reads, 128 the whole output stage (exchange, A^T M A, stores).  0 in the library.
 #ifndef AV2X_W4X3_ABLATE
 #define AV2X_W4X3_ABLATE 0
 #endif
@@ -280,6 +280,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_x3(const Wino4X3Params p) {
 
     // ---- output transform through LDS, one 32-cout block per pass: X[pos][row][lane]; wave w finalises rows 4 w .. 4 w + 3 of the block:
     // Z[a][nu] = sum_xi A^T[a][xi] M[xi][nu], Y[a][e] = sum_nu Z[a][nu] A^T[e][nu]
+    if constexpr ((AV2X_W4X3_ABLATE & 128) != 0) {   // timing only: no exchange, no output transform, one store per lane
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 18; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][r];
+        p.out[(size_t)b * 256 + tid] = t;
+        return;
+    }
     float* X = reinterpret_cast<float*>(smem);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const int opix = p.out_ctot * 4;

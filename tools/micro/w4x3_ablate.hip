@@ -8,7 +8,8 @@
 #include "../../airv2x_perception_amd/csrc/conv_wino4_x3.hip"
 
 int main(int argc, char** argv) {
-    const int n = argc > 1 ? atoi(argv[1]) : 4, h = 100, w = 352, cin = 256, cout = 256;
+    const int n = argc > 1 ? atoi(argv[1]) : 4, h = argc > 2 ? atoi(argv[2]) : 100, w = argc > 3 ? atoi(argv[3]) : 352, cin = argc > 4 ? atoi(argv[4]) : 256,
+              cout = argc > 5 ? atoi(argv[5]) : cin;
     const size_t in_e = (size_t)n * h * w * cin, out_e = (size_t)n * h * w * cout;
     float *in, *out, *wp, *shift;
     void* u;
@@ -40,6 +41,6 @@ int main(int argc, char** argv) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = 2.0 * n * h * w * cout * 9 * cin;
-    printf("ablate=%d n=%d: %.1f us  (%.1f TF bf16 executed)\n", AV2X_W4X3_ABLATE, n, ms * 1e3 / iters, flops * 0.25 * 6 / (ms * 1e-3 / iters) / 1e12);
+    printf("ablate=%d n=%d %dx%d %d->%d: %.1f us  (%.1f TF bf16 executed)\n", AV2X_W4X3_ABLATE, n, h, w, cin, cout, ms * 1e3 / iters, flops * 0.25 * 6 / (ms * 1e-3 / iters) / 1e12);
     return 0;
 }
