@@ -1588,6 +1588,7 @@ class FramePipeline:
         s = self.streams[k]
         s.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
         eng = self.engines[k]
+        eng.throughput_mode = self.engines[0].throughput_mode      # one mode for every slot: the first engine's (set True by __init__ for depth > 1)
         # "rule" stays on (a frame's bits must not depend on whether it was pipelined); the legacy timing-driven stream-K
         # gains nothing with several frames in flight and is switched off
         legacy = eng.stream_k is True or eng.stream_k == "tune"
