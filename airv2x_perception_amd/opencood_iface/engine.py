@@ -305,6 +305,7 @@ class Where2ComEngine:
         other.tile_cache = self.tile_cache
         other.autotune, other.conv_tile, other.stream_k, other.amp = self.autotune, self.conv_tile, self.stream_k, self.amp
         other.winograd, other.throughput_mode = self.winograd, self.throughput_mode
+        other.sharded_frame = self.sharded_frame
         other.split3 = self.split3
         other.wino_x3 = self.wino_x3
         other.x3p = self.x3p
@@ -704,15 +705,22 @@ class Where2ComEngine:
     # classes (both pinned by the same goldens at the same tolerances, tests/test_gpu_forward.py).
     WINO4_MIN_WGS_PER_IMAGE_T = int(os.environ.get("AV2X_WINO4_MIN_WGS_T", "20"))
     throughput_mode = False
+    # ... where whole frames of several agents are in flight on ONE GPU (FramePipeline).  The agent-sharded frame (ShardedPipeline: one or two
+    # agents per rank, every launch a fraction of the chip, the frame rate set by the length of the rank's kernel chain) keeps the latency-mode
+    # classes: `sharded_frame` is set by ShardedPipeline on its engines.
+    sharded_frame = False
+
+    def wino4_throughput(self):
+        return bool(self.throughput_mode) and not self.sharded_frame
     WINO4_MIN_CIN = 128
     wino4 = os.environ.get("AV2X_WINOGRAD4", "1") != "0"
 
     WINO4_MIN_CIN_T = int(os.environ.get("AV2X_WINO4_MIN_CIN_T", "128"))      # throughput mode's channel floor
 
     def wino4_rule(self, L, n, h, w):
-        if not (self.wino_rule(L) and L.cin >= (min(self.WINO4_MIN_CIN, self.WINO4_MIN_CIN_T) if self.throughput_mode else self.WINO4_MIN_CIN)):
+        if not (self.wino_rule(L) and L.cin >= (min(self.WINO4_MIN_CIN, self.WINO4_MIN_CIN_T) if self.wino4_throughput() else self.WINO4_MIN_CIN)):
             return False
-        need = min(self.WINO4_MIN_WGS_PER_IMAGE, self.WINO4_MIN_WGS_PER_IMAGE_T) if self.throughput_mode else self.WINO4_MIN_WGS_PER_IMAGE
+        need = min(self.WINO4_MIN_WGS_PER_IMAGE, self.WINO4_MIN_WGS_PER_IMAGE_T) if self.wino4_throughput() else self.WINO4_MIN_WGS_PER_IMAGE
         return -(-(((h + 3) // 4) * ((w + 3) // 4)) // 32) * (L.cout // 64) >= need
 
     # AMP mode with bf16 activation storage: 1x1 / 3x3 stride-1 layers run as the halo-tile direct convolution (csrc/conv_halo_bf16.inc:

@@ -186,7 +186,8 @@ class ShardedPipeline:
 
     @classmethod
     def from_engine(cls, engine, depth, group=None, rotate=True):
-        engine.throughput_mode = depth > 1     # frames in flight: the F(4x4,3x3) class for more layers (engine.wino4_rule); every rank alike
+        engine.throughput_mode = depth > 1     # tuner hint (bit-identical candidates)
+        engine.sharded_frame = True            # one or two agents per rank: the latency-mode Winograd classes (engine.wino4_rule), every rank alike
         engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
         return cls([EngineBackend(e) for e in engines], group, rotate, engine.device)
 

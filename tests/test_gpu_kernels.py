@@ -575,18 +575,23 @@ def test_winograd_f4x4_rule_is_a_function_of_the_layer_and_map_size_only():
     from airv2x_perception_amd import _lib
     from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
     mk = lambda cin, cout, ks=3, stride=1: ConvLayer(None, None, None, cin, cout, cout, ks, stride, 1 if ks == 3 else 0, 1, _lib.AV2X_CONV)
-    rule = lambda L, n, h, w: Where2ComEngine.wino4_rule(Where2ComEngine, L, n, h, w)
+    lat = object.__new__(Where2ComEngine)           # the rule reads class constants and the two mode flags only
+    rule = lat.wino4_rule
     assert rule(mk(256, 256), 4, 100, 352) and rule(mk(256, 256), 1, 100, 352) and rule(mk(384, 256), 2, 100, 352)
     # never a function of the number of agents in the launch (sharded frame == single frame, batch == single)
     assert all(rule(mk(256, 256), n, 100, 352) for n in range(1, 16)) and not any(rule(mk(128, 128), n, 50, 176) for n in range(1, 16))
     assert not rule(mk(256, 256), 8, 25, 88) and not rule(mk(64, 64), 4, 100, 352) and not rule(mk(256, 128), 4, 100, 352)
     assert not rule(mk(128, 256, stride=2), 4, 100, 352) and not rule(mk(256, 256, ks=1), 4, 100, 352)
-    # throughput mode (frames in flight): the 128 -> 128 layers at 50 x 176 and the 256 -> 256 layers at 25 x 88 join the class -- again whatever n
-    class T(Where2ComEngine):
-        throughput_mode = True
-    rule_t = lambda L, n, h, w: Where2ComEngine.wino4_rule(T, L, n, h, w)
+    # throughput mode (whole frames in flight on one GPU): the 128 -> 128 layers at 50 x 176 and the 256 -> 256 layers at 25 x 88 join the
+    # class -- again whatever n; the agent-sharded frame keeps the latency-mode classes even with frames in flight
+    thr = object.__new__(Where2ComEngine)
+    thr.throughput_mode = True
+    rule_t = thr.wino4_rule
     assert all(rule_t(mk(128, 128), n, 50, 176) and rule_t(mk(256, 256), n, 25, 88) and rule_t(mk(256, 256), n, 100, 352) for n in range(1, 16))
     assert not rule_t(mk(64, 64), 4, 100, 352) and not rule_t(mk(256, 256), 4, 12, 44) and not rule_t(mk(128, 256, stride=2), 4, 100, 352)
+    shd = object.__new__(Where2ComEngine)
+    shd.throughput_mode, shd.sharded_frame = True, True
+    assert not shd.wino4_rule(mk(128, 128), 1, 50, 176) and not shd.wino4_rule(mk(256, 256), 2, 25, 88) and shd.wino4_rule(mk(256, 256), 1, 100, 352)
 
 
 def test_winograd_conv_channel_slices_and_argument_checks(lib):
