@@ -604,7 +604,8 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                    "launch": "hipGraph replay" if (eng is not None and eng.graph_active()) else "eager",
                    "frames_in_flight": inflight_used,
                    "engine_mode": ("throughput (frames in flight: the 128- / 256-channel backbone layers on the Winograd F(4x4,3x3) class too, "
-                                   "engine.wino4_rule; same goldens, same tolerances)" if (eng is not None and eng.throughput_mode and inflight_used > 1)
+                                   "engine.wino4_rule; same goldens, same tolerances)" if (eng is not None and a.mode == "replica" and eng.throughput_mode and inflight_used > 1)
+                                   else "latency-mode kernel classes (agent-sharded frame: one or two agents per rank)" if a.mode == "shard"
                                    else "latency (one frame at a time)")},
         **res_extra,
     }
