@@ -952,21 +952,12 @@ class Where2ComEngine:
             cur, ch, cw = dst, ho, wo
         return out, ho, wo
 
-    DEBLOCK_OVERLAP = os.environ.get("AV2X_DEBLOCK_OVERLAP", "1") != "0"
-    _side = None
-
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
-
-    def run_deblocks(self, feats, n, cat, only=None):
-        """feats: [(buffer, h, w)] per level; writes the channel-concatenated map into cat (n,H,W,384).  ``only``: that level alone."""
+    def run_deblocks(self, feats, n, cat):
+        """feats: [(buffer, h, w)] per level; writes the channel-concatenated map into cat (n,H,W,384)."""
         coff = 0
-        for i, L in enumerate(self.deblocks):
-            if i < len(feats) and (only is None or only == i):
-                x, h, w = feats[i]
-                self.conv(L, x, n, h, w, cat, out_ctot=self.cat_c, out_coff=coff)
+        for i, (x, h, w) in enumerate(feats):
+            L = self.deblocks[i]
+            self.conv(L, x, n, h, w, cat, out_ctot=self.cat_c, out_coff=coff)
             coff += L.cout
 
     def run_shrink(self, x, n, h, w, tag, out=None):
@@ -1183,30 +1174,12 @@ class Where2ComEngine:
         """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""
         feats = []
         x, h, w = canvas, ny, nx
-        # Latency mode (one frame at a time): deblock i only needs block i, and the 25 x 88 layers of block 2 leave ~110 of the 256 CUs idle
-        # (144 / 108 one-per-CU workgroups per launch) -- the up-sampling deblocks of blocks 0 and 1 run on a side stream underneath them.
-        # A schedule only: same kernels, same bits.  With frames in flight the other frames fill those CUs already.
-        side = None
-        if (self.DEBLOCK_OVERLAP and not self.throughput_mode and self.profile is None and len(self.blocks) > 1
-                and not torch.cuda.is_current_stream_capturing()):
-            side = self._side_stream()
-            main = torch.cuda.current_stream()
-        H = W = cat = None
         for i in range(len(self.blocks)):
             x, h, w = self.run_block(i, x, n, h, w, tag, out=(block_out or {}).get(i))
             feats.append((x, h, w))
-            if i == 0:
-                H, W = h * self.deblocks[0].up, w * self.deblocks[0].up
-                cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c), self.trunk_dtype())
-            if side is not None and i < len(self.blocks) - 1:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self.run_deblocks(feats, n, cat, only=i)
-        if side is not None:
-            self.run_deblocks(feats, n, cat, only=len(self.blocks) - 1)
-            main.wait_stream(side)
-        else:
-            self.run_deblocks(feats, n, cat)
+        H, W = feats[0][1] * self.deblocks[0].up, feats[0][2] * self.deblocks[0].up
+        cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c), self.trunk_dtype())
+        self.run_deblocks(feats, n, cat)
         s = self.run_shrink(cat, n, H, W, tag, out=shrink_out) if self.shrink else cat
         return feats, s, H, W
 
