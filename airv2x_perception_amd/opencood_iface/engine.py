@@ -1380,7 +1380,7 @@ class Where2ComEngine:
         the other group's next layer.  Results are bit-identical to the single-stream schedule."""
         G = min(self.agent_streams, n)
         if self._streams is None or len(self._streams) < G:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(G)]
+            self._streams = pooled_streams(self.device, G)
         main = torch.cuda.current_stream()
         st = self.stream()
         nz = self.count_canvas(canvas, st)
@@ -1572,6 +1572,23 @@ class Where2ComEngine:
         return out
 
 
+_STREAM_POOL = {}
+
+
+def pooled_streams(device, k):
+    """The process's HIP side streams of ``device``, the first ``k`` of them.  HIP multiplexes streams onto FOUR hardware queues
+    (GPU_MAX_HW_QUEUES): the null stream plus three frame streams use exactly four, and every further stream a process has ever created makes
+    two frames share a queue -- measured: a fifth stream costs a 3-deep FramePipeline 25 % (profiles/r05z_deblock_overlap.txt), and
+    --inflight 4 runs slower than 3.  Hence ONE pool per device: FramePipeline, ShardedPipeline, the agent-group streams and the training
+    step's weight-gradient stream all take their streams from here instead of creating their own."""
+    dev = torch.device(device)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev.index is None else dev
+    pool = _STREAM_POOL.setdefault(dev, [])
+    while len(pool) < k:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:k]
+
+
 class FramePipeline:
     """Throughput mode: ``depth`` independent frames in flight, each on its own HIP stream with its own
     workspaces (weights shared).  Every layer launch ends in a partially filled last round of
@@ -1584,7 +1601,7 @@ class FramePipeline:
     def __init__(self, engine, depth=2):
         engine.throughput_mode = depth > 1
         self.engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
-        self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(depth)]
+        self.streams = pooled_streams(engine.device, depth)
         self.events = [None] * depth
         self.i = 0
 

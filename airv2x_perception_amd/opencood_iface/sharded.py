@@ -181,7 +181,11 @@ class ShardedPipeline:
         self.world, self.rank = self.frames[0].world, self.frames[0].rank
         self.rotate = rotate
         self.cuda = device is not None and torch.device(device).type == "cuda"
-        self.streams = [torch.cuda.Stream(device=device) for _ in backends] if self.cuda else [None] * len(backends)
+        if self.cuda:      # from the process-wide pool (engine.pooled_streams): HIP has four hardware queues, a stream too many costs 25 %
+            from .engine import pooled_streams
+            self.streams = pooled_streams(device, len(backends))
+        else:
+            self.streams = [None] * len(backends)
         self.t = 0
 
     @classmethod

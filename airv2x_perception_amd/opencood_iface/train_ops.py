@@ -374,7 +374,8 @@ def _wgrad_and_dgrad(x, dz, weight, stride, pad, need_w, need_x, owner=None):
     main = torch.cuda.current_stream(x.device)
     side = _SIDE.get(x.device)
     if side is None:
-        side = _SIDE[x.device] = torch.cuda.Stream(device=x.device)
+        from .engine import pooled_streams      # the process-wide pool: see engine.pooled_streams (four hardware queues)
+        side = _SIDE[x.device] = pooled_streams(x.device, 1)[0]
     side.wait_stream(main)
     with torch.cuda.stream(side):
         dw = conv_wgrad(x, dz, weight.shape, stride, pad)
