@@ -1601,6 +1601,10 @@ class FramePipeline:
     def __init__(self, engine, depth=2):
         engine.throughput_mode = depth > 1
         self.engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
+        if depth > 3:
+            import warnings
+            warnings.warn(f"FramePipeline(depth={depth}): HIP multiplexes streams onto four hardware queues (the null stream + three frame "
+                          "streams); a fourth frame stream shares a queue and measured SLOWER than depth 3 (433-441 against 521 frames/s)")
         self.streams = pooled_streams(engine.device, depth)
         self.events = [None] * depth
         self.i = 0
