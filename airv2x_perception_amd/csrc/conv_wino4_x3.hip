@@ -56,6 +56,7 @@ struct Wino4X3Params {
     int Cout, CoutP, out_ctot, out_coff, relu;
     int TH, TW, tiles_per_img, T;
     int nblocks, chunks;
+    int xcd_w;           // 1: the weight-stream form of the workgroup -> (tile block, cout block) map (see the kernel)
     unsigned in_bytes, u_bytes, out_bytes;
 };
 
@@ -90,8 +91,22 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_x3(const Wino4X3Params p) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nbk = gridDim.x, b = blockIdx.x;
     const int q8 = nbk >> 3, r8 = nbk & 7, xcd = b & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    const int mblock = swz / p.nblocks, nblock = swz - mblock * p.nblocks;
+    int mblock, nblock;
+    if (p.xcd_w) {
+        // Weight-stream map (workgroup b runs on XCD b % 8; speed and traffic only, same per-workgroup arithmetic): XCD x takes cout block
+        // x % nblocks of every (8 / nblocks)-th tile block, so an XCD's L2 streams 1 / nblocks of the layer's split planes -- 3.5 of the
+        // 14.2 MB of a 256 -> 256 layer, which every XCD fetched whole before (8 x 14.2 = 113 of the launch's 135 MB at 4 x 25 x 88) -- at the
+        // price of the input map being fetched by nblocks XCDs instead of one.  The host picks it where that trade wins (weights x (8 - 8 /
+        // nblocks) > input x (nblocks - 1)).  The hardware's workgroups-per-XCD counts, q8 + (x < r8), are exactly what this assignment needs.
+        const int G = 8 / p.nblocks;
+        nblock = xcd % p.nblocks;
+        mblock = xcd / p.nblocks + (b >> 3) * G;
+    } else {
+        // activation map: an XCD takes a contiguous range of (tile block, cout block) items -- every cout block of its tile blocks
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+        mblock = swz / p.nblocks;
+        nblock = swz - mblock * p.nblocks;
+    }
     const int t0 = mblock * TB;
     const int n0 = nblock * 64;
 
@@ -457,6 +472,9 @@ int wino4_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, c
     if (out_bytes >= (1ull << 31)) return fail("av2x_conv2d: output (%llu B) exceeds the 2 GiB buffer-descriptor window", out_bytes);
     p.out_bytes = (unsigned)out_bytes;
     const int mblocks = (p.T + 31) / 32;
+    // which XCD map (see the kernel): the weight-stream form where the split planes, fetched once per XCD, outweigh the input map
+    static const bool xcd_off = [] { const char* e = getenv("AV2X_W4X3_XCDMAP"); return e && e[0] == '0'; }();
+    p.xcd_w = (!xcd_off && p.nblocks > 1 && 8 % p.nblocks == 0 && u_bytes * (unsigned long long)(8 - 8 / p.nblocks) > in_bytes * (unsigned long long)(p.nblocks - 1)) ? 1 : 0;
     const size_t lds = 2ull * 36 * 4 * (32 * 16 + 32);
     const bool general = p.res || (p.relu != 0 && p.relu != 1);
     static LdsLimit lim_s, lim_g;
