@@ -118,3 +118,29 @@ def test_create_model_follows_the_reference_name_registry():
     assert isinstance(create_model(synth.default_hypes_v2xvit(rng, (2, 1, 1))), Airv2xV2XVit)
     with pytest.raises(ValueError):
         create_model({"model": {"core_method": "point_pillar_intermediate", "args": {}}})
+
+
+def test_winograd_class_rules_are_functions_of_layer_map_and_mode_only():
+    """engine.wino4_rule / wino_x3_rule decide which Winograd class a 3x3 layer runs in -- host logic, no GPU needed: never a function of the
+    number of agents in the launch (a batch, an agent group and the sharded frame must pick what the single frame picks); latency mode, the
+    throughput mode of FramePipeline, and the agent-sharded frame that keeps the latency-mode classes even with frames in flight."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.engine import ConvLayer, Where2ComEngine
+    from airv2x_perception_amd.opencood_iface.when2com_engine import When2comEngine
+    mk = lambda cin, cout, ks=3, stride=1: ConvLayer(None, None, None, cin, cout, cout, ks, stride, 1 if ks == 3 else 0, 1, _lib.AV2X_CONV)
+    lat = object.__new__(Where2ComEngine)
+    thr = object.__new__(Where2ComEngine)
+    thr.throughput_mode = True
+    shd = object.__new__(Where2ComEngine)
+    shd.throughput_mode, shd.sharded_frame = True, True
+    w2c = object.__new__(When2comEngine)
+    w2c.throughput_mode = True
+    shrink, b1, b2, b0 = (mk(256, 256), 100, 352), (mk(128, 128), 50, 176), (mk(256, 256), 25, 88), (mk(64, 64), 100, 352)
+    for n in range(1, 17):
+        assert lat.wino4_rule(shrink[0], n, *shrink[1:]) and not lat.wino4_rule(b1[0], n, *b1[1:]) and not lat.wino4_rule(b2[0], n, *b2[1:])
+        assert thr.wino4_rule(shrink[0], n, *shrink[1:]) and thr.wino4_rule(b1[0], n, *b1[1:]) and thr.wino4_rule(b2[0], n, *b2[1:])
+        assert not thr.wino4_rule(b0[0], n, *b0[1:])                                  # the 64-channel layers stay on F(2x2) in both modes
+        for e in (shd, w2c):                                                          # sharded frames / When2com: the latency-mode classes
+            assert e.wino4_rule(shrink[0], n, *shrink[1:]) and not e.wino4_rule(b1[0], n, *b1[1:]) and not e.wino4_rule(b2[0], n, *b2[1:])
+    assert Where2ComEngine.wino_x3_rule(b0[0]) and Where2ComEngine.wino_x3_rule(b1[0])
+    assert not Where2ComEngine.wino_x3_rule(mk(32, 64)) and not Where2ComEngine.wino_x3_rule(mk(128, 128, stride=2))
