@@ -172,6 +172,8 @@ SIGNATURES = {
     "av2x_eval_tp_fp": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
     "av2x_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "av2x_layernorm_stats": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "av2x_conv2d_ln": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_fax_attention": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_void_p]),
     "av2x_agent_mean": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p]),

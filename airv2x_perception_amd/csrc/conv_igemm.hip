@@ -21,7 +21,8 @@ int wino_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, co
                      const float* residual, float* out, hipStream_t st);   // conv_wino_x3.hip
 int wino4_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, const float* scale, const float* shift,
                       const float* residual, float* out, hipStream_t st);   // conv_wino4_x3.hip
-int x3p_dispatch(const void* conv_params, size_t bytes, int bm, int bn, hipStream_t st);   // conv_x3p.hip
+int x3p_dispatch(const void* conv_params, size_t bytes, int bm, int bn, hipStream_t st, const float* ln_stats = nullptr,
+                 const float* ln_gamma = nullptr, const float* ln_beta = nullptr);   // conv_x3p.hip
 }
 
 // Test-only: -DAV2X_ABLATE=<bits> (tools/micro/ablate.sh) removes pieces of the prefetch-2 main loop to see what each costs
@@ -452,9 +453,28 @@ extern "C" int av2x_conv2d(const av2x_conv_desc* d, const float* in, const float
     return av2x_conv2d_res(d, in, w, scale, shift, nullptr, out, stream);
 }
 
+static int conv2d_impl(const av2x_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift, const float* residual,
+                       float* out, float* workspace, uint64_t workspace_bytes, av2x_stream_t stream, const float* ln_stats,
+                       const float* ln_gamma, const float* ln_beta);
+
 extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const float* w, const float* scale,
                               const float* shift, const float* residual, float* out, float* workspace,
                               uint64_t workspace_bytes, av2x_stream_t stream) {
+    return conv2d_impl(d, in, w, scale, shift, residual, out, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int av2x_conv2d_ln(const av2x_conv_desc* d, const float* in, const float* ln_stats, const float* ln_gamma, const float* ln_beta,
+                              const float* w, const float* scale, const float* shift, const float* residual, float* out,
+                              av2x_stream_t stream) {
+    if (!ln_stats || !ln_gamma || !ln_beta) return av2x::fail("av2x_conv2d_ln: null LayerNorm argument");
+    if (!d || (d->tile & 0x1400) != 0x1400 || (d->tile & 0x40000000))
+        return av2x::fail("av2x_conv2d_ln: only the pipelined split-3 tiles (flag 0x0400 | 0x1000) normalise while they load");
+    return conv2d_impl(d, in, w, scale, shift, residual, out, nullptr, 0, stream, ln_stats, ln_gamma, ln_beta);
+}
+
+static int conv2d_impl(const av2x_conv_desc* d, const float* in, const float* w, const float* scale, const float* shift, const float* residual,
+                       float* out, float* workspace, uint64_t workspace_bytes, av2x_stream_t stream, const float* ln_stats,
+                       const float* ln_gamma, const float* ln_beta) {
     if (!d || !in || !w || !shift || !out) return av2x::fail("av2x_conv2d: null argument");
     if (residual && d->mode != AV2X_CONV) return av2x::fail("av2x_conv2d: residual only with mode AV2X_CONV");
     if (d->relu < 0 || d->relu > 6)
@@ -522,7 +542,7 @@ extern "C" int av2x_conv2d_sk(const av2x_conv_desc* d, const float* in, const fl
     int bm = (d->tile >> 16) & 0x7fff, bn = d->tile & 0x01ff;
     if (d->tile & 0x0400) {   // split-3: fp32-accurate products from three bf16 terms per operand; w = [3] bf16 planes
         p.w_bytes = (unsigned)(w_bytes / 2 * 3);
-        if (d->tile & 0x1000) return av2x::x3p_dispatch(&p, sizeof(p), bm, bn, st);   // pipelined form (conv_x3p.hip), same bits
+        if (d->tile & 0x1000) return av2x::x3p_dispatch(&p, sizeof(p), bm, bn, st, ln_stats, ln_gamma, ln_beta);   // pipelined form (conv_x3p.hip), same bits
         if (p.CoutP % bn != 0) return av2x::fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
         const bool w8b = (d->tile & 0x8000) != 0, db3 = (d->tile & 0x4000) != 0;   // 0x4000: second LDS buffer set
 #define AV2X_X3(W8, BMv, BNv, WMv, WNv)                                                                   \

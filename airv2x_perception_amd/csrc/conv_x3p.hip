@@ -37,8 +37,17 @@ __device__ __forceinline__ void p3_glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 #define P3_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
+// LayerNorm of the A rows applied while they are loaded (LN = true: token Linears whose input is nn.LayerNorm(x) over the 256 input channels --
+// 1x1, stride 1, whole rows): stats = (mean, rstd) per row from layernorm_stats_kernel, gamma / beta in LDS; (x - mean) * rstd * gamma + beta is
+// the expression of layernorm_kernel, so the operand the split sees has the bits of the materialised LayerNorm output.
+struct X3pLn {
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+};
+
+template <int BN, bool LN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p, const X3pLn ln) {
     constexpr int BM = 128, MT = 2, NT = BN / 64;          // 4 waves as 2 x 2; wave tile 64 x (BN / 2)
     constexpr int WN = BN / 2;
     constexpr int AOS = BM * 16 + 64;                       // bytes per (plane, k-oct) of A: [row][8 bf16] + pad (store conflicts)
@@ -80,6 +89,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
             pix0[i] = 0;
         }
     }
+    float lmean[2] = {0.f, 0.f}, lrstd[2] = {0.f, 0.f};
+    float* lgb = reinterpret_cast<float*>(smem_p3 + 2 * STAGE);      // LN: gamma[Cin] | beta[Cin] behind the two stages
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + (tid >> 2) + 64 * i;
+            if (m < p.M) {
+                lmean[i] = ln.stats[2 * (size_t)m];
+                lrstd[i] = ln.stats[2 * (size_t)m + 1];
+            }
+        }
+        for (int k = tid; k < p.Cin; k += 256) {
+            lgb[k] = ln.gamma[k];
+            lgb[p.Cin + k] = ln.beta[k];
+        }
+        // (visible to every wave after the prologue's first barrier, before the first lstore_a that reads them ... see below)
+    }
     unsigned voffA[2];
     auto tap_offsets = [&](int tp) {
         const int kh = tp / p.ks, kw = tp - kh * p.ks;
@@ -120,16 +146,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
         }
     };
     f32x4 ra[2][2];
-    auto gload_a = [&](f32x4 (&r)[2]) {
+    int rk[2] = {0, 0};                                                // LN: first channel of this thread's quad in the step held by ra[.]
+    auto gload_a = [&](f32x4 (&r)[2], int& k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, voffA[i], cc * 64, 0));
+        k0 = cc * 16 + qA * 4;
     };
     const unsigned wA = (unsigned)((qA >> 1) * AOS + (tid >> 2) * 16 + (qA & 1) * 8);
-    auto lstore_a = [&](const f32x4 (&r)[2], int buf) {
+    auto lstore_a = [&](const f32x4 (&r)[2], int buf, int k0) {
         unsigned char* st = smem_p3 + buf * STAGE + wA;
+        f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (LN) {
+            g4 = *reinterpret_cast<const f32x4*>(lgb + k0);
+            b4 = *reinterpret_cast<const f32x4*>(lgb + p.Cin + k0);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const f32x4 v = r[i];
+            f32x4 v = r[i];
+            if constexpr (LN) {
+                v[0] = (v[0] - lmean[i]) * lrstd[i] * g4[0] + b4[0];
+                v[1] = (v[1] - lmean[i]) * lrstd[i] * g4[1] + b4[1];
+                v[2] = (v[2] - lmean[i]) * lrstd[i] * g4[2] + b4[2];
+                v[3] = (v[3] - lmean[i]) * lrstd[i] * g4[3] + b4[3];
+            }
 #ifdef AV2X_X3P_NOSPLIT      // timing experiment only (wrong results): what the kernel costs without the hi / mid / lo split
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             const u32x2 raw = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
@@ -181,10 +220,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
 
     // prologue: step 0 -> stage 0; the A tile of step 1 in flight
     issue_b(0);
-    gload_a(ra[0]);
+    gload_a(ra[0], rk[0]);
     advance();
-    gload_a(ra[1]);
-    lstore_a(ra[0], 0);
+    gload_a(ra[1], rk[1]);
+    if constexpr (LN) __syncthreads();                         // gamma / beta are in LDS
+    lstore_a(ra[0], 0, rk[0]);
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // the DMA of step 0 has landed (the two loads of step 1 may still fly)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -192,17 +232,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
         // even step s: stage 0 holds it; ra[1] holds step s + 1
         issue_b(1);                                           // step s + 1 (its (tap, cc) is the current one)
         advance();
-        gload_a(ra[0]);                                       // step s + 2
+        const int k1 = rk[1];
+        gload_a(ra[0], rk[0]);                                // step s + 2
         compute(0);
-        lstore_a(ra[1], 1);
+        lstore_a(ra[1], 1, k1);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         P3_STEP_BARRIER();
         if (s + 1 < nst) {
             issue_b(0);                                       // step s + 2
             advance();
-            gload_a(ra[1]);                                   // step s + 3
+            const int k0 = rk[0];
+            gload_a(ra[1], rk[1]);                            // step s + 3
             compute(1);
-            lstore_a(ra[0], 0);
+            lstore_a(ra[0], 0, k0);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             P3_STEP_BARRIER();
         }
@@ -222,13 +264,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3p(const ConvParams p) {
 }
 
 template <int BN>
-int launch_x3p(const ConvParams& p, hipStream_t st) {
+int launch_x3p(const ConvParams& p, const X3pLn& ln, hipStream_t st) {
     constexpr int BM = 128;
     const int tiles_m = (p.M + BM - 1) / BM;
     ConvParams q = p;
     q.tiles_n = p.CoutP / BN;
     const size_t lds = 2ull * (3 * 2 * (BM * 16 + 64) + 3 * 2 * BN * 16);
-    hipLaunchKernelGGL((conv_igemm_x3p<BN>), dim3(tiles_m * q.tiles_n), dim3(256), lds, st, q);
+    if (ln.stats) {
+        hipLaunchKernelGGL((conv_igemm_x3p<BN, true>), dim3(tiles_m * q.tiles_n), dim3(256), lds + 2ull * p.Cin * sizeof(float), st, q, ln);
+        return av2x::check_launch("conv_igemm_x3p<LN>");
+    }
+    hipLaunchKernelGGL((conv_igemm_x3p<BN, false>), dim3(tiles_m * q.tiles_n), dim3(256), lds, st, q, ln);
     return av2x::check_launch("conv_igemm_x3p");
 }
 
@@ -238,14 +284,21 @@ namespace av2x {
 
 // called by av2x_conv2d* (conv_igemm.hip) for tile flag 0x0400 | 0x1000 with the validated ConvParams of that translation unit
 // (same header, same layout; passed as bytes because the type lives in an anonymous namespace)
-int x3p_dispatch(const void* conv_params, size_t bytes, int bm, int bn, hipStream_t st) {
+int x3p_dispatch(const void* conv_params, size_t bytes, int bm, int bn, hipStream_t st, const float* ln_stats, const float* ln_gamma,
+                 const float* ln_beta) {
     ConvParams p;
     if (bytes != sizeof(ConvParams)) return fail("av2x_conv2d: internal parameter block mismatch");
     std::memcpy(&p, conv_params, sizeof(p));
     if (p.Cin % 16) return fail("av2x_conv2d: the pipelined split-3 tiles need cin %% 16 == 0 (cin=%d)", p.Cin);
     if (bm != 128 || (bn != 128 && bn != 64)) return fail("av2x_conv2d: the pipelined split-3 tiles are 128x128 and 128x64 (tile %dx%d)", bm, bn);
     if (p.CoutP % bn) return fail("av2x_conv2d: tile BN=%d does not divide coutp=%d", bn, p.CoutP);
-    return bn == 128 ? launch_x3p<128>(p, st) : launch_x3p<64>(p, st);
+    const X3pLn ln = {ln_stats, ln_gamma, ln_beta};
+    if (ln_stats) {
+        if (!ln_gamma || !ln_beta) return fail("av2x_conv2d_ln: null gamma / beta");
+        if (p.ks != 1 || p.stride != 1 || p.pad != 0 || p.mode != AV2X_CONV || p.in_ctot != p.Cin || p.in_coff != 0 || p.Cin > 1024)
+            return fail("av2x_conv2d_ln: LayerNorm in the operand load needs a 1x1 / stride-1 layer over whole rows (in_ctot == cin, in_coff == 0)");
+    }
+    return bn == 128 ? launch_x3p<128>(p, ln, st) : launch_x3p<64>(p, ln, st);
 }
 
 }  // namespace av2x

@@ -54,6 +54,35 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float4* __restrict
     }
 }
 
+// The statistics half of layernorm_kernel<1> alone: stats[tok] = (mean, rstd) with the SAME arithmetic (same sums, same order), for a
+// consumer that normalises while it loads (conv_igemm_x3p's LN form): (x - mean) * rstd * gamma + beta there has the bits of this file's
+// kernel, and the normalised tensor (288 MB written + read per LayerNorm at 8 agents) never exists.
+__global__ __launch_bounds__(256) void layernorm_stats_kernel(const float4* __restrict__ x, float2* __restrict__ stats, int n_tokens, float eps) {
+    constexpr int C = 256, TPW = 4;                           // four tokens per wave: their 1-KB rows are requested together
+    const int lane = threadIdx.x & 63;
+    const int tok0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW;
+    if (tok0 >= n_tokens) return;
+    float4 v[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tok = min(tok0 + t, n_tokens - 1);
+        v[t] = x[(size_t)tok * (C / 4) + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        float s = (v[t].x + v[t].y) + (v[t].z + v[t].w);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        const float a = v[t].x - mean, b = v[t].y - mean, c = v[t].z - mean, d = v[t].w - mean;
+        float q = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+        if (lane == 0 && tok0 + t < n_tokens) stats[tok0 + t] = make_float2(mean, rstd);
+    }
+}
+
 // ---------------------------------------------------------------- fused axial attention
 struct FaxParams {
     const float* qkv;   // (L*H*W, 3*C) rows = tokens in NHWC order (agent-major)
@@ -869,6 +898,16 @@ __global__ void agent_mean_kernel(const float4* __restrict__ x, float4* __restri
 
 extern "C" int av2x_layernorm_act(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,
                                   int32_t c, float eps, int32_t relu, av2x_stream_t stream);
+
+extern "C" int av2x_layernorm_stats(const float* x, float* stats, int64_t n_tokens, int32_t c, float eps, av2x_stream_t stream) {
+    if (n_tokens == 0) return 0;
+    if (!x || !stats) return av2x::fail("av2x_layernorm_stats: null argument");
+    if (c != 256) return av2x::fail("av2x_layernorm_stats: c=%d unsupported (256)", c);
+    if (n_tokens < 0 || n_tokens > (1ll << 31) - 8) return av2x::fail("av2x_layernorm_stats: bad token count");
+    hipLaunchKernelGGL(layernorm_stats_kernel, dim3((unsigned)((n_tokens + 15) / 16)), dim3(256), 0, av2x::as_stream(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float2*>(stats), (int)n_tokens, eps);
+    return av2x::check_launch("layernorm_stats_kernel");
+}
 
 extern "C" int av2x_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens, int32_t c,
                               float eps, av2x_stream_t stream) {

@@ -95,34 +95,33 @@ class CoBEVTEngine(Where2ComEngine):
         if H % ws or W % ws:
             raise ValueError(f"BEV map {H}x{W} is not divisible by the window size {ws}")
         nt = L * H * W
-        xn = self.buf("fax_xn", (L, H, W, C))
         qkv = self.buf("fax_qkv", (L, H, W, 3 * C))
         att = self.buf("fax_att", (L, H, W, C))
         hid = self.buf("fax_hid", (L, H, W, self.fax["mlp_dim"]))
         for i, blk in enumerate(self.fax_layers):
             for gi, part in enumerate(("window", "grid")):
                 P = blk[part]
-                self.ln(x, P["ln1"], xn, nt, C)
+                # PreNorm: the LayerNorm of the residual stream is applied by the consuming Linear while it loads its rows (engine.conv ln=);
+                # only the per-token (mean, rstd) pass over x remains of it
+                ln1 = (self.ln_stats(x, nt, C, LN_EPS), P["ln1"][0], P["ln1"][1], LN_EPS)
                 if n_valid == L:
-                    self.conv(P["qkv"], xn, L, H, W, qkv)
+                    self.conv(P["qkv"], x, L, H, W, qkv, ln=ln1)
                 else:   # q for all L agents (padded query tokens attend the valid keys), k | v only for the valid ones
-                    self.conv(P["q"], xn, L, H, W, qkv, out_ctot=3 * C, out_coff=0)
-                    self.conv(P["kv"], xn, n_valid, H, W, qkv, out_ctot=3 * C, out_coff=C)
+                    self.conv(P["q"], x, L, H, W, qkv, out_ctot=3 * C, out_coff=0, ln=ln1)
+                    self.conv(P["kv"], x, n_valid, H, W, qkv, out_ctot=3 * C, out_coff=C, ln=ln1)
                 _lib.check(self.lib.av2x_fax_attention(_ptr(qkv), _ptr(P["table"]), _ptr(att), L, n_valid, H, W, ws,
                                                        self.heads_n, self.fax["dim_head"], gi | (32 if self.fax_x3() else 0), self.stream()),
                            "av2x_fax_attention")
                 self.conv(P["out"], att, L, H, W, x, residual=x)            # to_out(.) + x   (PreNormResidual)
-                self.ln(x, P["ln2"], xn, nt, C)
-                self.conv(P["ff1"], xn, L, H, W, hid)                        # Linear + bias + GELU
+                ln2 = (self.ln_stats(x, nt, C, LN_EPS), P["ln2"][0], P["ln2"][1], LN_EPS)
+                self.conv(P["ff1"], x, L, H, W, hid, ln=ln2)                 # LayerNorm + Linear + bias + GELU
                 self.conv(P["ff2"], hid, L, H, W, x, residual=x)            # Linear + bias + x
             if trace is not None:
                 trace[f"fax_block{i}"] = x.permute(0, 3, 1, 2).unsqueeze(0).clone()
         mean = self.buf("fax_mean", (1, H, W, C))
         _lib.check(self.lib.av2x_agent_mean(_ptr(x), _ptr(mean), L, H * W * C, self.stream()), "av2x_agent_mean")
-        mn = self.buf("fax_mean_ln", (1, H, W, C))
-        self.ln(mean, self.head_ln, mn, H * W, C)
         fused = self.buf("fax_fused", (1, H, W, C))
-        self.conv(self.head_lin, mn, 1, H, W, fused)
+        self.conv(self.head_lin, mean, 1, H, W, fused, ln=(self.ln_stats(mean, H * W, C, LN_EPS, "ln_stats_head"), self.head_ln[0], self.head_ln[1], LN_EPS))
         return fused
 
     def _heads_out(self, fused, H, W, B=1):

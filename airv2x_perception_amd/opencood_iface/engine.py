@@ -538,8 +538,18 @@ class Where2ComEngine:
         return c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------ kernels
-    def conv(self, L, x, n, h, w, out, in_ctot=None, in_coff=0, out_ctot=None, out_coff=0, residual=None):
-        """x: NHWC buffer holding >= n images of (h, w, in_ctot); returns (ho, wo)."""
+    LN_FOLD = os.environ.get("AV2X_LN_FOLD", "1") != "0"
+
+    def ln_stats(self, x, n_tokens, c, eps, tag="ln_stats"):
+        """(mean, rstd) of every token of x (n_tokens, c): the statistics half of av2x_layernorm, for conv(..., ln=(stats, gamma, beta))."""
+        st = self.buf(tag, (n_tokens, 2))
+        _lib.check(self.lib.av2x_layernorm_stats(_ptr(x), _ptr(st), n_tokens, c, eps, self.stream()), "av2x_layernorm_stats")
+        return st
+
+    def conv(self, L, x, n, h, w, out, in_ctot=None, in_coff=0, out_ctot=None, out_coff=0, residual=None, ln=None):
+        """x: NHWC buffer holding >= n images of (h, w, in_ctot); returns (ho, wo).  ``ln`` = (stats, gamma, beta, eps): the layer runs on
+        nn.LayerNorm(x) -- normalised while the pipelined split-3 tiles load their operand rows (av2x_conv2d_ln, same bits as the separate
+        LayerNorm launch); any other kernel class materialises the LayerNorm first."""
         d = self._desc
         d.n, d.h, d.w, d.cin = n, h, w, L.cin
         d.in_ctot = in_ctot if in_ctot is not None else L.cin
@@ -611,6 +621,14 @@ class Where2ComEngine:
             bm, bn = self.pick_tile(n * d.ho * d.wo, L.coutp)
             d.tile = (bm << 16) | bn | vflag
         bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff  # bn keeps the variant flags (profile key); bm & 0x4000 = Winograd
+        ln_fold = False
+        if ln is not None:
+            ln_fold = (self.LN_FOLD and (d.tile & 0x1400) == 0x1400 and not (d.tile & 0x40000000) and L.ks == 1 and L.stride == 1 and L.pad == 0
+                       and L.mode == _lib.AV2X_CONV and d.in_ctot == L.cin and d.in_coff == 0 and L.cin <= 1024 and not a16)
+            if not ln_fold:     # a kernel class that cannot normalise while it loads: the LayerNorm as its own launch
+                xn = self.buf("ln_materialised", (n, h, w, L.cin))
+                _lib.check(self.lib.av2x_layernorm(_ptr(x), _ptr(ln[1]), _ptr(ln[2]), _ptr(xn), n * h * w, L.cin, ln[3], self.stream()), "av2x_layernorm")
+                x = xn
         if self.profile is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -618,6 +636,9 @@ class Where2ComEngine:
             ws = self.sk_workspace()
             _lib.check(self.lib.av2x_conv2d_sk(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
                                                _ptr(out), _ptr(ws), ws.numel() * 4, self.stream()), "av2x_conv2d_sk")
+        elif ln_fold:
+            _lib.check(self.lib.av2x_conv2d_ln(byref(d), _ptr(x), _ptr(ln[0]), _ptr(ln[1]), _ptr(ln[2]), _ptr(wgt), _ptr(L.scale), _ptr(L.shift),
+                                               _ptr(residual), _ptr(out), self.stream()), "av2x_conv2d_ln")
         else:
             _lib.check(self.lib.av2x_conv2d_res(byref(d), _ptr(x), _ptr(wgt), _ptr(L.scale), _ptr(L.shift), _ptr(residual),
                                                 _ptr(out), self.stream()), "av2x_conv2d")

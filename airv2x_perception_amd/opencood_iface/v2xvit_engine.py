@@ -180,7 +180,6 @@ class V2XViTEngine(Where2ComEngine):
         if self.amp and self.bf16_activations and self.enc["feed_forward"]["mlp_dim"] == 256:
             return self._blocks_bf16(x, mask, n, H, W, types, world, trace)
         tarr = (c_int32 * n)(*types)
-        xn = self.buf("vit_xn", (n, H, W, C))
         proj = self.buf("vit_proj", (n, H, W, 1280))
         att = self.buf("vit_att", (n, H, W, C))
         qkv3 = self.buf("vit_qkv3", (n, H, W, 2304))
@@ -200,14 +199,17 @@ class V2XViTEngine(Where2ComEngine):
                 # are needed as KEYS / VALUES of the HGT attention and nowhere else -> m = 1 agent from there on
                 ego_only = self.ego_only_last and di == last and bi == len(blocks) - 1 and trace is None and n > 1
                 # ---- x = HGT(LN(x)) + x
-                self.ln(x, blk["ln1"], xn, n * hw, C)
+                # PreNorm: the consuming Linears normalise their rows while they load them (engine.conv ln=); what is left of the LayerNorm
+                # launch is the per-token (mean, rstd) pass
+                s1 = self.ln_stats(x, n * hw, C, LN_EPS)
+                ln1 = lambda a, b: (s1[a * hw:b * hw], blk["ln1"][0], blk["ln1"][1], LN_EPS)
                 if ego_only:
-                    self.conv(blk["proj"][types[0]], xn[0:1], 1, H, W, proj[0:1])
+                    self.conv(blk["proj"][types[0]], x[0:1], 1, H, W, proj[0:1], ln=ln1(0, 1))
                     for (a, b, t) in self._groups(types[1:]):
-                        self.conv(blk["proj_kv"][t], xn[a + 1:b + 1], b - a, H, W, proj[a + 1:b + 1], out_ctot=1280, out_coff=512)
+                        self.conv(blk["proj_kv"][t], x[a + 1:b + 1], b - a, H, W, proj[a + 1:b + 1], out_ctot=1280, out_coff=512, ln=ln1(a + 1, b + 1))
                 else:
                     for (a, b, t) in groups:
-                        self.conv(blk["proj"][t], xn[a:b], b - a, H, W, proj[a:b])
+                        self.conv(blk["proj"][t], x[a:b], b - a, H, W, proj[a:b], ln=ln1(a, b))
                 m = 1 if ego_only else n
                 _lib.check(self.lib.av2x_hgt_attention_q(_ptr(proj), _ptr(mask), ctypes.cast(tarr, c_void_p), _ptr(att), n, m, hw,
                                                          self.cav["heads"], self.cav["dim_head"], st()), "av2x_hgt_attention")
@@ -216,8 +218,7 @@ class V2XViTEngine(Where2ComEngine):
                 if trace is not None:
                     trace[f"hgt{di}"] = x.clone()
                 # ---- x = SplitAttn(window attentions(LN(x))) + x
-                self.ln(x, blk["ln2"], xn, m * hw, C)
-                self.conv(blk["qkv3"], xn, m, H, W, qkv3)
+                self.conv(blk["qkv3"], x, m, H, W, qkv3, ln=(self.ln_stats(x, m * hw, C, LN_EPS), blk["ln2"][0], blk["ln2"][1], LN_EPS))
                 for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
                     _lib.check(self.lib.av2x_window_attention(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat), m, H, W,
                                                               h, dh, ws, st()), "av2x_window_attention")
@@ -235,8 +236,7 @@ class V2XViTEngine(Where2ComEngine):
                                                             m, hw, C, st()), "combine")
             # ---- x = FFN(LN(x)) + x
             m = 1 if (self.ego_only_last and di == last and trace is None and n > 1) else n
-            self.ln(x, ffn["ln"], xn, m * hw, C)
-            self.conv(ffn["ff1"], xn, m, H, W, hid)
+            self.conv(ffn["ff1"], x, m, H, W, hid, ln=(self.ln_stats(x, m * hw, C, LN_EPS), ffn["ln"][0], ffn["ln"][1], LN_EPS))
             self.conv(ffn["ff2"], hid, m, H, W, x, residual=x)
             if trace is not None:
                 trace[f"layer{di}"] = x.clone()

@@ -704,6 +704,14 @@ int av2x_eval_tp_fp(const float* det_corners, const int32_t* order, int32_t n_de
  *   engines' x3 mode requests.
  * av2x_agent_mean: y = mean over the agent axis of x (n_agents, elems_per_agent)  (:270).
  * ------------------------------------------------------------------------------------ */
+/* LayerNorm folded into the consuming token Linear (round 5): av2x_layernorm_stats writes (mean, rstd) per token -- the statistics half of
+ * av2x_layernorm, same arithmetic -- and av2x_conv2d_ln is av2x_conv2d_res on nn.LayerNorm(in): the pipelined split-3 tiles (tile flag
+ * 0x0400 | 0x1000; 1x1, stride 1, in_ctot == cin <= 1024) apply (x - mean) * rstd * gamma + beta to the operand rows while they load them.
+ * Same bits as av2x_layernorm followed by av2x_conv2d_res; the normalised tensor never exists in HBM (base_transformer.py:9-20 PreNorm,
+ * swap_fusion_modules.py:78-195). */
+int av2x_layernorm_stats(const float* x, float* stats /* (n_tokens, 2) */, int64_t n_tokens, int32_t c, float eps, av2x_stream_t stream);
+int av2x_conv2d_ln(const av2x_conv_desc* d, const float* in, const float* ln_stats, const float* ln_gamma, const float* ln_beta,
+                   const float* w, const float* scale, const float* shift, const float* residual, float* out, av2x_stream_t stream);
 int av2x_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t n_tokens,
                    int32_t c, float eps, av2x_stream_t stream);
 int av2x_fax_attention(const float* qkv, const float* bias_table, float* out, int32_t n_agents_padded,

@@ -152,3 +152,43 @@ def test_goldens_in_x3_mode_at_unchanged_tolerances(which, name):
         assert_close(got[..., ::hs, ::hs] if hs > 1 else got, fx[k], rtol, atol_of(fx[k]), f"{name} {k} (x3)")
     if which == "w2c":
         assert int(out["comm_rate"]) == int(fx["comm_rate"])
+
+
+@pytest.mark.parametrize("m_tokens,cout,relu,res,bn", [(1000, 768, 0, False, 128), (333, 256, 2, True, 64), (4096 + 17, 1024, 2, False, 128)])
+def test_layernorm_in_the_operand_load_equals_layernorm_then_linear(m_tokens, cout, relu, res, bn):
+    """av2x_layernorm_stats + av2x_conv2d_ln (the token Linear normalises its rows while it loads them: PreNorm of base_transformer.py:9-20)
+    against av2x_layernorm followed by av2x_conv2d_res on the materialised tensor: the same bits, ragged token counts, bias / GELU / residual
+    epilogues, both pipelined split-3 tiles.  The statistics equal those of F.layer_norm's definition in float64."""
+    from airv2x_perception_amd import _lib
+    from airv2x_perception_amd.opencood_iface.packing import pack_conv_weight, to_bf16x3_koct
+    lib = _lib.load()
+    C = 256
+    g = torch.Generator().manual_seed(7 + cout)
+    x = (torch.randn(m_tokens, C, generator=g) * torch.exp(torch.randn(m_tokens, 1, generator=g)) + torch.randn(m_tokens, 1, generator=g)).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    wt = torch.randn(cout, C, 1, 1, generator=g) / 16
+    wp, coutp = pack_conv_weight(wt)
+    w3 = to_bf16x3_koct(wp).cuda()
+    shift = (torch.randn(cout, generator=g) * 0.1).cuda()
+    resid = torch.randn(m_tokens, cout, generator=g).cuda() if res else None
+    d = _lib.ConvDesc(n=1, h=1, w=m_tokens, cin=C, in_ctot=C, in_coff=0, ho=1, wo=m_tokens, cout=cout, coutp=coutp, out_ctot=cout, out_coff=0,
+                      ks=1, stride=1, pad=0, relu=relu, mode=0, up=1, tile=(128 << 16) | bn | 0x1400, sk_wgs=0)
+    xn = torch.empty_like(x)
+    _lib.check(lib.av2x_layernorm(_p(x), _p(gamma), _p(beta), _p(xn), m_tokens, C, 1e-5, _st()), "ln")
+    want = torch.full((m_tokens, cout), float("nan"), device="cuda")
+    _lib.check(lib.av2x_conv2d_res(byref(d), _p(xn), _p(w3), None, _p(shift), _p(resid), _p(want), _st()), "linear")
+    stats = torch.empty((m_tokens, 2), device="cuda")
+    _lib.check(lib.av2x_layernorm_stats(_p(x), _p(stats), m_tokens, C, 1e-5, _st()), "stats")
+    got = torch.full((m_tokens, cout), float("nan"), device="cuda")
+    _lib.check(lib.av2x_conv2d_ln(byref(d), _p(x), _p(stats), _p(gamma), _p(beta), _p(w3), None, _p(shift), _p(resid), _p(got), _st()), "ln+linear")
+    assert torch.equal(got, want)
+    xd = x.double().cpu()
+    assert torch.allclose(stats[:, 0].double().cpu(), xd.mean(1), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(stats[:, 1].double().cpu(), 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5), rtol=1e-5)
+    # refused: a 3x3 layer, a channel slice, a non-pipelined tile
+    d2 = _lib.ConvDesc(n=1, h=1, w=m_tokens, cin=C, in_ctot=C, in_coff=0, ho=1, wo=m_tokens, cout=cout, coutp=coutp, out_ctot=cout, out_coff=0,
+                       ks=1, stride=1, pad=0, relu=relu, mode=0, up=1, tile=(128 << 16) | 64 | 0x0400, sk_wgs=0)
+    assert lib.av2x_conv2d_ln(byref(d2), _p(x), _p(stats), _p(gamma), _p(beta), _p(w3), None, _p(shift), _p(resid), _p(got), _st()) != 0
+    d3 = _lib.ConvDesc(n=1, h=1, w=m_tokens, cin=C // 2, in_ctot=C, in_coff=0, ho=1, wo=m_tokens, cout=cout, coutp=coutp, out_ctot=cout, out_coff=0,
+                       ks=1, stride=1, pad=0, relu=relu, mode=0, up=1, tile=(128 << 16) | bn | 0x1400, sk_wgs=0)
+    assert lib.av2x_conv2d_ln(byref(d3), _p(x), _p(stats), _p(gamma), _p(beta), _p(w3), None, _p(shift), _p(resid), _p(got), _st()) != 0
