@@ -103,17 +103,17 @@ class CoBEVTEngine(Where2ComEngine):
                 P = blk[part]
                 # PreNorm: the LayerNorm of the residual stream is applied by the consuming Linear while it loads its rows (engine.conv ln=);
                 # only the per-token (mean, rstd) pass over x remains of it
-                ln1 = (self.ln_stats(x, nt, C, LN_EPS), P["ln1"][0], P["ln1"][1], LN_EPS)
+                ln1 = self.ln_operand(x, nt, C, P["ln1"][0], P["ln1"][1], LN_EPS)
                 if n_valid == L:
                     self.conv(P["qkv"], x, L, H, W, qkv, ln=ln1)
                 else:   # q for all L agents (padded query tokens attend the valid keys), k | v only for the valid ones
                     self.conv(P["q"], x, L, H, W, qkv, out_ctot=3 * C, out_coff=0, ln=ln1)
-                    self.conv(P["kv"], x, n_valid, H, W, qkv, out_ctot=3 * C, out_coff=C, ln=ln1)
+                    self.conv(P["kv"], x, n_valid, H, W, qkv, out_ctot=3 * C, out_coff=C, ln=ln1.rows(0, n_valid * H * W))
                 _lib.check(self.lib.av2x_fax_attention(_ptr(qkv), _ptr(P["table"]), _ptr(att), L, n_valid, H, W, ws,
                                                        self.heads_n, self.fax["dim_head"], gi | (32 if self.fax_x3() else 0), self.stream()),
                            "av2x_fax_attention")
                 self.conv(P["out"], att, L, H, W, x, residual=x)            # to_out(.) + x   (PreNormResidual)
-                ln2 = (self.ln_stats(x, nt, C, LN_EPS), P["ln2"][0], P["ln2"][1], LN_EPS)
+                ln2 = self.ln_operand(x, nt, C, P["ln2"][0], P["ln2"][1], LN_EPS)
                 self.conv(P["ff1"], x, L, H, W, hid, ln=ln2)                 # LayerNorm + Linear + bias + GELU
                 self.conv(P["ff2"], hid, L, H, W, x, residual=x)            # Linear + bias + x
             if trace is not None:
@@ -121,7 +121,7 @@ class CoBEVTEngine(Where2ComEngine):
         mean = self.buf("fax_mean", (1, H, W, C))
         _lib.check(self.lib.av2x_agent_mean(_ptr(x), _ptr(mean), L, H * W * C, self.stream()), "av2x_agent_mean")
         fused = self.buf("fax_fused", (1, H, W, C))
-        self.conv(self.head_lin, mean, 1, H, W, fused, ln=(self.ln_stats(mean, H * W, C, LN_EPS, "ln_stats_head"), self.head_ln[0], self.head_ln[1], LN_EPS))
+        self.conv(self.head_lin, mean, 1, H, W, fused, ln=self.ln_operand(mean, H * W, C, self.head_ln[0], self.head_ln[1], LN_EPS, "ln_stats_head"))
         return fused
 
     def _heads_out(self, fused, H, W, B=1):

@@ -137,6 +137,39 @@ def _wu43(L, lib, stream):
     return L._wu43
 
 
+class LnOperand:
+    """nn.LayerNorm over the channel axis of the first ``n_tokens`` rows of ``x`` (tokens x c, fp32), handed to Where2ComEngine.conv(ln=...).
+    Nothing is launched until a consumer asks: a kernel class that normalises while it loads its rows (av2x_conv2d_ln) takes ``stats()`` --
+    the per-token (mean, rstd) pass, run once --; any other class takes ``materialised()`` -- one av2x_layernorm launch whose result every
+    consumer of this operand shares (CoBEVT's q and k|v Linears read the same normalised rows).  ``rows(a, b)`` is the operand of a token
+    range (V2X-ViT's per-agent-type projections)."""
+
+    def __init__(self, eng, x, n_tokens, c, gamma, beta, eps, tag="ln_stats", lo=0, hi=None, root=None):
+        self.eng, self.x, self.n_tokens, self.c, self.gamma, self.beta, self.eps, self.tag = eng, x, int(n_tokens), int(c), gamma, beta, eps, tag
+        self.lo, self.hi, self.root = lo, (int(n_tokens) if hi is None else hi), root
+        self._stats = self._xn = None
+
+    def rows(self, a, b):
+        r = self.root or self
+        if not (0 <= a <= b <= self.hi - self.lo):
+            raise ValueError(f"LayerNorm operand rows [{a}, {b}) outside its {self.hi - self.lo} tokens")
+        return LnOperand(self.eng, self.x, b - a, self.c, self.gamma, self.beta, self.eps, self.tag, self.lo + a, self.lo + b, r)
+
+    def stats(self):
+        r = self.root or self
+        if r._stats is None:
+            r._stats = r.eng.ln_stats(r.x, r.n_tokens, r.c, r.eps, r.tag)
+        return r._stats[self.lo:self.hi] if self.root is not None else r._stats
+
+    def materialised(self):
+        r = self.root or self
+        if r._xn is None:
+            e = r.eng
+            r._xn = e.buf("ln_materialised_" + r.tag, (r.n_tokens, r.c))
+            _lib.check(e.lib.av2x_layernorm(_ptr(r.x), _ptr(r.gamma), _ptr(r.beta), _ptr(r._xn), r.n_tokens, r.c, r.eps, e.stream()), "av2x_layernorm")
+        return r._xn[self.lo:self.hi] if self.root is not None else r._xn
+
+
 def _ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
@@ -312,6 +345,22 @@ class Where2ComEngine:
         other.wino4_x3 = self.wino4_x3
         other.wino2_x3 = self.wino2_x3
         return other
+
+    def frame_mode(self, throughput, sharded):
+        """Context: the engine in the given (throughput_mode, sharded_frame) for the calls inside, the caller's own flags restored afterwards.
+        The flags select Winograd classes (wino4_rule), i.e. bits: a pipeline scopes ITS mode to ITS frames with this instead of leaving
+        it on the engine the caller handed over (a later direct forward() of that engine keeps the bits it had before)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            saved = (self.throughput_mode, self.sharded_frame)
+            self.throughput_mode, self.sharded_frame = bool(throughput), bool(sharded)
+            try:
+                yield self
+            finally:
+                self.throughput_mode, self.sharded_frame = saved
+        return scope()
 
     def graph_active(self):
         return self.use_graph and len(self.graphs) > 0
@@ -540,6 +589,10 @@ class Where2ComEngine:
     # ------------------------------------------------------------------ kernels
     LN_FOLD = os.environ.get("AV2X_LN_FOLD", "1") != "0"
 
+    def ln_operand(self, x, n_tokens, c, gamma, beta, eps, tag="ln_stats"):
+        """nn.LayerNorm(x) of the first n_tokens rows of x as an operand of conv(..., ln=): see LnOperand."""
+        return LnOperand(self, x, n_tokens, c, gamma, beta, eps, tag)
+
     def ln_stats(self, x, n_tokens, c, eps, tag="ln_stats"):
         """(mean, rstd) of every token of x (n_tokens, c): the statistics half of av2x_layernorm, for conv(..., ln=(stats, gamma, beta))."""
         st = self.buf(tag, (n_tokens, 2))
@@ -623,9 +676,18 @@ class Where2ComEngine:
         bm, bn = (d.tile >> 16) & 0x7fff, d.tile & 0xffff  # bn keeps the variant flags (profile key); bm & 0x4000 = Winograd
         ln_fold = False
         if ln is not None:
-            ln_fold = (self.LN_FOLD and (d.tile & 0x1400) == 0x1400 and not (d.tile & 0x40000000) and L.ks == 1 and L.stride == 1 and L.pad == 0
-                       and L.mode == _lib.AV2X_CONV and d.in_ctot == L.cin and d.in_coff == 0 and L.cin <= 1024 and not a16)
-            if not ln_fold:     # a kernel class that cannot normalise while it loads: the LayerNorm as its own launch
+            lazy = isinstance(ln, LnOperand)
+            ln_fold = (self.LN_FOLD and (d.tile & 0x1400) == 0x1400 and not (d.tile & 0x2000) and not (d.tile & 0x40000000) and L.ks == 1 and L.stride == 1 and L.pad == 0
+                       and L.mode == _lib.AV2X_CONV and d.in_ctot == L.cin and d.in_coff == 0 and L.cin <= 1024 and not a16
+                       and (L.cin == 256 or not lazy))      # av2x_layernorm_stats is built for 256 channels; other widths materialise (256 / 512)
+            if lazy:
+                if ln.c != L.cin or ln.n_tokens < n * h * w:
+                    raise ValueError(f"LayerNorm operand of {ln.n_tokens} x {ln.c} tokens for a Linear over {n * h * w} x {L.cin}")
+                if ln_fold:     # the statistics pass runs once per LayerNorm, on first use by a folding kernel
+                    ln = (ln.stats(), ln.gamma, ln.beta, ln.eps)
+                else:           # a kernel class that cannot normalise while it loads: ONE LayerNorm launch, shared by every consumer of this operand
+                    x = ln.materialised()
+            elif not ln_fold:
                 xn = self.buf("ln_materialised", (n, h, w, L.cin))
                 _lib.check(self.lib.av2x_layernorm(_ptr(x), _ptr(ln[1]), _ptr(ln[2]), _ptr(xn), n * h * w, L.cin, ln[3], self.stream()), "av2x_layernorm")
                 x = xn
@@ -1146,6 +1208,11 @@ class Where2ComEngine:
         self._occ_info = (self._frame, canvas.data_ptr(), n, ny, nx, occ)
         return occ
 
+    def sparse_eligible(self):
+        """This frame's canvas came from a counting LiDAR-only scatter (its occupancy bytes are valid): what sparse_first_conv keys on.  Part of
+        every hipGraph key: a capture made on a LiDAR-only frame holds the sparse gather, and must not replay over a frame with camera rows."""
+        return self._occ_info is not None and self._occ_info[0] == self._frame
+
     def sparse_first_conv(self, L, x, n, h, w, out):
         """Conv2d(64, 64, 3, stride 2) + folded BatchNorm + ReLU of block 0 on (rows of) this frame's scattered canvas: the gather over occupied
         taps (av2x_conv3x3s2_sparse).  A rule of the layer and of the frame kind (LiDAR-only, fp32-accurate mode), never of the agent count:
@@ -1281,7 +1348,9 @@ class Where2ComEngine:
             raise ValueError("empty frame: no agent has lidar input")
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         if self.use_graph and trace is None and self.profile is None:
-            key = (tuple(record_len), ny, nx)
+            # the first convolution's class (sparse gather over this frame's occupancy bytes, or the dense kernel: camera rows in the
+            # canvas) is decided per frame in Python and baked into the capture -> part of the key
+            key = (tuple(record_len), ny, nx, self.sparse_eligible())
             ent = self.graphs.get(key)
             if ent is None:
                 # one eager pass allocates every workspace buffer and layout tensor outside the capture
@@ -1511,7 +1580,7 @@ class Where2ComEngine:
         if n == 0:   # nothing to compute; the padding is never read by the fusion
             return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
         body = lambda: self._shard_local_body(canvas, send, n, n_pad, has_ego, ny, nx, record_len, dims, sizes)
-        stats = self._graphed(("shard_local", n, n_pad, bool(has_ego), ny, nx, canvas.data_ptr(), send.data_ptr()), body)
+        stats = self._graphed(("shard_local", n, n_pad, bool(has_ego), ny, nx, canvas.data_ptr(), send.data_ptr(), self.sparse_eligible()), body)
         return send, stats, meta
 
     def _graphed(self, key, body):
@@ -1620,7 +1689,9 @@ class FramePipeline:
     frames gained nothing on top (measured: -0.8 % vs +5 % single-stream)."""
 
     def __init__(self, engine, depth=2):
-        engine.throughput_mode = depth > 1
+        # the pipeline's mode, applied around each of ITS frames (engine.frame_mode): whole frames per GPU -> never the agent-sharded classes;
+        # more than one frame in flight -> throughput mode (engine.wino4_rule).  The caller's engine keeps its own flags for its own calls.
+        self.throughput_mode = depth > 1
         self.engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
         if depth > 3:
             import warnings
@@ -1638,13 +1709,12 @@ class FramePipeline:
         s = self.streams[k]
         s.wait_stream(torch.cuda.current_stream())  # inputs produced on the caller's stream
         eng = self.engines[k]
-        eng.throughput_mode = self.engines[0].throughput_mode      # one mode for every slot: the first engine's (set True by __init__ for depth > 1)
         # "rule" stays on (a frame's bits must not depend on whether it was pipelined); the legacy timing-driven stream-K
         # gains nothing with several frames in flight and is switched off
         legacy = eng.stream_k is True or eng.stream_k == "tune"
         saved, eng.stream_k = eng.stream_k, (eng.stream_k if (not legacy or len(self.engines) == 1 or os.environ.get("AV2X_PIPE_SK") == "1") else False)
         try:
-            with torch.cuda.stream(s):
+            with torch.cuda.stream(s), eng.frame_mode(self.throughput_mode, False):
                 out = eng.forward(data_dict, **kw)
         finally:
             eng.stream_k = saved

@@ -70,6 +70,15 @@ def forward(rois, pts, pts_feature, argmax, pts_idx_of_voxels, pooled_features, 
     if vx.dim() != 5 or pf.dim() != 5:
         raise ValueError("forward: pts_idx_of_voxels (N,ox,oy,oz,max_pts), pooled_features (N,ox,oy,oz,C)")
     n, ox, oy, oz, maxp = (int(v) for v in vx.shape)
+    # every extent the kernels index with comes from the shapes below: a mismatched caller gets an exception, not an out-of-bounds access
+    # (the reference takes boxes_num from rois.size(0), roiaware_pool3d.cpp:41)
+    if r.dim() != 2 or tuple(r.shape) != (n, 7) or p.dim() != 2 or p.shape[1] != 3 or f.dim() != 2 or f.shape[0] != p.shape[0]:
+        raise ValueError(f"forward: rois (N,7), pts (P,3), pts_feature (P,C) with N = {n} (got {tuple(r.shape)}, {tuple(p.shape)}, {tuple(f.shape)})")
+    c = int(f.shape[1])
+    if tuple(pf.shape) != (n, ox, oy, oz, c) or tuple(am.shape) != (n, ox, oy, oz, c):
+        raise ValueError(f"forward: argmax and pooled_features must be ({n},{ox},{oy},{oz},{c}) (got {tuple(am.shape)}, {tuple(pf.shape)})")
+    if maxp < 1 or len({t.device for t in (r, p, f, am, vx, pf)}) != 1:
+        raise ValueError("forward: max_pts >= 1 and every tensor on the same device")
     lib = _lib.load()
     with torch.cuda.device(p.device):
         ws = torch.empty(max(1, int(lib.av2x_roiaware_pool3d_workspace_bytes(n, p.shape[0])) // 4), dtype=torch.int32, device=p.device)
@@ -82,7 +91,15 @@ def backward(pts_idx_of_voxels, argmax, grad_out, grad_in, pool_method):
     """roiaware_pool3d.cpp:65-93: grad_in (P,C) += the gradient of the pooled features (N,ox,oy,oz,C)."""
     vx, am = _i32(pts_idx_of_voxels, "pts_idx_of_voxels", "cuda"), _i32(argmax, "argmax", "cuda")
     go, gi = _f32(grad_out, "grad_out", "cuda"), _f32(grad_in, "grad_in", "cuda")
+    if vx.dim() != 5 or go.dim() != 5 or gi.dim() != 2:
+        raise ValueError("backward: pts_idx_of_voxels (N,ox,oy,oz,max_pts), grad_out (N,ox,oy,oz,C), grad_in (P,C)")
     n, ox, oy, oz, maxp = (int(v) for v in vx.shape)
+    c = int(go.shape[4])
+    if tuple(go.shape) != (n, ox, oy, oz, c) or tuple(am.shape) != (n, ox, oy, oz, c) or gi.shape[1] != c:
+        raise ValueError(f"backward: argmax / grad_out ({n},{ox},{oy},{oz},C) and grad_in (P,C) with one C (got {tuple(am.shape)}, "
+                         f"{tuple(go.shape)}, {tuple(gi.shape)})")
+    if len({t.device for t in (vx, am, go, gi)}) != 1:
+        raise ValueError("backward: every tensor on the same device")
     with torch.cuda.device(go.device):
         _lib.check(_lib.load().av2x_roiaware_pool3d_backward(_p(vx), _p(am), _p(go), n, ox, oy, oz, go.shape[4], maxp, _p(gi), int(pool_method),
                                                              _stream(go)), "av2x_roiaware_pool3d_backward")

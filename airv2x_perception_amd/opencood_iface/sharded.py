@@ -135,14 +135,24 @@ class ShardedFrame:
 class EngineBackend:
     """Adapter: Where2ComEngine as the ShardedFrame backend."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, throughput=None):
         self.engine = engine
+        # the mode of the agent-sharded frame, applied around every stage (engine.frame_mode) instead of being left on the caller's engine:
+        # sharded_frame = the latency-mode Winograd classes on every rank (one or two agents per rank never fill the chip);
+        # throughput = tuner hint only here (bit-identical candidates).  None: the engine's own flag.
+        self.throughput = throughput
+
+    def _mode(self):
+        e = self.engine
+        return e.frame_mode(e.throughput_mode if self.throughput is None else self.throughput, True)
 
     def local_stage(self, data_dict_local, has_ego, **kw):
-        return self.engine.shard_local_stage(data_dict_local, has_ego, **kw)
+        with self._mode():
+            return self.engine.shard_local_stage(data_dict_local, has_ego, **kw)
 
     def ego_stage(self, recv, stats, meta, world, **kw):
-        return self.engine.shard_ego_stage(recv, stats, meta, world, **kw)
+        with self._mode():
+            return self.engine.shard_ego_stage(recv, stats, meta, world, **kw)
 
     def recv_buffer(self, numel, like):
         """The all-gather destination out of the engine's workspace pool (no allocator traffic per frame)."""
@@ -158,10 +168,12 @@ class EngineBackend:
         return fs is None or fs(meta["W"], world, 0) is not None
 
     def ego_partial(self, recv, stats, meta, world, rank):
-        return self.engine.shard_ego_partial(recv, stats, meta, world, rank)
+        with self._mode():
+            return self.engine.shard_ego_partial(recv, stats, meta, world, rank)
 
     def ego_finish(self, parts, ctx, world, **kw):
-        return self.engine.shard_ego_finish(parts, ctx, world, **kw)
+        with self._mode():
+            return self.engine.shard_ego_finish(parts, ctx, world, **kw)
 
 
 class ShardedPipeline:
@@ -190,10 +202,10 @@ class ShardedPipeline:
 
     @classmethod
     def from_engine(cls, engine, depth, group=None, rotate=True):
-        engine.throughput_mode = depth > 1     # tuner hint (bit-identical candidates)
-        engine.sharded_frame = True            # one or two agents per rank: the latency-mode Winograd classes (engine.wino4_rule), every rank alike
+        # depth > 1: tuner hint (bit-identical candidates); sharded_frame: one or two agents per rank -> the latency-mode Winograd classes
+        # (engine.wino4_rule), every rank alike.  Both live on the backends and are applied around each stage: the caller's engine keeps its flags.
         engines = [engine] + [engine.share_weights() for _ in range(depth - 1)]
-        return cls([EngineBackend(e) for e in engines], group, rotate, engine.device)
+        return cls([EngineBackend(e, throughput=depth > 1) for e in engines], group, rotate, engine.device)
 
     def submit(self, data_dict_local, counts=None, **kw):
         """Enqueue one frame; returns (output dict or None, event on the frame's stream or None)."""

@@ -201,8 +201,8 @@ class V2XViTEngine(Where2ComEngine):
                 # ---- x = HGT(LN(x)) + x
                 # PreNorm: the consuming Linears normalise their rows while they load them (engine.conv ln=); what is left of the LayerNorm
                 # launch is the per-token (mean, rstd) pass
-                s1 = self.ln_stats(x, n * hw, C, LN_EPS)
-                ln1 = lambda a, b: (s1[a * hw:b * hw], blk["ln1"][0], blk["ln1"][1], LN_EPS)
+                s1 = self.ln_operand(x, n * hw, C, blk["ln1"][0], blk["ln1"][1], LN_EPS)
+                ln1 = lambda a, b: s1.rows(a * hw, b * hw)
                 if ego_only:
                     self.conv(blk["proj"][types[0]], x[0:1], 1, H, W, proj[0:1], ln=ln1(0, 1))
                     for (a, b, t) in self._groups(types[1:]):
@@ -218,7 +218,7 @@ class V2XViTEngine(Where2ComEngine):
                 if trace is not None:
                     trace[f"hgt{di}"] = x.clone()
                 # ---- x = SplitAttn(window attentions(LN(x))) + x
-                self.conv(blk["qkv3"], x, m, H, W, qkv3, ln=(self.ln_stats(x, m * hw, C, LN_EPS), blk["ln2"][0], blk["ln2"][1], LN_EPS))
+                self.conv(blk["qkv3"], x, m, H, W, qkv3, ln=self.ln_operand(x, m * hw, C, blk["ln2"][0], blk["ln2"][1], LN_EPS))
                 for i, (h, dh, ws) in enumerate(zip(self.pw["heads"], self.pw["dim_head"], self.pw["window_size"])):
                     _lib.check(self.lib.av2x_window_attention(_ptr(qkv3), 2304, 768 * i, _ptr(blk["pos"][i]), _ptr(wat), m, H, W,
                                                               h, dh, ws, st()), "av2x_window_attention")
@@ -236,7 +236,7 @@ class V2XViTEngine(Where2ComEngine):
                                                             m, hw, C, st()), "combine")
             # ---- x = FFN(LN(x)) + x
             m = 1 if (self.ego_only_last and di == last and trace is None and n > 1) else n
-            self.conv(ffn["ff1"], x, m, H, W, hid, ln=(self.ln_stats(x, m * hw, C, LN_EPS), ffn["ln"][0], ffn["ln"][1], LN_EPS))
+            self.conv(ffn["ff1"], x, m, H, W, hid, ln=self.ln_operand(x, m * hw, C, ffn["ln"][0], ffn["ln"][1], LN_EPS))
             self.conv(ffn["ff2"], hid, m, H, W, x, residual=x)
             if trace is not None:
                 trace[f"layer{di}"] = x.clone()

@@ -397,7 +397,7 @@ def dry_run(a):
 
 
 SUBCONFIGS = {   # BASELINE.json configs[1..4] beyond the headline, each on ONE GPU (the 8-GPU forms are the driver's to launch)
-    "agents8": (["--agents", "8"], "Where2Comm-LiDAR, 8 agents on one GPU (north_star's agent count)", None),
+    "agents8": (["--agents", "8"], "Where2Comm-LiDAR, 8 agents on one GPU (north_star's agent count)", "w2c_full_n8"),
     "cobevt_n8": (["--model", "cobevt", "--agents", "8"], "BASELINE.json configs[2] fusion (CoBEVT, N = L = 8) on one GPU", "cobevt_full_n8"),
     "v2xvit_n8": (["--model", "v2xvit", "--agents", "8"], "BASELINE.json configs[3] model in the fp32-accurate mode", "v2xvit_full_n8"),
     "v2xvit_n8_amp": (["--model", "v2xvit", "--agents", "8", "--amp"], "BASELINE.json configs[3]: V2X-ViT, bf16 (autocast semantics)", None),
@@ -412,12 +412,15 @@ def golden_parity(name, dev):
     oracle's voxelizer exactly as the fixture's were."""
     from oracle import voxelize_oracle as vox
     from airv2x_perception_amd import synth
-    from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT, Airv2xV2XVit
+    from airv2x_perception_amd.opencood_iface import Airv2xCoBEVT, Airv2xV2XVit, Airv2xWhere2com
     fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", name + ".npz"), allow_pickle=False))
     rng = [float(v) for v in fx["lidar_range"]]
     types = [str(t) for t in fx["types"]]
-    mc = tuple(int(v) for v in fx["max_cav"])
-    if name.startswith("cobevt"):
+    mc = tuple(int(v) for v in fx["max_cav"]) if "max_cav" in fx else None
+    if name.startswith("w2c"):
+        hy = synth.default_hypes(rng)
+        spec, cls = synth.where2com_param_spec(hy["model"]["args"]), Airv2xWhere2com
+    elif name.startswith("cobevt"):
         hy = synth.default_hypes_cobevt(rng, mc, compression=int(fx["compression"]) if "compression" in fx else 0)
         spec, cls = synth.cobevt_param_spec(hy["model"]["args"]), Airv2xCoBEVT
     else:
@@ -436,10 +439,13 @@ def golden_parity(name, dev):
     model = model.to(dev).eval()
     out = model(dd)
     torch.cuda.synchronize()
-    hs = int(fx["head_stride"]) if "head_stride" in fx else 1
+    hs = int(fx["head_stride"]) if "head_stride" in fx else (int(fx["sample_stride"]) if "sample_stride" in fx else 1)
     err = {k: float(np.abs(out[k].cpu().numpy()[..., ::hs, ::hs] - fx[k]).max()) for k in ("psm", "rm", "obj")}
+    extra = {}
+    if name.startswith("w2c"):     # integer bookkeeping of the same frame: non-zero canvas elements (exact), communication rate
+        extra = {"comm_rate_equal": int(out["comm_rate"]) == int(fx["comm_rate"]), "com_abs_diff": abs(float(out["com"]) - float(fx["com"]))}
     return {"fixture": f"tests/golden/{name}.npz", "agents": len(types), "head_stride": hs, "max_abs_err": err,
-            "max_abs_ref": {k: float(np.abs(fx[k]).max()) for k in ("psm", "rm", "obj")}}
+            "max_abs_ref": {k: float(np.abs(fx[k]).max()) for k in ("psm", "rm", "obj")}, **extra}
 
 
 def main(argv=None, hooks=None, device=None, quiet=False):
@@ -488,6 +494,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
     from airv2x_perception_amd import synth
 
     res_extra = {}
+    pipe = None
     if a.mode == "shard":
         hooks = hooks or GpuShardHooks(a, dev)
         a.cpu_frames = 0
@@ -511,7 +518,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
             if isinstance(hooks, GpuShardHooks):
                 _, _, ddr, _, _ = build_inputs(a.agents, a.points, dev, only=None, model=a.model, modalities=a.mods)
                 from airv2x_perception_amd.opencood_iface.engine import FramePipeline
-                hooks.eng.sharded_frame = False      # whole frames per GPU from here on: the throughput-mode classes apply (engine.wino4_rule)
+                # whole frames per GPU from here on: FramePipeline runs its frames in throughput mode, never the agent-sharded classes (engine.frame_mode)
                 hooks.model(ddr)
                 rp = FramePipeline(hooks.eng, max(1, a.inflight))
                 for _ in range(max(1, a.inflight)):
@@ -535,6 +542,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
             a.cpu_frames = 0
         model, eng, sd = make_model(a, args, dev)
         eng.use_graph = bool(a.graph)
+        pipe = None
         if a.inflight > 1:
             from airv2x_perception_amd.opencood_iface.engine import FramePipeline
             model(dd)  # weights packed, tiles tuned
@@ -604,7 +612,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                    "launch": "hipGraph replay" if (eng is not None and eng.graph_active()) else "eager",
                    "frames_in_flight": inflight_used,
                    "engine_mode": ("throughput (frames in flight: the 128- / 256-channel backbone layers on the Winograd F(4x4,3x3) class too, "
-                                   "engine.wino4_rule; same goldens, same tolerances)" if (eng is not None and a.mode == "replica" and eng.throughput_mode and inflight_used > 1)
+                                   "engine.wino4_rule; same goldens, same tolerances)" if (eng is not None and a.mode == "replica" and pipe is not None and pipe.throughput_mode and inflight_used > 1)
                                    else "latency-mode kernel classes (agent-sharded frame: one or two agents per rank)" if a.mode == "shard"
                                    else "latency (one frame at a time)")},
         **res_extra,
@@ -645,8 +653,8 @@ def main(argv=None, hooks=None, device=None, quiet=False):
         eng.wino_x3 = eng.x3p = False
 
     # ---------------- the same frames in the OTHER product mode (x3 headline: the fp32-input MFMA kernels; f32 headline: x3): beside the headline
-    if secondary and a.inflight > 1:
-        eng.throughput_mode = True    # the pipelined secondary legs below
+    # (the pipelined legs below run in the PIPELINE's mode -- FramePipeline scopes throughput mode to its own frames, engine.frame_mode --;
+    # direct model(dd) calls stay in the engine's latency mode)
     if secondary and a.model == "where2com" and a.lidar_only and a.gemm in ("f32", "x3") and not a.amp and a.inflight > 1:
         other_x3 = a.gemm == "f32"
         for e in pipe.engines:
@@ -696,7 +704,6 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                                    "note": "model + av2x_postprocess per frame, one 20-byte host read-back of the counts"}
 
         if a.inflight > 1:   # the same with the frames (and their post-process) kept in flight; boxes are read one lap later
-            eng.throughput_mode = True
             for _ in range(a.inflight):
                 pipe.submit(dd)
             pipe.drain()
@@ -753,7 +760,6 @@ def main(argv=None, hooks=None, device=None, quiet=False):
         ndt = (time.perf_counter() - t0) / a.steps
         res["from_points"]["device_counts"] = {"frames_per_s": round(1.0 / ndt, 2), "ms_per_step": round(ndt * 1e3, 3)}
         if a.inflight > 1:
-            eng.throughput_mode = True
             for _ in range(a.inflight):
                 pipe.submit(ddp)
             pipe.drain()
@@ -1019,9 +1025,7 @@ def main(argv=None, hooks=None, device=None, quiet=False):
                     cfgs[name]["max_abs_err_vs_reference_golden"] = golden_parity(fixture, dev)
                 else:
                     cfgs[name]["max_abs_err_vs_oracle"] = None
-                    cfgs[name]["parity_note"] = {"agents8": "the 8-agent oracle frame is ~6 s of CPU per frame; parity of this model is the headline's "
-                                                            "parity_max_abs_err_vs_oracle (4 agents) + tests/test_gpu_forward.py",
-                                                 "v2xvit_n8_amp": "autocast drift vs the fp32-accurate path: tests/test_amp.py, AP-level: tests/test_gpu_amp_ap.py",
+                    cfgs[name]["parity_note"] = {"v2xvit_n8_amp": "autocast drift vs the fp32-accurate path: tests/test_amp.py, AP-level: tests/test_gpu_amp_ap.py",
                                                  "cam_lidar_n8": "the 8-agent camera + LiDAR oracle frame is ~25 s of CPU; tests/test_camera.py holds this "
                                                                  "configuration to the reference's own fixture w2c_cam_full_n8"}[name]
             except Exception as e:      # a failed leg must not take the headline line with it

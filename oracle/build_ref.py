@@ -90,7 +90,7 @@ def build_box_overlaps(force=False):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("gcc failed on the generated box_overlaps.c:\n" + r.stdout[-3000:])
-    os.unlink(c_file)      # the generated C embeds the .pyx text as comments: only the compiled module is kept (and travels with gpurun)
+    os.unlink(c_file)      # the generated C embeds the .pyx text as comments: only the compiled module is kept, in this container only (oracle/_ref is git- and gpurun-ignored)
     return out
 
 

@@ -41,7 +41,7 @@ def _mask_ok(got, ref, cmap, what):
 
 # "+T": the engine in throughput mode (what FramePipeline / the headline's three frames in flight run: the 128- and 256-channel backbone
 # layers on the F(4x4,3x3) class, engine.wino4_rule) against the same goldens at the same tolerances
-@pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_small_n1", "w2c_full_n2", "w2c_full_n4", "w2c_full_n2+T", "w2c_full_n4+T"])   # full_n2: BASELINE configs[0]
+@pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_small_n1", "w2c_full_n2", "w2c_full_n4", "w2c_full_n8", "w2c_full_n2+T", "w2c_full_n4+T", "w2c_full_n8+T"])   # full_n2: BASELINE configs[0]; full_n8: north_star's target workload (8 agents)
 def test_forward_matches_reference_golden(name):
     throughput = name.endswith("+T")
     name = name[:-2] if throughput else name
@@ -295,8 +295,12 @@ def test_default_forward_does_not_depend_on_the_tuning_outcome(name, mode, monke
             # FramePipeline puts the engine in throughput mode (more layers on the F(4x4,3x3) class at the full grid: engine.wino4_rule):
             # a pipelined frame equals the single-stream frame of the engine in THAT mode, bit for bit
             pipe = FramePipeline(eng, 2)
-            assert eng.throughput_mode
-            want_t = {k: v.clone() for k, v in model(dd).items() if k in ("psm", "rm", "obj")}
+            assert pipe.throughput_mode and not eng.throughput_mode      # the mode belongs to the pipeline's frames, not to the caller's engine
+            with eng.frame_mode(True, False):
+                want_t = {k: v.clone() for k, v in model(dd).items() if k in ("psm", "rm", "obj")}
+            again = model(dd)                                            # ... whose own direct calls keep the bits they had before
+            for k in ("psm", "rm", "obj"):
+                assert torch.equal(again[k], outs[-1][k]), k
             po, ev = pipe.submit(dd)
             ev.synchronize()
             for k in ("psm", "rm", "obj"):

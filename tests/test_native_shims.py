@@ -183,3 +183,16 @@ def test_roiaware_pool3d_empty_and_argument_errors():
     with pytest.raises(RuntimeError, match="1..255"):
         rp.forward(z(1, 7), z(4, 3), z(4, 2), z(1, 256, 1, 1, 2, dt=torch.int32), z(1, 256, 1, 1, 4, dt=torch.int32), z(1, 256, 1, 1, 2), 0)
     assert b"1..255" in _lib.load().av2x_last_error()
+    # mismatched shapes are refused by the shim before any kernel runs (the extents the kernels index with come from these shapes)
+    bad = [
+        lambda: rp.forward(z(2, 7), z(4, 3), z(4, 2), z(1, 2, 2, 2, 2, dt=torch.int32), z(1, 2, 2, 2, 4, dt=torch.int32), z(1, 2, 2, 2, 2), 0),   # rois N
+        lambda: rp.forward(z(1, 7), z(4, 3), z(5, 2), z(1, 2, 2, 2, 2, dt=torch.int32), z(1, 2, 2, 2, 4, dt=torch.int32), z(1, 2, 2, 2, 2), 0),   # feature rows
+        lambda: rp.forward(z(1, 7), z(4, 3), z(4, 2), z(1, 2, 2, 2, 3, dt=torch.int32), z(1, 2, 2, 2, 4, dt=torch.int32), z(1, 2, 2, 2, 2), 0),   # argmax C
+        lambda: rp.forward(z(1, 7), z(4, 3), z(4, 2), z(1, 2, 2, 2, 2, dt=torch.int32), z(1, 2, 2, 2, 4, dt=torch.int32), z(1, 2, 2, 1, 2), 0),   # pooled grid
+        lambda: rp.backward(z(1, 2, 2, 2, 4, dt=torch.int32), z(1, 2, 2, 2, 2, dt=torch.int32), z(1, 2, 2, 2), z(4, 2), 0),                      # grad_out rank
+        lambda: rp.backward(z(1, 2, 2, 2, 4, dt=torch.int32), z(1, 2, 2, 2, 2, dt=torch.int32), z(1, 2, 2, 2, 2), z(4, 3), 0),                   # grad_in C
+        lambda: rp.backward(z(1, 2, 2, 2, 4, dt=torch.int32), z(1, 2, 2, 2, 3, dt=torch.int32), z(1, 2, 2, 2, 2), z(4, 2), 0),                   # argmax C
+    ]
+    for call in bad:
+        with pytest.raises(ValueError):
+            call()

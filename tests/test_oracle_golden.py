@@ -12,7 +12,7 @@ from tests.helpers import assert_close, case_from_fixture, load_fixture, sample
 RTOL, ATOL = 1e-5, 1e-5
 
 
-@pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_small_n1", "w2c_full_n4"])
+@pytest.mark.parametrize("name", ["w2c_small_n3", "w2c_small_n1", "w2c_full_n4", "w2c_full_n8"])
 def test_oracle_matches_reference_golden(name):
     fx = load_fixture(name)
     hy, args, sd, dd, voxd, types = case_from_fixture(fx)

@@ -2394,6 +2394,8 @@ GROUPS = {
                     run_case("w2c_full_n2", None, ["vehicle", "rsu"], 8192, 3, 5, 20),
                     # default AirV2X grid, BASELINE configs[1]: 4 agents x 8192 points; strided samples + sums
                     run_case("w2c_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 0, 5, 20)),
+    # the target workload of BASELINE.json's north_star (>= 30 frames/s at 8 agents): Where2Comm-LiDAR, 8 agents x 8192 points
+    "w2c_n8": lambda: run_case("w2c_full_n8", None, T8, 8192, 4, 5, 20),
     "cobevt": lambda: run_cobevt_case("cobevt_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 0, 8),
     "cobevt_c4": lambda: run_cobevt_case("cobevt_small_n2_c4", SMALL, ["vehicle", "drone"], 700, 2, 8, compression=4),
     "v2xvit": lambda: run_v2xvit_case("v2xvit_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 0, (2, 1, 1), 4),
