@@ -402,6 +402,351 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_x3(const Wino4X3Params p) {
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_wino4_x3_pp: the same arithmetic (bit for bit: every accumulator receives the same six products per chunk in the same order, the
+// transforms and the finalising side are the same expressions) on EIGHT waves -- two per SIMD -- in a ping-pong schedule (round 6).
+//
+// Why.  The four-wave kernel above keeps ONE in-order wave per SIMD: its K loop is a sum, not a maximum, of its matrix time (3 456 cycles
+// per 16-channel chunk) and its vector-memory time (216 KB of B fragments + 74 KB of patch pixels through the CU's 64 B/clk path = 4 530
+// cycles): 7 100 cycles per chunk measured, zero overlap (profiles/r05w_wino4_x3_small_launches.txt), because a wave that blocks on a full
+// memory queue or on the issue latency of its ~11 instructions per MFMA (4.7 cycles each: SQ_ACTIVE_INST_ANY / instructions) leaves the
+// matrix pipe of its SIMD idle.  Two waves per SIMD halve the register budget (256), and 36 positions x 32 tiles x 64 couts of fp32
+// accumulators are 144 registers per wave of eight -- so the two waves of a SIMD must never hold their other big register sets at the same
+// program point.  Hence two ROLES that alternate:
+//   M phase  (matrix)  wave (pg, nb) multiplies its nine positions 9 pg .. 9 pg + 8 of chunk c for its 32-cout block nb: 54 MFMAs, the
+//                      hi / mid / lo split of its A fragments, B fragments from L2 three positions ahead (four register sets);
+//   T phase  (memory)  its threads gather the 6x6 patches of 16 tiles x 16 channels of chunk c + 1 (one channel per thread), apply B^T d B
+//                      and store fp32 V to the other LDS stage; the first three positions' B fragments of the NEXT M phase are requested
+//                      first, so they arrive while the patch is transformed.
+// The halves H0 = waves 0-3 (nb = 0, tiles 0-15 as producers) and H1 = waves 4-7 (nb = 1, tiles 16-31) run the two roles in opposite
+// phases, a workgroup barrier after each:   phase 2c: H0 M(c) | H1 T(c+1)     phase 2c+1: H0 T(c+1) | H1 M(c).
+// Every SIMD then always holds one wave that issues MFMAs and one that issues loads and VALU: matrix beside memory, the pairing that pays
+// (MI355X_MICROARCH.md, "Two waves per SIMD", item 5).  V(c+1) is complete after phase 2c+1; its stage was last read in phase 2c-1.
+// Same V layout, same LDS budget (2 x 76.5 KB), same B and patch bytes per MFMA as the four-wave kernel; the split runs once per (position,
+// cout block) instead of once per position (6 instead of 3 VALU per MFMA), which the second wave's issue slots absorb.
+template <bool GENERAL>
+__global__ __launch_bounds__(512) void conv_wino4_x3_pp(const Wino4X3Params p) {
+    constexpr int TB = 32, NP = 36, NG = 9;
+    constexpr int KQS = TB * 16 + 32;
+    constexpr int POSB = 4 * KQS;
+    constexpr int VSTAGE = NP * POSB;
+    constexpr unsigned OOB = 0xC0000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wv & 3, half = wv >> 2;
+    const int nbk = gridDim.x, b = blockIdx.x;
+    const int q8 = nbk >> 3, r8 = nbk & 7, xcd = b & 7;
+    int mblock, nblock;
+    if (p.xcd_w) {
+        const int G = 8 / p.nblocks;
+        nblock = xcd % p.nblocks;
+        mblock = xcd / p.nblocks + (b >> 3) * G;
+    } else {
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+        mblock = swz / p.nblocks;
+        nblock = swz - mblock * p.nblocks;
+    }
+    const int t0 = mblock * TB;
+    const int n0 = nblock * 64;
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.u), 0, p.u_bytes, 0x00020000);
+
+    // ---- weight side (M role): this wave's 32-cout block is n0 + 32 half
+    const unsigned voffU = (unsigned)(((lane >> 5) * p.CoutP + n0 + 32 * half + (lane & 31)) * 16);
+    const int plane_stride = 32 * p.CoutP;
+    const int kb_stride = 3 * plane_stride, pos_stride = (p.Cin >> 4) * kb_stride;
+    const int ubase = 9 * pg * pos_stride;
+    // [set = position % 3][plane].  A plane's registers are re-loaded with position g + 3's fragment right after the last MFMA of
+    // position g that reads them (lo: step 1, mid: step 4, hi: step 5; the data returns hundreds of cycles after that MFMA has read its
+    // operands): a three-deep ring with a prefetch distance of 13-17 MFMAs (~500-650 cycles, an L2 round trip under load)
+    x3_u32x4 bs[3][3];
+    auto load_b = [&](auto set_c, auto pl_c, int lp, int kb) {
+        constexpr int set = decltype(set_c)::value, pln = decltype(pl_c)::value;
+        bs[set][pln] = __builtin_bit_cast(x3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            ru, voffU, ubase + lp * pos_stride + kb * kb_stride + pln * plane_stride, 0));
+    };
+    // B fragments of positions 0 .. 2 of chunk kb: requested at the head of the T phase that precedes the M phase of that chunk
+    auto bprefetch = [&](int kb) {
+        x3_static_for<0, 9>([&](auto i) {
+            constexpr int ii = decltype(i)::value;
+            load_b(std::integral_constant<int, ii / 3>{}, std::integral_constant<int, ii % 3>{}, ii / 3, kb);
+        });
+    };
+
+    f32x16 acc[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // ---- input side (T role): thread t of the half takes tile 16 half + (t >> 4), channel t & 15 of every chunk
+    const int tq = tid & 255;
+    const int tl = 16 * half + (tq >> 4), ch = tq & 15;
+    const int RSb = p.W * p.in_ctot * 4;
+    unsigned colE[6];
+    unsigned long long rmask[6];
+    {
+        const int t = t0 + tl;
+        const bool tok = t < p.T;
+        const int tt = tok ? t : 0;
+        const int img = tt / p.tiles_per_img, r = tt - img * p.tiles_per_img;
+        const int ty = r / p.TW, tx = r - ty * p.TW;
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+        const int base = (((img * p.H + y0 + 1) * p.W + x0 + 1) * p.in_ctot + p.in_coff + ch) * 4;
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            colE[e] = (tok && (unsigned)(x0 + e) < (unsigned)p.W) ? (unsigned)(base + (e - 1) * p.in_ctot * 4) : OOB;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) rmask[a] = __builtin_amdgcn_ballot_w64((unsigned)(y0 + a) < (unsigned)p.H);
+    }
+    const unsigned oobv = OOB;
+    float d[36];
+    auto gather = [&](auto k_c, int c) {
+        constexpr int k = decltype(k_c)::value, a = k / 6, e = k % 6;
+        unsigned off = colE[e];
+        if constexpr (a == 0)
+            asm volatile("v_sub_u32 %0, %1, %2\n\tv_cndmask_b32 %0, %3, %0, %4" : "=&v"(off) : "v"(colE[e]), "s"(RSb), "v"(oobv), "s"(rmask[0]));
+        else if constexpr (a >= 2)
+            asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(off) : "v"(oobv), "v"(colE[e]), "s"(rmask[a]));
+        d[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, off, (a >= 2 ? (a - 1) * RSb : 0) + c * 64, 0));
+    };
+    W4Tmp tm;
+    auto rows = [&](auto u_c) {      // B^T d: unit u = 3 e + piece, column e of the patch, in place
+        constexpr int u = decltype(u_c)::value, e = u / 3, pc = u % 3;
+        if constexpr (pc == 0)       // the wait for the patch column: HERE
+            asm volatile("" : "+v"(d[e]), "+v"(d[6 + e]), "+v"(d[12 + e]), "+v"(d[18 + e]), "+v"(d[24 + e]), "+v"(d[30 + e]));
+        w4_bt6<pc>(d[e], d[6 + e], d[12 + e], d[18 + e], d[24 + e], d[30 + e], tm);
+    };
+    auto colsx = [&](auto u_c) {     // (B^T d) B: unit u = 3 a + piece, row a, in place
+        constexpr int u = decltype(u_c)::value, a = u / 3, pc = u % 3;
+        w4_bt6<pc>(d[6 * a], d[6 * a + 1], d[6 * a + 2], d[6 * a + 3], d[6 * a + 4], d[6 * a + 5], tm);
+    };
+    const unsigned wbase = (unsigned)((ch >> 2) * KQS + tl * 16 + (ch & 3) * 4);
+    auto vstore = [&](auto o_c, int stage) {
+        constexpr int o = decltype(o_c)::value;
+        *reinterpret_cast<float*>(smem + stage * VSTAGE + o * POSB + wbase) = d[o];
+    };
+    // T phase body: patch of chunk c -> V stage `stage`
+    auto tproduce = [&](int c, int stage) {
+        x3_static_for<0, 36>([&](auto k) { gather(k, c); });
+        __builtin_amdgcn_sched_barrier(0);
+        x3_static_for<0, 18>([&](auto u) { rows(u); });
+        x3_static_for<0, 6>([&](auto a_c) {
+            constexpr int a = decltype(a_c)::value;
+            colsx(std::integral_constant<int, 3 * a>{});
+            colsx(std::integral_constant<int, 3 * a + 1>{});
+            vstore(std::integral_constant<int, 6 * a>{}, stage);          // elements 0 and 5 of the row are complete after piece 1
+            vstore(std::integral_constant<int, 6 * a + 5>{}, stage);
+            colsx(std::integral_constant<int, 3 * a + 2>{});
+            vstore(std::integral_constant<int, 6 * a + 1>{}, stage);
+            vstore(std::integral_constant<int, 6 * a + 2>{}, stage);
+            vstore(std::integral_constant<int, 6 * a + 3>{}, stage);
+            vstore(std::integral_constant<int, 6 * a + 4>{}, stage);
+        });
+    };
+
+    // ---- A fragments (M role): lane (i = lane & 31, kh = lane >> 5) reads k quads 2 kh, 2 kh + 1 of tile i of its positions
+    const unsigned rbase = (unsigned)((2 * (lane >> 5)) * KQS + (lane & 31) * 16) + 9 * pg * POSB;
+    x3_f32x2 raw[4];
+    // split planes of the current / next position: hi and mid double-buffered; lo is read by the FIRST product of a position only
+    // (x3_ap(0) == 2), and the split writes the next position's lo plane from its step 4 on (MFMA step 2): one buffer
+    unsigned plh[2][4], plm[2][4], pll[4];
+    X3Split sp;
+    auto split = [&](auto j_c, auto nxt_c) {      // x3_split_step<J> with the three planes held separately
+        constexpr int J = decltype(j_c)::value, NX = decltype(nxt_c)::value;
+        constexpr int ua = x3_sa(J), up = x3_sp(J), qf = x3_sf(J);
+        unsigned w = 0;
+        if constexpr (ua >= 0) {
+            constexpr int q = 2 * (ua >> 2) + (ua & 1), ph = (ua >> 1) & 1;
+            const x3_f32x2 src = ph == 0 ? raw[q] : sp.r[q & 1];
+            w = __builtin_bit_cast(unsigned, __builtin_convertvector(src, x3_bf16x2));
+            if constexpr (ph == 0) plh[NX][q] = w;
+            else plm[NX][q] = w;
+        }
+        if constexpr (up >= 0) {
+            constexpr int q = 2 * (up >> 2) + (up & 1), ph = (up >> 1) & 1;
+            sp.r[q & 1] = x3_pk_sub(ph == 0 ? raw[q] : sp.r[q & 1], sp.hf[up & 1]);
+        }
+        if constexpr (ua >= 0) {
+            sp.hf[ua & 1].x = __builtin_bit_cast(float, w << 16);
+            sp.hf[ua & 1].y = __builtin_bit_cast(float, w & 0xffff0000u);
+        }
+        if constexpr (qf >= 0) pll[qf] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp.r[qf & 1], x3_bf16x2));
+    };
+    auto read_a = [&](auto half_c, int lp, int stage) {
+        constexpr int hf = decltype(half_c)::value;
+        const x3_pair2 v = __builtin_bit_cast(x3_pair2, *reinterpret_cast<const f32x4*>(smem + stage * VSTAGE + rbase + lp * POSB + hf * KQS));
+        raw[2 * hf] = v.a; raw[2 * hf + 1] = v.b;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // head of an M phase: fragment 0 split, fragment 1 read
+    auto mhead = [&](int stage) {
+        read_a(I0{}, 0, stage);
+        read_a(I1{}, 0, stage);
+        x3_static_for<0, 12>([&](auto jj) { split(jj, I0{}); });
+        read_a(I0{}, 1, stage);
+        read_a(I1{}, 1, stage);
+    };
+    // M phase body: 9 groups (positions) x 6 MFMAs on chunk c; B fragments of positions 0 .. 2 are in sets 0 .. 2 (bprefetch)
+    auto mphase = [&](int c, int stage) {
+        x3_static_for<0, 6 * NG>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            constexpr int g = s / 6, j = s % 6, cur = g & 1, nxt = cur ^ 1;
+            constexpr int ap = x3_ap(j), bp = x3_bp(j);
+            if constexpr (ap == 0) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(plh[cur]), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[g], 0, 0, 0);
+            else if constexpr (ap == 1) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(plm[cur]), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[g], 0, 0, 0);
+            else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(pll), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[g], 0, 0, 0);
+            if constexpr (g + 1 < NG) {      // split of the next position's A fragment: two of its twelve steps per MFMA
+                split(std::integral_constant<int, 2 * j>{}, std::integral_constant<int, nxt>{});
+                split(std::integral_constant<int, 2 * j + 1>{}, std::integral_constant<int, nxt>{});
+            }
+            if constexpr (g + 2 < NG && j == 2) read_a(I0{}, g + 2, stage);   // each half right after the split's last read of it
+            if constexpr (g + 2 < NG && j == 4) read_a(I1{}, g + 2, stage);
+            // B fragments three positions ahead into the plane this step has read for the last time (x3_bp: lo at 1, mid at 4, hi at 5)
+            if constexpr (g + 3 < NG && (j == 1 || j == 4 || j == 5))
+                load_b(std::integral_constant<int, g % 3>{}, std::integral_constant<int, (j == 1 ? 2 : j == 4 ? 1 : 0)>{}, g + 3, c);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // ---- prologue: V(0) by both halves; then the two halves run their roles in opposite phases
+    if (half == 0) bprefetch(0);
+    tproduce(0, 0);
+    x3_lds_barrier();
+    if (half == 0) {
+        for (int c = 0; c < p.chunks; ++c) {
+            mhead(c & 1);
+            mphase(c, c & 1);
+            x3_lds_barrier();
+            if (c + 1 < p.chunks) {
+                bprefetch(c + 1);
+                tproduce(c + 1, (c + 1) & 1);
+            }
+            x3_lds_barrier();
+        }
+    } else {
+        for (int c = 0; c < p.chunks; ++c) {
+            bprefetch(c);
+            if (c + 1 < p.chunks) tproduce(c + 1, (c + 1) & 1);
+            mhead(c & 1);                 // V(c) has been complete since the previous barrier: no wait at the head of this half's M phase
+            x3_lds_barrier();
+            mphase(c, c & 1);
+            x3_lds_barrier();
+        }
+    }
+
+    // ---- output transform through LDS in two passes of 16 TILES each (accumulator registers 8 pass .. 8 pass + 7 of every M tile = tiles
+    // 16 pass .. 16 pass + 15, both cout blocks): every wave dumps half of its accumulators per pass, so at most 72 of them are live while
+    // the finalising side runs, and all 512 threads finalise in both passes: thread (cout quad q8, half-wave kh, register rr, cout block nbq)
+    // of half h takes output rows 2 h, 2 h + 1 of its (tile, cout quad) item.  Y = A^T M A in the four-wave kernel's order: same bits.
+    float* X = reinterpret_cast<float*>(smem);     // [pos 36][rr 8][cout block 2][lane 64]
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const int opix = p.out_ctot * 4;
+    const bool relu1 = p.relu == 1;
+    const int cq = tq & 7, kh = (tq >> 3) & 1, rr = (tq >> 4) & 7, nbq = tq >> 7;
+    const int n = n0 + nbq * 32 + cq * 4;
+    const bool nok = n < p.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (nok) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    }
+    const unsigned ocol = (unsigned)((p.out_coff + n) * 4);
+    const float* xq = X + (rr * 2 + nbq) * 64 + kh * 32 + cq * 4;
+    x3_static_for<0, 2>([&](auto ps_c) {
+        constexpr int ps = decltype(ps_c)::value;
+        if constexpr (ps == 1) __syncthreads();      // the previous pass's exchange has been read
+        x3_static_for<0, 9>([&](auto lp_c) {
+            constexpr int lp = decltype(lp_c)::value;
+            float* xp = X + (((9 * pg + lp) * 8) * 2 + half) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xp[r * 128] = acc[lp][8 * ps + r];
+        });
+        __syncthreads();
+        // register 8 ps + rr of an accumulator tile is tile (rr & 3) + 8 ((8 ps + rr) >> 2) + 4 kh of the block
+        const int t = t0 + (rr & 3) + 8 * (2 * ps + (rr >> 2)) + 4 * kh;
+        const int img = t / p.tiles_per_img;
+        const int ty = (t - img * p.tiles_per_img) / p.TW;
+        const int tx = t - img * p.tiles_per_img - ty * p.TW;
+        const bool tvalid = nok && t < p.T;
+        const int py = 4 * ty, px = 4 * tx;
+        const unsigned pix = (unsigned)(((img * p.H + py) * p.W + px) * opix) + ocol;
+        bool colok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colok[e] = tvalid && px + e < p.W;
+        auto fin = [&](auto ah_c) {
+            constexpr int AH = decltype(ah_c)::value;
+            f32x4 z[2][6];
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                f32x4 m[6];
+#pragma unroll
+                for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(xq + (xi * 6 + nu) * 1024);
+                const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                if constexpr (AH == 0) {
+                    z[0][nu] = (m[0] + s12) + s34;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[1][nu][e] = fmaf(2.f, d34[e], d12[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        z[0][nu][e] = fmaf(4.f, s34[e], s12[e]);
+                        z[1][nu][e] = fmaf(8.f, d34[e], d12[e]) + m[5][e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int al = 0; al < 2; ++al) {
+                const int a = 2 * AH + al;
+                const f32x4 s12 = z[al][1] + z[al][2], d12 = z[al][1] - z[al][2], s34 = z[al][3] + z[al][4], d34 = z[al][3] - z[al][4];
+                f32x4 y[4];
+                y[0] = (z[al][0] + s12) + s34;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    y[1][c] = fmaf(2.f, d34[c], d12[c]);
+                    y[2][c] = fmaf(4.f, s34[c], s12[c]);
+                    y[3][c] = fmaf(8.f, d34[c], d12[c]) + z[al][5][c];
+                }
+                const bool rowok = py + a < p.H;
+                const unsigned rowoff = pix + (unsigned)(a * p.W * opix);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned off = (rowok && colok[e]) ? rowoff + (unsigned)(e * opix) : 0x80000000u;
+                    f32x4 v;
+                    f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+                    if (GENERAL) {
+                        if (p.res && off < 0x80000000u) {
+                            const size_t m_ = (size_t)(off - ocol) / (size_t)opix;
+                            rs = *reinterpret_cast<const f32x4*>(p.relu == 4 ? p.res + m_ * p.Cout + n : p.res + m_ * p.out_ctot + p.out_coff + n);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float u = fmaf(y[e][c], sc[c], sh[c]);
+                        if (GENERAL) {
+                            if (p.relu == 1) u = fmaxf(u, 0.f);
+                            else if (p.relu == 3) u = 1.0f / (1.0f + expf(-u));
+                            else if (p.relu == 4) u = tanhf(u);
+                            if (p.res && off < 0x80000000u) u = (p.relu == 4) ? u * rs[c] : u + rs[c];
+                            if (p.relu == 5) u = fmaxf(u, 0.f);
+                        } else {
+                            u = relu1 ? fmaxf(u, 0.f) : u;
+                        }
+                        v[c] = u;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(x3_u32x4, v), rout, off, 0, 0);
+                }
+            }
+        };
+        if (half == 0) fin(I0{});
+        else fin(I1{});
+    });
+}
+
 // U = G g G^T per (cin, cout) in fp64, split into hi / mid / lo bf16 (round to nearest even at every step):
 // w packed [tap][cin/4][coutp][4] fp32  ->  u [pos 36][cin/16][plane][k half][coutp][8] bf16
 __global__ void wino4_x3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ u, int cin, int coutp) {
@@ -477,6 +822,21 @@ int wino4_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, c
     p.xcd_w = (!xcd_off && p.nblocks > 1 && 8 % p.nblocks == 0 && u_bytes * (unsigned long long)(8 - 8 / p.nblocks) > in_bytes * (unsigned long long)(p.nblocks - 1)) ? 1 : 0;
     const size_t lds = 2ull * 36 * 4 * (32 * 16 + 32);
     const bool general = p.res || (p.relu != 0 && p.relu != 1);
+    // round 6: the eight-wave ping-pong form (same bits; AV2X_W4X3_PP=0 restores the four-wave kernel)
+    // (read per launch, ~0.1 us: tests/test_gpu_wino4_x3.py flips it inside one process to compare the two kernels bit for bit)
+    const char* ppe = getenv("AV2X_W4X3_PP");
+    const bool pp = !(ppe && ppe[0] == '0');
+    if (pp) {
+        static LdsLimit lim_ps, lim_pg;
+        if (general) {
+            lim_pg.ensure(reinterpret_cast<const void*>(&conv_wino4_x3_pp<true>), lds);
+            hipLaunchKernelGGL((conv_wino4_x3_pp<true>), dim3(mblocks * p.nblocks), dim3(512), lds, st, p);
+        } else {
+            lim_ps.ensure(reinterpret_cast<const void*>(&conv_wino4_x3_pp<false>), lds);
+            hipLaunchKernelGGL((conv_wino4_x3_pp<false>), dim3(mblocks * p.nblocks), dim3(512), lds, st, p);
+        }
+        return check_launch("conv_wino4_x3_pp");
+    }
     static LdsLimit lim_s, lim_g;
     if (general) {
         lim_g.ensure(reinterpret_cast<const void*>(&conv_wino4_x3<true>), lds);

@@ -92,6 +92,9 @@ class ShardedFrame:
                 data_dict_local["shard_agent_offset"] = sum(counts[:self.rank])
         lkw = {} if n_pad is None else {"n_pad": n_pad}
         send, stats, meta = self.backend.local_stage(data_dict_local, has_ego=(self.rank == 0), **lkw)
+        # what this rank puts on the wire for this frame (bench.py prints it next to --dry-run's prediction)
+        self.last_exchange = {"message_bytes": int(send.numel() * send.element_size()), "message_dtype": str(send.dtype).replace("torch.", ""),
+                              "world": self.world, "backend": (dist.get_backend(self.group) if dist.is_initialized() else None)}
         if counts is not None:
             meta = dict(meta, counts=counts, n_pad=n_pad)
         two_level = (self.world > 1 and getattr(self.backend, "two_level", False)
@@ -108,6 +111,7 @@ class ShardedFrame:
                 rb = getattr(self.backend, "recv_buffer", None)
                 recv = rb(self.world * send.numel(), send) if rb is not None else \
                     torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
+            self.last_exchange["collective"] = "gather to the fusion rank"
             dist.gather(send, list(recv.view(self.world, -1).unbind(0)) if recv is not None else None, dst=dst, group=self.group)
             dist.reduce(stats, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
         else:
@@ -116,6 +120,7 @@ class ShardedFrame:
                 torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
             # the feature-sharing step: every rank contributes 15.77 MB per agent (default grid);
             # xGMI is point-to-point, so the 7 peer transfers into each GPU run on separate links
+            self.last_exchange["collective"] = "all_gather_into_tensor"
             dist.all_gather_into_tensor(recv, send, group=self.group)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
         if two_level:
@@ -124,6 +129,7 @@ class ShardedFrame:
             # second level: every rank runs the fusion on ITS share of the map and the (small) head outputs are
             # gathered, instead of every rank repeating the whole fusion
             part, ctx = self.backend.ego_partial(recv, stats, meta, self.world, self.rank)
+            self.last_exchange["second_level_bytes"] = int(part.numel() * part.element_size())
             parts = torch.empty(self.world * part.numel(), dtype=part.dtype, device=part.device)
             dist.all_gather_into_tensor(parts, part, group=self.group)
             return self.backend.ego_finish(parts, ctx, self.world, **kw)

@@ -114,6 +114,42 @@ def test_results_are_run_to_run_identical_and_independent_of_the_launch_size(lib
         assert torch.equal(one[0], full[i]), i
 
 
+@pytest.mark.parametrize("case", CASES + [(3, 50, 176, 128, 128, 1), (4, 25, 88, 256, 256, 1), (1, 7, 6, 128, 64, 0)])
+@pytest.mark.parametrize("act,with_res", [(None, False), (5, True), (4, True)])
+def test_pingpong_form_equals_the_four_wave_form_bit_for_bit(lib, case, act, with_res, monkeypatch):
+    """conv_wino4_x3_pp (round 6: eight waves, two per SIMD, M / T roles in opposite phases -- the library's default) against
+    conv_wino4_x3 (four waves; AV2X_W4X3_PP=0): the same six products per accumulator and chunk in the same order, the same transforms,
+    the same finalising expressions -> torch.equal, on every shape class (full blocks, ragged edges, tiles beyond the last one, one- and
+    four-cout-block layers, slices) and in the plain and the GENERAL epilogue."""
+    n, h, w, cin, cout, relu = case
+    relu = relu if act is None else act
+    g = torch.Generator().manual_seed(4242 + cin + 3 * cout + h * w + relu)
+    x = (torch.randn(n, h, w, cin + 32, generator=g) * torch.exp(torch.randn(n, h, w, cin + 32, generator=g))).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+    res = torch.rand(n, h, w, cout, generator=g).cuda() if with_res else None     # relu 4: the gate operand is a dense (pixels, cout) tensor
+    _, u43, coutp = _pack(lib, wt)
+    outs = []
+    for pp in ("1", "0"):
+        monkeypatch.setenv("AV2X_W4X3_PP", pp)
+        out = torch.full((n, h, w, cout + 64), float("nan"), device="cuda")
+        if relu == 4:       # tanh(z) * gate: the gate is read as (pixels, cout) whatever the output slice
+            out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+            _run(lib, x, u43, scale, shift, res, out, W4_X3, relu, cin, cout, coutp, in_ctot=cin + 32, in_coff=32)
+            outs.append(out)
+        else:
+            if res is not None:
+                rs = torch.zeros(n, h, w, cout + 64, device="cuda")
+                rs[..., 64:] = res
+            _run(lib, x, u43, scale, shift, rs if res is not None else None, out, W4_X3, relu, cin, cout, coutp, in_ctot=cin + 32, in_coff=32,
+                 out_ctot=cout + 64, out_coff=64)
+            assert torch.isnan(out[..., :64]).all()                       # the other channels of the concat buffer are not touched
+            outs.append(out[..., 64:].contiguous())
+        torch.cuda.synchronize()
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("act,with_res", [(1, True), (3, True), (4, True), (5, True), (0, False)])
 def test_epilogues_and_residual(lib, act, with_res):
     n, h, w, cin, cout = 1, 13, 18, 256, 128

@@ -30,17 +30,24 @@ int main(int argc, char** argv) {
     d.tile = 0x60000400 | (32 << 16) | 64;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i)
-        if (av2x::wino4_x3_dispatch(&d, in, u, nullptr, shift, nullptr, out, nullptr)) { printf("launch failed: %s\n", av2x_last_error()); return 1; }
-    hipDeviceSynchronize();
-    const int iters = 20;
-    hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) av2x::wino4_x3_dispatch(&d, in, u, nullptr, shift, nullptr, out, nullptr);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    const double flops = 2.0 * n * h * w * cout * 9 * cin;
-    printf("ablate=%d n=%d %dx%d %d->%d: %.1f us  (%.1f TF bf16 executed)\n", AV2X_W4X3_ABLATE, n, h, w, cin, cout, ms * 1e3 / iters, flops * 0.25 * 6 / (ms * 1e-3 / iters) / 1e12);
+    // both forms of the kernel (AV2X_W4X3_PP is read per launch): 0 = four waves, one per SIMD; 1 = eight waves, ping-pong (round 6).
+    // The K-loop ablation macros apply to the four-wave form only.
+    for (int pp = 0; pp < 2; ++pp) {
+        setenv("AV2X_W4X3_PP", pp ? "1" : "0", 1);
+        if (pp && AV2X_W4X3_ABLATE) break;
+        for (int i = 0; i < 3; ++i)
+            if (av2x::wino4_x3_dispatch(&d, in, u, nullptr, shift, nullptr, out, nullptr)) { printf("launch failed: %s\n", av2x_last_error()); return 1; }
+        hipDeviceSynchronize();
+        const int iters = 20;
+        hipEventRecord(e0);
+        for (int i = 0; i < iters; ++i) av2x::wino4_x3_dispatch(&d, in, u, nullptr, shift, nullptr, out, nullptr);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = 2.0 * n * h * w * cout * 9 * cin;
+        printf("ablate=%d pp=%d n=%d %dx%d %d->%d: %.1f us  (%.1f TF bf16 executed)\n", AV2X_W4X3_ABLATE, pp, n, h, w, cin, cout, ms * 1e3 / iters,
+               flops * 0.25 * 6 / (ms * 1e-3 / iters) / 1e12);
+    }
     return 0;
 }
