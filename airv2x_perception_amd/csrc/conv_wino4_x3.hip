@@ -43,6 +43,13 @@
 #define AV2X_W4X3_BULK 0
 #endif
 
+// timing experiments on the ping-pong form (tools/micro/w4x3_ablate.hip -DAV2X_W4PP_ABLATE=..): 1 consecutive MFMAs go to ALTERNATING
+// accumulators (wrong sums: is the chain of six dependent MFMAs per position the M phase's length?), 2 no T-phase work (gathers,
+// transforms, LDS stores), 4 no MFMAs, 8 no split.  0 in the library.
+#ifndef AV2X_W4PP_ABLATE
+#define AV2X_W4PP_ABLATE 0
+#endif
+
 namespace {
 
 struct Wino4X3Params {
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(512) void conv_wino4_x3_pp(const Wino4X3Params p) {
     };
     // T phase body: patch of chunk c -> V stage `stage`
     auto tproduce = [&](int c, int stage) {
+        if constexpr ((AV2X_W4PP_ABLATE & 2) != 0) return;
         x3_static_for<0, 36>([&](auto k) { gather(k, c); });
         __builtin_amdgcn_sched_barrier(0);
         x3_static_for<0, 18>([&](auto u) { rows(u); });
@@ -597,10 +605,12 @@ __global__ __launch_bounds__(512) void conv_wino4_x3_pp(const Wino4X3Params p) {
             constexpr int s = decltype(ss)::value;
             constexpr int g = s / 6, j = s % 6, cur = g & 1, nxt = cur ^ 1;
             constexpr int ap = x3_ap(j), bp = x3_bp(j);
-            if constexpr (ap == 0) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(plh[cur]), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[g], 0, 0, 0);
-            else if constexpr (ap == 1) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(plm[cur]), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[g], 0, 0, 0);
-            else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(pll), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[g], 0, 0, 0);
-            if constexpr (g + 1 < NG) {      // split of the next position's A fragment: two of its twelve steps per MFMA
+            constexpr int AG = (AV2X_W4PP_ABLATE & 1) ? (g + (j & 1)) % NG : g;
+            if constexpr ((AV2X_W4PP_ABLATE & 4) != 0) {
+            } else if constexpr (ap == 0) acc[AG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(plh[cur]), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[AG], 0, 0, 0);
+            else if constexpr (ap == 1) acc[AG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(plm[cur]), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[AG], 0, 0, 0);
+            else acc[AG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_frag(pll), __builtin_bit_cast(x3_bf16x8, bs[g % 3][bp]), acc[AG], 0, 0, 0);
+            if constexpr (g + 1 < NG && !(AV2X_W4PP_ABLATE & 8)) {      // split of the next position's A fragment: two of its twelve steps per MFMA
                 split(std::integral_constant<int, 2 * j>{}, std::integral_constant<int, nxt>{});
                 split(std::integral_constant<int, 2 * j + 1>{}, std::integral_constant<int, nxt>{});
             }
@@ -822,10 +832,11 @@ int wino4_x3_dispatch(const av2x_conv_desc* d, const float* in, const void* u, c
     p.xcd_w = (!xcd_off && p.nblocks > 1 && 8 % p.nblocks == 0 && u_bytes * (unsigned long long)(8 - 8 / p.nblocks) > in_bytes * (unsigned long long)(p.nblocks - 1)) ? 1 : 0;
     const size_t lds = 2ull * 36 * 4 * (32 * 16 + 32);
     const bool general = p.res || (p.relu != 0 && p.relu != 1);
-    // round 6: the eight-wave ping-pong form (same bits; AV2X_W4X3_PP=0 restores the four-wave kernel)
+    // round 6: the eight-wave ping-pong form, OPT-IN (AV2X_W4X3_PP=1): same bits, measured SLOWER than the four-wave kernel on every launch
+    // class (profiles/r06_wino4_pp.txt: 82.9 vs 64.5 us at 4 x 25 x 88, 470.7 vs 426.8 us at 4 x 100 x 352, headline 474 vs 531 frames/s)
     // (read per launch, ~0.1 us: tests/test_gpu_wino4_x3.py flips it inside one process to compare the two kernels bit for bit)
     const char* ppe = getenv("AV2X_W4X3_PP");
-    const bool pp = !(ppe && ppe[0] == '0');
+    const bool pp = ppe && ppe[0] == '1';
     if (pp) {
         static LdsLimit lim_ps, lim_pg;
         if (general) {
