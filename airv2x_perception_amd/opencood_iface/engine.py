@@ -285,10 +285,13 @@ class Where2ComEngine:
                                       "YAML has them); the stand-alone BaseBEVBackbone module runs them")
         self.sh = args["modality_fusion"]["shrink_header"]
         self.fcfg = args["where2com_fusion"]
-        if not self.fcfg["multi_scale"]:
-            raise NotImplementedError("only the multi_scale Where2comm variant (the shipped AirV2X config) is built")
-        if args["modality_fusion"].get("compression", 0):
-            raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+        # multi_scale: false = the single-scale branch (where2comm_fuse.py:264-286, airv2x_where2com.py:163-166): the shrunk (and, with
+        # a compressor, compressed + decompressed) 256-channel map is masked and fused once, the heads read the fused map directly
+        self.multi_scale = bool(self.fcfg["multi_scale"])
+        # NaiveCompressor (airv2x_where2com.py:50-52): switched on by modality_fusion.compression > 0, ratio from the TOP-LEVEL
+        # ``compression`` key -- a KeyError when only the first is given, in the reference (:52) and here alike
+        from ..synth import model_compression
+        self.compression = model_compression(args)
 
     FUSION_WEIGHTS = ()   # attribute names of the packed fusion weights a subclass loads in _load_fusion
     compressor = None     # NaiveCompressor layers (CoBEVT: args["compression"]; V2X-ViT / When2com: synth.model_compression), else None
@@ -323,7 +326,7 @@ class Where2ComEngine:
         one engine per in-flight frame (FramePipeline)."""
         other = type(self)(self.args, self.device)
         for k in ("pfn", "blocks", "deblocks", "cat_c", "shrink", "feat_c", "cls_single", "head_splits", "heads",
-                  "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready") + tuple(self.FUSION_WEIGHTS):
+                  "gauss_w", "gauss_b", "gauss_k", "threshold", "weights_ready", "compressor") + tuple(self.FUSION_WEIGHTS):
             if hasattr(self, k):
                 setattr(other, k, getattr(self, k))
         if getattr(self, "cam", None):
@@ -530,6 +533,7 @@ class Where2ComEngine:
 
     def _load_fusion(self, sd, up):
         dev = self.device
+        self.compressor = self._load_compressor(sd, up, "naive_compressor") if getattr(self, "compression", 0) else None
         g = "fusion_net.naive_communication.gaussian_filter"
         comm = self.fcfg["communication"]
         if "gaussian_smooth" in comm:
@@ -1384,7 +1388,7 @@ class Where2ComEngine:
     def _post_encode(self, canvas, ny, nx, record_len, trace):
         """Everything after the scatter; static shapes for a given record_len -> capturable."""
         B, n = len(record_len), sum(record_len)
-        if (B == 1 and n >= 2 and self.agent_streams > 1 and trace is None and self.profile is None
+        if (B == 1 and n >= 2 and self.agent_streams > 1 and trace is None and self.profile is None and self.multi_scale
                 and not self.fcfg["fully"] and not torch.cuda.is_current_stream_capturing()):
             return self._post_encode_groups(canvas, ny, nx, n)
         st = self.stream()
@@ -1401,6 +1405,10 @@ class Where2ComEngine:
             trace["shrink"] = s.permute(0, 3, 1, 2).clone()
             trace["psm_single"] = psm_single.permute(0, 3, 1, 2).clone()
 
+        if not self.multi_scale:
+            return self._post_encode_single_scale(s, psm_single, n, H, W, record_len, nz, trace)
+        # (multi-scale: the reference runs its compressor on the shrunk map here too, airv2x_where2com.py:147-150, and then fuses
+        # batch_dict["spatial_features"] -- the result is dead; nothing is launched for it)
         (b0, h0, w0), (b1, h1, w1), (b2, h2, w2) = feats
         if self.fcfg["fully"]:
             com = torch.tensor(1, device=self.device)
@@ -1461,6 +1469,38 @@ class Where2ComEngine:
         if trace is not None:
             trace["fused_2d"] = catf.permute(0, 3, 1, 2).clone()
             trace["fused_shrink"] = fs.permute(0, 3, 1, 2).clone()
+        return heads, com, nz
+
+    def _post_encode_single_scale(self, s, psm_single, n, H, W, record_len, nz, trace):
+        """``multi_scale: false`` (airv2x_where2com.py:147-150, 163-166; where2comm_fuse.py:264-286): compressor (if any) on the shrunk map,
+        communication mask x map, ONE per-pixel attention over each sample's agents at 256 channels, heads on the fused map (no second
+        shrink).  Same kernels as the multi-scale levels (av2x_apply_mask, pixel_attn_kernel<4>)."""
+        B = len(record_len)
+        st = self.stream()
+        c = s.shape[-1]
+        if self.compressor:
+            self.run_compressor(s, n, H, W)                      # in place: encoder -> decoder writes s back (naive_compress.py:38-42)
+            if trace is not None:
+                trace["compressed"] = s.permute(0, 3, 1, 2).clone()
+        if self.fcfg["fully"]:
+            com = torch.tensor(1, device=self.device)
+        else:
+            mask, count, smooth, rl = self.comm_mask(psm_single, n, H, W, record_len)
+            com = self.comm_rate(count, rl, B, H * W)
+            self.timed_hbm("apply_mask (in place)", n * H * W * (2 * c + 1) * 4, 0.0,
+                           lambda: _lib.check(self.lib.av2x_apply_mask(_ptr(s), _ptr(mask), n, H * W, c, st), "av2x_apply_mask"))
+            if trace is not None:
+                trace["comm_mask"] = mask.unsqueeze(1).clone()
+                trace["comm_map"] = smooth.unsqueeze(1).clone()
+        fused = self.buf("fused_single", (B, H, W, c))
+        a0 = 0
+        for b, k in enumerate(record_len):
+            self.attn([s[j].data_ptr() for j in range(a0, a0 + k)], H * W, c, fused[b])
+            a0 += k
+        heads = torch.empty((B, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
+        self.conv(self.heads, fused, B, H, W, heads)
+        if trace is not None:
+            trace["fused_2d"] = fused.permute(0, 3, 1, 2).clone()
         return heads, com, nz
 
     def _post_encode_groups(self, canvas, ny, nx, n):
@@ -1560,8 +1600,9 @@ class Where2ComEngine:
         agent count is the largest count of any rank: an uneven frame pads the message, a rank without agents sends
         only padding).
         Returns (send flat f32, stats int64[2] = [mask ones before ego override, canvas non-zeros], meta)."""
-        if self.fcfg["fully"]:
-            raise NotImplementedError("agent sharding with fully-connected communication")
+        if not self.multi_scale:
+            raise NotImplementedError("agent-sharded single-scale Where2comm (multi_scale: false): the message would be the masked 256-channel "
+                                      "map plus its mask; run this variant unsharded")
         n, record_len, slots = self.shard_frame_agents(data_dict_local)
         n_pad = n if n_pad is None else int(n_pad)
         if n_pad < max(n, 1):
@@ -1608,6 +1649,13 @@ class Where2ComEngine:
         for (h, w, c), f in zip(dims, sizes):
             lv.append(send[off:off + n * f].view(n, h, w, c))
             off += n_pad * f
+        if self.fcfg["fully"]:
+            # fully connected communication graph (where2comm_fuse.py:222-223): no mask, the UNMASKED block outputs are the message (and the
+            # per-agent deblocks / shrink header / confidence head, whose only consumer is the mask, are not launched); com = 1
+            x, h, w = canvas, ny, nx
+            for i in range(len(self.blocks)):
+                x, h, w = self.run_block(i, x, n, h, w, "all", out=lv[i])
+            return torch.stack([torch.zeros((), dtype=torch.int64, device=self.device), nz[0]])
         feats, s, H, W = self.trunk(canvas, n, ny, nx, block_out={0: lv[0]})
         psm_single = self.buf("psm_single", (n, H, W, self.A * self.C))
         self.conv(self.cls_single, s, n, H, W, psm_single)
@@ -1656,7 +1704,7 @@ class Where2ComEngine:
         if self.args["obj_head"]:
             out["obj"] = outs[2]
         n_total = sum(counts)
-        com = stats[0].to(torch.float32) / float(n_total * H * W)
+        com = torch.tensor(1, device=self.device) if self.fcfg["fully"] else stats[0].to(torch.float32) / float(n_total * H * W)
         comm_rate = int(stats[1].item()) if sync_comm_rate else stats[1]
         out.update({"mask": 0, "com": com, "comm_rate": comm_rate})
         return out

@@ -487,9 +487,6 @@ class V2XViTEngine(Where2ComEngine):
         ``data_dict_local`` carries the frame-level ``prior_encoding`` / ``spatial_correction_matrix`` (host
         metadata of ALL agents, (1,L,.)) even on a rank without agents; stats = [0, canvas non-zeros] (summed over
         ranks = comm_rate)."""
-        if getattr(self, "compression", 0):
-            raise NotImplementedError("agent-sharded %s frame with a NaiveCompressor: the encoder-side message is built for CoBEVT only "
-                                      "(cobevt_engine.shard_local_stage); run this model unsharded" % "V2X-ViT")
         n, record_len, slots = self.shard_frame_agents(data_dict_local)
         n_pad = n if n_pad is None else int(n_pad)
         if n_pad < max(n, 1):
@@ -500,15 +497,28 @@ class V2XViTEngine(Where2ComEngine):
             ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
         H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
-        send = self.buf("shard_send", (n_pad * H * Wd * 256,), self.msg_dtype())     # autocast: the bf16 message, 18.0 MB per agent
-        meta = {"n_loc": n_pad, "H": H, "W": Wd,
+        # with a NaiveCompressor (airv2x_v2xvit.py:42-44, 122-123) the message is its ENCODER's output: 256 / ratio channels (36.0 / ratio MB per
+        # agent at the default grid, half of that under autocast); the two decoder layers run on the receiving side (_gathered_maps)
+        cm = self.compressor[0].cout if getattr(self, "compression", 0) else 256
+        send = self.buf("shard_send", (n_pad * H * Wd * cm,), self.msg_dtype())      # autocast: the bf16 message, 18.0 MB per agent
+        meta = {"n_loc": n_pad, "H": H, "W": Wd, "cm": cm,
                 "prior": data_dict_local["prior_encoding"][0].detach().cpu().numpy(),
                 "scm": data_dict_local["spatial_correction_matrix"][0].detach().cpu().numpy()}
         if n == 0:
             return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
         st = self.stream()
         nz = self.count_canvas(canvas, st)
-        self.trunk(canvas, n, ny, nx, shrink_out=send[:n * H * Wd * 256].view(n, H, Wd, 256))
+        if cm != 256:
+            s = self.buf("shard_shrink", (n, H, Wd, 256))
+            if self.msg_dtype() == torch.bfloat16:    # as forward(): the shrink header's output is stored as bf16 and widened into the fp32 stream
+                s16 = self.buf("shard_shrink16", (n, H, Wd, 256), torch.bfloat16)
+                self.trunk(canvas, n, ny, nx, shrink_out=s16)
+                self.widen(s16, s)
+            else:
+                self.trunk(canvas, n, ny, nx, shrink_out=s)
+            self.conv(self.compressor[0], s, n, H, Wd, send[:n * H * Wd * cm].view(n, H, Wd, cm))
+        else:
+            self.trunk(canvas, n, ny, nx, shrink_out=send[:n * H * Wd * 256].view(n, H, Wd, 256))
         stats = torch.stack([torch.zeros((), dtype=torch.int64, device=self.device), nz[0]])
         return send, stats, meta
 
@@ -516,12 +526,26 @@ class V2XViTEngine(Where2ComEngine):
         """(N,H,W,256) maps of the real agents in frame order: the gathered buffer itself, or (uneven frame) its valid
         slots compacted into a workspace."""
         n_loc, H, Wd = meta["n_loc"], meta["H"], meta["W"]
+        cm = meta.get("cm", 256)
         counts = meta.get("counts") or [n_loc] * world
         N = sum(counts)
-        if recv.numel() != world * n_loc * H * Wd * 256 or len(counts) != world or max(counts) > n_loc:
+        if recv.numel() != world * n_loc * H * Wd * cm or len(counts) != world or max(counts) > n_loc:
             raise ValueError("gathered buffer has the wrong size")
         if N > self.L:
             raise ValueError(f"{N} agents exceed max_cav_num = {self.L}")
+        if cm != 256:       # compressed message: the real agents' encoder outputs (compacted when the frame is uneven) through the decoder
+            msg = recv.view(world * n_loc, H, Wd, cm)
+            if N != world * n_loc:
+                from .sharded import valid_slots
+                cmp = self.buf("shard_compact", (N, H, Wd, cm), recv.dtype)
+                for a, slot in enumerate(valid_slots(counts, n_loc)):
+                    cmp[a].copy_(msg[slot])
+                msg = cmp
+            mid = self.buf("compress_mid", (N, H, Wd, 256))
+            dec = self.buf("compress_dec", (N, H, Wd, 256))
+            self.conv(self.compressor[1], msg, N, H, Wd, mid)
+            self.conv(self.compressor[2], mid, N, H, Wd, dec)
+            return dec, N, H, Wd
         maps = recv.view(world * n_loc, H, Wd, 256)
         if maps.dtype == torch.bfloat16:        # autocast message: widened into the fp32 stream (and compacted on the way)
             from .sharded import valid_slots

@@ -149,9 +149,6 @@ class When2comEngine(Where2ComEngine):
         each at the default grid) | n_loc keys (1 KB each) | the ego's projected query (1 KB; zeros on the other
         ranks)], so that every rank can finish the frame (SPMD).  ``data_dict_local`` carries the frame-level
         ``img_pairwise_t_matrix_collab`` and ``shard_rank`` (set by ShardedFrame): global agent index = rank * n_loc + j."""
-        if getattr(self, "compression", 0):
-            raise NotImplementedError("agent-sharded %s frame with a NaiveCompressor: the encoder-side message is built for CoBEVT only "
-                                      "(cobevt_engine.shard_local_stage); run this model unsharded" % "When2com")
         n, record_len, slots = self.shard_frame_agents(data_dict_local)
         n_pad = n if n_pad is None else int(n_pad)
         if n_pad < max(n, 1):
@@ -172,6 +169,12 @@ class When2comEngine(Where2ComEngine):
             return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
         s = self.buf("w2_shrink", (n, H, W, C))
         self.trunk(canvas, n, ny, nx, shrink_out=s)
+        if getattr(self, "compression", 0):
+            # NaiveCompressor (airv2x_when2com.py:50-52, 122-123): everything When2com does per agent after it -- the warp into the ego
+            # frame, the policy network, the key MLP: 290 of the ~300 GFLOP per agent -- works on the DECODED map, and this split keeps that
+            # work on the sender, so encoder and decoder both run here and the message stays the warped 256-channel map.  (Shipping the
+            # C / ratio-channel encoder output instead would move the warp and the policy network of every agent to the ego's rank.)
+            self.run_compressor(s, n, H, W)
         st = self.stream()
         nz = self.buf("nonzero", (1,), torch.int64)
         _lib.check(self.lib.av2x_fill_zero(_ptr(nz), 8, st), "av2x_fill_zero")

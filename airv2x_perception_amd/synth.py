@@ -259,6 +259,7 @@ def where2com_param_spec(args):
     spec = encoder_param_spec(args)
     spec += backbone_param_spec(args["modality_fusion"]["base_bev_backbone"], 64, "backbone.")
     spec += shrink_param_spec(args["modality_fusion"]["shrink_header"], "shrink_conv.")
+    spec += compressor_param_spec(256, model_compression(args))       # airv2x_where2com.py:50-52: NaiveCompressor(256, args["compression"])
     ks = args["where2com_fusion"]["communication"]["gaussian_smooth"]["k_size"]
     spec.append(("fusion_net.naive_communication.gaussian_filter.weight", (1, 1, ks, ks), "gauss_w"))
     spec.append(("fusion_net.naive_communication.gaussian_filter.bias", (1,), "gauss_b"))
@@ -620,7 +621,7 @@ def cobevt_param_spec(args):
                 "anchor_number": args["anchor_number"], "num_class": args["num_class"], "outC": args["outC"],
                 "obj_head": args["obj_head"]}
     base = where2com_param_spec(w2c_like)
-    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "naive_compressor.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
     fax = args["fax_fusion"]
     spec = list(trunk) + compressor_param_spec(fax["input_dim"], args.get("compression", 0))
@@ -694,7 +695,7 @@ def v2xvit_param_spec(args):
     w2c_like = dict(args)
     w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
     base = where2com_param_spec(w2c_like)
-    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "naive_compressor.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
     spec = list(trunk) + compressor_param_spec(256, model_compression(args)) + v2xvit_encoder_spec(args["transformer"]["encoder"], "fusion_net.encoder")
     return spec + heads
@@ -765,7 +766,7 @@ def when2com_param_spec(args):
     w2c_like = dict(args)
     w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
     base = where2com_param_spec(w2c_like)
-    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "naive_compressor.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
     return trunk + compressor_param_spec(256, model_compression(args)) + when2com_fusion_spec(args["when2com_fusion"], "fusion_net.") + heads
 
@@ -816,7 +817,7 @@ def v2vnet_param_spec(args):
     w2c_like = dict(args)
     w2c_like["where2com_fusion"] = {"communication": {"gaussian_smooth": {"k_size": 5}}}
     base = where2com_param_spec(w2c_like)
-    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "cls_head", "reg_head", "obj_head"))]
+    trunk = [e for e in base if not e[0].startswith(("fusion_net.", "naive_compressor.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
     return trunk + v2vnet_fusion_spec(args["v2vfusion"], "fusion_net.") + heads
 

@@ -278,9 +278,29 @@ def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None, topk=None, 
     return torch.cat(ups, dim=1), rate
 
 
+def where2comm_fuse_single(x, psm_single, record_len, sd, args, trace=None, topk=None, comm_mask=None):
+    """where2comm_fuse.py:264-286 (multi_scale: false): mask the (compressed) shrunk map, one per-pixel attention per sample.
+    x (sumN,256,H,W) -> (fused (B,256,H,W), rate)."""
+    fcfg = args["where2com_fusion"]
+    if fcfg["fully"]:
+        rate = torch.tensor(1)
+    else:
+        masks, rate, maps = communication(_split(psm_single, record_len), sd, fcfg["communication"], topk)
+        if comm_mask is not None:
+            masks = comm_mask.to(x.dtype).reshape(masks.shape)
+        x = x * masks
+        if trace is not None:
+            trace["comm_mask"] = masks
+            trace["comm_map"] = maps
+    fused = torch.stack([attention_fusion(xb) for xb in _split(x, record_len)])
+    if trace is not None:
+        trace["masked_single"] = x
+    return fused, rate
+
+
 # ---------------------------------------------------------------- full forward
 def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False, topk=None, comm_mask=None):
-    """models/airv2x_where2com.py:117-179 (det task, multi_scale, compression 0).
+    """models/airv2x_where2com.py:117-179 (det task; multi_scale true / false, compression 0 / r).
 
     The reference evaluates the backbone twice before the fusion (:119, :124); in
     eval mode both passes give identical tensors, so the oracle runs it once
@@ -296,8 +316,15 @@ def where2com_forward(data_dict, sd, args, trace=None, reference_schedule=False,
     comm_rate = int(feats.count_nonzero().item())  # :122
     s = shrink_conv(sf2d, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else sf2d
     psm_single = head(s, sd, "cls_head")  # :145
-    fused, rate = where2comm_fuse(feats, psm_single, record_len, sd, args, trace, topk, comm_mask)  # :153-159
-    fs = shrink_conv(fused, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else fused
+    sc = s
+    if mf.get("compression", 0) > 0:      # :147-150 (the ratio is args["compression"], read by the constructor :52)
+        sc = naive_compress(s, sd)
+    if args["where2com_fusion"]["multi_scale"]:
+        fused, rate = where2comm_fuse(feats, psm_single, record_len, sd, args, trace, topk, comm_mask)  # :153-159 (sc is dead here)
+        fs = shrink_conv(fused, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else fused      # :161-162
+    else:
+        fused, rate = where2comm_fuse_single(sc, psm_single, record_len, sd, args, trace, topk, comm_mask)  # :163-166
+        fs = fused
     out = {"psm": head(fs, sd, "cls_head"), "rm": head(fs, sd, "reg_head")}
     if args["obj_head"]:
         out["obj"] = head(fs, sd, "obj_head")

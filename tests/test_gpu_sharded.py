@@ -358,3 +358,63 @@ def test_bench_two_ranks_on_one_gpu_reports_the_sharded_frame(extra):
     assert "all_gather_into_tensor" in res["config"]["parallelism"]
     assert ("[2, 1]" if extra else "[2, 2]") in res["config"]["parallelism"]
     assert res["replica"]["frames_per_s"] > 0 and res["single_frame_latency"]["frames_per_s"] > 0
+
+
+@pytest.mark.parametrize("which,ratio,amp,uneven", [("v2xvit", 2, False, False), ("v2xvit", 4, True, False), ("v2xvit", 4, False, True),
+                                                    ("when2com", 4, False, False), ("when2com", 2, False, True)])
+def test_sharded_frame_with_a_naive_compressor_equals_the_single_gpu_forward(which, ratio, amp, uneven):
+    """V2X-ViT / When2com with ``modality_fusion.compression > 0`` (ratio = args["compression"]; airv2x_v2xvit.py:42-44,122-123,
+    airv2x_when2com.py:50-52,122-123) in the agent-sharded frame.  V2X-ViT: the message is the compressor's ENCODER output -- 256 / ratio
+    channels per pixel, ratio x fewer bytes through the all-gather -- and the receiver runs the decoder; When2com: its per-agent work (warp,
+    policy network, keys) stays on the sender, so encoder + decoder run there and the message is unchanged.  Same bits as the unsharded frame."""
+    from airv2x_perception_amd import opencood_iface as oi
+    from airv2x_perception_amd.opencood_iface.sharded import partition_agents
+    from oracle import voxelize_oracle as vox
+    rng = [-25.6, -12.8, -3.0, 25.6, 12.8, 1.0]
+    types = ["vehicle", "vehicle", "rsu"] if uneven else ["vehicle", "rsu"]
+    if which == "v2xvit":
+        hy, spec_fn, cls = synth.default_hypes_v2xvit(rng, (2, 1, 1)), synth.v2xvit_param_spec, oi.Airv2xV2XVit
+    else:
+        hy, spec_fn, cls = synth.default_hypes_when2com(rng), synth.when2com_param_spec, oi.Airv2xWhen2com
+    args = hy["model"]["args"]
+    args["modality_fusion"]["compression"] = args["compression"] = ratio
+    sd = synth.synthetic_state_dict(spec_fn(args), seed=40 + ratio)
+    pp = hy["preprocess"]
+    voxd = [vox.points_to_voxels(vox.mask_points_by_range(synth.synthetic_cloud(i, 900, rng), pp["cav_lidar_range"]), pp["cav_lidar_range"],
+                                 pp["args"]["voxel_size"]) for i in range(len(types))]
+    dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
+    if which == "v2xvit":
+        scm = torch.eye(4, dtype=torch.float64).repeat(1, args["max_cav_num"], 1, 1)
+        for i in range(1, len(types)):
+            scm[0, i] = torch.from_numpy(synth.se2_correction(2.0 * i, 0.6 * i, -0.3 * i))
+        dd["spatial_correction_matrix"] = scm
+    else:
+        dd["img_pairwise_t_matrix_collab"] = synth.when2com_pairwise(len(types), args["max_cav_num"])
+    model = cls(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda").eval()
+    eng = model.engine()
+    eng.stream_k = False
+    eng.amp = amp
+    ref = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.forward(dd, sync_comm_rate=True).items()}
+    world = 2
+    parts = partition_agents(len(types), world)
+    counts = [len(p) for p in parts]
+    sends, stats, meta = [], None, None
+    for r, mine in enumerate(parts):
+        dd_local = synth.build_data_dict([voxd[i] for i in mine], [types[i] for i in mine], max_cav_num=args["max_cav_num"])
+        for k in ("prior_encoding", "spatial_correction_matrix", "img_pairwise_t_matrix_collab"):
+            if k in dd:
+                dd_local[k] = dd[k]
+        dd_local["shard_rank"] = r
+        dd_local["shard_agent_offset"] = sum(counts[:r])
+        send, st, meta = eng.shard_local_stage(dd_local, has_ego=(r == 0), n_pad=max(counts))
+        if which == "v2xvit":       # the payload: n_pad x H x W x 256 / ratio elements of 4 (autocast: 2) bytes
+            assert send.numel() == max(counts) * meta["H"] * meta["W"] * (256 // ratio)
+            assert send.dtype == (torch.bfloat16 if amp else torch.float32)
+        sends.append(send.clone())
+        stats = st.clone() if stats is None else stats + st
+    out = eng.shard_ego_stage(torch.cat(sends), stats, dict(meta, counts=counts, n_pad=max(counts)), world=world, sync_comm_rate=True)
+    for k in ("psm", "rm", "obj"):
+        assert torch.equal(out[k], ref[k]), k
+    assert out["comm_rate"] == ref["comm_rate"]

@@ -10,6 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import torch.nn.functional as F
 
 from airv2x_perception_amd import synth
 from airv2x_perception_amd.opencood_iface.sharded import ShardedFrame, partition_agents
@@ -269,13 +270,18 @@ class V2XViTOracleBackend:
         n = _local_count(dd_local)
         n_pad = n if n_pad is None else n_pad
         g = args["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]
-        shape = (n_pad, mf["shrink_header"]["dim"][-1], int(g[1]) // 2, int(g[0]) // 2)
+        # NaiveCompressor (airv2x_v2xvit.py:42-44, 122-123): the message is the ENCODER's output, 256 / ratio channels; the receiver decodes
+        self.ratio = synth.model_compression(args)
+        shape = (n_pad, mf["shrink_header"]["dim"][-1] // (self.ratio or 1), int(g[1]) // 2, int(g[0]) // 2)
         meta = {"shape": shape, "prior": dd_local["prior_encoding"], "scm": dd_local["spatial_correction_matrix"]}
         if n == 0:
             return torch.full((int(np.prod(shape)),), float("nan"), dtype=self.msg_dtype), torch.zeros(2, dtype=torch.int64), meta
         feats, _ = orc.extract_features(dd_local, sd, args)
         sf2d, _ = orc.backbone_forward(feats, sd, mf["base_bev_backbone"])
         s = orc.shrink_conv(sf2d, sd, mf["shrink_header"])
+        if self.ratio:
+            s = F.conv2d(s, sd["naive_compressor.encoder.0.weight"], sd["naive_compressor.encoder.0.bias"], padding=1)
+            s = F.relu(orc._bn(s, sd, "naive_compressor.encoder.1"))
         s = torch.cat([s, s.new_full((n_pad - n,) + tuple(s.shape[1:]), float("nan"))], 0)
         return s.reshape(-1).to(self.msg_dtype), torch.tensor([0, int(feats.count_nonzero())], dtype=torch.int64), meta
 
@@ -284,6 +290,10 @@ class V2XViTOracleBackend:
         n_loc, c, h, w = meta["shape"]
         assert recv.dtype == self.msg_dtype
         s = _real_agents(recv, meta, world).float()
+        if synth.model_compression(self.args):      # the two decoder layers, on the receiving side
+            for conv, bn in (("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+                s = F.conv2d(s, self.sd[f"naive_compressor.{conv}.weight"], self.sd[f"naive_compressor.{conv}.bias"], padding=1)
+                s = F.relu(orc._bn(s, self.sd, f"naive_compressor.{bn}"))
         x, mask = cob.regroup(s, torch.tensor([s.shape[0]]), self.args["max_cav_num"])
         prior = meta["prior"].unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, h, w)
         return torch.cat([x, prior], dim=2).permute(0, 1, 3, 4, 2).contiguous(), mask
@@ -325,9 +335,11 @@ class V2XViTOracleBackend:
         return self._split(full, ctx["stats"])
 
 
-def _v2xvit_frame():
+def _v2xvit_frame(compression=0):
     hy = synth.default_hypes_v2xvit(RNG)
     args = hy["model"]["args"]
+    if compression:
+        args["modality_fusion"]["compression"] = args["compression"] = int(compression)
     sd = synth.synthetic_state_dict(synth.v2xvit_param_spec(args), seed=5)
     _, _, voxd = _frame()
     dd = synth.build_data_dict(voxd, TYPES, max_cav_num=args["max_cav_num"])
@@ -338,21 +350,43 @@ def _v2xvit_frame():
     return args, sd, voxd, dd
 
 
-def _v2xvit_worker(rank, world, port, result_path, two_level, msg_dtype=torch.float32):
+def _v2xvit_worker(rank, world, port, result_path, two_level, msg_dtype=torch.float32, compression=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    args, sd, voxd, dd = _v2xvit_frame()
+    args, sd, voxd, dd = _v2xvit_frame(compression)
     mine = partition_agents(len(TYPES), world)[rank]
     dd_local = synth.build_data_dict([voxd[i] for i in mine], [TYPES[i] for i in mine], max_cav_num=args["max_cav_num"])
     for k in ("prior_encoding", "spatial_correction_matrix"):      # frame-level metadata of all agents
         dd_local[k] = dd[k]
     with torch.no_grad():
-        out = ShardedFrame(V2XViTOracleBackend(sd, args, two_level, msg_dtype)).forward(dd_local)
+        frame = ShardedFrame(V2XViTOracleBackend(sd, args, two_level, msg_dtype))
+        out = frame.forward(dd_local)
     if rank == 0:
+        out["message_bytes"] = frame.last_exchange["message_bytes"]
         torch.save(out, result_path)
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("two_level,ratio", [(False, 2), (True, 4)])
+def test_v2xvit_compressed_message_sharded_frame_equals_single_process(tmp_path, two_level, ratio):
+    """V2X-ViT with a NaiveCompressor (modality_fusion.compression > 0, ratio = args["compression"]) in the agent-sharded frame: the message
+    is the encoder's 256 / ratio-channel output -- the all-gather payload shrinks ratio x (36.0 -> 36.0 / ratio MB per agent at the default
+    grid) -- and the receiver runs the decoder; outputs equal the single-process oracle of the same model."""
+    from oracle import v2xvit_oracle as vit
+    path = str(tmp_path / "out.pt")
+    mp.spawn(_v2xvit_worker, args=(2, _free_port(), path, two_level, torch.float32, ratio), nprocs=2, join=True)
+    got = torch.load(path)
+    args, sd, voxd, dd = _v2xvit_frame(ratio)
+    g = args["vehicle"]["lidar"]["point_pillar_scatter"]["grid_size"]
+    agents_per_rank = max(len(p) for p in partition_agents(len(TYPES), 2))
+    assert got["message_bytes"] == agents_per_rank * (256 // ratio) * (int(g[1]) // 2) * (int(g[0]) // 2) * 4      # ratio x fewer bytes per agent
+    with torch.no_grad():
+        ref = vit.v2xvit_forward(dd, sd, args)
+    for k in ("psm", "rm", "obj"):
+        assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), k
+    assert got["comm_rate"] == ref["comm_rate"]
 
 
 @pytest.mark.parametrize("two_level", [False, True])
