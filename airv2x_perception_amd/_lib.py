@@ -219,6 +219,7 @@ SIGNATURES = {
                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_comm_mask_topk": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "av2x_apply_mask": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "av2x_mask_resize_bilinear": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_pixel_attn_fuse": (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_warp_fuse": (c_int32, [POINTER(c_void_p), c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "av2x_agent_max": (c_int32, [POINTER(c_void_p), c_int32, c_uint64, c_void_p, c_void_p]),

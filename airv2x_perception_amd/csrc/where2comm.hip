@@ -316,6 +316,41 @@ extern "C" int av2x_apply_mask(float* x, const float* mask, int32_t n, int32_t h
     return av2x::check_launch("apply_mask_kernel");
 }
 
+namespace {
+// F.interpolate(mask, size=(ho, wo), mode="bilinear", align_corners=False) of single-channel maps (where2comm_fuse.py:229-235: the
+// communication mask when the first block's map and the confidence map differ in size).  ATen's arithmetic: scale = in / out,
+// src = scale (dst + 0.5) - 0.5 clamped at 0, the two weights of each axis, rows combined after columns.
+__global__ void mask_resize_kernel(const float* __restrict__ in, int n, int hi, int wi, int ho, int wo, float sh, float sw,
+                                   float* __restrict__ out) {
+    const size_t total = (size_t)n * ho * wo;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % wo), y = (int)((e / wo) % ho), img = (int)(e / ((size_t)wo * ho));
+        float fy = sh * ((float)y + 0.5f) - 0.5f, fx = sw * ((float)x + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* p = in + (size_t)img * hi * wi;
+        out[e] = ly0 * (lx0 * p[(size_t)y0 * wi + x0] + lx1 * p[(size_t)y0 * wi + x1])
+               + ly1 * (lx0 * p[(size_t)y1 * wi + x0] + lx1 * p[(size_t)y1 * wi + x1]);
+    }
+}
+}  // namespace
+
+extern "C" int av2x_mask_resize_bilinear(const float* in, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, float* out,
+                                         av2x_stream_t stream) {
+    if (n == 0) return 0;
+    if (!in || !out) return av2x::fail("av2x_mask_resize_bilinear: null argument");
+    if (hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0) return av2x::fail("av2x_mask_resize_bilinear: empty map");
+    const size_t total = (size_t)n * ho * wo;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mask_resize_kernel, dim3((unsigned)blocks), dim3(256), 0, av2x::as_stream(stream), in, n, hi, wi, ho, wo,
+                       (float)hi / (float)ho, (float)wi / (float)wo, out);
+    return av2x::check_launch("mask_resize_kernel");
+}
+
 extern "C" int av2x_pixel_attn_fuse(const float* const* agents, int32_t n_agents, int32_t hw, int32_t c, float* out,
                                     av2x_stream_t stream) {
     if (!agents || !out) return av2x::fail("av2x_pixel_attn_fuse: null argument");

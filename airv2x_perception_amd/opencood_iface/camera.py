@@ -67,6 +67,15 @@ def _cam_calibration_on_host(ci):
             flat[:, 30:33].reshape(B, N, 3)]
 
 
+def _check_downsample(cam_args):
+    """img_downsample as the reference's CamEncode takes it (lss_submodule.py:72-75, 152-153): 8 = up1 + up2 on the stride-8 EfficientNet
+    endpoint (every shipped AirV2X config); 16 = up1 only, features at stride 16 (``up2`` does not exist in the state_dict then).  Any other
+    value gives a feature map that does not match the frustum in the reference either; CamEncode_Resnet101 ends at its stride-8 layer2."""
+    ds = int(cam_args["img_downsample"])
+    if ds not in (8, 16) or (ds == 16 and cam_args["camera_encoder"] == "Resnet101"):
+        raise NotImplementedError(f"img_downsample {ds} with {cam_args['camera_encoder']}: 8 (EfficientNet / Resnet101) or 16 (EfficientNet)")
+
+
 class CameraGeometry:
     """The weight-free part of one agent type's LiftSplatShootEncoder: frustum, BEV grid, depth bins and the per-camera matrices
     (airv2x_encoder.py:31-167).  The training forward (train_camera.py) uses it on its own; CameraEncoder builds the same values."""
@@ -75,8 +84,7 @@ class CameraGeometry:
         self.cfg, self.device = cam_args, device
         if cam_args["camera_encoder"] not in ("EfficientNet", "Resnet101"):
             raise NotImplementedError(f"camera_encoder {cam_args['camera_encoder']!r}: EfficientNet or Resnet101 (airv2x_encoder.py:67-86)")
-        if cam_args["img_downsample"] != 8:
-            raise NotImplementedError("img_downsample: 8 (the shipped AirV2X configs)")
+        _check_downsample(cam_args)
         g = cam_args["grid_conf"]
         self.dx, self.bx, self.nx = gen_dx_bx(g["xbound"], g["ybound"], g["zbound"])
         self.ds = int(cam_args["img_downsample"])
@@ -124,8 +132,7 @@ class CameraEncoder:
         if cam_args["camera_encoder"] not in ("EfficientNet", "Resnet101"):
             raise NotImplementedError(f"camera_encoder {cam_args['camera_encoder']!r}: EfficientNet or Resnet101 (airv2x_encoder.py:67-86)")
         self.resnet = cam_args["camera_encoder"] == "Resnet101"
-        if cam_args["img_downsample"] != 8:
-            raise NotImplementedError("img_downsample: 8 (the shipped AirV2X configs)")
+        _check_downsample(cam_args)
         self.lib = eng.lib
         up = eng._up
         g = cam_args["grid_conf"]
@@ -229,7 +236,7 @@ class CameraEncoder:
             b["project"] = conv(sd[q + "_project_conv.weight"], s2, h2, 0, cin_p=mid_p, cout_p=cout_p)
             self.blocks.append(b)
         self.up1 = up_block(p + "up1.", 112, 320)
-        self.up2 = up_block(p + "up2.", 40, 256)
+        self.up2 = up_block(p + "up2.", 40, 256) if int(self.cfg["img_downsample"]) == 8 else None    # lss_submodule.py:74-75
 
     def _build_bevencode(self, sd, prefix, conv, up_block):
         # ---- BevEncode
@@ -327,9 +334,12 @@ class CameraEncoder:
         ends.append(prev)
         (r3, h3, w3), (r4, h4, w4), (r5, h5, w5) = ends[2], ends[3], ends[4]
         u1 = self._up(self.up1, r5, h5, w5, r4, h4, w4, _pad32(112), 2, n, tag + "a")
-        f = self._up(self.up2, u1, h4, w4, r3, h3, w3, _pad32(40), 2, n, tag + "b")
+        if self.up2 is not None:
+            f = self._up(self.up2, u1, h4, w4, r3, h3, w3, _pad32(40), 2, n, tag + "b")
+        else:       # img_downsample 16: the stride-16 map of up1 is the feature map (lss_submodule.py:152-153)
+            f, h3, w3 = u1, h4, w4
         if (h3, w3) != (H // self.ds, W // self.ds):
-            raise ValueError(f"camera image {H}x{W}: the stride-8 feature map is {h3}x{w3}, the frustum expects {H // self.ds}x{W // self.ds}")
+            raise ValueError(f"camera image {H}x{W}: the stride-{self.ds} feature map is {h3}x{w3}, the frustum expects {H // self.ds}x{W // self.ds}")
         e.conv(self.image_head, f, n, h3, w3, feat)
         if not self.use_gt:
             logit = e.buf(f"cam_logit_{tag}", (n, h3, w3, self.nbins))

@@ -150,7 +150,7 @@ class CoBEVTEngine(Where2ComEngine):
         else:
             ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
-        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, W = self.cat_hw(dims)
         C = self.fax["input_dim"]
         cm = self.compressor[0].cout if self.compression else C
         send = self.buf("shard_send", (n_pad * H * W * cm,), self.msg_dtype())     # autocast: bf16, 18.0 MB per agent (uncompressed)
@@ -271,7 +271,7 @@ class CoBEVTEngine(Where2ComEngine):
             raise ValueError(f"{max(record_len)} agents exceed max_cav_num = {self.L}")
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         dims = self.level_dims(ny, nx)
-        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, W = self.cat_hw(dims)
         C = self.fax["input_dim"]
         x = self.buf("fax_x", (self.L, H, W, C))
         if B == 1:

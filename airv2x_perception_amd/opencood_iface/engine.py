@@ -279,10 +279,9 @@ class Where2ComEngine:
 
     def _init_config(self, args):
         self.bb = args["modality_fusion"]["base_bev_backbone"]
-        ups = self.bb.get("upsample_strides", [])
-        if len(ups) != len(self.bb["layer_nums"]) or any(s < 1 for s in ups):
-            raise NotImplementedError("down-sampling deblocks / the extra final deblock inside the full AirV2X models (no shipped AirV2X "
-                                      "YAML has them); the stand-alone BaseBEVBackbone module runs them")
+        # (BaseBEVBackbone's variants -- deblocks that down-sample, upsample_strides < 1, and the extra deblock on the concatenated map,
+        # base_bev_backbone.py:87-121 -- change the resolution of the shared map: cat_hw() / trunk() follow it, and the communication mask
+        # is brought to the first block's resolution as where2comm_fuse.py:229-235 does)
         self.sh = args["modality_fusion"]["shrink_header"]
         self.fcfg = args["where2com_fusion"]
         # multi_scale: false = the single-scale branch (where2comm_fuse.py:264-286, airv2x_where2com.py:163-166): the shrunk (and, with
@@ -1262,6 +1261,35 @@ class Where2ComEngine:
                                                                                      _ptr(smap), len(sl), ny, nx, _ptr(nz), _ptr(occ), st),
                                               "av2x_pillar_vfe_scatter_count"))
 
+    @staticmethod
+    def _deblock_hw(L, h, w):
+        """Output size of one deblock: ConvTranspose2d(k = s, stride s) or, for upsample_strides < 1, Conv2d(k, stride k)."""
+        if L.mode == _lib.AV2X_DECONV:
+            return h * L.up, w * L.up
+        return (h + 2 * L.pad - L.ks) // L.stride + 1, (w + 2 * L.pad - L.ks) // L.stride + 1
+
+    def cat_hw(self, dims):
+        """(H, W) of spatial_features_2d for the per-level (h, w, c) of level_dims(): the per-level deblocks' common output size, times the
+        final deblock's stride when the backbone has one (base_bev_backbone.py:141-152)."""
+        H, W = self._deblock_hw(self.deblocks[0], dims[0][0], dims[0][1])
+        for L, (h, w, _) in zip(self.deblocks, dims):
+            if self._deblock_hw(L, h, w) != (H, W):
+                raise ValueError("BaseBEVBackbone: the deblock outputs do not share one resolution (torch.cat would fail in the reference)")
+        fd = getattr(self, "final_deblock", None)
+        return (H * fd.up, W * fd.up) if fd is not None else (H, W)
+
+    def run_cat(self, feats, n, tag, trunk_dtype=None):
+        """deblocks -> channel concatenation (-> the extra deblock on the concatenated map): spatial_features_2d of n images."""
+        Hc, Wc = self._deblock_hw(self.deblocks[0], feats[0][1], feats[0][2])
+        cat = self.buf(f"cat_{tag}", (n, Hc, Wc, self.cat_c), trunk_dtype or torch.float32)
+        self.run_deblocks(feats, n, cat)
+        fd = getattr(self, "final_deblock", None)
+        if fd is None:
+            return cat, Hc, Wc
+        out = self.buf(f"cat_final_{tag}", (n, Hc * fd.up, Wc * fd.up, self.cat_c), trunk_dtype or torch.float32)
+        self.conv(fd, cat, n, Hc, Wc, out)
+        return out, Hc * fd.up, Wc * fd.up
+
     def trunk(self, canvas, n, ny, nx, tag="all", block_out=None, shrink_out=None):
         """blocks -> deblocks -> shrink for n agents.  Returns (feats per level, shrink out, H, W)."""
         feats = []
@@ -1269,9 +1297,7 @@ class Where2ComEngine:
         for i in range(len(self.blocks)):
             x, h, w = self.run_block(i, x, n, h, w, tag, out=(block_out or {}).get(i))
             feats.append((x, h, w))
-        H, W = feats[0][1] * self.deblocks[0].up, feats[0][2] * self.deblocks[0].up
-        cat = self.buf(f"cat_{tag}", (n, H, W, self.cat_c), self.trunk_dtype())
-        self.run_deblocks(feats, n, cat)
+        cat, H, W = self.run_cat(feats, n, tag, self.trunk_dtype())
         s = self.run_shrink(cat, n, H, W, tag, out=shrink_out) if self.shrink else cat
         return feats, s, H, W
 
@@ -1389,6 +1415,7 @@ class Where2ComEngine:
         """Everything after the scatter; static shapes for a given record_len -> capturable."""
         B, n = len(record_len), sum(record_len)
         if (B == 1 and n >= 2 and self.agent_streams > 1 and trace is None and self.profile is None and self.multi_scale
+                and getattr(self, "final_deblock", None) is None and all(L.mode == _lib.AV2X_DECONV for L in self.deblocks)
                 and not self.fcfg["fully"] and not torch.cuda.is_current_stream_capturing()):
             return self._post_encode_groups(canvas, ny, nx, n)
         st = self.stream()
@@ -1401,7 +1428,8 @@ class Where2ComEngine:
             trace["spatial_features"] = canvas.permute(0, 3, 1, 2).clone()
             for i, (x, _, _) in enumerate(feats):
                 trace[f"block{i}"] = x.permute(0, 3, 1, 2).clone()
-            trace["spatial_features_2d"] = self.buf("cat_all", (n, H, W, self.cat_c)).permute(0, 3, 1, 2).clone()
+            trace["spatial_features_2d"] = self.buf("cat_final_all" if getattr(self, "final_deblock", None) is not None else "cat_all",
+                                                    (n, H, W, self.cat_c)).permute(0, 3, 1, 2).clone()
             trace["shrink"] = s.permute(0, 3, 1, 2).clone()
             trace["psm_single"] = psm_single.permute(0, 3, 1, 2).clone()
 
@@ -1414,16 +1442,17 @@ class Where2ComEngine:
             com = torch.tensor(1, device=self.device)
             mask = None
         else:
-            if (h0, w0) != (H, W):
-                raise NotImplementedError("mask/feature size mismatch (bilinear resize branch, where2comm_fuse.py:230) "
-                                          "is never taken by AirV2X configs")
             mask, count, smooth, rl = self.comm_mask(psm_single, n, H, W, record_len)
             com = self.comm_rate(count, rl, B, H * W)                    # where2comm_fuse.py:137,147
-            self.timed_hbm("apply_mask (in place)", n * h0 * w0 * (2 * b0.shape[-1] + 1) * 4, 0.0,
-                           lambda: _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask"))
             if trace is not None:
                 trace["comm_mask"] = mask.unsqueeze(1).clone()
                 trace["comm_map"] = smooth.unsqueeze(1).clone()
+            if (h0, w0) != (H, W):      # where2comm_fuse.py:229-235: the mask at the first block's resolution (bilinear, align_corners=False)
+                mask_r = self.buf("comm_mask_resized", (n, h0, w0))
+                _lib.check(self.lib.av2x_mask_resize_bilinear(_ptr(mask), n, H, W, h0, w0, _ptr(mask_r), st), "av2x_mask_resize_bilinear")
+                mask = mask_r
+            self.timed_hbm("apply_mask (in place)", n * h0 * w0 * (2 * b0.shape[-1] + 1) * 4, 0.0,
+                           lambda: _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask"))
 
         # masked pass through blocks 1, 2.  B == 1: agent 0 is the ego (mask == 1) and is skipped.
         skip_ego = (B == 1) and mask is not None
@@ -1460,8 +1489,7 @@ class Where2ComEngine:
             fused.append((f, h, w))
             if trace is not None:
                 trace[f"fused{i}"] = f.permute(0, 3, 1, 2).clone()
-        catf = self.buf("cat_fused", (B, H, W, self.cat_c))
-        self.run_deblocks(fused, B, catf)
+        catf, _, _ = self.run_cat(fused, B, "fused")
         fs = self.run_shrink(catf, B, H, W, "fused") if self.shrink else catf
         nh = self.heads.cout
         heads = torch.empty((B, nh, H, W), dtype=torch.float32, device=self.device)
@@ -1615,7 +1643,7 @@ class Where2ComEngine:
             ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
         sizes = [h * w * c for h, w, c in dims]
-        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, W = self.cat_hw(dims)
         send = self.buf("shard_send", (n_pad * sum(sizes),))
         meta = {"dims": dims, "n_loc": n_pad, "H": H, "W": W}
         if n == 0:   # nothing to compute; the padding is never read by the fusion
@@ -1661,6 +1689,10 @@ class Where2ComEngine:
         self.conv(self.cls_single, s, n, H, W, psm_single)
         mask, count, _, _ = self.comm_mask(psm_single, n, H, W, record_len, has_ego=has_ego)
         (b0, h0, w0), (b1, h1, w1), (b2, h2, w2) = feats
+        if (h0, w0) != (H, W):      # where2comm_fuse.py:229-235 (backbone variants whose shared map is not at the first block's resolution)
+            mask_r = self.buf("comm_mask_resized", (n, h0, w0))
+            _lib.check(self.lib.av2x_mask_resize_bilinear(_ptr(mask), n, H, W, h0, w0, _ptr(mask_r), st), "av2x_mask_resize_bilinear")
+            mask = mask_r
         _lib.check(self.lib.av2x_apply_mask(_ptr(b0), _ptr(mask), n, h0 * w0, b0.shape[-1], st), "av2x_apply_mask")
         first = 1 if has_ego else 0
         if n - first > 0:
@@ -1691,8 +1723,7 @@ class Where2ComEngine:
                 self.attn(ptrs, h * w, c, out[0])
                 fused.append((out, h, w))
                 off += n_loc * f
-            catf = self.buf("cat_fused", (1, H, W, self.cat_c))
-            self.run_deblocks(fused, 1, catf)
+            catf, _, _ = self.run_cat(fused, 1, "fused")
             fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
             heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
             self.conv(self.heads, fs, 1, H, W, heads)

@@ -511,7 +511,7 @@ def cam_features(P, sd, p, flat, training, drop_connect=None, depth_bins=0):
     ends.append(x)
     r3, r4, r5 = ends[2], ends[3], ends[4]
     u1 = up_block(P, sd, p + "up1.", r5, r4, 112, 2)
-    f = up_block(P, sd, p + "up2.", u1, r3, 40, 2)
+    f = up_block(P, sd, p + "up2.", u1, r3, 40, 2) if (p + "up2.conv.0.weight") in P else u1     # img_downsample 16: no up2 (lss_submodule.py:74-75)
     feat = T.conv_bias_act(f, P[p + "image_head.weight"], P[p + "image_head.bias"], 1, 0, False)
     if not depth_bins:
         return feat

@@ -128,7 +128,7 @@ class V2VNetEngine(Where2ComEngine):
         B, n_total = len(record_len), sum(record_len)
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         dims = self.level_dims(ny, nx)
-        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, W = self.cat_hw(dims)
         C = self.feat_c
         if C != self.v2v["in_channels"] or (H, W) != (self.v2v["conv_gru"]["H"], self.v2v["conv_gru"]["W"]):
             raise ValueError(f"v2vfusion is configured for {self.v2v['in_channels']}x{self.v2v['conv_gru']['H']}x"

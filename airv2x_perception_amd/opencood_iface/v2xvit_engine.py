@@ -496,7 +496,7 @@ class V2XViTEngine(Where2ComEngine):
         else:
             ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
-        H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, Wd = self.cat_hw(dims)
         # with a NaiveCompressor (airv2x_v2xvit.py:42-44, 122-123) the message is its ENCODER's output: 256 / ratio channels (36.0 / ratio MB per
         # agent at the default grid, half of that under autocast); the two decoder layers run on the receiving side (_gathered_maps)
         cm = self.compressor[0].cout if getattr(self, "compression", 0) else 256
@@ -630,7 +630,7 @@ class V2XViTEngine(Where2ComEngine):
         st = self.stream()
         nz = self.count_canvas(canvas, st)
         dims = self.level_dims(ny, nx)
-        H, Wd = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, Wd = self.cat_hw(dims)
         x = self.buf("vit_x", (n_total, H, Wd, 256))
         if self.msg_dtype() == torch.bfloat16:   # the shrink header's output is the (bf16) message: same rounding as the sharded frame
             x16 = self.buf("vit_x16", (n_total, H, Wd, 256), torch.bfloat16)

@@ -158,7 +158,7 @@ class When2comEngine(Where2ComEngine):
         else:
             ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
-        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, W = self.cat_hw(dims)
         C, ks = self.feat_c, self.key_fc[-1][0].shape[0]
         hwc = H * W * C
         # message layout: [n_pad warped maps | n_pad keys | the ego's query]; only the first n slots are written
@@ -232,7 +232,7 @@ class When2comEngine(Where2ComEngine):
         B, n_total = len(record_len), sum(record_len)
         canvas, ny, nx = self.encode(data_dict, record_len, slots)
         dims = self.level_dims(ny, nx)
-        H, W = dims[0][0] * self.deblocks[0].up, dims[0][1] * self.deblocks[0].up
+        H, W = self.cat_hw(dims)
         C = self.feat_c
         s_all = self.buf("w2_shrink", (n_total, H, W, C))
         self.trunk(canvas, n_total, ny, nx, shrink_out=s_all)

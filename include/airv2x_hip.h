@@ -235,6 +235,11 @@ int av2x_comm_mask(const float* psm, int32_t n, int32_t h, int32_t w, int32_t ct
 int av2x_apply_mask(float* x, const float* mask, int32_t n, int32_t hw, int32_t c,
                     av2x_stream_t stream);
 
+/* out[n,ho,wo] = F.interpolate(in[n,hi,wi], size=(ho,wo), mode="bilinear", align_corners=False): the communication mask brought to
+ * the first block's resolution when the backbone's deblocks change it (where2comm_fuse.py:229-235). */
+int av2x_mask_resize_bilinear(const float* in, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, float* out,
+                              av2x_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Per-pixel scaled-dot-product attention across the agents of one sample, ego row only.
  * Replaces AttentionFusion.forward + ScaledDotProductAttention.forward

@@ -290,17 +290,19 @@ def bin_depths(depth, mode, dmin, dmax, nbins, target):
 
 
 def cam_encode(sd, p, imgs, cam_args, training=False):
-    """CamEncode.forward (lss_submodule.py:148-189), downsample 8: imgs (BN, 4, H, W) -> (image features (BN, C, fH, fW),
+    """CamEncode.forward (lss_submodule.py:148-189), downsample 8 or 16: imgs (BN, 4, H, W) -> (image features (BN, C, fH, fW),
     depth distribution (BN, D, fH, fW) float)."""
     ds = cam_args["img_downsample"]
-    if ds != 8:
-        raise NotImplementedError("img_downsample 8 (the shipped AirV2X camera configuration)")
+    if ds not in (8, 16):
+        raise NotImplementedError("img_downsample 8 or 16 (lss_submodule.py:72-75)")
     dmin, dmax, nb = cam_args["grid_conf"]["ddiscr"]
     if cam_args.get("camera_encoder", "EfficientNet") == "Resnet101":
         f = resnet101_features(sd, p, imgs[:, :3])                                  # CamEncode_Resnet101.forward :280-310 (512 channels)
     else:
         r3, r4, r5 = effnet_features(sd, p + "trunk.", imgs[:, :3])
-        f = up_block(sd, p + "up2.", up_block(sd, p + "up1.", r5, r4, 2), r3, 2)
+        f = up_block(sd, p + "up1.", r5, r4, 2)
+        if ds == 8:                                                                 # :152-153
+            f = up_block(sd, p + "up2.", f, r3, 2)
     x_img = F.conv2d(f, sd[p + "image_head.weight"], sd[p + "image_head.bias"])
     if cam_args["use_depth_gt"]:
         d = torch.clamp(imgs[:, 3], max=dmax)                                       # :103 (clamp_max_)

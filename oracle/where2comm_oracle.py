@@ -152,10 +152,23 @@ def backbone_block(x, sd, i, layer_num):
 
 
 def backbone_deblock(x, sd, i, stride):
-    """base_bev_backbone.py:71-88: ConvTranspose2d(k=s, stride=s, no bias)+BN+ReLU."""
+    """base_bev_backbone.py:71-105: ConvTranspose2d(k=s, stride=s, no bias)+BN+ReLU, or -- stride < 1, a "deblock" that down-samples --
+    Conv2d(k, stride=k, no bias)+BN+ReLU with k = round(1 / stride)."""
     p = f"backbone.deblocks.{i}"
-    x = F.conv_transpose2d(x, sd[f"{p}.0.weight"], None, stride=stride)
+    if stride >= 1:
+        x = F.conv_transpose2d(x, sd[f"{p}.0.weight"], None, stride=int(stride))
+    else:
+        x = F.conv2d(x, sd[f"{p}.0.weight"], None, stride=int(round(1.0 / stride)))
     return F.relu(_bn(x, sd, f"{p}.1"))
+
+
+def backbone_final_deblock(x, sd, bb_cfg):
+    """base_bev_backbone.py:107-121, 151-152: one more ConvTranspose2d + BN + ReLU on the concatenated map when ``upsample_strides`` has
+    an entry beyond the levels."""
+    nlev = len(bb_cfg["layer_nums"])
+    if len(bb_cfg.get("upsample_strides", [])) <= nlev:
+        return x
+    return backbone_deblock(x, sd, nlev, bb_cfg["upsample_strides"][-1])
 
 
 def backbone_forward(x, sd, bb_cfg):
@@ -165,7 +178,7 @@ def backbone_forward(x, sd, bb_cfg):
         x = backbone_block(x, sd, i, n)
         blocks.append(x)
         ups.append(backbone_deblock(x, sd, i, bb_cfg["upsample_strides"][i]))
-    return torch.cat(ups, dim=1), blocks
+    return backbone_final_deblock(torch.cat(ups, dim=1), sd, bb_cfg), blocks
 
 
 # ---------------------------------------------------------------- a8: shrink header
@@ -263,19 +276,21 @@ def where2comm_fuse(x, psm_single, record_len, sd, args, trace=None, topk=None, 
                 masks, rate, maps = communication(_split(psm_single, record_len), sd, fcfg["communication"], topk)
                 if comm_mask is not None:   # replay a recorded mask (the top-K / threshold cut is discontinuous in the logits)
                     masks = comm_mask.to(x.dtype).reshape(masks.shape)
+                if trace is not None:
+                    trace["comm_mask"] = masks          # Communication's output, before any resize
+                    trace["comm_map"] = maps
                 if x.shape[-1] != masks.shape[-1]:
                     masks = F.interpolate(masks, size=(x.shape[-2], x.shape[-1]), mode="bilinear",
                                           align_corners=False)
+                    if trace is not None:
+                        trace["comm_mask_resized"] = masks
                 x = x * masks
-                if trace is not None:
-                    trace["comm_mask"] = masks
-                    trace["comm_map"] = maps
         fused = torch.stack([attention_fusion(xb) for xb in _split(x, record_len)])
         if trace is not None:
             trace[f"masked_block{i}"] = x
             trace[f"fused{i}"] = fused
         ups.append(backbone_deblock(fused, sd, i, bb["upsample_strides"][i]))
-    return torch.cat(ups, dim=1), rate
+    return backbone_final_deblock(torch.cat(ups, dim=1), sd, bb), rate      # where2comm_fuse.py:260-263
 
 
 def where2comm_fuse_single(x, psm_single, record_len, sd, args, trace=None, topk=None, comm_mask=None):

@@ -28,6 +28,9 @@ def cam_case(fx):
     hy = synth.multimodal_hypes(mods, None if rng == synth.DEFAULT_RANGE else rng, final_dim, bool(int(fx["use_depth_gt"])),
                                 camera_encoder=str(fx["camera_encoder"]) if "camera_encoder" in fx else "EfficientNet")
     args = hy["model"]["args"]
+    if "img_downsample" in fx:          # 16: CamEncode without up2 (lss_submodule.py:74-75)
+        for t in synth.AGENT_TYPES:
+            args[t]["cam"]["img_downsample"] = int(fx["img_downsample"])
     spec = synth.where2com_param_spec(args)
     assert len(spec) == int(fx["spec_len"])
     sd = synth.synthetic_state_dict(spec, seed=int(fx["seed"]))
@@ -77,7 +80,8 @@ def test_effnet_block_table():
     assert [dict(cin=r[0], cout=r[1], k=r[2], s=r[3], expand=r[4], se=r[5], pad=r[6]) for r in rows] == cam.b0_block_table()
 
 
-@pytest.mark.parametrize("name", ["w2c_cam_small", "w2c_cam_small_softmax", "w2c_cam_small_resnet101", "w2c_cam_small_resnet101_softmax"])
+@pytest.mark.parametrize("name", ["w2c_cam_small", "w2c_cam_small_softmax", "w2c_cam_small_resnet101", "w2c_cam_small_resnet101_softmax",
+                                  "w2c_cam_small_ds16", "w2c_cam_small_ds16_softmax"])
 def test_oracle_matches_reference_fixture(name):
     fx = load_fixture(name)
     hy, args, sd, dd, types = cam_case(fx)
@@ -333,7 +337,8 @@ def _run_model(fx_name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["w2c_cam_small", "w2c_cam_small_softmax", "w2c_cam_small_resnet101", "w2c_cam_small_resnet101_softmax"])
+@pytest.mark.parametrize("name", ["w2c_cam_small", "w2c_cam_small_softmax", "w2c_cam_small_resnet101", "w2c_cam_small_resnet101_softmax",
+                                  "w2c_cam_small_ds16", "w2c_cam_small_ds16_softmax"])     # ds16: img_downsample 16, CamEncode without up2
 def test_hip_model_small_vs_oracle_and_fixture(name):
     fx, (hy, args, sd, dd, types), out, trace, cams = _run_model(name)
     otr = {}

@@ -13,7 +13,10 @@ from oracle import voxelize_oracle as vox
 from oracle import where2comm_oracle as orc
 from tests.helpers import assert_close, load_fixture
 
-NAMES = ["w2c_small_single_c2", "w2c_small_single", "w2c_small_multi_c4", "w2c_small_single_fully", "w2c_small_multi_fully"]
+NAMES = ["w2c_small_single_c2", "w2c_small_single", "w2c_small_multi_c4", "w2c_small_single_fully", "w2c_small_multi_fully",
+         # BaseBEVBackbone variants inside the full model (base_bev_backbone.py:87-121): the extra deblock on the concatenated map, deblocks that
+         # down-sample -- the shared map is at twice / half the first block's resolution and the mask takes where2comm_fuse.py:229-235
+         "w2c_small_final_deblock", "w2c_small_down_deblock"]
 RTOL, ATOL = 2e-4, 2e-4
 
 
@@ -27,6 +30,10 @@ def case(fx):
     a["modality_fusion"]["compression"] = int(fx["compression"])
     if int(fx["compression"]):
         a["compression"] = int(fx["compression"])
+    if "upsample_strides" in fx:
+        us = [float(v) for v in fx["upsample_strides"]]
+        a["modality_fusion"]["base_bev_backbone"]["upsample_strides"] = [int(v) if v >= 1 else v for v in us]
+        a["modality_fusion"]["base_bev_backbone"]["num_upsample_filter"] = [int(v) for v in fx["num_upsample_filter"]]
     spec = synth.where2com_param_spec(a)
     assert [k for k, _, _ in spec] == [str(k) for k in fx["spec_keys"]]
     sd = synth.synthetic_state_dict(spec, seed=int(fx["seed"]))
@@ -136,3 +143,28 @@ def test_fully_connected_frame_through_the_agent_sharded_stages():
     for k in ("psm", "rm", "obj"):
         assert torch.equal(out[k], ref[k]), k
     assert out["comm_rate"] == ref["comm_rate"] == int(fx["comm_rate"]) and int(out["com"]) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hi,wi,ho,wo", [(2, 64, 128, 32, 64), (3, 16, 32, 32, 64), (1, 25, 88, 100, 352), (2, 7, 9, 13, 5), (1, 1, 1, 4, 3)])
+def test_mask_resize_kernel_matches_interpolate(n, hi, wi, ho, wo):
+    """av2x_mask_resize_bilinear = F.interpolate(mode="bilinear", align_corners=False) (where2comm_fuse.py:229-235): bit-exact for binary
+    masks at power-of-two ratios (every weight and product is exact), 1e-6 for arbitrary values and sizes."""
+    import torch.nn.functional as F
+    from ctypes import c_void_p
+
+    from airv2x_perception_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n * 1000 + hi + wo)
+    for binary in (True, False):
+        m = (torch.rand(n, hi, wi, generator=g) > 0.4).float() if binary else torch.rand(n, hi, wi, generator=g)
+        want = F.interpolate(m.unsqueeze(1), size=(ho, wo), mode="bilinear", align_corners=False)[:, 0]
+        md = m.cuda()
+        out = torch.full((n, ho, wo), float("nan"), device="cuda")
+        _lib.check(lib.av2x_mask_resize_bilinear(c_void_p(md.data_ptr()), n, hi, wi, ho, wo, c_void_p(out.data_ptr()),
+                                                 c_void_p(torch.cuda.current_stream().cuda_stream)), "av2x_mask_resize_bilinear")
+        pow2 = (hi * 2 == ho or ho * 2 == hi) and (wi * 2 == wo or wo * 2 == wi)
+        if binary and pow2:
+            assert torch.equal(out.cpu(), want)
+        else:
+            assert float((out.cpu() - want).abs().max()) <= 1e-6
