@@ -1628,9 +1628,6 @@ class Where2ComEngine:
         agent count is the largest count of any rank: an uneven frame pads the message, a rank without agents sends
         only padding).
         Returns (send flat f32, stats int64[2] = [mask ones before ego override, canvas non-zeros], meta)."""
-        if not self.multi_scale:
-            raise NotImplementedError("agent-sharded single-scale Where2comm (multi_scale: false): the message would be the masked 256-channel "
-                                      "map plus its mask; run this variant unsharded")
         n, record_len, slots = self.shard_frame_agents(data_dict_local)
         n_pad = n if n_pad is None else int(n_pad)
         if n_pad < max(n, 1):
@@ -1642,8 +1639,32 @@ class Where2ComEngine:
         else:
             ny, nx = self.canvas_dims()
         dims = self.level_dims(ny, nx)
-        sizes = [h * w * c for h, w, c in dims]
         H, W = self.cat_hw(dims)
+        if not self.multi_scale:
+            # single-scale Where2comm (multi_scale: false): ONE level -- the shrunk (compressed + decompressed) 256-channel map times the
+            # agent's communication mask, 36.0 MB per agent at the default grid.  The mask multiplies the DECODED map
+            # (airv2x_where2com.py:147-150, where2comm_fuse.py:264-275), so the compressor runs whole on the sender.
+            C = self.feat_c
+            send = self.buf("shard_send", (n_pad * H * W * C,))
+            meta = {"dims": [(H, W, C)], "n_loc": n_pad, "H": H, "W": W}
+            if n == 0:
+                return send, torch.zeros(2, dtype=torch.int64, device=self.device), meta
+            st = self.stream()
+            nz = self.count_canvas(canvas, st)
+            s = send[:n * H * W * C].view(n, H, W, C)
+            self.trunk(canvas, n, ny, nx, shrink_out=s)
+            psm_single = self.buf("psm_single", (n, H, W, self.A * self.C))
+            self.conv(self.cls_single, s, n, H, W, psm_single)
+            if self.compressor:
+                self.run_compressor(s, n, H, W)
+            if self.fcfg["fully"]:
+                ones = torch.zeros((), dtype=torch.int64, device=self.device)
+            else:
+                mask, count, _, _ = self.comm_mask(psm_single, n, H, W, record_len, has_ego=has_ego)
+                _lib.check(self.lib.av2x_apply_mask(_ptr(s), _ptr(mask), n, H * W, C, st), "av2x_apply_mask")
+                ones = count.sum().to(torch.int64)
+            return send, torch.stack([ones, nz[0]]), meta
+        sizes = [h * w * c for h, w, c in dims]
         send = self.buf("shard_send", (n_pad * sum(sizes),))
         meta = {"dims": dims, "n_loc": n_pad, "H": H, "W": W}
         if n == 0:   # nothing to compute; the padding is never read by the fusion
@@ -1723,8 +1744,11 @@ class Where2ComEngine:
                 self.attn(ptrs, h * w, c, out[0])
                 fused.append((out, h, w))
                 off += n_loc * f
-            catf, _, _ = self.run_cat(fused, 1, "fused")
-            fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
+            if not self.multi_scale:        # single scale: the heads read the fused map directly (airv2x_where2com.py:163-169)
+                fs = fused[0][0]
+            else:
+                catf, _, _ = self.run_cat(fused, 1, "fused")
+                fs = self.run_shrink(catf, 1, H, W, "fused") if self.shrink else catf
             heads = torch.empty((1, self.heads.cout, H, W), dtype=torch.float32, device=self.device)
             self.conv(self.heads, fs, 1, H, W, heads)
             return heads

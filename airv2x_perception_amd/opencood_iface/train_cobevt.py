@@ -31,6 +31,9 @@ def _compressor(P, sd, x, prefix="naive_compressor."):
     for conv, bn in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
         x = T.conv_bn_act(x, P[f"{prefix}{conv}.weight"], P[f"{prefix}{bn}.weight"], P[f"{prefix}{bn}.bias"], 1, 1,
                           running=_running(sd, prefix + bn, 1))
+        # ... but the batch MEAN the BatchNorm tracks is that of conv(x) + bias: the running mean moves by momentum x bias on top
+        with torch.no_grad():
+            sd[f"{prefix}{bn}.running_mean"].add_(P[f"{prefix}{conv}.bias"].detach(), alpha=T.BN_MOMENTUM)
     return x
 
 

@@ -152,8 +152,6 @@ def _forward_train(model, data_dict, topk=None, mask=None, trace=None):
     dev = next(iter(P.values())).device
     if dev.type != "cuda":
         raise RuntimeError("Airv2xWhere2com (MI355X build) has no CPU path: move the module to the GPU (model.to('cuda'))")
-    if not model.multi_scale:
-        raise NotImplementedError("training: the multi-scale fusion (every shipped AirV2X Where2Comm config)")
     r = _runner(dev)
     # torch.autocast around the forward (tools/train.py:118) or model.amp = True -> bf16 matrix-core operands for this step's
     # convolutions, forward and data gradients alike (train_ops.AMP_STEP); a GradScaler on top works unchanged (fp32 gradients)
@@ -168,6 +166,12 @@ def _forward_train(model, data_dict, topk=None, mask=None, trace=None):
     canvas, nz = encode_train(args, P, sd, data_dict, slots, n, dev, r, model)
 
     layer_nums, strides, ups = bb["layer_nums"], bb["layer_strides"], bb["upsample_strides"]
+    if len(ups) != len(layer_nums) or any(u < 1 for u in ups):
+        raise NotImplementedError("training: BaseBEVBackbone with down-sampling deblocks / the extra final deblock (eval mode runs them)")
+    from ..synth import model_compression
+    compression = model_compression(args)          # NaiveCompressor(256, args["compression"]) (airv2x_where2com.py:50-52)
+    if not model.multi_scale:
+        return _forward_train_single_scale(model, args, P, sd, dev, r, data_dict, canvas, nz, record_len, compression, topk, mask, trace)
     # ---- blocks[0] once, with the graph (the fusion pass's blocks[0] sees the same canvas): three identical updates
     y0 = _block(P, sd, 0, canvas, layer_nums[0], strides[0], 3)
     # ---- the two full backbone passes + shrink + cls_head: mask only, no gradient
@@ -178,6 +182,9 @@ def _forward_train(model, data_dict, topk=None, mask=None, trace=None):
         cat = torch.cat([_deblock(P, sd, i, feats[i], 2) for i in range(3)], -1)
         s = _shrink(P, mf["shrink_header"], cat)
         psm_single = T.conv_raw(s, P["cls_head.weight"], 1, 0, None, P["cls_head.bias"].detach(), 0)      # (n, H, W, A*C)
+        if compression:     # airv2x_where2com.py:147-150: the compressor runs on the shrunk map in this branch too; its output is dead for
+            from .train_cobevt import _compressor           # the multi-scale fusion (no gradient reaches it) but its BatchNorms see the batch
+            _compressor(P, sd, s)
         H, W = psm_single.shape[1:3]
         if fcfg["fully"]:
             mask, com = None, torch.tensor(1, device=dev)
@@ -222,6 +229,70 @@ def _forward_train(model, data_dict, topk=None, mask=None, trace=None):
     out = {"psm": outs[0], "rm": outs[1]}
     if args["obj_head"]:
         out["obj"] = outs[2]
+    out.update({"mask": 0, "com": com, "comm_rate": int(nz[0].item()) if model.sync_comm_rate else nz[0]})
+    return out
+
+
+def _comm_mask_train(r, args, P, dev, psm_single, n, record_len, topk, mask, trace):
+    """The training branch of Communication (where2comm_fuse.py:104-121) on the single-agent scores -> (mask (n, H, W) float, com)."""
+    fcfg = args["where2com_fusion"]
+    B = len(record_len)
+    H, W = psm_single.shape[1:3]
+    if topk is None:
+        topk = [int(H * W * random.uniform(0, 1)) for _ in range(B)]      # where2comm_fuse.py:106, one draw per sample
+    r.A, r.C = args["anchor_number"], args["num_class"]
+    comm = fcfg["communication"]
+    if "gaussian_smooth" in comm:
+        gw = P["fusion_net.naive_communication.gaussian_filter.weight"].detach()
+        r.gauss_w, r.gauss_b, r.gauss_k = gw.reshape(-1).contiguous(), P["fusion_net.naive_communication.gaussian_filter.bias"].detach(), int(gw.shape[-1])
+    else:
+        r.gauss_w, r.gauss_b, r.gauss_k = torch.ones(1, device=dev), torch.zeros(1, device=dev), 1
+    r.threshold = float(comm["threshold"] or 0.0)
+    r._frame += 1
+    cmask, count, _, rl = r.comm_mask(psm_single, n, H, W, record_len, topk=topk)
+    if trace is not None:
+        trace["comm_mask"] = cmask.clone()
+        trace["psm_single"] = psm_single
+    m = cmask.clone() if mask is None else mask.to(dev, torch.float32).reshape(n, H, W).contiguous()
+    return m, r.comm_rate(count, rl, B, H * W)
+
+
+def _forward_train_single_scale(model, args, P, sd, dev, r, data_dict, canvas, nz, record_len, compression, topk, mask, trace):
+    """``multi_scale: false`` in train mode (airv2x_where2com.py:117-179 with :163-166; where2comm_fuse.py:264-286): the backbone runs twice
+    on the canvas (:119, :124 -- identical batch statistics, two running-statistic updates), the second pass carries the graph; shrink
+    header -> single-agent scores (mask only) -> NaiveCompressor (if any, with the graph: it is live here) -> x mask -> one per-pixel
+    attention per sample -> heads on the fused map."""
+    mf = args["modality_fusion"]
+    bb = mf["base_bev_backbone"]
+    fcfg = args["where2com_fusion"]
+    layer_nums, strides = bb["layer_nums"], bb["layer_strides"]
+    B, n = len(record_len), sum(record_len)
+    x, ups_out = canvas, []
+    for i in range(len(layer_nums)):
+        x = _block(P, sd, i, x, layer_nums[i], strides[i], 2)
+        ups_out.append(_deblock(P, sd, i, x, 2))
+    s = _shrink(P, mf["shrink_header"], torch.cat(ups_out, -1))
+    with torch.no_grad():
+        psm_single = T.conv_raw(s.detach(), P["cls_head.weight"], 1, 0, None, P["cls_head.bias"].detach(), 0)
+    if compression:
+        from .train_cobevt import _compressor
+        s = _compressor(P, sd, s)
+    if fcfg["fully"]:
+        m, com = None, torch.tensor(1, device=dev)
+    else:
+        with torch.no_grad():
+            m, com = _comm_mask_train(r, args, P, dev, psm_single, n, record_len, topk, mask, trace)
+    xm = T.MaskMul.apply(s, m) if m is not None else s
+    outs, a0 = [], 0
+    for k in record_len:
+        outs.append(T.PixelAttn.apply(xm[a0:a0 + k]))
+        a0 += k
+    fused = torch.stack(outs)
+    names = ["cls_head", "reg_head"] + (["obj_head"] if args["obj_head"] else [])
+    hs = _heads(P, names, fused)
+    out = {"psm": hs[0], "rm": hs[1]}
+    if args["obj_head"]:
+        out["obj"] = hs[2]
     out.update({"mask": 0, "com": com, "comm_rate": int(nz[0].item()) if model.sync_comm_rate else nz[0]})
     return out
 

@@ -57,6 +57,11 @@ def train_case_from_fixture(fx):
     types = [str(t) for t in fx["types"]]
     hy = synth.default_hypes(rng)
     args = hy["model"]["args"]
+    if "multi_scale" in fx:         # round 6: the single-scale / compressed variants (tools/gen_golden.py train_variants)
+        args["where2com_fusion"]["multi_scale"] = bool(int(fx["multi_scale"]))
+        args["modality_fusion"]["compression"] = int(fx["compression"])
+        if int(fx["compression"]):
+            args["compression"] = int(fx["compression"])
     sd = synth.synthetic_state_dict(synth.where2com_param_spec(args), seed=int(fx["seed"]))
     pp = hy["preprocess"]
     voxd = []

@@ -231,7 +231,9 @@ def _loss(args):
     return PointPillarLossMultiClass({"cls_weight": 1.0, "reg": 2.0, "num_class": args["num_class"]})
 
 
-@pytest.mark.parametrize("name", ["train_small_n3", "train_small_n2", "train_full_n4"])
+@pytest.mark.parametrize("name", ["train_small_n3", "train_small_n2", "train_full_n4",
+                                  # round 6: multi_scale false (+ a live NaiveCompressor), and the compressor beside the multi-scale fusion
+                                  "train_small_single_c2", "train_small_single", "train_small_multi_c4"])
 def test_training_step_matches_the_reference(name):
     from airv2x_perception_amd.opencood_iface.train_where2com import forward_train
     fx = load_fixture(name)
@@ -263,7 +265,15 @@ def test_training_step_matches_the_reference(name):
     assert abs(float(total.detach()) - fx["losses"][0]) < 2e-4 * abs(fx["losses"][0])
     P = dict(model.named_parameters())
     keys = [str(k) for k in fx["grad_keys"]]
-    assert sorted(k for k, p in P.items() if p.grad is not None) == sorted(keys)
+    # a convolution bias in front of a batch-statistics BatchNorm (NaiveCompressor) has an exactly-zero gradient: the reference reports rounding
+    # noise for it, this build none (tests/test_gpu_train_cobevt.py); with the compressor beside the multi-scale fusion nothing of it gets one
+    noise = {k for k in keys if float(fx["g64max:" + k]) < 1e-12}
+    assert all(k.startswith("naive_compressor.") and k.endswith(".bias") for k in noise), sorted(noise)
+    keys = [k for k in keys if k not in noise]
+    have = sorted(k for k, p in P.items() if p.grad is not None)
+    assert set(keys) <= set(have), sorted(set(keys) - set(have))
+    for k in set(have) - set(keys):
+        assert float(P[k].grad.abs().max()) == 0.0, k
     # gradients.  The graph is ~25 ReLUs deep with a max over points at the bottom: an activation within fp32 rounding of zero
     # falls on either side of the kink in ANY fp32 evaluation order, so fp32 gradients are only defined up to that noise.  The
     # fixture carries the yardstick: the same step in float64 (``g64:*``) and how far the REFERENCE's own fp32 gradients are

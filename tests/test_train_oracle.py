@@ -21,7 +21,7 @@ def oracle_step(args, sd, dd, tgt, K, loss_args=(7, 1.0, 2.0)):
     return o, losses, sd
 
 
-@pytest.mark.parametrize("name", ["train_small_n3", "train_small_n2"])
+@pytest.mark.parametrize("name", ["train_small_n3", "train_small_n2", "train_small_single_c2", "train_small_single", "train_small_multi_c4"])
 def test_train_oracle_reproduces_the_reference_step(name):
     fx = load_fixture(name)
     hy, args, sd, dd, tgt = train_case_from_fixture(fx)

@@ -1578,7 +1578,7 @@ def comm_train_golden(name="comm_train"):
     print(f"[{name}] wrote {path}")
 
 
-def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01, head_stride=1):
+def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01, head_stride=1, multi_scale=True, compression=0):
     """One TRAINING step of the reference's Airv2xWhere2com (train mode: BatchNorm batch statistics + running-stat updates,
     random top-K communication mask from python's seeded `random`) + PointPillarLossMultiClass + torch autograd:
     head maps, losses, the gradient of every parameter (strided samples + fp64 sums) and every buffer after the step.
@@ -1594,9 +1594,16 @@ def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01,
 
     hy_ref = load_ref_hypes(lidar_range)
     hy = synth.default_hypes(lidar_range)
+    for h_ in (hy_ref, hy):       # round 6: the variants no shipped YAML selects (single-scale fusion, NaiveCompressor)
+        a_ = h_["model"]["args"]
+        a_["where2com_fusion"]["multi_scale"] = bool(multi_scale)
+        a_["modality_fusion"]["compression"] = int(compression)
+        if compression:
+            a_["compression"] = int(compression)
     args = hy["model"]["args"]
     model = Airv2xWhere2com(hy_ref["model"]["args"]).train()
     spec = synth.where2com_param_spec(args)
+    assert [k for k, _, _ in spec] == list(model.state_dict().keys())
     sd = synth.synthetic_state_dict(spec, seed=seed)
     model.load_state_dict(sd, strict=True)
     rng = lidar_range or synth.DEFAULT_RANGE
@@ -1642,7 +1649,7 @@ def train_golden(name, lidar_range, types, n_points, seed, rseed, pos_frac=0.01,
           "losses": np.asarray([float(total), crit.loss_dict["reg_loss"], crit.loss_dict["conf_loss"]], np.float64),
           "mask": np.packbits(cap["comm"][0].detach().numpy().astype(np.uint8).reshape(-1)),
           "mask_shape": np.asarray(cap["comm"][0].shape, np.int64), "com": np.float64(float(out["com"])),
-          "comm_rate": np.int64(out["comm_rate"])}
+          "comm_rate": np.int64(out["comm_rate"]), "multi_scale": np.int64(bool(multi_scale)), "compression": np.int64(compression)}
     hs = head_stride
     fx["head_stride"] = np.int64(hs)
     for k in ("psm", "rm", "obj"):
@@ -2569,6 +2576,10 @@ GROUPS = {
     "comm_train": lambda: comm_train_golden(),
     "train": lambda: (train_golden("train_small_n3", SMALL, ["vehicle", "rsu", "drone"], 700, 11, 3),
                       train_golden("train_small_n2", SMALL, ["vehicle", "vehicle"], 900, 12, 4)),
+    # round 6: one training step of the reference in the single-scale / compressed configurations
+    "train_variants": lambda: (train_golden("train_small_single_c2", SMALL, ["vehicle", "rsu", "drone"], 700, 81, 7, multi_scale=False, compression=2),
+                               train_golden("train_small_single", SMALL, ["vehicle", "vehicle"], 900, 82, 8, multi_scale=False),
+                               train_golden("train_small_multi_c4", SMALL, ["vehicle", "drone"], 900, 83, 9, multi_scale=True, compression=4)),
     # BASELINE configs[1]'s frame (4 agents x 8192 points, 704 x 200 grid): one training step of the reference (minutes of CPU)
     "train_full": lambda: train_golden("train_full_n4", None, ["vehicle", "vehicle", "rsu", "drone"], 8192, 13, 5, pos_frac=0.002,
                                        head_stride=4),
