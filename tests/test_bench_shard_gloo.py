@@ -73,6 +73,12 @@ def test_bench_multi_rank_default_is_the_agent_sharded_frame(tmp_path, world):
     assert res["config"]["frames_in_flight"] == 2
     counts = {2: [2, 2], 3: [2, 1, 1]}[world]
     assert str(counts) in res["config"]["parallelism"]
+    # round 6: the run describes its own exchange -- the process group's backend and rank count, the collective it took and every rank's
+    # MEASURED message bytes (what `--dry-run` predicts), so that a SCALE record can be checked without the code
+    par = res["config"]["parallelism"]
+    assert "backend gloo" in par and f"{world} rank(s), collective" in par and "message bytes per rank and frame [" in par
+    sizes = json.loads(par.split("message bytes per rank and frame ")[1].split("]")[0] + "]")
+    assert len(sizes) == world and all(isinstance(v, int) and v > 0 for v in sizes) and len(set(sizes)) == 1      # padded to the largest rank
     assert "single_frame_latency" in res and res["single_frame_latency"]["ms_per_frame"] > 0
     # rank 0 was asked for its balanced slice of the 4-agent frame
     assert got["log"][0] == [4, list(range(counts[0]))]
