@@ -138,8 +138,8 @@ def _forward_train(model, data_dict):
     r = _runner(dev)
     mf = args["modality_fusion"]
     bb, cfg = mf["base_bev_backbone"], args["v2vfusion"]
-    if mf.get("compression", 0):
-        raise NotImplementedError("compression > 0 is not enabled in any shipped AirV2X config")
+    from ..synth import model_compression
+    compression = model_compression(args)          # NaiveCompressor(256, args["compression"]) behind the shrink header (airv2x_v2vnet.py:42-44)
     record_len, slots = frame_layout(args["collaborators"], data_dict)
     B, n = len(record_len), sum(record_len)
     if n == 0:
@@ -151,6 +151,9 @@ def _forward_train(model, data_dict):
         feats.append(x)
     s = torch.cat([_deblock(P, sd, i, f, 1) for i, f in enumerate(feats)], -1)
     s = _shrink(P, mf["shrink_header"], s)
+    if compression:
+        from .train_cobevt import _compressor
+        s = _compressor(P, sd, s)
     H, W = s.shape[1:3]
     pair = data_dict["img_pairwise_t_matrix_collab"]
     pair = pair.detach().cpu().numpy() if isinstance(pair, torch.Tensor) else np.asarray(pair)

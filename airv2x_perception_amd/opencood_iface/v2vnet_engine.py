@@ -35,18 +35,20 @@ class V2VNetEngine(Where2ComEngine):
         mf = args["modality_fusion"]
         self.bb, self.sh = mf["base_bev_backbone"], mf["shrink_header"]
         self.fcfg = {"fully": False}
-        if mf.get("compression", 0):
-            raise NotImplementedError("compression > 0: the reference's constructor reads args['compression'], which no "
-                                      "AirV2X configuration defines (airv2x_v2vnet.py:41-43)")
+        from ..synth import model_compression
+        self.compression = model_compression(args)     # airv2x_v2vnet.py:42-44, 180-181: NaiveCompressor(256, args["compression"]) behind the shrink header
+        if self.compression and (256 % self.compression or (256 // self.compression) % 32):
+            raise NotImplementedError(f"compression {self.compression}: 256/ratio must be a multiple of 32 channels")
         self.v2v = args["v2vfusion"]
         if self.v2v["conv_gru"]["num_layers"] != 1 or not self.v2v["gru_flag"]:
             raise NotImplementedError("one ConvGRU layer with gru_flag (every shipped v2vfusion block)")
         if self.v2v["agg_operator"] not in ("avg", "max"):
             raise NotImplementedError("agg_operator 'weight' needs a weight input the AirV2X forward never passes (airv2x_v2vnet.py:209)")
 
-    FUSION_WEIGHTS = ("msg_a", "msg_b", "gru_u", "gru_c", "mlp_lin")
+    FUSION_WEIGHTS = ("msg_a", "msg_b", "gru_u", "gru_c", "mlp_lin", "compressor")
 
     def _load_fusion(self, sd, up, prefix="fusion_net."):
+        self.compressor = self._load_compressor(sd, up) if getattr(self, "compression", 0) else None
         c = self.v2v["in_channels"]
         wm, bm = sd[prefix + "msg_cnn.weight"].detach().float(), sd[prefix + "msg_cnn.bias"].detach().float()
 
@@ -135,6 +137,8 @@ class V2VNetEngine(Where2ComEngine):
                              f"{self.v2v['conv_gru']['W']}, the trunk delivers {C}x{H}x{W}")
         s_all = self.buf("v2v_shrink", (n_total, H, W, C))
         self.trunk(canvas, n_total, ny, nx, shrink_out=s_all)
+        if self.compression:                                   # airv2x_v2vnet.py:180-181
+            self.run_compressor(s_all, n_total, H, W)
         pair = data_dict["img_pairwise_t_matrix_collab"]
         pair = pair.detach().cpu().numpy() if isinstance(pair, torch.Tensor) else np.asarray(pair)
         if pair.shape[0] != B:

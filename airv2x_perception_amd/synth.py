@@ -819,7 +819,7 @@ def v2vnet_param_spec(args):
     base = where2com_param_spec(w2c_like)
     trunk = [e for e in base if not e[0].startswith(("fusion_net.", "naive_compressor.", "cls_head", "reg_head", "obj_head"))]
     heads = [e for e in base if e[0].startswith(("cls_head", "reg_head", "obj_head"))]
-    return trunk + v2vnet_fusion_spec(args["v2vfusion"], "fusion_net.") + heads
+    return trunk + compressor_param_spec(256, model_compression(args)) + v2vnet_fusion_spec(args["v2vfusion"], "fusion_net.") + heads
 
 
 # --------------------------------------------------------------------------

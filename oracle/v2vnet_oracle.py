@@ -82,6 +82,8 @@ def v2vnet_forward(data_dict, sd, args, trace=None):
     feats, record_len = w2c.extract_features(data_dict, sd, args)
     sf2d, _ = w2c.backbone_forward(feats, sd, mf["base_bev_backbone"])
     s = w2c.shrink_conv(sf2d, sd, mf["shrink_header"]) if mf["shrink_header"]["use"] else sf2d
+    if mf.get("compression", 0) > 0:      # NaiveCompressor(256, args["compression"]) (airv2x_v2vnet.py:42-44, 180-181)
+        s = w2c.naive_compress(s, sd)
     fused, rate = v2vnet_fuse(s, record_len, data_dict["img_pairwise_t_matrix_collab"], sd, args["v2vfusion"], trace=trace)
     out = {"psm": w2c.head(fused, sd, "cls_head"), "rm": w2c.head(fused, sd, "reg_head")}
     if args["obj_head"]:

@@ -16,6 +16,8 @@ def _case(fx):
     types = [str(t) for t in fx["types"]]
     hy = synth.default_hypes_v2vnet(rng, agg=str(fx["agg"]))
     args = hy["model"]["args"]
+    if "compression" in fx and int(fx["compression"]):      # NaiveCompressor behind the shrink header (airv2x_v2vnet.py:42-44, 180-181)
+        args["modality_fusion"]["compression"] = args["compression"] = int(fx["compression"])
     spec = synth.v2vnet_param_spec(args)
     assert [k for k, _, _ in spec] == [str(k) for k in fx["spec_keys"]]
     sd = synth.synthetic_state_dict(spec, seed=int(fx["seed"]))
@@ -29,7 +31,7 @@ def _case(fx):
     return hy, args, sd, dd
 
 
-@pytest.mark.parametrize("name", ["v2vnet_small_n3", "v2vnet_small_n2_max"])
+@pytest.mark.parametrize("name", ["v2vnet_small_n3", "v2vnet_small_n2_max", "v2vnet_small_n2_c2"])
 def test_oracle_matches_reference_golden(name):
     fx = load_fixture(name)
     hy, args, sd, dd = _case(fx)
@@ -63,7 +65,7 @@ def test_zero_hidden_state_reduces_the_conv_gru_to_two_half_convolutions():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["v2vnet_small_n3", "v2vnet_small_n2_max", "v2vnet_full_n3"])
+@pytest.mark.parametrize("name", ["v2vnet_small_n3", "v2vnet_small_n2_max", "v2vnet_full_n3", "v2vnet_small_n2_c2"])
 def test_gpu_forward_matches_golden(name):
     from airv2x_perception_amd.opencood_iface import Airv2xV2VNet, create_model
     fx = load_fixture(name)

@@ -1017,7 +1017,7 @@ def run_when2com_case(name, lidar_range, types, n_points, seed, mode="softmax", 
     print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def run_v2vnet_case(name, lidar_range, types, n_points, seed, agg="avg", head_stride=1, big_stride=4):
+def run_v2vnet_case(name, lidar_range, types, n_points, seed, agg="avg", head_stride=1, big_stride=4, compression=0):
     """Airv2xV2VNet (models/airv2x_v2vnet.py) on the real reference vs oracle/v2vnet_oracle.py.  No AirV2X YAML ships for
     it: the reference is constructed from the Where2Comm AirV2X YAML's trunk + a `v2vfusion` block (the OPV2V one re-sized
     to the AirV2X feature map), exactly the dict synth.default_hypes_v2vnet builds."""
@@ -1043,6 +1043,9 @@ def run_v2vnet_case(name, lidar_range, types, n_points, seed, agg="avg", head_st
     a_ref.pop("where2com_fusion")
     a_ref["v2vfusion"] = synth.clone_hypes(args["v2vfusion"])
     a_ref["backbone_fix"] = False
+    if compression:     # round 6: NaiveCompressor(256, args["compression"]) behind the shrink header (airv2x_v2vnet.py:42-44, 180-181)
+        for a_ in (a_ref, args):
+            a_["modality_fusion"]["compression"] = a_["compression"] = int(compression)
     check_hypes(a_ref, args)
     model = Airv2xV2VNet(a_ref).eval()
     spec = synth.v2vnet_param_spec(args)
@@ -1074,7 +1077,8 @@ def run_v2vnet_case(name, lidar_range, types, n_points, seed, agg="avg", head_st
     assert float(out["comm_rate"]) == float(o["comm_rate"]) and out["mask"] == 0
     fx = {"seed": np.int64(seed), "lidar_range": np.asarray(rng, np.float64), "types": np.asarray(types),
           "n_points": np.int64(n_points), "spec_keys": np.asarray([k for k, _, _ in spec]), "agg": np.asarray(agg),
-          "head_stride": np.int64(head_stride), "big_stride": np.int64(big_stride), "comm_rate": np.float64(out["comm_rate"])}
+          "head_stride": np.int64(head_stride), "big_stride": np.int64(big_stride), "comm_rate": np.float64(out["comm_rate"]),
+          "compression": np.int64(compression)}
     for i, (v, c, n) in enumerate(voxd):
         fx[f"vox_coords_{i}"], fx[f"vox_num_{i}"] = c, n
     for k in ("psm", "rm", "obj"):
@@ -2532,6 +2536,7 @@ GROUPS = {
     "loss": lambda: loss_golden(),
     "v2vnet": lambda: (run_v2vnet_case("v2vnet_small_n3", SMALL, ["vehicle", "rsu", "drone"], 1500, 8),
                        run_v2vnet_case("v2vnet_small_n2_max", SMALL, ["vehicle", "vehicle"], 1500, 9, agg="max")),
+    "v2vnet_c2": lambda: run_v2vnet_case("v2vnet_small_n2_c2", SMALL, ["vehicle", "rsu"], 1500, 11, compression=2),
     "v2vnet_full": lambda: run_v2vnet_case("v2vnet_full_n3", None, ["vehicle", "rsu", "drone"], 8192, 10, head_stride=4, big_stride=16),
     # camera lift-splat: a small rig (every tensor), and BASELINE configs[4]'s shapes (360x640 images / 8, 48 or 144 depth
     # bins, the 704x200 BEV grid; strided samples + sums)
