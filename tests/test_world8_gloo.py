@@ -100,9 +100,11 @@ def _cobevt_case(rng):
     return args, synth.synthetic_state_dict(synth.cobevt_param_spec(args), seed=3)
 
 
-def _v2xvit_case(rng, n_agents):
+def _v2xvit_case(rng, n_agents, compression=0):
     hy = synth.default_hypes_v2xvit(rng)
     args = hy["model"]["args"]
+    if compression:     # NaiveCompressor: the sharded message is its encoder output (256 / ratio channels), decoded on the receiver
+        args["modality_fusion"]["compression"] = args["compression"] = int(compression)
     sd = synth.synthetic_state_dict(synth.v2xvit_param_spec(args), seed=5)
     types, voxd = _types(n_agents), _voxels(n_agents, rng, 300)
     dd = synth.build_data_dict(voxd, types, max_cav_num=args["max_cav_num"])
@@ -163,6 +165,42 @@ def test_two_level_fusion_sharding_world8(tmp_path, model, wide, n_agents):
         got = torch.load(f"{path}.{r}")
         for k in ("psm", "rm", "obj"):
             assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), (model, r, k, float((got[k] - ref[k]).abs().max()))
+
+
+def _v2xvit_compressed_worker(rank, port, path, n_agents, ratio):
+    _init(rank, port)
+    parts = partition_agents(n_agents, WORLD)
+    counts = [len(p) for p in parts]
+    args, sd, types, voxd, dd = _v2xvit_case(RNG, n_agents, ratio)
+    dd_local = _local(voxd, types, parts[rank], max_cav_num=args["max_cav_num"])
+    for k in ("prior_encoding", "spatial_correction_matrix"):
+        dd_local[k] = dd[k]
+    frame = ShardedFrame(V2XViTOracleBackend(sd, args, two_level=False))
+    with torch.no_grad():
+        out = frame.forward(dd_local, counts=None if len(set(counts)) == 1 else counts)
+    torch.save({**{k: out[k] for k in ("psm", "rm", "obj")}, "message_bytes": frame.last_exchange["message_bytes"],
+                "collective": frame.last_exchange.get("collective")}, f"{path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_agents,ratio", [(8, 4), (5, 2)])
+def test_v2xvit_compressed_message_world8(tmp_path, n_agents, ratio):
+    """V2X-ViT with a NaiveCompressor over 8 ranks (one agent per rank; 5 agents: three idle ranks send padding): every rank's message is
+    the encoder output of ITS agents -- 256 / ratio channels per pixel, ratio x fewer bytes through the exchange than the uncompressed
+    frame -- and every rank's result equals the single-process oracle of the compressed model."""
+    from oracle import v2xvit_oracle as vit
+    path = str(tmp_path / "o")
+    mp.spawn(_v2xvit_compressed_worker, args=(_free_port(), path, n_agents, ratio), nprocs=WORLD, join=True)
+    args, sd, types, voxd, dd = _v2xvit_case(RNG, n_agents, ratio)
+    with torch.no_grad():
+        ref = vit.v2xvit_forward(dd, sd, args)
+    H, W = ref["psm"].shape[-2:]
+    for r in range(WORLD):
+        got = torch.load(f"{path}.{r}")
+        assert got["message_bytes"] == 1 * (256 // ratio) * H * W * 4, (r, got["message_bytes"])      # n_pad = 1 agent slot per rank
+        for k in ("psm", "rm", "obj"):
+            assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-4), (r, k, float((got[k] - ref[k]).abs().max()))
 
 
 # ------------------------------------------------------------------------------------------------- bench.py --gpus 8
