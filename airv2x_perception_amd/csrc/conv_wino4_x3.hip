@@ -42,6 +42,10 @@
 #ifndef AV2X_W4X3_BULK
 #define AV2X_W4X3_BULK 0
 #endif
+// the six steps (of a group's twelve) that issue a B-fragment load, as a bit mask; results do not depend on it
+#ifndef AV2X_W4X3_BMASK
+#define AV2X_W4X3_BMASK 0x1CE
+#endif
 
 // timing experiments on the ping-pong form (tools/micro/w4x3_ablate.hip -DAV2X_W4PP_ABLATE=..): 1 consecutive MFMAs go to ALTERNATING
 // accumulators (wrong sums: is the chain of six dependent MFMAs per position the M phase's length?), 2 no T-phase work (gathers,
@@ -273,9 +277,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_x3(const Wino4X3Params p) {
                 else read_a(HALF{}, g + 2 - NG, PC ^ 1);
             }
             // B fragments of position g + 2 into the register set position g - 1 has released (BULK: in the gaps the split leaves light)
-            constexpr bool bstep = BULK ? (j == 0 || j == 4 || j == 5 || j == 9 || j == 10 || j == 11) : (j == 1 || j == 2 || j == 3 || j == 6 || j == 7 || j == 8);
+            // which six of a group's twelve steps carry a B load: AV2X_W4X3_BMASK (bit j = step j; 0x1CE = steps 1,2,3,6,7,8)
+            constexpr int BM_ = BULK ? 0xE31 : AV2X_W4X3_BMASK;
+            constexpr bool bstep = (BM_ >> j) & 1;
             if constexpr (bstep && !(AB & 1)) {
-                using IB = std::integral_constant<int, BULK ? (j == 0 ? 0 : j < 6 ? j - 3 : j - 6) : (j < 4 ? j - 1 : j - 3)>;
+                using IB = std::integral_constant<int, __builtin_popcount(BM_ & ((1 << j) - 1))>;
                 if constexpr (g + 2 < NG) load_b(std::integral_constant<int, (g + 2) % 3>{}, IB{}, g + 2, c);
                 else load_b(std::integral_constant<int, (g + 2) % 3>{}, IB{}, g + 2 - NG, c1);
             }
